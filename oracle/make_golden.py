@@ -1,0 +1,369 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator.  TEST INFRASTRUCTURE ONLY -- never imported by the product.
+
+Runs ONLY in the build container, where /root/reference exists.  It executes the
+reference's own source for the index/bookkeeping half of the hot path
+(PeriodicPadding2D/3D.call, FillPadding2D.call, DLWPNeuralNet/DLWPFunctional
+.predict_timeseries, DataGenerator, delete_nan_samples) under a numpy-backed stub of
+the third-party modules the reference imports but this image lacks (keras, tensorflow,
+xarray, netCDF4, dask), and writes the inputs + outputs as small .npz fixtures under
+tests/golden/.  Only data travels: no reference source or bytecode is written anywhere
+(sys.dont_write_bytecode is set before the import).
+
+The Conv2D / pooling / optimiser arithmetic of the reference lives in unpinned
+third-party Keras/TF and cannot be executed here: those parts are "parity unpinned"
+ and are NOT covered by these fixtures.
+
+Usage:  python oracle/make_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+import itertools
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+# --------------------------------------------------------------------------------------------------------------- #
+# numpy-backed stub of the reference's missing third-party imports
+# --------------------------------------------------------------------------------------------------------------- #
+
+def _normalize_tuple(value, n):
+    if isinstance(value, int):
+        return (value,) * n
+    value = tuple(value)
+    assert len(value) == n
+    return value
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Var(np.ndarray):
+        """ndarray with the .assign() the reference calls on K.zeros(...) results."""
+        def assign(self, v):
+            self[...] = v
+            return self
+
+    def _zeros(shape, *a, **k):
+        return np.zeros(shape, dtype=np.float32).view(_Var)
+
+    K = mod('keras.backend',
+            backend=lambda: 'numpy',
+            floatx=lambda: 'float32',
+            concatenate=lambda xs, axis=-1: np.concatenate(xs, axis=axis),
+            stack=lambda xs, axis=0: np.stack(xs, axis=axis),
+            normalize_data_format=lambda v: 'channels_last' if v is None else v,
+            zeros=_zeros,
+            ones=lambda shape, *a, **k: np.ones(shape, dtype=np.float32),
+            cos=np.cos, sin=np.sin, pow=np.power, sqrt=np.sqrt, square=np.square, abs=np.abs,
+            mean=lambda x, axis=None, keepdims=False: np.mean(x, axis=tuple(axis) if isinstance(axis, list) else axis,
+                                                             keepdims=keepdims),
+            expand_dims=lambda x, axis=-1: np.expand_dims(x, axis),
+            repeat_elements=lambda x, rep, axis: np.repeat(x, rep, axis=axis),
+            variable=lambda v, name=None: np.asarray(v, dtype=np.float32),
+            cast_to_floatx=lambda v: np.asarray(v, dtype=np.float32),
+            cast=lambda v, dt: np.asarray(v, dtype=dt),
+            eval=lambda v: v,
+            int_shape=lambda x: tuple(x.shape))
+
+    class Layer(object):
+        def __init__(self, **kwargs):
+            self.input_shape_arg = kwargs.get('input_shape')
+
+    class _ZeroPaddingND(Layer):
+        """Only what the reference's subclasses rely on: padding-tuple normalisation + data_format."""
+        rank = 2
+
+        def __init__(self, padding=1, data_format=None, **kwargs):
+            super(_ZeroPaddingND, self).__init__(**kwargs)
+            self.data_format = K.normalize_data_format(data_format)
+            n = self.rank
+            if isinstance(padding, int):
+                self.padding = ((padding, padding),) * n
+            else:
+                if len(padding) != n:
+                    raise ValueError('padding should have %d elements' % n)
+                self.padding = tuple(_normalize_tuple(p, 2) for p in padding)
+
+    class ZeroPadding2D(_ZeroPaddingND):
+        rank = 2
+
+    class ZeroPadding3D(_ZeroPaddingND):
+        rank = 3
+
+    class Lambda(Layer):
+        def __init__(self, function, **kwargs):
+            super(Lambda, self).__init__(**kwargs)
+            self.function = function
+
+        def __call__(self, x):
+            return self.function(x)
+
+    class Callback(object):
+        pass
+
+    class EarlyStopping(Callback):
+        def __init__(self, **kwargs):
+            self.__dict__.update(kwargs)
+
+    class LocallyConnected2D(Layer):
+        pass
+
+    class Model(object):
+        pass
+
+    class InputSpec(object):
+        def __init__(self, **kwargs):
+            pass
+
+    keras = mod('keras', backend=K)
+    keras.callbacks = mod('keras.callbacks', Callback=Callback, EarlyStopping=EarlyStopping)
+    keras.layers = mod('keras.layers', Lambda=Lambda, Layer=Layer)
+    keras.layers.convolutional = mod('keras.layers.convolutional', ZeroPadding2D=ZeroPadding2D,
+                                     ZeroPadding3D=ZeroPadding3D)
+    keras.layers.local = mod('keras.layers.local', LocallyConnected2D=LocallyConnected2D)
+    keras.losses = mod('keras.losses',
+                       mean_absolute_error=lambda t, p: np.mean(np.abs(p - t), axis=-1),
+                       mean_squared_error=lambda t, p: np.mean(np.square(p - t), axis=-1))
+    conv_utils = types.SimpleNamespace(normalize_tuple=lambda v, n, name: _normalize_tuple(v, n))
+    keras.utils = mod('keras.utils', conv_utils=conv_utils, multi_gpu_model=lambda m, gpus=1: m, Sequence=object)
+    keras.engine = mod('keras.engine')
+    keras.engine.base_layer = mod('keras.engine.base_layer', InputSpec=InputSpec)
+    keras.models = mod('keras.models', Model=Model, Sequential=Model)
+    mod('tensorflow', pad=None)
+    mod('xarray')
+    mod('dask')
+    mod('netCDF4', default_fillvals={'f4': 9.969209968386869e+36})
+
+
+class FakeDS(object):
+    """Duck-typed stand-in for the xarray Dataset the reference DataGenerator consumes."""
+
+    class _Var(object):
+        def __init__(self, a):
+            self.values = a
+            self.shape = a.shape
+
+    def __init__(self, predictors, targets, dims):
+        self._p, self._t, self._dimnames = predictors, targets, dims
+        self.predictors = FakeDS._Var(predictors)
+        self.targets = FakeDS._Var(targets)
+        self.dims = dict(zip(dims, predictors.shape))
+
+    def isel(self, sample=slice(None)):
+        return FakeDS(self._p[sample], self._t[sample], self._dimnames)
+
+    def close(self):
+        pass
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit('make_golden.py needs %s (build container only)' % REF)
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import DLWP.custom as rc                     # noqa: E402  (reference, under stubs)
+    from DLWP.model.models import DLWPNeuralNet, DLWPFunctional
+    from DLWP.model.generators import DataGenerator
+    from DLWP.util import delete_nan_samples, train_test_split_ind
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20190424)
+
+    # ----- padding -------------------------------------------------------------------------------------------- #
+    pad = {}
+    x_cf = rng.standard_normal((2, 4, 5, 6)).astype(np.float32)         # channels_first  [N,C,H,W]
+    x_cl = np.ascontiguousarray(x_cf.transpose(0, 2, 3, 1))             # channels_last   [N,H,W,C]
+    pad['x_cf'], pad['x_cl'] = x_cf, x_cl
+    per_cases = [(0, 1), (0, 2), (1, 2), ((1, 2), (3, 1)), 0, 1, (2, 0), ((0, 3), (2, 0)), (5, 6)]
+    pad['periodic_n'] = np.int64(len(per_cases))
+    for i, p in enumerate(per_cases):
+        lay = rc.PeriodicPadding2D(p, data_format='channels_first')
+        pad['periodic_%d_padding' % i] = np.asarray(lay.padding, dtype=np.int64)
+        pad['periodic_%d_cf' % i] = lay.call(x_cf)
+        pad['periodic_%d_cl' % i] = rc.PeriodicPadding2D(p, data_format='channels_last').call(x_cl)
+    fill_cases = [(2, 0), (1, 1), ((0, 2), (1, 0)), 0, (0, 3), ((3, 1), (2, 4))]
+    pad['fill_n'] = np.int64(len(fill_cases))
+    for i, p in enumerate(fill_cases):
+        lay = rc.FillPadding2D(p, data_format='channels_first')
+        pad['fill_%d_padding' % i] = np.asarray(lay.padding, dtype=np.int64)
+        pad['fill_%d_cf' % i] = lay.call(x_cf)
+        pad['fill_%d_cl' % i] = rc.FillPadding2D(p, data_format='channels_last').call(x_cl)
+    x3 = rng.standard_normal((2, 3, 2, 5, 6)).astype(np.float32)
+    pad['x3_cf'] = x3
+    p3_cases = [(0, 0, 2), (1, 0, 1), ((0, 1), (2, 0), (1, 3))]
+    pad['periodic3_n'] = np.int64(len(p3_cases))
+    for i, p in enumerate(p3_cases):
+        lay = rc.PeriodicPadding3D(p, data_format='channels_first')
+        pad['periodic3_%d_padding' % i] = np.asarray(lay.padding, dtype=np.int64)
+        pad['periodic3_%d_cf' % i] = lay.call(x3)
+    # the composite every call site uses: Periodic((0,k)) then "ZeroPadding2D((k,0))" (zero rows written with numpy
+    # since Keras' own ZeroPadding2D.call is third-party); both orders (train.py:159-163 vs train_functional.py:227)
+    for k in (1, 2):
+        a = rc.PeriodicPadding2D((0, k), data_format='channels_first').call(x_cf)
+        a = np.pad(a, ((0, 0), (0, 0), (k, k), (0, 0)))
+        b = np.pad(x_cf, ((0, 0), (0, 0), (k, k), (0, 0)))
+        b = rc.PeriodicPadding2D((0, k), data_format='channels_first').call(b)
+        pad['composite_pz_%d' % k] = a
+        pad['composite_zp_%d' % k] = b
+    np.savez_compressed(os.path.join(OUT, 'padding.npz'), **pad)
+
+    # ----- rollout bookkeeping -------------------------------------------------------------------------------- #
+    roll = {}
+
+    def step_lin(p, **kw):
+        return (0.5 * p + 1.0).astype(np.float32)
+
+    def step_nl(p, **kw):
+        return np.tanh(np.roll(p, 1, axis=-1) * 0.75 + 0.1 * p).astype(np.float32)
+
+    n_case = 0
+    for time_dim, steps, seq, keep, rec, fn in itertools.product((1, 2, 3), (1, 3, 8), (False, True), (False, True),
+                                                                 (False, True), ('lin', 'nl')):
+        V = 2
+        if rec:
+            p0 = rng.standard_normal((3, time_dim, V, 5, 6)).astype(np.float32)
+        else:
+            p0 = rng.standard_normal((3, time_dim * V, 5, 6)).astype(np.float32)
+        m = DLWPNeuralNet(is_convolutional=True, is_recurrent=rec, time_dim=time_dim, scaler_type=None,
+                          scale_targets=False)
+        m.model = types.SimpleNamespace(predict=step_lin if fn == 'lin' else step_nl)
+        out = m.predict_timeseries(p0, steps, step_sequence=seq, keep_time_dim=keep)
+        roll['nn_%d_cfg' % n_case] = np.asarray([time_dim, steps, int(seq), int(keep), int(rec), int(fn == 'nl')],
+                                                dtype=np.int64)
+        roll['nn_%d_in' % n_case] = p0
+        roll['nn_%d_out' % n_case] = out
+        n_case += 1
+    roll['nn_n'] = np.int64(n_case)
+
+    n_case = 0
+    for time_dim, steps, n_out, keep, rec in itertools.product((1, 2), (1, 3, 8), (1, 3), (False, True), (False, True)):
+        V = 2
+        if rec:
+            p0 = rng.standard_normal((3, time_dim, V, 5, 6)).astype(np.float32)
+        else:
+            p0 = rng.standard_normal((3, time_dim * V, 5, 6)).astype(np.float32)
+        f = DLWPFunctional(is_convolutional=True, is_recurrent=rec, time_dim=time_dim)
+        f._n_steps = n_out
+
+        def predict(p, _n=n_out, **kw):
+            outs, q = [], p
+            for _ in range(_n):
+                q = step_nl(q)
+                outs.append(q)
+            return outs[0] if _n == 1 else outs
+        f.model = types.SimpleNamespace(predict=predict)
+        out = f.predict_timeseries(p0, steps, keep_time_dim=keep)
+        roll['fn_%d_cfg' % n_case] = np.asarray([time_dim, steps, n_out, int(keep), int(rec)], dtype=np.int64)
+        roll['fn_%d_in' % n_case] = p0
+        roll['fn_%d_out' % n_case] = out
+        n_case += 1
+    roll['fn_n'] = np.int64(n_case)
+    np.savez_compressed(os.path.join(OUT, 'rollout.npz'), **roll)
+
+    # ----- data generator -------------------------------------------------------------------------------------- #
+    gen = {}
+    P = rng.standard_normal((10, 2, 2, 6, 8)).astype(np.float32)        # (sample, time_step, varlev, lat, lon)
+    T = rng.standard_normal((10, 2, 2, 6, 8)).astype(np.float32)
+    gen['P'], gen['T'] = P, T
+    dims = ('sample', 'time_step', 'varlev', 'lat', 'lon')
+    for rec in (False, True):
+        tag = 'rec' if rec else 'conv'
+        m = DLWPNeuralNet(is_convolutional=True, is_recurrent=rec, time_dim=2, scaler_type=None, scale_targets=False)
+        g = DataGenerator(m, FakeDS(P, T, dims), batch_size=4, shuffle=False)
+        gen['%s_len' % tag] = np.int64(len(g))
+        gen['%s_shape' % tag] = np.asarray(g.shape, dtype=np.int64)
+        gen['%s_n_features' % tag] = np.int64(g.n_features)
+        gen['%s_dense_shape' % tag] = np.asarray(g.dense_shape, dtype=np.int64)
+        gen['%s_convolution_shape' % tag] = np.asarray(g.convolution_shape, dtype=np.int64)
+        gen['%s_shape_2d' % tag] = np.asarray(g.shape_2d, dtype=np.int64)
+        for b in range(len(g)):
+            X, y = g[b]
+            gen['%s_X%d' % (tag, b)], gen['%s_y%d' % (tag, b)] = X, y
+        X, y = g[-1]
+        gen['%s_Xneg1' % tag] = X
+        Xa, ya = g.generate([], scale_and_impute=False)
+        gen['%s_Xall' % tag], gen['%s_yall' % tag] = Xa, ya
+    # dense (non-convolutional) variants
+    m = DLWPNeuralNet(is_convolutional=False, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
+    g = DataGenerator(m, FakeDS(P, T, dims), batch_size=4)
+    gen['dense_X0'] = g[0][0]
+    m = DLWPNeuralNet(is_convolutional=False, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
+    g = DataGenerator(m, FakeDS(P, T, dims), batch_size=4)
+    gen['dense_rec_X0'] = g[0][0]
+    # shuffle order under the legacy global RandomState (generators.py:103-106)
+    for seed in (0, 7):
+        np.random.seed(seed)
+        m = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
+        g = DataGenerator(m, FakeDS(P, T, dims), batch_size=4, shuffle=True)
+        gen['shuffle_%d_epoch0' % seed] = np.asarray(g._indices, dtype=np.int64)
+        gen['shuffle_%d_X0' % seed] = g[0][0]
+        g.on_epoch_end()
+        gen['shuffle_%d_epoch1' % seed] = np.asarray(g._indices, dtype=np.int64)
+    # no time_step dimension in the dataset
+    P4 = rng.standard_normal((7, 3, 6, 8)).astype(np.float32)
+    m = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=1, scaler_type=None, scale_targets=False)
+    g = DataGenerator(m, FakeDS(P4, P4 * 2, ('sample', 'varlev', 'lat', 'lon')), batch_size=3)
+    gen['P4'] = P4
+    gen['nots_shape'] = np.asarray(g.shape, dtype=np.int64)
+    gen['nots_convolution_shape'] = np.asarray(g.convolution_shape, dtype=np.int64)
+    gen['nots_len'] = np.int64(len(g))
+    gen['nots_X2'], gen['nots_y2'] = g[2]
+    # delete_nan_samples
+    Pn, Tn = P.copy(), T.copy()
+    Pn[3, 0, 1, 2, 2] = np.nan
+    Tn[8, 1, 0, 0, 0] = np.nan
+    Tn[3, 1, 1, 5, 7] = np.nan
+    pn, tn = delete_nan_samples(Pn.copy(), Tn.copy())
+    gen['nan_P'], gen['nan_T'], gen['nan_p_out'], gen['nan_t_out'] = Pn, Tn, pn, tn
+    Pl = P.copy()
+    Pl[1, 0, 0, 0, 0] = 1.e21
+    Pl[5, 1, 1, 1, 1] = -3.e20
+    pl, tl = delete_nan_samples(Pl.copy(), T.copy(), large_fill_value=True)
+    gen['large_P'], gen['large_p_out'], gen['large_t_out'] = Pl, pl, tl
+    Pt = P.copy()
+    Pt[2, 0] = np.nan                      # half of sample 2's features
+    Pt[6, 0, 0, 0, 0] = np.nan             # a single value
+    pt, tt = delete_nan_samples(Pt.copy(), T.copy(), threshold=0.25)
+    gen['thr_P'], gen['thr_p_out'], gen['thr_t_out'] = Pt, pt, tt
+    # train_test_split_ind deterministic modes
+    for method in ('first', 'last'):
+        tr, te = train_test_split_ind(10, 3, method=method)
+        gen['split_%s_train' % method] = np.asarray(tr, dtype=np.int64)
+        gen['split_%s_test' % method] = np.asarray(te, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, 'generator.npz'), **gen)
+
+    # ----- custom losses (numpy-K evaluation of the reference formulas) ----------------------------------------- #
+    los = {}
+    yt = rng.standard_normal((4, 4, 6, 8)).astype(np.float32)
+    yp = (yt + 0.3 * rng.standard_normal((4, 4, 6, 8))).astype(np.float32)
+    climo = rng.standard_normal((1, 4, 6, 8)).astype(np.float32) * 0.1
+    los['y_true'], los['y_pred'], los['climo'] = yt, yp, climo
+    for reg in (None, 'mse', 'mae', 'global'):
+        for use_mean in (False, True):
+            fn = rc.anomaly_correlation_loss(climo if use_mean else None, regularize_mean=reg, reverse=True)
+            v = fn(yt, yp)
+            los['acc_%s_%d' % (reg, int(use_mean))] = np.asarray(np.mean(v), dtype=np.float64)
+    lats = np.linspace(87.5, -87.5, 6).astype(np.float32)
+    los['lats'] = lats
+    for weighting in ('cosine', 'midlatitude'):
+        fn = rc.latitude_weighted_loss(sys.modules['keras.losses'].mean_squared_error, lats, (4, 6, 8), axis=-2,
+                                       weighting=weighting)
+        los['latw_%s' % weighting] = np.asarray(np.mean(fn(yt, yp)), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'losses.npz'), **los)
+
+    for f in sorted(os.listdir(OUT)):
+        print('%-16s %8d bytes' % (f, os.path.getsize(os.path.join(OUT, f))))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,508 @@
+"""
+numpy restatement of the reference hot path (float64 arithmetic unless stated).  TEST INFRASTRUCTURE ONLY -- see
+oracle/__init__.py for who may import this and for the pinning status of each part.
+
+All `file:line` citations are relative to /root/reference.
+"""
+import math
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# padding  (PINNED by tests/golden/padding.npz)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def normalize_padding(padding, rank=2):
+    """Keras ZeroPadding{2,3}D argument forms -> ((lo, hi),)*rank.  int | tuple of ints | tuple of pairs.
+    (The reference inherits this from keras.layers.ZeroPadding2D, DLWP/custom.py:139,187-189.)"""
+    if isinstance(padding, (int, np.integer)):
+        return tuple((int(padding), int(padding)) for _ in range(rank))
+    padding = tuple(padding)
+    if len(padding) != rank:
+        raise ValueError('`padding` should have %d elements, got %r' % (rank, padding))
+    out = []
+    for p in padding:
+        if isinstance(p, (int, np.integer)):
+            out.append((int(p), int(p)))
+        else:
+            p = tuple(int(v) for v in p)
+            if len(p) != 2:
+                raise ValueError('each padding entry must be an int or a pair, got %r' % (p,))
+            out.append(p)
+    return tuple(out)
+
+
+def _spatial_axes(ndim, data_format):
+    # channels_first: (N, C, d1..dk); channels_last: (N, d1..dk, C)
+    return tuple(range(2, ndim)) if data_format == 'channels_first' else tuple(range(1, ndim - 1))
+
+
+def _wrap_axis(a, axis, lo, hi):
+    """One axis of the reference's periodic pad: cat(a[n-lo:n], a, a[0:hi]) -- DLWP/custom.py:197-204.
+    Like the reference's slices this does NOT tile; lo/hi > n is invalid there (negative slice start) and here."""
+    n = a.shape[axis]
+    if lo > n or hi > n:
+        raise ValueError('periodic padding (%d, %d) exceeds the axis length %d' % (lo, hi, n))
+    head = np.take(a, range(n - lo, n), axis=axis)
+    tail = np.take(a, range(0, hi), axis=axis)
+    return np.concatenate([head, a, tail], axis=axis)
+
+
+def periodic_padding2d(x, padding, data_format='channels_first'):
+    """PeriodicPadding2D.call, DLWP/custom.py:191-214: pad the horizontal (W) first, then the vertical (H) using the
+    already W-padded tensor, so corners are wrap-of-wrap."""
+    (t, b), (l, r) = normalize_padding(padding, 2)
+    ah, aw = _spatial_axes(x.ndim, data_format)
+    y = _wrap_axis(x, aw, l, r)
+    return _wrap_axis(y, ah, t, b)
+
+
+def periodic_padding3d(x, padding, data_format='channels_first'):
+    """PeriodicPadding3D.call, DLWP/custom.py:275-306: last spatial axis first, then the middle, then the first."""
+    pads = normalize_padding(padding, 3)
+    axes = _spatial_axes(x.ndim, data_format)
+    y = x
+    for ax, (lo, hi) in reversed(list(zip(axes, pads))):
+        y = _wrap_axis(y, ax, lo, hi)
+    return y
+
+
+def _edge_axis(a, axis, lo, hi):
+    first = np.take(a, [0], axis=axis)
+    last = np.take(a, [a.shape[axis] - 1], axis=axis)
+    return np.concatenate([first] * lo + [a] + [last] * hi, axis=axis)
+
+
+def fill_padding2d(x, padding, data_format='channels_first'):
+    """FillPadding2D.call, DLWP/custom.py:359-402: replicate edge rows first, then edge columns of the row-padded
+    tensor."""
+    (t, b), (l, r) = normalize_padding(padding, 2)
+    ah, aw = _spatial_axes(x.ndim, data_format)
+    y = _edge_axis(x, ah, t, b)
+    return _edge_axis(y, aw, l, r)
+
+
+def zero_padding2d(x, padding, data_format='channels_first'):
+    """Keras ZeroPadding2D (third-party; call sites examples/train.py:163,173,183,193,203,212).  UNPINNED."""
+    (t, b), (l, r) = normalize_padding(padding, 2)
+    ah, aw = _spatial_axes(x.ndim, data_format)
+    widths = [(0, 0)] * x.ndim
+    widths[ah], widths[aw] = (t, b), (l, r)
+    return np.pad(x, widths)
+
+
+PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
+
+
+def pad2d_modes(x, pads, mode_h, mode_w):
+    """Per-axis-mode pad of an NCHW tensor -- the form the fused HIP halo uses (include/dlwp_hip.h dlwp_pad2d).
+    pads = (top, bottom, left, right).  Equivalent to composing the layer functions above one axis at a time."""
+    t, b, l, r = pads
+    fn = {PAD_ZERO: lambda a, ax, lo, hi: np.pad(a, [(lo, hi) if i == ax else (0, 0) for i in range(a.ndim)]),
+          PAD_WRAP: _wrap_axis, PAD_EDGE: _edge_axis}
+    y = fn[mode_w](x, x.ndim - 1, l, r)
+    return fn[mode_h](y, x.ndim - 2, t, b)
+
+
+def pad2d_modes_grad(dy, x_shape, pads, mode_h, mode_w):
+    """Adjoint of pad2d_modes: fold the halo of dy back onto the interior (wrap: add to the periodic image;
+    edge: add to the border row/column; zero: drop)."""
+    t, b, l, r = pads
+    H, W = x_shape[-2:]
+
+    def fold(a, axis, lo, hi, n, mode):
+        a = np.moveaxis(a, axis, -1)
+        core = a[..., lo:lo + n].copy()
+        if mode == PAD_WRAP:
+            if lo:
+                core[..., n - lo:] += a[..., :lo]
+            if hi:
+                core[..., :hi] += a[..., lo + n:]
+        elif mode == PAD_EDGE:
+            if lo:
+                core[..., 0] += a[..., :lo].sum(-1)
+            if hi:
+                core[..., n - 1] += a[..., lo + n:].sum(-1)
+        return np.moveaxis(core, -1, axis)
+    g = fold(np.asarray(dy, dtype=np.float64), dy.ndim - 2, t, b, H, mode_h)
+    return fold(g, dy.ndim - 1, l, r, W, mode_w)
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# convolution / pooling / activations  (UNPINNED: Keras semantics)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def conv2d(x, w_hwio, bias=None, dilation=1, activation='linear'):
+    """Keras Conv2D(padding='valid', strides=1, data_format='channels_first'): cross-correlation (no kernel flip),
+    y[n,co,i,j] = b[co] + sum_{ci,u,v} x[n,ci,i+u*d,j+v*d] * w[u,v,ci,co]; call sites examples/train.py:164-219.
+    float64 direct sum."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(w_hwio, dtype=np.float64)
+    kh, kw, cin, cout = w.shape
+    n, c, h, wd = x.shape
+    assert c == cin, (c, cin)
+    d = int(dilation)
+    ho, wo = h - d * (kh - 1), wd - d * (kw - 1)
+    y = np.zeros((n, cout, ho, wo), dtype=np.float64)
+    for u in range(kh):
+        for v in range(kw):
+            patch = x[:, :, u * d:u * d + ho, v * d:v * d + wo]            # [n, ci, ho, wo]
+            y += np.einsum('nchw,co->nohw', patch, w[u, v], optimize=True)
+    if bias is not None:
+        y += np.asarray(bias, dtype=np.float64)[None, :, None, None]
+    return activate(y, activation)
+
+
+def conv2d_grads(x, w_hwio, dz, dilation=1):
+    """Gradients of the valid cross-correlation above w.r.t. x, w and the bias, given dz = dL/d(pre-activation)."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(w_hwio, dtype=np.float64)
+    dz = np.asarray(dz, dtype=np.float64)
+    kh, kw, cin, cout = w.shape
+    d = int(dilation)
+    ho, wo = dz.shape[-2:]
+    dx = np.zeros_like(x)
+    dw = np.zeros_like(w)
+    for u in range(kh):
+        for v in range(kw):
+            sl = (slice(None), slice(None), slice(u * d, u * d + ho), slice(v * d, v * d + wo))
+            dx[sl] += np.einsum('nohw,co->nchw', dz, w[u, v], optimize=True)
+            dw[u, v] = np.einsum('nchw,nohw->co', x[sl], dz, optimize=True)
+    return dx, dw, dz.sum(axis=(0, 2, 3))
+
+
+def activate(z, activation):
+    if activation in (None, 'linear'):
+        return z
+    if activation == 'tanh':
+        return np.tanh(z)
+    if activation == 'relu':
+        return np.maximum(z, 0.)
+    raise ValueError('activation %r not restated' % (activation,))
+
+
+def activation_grad(y, dy, activation):
+    """dL/dz from dL/dy and the layer OUTPUT y."""
+    if activation in (None, 'linear'):
+        return dy
+    if activation == 'tanh':
+        return dy * (1. - y * y)
+    if activation == 'relu':
+        return dy * (y > 0)
+    raise ValueError(activation)
+
+
+def maxpool2(x):
+    """Keras MaxPooling2D(2): 2x2 window, stride 2, 'valid' (floor) -- examples/train.py:171,181."""
+    n, c, h, w = x.shape
+    h2, w2 = h // 2, w // 2
+    v = x[:, :, :h2 * 2, :w2 * 2].reshape(n, c, h2, 2, w2, 2)
+    return v.max(axis=(3, 5))
+
+
+def maxpool2_grad(x, dy):
+    """Route dy to the FIRST maximal element of each window in row-major window order (TF MaxPoolGrad convention)."""
+    n, c, h, w = x.shape
+    h2, w2 = h // 2, w // 2
+    v = x[:, :, :h2 * 2, :w2 * 2].reshape(n, c, h2, 2, w2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, h2, w2, 4)
+    arg = v.argmax(axis=-1)
+    g = np.zeros(v.shape, dtype=np.float64)
+    np.put_along_axis(g, arg[..., None], np.asarray(dy, dtype=np.float64)[..., None], axis=-1)
+    dx = np.zeros(x.shape, dtype=np.float64)
+    dx[:, :, :h2 * 2, :w2 * 2] = g.reshape(n, c, h2, w2, 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, h2 * 2, w2 * 2)
+    return dx
+
+
+def upsample2(x):
+    """Keras UpSampling2D(2), nearest: y[i,j] = x[i//2, j//2] -- examples/train.py:191,201."""
+    return x.repeat(2, axis=-2).repeat(2, axis=-1)
+
+
+def upsample2_grad(dy):
+    n, c, h, w = dy.shape
+    return np.asarray(dy, dtype=np.float64).reshape(n, c, h // 2, 2, w // 2, 2).sum(axis=(3, 5))
+
+
+def mse(y_true, y_pred):
+    """Keras 'mse' reduced to the scalar the train loop reports (mean over every element)."""
+    return float(np.mean(np.square(np.asarray(y_pred, np.float64) - np.asarray(y_true, np.float64))))
+
+
+def mae(y_true, y_pred):
+    return float(np.mean(np.abs(np.asarray(y_pred, np.float64) - np.asarray(y_true, np.float64))))
+
+
+def glorot_uniform(shape_hwio, rng):
+    """Keras glorot_uniform for a conv kernel: limit = sqrt(6 / (fan_in + fan_out)), fan_in = kh*kw*cin,
+    fan_out = kh*kw*cout."""
+    kh, kw, cin, cout = shape_hwio
+    limit = math.sqrt(6. / (kh * kw * cin + kh * kw * cout))
+    return rng.uniform(-limit, limit, size=shape_hwio).astype(np.float32)
+
+
+def adam_keras_step(p, m, v, g, iteration, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, decay=0.):
+    """One Keras-2.2-form Adam update, as the reference's own tracker restates it (DLWP/custom.py:34-40):
+    t = it+1; lr' = lr/(1+decay*it); lr_t = lr'*sqrt(1-b2^t)/(1-b1^t); m,v EMA; p -= lr_t*m/(sqrt(v)+eps)."""
+    t = iteration + 1
+    lr_ = lr / (1. + decay * iteration)
+    lr_t = lr_ * math.sqrt(1. - beta_2 ** t) / (1. - beta_1 ** t)
+    m = beta_1 * m + (1. - beta_1) * g
+    v = beta_2 * v + (1. - beta_2) * g * g
+    p = p - lr_t * m / (np.sqrt(v) + epsilon)
+    return p, m, v
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# a tiny interpreter for the reference's (layer_name, args, kwargs) stacks  (examples/train.py:142-221)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def _conv_args(args, kwargs):
+    filters = args[0] if len(args) > 0 else kwargs['filters']
+    ks = args[1] if len(args) > 1 else kwargs['kernel_size']
+    ks = (ks, ks) if isinstance(ks, int) else tuple(ks)
+    dil = kwargs.get('dilation_rate', 1)
+    dil = dil if isinstance(dil, int) else dil[0]
+    return int(filters), ks, int(dil), kwargs.get('activation', None)
+
+
+def init_weights(layers, in_channels, rng):
+    """glorot_uniform kernels / zero biases for every Conv2D in a layer stack; returns [(w_hwio, b), ...]."""
+    out, c = [], in_channels
+    for name, args, kwargs in layers:
+        if name == 'Conv2D':
+            filters, ks, _, _ = _conv_args(args or (), kwargs or {})
+            out.append((glorot_uniform(ks + (c, filters), rng), np.zeros(filters, dtype=np.float32)))
+            c = filters
+    return out
+
+
+def run_layers(layers, x, weights, record=None):
+    """Execute a sequential stack exactly as the reference graph is laid out (one op per layer, unfused)."""
+    x = np.asarray(x, dtype=np.float64)
+    wi = 0
+    for name, args, kwargs in layers:
+        args, kwargs = args or (), kwargs or {}
+        fmt = kwargs.get('data_format', 'channels_first')
+        if name == 'PeriodicPadding2D':
+            x = periodic_padding2d(x, args[0] if args else kwargs.get('padding', (1, 1)), fmt)
+        elif name == 'FillPadding2D':
+            x = fill_padding2d(x, args[0] if args else kwargs.get('padding', (1, 1)), fmt)
+        elif name == 'ZeroPadding2D':
+            x = zero_padding2d(x, args[0] if args else kwargs.get('padding', (1, 1)), fmt)
+        elif name == 'Conv2D':
+            _, _, dil, act = _conv_args(args, kwargs)
+            w, b = weights[wi]
+            wi += 1
+            x = conv2d(x, w, b, dil, act or 'linear')
+        elif name == 'MaxPooling2D':
+            x = maxpool2(x)
+        elif name == 'UpSampling2D':
+            x = upsample2(x)
+        elif name == 'Reshape':
+            x = x.reshape((x.shape[0],) + tuple(args[0]))
+        else:
+            raise ValueError('layer %r not restated' % name)
+        if record is not None:
+            record.append((name, x))
+    return x
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# rollout bookkeeping  (PINNED by tests/golden/rollout.npz)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def _merge_time(series, n_slots, n_sample, time_dim, feature_shape, keep_time_dim):
+    # DLWP/model/models.py:294-300 / 448-451: (T,N,time_dim,V,...) -> (T*time_dim, N, V, ...)
+    series = series.reshape((n_slots, n_sample, time_dim, -1) + tuple(feature_shape[1:]))
+    if keep_time_dim:
+        return series
+    order = (0, 2, 1) + tuple(range(3, series.ndim))
+    return series.transpose(order).reshape((n_slots * time_dim, n_sample, -1) + tuple(feature_shape[1:]))
+
+
+def predict_timeseries_nn(predict, predictors, time_steps, time_dim, is_recurrent=False, step_sequence=False,
+                          keep_time_dim=False):
+    """DLWPNeuralNet.predict_timeseries, DLWP/model/models.py:247-301.  `predict` maps a state array to the next one.
+    Output is float32 whatever `predict` returns (:270) and is NOT truncated to time_steps."""
+    time_steps = int(time_steps)
+    if time_steps < 1:
+        raise ValueError('time_steps must be an int > 0')
+    n_fwd = time_steps if step_sequence else int(math.ceil(float(time_steps) / time_dim))
+    state = np.array(predictors, copy=True)
+    n_sample = state.shape[0]
+    feature_shape = state.shape[2:] if is_recurrent else state.shape[1:]
+    series = np.full((n_fwd,) + predictors.shape, np.nan, dtype=np.float32)
+    for t in range(n_fwd):
+        if not step_sequence:
+            state = predict(state)                                          # :292
+            series[t] = state
+            continue
+        out = predict(state)                                                # :281-290
+        if is_recurrent:
+            state = np.concatenate([state[:, 1:], out[:, :1]], axis=1)
+        else:
+            split = (n_sample, time_dim, -1) + tuple(feature_shape[1:])
+            o5, s5 = out.reshape(split), state.reshape(split)
+            state = np.concatenate([s5[:, 1:], o5[:, :1]], axis=1).reshape(predictors.shape)
+        series[t] = out
+    merged = _merge_time(series, n_fwd, n_sample, time_dim, feature_shape, keep_time_dim or step_sequence)
+    if step_sequence and not keep_time_dim:
+        merged = merged[:, :, 0]                                            # :296-297
+    return merged
+
+
+def predict_timeseries_functional(predict, predictors, time_steps, time_dim, n_outputs=1, is_recurrent=False,
+                                  keep_time_dim=False):
+    """DLWPFunctional.predict_timeseries, DLWP/model/models.py:414-452.  `predict` returns one array
+    (n_outputs == 1) or a list of n_outputs arrays; the last one seeds the next call (:443-446)."""
+    time_steps = int(time_steps)
+    if time_steps < 1:
+        raise ValueError('time_steps must be an int > 0')
+    n_calls = int(math.ceil(time_steps / n_outputs / time_dim))
+    n_slots = n_calls * n_outputs
+    state = np.array(predictors, copy=True)
+    n_sample = state.shape[0]
+    feature_shape = state.shape[2:] if is_recurrent else state.shape[1:]
+    series = np.full((n_slots,) + predictors.shape, np.nan, dtype=np.float32)
+    for t in range(n_calls):
+        result = predict(state)
+        if n_outputs == 1:
+            # :447 np.stack(result, axis=0) of a single ARRAY stacks its samples: with n_outputs == 1 slot t receives
+            # the (N, ...) array itself.
+            state = np.array(result, copy=True)
+            series[t] = result
+        else:
+            state = np.array(result[-1], copy=True)
+            series[t * n_outputs:(t + 1) * n_outputs] = np.stack(result, axis=0)
+    return _merge_time(series, n_slots, n_sample, time_dim, feature_shape, keep_time_dim)
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# data feed  (PINNED by tests/golden/generator.npz)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def delete_nan_samples(predictors, targets, large_fill_value=False, threshold=None):
+    """DLWP/util.py:238-268: drop every sample (row) with a NaN in either array (or with a NaN fraction >= threshold)."""
+    if threshold is not None and not (0 <= threshold <= 1):
+        raise ValueError("'threshold' must be between 0 and 1")
+    if large_fill_value:
+        predictors[np.abs(predictors) >= 1.e20] = np.nan
+        targets[np.abs(targets) >= 1.e20] = np.nan
+    p2 = predictors.reshape((predictors.shape[0], -1))
+    t2 = targets.reshape((targets.shape[0], -1))
+    if threshold is None:
+        bad = np.isnan(p2).any(axis=1) | np.isnan(t2).any(axis=1)
+    else:
+        bad = (np.isnan(p2).mean(axis=1) >= threshold) | (np.isnan(t2).mean(axis=1) >= threshold)
+    keep = ~bad
+    return predictors[keep], targets[keep]
+
+
+class DataGeneratorRef(object):
+    """DataGenerator, DLWP/model/generators.py:19-159, over plain arrays laid out like the predictor file
+    (sample, [time_step,] varlev..., lat, lon)."""
+
+    def __init__(self, predictors, targets, has_time_step=True, is_convolutional=True, is_recurrent=False,
+                 batch_size=32, shuffle=False, remove_nan=True):
+        self.P, self.T = predictors, targets
+        self.has_time_step = has_time_step
+        self.is_convolutional, self.is_recurrent = is_convolutional, is_recurrent
+        self.batch_size, self.shuffle, self.remove_nan = batch_size, shuffle, remove_nan
+        self.n_sample = predictors.shape[0]
+        self.on_epoch_end()
+
+    @property
+    def shape(self):                                                    # :51-59
+        return self.P.shape[1:] if self.has_time_step else (1,) + self.P.shape[1:]
+
+    @property
+    def n_features(self):                                               # :61-66
+        return int(np.prod(self.shape))
+
+    @property
+    def dense_shape(self):                                              # :68-77
+        if self.is_recurrent:
+            return (self.shape[0], self.n_features // self.shape[0])
+        return (self.n_features,)
+
+    def _conv_shape(self, keep_time):                                   # :79-101
+        if keep_time:
+            return (self.shape[0], int(np.prod(self.shape[1:-2]))) + tuple(self.shape[-2:])
+        return (int(np.prod(self.shape[:-2])),) + tuple(self.P.shape[-2:])
+
+    @property
+    def convolution_shape(self):
+        return self._conv_shape(self.is_recurrent)
+
+    @property
+    def shape_2d(self):
+        return self._conv_shape(False)
+
+    def on_epoch_end(self):                                             # :103-106 (legacy global RandomState)
+        self.indices = np.arange(self.n_sample)
+        if self.shuffle:
+            np.random.shuffle(self.indices)
+
+    def __len__(self):                                                  # :141
+        return int(np.ceil(self.n_sample / self.batch_size))
+
+    def generate(self, samples):                                        # :108-135
+        sel = samples if len(samples) > 0 else slice(None)
+        p, t = self.P[sel], self.T[sel]
+        n = p.shape[0]
+        p, t = p.reshape((n, -1)), t.reshape((n, -1))
+        if self.remove_nan:
+            p, t = delete_nan_samples(p, t)
+        # NOTE: the reference keeps the PRE-deletion n (:113 vs :129), which raises whenever a sample was dropped
+        # (SURVEY.md App. C); the goldens contain no dropped samples on this path.
+        if self.is_convolutional:
+            p = p.reshape((n,) + self.convolution_shape)
+            t = t.reshape((n,) + self.convolution_shape)
+        elif self.is_recurrent:
+            p = p.reshape((n,) + self.dense_shape)
+            t = t.reshape((n,) + self.dense_shape)
+        return p, t
+
+    def __getitem__(self, index):                                       # :143-159
+        if int(index) < 0:
+            index = len(self) + index
+        if index > len(self):
+            raise IndexError
+        return self.generate(self.indices[index * self.batch_size:(index + 1) * self.batch_size])
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# custom losses  (PINNED by tests/golden/losses.npz; "next" row of SURVEY.md section 8f)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def anomaly_correlation_loss(y_true, y_pred, mean=None, regularize_mean='mse'):
+    """acc_loss with reverse=True, DLWP/custom.py:1036-1088, reduced to its batch-mean scalar."""
+    yt = np.asarray(y_true, np.float64)
+    yp = np.asarray(y_pred, np.float64)
+    if mean is not None:
+        yt_a, yp_a = yt - mean, yp - mean
+    else:
+        yt_a, yp_a = yt, yp
+    a = np.mean(yp_a * yt_a) / np.sqrt(np.mean(yp_a ** 2) * np.mean(yt_a ** 2))
+    if regularize_mean is None:
+        return float(-a)
+    if regularize_mean == 'mse':
+        m = np.mean((yp - yt) ** 2)
+    elif regularize_mean == 'mae':
+        m = np.mean(np.abs(yp - yt))
+    elif regularize_mean == 'global':
+        m = np.abs((yt.mean() - yp.mean()) / yt.mean())
+    else:
+        raise ValueError(regularize_mean)
+    return float(m - a)
+
+
+def latitude_weights(lats, weighting='cosine'):
+    """Weights of latitude_weighted_loss, DLWP/custom.py:975-978 (the FUNCTION form, whose 'midlatitude' formula
+    differs from the class form at :926)."""
+    lat = np.asarray(lats, np.float64) * np.pi / 180.
+    w = np.cos(lat)
+    if weighting == 'midlatitude':
+        w = w + 0.5 * np.sin(2 * lat) ** 2
+    return w

@@ -1,0 +1,109 @@
+"""Cross-checks inside the oracle for the UNPINNED arithmetic (Conv2D / pooling / Adam): float64 numpy direct sum
+vs torch-CPU float32 ops vs torch autograd, plus the circular-convolution identity for the periodic axis."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref, torch_ref
+
+UNET = (
+    ('PeriodicPadding2D', ((0, 2),), {'data_format': 'channels_first'}),
+    ('ZeroPadding2D', ((2, 0),), {'data_format': 'channels_first'}),
+    ('Conv2D', (8, 3), {'dilation_rate': 2, 'padding': 'valid', 'activation': 'tanh', 'data_format': 'channels_first'}),
+    ('MaxPooling2D', (2,), {'data_format': 'channels_first'}),
+    ('PeriodicPadding2D', ((0, 1),), {'data_format': 'channels_first'}),
+    ('ZeroPadding2D', ((1, 0),), {'data_format': 'channels_first'}),
+    ('Conv2D', (16, 3), {'dilation_rate': 1, 'padding': 'valid', 'activation': 'tanh', 'data_format': 'channels_first'}),
+    ('UpSampling2D', (2,), {'data_format': 'channels_first'}),
+    ('PeriodicPadding2D', ((0, 2),), {'data_format': 'channels_first'}),
+    ('ZeroPadding2D', ((2, 0),), {'data_format': 'channels_first'}),
+    ('Conv2D', (4, 5), {'padding': 'valid', 'activation': 'linear', 'data_format': 'channels_first'}),
+)
+
+
+@pytest.mark.parametrize('k,d', [(3, 1), (3, 2), (5, 1)])
+def test_conv2d_numpy_vs_torch(k, d):
+    rng = np.random.default_rng(k * 10 + d)
+    x = rng.standard_normal((2, 5, 12, 14)).astype(np.float32)
+    w = np_ref.glorot_uniform((k, k, 5, 7), rng)
+    b = rng.standard_normal(7).astype(np.float32)
+    y = np_ref.conv2d(x, w, b, d, 'tanh')
+    (wt, bt), = torch_ref.to_torch_weights([(w, b)], dtype=torch.float64)
+    yt = torch.tanh(torch.nn.functional.conv2d(torch.tensor(x, dtype=torch.float64), wt, bt, dilation=d)).numpy()
+    assert y.shape == yt.shape
+    assert np.abs(y - yt).max() < 1e-13
+
+
+def test_conv2d_grads_vs_autograd():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 3, 9, 10))
+    w = rng.standard_normal((3, 3, 3, 4))
+    dz = rng.standard_normal((2, 4, 5, 6))
+    dx, dw, db = np_ref.conv2d_grads(x, w, dz, dilation=2)
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(np.transpose(w, (3, 2, 0, 1)).copy(), requires_grad=True)
+    bt = torch.zeros(4, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(xt, wt, bt, dilation=2)
+    y.backward(torch.tensor(dz))
+    assert np.abs(dx - xt.grad.numpy()).max() < 1e-12
+    assert np.abs(dw - wt.grad.numpy().transpose(2, 3, 1, 0)).max() < 1e-12
+    assert np.abs(db - bt.grad.numpy()).max() < 1e-12
+
+
+def test_pool_upsample_and_grads():
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 3, 7, 10))
+    xt = torch.tensor(x, requires_grad=True)
+    yt = torch.nn.functional.max_pool2d(xt, 2)
+    assert np.array_equal(np_ref.maxpool2(x), yt.detach().numpy())
+    dy = rng.standard_normal(yt.shape)
+    yt.backward(torch.tensor(dy))
+    assert np.allclose(np_ref.maxpool2_grad(x, dy), xt.grad.numpy())
+    u = np_ref.upsample2(x)
+    ut = torch.nn.functional.interpolate(torch.tensor(x), scale_factor=2, mode='nearest').numpy()
+    assert np.array_equal(u, ut)
+    du = rng.standard_normal(u.shape)
+    assert np.isclose((np_ref.upsample2_grad(du) * x).sum(), (du * u).sum())
+
+
+def test_periodic_conv_is_circular_convolution():
+    """periodic-pad o valid-conv along longitude == circular cross-correlation (FFT identity)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 1, 1, 24))
+    w = rng.standard_normal((1, 5, 1, 1))
+    y = np_ref.conv2d(np_ref.periodic_padding2d(x, (0, 2)), w)[0, 0, 0]
+    k = np.zeros(24)
+    for v in range(5):
+        k[(v - 2) % 24] = w[0, v, 0, 0]
+    want = np.real(np.fft.ifft(np.fft.fft(x[0, 0, 0]) * np.conj(np.fft.fft(k))))
+    assert np.abs(y - want).max() < 1e-12
+
+
+def test_layer_stack_numpy_vs_torch_and_shift_equivariance():
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2, 4, 8, 12)).astype(np.float32)
+    weights = np_ref.init_weights(UNET, 4, rng)
+    weights = [(w, rng.standard_normal(b.shape).astype(np.float32) * 0.1) for w, b in weights]
+    y64 = np_ref.run_layers(UNET, x, weights)
+    y32 = torch_ref.run_layers(UNET, torch.from_numpy(x), torch_ref.to_torch_weights(weights)).numpy()
+    assert y64.shape == (2, 4, 8, 12)
+    assert np.abs(y64 - y32).max() < 2e-5
+    # the whole periodic stack commutes with a longitude shift by a multiple of the pooling factor
+    ys = np_ref.run_layers(UNET, np.roll(x, 4, axis=-1), weights)
+    assert np.abs(ys - np.roll(y64, 4, axis=-1)).max() < 1e-12
+
+
+def test_adam_keras_form():
+    rng = np.random.default_rng(7)
+    p = rng.standard_normal(50)
+    m = np.zeros(50)
+    v = np.zeros(50)
+    pt, mt, vt = (torch.tensor(a, dtype=torch.float32) for a in (p, m, v))
+    for it in range(5):
+        g = rng.standard_normal(50)
+        p, m, v = np_ref.adam_keras_step(p, m, v, g, it)
+        torch_ref.adam_keras_step(pt, mt, vt, torch.tensor(g, dtype=torch.float32), it)
+    assert np.abs(p - pt.numpy()).max() < 1e-6
+    # first step of Adam moves every weight by ~lr regardless of gradient scale
+    p1, _, _ = np_ref.adam_keras_step(np.zeros(3), np.zeros(3), np.zeros(3), np.array([1e-3, 1., 1e3]), 0)
+    assert np.allclose(p1, -1e-3, rtol=5e-3)      # eps=1e-7 shows at |g|=1e-3
