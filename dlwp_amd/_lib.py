@@ -1,0 +1,118 @@
+"""
+ctypes binding of libdlwp_hip.so (include/dlwp_hip.h).  There is NO fallback: if the HIP library is missing or fails to
+load, importing this module raises -- the product never computes on the CPU.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdlwp_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dlwp_hip.h')
+
+OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
+F32, BF16 = 0, 1
+PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
+ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
+SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
+OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH = 0, 1, 2, 3, 4
+BUF_STATE_IN = -1
+
+
+def BUF_OUT(o):
+    return -2 - o
+
+
+class Shape4(ctypes.Structure):
+    _fields_ = [('n', ctypes.c_int), ('c', ctypes.c_int), ('h', ctypes.c_int), ('w', ctypes.c_int)]
+
+
+class Pad2d(ctypes.Structure):
+    _fields_ = [('top', ctypes.c_int), ('bottom', ctypes.c_int), ('left', ctypes.c_int), ('right', ctypes.c_int),
+                ('mode_h', ctypes.c_int), ('mode_w', ctypes.c_int)]
+
+
+class Conv2d(ctypes.Structure):
+    _fields_ = [('cout', ctypes.c_int), ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('dil_h', ctypes.c_int),
+                ('dil_w', ctypes.c_int), ('halo', Pad2d), ('act', ctypes.c_int), ('in_c_off', ctypes.c_int),
+                ('in_c_total', ctypes.c_int), ('out_c_off', ctypes.c_int), ('out_c_total', ctypes.c_int),
+                ('src_mode', ctypes.c_int)]
+
+
+class Op(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int), ('src', ctypes.c_int), ('dst', ctypes.c_int), ('w', ctypes.c_int),
+                ('b', ctypes.c_int), ('xs', Shape4), ('conv', Conv2d), ('pad', Pad2d)]
+
+
+class DlwpError(RuntimeError):
+    """A non-zero status from libdlwp_hip.so (message from dlwp_last_error())."""
+
+    def __init__(self, code, message):
+        super(DlwpError, self).__init__('libdlwp_hip error %d: %s' % (code, message))
+        self.code = code
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Every function name include/dlwp_hip.h declares (used by the CPU test that checks the .so exports them all)."""
+    text = open(header_path).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(dlwp_[a-z0-9_]+)\s*\(', text)))
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+                      '`make -C dlwp_amd/csrc`.  dlwp_amd has no CPU fallback.' % LIB_PATH)
+lib = ctypes.CDLL(LIB_PATH)
+
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_P = ctypes.POINTER
+
+
+def _sig(name, argtypes, restype=ctypes.c_int):
+    fn = getattr(lib, name)
+    fn.argtypes, fn.restype = argtypes, restype
+    return fn
+
+
+_sig('dlwp_version', [])
+_sig('dlwp_last_error', [], ctypes.c_char_p)
+_sig('dlwp_create', [_P(_vp), _i])
+_sig('dlwp_destroy', [_vp])
+_sig('dlwp_device_info', [_vp, _P(_i), _P(_i), ctypes.c_char_p, _sz])
+_sig('dlwp_pad2d_fwd', [_vp, _vp, _vp, _i, _i, _i, _i, Pad2d, _i, _vp])
+_sig('dlwp_pad2d_bwd', [_vp, _vp, _vp, _i, _i, _i, _i, Pad2d, _i, _vp])
+_sig('dlwp_conv2d_out_shape', [Shape4, _P(Conv2d), _P(Shape4)])
+_sig('dlwp_conv2d_fwd', [_vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
+_sig('dlwp_conv2d_fwd_direct', [_vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
+_sig('dlwp_conv2d_num_configs', [])
+_sig('dlwp_conv2d_config_info', [_i, _P(_i), _P(_i)])
+_sig('dlwp_conv2d_force_config', [_i])
+_sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
+_sig('dlwp_maxpool2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])
+_sig('dlwp_maxpool2_bwd', [_vp, _vp, _vp, _vp, Shape4, _i, _vp])
+_sig('dlwp_upsample2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])
+_sig('dlwp_upsample2_bwd', [_vp, _vp, _vp, Shape4, _i, _vp])
+_sig('dlwp_copy_channels', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
+_sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])
+_sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _P(_vp)])
+_sig('dlwp_rollout_launch', [_vp, _vp])
+_sig('dlwp_rollout_destroy', [_vp])
+
+
+def check(rc):
+    if rc != OK:
+        raise DlwpError(rc, lib.dlwp_last_error().decode('utf-8', 'replace'))
+    return rc
+
+
+_handles = {}
+
+
+def handle(device_index=0):
+    """One library handle per device, created on first use.  Raises DlwpError when there is no gfx950 GPU."""
+    h = _handles.get(device_index)
+    if h is None:
+        out = _vp()
+        check(lib.dlwp_create(ctypes.byref(out), int(device_index)))
+        h = _handles[device_index] = out
+    return h

@@ -1,0 +1,61 @@
+// common.h -- internal helpers shared by the translation units of libdlwp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/dlwp_hip.h"
+
+struct dlwp_handle {
+  int device;
+  int cu_count;
+  int lds_bytes;
+  char arch[64];
+};
+
+// thread-local error string (defined in api.hip)
+void dlwp_set_error(const char* fmt, ...);
+
+#define DLWP_FAIL(code, ...)      \
+  do {                            \
+    dlwp_set_error(__VA_ARGS__);  \
+    return (code);                \
+  } while (0)
+
+#define DLWP_CHECK_ARG(cond, ...) \
+  do {                            \
+    if (!(cond)) DLWP_FAIL(DLWP_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+#define DLWP_HIP(call)                                                                          \
+  do {                                                                                          \
+    hipError_t e__ = (call);                                                                    \
+    if (e__ != hipSuccess) DLWP_FAIL(DLWP_EHIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+// after a kernel launch (launch-configuration errors surface here; execution errors surface at the next sync)
+#define DLWP_LAUNCH_CHECK(name)                                                                   \
+  do {                                                                                            \
+    hipError_t e__ = hipGetLastError();                                                           \
+    if (e__ != hipSuccess) DLWP_FAIL(DLWP_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline int dlwp_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// input size seen by a conv after its loader-side transform
+static inline int dlwp_src_dim(int stored, int src_mode) {
+  return src_mode == DLWP_SRC_UPSAMPLE2 ? stored * 2 : (src_mode == DLWP_SRC_MAXPOOL2 ? stored / 2 : stored);
+}
+
+// map a padded coordinate to a source coordinate; returns -1 for "zero"
+__host__ __device__ static inline int dlwp_map_coord(int p, int n, int mode) {
+  if (p >= 0 && p < n) return p;
+  if (mode == DLWP_PAD_ZERO) return -1;
+  if (mode == DLWP_PAD_EDGE) return p < 0 ? 0 : n - 1;
+  int q = p % n;             // DLWP_PAD_WRAP
+  return q < 0 ? q + n : q;
+}
+
+// internal launchers shared between the public entry points and the rollout graph builder
+int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                       const dlwp_conv2d* cd, int dtype, hipStream_t s);

@@ -1,0 +1,274 @@
+// conv_fwd.hip -- Conv2D forward: argument validation, tile-configuration choice, launch; plus the direct
+// (one thread per output) vector-ALU kernel that covers every kernel size and serves as an in-library cross-check.
+// Reference call sites: examples/train.py:164-169 ... 214-219, Azure/train_tf.py:213-268.
+#include "conv_fwd_kernel.h"
+#include <mutex>
+#include <vector>
+
+const ConvKernelEntry* dlwp_conv_table_k3d1(int* n);
+const ConvKernelEntry* dlwp_conv_table_k3d2(int* n);
+const ConvKernelEntry* dlwp_conv_table_k5d1(int* n);
+
+namespace {
+
+struct Registry {
+  std::vector<ConvKernelEntry> entries;
+  std::vector<char> prepared;
+  Registry() {
+    int n = 0;
+    const ConvKernelEntry* t = dlwp_conv_table_k3d1(&n);
+    entries.insert(entries.end(), t, t + n);
+    t = dlwp_conv_table_k3d2(&n);
+    entries.insert(entries.end(), t, t + n);
+    t = dlwp_conv_table_k5d1(&n);
+    entries.insert(entries.end(), t, t + n);
+    prepared.assign(entries.size(), 0);
+  }
+};
+Registry& registry() {
+  static Registry r;
+  return r;
+}
+std::mutex g_prepare_mutex;
+
+// forced configuration for tuning sweeps (-1 = heuristic); per-thread so concurrent handles do not interfere
+thread_local int g_forced_cfg = -1;
+
+int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void* y, dlwp_shape4 xs,
+             const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
+  DLWP_CHECK_ARG(h && x && w && y && cd, "%s: null handle or pointer", fn);
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "%s: dtype %d not supported", fn, dtype);
+  DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, "%s: bad input shape (%d,%d,%d,%d)", fn, xs.n, xs.c,
+                 xs.h, xs.w);
+  if (dlwp_conv2d_out_shape(xs, cd, ys) != DLWP_OK) return DLWP_EINVAL;
+  return DLWP_OK;
+}
+
+ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs, const dlwp_conv2d* cd,
+                   dlwp_shape4 ys) {
+  ConvArgs a;
+  a.x = (const float*)x;
+  a.w = (const float*)w;
+  a.bias = (const float*)bias;
+  a.y = (float*)y;
+  a.N = xs.n;
+  a.Cin = xs.c;
+  a.Hs = xs.h;
+  a.Ws = xs.w;
+  a.H = dlwp_src_dim(xs.h, cd->src_mode);
+  a.W = dlwp_src_dim(xs.w, cd->src_mode);
+  a.Ho = ys.h;
+  a.Wo = ys.w;
+  a.Cout = cd->cout;
+  a.in_c_off = cd->in_c_off;
+  a.in_c_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
+  a.out_c_off = cd->out_c_off;
+  a.out_c_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
+  a.pad_top = cd->halo.top;
+  a.pad_left = cd->halo.left;
+  a.mode_h = cd->halo.mode_h;
+  a.mode_w = cd->halo.mode_w;
+  a.src_mode = cd->src_mode;
+  a.act = cd->act;
+  a.tiles_h = a.tiles_w = a.cout_tiles = 0;
+  return a;
+}
+
+// Padded MFMA work of a configuration on a problem, in units of 16x16x4 MFMAs, plus a small-grid penalty: a grid
+// that cannot give every CU ~2 workgroups is charged as if it ran that many (tail / under-fill), which steers small
+// batches toward smaller tiles.
+double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
+  const long long tiles = (long long)dlwp_ceil_div(a.Ho, e.th) * dlwp_ceil_div(a.Wo, e.tw);
+  const long long cout_tiles = dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  const long long blocks = tiles * cout_tiles * a.N;
+  const long long ksteps = (long long)dlwp_ceil_div(a.Cin, e.ck) * (e.ck / 4) * e.ks * e.ks;
+  const double per_block = (double)e.waves * e.fa * e.bnf * ksteps;
+  // staging cost per block in "MFMA-equivalents" (empirical weight): x tile + weight tile floats per chunk
+  const int lr = e.th + e.dil * (e.ks - 1), lc = e.tw + e.dil * (e.ks - 1);
+  const double stage = (double)dlwp_ceil_div(a.Cin, e.ck) * (e.ck * (double)lr * lc + e.ks * e.ks * e.ck * 16.0 * e.bnf) /
+                       64.0 * 0.25;
+  const double waves_per_cu = 8.0;  // rough co-residency
+  const double slots = cu_count * waves_per_cu / e.waves;
+  const double rounds = blocks < slots ? 1.0 : (double)blocks / slots;
+  return (per_block + stage) * e.waves * rounds;
+}
+
+int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
+  Registry& r = registry();
+  if (g_forced_cfg >= 0) {
+    if (g_forced_cfg >= (int)r.entries.size()) return -1;
+    const ConvKernelEntry& e = r.entries[g_forced_cfg];
+    return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w) ? g_forced_cfg : -1;
+  }
+  int best = -1;
+  double best_cost = 0;
+  for (int i = 0; i < (int)r.entries.size(); ++i) {
+    const ConvKernelEntry& e = r.entries[i];
+    if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
+    const double c = config_cost(e, a, cu_count);
+    if (best < 0 || c < best_cost) {
+      best = i;
+      best_cost = c;
+    }
+  }
+  return best;
+}
+
+// ---- direct kernel: one thread per output element, any kh/kw/dilation --------------------------------------------- //
+__global__ __launch_bounds__(256) void conv2d_fwd_direct_f32(const ConvArgs a, int kh, int kw, int dil_h, int dil_w) {
+  const long long total = (long long)a.N * a.Cout * a.Ho * a.Wo;
+  const long long plane = (long long)a.Hs * a.Ws;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ow = (int)(i % a.Wo);
+    long long q = i / a.Wo;
+    const int oh = (int)(q % a.Ho);
+    q /= a.Ho;
+    const int co = (int)(q % a.Cout);
+    const int n = (int)(q / a.Cout);
+    const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
+    float acc = 0.f;
+    // same summation order as the MFMA kernel's k order inside a channel chunk is NOT guaranteed; this kernel is a
+    // tolerance-level cross-check, not a bit-level one
+    for (int u = 0; u < kh; ++u) {
+      const int rs = dlwp_map_coord(oh + u * dil_h - a.pad_top, a.H, a.mode_h);
+      for (int v = 0; v < kw; ++v) {
+        const int cs = dlwp_map_coord(ow + v * dil_w - a.pad_left, a.W, a.mode_w);
+        if (rs < 0 || cs < 0) continue;
+        const float* wp = a.w + ((long long)(u * kw + v) * a.Cin) * a.Cout + co;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+          const float* xp = xn + (long long)ci * plane;
+          float xv;
+          if (a.src_mode == DLWP_SRC_UPSAMPLE2) xv = xp[(rs >> 1) * a.Ws + (cs >> 1)];
+          else if (a.src_mode == DLWP_SRC_MAXPOOL2) {
+            const float* s = xp + (rs * 2) * a.Ws + cs * 2;
+            xv = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[a.Ws], s[a.Ws + 1]));
+          } else xv = xp[rs * a.Ws + cs];
+          acc = fmaf(xv, wp[(long long)ci * a.Cout], acc);
+        }
+      }
+    }
+    if (a.bias) acc += a.bias[co];
+    a.y[(((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho + oh) * a.Wo + ow] = act_apply(acc, a.act);
+  }
+}
+
+int launch_direct(dlwp_handle_t h, ConvArgs& a, const dlwp_conv2d* cd, hipStream_t s) {
+  const long long total = (long long)a.N * a.Cout * a.Ho * a.Wo;
+  if (total == 0) return DLWP_OK;
+  long long want = (total + 255) / 256;
+  const long long cap = (long long)h->cu_count * 16;
+  const int grid = (int)(want < cap ? want : cap);
+  conv2d_fwd_direct_f32<<<grid, 256, 0, s>>>(a, cd->kh, cd->kw, cd->dil_h, cd->dil_w);
+  DLWP_LAUNCH_CHECK("conv2d_fwd_direct_f32");
+  return DLWP_OK;
+}
+
+}  // namespace
+
+int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                       const dlwp_conv2d* cd, int dtype, hipStream_t s) {
+  dlwp_shape4 ys;
+  int rc = validate("dlwp_conv2d_fwd", h, x, w, y, xs, cd, dtype, &ys);
+  if (rc != DLWP_OK) return rc;
+  if (xs.n == 0) return DLWP_OK;
+  ConvArgs a = make_args(x, w, bias, y, xs, cd, ys);
+  const int ci = choose_config(a, cd, h->cu_count);
+  if (ci < 0) {
+    if (g_forced_cfg >= 0) DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", g_forced_cfg);
+    return launch_direct(h, a, cd, s);  // kernel sizes without an MFMA tile configuration
+  }
+  Registry& r = registry();
+  const ConvKernelEntry& e = r.entries[ci];
+  if (!r.prepared[ci]) {
+    std::lock_guard<std::mutex> lock(g_prepare_mutex);
+    if (!r.prepared[ci]) {
+      const int pe = e.prepare();
+      if (pe != 0) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: hipFuncSetAttribute failed (%d)", pe);
+      r.prepared[ci] = 1;
+    }
+  }
+  a.tiles_h = dlwp_ceil_div(a.Ho, e.th);
+  a.tiles_w = dlwp_ceil_div(a.Wo, e.tw);
+  a.cout_tiles = dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  const long long grid = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
+  DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
+  e.launch(a, (int)grid, s);
+  DLWP_LAUNCH_CHECK("conv2d_fwd_mfma_f32");
+  return DLWP_OK;
+}
+
+extern "C" {
+
+int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys) {
+  DLWP_CHECK_ARG(cd && ys, "dlwp_conv2d_out_shape: null pointer");
+  DLWP_CHECK_ARG(cd->cout > 0 && cd->kh > 0 && cd->kw > 0 && cd->dil_h > 0 && cd->dil_w > 0,
+                 "conv2d: bad filter spec (cout=%d k=%dx%d dil=%dx%d)", cd->cout, cd->kh, cd->kw, cd->dil_h, cd->dil_w);
+  DLWP_CHECK_ARG((unsigned)cd->src_mode <= 2u, "conv2d: unknown src_mode %d", cd->src_mode);
+  DLWP_CHECK_ARG((unsigned)cd->act <= 2u, "conv2d: unknown activation %d", cd->act);
+  const dlwp_pad2d& p = cd->halo;
+  DLWP_CHECK_ARG(p.top >= 0 && p.bottom >= 0 && p.left >= 0 && p.right >= 0, "conv2d: negative halo");
+  DLWP_CHECK_ARG((unsigned)p.mode_h <= 2u && (unsigned)p.mode_w <= 2u, "conv2d: unknown halo mode");
+  const int hin = dlwp_src_dim(xs.h, cd->src_mode), win = dlwp_src_dim(xs.w, cd->src_mode);
+  DLWP_CHECK_ARG(hin > 0 && win > 0, "conv2d: empty input after the src transform");
+  DLWP_CHECK_ARG(p.mode_h != DLWP_PAD_WRAP || (p.top <= hin && p.bottom <= hin),
+                 "conv2d: periodic row halo (%d,%d) exceeds H=%d", p.top, p.bottom, hin);
+  DLWP_CHECK_ARG(p.mode_w != DLWP_PAD_WRAP || (p.left <= win && p.right <= win),
+                 "conv2d: periodic column halo (%d,%d) exceeds W=%d", p.left, p.right, win);
+  const int ho = hin + p.top + p.bottom - cd->dil_h * (cd->kh - 1);
+  const int wo = win + p.left + p.right - cd->dil_w * (cd->kw - 1);
+  DLWP_CHECK_ARG(ho > 0 && wo > 0, "conv2d: kernel %dx%d (dilation %dx%d) larger than the padded input %dx%d", cd->kh,
+                 cd->kw, cd->dil_h, cd->dil_w, hin + p.top + p.bottom, win + p.left + p.right);
+  const int in_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
+  const int out_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
+  DLWP_CHECK_ARG(cd->in_c_off >= 0 && cd->in_c_off + xs.c <= in_total, "conv2d: input channel window [%d,%d) of %d",
+                 cd->in_c_off, cd->in_c_off + xs.c, in_total);
+  DLWP_CHECK_ARG(cd->out_c_off >= 0 && cd->out_c_off + cd->cout <= out_total,
+                 "conv2d: output channel window [%d,%d) of %d", cd->out_c_off, cd->out_c_off + cd->cout, out_total);
+  ys->n = xs.n;
+  ys->c = cd->cout;
+  ys->h = ho;
+  ys->w = wo;
+  return DLWP_OK;
+}
+
+int dlwp_conv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                    const dlwp_conv2d* cd, int dtype, void* stream) {
+  return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream);
+}
+
+int dlwp_conv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                           const dlwp_conv2d* cd, int dtype, void* stream) {
+  dlwp_shape4 ys;
+  int rc = validate("dlwp_conv2d_fwd_direct", h, x, w, y, xs, cd, dtype, &ys);
+  if (rc != DLWP_OK) return rc;
+  ConvArgs a = make_args(x, w, bias, y, xs, cd, ys);
+  return launch_direct(h, a, cd, (hipStream_t)stream);
+}
+
+// ---- tuning hooks (used by tools/tune_conv.py and the tests; not part of the drop-in surface) -------------------- //
+int dlwp_conv2d_num_configs(void) { return (int)registry().entries.size(); }
+
+int dlwp_conv2d_config_info(int i, int* info8, int* lds_bytes) {
+  Registry& r = registry();
+  DLWP_CHECK_ARG(i >= 0 && i < (int)r.entries.size() && info8, "dlwp_conv2d_config_info: index %d out of range", i);
+  const ConvKernelEntry& e = r.entries[i];
+  const int v[8] = {e.ks, e.dil, e.th, e.tw, e.waves, e.fa, e.bnf, e.ck};
+  for (int k = 0; k < 8; ++k) info8[k] = v[k];
+  if (lds_bytes) *lds_bytes = e.lds_bytes;
+  return DLWP_OK;
+}
+
+int dlwp_conv2d_force_config(int i) {
+  g_forced_cfg = i;
+  return DLWP_OK;
+}
+
+// which configuration the heuristic picks for a problem (-1 = direct kernel)
+int dlwp_conv2d_pick_config(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
+  dlwp_shape4 ys;
+  if (!h || !cd || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return -2;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys);
+  return choose_config(a, cd, h->cu_count);
+}
+
+}  // extern "C"

@@ -1,0 +1,270 @@
+// conv_fwd_kernel.h -- implicit-GEMM Conv2D on the CDNA4 matrix cores, fp32 in / fp32 accumulate (gfx950).
+//
+// Replaces, in ONE kernel, what the reference executes as 5-7 separate TF ops per layer:
+//   [UpSampling2D | MaxPooling2D] -> PeriodicPadding2D (2 concat copies, DLWP/custom.py:202,204) -> ZeroPadding2D
+//   (tf.pad copy) -> Conv2D 'valid' (+ NCHW<->NHWC transposes on CPU) -> BiasAdd -> tanh   (examples/train.py:159-219)
+//
+// GEMM view:  D[pixel, cout] = sum_k A[pixel, k] * B[k, cout],  k = (tap u,v ; channel ci)
+//   A is never materialised: the haloed input tile of CK channels lives in LDS ([ci][row][col], wrap / zero / edge
+//   halo and the 2x up-sampling / 2x2 max-pooling of the stored tensor resolved by the loader), and every A fragment is
+//   one ds_read_b32 at  lane_base + compile-time offset(tap, ci).
+//   B = the Keras HWIO weights, staged per channel chunk as [tap][ci][cout] (cout contiguous, as stored).
+//   MFMA: v_mfma_f32_16x16x4_f32 (exact f32, == an fmaf chain in k order); A lane l -> A[l&15][l>>4], B lane l ->
+//   B[l>>4][l&15], D lane l reg r -> D[4*(l>>4)+r][l&15]: with pixels on rows each lane ends up owning 4 consecutive
+//   pixels of one output channel = one 16-byte store into the NCHW output.
+//
+// Tile: TH x TW output pixels (flattened, padded to 16*FA*WAVES), BN = 16*BNF output channels, CK input channels per
+// LDS stage.  Both LDS strides are chosen == 16 (mod 32) floats so the two 16-lane halves of a ds_read_b32 lane group
+// (k and k+1) fall on disjoint banks.
+#pragma once
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  int N, Cin, Hs, Ws;  // stored input
+  int H, W;            // input as the conv sees it (after the src transform), before the halo
+  int Ho, Wo, Cout;
+  int in_c_off, in_c_total, out_c_off, out_c_total;
+  int pad_top, pad_left, mode_h, mode_w;
+  int src_mode, act;
+  int tiles_h, tiles_w, cout_tiles;
+};
+
+template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_>
+struct ConvCfg {
+  static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, FA = FA_, BNF = BNF_, CK = CK_;
+  static constexpr int NT = WAVES * 64;
+  static constexpr int LR = TH + DIL * (KS - 1), LC = TW + DIL * (KS - 1);
+  static constexpr int LCS = LC;
+  static constexpr int PS_RAW = LR * LCS;
+  static constexpr int PS = PS_RAW + (((16 - PS_RAW % 32) % 32) + 32) % 32;  // == 16 (mod 32)
+  static constexpr int BN = 16 * BNF;
+  static constexpr int BNP = (BN % 32 == 0) ? BN + 16 : BN;  // == 16 (mod 32)
+  static constexpr int TAPS = KS * KS;
+  static constexpr int X_FLOATS = CK * PS;
+  static constexpr int W_FLOATS = TAPS * CK * BNP;
+  static constexpr int LDS_BYTES = (X_FLOATS + W_FLOATS) * 4;
+  static constexpr int P = TH * TW;
+  static constexpr int MPAD = 16 * FA * WAVES;
+  static constexpr int NPOS = (LR * LC + NT - 1) / NT;
+  static_assert(MPAD >= P, "tile pixels must fit the wave/fragment decomposition");
+  static_assert(CK % 4 == 0, "channel chunk must be a multiple of the MFMA K (4)");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == DLWP_ACT_TANH) return tanhf(v);
+  if (act == DLWP_ACT_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;
+  float* ws = lds + C::X_FLOATS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- XCD-aware block -> tile mapping: hardware places block b on XCD b%8; give each XCD a contiguous run of
+  //      logical tiles (whole images) so halo / weight re-reads hit that XCD's L2.  Bijective for any grid size.
+  int L;
+  {
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int xcd = b & 7, idx = b >> 3, q = nb >> 3, r = nb & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tw = L % a.tiles_w;
+  L /= a.tiles_w;
+  const int th = L % a.tiles_h;
+  L /= a.tiles_h;
+  const int ct = L % a.cout_tiles;
+  const int n = L / a.cout_tiles;
+  const int i0 = th * C::TH, j0 = tw * C::TW, n0 = ct * C::BN;
+
+  // ---- loader bookkeeping: each thread owns NPOS spatial positions of the LDS tile, the same for every channel
+  int goff[C::NPOS], loff[C::NPOS];
+#pragma unroll
+  for (int q = 0; q < C::NPOS; ++q) {
+    const int s = tid + q * C::NT;
+    const bool in_tile = s < C::LR * C::LC;
+    const int lr = s / C::LC, lc = s - lr * C::LC;
+    const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
+    const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
+    int g = -1;
+    if (in_tile && rs >= 0 && cs >= 0) {
+      if (a.src_mode == DLWP_SRC_UPSAMPLE2) g = (rs >> 1) * a.Ws + (cs >> 1);
+      else if (a.src_mode == DLWP_SRC_MAXPOOL2) g = (rs * 2) * a.Ws + cs * 2;
+      else g = rs * a.Ws + cs;
+    }
+    goff[q] = g;
+    loff[q] = in_tile ? lr * C::LCS + lc : -1;
+  }
+  const long long plane = (long long)a.Hs * a.Ws;
+  const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
+
+  // ---- MFMA fragment bookkeeping
+  int abase[C::FA];
+#pragma unroll
+  for (int i = 0; i < C::FA; ++i) {
+    int p = (wave * C::FA + i) * 16 + (lane & 15);
+    if (p >= C::P) p = 0;  // padded pixel: compute on a valid address, never stored
+    const int r = p / C::TW, c = p - r * C::TW;
+    abase[i] = r * C::LCS + c + (lane >> 4) * C::PS;
+  }
+  const int bbase = (lane >> 4) * C::BNP + (lane & 15);
+
+  f32x4 acc[C::FA][C::BNF];
+#pragma unroll
+  for (int i = 0; i < C::FA; ++i)
+#pragma unroll
+    for (int g = 0; g < C::BNF; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool w_vec = (a.Cout & 3) == 0;
+
+  for (int c0 = 0; c0 < a.Cin; c0 += C::CK) {
+    __syncthreads();  // everyone is done reading the previous chunk
+    // -- stage the input chunk (halo, wrap, pole rows, up-sampling / pooling resolved here)
+    if (a.src_mode != DLWP_SRC_MAXPOOL2) {
+      float v[C::CK][C::NPOS];
+#pragma unroll
+      for (int ci = 0; ci < C::CK; ++ci) {
+        const bool c_ok = c0 + ci < a.Cin;
+        const float* xp = xn + (long long)(c0 + ci) * plane;
+#pragma unroll
+        for (int q = 0; q < C::NPOS; ++q) v[ci][q] = (c_ok && goff[q] >= 0) ? xp[goff[q]] : 0.f;
+      }
+#pragma unroll
+      for (int ci = 0; ci < C::CK; ++ci)
+#pragma unroll
+        for (int q = 0; q < C::NPOS; ++q)
+          if (loff[q] >= 0) xs[ci * C::PS + loff[q]] = v[ci][q];
+    } else {
+#pragma unroll
+      for (int ci = 0; ci < C::CK; ++ci) {
+        const bool c_ok = c0 + ci < a.Cin;
+        const float* xp = xn + (long long)(c0 + ci) * plane;
+#pragma unroll
+        for (int q = 0; q < C::NPOS; ++q) {
+          float m = 0.f;
+          if (c_ok && goff[q] >= 0) {
+            const float* s = xp + goff[q];
+            m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[a.Ws], s[a.Ws + 1]));
+          }
+          if (loff[q] >= 0) xs[ci * C::PS + loff[q]] = m;
+        }
+      }
+    }
+    // -- stage the weight chunk [tap][ci][BN]
+    if (w_vec) {
+      constexpr int V4 = C::BN / 4;
+      constexpr int TOT = C::TAPS * C::CK * V4;
+      for (int e = tid; e < TOT; e += C::NT) {
+        const int col = (e % V4) * 4;
+        const int row = e / V4;  // tap*CK + ci
+        const int tap = row / C::CK, ci = row - tap * C::CK;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c0 + ci < a.Cin && n0 + col < a.Cout)
+          v = *(const f32x4*)(a.w + ((long long)tap * a.Cin + c0 + ci) * a.Cout + n0 + col);
+        *(f32x4*)(ws + row * C::BNP + col) = v;
+      }
+    } else {
+      constexpr int TOT = C::TAPS * C::CK * C::BN;
+      for (int e = tid; e < TOT; e += C::NT) {
+        const int col = e % C::BN;
+        const int row = e / C::BN;
+        const int tap = row / C::CK, ci = row - tap * C::CK;
+        float v = 0.f;
+        if (c0 + ci < a.Cin && n0 + col < a.Cout) v = a.w[((long long)tap * a.Cin + c0 + ci) * a.Cout + n0 + col];
+        ws[row * C::BNP + col] = v;
+      }
+    }
+    __syncthreads();
+    // -- K loop over this chunk.  Order = (group of 4 channels, tap): the accumulation chain of every output element
+    //    is then the same whatever CK / tile shape / batch size is in use, so results are bit-identical across tile
+    //    configurations and across batch shardings.  Every LDS address = lane base + immediate.
+#pragma unroll
+    for (int c4 = 0; c4 < C::CK / 4; ++c4) {
+#pragma unroll
+      for (int tap = 0; tap < C::TAPS; ++tap) {
+        const int u = tap / C::KS, vv = tap - u * C::KS;
+        float af[C::FA], bf[C::BNF];
+#pragma unroll
+        for (int i = 0; i < C::FA; ++i) af[i] = xs[abase[i] + (c4 * 4) * C::PS + u * C::DIL * C::LCS + vv * C::DIL];
+#pragma unroll
+        for (int g = 0; g < C::BNF; ++g) bf[g] = ws[bbase + (tap * C::CK + c4 * 4) * C::BNP + g * 16];
+#pragma unroll
+        for (int i = 0; i < C::FA; ++i)
+#pragma unroll
+          for (int g = 0; g < C::BNF; ++g)
+            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[g], acc[i][g], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: bias + activation, 4 consecutive pixels of one channel per lane
+  const bool vec_store = (C::TW % 4 == 0) && ((a.Wo & 3) == 0);
+  float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;
+#pragma unroll
+  for (int g = 0; g < C::BNF; ++g) {
+    const int co = n0 + g * 16 + (lane & 15);
+    if (co >= a.Cout) continue;
+    const float bv = a.bias ? a.bias[co] : 0.f;
+    float* yc = yn + (long long)co * a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < C::FA; ++i) {
+      const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
+      if (p >= C::P) continue;
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][g][r] + bv, a.act);
+      if (vec_store) {
+        const int row = p / C::TW, col = p - row * C::TW;
+        const int oh = i0 + row, ow = j0 + col;
+        if (oh < a.Ho && ow < a.Wo) *(f32x4*)(yc + (long long)oh * a.Wo + ow) = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pp = p + r;
+          const int row = pp / C::TW, col = pp - row * C::TW;
+          const int oh = i0 + row, ow = j0 + col;
+          if (pp < C::P && oh < a.Ho && ow < a.Wo) yc[(long long)oh * a.Wo + ow] = o[r];
+        }
+      }
+    }
+  }
+}
+
+// ---- registry of compiled tile configurations ------------------------------------------------------------------- //
+struct ConvKernelEntry {
+  int ks, dil, th, tw, waves, fa, bnf, ck, lds_bytes;
+  void (*launch)(const ConvArgs&, int grid, hipStream_t s);
+  int (*prepare)();
+};
+
+template <class C>
+static void conv_launch_thunk(const ConvArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((conv2d_fwd_mfma_f32<C>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
+}
+
+template <class C>
+static int conv_prepare() {
+  // > 64 KiB of dynamic LDS needs the opt-in attribute
+  if (C::LDS_BYTES > 64 * 1024)
+    return (int)hipFuncSetAttribute((const void*)conv2d_fwd_mfma_f32<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    C::LDS_BYTES);
+  return 0;
+}
+
+#define CONV_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK)                                                        \
+  {                                                                                                             \
+    KS, DIL, TH, TW, WAVES, FA, BNF, CK, ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::LDS_BYTES,              \
+        &conv_launch_thunk<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>,                                       \
+        &conv_prepare<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>                                             \
+  }

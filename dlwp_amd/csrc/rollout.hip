@@ -1,0 +1,125 @@
+// rollout.hip -- the autoregressive predict_timeseries loop as ONE hipGraph.
+//
+// Reference: DLWPNeuralNet.predict_timeseries (DLWP/model/models.py:277-293) and DLWPFunctional.predict_timeseries
+// (:439-447) run a host loop: numpy state -> Keras predict (H2D, graph, D2H per 32-sample chunk) -> two full host
+// copies -> next step.  Here the state never leaves HBM: call t's last kernel writes straight into slot(s)
+// [t*n_outputs, (t+1)*n_outputs) of the device-resident series buffer and call t+1 reads its input from the last of
+// those slots.  All `calls` forwards are stream-captured once and replayed with a single hipGraphLaunch.
+#include "common.h"
+#include <vector>
+
+struct dlwp_rollout {
+  dlwp_handle_t h;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int calls, n_ops;
+};
+
+namespace {
+
+int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, const void* w, const void* b, int dtype,
+               hipStream_t s) {
+  switch (op.kind) {
+    case DLWP_OP_CONV2D:
+      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, dtype, s);
+    case DLWP_OP_PAD2D:
+      return dlwp_pad2d_fwd(h, src, dst, op.xs.n * op.xs.c, op.xs.h, op.xs.w, 1, op.pad, dtype, (void*)s);
+    case DLWP_OP_MAXPOOL2:
+      return dlwp_maxpool2_fwd(h, src, dst, op.xs, dtype, (void*)s);
+    case DLWP_OP_UPSAMPLE2:
+      return dlwp_upsample2_fwd(h, src, dst, op.xs, dtype, (void*)s);
+    case DLWP_OP_COPYCH:
+      return dlwp_copy_channels(h, src, dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w, op.conv.in_c_off,
+                                op.conv.in_c_total, op.conv.out_c_off, op.conv.out_c_total, dtype, (void*)s);
+    default:
+      DLWP_FAIL(DLWP_EINVAL, "rollout: unknown op kind %d", op.kind);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
+                        const void* state0, void* series, size_t slot_elems, int calls, int n_outputs, int dtype,
+                        dlwp_rollout_t* out) {
+  DLWP_CHECK_ARG(h && plan && out && state0 && series, "dlwp_rollout_create: null handle or pointer");
+  DLWP_CHECK_ARG(n_ops > 0 && calls > 0 && n_outputs > 0 && slot_elems > 0, "dlwp_rollout_create: bad sizes");
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_rollout_create: dtype %d not supported", dtype);
+  DLWP_CHECK_ARG(n_buffers == 0 || buffers, "dlwp_rollout_create: null buffer table");
+  for (int i = 0; i < n_ops; ++i) {
+    const dlwp_op& op = plan[i];
+    DLWP_CHECK_ARG(op.src >= DLWP_BUF_STATE_IN && op.src < n_buffers, "rollout op %d: src buffer %d out of range", i, op.src);
+    DLWP_CHECK_ARG(op.dst != DLWP_BUF_STATE_IN && op.dst >= DLWP_BUF_OUT(n_outputs - 1) && op.dst < n_buffers,
+                   "rollout op %d: dst buffer %d out of range", i, op.dst);
+    if (op.kind == DLWP_OP_CONV2D)
+      DLWP_CHECK_ARG(op.w >= 0 && op.w < n_buffers && op.b >= -1 && op.b < n_buffers,
+                     "rollout op %d: weight/bias buffer out of range", i);
+  }
+  const size_t esz = sizeof(float);
+  auto resolve = [&](int idx, int call, bool is_src) -> void* {
+    if (idx >= 0) return buffers[idx];
+    if (idx == DLWP_BUF_STATE_IN) {
+      if (call == 0) return const_cast<void*>(state0);
+      return (char*)series + ((size_t)call * n_outputs - 1) * slot_elems * esz;
+    }
+    const int o = -2 - idx;  // DLWP_BUF_OUT(o)
+    (void)is_src;
+    return (char*)series + ((size_t)call * n_outputs + o) * slot_elems * esz;
+  };
+
+  hipStream_t cap;
+  DLWP_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(cap);
+    DLWP_FAIL(DLWP_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+  }
+  int rc = DLWP_OK;
+  for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
+    for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
+      const dlwp_op& op = plan[i];
+      const void* w = op.kind == DLWP_OP_CONV2D ? buffers[op.w] : nullptr;
+      const void* b = (op.kind == DLWP_OP_CONV2D && op.b >= 0) ? buffers[op.b] : nullptr;
+      rc = enqueue_op(h, op, resolve(op.src, t, true), resolve(op.dst, t, false), w, b, dtype, cap);
+    }
+  }
+  e = hipStreamEndCapture(cap, &graph);
+  (void)hipStreamDestroy(cap);
+  if (rc != DLWP_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;  // error string already set by the failing op
+  }
+  if (e != hipSuccess) DLWP_FAIL(DLWP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    DLWP_FAIL(DLWP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  }
+  dlwp_rollout* r = new dlwp_rollout();
+  r->h = h;
+  r->graph = graph;
+  r->exec = exec;
+  r->calls = calls;
+  r->n_ops = n_ops;
+  *out = r;
+  return DLWP_OK;
+}
+
+int dlwp_rollout_launch(dlwp_rollout_t r, void* stream) {
+  DLWP_CHECK_ARG(r && r->exec, "dlwp_rollout_launch: null rollout");
+  DLWP_HIP(hipGraphLaunch(r->exec, (hipStream_t)stream));
+  return DLWP_OK;
+}
+
+int dlwp_rollout_destroy(dlwp_rollout_t r) {
+  if (!r) return DLWP_OK;
+  if (r->exec) (void)hipGraphExecDestroy(r->exec);
+  if (r->graph) (void)hipGraphDestroy(r->graph);
+  delete r;
+  return DLWP_OK;
+}
+
+}  // extern "C"

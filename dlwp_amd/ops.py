@@ -1,0 +1,181 @@
+"""
+Tensor-level wrappers over the C ABI.  torch is used ONLY as plumbing here: device allocations (torch.empty), the
+current HIP stream, and device indices.  Every arithmetic / data-movement operation is a libdlwp_hip.so kernel.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LINEAR, ACT_RELU, ACT_TANH, PAD_EDGE, PAD_WRAP, PAD_ZERO, SRC_DIRECT, SRC_MAXPOOL2,  # noqa: F401
+                   SRC_UPSAMPLE2, Conv2d, Pad2d, Shape4)
+
+ACTIVATIONS = {None: ACT_LINEAR, 'linear': ACT_LINEAR, 'tanh': ACT_TANH, 'relu': ACT_RELU}
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise RuntimeError('dlwp_amd ops need device (HIP) tensors; there is no CPU fallback')
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _check_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError('expected contiguous float32 tensors, got %s contiguous=%s' % (t.dtype, t.is_contiguous()))
+
+
+def make_pad(top=0, bottom=0, left=0, right=0, mode_h=PAD_ZERO, mode_w=PAD_ZERO):
+    return Pad2d(int(top), int(bottom), int(left), int(right), int(mode_h), int(mode_w))
+
+
+def make_conv(cout, kh, kw, dil=1, halo=None, act=ACT_LINEAR, in_c_off=0, in_c_total=0, out_c_off=0, out_c_total=0,
+              src_mode=SRC_DIRECT):
+    dh, dw = (dil, dil) if isinstance(dil, int) else dil
+    return Conv2d(int(cout), int(kh), int(kw), int(dh), int(dw), halo if halo is not None else make_pad(), int(act),
+                  int(in_c_off), int(in_c_total), int(out_c_off), int(out_c_total), int(src_mode))
+
+
+def conv_out_shape(xs, cd):
+    ys = Shape4()
+    _lib.check(_lib.lib.dlwp_conv2d_out_shape(xs, ctypes.byref(cd), ctypes.byref(ys)))
+    return ys
+
+
+def pad2d(x, pad, channels_last=False, out=None):
+    """x: NCHW (or NHWC with channels_last=True) -> padded copy."""
+    _check_f32(x)
+    if channels_last:
+        n, h, w, c = x.shape
+        outer, inner = n, c
+        oshape = (n, h + pad.top + pad.bottom, w + pad.left + pad.right, c)
+    else:
+        n, c, h, w = x.shape
+        outer, inner = n * c, 1
+        oshape = (n, c, h + pad.top + pad.bottom, w + pad.left + pad.right)
+    y = out if out is not None else torch.empty(oshape, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib.dlwp_pad2d_fwd(_lib.handle(_dev(x)), _ptr(x), _ptr(y), outer, h, w, inner, pad, _lib.F32,
+                                       _stream(x)))
+    return y
+
+
+def pad2d_bwd(dy, x_shape, pad, channels_last=False):
+    _check_f32(dy)
+    if channels_last:
+        n, h, w, c = x_shape
+        outer, inner = n, c
+    else:
+        n, c, h, w = x_shape
+        outer, inner = n * c, 1
+    dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.lib.dlwp_pad2d_bwd(_lib.handle(_dev(dy)), _ptr(dy), _ptr(dx), outer, h, w, inner, pad, _lib.F32,
+                                       _stream(dy)))
+    return dx
+
+
+def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None):
+    """x: stored input (n, in_c_total, h, w); the conv reads `x_channels` (default: all) channels from cd.in_c_off.
+    Returns (n, out_c_total, ho, wo); writes channels [out_c_off, out_c_off+cout)."""
+    _check_f32(x, w_hwio, bias)
+    n, c_total, h, w = x.shape
+    cin = int(x_channels) if x_channels is not None else c_total
+    if tuple(w_hwio.shape) != (cd.kh, cd.kw, cin, cd.cout):
+        raise ValueError('kernel shape %s does not match (kh,kw,cin,cout)=(%d,%d,%d,%d)' %
+                         (tuple(w_hwio.shape), cd.kh, cd.kw, cin, cd.cout))
+    if cd.in_c_total == 0 and cin != c_total:
+        cd.in_c_total = c_total
+    xs = Shape4(n, cin, h, w)
+    ys = conv_out_shape(xs, cd)
+    oc = cd.out_c_total if cd.out_c_total > 0 else cd.cout
+    if out is None:
+        out = torch.empty((n, oc, ys.h, ys.w), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (n, oc, ys.h, ys.w):
+        raise ValueError('output buffer shape %s != %s' % (tuple(out.shape), (n, oc, ys.h, ys.w)))
+    fn = _lib.lib.dlwp_conv2d_fwd_direct if direct else _lib.lib.dlwp_conv2d_fwd
+    _lib.check(fn(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(bias), _ptr(out), xs, ctypes.byref(cd), _lib.F32,
+                  _stream(x)))
+    return out
+
+
+def maxpool2(x, out=None):
+    _check_f32(x)
+    n, c, h, w = x.shape
+    y = out if out is not None else torch.empty((n, c, h // 2, w // 2), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib.dlwp_maxpool2_fwd(_lib.handle(_dev(x)), _ptr(x), _ptr(y), Shape4(n, c, h, w), _lib.F32,
+                                          _stream(x)))
+    return y
+
+
+def maxpool2_bwd(x, dy):
+    _check_f32(x, dy)
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib.dlwp_maxpool2_bwd(_lib.handle(_dev(x)), _ptr(x), _ptr(dy), _ptr(dx), Shape4(n, c, h, w),
+                                          _lib.F32, _stream(x)))
+    return dx
+
+
+def upsample2(x, out=None):
+    _check_f32(x)
+    n, c, h, w = x.shape
+    y = out if out is not None else torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.lib.dlwp_upsample2_fwd(_lib.handle(_dev(x)), _ptr(x), _ptr(y), Shape4(n, c, h, w), _lib.F32,
+                                           _stream(x)))
+    return y
+
+
+def upsample2_bwd(dy):
+    _check_f32(dy)
+    n, c, h2, w2 = dy.shape
+    dx = torch.empty((n, c, h2 // 2, w2 // 2), dtype=dy.dtype, device=dy.device)
+    _lib.check(_lib.lib.dlwp_upsample2_bwd(_lib.handle(_dev(dy)), _ptr(dy), _ptr(dx), Shape4(n, c, h2 // 2, w2 // 2),
+                                           _lib.F32, _stream(dy)))
+    return dx
+
+
+def copy_channels(src, dst, c, src_c_off=0, dst_c_off=0):
+    _check_f32(src, dst)
+    n, sc, h, w = src.shape
+    _lib.check(_lib.lib.dlwp_copy_channels(_lib.handle(_dev(src)), _ptr(src), _ptr(dst), n, int(c), h * w,
+                                           int(src_c_off), sc, int(dst_c_off), dst.shape[1], _lib.F32, _stream(src)))
+    return dst
+
+
+def series_merge_time(series, time_dim):
+    """(T, N, time_dim*V, ...) -> (T*time_dim, N, V, ...)  -- DLWP/model/models.py:294-300."""
+    _check_f32(series)
+    t, n, c = series.shape[:3]
+    v = c // time_dim
+    rest = tuple(series.shape[3:])
+    hw = 1
+    for d in rest:
+        hw *= d
+    out = torch.empty((t * time_dim, n, v) + rest, dtype=series.dtype, device=series.device)
+    _lib.check(_lib.lib.dlwp_series_merge_time(_lib.handle(_dev(series)), _ptr(series), _ptr(out), t, n, time_dim, v,
+                                               hw, _lib.F32, _stream(series)))
+    return out
+
+
+def conv_configs():
+    """[(ks, dil, th, tw, waves, frags_per_wave, cout_frags, channel_chunk, lds_bytes)] of the compiled MFMA tiles."""
+    out = []
+    info = (ctypes.c_int * 8)()
+    lds = ctypes.c_int()
+    for i in range(_lib.lib.dlwp_conv2d_num_configs()):
+        _lib.check(_lib.lib.dlwp_conv2d_config_info(i, info, ctypes.byref(lds)))
+        out.append(tuple(info) + (lds.value,))
+    return out
+
+
+def force_conv_config(i):
+    _lib.lib.dlwp_conv2d_force_config(int(i))

@@ -1,0 +1,149 @@
+/*
+ * dlwp_hip.h -- C ABI of libdlwp_hip.so: the MI355X (gfx950) forecast-step hot path of DLWP.
+ *
+ * The reference (jweyn/DLWP) has NO native code and NO FFI: its drop-in boundary is a Python name registry
+ * (DLWP/model/models.py:97-103 -> DLWP/util.py:82-93) on top of third-party Keras/TensorFlow ops.  Every entry point
+ * below therefore replaces the Keras/TF op(s) that a reference layer resolves to; the reference call site is cited
+ * per function.  The Python host layer (dlwp_amd/) binds these with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns int: 0 ok, DLWP_EINVAL (-1) bad argument, DLWP_EUNSUPPORTED (-2), DLWP_EHIP (-3) HIP
+ *     runtime error; dlwp_last_error() returns a thread-local message for the last non-zero return.
+ *   - all tensor pointers are CALLER-OWNED DEVICE memory (e.g. torch-ROCm storage), dense, row-major, NCHW unless
+ *     stated; the library never allocates, frees or retains them (rollout objects excepted: buffers captured in a
+ *     rollout graph must outlive it).
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it.  No host synchronisation inside.
+ *   - dtype: DLWP_F32 (0) everywhere in this version.  (DLWP_BF16 = 1 reserved.)
+ */
+#ifndef DLWP_HIP_H
+#define DLWP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLWP_OK            0
+#define DLWP_EINVAL       (-1)
+#define DLWP_EUNSUPPORTED (-2)
+#define DLWP_EHIP         (-3)
+
+#define DLWP_F32  0
+#define DLWP_BF16 1
+
+/* per-axis halo modes */
+#define DLWP_PAD_ZERO 0   /* keras.layers.ZeroPadding2D                                  (examples/train.py:163)   */
+#define DLWP_PAD_WRAP 1   /* DLWP.custom.PeriodicPadding2D                               (DLWP/custom.py:139-214)  */
+#define DLWP_PAD_EDGE 2   /* DLWP.custom.FillPadding2D (pole rows)                       (DLWP/custom.py:309-402)  */
+
+#define DLWP_ACT_LINEAR 0
+#define DLWP_ACT_TANH   1
+#define DLWP_ACT_RELU   2
+
+/* how the conv loader reads its stored input tensor */
+#define DLWP_SRC_DIRECT    0
+#define DLWP_SRC_UPSAMPLE2 1   /* fused keras UpSampling2D(2) in front of the conv       (examples/train.py:191,201) */
+#define DLWP_SRC_MAXPOOL2  2   /* fused keras MaxPooling2D(2) in front of the conv       (examples/train.py:171,181) */
+
+typedef struct dlwp_handle* dlwp_handle_t;
+
+typedef struct { int n, c, h, w; } dlwp_shape4;
+
+typedef struct {
+  int top, bottom, left, right;   /* asymmetric amounts                                                    */
+  int mode_h, mode_w;             /* DLWP_PAD_* per axis; corners follow from applying the two axes in turn */
+} dlwp_pad2d;
+
+typedef struct {
+  int cout, kh, kw, dil_h, dil_w; /* stride 1, 'valid' after the implicit halo                              */
+  dlwp_pad2d halo;                /* fused Periodic/Zero/Fill padding in front of the conv; all-zero = none */
+  int act;                        /* DLWP_ACT_* applied in the epilogue after the bias                      */
+  int in_c_off, in_c_total;       /* read channels [off, off+xs.c) of a buffer that has in_c_total channels (slice_layer) */
+  int out_c_off, out_c_total;     /* write channels [off, off+cout) of a buffer with out_c_total channels (concatenate)   */
+  int src_mode;                   /* DLWP_SRC_*: xs describes the STORED tensor; the conv sees it transformed */
+} dlwp_conv2d;
+
+/* ---- library ---------------------------------------------------------------------------------------------------- */
+int         dlwp_version(void);
+const char* dlwp_last_error(void);
+int         dlwp_create(dlwp_handle_t* h, int device);   /* one handle per device; thread-compatible */
+int         dlwp_destroy(dlwp_handle_t h);
+int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, char* arch, size_t arch_len);
+
+/* ---- halo padding: DLWP.custom.PeriodicPadding2D.call (custom.py:191-214), FillPadding2D.call (custom.py:359-402),
+ *      keras ZeroPadding2D.  Generic [outer, H, W, inner] view: NCHW -> outer=N*C, inner=1; NHWC -> outer=N, inner=C.
+ *      fwd: y[outer, H+t+b, W+l+r, inner];  bwd: dx = adjoint (halo folded back: wrap adds to the periodic image,
+ *      edge adds to the border, zero drops).                                                                          */
+int dlwp_pad2d_fwd(dlwp_handle_t, const void* x, void* y, int outer, int h, int w, int inner, dlwp_pad2d p,
+                   int dtype, void* stream);
+int dlwp_pad2d_bwd(dlwp_handle_t, const void* dy, void* dx, int outer, int h, int w, int inner, dlwp_pad2d p,
+                   int dtype, void* stream);
+
+/* ---- keras Conv2D(filters, k, dilation_rate, padding='valid', activation, data_format='channels_first')
+ *      (examples/train.py:164-169 ... 214-219) with the halo, UpSampling2D/MaxPooling2D-in-front, bias, activation,
+ *      slice_layer (custom.py:675-692) and concatenate fused.  Weights: Keras HWIO (kh,kw,cin,cout); bias (cout).
+ *      xs = stored input (n, cin, h, w).  Output (n, cout, ho, wo) with
+ *        hin = h (direct) | 2h (upsample2) | h/2 (maxpool2);  ho = hin + top + bottom - dil_h*(kh-1);  same for w.   */
+int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys);
+int dlwp_conv2d_fwd(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                    const dlwp_conv2d* cd, int dtype, void* stream);
+/* same contract, one thread per output element on the vector ALU: any kernel size; used as the in-library cross-check */
+int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                           const dlwp_conv2d* cd, int dtype, void* stream);
+
+/* tuning hooks (tools/tune_conv.py, tests): enumerate the compiled MFMA tile configurations, force one for the calling
+ * thread (-1 = heuristic), ask which one the heuristic picks (-1 = direct kernel).  info8 = {ks, dil, th, tw, waves,
+ * frags_per_wave, cout_frags, channel_chunk}.  Not part of the drop-in surface.                                      */
+int dlwp_conv2d_num_configs(void);
+int dlwp_conv2d_config_info(int i, int* info8, int* lds_bytes);
+int dlwp_conv2d_force_config(int i);
+int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
+
+/* ---- keras MaxPooling2D(2) / UpSampling2D(2) standalone (examples/train.py:171,181,191,201) ------------------------ */
+int dlwp_maxpool2_fwd (dlwp_handle_t, const void* x, void* y, dlwp_shape4 xs, int dtype, void* stream);
+int dlwp_maxpool2_bwd (dlwp_handle_t, const void* x, const void* dy, void* dx, dlwp_shape4 xs, int dtype, void* stream);
+int dlwp_upsample2_fwd(dlwp_handle_t, const void* x, void* y, dlwp_shape4 xs, int dtype, void* stream);
+int dlwp_upsample2_bwd(dlwp_handle_t, const void* dy, void* dx, dlwp_shape4 xs, int dtype, void* stream);
+
+/* ---- slice_layer (custom.py:675-692) / keras concatenate(axis=1): copy c channels between buffers of different
+ *      channel counts.  src (n, src_c_total, h, w) channels [src_off, src_off+c) -> dst channels [dst_off, dst_off+c). */
+int dlwp_copy_channels(dlwp_handle_t, const void* src, void* dst, int n, int c, int hw, int src_c_off, int src_c_total,
+                       int dst_c_off, int dst_c_total, int dtype, void* stream);
+
+/* ---- predict_timeseries bookkeeping (DLWP/model/models.py:294-300, 448-451): series (T, N, time_dim, V, H*W) ->
+ *      (T*time_dim, N, V, H*W).                                                                                        */
+int dlwp_series_merge_time(dlwp_handle_t, const void* series, void* out, int t, int n, int time_dim, int v, int hw,
+                           int dtype, void* stream);
+
+/* ---- rollout: the N-step predict_timeseries loop (DLWP/model/models.py:277-293, 439-447) captured as ONE hipGraph.
+ *      A plan is an array of dlwp_op describing one model call; buffer index >= 0 = caller scratch buffer,
+ *      DLWP_BUF_STATE_IN = the call's input state, DLWP_BUF_OUT(o) = output o of the call.  Call t reads
+ *      state0 (t == 0) or slot t*n_outputs-1 of `series` and writes slots [t*n_outputs, (t+1)*n_outputs).          */
+#define DLWP_BUF_STATE_IN (-1)
+#define DLWP_BUF_OUT(o)   (-2 - (o))
+#define DLWP_OP_CONV2D     0
+#define DLWP_OP_PAD2D      1
+#define DLWP_OP_MAXPOOL2   2
+#define DLWP_OP_UPSAMPLE2  3
+#define DLWP_OP_COPYCH     4
+typedef struct {
+  int kind;                 /* DLWP_OP_*                                                                  */
+  int src, dst;             /* buffer indices                                                              */
+  int w, b;                 /* weight / bias buffer indices (conv only)                                    */
+  dlwp_shape4 xs;           /* stored input shape of this op                                               */
+  dlwp_conv2d conv;         /* DLWP_OP_CONV2D; for DLWP_OP_COPYCH: in_c_off/in_c_total/out_c_off/out_c_total */
+  dlwp_pad2d pad;           /* DLWP_OP_PAD2D                                                               */
+} dlwp_op;
+typedef struct dlwp_rollout* dlwp_rollout_t;
+int dlwp_rollout_create(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
+                        const void* state0, void* series, size_t slot_elems, int calls, int n_outputs, int dtype,
+                        dlwp_rollout_t* out);
+int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
+int dlwp_rollout_destroy(dlwp_rollout_t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLWP_HIP_H */

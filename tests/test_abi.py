@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every symbol that
+include/dlwp_hip.h declares; argument validation that needs no device."""
+import ctypes
+
+import pytest
+
+from dlwp_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    names = _lib.declared_symbols()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(_lib.lib, n)]
+    assert not missing, missing
+
+
+def test_every_declared_symbol_is_bound_with_a_signature():
+    for n in _lib.declared_symbols():
+        fn = getattr(_lib.lib, n)
+        assert fn.argtypes is not None, '%s has no ctypes signature in dlwp_amd/_lib.py' % n
+
+
+def test_version_and_error_string():
+    assert _lib.lib.dlwp_version() >= 100
+    assert isinstance(_lib.lib.dlwp_last_error(), bytes)
+
+
+def test_struct_layouts_match_the_header():
+    # sizes implied by include/dlwp_hip.h (all-int structs, no padding)
+    assert ctypes.sizeof(_lib.Shape4) == 16
+    assert ctypes.sizeof(_lib.Pad2d) == 24
+    assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 6 * 4
+    assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24
+
+
+def test_conv_out_shape_and_validation_without_a_device():
+    from dlwp_amd import ops
+    cd = ops.make_conv(32, 3, 3, dil=2, halo=ops.make_pad(2, 2, 2, 2, ops.PAD_ZERO, ops.PAD_WRAP), act=ops.ACT_TANH)
+    ys = ops.conv_out_shape(_lib.Shape4(3, 4, 88, 180), cd)
+    assert (ys.n, ys.c, ys.h, ys.w) == (3, 32, 88, 180)
+    cd.src_mode = ops.SRC_MAXPOOL2
+    ys = ops.conv_out_shape(_lib.Shape4(3, 4, 88, 180), cd)
+    assert (ys.h, ys.w) == (44, 90)
+    cd.src_mode = ops.SRC_UPSAMPLE2
+    ys = ops.conv_out_shape(_lib.Shape4(3, 4, 22, 45), cd)
+    assert (ys.h, ys.w) == (44, 90)
+    # the reference's periodic slices do not tile: halo > axis is an error (custom.py:197-200)
+    bad = ops.make_conv(4, 3, 3, halo=ops.make_pad(0, 0, 7, 7, ops.PAD_ZERO, ops.PAD_WRAP))
+    with pytest.raises(_lib.DlwpError, match='periodic column halo'):
+        ops.conv_out_shape(_lib.Shape4(1, 1, 5, 6), bad)
+    with pytest.raises(_lib.DlwpError, match='larger than the padded input'):
+        ops.conv_out_shape(_lib.Shape4(1, 1, 3, 3), ops.make_conv(4, 5, 5))
+    with pytest.raises(_lib.DlwpError, match='output channel window'):
+        ops.conv_out_shape(_lib.Shape4(1, 1, 8, 8), ops.make_conv(4, 3, 3, out_c_off=2, out_c_total=4))
+
+
+def test_compiled_tile_configurations_cover_the_unet_layers():
+    from dlwp_amd import ops
+    cfgs = ops.conv_configs()
+    kinds = {(c[0], c[1]) for c in cfgs}
+    assert {(3, 1), (3, 2), (5, 1)} <= kinds
+    for c in cfgs:
+        ks, dil, th, tw, waves, fa, bnf, ck, lds = c
+        assert th * tw <= 16 * fa * waves and lds <= 160 * 1024 and ck % 4 == 0

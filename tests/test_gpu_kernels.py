@@ -1,0 +1,269 @@
+"""GPU parity tests proper: every libdlwp_hip.so kernel, called through the C ABI, against the oracle on the same
+seeded inputs and against the committed golden fixtures.  Bit-exact for padding / pooling / copies; fp32 convolution
+within 1e-5 of the float64 direct sum (relative to the output scale; the tolerance BASELINE.md states)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref
+
+pytestmark = pytest.mark.gpu
+
+CONV_RTOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from dlwp_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# padding
+# ----------------------------------------------------------------------------------------------------------------- #
+
+def _pad_struct(ops, padding, mode):
+    (t, b), (l, r) = padding
+    return ops.make_pad(t, b, l, r, mode, mode)
+
+
+def test_pad2d_golden_periodic_and_fill(ops, golden):
+    g = golden('padding')
+    x_cf, x_cl = g['x_cf'], g['x_cl']
+    for kind, mode in (('periodic', ops.PAD_WRAP), ('fill', ops.PAD_EDGE)):
+        for i in range(int(g['%s_n' % kind])):
+            padding = tuple(map(tuple, g['%s_%d_padding' % (kind, i)]))
+            (t, b), (l, r) = padding
+            if kind == 'periodic' and (max(t, b) > x_cf.shape[2] or max(l, r) > x_cf.shape[3]):
+                continue
+            p = _pad_struct(ops, padding, mode)
+            assert np.array_equal(host(ops.pad2d(dev(x_cf), p)), g['%s_%d_cf' % (kind, i)]), (kind, padding)
+            assert np.array_equal(host(ops.pad2d(dev(x_cl), p, channels_last=True)), g['%s_%d_cl' % (kind, i)])
+
+
+def test_pad2d_golden_composite_halo(ops, golden):
+    g = golden('padding')
+    for k in (1, 2):
+        p = ops.make_pad(k, k, k, k, ops.PAD_ZERO, ops.PAD_WRAP)
+        assert np.array_equal(host(ops.pad2d(dev(g['x_cf']), p)), g['composite_pz_%d' % k])
+
+
+def test_pad2d_rejects_periodic_pad_larger_than_axis(ops):
+    from dlwp_amd._lib import DlwpError
+    x = torch.zeros((1, 1, 3, 4), device='cuda')
+    with pytest.raises(DlwpError, match='periodic column padding'):
+        ops.pad2d(x, ops.make_pad(0, 0, 5, 5, ops.PAD_ZERO, ops.PAD_WRAP))
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 7, 9), (2, 4, 88, 180), (1, 3, 73, 144), (2, 2, 16, 20)])
+def test_pad2d_all_modes_fwd_bwd(ops, shape):
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape).astype(np.float32)
+    for mh in (0, 1, 2):
+        for mw in (0, 1, 2):
+            pads = (2, 1, 3, 2) if shape[-1] % 4 else (2, 2, 2, 2)
+            p = ops.make_pad(*pads, mh, mw)
+            want = np_ref.pad2d_modes(x, pads, mh, mw)
+            got = host(ops.pad2d(dev(x), p))
+            assert np.array_equal(got, want), (mh, mw)
+            dy = rng.standard_normal(want.shape).astype(np.float32)
+            dx = host(ops.pad2d_bwd(dev(dy), shape, p))
+            dx_ref = np_ref.pad2d_modes_grad(dy, shape, pads, mh, mw)
+            assert np.abs(dx - dx_ref).max() <= 1e-5 * max(1., np.abs(dx_ref).max())
+
+
+def test_pad2d_empty_and_single(ops):
+    p = ops.make_pad(1, 1, 1, 1, ops.PAD_ZERO, ops.PAD_WRAP)
+    y = ops.pad2d(torch.zeros((0, 3, 4, 5), device='cuda'), p)
+    assert tuple(y.shape) == (0, 3, 6, 7)
+    x = np.arange(1, dtype=np.float32).reshape(1, 1, 1, 1) + 5
+    assert np.array_equal(host(ops.pad2d(dev(x), p)), np_ref.pad2d_modes(x, (1, 1, 1, 1), 0, 1))
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# pooling / up-sampling / copies
+# ----------------------------------------------------------------------------------------------------------------- #
+
+@pytest.mark.parametrize('shape', [(2, 3, 8, 10), (1, 2, 7, 9), (2, 32, 88, 180), (1, 5, 45, 22)])
+def test_maxpool2_and_upsample2(ops, shape):
+    rng = np.random.default_rng(shape[-1])
+    x = rng.standard_normal(shape).astype(np.float32)
+    y = host(ops.maxpool2(dev(x)))
+    assert np.array_equal(y, np_ref.maxpool2(x))
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    assert np.array_equal(host(ops.maxpool2_bwd(dev(x), dev(dy))), np_ref.maxpool2_grad(x, dy).astype(np.float32))
+    u = host(ops.upsample2(dev(x)))
+    assert np.array_equal(u, np_ref.upsample2(x))
+    du = rng.standard_normal(u.shape).astype(np.float32)
+    got = host(ops.upsample2_bwd(dev(du)))
+    assert np.abs(got - np_ref.upsample2_grad(du)).max() < 1e-5
+
+
+def test_maxpool2_bwd_ties_route_to_first_maximum(ops):
+    x = np.zeros((1, 1, 4, 4), np.float32)
+    dy = np.arange(1, 5, dtype=np.float32).reshape(1, 1, 2, 2)
+    got = host(ops.maxpool2_bwd(dev(x), dev(dy)))
+    assert np.array_equal(got, np_ref.maxpool2_grad(x, dy).astype(np.float32))
+    assert got[0, 0, 0, 0] == 1 and got[0, 0, 0, 1] == 0
+
+
+def test_copy_channels_slice_and_concat(ops):
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((3, 32, 6, 10)).astype(np.float32)
+    b = rng.standard_normal((3, 16, 6, 10)).astype(np.float32)
+    # slice_layer(16, 32) of a, concatenated behind b  (train_functional.py:203-206, 259)
+    out = torch.full((3, 32, 6, 10), float('nan'), device='cuda')
+    ops.copy_channels(dev(b), out, 16, 0, 0)
+    ops.copy_channels(dev(a), out, 16, 16, 16)
+    assert np.array_equal(host(out), np.concatenate([b, a[:, 16:32]], axis=1))
+    # odd sizes take the scalar path
+    a2 = rng.standard_normal((2, 5, 3, 3)).astype(np.float32)
+    out2 = torch.zeros((2, 7, 3, 3), device='cuda')
+    ops.copy_channels(dev(a2), out2, 3, 1, 4)
+    want = np.zeros((2, 7, 3, 3), np.float32)
+    want[:, 4:7] = a2[:, 1:4]
+    assert np.array_equal(host(out2), want)
+
+
+@pytest.mark.parametrize('t,n,td,v,h,w', [(3, 4, 2, 2, 5, 6), (2, 3, 3, 1, 4, 4), (4, 1, 1, 4, 8, 12), (5, 2, 2, 3, 3, 5)])
+def test_series_merge_time_matches_reference_reshape(ops, t, n, td, v, h, w):
+    rng = np.random.default_rng(t * 100 + n)
+    s = rng.standard_normal((t, n, td * v, h, w)).astype(np.float32)
+    want = np_ref._merge_time(s, t, n, td, (td * v, h, w), False)
+    got = host(ops.series_merge_time(dev(s), td))
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# convolution
+# ----------------------------------------------------------------------------------------------------------------- #
+
+def _conv_ref(x, w, b, dil, pads, mh, mw, act, src_mode):
+    xs = np.asarray(x, np.float64)
+    if src_mode == 1:
+        xs = np_ref.upsample2(xs)
+    elif src_mode == 2:
+        xs = np_ref.maxpool2(xs)
+    xp = np_ref.pad2d_modes(xs, pads, mh, mw)
+    return np_ref.conv2d(xp, w, b, dil, act)
+
+
+def _check_conv(ops, got, want, what=''):
+    scale = max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert got.shape == want.shape, (got.shape, want.shape, what)
+    assert err <= CONV_RTOL * scale, (what, err, scale)
+
+
+CASES = [
+    # (n, cin, h, w, cout, k, dil, pads(t,b,l,r), mode_h, mode_w, act, src_mode)
+    (2, 4, 16, 36, 32, 3, 2, (2, 2, 2, 2), 0, 1, 'tanh', 0),          # U-Net L1
+    (2, 8, 16, 36, 24, 3, 1, (1, 1, 1, 1), 0, 1, 'tanh', 2),          # pooled input
+    (2, 16, 6, 10, 40, 3, 1, (1, 1, 1, 1), 0, 1, 'tanh', 1),          # up-sampled input
+    (1, 32, 16, 36, 4, 5, 1, (2, 2, 2, 2), 0, 1, 'linear', 0),        # output layer, cout=4
+    (1, 2, 13, 17, 32, 5, 1, (2, 2, 2, 2), 0, 1, 'tanh', 0),          # config-1 first layer, odd sizes, cin=2
+    (2, 5, 9, 11, 7, 3, 2, (2, 1, 3, 2), 2, 1, 'relu', 0),            # asymmetric, edge rows, odd channels
+    (1, 6, 12, 12, 16, 3, 1, (1, 1, 1, 1), 1, 1, 'linear', 0),        # periodic in both axes
+    (1, 4, 10, 14, 8, 3, 1, (0, 0, 0, 0), 0, 0, 'linear', 0),         # plain valid conv, output smaller than input
+    (1, 12, 10, 20, 32, 3, 2, (2, 2, 2, 2), 2, 2, 'tanh', 0),         # fill both axes, cin=12
+    (3, 4, 8, 36, 32, 3, 2, (2, 2, 2, 2), 0, 1, 'tanh', 0),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv2d_fused_vs_float64_oracle(ops, case):
+    n, cin, h, w, cout, k, dil, pads, mh, mw, act, src = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    want = _conv_ref(x, wt, b, dil, pads, mh, mw, act, src)
+    cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, mh, mw), ops.ACTIVATIONS[act], src_mode=src)
+    got = host(ops.conv2d(dev(x), dev(wt), dev(b), cd))
+    _check_conv(ops, got, want, 'mfma')
+    got_d = host(ops.conv2d(dev(x), dev(wt), dev(b), cd, direct=True))
+    _check_conv(ops, got_d, want, 'direct')
+
+
+def test_conv2d_every_compiled_tile_configuration(ops):
+    """Force each MFMA tile configuration in turn on a shape with ragged tile edges and ragged channel counts."""
+    rng = np.random.default_rng(99)
+    cfgs = ops.conv_configs()
+    problems = {}
+    try:
+        for i, (ks, dil, th, tw, waves, fa, bnf, ck, lds) in enumerate(cfgs):
+            key = (ks, dil)
+            if key not in problems:
+                n, cin, h, w, cout = 2, 20, 19, 50, 36
+                x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+                wt = np_ref.glorot_uniform((ks, ks, cin, cout), rng)
+                b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+                p = dil * (ks - 1) // 2
+                pads = (p, p, p, p)
+                want = _conv_ref(x, wt, b, dil, pads, 0, 1, 'tanh', 0)
+                problems[key] = (dev(x), dev(wt), dev(b), pads, want, cout)
+            xd, wd, bd, pads, want, cout = problems[key]
+            ops.force_conv_config(i)
+            cd = ops.make_conv(cout, ks, ks, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH)
+            got = host(ops.conv2d(xd, wd, bd, cd))
+            _check_conv(ops, got, want, 'config %d %r' % (i, cfgs[i]))
+    finally:
+        ops.force_conv_config(-1)
+
+
+def test_conv2d_channel_windows_slice_and_concat(ops):
+    """slice_layer on the input side and concatenate on the output side without copies (custom.py:675-692)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 32, 8, 12)).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, 16, 24), rng)
+    b = (0.1 * rng.standard_normal(24)).astype(np.float32)
+    want = _conv_ref(x[:, 16:32], wt, b, 1, (1, 1, 1, 1), 0, 1, 'tanh', 0)
+    cd = ops.make_conv(24, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, in_c_off=16, in_c_total=32,
+                       out_c_off=8, out_c_total=40)
+    out = torch.full((2, 40, 8, 12), 7.0, device='cuda')
+    ops.conv2d(dev(x), dev(wt), dev(b), cd, out=out, x_channels=16)
+    got = host(out)
+    _check_conv(ops, got[:, 8:32], want)
+    assert np.all(got[:, :8] == 7.0) and np.all(got[:, 32:] == 7.0)
+
+
+def test_conv2d_linearity_and_longitude_shift_equivariance_full_size(ops):
+    """Size-independent properties at BASELINE.json's full 88x180 grid (config 2, layer 5 shape)."""
+    rng = np.random.default_rng(2)
+    n, cin, h, w, cout = 2, 64, 88, 180, 32
+    x1 = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    x2 = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+    cd = ops.make_conv(cout, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_LINEAR)
+    y1 = host(ops.conv2d(dev(x1), wt, None, cd))
+    y2 = host(ops.conv2d(dev(x2), wt, None, cd))
+    y12 = host(ops.conv2d(dev(x1 + 2 * x2), wt, None, cd))
+    assert np.abs(y12 - (y1 + 2 * y2)).max() < 2e-4
+    ys = host(ops.conv2d(dev(np.roll(x1, 7, axis=-1)), wt, None, cd))
+    assert np.array_equal(ys, np.roll(y1, 7, axis=-1))     # periodic halo: exact shift equivariance, bit for bit
+    # spot-check against the float64 oracle on one sample / a few channels (full tensor would take minutes on CPU)
+    want = _conv_ref(x1[:1], host(wt)[..., :4], None, 2, (2, 2, 2, 2), 0, 1, 'linear', 0)
+    _check_conv(ops, y1[:1, :4], want)
+
+
+def test_conv2d_batch_invariance(ops):
+    """A sample's result must not depend on what else is in the batch (member sharding across GPUs relies on it)."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((5, 16, 22, 45)).astype(np.float32)
+    wt = dev(np_ref.glorot_uniform((3, 3, 16, 48), rng))
+    cd = ops.make_conv(48, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
+    full = host(ops.conv2d(dev(x), wt, None, cd))
+    for i in (0, 3):
+        one = host(ops.conv2d(dev(x[i:i + 1]), wt, None, cd))
+        assert np.array_equal(one[0], full[i])
