@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""
+bench.py -- BASELINE.json's metric: 6-h forecast steps/s on the 2-degree 4-channel state, predict_timeseries rollout.
+
+Workload (BASELINE.json configs[1]): the sequential PeriodicPadding2D U-Net of
+Azure/train_tf.py:208-268 (4 -> 32 -> 64 -> 128 -> 64 -> 32 -> 4, 188 996 parameters, glorot_uniform seed 1234, zero biases)
+on the closed 88 x 180 grid (nominal 91 x 180 does not close under two 2x poolings), float32, built through
+DLWPNeuralNet.build_model from the reference's own (name, args, kwargs) triples; a 14-day rollout = 28 forwards x
+time_dim 2 = 56 six-hour steps per member.  One "step" of this benchmark = ONE such rollout of all members on this GPU =
+one hipGraph launch (168 fused conv kernels).  Members are sharded across ranks, no collective (weak scaling).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints one JSON line on rank 0.  `value` = members x 56 x K x N / wall  [6-h forecast steps / s], state resident in HBM.
+`roofline`: the dominant kernel of the forward (largest share of time), timed live with HIP events on the launch stream;
+`cpu_baseline`: the unfused torch-CPU restatement of the reference graph + its host rollout loop (oracle/torch_ref.py),
+timed on this node's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(grid, cin, seed=1234):
+    from dlwp_amd.model import DLWPNeuralNet
+    from tests.nets import unet_layers
+    np.random.seed(seed)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(unet_layers((cin,) + grid), loss='mse', optimizer='adam', metrics=['mae'], gpus=1)
+    return d
+
+
+def time_layers(model, members, iters=5):
+    """Per-launch duration of every kernel of one forward, HIP events on the stream the kernels are launched on."""
+    from dlwp_amd import ops
+    ex = model.executor
+    plan = model.plan
+    x = torch.randn((members,) + plan._in_store, device=model.device)
+    outs = ex.run(x)                                    # fills every scratch buffer with realistic data
+    bufs = ex.scratch(members)
+    rows = []
+    for op, d in zip(plan.ops, ex._descriptors()):
+        if op.kind != 'conv':
+            continue
+        src = x if op.src == -1 else (bufs[op.src] if op.src >= 0 else outs[-2 - op.src])
+        dst = bufs[op.dst] if op.dst >= 0 else outs[-2 - op.dst]
+        lay = op.layer
+        for _ in range(2):
+            ops.conv2d(src, lay.kernel, lay.bias, d, out=dst, x_channels=op.xs[0])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.conv2d(src, lay.kernel, lay.bias, d, out=dst, x_channels=op.xs[0])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        kh, kw = lay.kernel_size
+        co, ho, wo = op.out_shape
+        flops = 2.0 * ho * wo * co * op.xs[0] * kh * kw * members
+        nbytes = 4.0 * members * (op.xs[0] * op.xs[1] * op.xs[2] + co * ho * wo) + 4.0 * kh * kw * op.xs[0] * co
+        rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': lay.dilation_rate[0],
+                     'out': [ho, wo], 'ms': ms, 'tflops': flops / ms / 1e9, 'gbs': nbytes / ms / 1e6,
+                     'flops': flops, 'bytes': nbytes})
+    return rows
+
+
+def cpu_baseline(grid, cin, forwards, weights, budget_s=12.0):
+    """The reference's CPU path as restated in oracle/torch_ref.py: unfused pad-copy / zero-pad-copy / conv / bias /
+    tanh / pool / upsample in torch-CPU float32 + the host rollout loop with a full state copy per step."""
+    from oracle import torch_ref
+    from tests.nets import unet_layers
+    layers = unet_layers((cin,) + grid)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tw = torch_ref.to_torch_weights(weights)
+    rng = np.random.default_rng(0)
+    members = 8
+    x = rng.standard_normal((members, cin) + grid).astype(np.float32)
+    t0 = time.time()
+    torch_ref.rollout_host_loop(layers, tw, x, 1)       # warm-up + cost probe
+    t1 = time.time()
+    torch_ref.rollout_host_loop(layers, tw, x, 1)
+    per_fwd = max(time.time() - t1, 1e-3)
+    n_fwd = int(max(1, min(forwards, budget_s / per_fwd)))
+    t2 = time.time()
+    torch_ref.rollout_host_loop(layers, tw, x, n_fwd)
+    dt = time.time() - t2
+    steps = members * n_fwd * 2
+    name = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    name = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'value': steps / dt, 'unit': '6-h forecast steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d members x %d forwards (of %d) of the same U-Net rollout, torch-CPU fp32 unfused restatement '
+                      '(oracle/torch_ref.py), %.1f s' % (members, n_fwd, forwards, dt),
+            'cpu': name, 'first_call_s': t1 - t0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--members', type=int, default=256, help='ensemble members / initial conditions PER GPU')
+    ap.add_argument('--forwards', type=int, default=28, help='model applications per rollout (28 = 14 days)')
+    ap.add_argument('--grid', default='88x180')
+    ap.add_argument('--channels', type=int, default=4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+    grid = tuple(int(v) for v in a.grid.split('x'))
+
+    from dlwp_amd import parallel
+    rank, world, local = parallel.init()
+    if world != a.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' %
+                         (a.gpus, world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X; there is no CPU fallback for the product path')
+    dev = torch.device('cuda', local)
+
+    d = build_model(grid, a.channels)
+    net = d.model
+    flops_fwd = net.plan.conv_flops_per_sample()
+    bytes_fwd = net.plan.algorithmic_bytes_per_sample()
+    weights_np = [(w, b) for w, b in zip(net.get_weights()[0::2], net.get_weights()[1::2])]
+
+    # members: one base state + 0.01 * N(0,1) perturbations, different per rank
+    g = torch.Generator(device='cpu').manual_seed(1000 + rank)
+    base = torch.randn((1, a.channels) + grid, generator=torch.Generator().manual_seed(0))
+    state0 = (base + 0.01 * torch.randn((a.members, a.channels) + grid, generator=g)).to(dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def rollout():
+        return net.rollout_on_device(state0, a.forwards)
+
+    series = rollout()                           # set-up: captures the hipGraph (never inside the timed region)
+    for _ in range(a.warmup):
+        series = rollout()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        series = rollout()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = bool(torch.isfinite(series[-1]).all().item())
+
+    six_hour_steps = a.members * world * a.forwards * 2 * a.steps
+    value = six_hour_steps / dt
+    fwd_per_s = a.members * world * a.forwards * a.steps / dt
+    out = {
+        'metric': '6-h forecast steps/sec on 91x180x4-chan state (closed grid 88x180), predict_timeseries rollout',
+        'value': value, 'unit': '6-h forecast steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'cfg2: 2-deg %dx%d x%d-chan sequential PeriodicPadding2D U-Net (188996 params), fp32, '
+                               '%d-forward (14-day) predict_timeseries rollout as one hipGraph, %d members per GPU'
+                               % (grid[0], grid[1], a.channels, a.forwards, a.members),
+                   'members_per_gpu': a.members, 'forwards_per_rollout': a.forwards, 'time_dim': 2,
+                   'grid': list(grid), 'channels': a.channels, 'launches_per_forward': net.plan.n_launches,
+                   'parallelism': 'members sharded over %d GPU(s), no collective' % world},
+        'forwards_per_s': fwd_per_s,
+        'conv_mflop_per_forward_per_member': flops_fwd / 1e6,
+        'forward': {'achieved_tflops': fwd_per_s * flops_fwd / 1e12 / world,
+                    'mfma_util_frac': fwd_per_s * flops_fwd / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+                    'algorithmic_gbs': fwd_per_s * bytes_fwd / 1e9 / world, 'per_gpu': True},
+        'finite': finite,
+    }
+    if rank == 0:
+        rows = time_layers(net, a.members)
+        tot = sum(r['ms'] for r in rows)
+        dom = max(rows, key=lambda r: r['ms'])
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'conv2d_fwd_mfma_f32 (%s: %d->%d, %dx%d dil %d, %dx%d)' %
+                           (dom['layer'], dom['cin'], dom['cout'], dom['k'], dom['k'], dom['dil'], dom['out'][0], dom['out'][1]),
+                           'achieved': dom['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': dom['tflops'] / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                           'launch_ms': dom['ms'], 'algorithmic_flops_per_launch': dom['flops'],
+                           'share_of_forward_time': dom['ms'] / tot}
+        out['layers'] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k not in ('flops', 'bytes')}
+                         for r in rows]
+        out['forward']['sum_of_kernel_ms'] = tot
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(grid, a.channels, a.forwards, weights_np)
+        print(json.dumps(out))
+    barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -6,6 +6,11 @@ import ctypes
 import os
 import re
 
+# torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  It MUST be in the
+# process before libdlwp_hip.so is loaded so that our DT_NEEDED libamdhip64.so.7 binds to that same instance: two HIP
+# runtimes in one process cannot both open the device ("no ROCm-capable device is detected").
+import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlwp_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dlwp_hip.h')
@@ -88,6 +93,19 @@ _sig('dlwp_conv2d_num_configs', [])
 _sig('dlwp_conv2d_config_info', [_i, _P(_i), _P(_i)])
 _sig('dlwp_conv2d_force_config', [_i])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
+_sig('dlwp_conv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _i, _P(_sz)])
+_sig('dlwp_conv2d_bwd_data', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])
+_sig('dlwp_conv2d_bwd_weight', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _i, _vp, _sz, _vp])
+_sig('dlwp_conv2d_wgrad_num_configs', [])
+_sig('dlwp_conv2d_wgrad_config_info', [_i, _P(_i), _P(_i)])
+_sig('dlwp_conv2d_wgrad_force_config', [_i])
+_sig('dlwp_act_bwd', [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp])
+_sig('dlwp_bias_grad', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])
+_sig('dlwp_mse_mae_workspace', [_vp], _sz)
+_sig('dlwp_mse_mae', [_vp, _vp, _vp, _sz, _vp, _vp, ctypes.c_float, _vp, _sz, _i, _vp])
+_sig('dlwp_adam_keras', [_vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 5 + [ctypes.c_longlong, ctypes.c_float, _vp])
+_sig('dlwp_sgd_keras', [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 3 + [ctypes.c_longlong, ctypes.c_float, _vp])
+_sig('dlwp_axpby', [_vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, _vp])
 _sig('dlwp_maxpool2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_maxpool2_bwd', [_vp, _vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_upsample2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])

@@ -1,0 +1,241 @@
+// conv_bwd.hip -- Conv2D backward: data gradient (re-using the forward implicit-GEMM kernel on flipped / transposed
+// weights) and weight gradient (conv_wgrad_kernel.h).  These are the backward halves of the Keras train step that
+// DLWPNeuralNet.fit / fit_generator drive (DLWP/model/models.py:188-228; layers of examples/train.py:159-219).
+#include "conv_wgrad_kernel.h"
+#include <mutex>
+#include <vector>
+
+int dlwp_launch_flip_transpose(dlwp_handle_t h, const float* w, float* wt, int kh, int kw, int cin, int cout,
+                               hipStream_t s);
+int dlwp_launch_reduce_slabs(dlwp_handle_t h, const float* slabs, float* out, long long n, int S, int accumulate,
+                             hipStream_t s);
+
+namespace {
+
+//                              KS DIL TH TW  NT WAVES
+const WgradKernelEntry k_wgrad[] = {
+    WGRAD_ENTRY(3, 1, 8, 32, 2, 4), WGRAD_ENTRY(3, 1, 8, 32, 4, 4), WGRAD_ENTRY(3, 1, 8, 32, 1, 4),
+    WGRAD_ENTRY(3, 1, 4, 48, 2, 4), WGRAD_ENTRY(3, 1, 4, 48, 4, 4), WGRAD_ENTRY(3, 1, 8, 36, 2, 4),
+    WGRAD_ENTRY(3, 1, 8, 36, 4, 4),
+    WGRAD_ENTRY(3, 2, 8, 32, 2, 4), WGRAD_ENTRY(3, 2, 8, 32, 4, 4), WGRAD_ENTRY(3, 2, 8, 32, 1, 4),
+    WGRAD_ENTRY(3, 2, 8, 36, 2, 4), WGRAD_ENTRY(3, 2, 8, 36, 4, 4), WGRAD_ENTRY(3, 2, 4, 48, 2, 4),
+    WGRAD_ENTRY(5, 1, 8, 32, 1, 4), WGRAD_ENTRY(5, 1, 8, 32, 2, 4), WGRAD_ENTRY(5, 1, 8, 36, 1, 4),
+    WGRAD_ENTRY(5, 1, 8, 36, 2, 4), WGRAD_ENTRY(5, 1, 4, 48, 1, 4),
+};
+constexpr int N_WGRAD = (int)(sizeof(k_wgrad) / sizeof(k_wgrad[0]));
+char g_wg_prepared[N_WGRAD] = {0};
+std::mutex g_wg_mutex;
+thread_local int g_forced_wgrad = -1;
+
+struct WgChoice {
+  int idx, splits, nslabs, tiles_h, tiles_w, ci_groups, co_tiles;
+};
+
+bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const dlwp_conv2d* cd, WgChoice* out) {
+  int best = -1;
+  double best_cost = 0;
+  for (int i = 0; i < N_WGRAD; ++i) {
+    const WgradKernelEntry& e = k_wgrad[i];
+    if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
+    if (g_forced_wgrad >= 0 && i != g_forced_wgrad) continue;
+    const double tiles = (double)dlwp_ceil_div(Ho, e.th) * dlwp_ceil_div(Wo, e.tw);
+    const double co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
+    const double ci_groups = dlwp_ceil_div(Cin, 16);
+    // padded MFMA count + staging traffic (x tile re-read per co tile, dz tile per ci group), per image
+    const int lr = e.th + e.dil * (e.ks - 1), lc = e.tw + e.dil * (e.ks - 1);
+    const double mfma = tiles * (e.th * e.tw / 4.0) * e.ks * e.ks * e.nt * co_tiles * ci_groups;
+    const double stage = tiles * co_tiles * ci_groups * (16.0 * lr * lc + 16.0 * e.nt * e.th * e.tw) / 64.0 * 0.5;
+    const double c = mfma + stage;
+    if (best < 0 || c < best_cost) {
+      best = i;
+      best_cost = c;
+    }
+  }
+  if (best < 0) return false;
+  const WgradKernelEntry& e = k_wgrad[best];
+  out->idx = best;
+  out->tiles_h = dlwp_ceil_div(Ho, e.th);
+  out->tiles_w = dlwp_ceil_div(Wo, e.tw);
+  out->ci_groups = dlwp_ceil_div(Cin, 16);
+  out->co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
+  const long long total_tiles = (long long)N * out->tiles_h * out->tiles_w;
+  long long splits = ((long long)h->cu_count * 4) / ((long long)out->ci_groups * out->co_tiles);
+  if (splits < 1) splits = 1;
+  if (splits > total_tiles) splits = total_tiles;
+  // bound slab memory to 128 MiB
+  const long long slab_bytes = (long long)e.ks * e.ks * Cin * Cout * 4;
+  while (splits > 1 && splits * e.waves * slab_bytes > (128ll << 20)) splits /= 2;
+  out->splits = (int)splits;
+  out->nslabs = (int)splits * e.waves;
+  return true;
+}
+
+bool same_halo_fast_path(const dlwp_conv2d* cd) {
+  const dlwp_pad2d& p = cd->halo;
+  const int th = cd->dil_h * (cd->kh - 1), tw = cd->dil_w * (cd->kw - 1);
+  if ((th & 1) || (tw & 1)) return false;
+  if (p.top != th / 2 || p.bottom != th / 2 || p.left != tw / 2 || p.right != tw / 2) return false;
+  const bool mh_ok = p.mode_h != DLWP_PAD_EDGE || th == 0;
+  const bool mw_ok = p.mode_w != DLWP_PAD_EDGE || tw == 0;
+  return mh_ok && mw_ok;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+// pass: 0 = bwd_data, 1 = bwd_weight
+int dlwp_conv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int pass, size_t* bytes) {
+  DLWP_CHECK_ARG(h && cd && bytes, "dlwp_conv2d_bwd_workspace: null pointer");
+  dlwp_shape4 ys;
+  if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return DLWP_EINVAL;
+  const size_t wbytes = (size_t)cd->kh * cd->kw * xs.c * cd->cout * sizeof(float);
+  if (pass == 0) {
+    size_t b = align256(wbytes);
+    if (!same_halo_fast_path(cd)) {
+      const int hp = dlwp_src_dim(xs.h, cd->src_mode) + cd->halo.top + cd->halo.bottom;
+      const int wp = dlwp_src_dim(xs.w, cd->src_mode) + cd->halo.left + cd->halo.right;
+      b += align256((size_t)xs.n * xs.c * hp * wp * sizeof(float));
+    }
+    *bytes = b;
+    return DLWP_OK;
+  }
+  DLWP_CHECK_ARG(pass == 1, "dlwp_conv2d_bwd_workspace: pass must be 0 or 1");
+  WgChoice c;
+  if (!pick_wgrad(h, xs.n, xs.c, cd->cout, ys.h, ys.w, cd, &c))
+    DLWP_FAIL(DLWP_EUNSUPPORTED, "conv2d_bwd_weight: no kernel for %dx%d dilation %dx%d", cd->kh, cd->kw, cd->dil_h,
+              cd->dil_w);
+  *bytes = align256((size_t)c.nslabs * wbytes);
+  return DLWP_OK;
+}
+
+// dx = dL/d(input as the conv sees it BEFORE the halo and AFTER the src transform): (n, cin, hin, win).
+// dz: (n, out_c_total, ho, wo), channels [out_c_off, +cout).  For src_mode == DIRECT dx may be a channel window
+// [in_c_off, +cin) of a buffer with in_c_total channels (the stored tensor's gradient); otherwise it is dense and the
+// caller applies dlwp_upsample2_bwd / dlwp_maxpool2_bwd.
+int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
+                         const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  DLWP_CHECK_ARG(h && dz && w && dx && cd && ws, "dlwp_conv2d_bwd_data: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_conv2d_bwd_data: dtype %d not supported", dtype);
+  size_t need = 0;
+  int rc = dlwp_conv2d_bwd_workspace(h, xs, cd, 0, &need);
+  if (rc != DLWP_OK) return rc;
+  DLWP_CHECK_ARG(ws_bytes >= need, "dlwp_conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
+  dlwp_shape4 ys;
+  dlwp_conv2d_out_shape(xs, cd, &ys);
+  if (xs.n == 0) return DLWP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float* wt = (float*)ws;
+  rc = dlwp_launch_flip_transpose(h, (const float*)w, wt, cd->kh, cd->kw, xs.c, cd->cout, s);
+  if (rc != DLWP_OK) return rc;
+  const int hin = dlwp_src_dim(xs.h, cd->src_mode), win = dlwp_src_dim(xs.w, cd->src_mode);
+  const bool window = cd->src_mode == DLWP_SRC_DIRECT && cd->in_c_total > 0;
+  dlwp_conv2d g;
+  memset(&g, 0, sizeof(g));
+  g.cout = xs.c;
+  g.kh = cd->kh;
+  g.kw = cd->kw;
+  g.dil_h = cd->dil_h;
+  g.dil_w = cd->dil_w;
+  g.act = DLWP_ACT_LINEAR;
+  g.in_c_off = cd->out_c_off;
+  g.in_c_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
+  g.src_mode = DLWP_SRC_DIRECT;
+  dlwp_shape4 zs = {xs.n, cd->cout, ys.h, ys.w};
+  if (same_halo_fast_path(cd)) {
+    // symmetric 'same' halo with wrap / zero modes: the adjoint is the same fused conv on the flipped kernel
+    g.halo = cd->halo;
+    g.out_c_off = window ? cd->in_c_off : 0;
+    g.out_c_total = window ? cd->in_c_total : xs.c;
+    return dlwp_launch_conv2d(h, dz, wt, nullptr, dx, zs, &g, dtype, s);
+  }
+  // general halo: full correlation into the padded gradient, then fold the halo back
+  DLWP_CHECK_ARG(!window || (cd->in_c_off == 0 && cd->in_c_total == xs.c),
+                 "dlwp_conv2d_bwd_data: channel-window output needs the symmetric wrap/zero halo fast path");
+  const int fh = cd->dil_h * (cd->kh - 1), fw = cd->dil_w * (cd->kw - 1);
+  g.halo = dlwp_pad2d{fh, fh, fw, fw, DLWP_PAD_ZERO, DLWP_PAD_ZERO};
+  g.out_c_off = 0;
+  g.out_c_total = xs.c;
+  float* padded = (float*)((char*)ws + align256((size_t)cd->kh * cd->kw * xs.c * cd->cout * sizeof(float)));
+  rc = dlwp_launch_conv2d(h, dz, wt, nullptr, padded, zs, &g, dtype, s);
+  if (rc != DLWP_OK) return rc;
+  return dlwp_pad2d_bwd(h, padded, dx, xs.n * xs.c, hin, win, 1, cd->halo, dtype, stream);
+}
+
+// dw: (kh, kw, cin, cout) Keras HWIO.  accumulate != 0 adds to dw instead of overwriting (shared layers).
+int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
+                           const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  DLWP_CHECK_ARG(h && x && dz && dw && cd && ws, "dlwp_conv2d_bwd_weight: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_conv2d_bwd_weight: dtype %d not supported", dtype);
+  dlwp_shape4 ys;
+  if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return DLWP_EINVAL;
+  WgChoice c;
+  if (!pick_wgrad(h, xs.n, xs.c, cd->cout, ys.h, ys.w, cd, &c))
+    DLWP_FAIL(DLWP_EUNSUPPORTED, "conv2d_bwd_weight: no kernel for %dx%d dilation %dx%d", cd->kh, cd->kw, cd->dil_h,
+              cd->dil_w);
+  const long long wn = (long long)cd->kh * cd->kw * xs.c * cd->cout;
+  DLWP_CHECK_ARG(ws_bytes >= (size_t)c.nslabs * wn * sizeof(float), "dlwp_conv2d_bwd_weight: workspace %zu < %zu", ws_bytes,
+                 (size_t)c.nslabs * wn * sizeof(float));
+  DLWP_CHECK_ARG(xs.n > 0, "dlwp_conv2d_bwd_weight: empty batch");
+  const WgradKernelEntry& e = k_wgrad[c.idx];
+  if (!g_wg_prepared[c.idx]) {
+    std::lock_guard<std::mutex> lock(g_wg_mutex);
+    if (!g_wg_prepared[c.idx]) {
+      const int pe = e.prepare();
+      if (pe != 0) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_bwd_weight: hipFuncSetAttribute failed (%d)", pe);
+      g_wg_prepared[c.idx] = 1;
+    }
+  }
+  WgradArgs a;
+  a.x = (const float*)x;
+  a.dz = (const float*)dz;
+  a.slabs = (float*)ws;
+  a.N = xs.n;
+  a.Cin = xs.c;
+  a.Hs = xs.h;
+  a.Ws = xs.w;
+  a.H = dlwp_src_dim(xs.h, cd->src_mode);
+  a.W = dlwp_src_dim(xs.w, cd->src_mode);
+  a.Ho = ys.h;
+  a.Wo = ys.w;
+  a.Cout = cd->cout;
+  a.in_c_off = cd->in_c_off;
+  a.in_c_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
+  a.dz_c_off = cd->out_c_off;
+  a.dz_c_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
+  a.pad_top = cd->halo.top;
+  a.pad_left = cd->halo.left;
+  a.mode_h = cd->halo.mode_h;
+  a.mode_w = cd->halo.mode_w;
+  a.src_mode = cd->src_mode;
+  a.tiles_h = c.tiles_h;
+  a.tiles_w = c.tiles_w;
+  a.total_tiles = xs.n * c.tiles_h * c.tiles_w;
+  a.splits = c.splits;
+  a.ci_groups = c.ci_groups;
+  a.co_tiles = c.co_tiles;
+  const int grid = c.ci_groups * c.co_tiles * c.splits;
+  e.launch(a, grid, (hipStream_t)stream);
+  DLWP_LAUNCH_CHECK("conv2d_wgrad_mfma_f32");
+  return dlwp_launch_reduce_slabs(h, (const float*)ws, (float*)dw, wn, c.nslabs, accumulate, (hipStream_t)stream);
+}
+
+int dlwp_conv2d_wgrad_num_configs(void) { return N_WGRAD; }
+
+int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes) {
+  DLWP_CHECK_ARG(i >= 0 && i < N_WGRAD && info6, "dlwp_conv2d_wgrad_config_info: index out of range");
+  const WgradKernelEntry& e = k_wgrad[i];
+  const int v[6] = {e.ks, e.dil, e.th, e.tw, e.nt, e.waves};
+  for (int k = 0; k < 6; ++k) info6[k] = v[k];
+  if (lds_bytes) *lds_bytes = e.lds_bytes;
+  return DLWP_OK;
+}
+
+int dlwp_conv2d_wgrad_force_config(int i) {
+  g_forced_wgrad = i;
+  return DLWP_OK;
+}
+
+}  // extern "C"

@@ -23,7 +23,9 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
     case DLWP_OP_CONV2D:
       return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, dtype, s);
     case DLWP_OP_PAD2D:
-      return dlwp_pad2d_fwd(h, src, dst, op.xs.n * op.xs.c, op.xs.h, op.xs.w, 1, op.pad, dtype, (void*)s);
+      // NCHW: outer = n*c rows-of-W planes; NHWC: xs = (n, 1, h, w) and conv.in_c_total carries the inner (channel) run
+      return dlwp_pad2d_fwd(h, src, dst, op.xs.n * op.xs.c, op.xs.h, op.xs.w,
+                            op.conv.in_c_total > 1 ? op.conv.in_c_total : 1, op.pad, dtype, (void*)s);
     case DLWP_OP_MAXPOOL2:
       return dlwp_maxpool2_fwd(h, src, dst, op.xs, dtype, (void*)s);
     case DLWP_OP_UPSAMPLE2:

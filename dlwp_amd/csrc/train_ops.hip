@@ -1,0 +1,248 @@
+// train_ops.hip -- the small kernels of the training step (gfx950): activation backward, per-channel bias gradient,
+// 'mse' loss + 'mae' metric + loss gradient, Keras-form Adam, partial-slab reduction, flat-buffer helpers.
+//
+// Reference: the Keras train step behind DLWPNeuralNet.fit / fit_generator (DLWP/model/models.py:188-228) compiled with
+// loss='mse' | mean_squared_error, optimizer='adam', metrics=['mae'] (examples/train.py:240, train_functional.py:285);
+// Adam in the Keras 2.2 form the reference's own tracker restates (DLWP/custom.py:34-40).
+// All reductions are two-stage with a fixed summation tree: results are bit-reproducible run to run, and a
+// data-parallel step can be compared with the single-GPU step on the concatenated batch.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// block-wide sum of (a, b); result valid in thread 0.  256 threads.
+__device__ __forceinline__ void block_sum2(float& a, float& b) {
+  __shared__ float sa[4], sb[4];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sa[wave] = a; sb[wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    b = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+  }
+  __syncthreads();
+}
+
+// dz = dy * act'(y)   (tanh: 1 - y^2; relu: y > 0; linear: copy)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dz, long long n, int act) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float g = dy[i];
+    float r = g;
+    if (act == DLWP_ACT_TANH) { const float t = y[i]; r = g * (1.f - t * t); }
+    else if (act == DLWP_ACT_RELU) r = y[i] > 0.f ? g : 0.f;
+    dz[i] = r;
+  }
+}
+
+// db[c] = sum over (n, hw) of dz[n, c_off + c, hw]: one block per channel, fixed tree
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ db, int N, int C,
+                                                        int c_off, int c_total, int hw) {
+  const int c = blockIdx.x;
+  float s = 0.f, dummy = 0.f;
+  const long long per = (long long)N * hw;
+  for (long long i = threadIdx.x; i < per; i += 256) {
+    const long long n = i / hw, p = i - n * hw;
+    s += dz[(n * c_total + c_off + c) * hw + p];
+  }
+  block_sum2(s, dummy);
+  if (threadIdx.x == 0) db[c] = s;
+}
+
+// stage 1 of the loss: per-block partial sums of (d^2, |d|) and the gradient dy = scale * d
+__global__ __launch_bounds__(256) void mse_mae_partial_kernel(const float* __restrict__ yp, const float* __restrict__ yt,
+                                                              float* __restrict__ dy, float* __restrict__ partial,
+                                                              long long n, float grad_scale) {
+  float s2 = 0.f, s1 = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float d = yp[i] - yt[i];
+    s2 += d * d;
+    s1 += fabsf(d);
+    if (dy) dy[i] = grad_scale * d;
+  }
+  block_sum2(s2, s1);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = s2;
+    partial[2 * blockIdx.x + 1] = s1;
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_mae_final_kernel(const float* __restrict__ partial, int nblocks, float inv_n,
+                                                            float* __restrict__ out2) {
+  float s2 = 0.f, s1 = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    s2 += partial[2 * i];
+    s1 += partial[2 * i + 1];
+  }
+  block_sum2(s2, s1);
+  if (threadIdx.x == 0) {
+    out2[0] = s2 * inv_n;
+    out2[1] = s1 * inv_n;
+  }
+}
+
+// Keras-form Adam on a flat buffer: p -= lr_t * m / (sqrt(v) + eps); g is scaled by grad_scale first (1/world for DP)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, long long n, float lr_t, float b1,
+                                                   float b2, float eps, float grad_scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// plain SGD with optional momentum (keras.optimizers.SGD): v = mom*v - lr*g ; p += v
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ vel,
+                                                  const float* __restrict__ g, long long n, float lr, float momentum,
+                                                  float grad_scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    const float vi = momentum * vel[i] - lr * gi;
+    vel[i] = vi;
+    p[i] += vi;
+  }
+}
+
+// out[i] = sum_s slabs[s][i]  (fixed order s = 0..S-1), optionally out += (accumulate)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                           long long n, int S, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < S; ++k) s += slabs[(long long)k * n + i];
+    out[i] = s;
+  }
+}
+
+// y = a*x + b*y
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long long n,
+                                                    float a, float b) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
+}
+
+// w'[u', v', co, ci] = w[kh-1-u', kw-1-v', ci, co]   (HWIO -> flipped HWOI, the dgrad operand)
+__global__ __launch_bounds__(256) void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int kh,
+                                                             int kw, int cin, int cout) {
+  const long long total = (long long)kh * kw * cin * cout;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cin);
+    long long q = i / cin;
+    const int co = (int)(q % cout);
+    q /= cout;
+    const int v = (int)(q % kw), u = (int)(q / kw);
+    wt[i] = w[(((long long)(kh - 1 - u) * kw + (kw - 1 - v)) * cin + ci) * cout + co];
+  }
+}
+
+inline int grid_for(long long items, int cu) {
+  long long want = (items + 255) / 256;
+  const long long cap = (long long)cu * 8;
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+}  // namespace
+
+int dlwp_launch_flip_transpose(dlwp_handle_t h, const float* w, float* wt, int kh, int kw, int cin, int cout,
+                               hipStream_t s) {
+  const long long total = (long long)kh * kw * cin * cout;
+  flip_transpose_kernel<<<grid_for(total, h->cu_count), 256, 0, s>>>(w, wt, kh, kw, cin, cout);
+  DLWP_LAUNCH_CHECK("flip_transpose_kernel");
+  return DLWP_OK;
+}
+
+int dlwp_launch_reduce_slabs(dlwp_handle_t h, const float* slabs, float* out, long long n, int S, int accumulate,
+                             hipStream_t s) {
+  reduce_slabs_kernel<<<grid_for(n, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);
+  DLWP_LAUNCH_CHECK("reduce_slabs_kernel");
+  return DLWP_OK;
+}
+
+extern "C" {
+
+int dlwp_act_bwd(dlwp_handle_t h, const void* y, const void* dy, void* dz, size_t n, int act, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && dy && dz && (y || act == DLWP_ACT_LINEAR), "dlwp_act_bwd: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32 && (unsigned)act <= 2u, "dlwp_act_bwd: bad dtype/activation");
+  if (n == 0) return DLWP_OK;
+  act_bwd_kernel<<<grid_for((long long)n, h->cu_count), 256, 0, (hipStream_t)stream>>>(
+      (const float*)y, (const float*)dy, (float*)dz, (long long)n, act);
+  DLWP_LAUNCH_CHECK("act_bwd_kernel");
+  return DLWP_OK;
+}
+
+int dlwp_bias_grad(dlwp_handle_t h, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, int dtype,
+                   void* stream) {
+  DLWP_CHECK_ARG(h && dz && db, "dlwp_bias_grad: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32 && n >= 0 && c > 0 && hw > 0 && c_off >= 0 && c_off + c <= c_total,
+                 "dlwp_bias_grad: bad arguments");
+  bias_grad_kernel<<<c, 256, 0, (hipStream_t)stream>>>((const float*)dz, (float*)db, n, c, c_off, c_total, hw);
+  DLWP_LAUNCH_CHECK("bias_grad_kernel");
+  return DLWP_OK;
+}
+
+size_t dlwp_mse_mae_workspace(dlwp_handle_t h) { return h ? (size_t)h->cu_count * 8 * 2 * sizeof(float) : 0; }
+
+int dlwp_mse_mae(dlwp_handle_t h, const void* y_pred, const void* y_true, size_t n, void* out2, void* dy,
+                 float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && y_pred && y_true && out2 && ws, "dlwp_mse_mae: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32 && n > 0, "dlwp_mse_mae: bad dtype / empty input");
+  const int grid = grid_for((long long)n, h->cu_count);
+  DLWP_CHECK_ARG(ws_bytes >= (size_t)grid * 2 * sizeof(float), "dlwp_mse_mae: workspace too small (%zu < %zu)", ws_bytes,
+                 (size_t)grid * 2 * sizeof(float));
+  const float inv_n = 1.0f / (float)n;
+  mse_mae_partial_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float*)y_pred, (const float*)y_true, (float*)dy,
+                                                               (float*)ws, (long long)n, 2.0f * loss_weight * inv_n);
+  mse_mae_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>((const float*)ws, grid, inv_n, (float*)out2);
+  DLWP_LAUNCH_CHECK("mse_mae kernels");
+  return DLWP_OK;
+}
+
+int dlwp_adam_keras(dlwp_handle_t h, void* p, void* m, void* v, const void* g, size_t n, float lr, float beta_1,
+                    float beta_2, float epsilon, float decay, long long iteration, float grad_scale, void* stream) {
+  DLWP_CHECK_ARG(h && p && m && v && g, "dlwp_adam_keras: null handle or pointer");
+  if (n == 0) return DLWP_OK;
+  // t = it+1; lr' = lr/(1+decay*it); lr_t = lr' * sqrt(1-b2^t)/(1-b1^t)    (DLWP/custom.py:38-40), in double on the host
+  const double t = (double)iteration + 1.0;
+  const double lr_ = (double)lr / (1.0 + (double)decay * (double)iteration);
+  const double lr_t = lr_ * sqrt(1.0 - pow((double)beta_2, t)) / (1.0 - pow((double)beta_1, t));
+  adam_kernel<<<grid_for((long long)n, h->cu_count), 256, 0, (hipStream_t)stream>>>(
+      (float*)p, (float*)m, (float*)v, (const float*)g, (long long)n, (float)lr_t, beta_1, beta_2, epsilon, grad_scale);
+  DLWP_LAUNCH_CHECK("adam_kernel");
+  return DLWP_OK;
+}
+
+int dlwp_sgd_keras(dlwp_handle_t h, void* p, void* vel, const void* g, size_t n, float lr, float momentum, float decay,
+                   long long iteration, float grad_scale, void* stream) {
+  DLWP_CHECK_ARG(h && p && vel && g, "dlwp_sgd_keras: null handle or pointer");
+  if (n == 0) return DLWP_OK;
+  const float lr_ = (float)((double)lr / (1.0 + (double)decay * (double)iteration));
+  sgd_kernel<<<grid_for((long long)n, h->cu_count), 256, 0, (hipStream_t)stream>>>(
+      (float*)p, (float*)vel, (const float*)g, (long long)n, lr_, momentum, grad_scale);
+  DLWP_LAUNCH_CHECK("sgd_kernel");
+  return DLWP_OK;
+}
+
+int dlwp_axpby(dlwp_handle_t h, const void* x, void* y, size_t n, float a, float b, void* stream) {
+  DLWP_CHECK_ARG(h && x && y, "dlwp_axpby: null handle or pointer");
+  if (n == 0) return DLWP_OK;
+  axpby_kernel<<<grid_for((long long)n, h->cu_count), 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)y,
+                                                                                    (long long)n, a, b);
+  DLWP_LAUNCH_CHECK("axpby_kernel");
+  return DLWP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""
+The DLWP.custom names on the hot path, as descriptions for the HIP back end.
+
+  PeriodicPadding2D   reference DLWP/custom.py:139-214   -> halo mode WRAP (fused into the next Conv2D's LDS loader,
+                                                            or the standalone LDS-staged pad kernel)
+  FillPadding2D       reference DLWP/custom.py:309-402   -> halo mode EDGE (pole-row replication)
+  slice_layer         reference DLWP/custom.py:675-692   -> a channel window, resolved as an input-channel offset
+  EarlyStoppingMin    reference DLWP/custom.py:99-136
+  RNNResetStates      reference DLWP/custom.py:94-96
+  History             keras.callbacks.History (what examples/train.py:253 passes)
+"""
+import numpy as np
+
+from . import layers as _layers
+from .layers import Layer  # noqa: F401  (re-export: custom layers subclass it)
+
+
+class PeriodicPadding2D(_layers._Pad2DBase):
+    """Periodic padding of rows and columns; corners are wrap-of-wrap (the reference pads W first, then H of the
+    already W-padded tensor).  Like the reference's slices it does not tile: padding > axis length is an error
+    (raised when the model is planned, where the shapes are known)."""
+    mode = 1
+
+    def compute_output_shape(self, s):
+        out = super(PeriodicPadding2D, self).compute_output_shape(s)
+        (t, b), (l, r) = self.padding
+        h, w = (s[1], s[2]) if self.data_format == 'channels_first' else (s[0], s[1])
+        if max(t, b) > h or max(l, r) > w:
+            raise ValueError('%s: periodic padding %r exceeds the input size %dx%d' % (self.name, self.padding, h, w))
+        return out
+
+
+class FillPadding2D(_layers._Pad2DBase):
+    """Edge-replicating padding (rows first, then columns of the row-padded tensor == np.pad(mode='edge'))."""
+    mode = 2
+
+
+def slice_layer(start, end, step=None, axis=1):
+    """Return a layer that slices `axis` -- the reference returns a keras Lambda; here it is a channel window that the
+    consuming convolution reads in place (no copy)."""
+    if axis < 0:
+        raise ValueError("'slice_layer' can only work on a specified axis > 0")
+    return _layers.ChannelSlice(start, end, step=step, axis=axis)
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# callbacks (host-side plumbing of examples/train.py:253-263)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+class Callback(object):
+    def __init__(self):
+        self.model = None
+        self.params = {}
+
+    def set_model(self, model):
+        self.model = model
+
+    def set_params(self, params):
+        self.params = params
+
+    def on_train_begin(self, logs=None):
+        pass
+
+    def on_train_end(self, logs=None):
+        pass
+
+    def on_epoch_begin(self, epoch, logs=None):
+        pass
+
+    def on_epoch_end(self, epoch, logs=None):
+        pass
+
+    def on_batch_begin(self, batch, logs=None):
+        pass
+
+    def on_batch_end(self, batch, logs=None):
+        pass
+
+
+class History(Callback):
+    """Per-epoch record of the logs dict: history = {metric: [value per epoch]}, epoch = [indices]."""
+
+    def on_train_begin(self, logs=None):
+        self.epoch = []
+        self.history = {}
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.epoch.append(epoch)
+        for k, v in (logs or {}).items():
+            self.history.setdefault(k, []).append(v)
+
+
+class BatchHistory(Callback):
+    """Per-batch record, one dict per epoch (reference DLWP/custom.py:54-68)."""
+
+    def on_train_begin(self, logs=None):
+        self.history = []
+        self.epoch = 0
+
+    def on_epoch_begin(self, epoch, logs=None):
+        self.history.append({})
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.epoch += 1
+
+    def on_batch_end(self, batch, logs=None):
+        for k, v in (logs or {}).items():
+            self.history[self.epoch].setdefault(k, []).append(v)
+
+
+class RNNResetStates(Callback):
+    def on_epoch_begin(self, epoch, logs=None):
+        self.model.reset_states()
+
+
+class EarlyStopping(Callback):
+    """keras.callbacks.EarlyStopping semantics (monitor / min_delta / patience / mode / restore_best_weights)."""
+
+    def __init__(self, monitor='val_loss', min_delta=0, patience=0, verbose=0, mode='auto', baseline=None,
+                 restore_best_weights=False):
+        super(EarlyStopping, self).__init__()
+        self.monitor, self.patience, self.verbose = monitor, patience, verbose
+        self.baseline, self.restore_best_weights = baseline, restore_best_weights
+        self.min_delta = abs(min_delta)
+        if mode not in ('auto', 'min', 'max'):
+            mode = 'auto'
+        if mode == 'max' or (mode == 'auto' and 'acc' in monitor):
+            self.monitor_op = np.greater
+        else:
+            self.monitor_op = np.less
+            self.min_delta *= -1
+        if self.monitor_op is np.greater:
+            self.min_delta = abs(self.min_delta)
+        self.wait = 0
+        self.stopped_epoch = 0
+        self.best = None
+        self.best_weights = None
+
+    def on_train_begin(self, logs=None):
+        self.wait = 0
+        self.stopped_epoch = 0
+        self.best = self.baseline if self.baseline is not None else (np.inf if self.monitor_op is np.less else -np.inf)
+
+    def get_monitor_value(self, logs):
+        value = (logs or {}).get(self.monitor)
+        if value is None:
+            import warnings
+            warnings.warn('Early stopping conditioned on metric `%s` which is not available. Available metrics are: %s'
+                          % (self.monitor, ','.join(sorted((logs or {}).keys()))), RuntimeWarning)
+        return value
+
+    def _improved(self, current):
+        return self.monitor_op(current - self.min_delta, self.best)
+
+    def on_epoch_end(self, epoch, logs=None):
+        current = self.get_monitor_value(logs)
+        if current is None:
+            return
+        if self._improved(current):
+            self.best, self.wait = current, 0
+            if self.restore_best_weights:
+                self.best_weights = self.model.get_weights()
+            return
+        self.wait += 1
+        if self.wait >= self.patience:
+            self.stopped_epoch = epoch
+            self.model.stop_training = True
+            if self.restore_best_weights and self.best_weights is not None:
+                if self.verbose > 0:
+                    print('Restoring model weights from the end of the best epoch')
+                self.model.set_weights(self.best_weights)
+
+    def on_train_end(self, logs=None):
+        if self.stopped_epoch > 0 and self.verbose > 0:
+            print('Epoch %05d: early stopping' % (self.stopped_epoch + 1))
+
+
+class EarlyStoppingMin(EarlyStopping):
+    """EarlyStopping that does not even start counting before `min_epochs` epochs have run."""
+
+    def __init__(self, min_epochs=0, **kwargs):
+        super(EarlyStoppingMin, self).__init__(**kwargs)
+        if not isinstance(min_epochs, int) or min_epochs < 0:
+            raise ValueError('min_epochs must be an integer >= 0')
+        self.min_epochs = min_epochs
+
+    def on_epoch_end(self, epoch, logs=None):
+        if epoch >= self.min_epochs:
+            super(EarlyStoppingMin, self).on_epoch_end(epoch, logs)

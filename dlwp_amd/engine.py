@@ -1,0 +1,393 @@
+"""
+Minimal Keras-shaped model containers (Sequential, functional Model) over the HIP back end: exactly the protocol the
+reference's wrappers use: compile / fit / fit_generator / predict / evaluate / get_weights /
+set_weights / reset_states / summary / layers / outputs / stop_training / save.
+
+Forward execution = dlwp_amd.plan.Plan run by the Executor below: eager launches for predict, one captured hipGraph for
+the autoregressive rollout.  torch is plumbing only (device buffers, streams, H2D/D2H copies).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import layers as L
+from . import plan as P
+
+
+def default_device():
+    if torch.cuda.is_available():
+        idx = int(os.environ.get('LOCAL_RANK', torch.cuda.current_device()))
+        return torch.device('cuda', idx)
+    return torch.device('cpu')     # weights can be held for planning / inspection; every compute call will raise
+
+
+class Executor(object):
+    """Runs a Plan on one device for a given batch size.  Buffers are cached per batch size."""
+
+    def __init__(self, plan, device):
+        self.plan, self.device = plan, device
+        self._bufs = {}
+        self._descs = None
+
+    # -- buffers ----------------------------------------------------------------------------------------------------- #
+    def scratch(self, n):
+        b = self._bufs.get(n)
+        if b is None:
+            if len(self._bufs) > 4:
+                self._bufs.clear()
+            b = [torch.empty((n,) + s, dtype=torch.float32, device=self.device) for s in self.plan.buffers]
+            self._bufs[n] = b
+        return b
+
+    def alloc_outputs(self, n):
+        return [torch.empty((n,) + s, dtype=torch.float32, device=self.device) for s in self.plan.output_store]
+
+    def _descriptors(self):
+        from . import ops
+        if self._descs is None:
+            descs = []
+            for op in self.plan.ops:
+                if op.kind == 'conv':
+                    lay = op.layer
+                    kh, kw = lay.kernel_size
+                    descs.append(ops.make_conv(lay.filters, kh, kw, lay.dilation_rate, ops.make_pad(*op.halo), op.act,
+                                               op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode))
+                elif op.kind == 'pad':
+                    descs.append(ops.make_pad(*op.halo))
+                else:
+                    descs.append(None)
+            self._descs = descs
+        return self._descs
+
+    # -- eager forward ----------------------------------------------------------------------------------------------- #
+    def run(self, x, outs=None):
+        """x: device tensor (n, ...) matching the model input; returns the list of output tensors (stored layout)."""
+        from . import ops
+        n = x.shape[0]
+        x = x.reshape((n,) + self.plan._in_store)
+        bufs = self.scratch(n)
+        outs = outs if outs is not None else self.alloc_outputs(n)
+
+        def res(i):
+            if i >= 0:
+                return bufs[i]
+            if i == P.STATE_IN:
+                return x
+            return outs[-2 - i]
+        for op, d in zip(self.plan.ops, self._descriptors()):
+            src, dst = res(op.src), res(op.dst)
+            if op.kind == 'conv':
+                ops.conv2d(src, op.layer.kernel, op.layer.bias, d, out=dst, x_channels=op.xs[0])
+            elif op.kind == 'pad':
+                if op.inner > 1:
+                    hh, ww = op.xs[1], op.xs[2]
+                    ops.pad2d(src.reshape(n, hh, ww, op.inner), d, channels_last=True, out=dst)
+                else:
+                    ops.pad2d(src, d, out=dst)
+            elif op.kind == 'maxpool':
+                ops.maxpool2(src, out=dst)
+            elif op.kind == 'upsample':
+                ops.upsample2(src, out=dst)
+            elif op.kind == 'copy':
+                ops.copy_channels(src, dst, op.xs[0], op.in_c_off, op.out_c_off)
+            else:
+                raise RuntimeError(op.kind)
+        return outs
+
+    # -- hipGraph rollout -------------------------------------------------------------------------------------------- #
+    def make_rollout(self, state0, series, calls):
+        """Capture `calls` model applications.  state0: (n,)+input store; series: (calls*n_out, n)+store, contiguous."""
+        from . import _lib, ops
+        n = state0.shape[0]
+        n_out = len(self.plan.output_store)
+        for s in self.plan.output_store:
+            if tuple(s) != tuple(self.plan._in_store):
+                raise ValueError('rollout needs every model output to have the input state shape %r, got %r' %
+                                 (self.plan._in_store, s))
+        bufs = self.scratch(n)
+        table = [b for b in bufs]
+        widx = {}
+        for lay in self.plan.conv_layers:
+            widx[id(lay)] = (len(table), len(table) + 1 if lay.bias is not None else -1)
+            table.append(lay.kernel)
+            if lay.bias is not None:
+                table.append(lay.bias)
+        kind = {'conv': _lib.OP_CONV2D, 'pad': _lib.OP_PAD2D, 'maxpool': _lib.OP_MAXPOOL2,
+                'upsample': _lib.OP_UPSAMPLE2, 'copy': _lib.OP_COPYCH}
+        arr = (_lib.Op * len(self.plan.ops))()
+        for k, (op, d) in enumerate(zip(self.plan.ops, self._descriptors())):
+            o = arr[k]
+            o.kind, o.src, o.dst, o.w, o.b = kind[op.kind], op.src, op.dst, -1, -1
+            o.xs = _lib.Shape4(n, *op.xs)
+            if op.kind == 'conv':
+                o.w, o.b = widx[id(op.layer)]
+                o.conv = d
+            elif op.kind == 'pad':
+                o.pad = d
+                if op.inner > 1:
+                    o.xs = _lib.Shape4(n, 1, op.xs[1], op.xs[2])
+                    o.conv.in_c_total = op.inner
+            elif op.kind == 'copy':
+                o.conv.in_c_off, o.conv.in_c_total = op.in_c_off, op.in_c_total
+                o.conv.out_c_off, o.conv.out_c_total = op.out_c_off, op.out_c_total
+        ptrs = (ctypes.c_void_p * max(1, len(table)))(*[t.data_ptr() for t in table])
+        slot = int(np.prod(self.plan._in_store)) * n
+        out = ctypes.c_void_p()
+        dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(_lib.lib.dlwp_rollout_create(_lib.handle(dev), arr, len(self.plan.ops), ptrs, len(table),
+                                                ctypes.c_void_p(state0.data_ptr()), ctypes.c_void_p(series.data_ptr()),
+                                                slot, int(calls), n_out, _lib.F32, ctypes.byref(out)))
+        return RolloutGraph(out, keep=(table, state0, series, arr, ptrs), device=self.device)
+
+
+class RolloutGraph(object):
+    """Owner of a captured rollout (dlwp_rollout_t).  launch() replays all forwards with one hipGraphLaunch."""
+
+    def __init__(self, handle, keep, device):
+        self._h, self._keep, self.device = handle, keep, device
+
+    def launch(self):
+        from . import _lib
+        _lib.check(_lib.lib.dlwp_rollout_launch(self._h, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def close(self):
+        if self._h is not None:
+            from . import _lib
+            _lib.lib.dlwp_rollout_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Model(object):
+    """Functional model: Model(inputs=Input(...), outputs=tensor | [tensors])."""
+
+    def __init__(self, inputs=None, outputs=None, name=None, device=None, seed=None):
+        self.name = name or 'model'
+        self.device = device if device is not None else default_device()
+        self.stop_training = False
+        self.optimizer = None
+        self.loss = None
+        self.metrics = []
+        self.metrics_names = ['loss']
+        self.loss_weights = None
+        self.history = None
+        self._seed = seed
+        self._trainer = None
+        if inputs is not None:
+            self._init_graph(inputs, outputs)
+
+    # -- graph ------------------------------------------------------------------------------------------------------- #
+    def _init_graph(self, inputs, outputs, rng=None):
+        self.inputs = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+        self.outputs = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
+        order = P.toposort(self.outputs)
+        self.layers = []
+        for t in order:
+            if t.layer not in self.layers:
+                self.layers.append(t.layer)
+        if rng is None:
+            rng = np.random.RandomState(self._seed if self._seed is not None else np.random.randint(0, 2 ** 31 - 1))
+        for t in order:
+            if isinstance(t.layer, L.InputLayer):
+                continue
+            t.layer.build(t.inputs[0].shape, self.device, rng)
+        self.plan = P.build_plan(self.inputs, self.outputs)
+        self.executor = Executor(self.plan, self.device)
+        self.input_shape = (None,) + tuple(self.inputs[0].shape)
+        shapes = [(None,) + tuple(o.shape) for o in self.outputs]
+        self.output_shape = shapes[0] if len(shapes) == 1 else shapes
+
+    # -- weights ----------------------------------------------------------------------------------------------------- #
+    @property
+    def weights(self):
+        return [w for lay in self.layers for w in lay.weights]
+
+    def get_weights(self):
+        return [a for lay in self.layers for a in lay.get_weights()]
+
+    def set_weights(self, arrays):
+        arrays = list(arrays)
+        k = 0
+        for lay in self.layers:
+            m = len(lay._weights)
+            if m:
+                lay.set_weights(arrays[k:k + m])
+                k += m
+        if k != len(arrays):
+            raise ValueError('model has %d weight arrays, got %d' % (k, len(arrays)))
+
+    def count_params(self):
+        return int(sum(lay.count_params() for lay in self.layers))
+
+    def summary(self, print_fn=None):
+        pr = print_fn or print
+        pr('_' * 72)
+        pr('%-34s %-26s %10s' % ('Layer (type)', 'Output Shape', 'Param #'))
+        pr('=' * 72)
+        for lay in self.layers:
+            pr('%-34s %-26s %10d' % ('%s (%s)' % (lay.name, type(lay).__name__), str(lay.output_shape),
+                                     lay.count_params()))
+        pr('=' * 72)
+        pr('Total params: %d' % self.count_params())
+        pr('fused launches per forward: %d (%d conv)' % (self.plan.n_launches,
+                                                         sum(1 for o in self.plan.ops if o.kind == 'conv')))
+        pr('_' * 72)
+
+    def reset_states(self):
+        pass    # no stateful recurrent layers on this path
+
+    # -- inference --------------------------------------------------------------------------------------------------- #
+    def _logical_outputs(self, outs, n):
+        res = [o.reshape((n,) + tuple(s)) for o, s in zip(outs, self.plan.output_shapes)]
+        return res
+
+    def predict_on_device(self, x):
+        """x: float32 device tensor (n,)+input_shape  ->  device tensor (or list for multi-output models)."""
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        outs = self._logical_outputs(self.executor.run(x), x.shape[0])
+        return outs[0] if len(outs) == 1 else outs
+
+    def predict(self, x, batch_size=None, verbose=0, steps=None, **kwargs):
+        """numpy in, numpy out (Keras contract).  batch_size only bounds the device working set: results do not depend
+        on it (tests/test_gpu_model.py checks bit-identity)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if tuple(x.shape[1:]) != tuple(self.inputs[0].shape):
+            raise ValueError('expected input of shape %r, got %r' % ((None,) + tuple(self.inputs[0].shape), x.shape))
+        n = x.shape[0]
+        chunk = int(batch_size) if batch_size else 2048
+        chunk = max(1, min(max(chunk, 256), n)) if n else 1
+        results = None
+        for lo in range(0, n, chunk):
+            xd = torch.from_numpy(x[lo:lo + chunk]).to(self.device, non_blocking=False)
+            outs = self.predict_on_device(xd)
+            outs = outs if isinstance(outs, list) else [outs]
+            host = [o.cpu().numpy() for o in outs]
+            if results is None:
+                results = [np.empty((n,) + h.shape[1:], dtype=np.float32) for h in host]
+            for r, h in zip(results, host):
+                r[lo:lo + chunk] = h
+        if results is None:
+            results = [np.empty((0,) + tuple(s), dtype=np.float32) for s in self.plan.output_shapes]
+        return results[0] if len(results) == 1 else results
+
+    def rollout_on_device(self, state0, calls, series=None, graph_cache=True):
+        """Autoregressive rollout entirely in HBM: returns series (calls*n_outputs, n)+input_shape (device).
+        The captured hipGraph is cached per (n, calls) and replayed on later calls."""
+        n = state0.shape[0]
+        n_out = len(self.outputs)
+        key = (n, int(calls))
+        cache = self.__dict__.setdefault('_rollouts', {})
+        entry = cache.get(key) if graph_cache else None
+        if entry is None:
+            s0 = torch.empty((n,) + self.plan._in_store, dtype=torch.float32, device=self.device)
+            ser = torch.empty((calls * n_out, n) + self.plan._in_store, dtype=torch.float32, device=self.device)
+            g = self.executor.make_rollout(s0, ser, calls)
+            entry = (g, s0, ser)
+            if graph_cache:
+                if len(cache) > 2:
+                    cache.clear()
+                cache[key] = entry
+        g, s0, ser = entry
+        s0.copy_(state0.reshape(s0.shape))
+        g.launch()
+        out = ser.reshape((calls * n_out, n) + tuple(self.inputs[0].shape))
+        if series is not None:
+            series.copy_(out)
+            return series
+        return out
+
+    # -- training (dlwp_amd.training) ---------------------------------------------------------------------------------- #
+    def compile(self, optimizer='adam', loss=None, metrics=None, loss_weights=None, **kwargs):
+        from . import training
+        self.__dict__.pop('_rollouts', None)     # compile re-homes the weights into one flat buffer: drop captured graphs
+        self.optimizer = training.get_optimizer(optimizer)
+        self.loss = loss
+        self.loss_weights = loss_weights
+        self.metrics = list(metrics or [])
+        self._trainer = training.Trainer(self)
+        self.metrics_names = self._trainer.metrics_names
+
+    def _need_trainer(self):
+        if self._trainer is None:
+            raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
+        return self._trainer
+
+    def train_on_batch(self, x, y):
+        return self._need_trainer().train_on_batch(x, y)
+
+    def test_on_batch(self, x, y):
+        return self._need_trainer().test_on_batch(x, y)
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
+            shuffle=True, initial_epoch=0, **kwargs):
+        return self._need_trainer().fit(x, y, batch_size=batch_size, epochs=epochs, verbose=verbose,
+                                        callbacks=callbacks, validation_data=validation_data, shuffle=shuffle,
+                                        initial_epoch=initial_epoch)
+
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=1, callbacks=None,
+                      validation_data=None, validation_steps=None, use_multiprocessing=False, workers=1,
+                      max_queue_size=10, shuffle=True, initial_epoch=0, **kwargs):
+        return self._need_trainer().fit_generator(generator, steps_per_epoch=steps_per_epoch, epochs=epochs,
+                                                  verbose=verbose, callbacks=callbacks,
+                                                  validation_data=validation_data, validation_steps=validation_steps,
+                                                  shuffle=shuffle, initial_epoch=initial_epoch)
+
+    def evaluate(self, x=None, y=None, batch_size=None, verbose=1, **kwargs):
+        return self._need_trainer().evaluate(x, y, batch_size=batch_size, verbose=verbose)
+
+    # -- persistence ---------------------------------------------------------------------------------------------------- #
+    def save(self, path):
+        from . import serialization
+        serialization.save_model_file(self, path)
+
+
+class Sequential(Model):
+    """keras.models.Sequential: the first layer carries input_shape= (examples/train.py:159-162).  The graph, the
+    weights of the new layer and the fused plan are (re)built at every add(), so shape errors surface where Keras
+    raises them."""
+
+    def __init__(self, layers=None, name=None, device=None, seed=None):
+        super(Sequential, self).__init__(name=name or 'sequential', device=device, seed=seed)
+        self._stack = []
+        self._input_layer = None
+        self.layers = []
+        self._rng = np.random.RandomState(seed if seed is not None else np.random.randint(0, 2 ** 31 - 1))
+        for lay in (layers or []):
+            self.add(lay)
+
+    def add(self, layer):
+        if not isinstance(layer, L.Layer):
+            raise TypeError('The added layer must be an instance of class Layer. Found: %r' % (layer,))
+        if not self._stack and layer.batch_input_shape is None and not isinstance(layer, L.InputLayer):
+            raise ValueError('The first layer in a Sequential model must get an `input_shape` argument.')
+        self._stack.append(layer)
+        try:
+            self._rebuild()
+        except Exception:
+            self._stack.pop()
+            raise
+
+    def _rebuild(self):
+        first = self._stack[0]
+        if isinstance(first, L.InputLayer):
+            self._input_layer = first
+            rest = self._stack[1:]
+        else:
+            if self._input_layer is None:
+                self._input_layer = L.InputLayer(input_shape=first.batch_input_shape[1:])
+            rest = self._stack
+        t = x_in = L.KTensor(self._input_layer.batch_input_shape[1:], self._input_layer, ())
+        for lay in rest:
+            lay._calls = 0
+            t = lay(t)
+        self._init_graph(x_in, t, rng=self._rng)
+        self.layers = list(self._stack)

@@ -179,3 +179,95 @@ def conv_configs():
 
 def force_conv_config(i):
     _lib.lib.dlwp_conv2d_force_config(int(i))
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# training kernels
+# ------------------------------------------------------------------------------------------------------------------ #
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """A growable per-device scratch allocation (bytes) for the *_bwd / loss kernels."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def conv_bwd_workspace_bytes(dev_index, xs, cd, which):
+    out = ctypes.c_size_t()
+    _lib.check(_lib.lib.dlwp_conv2d_bwd_workspace(_lib.handle(dev_index), xs, ctypes.byref(cd), int(which),
+                                                  ctypes.byref(out)))
+    return out.value
+
+
+def conv2d_bwd_data(dz, w_hwio, cd, xs, dx):
+    """dz: (n, out_c_total, ho, wo); dx: preallocated gradient buffer (see include/dlwp_hip.h for its layout)."""
+    _check_f32(dz, w_hwio, dx)
+    d = _dev(dz)
+    need = conv_bwd_workspace_bytes(d, xs, cd, 0)
+    ws = workspace(dz.device, need)
+    _lib.check(_lib.lib.dlwp_conv2d_bwd_data(_lib.handle(d), _ptr(dz), _ptr(w_hwio), _ptr(dx), xs, ctypes.byref(cd),
+                                             _lib.F32, _ptr(ws), ws.numel(), _stream(dz)))
+    return dx
+
+
+def conv2d_bwd_weight(x, dz, dw, cd, xs, accumulate=False):
+    _check_f32(x, dz, dw)
+    d = _dev(x)
+    need = conv_bwd_workspace_bytes(d, xs, cd, 1)
+    ws = workspace(x.device, need)
+    _lib.check(_lib.lib.dlwp_conv2d_bwd_weight(_lib.handle(d), _ptr(x), _ptr(dz), _ptr(dw), xs, ctypes.byref(cd),
+                                               int(bool(accumulate)), _lib.F32, _ptr(ws), ws.numel(), _stream(x)))
+    return dw
+
+
+def act_bwd(y, dy, act, out=None):
+    _check_f32(y, dy)
+    dz = out if out is not None else torch.empty_like(dy)
+    _lib.check(_lib.lib.dlwp_act_bwd(_lib.handle(_dev(dy)), _ptr(y), _ptr(dy), _ptr(dz), dy.numel(), int(act), _lib.F32,
+                                     _stream(dy)))
+    return dz
+
+
+def bias_grad(dz, db, c, c_off=0):
+    _check_f32(dz, db)
+    n, c_total, h, w = dz.shape
+    _lib.check(_lib.lib.dlwp_bias_grad(_lib.handle(_dev(dz)), _ptr(dz), _ptr(db), n, int(c), int(c_off), c_total, h * w,
+                                       _lib.F32, _stream(dz)))
+    return db
+
+
+def mse_mae(y_pred, y_true, out2, dy=None, loss_weight=1.0):
+    """out2 (device, 2 floats) <- [mse, mae]; dy <- loss_weight * 2 (y_pred - y_true) / numel."""
+    _check_f32(y_pred, y_true, out2, dy)
+    d = _dev(y_pred)
+    h = _lib.handle(d)
+    need = _lib.lib.dlwp_mse_mae_workspace(h)
+    ws = workspace(y_pred.device, need)
+    _lib.check(_lib.lib.dlwp_mse_mae(h, _ptr(y_pred), _ptr(y_true), y_pred.numel(), _ptr(out2), _ptr(dy),
+                                     float(loss_weight), _ptr(ws), ws.numel(), _lib.F32, _stream(y_pred)))
+    return out2
+
+
+def adam_keras(p, m, v, g, iteration, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, decay=0.0, grad_scale=1.0):
+    _check_f32(p, m, v, g)
+    _lib.check(_lib.lib.dlwp_adam_keras(_lib.handle(_dev(p)), _ptr(p), _ptr(m), _ptr(v), _ptr(g), p.numel(), lr, beta_1,
+                                        beta_2, epsilon, decay, int(iteration), grad_scale, _stream(p)))
+
+
+def sgd_keras(p, vel, g, iteration, lr=0.01, momentum=0.0, decay=0.0, grad_scale=1.0):
+    _check_f32(p, vel, g)
+    _lib.check(_lib.lib.dlwp_sgd_keras(_lib.handle(_dev(p)), _ptr(p), _ptr(vel), _ptr(g), p.numel(), lr, momentum, decay,
+                                       int(iteration), grad_scale, _stream(p)))
+
+
+def axpby(x, y, a=1.0, b=1.0):
+    """y <- a*x + b*y"""
+    _check_f32(x, y)
+    _lib.check(_lib.lib.dlwp_axpby(_lib.handle(_dev(x)), _ptr(x), _ptr(y), x.numel(), float(a), float(b), _stream(x)))
+    return y

@@ -1,0 +1,378 @@
+"""
+Lowering of a layer graph to fused libdlwp_hip.so launches.
+
+The reference executes every layer as its own TF op and materialises 3 padded copies in front of each convolution
+(SURVEY.md 3.4).  Here padding, pooling, up-sampling and channel slicing are *lazy*: they only edit a `View` (which
+stored buffer, which channel window, which loader transform, which halo).  A Conv2D consumes the view in one fused kernel
+(dlwp_conv2d_fwd).  Only when a view reaches a consumer that cannot fuse it (a model output, a concatenate, a second
+pad on the same axis with another mode, ...) is it materialised with the standalone kernels.
+
+A plan is pure host data (no device access): it can be built and inspected on a machine without a GPU.
+"""
+import collections
+
+from . import layers as L
+
+PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
+SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
+ACT = {'linear': 0, None: 0, 'tanh': 1, 'relu': 2}
+STATE_IN = -1
+
+
+def OUT(o):
+    return -2 - o
+
+
+Halo = collections.namedtuple('Halo', 'top bottom left right mode_h mode_w')
+NO_HALO = Halo(0, 0, 0, 0, PAD_ZERO, PAD_ZERO)
+
+
+class View(object):
+    """Lazy value of a symbolic NCHW tensor: pad(src_transform(buffer[:, c_off:c_off+c]))."""
+    __slots__ = ('buf', 'c_off', 'c', 'c_total', 'h', 'w', 'src_mode', 'halo', 'shape')
+
+    def __init__(self, buf, c_off, c, c_total, h, w, src_mode=SRC_DIRECT, halo=NO_HALO, shape=None):
+        self.buf, self.c_off, self.c, self.c_total, self.h, self.w = buf, c_off, c, c_total, h, w
+        self.src_mode, self.halo = src_mode, halo
+        self.shape = shape      # logical per-sample shape when it is not (c, H, W) (after a Reshape)
+
+    def copy(self, **kw):
+        v = View(self.buf, self.c_off, self.c, self.c_total, self.h, self.w, self.src_mode, self.halo, self.shape)
+        for k, val in kw.items():
+            setattr(v, k, val)
+        return v
+
+    @property
+    def src_hw(self):
+        f = {SRC_DIRECT: lambda d: d, SRC_UPSAMPLE2: lambda d: 2 * d, SRC_MAXPOOL2: lambda d: d // 2}[self.src_mode]
+        return f(self.h), f(self.w)
+
+    @property
+    def logical(self):
+        h, w = self.src_hw
+        return (self.c, h + self.halo.top + self.halo.bottom, w + self.halo.left + self.halo.right)
+
+    @property
+    def plain(self):
+        return self.src_mode == SRC_DIRECT and self.halo == NO_HALO
+
+    @property
+    def full(self):
+        return self.plain and self.c_off == 0 and self.c == self.c_total
+
+
+class PlanOp(object):
+    """One launch.  kind in {'conv','pad','maxpool','upsample','copy'}."""
+
+    def __init__(self, kind, src, dst, xs, **kw):
+        self.kind, self.src, self.dst = kind, src, dst
+        self.xs = tuple(xs)                 # per-sample (c, h, w) of the stored input this op reads
+        self.layer = kw.pop('layer', None)  # Conv2D layer owning the weights
+        self.halo = kw.pop('halo', NO_HALO)
+        self.src_mode = kw.pop('src_mode', SRC_DIRECT)
+        self.act = kw.pop('act', 0)
+        self.in_c_off = kw.pop('in_c_off', 0)
+        self.in_c_total = kw.pop('in_c_total', 0)
+        self.out_c_off = kw.pop('out_c_off', 0)
+        self.out_c_total = kw.pop('out_c_total', 0)
+        self.inner = kw.pop('inner', 1)     # pad only: 1 = NCHW rows, C = NHWC
+        self.out_shape = kw.pop('out_shape', None)   # per-sample (c, h, w) this op produces (window it writes)
+        assert not kw, kw
+
+    def __repr__(self):
+        extra = ''
+        if self.kind == 'conv':
+            extra = ' %s k%s d%s src%d halo%s act%d cin[%d:+%d/%d] cout[%d:+%d/%d]' % (
+                self.layer.name, self.layer.kernel_size, self.layer.dilation_rate, self.src_mode, tuple(self.halo),
+                self.act, self.in_c_off, self.xs[0], self.in_c_total, self.out_c_off, self.layer.filters,
+                self.out_c_total)
+        return '<%s %s -> %s xs=%s%s>' % (self.kind, self.src, self.dst, self.xs, extra)
+
+
+class Plan(object):
+    def __init__(self):
+        self.ops = []
+        self.buffers = []        # per-sample (c_total, h, w) of each scratch buffer; index = buffer id
+        self.input_shape = None  # per-sample
+        self.output_shapes = []  # per-sample logical shapes of the model outputs
+        self.output_store = []   # per-sample stored (c, h, w) of each output slot
+        self.conv_layers = []    # unique Conv2D layers in first-use order
+
+    def new_buffer(self, c, h, w):
+        self.buffers.append((int(c), int(h), int(w)))
+        return len(self.buffers) - 1
+
+    def buffer_shape(self, buf):
+        if buf == STATE_IN:
+            return self._in_store
+        if buf <= -2:
+            return self.output_store[-2 - buf]
+        return self.buffers[buf]
+
+    @property
+    def n_launches(self):
+        return len(self.ops)
+
+    def conv_flops_per_sample(self):
+        """sum over conv ops of 2*Ho*Wo*Cout*Cin*kh*kw."""
+        tot = 0
+        for op in self.ops:
+            if op.kind == 'conv':
+                kh, kw = op.layer.kernel_size
+                co, ho, wo = op.out_shape
+                tot += 2 * ho * wo * co * op.xs[0] * kh * kw
+        return tot
+
+    def algorithmic_bytes_per_sample(self, itemsize=4):
+        """fused-forward algorithmic bytes: sum over launches of (input window + output window) + weights once."""
+        tot = 0
+        for op in self.ops:
+            c, h, w = op.xs
+            tot += c * h * w * itemsize
+            co, ho, wo = op.out_shape
+            tot += co * ho * wo * itemsize
+        for lay in self.conv_layers:
+            kh, kw = lay.kernel_size
+            tot += (kh * kw * lay.kernel.shape[2] * lay.filters + lay.filters) * itemsize if lay.kernel is not None else 0
+        return tot
+
+    def describe(self):
+        return '\n'.join(repr(op) for op in self.ops)
+
+
+def _compose_halo(first, layer_pad, mode):
+    """Halo after applying a padding layer (pads ((t,b),(l,r)), `mode`) on top of an existing lazy halo.
+    Returns None when the two do not compose into one per-axis mode (caller materialises first)."""
+    (t, b), (l, r) = layer_pad
+
+    def axis(lo0, hi0, m0, lo1, hi1):
+        if lo1 == 0 and hi1 == 0:
+            return lo0, hi0, m0
+        if lo0 == 0 and hi0 == 0:
+            return lo1, hi1, mode
+        if m0 == mode and mode in (PAD_ZERO, PAD_EDGE):
+            return lo0 + lo1, hi0 + hi1, mode       # zero-of-zero / edge-of-edge extend; wrap-of-wrap does not
+        return None
+    ah = axis(first.top, first.bottom, first.mode_h, t, b)
+    aw = axis(first.left, first.right, first.mode_w, l, r)
+    if ah is None or aw is None:
+        return None
+    return Halo(ah[0], ah[1], aw[0], aw[1], ah[2], aw[2])
+
+
+def toposort(outputs):
+    order, seen = [], set()
+
+    def visit(t):
+        if t.uid in seen:
+            return
+        seen.add(t.uid)
+        for i in t.inputs:
+            visit(i)
+        order.append(t)
+    for o in outputs:
+        visit(o)
+    return order
+
+
+def build_plan(inputs, outputs):
+    """inputs: [KTensor] (exactly one), outputs: [KTensor].  Returns a Plan."""
+    if len(inputs) != 1:
+        raise NotImplementedError('exactly one model input is supported')
+    plan = Plan()
+    x_in = inputs[0]
+    plan.input_shape = tuple(x_in.shape)
+    order = toposort(outputs)
+    consumers = collections.Counter()
+    for t in order:
+        for i in t.inputs:
+            consumers[i.uid] += 1
+    out_index = {}
+    for o, t in enumerate(outputs):
+        out_index.setdefault(t.uid, []).append(o)
+    plan.output_shapes = [tuple(t.shape) for t in outputs]
+    plan.output_store = [None] * len(outputs)
+
+    def store_of(shape):
+        """stored 3-D (c, h, w) block of a logical per-sample shape: everything in front of the last two axes is
+        channels (the recurrent (T, C, H, W) layout is (T*C, H, W) in memory)."""
+        if len(shape) < 3:
+            raise NotImplementedError('dense (non-convolutional) tensors of per-sample shape %r are not on the HIP path'
+                                      % (shape,))
+        c = 1
+        for d in shape[:-2]:
+            c *= d
+        return (c, shape[-2], shape[-1])
+
+    plan._in_store = store_of(x_in.shape)
+    views = {}
+
+    def emit(op):
+        plan.ops.append(op)
+        if op.kind == 'conv' and op.layer not in plan.conv_layers:
+            plan.conv_layers.append(op.layer)
+        return op
+
+    def materialize(v, dst=None, dst_c_off=0, dst_c_total=None):
+        """Turn a lazy view into real data.  With dst=None a new buffer is created (or the view is returned untouched if
+        it is already a whole buffer).  With dst given, the data lands in channels [dst_c_off, +c) of that buffer."""
+        cur = v
+        steps = []
+        if not (cur.c_off == 0 and cur.c == cur.c_total) and not cur.plain:
+            steps.append('window')      # pool/pad kernels want a dense (n*c) plane run: extract the window first
+        if cur.src_mode != SRC_DIRECT:
+            steps.append('src')
+        if cur.halo != NO_HALO:
+            steps.append('halo')
+        into_window = dst is not None and not (dst_c_off == 0 and (dst_c_total is None or dst_c_total == v.logical[0]))
+        if dst is not None and (not steps or into_window or steps[-1] == 'window'):
+            steps.append('final_copy')
+        if not steps:
+            return cur
+        for k, step in enumerate(steps):
+            last = k == len(steps) - 1
+            tgt_direct = last and dst is not None and step != 'final_copy'
+            if step == 'window':
+                nb = plan.new_buffer(cur.c, cur.h, cur.w)
+                emit(PlanOp('copy', cur.buf, nb, (cur.c, cur.h, cur.w), in_c_off=cur.c_off, in_c_total=cur.c_total,
+                            out_c_off=0, out_c_total=cur.c, out_shape=(cur.c, cur.h, cur.w)))
+                cur = cur.copy(buf=nb, c_off=0, c_total=cur.c)
+            elif step == 'src':
+                h2, w2 = cur.src_hw
+                nb = dst if tgt_direct else plan.new_buffer(cur.c, h2, w2)
+                emit(PlanOp('maxpool' if cur.src_mode == SRC_MAXPOOL2 else 'upsample', cur.buf, nb,
+                            (cur.c, cur.h, cur.w), out_shape=(cur.c, h2, w2)))
+                cur = cur.copy(buf=nb, h=h2, w=w2, src_mode=SRC_DIRECT)
+            elif step == 'halo':
+                c, hp, wp = cur.logical
+                nb = dst if tgt_direct else plan.new_buffer(c, hp, wp)
+                emit(PlanOp('pad', cur.buf, nb, (cur.c, cur.h, cur.w), halo=cur.halo, out_shape=(c, hp, wp)))
+                cur = cur.copy(buf=nb, h=hp, w=wp, halo=NO_HALO)
+            else:  # final_copy
+                tot = dst_c_total if dst_c_total is not None else cur.c
+                emit(PlanOp('copy', cur.buf, dst, (cur.c, cur.h, cur.w), in_c_off=cur.c_off, in_c_total=cur.c_total,
+                            out_c_off=dst_c_off, out_c_total=tot, out_shape=(cur.c, cur.h, cur.w)))
+                cur = View(dst, dst_c_off, cur.c, tot, cur.h, cur.w)
+        return cur
+
+    for t in order:
+        lay = t.layer
+        if isinstance(lay, L.InputLayer):
+            if t.uid != x_in.uid:
+                raise ValueError('graph reaches an Input that is not the model input')
+            c, h, w = plan._in_store
+            views[t.uid] = View(STATE_IN, 0, c, c, h, w, shape=tuple(t.shape) if len(t.shape) != 3 else None)
+            continue
+        ins = [views[i.uid] for i in t.inputs]
+        outs = out_index.get(t.uid, [])
+
+        if isinstance(lay, L._Pad2DBase):
+            v = ins[0]
+            if v.shape is not None:
+                raise NotImplementedError('%s on a reshaped (non-3D) tensor' % lay.name)
+            if lay.data_format == 'channels_last':
+                # standalone only: buffer holds (H, W, C) per sample, rows of W*C floats
+                v = materialize(v)
+                hh, ww, cc = t.inputs[0].shape
+                (tp, bt), (lf, rt) = lay.padding
+                nb = plan.new_buffer(hh + tp + bt, ww + lf + rt, cc)
+                emit(PlanOp('pad', v.buf, nb, (1, hh, ww), halo=Halo(tp, bt, lf, rt, lay.mode, lay.mode), inner=cc,
+                            out_shape=(hh + tp + bt, ww + lf + rt, cc)))
+                views[t.uid] = View(nb, 0, hh + tp + bt, hh + tp + bt, ww + lf + rt, cc)
+                views[t.uid].shape = tuple(t.shape)
+            else:
+                halo = _compose_halo(v.halo, lay.padding, lay.mode)
+                if halo is None:
+                    v = materialize(v)
+                    halo = _compose_halo(NO_HALO, lay.padding, lay.mode)
+                hh, ww = v.src_hw
+                if halo.mode_h == PAD_WRAP and max(halo.top, halo.bottom) > hh:
+                    raise ValueError('%s: periodic row padding exceeds the input height %d' % (lay.name, hh))
+                if halo.mode_w == PAD_WRAP and max(halo.left, halo.right) > ww:
+                    raise ValueError('%s: periodic column padding exceeds the input width %d' % (lay.name, ww))
+                views[t.uid] = v.copy(halo=halo)
+        elif isinstance(lay, (L.MaxPooling2D, L.UpSampling2D)):
+            v = ins[0]
+            if v.shape is not None:
+                raise NotImplementedError('%s on a reshaped tensor' % lay.name)
+            if not v.plain:
+                v = materialize(v)
+            views[t.uid] = v.copy(src_mode=SRC_MAXPOOL2 if isinstance(lay, L.MaxPooling2D) else SRC_UPSAMPLE2)
+        elif isinstance(lay, L.ChannelSlice):
+            v = ins[0]
+            if v.shape is not None:
+                raise NotImplementedError('slice_layer on a reshaped tensor')
+            lo, hi = lay.window(v.c)
+            views[t.uid] = v.copy(c_off=v.c_off + lo, c=hi - lo)
+        elif isinstance(lay, L.Reshape):
+            v = materialize(ins[0])
+            if not v.full:
+                v = materialize(v, dst=plan.new_buffer(*v.logical))
+            c, h, w = store_of(t.shape)
+            if (c * h * w) != v.c * v.h * v.w:
+                raise ValueError('Reshape size mismatch')
+            # relabel the same contiguous block
+            if v.buf >= 0:
+                plan.buffers[v.buf] = (c, h, w)
+                views[t.uid] = View(v.buf, 0, c, c, h, w, shape=tuple(t.shape) if len(t.shape) != 3 else None)
+            else:
+                nb = plan.new_buffer(v.c, v.h, v.w)
+                emit(PlanOp('copy', v.buf, nb, (v.c, v.h, v.w), in_c_total=v.c, out_c_total=v.c,
+                            out_shape=(v.c, v.h, v.w)))
+                plan.buffers[nb] = (c, h, w)
+                views[t.uid] = View(nb, 0, c, c, h, w, shape=tuple(t.shape) if len(t.shape) != 3 else None)
+        elif isinstance(lay, L.Concatenate):
+            c_tot = sum(v.logical[0] for v in ins)
+            _, hh, ww = ins[0].logical
+            if outs:
+                o = outs[0]
+                dst = OUT(o)
+                plan.output_store[o] = (c_tot, hh, ww)
+            else:
+                dst = plan.new_buffer(c_tot, hh, ww)
+            off = 0
+            for v in ins:
+                materialize(v, dst=dst, dst_c_off=off, dst_c_total=c_tot)
+                off += v.logical[0]
+            views[t.uid] = View(dst, 0, c_tot, c_tot, hh, ww)
+        elif isinstance(lay, L.Conv2D):
+            v = ins[0]
+            if v.shape is not None and len(v.shape) != 3:
+                raise NotImplementedError('%s on a non-3D tensor %r' % (lay.name, v.shape))
+            halo = v.halo
+            if lay.padding == 'same':
+                st, sb, sl, sr = lay.same_halo()
+                halo2 = _compose_halo(halo, ((st, sb), (sl, sr)), PAD_ZERO)
+                if halo2 is None:
+                    v = materialize(v)
+                    halo2 = Halo(st, sb, sl, sr, PAD_ZERO, PAD_ZERO)
+                halo = halo2
+            _, hl, wl = v.copy(halo=halo).logical
+            ho = hl - lay.dilation_rate[0] * (lay.kernel_size[0] - 1)
+            wo = wl - lay.dilation_rate[1] * (lay.kernel_size[1] - 1)
+            if outs:
+                dst = OUT(outs[0])
+                plan.output_store[outs[0]] = (lay.filters, ho, wo)
+            else:
+                dst = plan.new_buffer(lay.filters, ho, wo)
+            emit(PlanOp('conv', v.buf, dst, (v.c, v.h, v.w), layer=lay, halo=halo, src_mode=v.src_mode,
+                        act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
+                        out_c_total=lay.filters, out_shape=(lay.filters, ho, wo)))
+            views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)
+        else:
+            raise NotImplementedError('layer %s (%s) has no HIP lowering' % (lay.name, type(lay).__name__))
+
+        # a model output that was not produced in place by a conv / concatenate: materialise it into its slot
+        for k, o in enumerate(outs):
+            v = views[t.uid]
+            if v.buf == OUT(o) and v.full:
+                continue
+            lc = v.logical
+            plan.output_store[o] = lc
+            materialize(v, dst=OUT(o), dst_c_off=0, dst_c_total=lc[0])
+            if k == 0:
+                views[t.uid] = View(OUT(o), 0, lc[0], lc[0], lc[1], lc[2], shape=v.shape)
+    for o, st in enumerate(plan.output_store):
+        if st is None:
+            raise RuntimeError('output %d was never produced' % o)
+    return plan

@@ -1,0 +1,516 @@
+"""
+The train step behind model.fit / fit_generator / evaluate: forward (activations stay in the plan's buffers), 'mse'
+loss + 'mae' metric, backward through the fused plan (dlwp_conv2d_bwd_data / _bwd_weight, activation / pooling /
+up-sampling / halo adjoints), Keras-form Adam on ONE flat parameter buffer, and -- under torch.distributed -- one
+all-reduce of ONE flat gradient buffer per step (RCCL over xGMI on the GPU box, gloo in the CPU tests).
+
+Reference: keras Model.fit / fit_generator / evaluate as driven by DLWP/model/models.py:188-228, 303-316 and
+examples/train.py:240,258-263,274; loss / metric / optimizer strings of examples/train.py:240.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import plan as P
+from .custom import Callback, History
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# optimizers (hyper-parameter holders; the update itself is a HIP kernel over the flat buffers)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+class Optimizer(object):
+    def __init__(self, lr, decay):
+        self.lr, self.decay = float(lr), float(decay)
+        self.iterations = 0
+
+
+class Adam(Optimizer):
+    """keras.optimizers.Adam (Keras 2.2 form: epsilon outside the sqrt, bias correction folded into lr_t)."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=None, decay=0., amsgrad=False, **kwargs):
+        super(Adam, self).__init__(lr, decay)
+        if amsgrad:
+            raise NotImplementedError('amsgrad is not implemented')
+        self.beta_1, self.beta_2 = float(beta_1), float(beta_2)
+        self.epsilon = 1e-7 if epsilon is None else float(epsilon)      # K.epsilon()
+
+
+class SGD(Optimizer):
+    def __init__(self, lr=0.01, momentum=0., decay=0., nesterov=False, **kwargs):
+        super(SGD, self).__init__(lr, decay)
+        if nesterov:
+            raise NotImplementedError('nesterov momentum is not implemented')
+        self.momentum = float(momentum)
+
+
+def get_optimizer(spec):
+    if isinstance(spec, Optimizer):
+        return spec
+    if isinstance(spec, str):
+        table = {'adam': Adam, 'sgd': SGD}
+        if spec.lower() not in table:
+            raise NotImplementedError("optimizer %r is not implemented ('adam', 'sgd' are)" % spec)
+        return table[spec.lower()]()
+    raise TypeError('optimizer must be a name or a dlwp_amd.training.Optimizer instance')
+
+
+def mean_squared_error(y_true, y_pred):  # marker objects accepted as loss= (the reference passes keras.losses.mean_squared_error)
+    raise RuntimeError('marker only: pass it as loss=, the HIP loss kernel computes it')
+
+
+def mean_absolute_error(y_true, y_pred):
+    raise RuntimeError('marker only')
+
+
+def _loss_name(loss):
+    name = loss if isinstance(loss, str) else getattr(loss, '__name__', None)
+    if name in ('mse', 'MSE', 'mean_squared_error'):
+        return 'mse'
+    raise NotImplementedError("loss %r is not implemented on the HIP path yet ('mse' / mean_squared_error is; the "
+                              "custom anomaly-correlation / latitude-weighted losses are listed as next rows in "
+                              "DESIGN.md)" % (loss,))
+
+
+_METRIC_NAMES = {'mae': 'mean_absolute_error', 'mean_absolute_error': 'mean_absolute_error',
+                 'mse': 'mean_squared_error', 'mean_squared_error': 'mean_squared_error'}
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# flat parameter storage
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def flatten_parameters(model):
+    """Re-home every layer weight as a view into one contiguous fp32 buffer (values preserved).  Returns the buffer and
+    [(layer, name, offset, numel, shape)]."""
+    entries, total = [], 0
+    seen = set()
+    for lay in model.layers:
+        if id(lay) in seen:
+            continue
+        seen.add(id(lay))
+        for name, w in lay._weights:
+            entries.append((lay, name, total, w.numel(), tuple(w.shape)))
+            total += w.numel()
+    flat = torch.empty(max(total, 1), dtype=torch.float32, device=model.device)
+    for lay, name, off, numel, shape in entries:
+        old = dict(lay._weights)[name]
+        view = flat[off:off + numel].view(shape)
+        view.copy_(old)
+        setattr(lay, name, view)
+        lay._weights = [(nm, view if nm == name else t) for nm, t in lay._weights]
+    return flat, entries
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# trainer
+# ------------------------------------------------------------------------------------------------------------------ #
+
+class Trainer(object):
+    def __init__(self, model):
+        self.model = model
+        self.plan = model.plan
+        self.device = model.device
+        self.loss_kind = _loss_name(model.loss)
+        n_out = len(model.outputs)
+        lw = model.loss_weights
+        if lw is None:
+            lw = [1.0] * n_out
+        if isinstance(lw, dict):
+            raise NotImplementedError('loss_weights as a dict')
+        if len(lw) != n_out:
+            raise ValueError('loss_weights has %d entries for %d outputs' % (len(lw), n_out))
+        self.loss_weights = [float(v) for v in lw]
+        self.metric_keys = []
+        for m in model.metrics:
+            key = m if isinstance(m, str) else getattr(m, '__name__', None)
+            if key not in _METRIC_NAMES:
+                raise NotImplementedError('metric %r is not implemented (mae, mse are)' % (m,))
+            self.metric_keys.append(_METRIC_NAMES[key])
+        out_names = [t.layer.name for t in model.outputs]
+        if n_out == 1:
+            self.metrics_names = ['loss'] + list(self.metric_keys)
+        else:
+            self.metrics_names = (['loss'] + ['%s_loss' % nm for nm in out_names] +
+                                  ['%s_%s' % (nm, mk) for nm in out_names for mk in self.metric_keys])
+        self.flat_params, self.entries = flatten_parameters(model)
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        self.opt_state = None
+        self.dp = getattr(model, '_dp', None)
+        self._grad_bufs = {}
+        self._loss_out = None
+
+    # -- helpers ------------------------------------------------------------------------------------------------------ #
+    def _grad_view(self, layer, name):
+        for lay, nm, off, numel, shape in self.entries:
+            if lay is layer and nm == name:
+                return self.flat_grads[off:off + numel].view(shape)
+        raise KeyError(name)
+
+    def _to_device(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, dtype=torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def _targets(self, y, n):
+        ys = list(y) if isinstance(y, (list, tuple)) else [y]
+        if len(ys) != len(self.plan.output_store):
+            raise ValueError('model has %d outputs but %d target arrays were given' % (len(self.plan.output_store), len(ys)))
+        out = []
+        for t, store in zip(ys, self.plan.output_store):
+            t = self._to_device(t)
+            if t.shape[0] != n or t.numel() != n * int(np.prod(store)):
+                raise ValueError('target shape %r does not match the model output %r' % (tuple(t.shape), (n,) + tuple(store)))
+            out.append(t.reshape((n,) + tuple(store)))
+        return out
+
+    # -- forward + loss ------------------------------------------------------------------------------------------------ #
+    def _forward_loss(self, x, ys, want_grad, weight_scale=1.0):
+        """Returns (outs, loss_vals tensor [n_out, 2] on device, dys or None)."""
+        from . import ops
+        outs = self.model.executor.run(x)
+        n_out = len(outs)
+        if self._loss_out is None or self._loss_out.shape[0] != n_out:
+            self._loss_out = torch.zeros((n_out, 2), dtype=torch.float32, device=self.device)
+        dys = []
+        for o, (yp, yt) in enumerate(zip(outs, ys)):
+            dy = torch.empty_like(yp) if want_grad else None
+            ops.mse_mae(yp, yt, self._loss_out[o], dy, self.loss_weights[o] * weight_scale)
+            dys.append(dy)
+        return outs, self._loss_out, dys
+
+    def _report(self, loss_vals):
+        """[loss, (per-output losses), metrics...] as python floats from the device [n_out, 2] (mse, mae) table."""
+        v = loss_vals.detach().cpu().numpy().astype(np.float64)
+        return self._report_from(v)
+
+    def _report_from(self, v):
+        n_out = v.shape[0]
+        total = float(sum(w * v[o, 0] for o, w in enumerate(self.loss_weights)))
+        col = {'mean_squared_error': 0, 'mean_absolute_error': 1}
+        if n_out == 1:
+            return [total] + [float(v[0, col[k]]) for k in self.metric_keys]
+        return ([total] + [float(v[o, 0]) for o in range(n_out)] +
+                [float(v[o, col[k]]) for o in range(n_out) for k in self.metric_keys])
+
+    # -- backward ------------------------------------------------------------------------------------------------------ #
+    def _backward(self, x, outs, dys):
+        from . import _lib, ops
+        plan = self.plan
+        n = x.shape[0]
+        bufs = self.model.executor.scratch(n)
+        x = x.reshape((n,) + plan._in_store)
+
+        def tensor(i):
+            if i >= 0:
+                return bufs[i]
+            return x if i == P.STATE_IN else outs[-2 - i]
+
+        grads = {}          # buffer id -> gradient tensor
+        written = {}        # buffer id -> list of (c_off, c) windows already holding a gradient
+
+        def overlaps(buf, c_off, c):
+            return any(not (c_off + c <= o or o + k <= c_off) for o, k in written.get(buf, []))
+
+        def grad_of(buf):
+            g = grads.get(buf)
+            if g is None:
+                g = torch.empty_like(tensor(buf))
+                grads[buf] = g
+            return g
+
+        for o, dy in enumerate(dys):
+            grads[P.OUT(o)] = dy
+            written[P.OUT(o)] = [(0, dy.shape[1])]
+
+        def deposit(buf, c_off, c, dense):
+            """Put `dense` (n, c, h, w) into window [c_off, +c) of grad[buf]: overwrite on first touch, add after."""
+            g = grad_of(buf)
+            full = c_off == 0 and c == g.shape[1]
+            if not overlaps(buf, c_off, c):
+                if full:
+                    if dense.data_ptr() != g.data_ptr():
+                        g.view(-1).copy_(dense.reshape(-1))
+                else:
+                    ops.copy_channels(dense.reshape((n, c) + tuple(g.shape[2:])), g, c, 0, c_off)
+                written.setdefault(buf, []).append((c_off, c))
+            elif full and written[buf] == [(0, g.shape[1])]:
+                ops.axpby(dense.reshape(-1), g.view(-1), 1.0, 1.0)
+            else:
+                raise NotImplementedError('overlapping partial channel windows in the backward pass')
+
+        touched_layers = set()
+        descs = self.model.executor._descriptors()
+        for op, d in reversed(list(zip(plan.ops, descs))):
+            if op.dst not in grads:
+                continue                      # nothing downstream of this op contributes to the loss
+            gD = grads[op.dst]
+            src = tensor(op.src)
+            if op.kind == 'conv':
+                lay = op.layer
+                y = tensor(op.dst)
+                if lay.activation != 'linear':
+                    ops.act_bwd(y, gD, op.act, out=gD)          # dz in place of dy
+                dz = gD
+                xs = _lib.Shape4(n, op.xs[0], op.xs[1], op.xs[2])
+                acc = id(lay) in touched_layers
+                ops.conv2d_bwd_weight(src, dz, self._grad_view(lay, 'kernel'), d, xs, accumulate=acc)
+                if lay.bias is not None:
+                    gb = self._grad_view(lay, 'bias')
+                    if acc:
+                        tmp = torch.empty_like(gb)
+                        ops.bias_grad(dz, tmp, lay.filters)
+                        ops.axpby(tmp, gb, 1.0, 1.0)
+                    else:
+                        ops.bias_grad(dz, gb, lay.filters)
+                touched_layers.add(id(lay))
+                if op.src == P.STATE_IN:
+                    continue                  # no gradient w.r.t. the model input is needed
+                cin = op.xs[0]
+                c_total = src.shape[1]
+                if op.src_mode == P.SRC_DIRECT:
+                    g = grad_of(op.src)
+                    if not overlaps(op.src, op.in_c_off, cin):
+                        ops.conv2d_bwd_data(dz, lay.kernel, d, xs, g)        # writes its channel window in place
+                        written.setdefault(op.src, []).append((op.in_c_off, cin))
+                    else:
+                        dd = ops.make_conv(d.cout, d.kh, d.kw, (d.dil_h, d.dil_w), d.halo, d.act, 0, 0, d.out_c_off,
+                                           d.out_c_total, d.src_mode)
+                        tmp = torch.empty((n, cin) + tuple(src.shape[2:]), dtype=torch.float32, device=self.device)
+                        ops.conv2d_bwd_data(dz, lay.kernel, dd, xs, tmp)
+                        deposit(op.src, op.in_c_off, cin, tmp)
+                else:
+                    hin = 2 * op.xs[1] if op.src_mode == P.SRC_UPSAMPLE2 else op.xs[1] // 2
+                    win = 2 * op.xs[2] if op.src_mode == P.SRC_UPSAMPLE2 else op.xs[2] // 2
+                    tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
+                    ops.conv2d_bwd_data(dz, lay.kernel, d, xs, tmp)
+                    if op.src_mode == P.SRC_UPSAMPLE2:
+                        dense = ops.upsample2_bwd(tmp)
+                    else:
+                        if op.in_c_off == 0 and cin == c_total:
+                            xw = src
+                        else:
+                            xw = torch.empty((n, cin) + tuple(src.shape[2:]), dtype=torch.float32, device=self.device)
+                            ops.copy_channels(src, xw, cin, op.in_c_off, 0)
+                        dense = ops.maxpool2_bwd(xw, tmp)
+                    deposit(op.src, op.in_c_off, cin, dense)
+            elif op.kind == 'copy':
+                if op.src == P.STATE_IN:
+                    continue
+                c = op.xs[0]
+                gw = torch.empty((n, c) + tuple(gD.shape[2:]), dtype=torch.float32, device=self.device)
+                ops.copy_channels(gD, gw, c, op.out_c_off, 0)
+                deposit(op.src, op.in_c_off, c, gw)
+            elif op.kind == 'pad':
+                if op.src == P.STATE_IN:
+                    continue
+                if op.inner > 1:
+                    dense = ops.pad2d_bwd(gD.reshape((n, gD.shape[1], gD.shape[2], -1)) if gD.dim() == 4 else gD,
+                                          (n, op.xs[1], op.xs[2], op.inner), d, channels_last=True)
+                else:
+                    dense = ops.pad2d_bwd(gD, (n,) + tuple(op.xs), d)
+                deposit(op.src, 0, src.shape[1], dense)
+            elif op.kind == 'maxpool':
+                if op.src == P.STATE_IN:
+                    continue
+                deposit(op.src, 0, src.shape[1], ops.maxpool2_bwd(src, gD))
+            elif op.kind == 'upsample':
+                if op.src == P.STATE_IN:
+                    continue
+                deposit(op.src, 0, src.shape[1], ops.upsample2_bwd(gD))
+            else:
+                raise RuntimeError(op.kind)
+        # layers that received no gradient this step (unused by any output) must not keep a stale one
+        for lay, nm, off, numel, shape in self.entries:
+            if id(lay) not in touched_layers:
+                self.flat_grads[off:off + numel].zero_()
+
+    # -- optimizer ----------------------------------------------------------------------------------------------------- #
+    def _apply(self, grad_scale=1.0):
+        from . import ops
+        opt = self.model.optimizer
+        if self.opt_state is None:
+            if isinstance(opt, Adam):
+                self.opt_state = (torch.zeros_like(self.flat_params), torch.zeros_like(self.flat_params))
+            else:
+                self.opt_state = (torch.zeros_like(self.flat_params),)
+        if isinstance(opt, Adam):
+            m, v = self.opt_state
+            ops.adam_keras(self.flat_params, m, v, self.flat_grads, opt.iterations, opt.lr, opt.beta_1, opt.beta_2,
+                           opt.epsilon, opt.decay, grad_scale)
+        else:
+            ops.sgd_keras(self.flat_params, self.opt_state[0], self.flat_grads, opt.iterations, opt.lr, opt.momentum,
+                          opt.decay, grad_scale)
+        opt.iterations += 1
+
+    # -- public steps -------------------------------------------------------------------------------------------------- #
+    def train_on_batch(self, x, y, return_device=False):
+        """One optimisation step on a GLOBAL batch.  Under data parallelism every rank passes the same global batch and
+        trains on its own row shard; the reported loss is the global-batch value on every rank."""
+        x = self._to_device(x)
+        n_global = x.shape[0]
+        ys = self._targets(y, n_global)
+        scale = 1.0
+        dp = self.dp
+        if dp is not None and dp.world > 1:
+            lo, hi = dp.shard(n_global)
+            x = x[lo:hi].contiguous()
+            ys = [t[lo:hi].contiguous() for t in ys]
+            # local means are averaged over ranks: weight each by its share so ragged shards stay exact
+            scale = (hi - lo) * dp.world / float(n_global)
+        outs, loss_vals, dys = self._forward_loss(x, ys, True, scale)
+        self._backward(x, outs, dys)
+        if dp is not None and dp.world > 1:
+            dp.all_reduce_sum_(self.flat_grads)
+            self._apply(1.0 / dp.world)
+            loss_vals = dp.mean_loss(loss_vals * scale)
+        else:
+            self._apply(1.0)
+        if return_device:
+            return loss_vals
+        return self._report(loss_vals)
+
+    def test_on_batch(self, x, y):
+        x = self._to_device(x)
+        ys = self._targets(y, x.shape[0])
+        _, loss_vals, _ = self._forward_loss(x, ys, False)
+        return self._report(loss_vals)
+
+    # -- loops --------------------------------------------------------------------------------------------------------- #
+    def _callbacks(self, callbacks, params):
+        hist = History()
+        cbs = [hist] + [c for c in (callbacks or [])]
+        for c in cbs:
+            if hasattr(c, 'set_model'):
+                c.set_model(self.model)
+            else:
+                c.model = self.model
+            if hasattr(c, 'set_params'):
+                c.set_params(params)
+        self.model.history = hist
+        return hist, cbs
+
+    @staticmethod
+    def _call(cbs, name, *args):
+        for c in cbs:
+            fn = getattr(c, name, None)
+            if fn is not None:
+                fn(*args)
+
+    def _run_epochs(self, epochs, initial_epoch, batches_fn, n_batches_fn, validate_fn, callbacks, verbose, on_epoch_end):
+        params = {'epochs': epochs, 'metrics': self.metrics_names, 'verbose': verbose}
+        hist, cbs = self._callbacks(callbacks, params)
+        self.model.stop_training = False
+        self._call(cbs, 'on_train_begin', {})
+        for epoch in range(initial_epoch, epochs):
+            t0 = time.time()
+            self._call(cbs, 'on_epoch_begin', epoch, {})
+            sums = None
+            seen = 0
+            pending = []
+            for bi, (X, y) in enumerate(batches_fn(epoch)):
+                self._call(cbs, 'on_batch_begin', bi, {'batch': bi, 'size': int(X.shape[0])})
+                lv = self.train_on_batch(X, y, return_device=True).clone()
+                pending.append((lv, int(X.shape[0])))
+                # convert lazily: one host sync per epoch unless a callback wants per-batch logs
+                if any(getattr(type(c), 'on_batch_end', Callback.on_batch_end) is not Callback.on_batch_end
+                       for c in cbs if isinstance(c, Callback)) or any(not isinstance(c, Callback) for c in cbs):
+                    vals = self._report(lv)
+                    self._call(cbs, 'on_batch_end', bi, dict(zip(self.metrics_names, vals), batch=bi, size=int(X.shape[0])))
+                if self.model.stop_training:
+                    break
+            for lv, bs in pending:
+                vals = np.asarray(self._report(lv), dtype=np.float64)
+                sums = vals * bs if sums is None else sums + vals * bs
+                seen += bs
+            logs = dict(zip(self.metrics_names, (sums / max(seen, 1)).tolist())) if sums is not None else {}
+            if validate_fn is not None:
+                vvals = validate_fn()
+                logs.update({'val_' + k: v for k, v in zip(self.metrics_names, vvals)})
+            if on_epoch_end is not None:
+                on_epoch_end()
+            if verbose:
+                msg = ' - '.join('%s: %.4f' % (k, v) for k, v in logs.items())
+                print('Epoch %d/%d - %.1fs - %s' % (epoch + 1, epochs, time.time() - t0, msg))
+            self._call(cbs, 'on_epoch_end', epoch, logs)
+            if self.model.stop_training:
+                break
+        self._call(cbs, 'on_train_end', {})
+        return hist
+
+    def fit(self, x, y, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None, shuffle=True,
+            initial_epoch=0):
+        batch_size = int(batch_size or 32)
+        x = np.asarray(x) if not isinstance(x, torch.Tensor) else x
+        n = x.shape[0]
+        ys = list(y) if isinstance(y, (list, tuple)) else [y]
+
+        def batches(epoch):
+            idx = np.arange(n)
+            if shuffle:
+                np.random.shuffle(idx)
+            for lo in range(0, n, batch_size):
+                sel = idx[lo:lo + batch_size]
+                yield x[sel], ([t[sel] for t in ys] if len(ys) > 1 else ys[0][sel])
+
+        val = None
+        if validation_data is not None:
+            vx, vy = validation_data[0], validation_data[1]
+            val = lambda: self.evaluate(vx, vy, batch_size=batch_size, verbose=0, as_list=True)  # noqa: E731
+        return self._run_epochs(epochs, initial_epoch, batches, None, val, callbacks, verbose, None)
+
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
+                      validation_steps=None, shuffle=True, initial_epoch=0):
+        from .model.generators import DeviceLoader
+        steps = int(steps_per_epoch) if steps_per_epoch is not None else len(generator)
+
+        def batches(epoch):
+            order = list(range(steps))
+            if self.device.type == 'cuda':
+                for X, y in DeviceLoader(generator, self.device, order=order):
+                    yield X, y
+            else:
+                for i in order:
+                    yield generator[i]
+
+        def end():
+            if hasattr(generator, 'on_epoch_end'):
+                generator.on_epoch_end()
+
+        val = None
+        if validation_data is not None:
+            if isinstance(validation_data, (tuple, list)):
+                vx, vy = validation_data[0], validation_data[1]
+                val = lambda: self.evaluate(vx, vy, verbose=0, as_list=True)  # noqa: E731
+            else:
+                vgen = validation_data
+                vsteps = int(validation_steps) if validation_steps is not None else len(vgen)
+                val = lambda: self.evaluate_generator(vgen, vsteps)  # noqa: E731
+        return self._run_epochs(epochs, initial_epoch, batches, None, val, callbacks, verbose, end)
+
+    def evaluate_generator(self, generator, steps=None):
+        steps = int(steps) if steps is not None else len(generator)
+        sums, seen = None, 0
+        for i in range(steps):
+            X, y = generator[i]
+            vals = np.asarray(self.test_on_batch(X, y), dtype=np.float64)
+            bs = int(np.asarray(X).shape[0]) if not isinstance(X, torch.Tensor) else int(X.shape[0])
+            sums = vals * bs if sums is None else sums + vals * bs
+            seen += bs
+        return (sums / max(seen, 1)).tolist()
+
+    def evaluate(self, x, y, batch_size=None, verbose=1, as_list=False):
+        batch_size = int(batch_size or 32)
+        batch_size = max(batch_size, 256)        # the result does not depend on it; larger chunks fill the GPU
+        n = x.shape[0]
+        ys = list(y) if isinstance(y, (list, tuple)) else [y]
+        sums, seen = None, 0
+        for lo in range(0, n, batch_size):
+            yb = [t[lo:lo + batch_size] for t in ys]
+            vals = np.asarray(self.test_on_batch(x[lo:lo + batch_size], yb if len(yb) > 1 else yb[0]), dtype=np.float64)
+            bs = min(batch_size, n - lo)
+            sums = vals * bs if sums is None else sums + vals * bs
+            seen += bs
+        out = (sums / max(seen, 1)).tolist()
+        return out if (len(out) > 1 or as_list) else out[0]

@@ -101,6 +101,39 @@ int dlwp_conv2d_config_info(int i, int* info8, int* lds_bytes);
 int dlwp_conv2d_force_config(int i);
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 
+/* ---- backward of the fused Conv2D: the two halves of the Keras train step behind DLWPNeuralNet.fit / fit_generator
+ *      (DLWP/model/models.py:188-228).  dz = dL/d(pre-activation), (n, out_c_total, ho, wo) window [out_c_off,+cout).
+ *      bwd_data : dx = dL/d(input after the src transform, before the halo), (n, cin, hin, win); for DLWP_SRC_DIRECT it
+ *                 may be the channel window [in_c_off,+cin) of an in_c_total-channel buffer; for the pooled / up-sampled
+ *                 loaders the caller finishes with dlwp_maxpool2_bwd / dlwp_upsample2_bwd.
+ *      bwd_weight: dw (kh,kw,cin,cout) HWIO, deterministic (fixed-order slab reduction); accumulate != 0 adds to dw.
+ *      Workspace: caller-owned device memory of at least dlwp_conv2d_bwd_workspace(pass 0 = data, 1 = weight) bytes.   */
+int dlwp_conv2d_bwd_workspace(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int pass, size_t* bytes);
+int dlwp_conv2d_bwd_data(dlwp_handle_t, const void* dz, const void* w, void* dx, dlwp_shape4 xs, const dlwp_conv2d* cd,
+                         int dtype, void* ws, size_t ws_bytes, void* stream);
+int dlwp_conv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
+                           const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
+int dlwp_conv2d_wgrad_num_configs(void);                                   /* tuning hooks, as for the forward */
+int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes);      /* {ks, dil, th, tw, cout_frags, waves} */
+int dlwp_conv2d_wgrad_force_config(int i);
+
+/* ---- the rest of the train step: Keras 'mse' loss + 'mae' metric (examples/train.py:240, train_functional.py:285),
+ *      activation backward, bias gradient, Keras-2.2-form Adam (restated by the reference at DLWP/custom.py:34-40) and
+ *      SGD on flat parameter buffers.  Reductions use fixed trees: bit-reproducible.
+ *      dlwp_mse_mae: out2[0] = mean((yp-yt)^2), out2[1] = mean(|yp-yt|) (device floats); dy (nullable) =
+ *      loss_weight * 2*(yp-yt)/n.  ws >= dlwp_mse_mae_workspace() bytes.                                                */
+int    dlwp_act_bwd(dlwp_handle_t, const void* y, const void* dy, void* dz, size_t n, int act, int dtype, void* stream);
+int    dlwp_bias_grad(dlwp_handle_t, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, int dtype,
+                      void* stream);
+size_t dlwp_mse_mae_workspace(dlwp_handle_t);
+int    dlwp_mse_mae(dlwp_handle_t, const void* y_pred, const void* y_true, size_t n, void* out2, void* dy,
+                    float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream);
+int    dlwp_adam_keras(dlwp_handle_t, void* p, void* m, void* v, const void* g, size_t n, float lr, float beta_1,
+                       float beta_2, float epsilon, float decay, long long iteration, float grad_scale, void* stream);
+int    dlwp_sgd_keras(dlwp_handle_t, void* p, void* vel, const void* g, size_t n, float lr, float momentum, float decay,
+                      long long iteration, float grad_scale, void* stream);
+int    dlwp_axpby(dlwp_handle_t, const void* x, void* y, size_t n, float a, float b, void* stream);   /* y = a*x + b*y */
+
 /* ---- keras MaxPooling2D(2) / UpSampling2D(2) standalone (examples/train.py:171,181,191,201) ------------------------ */
 int dlwp_maxpool2_fwd (dlwp_handle_t, const void* x, void* y, dlwp_shape4 xs, int dtype, void* stream);
 int dlwp_maxpool2_bwd (dlwp_handle_t, const void* x, const void* dy, void* dx, dlwp_shape4 xs, int dtype, void* stream);
@@ -134,7 +167,7 @@ typedef struct {
   int w, b;                 /* weight / bias buffer indices (conv only)                                    */
   dlwp_shape4 xs;           /* stored input shape of this op                                               */
   dlwp_conv2d conv;         /* DLWP_OP_CONV2D; for DLWP_OP_COPYCH: in_c_off/in_c_total/out_c_off/out_c_total */
-  dlwp_pad2d pad;           /* DLWP_OP_PAD2D                                                               */
+  dlwp_pad2d pad;           /* DLWP_OP_PAD2D (NHWC: xs = (n,1,h,w) and conv.in_c_total = channels)          */
 } dlwp_op;
 typedef struct dlwp_rollout* dlwp_rollout_t;
 int dlwp_rollout_create(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,

@@ -1,0 +1,385 @@
+"""GPU parity at the model level, through the reference's own API (DLWPNeuralNet / DLWPFunctional build_model, predict,
+predict_timeseries, fit, evaluate) with everything below it running in libdlwp_hip.so, against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref, torch_ref
+from tests.nets import CF, cnn2_layers, unet_layers
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 2e-5      # whole 6-conv forward vs float64 oracle, relative to output scale (fp32 roundoff through 6 layers)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+def _build(layers, time_dim=2, seed=0, **compile_kw):
+    from dlwp_amd.model import DLWPNeuralNet
+    np.random.seed(seed)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=time_dim, scaler_type=None, scale_targets=False)
+    compile_kw.setdefault('loss', 'mse')
+    compile_kw.setdefault('optimizer', 'adam')
+    compile_kw.setdefault('metrics', ['mae'])
+    d.build_model(layers, **compile_kw)
+    return d
+
+
+def _weights_of(model, rng=None, bias_scale=0.1):
+    """[(w_hwio, b)] of the Conv2D layers in order; biases randomised so they are actually tested."""
+    ws = model.get_weights()
+    pairs = [(ws[i], ws[i + 1]) for i in range(0, len(ws), 2)]
+    if rng is not None:
+        pairs = [(w, (bias_scale * rng.standard_normal(b.shape)).astype(np.float32)) for w, b in pairs]
+        model.set_weights([a for p in pairs for a in p])
+    return pairs
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def test_unet_forward_matches_float64_oracle():
+    rng = np.random.default_rng(0)
+    cs = (4, 16, 24)
+    layers = unet_layers(cs)
+    d = _build(layers)
+    weights = _weights_of(d.model, rng)
+    x = rng.standard_normal((3,) + cs).astype(np.float32)
+    got = d.predict(x)
+    want = np_ref.run_layers(layers, x, weights)
+    assert got.shape == want.shape == (3,) + cs and got.dtype == np.float32
+    assert _rel(got, want) < FWD_TOL
+    # second opinion: the unfused torch-CPU float32 graph agrees to the same level
+    want32 = torch_ref.run_layers(layers, torch.from_numpy(x), torch_ref.to_torch_weights(weights)).numpy()
+    assert _rel(got, want32) < FWD_TOL
+
+
+def test_config1_cnn_on_odd_grid_matches_oracle():
+    """Config 1 shape class: 73x144-like odd height, 2 channels, two 5x5 convs (examples/train.py plumbing path)."""
+    rng = np.random.default_rng(1)
+    cs = (2, 19, 36)
+    layers = cnn2_layers(cs, hidden=32)
+    d = _build(layers, time_dim=2)
+    weights = _weights_of(d.model, rng)
+    x = rng.standard_normal((2,) + cs).astype(np.float32)
+    assert _rel(d.predict(x), np_ref.run_layers(layers, x, weights)) < FWD_TOL
+
+
+def test_predict_does_not_depend_on_batch_chunking_or_batch_mates():
+    rng = np.random.default_rng(2)
+    cs = (4, 16, 24)
+    d = _build(unet_layers(cs))
+    _weights_of(d.model, rng)
+    x = rng.standard_normal((300,) + cs).astype(np.float32)
+    full = d.predict(x)
+    assert np.array_equal(full, d.predict(x, batch_size=256))      # chunked (256 + 44) == one pass, bit for bit
+    assert np.array_equal(full[7:8], d.predict(x[7:8]))              # a member alone == the member inside a batch
+
+
+def test_predict_timeseries_graph_equals_host_loop_and_tracks_the_oracle():
+    rng = np.random.default_rng(3)
+    cs = (4, 16, 24)                                                  # time_dim 2 x 2 variables
+    layers = unet_layers(cs)
+    d = _build(layers, time_dim=2)
+    weights = _weights_of(d.model, rng)
+    x = rng.standard_normal((5,) + cs).astype(np.float32)
+    steps = 7                                                         # -> ceil(7/2) = 4 forwards, 8 output steps
+    got = d.predict_timeseries(x, steps)
+    assert got.shape == (8, 5, 2, 16, 24) and got.dtype == np.float32
+    kept = d.predict_timeseries(x, steps, keep_time_dim=True)
+    assert kept.shape == (4, 5, 2, 2, 16, 24)
+    # (1) the captured hipGraph rollout == the reference-style host loop over our own predict(), bit for bit
+    def host_loop(p):
+        ser = []
+        for _ in range(4):
+            p = d.predict(p)
+            ser.append(p)
+        return np.stack(ser)
+    ser = host_loop(x)
+    assert np.array_equal(kept, ser.reshape(4, 5, 2, 2, 16, 24))
+    assert np.array_equal(got, np_ref._merge_time(ser, 4, 5, 2, cs, False))
+    # (2) against the float64 oracle rollout: tight on the first forward, bounded growth afterwards
+    want = np_ref.predict_timeseries_nn(lambda p: np_ref.run_layers(layers, p, weights), x.astype(np.float64), steps, 2)
+    assert _rel(got[:2], want[:2]) < FWD_TOL
+    assert _rel(got, want) < 50 * FWD_TOL
+    # replay: same graph, new initial state
+    x2 = rng.standard_normal((5,) + cs).astype(np.float32)
+    got2 = d.predict_timeseries(x2, steps)
+    assert np.array_equal(got2[:2], np_ref._merge_time(d.predict(x2)[None], 1, 5, 2, cs, False))
+    # step_sequence goes through the generic loop and keeps only the first predicted step
+    seq = d.predict_timeseries(x, 3, step_sequence=True)
+    assert seq.shape == (3, 5, 2, 16, 24)
+    assert np.array_equal(seq[0], d.predict(x).reshape(5, 2, 2, 16, 24)[:, 0])
+
+
+def test_member_sharding_is_bit_identical():
+    """Ensemble members are independent: a rollout of a shard equals the same rows of the full rollout (what lets the
+    8-GPU run be compared member by member with the 1-GPU run)."""
+    from dlwp_amd.parallel import shard_bounds
+    rng = np.random.default_rng(4)
+    cs = (4, 16, 24)
+    d = _build(unet_layers(cs), time_dim=2)
+    _weights_of(d.model, rng)
+    base = rng.standard_normal((1,) + cs).astype(np.float32)
+    members = base + 0.01 * rng.standard_normal((8,) + cs).astype(np.float32)
+    full = d.predict_timeseries(members, 6)
+    for rank in range(4):
+        lo, hi = shard_bounds(8, rank, 4)
+        assert np.array_equal(d.predict_timeseries(members[lo:hi], 6), full[:, lo:hi])
+
+
+def test_functional_skip_unet_and_chained_outputs():
+    from dlwp_amd import custom, layers as L
+    from dlwp_amd.engine import Model
+    from dlwp_amd.model import DLWPFunctional
+    rng = np.random.default_rng(5)
+    cs = (4, 16, 24)
+    x0 = L.Input(shape=cs)
+    pp2, zp2 = custom.PeriodicPadding2D((0, 2), **CF), L.ZeroPadding2D((2, 0), **CF)
+    pp1, zp1 = custom.PeriodicPadding2D((0, 1), **CF), L.ZeroPadding2D((1, 0), **CF)
+    pool, up = L.MaxPooling2D(2, **CF), L.UpSampling2D(2, **CF)
+    convs = [L.Conv2D(32, 3, dilation_rate=2, activation='tanh', **CF), L.Conv2D(64, 3, activation='tanh', **CF),
+             L.Conv2D(128, 3, activation='tanh', **CF), L.Conv2D(32, 3, activation='tanh', **CF),
+             L.Conv2D(16, 3, dilation_rate=2, activation='tanh', **CF), L.Conv2D(4, 5, activation='linear', **CF)]
+    s11, s12 = custom.slice_layer(0, 16, axis=1), custom.slice_layer(16, 32, axis=1)
+    s21, s22 = custom.slice_layer(0, 32, axis=1), custom.slice_layer(32, 64, axis=1)
+
+    def skip_model(x):                                               # examples/train_functional.py:248-275
+        x = convs[0](pp2(zp2(x)))
+        x, x1 = s11(x), s12(x)
+        x = convs[1](pp1(zp1(pool(x))))
+        x, x2 = s21(x), s22(x)
+        x = convs[2](pp1(zp1(pool(x))))
+        x = convs[3](pp1(zp1(up(x))))
+        x = L.concatenate([x, x2], axis=1)
+        x = convs[4](pp2(zp2(up(x))))
+        x = L.concatenate([x, x1], axis=1)
+        return convs[5](pp2(zp2(x)))
+    outs = [skip_model(x0)]
+    outs.append(skip_model(outs[0]))                                 # integration_steps = 2
+    np.random.seed(5)
+    m = Model(inputs=x0, outputs=outs)
+    f = DLWPFunctional(is_convolutional=True, time_dim=2)
+    f.build_model(m, loss='mse', loss_weights=[0.5, 0.5], optimizer='adam', metrics=['mae'])
+    ws = m.get_weights()
+    pairs = [(ws[i], (0.1 * rng.standard_normal(ws[i + 1].shape)).astype(np.float32)) for i in range(0, 12, 2)]
+    m.set_weights([a for p in pairs for a in p])
+
+    def ref(x):
+        def halo(t, k):
+            return np_ref.zero_padding2d(np_ref.periodic_padding2d(t, (0, k)), (k, 0))
+        a = np_ref.conv2d(halo(x, 2), *pairs[0], 2, 'tanh')
+        a, a1 = a[:, :16], a[:, 16:]
+        b = np_ref.conv2d(halo(np_ref.maxpool2(a), 1), *pairs[1], 1, 'tanh')
+        b, b2 = b[:, :32], b[:, 32:]
+        c = np_ref.conv2d(halo(np_ref.maxpool2(b), 1), *pairs[2], 1, 'tanh')
+        e = np_ref.conv2d(halo(np_ref.upsample2(c), 1), *pairs[3], 1, 'tanh')
+        e = np.concatenate([e, b2], axis=1)
+        g = np_ref.conv2d(halo(np_ref.upsample2(e), 2), *pairs[4], 2, 'tanh')
+        g = np.concatenate([g, a1], axis=1)
+        return np_ref.conv2d(halo(g, 2), *pairs[5], 1, 'linear')
+    x = rng.standard_normal((3,) + cs).astype(np.float32)
+    y1, y2 = f.predict(x)
+    r1 = ref(x.astype(np.float64))
+    r2 = ref(r1)
+    assert _rel(y1, r1) < FWD_TOL and _rel(y2, r2) < 4 * FWD_TOL
+    # rollout: 2 outputs per call, time_dim 2 -> 5 steps need ceil(5/2/2) = 2 calls = 4 slots = 8 steps
+    ts = f.predict_timeseries(x, 5)
+    assert ts.shape == (8, 3, 2, 16, 24)
+    want = np_ref.predict_timeseries_functional(lambda p: [ref(p), ref(ref(p))], x.astype(np.float64), 5, 2, n_outputs=2)
+    assert _rel(ts[:4], want[:4]) < 4 * FWD_TOL
+    # and it is exactly the host loop over predict()
+    p, slots = x, []
+    for _ in range(2):
+        o1, o2 = f.predict(p)
+        slots += [o1, o2]
+        p = o2
+    assert np.array_equal(ts, np_ref._merge_time(np.stack(slots), 4, 3, 2, cs, False))
+
+
+def test_standalone_layers_run_when_nothing_fuses():
+    """Padding-only / pooling-tail models exercise the standalone kernels through build_model (both data formats)."""
+    rng = np.random.default_rng(6)
+    from dlwp_amd.model import DLWPNeuralNet
+    d = DLWPNeuralNet(scaler_type=None, scale_targets=False)
+    d.build_model((('PeriodicPadding2D', ((1, 2),), {'input_shape': (5, 6, 3)}),), loss='mse')     # channels_last default
+    x = rng.standard_normal((4, 5, 6, 3)).astype(np.float32)
+    assert np.array_equal(d.predict(x), np_ref.periodic_padding2d(x, (1, 2), 'channels_last'))
+    d.build_model((('Conv2D', (4, 3), dict(CF, input_shape=(2, 8, 8))), ('MaxPooling2D', (2,), dict(CF)),
+                   ('FillPadding2D', ((1, 0),), dict(CF))), loss='mse')
+    w, b = d.model.get_weights()
+    x = rng.standard_normal((2, 2, 8, 8)).astype(np.float32)
+    want = np_ref.fill_padding2d(np_ref.maxpool2(np_ref.conv2d(x, w, b)), (1, 0))
+    assert _rel(d.predict(x), want) < FWD_TOL
+
+
+def test_full_size_unet_longitude_shift_equivariance_and_spot_parity():
+    """BASELINE.json config-2 size (4 x 88 x 180): size-independent property + one sample against the oracle."""
+    rng = np.random.default_rng(7)
+    cs = (4, 88, 180)
+    layers = unet_layers(cs)
+    d = _build(layers, time_dim=2)
+    weights = _weights_of(d.model, rng)
+    x = rng.standard_normal((4,) + cs).astype(np.float32)
+    y = d.predict(x)
+    ys = d.predict(np.roll(x, 8, axis=-1))                          # shift by a multiple of the pooling factor (4)
+    assert np.array_equal(ys, np.roll(y, 8, axis=-1))
+    want = torch_ref.run_layers(layers, torch.from_numpy(x[:1]), torch_ref.to_torch_weights(weights)).numpy()
+    assert _rel(y[:1], want) < FWD_TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# training
+# ----------------------------------------------------------------------------------------------------------------- #
+
+def _torch_step(layers, weights, x, y, lr=1e-3):
+    """One oracle train step: torch autograd on the unfused float64 graph + Keras-form Adam.  Returns loss, mae, grads,
+    new weights (all numpy, HWIO)."""
+    tw = torch_ref.to_torch_weights(weights, dtype=torch.float64, requires_grad=True)
+    out = torch_ref.run_layers(layers, torch.tensor(x, dtype=torch.float64), tw)
+    yt = torch.tensor(y, dtype=torch.float64)
+    loss = ((out - yt) ** 2).mean()
+    mae = (out - yt).abs().mean()
+    loss.backward()
+    grads, new = [], []
+    for (w, b), (w0, b0) in zip(tw, weights):
+        gw = w.grad.numpy().transpose(2, 3, 1, 0)
+        gb = b.grad.numpy()
+        grads += [gw, gb]
+        for p0, g in ((w0, gw), (b0, gb)):
+            p1, _, _ = np_ref.adam_keras_step(p0.astype(np.float64), np.zeros_like(g), np.zeros_like(g), g, 0, lr=lr)
+            new.append(p1)
+    return float(loss), float(mae), grads, new
+
+
+def test_train_step_gradients_loss_and_adam_match_autograd_oracle():
+    rng = np.random.default_rng(8)
+    cs = (4, 16, 24)
+    layers = unet_layers(cs)
+    d = _build(layers, time_dim=2)
+    weights = _weights_of(d.model, rng)
+    x = rng.standard_normal((6,) + cs).astype(np.float32)
+    y = rng.standard_normal((6,) + cs).astype(np.float32)
+    loss_ref, mae_ref, grads_ref, new_ref = _torch_step(layers, weights, x, y)
+    tr = d.model._trainer
+    vals = d.model.train_on_batch(x, y)
+    assert vals[0] == pytest.approx(loss_ref, rel=2e-5) and vals[1] == pytest.approx(mae_ref, rel=2e-5)
+    torch.cuda.synchronize()
+    off = 0
+    for g_ref in grads_ref:
+        g = tr.flat_grads[off:off + g_ref.size].cpu().numpy().reshape(g_ref.shape)
+        off += g_ref.size
+        assert np.abs(g - g_ref).max() <= 2e-4 * max(np.abs(g_ref).max(), 1e-6), g_ref.shape
+    for w_new, w_ref in zip(d.model.get_weights(), new_ref):
+        assert np.abs(w_new - w_ref).max() < 5e-6                    # first Adam step moves every weight by ~lr = 1e-3
+    assert d.model.optimizer.iterations == 1
+    ev = d.evaluate(x, y, verbose=0)
+    assert len(ev) == 2 and ev[0] < vals[0] * 1.5
+
+
+def test_fit_and_fit_generator_reduce_the_loss():
+    from dlwp_amd import custom
+    from dlwp_amd.model import ArrayDataset, DataGenerator
+    rng = np.random.default_rng(9)
+    cs = (2, 12, 16)
+    d = _build(cnn2_layers(cs, hidden=16), time_dim=2)
+    # a learnable target: a fixed smoothing of the input
+    P = rng.standard_normal((48, 2, 1, 12, 16)).astype(np.float32)
+    T = (0.5 * P + 0.25 * np.roll(P, 1, axis=-1) + 0.25 * np.roll(P, -1, axis=-1)).astype(np.float32)
+    gen = DataGenerator(d, ArrayDataset(P, T), batch_size=16, shuffle=True)
+    assert gen.convolution_shape == cs
+    hist = custom.History()
+    early = custom.EarlyStoppingMin(min_epochs=2, monitor='val_loss', min_delta=0., patience=50, restore_best_weights=True)
+    X, y = gen.generate([], scale_and_impute=False)
+    d.fit_generator(gen, epochs=12, verbose=0, validation_data=gen, use_multiprocessing=True,
+                    callbacks=[hist, custom.RNNResetStates(), early])
+    assert len(hist.history['loss']) == 12 and 'val_loss' in hist.history and 'mean_absolute_error' in hist.history
+    assert hist.history['loss'][-1] < 0.5 * hist.history['loss'][0]
+    before = d.evaluate(X, y, verbose=0)[0]
+    d.fit(X, y, batch_size=16, epochs=6, verbose=0, validation_data=(X, y), shuffle=True, callbacks=[hist])
+    after = d.evaluate(X, y, verbose=0)[0]
+    assert after < before
+    assert d.model.optimizer.iterations == 12 * 3 + 6 * 3
+
+
+def test_multi_output_training_accumulates_shared_layer_gradients():
+    from dlwp_amd import custom, layers as L
+    from dlwp_amd.engine import Model
+    rng = np.random.default_rng(10)
+    cs = (2, 8, 12)
+    x0 = L.Input(shape=cs)
+    pp, zp = custom.PeriodicPadding2D((0, 1), **CF), L.ZeroPadding2D((1, 0), **CF)
+    c1 = L.Conv2D(8, 3, activation='tanh', **CF)
+    c2 = L.Conv2D(2, 3, activation='linear', **CF)
+
+    def f(t):
+        return c2(pp(zp(c1(pp(zp(t))))))
+    o1 = f(x0)
+    o2 = f(o1)
+    np.random.seed(10)
+    m = Model(inputs=x0, outputs=[o1, o2])
+    m.compile(optimizer='adam', loss='mse', loss_weights=[0.5, 0.5], metrics=['mae'])
+    ws = m.get_weights()
+    pairs = [(ws[0], (0.1 * rng.standard_normal(8)).astype(np.float32)), (ws[2], (0.1 * rng.standard_normal(2)).astype(np.float32))]
+    m.set_weights([a for p in pairs for a in p])
+    x = rng.standard_normal((4,) + cs).astype(np.float32)
+    y1 = rng.standard_normal((4,) + cs).astype(np.float32)
+    y2 = rng.standard_normal((4,) + cs).astype(np.float32)
+    tw = torch_ref.to_torch_weights(pairs, dtype=torch.float64, requires_grad=True)
+    blk = (('PeriodicPadding2D', ((0, 1),), CF), ('ZeroPadding2D', ((1, 0),), CF),
+           ('Conv2D', (8, 3), dict(CF, activation='tanh')), ('PeriodicPadding2D', ((0, 1),), CF),
+           ('ZeroPadding2D', ((1, 0),), CF), ('Conv2D', (2, 3), dict(CF, activation='linear')))
+    t1 = torch_ref.run_layers(blk, torch.tensor(x, dtype=torch.float64), tw)
+    t2 = torch_ref.run_layers(blk, t1, tw)
+    l1 = ((t1 - torch.tensor(y1, dtype=torch.float64)) ** 2).mean()
+    l2 = ((t2 - torch.tensor(y2, dtype=torch.float64)) ** 2).mean()
+    (0.5 * l1 + 0.5 * l2).backward()
+    vals = m.train_on_batch(x, [y1, y2])
+    assert vals[0] == pytest.approx(float(0.5 * l1 + 0.5 * l2), rel=2e-5)
+    assert vals[1] == pytest.approx(float(l1), rel=2e-5) and vals[2] == pytest.approx(float(l2), rel=2e-5)
+    torch.cuda.synchronize()
+    tr = m._trainer
+    refs = [tw[0][0].grad.numpy().transpose(2, 3, 1, 0), tw[0][1].grad.numpy(),
+            tw[1][0].grad.numpy().transpose(2, 3, 1, 0), tw[1][1].grad.numpy()]
+    off = 0
+    for g_ref in refs:
+        g = tr.flat_grads[off:off + g_ref.size].cpu().numpy().reshape(g_ref.shape)
+        off += g_ref.size
+        assert np.abs(g - g_ref).max() <= 2e-4 * max(np.abs(g_ref).max(), 1e-6)
+
+
+def test_conv_backward_kernels_against_oracle_all_halo_modes():
+    """dlwp_conv2d_bwd_data / _bwd_weight directly through the C ABI: symmetric fast path and the general
+    (asymmetric / edge halo) path, with pooled and up-sampled loaders."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(11)
+    cases = [  # cin, cout, k, dil, pads, mh, mw, src
+        (8, 24, 3, 1, (1, 1, 1, 1), 0, 1, 0), (20, 36, 3, 2, (2, 2, 2, 2), 0, 1, 0), (6, 4, 5, 1, (2, 2, 2, 2), 0, 1, 0),
+        (8, 16, 3, 1, (1, 1, 1, 1), 0, 1, 1), (8, 16, 3, 1, (1, 1, 1, 1), 0, 1, 2), (5, 7, 3, 2, (2, 1, 3, 2), 2, 1, 0),
+        (4, 8, 3, 1, (0, 0, 0, 0), 0, 0, 0), (6, 8, 3, 1, (1, 1, 1, 1), 2, 2, 0), (33, 40, 3, 1, (1, 1, 1, 1), 1, 1, 0)]
+    for cin, cout, k, dil, pads, mh, mw, src in cases:
+        n, h, w = 3, 12, 20
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
+        xs64 = np.asarray(x, np.float64)
+        xt = {0: xs64, 1: np_ref.upsample2(xs64), 2: np_ref.maxpool2(xs64)}[src]
+        xp = np_ref.pad2d_modes(xt, pads, mh, mw)
+        ho, wo = xp.shape[2] - dil * (k - 1), xp.shape[3] - dil * (k - 1)
+        dz = rng.standard_normal((n, cout, ho, wo)).astype(np.float32)
+        dxp, dw_ref, _ = np_ref.conv2d_grads(xp, wt, dz, dil)
+        dx_ref = np_ref.pad2d_modes_grad(dxp, xt.shape, pads, mh, mw)
+        cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, mh, mw), ops.ACT_LINEAR, src_mode=src)
+        xs = _lib.Shape4(n, cin, h, w)
+        dxd = torch.empty(xt.shape, dtype=torch.float32, device='cuda')
+        ops.conv2d_bwd_data(torch.from_numpy(dz).cuda(), torch.from_numpy(wt).cuda(), cd, xs, dxd)
+        dwd = torch.empty(wt.shape, dtype=torch.float32, device='cuda')
+        ops.conv2d_bwd_weight(torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda(), dwd, cd, xs)
+        torch.cuda.synchronize()
+        case = (cin, cout, k, dil, pads, mh, mw, src)
+        assert np.abs(dxd.cpu().numpy() - dx_ref).max() <= 2e-5 * max(1., np.abs(dx_ref).max()), case
+        assert np.abs(dwd.cpu().numpy() - dw_ref).max() <= 2e-5 * max(1., np.abs(dw_ref).max()), case
