@@ -36,7 +36,7 @@ thread_local int g_forced_cfg = -1;
 
 int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void* y, dlwp_shape4 xs,
              const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
-  DLWP_CHECK_ARG(h && x && w && y && cd, "%s: null handle or pointer", fn);
+  DLWP_CHECK_ARG(h && cd && (xs.n == 0 || (x && w && y)), "%s: null handle or pointer", fn);
   DLWP_CHECK_ARG(dtype == DLWP_F32, "%s: dtype %d not supported", fn, dtype);
   DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, "%s: bad input shape (%d,%d,%d,%d)", fn, xs.n, xs.c,
                  xs.h, xs.w);

@@ -242,7 +242,9 @@ extern "C" {
 
 int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, int W, int inner, dlwp_pad2d p, int dtype,
                    void* stream) {
-  DLWP_CHECK_ARG(h && x && y, "dlwp_pad2d_fwd: null handle or pointer");
+  DLWP_CHECK_ARG(h != nullptr, "dlwp_pad2d_fwd: null handle");
+  if (outer == 0) return DLWP_OK;  // empty batch: torch hands out null data pointers for empty tensors
+  DLWP_CHECK_ARG(x && y, "dlwp_pad2d_fwd: null pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_pad2d_fwd: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(outer >= 0 && H > 0 && W > 0 && inner > 0, "dlwp_pad2d_fwd: bad shape");
   DLWP_CHECK_ARG(p.top >= 0 && p.bottom >= 0 && p.left >= 0 && p.right >= 0, "dlwp_pad2d_fwd: negative padding");
@@ -276,7 +278,9 @@ int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, in
 
 int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, int W, int inner, dlwp_pad2d p,
                    int dtype, void* stream) {
-  DLWP_CHECK_ARG(h && dy && dx, "dlwp_pad2d_bwd: null handle or pointer");
+  DLWP_CHECK_ARG(h != nullptr, "dlwp_pad2d_bwd: null handle");
+  if (outer == 0) return DLWP_OK;
+  DLWP_CHECK_ARG(dy && dx, "dlwp_pad2d_bwd: null pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_pad2d_bwd: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(outer >= 0 && H > 0 && W > 0 && inner > 0, "dlwp_pad2d_bwd: bad shape");
   DLWP_CHECK_ARG(p.top >= 0 && p.bottom >= 0 && p.left >= 0 && p.right >= 0, "dlwp_pad2d_bwd: negative padding");
@@ -293,7 +297,9 @@ int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, 
 }
 
 #define POOL_ARGS_OK(name)                                                                  \
-  DLWP_CHECK_ARG(h && x_ok, name ": null handle or pointer");                               \
+  DLWP_CHECK_ARG(h != nullptr, name ": null handle");                                       \
+  if (xs.n == 0) return DLWP_OK;                                                            \
+  DLWP_CHECK_ARG(x_ok, name ": null pointer");                                              \
   DLWP_CHECK_ARG(dtype == DLWP_F32, name ": dtype %d not supported", dtype);                \
   DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, name ": bad shape")
 
@@ -351,7 +357,9 @@ int dlwp_upsample2_bwd(dlwp_handle_t h, const void* dy, void* dx, dlwp_shape4 xs
 
 int dlwp_copy_channels(dlwp_handle_t h, const void* src, void* dst, int n, int c, int hw, int src_c_off, int src_c_total,
                        int dst_c_off, int dst_c_total, int dtype, void* stream) {
-  DLWP_CHECK_ARG(h && src && dst, "dlwp_copy_channels: null handle or pointer");
+  DLWP_CHECK_ARG(h != nullptr, "dlwp_copy_channels: null handle");
+  if (n == 0) return DLWP_OK;
+  DLWP_CHECK_ARG(src && dst, "dlwp_copy_channels: null pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_copy_channels: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(n >= 0 && c > 0 && hw > 0, "dlwp_copy_channels: bad shape");
   DLWP_CHECK_ARG(src_c_off >= 0 && src_c_off + c <= src_c_total, "dlwp_copy_channels: source channel range");

@@ -51,7 +51,9 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
   DLWP_CHECK_ARG(n_buffers == 0 || buffers, "dlwp_rollout_create: null buffer table");
   for (int i = 0; i < n_ops; ++i) {
     const dlwp_op& op = plan[i];
-    DLWP_CHECK_ARG(op.src >= DLWP_BUF_STATE_IN && op.src < n_buffers, "rollout op %d: src buffer %d out of range", i, op.src);
+    // a source may be a scratch buffer, the call's input state, or an earlier output of the same call (chained outputs)
+    DLWP_CHECK_ARG(op.src >= DLWP_BUF_OUT(n_outputs - 1) && op.src < n_buffers, "rollout op %d: src buffer %d out of range", i,
+                   op.src);
     DLWP_CHECK_ARG(op.dst != DLWP_BUF_STATE_IN && op.dst >= DLWP_BUF_OUT(n_outputs - 1) && op.dst < n_buffers,
                    "rollout op %d: dst buffer %d out of range", i, op.dst);
     if (op.kind == DLWP_OP_CONV2D)
