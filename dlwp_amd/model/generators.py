@@ -186,6 +186,8 @@ class DeviceLoader(object):
                     'dy': torch.empty(y.size, dtype=torch.float32, device=self.device),
                     'ev': torch.cuda.Event() if pin else None, 'free': None}
             self._slots[slot] = bufs
+        if bufs['ev'] is not None and bufs.get('recorded'):
+            bufs['ev'].synchronize()        # the previous H2D copy out of this pinned slot must have drained
         hx = bufs['hx'][:X.size].view(need[0])
         hy = bufs['hy'][:y.size].view(need[1])
         hx.numpy()[...] = X
@@ -199,6 +201,7 @@ class DeviceLoader(object):
                 dx.copy_(hx, non_blocking=True)
                 dy.copy_(hy, non_blocking=True)
                 bufs['ev'].record(self._copy_stream)
+                bufs['recorded'] = True
         else:
             dx.copy_(hx)
             dy.copy_(hy)
