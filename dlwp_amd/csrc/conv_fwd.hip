@@ -74,23 +74,29 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
   return a;
 }
 
-// Padded MFMA work of a configuration on a problem, in units of 16x16x4 MFMAs, plus a small-grid penalty: a grid
-// that cannot give every CU ~2 workgroups is charged as if it ran that many (tail / under-fill), which steers small
-// batches toward smaller tiles.
+// Cost model for picking a tile configuration (fitted against tools/tune_conv.py sweeps on an MI355X, see
+// profiles/*conv_tile_sweep*): padded MFMA work of one workgroup, inflated by a co-residency term (how many
+// workgroups a CU can overlap -- bounded by LDS and by 16 waves/CU at this kernel's register use -- decides how
+// well staging / barriers / epilogues hide under other workgroups' MFMAs) and by a SIMD-imbalance penalty for wave
+// counts that are not a multiple of 4; times the number of workgroup "rounds" the grid needs.  A grid smaller than the
+// chip runs one round, which steers small batches toward small tiles.
 double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   const long long tiles = (long long)dlwp_ceil_div(a.Ho, e.th) * dlwp_ceil_div(a.Wo, e.tw);
-  const long long cout_tiles = dlwp_ceil_div(a.Cout, 16 * e.bnf);
-  const long long blocks = tiles * cout_tiles * a.N;
-  const long long ksteps = (long long)dlwp_ceil_div(a.Cin, e.ck) * (e.ck / 4) * e.ks * e.ks;
-  const double per_block = (double)e.waves * e.fa * e.bnf * ksteps;
-  // staging cost per block in "MFMA-equivalents" (empirical weight): x tile + weight tile floats per chunk
-  const int lr = e.th + e.dil * (e.ks - 1), lc = e.tw + e.dil * (e.ks - 1);
-  const double stage = (double)dlwp_ceil_div(a.Cin, e.ck) * (e.ck * (double)lr * lc + e.ks * e.ks * e.ck * 16.0 * e.bnf) /
-                       64.0 * 0.25;
-  const double waves_per_cu = 8.0;  // rough co-residency
-  const double slots = cu_count * waves_per_cu / e.waves;
-  const double rounds = blocks < slots ? 1.0 : (double)blocks / slots;
-  return (per_block + stage) * e.waves * rounds;
+  const int bnf = e.pack ? 1 : e.bnf;
+  const int kwe = e.pack ? (e.ks - 1) * e.dil + e.pack : e.ks;  // packed-N: effective kernel width
+  const long long cout_tiles = e.pack ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  const double blocks = (double)tiles * cout_tiles * a.N;
+  const double ksteps = (double)dlwp_ceil_div(a.Cin, e.ck) * (e.ck / 4) * e.ks * kwe;
+  const double work = (double)e.waves * e.fa * bnf * ksteps;  // MFMAs of one workgroup
+  int resident = (160 * 1024) / e.lds_bytes;
+  if (resident > 16 / e.waves) resident = 16 / e.waves;
+  if (resident > 8) resident = 8;
+  if (resident < 1) resident = 1;
+  const double per_cu = blocks / cu_count;
+  const double rounds = per_cu < 1.0 ? 1.0 : per_cu;
+  double overlap = per_cu < resident ? (per_cu < 1.0 ? 1.0 : per_cu) : (double)resident;
+  const double imbalance = (e.waves % 4) ? 1.1 : 1.0;
+  return rounds * work * (1.0 + 0.6 / overlap) * imbalance;
 }
 
 int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
@@ -98,13 +104,19 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
   if (g_forced_cfg >= 0) {
     if (g_forced_cfg >= (int)r.entries.size()) return -1;
     const ConvKernelEntry& e = r.entries[g_forced_cfg];
-    return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w) ? g_forced_cfg : -1;
+    const bool pool = cd->src_mode == DLWP_SRC_MAXPOOL2;
+    const bool pack_ok = e.pack == 0 || (cd->cout <= 16 / e.pack);
+    return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
+               ? g_forced_cfg
+               : -1;
   }
   int best = -1;
   double best_cost = 0;
   for (int i = 0; i < (int)r.entries.size(); ++i) {
     const ConvKernelEntry& e = r.entries[i];
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
+    if ((e.pool != 0) != (cd->src_mode == DLWP_SRC_MAXPOOL2)) continue;  // pooled loader <-> POOL instances only
+    if (e.pack != 0 && cd->cout > 16 / e.pack) continue;                   // packed-N instances cover cout <= 16/S
     const double c = config_cost(e, a, cu_count);
     if (best < 0 || c < best_cost) {
       best = i;
@@ -189,7 +201,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   }
   a.tiles_h = dlwp_ceil_div(a.Ho, e.th);
   a.tiles_w = dlwp_ceil_div(a.Wo, e.tw);
-  a.cout_tiles = dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  a.cout_tiles = e.pack ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
   const long long grid = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
   DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
   e.launch(a, (int)grid, s);
@@ -248,12 +260,12 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const 
 // ---- tuning hooks (used by tools/tune_conv.py and the tests; not part of the drop-in surface) -------------------- //
 int dlwp_conv2d_num_configs(void) { return (int)registry().entries.size(); }
 
-int dlwp_conv2d_config_info(int i, int* info8, int* lds_bytes) {
+int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes) {
   Registry& r = registry();
-  DLWP_CHECK_ARG(i >= 0 && i < (int)r.entries.size() && info8, "dlwp_conv2d_config_info: index %d out of range", i);
+  DLWP_CHECK_ARG(i >= 0 && i < (int)r.entries.size() && info9, "dlwp_conv2d_config_info: index %d out of range", i);
   const ConvKernelEntry& e = r.entries[i];
-  const int v[8] = {e.ks, e.dil, e.th, e.tw, e.waves, e.fa, e.bnf, e.ck};
-  for (int k = 0; k < 8; ++k) info8[k] = v[k];
+  const int v[9] = {e.ks, e.dil, e.th, e.tw, e.waves, e.fa, e.pack ? -e.pack : e.bnf, e.ck, e.pool};
+  for (int k = 0; k < 9; ++k) info9[k] = v[k];  // cout_frags < 0: packed-N instance with S = -cout_frags shifts
   if (lds_bytes) *lds_bytes = e.lds_bytes;
   return DLWP_OK;
 }

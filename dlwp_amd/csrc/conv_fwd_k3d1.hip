@@ -1,5 +1,5 @@
 // conv_fwd_k3d1.hip -- 3x3, dilation 1 tile configurations (U-Net layers 2-4: examples/train.py:174-199).
-#include "conv_fwd_kernel.h"
+#include "conv_fwd_packn_kernel.h"
 //                         KS DIL TH  TW  WAVES FA BNF CK
 static const ConvKernelEntry k_table[] = {
     CONV_ENTRY(3, 1, 4, 45, 4, 3, 2, 16),
@@ -16,6 +16,20 @@ static const ConvKernelEntry k_table[] = {
     CONV_ENTRY(3, 1, 8, 32, 4, 4, 1, 8),
     CONV_ENTRY(3, 1, 4, 16, 4, 1, 2, 8),
     CONV_ENTRY(3, 1, 4, 16, 4, 1, 1, 4),
+    // instances with the fused 2x2 max-pooling loader (U-Net layers 2 and 3)
+    CONV_ENTRY_POOL(3, 1, 11, 45, 8, 4, 4, 8),
+    CONV_ENTRY_POOL(3, 1, 11, 45, 8, 4, 2, 8),
+    CONV_ENTRY_POOL(3, 1, 4, 45, 4, 3, 2, 8),
+    CONV_ENTRY_POOL(3, 1, 4, 45, 4, 3, 4, 8),
+    CONV_ENTRY_POOL(3, 1, 2, 45, 3, 2, 4, 8),
+    CONV_ENTRY_POOL(3, 1, 4, 90, 6, 4, 4, 8),
+    CONV_ENTRY_POOL(3, 1, 8, 32, 4, 4, 2, 8),
+    CONV_ENTRY_POOL(3, 1, 8, 32, 4, 4, 4, 8),
+    CONV_ENTRY_POOL(3, 1, 8, 32, 4, 4, 2, 4),
+    CONV_ENTRY_POOL(3, 1, 4, 16, 4, 1, 2, 8),
+    CONV_ENTRY_POOL(3, 1, 4, 16, 4, 1, 1, 4),
+    PACKN_ENTRY(3, 1, 8, 64, 4, 2, 8, 4),
+    PACKN_ENTRY(3, 1, 8, 32, 4, 2, 8, 2),
 };
 const ConvKernelEntry* dlwp_conv_table_k3d1(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));

@@ -35,9 +35,10 @@ struct ConvArgs {
   int tiles_h, tiles_w, cout_tiles;
 };
 
-template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_>
+template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool POOL_ = false>
 struct ConvCfg {
   static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, FA = FA_, BNF = BNF_, CK = CK_;
+  static constexpr bool POOL = POOL_;  // instance able to run the fused 2x2 max-pooling loader (4 raw values / element)
   static constexpr int NT = WAVES * 64;
   static constexpr int LR = TH + DIL * (KS - 1), LC = TW + DIL * (KS - 1);
   static constexpr int LCS = LC;
@@ -48,7 +49,8 @@ struct ConvCfg {
   static constexpr int TAPS = KS * KS;
   static constexpr int X_FLOATS = CK * PS;
   static constexpr int W_FLOATS = TAPS * CK * BNP;
-  static constexpr int LDS_BYTES = (X_FLOATS + W_FLOATS) * 4;
+  static constexpr int TRASH = X_FLOATS + W_FLOATS;  // 4 floats nobody reads: target of the loader's out-of-tile lanes
+  static constexpr int LDS_BYTES = (X_FLOATS + W_FLOATS + 4) * 4;
   static constexpr int P = TH * TW;
   static constexpr int MPAD = 16 * FA * WAVES;
   static constexpr int NPOS = (LR * LC + NT - 1) / NT;
@@ -57,8 +59,29 @@ struct ConvCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
 
+// tanh as the rational 13/6 minimax approximation Eigen (and therefore TensorFlow's CPU and GPU kernels, i.e. what the
+// reference's Keras Conv2D(activation='tanh') actually evaluates) uses: clamp to +-7.905, odd numerator / even
+// denominator in x^2.  Max error 4e-7 absolute (6.6 ulp next to saturation), 2.4e-7 relative for small |x|; ~17 VALU ops
+// instead of the ~50 of the libm tanhf.
+__device__ __forceinline__ float dlwp_tanh(float x) {
+  if (x != x) return x;
+  x = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
+  const float x2 = x * x;
+  float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
+  p = fmaf(x2, p, -8.60467152213735e-11f);
+  p = fmaf(x2, p, 5.12229709037114e-08f);
+  p = fmaf(x2, p, 1.48572235717979e-05f);
+  p = fmaf(x2, p, 6.37261928875436e-04f);
+  p = fmaf(x2, p, 4.89352455891786e-03f);
+  p = x * p;
+  float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
+  q = fmaf(x2, q, 2.26843463243900e-03f);
+  q = fmaf(x2, q, 4.89352518554385e-03f);
+  return p * __builtin_amdgcn_rcpf(q);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == DLWP_ACT_TANH) return tanhf(v);
+  if (act == DLWP_ACT_TANH) return dlwp_tanh(v);
   if (act == DLWP_ACT_RELU) return fmaxf(v, 0.f);
   return v;
 }
@@ -88,26 +111,51 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
   const int n = L / a.cout_tiles;
   const int i0 = th * C::TH, j0 = tw * C::TW, n0 = ct * C::BN;
 
-  // ---- loader bookkeeping: each thread owns NPOS spatial positions of the LDS tile, the same for every channel
+  // ---- loader bookkeeping: each thread owns NPOS spatial positions of the LDS tile, the same for every channel.
+  //      Invalid positions (zero halo, outside the tile) keep a VALID clamped offset and a false flag: every global load
+  //      below is unconditional (no exec-mask branch per load) and the value is selected afterwards.
   int goff[C::NPOS], loff[C::NPOS];
+  bool gok[C::NPOS];
 #pragma unroll
   for (int q = 0; q < C::NPOS; ++q) {
     const int s = tid + q * C::NT;
-    const bool in_tile = s < C::LR * C::LC;
+    // only the last position of a thread can fall outside the tile (NPOS = ceil(LR*LC / NT))
+    const bool in_tile = (q < C::NPOS - 1) || s < C::LR * C::LC;
     const int lr = s / C::LC, lc = s - lr * C::LC;
     const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
     const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
-    int g = -1;
-    if (in_tile && rs >= 0 && cs >= 0) {
+    const bool ok = in_tile && rs >= 0 && cs >= 0;
+    int g = 0;
+    if (ok) {
       if (a.src_mode == DLWP_SRC_UPSAMPLE2) g = (rs >> 1) * a.Ws + (cs >> 1);
       else if (a.src_mode == DLWP_SRC_MAXPOOL2) g = (rs * 2) * a.Ws + cs * 2;
       else g = rs * a.Ws + cs;
     }
     goff[q] = g;
-    loff[q] = in_tile ? lr * C::LCS + lc : -1;
+    gok[q] = ok;
+    loff[q] = in_tile ? lr * C::LCS + lc : (C::TRASH - 0);  // out-of-tile lanes store to the trash slot: no branch
   }
   const long long plane = (long long)a.Hs * a.Ws;
   const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
+
+  // ---- weight-slot bookkeeping: each thread owns NWV 16-byte slots of the [tap][ci][BN] weight chunk
+  constexpr int V4 = C::BN / 4;
+  constexpr int TOTW = C::TAPS * C::CK * V4;
+  constexpr int NWV = (TOTW + C::NT - 1) / C::NT;
+  int wsrc[NWV], wdst[NWV], wci[NWV];
+  bool wok[NWV];
+#pragma unroll
+  for (int k = 0; k < NWV; ++k) {
+    const int e = tid + k * C::NT;
+    const int col = (e % V4) * 4;
+    const int row = e / V4;  // tap*CK + ci
+    const int tap = row / C::CK, ci = row - tap * C::CK;
+    const bool in = e < TOTW;
+    wok[k] = in && (n0 + col < a.Cout);
+    wci[k] = ci;
+    wsrc[k] = in ? tap * a.Cin * a.Cout + (wok[k] ? n0 + col : 0) : 0;
+    wdst[k] = in ? row * C::BNP + col : C::TRASH - C::X_FLOATS;
+  }
 
   // ---- MFMA fragment bookkeeping
   int abase[C::FA];
@@ -127,54 +175,81 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
     for (int g = 0; g < C::BNF; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool w_vec = (a.Cout & 3) == 0;
+  const bool pool = a.src_mode == DLWP_SRC_MAXPOOL2;
 
-  for (int c0 = 0; c0 < a.Cin; c0 += C::CK) {
-    __syncthreads();  // everyone is done reading the previous chunk
-    // -- stage the input chunk (halo, wrap, pole rows, up-sampling / pooling resolved here)
-    if (a.src_mode != DLWP_SRC_MAXPOOL2) {
-      float v[C::CK][C::NPOS];
+  // ---- register-staged software pipeline (issue-early / write-late): the global loads of chunk c+1 are issued right
+  //      after chunk c has been written to LDS and stay in flight under chunk c's MFMA loop; they are only waited for
+  //      at the next LDS write.  One LDS buffer, two barriers per chunk.
+  // POOL instances keep only the weights in the register pipeline: staging 4 raw values per pooled element would cost
+  // 4x the registers (measured: occupancy loss outweighs the hidden latency); their x tile is loaded and max-reduced
+  // when it is written to LDS.
+  constexpr int XR = 1;
+  float xr[C::POOL ? 1 : C::CK][C::POOL ? 1 : C::NPOS][XR];
+  f32x4 wr[NWV];
+
+  auto prefetch = [&](int c0) {
+    if constexpr (!C::POOL) {
+#pragma unroll
+      for (int ci = 0; ci < C::CK; ++ci) {
+        const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
+#pragma unroll
+        for (int q = 0; q < C::NPOS; ++q) xr[ci][q][0] = xp[goff[q]];
+      }
+    }
+    if (w_vec) {
+#pragma unroll
+      for (int k = 0; k < NWV; ++k) {
+        const int cc = min(c0 + wci[k], a.Cin - 1);
+        wr[k] = *(const f32x4*)(a.w + wsrc[k] + (long long)cc * a.Cout);
+      }
+    }
+  };
+
+  auto commit = [&](int c0) {
+    if constexpr (C::POOL) {
+      float pv[C::CK][C::NPOS][4];
+#pragma unroll
+      for (int ci = 0; ci < C::CK; ++ci) {
+        const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
+#pragma unroll
+        for (int q = 0; q < C::NPOS; ++q) {
+          const float* sp = xp + goff[q];
+          pv[ci][q][0] = sp[0];
+          pv[ci][q][1] = sp[1];
+          pv[ci][q][2] = sp[a.Ws];
+          pv[ci][q][3] = sp[a.Ws + 1];
+        }
+      }
 #pragma unroll
       for (int ci = 0; ci < C::CK; ++ci) {
         const bool c_ok = c0 + ci < a.Cin;
-        const float* xp = xn + (long long)(c0 + ci) * plane;
 #pragma unroll
-        for (int q = 0; q < C::NPOS; ++q) v[ci][q] = (c_ok && goff[q] >= 0) ? xp[goff[q]] : 0.f;
+        for (int q = 0; q < C::NPOS; ++q) {
+          float v = fmaxf(fmaxf(pv[ci][q][0], pv[ci][q][1]), fmaxf(pv[ci][q][2], pv[ci][q][3]));
+          v = (c_ok && gok[q]) ? v : 0.f;
+          xs[((q == C::NPOS - 1 && loff[q] == C::TRASH) ? 0 : ci * C::PS) + loff[q]] = v;
+        }
       }
-#pragma unroll
-      for (int ci = 0; ci < C::CK; ++ci)
-#pragma unroll
-        for (int q = 0; q < C::NPOS; ++q)
-          if (loff[q] >= 0) xs[ci * C::PS + loff[q]] = v[ci][q];
     } else {
 #pragma unroll
       for (int ci = 0; ci < C::CK; ++ci) {
         const bool c_ok = c0 + ci < a.Cin;
-        const float* xp = xn + (long long)(c0 + ci) * plane;
 #pragma unroll
         for (int q = 0; q < C::NPOS; ++q) {
-          float m = 0.f;
-          if (c_ok && goff[q] >= 0) {
-            const float* s = xp + goff[q];
-            m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[a.Ws], s[a.Ws + 1]));
-          }
-          if (loff[q] >= 0) xs[ci * C::PS + loff[q]] = m;
+          const float v = (c_ok && gok[q]) ? xr[ci][q][0] : 0.f;
+          xs[((q == C::NPOS - 1 && loff[q] == C::TRASH) ? 0 : ci * C::PS) + loff[q]] = v;
         }
       }
     }
-    // -- stage the weight chunk [tap][ci][BN]
     if (w_vec) {
-      constexpr int V4 = C::BN / 4;
-      constexpr int TOT = C::TAPS * C::CK * V4;
-      for (int e = tid; e < TOT; e += C::NT) {
-        const int col = (e % V4) * 4;
-        const int row = e / V4;  // tap*CK + ci
-        const int tap = row / C::CK, ci = row - tap * C::CK;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (c0 + ci < a.Cin && n0 + col < a.Cout)
-          v = *(const f32x4*)(a.w + ((long long)tap * a.Cin + c0 + ci) * a.Cout + n0 + col);
-        *(f32x4*)(ws + row * C::BNP + col) = v;
+#pragma unroll
+      for (int k = 0; k < NWV; ++k) {
+        const bool ok = wok[k] && (c0 + wci[k] < a.Cin);
+        const f32x4 v = ok ? wr[k] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(ws + wdst[k]) = v;
       }
     } else {
+      // output-channel counts that are not a multiple of 4 (e.g. 2): scalar staging, not pipelined
       constexpr int TOT = C::TAPS * C::CK * C::BN;
       for (int e = tid; e < TOT; e += C::NT) {
         const int col = e % C::BN;
@@ -185,7 +260,16 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
         ws[row * C::BNP + col] = v;
       }
     }
+  };
+
+  if (C::POOL != pool) return;  // the host pairs the pooled loader with POOL instances only (conv_fwd.hip)
+
+  prefetch(0);
+  for (int c0 = 0; c0 < a.Cin; c0 += C::CK) {
+    __syncthreads();  // everyone is done reading the previous chunk
+    commit(c0);
     __syncthreads();
+    if (c0 + C::CK < a.Cin) prefetch(c0 + C::CK);
     // -- K loop over this chunk.  Order = (group of 4 channels, tap): the accumulation chain of every output element
     //    is then the same whatever CK / tile shape / batch size is in use, so results are bit-identical across tile
     //    configurations and across batch shardings.  Every LDS address = lane base + immediate.
@@ -243,7 +327,8 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
 
 // ---- registry of compiled tile configurations ------------------------------------------------------------------- //
 struct ConvKernelEntry {
-  int ks, dil, th, tw, waves, fa, bnf, ck, lds_bytes;
+  int ks, dil, th, tw, waves, fa, bnf, ck, lds_bytes, pool;
+  int pack;  // 0 = plain kernel; S > 0 = packed-N kernel for cout <= 16/S (conv_fwd_packn_kernel.h), bnf unused
   void (*launch)(const ConvArgs&, int grid, hipStream_t s);
   int (*prepare)();
 };
@@ -262,9 +347,11 @@ static int conv_prepare() {
   return 0;
 }
 
-#define CONV_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK)                                                        \
-  {                                                                                                             \
-    KS, DIL, TH, TW, WAVES, FA, BNF, CK, ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::LDS_BYTES,              \
-        &conv_launch_thunk<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>,                                       \
-        &conv_prepare<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>                                             \
+#define CONV_ENTRY_P(KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL)                                                   \
+  {                                                                                                                \
+    KS, DIL, TH, TW, WAVES, FA, BNF, CK, ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>::LDS_BYTES, POOL, 0,   \
+        &conv_launch_thunk<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>>,                                    \
+        &conv_prepare<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>>                                          \
   }
+#define CONV_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK) CONV_ENTRY_P(KS, DIL, TH, TW, WAVES, FA, BNF, CK, false)
+#define CONV_ENTRY_POOL(KS, DIL, TH, TW, WAVES, FA, BNF, CK) CONV_ENTRY_P(KS, DIL, TH, TW, WAVES, FA, BNF, CK, true)

@@ -167,9 +167,10 @@ def series_merge_time(series, time_dim):
 
 
 def conv_configs():
-    """[(ks, dil, th, tw, waves, frags_per_wave, cout_frags, channel_chunk, lds_bytes)] of the compiled MFMA tiles."""
+    """[(ks, dil, th, tw, waves, frags_per_wave, cout_frags, channel_chunk, pooled_loader, lds_bytes)] of the compiled
+    MFMA tiles."""
     out = []
-    info = (ctypes.c_int * 8)()
+    info = (ctypes.c_int * 9)()
     lds = ctypes.c_int()
     for i in range(_lib.lib.dlwp_conv2d_num_configs()):
         _lib.check(_lib.lib.dlwp_conv2d_config_info(i, info, ctypes.byref(lds)))

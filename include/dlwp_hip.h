@@ -94,10 +94,11 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const vo
                            const dlwp_conv2d* cd, int dtype, void* stream);
 
 /* tuning hooks (tools/tune_conv.py, tests): enumerate the compiled MFMA tile configurations, force one for the calling
- * thread (-1 = heuristic), ask which one the heuristic picks (-1 = direct kernel).  info8 = {ks, dil, th, tw, waves,
- * frags_per_wave, cout_frags, channel_chunk}.  Not part of the drop-in surface.                                      */
+ * thread (-1 = heuristic), ask which one the heuristic picks (-1 = direct kernel).  info9 = {ks, dil, th, tw, waves,
+ * frags_per_wave, cout_frags (< 0: packed-N instance for cout <= 16/-cout_frags), channel_chunk, pooled_loader}.
+ * Not part of the drop-in surface.                                                                                  */
 int dlwp_conv2d_num_configs(void);
-int dlwp_conv2d_config_info(int i, int* info8, int* lds_bytes);
+int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes);
 int dlwp_conv2d_force_config(int i);
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 

@@ -60,5 +60,6 @@ def test_compiled_tile_configurations_cover_the_unet_layers():
     kinds = {(c[0], c[1]) for c in cfgs}
     assert {(3, 1), (3, 2), (5, 1)} <= kinds
     for c in cfgs:
-        ks, dil, th, tw, waves, fa, bnf, ck, lds = c
-        assert th * tw <= 16 * fa * waves and lds <= 160 * 1024 and ck % 4 == 0
+        ks, dil, th, tw, waves, fa, bnf, ck, pool, lds = c
+        pixels = th * tw if bnf > 0 else th * tw // (-bnf)          # packed-N instances tile super-pixels
+        assert pixels <= 16 * fa * waves and lds <= 160 * 1024 and ck % 4 == 0

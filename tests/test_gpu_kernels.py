@@ -202,20 +202,22 @@ def test_conv2d_every_compiled_tile_configuration(ops):
     cfgs = ops.conv_configs()
     problems = {}
     try:
-        for i, (ks, dil, th, tw, waves, fa, bnf, ck, lds) in enumerate(cfgs):
-            key = (ks, dil)
+        for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds) in enumerate(cfgs):
+            cmax = 16 // (-bnf) if bnf < 0 else 0       # packed-N instances cover cout <= 16/S
+            key = (ks, dil, pool, cmax)
+            src = 2 if pool else 0                      # pooled-loader instances only run the fused max-pool source
             if key not in problems:
-                n, cin, h, w, cout = 2, 20, 19, 50, 36
+                n, cin, h, w, cout = 2, 20, (39 if pool else 19), (101 if pool else 50), (36 if not cmax else max(1, cmax - 1))
                 x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
                 wt = np_ref.glorot_uniform((ks, ks, cin, cout), rng)
                 b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
                 p = dil * (ks - 1) // 2
                 pads = (p, p, p, p)
-                want = _conv_ref(x, wt, b, dil, pads, 0, 1, 'tanh', 0)
+                want = _conv_ref(x, wt, b, dil, pads, 0, 1, 'tanh', src)
                 problems[key] = (dev(x), dev(wt), dev(b), pads, want, cout)
             xd, wd, bd, pads, want, cout = problems[key]
             ops.force_conv_config(i)
-            cd = ops.make_conv(cout, ks, ks, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH)
+            cd = ops.make_conv(cout, ks, ks, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH, src_mode=src)
             got = host(ops.conv2d(xd, wd, bd, cd))
             _check_conv(ops, got, want, 'config %d %r' % (i, cfgs[i]))
     finally:

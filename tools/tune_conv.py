@@ -52,7 +52,7 @@ def main():
         flops = 2.0 * a.batch * ys.h * ys.w * cout * cin * k * k
         rows = []
         for i, c in enumerate(cfgs):
-            if (c[0], c[1]) != (k, dil):
+            if (c[0], c[1]) != (k, dil) or bool(c[8]) != (src == 2) or (c[6] < 0 and cout > 16 // (-c[6])):
                 continue
             ops.force_conv_config(i)
             try:
@@ -86,8 +86,8 @@ def main():
         print('%s  %d->%d k%d d%d src%d out %dx%d  batch %d  %.1f MFLOP/sample   heuristic: %.3f ms = %.1f TF' %
               (name, cin, cout, k, dil, src, ys.h, ys.w, a.batch, flops / a.batch / 1e6, hms, flops / hms / 1e9))
         for ms, i, c in rows:
-            print('   cfg %2d th=%2d tw=%2d waves=%d fa=%d bnf=%d ck=%2d lds=%6d : %8.3f ms  %7.1f TF' %
-                  (i, c[2], c[3], c[4], c[5], c[6], c[7], c[8], ms, flops / ms / 1e9))
+            print('   cfg %2d th=%2d tw=%2d waves=%d fa=%d bnf=%d ck=%2d pool=%d lds=%6d : %8.3f ms  %7.1f TF' %
+                  (i, c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], ms, flops / ms / 1e9))
         results[name] = {'flops': flops, 'heuristic_ms': hms, 'rows': [(ms, i) + tuple(c) for ms, i, c in rows]}
     if a.out:
         with open(a.out, 'w') as f:
