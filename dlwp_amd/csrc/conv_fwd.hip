@@ -96,7 +96,11 @@ double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   const double rounds = per_cu < 1.0 ? 1.0 : per_cu;
   double overlap = per_cu < resident ? (per_cu < 1.0 ? 1.0 : per_cu) : (double)resident;
   const double imbalance = (e.waves % 4) ? 1.1 : 1.0;
-  return rounds * work * (1.0 + 0.6 / overlap) * imbalance;
+  // staging traffic of one workgroup (floats through LDS), a small term that mostly breaks ties toward larger tiles
+  const int lr = e.th + e.dil * (e.ks - 1), lc = e.tw + e.dil * (e.ks - 1);
+  const double stage = (double)dlwp_ceil_div(a.Cin, e.ck) *
+                       ((double)e.ck * lr * lc * (e.pool ? 4 : 1) + (double)e.ks * kwe * e.ck * 16.0 * bnf);
+  return rounds * (work * (1.0 + 0.3 / overlap) * imbalance + 0.01 * stage);
 }
 
 int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {

@@ -207,17 +207,20 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
 
   auto commit = [&](int c0) {
     if constexpr (C::POOL) {
-      float pv[C::CK][C::NPOS][4];
+      // 2x2 window = two 8-byte loads (the window's first element sits at an even float offset; the second row is
+      // 8-byte aligned when the stored width is even -- otherwise scalar loads)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 pv[C::CK][C::NPOS][2];
+      const bool ws_even = (a.Ws & 1) == 0;
 #pragma unroll
       for (int ci = 0; ci < C::CK; ++ci) {
         const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
 #pragma unroll
         for (int q = 0; q < C::NPOS; ++q) {
           const float* sp = xp + goff[q];
-          pv[ci][q][0] = sp[0];
-          pv[ci][q][1] = sp[1];
-          pv[ci][q][2] = sp[a.Ws];
-          pv[ci][q][3] = sp[a.Ws + 1];
+          pv[ci][q][0] = *(const f32x2*)sp;
+          if (ws_even) pv[ci][q][1] = *(const f32x2*)(sp + a.Ws);
+          else pv[ci][q][1] = (f32x2){sp[a.Ws], sp[a.Ws + 1]};
         }
       }
 #pragma unroll
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
         const bool c_ok = c0 + ci < a.Cin;
 #pragma unroll
         for (int q = 0; q < C::NPOS; ++q) {
-          float v = fmaxf(fmaxf(pv[ci][q][0], pv[ci][q][1]), fmaxf(pv[ci][q][2], pv[ci][q][3]));
+          float v = fmaxf(fmaxf(pv[ci][q][0][0], pv[ci][q][0][1]), fmaxf(pv[ci][q][1][0], pv[ci][q][1][1]));
           v = (c_ok && gok[q]) ? v : 0.f;
           xs[((q == C::NPOS - 1 && loff[q] == C::TRASH) ? 0 : ci * C::PS) + loff[q]] = v;
         }
@@ -273,22 +276,31 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
     // -- K loop over this chunk.  Order = (group of 4 channels, tap): the accumulation chain of every output element
     //    is then the same whatever CK / tile shape / batch size is in use, so results are bit-identical across tile
     //    configurations and across batch shardings.  Every LDS address = lane base + immediate.
+    //    Fragments are double-buffered in registers: the ds_reads of step s+1 are issued (and pinned by sched_barrier)
+    //    BEFORE the MFMAs of step s, so the LDS latency of every step hides under the previous step's MFMAs instead of
+    //    being exposed behind an lgkmcnt(0) in front of each MFMA group (what hipcc schedules on its own).
+    constexpr int NSTEPS = (C::CK / 4) * C::TAPS;
+    float af[2][C::FA], bf[2][C::BNF];
+    auto load_frags = [&](int step, int buf) {
+      const int c4 = step / C::TAPS, tap = step - c4 * C::TAPS;
+      const int u = tap / C::KS, vv = tap - u * C::KS;
 #pragma unroll
-    for (int c4 = 0; c4 < C::CK / 4; ++c4) {
+      for (int i = 0; i < C::FA; ++i) af[buf][i] = xs[abase[i] + (c4 * 4) * C::PS + u * C::DIL * C::LCS + vv * C::DIL];
 #pragma unroll
-      for (int tap = 0; tap < C::TAPS; ++tap) {
-        const int u = tap / C::KS, vv = tap - u * C::KS;
-        float af[C::FA], bf[C::BNF];
+      for (int g = 0; g < C::BNF; ++g) bf[buf][g] = ws[bbase + (tap * C::CK + c4 * 4) * C::BNP + g * 16];
+    };
+    load_frags(0, 0);
 #pragma unroll
-        for (int i = 0; i < C::FA; ++i) af[i] = xs[abase[i] + (c4 * 4) * C::PS + u * C::DIL * C::LCS + vv * C::DIL];
+    for (int step = 0; step < NSTEPS; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < NSTEPS) load_frags(step + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < C::BNF; ++g) bf[g] = ws[bbase + (tap * C::CK + c4 * 4) * C::BNP + g * 16];
+      for (int i = 0; i < C::FA; ++i)
 #pragma unroll
-        for (int i = 0; i < C::FA; ++i)
-#pragma unroll
-          for (int g = 0; g < C::BNF; ++g)
-            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[g], acc[i][g], 0, 0, 0);
-      }
+        for (int g = 0; g < C::BNF; ++g)
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[cur][g], acc[i][g], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

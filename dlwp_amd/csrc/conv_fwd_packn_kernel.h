@@ -157,20 +157,26 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
     if (c0 + C::CK < a.Cin) prefetch(c0 + C::CK);
     // K order (channel group, row tap u, column offset t): zero entries of W' contribute exact zeros, so each output
     // element sees the same non-zero products in the same order as in the plain kernel
+    //    Fragments double-buffered in registers, reads of step s+1 pinned before the MFMAs of step s (see the plain kernel).
+    constexpr int NSTEPS = (C::CK / 4) * C::TAPS;
+    float af[2][C::FA], bf[2];
+    auto load_frags = [&](int step, int buf) {
+      const int c4 = step / C::TAPS, tap = step - c4 * C::TAPS;
+      const int u = tap / C::KWE, t = tap - u * C::KWE;
+      bf[buf] = ws[bbase + (tap * C::CK + c4 * 4) * 16];
 #pragma unroll
-    for (int c4 = 0; c4 < C::CK / 4; ++c4) {
+      for (int i = 0; i < C::FA; ++i)
+        af[buf][i] = xs[abase[i] + (c4 * 4) * C::PS + u * C::DIL * C::LCS + (t % C::S) * C::Q + t / C::S];
+    };
+    load_frags(0, 0);
 #pragma unroll
-      for (int u = 0; u < C::KS; ++u) {
+    for (int step = 0; step < NSTEPS; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < NSTEPS) load_frags(step + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < C::KWE; ++t) {
-          const float bf = ws[bbase + ((u * C::KWE + t) * C::CK + c4 * 4) * 16];
-#pragma unroll
-          for (int i = 0; i < C::FA; ++i) {
-            const float af = xs[abase[i] + (c4 * 4) * C::PS + u * C::DIL * C::LCS + (t % C::S) * C::Q + t / C::S];
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[i], 0, 0, 0);
-          }
-        }
-      }
+      for (int i = 0; i < C::FA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[cur], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

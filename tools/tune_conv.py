@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--layers', default='')
     ap.add_argument('--out', default='')
+    ap.add_argument('--cfg', type=int, default=-2, help='only time this configuration index (-1 = heuristic only)')
     a = ap.parse_args()
     h, w = (int(v) for v in a.grid.split('x'))
     cfgs = ops.conv_configs()
@@ -53,6 +54,8 @@ def main():
         rows = []
         for i, c in enumerate(cfgs):
             if (c[0], c[1]) != (k, dil) or bool(c[8]) != (src == 2) or (c[6] < 0 and cout > 16 // (-c[6])):
+                continue
+            if a.cfg != -2 and i != a.cfg:
                 continue
             ops.force_conv_config(i)
             try:
