@@ -12,15 +12,24 @@ int dlwp_launch_reduce_slabs(dlwp_handle_t h, const float* slabs, float* out, lo
 
 namespace {
 
-//                              KS DIL TH TW  NT WAVES
+//                              KS DIL TH TW  NT
 const WgradKernelEntry k_wgrad[] = {
-    WGRAD_ENTRY(3, 1, 8, 32, 2, 4), WGRAD_ENTRY(3, 1, 8, 32, 4, 4), WGRAD_ENTRY(3, 1, 8, 32, 1, 4),
-    WGRAD_ENTRY(3, 1, 4, 48, 2, 4), WGRAD_ENTRY(3, 1, 4, 48, 4, 4), WGRAD_ENTRY(3, 1, 8, 36, 2, 4),
-    WGRAD_ENTRY(3, 1, 8, 36, 4, 4),
-    WGRAD_ENTRY(3, 2, 8, 32, 2, 4), WGRAD_ENTRY(3, 2, 8, 32, 4, 4), WGRAD_ENTRY(3, 2, 8, 32, 1, 4),
-    WGRAD_ENTRY(3, 2, 8, 36, 2, 4), WGRAD_ENTRY(3, 2, 8, 36, 4, 4), WGRAD_ENTRY(3, 2, 4, 48, 2, 4),
-    WGRAD_ENTRY(5, 1, 8, 32, 1, 4), WGRAD_ENTRY(5, 1, 8, 32, 2, 4), WGRAD_ENTRY(5, 1, 8, 36, 1, 4),
-    WGRAD_ENTRY(5, 1, 8, 36, 2, 4), WGRAD_ENTRY(5, 1, 4, 48, 1, 4),
+    WGRAD_ENTRY(3, 1, 4, 32, 4), WGRAD_ENTRY(3, 1, 4, 32, 2), WGRAD_ENTRY(3, 1, 4, 32, 1), WGRAD_ENTRY(3, 1, 8, 32, 4),
+    WGRAD_ENTRY(3, 1, 8, 32, 2), WGRAD_ENTRY(3, 1, 4, 48, 4), WGRAD_ENTRY(3, 1, 4, 48, 2), WGRAD_ENTRY(3, 1, 2, 48, 4),
+    WGRAD_ENTRY(3, 1, 8, 16, 4), WGRAD_ENTRY(3, 1, 4, 16, 2),
+    WGRAD_ENTRY(3, 2, 4, 32, 4), WGRAD_ENTRY(3, 2, 4, 32, 2), WGRAD_ENTRY(3, 2, 4, 32, 1), WGRAD_ENTRY(3, 2, 8, 32, 2),
+    WGRAD_ENTRY(3, 2, 8, 36, 2), WGRAD_ENTRY(3, 2, 4, 36, 2), WGRAD_ENTRY(3, 2, 8, 32, 4), WGRAD_ENTRY(3, 2, 4, 16, 2),
+    WGRAD_ENTRY(5, 1, 4, 32, 1), WGRAD_ENTRY(5, 1, 8, 32, 1), WGRAD_ENTRY(5, 1, 8, 36, 1), WGRAD_ENTRY(5, 1, 4, 32, 2),
+    WGRAD_ENTRY(5, 1, 8, 32, 2), WGRAD_ENTRY(5, 1, 4, 16, 1),
+    // pixel-split waves: few output channels (NT = 1) or to fill 4 waves with NT = 2
+    WGRAD_ENTRY_P(5, 1, 8, 32, 1, 4), WGRAD_ENTRY_P(5, 1, 4, 32, 1, 4), WGRAD_ENTRY_P(5, 1, 8, 32, 2, 2),
+    WGRAD_ENTRY_P(3, 1, 4, 32, 1, 4), WGRAD_ENTRY_P(3, 1, 4, 32, 2, 2), WGRAD_ENTRY_P(3, 1, 8, 32, 2, 2),
+    WGRAD_ENTRY_P(3, 2, 4, 32, 1, 4), WGRAD_ENTRY_P(3, 2, 4, 32, 2, 2), WGRAD_ENTRY_P(3, 2, 8, 32, 2, 2),
+    WGRAD_ENTRY_P(3, 2, 8, 36, 2, 2), WGRAD_ENTRY_P(3, 1, 4, 48, 2, 2),
+    // few input channels (first layer): 4 or 8 channels per block, taps folded into the M fragment rows
+    WGRAD_ENTRY_C(3, 2, 8, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 2, 4, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 2, 8, 32, 2, 2, 8),
+    WGRAD_ENTRY_C(3, 1, 8, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 1, 8, 32, 2, 2, 8), WGRAD_ENTRY_C(5, 1, 8, 32, 2, 2, 4),
+    WGRAD_ENTRY_C(5, 1, 8, 32, 2, 2, 8), WGRAD_ENTRY_C(5, 1, 8, 32, 1, 4, 8),
 };
 constexpr int N_WGRAD = (int)(sizeof(k_wgrad) / sizeof(k_wgrad[0]));
 char g_wg_prepared[N_WGRAD] = {0};
@@ -40,12 +49,17 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
     if (g_forced_wgrad >= 0 && i != g_forced_wgrad) continue;
     const double tiles = (double)dlwp_ceil_div(Ho, e.th) * dlwp_ceil_div(Wo, e.tw);
     const double co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
-    const double ci_groups = dlwp_ceil_div(Cin, 16);
-    // padded MFMA count + staging traffic (x tile re-read per co tile, dz tile per ci group), per image
+    const double ci_groups = dlwp_ceil_div(Cin, e.cib);
+    const double mfrags = (e.ks * e.ks * e.cib + 15) / 16;
+    // padded MFMA count per image (all waves) + staging traffic (x tile re-read per co tile, dz tile per ci group)
     const int lr = e.th + e.dil * (e.ks - 1), lc = e.tw + e.dil * (e.ks - 1);
-    const double mfma = tiles * (e.th * e.tw / 4.0) * e.ks * e.ks * e.nt * co_tiles * ci_groups;
-    const double stage = tiles * co_tiles * ci_groups * (16.0 * lr * lc + 16.0 * e.nt * e.th * e.tw) / 64.0 * 0.5;
-    const double c = mfma + stage;
+    const double mfma = tiles * (e.th * e.tw / 4.0) * mfrags * e.nt * co_tiles * ci_groups;
+    const double stage = tiles * co_tiles * ci_groups * ((double)e.cib * lr * lc + 16.0 * e.nt * e.th * e.tw);
+    int resident = (160 * 1024) / e.lds_bytes;
+    if (resident > 16 / e.waves) resident = 16 / e.waves;
+    if (resident < 1) resident = 1;
+    const double imbalance = (e.waves % 4) ? 1.25 : 1.0;  // 1- and 2-wave workgroups leave SIMDs idle (measured)
+    const double c = mfma * (1.0 + 0.3 / resident) * imbalance + 0.02 * stage;
     if (best < 0 || c < best_cost) {
       best = i;
       best_cost = c;
@@ -56,17 +70,19 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
   out->idx = best;
   out->tiles_h = dlwp_ceil_div(Ho, e.th);
   out->tiles_w = dlwp_ceil_div(Wo, e.tw);
-  out->ci_groups = dlwp_ceil_div(Cin, 16);
+  out->ci_groups = dlwp_ceil_div(Cin, e.cib);
   out->co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
   const long long total_tiles = (long long)N * out->tiles_h * out->tiles_w;
-  long long splits = ((long long)h->cu_count * 4) / ((long long)out->ci_groups * out->co_tiles);
+  // enough workgroups to fill the chip a few times over (16 waves per CU), every split walks >= 2 tiles
+  long long splits = ((long long)h->cu_count * 16 * 2) / ((long long)e.waves * out->ci_groups * out->co_tiles);
+  if (splits > total_tiles / 2) splits = total_tiles / 2;
   if (splits < 1) splits = 1;
-  if (splits > total_tiles) splits = total_tiles;
-  // bound slab memory to 128 MiB
+  // bound slab memory to 64 MiB
   const long long slab_bytes = (long long)e.ks * e.ks * Cin * Cout * 4;
-  while (splits > 1 && splits * e.waves * slab_bytes > (128ll << 20)) splits /= 2;
+  while (splits > 1 && splits * slab_bytes > (64ll << 20)) splits /= 2;
+  while (splits > 1 && splits * e.pw * slab_bytes > (64ll << 20)) splits /= 2;
   out->splits = (int)splits;
-  out->nslabs = (int)splits * e.waves;
+  out->nslabs = (int)splits * e.pw;
   return true;
 }
 
@@ -227,7 +243,7 @@ int dlwp_conv2d_wgrad_num_configs(void) { return N_WGRAD; }
 int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes) {
   DLWP_CHECK_ARG(i >= 0 && i < N_WGRAD && info6, "dlwp_conv2d_wgrad_config_info: index out of range");
   const WgradKernelEntry& e = k_wgrad[i];
-  const int v[6] = {e.ks, e.dil, e.th, e.tw, e.nt, e.waves};
+  const int v[6] = {e.ks, e.dil, e.th, e.tw, e.nt, e.waves};  // waves = nt * pixel-split waves
   for (int k = 0; k < 6; ++k) info6[k] = v[k];
   if (lds_bytes) *lds_bytes = e.lds_bytes;
   return DLWP_OK;

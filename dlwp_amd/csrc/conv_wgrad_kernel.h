@@ -6,10 +6,13 @@
 // channels per block, N = 16*NT output channels.  One v_mfma_f32_16x16x4_f32 consumes 4 consecutive pixels of a row:
 //   A lane l -> xs[ci = l&15][pixel + (l>>4) + tap offset]   (same haloed LDS tile the forward kernel uses)
 //   B lane l -> dz[co = l&15][pixel + (l>>4)]
-// A block keeps all KS*KS*NT accumulator fragments for its (ci group, co tile) in registers while it walks over its
-// share of the (image, spatial tile) list ("split-K over pixels"); every wave owns a private set and writes a private
-// partial slab at the end, and a second kernel sums the slabs in a fixed order -> deterministic, atomic-free.
+// Wave w of a block owns output-channel fragment w (16 couts) for ALL pixels of the tile: KS*KS accumulator fragments
+// per wave (36 registers for 3x3), no cross-wave reduction.  A block keeps them in registers while it walks over its
+// share of the (image, spatial tile) list ("split-K over pixels") and writes ONE partial slab at the end; a second
+// kernel sums the slabs in a fixed order -> deterministic, atomic-free.
 // LDS plane strides are == 2 (mod 32) floats: lanes (ci, k) of one ds_read_b32 group then hit 32 distinct banks.
+// All global loads are unconditional on clamped addresses (no exec-mask branch per load); fragments are
+// double-buffered in registers with the reads of pixel quad q+1 pinned in front of the MFMAs of quad q.
 #pragma once
 #include "conv_fwd_kernel.h"
 
@@ -23,9 +26,15 @@ struct WgradArgs {
   int tiles_h, tiles_w, total_tiles, splits, ci_groups, co_tiles;
 };
 
-template <int KS_, int DIL_, int TH_, int TW_, int NT_, int WAVES_>
+template <int KS_, int DIL_, int TH_, int TW_, int NT_, int PW_ = 1, int CIB_ = 16>
 struct WgCfg {
-  static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, NT = NT_, WAVES = WAVES_;
+  static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, NT = NT_, PW = PW_;
+  // CIB input channels per block.  The 16 rows of an M fragment are (tap, ci) pairs, ci fastest: with CIB = 16 one
+  // fragment = one tap x 16 channels; with CIB = 4 (first layer: cin = 4) one fragment = 4 taps x 4 channels, so a
+  // 3x3 kernel needs 3 fragments instead of 9 and the LDS tile holds 4 channel planes instead of 16.
+  static constexpr int CI = CIB_;
+  static constexpr int MF = (KS_ * KS_ * CIB_ + 15) / 16;
+  static constexpr int WAVES = NT * PW;  // wave = (cout fragment, pixel-quad residue class); PW > 1 -> PW slabs per split
   static constexpr int NTHREADS = WAVES * 64;
   static constexpr int LR = TH + DIL * (KS - 1), LC = TW + DIL * (KS - 1);
   static constexpr int PSX_RAW = LR * LC;
@@ -33,13 +42,15 @@ struct WgCfg {
   static constexpr int P = TH * TW;
   static constexpr int PSZ = P + (((2 - P % 32) % 32) + 32) % 32;  // == 2 (mod 32)
   static constexpr int TAPS = KS * KS;
-  static constexpr int CI = 16;
   static constexpr int X_FLOATS = CI * PSX;
   static constexpr int Z_FLOATS = 16 * NT * PSZ;
   static constexpr int LDS_BYTES = (X_FLOATS + Z_FLOATS) * 4;
   static constexpr int NPOS = (LR * LC + NTHREADS - 1) / NTHREADS;
+  static constexpr int NZ = (16 * NT * P + NTHREADS - 1) / NTHREADS;  // dz elements per thread per tile (= 16*P/64)
   static constexpr int QUADS = P / 4;
   static_assert(TW % 4 == 0, "pixel quads must not straddle rows");
+  static_assert(QUADS % (2 * PW) == 0, "the quad loop is unrolled by 2 per pixel-wave");
+  static_assert((16 * NT * P) % NTHREADS == 0, "dz tile must divide evenly over the threads");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
 
@@ -62,103 +73,134 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
   const int t_begin = split * per;
   const int t_end = min(a.total_tiles, t_begin + per);
 
-  f32x4 acc[C::TAPS][C::NT];
+  f32x4 acc[C::MF];
 #pragma unroll
-  for (int t = 0; t < C::TAPS; ++t)
-#pragma unroll
-    for (int g = 0; g < C::NT; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < C::MF; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const long long plane = (long long)a.Hs * a.Ws;
   const long long oplane = (long long)a.Ho * a.Wo;
-  const int a_lane = (lane & 15) * C::PSX + (lane >> 4);
-  const int b_lane = (lane & 15) * C::PSZ + (lane >> 4);
+  // A-fragment lane offsets: row m = 16*f + (lane & 15) -> (tap, ci) = (m / CI, m % CI); rows past TAPS*CI read tap 0
+  int a_off[C::MF];
+#pragma unroll
+  for (int f = 0; f < C::MF; ++f) {
+    const int m = f * 16 + (lane & 15);
+    const int tap = m / C::CI < C::TAPS ? m / C::CI : 0, ci = m % C::CI;
+    const int u = tap / C::KS, v = tap - u * C::KS;
+    a_off[f] = ci * C::PSX + u * C::DIL * C::LC + v * C::DIL + (lane >> 4);
+  }
+  const int wn = wave % C::NT, wp = wave / C::NT;
+  const int b_lane = (wn * 16 + (lane & 15)) * C::PSZ + (lane >> 4);
 
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // tile-independent part of the loader bookkeeping
+  int x_lr[C::NPOS], x_lc[C::NPOS];
+#pragma unroll
+  for (int k = 0; k < C::NPOS; ++k) {
+    const int s = min(tid + k * C::NTHREADS, C::LR * C::LC - 1);  // surplus threads duplicate the last position
+    x_lr[k] = s / C::LC;
+    x_lc[k] = s - x_lr[k] * C::LC;
+  }
+  int z_co[C::NZ], z_r[C::NZ], z_c[C::NZ];
+#pragma unroll
+  for (int k = 0; k < C::NZ; ++k) {
+    const int e = tid + k * C::NTHREADS;
+    z_co[k] = e / C::P;
+    const int p = e - z_co[k] * C::P;
+    z_r[k] = p / C::TW;
+    z_c[k] = p - z_r[k] * C::TW;
+  }
+
+  // register-staged pipeline over tiles: the loads of tile t+1 are in flight under tile t's MFMA loop
+  float xv[C::NPOS][C::CI], zv[C::NZ];
+  bool xok[C::NPOS], zok[C::NZ];
+  auto prefetch = [&](int tile) {
     int q = tile;
     const int tw = q % a.tiles_w;
     q /= a.tiles_w;
     const int th = q % a.tiles_h;
     const int n = q / a.tiles_h;
     const int i0 = th * C::TH, j0 = tw * C::TW;
-    __syncthreads();  // previous tile consumed
-    // ---- haloed input tile, 16 channels (zero beyond Cin)
-    const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off + ci0) * plane;
+    const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
 #pragma unroll
     for (int k = 0; k < C::NPOS; ++k) {
-      const int s = tid + k * C::NTHREADS;
-      if (s < C::LR * C::LC) {
-        const int lr = s / C::LC, lc = s - lr * C::LC;
-        const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
-        const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
-        const bool ok = rs >= 0 && cs >= 0;
-        int g = 0;
-        if (ok) {
-          if (a.src_mode == DLWP_SRC_UPSAMPLE2) g = (rs >> 1) * a.Ws + (cs >> 1);
-          else if (a.src_mode == DLWP_SRC_MAXPOOL2) g = (rs * 2) * a.Ws + cs * 2;
-          else g = rs * a.Ws + cs;
-        }
-        float v[C::CI];
+      const int rs = dlwp_map_coord(i0 + x_lr[k] - a.pad_top, a.H, a.mode_h);
+      const int cs = dlwp_map_coord(j0 + x_lc[k] - a.pad_left, a.W, a.mode_w);
+      xok[k] = rs >= 0 && cs >= 0;
+      int g = 0;
+      if (xok[k]) {
+        if (a.src_mode == DLWP_SRC_UPSAMPLE2) g = (rs >> 1) * a.Ws + (cs >> 1);
+        else if (a.src_mode == DLWP_SRC_MAXPOOL2) g = (rs * 2) * a.Ws + cs * 2;
+        else g = rs * a.Ws + cs;
+      }
 #pragma unroll
-        for (int ci = 0; ci < C::CI; ++ci) {
-          float val = 0.f;
-          if (ok && ci0 + ci < a.Cin) {
-            const float* sp = xn + (long long)ci * plane + g;
-            if (a.src_mode == DLWP_SRC_MAXPOOL2) val = fmaxf(fmaxf(sp[0], sp[1]), fmaxf(sp[a.Ws], sp[a.Ws + 1]));
-            else val = sp[0];
-          }
-          v[ci] = val;
-        }
-#pragma unroll
-        for (int ci = 0; ci < C::CI; ++ci) xs[ci * C::PSX + lr * C::LC + lc] = v[ci];
+      for (int ci = 0; ci < C::CI; ++ci) {
+        const float* sp = xn + (long long)min(ci0 + ci, a.Cin - 1) * plane + g;
+        if (a.src_mode == DLWP_SRC_MAXPOOL2) xv[k][ci] = fmaxf(fmaxf(sp[0], sp[1]), fmaxf(sp[a.Ws], sp[a.Ws + 1]));
+        else xv[k][ci] = sp[0];
       }
     }
-    // ---- dz tile [16*NT co][P pixels], zero outside the image / beyond Cout
-    const float* zn = a.dz + ((long long)n * a.dz_c_total + a.dz_c_off + co0) * oplane;
-    for (int e = tid; e < 16 * C::NT * C::P; e += C::NTHREADS) {
-      const int co = e / C::P, p = e - co * C::P;
-      const int r = p / C::TW, c = p - r * C::TW;
-      const int oh = i0 + r, ow = j0 + c;
-      float v = 0.f;
-      if (oh < a.Ho && ow < a.Wo && co0 + co < a.Cout) v = zn[(long long)co * oplane + (long long)oh * a.Wo + ow];
-      zs[co * C::PSZ + p] = v;
+    const float* zn = a.dz + ((long long)n * a.dz_c_total + a.dz_c_off) * oplane;
+#pragma unroll
+    for (int k = 0; k < C::NZ; ++k) {
+      const int oh = i0 + z_r[k], ow = j0 + z_c[k];
+      zok[k] = oh < a.Ho && ow < a.Wo && co0 + z_co[k] < a.Cout;
+      const int co = min(co0 + z_co[k], a.Cout - 1);
+      zv[k] = zn[(long long)co * oplane + (long long)min(oh, a.Ho - 1) * a.Wo + min(ow, a.Wo - 1)];
     }
+  };
+
+  if (t_begin < t_end) prefetch(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();  // previous tile consumed
+#pragma unroll
+    for (int k = 0; k < C::NPOS; ++k)
+#pragma unroll
+      for (int ci = 0; ci < C::CI; ++ci)
+        xs[ci * C::PSX + x_lr[k] * C::LC + x_lc[k]] = (xok[k] && ci0 + ci < a.Cin) ? xv[k][ci] : 0.f;
+#pragma unroll
+    for (int k = 0; k < C::NZ; ++k) zs[z_co[k] * C::PSZ + z_r[k] * C::TW + z_c[k]] = zok[k] ? zv[k] : 0.f;
     __syncthreads();
-    // ---- each wave takes every WAVES-th pixel quad
-    for (int qd = wave; qd < C::QUADS; qd += C::WAVES) {
+    if (tile + 1 < t_end) prefetch(tile + 1);
+
+    // ---- pixel quads: 1 B fragment + MF A fragments -> MF MFMAs, double-buffered
+    float af[2][C::MF], bf[2];
+    auto load_quad = [&](int qd, int buf) {
       const int p = qd * 4;
       const int r = p / C::TW, c = p - r * C::TW;
-      const int xb = a_lane + r * C::LC + c;
-      float bf[C::NT];
+      const int xb = r * C::LC + c;
+      bf[buf] = zs[b_lane + p];
 #pragma unroll
-      for (int g = 0; g < C::NT; ++g) bf[g] = zs[b_lane + g * 16 * C::PSZ + p];
+      for (int t = 0; t < C::MF; ++t) af[buf][t] = xs[xb + a_off[t]];
+    };
+    load_quad(wp, 0);
+    for (int qd = wp; qd < C::QUADS; qd += 2 * C::PW) {
+      load_quad(qd + C::PW, 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < C::TAPS; ++t) {
-        const int u = t / C::KS, v = t - u * C::KS;
-        const float af = xs[xb + u * C::DIL * C::LC + v * C::DIL];
+      for (int t = 0; t < C::MF; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][t], bf[0], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (qd + 2 * C::PW < C::QUADS) load_quad(qd + 2 * C::PW, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < C::NT; ++g) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[g], acc[t][g], 0, 0, 0);
-      }
+      for (int t = 0; t < C::MF; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][t], bf[1], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
-  // ---- private partial slab of this wave: slab index = split*WAVES + wave
-  float* slab = a.slabs + (long long)(split * C::WAVES + wave) * C::TAPS * a.Cin * a.Cout;
-  const int co_l = lane & 15;
+  // ---- one partial slab per (block split, pixel-wave)
+  float* slab = a.slabs + (long long)(split * C::PW + wp) * C::TAPS * a.Cin * a.Cout;
+  const int co = co0 + wn * 16 + (lane & 15);
 #pragma unroll
-  for (int t = 0; t < C::TAPS; ++t)
+  for (int f = 0; f < C::MF; ++f)
 #pragma unroll
-    for (int g = 0; g < C::NT; ++g) {
-      const int co = co0 + g * 16 + co_l;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = ci0 + (lane >> 4) * 4 + r;
-        if (ci < a.Cin && co < a.Cout) slab[((long long)t * a.Cin + ci) * a.Cout + co] = acc[t][g][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int m = f * 16 + (lane >> 4) * 4 + r;
+      const int t = m / C::CI, ci = ci0 + m % C::CI;
+      if (t < C::TAPS && ci < a.Cin && co < a.Cout) slab[((long long)t * a.Cin + ci) * a.Cout + co] = acc[f][r];
     }
 }
 
 struct WgradKernelEntry {
-  int ks, dil, th, tw, nt, waves, lds_bytes;
+  int ks, dil, th, tw, nt, waves, lds_bytes, pw, cib;
   void (*launch)(const WgradArgs&, int grid, hipStream_t s);
   int (*prepare)();
 };
@@ -176,8 +218,10 @@ static int wgrad_prepare() {
   return 0;
 }
 
-#define WGRAD_ENTRY(KS, DIL, TH, TW, NT, WAVES)                                              \
-  {                                                                                           \
-    KS, DIL, TH, TW, NT, WAVES, WgCfg<KS, DIL, TH, TW, NT, WAVES>::LDS_BYTES,                 \
-        &wgrad_launch_thunk<WgCfg<KS, DIL, TH, TW, NT, WAVES>>, &wgrad_prepare<WgCfg<KS, DIL, TH, TW, NT, WAVES>> \
+#define WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, PW, CIB)                                                                    \
+  {                                                                                                                     \
+    KS, DIL, TH, TW, NT, NT * PW, WgCfg<KS, DIL, TH, TW, NT, PW, CIB>::LDS_BYTES, PW, CIB,                              \
+        &wgrad_launch_thunk<WgCfg<KS, DIL, TH, TW, NT, PW, CIB>>, &wgrad_prepare<WgCfg<KS, DIL, TH, TW, NT, PW, CIB>>   \
   }
+#define WGRAD_ENTRY_P(KS, DIL, TH, TW, NT, PW) WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, PW, 16)
+#define WGRAD_ENTRY(KS, DIL, TH, TW, NT) WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, 1, 16)

@@ -45,18 +45,28 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   }
 }
 
-// db[c] = sum over (n, hw) of dz[n, c_off + c, hw]: one block per channel, fixed tree
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dz, float* __restrict__ db, int N, int C,
-                                                        int c_off, int c_total, int hw) {
-  const int c = blockIdx.x;
-  float s = 0.f, dummy = 0.f;
+// db[c] = sum over (n, hw) of dz[n, c_off + c, hw], two stages with a fixed tree (deterministic):
+//   stage 1: block (c, s) sums slice s of BIAS_SPLIT of the N*hw elements of channel c  -> partial[c][s]
+//   stage 2: one wave per channel sums the BIAS_SPLIT partials
+constexpr int BIAS_SPLIT = 64;
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dz, float* __restrict__ partial,
+                                                                int N, int c_off, int c_total, int hw) {
+  const int c = blockIdx.x, sidx = blockIdx.y;
   const long long per = (long long)N * hw;
-  for (long long i = threadIdx.x; i < per; i += 256) {
+  const long long chunk = (per + BIAS_SPLIT - 1) / BIAS_SPLIT;
+  const long long lo = sidx * chunk, hi = lo + chunk < per ? lo + chunk : per;
+  float s = 0.f, dummy = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const long long n = i / hw, p = i - n * hw;
     s += dz[(n * c_total + c_off + c) * hw + p];
   }
   block_sum2(s, dummy);
-  if (threadIdx.x == 0) db[c] = s;
+  if (threadIdx.x == 0) partial[c * BIAS_SPLIT + sidx] = s;
+}
+
+__global__ __launch_bounds__(64) void bias_grad_final_kernel(const float* __restrict__ partial, float* __restrict__ db) {
+  const float v = wave_sum(partial[blockIdx.x * BIAS_SPLIT + threadIdx.x]);
+  if (threadIdx.x == 0) db[blockIdx.x] = v;
 }
 
 // stage 1 of the loss: per-block partial sums of (d^2, |d|) and the gradient dy = scale * d
@@ -117,13 +127,26 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
   }
 }
 
-// out[i] = sum_s slabs[s][i]  (fixed order s = 0..S-1), optionally out += (accumulate)
+// out[i] = sum_s slabs[s][i]  (fixed order: 8 interleaved partial sums over s, combined in a fixed tree), optionally
+// out += (accumulate).  8 independent loads in flight per thread.
+template <int VEC>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            long long n, int S, int accumulate) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    float s = accumulate ? out[i] : 0.f;
-    for (int k = 0; k < S; ++k) s += slabs[(long long)k * n + i];
-    out[i] = s;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const long long nv = n / VEC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    vec_t part[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[j] = (vec_t)(0.f);
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part[j] += *(const vec_t*)(slabs + (long long)(k + j) * n + i * VEC);
+    }
+    for (int j = 0; k < S; ++k, ++j) part[j] += *(const vec_t*)(slabs + (long long)k * n + i * VEC);
+    vec_t s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    if (accumulate) s += *(const vec_t*)(out + i * VEC);
+    *(vec_t*)(out + i * VEC) = s;
   }
 }
 
@@ -167,7 +190,10 @@ int dlwp_launch_flip_transpose(dlwp_handle_t h, const float* w, float* wt, int k
 
 int dlwp_launch_reduce_slabs(dlwp_handle_t h, const float* slabs, float* out, long long n, int S, int accumulate,
                              hipStream_t s) {
-  reduce_slabs_kernel<<<grid_for(n, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);
+  if (n % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0)
+    reduce_slabs_kernel<4><<<grid_for(n / 4, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);
+  else
+    reduce_slabs_kernel<1><<<grid_for(n, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);
   DLWP_LAUNCH_CHECK("reduce_slabs_kernel");
   return DLWP_OK;
 }
@@ -184,13 +210,18 @@ int dlwp_act_bwd(dlwp_handle_t h, const void* y, const void* dy, void* dz, size_
   return DLWP_OK;
 }
 
-int dlwp_bias_grad(dlwp_handle_t h, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, int dtype,
-                   void* stream) {
-  DLWP_CHECK_ARG(h && dz && db, "dlwp_bias_grad: null handle or pointer");
+size_t dlwp_bias_grad_workspace(int c) { return (size_t)(c > 0 ? c : 0) * BIAS_SPLIT * sizeof(float); }
+
+int dlwp_bias_grad(dlwp_handle_t h, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, void* ws,
+                   size_t ws_bytes, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && dz && db && ws, "dlwp_bias_grad: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n >= 0 && c > 0 && hw > 0 && c_off >= 0 && c_off + c <= c_total,
                  "dlwp_bias_grad: bad arguments");
-  bias_grad_kernel<<<c, 256, 0, (hipStream_t)stream>>>((const float*)dz, (float*)db, n, c, c_off, c_total, hw);
-  DLWP_LAUNCH_CHECK("bias_grad_kernel");
+  DLWP_CHECK_ARG(ws_bytes >= dlwp_bias_grad_workspace(c), "dlwp_bias_grad: workspace too small");
+  bias_grad_partial_kernel<<<dim3(c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>((const float*)dz, (float*)ws, n, c_off,
+                                                                              c_total, hw);
+  bias_grad_final_kernel<<<c, 64, 0, (hipStream_t)stream>>>((const float*)ws, (float*)db);
+  DLWP_LAUNCH_CHECK("bias_grad kernels");
   return DLWP_OK;
 }
 

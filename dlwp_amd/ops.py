@@ -199,6 +199,19 @@ def workspace(device, nbytes):
     return ws
 
 
+_workspaces2 = {}
+
+
+def workspace2(device, nbytes):
+    """A second, small scratch allocation (reduction partials) that may be live next to `workspace`."""
+    key = (device.type, device.index)
+    ws = _workspaces2.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces2[key] = ws
+    return ws
+
+
 def conv_bwd_workspace_bytes(dev_index, xs, cd, which):
     out = ctypes.c_size_t()
     _lib.check(_lib.lib.dlwp_conv2d_bwd_workspace(_lib.handle(dev_index), xs, ctypes.byref(cd), int(which),
@@ -238,8 +251,9 @@ def act_bwd(y, dy, act, out=None):
 def bias_grad(dz, db, c, c_off=0):
     _check_f32(dz, db)
     n, c_total, h, w = dz.shape
+    ws = workspace2(dz.device, _lib.lib.dlwp_bias_grad_workspace(int(c)))
     _lib.check(_lib.lib.dlwp_bias_grad(_lib.handle(_dev(dz)), _ptr(dz), _ptr(db), n, int(c), int(c_off), c_total, h * w,
-                                       _lib.F32, _stream(dz)))
+                                       _ptr(ws), ws.numel(), _lib.F32, _stream(dz)))
     return db
 
 
@@ -272,3 +286,18 @@ def axpby(x, y, a=1.0, b=1.0):
     _check_f32(x, y)
     _lib.check(_lib.lib.dlwp_axpby(_lib.handle(_dev(x)), _ptr(x), _ptr(y), x.numel(), float(a), float(b), _stream(x)))
     return y
+
+
+def wgrad_configs():
+    """[(ks, dil, th, tw, cout_frags, waves, lds_bytes)] of the compiled weight-gradient tiles."""
+    out = []
+    info = (ctypes.c_int * 6)()
+    lds = ctypes.c_int()
+    for i in range(_lib.lib.dlwp_conv2d_wgrad_num_configs()):
+        _lib.check(_lib.lib.dlwp_conv2d_wgrad_config_info(i, info, ctypes.byref(lds)))
+        out.append(tuple(info) + (lds.value,))
+    return out
+
+
+def force_wgrad_config(i):
+    _lib.lib.dlwp_conv2d_wgrad_force_config(int(i))

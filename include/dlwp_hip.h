@@ -124,8 +124,9 @@ int dlwp_conv2d_wgrad_force_config(int i);
  *      dlwp_mse_mae: out2[0] = mean((yp-yt)^2), out2[1] = mean(|yp-yt|) (device floats); dy (nullable) =
  *      loss_weight * 2*(yp-yt)/n.  ws >= dlwp_mse_mae_workspace() bytes.                                                */
 int    dlwp_act_bwd(dlwp_handle_t, const void* y, const void* dy, void* dz, size_t n, int act, int dtype, void* stream);
-int    dlwp_bias_grad(dlwp_handle_t, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, int dtype,
-                      void* stream);
+size_t dlwp_bias_grad_workspace(int c);
+int    dlwp_bias_grad(dlwp_handle_t, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, void* ws,
+                      size_t ws_bytes, int dtype, void* stream);
 size_t dlwp_mse_mae_workspace(dlwp_handle_t);
 int    dlwp_mse_mae(dlwp_handle_t, const void* y_pred, const void* y_true, size_t n, void* out2, void* dy,
                     float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream);
