@@ -41,6 +41,27 @@ def build_model(grid, cin, seed=1234):
     return d
 
 
+def measured_traffic(cfg_tuple, members):
+    """HBM bytes per launch of a conv tile configuration from the committed rocprofv3 --pmc passes
+    (profiles/*hbm_traffic_b256.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes, 256 members),
+    scaled to `members`.  None when that configuration was not profiled."""
+    import glob
+    ks, dil, th, tw, waves, fa, bnf, ck, pool = cfg_tuple[:9]
+    if bnf < 0:
+        key = 'PackCfg<%d, %d, %d, %d, %d, %d, %d, %d>' % (ks, dil, th, tw, waves, fa, ck, -bnf)
+    else:
+        key = 'ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %s>' % (ks, dil, th, tw, waves, fa, bnf, ck, 'true' if pool else 'false')
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_b256.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for name, e in d.items():
+            if key in name and 'hbm_read_bytes' in e and 'hbm_write_bytes' in e:
+                return (e['hbm_read_bytes'] + e['hbm_write_bytes']) * members / 256.0, os.path.basename(f)
+    return None, None
+
+
 def time_layers(model, members, iters=5):
     """Per-launch duration of every kernel of one forward, HIP events on the stream the kernels are launched on."""
     from dlwp_amd import ops
@@ -69,7 +90,12 @@ def time_layers(model, members, iters=5):
         co, ho, wo = op.out_shape
         flops = 2.0 * ho * wo * co * op.xs[0] * kh * kw * members
         nbytes = 4.0 * members * (op.xs[0] * op.xs[1] * op.xs[2] + co * ho * wo) + 4.0 * kh * kw * op.xs[0] * co
-        rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': lay.dilation_rate[0],
+        from dlwp_amd import _lib
+        import ctypes
+        pick = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(model.device.index or 0),
+                                                _lib.Shape4(members, op.xs[0], op.xs[1], op.xs[2]), ctypes.byref(d))
+        cfg = ops.conv_configs()[pick] if pick >= 0 else None
+        rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': lay.dilation_rate[0], 'tile_cfg': cfg,
                      'out': [ho, wo], 'ms': ms, 'tflops': flops / ms / 1e9, 'gbs': nbytes / ms / 1e6,
                      'flops': flops, 'bytes': nbytes})
     return rows
@@ -214,9 +240,14 @@ def main():
         out['roofline'] = {'bound': 'mfma', 'kernel': 'conv2d_fwd_mfma_f32 (%s: %d->%d, %dx%d dil %d, %dx%d)' %
                            (dom['layer'], dom['cin'], dom['cout'], dom['k'], dom['k'], dom['dil'], dom['out'][0], dom['out'][1]),
                            'achieved': dom['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': dom['tflops'] / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                           'frac': dom['tflops'] / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'traffic_unit': 'bytes per launch',
+                           'algorithmic_bytes_per_launch': dom['bytes'],
                            'launch_ms': dom['ms'], 'algorithmic_flops_per_launch': dom['flops'],
                            'share_of_forward_time': dom['ms'] / tot}
+        if dom.get('tile_cfg'):
+            tr, src = measured_traffic(dom['tile_cfg'], a.members)
+            out['roofline']['traffic'] = tr
+            out['roofline']['traffic_source'] = src
         out['layers'] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k not in ('flops', 'bytes')}
                          for r in rows]
         out['forward']['sum_of_kernel_ms'] = tot

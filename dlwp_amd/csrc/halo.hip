@@ -28,59 +28,76 @@ static inline int grid_for(long long work_items, int block, int cu_count) {
 // shifted / wrapped / clamped position.  The shift by `left*inner` elements that makes direct vector copies
 // misaligned is absorbed by LDS.
 // ------------------------------------------------------------------------------------------------------------------ //
-template <int VEC>
+// column map for padding amounts <= W (validated by the host): one conditional add instead of an integer modulo
+__device__ __forceinline__ int pad_map_col(int p, int n, int mode) {
+  if (p >= 0 && p < n) return p;
+  if (mode == DLWP_PAD_ZERO) return -1;
+  if (mode == DLWP_PAD_EDGE) return p < 0 ? 0 : n - 1;
+  return p < 0 ? p + n : p - n;
+}
+
+template <int VEC, bool INNER1>
 __global__ __launch_bounds__(256) void pad2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int outer,
                                                         int H, int W, int inner, int Ho, int Wo, int top, int left,
-                                                        int mode_h, int mode_w, int row_lds /* floats per wave slice */) {
+                                                        int mode_h, int mode_w, int row_lds /* floats per row slot */) {
+  // Every wave works alone on its own LDS slots (ROWS output rows per trip): no workgroup barrier anywhere -- a
+  // wave's DS instructions execute in program order, so its ds_reads see its own preceding ds_writes.  The ROWS rows
+  // are walked as ONE flat list of VEC-wide slots so that all 64 lanes stay busy although a row is only ~46 slots.
+  constexpr int ROWS = 4;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  float* row = lds + wave * row_lds;
+  float* slot = lds + wave * ROWS * row_lds;
   const int RI = W * inner, RO = Wo * inner;
+  const int RIV = RI / VEC, ROV = RO / VEC;
   const long long n_rows = (long long)outer * Ho;
-  const long long waves_total = (long long)gridDim.x * 4;
-  // uniform trip count per block so __syncthreads() is legal
-  const long long iters = (n_rows + waves_total - 1) / waves_total;
-  for (long long it = 0; it < iters; ++it) {
-    const long long r = it * waves_total + (long long)blockIdx.x * 4 + wave;
-    const bool live = r < n_rows;
-    int o = 0, ho = 0, hs = -1;
-    if (live) {
-      o = (int)(r / Ho);
-      ho = (int)(r - (long long)o * Ho);
-      hs = dlwp_map_coord(ho - top, H, mode_h);
-    }
-    __syncthreads();  // previous row fully consumed
-    if (live && hs >= 0) {
-      const float* src = x + ((long long)o * H + hs) * RI;
-      if (VEC == 4) {
-        for (int j = lane * 4; j < RI; j += 256) *(f32x4*)(row + j) = *(const f32x4*)(src + j);
-      } else {
-        for (int j = lane; j < RI; j += 64) row[j] = src[j];
-      }
-    }
-    __syncthreads();
-    if (!live) continue;
-    float* dst = y + r * RO;
-    if (VEC == 4) {
-      for (int j = lane * 4; j < RO; j += 256) {
-        f32x4 v;
+  const long long stride = (long long)gridDim.x * 4 * ROWS;
+  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * ROWS; r0 < n_rows; r0 += stride) {
+    // source row (in rows of the whole input tensor) of each of the ROWS output rows, -1 = zero row / past the end
+    long long srow[ROWS];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = j + k;
-          const int wo = e / inner, ch = e - wo * inner;
-          const int ws = dlwp_map_coord(wo - left, W, mode_w);
-          v[k] = (hs >= 0 && ws >= 0) ? row[ws * inner + ch] : 0.f;
-        }
-        *(f32x4*)(dst + j) = v;
-      }
-    } else {
-      for (int e = lane; e < RO; e += 64) {
-        const int wo = e / inner, ch = e - wo * inner;
-        const int ws = dlwp_map_coord(wo - left, W, mode_w);
-        dst[e] = (hs >= 0 && ws >= 0) ? row[ws * inner + ch] : 0.f;
+    for (int k = 0; k < ROWS; ++k) {
+      const long long r = r0 + k;
+      srow[k] = -1;
+      if (r < n_rows) {
+        const int o = (int)(r / Ho);
+        const int hs = dlwp_map_coord((int)(r - (long long)o * Ho) - top, H, mode_h);
+        if (hs >= 0) srow[k] = (long long)o * H + hs;
       }
     }
+    for (int j = lane; j < ROWS * RIV; j += 64) {
+      const int k = (j >= RIV) + (j >= 2 * RIV) + (j >= 3 * RIV);
+      const int c = (j - k * RIV) * VEC;
+      const long long sr = k == 0 ? srow[0] : (k == 1 ? srow[1] : (k == 2 ? srow[2] : srow[3]));
+      if (sr >= 0) *(vec_t*)(slot + k * row_lds + c) = *(const vec_t*)(x + sr * RI + c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = lane; j < ROWS * ROV; j += 64) {
+      const int k = (j >= ROV) + (j >= 2 * ROV) + (j >= 3 * ROV);
+      const int c = (j - k * ROV) * VEC;
+      const long long r = r0 + k;
+      if (r >= n_rows) continue;
+      const long long sr = k == 0 ? srow[0] : (k == 1 ? srow[1] : (k == 2 ? srow[2] : srow[3]));
+      const float* row = slot + k * row_lds;
+      vec_t v;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        const int e = c + q;
+        int wo = e, ch = 0;
+        if (!INNER1) {
+          wo = e / inner;
+          ch = e - wo * inner;
+        }
+        const int ws = pad_map_col(wo - left, W, mode_w);
+        v[q] = (sr >= 0 && ws >= 0) ? row[(ws >= 0 ? ws : 0) * (INNER1 ? 1 : inner) + ch] : 0.f;
+      }
+      *(vec_t*)(y + r * RO + c) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -258,20 +275,28 @@ int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, in
   const int Ho = H + p.top + p.bottom, Wo = W + p.left + p.right;
   const long long RI = (long long)W * inner, RO = (long long)Wo * inner;
   const int row_lds = (int)((RI + 3) / 4 * 4);
-  const size_t lds_bytes = (size_t)row_lds * 4 * sizeof(float);
+  const size_t lds_bytes = (size_t)row_lds * 4 * 4 * sizeof(float);  // 4 waves x ROWS(4) row slots
   DLWP_CHECK_ARG(lds_bytes <= (size_t)h->lds_bytes, "dlwp_pad2d_fwd: row of %lld floats does not fit in LDS", RI);
   const long long n_rows = (long long)outer * Ho;
-  int grid = (int)((n_rows + 3) / 4);
+  int grid = (int)((n_rows + 15) / 16);
   const int cap = h->cu_count * 8;
   if (grid > cap) grid = cap;
   const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(x) && aligned16(y);
+  const bool vec2 = (RI % 2 == 0) && (RO % 2 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 7) == 0;
   hipStream_t s = (hipStream_t)stream;
-  if (vec)
-    pad2d_fwd_kernel<4><<<grid, 256, lds_bytes, s>>>((const float*)x, (float*)y, outer, H, W, inner, Ho, Wo, p.top,
-                                                    p.left, p.mode_h, p.mode_w, row_lds);
-  else
-    pad2d_fwd_kernel<1><<<grid, 256, lds_bytes, s>>>((const float*)x, (float*)y, outer, H, W, inner, Ho, Wo, p.top,
-                                                    p.left, p.mode_h, p.mode_w, row_lds);
+#define PAD_LAUNCH(V, I1)                                                                                            \
+  pad2d_fwd_kernel<V, I1><<<grid, 256, lds_bytes, s>>>((const float*)x, (float*)y, outer, H, W, inner, Ho, Wo, p.top, \
+                                                       p.left, p.mode_h, p.mode_w, row_lds)
+  if (inner == 1) {
+    if (vec) PAD_LAUNCH(4, true);
+    else if (vec2) PAD_LAUNCH(2, true);
+    else PAD_LAUNCH(1, true);
+  } else {
+    if (vec) PAD_LAUNCH(4, false);
+    else if (vec2) PAD_LAUNCH(2, false);
+    else PAD_LAUNCH(1, false);
+  }
+#undef PAD_LAUNCH
   DLWP_LAUNCH_CHECK("pad2d_fwd_kernel");
   return DLWP_OK;
 }
