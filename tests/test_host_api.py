@@ -367,3 +367,20 @@ def test_compute_paths_fail_loudly_without_a_gpu():
     d.build_model(cnn2_layers((2, 9, 12), hidden=8), loss='mse')
     with pytest.raises(RuntimeError):
         d.predict(np.zeros((1, 2, 9, 12), np.float32))
+
+
+def test_compat_shim_registers_reference_module_names():
+    import importlib
+    import dlwp_amd.compat  # noqa: F401
+    from DLWP.model import DLWPNeuralNet as A, DataGenerator as G
+    from DLWP.custom import PeriodicPadding2D as PP, EarlyStoppingMin, slice_layer  # noqa: F401
+    from DLWP.util import save_model, load_model, get_from_class  # noqa: F401
+    from keras.layers import Input, ZeroPadding2D, Conv2D, MaxPooling2D, UpSampling2D, concatenate  # noqa: F401
+    from keras.models import Model as KM
+    from keras.callbacks import History  # noqa: F401
+    from keras.losses import mean_squared_error
+    assert A is DLWPNeuralNet and G is DataGenerator and PP is custom.PeriodicPadding2D and KM is Model
+    d = A(is_convolutional=True, time_dim=1, scaler_type=None, scale_targets=False)
+    d.build_model(cnn2_layers((2, 9, 12), hidden=8), loss=mean_squared_error, optimizer='adam', metrics=['mae'])
+    assert d.model.metrics_names == ['loss', 'mean_absolute_error']
+    assert importlib.import_module('DLWP.model.models').DLWPFunctional is DLWPFunctional
