@@ -101,6 +101,111 @@ __global__ __launch_bounds__(256) void mse_mae_final_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ //
+// custom losses of the reference: anomaly_correlation_loss (DLWP/custom.py:1036-1088, the default of examples/train.py:43)
+// and latitude_weighted_loss (custom.py:956-991), optionally nested (lat-weighted ACC, train.py:224-234).
+//   y' = w[h] * y (row weights, or 1);  P = yp' - M, T = yt' - M (M = climatology broadcast over the batch, or 0)
+//   a = mean(P T) / sqrt(mean(P^2) mean(T^2));  reg = mse(y') | mae(y') | 0;  loss = reg - a   (reverse=True form)
+//   kind 0: loss = mse(y')  (plain / latitude-weighted mse)      kind 1: loss = reg - a
+// stage 1 accumulates 7 sums per block, stage 2 folds them in a fixed order and leaves on the device
+//   stats = {loss, mse(unweighted), mae(unweighted), S_pt, S_pp, S_tt, reg}  -- the gradient kernel reads them there,
+// so the whole loss needs no host round trip.
+struct LossArgs {
+  const float* yp;
+  const float* yt;
+  const float* mean;      // (C*H*W) or null
+  const float* row_w;     // (H) or null
+  long long n;            // all elements
+  int chw, H, W;
+  int kind, reg;          // reg: 0 none, 1 mse, 2 mae
+};
+
+__device__ __forceinline__ void loss_terms(const LossArgs& a, long long i, float& d, float& dw, float& P, float& T,
+                                           float& w) {
+  const float yp = a.yp[i], yt = a.yt[i];
+  w = 1.f;
+  if (a.row_w) w = a.row_w[(int)((i / a.W) % a.H)];
+  const float m = a.mean ? a.mean[(int)(i % a.chw)] : 0.f;
+  d = yp - yt;
+  dw = w * d;
+  P = w * yp - m;
+  T = w * yt - m;
+}
+
+__global__ __launch_bounds__(256) void loss_stats_partial_kernel(const LossArgs a, float* __restrict__ partial) {
+  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+    float d, dw, P, T, w;
+    loss_terms(a, i, d, dw, P, T, w);
+    s[0] += d * d;
+    s[1] += fabsf(d);
+    s[2] += dw * dw;
+    s[3] += fabsf(dw);
+    s[4] += P * T;
+    s[5] += P * P;
+    s[6] += T * T;
+  }
+  float z = 0.f;
+  block_sum2(s[0], s[1]);
+  block_sum2(s[2], s[3]);
+  block_sum2(s[4], s[5]);
+  block_sum2(s[6], z);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 7; ++k) partial[7 * blockIdx.x + k] = s[k];
+}
+
+__global__ __launch_bounds__(256) void loss_stats_final_kernel(const float* __restrict__ partial, int nblocks,
+                                                               long long n, int kind, int reg, float* __restrict__ stats) {
+  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < nblocks; i += 256)
+    for (int k = 0; k < 7; ++k) s[k] += partial[7 * i + k];
+  float z = 0.f;
+  block_sum2(s[0], s[1]);
+  block_sum2(s[2], s[3]);
+  block_sum2(s[4], s[5]);
+  block_sum2(s[6], z);
+  if (threadIdx.x == 0) {
+    const float inv_n = 1.0f / (float)n;
+    const float mse_w = s[2] * inv_n, mae_w = s[3] * inv_n;
+    float loss, regv = 0.f;
+    if (kind == 0) {
+      loss = mse_w;
+    } else {
+      const float acc = s[4] / sqrtf(s[5] * s[6]);   // the 1/n factors cancel
+      regv = reg == 1 ? mse_w : (reg == 2 ? mae_w : 0.f);
+      loss = regv - acc;
+    }
+    stats[0] = loss;
+    stats[1] = s[0] * inv_n;
+    stats[2] = s[1] * inv_n;
+    stats[3] = s[4];
+    stats[4] = s[5];
+    stats[5] = s[6];
+    stats[6] = regv;
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const LossArgs a, const float* __restrict__ stats,
+                                                        float* __restrict__ dy, float loss_weight) {
+  const float inv_n = 1.0f / (float)a.n;
+  const float spt = stats[3], spp = stats[4], stt = stats[5];
+  const float inv_norm = a.kind == 1 ? 1.0f / sqrtf(spp * stt) : 0.f;
+  const float ratio = a.kind == 1 ? spt / spp : 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
+    float d, dw, P, T, w;
+    loss_terms(a, i, d, dw, P, T, w);
+    float g;  // dL / d(y'_pred)
+    if (a.kind == 0) {
+      g = 2.f * dw * inv_n;
+    } else {
+      g = -(T - ratio * P) * inv_norm;
+      if (a.reg == 1) g += 2.f * dw * inv_n;
+      else if (a.reg == 2) g += (dw > 0.f ? 1.f : (dw < 0.f ? -1.f : 0.f)) * inv_n;
+    }
+    dy[i] = loss_weight * w * g;
+  }
+}
+
 // Keras-form Adam on a flat buffer: p -= lr_t * m / (sqrt(v) + eps); g is scaled by grad_scale first (1/world for DP)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, long long n, float lr_t, float b1,
@@ -239,6 +344,35 @@ int dlwp_mse_mae(dlwp_handle_t h, const void* y_pred, const void* y_true, size_t
                                                                (float*)ws, (long long)n, 2.0f * loss_weight * inv_n);
   mse_mae_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>((const float*)ws, grid, inv_n, (float*)out2);
   DLWP_LAUNCH_CHECK("mse_mae kernels");
+  return DLWP_OK;
+}
+
+size_t dlwp_loss_workspace(dlwp_handle_t h) { return h ? (size_t)h->cu_count * 8 * 7 * sizeof(float) : 0; }
+
+int dlwp_loss_custom(dlwp_handle_t h, const void* y_pred, const void* y_true, int n, int c, int hh, int ww,
+                     const void* mean, const void* row_weights, int kind, int regularize, void* stats7, void* dy,
+                     float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && y_pred && y_true && stats7 && ws, "dlwp_loss_custom: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32 && n > 0 && c > 0 && hh > 0 && ww > 0, "dlwp_loss_custom: bad dtype / shape");
+  DLWP_CHECK_ARG((kind == 0 || kind == 1) && regularize >= 0 && regularize <= 2, "dlwp_loss_custom: bad kind / regularizer");
+  LossArgs a;
+  a.yp = (const float*)y_pred;
+  a.yt = (const float*)y_true;
+  a.mean = (const float*)mean;
+  a.row_w = (const float*)row_weights;
+  a.chw = c * hh * ww;
+  a.n = (long long)n * a.chw;
+  a.H = hh;
+  a.W = ww;
+  a.kind = kind;
+  a.reg = regularize;
+  const int grid = grid_for(a.n, h->cu_count);
+  DLWP_CHECK_ARG(ws_bytes >= (size_t)grid * 7 * sizeof(float), "dlwp_loss_custom: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  loss_stats_partial_kernel<<<grid, 256, 0, s>>>(a, (float*)ws);
+  loss_stats_final_kernel<<<1, 256, 0, s>>>((const float*)ws, grid, a.n, kind, regularize, (float*)stats7);
+  if (dy) loss_grad_kernel<<<grid, 256, 0, s>>>(a, (const float*)stats7, (float*)dy, loss_weight);
+  DLWP_LAUNCH_CHECK("loss_custom kernels");
   return DLWP_OK;
 }
 

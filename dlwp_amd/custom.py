@@ -44,6 +44,71 @@ def slice_layer(start, end, step=None, axis=1):
 
 
 # ------------------------------------------------------------------------------------------------------------------ #
+# custom losses (reference DLWP/custom.py:899-1093): descriptions consumed by the HIP loss kernels (dlwp_loss_custom)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+class LossSpec(object):
+    """What `anomaly_correlation_loss(...)` / `latitude_weighted_loss(...)` return: a description the trainer lowers to
+    dlwp_loss_custom.  kind 0 = (latitude-weighted) mse, kind 1 = regularizer - anomaly correlation."""
+
+    def __init__(self, kind, regularize=0, mean=None, row_weights=None, scale=1.0, name='loss'):
+        self.kind, self.regularize, self.scale = kind, regularize, scale
+        self.mean = None if mean is None else np.ascontiguousarray(mean, dtype=np.float32)
+        self.row_weights = None if row_weights is None else np.ascontiguousarray(row_weights, dtype=np.float32)
+        self.__name__ = name
+
+    def __call__(self, y_true, y_pred):
+        raise RuntimeError('%s is evaluated by the HIP loss kernel; pass it as loss= to build_model' % self.__name__)
+
+
+def latitude_weights(lats, weighting='cosine'):
+    """cos(lat) [+ 0.5 sin^2(2 lat) for 'midlatitude'] -- the function form of the reference (custom.py:975-978)."""
+    if weighting not in ['cosine', 'midlatitude']:
+        raise ValueError("'weighting' must be one of 'cosine' or 'midlatitude'")
+    lat = np.asarray(lats, dtype=np.float32) * np.float32(np.pi / 180.)
+    w = np.cos(lat)
+    if weighting == 'midlatitude':
+        w = w + np.float32(0.5) * np.sin(2 * lat) ** 2
+    return w.astype(np.float32)
+
+
+def anomaly_correlation_loss(mean=None, regularize_mean='mse', reverse=True):
+    """Anomaly-correlation loss, `regularizer - ACC` (reference custom.py:1036-1088; the default loss of
+    examples/train.py).  mean: climatology of shape (1,) + output shape, or None.  regularize_mean: None | 'mse' | 'mae'
+    ('global' / 'spatial' are not lowered to the device yet)."""
+    if mean is not None:
+        assert len(mean.shape) > 1
+        assert mean.shape[0] == 1
+    if regularize_mean is not None:
+        assert regularize_mean in ['global', 'spatial', 'mse', 'mae']
+        reverse = True
+        if regularize_mean in ('global', 'spatial'):
+            raise NotImplementedError("regularize_mean=%r is not implemented on the HIP path ('mse', 'mae', None are)"
+                                      % regularize_mean)
+    reg = {None: 0, 'mse': 1, 'mae': 2}[regularize_mean]
+    return LossSpec(1, reg, None if mean is None else np.asarray(mean)[0], None, 1.0 if reverse else -1.0, 'acc_loss')
+
+
+def latitude_weighted_loss(loss_function=None, lats=None, output_shape=(), axis=-2, weighting='cosine'):
+    """Weight predictions and targets by a function of latitude before the loss (reference custom.py:956-991).
+    loss_function: mean_squared_error (default) or the result of anomaly_correlation_loss(...)."""
+    if weighting not in ['cosine', 'midlatitude']:
+        raise ValueError("'weighting' must be one of 'cosine' or 'midlatitude'")
+    w = None
+    if lats is not None:
+        if axis != -2 and axis != len(output_shape) - 2:
+            raise NotImplementedError('latitude_weighted_loss: the latitude axis must be the second to last (axis=-2)')
+        w = latitude_weights(lats, weighting)
+    if isinstance(loss_function, LossSpec):
+        return LossSpec(loss_function.kind, loss_function.regularize, loss_function.mean, w, loss_function.scale,
+                        'lat_loss')
+    name = loss_function if isinstance(loss_function, str) else getattr(loss_function, '__name__', 'mean_squared_error')
+    if loss_function is not None and name not in ('mse', 'mean_squared_error'):
+        raise NotImplementedError('latitude_weighted_loss over %r is not implemented' % (loss_function,))
+    return LossSpec(0, 0, None, w, 1.0, 'lat_loss')
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
 # callbacks (host-side plumbing of examples/train.py:253-263)
 # ------------------------------------------------------------------------------------------------------------------ #
 

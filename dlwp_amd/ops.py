@@ -269,6 +269,19 @@ def mse_mae(y_pred, y_true, out2, dy=None, loss_weight=1.0):
     return out2
 
 
+def loss_custom(y_pred, y_true, stats7, dy=None, loss_weight=1.0, mean=None, row_weights=None, kind=0, regularize=0):
+    """The reference's custom losses (include/dlwp_hip.h: dlwp_loss_custom).  y: (n, c, h, w) device tensors."""
+    _check_f32(y_pred, y_true, stats7, dy, mean, row_weights)
+    n, c, hh, ww = y_pred.shape
+    d = _dev(y_pred)
+    h = _lib.handle(d)
+    ws = workspace(y_pred.device, _lib.lib.dlwp_loss_workspace(h))
+    _lib.check(_lib.lib.dlwp_loss_custom(h, _ptr(y_pred), _ptr(y_true), n, c, hh, ww, _ptr(mean), _ptr(row_weights),
+                                         int(kind), int(regularize), _ptr(stats7), _ptr(dy), float(loss_weight), _ptr(ws),
+                                         ws.numel(), _lib.F32, _stream(y_pred)))
+    return stats7
+
+
 def adam_keras(p, m, v, g, iteration, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, decay=0.0, grad_scale=1.0):
     _check_f32(p, m, v, g)
     _lib.check(_lib.lib.dlwp_adam_keras(_lib.handle(_dev(p)), _ptr(p), _ptr(m), _ptr(v), _ptr(g), p.numel(), lr, beta_1,

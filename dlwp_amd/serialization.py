@@ -38,6 +38,14 @@ def _layer_config(lay):
     return cfg
 
 
+def _loss_config(loss):
+    from .custom import LossSpec
+    if isinstance(loss, LossSpec):
+        return {'spec': {'kind': loss.kind, 'regularize': loss.regularize, 'scale': loss.scale, 'name': loss.__name__,
+                         'has_mean': loss.mean is not None, 'has_row_weights': loss.row_weights is not None}}
+    return loss if isinstance(loss, str) else getattr(loss, '__name__', None)
+
+
 def describe(model):
     from . import plan as P
     order = P.toposort(model.outputs)
@@ -55,7 +63,7 @@ def describe(model):
         arch['compile'] = {
             'optimizer': {'class': type(opt).__name__,
                           'config': {k: v for k, v in vars(opt).items() if isinstance(v, (int, float))}},
-            'loss': model.loss if isinstance(model.loss, str) else getattr(model.loss, '__name__', None),
+            'loss': _loss_config(model.loss),
             'metrics': [m if isinstance(m, str) else getattr(m, '__name__', None) for m in model.metrics],
             'loss_weights': list(model.loss_weights) if model.loss_weights is not None else None}
     return arch, layers, order
@@ -72,6 +80,12 @@ def save_model_file(model, path):
         seen.add(id(lay))
         for (nm, _), a in zip(lay._weights, lay.get_weights()):
             arrays['%s/%s' % (lay.name, nm)] = a
+    from .custom import LossSpec
+    if isinstance(model.loss, LossSpec):
+        if model.loss.mean is not None:
+            arrays['__loss_mean__'] = model.loss.mean
+        if model.loss.row_weights is not None:
+            arrays['__loss_row_weights__'] = model.loss.row_weights
     buf = io.BytesIO()
     np.savez(buf, __arch__=np.frombuffer(json.dumps(arch).encode('utf-8'), dtype=np.uint8), **arrays)
     with open(path, 'wb') as f:
@@ -122,5 +136,10 @@ def load_model_file(path, custom_objects=None, device=None):
         iters = int(ocfg.pop('iterations', 0))
         opt = ocls(**ocfg)
         opt.iterations = iters
-        model.compile(optimizer=opt, loss=comp['loss'], metrics=comp['metrics'], loss_weights=comp['loss_weights'])
+        loss = comp['loss']
+        if isinstance(loss, dict):
+            sp = loss['spec']
+            loss = C.LossSpec(sp['kind'], sp['regularize'], data['__loss_mean__'] if sp['has_mean'] else None,
+                              data['__loss_row_weights__'] if sp['has_row_weights'] else None, sp['scale'], sp['name'])
+        model.compile(optimizer=opt, loss=loss, metrics=comp['metrics'], loss_weights=comp['loss_weights'])
     return model

@@ -65,12 +65,15 @@ def mean_absolute_error(y_true, y_pred):
 
 
 def _loss_name(loss):
+    from .custom import LossSpec
+    if isinstance(loss, LossSpec):
+        return 'custom'
     name = loss if isinstance(loss, str) else getattr(loss, '__name__', None)
     if name in ('mse', 'MSE', 'mean_squared_error'):
         return 'mse'
-    raise NotImplementedError("loss %r is not implemented on the HIP path yet ('mse' / mean_squared_error is; the "
-                              "custom anomaly-correlation / latitude-weighted losses are listed as next rows in "
-                              "DESIGN.md)" % (loss,))
+    raise NotImplementedError("loss %r is not implemented on the HIP path ('mse' / mean_squared_error, "
+                              "dlwp_amd.custom.anomaly_correlation_loss(...) and latitude_weighted_loss(...) are)"
+                              % (loss,))
 
 
 _METRIC_NAMES = {'mae': 'mean_absolute_error', 'mean_absolute_error': 'mean_absolute_error',
@@ -140,6 +143,7 @@ class Trainer(object):
         self.dp = getattr(model, '_dp', None)
         self._grad_bufs = {}
         self._loss_out = None
+        self._loss_consts = None      # device copies of a custom loss's climatology / latitude weights
 
     # -- helpers ------------------------------------------------------------------------------------------------------ #
     def _grad_view(self, layer, name):
@@ -167,32 +171,52 @@ class Trainer(object):
 
     # -- forward + loss ------------------------------------------------------------------------------------------------ #
     def _forward_loss(self, x, ys, want_grad, weight_scale=1.0):
-        """Returns (outs, loss_vals tensor [n_out, 2] on device, dys or None)."""
+        """Returns (outs, loss table [n_out, 7] on device: col 0 custom-loss value, 1 mse, 2 mae, dys or None)."""
         from . import ops
         outs = self.model.executor.run(x)
         n_out = len(outs)
         if self._loss_out is None or self._loss_out.shape[0] != n_out:
-            self._loss_out = torch.zeros((n_out, 2), dtype=torch.float32, device=self.device)
+            self._loss_out = torch.zeros((n_out, 7), dtype=torch.float32, device=self.device)
+        spec = self.model.loss if self.loss_kind == 'custom' else None
+        if spec is not None and self._loss_consts is None:
+            mean = None if spec.mean is None else torch.from_numpy(spec.mean).to(self.device).contiguous()
+            roww = None if spec.row_weights is None else torch.from_numpy(spec.row_weights).to(self.device).contiguous()
+            self._loss_consts = (mean, roww)
         dys = []
         for o, (yp, yt) in enumerate(zip(outs, ys)):
             dy = torch.empty_like(yp) if want_grad else None
-            ops.mse_mae(yp, yt, self._loss_out[o], dy, self.loss_weights[o] * weight_scale)
+            lw = self.loss_weights[o] * weight_scale
+            if spec is None:
+                ops.mse_mae(yp, yt, self._loss_out[o, 1:3], dy, lw)
+            else:
+                mean, roww = self._loss_consts
+                if yp.dim() != 4:
+                    raise NotImplementedError('custom losses need (n, c, h, w) outputs')
+                if mean is not None and mean.numel() != yp[0].numel():
+                    raise ValueError('anomaly_correlation_loss mean has %d elements, the model output %d per sample'
+                                     % (mean.numel(), yp[0].numel()))
+                if roww is not None and roww.numel() != yp.shape[2]:
+                    raise ValueError('latitude weights have %d rows, the model output %d' % (roww.numel(), yp.shape[2]))
+                ops.loss_custom(yp, yt, self._loss_out[o], dy, lw * spec.scale, mean, roww, spec.kind, spec.regularize)
             dys.append(dy)
         return outs, self._loss_out, dys
 
     def _report(self, loss_vals):
-        """[loss, (per-output losses), metrics...] as python floats from the device [n_out, 2] (mse, mae) table."""
+        """[loss, (per-output losses), metrics...] as python floats from the device loss table."""
         v = loss_vals.detach().cpu().numpy().astype(np.float64)
         return self._report_from(v)
 
     def _report_from(self, v):
         n_out = v.shape[0]
-        total = float(sum(w * v[o, 0] for o, w in enumerate(self.loss_weights)))
-        col = {'mean_squared_error': 0, 'mean_absolute_error': 1}
+        if self.loss_kind == 'custom':
+            per_out = [float(self.model.loss.scale * v[o, 0]) for o in range(n_out)]
+        else:
+            per_out = [float(v[o, 1]) for o in range(n_out)]
+        total = float(sum(w * l for w, l in zip(self.loss_weights, per_out)))
+        col = {'mean_squared_error': 1, 'mean_absolute_error': 2}
         if n_out == 1:
             return [total] + [float(v[0, col[k]]) for k in self.metric_keys]
-        return ([total] + [float(v[o, 0]) for o in range(n_out)] +
-                [float(v[o, col[k]]) for o in range(n_out) for k in self.metric_keys])
+        return ([total] + per_out + [float(v[o, col[k]]) for o in range(n_out) for k in self.metric_keys])
 
     # -- backward ------------------------------------------------------------------------------------------------------ #
     def _backward(self, x, outs, dys):

@@ -408,3 +408,70 @@ def test_reference_style_example_script_runs_end_to_end(tmp_path):
     finally:
         sys.argv = argv
     assert len(score) == 2 and np.isfinite(score[0]) and series.shape == (8, 12, 2, 16, 24)
+
+
+def test_custom_losses_match_reference_goldens_and_autograd(golden):
+    """anomaly_correlation_loss / latitude_weighted_loss on the device: VALUES pinned by tests/golden/losses.npz (produced by
+    running the reference's own loss functions under the numpy-K shim), gradients against torch autograd of the oracle
+    formula."""
+    from dlwp_amd import custom, ops
+    g = golden('losses')
+    yt, yp, climo, lats = g['y_true'], g['y_pred'], g['climo'], g['lats']
+    ypd, ytd = torch.from_numpy(yp).cuda(), torch.from_numpy(yt).cuda()
+    stats = torch.zeros(7, device='cuda')
+
+    def run(spec):
+        dy = torch.empty_like(ypd)
+        mean = None if spec.mean is None else torch.from_numpy(spec.mean).cuda()
+        roww = None if spec.row_weights is None else torch.from_numpy(spec.row_weights).cuda()
+        ops.loss_custom(ypd, ytd, stats, dy, spec.scale, mean, roww, spec.kind, spec.regularize)
+        torch.cuda.synchronize()
+        return spec.scale * float(stats[0]), dy.cpu().numpy(), stats.cpu().numpy()
+
+    def torch_loss(spec, p):
+        t = torch.tensor(yt, dtype=torch.float64)
+        w = torch.ones(1, dtype=torch.float64) if spec.row_weights is None else \
+            torch.tensor(spec.row_weights, dtype=torch.float64)[None, None, :, None]
+        m = torch.zeros(1, dtype=torch.float64) if spec.mean is None else torch.tensor(spec.mean, dtype=torch.float64)[None]
+        pw, tw = p * w, t * w
+        if spec.kind == 0:
+            return ((pw - tw) ** 2).mean()
+        P, T = pw - m, tw - m
+        a = (P * T).mean() / torch.sqrt((P * P).mean() * (T * T).mean())
+        reg = {0: 0.0, 1: ((pw - tw) ** 2).mean(), 2: (pw - tw).abs().mean()}[spec.regularize]
+        return spec.scale * (reg - a)
+
+    for reg in (None, 'mse', 'mae'):
+        for use_mean in (False, True):
+            spec = custom.anomaly_correlation_loss(climo if use_mean else None, regularize_mean=reg, reverse=True)
+            val, dy, st = run(spec)
+            want = float(g['acc_%s_%d' % (reg, int(use_mean))])
+            assert val == pytest.approx(want, rel=2e-5, abs=2e-6), (reg, use_mean)
+            assert st[1] == pytest.approx(np_ref.mse(yt, yp), rel=1e-5) and st[2] == pytest.approx(np_ref.mae(yt, yp), rel=1e-5)
+            p = torch.tensor(yp, dtype=torch.float64, requires_grad=True)
+            torch_loss(spec, p).backward()
+            assert np.abs(dy - p.grad.numpy()).max() <= 2e-5 * np.abs(p.grad.numpy()).max(), (reg, use_mean)
+    for weighting in ('cosine', 'midlatitude'):
+        spec = custom.latitude_weighted_loss(None, lats, (4, 6, 8), axis=-2, weighting=weighting)
+        val, dy, _ = run(spec)
+        assert val == pytest.approx(float(g['latw_%s' % weighting]), rel=2e-5)
+        p = torch.tensor(yp, dtype=torch.float64, requires_grad=True)
+        torch_loss(spec, p).backward()
+        assert np.abs(dy - p.grad.numpy()).max() <= 2e-5 * np.abs(p.grad.numpy()).max()
+    # nested, as examples/train.py:224-234 builds it, and trained through build_model
+    spec = custom.latitude_weighted_loss(custom.anomaly_correlation_loss(climo, regularize_mean='mse'), lats, (4, 6, 8),
+                                         axis=-2, weighting='midlatitude')
+    val, dy, _ = run(spec)
+    p = torch.tensor(yp, dtype=torch.float64, requires_grad=True)
+    ref = torch_loss(spec, p)
+    ref.backward()
+    assert val == pytest.approx(float(ref.detach()), rel=2e-5)
+    assert np.abs(dy - p.grad.numpy()).max() <= 2e-5 * np.abs(p.grad.numpy()).max()
+    rng = np.random.default_rng(12)
+    cs = (4, 6, 8)
+    d = _build(cnn2_layers(cs, hidden=8), time_dim=2, loss=spec)
+    x = rng.standard_normal((8,) + cs).astype(np.float32)
+    l0 = d.model.train_on_batch(x, yt[:1].repeat(8, axis=0) * 0 + x)
+    for _ in range(30):
+        l1 = d.model.train_on_batch(x, x)
+    assert d.model.metrics_names == ['loss', 'mean_absolute_error'] and l1[0] < l0[0] and -1.1 < l1[0]

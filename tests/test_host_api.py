@@ -348,6 +348,20 @@ def test_save_and_load_model_round_trip(tmp_path):
     assert all(np.array_equal(a, b) for a, b in zip(w0, d2.model.get_weights()))
     assert [op.kind for op in d2.model.plan.ops] == ['conv', 'conv']
     assert d2.model.optimizer.lr == pytest.approx(1e-3) and d2.model.metrics_names == ['loss', 'mean_absolute_error']
+    # a custom loss survives the round trip (examples/train.py saves models compiled with the ACC loss)
+    climo = np.random.default_rng(0).standard_normal((1, 2, 9, 12)).astype(np.float32)
+    lats = np.linspace(80, -80, 9)
+    d3 = _dlwp(time_dim=2)
+    d3.build_model(cnn2_layers((2, 9, 12), hidden=8), optimizer='adam', metrics=['mae'],
+                   loss=custom.latitude_weighted_loss(custom.anomaly_correlation_loss(climo, regularize_mean='mse'), lats,
+                                                      (2, 9, 12), axis=-2, weighting='midlatitude'))
+    util.save_model(d3, base + '_acc')
+    d4 = util.load_model(base + '_acc')
+    sp = d4.model.loss
+    assert isinstance(sp, custom.LossSpec) and (sp.kind, sp.regularize, sp.scale) == (1, 1, 1.0)
+    assert np.array_equal(sp.mean, climo[0]) and np.allclose(sp.row_weights, custom.latitude_weights(lats, 'midlatitude'))
+    with pytest.raises(NotImplementedError):
+        custom.anomaly_correlation_loss(None, regularize_mean='global')
     # functional graph with shared layers and skips
     x0, y = _skip_model((4, 8, 12))
     m = Model(inputs=x0, outputs=y)
