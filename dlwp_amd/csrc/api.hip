@@ -32,11 +32,14 @@ int dlwp_create(dlwp_handle_t* out, int device) {
   h->cu_count = prop.multiProcessorCount;
   h->lds_bytes = (int)prop.sharedMemPerBlock;
   strncpy(h->arch, prop.gcnArchName, sizeof(h->arch) - 1);
+  h->wino_u = nullptr;
+  h->wino_u_floats = 0;
   *out = h;
   return DLWP_OK;
 }
 
 int dlwp_destroy(dlwp_handle_t h) {
+  if (h && h->wino_u) (void)hipFree(h->wino_u);
   delete h;
   return DLWP_OK;
 }

@@ -11,7 +11,12 @@ struct dlwp_handle {
   int cu_count;
   int lds_bytes;
   char arch[64];
+  float* wino_u;        // transformed 3x3 filters of the Winograd path (conv_fwd.hip); fixed capacity, allocated once
+  size_t wino_u_floats;
 };
+
+// scratch for Cin x Cout transformed filters: NULL when it does not fit or cannot be allocated now (stream capture)
+float* dlwp_wino_scratch(dlwp_handle_t h, size_t floats, hipStream_t s);
 
 // thread-local error string (defined in api.hip)
 void dlwp_set_error(const char* fmt, ...);

@@ -34,6 +34,54 @@ std::mutex g_prepare_mutex;
 // forced configuration for tuning sweeps (-1 = heuristic); per-thread so concurrent handles do not interfere
 thread_local int g_forced_cfg = -1;
 
+// Winograd on/off (process-wide; DLWP_WINOGRAD=0 in the environment or dlwp_conv2d_set_winograd(0) disables it).
+// The kernel FAMILY is chosen from the layer geometry only -- never from the batch size -- so a sample's result does not
+// depend on its batch mates (within a family every tile configuration is bit-identical).
+int g_winograd = -1;
+bool winograd_enabled() {
+  if (g_winograd < 0) {
+    const char* e = getenv("DLWP_WINOGRAD");
+    g_winograd = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_winograd != 0;
+}
+// geometry the Winograd instances cover: 3x3, whole channel chunks (8 in, 32 out), no pooled loader, planes addressable
+// with 32-bit byte offsets, filters that fit the handle's scratch
+constexpr size_t WINO_SCRATCH_FLOATS = 8u << 20;  // 32 MB: Cin*Cout <= 512K
+bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
+  return winograd_enabled() && cd->kh == 3 && cd->kw == 3 && cd->dil_h == cd->dil_w && a.Cin % 8 == 0 &&
+         a.Cout % 32 == 0 && cd->src_mode != DLWP_SRC_MAXPOOL2 && (long long)a.Hs * a.Ws < (1ll << 28) &&
+         (size_t)a.Cin * a.Cout * 16 <= WINO_SCRATCH_FLOATS;
+}
+
+// U = G g G^T for all (ci, co): u[((ci*4 + r)*Cout + co)*4 + c] = U[r][c]; HWIO weights in.
+__global__ __launch_bounds__(256) void wino_filter_transform_f32(const float* __restrict__ w, float* __restrict__ u,
+                                                                  int Cin, int Cout) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Cin * Cout) return;
+  const int ci = e / Cout, co = e - ci * Cout;
+  float g[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) g[tap] = w[((long long)tap * Cin + ci) * Cout + co];
+  float tm[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float g0 = g[c], g1 = g[3 + c], g2 = g[6 + c];
+    tm[0][c] = g0;
+    tm[1][c] = 0.5f * (g0 + g1 + g2);
+    tm[2][c] = 0.5f * (g0 - g1 + g2);
+    tm[3][c] = g2;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float t0 = tm[r][0], t1 = tm[r][1], t2 = tm[r][2];
+    *(f32x4*)(u + (((long long)ci * 4 + r) * Cout + co) * 4) =
+        (f32x4){t0, 0.5f * (t0 + t1 + t2), 0.5f * (t0 - t1 + t2), t2};
+  }
+}
+
+
+
 int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void* y, dlwp_shape4 xs,
              const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
   DLWP_CHECK_ARG(h && cd && (xs.n == 0 || (x && w && y)), "%s: null handle or pointer", fn);
@@ -82,12 +130,14 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
 // chip runs one round, which steers small batches toward small tiles.
 double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   const long long tiles = (long long)dlwp_ceil_div(a.Ho, e.th) * dlwp_ceil_div(a.Wo, e.tw);
-  const int bnf = e.pack ? 1 : e.bnf;
-  const int kwe = e.pack ? (e.ks - 1) * e.dil + e.pack : e.ks;  // packed-N: effective kernel width
-  const long long cout_tiles = e.pack ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  const bool wino = e.pack < 0;
+  const int bnf = e.pack > 0 ? 1 : e.bnf;
+  const int kwe = e.pack > 0 ? (e.ks - 1) * e.dil + e.pack : e.ks;  // packed-N: effective kernel width
+  const long long cout_tiles = e.pack > 0 ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
   const double blocks = (double)tiles * cout_tiles * a.N;
-  const double ksteps = (double)dlwp_ceil_div(a.Cin, e.ck) * (e.ck / 4) * e.ks * kwe;
-  const double work = (double)e.waves * e.fa * bnf * ksteps;  // MFMAs of one workgroup
+  // MFMA steps per wave: direct = taps per 4-channel group; Winograd = 16 transformed positions per 4-channel group
+  const double ksteps = (double)dlwp_ceil_div(a.Cin, e.ck) * (e.ck / 4) * (wino ? 16 : e.ks * kwe);
+  const double work = (double)e.waves * e.fa * bnf * ksteps * (wino ? 1.3 : 1.0);  // MFMAs of one workgroup (+ transforms)
   int resident = (160 * 1024) / e.lds_bytes;
   if (resident > 16 / e.waves) resident = 16 / e.waves;
   if (resident > 8) resident = 8;
@@ -99,7 +149,7 @@ double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   // staging traffic of one workgroup (floats through LDS), a small term that mostly breaks ties toward larger tiles
   const int lr = e.th + e.dil * (e.ks - 1), lc = e.tw + e.dil * (e.ks - 1);
   const double stage = (double)dlwp_ceil_div(a.Cin, e.ck) *
-                       ((double)e.ck * lr * lc * (e.pool ? 4 : 1) + (double)e.ks * kwe * e.ck * 16.0 * bnf);
+                       ((double)e.ck * lr * lc * (e.pool ? 4 : 1) + (double)(wino ? 16 : e.ks * kwe) * e.ck * 16.0 * bnf);
   return rounds * (work * (1.0 + 0.3 / overlap) * imbalance + 0.01 * stage);
 }
 
@@ -109,18 +159,27 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if (g_forced_cfg >= (int)r.entries.size()) return -1;
     const ConvKernelEntry& e = r.entries[g_forced_cfg];
     const bool pool = cd->src_mode == DLWP_SRC_MAXPOOL2;
-    const bool pack_ok = e.pack == 0 || (cd->cout <= 16 / e.pack);
+    const bool pack_ok = e.pack <= 0 || (cd->cout <= 16 / e.pack);
+    if (e.pack < 0 && !winograd_wanted(a, cd)) return -1;  // Winograd instances: whole channel chunks only
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? g_forced_cfg
                : -1;
   }
   int best = -1;
   double best_cost = 0;
+  bool want_wino = winograd_wanted(a, cd);
+  if (want_wino) {  // fall back to the direct family when no Winograd instance matches (dilation / pooled loader)
+    bool any = false;
+    for (const ConvKernelEntry& e : r.entries)
+      any = any || (e.pack < 0 && e.dil == cd->dil_h && (e.pool != 0) == (cd->src_mode == DLWP_SRC_MAXPOOL2));
+    want_wino = any;
+  }
   for (int i = 0; i < (int)r.entries.size(); ++i) {
     const ConvKernelEntry& e = r.entries[i];
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
     if ((e.pool != 0) != (cd->src_mode == DLWP_SRC_MAXPOOL2)) continue;  // pooled loader <-> POOL instances only
-    if (e.pack != 0 && cd->cout > 16 / e.pack) continue;                   // packed-N instances cover cout <= 16/S
+    if (e.pack > 0 && cd->cout > 16 / e.pack) continue;                    // packed-N instances cover cout <= 16/S
+    if ((e.pack < 0) != want_wino) continue;                               // kernel family fixed by the layer geometry
     const double c = config_cost(e, a, cu_count);
     if (best < 0 || c < best_cost) {
       best = i;
@@ -205,12 +264,39 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   }
   a.tiles_h = dlwp_ceil_div(a.Ho, e.th);
   a.tiles_w = dlwp_ceil_div(a.Wo, e.tw);
-  a.cout_tiles = e.pack ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  a.cout_tiles = e.pack > 0 ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
   const long long grid = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
   DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
+  if (e.pack < 0) {  // Winograd: transform the filters into the handle's scratch, then multiply
+    float* u = dlwp_wino_scratch(h, (size_t)a.Cin * a.Cout * 16, s);
+    if (!u) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: no scratch for the transformed filters");
+    wino_filter_transform_f32<<<dlwp_ceil_div((long long)a.Cin * a.Cout, 256), 256, 0, s>>>(a.w, u, a.Cin, a.Cout);
+    DLWP_LAUNCH_CHECK("wino_filter_transform_f32");
+    a.w = u;
+  }
   e.launch(a, (int)grid, s);
   DLWP_LAUNCH_CHECK("conv2d_fwd_mfma_f32");
   return DLWP_OK;
+}
+
+float* dlwp_wino_scratch(dlwp_handle_t h, size_t floats, hipStream_t s) {
+  if (floats > WINO_SCRATCH_FLOATS) return nullptr;
+  if (!h->wino_u) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return nullptr;
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (!h->wino_u) {
+      float* p = nullptr;
+      if (hipMalloc(&p, WINO_SCRATCH_FLOATS * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+      h->wino_u = p;
+      h->wino_u_floats = WINO_SCRATCH_FLOATS;
+    }
+  }
+  return h->wino_u;
 }
 
 extern "C" {
@@ -268,9 +354,15 @@ int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes) {
   Registry& r = registry();
   DLWP_CHECK_ARG(i >= 0 && i < (int)r.entries.size() && info9, "dlwp_conv2d_config_info: index %d out of range", i);
   const ConvKernelEntry& e = r.entries[i];
-  const int v[9] = {e.ks, e.dil, e.th, e.tw, e.waves, e.fa, e.pack ? -e.pack : e.bnf, e.ck, e.pool};
-  for (int k = 0; k < 9; ++k) info9[k] = v[k];  // cout_frags < 0: packed-N instance with S = -cout_frags shifts
+  // cout_frags < 0: packed-N instance with S = -cout_frags shifts; frags_per_wave == 0: Winograd instance
+  const int v[9] = {e.ks, e.dil, e.th, e.tw, e.waves, e.pack < 0 ? 0 : e.fa, e.pack > 0 ? -e.pack : e.bnf, e.ck, e.pool};
+  for (int k = 0; k < 9; ++k) info9[k] = v[k];
   if (lds_bytes) *lds_bytes = e.lds_bytes;
+  return DLWP_OK;
+}
+
+int dlwp_conv2d_set_winograd(int enable) {
+  g_winograd = enable ? 1 : 0;
   return DLWP_OK;
 }
 

@@ -1,5 +1,6 @@
 // conv_fwd_k3d1.hip -- 3x3, dilation 1 tile configurations (U-Net layers 2-4: examples/train.py:174-199).
 #include "conv_fwd_packn_kernel.h"
+#include "conv_fwd_wino_kernel.h"
 //                         KS DIL TH  TW  WAVES FA BNF CK
 static const ConvKernelEntry k_table[] = {
     CONV_ENTRY(3, 1, 4, 45, 4, 3, 2, 16),
@@ -30,6 +31,9 @@ static const ConvKernelEntry k_table[] = {
     CONV_ENTRY_POOL(3, 1, 4, 16, 4, 1, 1, 4),
     PACKN_ENTRY(3, 1, 8, 64, 4, 2, 8, 4),
     PACKN_ENTRY(3, 1, 8, 32, 4, 2, 8, 2),
+    // Winograd F(2x2,3x3) instances (conv_fwd_wino_kernel.h): DIL TH TW WAVES BNF CK
+    WINO_ENTRY(1, 8, 32, 4, 2, 8),
+    WINO_ENTRY(1, 4, 64, 4, 2, 8),
 };
 const ConvKernelEntry* dlwp_conv_table_k3d1(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));

@@ -1,0 +1,368 @@
+// conv_fwd_wino_kernel.h -- 3x3 Conv2D forward as Winograd F(2x2, 3x3) on the fp32 matrix cores, gfx950.
+//
+// Five of the six convolutions of the reference U-Net are 3x3 (94 % of its FLOPs; examples/train.py:164-209).  On CDNA4 the
+// exact-fp32 MFMA runs at the vector rate (157 TF), so the direct implicit GEMM (conv_fwd_kernel.h) is bounded by the
+// multiply count itself; Winograd's minimal filtering cuts that count 2.25x:
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g
+//
+// Two kernels per convolution:
+//   wino_filter_transform_f32   U = G g G^T for every (ci, co), once per launch, into a scratch buffer of the handle laid
+//                               out [ci][xy/4][co][xy%4] (tiny: Cin*Cout threads);
+//   conv2d_fwd_wino_f32         one block = TH x TW outputs = T = TH*TW/4 tiles, 32 output channels, 8 input channels per
+//                               stage:
+//     * the haloed input tile is staged in LDS as in the direct kernel (wrap / zero / edge halo, fused 2x up-sampling);
+//       the loads are buffer loads whose out-of-range lanes return 0 -- the zero halo costs no instruction;
+//     * U goes to LDS as us[xy/4][ci][co][xy%4]: one ds_read_b128 = the B operands of 4 GEMMs;
+//     * every lane transforms V = B^T d B (32 adds) for exactly the (tile, channel) pairs it feeds to the MFMA as A
+//       operand -- V lives in REGISTERS, never in LDS;
+//     * 16 independent GEMMs M[xy][tile, co] += V[xy][tile, ci] * U[xy][ci, co] on v_mfma_f32_16x16x4_f32; wave w owns
+//       tile fragment w (16 tiles) for all 16 xy, so the 16 values of one (tile, co) end up in ONE lane, which applies
+//       A^T . A in registers after the last chunk, adds the bias and activates; the block's outputs are transposed
+//       through LDS so that the global stores are 16-byte row segments.
+// Measured on gfx950 (profiles/r1d_wino_knockout.txt): the fp32 MFMA does not overlap with VALU work of the same SIMD --
+// matrix time and vector time ADD -- so the loop is written to contain as few vector instructions as possible (scalar
+// bases + 32-bit lane offsets for every load, no selects, no address toggling: the loop is unrolled over the two LDS
+// buffers) and as a software pipeline (xs / us double buffered, loads two chunks ahead) so that no latency is exposed:
+//     MFMAs of channel group 0 of chunk k   |  V(group 1, k) from xs[k] ; registers -> xs[k+1] ; barrier A
+//     MFMAs of channel group 1 of chunk k   |  V(group 0, k+1) from xs[k+1] ; registers -> us[k+1] ; buffer loads of
+//                                           |  chunk k+2 ; barrier B
+// The loop body has no branch: the chunk after the last one is "staged" from clamped addresses and never used.
+// Dilation d (2 for the first / fifth layer) is the same algorithm on the d*d parity sub-lattices: tile elements are d
+// pixels apart.  Numerics: fp32 throughout; the transforms use only +, - and exact multiples of 1/2, 1/4, so the result
+// differs from the direct sum by ordinary fp32 round-off (measured <= 2e-6 of the output scale; tests use 1e-5).  The
+// summation order over input channels is fixed (chunks of 8 ascending), so every instance gives the same bits.
+#pragma once
+#include <type_traits>
+#include "conv_fwd_kernel.h"
+
+template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_>
+struct WinoCfg {
+  static constexpr int DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, BNF = BNF_, CK = CK_;
+  static constexpr int NT = WAVES * 64;
+  static constexpr int LR = TH + 2 * DIL, LC = TW + 2 * DIL;
+  static constexpr int LCS = LC;
+  static constexpr int PS_RAW = LR * LCS;
+  static constexpr int PS = PS_RAW + (((16 - PS_RAW % 32) % 32) + 32) % 32;
+  static constexpr int RTH = TH / (2 * DIL), RTW = TW / (2 * DIL);  // tiles per parity class
+  static constexpr int T = DIL * DIL * RTH * RTW;                      // = TH*TW/4
+  static constexpr int TPAD = 16 * WAVES;
+  static constexpr int BN = 16 * BNF;
+  static constexpr int X_FLOATS = CK * PS;
+  static constexpr int U_FLOATS = 16 * CK * BN;    // us[xy/4][ci][co][xy%4]
+  static constexpr int OPS = TH * TW + 4;          // output staging: plane stride of one channel
+  static constexpr int O_FLOATS = BN * OPS;
+  static constexpr int L_FLOATS = (2 * X_FLOATS + 2 * U_FLOATS) > O_FLOATS ? (2 * X_FLOATS + 2 * U_FLOATS) : O_FLOATS;
+  static constexpr int LDS_BYTES = L_FLOATS * 4;
+  static constexpr int NPOS = (LR * LC + NT - 1) / NT;
+  static constexpr int NXI = CK * NPOS;            // input elements per thread and chunk
+  static constexpr int NUI = (CK * BN) / NT;       // (ci, co) filter items per thread
+  static constexpr int NWI = 4 * NUI;              // float4 filter loads per thread and chunk
+  static constexpr int HL = 32;                    // MFMAs per channel group
+  static constexpr int BLOCKS = (8 / WAVES) < 1 ? 1 : 8 / WAVES;  // two waves per SIMD
+  static_assert(TH % (2 * DIL) == 0 && TW % (2 * DIL) == 0, "region must be whole 2x2 tiles on every parity class");
+  static_assert(TPAD >= T, "tiles must fit the wave decomposition");
+  static_assert(CK == 8 && BNF == 2, "the pipeline is written for two channel groups of 4 and 32 output channels");
+  static_assert((CK * BN) % NT == 0 && NUI >= 1, "every thread owns NUI whole (ci, co) items");
+  static_assert((TH * TW) % 4 == 0 && (BN * TH * TW / 4) % NT == 0, "output staging: whole float4 per thread");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT, C::BLOCKS) void conv2d_fwd_wino_f32(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int US0 = 2 * C::X_FLOATS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int L;
+  {
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int xcd = b & 7, idx = b >> 3, q = nb >> 3, r = nb & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tw = L % a.tiles_w;
+  L /= a.tiles_w;
+  const int th = L % a.tiles_h;
+  L /= a.tiles_h;
+  const int ct = L % a.cout_tiles;
+  const int n = L / a.cout_tiles;
+  const int i0 = th * C::TH, j0 = tw * C::TW, n0 = ct * C::BN;
+
+  // ---- input loader bookkeeping: byte offset inside a channel plane (0x7ffffff0 = out of range = reads 0) and the LDS
+  //      slot; the lanes past the tile of the last pass repeat element 0 (same value written twice: harmless)
+  unsigned goff[C::NPOS];
+  int loff[C::NPOS];
+#pragma unroll
+  for (int q = 0; q < C::NPOS; ++q) {
+    int s = tid + q * C::NT;
+    if (q == C::NPOS - 1 && s >= C::LR * C::LC) s = 0;
+    const int lr = s / C::LC, lc = s - lr * C::LC;
+    const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
+    const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
+    const bool ok = rs >= 0 && cs >= 0;
+    const int g = (a.src_mode == DLWP_SRC_UPSAMPLE2) ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
+    goff[q] = ok ? (unsigned)g * 4u : 0x7ffffff0u;
+    loff[q] = lr * C::LCS + lc;
+  }
+  const long long plane = (long long)a.Hs * a.Ws;
+  const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
+  const unsigned plane_bytes = (unsigned)plane * 4u;
+
+  // ---- this lane's tile (= its MFMA A-operand row) and the LDS offset of the tile's 4x4 patch origin, channel l>>4
+  int v_src;
+  {
+    const int t = wave * 16 + (lane & 15);
+    const int tt = t < C::T ? t : 0;
+    const int pc = tt / (C::RTH * C::RTW), rem = tt - pc * (C::RTH * C::RTW);
+    const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
+    const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
+    v_src = (lane >> 4) * C::PS + (ti * 2 * C::DIL + pi) * C::LCS + tj * 2 * C::DIL + pj;
+  }
+  // ---- filter items -> (ci, co): byte offset in the transformed filter (chunk 0, xy quad 0) and LDS slot
+  unsigned u_off[C::NUI];
+  int u_dst[C::NUI];
+#pragma unroll
+  for (int k = 0; k < C::NUI; ++k) {
+    const int e = tid + k * C::NT;
+    const int ci = e / C::BN, co = e - ci * C::BN;
+    u_off[k] = (unsigned)((ci * 4 * a.Cout + n0 + co) * 16);
+    u_dst[k] = (ci * C::BN + co) * 4;
+  }
+  const __amdgpu_buffer_rsrc_t u_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cin * a.Cout * 64, 0x00020000);
+  const int b_lane = ((lane >> 4) * C::BN + (lane & 15)) * 4;
+  const int last_c0 = a.Cin - C::CK;
+
+  f32x4 acc[16][C::BNF];
+#pragma unroll
+  for (int xy = 0; xy < 16; ++xy)
+#pragma unroll
+    for (int g = 0; g < C::BNF; ++g) acc[xy][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float xr[C::CK][C::NPOS];
+  f32x4 ur[C::NUI][2];  // two xy quads at a time: (0,1) loaded a chunk ahead, (2,3) half a chunk ahead
+  // element i of the chunk starting at channel c0 (uniform; clamped to the last chunk): one buffer descriptor per plane
+  auto load_x = [&](int c0, int i) {
+    const int ci = i / C::NPOS, q = i - ci * C::NPOS;
+    const float* xp = xn + (long long)(min(c0, last_c0) + ci) * plane;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, plane_bytes, 0x00020000);
+    xr[ci][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, goff[q], 0, 0));
+  };
+  auto load_u = [&](int c0, int k, int r) {
+    const int soff = (min(c0, last_c0) * 4 + r) * a.Cout * 16;
+    ur[k][r & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off[k], soff, 0));
+  };
+  auto stage_x = [&](int xdst, int i) {
+    const int ci = i / C::NPOS, q = i - ci * C::NPOS;
+    lds[xdst + ci * C::PS + loff[q]] = xr[ci][q];
+  };
+  auto stage_u = [&](int udst, int k, int r) {
+    *(f32x4*)(lds + udst + u_dst[k] + r * C::CK * C::BN * 4) = ur[k][r & 1];
+  };
+  // input transform V = B^T d B of this lane's own A-operand elements, channel group c4 (channels (l>>4) + 4*c4)
+  float v[2][16];
+  float d[4][4], t[4][4];
+  auto vt_read = [&](int xsrc, int c4, int part) {  // 8 parts: column part/2, rows 2*(part%2) and +1
+    const float* dp = lds + xsrc + v_src + c4 * 4 * C::PS;
+    const int c = part >> 1, r0 = (part & 1) * 2;
+    d[r0][c] = dp[r0 * C::DIL * C::LCS + c * C::DIL];
+    d[r0 + 1][c] = dp[(r0 + 1) * C::DIL * C::LCS + c * C::DIL];
+  };
+  auto vt_rows = [&](int c) {
+    t[0][c] = d[0][c] - d[2][c];
+    t[1][c] = d[1][c] + d[2][c];
+    t[2][c] = d[2][c] - d[1][c];
+    t[3][c] = d[1][c] - d[3][c];
+  };
+  auto vt_cols = [&](int c4, int r) {
+    v[c4][r * 4 + 0] = t[r][0] - t[r][2];
+    v[c4][r * 4 + 1] = t[r][1] + t[r][2];
+    v[c4][r * 4 + 2] = t[r][2] - t[r][1];
+    v[c4][r * 4 + 3] = t[r][1] - t[r][3];
+  };
+  f32x4 bf[2][C::BNF];
+  auto load_frags = [&](int usrc, int c4, int xq, int buf) {
+#pragma unroll
+    for (int g = 0; g < C::BNF; ++g)
+      bf[buf][g] = *(const f32x4*)(lds + usrc + b_lane + ((xq * C::CK + c4 * 4) * C::BN + g * 16) * 4);
+  };
+
+  // ---- prologue: chunk 0 staged, chunk 1 in registers, V(group 0, chunk 0) and the first B fragments loaded
+#pragma unroll
+  for (int i = 0; i < C::NXI; ++i) load_x(0, i);
+#pragma unroll
+  for (int i = 0; i < C::NXI; ++i) stage_x(0, i);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int h = 0; h < 2 * C::NUI; ++h) load_u(0, h >> 1, (h & 1) + 2 * half);
+#pragma unroll
+    for (int h = 0; h < 2 * C::NUI; ++h) stage_u(US0, h >> 1, (h & 1) + 2 * half);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < C::NXI; ++i) load_x(C::CK, i);
+#pragma unroll
+  for (int h = 0; h < 2 * C::NUI; ++h) load_u(C::CK, h >> 1, h & 1);
+#pragma unroll
+  for (int part = 0; part < 8; ++part) vt_read(0, 0, part);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vt_rows(c);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vt_cols(0, r);
+  load_frags(US0, 0, 0, 0);
+
+  // one chunk; PAR = which LDS buffer holds it (compile time: every LDS address is lane base + immediate)
+  auto chunk = [&](auto par, int c0) {
+    constexpr int P = decltype(par)::value;
+    constexpr int xcur = P * C::X_FLOATS, xnxt = (1 - P) * C::X_FLOATS;
+    constexpr int ucur = US0 + P * C::U_FLOATS, unxt = US0 + (1 - P) * C::U_FLOATS;
+    constexpr int HL = C::HL, GS = HL / 4;  // GS MFMAs per B-fragment group (4 xy x BNF)
+    // ================= channel group 0 ==================================================================
+#pragma unroll
+    for (int s = 0; s < HL; ++s) {
+      if (s % GS == 0) load_frags(ucur, s / GS == 3 ? 1 : 0, (s / GS + 1) & 3, (s / GS + 1) & 1);
+      if (s < 8) vt_read(xcur, 1, s);
+      if (s >= 8 && s < 24) {  // registers (chunk k+1) -> xs[nxt]
+#pragma unroll
+        for (int i = (s - 8) * C::NXI / 16; i < (s - 7) * C::NXI / 16; ++i) stage_x(xnxt, i);
+      }
+      if (s >= 4 && s < 12 && (s & 1) == 0) vt_rows((s - 4) >> 1);
+      if (s >= 12 && s < 16) vt_cols(1, s - 12);
+      if (s >= 6 && s < 6 + 2 * C::NUI) stage_u(unxt, (s - 6) >> 1, (s - 6) & 1);            // xy quads 0,1 of chunk k+1
+      if (s >= 8 + 2 * C::NUI && s < 8 + 4 * C::NUI) {                                        // load quads 2,3 of chunk k+1
+        const int h = s - 8 - 2 * C::NUI;
+        load_u(c0 + C::CK, h >> 1, 2 + (h & 1));
+      }
+      if (s >= 24) {  // chunk k+2 -> registers (first third)
+#pragma unroll
+        for (int i = (s - 24) * C::NXI / 24; i < (s - 23) * C::NXI / 24; ++i) load_x(c0 + 2 * C::CK, i);
+      }
+      {
+        const int xq = s / (4 * C::BNF), j = (s / C::BNF) & 3, g = s % C::BNF;
+        acc[xq * 4 + j][g] =
+            __builtin_amdgcn_mfma_f32_16x16x4f32(v[0][xq * 4 + j], bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s == 23) {
+        __syncthreads();  // A: xs[nxt] complete
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ================= channel group 1 ==================================================================
+#pragma unroll
+    for (int s = 0; s < HL; ++s) {
+      if (s % GS == 0) {
+        if (s / GS < 3) load_frags(ucur, 1, s / GS + 1, (s / GS + 1) & 1);
+        else load_frags(unxt, 0, 0, 0);  // first fragments of the next chunk (after barrier B)
+      }
+      if (s < 8) vt_read(xnxt, 0, s);
+      if (s >= 16 && s < 16 + 2 * C::NUI) stage_u(unxt, (s - 16) >> 1, 2 + ((s - 16) & 1));  // xy quads 2,3 of chunk k+1
+      if (s >= 18 + 2 * C::NUI && s < 18 + 4 * C::NUI) {                                      // load quads 0,1 of chunk k+2
+        const int h = s - 18 - 2 * C::NUI;
+        load_u(c0 + 2 * C::CK, h >> 1, h & 1);
+      }
+      if (s >= 4 && s < 12 && (s & 1) == 0) vt_rows((s - 4) >> 1);
+      if (s >= 12 && s < 16) vt_cols(0, s - 12);
+      if (s < 16) {  // chunk k+2 -> registers (the rest of the input, then the filters)
+#pragma unroll
+        for (int i = (s + 8) * C::NXI / 24; i < (s + 9) * C::NXI / 24; ++i) load_x(c0 + 2 * C::CK, i);
+      }
+      {
+        const int xq = s / (4 * C::BNF), j = (s / C::BNF) & 3, g = s % C::BNF;
+        acc[xq * 4 + j][g] =
+            __builtin_amdgcn_mfma_f32_16x16x4f32(v[1][xq * 4 + j], bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s == 23) {
+        __syncthreads();  // B: us[nxt] complete, xs[cur] / us[cur] no longer read (their last reads were issued above)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  static_assert(C::NUI <= 2, "filter staging slots");
+  {
+    int c0 = 0;
+    for (; c0 + C::CK < a.Cin; c0 += 2 * C::CK) {
+      chunk(std::integral_constant<int, 0>{}, c0);
+      chunk(std::integral_constant<int, 1>{}, c0 + C::CK);
+    }
+    if (c0 < a.Cin) chunk(std::integral_constant<int, 0>{}, c0);
+  }
+  __syncthreads();  // every wave is out of the loop: LDS becomes the output staging area
+
+  // ---- output transform Y = A^T M A in registers, bias + activation, then [co][row][col] through LDS
+#pragma unroll
+  for (int g = 0; g < C::BNF; ++g) {
+    const int col = g * 16 + (lane & 15);
+    const float bv = a.bias ? a.bias[n0 + col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = wave * 16 + (lane >> 4) * 4 + r;
+      if (t >= C::T) continue;
+      const int pc = t / (C::RTH * C::RTW), rem = t - pc * (C::RTH * C::RTW);
+      const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
+      const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
+      float m[4][4];
+#pragma unroll
+      for (int xy = 0; xy < 16; ++xy) m[xy >> 2][xy & 3] = acc[xy][g][r];
+      float s[2][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // A^T m
+        s[0][c] = m[0][c] + m[1][c] + m[2][c];
+        s[1][c] = m[1][c] - m[2][c] - m[3][c];
+      }
+      float* op = lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const float y0 = act_apply(s[aa][0] + s[aa][1] + s[aa][2] + bv, a.act);
+        const float y1 = act_apply(s[aa][1] - s[aa][2] - s[aa][3] + bv, a.act);
+        op[aa * C::DIL * C::TW] = y0;
+        op[aa * C::DIL * C::TW + C::DIL] = y1;
+      }
+    }
+  }
+  __syncthreads();
+  float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
+  constexpr int NOUT = C::BN * C::TH * C::TW / 4 / C::NT;
+#pragma unroll
+  for (int k = 0; k < NOUT; ++k) {
+    const int e = (k * C::NT + tid) * 4;
+    const int co = e / (C::TH * C::TW), rem = e - co * (C::TH * C::TW);
+    const int row = rem / C::TW, colx = rem - row * C::TW;
+    const int oh = i0 + row, ow = j0 + colx;
+    if (oh >= a.Ho || ow >= a.Wo) continue;
+    const f32x4 o = *(const f32x4*)(lds + co * C::OPS + rem);
+    float* yp = yn + ((long long)co * a.Ho + oh) * a.Wo + ow;
+    if (ow + 3 < a.Wo) {
+      *(f32x4*)yp = o;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ow + r < a.Wo) yp[r] = o[r];
+    }
+  }
+}
+
+template <class C>
+static void wino_launch_thunk(const ConvArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((conv2d_fwd_wino_f32<C>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
+}
+
+template <class C>
+static int wino_prepare() {
+  if (C::LDS_BYTES > 64 * 1024)
+    return (int)hipFuncSetAttribute((const void*)conv2d_fwd_wino_f32<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    C::LDS_BYTES);
+  return 0;
+}
+
+// registry entry: ks = 3, fa = 0, pack = -1 marks a Winograd instance (a.w = the transformed filter)
+#define WINO_ENTRY(DIL, TH, TW, WAVES, BNF, CK)                                                        \
+  {                                                                                                     \
+    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1,      \
+        &wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>>,                                       \
+        &wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>>                                             \
+  }

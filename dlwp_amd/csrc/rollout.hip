@@ -72,6 +72,10 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
     return (char*)series + ((size_t)call * n_outputs + o) * slot_elems * esz;
   };
 
+  // the Winograd convolutions keep their transformed filters in a scratch buffer of the handle: allocate it now,
+  // allocation is not possible while the stream is capturing
+  (void)dlwp_wino_scratch(h, 1, nullptr);
+
   hipStream_t cap;
   DLWP_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
   hipGraph_t graph = nullptr;

@@ -182,6 +182,11 @@ def force_conv_config(i):
     _lib.lib.dlwp_conv2d_force_config(int(i))
 
 
+def set_winograd(enable):
+    """3x3 convolutions with >= 16 input and output channels run as Winograd F(2x2,3x3) by default."""
+    _lib.lib.dlwp_conv2d_set_winograd(1 if enable else 0)
+
+
 # ------------------------------------------------------------------------------------------------------------------ #
 # training kernels
 # ------------------------------------------------------------------------------------------------------------------ #

@@ -95,11 +95,13 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const vo
 
 /* tuning hooks (tools/tune_conv.py, tests): enumerate the compiled MFMA tile configurations, force one for the calling
  * thread (-1 = heuristic), ask which one the heuristic picks (-1 = direct kernel).  info9 = {ks, dil, th, tw, waves,
- * frags_per_wave, cout_frags (< 0: packed-N instance for cout <= 16/-cout_frags), channel_chunk, pooled_loader}.
+ * frags_per_wave (0: Winograd instance), cout_frags (< 0: packed-N instance for cout <= 16/-cout_frags), channel_chunk,
+ * pooled_loader}.
  * Not part of the drop-in surface.                                                                                  */
 int dlwp_conv2d_num_configs(void);
 int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes);
 int dlwp_conv2d_force_config(int i);
+int dlwp_conv2d_set_winograd(int enable);   /* 3x3 layers with cin, cout >= 16: Winograd F(2x2,3x3) (default) or direct */
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 
 /* ---- backward of the fused Conv2D: the two halves of the Keras train step behind DLWPNeuralNet.fit / fit_generator

@@ -62,4 +62,6 @@ def test_compiled_tile_configurations_cover_the_unet_layers():
     for c in cfgs:
         ks, dil, th, tw, waves, fa, bnf, ck, pool, lds = c
         pixels = th * tw if bnf > 0 else th * tw // (-bnf)          # packed-N instances tile super-pixels
+        if fa == 0:                                                 # Winograd instance: 2x2 tiles, one fragment / wave
+            pixels, fa = th * tw // 4, 1
         assert pixels <= 16 * fa * waves and lds <= 160 * 1024 and ck % 4 == 0

@@ -204,10 +204,13 @@ def test_conv2d_every_compiled_tile_configuration(ops):
     try:
         for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds) in enumerate(cfgs):
             cmax = 16 // (-bnf) if bnf < 0 else 0       # packed-N instances cover cout <= 16/S
-            key = (ks, dil, pool, cmax)
+            wino = fa == 0                              # Winograd instances: whole chunks of 8 in / 32 out channels
+            key = (ks, dil, pool, cmax, wino)
             src = 2 if pool else 0                      # pooled-loader instances only run the fused max-pool source
             if key not in problems:
                 n, cin, h, w, cout = 2, 20, (39 if pool else 19), (101 if pool else 50), (36 if not cmax else max(1, cmax - 1))
+                if wino:
+                    cin, cout = 24, 64
                 x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
                 wt = np_ref.glorot_uniform((ks, ks, cin, cout), rng)
                 b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
@@ -252,20 +255,30 @@ def test_conv2d_linearity_and_longitude_shift_equivariance_full_size(ops):
     y2 = host(ops.conv2d(dev(x2), wt, None, cd))
     y12 = host(ops.conv2d(dev(x1 + 2 * x2), wt, None, cd))
     assert np.abs(y12 - (y1 + 2 * y2)).max() < 2e-4
-    ys = host(ops.conv2d(dev(np.roll(x1, 7, axis=-1)), wt, None, cd))
-    assert np.array_equal(ys, np.roll(y1, 7, axis=-1))     # periodic halo: exact shift equivariance, bit for bit
+    # periodic halo: exact shift equivariance, bit for bit, for shifts by the Winograd tile period (2 * dilation = 4)
+    ys = host(ops.conv2d(dev(np.roll(x1, 8, axis=-1)), wt, None, cd))
+    assert np.array_equal(ys, np.roll(y1, 8, axis=-1))
+    ops.set_winograd(False)                                 # the direct kernel is equivariant under ANY shift
+    try:
+        yd = host(ops.conv2d(dev(x1), wt, None, cd))
+        assert np.array_equal(host(ops.conv2d(dev(np.roll(x1, 7, axis=-1)), wt, None, cd)), np.roll(yd, 7, axis=-1))
+        assert np.abs(yd - y1).max() < 1e-5 * max(1.0, np.abs(yd).max())     # Winograd vs direct: fp32 round-off only
+    finally:
+        ops.set_winograd(True)
     # spot-check against the float64 oracle on one sample / a few channels (full tensor would take minutes on CPU)
     want = _conv_ref(x1[:1], host(wt)[..., :4], None, 2, (2, 2, 2, 2), 0, 1, 'linear', 0)
     _check_conv(ops, y1[:1, :4], want)
 
 
 def test_conv2d_batch_invariance(ops):
-    """A sample's result must not depend on what else is in the batch (member sharding across GPUs relies on it)."""
+    """A sample's result must not depend on what else is in the batch (member sharding across GPUs relies on it):
+    direct family (48 output channels) and Winograd family (64)."""
     rng = np.random.default_rng(3)
     x = rng.standard_normal((5, 16, 22, 45)).astype(np.float32)
-    wt = dev(np_ref.glorot_uniform((3, 3, 16, 48), rng))
-    cd = ops.make_conv(48, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
-    full = host(ops.conv2d(dev(x), wt, None, cd))
-    for i in (0, 3):
-        one = host(ops.conv2d(dev(x[i:i + 1]), wt, None, cd))
-        assert np.array_equal(one[0], full[i])
+    for cout in (48, 64):
+        wt = dev(np_ref.glorot_uniform((3, 3, 16, cout), rng))
+        cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
+        full = host(ops.conv2d(dev(x), wt, None, cd))
+        for i in (0, 3):
+            one = host(ops.conv2d(dev(x[i:i + 1]), wt, None, cd))
+            assert np.array_equal(one[0], full[i])
