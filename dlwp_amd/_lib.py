@@ -93,6 +93,7 @@ _sig('dlwp_conv2d_num_configs', [])
 _sig('dlwp_conv2d_config_info', [_i, _P(_i), _P(_i)])
 _sig('dlwp_conv2d_force_config', [_i])
 _sig('dlwp_conv2d_set_winograd', [_i])
+_sig('dlwp_conv2d_prefers_unfused_pool', [_i, _i, _i, _i, _i, _i])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _i, _P(_sz)])
 _sig('dlwp_conv2d_bwd_data', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])

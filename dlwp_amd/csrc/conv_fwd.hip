@@ -361,6 +361,13 @@ int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes) {
   return DLWP_OK;
 }
 
+int dlwp_conv2d_prefers_unfused_pool(int cin, int cout, int kh, int kw, int dil_h, int dil_w) {
+  return (winograd_enabled() && kh == 3 && kw == 3 && dil_h == dil_w && (dil_h == 1 || dil_h == 2) && cin % 8 == 0 &&
+          cout % 32 == 0 && (size_t)cin * cout * 16 <= WINO_SCRATCH_FLOATS)
+             ? 1
+             : 0;
+}
+
 int dlwp_conv2d_set_winograd(int enable) {
   g_winograd = enable ? 1 : 0;
   return DLWP_OK;

@@ -34,6 +34,8 @@ static const ConvKernelEntry k_table[] = {
     // Winograd F(2x2,3x3) instances (conv_fwd_wino_kernel.h): DIL TH TW WAVES BNF CK
     WINO_ENTRY(1, 8, 32, 4, 2, 8),
     WINO_ENTRY(1, 4, 64, 4, 2, 8),
+    WINO_ENTRY(1, 8, 16, 2, 2, 8),
+    WINO_ENTRY(1, 4, 32, 2, 2, 8),
 };
 const ConvKernelEntry* dlwp_conv_table_k3d1(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));

@@ -41,8 +41,10 @@ struct WinoCfg {
   static constexpr int DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, BNF = BNF_, CK = CK_;
   static constexpr int NT = WAVES * 64;
   static constexpr int LR = TH + 2 * DIL, LC = TW + 2 * DIL;
-  static constexpr int LCS = LC;
-  static constexpr int PS_RAW = LR * LCS;
+  // LDS layout of one channel: the DIL*DIL parity sub-lattices de-interleaved, [pi][pj][LR/DIL][LC/DIL] -- the elements of
+  // a tile's 4x4 patch (DIL pixels apart in the image) are adjacent in LDS, whatever the dilation
+  static constexpr int LRP = LR / DIL, LCP = LC / DIL;
+  static constexpr int PS_RAW = LR * LC;
   static constexpr int PS = PS_RAW + (((16 - PS_RAW % 32) % 32) + 32) % 32;
   static constexpr int RTH = TH / (2 * DIL), RTW = TW / (2 * DIL);  // tiles per parity class
   static constexpr int T = DIL * DIL * RTH * RTW;                      // = TH*TW/4
@@ -59,7 +61,6 @@ struct WinoCfg {
   static constexpr int NUI = (CK * BN) / NT;       // (ci, co) filter items per thread
   static constexpr int NWI = 4 * NUI;              // float4 filter loads per thread and chunk
   static constexpr int HL = 32;                    // MFMAs per channel group
-  static constexpr int BLOCKS = (8 / WAVES) < 1 ? 1 : 8 / WAVES;  // two waves per SIMD
   static_assert(TH % (2 * DIL) == 0 && TW % (2 * DIL) == 0, "region must be whole 2x2 tiles on every parity class");
   static_assert(TPAD >= T, "tiles must fit the wave decomposition");
   static_assert(CK == 8 && BNF == 2, "the pipeline is written for two channel groups of 4 and 32 output channels");
@@ -69,7 +70,8 @@ struct WinoCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NT, C::BLOCKS) void conv2d_fwd_wino_f32(const ConvArgs a) {
+// __launch_bounds__(threads, waves per SIMD): 2 waves per SIMD = 256 VGPRs
+__global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int US0 = 2 * C::X_FLOATS;
   const int tid = threadIdx.x;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(C::NT, C::BLOCKS) void conv2d_fwd_wino_f32(const Co
     const bool ok = rs >= 0 && cs >= 0;
     const int g = (a.src_mode == DLWP_SRC_UPSAMPLE2) ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
     goff[q] = ok ? (unsigned)g * 4u : 0x7ffffff0u;
-    loff[q] = lr * C::LCS + lc;
+    loff[q] = (((lr % C::DIL) * C::DIL + lc % C::DIL) * C::LRP + lr / C::DIL) * C::LCP + lc / C::DIL;
   }
   const long long plane = (long long)a.Hs * a.Ws;
   const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(C::NT, C::BLOCKS) void conv2d_fwd_wino_f32(const Co
     const int pc = tt / (C::RTH * C::RTW), rem = tt - pc * (C::RTH * C::RTW);
     const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
     const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
-    v_src = (lane >> 4) * C::PS + (ti * 2 * C::DIL + pi) * C::LCS + tj * 2 * C::DIL + pj;
+    v_src = (lane >> 4) * C::PS + ((pi * C::DIL + pj) * C::LRP + ti * 2) * C::LCP + tj * 2;
   }
   // ---- filter items -> (ci, co): byte offset in the transformed filter (chunk 0, xy quad 0) and LDS slot
   unsigned u_off[C::NUI];
@@ -164,23 +166,23 @@ __global__ __launch_bounds__(C::NT, C::BLOCKS) void conv2d_fwd_wino_f32(const Co
   // input transform V = B^T d B of this lane's own A-operand elements, channel group c4 (channels (l>>4) + 4*c4)
   float v[2][16];
   float d[4][4], t[4][4];
-  auto vt_read = [&](int xsrc, int c4, int part) {  // 8 parts: column part/2, rows 2*(part%2) and +1
+  auto vt_read = [&](int xsrc, int c4, int part) {  // 8 parts: row part/2, columns 2*(part%2) and +1 (one ds_read_b64)
     const float* dp = lds + xsrc + v_src + c4 * 4 * C::PS;
-    const int c = part >> 1, r0 = (part & 1) * 2;
-    d[r0][c] = dp[r0 * C::DIL * C::LCS + c * C::DIL];
-    d[r0 + 1][c] = dp[(r0 + 1) * C::DIL * C::LCS + c * C::DIL];
+    const int r = part >> 1, c0 = (part & 1) * 2;
+    d[r][c0] = dp[r * C::LCP + c0];
+    d[r][c0 + 1] = dp[r * C::LCP + c0 + 1];
   };
-  auto vt_rows = [&](int c) {
-    t[0][c] = d[0][c] - d[2][c];
-    t[1][c] = d[1][c] + d[2][c];
-    t[2][c] = d[2][c] - d[1][c];
-    t[3][c] = d[1][c] - d[3][c];
+  auto vt_rows = [&](int r) {  // d B, one patch row
+    t[r][0] = d[r][0] - d[r][2];
+    t[r][1] = d[r][1] + d[r][2];
+    t[r][2] = d[r][2] - d[r][1];
+    t[r][3] = d[r][1] - d[r][3];
   };
-  auto vt_cols = [&](int c4, int r) {
-    v[c4][r * 4 + 0] = t[r][0] - t[r][2];
-    v[c4][r * 4 + 1] = t[r][1] + t[r][2];
-    v[c4][r * 4 + 2] = t[r][2] - t[r][1];
-    v[c4][r * 4 + 3] = t[r][1] - t[r][3];
+  auto vt_cols = [&](int c4, int c) {  // B^T (d B), one column
+    v[c4][0 * 4 + c] = t[0][c] - t[2][c];
+    v[c4][1 * 4 + c] = t[1][c] + t[2][c];
+    v[c4][2 * 4 + c] = t[2][c] - t[1][c];
+    v[c4][3 * 4 + c] = t[1][c] - t[3][c];
   };
   f32x4 bf[2][C::BNF];
   auto load_frags = [&](int usrc, int c4, int xq, int buf) {

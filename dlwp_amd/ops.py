@@ -182,6 +182,11 @@ def force_conv_config(i):
     _lib.lib.dlwp_conv2d_force_config(int(i))
 
 
+def prefers_unfused_pool(cin, cout, kh, kw, dil_h, dil_w):
+    """Planner hint: materialise a MaxPooling2D in front of this convolution instead of fusing it into the loader?"""
+    return bool(_lib.lib.dlwp_conv2d_prefers_unfused_pool(cin, cout, kh, kw, dil_h, dil_w))
+
+
 def set_winograd(enable):
     """3x3 convolutions with >= 16 input and output channels run as Winograd F(2x2,3x3) by default."""
     _lib.lib.dlwp_conv2d_set_winograd(1 if enable else 0)

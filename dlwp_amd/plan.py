@@ -160,6 +160,17 @@ def _compose_halo(first, layer_pad, mode):
     return Halo(ah[0], ah[1], aw[0], aw[1], ah[2], aw[2])
 
 
+def _prefers_unfused_pool(cin, lay):
+    """Ask the library (host logic only, works without a GPU) whether a pooled source should be materialised for this
+    convolution; False when the library is not built."""
+    try:
+        from . import ops
+        return ops.prefers_unfused_pool(cin, lay.filters, lay.kernel_size[0], lay.kernel_size[1],
+                                        lay.dilation_rate[0], lay.dilation_rate[1])
+    except (ImportError, OSError, AttributeError):
+        return False
+
+
 def toposort(outputs):
     order, seen = [], set()
 
@@ -339,6 +350,9 @@ def build_plan(inputs, outputs):
             v = ins[0]
             if v.shape is not None and len(v.shape) != 3:
                 raise NotImplementedError('%s on a non-3D tensor %r' % (lay.name, v.shape))
+            if v.src_mode == SRC_MAXPOOL2 and _prefers_unfused_pool(v.c, lay):
+                # the Winograd kernels read plain tensors: pool once with the standalone kernel, keep the halo lazy
+                v = materialize(v.copy(halo=NO_HALO)).copy(halo=v.halo)
             halo = v.halo
             if lay.padding == 'same':
                 st, sb, sl, sr = lay.same_halo()

@@ -101,7 +101,12 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const vo
 int dlwp_conv2d_num_configs(void);
 int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes);
 int dlwp_conv2d_force_config(int i);
-int dlwp_conv2d_set_winograd(int enable);   /* 3x3 layers with cin, cout >= 16: Winograd F(2x2,3x3) (default) or direct */
+int dlwp_conv2d_set_winograd(int enable);   /* 3x3 layers with cin % 8 == 0, cout % 32 == 0: Winograd F(2x2,3x3)
+                                              * (default) or the direct implicit GEMM */
+/* Planner hint (pure host logic, no device): 1 when a convolution of this geometry behind a MaxPooling2D runs faster with
+ * the pooled tensor materialised by dlwp_maxpool2_fwd (the Winograd family has no pooled loader) than with the pooling
+ * fused into the direct kernel's loader; 0 otherwise. */
+int dlwp_conv2d_prefers_unfused_pool(int cin, int cout, int kh, int kw, int dil_h, int dil_w);
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 
 /* ---- backward of the fused Conv2D: the two halves of the Keras train step behind DLWPNeuralNet.fit / fit_generator

@@ -22,8 +22,13 @@ def _dlwp(**kw):
 # ---- build_model ------------------------------------------------------------------------------------------------- #
 
 def test_build_model_accepts_reference_triples_and_fuses_to_six_launches():
-    d = _dlwp(time_dim=2)
-    d.build_model(unet_layers((4, 88, 180)), loss='mse', optimizer='adam', metrics=['mae'], gpus=1)
+    from dlwp_amd import ops
+    ops.set_winograd(False)                                     # direct kernels: every pooling fused into a loader
+    try:
+        d = _dlwp(time_dim=2)
+        d.build_model(unet_layers((4, 88, 180)), loss='mse', optimizer='adam', metrics=['mae'], gpus=1)
+    finally:
+        ops.set_winograd(True)
     assert d.model is d.base_model and d.gpus == 1
     assert d.model.count_params() == 188996
     assert d.model.output_shape == (None, 4, 88, 180)
@@ -37,6 +42,18 @@ def test_build_model_accepts_reference_triples_and_fuses_to_six_launches():
     assert d.model.metrics_names == ['loss', 'mean_absolute_error']
     names = [lay.name for lay in d.base_model.layers]
     assert len(names) == 22 and all(hasattr(lay, 'output_shape') for lay in d.base_model.layers)
+
+
+def test_default_plan_pools_once_in_front_of_the_winograd_layers():
+    """With the Winograd family on (default) the two pooled 3x3 layers (32->64, 64->128) read a pooled tensor written by
+    dlwp_maxpool2_fwd: 8 launches, same FLOPs, every halo still fused."""
+    d = _dlwp(time_dim=2)
+    d.build_model(unet_layers((4, 88, 180)), loss='mse', optimizer='adam', gpus=1)
+    plan = d.model.plan
+    assert [op.kind for op in plan.ops] == ['conv', 'maxpool', 'conv', 'maxpool', 'conv', 'conv', 'conv', 'conv']
+    assert plan.conv_flops_per_sample() == 1597685760
+    assert [op.src_mode for op in plan.ops if op.kind == 'conv'] == [0, 0, 0, 1, 1, 0]
+    assert [op.halo.left for op in plan.ops if op.kind == 'conv'] == [2, 1, 1, 1, 2, 2]
 
 
 def test_build_model_argument_errors_match_the_reference():
@@ -121,8 +138,13 @@ def _skip_model(cs=(4, 16, 24)):
 
 
 def test_planner_skip_unet_slices_are_free_and_concat_is_a_copy():
+    from dlwp_amd import ops
     x0, y = _skip_model()
-    m = Model(inputs=x0, outputs=y)
+    ops.set_winograd(False)         # the fully fused plan (with Winograd on, pooled slices are materialised first)
+    try:
+        m = Model(inputs=x0, outputs=y)
+    finally:
+        ops.set_winograd(True)
     kinds = [op.kind for op in m.plan.ops]
     assert kinds.count('conv') == 6 and kinds.count('copy') == 4 and set(kinds) == {'conv', 'copy'}
     convs = [op for op in m.plan.ops if op.kind == 'conv']

@@ -22,6 +22,9 @@ def unet_layers(cin, h, w):
         ('L4', 128, 64, 3, 1, 1, h // 4, w // 4),
         ('L5', 64, 32, 3, 2, 1, h // 2, w // 2),
         ('L6', 32, cin, 5, 1, 0, h, w),
+        # the pooled layers as the default plan runs them: plain source written by dlwp_maxpool2_fwd
+        ('L2p', 32, 64, 3, 1, 0, h // 2, w // 2),
+        ('L3p', 64, 128, 3, 1, 0, h // 4, w // 4),
     ]
 
 
@@ -59,7 +62,7 @@ def main():
                 continue
             ops.force_conv_config(i)
             try:
-                for _ in range(3):
+                for _ in range(5):
                     ops.conv2d(x, wt, b, cd, out=out)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
