@@ -20,7 +20,8 @@ F32, BF16 = 0, 1
 PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
-OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH = 0, 1, 2, 3, 4
+OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES = 0, 1, 2, 3, 4, 5
+BUF_NONE = -1000
 BUF_STATE_IN = -1
 
 
@@ -46,7 +47,7 @@ class Conv2d(ctypes.Structure):
 
 class Op(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int), ('src', ctypes.c_int), ('dst', ctypes.c_int), ('w', ctypes.c_int),
-                ('b', ctypes.c_int), ('xs', Shape4), ('conv', Conv2d), ('pad', Pad2d)]
+                ('b', ctypes.c_int), ('xs', Shape4), ('conv', Conv2d), ('pad', Pad2d), ('aux', ctypes.c_int * 4)]
 
 
 class DlwpError(RuntimeError):
@@ -115,6 +116,7 @@ _sig('dlwp_maxpool2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_maxpool2_bwd', [_vp, _vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_upsample2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_upsample2_bwd', [_vp, _vp, _vp, Shape4, _i, _vp])
+_sig('dlwp_convlstm_gates', [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_copy_channels', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _P(_vp)])

@@ -1,0 +1,98 @@
+// convlstm.hip -- the cell update of keras ConvLSTM2D (the recurrent front end of examples/train.py:144-157 and
+// examples/train_functional.py:207-219).  The two convolutions of a step (input conv: 'valid', dilated, fused halo;
+// recurrent conv: 'same', zero halo) are ordinary dlwp_conv2d_fwd launches into two pre-activation tensors; this kernel
+// adds them and applies the gate arithmetic of ConvLSTM2DCell.call:
+//     i, f, o = rec(z_i), rec(z_f), rec(z_o);   c = f * c_prev + i * act(z_c);   h = o * act(c)
+// HBM-bound: reads 8F (4F on the first step) + F values per pixel and sample, writes 2F.
+#include "conv_fwd_kernel.h"  // dlwp_tanh / act_apply
+
+namespace {
+
+__device__ __forceinline__ float rec_apply(float z, int rec_act) {
+  if (rec_act == 0) return fminf(fmaxf(fmaf(0.2f, z, 0.5f), 0.f), 1.f);  // keras hard_sigmoid
+  return 1.f / (1.f + __expf(-z));
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&out)[VEC]) {
+  if constexpr (VEC == 4) {
+    const f32x4 v = *(const f32x4*)p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = v[k];
+  } else {
+    out[0] = *p;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]};
+  } else {
+    *p = v[0];
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __restrict__ zx, const float* __restrict__ zh,
+                                                             const float* __restrict__ c_prev, float* __restrict__ c_out,
+                                                             float* __restrict__ h_out, int n, int f, int hw, int h_c_off,
+                                                             int h_c_total, int act, int rec_act) {
+  const long long per = (long long)f * hw / VEC;  // vectors per sample and gate
+  const long long total = (long long)n * per;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long s = e / per, r = (e - s * per) * VEC;  // r = offset inside the (F, hw) block of one gate
+    const long long zb = s * 4 * f * hw + r;
+    float z[4][VEC], cp[VEC], c[VEC], h[VEC];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      load_vec<VEC>(zx + zb + (long long)g * f * hw, z[g]);
+      if (zh) {
+        float t[VEC];
+        load_vec<VEC>(zh + zb + (long long)g * f * hw, t);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) z[g][k] += t[k];
+      }
+    }
+    if (c_prev) load_vec<VEC>(c_prev + s * f * hw + r, cp);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float cv = rec_apply(z[0][k], rec_act) * act_apply(z[2][k], act);
+      if (c_prev) cv = fmaf(rec_apply(z[1][k], rec_act), cp[k], cv);
+      c[k] = cv;
+      h[k] = rec_apply(z[3][k], rec_act) * act_apply(cv, act);
+    }
+    store_vec<VEC>(c_out + s * f * hw + r, c);
+    store_vec<VEC>(h_out + (s * h_c_total + h_c_off) * hw + r, h);
+  }
+}
+
+}  // namespace
+
+extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* zh, const void* c_prev, void* c_out,
+                                   void* h_out, int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act,
+                                   int dtype, void* stream) {
+  DLWP_CHECK_ARG(h != nullptr, "dlwp_convlstm_gates: null handle");
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_convlstm_gates: dtype %d not supported", dtype);
+  DLWP_CHECK_ARG(n >= 0 && f > 0 && hw > 0, "dlwp_convlstm_gates: bad sizes n=%d f=%d hw=%d", n, f, hw);
+  DLWP_CHECK_ARG(h_c_off >= 0 && h_c_off + f <= h_c_total, "dlwp_convlstm_gates: h window [%d,%d) of %d", h_c_off,
+                 h_c_off + f, h_c_total);
+  DLWP_CHECK_ARG((unsigned)act <= 2u && (unsigned)rec_act <= 1u, "dlwp_convlstm_gates: unknown activation");
+  if (n == 0) return DLWP_OK;
+  DLWP_CHECK_ARG(zx && c_out && h_out, "dlwp_convlstm_gates: null pointer");
+  const long long elems = (long long)n * f * hw;
+  const bool vec4 = hw % 4 == 0;  // every (sample, gate, channel) plane then starts 16-byte aligned
+  const long long work = vec4 ? elems / 4 : elems;
+  long long blocks = (work + 255) / 256;
+  const long long cap = (long long)h->cu_count * 16;
+  const int grid = (int)(blocks < cap ? blocks : cap);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec4)
+    convlstm_gates_kernel<4><<<grid, 256, 0, s>>>((const float*)zx, (const float*)zh, (const float*)c_prev, (float*)c_out,
+                                                  (float*)h_out, n, f, hw, h_c_off, h_c_total, act, rec_act);
+  else
+    convlstm_gates_kernel<1><<<grid, 256, 0, s>>>((const float*)zx, (const float*)zh, (const float*)c_prev, (float*)c_out,
+                                                  (float*)h_out, n, f, hw, h_c_off, h_c_total, act, rec_act);
+  DLWP_LAUNCH_CHECK("convlstm_gates_kernel");
+  return DLWP_OK;
+}

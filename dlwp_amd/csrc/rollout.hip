@@ -18,8 +18,11 @@ struct dlwp_rollout {
 namespace {
 
 int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, const void* w, const void* b, int dtype,
-               hipStream_t s) {
+               hipStream_t s, void* const* aux = nullptr) {
   switch (op.kind) {
+    case DLWP_OP_LSTM_GATES:
+      return dlwp_convlstm_gates(h, src, aux[0], aux[1], aux[2], dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w,
+                                 op.conv.out_c_off, op.conv.out_c_total, op.conv.act, op.aux[3], dtype, (void*)s);
     case DLWP_OP_CONV2D:
       return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, dtype, s);
     case DLWP_OP_PAD2D:
@@ -59,6 +62,10 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
     if (op.kind == DLWP_OP_CONV2D)
       DLWP_CHECK_ARG(op.w >= 0 && op.w < n_buffers && op.b >= -1 && op.b < n_buffers,
                      "rollout op %d: weight/bias buffer out of range", i);
+    if (op.kind == DLWP_OP_LSTM_GATES)
+      for (int k = 0; k < 3; ++k)
+        DLWP_CHECK_ARG((k < 2 && op.aux[k] == DLWP_BUF_NONE) || (op.aux[k] >= 0 && op.aux[k] < n_buffers),
+                       "rollout op %d: aux buffer %d out of range", i, op.aux[k]);
   }
   const size_t esz = sizeof(float);
   auto resolve = [&](int idx, int call, bool is_src) -> void* {
@@ -90,7 +97,10 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
       const dlwp_op& op = plan[i];
       const void* w = op.kind == DLWP_OP_CONV2D ? buffers[op.w] : nullptr;
       const void* b = (op.kind == DLWP_OP_CONV2D && op.b >= 0) ? buffers[op.b] : nullptr;
-      rc = enqueue_op(h, op, resolve(op.src, t, true), resolve(op.dst, t, false), w, b, dtype, cap);
+      void* aux[3] = {nullptr, nullptr, nullptr};
+      if (op.kind == DLWP_OP_LSTM_GATES)
+        for (int k = 0; k < 3; ++k) aux[k] = op.aux[k] == DLWP_BUF_NONE ? nullptr : buffers[op.aux[k]];
+      rc = enqueue_op(h, op, resolve(op.src, t, true), resolve(op.dst, t, false), w, b, dtype, cap, aux);
     }
   }
   e = hipStreamEndCapture(cap, &graph);

@@ -1,6 +1,7 @@
 """
 The DLWP.custom names on the hot path, as descriptions for the HIP back end.
 
+  PeriodicPadding3D   reference DLWP/custom.py:217-306   -> the same halo on the (T*C, H, W) store of the recurrent input
   PeriodicPadding2D   reference DLWP/custom.py:139-214   -> halo mode WRAP (fused into the next Conv2D's LDS loader,
                                                             or the standalone LDS-staged pad kernel)
   FillPadding2D       reference DLWP/custom.py:309-402   -> halo mode EDGE (pole-row replication)
@@ -32,6 +33,26 @@ class PeriodicPadding2D(_layers._Pad2DBase):
 
 class FillPadding2D(_layers._Pad2DBase):
     """Edge-replicating padding (rows first, then columns of the row-padded tensor == np.pad(mode='edge'))."""
+    mode = 2
+
+
+class PeriodicPadding3D(_layers._Pad3DBase):
+    """Periodic padding of the three trailing axes (reference DLWP/custom.py:217-306; last axis first, then the middle one
+    of the already padded tensor, then the first).  On the HIP path it pads the (T, C, H, W) input of ConvLSTM2D
+    (examples/train.py:144-146: padding (0, 0, 2)); a non-zero pad of the first (channel) axis is not lowered."""
+    mode = 1
+
+    def compute_output_shape(self, s):
+        out = super(PeriodicPadding3D, self).compute_output_shape(s)
+        dims = s[1:] if self.data_format == 'channels_first' else s[:3]
+        for (lo, hi), d in zip(self.padding, dims):
+            if max(lo, hi) > d:
+                raise ValueError('%s: periodic padding %r exceeds the input size %r' % (self.name, self.padding, dims))
+        return out
+
+
+class FillPadding3D(_layers._Pad3DBase):
+    """Edge-replicating 3-D padding (reference DLWP/custom.py:405-520)."""
     mode = 2
 
 

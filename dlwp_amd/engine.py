@@ -92,6 +92,10 @@ class Executor(object):
                 ops.upsample2(src, out=dst)
             elif op.kind == 'copy':
                 ops.copy_channels(src, dst, op.xs[0], op.in_c_off, op.out_c_off)
+            elif op.kind == 'lstm':
+                zh, cp, co = op.aux
+                ops.convlstm_gates(src, res(zh) if zh is not None else None, res(cp) if cp is not None else None,
+                                   res(co), dst, op.xs[0], h_c_off=op.out_c_off, act=op.act, rec_act=op.rec_act)
             else:
                 raise RuntimeError(op.kind)
         return outs
@@ -115,7 +119,7 @@ class Executor(object):
             if lay.bias is not None:
                 table.append(lay.bias)
         kind = {'conv': _lib.OP_CONV2D, 'pad': _lib.OP_PAD2D, 'maxpool': _lib.OP_MAXPOOL2,
-                'upsample': _lib.OP_UPSAMPLE2, 'copy': _lib.OP_COPYCH}
+                'upsample': _lib.OP_UPSAMPLE2, 'copy': _lib.OP_COPYCH, 'lstm': _lib.OP_LSTM_GATES}
         arr = (_lib.Op * len(self.plan.ops))()
         for k, (op, d) in enumerate(zip(self.plan.ops, self._descriptors())):
             o = arr[k]
@@ -131,6 +135,13 @@ class Executor(object):
                     o.conv.in_c_total = op.inner
             elif op.kind == 'copy':
                 o.conv.in_c_off, o.conv.in_c_total = op.in_c_off, op.in_c_total
+                o.conv.out_c_off, o.conv.out_c_total = op.out_c_off, op.out_c_total
+            elif op.kind == 'lstm':
+                zh, cp, co = op.aux
+                o.aux[0] = zh if zh is not None else _lib.BUF_NONE
+                o.aux[1] = cp if cp is not None else _lib.BUF_NONE
+                o.aux[2], o.aux[3] = co, op.rec_act
+                o.conv.act = op.act
                 o.conv.out_c_off, o.conv.out_c_total = op.out_c_off, op.out_c_total
         ptrs = (ctypes.c_void_p * max(1, len(table)))(*[t.data_ptr() for t in table])
         slot = int(np.prod(self.plan._in_store)) * n

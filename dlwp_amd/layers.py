@@ -272,6 +272,165 @@ class Conv2D(Layer):
         return cfg
 
 
+class _Pad3DBase(Layer):
+    """ZeroPadding3D / PeriodicPadding3D argument handling (keras ZeroPadding3D forms).  On the HIP path these layers
+    pad the recurrent (T, C, H, W) tensor in front of ConvLSTM2D (examples/train.py:144-147): channels_first makes T the
+    'channel' axis, so `padding` addresses (C, H, W)."""
+    mode = 0
+
+    def __init__(self, padding=(1, 1, 1), data_format=None, **kwargs):
+        super(_Pad3DBase, self).__init__(**kwargs)
+        self.padding = normalize_padding(padding, 3)
+        self.data_format = normalize_data_format(data_format)
+
+    def compute_output_shape(self, s):
+        if len(s) != 4:
+            raise ValueError('%s expects 5D input (batch + 4), got per-sample shape %r' % (self.name, s))
+        p = self.padding
+        if self.data_format == 'channels_first':
+            return (s[0],) + tuple(s[1 + k] + p[k][0] + p[k][1] for k in range(3))
+        return tuple(s[k] + p[k][0] + p[k][1] for k in range(3)) + (s[3],)
+
+    def get_config(self):
+        cfg = super(_Pad3DBase, self).get_config()
+        cfg.update({'padding': self.padding, 'data_format': self.data_format})
+        return cfg
+
+
+class ZeroPadding3D(_Pad3DBase):
+    """keras.layers.ZeroPadding3D -- the pole-row halo in front of ConvLSTM2D (examples/train.py:147)."""
+    mode = 0
+
+
+class _ConvPart(object):
+    """One of the two convolutions of a ConvLSTM2D step, presented to the planner / executor like a Conv2D layer: it
+    reads the parent's weights through properties, so re-homed (flattened) parameters stay visible."""
+
+    def __init__(self, parent, which):
+        self.parent, self.which = parent, which
+        self.name = '%s/%s' % (parent.name, 'input_conv' if which == 'kernel' else 'recurrent_conv')
+        self.kernel_size = parent.kernel_size
+        self.dilation_rate = parent.dilation_rate if which == 'kernel' else (1, 1)
+        self.filters = 4 * parent.filters
+        self.activation = 'linear'
+
+    @property
+    def kernel(self):
+        return getattr(self.parent, self.which)
+
+    @property
+    def bias(self):
+        return self.parent.bias if self.which == 'kernel' else None
+
+
+class ConvLSTM2D(Layer):
+    """keras.layers.ConvLSTM2D as the reference uses it (examples/train.py:148-155, train_functional.py:207-219):
+    data_format='channels_first' input (T, C, H, W), stride 1, input convolution 'valid' | 'same' with dilation,
+    recurrent convolution 'same' / zero halo / no dilation, gates i, f, c, o, activation tanh,
+    recurrent_activation hard_sigmoid | sigmoid, unit_forget_bias, return_sequences.  Weights in Keras order and layout:
+    kernel (kh, kw, C, 4F) glorot_uniform, recurrent_kernel (kh, kw, F, 4F) orthogonal, bias (4F,) zeros with the
+    forget block at 1.  States start at zero on every call (stateful=False, as everywhere in the reference)."""
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding='valid', data_format=None, dilation_rate=(1, 1),
+                 activation='tanh', recurrent_activation='hard_sigmoid', use_bias=True,
+                 kernel_initializer='glorot_uniform', recurrent_initializer='orthogonal', bias_initializer='zeros',
+                 unit_forget_bias=True, kernel_regularizer=None, recurrent_regularizer=None, bias_regularizer=None,
+                 activity_regularizer=None, kernel_constraint=None, recurrent_constraint=None, bias_constraint=None,
+                 return_sequences=False, go_backwards=False, stateful=False, dropout=0., recurrent_dropout=0., **kwargs):
+        super(ConvLSTM2D, self).__init__(**kwargs)
+        self.filters = int(filters)
+        ks = (kernel_size, kernel_size) if isinstance(kernel_size, (int, np.integer)) else tuple(kernel_size)
+        st = (strides, strides) if isinstance(strides, (int, np.integer)) else tuple(strides)
+        dl = (dilation_rate, dilation_rate) if isinstance(dilation_rate, (int, np.integer)) else tuple(dilation_rate)
+        if tuple(st) != (1, 1):
+            raise NotImplementedError('ConvLSTM2D: only strides=1 is implemented')
+        if padding not in ('valid', 'same'):
+            raise ValueError("ConvLSTM2D padding must be 'valid' or 'same'")
+        if callable(activation):
+            activation = getattr(activation, '__name__', None)
+        if activation not in (None, 'linear', 'tanh', 'relu'):
+            raise NotImplementedError('ConvLSTM2D activation %r is not implemented' % (activation,))
+        if recurrent_activation not in ('hard_sigmoid', 'sigmoid'):
+            raise NotImplementedError('ConvLSTM2D recurrent_activation %r is not implemented' % (recurrent_activation,))
+        if go_backwards or stateful or dropout or recurrent_dropout:
+            raise NotImplementedError('ConvLSTM2D: go_backwards / stateful / dropout are not implemented')
+        if any(k % 2 == 0 for k in ks):
+            raise NotImplementedError("ConvLSTM2D: even kernel sizes (asymmetric 'same' recurrent halo) are not implemented")
+        self.kernel_size = tuple(int(k) for k in ks)
+        self.strides = (1, 1)
+        self.padding = padding
+        self.data_format = normalize_data_format(data_format)
+        if self.data_format != 'channels_first':
+            raise NotImplementedError("ConvLSTM2D: data_format='channels_first' is required")
+        self.dilation_rate = tuple(int(d) for d in dl)
+        self.activation = activation or 'linear'
+        self.recurrent_activation = recurrent_activation
+        self.use_bias = bool(use_bias)
+        self.unit_forget_bias = bool(unit_forget_bias)
+        self.kernel_regularizer = kernel_regularizer
+        self.return_sequences = bool(return_sequences)
+        self.kernel = self.recurrent_kernel = self.bias = None
+        self.input_part = _ConvPart(self, 'kernel')
+        self.recurrent_part = _ConvPart(self, 'recurrent_kernel')
+
+    def same_halo(self):
+        tot_h = self.dilation_rate[0] * (self.kernel_size[0] - 1)
+        tot_w = self.dilation_rate[1] * (self.kernel_size[1] - 1)
+        return (tot_h // 2, tot_h - tot_h // 2, tot_w // 2, tot_w - tot_w // 2)
+
+    def compute_output_shape(self, s):
+        if len(s) != 4:
+            raise ValueError('%s expects 5D input (batch, time, channels, rows, cols), got per-sample shape %r' %
+                             (self.name, s))
+        t, c, h, w = s
+        if self.padding == 'same':
+            ho, wo = h, w
+        else:
+            ho = h - self.dilation_rate[0] * (self.kernel_size[0] - 1)
+            wo = w - self.dilation_rate[1] * (self.kernel_size[1] - 1)
+        if ho <= 0 or wo <= 0:
+            raise ValueError('%s: kernel %r with dilation %r does not fit the input %r' %
+                             (self.name, self.kernel_size, self.dilation_rate, s))
+        return (t, self.filters, ho, wo) if self.return_sequences else (self.filters, ho, wo)
+
+    def build(self, input_shape, device, rng):
+        import torch
+        cin = int(input_shape[1])
+        if self.built:
+            if self.kernel.shape[2] != cin:
+                raise ValueError('%s was built for %d input channels, now called with %d' %
+                                 (self.name, self.kernel.shape[2], cin))
+            return
+        kh, kw = self.kernel_size
+        f = self.filters
+        limit = math.sqrt(6.0 / (kh * kw * cin + kh * kw * 4 * f))
+        k = rng.uniform(-limit, limit, size=(kh, kw, cin, 4 * f)).astype(np.float32)
+        # keras.initializers.Orthogonal: SVD of a normal matrix flattened to (prod(shape[:-1]), shape[-1])
+        a = rng.normal(0.0, 1.0, (kh * kw * f, 4 * f))
+        u, _, vt = np.linalg.svd(a, full_matrices=False)
+        q = u if u.shape == a.shape else vt
+        r = q.reshape(kh, kw, f, 4 * f).astype(np.float32)
+        self.kernel = torch.from_numpy(k).to(device)
+        self.recurrent_kernel = torch.from_numpy(np.ascontiguousarray(r)).to(device)
+        self._weights = [('kernel', self.kernel), ('recurrent_kernel', self.recurrent_kernel)]
+        if self.use_bias:
+            b = np.zeros(4 * f, dtype=np.float32)
+            if self.unit_forget_bias:
+                b[f:2 * f] = 1.0
+            self.bias = torch.from_numpy(b).to(device)
+            self._weights.append(('bias', self.bias))
+        self.built = True
+
+    def get_config(self):
+        cfg = super(ConvLSTM2D, self).get_config()
+        cfg.update({'filters': self.filters, 'kernel_size': self.kernel_size, 'padding': self.padding,
+                    'data_format': self.data_format, 'dilation_rate': self.dilation_rate,
+                    'activation': self.activation, 'recurrent_activation': self.recurrent_activation,
+                    'use_bias': self.use_bias, 'unit_forget_bias': self.unit_forget_bias,
+                    'return_sequences': self.return_sequences})
+        return cfg
+
+
 class MaxPooling2D(Layer):
     """keras.layers.MaxPooling2D(2): 2x2 / stride 2 / 'valid' (examples/train.py:171,181)."""
 

@@ -151,6 +151,28 @@ def copy_channels(src, dst, c, src_c_off=0, dst_c_off=0):
     return dst
 
 
+REC_HARD_SIGMOID, REC_SIGMOID = 0, 1
+
+
+def convlstm_gates(zx, zh, c_prev, c_out, h_out, f, h_c_off=0, act=1, rec_act=REC_HARD_SIGMOID):
+    """ConvLSTM2D cell update: zx/zh (n, 4F, h, w) gate pre-activations (zh, c_prev may be None on the first step),
+    c_out (n, F, h, w), h written to channels [h_c_off, +F) of h_out (n, h_c_total, h, w)."""
+    _check_f32(zx, c_out, h_out)
+    n, f4, h, w = zx.shape
+    if f4 != 4 * f or tuple(c_out.shape) != (n, f, h, w) or tuple(h_out.shape[2:]) != (h, w) or h_out.shape[0] != n:
+        raise ValueError('convlstm_gates: inconsistent shapes zx %r c_out %r h_out %r (F=%d)' %
+                         (tuple(zx.shape), tuple(c_out.shape), tuple(h_out.shape), f))
+    for t in (zh, c_prev):
+        if t is not None:
+            _check_f32(t)
+    nul = ctypes.c_void_p(0)
+    _lib.check(_lib.lib.dlwp_convlstm_gates(_lib.handle(_dev(zx)), _ptr(zx), _ptr(zh) if zh is not None else nul,
+                                            _ptr(c_prev) if c_prev is not None else nul, _ptr(c_out), _ptr(h_out), n,
+                                            int(f), h * w, int(h_c_off), h_out.shape[1], int(act), int(rec_act),
+                                            _lib.F32, _stream(zx)))
+    return h_out
+
+
 def series_merge_time(series, time_dim):
     """(T, N, time_dim*V, ...) -> (T*time_dim, N, V, ...)  -- DLWP/model/models.py:294-300."""
     _check_f32(series)

@@ -62,7 +62,7 @@ class View(object):
 
 
 class PlanOp(object):
-    """One launch.  kind in {'conv','pad','maxpool','upsample','copy'}."""
+    """One launch.  kind in {'conv','pad','maxpool','upsample','copy','lstm'}."""
 
     def __init__(self, kind, src, dst, xs, **kw):
         self.kind, self.src, self.dst = kind, src, dst
@@ -77,10 +77,16 @@ class PlanOp(object):
         self.out_c_total = kw.pop('out_c_total', 0)
         self.inner = kw.pop('inner', 1)     # pad only: 1 = NCHW rows, C = NHWC
         self.out_shape = kw.pop('out_shape', None)   # per-sample (c, h, w) this op produces (window it writes)
+        # lstm only: src = zx buffer, dst = h buffer; aux = (zh buffer | None, c_prev buffer | None, c_out buffer)
+        self.aux = kw.pop('aux', None)
+        self.rec_act = kw.pop('rec_act', 0)
         assert not kw, kw
 
     def __repr__(self):
         extra = ''
+        if self.kind == 'lstm':
+            extra = ' aux%r h[%d:+%d/%d] act%d rec%d' % (self.aux, self.out_c_off, self.xs[0], self.out_c_total, self.act,
+                                                        self.rec_act)
         if self.kind == 'conv':
             extra = ' %s k%s d%s src%d halo%s act%d cin[%d:+%d/%d] cout[%d:+%d/%d]' % (
                 self.layer.name, self.layer.kernel_size, self.layer.dilation_rate, self.src_mode, tuple(self.halo),
@@ -302,6 +308,65 @@ def build_plan(inputs, outputs):
                 if halo.mode_w == PAD_WRAP and max(halo.left, halo.right) > ww:
                     raise ValueError('%s: periodic column padding exceeds the input width %d' % (lay.name, ww))
                 views[t.uid] = v.copy(halo=halo)
+        elif isinstance(lay, L._Pad3DBase):
+            # (T, C, H, W) stored as (T*C, H, W): a 3-D pad that leaves the first (channel) axis alone is the 2-D halo
+            v = ins[0]
+            if lay.data_format != 'channels_first':
+                raise NotImplementedError("%s: data_format='channels_first' is required" % lay.name)
+            if lay.padding[0] != (0, 0):
+                raise NotImplementedError('%s: padding of the first (channel) axis %r is not lowered to the HIP path'
+                                          % (lay.name, lay.padding[0]))
+            pad2 = (lay.padding[1], lay.padding[2])
+            halo = _compose_halo(v.halo, pad2, lay.mode)
+            if halo is None:
+                shp = v.shape
+                v = materialize(v)
+                v.shape = shp
+                halo = _compose_halo(NO_HALO, pad2, lay.mode)
+            hh, ww = v.src_hw
+            if halo.mode_h == PAD_WRAP and max(halo.top, halo.bottom) > hh:
+                raise ValueError('%s: periodic row padding exceeds the input height %d' % (lay.name, hh))
+            if halo.mode_w == PAD_WRAP and max(halo.left, halo.right) > ww:
+                raise ValueError('%s: periodic column padding exceeds the input width %d' % (lay.name, ww))
+            views[t.uid] = v.copy(halo=halo, shape=tuple(t.shape))
+        elif isinstance(lay, L.ConvLSTM2D):
+            v = ins[0]
+            t_len, cin = t.inputs[0].shape[0], t.inputs[0].shape[1]
+            if v.c != t_len * cin:
+                raise ValueError('%s: input view has %d channels, expected T*C = %d' % (lay.name, v.c, t_len * cin))
+            halo = v.halo
+            if lay.padding == 'same':
+                st, sb, sl, sr = lay.same_halo()
+                halo2 = _compose_halo(halo, ((st, sb), (sl, sr)), PAD_ZERO)
+                if halo2 is None:
+                    v = materialize(v)
+                    halo2 = Halo(st, sb, sl, sr, PAD_ZERO, PAD_ZERO)
+                halo = halo2
+            _, hl, wl = v.copy(halo=halo).logical
+            ho = hl - lay.dilation_rate[0] * (lay.kernel_size[0] - 1)
+            wo = wl - lay.dilation_rate[1] * (lay.kernel_size[1] - 1)
+            f = lay.filters
+            hbuf = plan.new_buffer(t_len * f, ho, wo)           # h_0 .. h_{T-1}, the return_sequences output
+            zx, zh = plan.new_buffer(4 * f, ho, wo), (plan.new_buffer(4 * f, ho, wo) if t_len > 1 else None)
+            cbufs = [plan.new_buffer(f, ho, wo) for _ in range(min(2, t_len))]
+            rk = ((lay.kernel_size[0] - 1) // 2, (lay.kernel_size[1] - 1) // 2)
+            for step in range(t_len):
+                emit(PlanOp('conv', v.buf, zx, (cin, v.h, v.w), layer=lay.input_part, halo=halo, src_mode=v.src_mode,
+                            act=0, in_c_off=v.c_off + step * cin, in_c_total=v.c_total, out_c_off=0, out_c_total=4 * f,
+                            out_shape=(4 * f, ho, wo)))
+                if step > 0:
+                    emit(PlanOp('conv', hbuf, zh, (f, ho, wo), layer=lay.recurrent_part,
+                                halo=Halo(rk[0], rk[0], rk[1], rk[1], PAD_ZERO, PAD_ZERO), src_mode=SRC_DIRECT, act=0,
+                                in_c_off=(step - 1) * f, in_c_total=t_len * f, out_c_off=0, out_c_total=4 * f,
+                                out_shape=(4 * f, ho, wo)))
+                emit(PlanOp('lstm', zx, hbuf, (f, ho, wo), act=ACT[lay.activation],
+                            rec_act={'hard_sigmoid': 0, 'sigmoid': 1}[lay.recurrent_activation],
+                            aux=(zh if step > 0 else None, cbufs[(step - 1) % 2] if step > 0 else None, cbufs[step % 2]),
+                            out_c_off=step * f, out_c_total=t_len * f, out_shape=(f, ho, wo)))
+            if lay.return_sequences:
+                views[t.uid] = View(hbuf, 0, t_len * f, t_len * f, ho, wo, shape=(t_len, f, ho, wo))
+            else:
+                views[t.uid] = View(hbuf, (t_len - 1) * f, f, t_len * f, ho, wo)
         elif isinstance(lay, (L.MaxPooling2D, L.UpSampling2D)):
             v = ins[0]
             if v.shape is not None:

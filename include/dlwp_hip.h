@@ -170,6 +170,15 @@ int dlwp_copy_channels(dlwp_handle_t, const void* src, void* dst, int n, int c, 
 int dlwp_series_merge_time(dlwp_handle_t, const void* series, void* out, int t, int n, int time_dim, int v, int hw,
                            int dtype, void* stream);
 
+/* ---- ConvLSTM2D cell update (keras ConvLSTM2DCell.call; call sites examples/train.py:148-155,
+ *      examples/train_functional.py:207-219).  zx / zh: (n, 4F, h*w) gate pre-activations i | f | c | o from the input
+ *      convolution (+bias) and the recurrent 'same' convolution of h_{t-1}; zh and c_prev may be NULL on the first step
+ *      (h = c = 0).   c = rec(z_f)*c_prev + rec(z_i)*act(z_c);  h = rec(z_o)*act(c).   c_out: dense (n, F, h*w); h is
+ *      written to channels [h_c_off, +F) of an h_c_total-channel buffer (the return_sequences output (T*F, h, w)).
+ *      act: DLWP_ACT_*; rec_act: 0 = hard_sigmoid (Keras default), 1 = sigmoid.                                       */
+int dlwp_convlstm_gates(dlwp_handle_t, const void* zx, const void* zh, const void* c_prev, void* c_out, void* h_out,
+                        int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act, int dtype, void* stream);
+
 /* ---- rollout: the N-step predict_timeseries loop (DLWP/model/models.py:277-293, 439-447) captured as ONE hipGraph.
  *      A plan is an array of dlwp_op describing one model call; buffer index >= 0 = caller scratch buffer,
  *      DLWP_BUF_STATE_IN = the call's input state, DLWP_BUF_OUT(o) = output o of the call.  Call t reads
@@ -181,6 +190,7 @@ int dlwp_series_merge_time(dlwp_handle_t, const void* series, void* out, int t, 
 #define DLWP_OP_MAXPOOL2   2
 #define DLWP_OP_UPSAMPLE2  3
 #define DLWP_OP_COPYCH     4
+#define DLWP_OP_LSTM_GATES 5
 typedef struct {
   int kind;                 /* DLWP_OP_*                                                                  */
   int src, dst;             /* buffer indices                                                              */
@@ -188,7 +198,10 @@ typedef struct {
   dlwp_shape4 xs;           /* stored input shape of this op                                               */
   dlwp_conv2d conv;         /* DLWP_OP_CONV2D; for DLWP_OP_COPYCH: in_c_off/in_c_total/out_c_off/out_c_total */
   dlwp_pad2d pad;           /* DLWP_OP_PAD2D (NHWC: xs = (n,1,h,w) and conv.in_c_total = channels)          */
+  int aux[4];               /* DLWP_OP_LSTM_GATES: src = zx, dst = h buffer (window conv.out_c_off/out_c_total), xs =
+                             * (n, F, h, w), aux = {zh | -1000, c_prev | -1000, c_out, rec_act}, conv.act = activation */
 } dlwp_op;
+#define DLWP_BUF_NONE (-1000)
 typedef struct dlwp_rollout* dlwp_rollout_t;
 int dlwp_rollout_create(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
                         const void* state0, void* series, size_t slot_elems, int calls, int n_outputs, int dtype,

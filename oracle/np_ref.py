@@ -254,6 +254,72 @@ def adam_keras_step(p, m, v, g, iteration, lr=1e-3, beta_1=0.9, beta_2=0.999, ep
 
 
 # ------------------------------------------------------------------------------------------------------------------ #
+# ConvLSTM2D  (PARITY UNPINNED: the arithmetic lives in Keras 2.2.x, keras/layers/convolutional_recurrent.py
+# ConvLSTM2DCell.call, absent here; restated from its published algorithm.  Call sites: examples/train.py:148-155,
+# examples/train_functional.py:207-219.  Cross-checked against oracle/torch_ref.conv_lstm2d, an independent restatement
+# on torch-CPU F.conv2d.)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def hard_sigmoid(z):
+    """Keras' default recurrent_activation: clip(0.2 z + 0.5, 0, 1)."""
+    return np.clip(0.2 * z + 0.5, 0.0, 1.0)
+
+
+def zero_padding3d(x, padding, data_format='channels_first'):
+    """keras ZeroPadding3D on (N, A, d1, d2, d3): pads the last three axes for channels_first."""
+    pads = normalize_padding(padding, 3)
+    if data_format != 'channels_first':
+        return np.pad(x, ((0, 0),) + pads + ((0, 0),))
+    return np.pad(x, ((0, 0), (0, 0)) + pads)
+
+
+def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', activation='tanh',
+                recurrent_activation='hard_sigmoid', return_sequences=True):
+    """x: (N, T, C, H, W) channels_first, already padded for the 'valid' input convolution.  kernel (kh,kw,C,4F),
+    recurrent_kernel (kh,kw,F,4F), bias (4F,); gate order i, f, c, o.  Per step (ConvLSTM2DCell.call):
+        z  = conv(x_t, kernel, dilation, padding) + bias + conv(h_{t-1}, recurrent_kernel, 'same', no dilation)
+        i, f, o = rec_act(z_i), rec_act(z_f), rec_act(z_o);  c_t = f*c_{t-1} + i*act(z_c);  h_t = o*act(c_t)
+    with h_{-1} = c_{-1} = 0.  Returns (N, T, F, Ho, Wo) or the last h (N, F, Ho, Wo)."""
+    x = np.asarray(x, dtype=np.float64)
+    n, t_len = x.shape[:2]
+    kh, kw, _, f4 = kernel.shape
+    f = f4 // 4
+    rec = {'hard_sigmoid': hard_sigmoid, 'sigmoid': lambda z: 1.0 / (1.0 + np.exp(-z))}[recurrent_activation]
+    rkh, rkw = recurrent_kernel.shape[:2]
+    h = c = None
+    outs = []
+    for t in range(t_len):
+        xt = x[:, t]
+        if padding == 'same':
+            ph, pw = dilation * (kh - 1), dilation * (kw - 1)
+            xt = np.pad(xt, ((0, 0), (0, 0), (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)))
+        z = conv2d(xt, kernel, bias, dilation, 'linear')
+        if h is not None:
+            hp = np.pad(h, ((0, 0), (0, 0), ((rkh - 1) // 2, rkh - 1 - (rkh - 1) // 2),
+                            ((rkw - 1) // 2, rkw - 1 - (rkw - 1) // 2)))
+            z = z + conv2d(hp, recurrent_kernel, None, 1, 'linear')
+        zi, zf, zc, zo = z[:, :f], z[:, f:2 * f], z[:, 2 * f:3 * f], z[:, 3 * f:]
+        c_new = rec(zi) * activate(zc, activation)
+        if c is not None:
+            c_new = c_new + rec(zf) * c
+        c = c_new
+        h = rec(zo) * activate(c, activation)
+        outs.append(h)
+    return np.stack(outs, axis=1) if return_sequences else h
+
+
+def init_conv_lstm_weights(cin, filters, ks, rng):
+    """Keras initialisers: kernel glorot_uniform over the whole (kh,kw,cin,4F) tensor, recurrent kernel here also
+    glorot_uniform (Keras uses an orthogonal matrix; any fixed numbers serve a parity test), bias zeros with the forget
+    block = 1 (unit_forget_bias)."""
+    k = glorot_uniform(tuple(ks) + (cin, 4 * filters), rng)
+    r = glorot_uniform(tuple(ks) + (filters, 4 * filters), rng)
+    b = np.zeros(4 * filters, dtype=np.float32)
+    b[filters:2 * filters] = 1.0
+    return k, r, b
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
 # a tiny interpreter for the reference's (layer_name, args, kwargs) stacks  (examples/train.py:142-221)
 # ------------------------------------------------------------------------------------------------------------------ #
 
@@ -274,6 +340,13 @@ def init_weights(layers, in_channels, rng):
             filters, ks, _, _ = _conv_args(args or (), kwargs or {})
             out.append((glorot_uniform(ks + (c, filters), rng), np.zeros(filters, dtype=np.float32)))
             c = filters
+        elif name == 'ConvLSTM2D':
+            # in_channels is then the per-time-step channel count C of the (T, C, H, W) input
+            filters, ks, _, _ = _conv_args(args or (), kwargs or {})
+            out.append(init_conv_lstm_weights(c, filters, ks, rng))
+            c = filters
+        elif name == 'Reshape':
+            c = (args or kwargs['target_shape'])[0][0] if args else kwargs['target_shape'][0]
     return out
 
 
@@ -295,6 +368,16 @@ def run_layers(layers, x, weights, record=None):
             w, b = weights[wi]
             wi += 1
             x = conv2d(x, w, b, dil, act or 'linear')
+        elif name == 'PeriodicPadding3D':
+            x = periodic_padding3d(x, args[0] if args else kwargs.get('padding', (1, 1, 1)), fmt)
+        elif name == 'ZeroPadding3D':
+            x = zero_padding3d(x, args[0] if args else kwargs.get('padding', (1, 1, 1)), fmt)
+        elif name == 'ConvLSTM2D':
+            _, _, dil, act = _conv_args(args, kwargs)
+            k, r, b = weights[wi]
+            wi += 1
+            x = conv_lstm2d(x, k, r, b, dil, kwargs.get('padding', 'valid'), act or 'tanh',
+                            kwargs.get('recurrent_activation', 'hard_sigmoid'), kwargs.get('return_sequences', False))
         elif name == 'MaxPooling2D':
             x = maxpool2(x)
         elif name == 'UpSampling2D':

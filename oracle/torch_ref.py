@@ -34,7 +34,14 @@ def _pad_layer(x, name, padding):
 def to_torch_weights(weights, dtype=torch.float32, requires_grad=False):
     """[(w_hwio, b)] numpy -> [(w_oihw, b)] torch."""
     out = []
-    for w, b in weights:
+    for item in weights:
+        if len(item) == 3:      # ConvLSTM2D: (kernel, recurrent_kernel, bias)
+            k, r, b = item
+            out.append(tuple(torch.tensor(np.ascontiguousarray(np.transpose(a, (3, 2, 0, 1))), dtype=dtype,
+                                          requires_grad=requires_grad) for a in (k, r)) +
+                       (torch.tensor(np.asarray(b), dtype=dtype, requires_grad=requires_grad),))
+            continue
+        w, b = item
         wt = torch.tensor(np.ascontiguousarray(np.transpose(w, (3, 2, 0, 1))), dtype=dtype, requires_grad=requires_grad)
         bt = torch.tensor(np.asarray(b), dtype=dtype, requires_grad=requires_grad)
         out.append((wt, bt))
@@ -57,6 +64,16 @@ def run_layers(layers, x, tweights, record=None):
                 x = torch.tanh(x)
             elif act == 'relu':
                 x = torch.relu(x)
+        elif name in ('PeriodicPadding3D', 'ZeroPadding3D'):
+            # 3-D pads of the recurrent front end act on (N, T, C, H, W): fold T into the batch-side axes via numpy
+            fn = np_ref.periodic_padding3d if name == 'PeriodicPadding3D' else np_ref.zero_padding3d
+            x = torch.from_numpy(np.ascontiguousarray(fn(x.detach().numpy(), args[0] if args else (1, 1, 1),
+                                                         kwargs.get('data_format', 'channels_first'))))
+        elif name == 'ConvLSTM2D':
+            _, _, dil, act = np_ref._conv_args(args, kwargs)
+            k, r, b = tweights[wi]
+            wi += 1
+            x = conv_lstm2d(x, k, r, b, dil, act or 'tanh', kwargs.get('return_sequences', False))
         elif name == 'MaxPooling2D':
             x = F.max_pool2d(x, 2)
         elif name == 'UpSampling2D':
@@ -68,6 +85,25 @@ def run_layers(layers, x, tweights, record=None):
         if record is not None:
             record.append((name, x))
     return x
+
+
+def conv_lstm2d(x, k_oihw, r_oihw, b, dilation=1, activation='tanh', return_sequences=True):
+    """Independent restatement of Keras' ConvLSTM2DCell on torch-CPU convolutions ('valid' input conv, 'same'
+    recurrent conv, hard_sigmoid gates); weights OIHW as to_torch_weights produces them."""
+    act = torch.tanh if activation == 'tanh' else (lambda v: v)
+    hs = lambda v: torch.clamp(0.2 * v + 0.5, 0.0, 1.0)  # noqa: E731
+    f = k_oihw.shape[0] // 4
+    h = c = None
+    outs = []
+    for t in range(x.shape[1]):
+        z = F.conv2d(x[:, t], k_oihw, b, dilation=dilation)
+        if h is not None:
+            z = z + F.conv2d(h, r_oihw, None, padding=(r_oihw.shape[2] // 2, r_oihw.shape[3] // 2))
+        i, fg, g, o = hs(z[:, :f]), hs(z[:, f:2 * f]), act(z[:, 2 * f:3 * f]), hs(z[:, 3 * f:])
+        c = i * g if c is None else fg * c + i * g
+        h = o * act(c)
+        outs.append(h)
+    return torch.stack(outs, dim=1) if return_sequences else h
 
 
 def rollout_host_loop(layers, tweights, state, forwards):

@@ -29,3 +29,18 @@ def cnn2_layers(cs, hidden=32):
     layers[0][2]['input_shape'] = tuple(cs)
     layers += _block(2, cs[0], 5, 1, 'linear')
     return tuple(layers)
+
+
+def lstm_unet_layers(cs, lstm_mult=4, widths=(32, 64, 128, 64, 32)):
+    """examples/train.py:142-221 with model_is_recurrent=True: ConvLSTM2D front end on the (T, C, H, W) input, Reshape to
+    (4*T*C, H, W), the sequential U-Net, Reshape back to (T, C, H, W)."""
+    t, c, h, w = cs
+    cf5 = {'data_format': 'channels_first'}
+    front = [('PeriodicPadding3D', ((0, 0, 2),), dict(cf5, input_shape=tuple(cs))),
+             ('ZeroPadding3D', ((0, 2, 0),), dict(cf5)),
+             ('ConvLSTM2D', (lstm_mult * c, 3), dict(cf5, dilation_rate=2, padding='valid', activation='tanh',
+                                                     return_sequences=True)),
+             ('Reshape', ((lstm_mult * t * c, h, w),), None)]
+    body = list(unet_layers((lstm_mult * t * c, h, w), widths=widths, cout=t * c))
+    body[0] = (body[0][0], body[0][1], {k: v for k, v in body[0][2].items() if k != 'input_shape'})
+    return tuple(front + body + [('Reshape', ((t, c, h, w),), None)])

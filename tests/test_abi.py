@@ -30,7 +30,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.Shape4) == 16
     assert ctypes.sizeof(_lib.Pad2d) == 24
     assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 6 * 4
-    assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24
+    assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24 + 4 * 4   # + aux[4]
 
 
 def test_conv_out_shape_and_validation_without_a_device():

@@ -282,3 +282,32 @@ def test_conv2d_batch_invariance(ops):
         for i in (0, 3):
             one = host(ops.conv2d(dev(x[i:i + 1]), wt, None, cd))
             assert np.array_equal(one[0], full[i])
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# ConvLSTM2D cell update
+# ----------------------------------------------------------------------------------------------------------------- #
+
+@pytest.mark.parametrize('n,f,h,w,first,rec', [(2, 3, 5, 8, True, 'hard_sigmoid'), (3, 4, 6, 7, False, 'hard_sigmoid'),
+                                                (1, 8, 16, 24, False, 'sigmoid'), (0, 2, 4, 4, False, 'hard_sigmoid')])
+def test_convlstm_gates_match_oracle(ops, n, f, h, w, first, rec):
+    """c = rec(z_f) c' + rec(z_i) tanh(z_c), h = rec(z_o) tanh(c) (keras ConvLSTM2DCell.call); h lands in a channel
+    window of the return_sequences buffer.  Vector (hw % 4 == 0) and scalar paths, first step (no zh / c')."""
+    rng = np.random.default_rng(n * 100 + f)
+    zx = (2 * rng.standard_normal((n, 4 * f, h, w))).astype(np.float32)
+    zh = None if first else (2 * rng.standard_normal((n, 4 * f, h, w))).astype(np.float32)
+    cp = None if first else rng.standard_normal((n, f, h, w)).astype(np.float32)
+    z = zx.astype(np.float64) + (0 if zh is None else zh)
+    r = np_ref.hard_sigmoid if rec == 'hard_sigmoid' else (lambda v: 1 / (1 + np.exp(-v)))
+    c_want = r(z[:, :f]) * np.tanh(z[:, 2 * f:3 * f]) + (0 if cp is None else r(z[:, f:2 * f]) * cp)
+    h_want = r(z[:, 3 * f:]) * np.tanh(c_want)
+    c_out = torch.empty((n, f, h, w), device='cuda')
+    h_out = torch.full((n, 3 * f, h, w), 7.0, device='cuda')
+    ops.convlstm_gates(dev(zx), None if zh is None else dev(zh), None if cp is None else dev(cp), c_out, h_out, f,
+                       h_c_off=f, act=ops.ACT_TANH, rec_act=ops.REC_HARD_SIGMOID if rec == 'hard_sigmoid' else ops.REC_SIGMOID)
+    if n == 0:
+        return
+    assert np.abs(host(c_out) - c_want).max() < 2e-6
+    got = host(h_out)
+    assert np.abs(got[:, f:2 * f] - h_want).max() < 2e-6
+    assert np.all(got[:, :f] == 7.0) and np.all(got[:, 2 * f:] == 7.0)

@@ -488,3 +488,54 @@ def test_custom_losses_match_reference_goldens_and_autograd(golden):
     for _ in range(30):
         l1 = d.model.train_on_batch(x, x)
     assert d.model.metrics_names == ['loss', 'mean_absolute_error'] and l1[0] < l0[0] and -1.1 < l1[0]
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# recurrent front end: PeriodicPadding3D + ZeroPadding3D + ConvLSTM2D  (examples/train.py:142-157)
+# ----------------------------------------------------------------------------------------------------------------- #
+
+def _lstm_weights(model, rng):
+    """Weights of a ConvLSTM2D + Conv2D stack in the oracle's form [(k, r, b) | (w, b)], biases randomised."""
+    ws = model.get_weights()
+    out, i = [], 0
+    for lay in model.layers:
+        n = len(lay._weights)
+        if n == 0:
+            continue
+        arrs = [a.copy() for a in ws[i:i + n]]
+        arrs[-1] = (arrs[-1] + 0.1 * rng.standard_normal(arrs[-1].shape)).astype(np.float32)
+        out.append(tuple(arrs))
+        i += n
+    model.set_weights([a for item in out for a in item])
+    return out
+
+
+def test_convlstm_unet_forward_and_rollout_match_oracle():
+    from dlwp_amd.model import DLWPNeuralNet
+    from tests.nets import lstm_unet_layers
+    rng = np.random.default_rng(21)
+    cs = (2, 2, 16, 24)                                               # (time_dim, variables, lat, lon)
+    layers = lstm_unet_layers(cs, widths=(16, 32, 64, 32, 16))
+    np.random.seed(3)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(layers, loss='mse', optimizer='adam')
+    assert d.model.output_shape == (None,) + cs
+    kinds = [op.kind for op in d.model.plan.ops]
+    assert kinds[:5] == ['conv', 'lstm', 'conv', 'conv', 'lstm']      # x-conv, gates | x-conv, h-conv, gates
+    weights = _lstm_weights(d.model, rng)
+    x = rng.standard_normal((3,) + cs).astype(np.float32)
+    got = d.predict(x)
+    want = np_ref.run_layers(layers, x, weights)
+    assert got.shape == want.shape == (3,) + cs
+    assert _rel(got, want) < 2 * FWD_TOL
+    want32 = torch_ref.run_layers(layers, torch.from_numpy(x), torch_ref.to_torch_weights(weights)).numpy()
+    assert _rel(got, want32) < 2 * FWD_TOL
+    # rollout: the hipGraph replay equals the host loop over predict(), and follows the reference's bookkeeping
+    series = d.predict_timeseries(x, 5)                               # ceil(5/2) = 3 forwards -> 6 steps
+    assert series.shape == (6, 3, 2, 16, 24)
+    p, ser = x, []
+    for _ in range(3):
+        p = d.predict(p)
+        ser.append(p)
+    ser = np.stack(ser)
+    assert np.array_equal(series, np_ref._merge_time(ser, 3, 3, 2, cs[1:], False).reshape(series.shape))

@@ -420,3 +420,32 @@ def test_compat_shim_registers_reference_module_names():
     d.build_model(cnn2_layers((2, 9, 12), hidden=8), loss=mean_squared_error, optimizer='adam', metrics=['mae'])
     assert d.model.metrics_names == ['loss', 'mean_absolute_error']
     assert importlib.import_module('DLWP.model.models').DLWPFunctional is DLWPFunctional
+
+
+def test_recurrent_front_end_lowers_to_convs_and_gate_updates():
+    """examples/train.py:142-157: PeriodicPadding3D + ZeroPadding3D + ConvLSTM2D + Reshape.  Both 3-D pads become the
+    fused halo of the input convolution; each time step is input conv (+ recurrent 'same' conv) + one gate kernel."""
+    from tests.nets import lstm_unet_layers
+    cs = (2, 3, 16, 24)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(lstm_unet_layers(cs, widths=(8, 16, 32, 16, 8)), loss='mse', optimizer='adam')
+    plan = d.model.plan
+    ops5 = plan.ops[:5]
+    assert [op.kind for op in ops5] == ['conv', 'lstm', 'conv', 'conv', 'lstm']
+    xc0, g0, xc1, hc1, g1 = ops5
+    assert xc0.src == P.STATE_IN and (xc0.in_c_off, xc0.xs[0], xc0.in_c_total) == (0, 3, 6) and xc1.in_c_off == 3
+    assert tuple(xc0.halo) == (2, 2, 2, 2, P.PAD_ZERO, P.PAD_WRAP) and xc0.layer.dilation_rate == (2, 2)
+    assert tuple(hc1.halo) == (1, 1, 1, 1, P.PAD_ZERO, P.PAD_ZERO) and hc1.layer.dilation_rate == (1, 1)
+    assert hc1.src == g0.dst and (hc1.in_c_off, hc1.xs[0], hc1.in_c_total) == (0, 12, 24)
+    assert g0.aux[0] is None and g0.aux[1] is None and g1.aux[1] == g0.aux[2] and g1.out_c_off == 12
+    lstm = d.model.layers[2]
+    assert [tuple(w.shape) for w in lstm.weights] == [(3, 3, 3, 48), (3, 3, 12, 48), (48,)]
+    b = lstm.get_weights()[2]
+    assert np.all(b[12:24] == 1) and b.sum() == 12                      # unit_forget_bias
+    r = lstm.get_weights()[1].reshape(-1, 48)
+    assert np.allclose(r.T @ r, np.eye(48), atol=1e-5)                  # orthogonal recurrent initialiser
+    assert d.model.output_shape == (None,) + cs
+    with pytest.raises(NotImplementedError, match='first'):
+        d2 = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
+        d2.build_model((('PeriodicPadding3D', ((1, 0, 2),), dict(CF, input_shape=cs)),
+                        ('ConvLSTM2D', (4, 3), dict(CF, return_sequences=True))), loss='mse')

@@ -107,3 +107,27 @@ def test_adam_keras_form():
     # first step of Adam moves every weight by ~lr regardless of gradient scale
     p1, _, _ = np_ref.adam_keras_step(np.zeros(3), np.zeros(3), np.zeros(3), np.array([1e-3, 1., 1e3]), 0)
     assert np.allclose(p1, -1e-3, rtol=5e-3)      # eps=1e-7 shows at |g|=1e-3
+
+
+def test_conv_lstm2d_numpy_and_torch_restatements_agree():
+    """ConvLSTM2D parity is unpinned (Keras is absent): the two independent restatements -- numpy direct sums and
+    torch-CPU F.conv2d -- must at least agree with each other, through the reference's recurrent front end
+    (examples/train.py:144-157)."""
+    import torch
+    from oracle import torch_ref
+    from tests.nets import lstm_unet_layers
+    rng = np.random.default_rng(5)
+    cs = (3, 2, 8, 12)
+    layers = lstm_unet_layers(cs, widths=(8, 8, 8, 8, 8))[:4]          # pads + ConvLSTM2D + Reshape
+    (k, r, b), = np_ref.init_weights(layers, cs[1], rng)
+    assert k.shape == (3, 3, 2, 32) and r.shape == (3, 3, 8, 32) and np.all(b[8:16] == 1) and b.sum() == 8
+    b = (b + 0.1 * rng.standard_normal(b.shape)).astype(np.float32)
+    x = rng.standard_normal((2,) + cs)
+    a = np_ref.run_layers(layers, x, [(k, r, b)])
+    t = torch_ref.run_layers(layers, torch.tensor(x), torch_ref.to_torch_weights([(k, r, b)], dtype=torch.float64)).numpy()
+    assert a.shape == (2, 3 * 8, 8, 12) and np.abs(a - t).max() < 1e-12
+    # first step by hand: h_{-1} = c_{-1} = 0  ->  c_0 = hs(z_i) tanh(z_c), h_0 = hs(z_o) tanh(c_0)
+    xp = np_ref.zero_padding3d(np_ref.periodic_padding3d(x, (0, 0, 2)), (0, 2, 0))
+    z = np_ref.conv2d(xp[:, 0], k, b, 2, 'linear')
+    c0 = np_ref.hard_sigmoid(z[:, :8]) * np.tanh(z[:, 16:24])
+    assert np.abs(a[:, :8] - np_ref.hard_sigmoid(z[:, 24:]) * np.tanh(c0)).max() < 1e-12
