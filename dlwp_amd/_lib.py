@@ -117,6 +117,7 @@ _sig('dlwp_maxpool2_bwd', [_vp, _vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_upsample2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_upsample2_bwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_convlstm_gates', [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
+_sig('dlwp_convlstm_gates_bwd', [_vp] * 9 + [_i] * 8 + [_vp])
 _sig('dlwp_copy_channels', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _P(_vp)])

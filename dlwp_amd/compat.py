@@ -28,7 +28,7 @@ def _module(name, **attrs):
 
 
 def install(force=False):
-    from . import custom, engine, layers, training, util
+    from . import custom, engine, layers, regularizers, training, util
     from . import model as model_pkg
     from .model import generators, models
     have_keras = 'keras' in sys.modules or importlib.util.find_spec('keras') is not None
@@ -45,6 +45,8 @@ def install(force=False):
                               EarlyStopping=custom.EarlyStopping)
     keras.losses = _module('keras.losses', mean_squared_error=training.mean_squared_error,
                            mean_absolute_error=training.mean_absolute_error)
+    keras.regularizers = _module('keras.regularizers', l2=regularizers.l2, l1_l2=regularizers.l1_l2,
+                                 L1L2=regularizers.L1L2)
     keras.optimizers = _module('keras.optimizers', Adam=training.Adam, SGD=training.SGD)
     dlwp = _module('DLWP')
     dlwp.custom = _module('DLWP.custom', **{k: v for k, v in vars(custom).items() if not k.startswith('_')})

@@ -67,6 +67,46 @@ __global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __rest
   }
 }
 
+__device__ __forceinline__ float rec_grad(float z, int rec_act) {
+  if (rec_act == 0) return (z > -2.5f && z < 2.5f) ? 0.2f : 0.f;  // d/dz clip(0.2 z + 0.5, 0, 1)
+  const float s = 1.f / (1.f + __expf(-z));
+  return s * (1.f - s);
+}
+
+// derivative of the activation expressed through its VALUE y = act(z)
+__device__ __forceinline__ float act_grad_from_value(float y, int act) {
+  if (act == DLWP_ACT_TANH) return 1.f - y * y;
+  if (act == DLWP_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// backward of the cell update: dz (n, 4F, hw) = dL/d(zx) = dL/d(zh), dc_prev = dL/dc_{t-1}
+__global__ __launch_bounds__(256) void convlstm_gates_bwd_kernel(
+    const float* __restrict__ zx, const float* __restrict__ zh, const float* __restrict__ c_prev,
+    const float* __restrict__ c, const float* __restrict__ dh, const float* __restrict__ dc_in, float* __restrict__ dz,
+    float* __restrict__ dc_prev, int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act) {
+  const long long per = (long long)f * hw;
+  const long long total = (long long)n * per;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long s = e / per, r = e - s * per;
+    const long long zb = s * 4 * per + r;
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = zx[zb + g * per] + (zh ? zh[zb + g * per] : 0.f);
+    const float cp = c_prev ? c_prev[e] : 0.f;
+    const float gi = rec_apply(z[0], rec_act), gf = rec_apply(z[1], rec_act), go = rec_apply(z[3], rec_act);
+    const float gg = act_apply(z[2], act);
+    const float tc = act_apply(c[e], act);
+    const float dhv = dh[(s * h_c_total + h_c_off) * hw + r];
+    const float dcv = dhv * go * act_grad_from_value(tc, act) + (dc_in ? dc_in[e] : 0.f);
+    dz[zb] = dcv * gg * rec_grad(z[0], rec_act);
+    dz[zb + per] = c_prev ? dcv * cp * rec_grad(z[1], rec_act) : 0.f;
+    dz[zb + 2 * per] = dcv * gi * act_grad_from_value(gg, act);
+    dz[zb + 3 * per] = dhv * tc * rec_grad(z[3], rec_act);
+    if (dc_prev) dc_prev[e] = dcv * gf;
+  }
+}
+
 }  // namespace
 
 extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* zh, const void* c_prev, void* c_out,
@@ -94,5 +134,29 @@ extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* 
     convlstm_gates_kernel<1><<<grid, 256, 0, s>>>((const float*)zx, (const float*)zh, (const float*)c_prev, (float*)c_out,
                                                   (float*)h_out, n, f, hw, h_c_off, h_c_total, act, rec_act);
   DLWP_LAUNCH_CHECK("convlstm_gates_kernel");
+  return DLWP_OK;
+}
+
+extern "C" int dlwp_convlstm_gates_bwd(dlwp_handle_t h, const void* zx, const void* zh, const void* c_prev, const void* c,
+                                       const void* dh, const void* dc_in, void* dz, void* dc_prev, int n, int f, int hw,
+                                       int h_c_off, int h_c_total, int act, int rec_act, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h != nullptr, "dlwp_convlstm_gates_bwd: null handle");
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_convlstm_gates_bwd: dtype %d not supported", dtype);
+  DLWP_CHECK_ARG(n >= 0 && f > 0 && hw > 0, "dlwp_convlstm_gates_bwd: bad sizes n=%d f=%d hw=%d", n, f, hw);
+  DLWP_CHECK_ARG(h_c_off >= 0 && h_c_off + f <= h_c_total, "dlwp_convlstm_gates_bwd: h window [%d,%d) of %d", h_c_off,
+                 h_c_off + f, h_c_total);
+  DLWP_CHECK_ARG((unsigned)act <= 2u && (unsigned)rec_act <= 1u, "dlwp_convlstm_gates_bwd: unknown activation");
+  if (n == 0) return DLWP_OK;
+  DLWP_CHECK_ARG(zx && c && dh && dz, "dlwp_convlstm_gates_bwd: null pointer");
+  DLWP_CHECK_ARG((c_prev != nullptr) == (dc_prev != nullptr) || dc_prev == nullptr,
+                 "dlwp_convlstm_gates_bwd: dc_prev without c_prev");
+  const long long elems = (long long)n * f * hw;
+  long long blocks = (elems + 255) / 256;
+  const long long cap = (long long)h->cu_count * 16;
+  const int grid = (int)(blocks < cap ? blocks : cap);
+  convlstm_gates_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(
+      (const float*)zx, (const float*)zh, (const float*)c_prev, (const float*)c, (const float*)dh, (const float*)dc_in,
+      (float*)dz, (float*)dc_prev, n, f, hw, h_c_off, h_c_total, act, rec_act);
+  DLWP_LAUNCH_CHECK("convlstm_gates_bwd_kernel");
   return DLWP_OK;
 }

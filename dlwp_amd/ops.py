@@ -173,6 +173,18 @@ def convlstm_gates(zx, zh, c_prev, c_out, h_out, f, h_c_off=0, act=1, rec_act=RE
     return h_out
 
 
+def convlstm_gates_bwd(zx, zh, c_prev, c, dh, dc_in, f, h_c_off=0, act=1, rec_act=REC_HARD_SIGMOID, want_dc_prev=True):
+    """Backward of convlstm_gates: returns (dz (n, 4F, h, w), dc_prev | None)."""
+    _check_f32(zx, c, dh)
+    n, f4, h, w = zx.shape
+    dz = torch.empty_like(zx)
+    dcp = torch.empty_like(c) if (c_prev is not None and want_dc_prev) else None
+    _lib.check(_lib.lib.dlwp_convlstm_gates_bwd(_lib.handle(_dev(zx)), _ptr(zx), _ptr(zh), _ptr(c_prev), _ptr(c), _ptr(dh),
+                                                _ptr(dc_in), _ptr(dz), _ptr(dcp), n, int(f), h * w, int(h_c_off),
+                                                dh.shape[1], int(act), int(rec_act), _lib.F32, _stream(zx)))
+    return dz, dcp
+
+
 def series_merge_time(series, time_dim):
     """(T, N, time_dim*V, ...) -> (T*time_dim, N, V, ...)  -- DLWP/model/models.py:294-300."""
     _check_f32(series)

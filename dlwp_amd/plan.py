@@ -347,21 +347,24 @@ def build_plan(inputs, outputs):
             wo = wl - lay.dilation_rate[1] * (lay.kernel_size[1] - 1)
             f = lay.filters
             hbuf = plan.new_buffer(t_len * f, ho, wo)           # h_0 .. h_{T-1}, the return_sequences output
-            zx, zh = plan.new_buffer(4 * f, ho, wo), (plan.new_buffer(4 * f, ho, wo) if t_len > 1 else None)
-            cbufs = [plan.new_buffer(f, ho, wo) for _ in range(min(2, t_len))]
+            # every step keeps its own pre-activations and cell state: they are the saved activations of the backward
+            # pass (dlwp_convlstm_gates_bwd) -- T is the reference's time_dim (2), so this costs little
+            zxs = [plan.new_buffer(4 * f, ho, wo) for _ in range(t_len)]
+            zhs = [None] + [plan.new_buffer(4 * f, ho, wo) for _ in range(t_len - 1)]
+            cbufs = [plan.new_buffer(f, ho, wo) for _ in range(t_len)]
             rk = ((lay.kernel_size[0] - 1) // 2, (lay.kernel_size[1] - 1) // 2)
             for step in range(t_len):
-                emit(PlanOp('conv', v.buf, zx, (cin, v.h, v.w), layer=lay.input_part, halo=halo, src_mode=v.src_mode,
-                            act=0, in_c_off=v.c_off + step * cin, in_c_total=v.c_total, out_c_off=0, out_c_total=4 * f,
-                            out_shape=(4 * f, ho, wo)))
+                emit(PlanOp('conv', v.buf, zxs[step], (cin, v.h, v.w), layer=lay.input_part, halo=halo,
+                            src_mode=v.src_mode, act=0, in_c_off=v.c_off + step * cin, in_c_total=v.c_total, out_c_off=0,
+                            out_c_total=4 * f, out_shape=(4 * f, ho, wo)))
                 if step > 0:
-                    emit(PlanOp('conv', hbuf, zh, (f, ho, wo), layer=lay.recurrent_part,
+                    emit(PlanOp('conv', hbuf, zhs[step], (f, ho, wo), layer=lay.recurrent_part,
                                 halo=Halo(rk[0], rk[0], rk[1], rk[1], PAD_ZERO, PAD_ZERO), src_mode=SRC_DIRECT, act=0,
                                 in_c_off=(step - 1) * f, in_c_total=t_len * f, out_c_off=0, out_c_total=4 * f,
                                 out_shape=(4 * f, ho, wo)))
-                emit(PlanOp('lstm', zx, hbuf, (f, ho, wo), act=ACT[lay.activation],
+                emit(PlanOp('lstm', zxs[step], hbuf, (f, ho, wo), act=ACT[lay.activation],
                             rec_act={'hard_sigmoid': 0, 'sigmoid': 1}[lay.recurrent_activation],
-                            aux=(zh if step > 0 else None, cbufs[(step - 1) % 2] if step > 0 else None, cbufs[step % 2]),
+                            aux=(zhs[step], cbufs[step - 1] if step > 0 else None, cbufs[step]),
                             out_c_off=step * f, out_c_total=t_len * f, out_shape=(f, ho, wo)))
             if lay.return_sequences:
                 views[t.uid] = View(hbuf, 0, t_len * f, t_len * f, ho, wo, shape=(t_len, f, ho, wo))

@@ -17,8 +17,16 @@ def _layer_config(lay):
     cfg = {'name': lay.name}
     if isinstance(lay, L.InputLayer):
         cfg['input_shape'] = list(lay.batch_input_shape[1:])
-    elif isinstance(lay, L._Pad2DBase):
+    elif isinstance(lay, (L._Pad2DBase, L._Pad3DBase)):
         cfg.update(padding=[list(p) for p in lay.padding], data_format=lay.data_format)
+    elif isinstance(lay, L.ConvLSTM2D):
+        from .regularizers import L1L2
+        cfg.update(filters=lay.filters, kernel_size=list(lay.kernel_size), padding=lay.padding,
+                   data_format=lay.data_format, dilation_rate=list(lay.dilation_rate), activation=lay.activation,
+                   recurrent_activation=lay.recurrent_activation, use_bias=lay.use_bias,
+                   unit_forget_bias=lay.unit_forget_bias, return_sequences=lay.return_sequences)
+        if isinstance(lay.kernel_regularizer, L1L2):
+            cfg['kernel_regularizer'] = {'l2': lay.kernel_regularizer.l2}
     elif isinstance(lay, L.Conv2D):
         cfg.update(filters=lay.filters, kernel_size=list(lay.kernel_size), padding=lay.padding,
                    data_format=lay.data_format, dilation_rate=list(lay.dilation_rate), activation=lay.activation,
@@ -114,6 +122,9 @@ def load_model_file(path, custom_objects=None, device=None):
         for k in ('kernel_size', 'dilation_rate', 'target_shape', 'input_shape'):
             if k in cfg and isinstance(cfg[k], list):
                 cfg[k] = tuple(cfg[k])
+        if isinstance(cfg.get('kernel_regularizer'), dict):
+            from .regularizers import L1L2
+            cfg['kernel_regularizer'] = L1L2(l2=cfg['kernel_regularizer']['l2'])
         objs.append(cls(**cfg))
     tensors = []
     for node in arch['nodes']:

@@ -12,6 +12,7 @@ import time
 import numpy as np
 import torch
 
+from . import layers as L
 from . import plan as P
 from .custom import Callback, History
 
@@ -147,6 +148,8 @@ class Trainer(object):
 
     # -- helpers ------------------------------------------------------------------------------------------------------ #
     def _grad_view(self, layer, name):
+        if isinstance(layer, L._ConvPart):       # a ConvLSTM2D convolution: the weights belong to the parent layer
+            layer, name = layer.parent, (layer.which if name == 'kernel' else 'bias')
         for lay, nm, off, numel, shape in self.entries:
             if lay is layer and nm == name:
                 return self.flat_grads[off:off + numel].view(shape)
@@ -201,6 +204,27 @@ class Trainer(object):
             dys.append(dy)
         return outs, self._loss_out, dys
 
+    # -- kernel regularisers (keras.regularizers.l2 on the ConvLSTM2D kernel, examples/train.py:154) --------------------- #
+    def _regularized(self):
+        from .regularizers import L1L2
+        for lay, nm, off, numel, shape in self.entries:
+            reg = getattr(lay, 'kernel_regularizer', None)
+            if nm == 'kernel' and isinstance(reg, L1L2) and reg.l2 > 0:
+                yield reg.l2, off, numel
+
+    def _add_regularizer_gradients(self):
+        from . import ops
+        for l2, off, numel in self._regularized():
+            ops.axpby(self.flat_params[off:off + numel], self.flat_grads[off:off + numel], 2.0 * l2, 1.0)
+
+    def _regularizer_loss(self):
+        """sum over regularised kernels of l2 * sum(w^2) -- Keras adds it to the reported total loss."""
+        tot = 0.0
+        for l2, off, numel in self._regularized():
+            w = self.flat_params[off:off + numel]
+            tot += l2 * float(torch.dot(w, w))
+        return tot
+
     def _report(self, loss_vals):
         """[loss, (per-output losses), metrics...] as python floats from the device loss table."""
         v = loss_vals.detach().cpu().numpy().astype(np.float64)
@@ -212,7 +236,8 @@ class Trainer(object):
             per_out = [float(self.model.loss.scale * v[o, 0]) for o in range(n_out)]
         else:
             per_out = [float(v[o, 1]) for o in range(n_out)]
-        total = float(sum(w * l for w, l in zip(self.loss_weights, per_out)))
+        reg = getattr(self, '_reg_at_step', None)
+        total = float(sum(w * l for w, l in zip(self.loss_weights, per_out))) + (self._regularizer_loss() if reg is None else reg)
         col = {'mean_squared_error': 1, 'mean_absolute_error': 2}
         if n_out == 1:
             return [total] + [float(v[0, col[k]]) for k in self.metric_keys]
@@ -261,8 +286,15 @@ class Trainer(object):
                 written.setdefault(buf, []).append((c_off, c))
             elif full and written[buf] == [(0, g.shape[1])]:
                 ops.axpby(dense.reshape(-1), g.view(-1), 1.0, 1.0)
+            elif all(any(o <= ch < o + k for o, k in written[buf]) for ch in range(c_off, c_off + c)):
+                # the window already holds a gradient everywhere (e.g. h_{t-1}: read by the next layer as part of the
+                # whole sequence AND by the recurrent convolution of step t): extract, add, put back
+                cur = torch.empty((n, c) + tuple(g.shape[2:]), dtype=torch.float32, device=self.device)
+                ops.copy_channels(g, cur, c, c_off, 0)
+                ops.axpby(dense.reshape(-1), cur.view(-1), 1.0, 1.0)
+                ops.copy_channels(cur, g, c, 0, c_off)
             else:
-                raise NotImplementedError('overlapping partial channel windows in the backward pass')
+                raise NotImplementedError('partially overlapping channel windows in the backward pass')
 
         touched_layers = set()
         descs = self.model.executor._descriptors()
@@ -289,6 +321,8 @@ class Trainer(object):
                     else:
                         ops.bias_grad(dz, gb, lay.filters)
                 touched_layers.add(id(lay))
+                if isinstance(lay, L._ConvPart):
+                    touched_layers.add(id(lay.parent))
                 if op.src == P.STATE_IN:
                     continue                  # no gradient w.r.t. the model input is needed
                 cin = op.xs[0]
@@ -319,6 +353,26 @@ class Trainer(object):
                             ops.copy_channels(src, xw, cin, op.in_c_off, 0)
                         dense = ops.maxpool2_bwd(xw, tmp)
                     deposit(op.src, op.in_c_off, cin, dense)
+            elif op.kind == 'lstm':
+                zh_i, cp_i, co_i = op.aux
+                f = op.xs[0]
+                win = (op.out_c_off, f)
+                if not all(any(o <= ch < o + k for o, k in written.get(op.dst, [])) for ch in range(win[0], win[0] + f)):
+                    if overlaps(op.dst, *win):
+                        raise NotImplementedError('ConvLSTM2D output used through partially overlapping channel windows')
+                    deposit(op.dst, win[0], f, torch.zeros((n, f) + tuple(gD.shape[2:]), dtype=torch.float32,
+                                                           device=self.device))   # this h_t feeds nothing downstream
+                dz, dcp = ops.convlstm_gates_bwd(src, tensor(zh_i) if zh_i is not None else None,
+                                                 tensor(cp_i) if cp_i is not None else None, tensor(co_i), gD,
+                                                 grads.get(co_i), f, h_c_off=op.out_c_off, act=op.act, rec_act=op.rec_act)
+                grads[op.src] = dz
+                written[op.src] = [(0, 4 * f)]
+                if zh_i is not None:
+                    grads[zh_i] = dz                 # z = zx + zh: the same gradient flows into both convolutions
+                    written[zh_i] = [(0, 4 * f)]
+                if cp_i is not None:
+                    grads[cp_i] = dcp
+                    written[cp_i] = [(0, f)]
             elif op.kind == 'copy':
                 if op.src == P.STATE_IN:
                     continue
@@ -385,6 +439,8 @@ class Trainer(object):
             scale = (hi - lo) * dp.world / float(n_global)
         outs, loss_vals, dys = self._forward_loss(x, ys, True, scale)
         self._backward(x, outs, dys)
+        self._add_regularizer_gradients()
+        self._reg_at_step = self._regularizer_loss()      # Keras reports the penalty at the weights the step started from
         if dp is not None and dp.world > 1:
             dp.all_reduce_sum_(self.flat_grads)
             self._apply(1.0 / dp.world)
@@ -393,9 +449,13 @@ class Trainer(object):
             self._apply(1.0)
         if return_device:
             return loss_vals
-        return self._report(loss_vals)
+        try:
+            return self._report(loss_vals)
+        finally:
+            self._reg_at_step = None
 
     def test_on_batch(self, x, y):
+        self._reg_at_step = None
         x = self._to_device(x)
         ys = self._targets(y, x.shape[0])
         _, loss_vals, _ = self._forward_loss(x, ys, False)

@@ -178,6 +178,13 @@ int dlwp_series_merge_time(dlwp_handle_t, const void* series, void* out, int t, 
  *      act: DLWP_ACT_*; rec_act: 0 = hard_sigmoid (Keras default), 1 = sigmoid.                                       */
 int dlwp_convlstm_gates(dlwp_handle_t, const void* zx, const void* zh, const void* c_prev, void* c_out, void* h_out,
                         int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act, int dtype, void* stream);
+/* backward of the cell update (one step of back-propagation through time behind DLWPNeuralNet.fit on the recurrent
+ * model): zx, zh, c_prev as given to the forward, c = the c_out it produced, dh = dL/dh_t read from channels
+ * [h_c_off, +F) of an h_c_total-channel gradient buffer, dc_in = dL/dc_t arriving from step t+1 (NULL on the last step).
+ * Writes dz (n, 4F, h*w) = dL/d zx = dL/d zh and dc_prev = dL/dc_{t-1} (NULL allowed when there is no previous step). */
+int dlwp_convlstm_gates_bwd(dlwp_handle_t, const void* zx, const void* zh, const void* c_prev, const void* c,
+                            const void* dh, const void* dc_in, void* dz, void* dc_prev, int n, int f, int hw,
+                            int h_c_off, int h_c_total, int act, int rec_act, int dtype, void* stream);
 
 /* ---- rollout: the N-step predict_timeseries loop (DLWP/model/models.py:277-293, 439-447) captured as ONE hipGraph.
  *      A plan is an array of dlwp_op describing one model call; buffer index >= 0 = caller scratch buffer,

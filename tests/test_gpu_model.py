@@ -539,3 +539,52 @@ def test_convlstm_unet_forward_and_rollout_match_oracle():
         ser.append(p)
     ser = np.stack(ser)
     assert np.array_equal(series, np_ref._merge_time(ser, 3, 3, 2, cs[1:], False).reshape(series.shape))
+
+
+def test_convlstm_train_step_matches_autograd_oracle_with_l2():
+    """Back-propagation through time on the recurrent front end (gate backward kernel + the two convolutions per step,
+    weight gradients accumulated over the steps), l2 kernel regulariser on the ConvLSTM2D kernel as in
+    examples/train.py:154, against torch autograd on the float64 restatement."""
+    from dlwp_amd.model import DLWPNeuralNet
+    from dlwp_amd.regularizers import l2
+    from tests.nets import lstm_unet_layers
+    rng = np.random.default_rng(31)
+    cs = (3, 2, 8, 12)                                                # three time steps: h_0, h_1 feed recurrent convs
+    lam = 1e-3
+    layers = list(lstm_unet_layers(cs, widths=(8, 16, 16, 16, 8)))
+    layers[2] = (layers[2][0], layers[2][1], dict(layers[2][2], kernel_regularizer=l2(lam)))
+    layers = tuple(layers)
+    np.random.seed(4)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=3, scaler_type=None, scale_targets=False)
+    d.build_model(layers, loss='mse', optimizer='adam', metrics=['mae'])
+    weights = _lstm_weights(d.model, rng)
+    x = rng.standard_normal((4,) + cs).astype(np.float32)
+    y = rng.standard_normal((4,) + cs).astype(np.float32)
+    # oracle: float64 autograd
+    tw = torch_ref.to_torch_weights(weights, dtype=torch.float64, requires_grad=True)
+    out = torch_ref.run_layers(layers, torch.tensor(x, dtype=torch.float64), tw)
+    yt = torch.tensor(y, dtype=torch.float64)
+    mse = ((out - yt) ** 2).mean()
+    reg = lam * (tw[0][0] ** 2).sum()
+    (mse + reg).backward()
+    grads_ref = []
+    for item in tw:
+        for k, a in enumerate(item):
+            g = a.grad.numpy()
+            grads_ref.append(g.transpose(2, 3, 1, 0) if g.ndim == 4 else g)
+    vals = d.model.train_on_batch(x, y)
+    assert vals[0] == pytest.approx(float(mse + reg), rel=2e-5)
+    assert vals[1] == pytest.approx(float((out - yt).abs().mean()), rel=2e-5)
+    torch.cuda.synchronize()
+    tr = d.model._trainer
+    off = 0
+    for g_ref in grads_ref:
+        g = tr.flat_grads[off:off + g_ref.size].cpu().numpy().reshape(g_ref.shape)
+        off += g_ref.size
+        assert np.abs(g - g_ref).max() <= 3e-4 * max(np.abs(g_ref).max(), 1e-6), g_ref.shape
+    assert off == tr.flat_grads.numel()
+    # a few more steps reduce the loss
+    first = vals[0]
+    for _ in range(20):
+        vals = d.model.train_on_batch(x, y)
+    assert vals[0] < first

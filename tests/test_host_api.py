@@ -449,3 +449,22 @@ def test_recurrent_front_end_lowers_to_convs_and_gate_updates():
         d2 = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
         d2.build_model((('PeriodicPadding3D', ((1, 0, 2),), dict(CF, input_shape=cs)),
                         ('ConvLSTM2D', (4, 3), dict(CF, return_sequences=True))), loss='mse')
+
+
+def test_recurrent_model_file_round_trip(tmp_path):
+    """util.save_model / load_model (reference DLWP/util.py:126-174) keep the ConvLSTM2D front end: layer configs, l2
+    regulariser, Keras-ordered weights (kernel, recurrent_kernel, bias)."""
+    from dlwp_amd.regularizers import l2
+    from tests.nets import lstm_unet_layers
+    cs = (2, 3, 16, 24)
+    layers = list(lstm_unet_layers(cs, widths=(8, 16, 32, 16, 8)))
+    layers[2] = (layers[2][0], layers[2][1], dict(layers[2][2], kernel_regularizer=l2(1e-4)))
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(tuple(layers), loss='mse', optimizer='adam')
+    util.save_model(d, str(tmp_path / 'lstm'))
+    d2 = util.load_model(str(tmp_path / 'lstm'))
+    assert d2.is_recurrent and d2.model.output_shape == (None,) + cs
+    assert [op.kind for op in d2.model.plan.ops] == [op.kind for op in d.model.plan.ops]
+    lstm = [lay for lay in d2.model.layers if isinstance(lay, L.ConvLSTM2D)][0]
+    assert lstm.kernel_regularizer.l2 == 1e-4 and lstm.return_sequences and lstm.dilation_rate == (2, 2)
+    assert all(np.array_equal(a, b) for a, b in zip(d.model.get_weights(), d2.model.get_weights()))
