@@ -52,11 +52,13 @@ def install(force=False):
     dlwp.custom = _module('DLWP.custom', **{k: v for k, v in vars(custom).items() if not k.startswith('_')})
     dlwp.util = _module('DLWP.util', **{k: v for k, v in vars(util).items() if not k.startswith('_')})
     dlwp.model = _module('DLWP.model', DLWPNeuralNet=models.DLWPNeuralNet, DLWPFunctional=models.DLWPFunctional,
-                         DataGenerator=generators.DataGenerator, ArrayDataset=generators.ArrayDataset)
+                         DataGenerator=generators.DataGenerator, ArrayDataset=generators.ArrayDataset,
+                         SeriesDataGenerator=generators.SeriesDataGenerator)
     dlwp.model.models = _module('DLWP.model.models', DLWPNeuralNet=models.DLWPNeuralNet,
                                 DLWPFunctional=models.DLWPFunctional)
     dlwp.model.generators = _module('DLWP.model.generators', DataGenerator=generators.DataGenerator,
-                                    ArrayDataset=generators.ArrayDataset)
+                                    ArrayDataset=generators.ArrayDataset,
+                                    SeriesDataGenerator=generators.SeriesDataGenerator)
     return dlwp
 
 

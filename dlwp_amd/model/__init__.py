@@ -1,2 +1,3 @@
 from .models import DLWPNeuralNet, DLWPFunctional  # noqa: F401
-from .generators import DataGenerator, ArrayDataset  # noqa: F401
+from .generators import (DataGenerator, ArrayDataset, SeriesDataGenerator, SeriesDataset,  # noqa: F401
+                         LabeledArray)

@@ -5,6 +5,10 @@ Batch feed for fit_generator.
                   properties, shuffle order, NaN-sample removal and (X, y) batches of shape (n,)+convolution_shape.
   ArrayDataset    an in-memory stand-in for the xarray Dataset the reference reads (dims, predictors, targets, isel):
                   xarray / netCDF4 are absent from this image and stay out of scope.
+  SeriesDataGenerator  the generator examples/train.py:120 and validate.py:191 construct (DLWP/model/generators.py:
+                  323-629): one continuous time series, variable / level selection, input / output time windows,
+                  `interval`, multi-target `sequence`, optional insolation channel.
+  SeriesDataset / LabeledArray   in-memory stand-ins for the xarray objects it reads (label selection, coordinates).
   DeviceLoader    what replaces Keras' worker *processes* + per-batch feed_dict copy: a background thread gathers batch
                   i+1 into a pinned host buffer and a copy stream moves it to HBM while batch i trains
                   (pinned-host -> HBM double buffering).
@@ -13,7 +17,7 @@ import threading
 
 import numpy as np
 
-from ..util import delete_nan_samples
+from ..util import delete_nan_samples, insolation
 
 
 class _Var(object):
@@ -143,6 +147,292 @@ class DataGenerator(object):
         # the reference tests `index > len(self)`, so index == len(self) silently returns the WHOLE dataset (empty index
         # list -> "all samples"); raise instead
         if index >= len(self) or index < 0:
+            raise IndexError('batch index out of range')
+        return self.generate(self._indices[index * self._batch_size:(index + 1) * self._batch_size])
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+class LabeledArray(object):
+    """The part of xarray.DataArray the series generator uses: `values`, `shape`, named dimensions with coordinate
+    labels, `.sel(dim=[labels])`, `.isel(dim=index)`, `.load()`, and coordinates as attributes (`.sample.values` ...)."""
+
+    class _Coord(object):
+        def __init__(self, values):
+            self.values = values
+
+    def __init__(self, values, coords, dims):
+        self.values = np.asarray(values)
+        self.dims = tuple(dims)
+        if len(self.dims) != self.values.ndim:
+            raise ValueError('dims %r do not match an array of rank %d' % (self.dims, self.values.ndim))
+        self.coords = {k: np.asarray(v) for k, v in (coords or {}).items()}
+        for d, n in zip(self.dims, self.values.shape):
+            if d in self.coords and len(self.coords[d]) != n:
+                raise ValueError('coordinate %r has %d labels for an axis of length %d' % (d, len(self.coords[d]), n))
+
+    @property
+    def shape(self):
+        return self.values.shape
+
+    def __getattr__(self, name):
+        coords = self.__dict__.get('coords', {})
+        if name in coords:
+            return LabeledArray._Coord(coords[name])
+        raise AttributeError(name)
+
+    def load(self):
+        return self
+
+    def sel(self, **selection):
+        out = self
+        for dim, labels in selection.items():
+            if dim not in out.dims:
+                raise KeyError('no dimension %r (have %r)' % (dim, out.dims))
+            scalar = np.ndim(labels) == 0
+            have = out.coords[dim].tolist()
+            try:
+                idx = [have.index(l) for l in ([labels] if scalar else list(labels))]
+            except ValueError:
+                raise KeyError('label(s) %r not found on dimension %r' % (labels, dim))
+            ax = out.dims.index(dim)
+            vals = np.take(out.values, idx[0] if scalar else idx, axis=ax)
+            coords = dict(out.coords)
+            if scalar:
+                coords.pop(dim)
+                out = LabeledArray(vals, coords, tuple(d for d in out.dims if d != dim))
+            else:
+                coords[dim] = out.coords[dim][idx]
+                out = LabeledArray(vals, coords, out.dims)
+        return out
+
+    def isel(self, **indexers):
+        out = self
+        for dim, i in indexers.items():
+            ax = out.dims.index(dim)
+            vals = np.take(out.values, i, axis=ax) if np.ndim(i) == 0 else out.values[(slice(None),) * ax + (i,)]
+            coords = dict(out.coords)
+            if np.ndim(i) == 0 and not isinstance(i, slice):
+                coords.pop(dim, None)
+                out = LabeledArray(vals, coords, tuple(d for d in out.dims if d != dim))
+            else:
+                if dim in coords:
+                    coords[dim] = coords[dim][i]
+                out = LabeledArray(vals, coords, out.dims)
+        return out
+
+
+class SeriesDataset(object):
+    """A predictor file holding ONE continuous time series: `predictors` (sample, [time_step,] selection dims..., lat,
+    lon) with coordinates sample (timestamps), lat, lon and the labels of the selection dimensions."""
+
+    def __init__(self, predictors, coords, dims):
+        self.predictors = predictors if isinstance(predictors, LabeledArray) else LabeledArray(predictors, coords, dims)
+        self.dims = dict(zip(self.predictors.dims, self.predictors.shape))
+
+    def load(self):
+        return self
+
+    def close(self):
+        pass
+
+
+class SeriesDataGenerator(object):
+    """Batches from a continuous series: inputs = `input_time_steps` consecutive states of the `input_sel` variables
+    (+ insolation), targets = `output_time_steps` states of the `output_sel` variables starting `interval` steps after
+    the last input step; `sequence` = K gives a list of K consecutive target blocks (multi-output functional models).
+    Same constructor, properties and batch layout as the reference (DLWP/model/generators.py:323-629)."""
+
+    def __init__(self, model, ds, input_sel=None, output_sel=None, input_time_steps=1, output_time_steps=1,
+                 sequence=None, interval=1, add_insolation=False, batch_size=32, shuffle=False, remove_nan=True,
+                 load='required'):
+        self.model = model
+        if not hasattr(ds, 'predictors'):
+            raise ValueError("dataset must have 'predictors' variable")
+        assert int(input_time_steps) > 0
+        assert int(output_time_steps) > 0
+        assert int(batch_size) > 0
+        assert int(interval) > 0
+        if sequence is not None:
+            assert int(sequence) > 0
+        if load and load not in ['full', 'required', 'minimal']:
+            if isinstance(load, bool):
+                load = 'required'
+            else:
+                raise ValueError("'load' must be one of 'full', 'required', or 'minimal'")
+        self.ds = ds
+        if load == 'full':
+            ds.load()
+        self._batch_size = batch_size
+        self._shuffle = shuffle
+        self._remove_nan = remove_nan
+        self._is_convolutional = model.is_convolutional
+        self._keep_time_axis = model.is_recurrent
+        self._impute_missing = model.impute
+        self._indices = []
+        self._sequence = sequence
+        n_out = output_time_steps * (sequence if sequence is not None else 1)
+        self._n_sample = ds.dims['sample'] - input_time_steps - n_out + 2 - interval
+        # a file written with a 'time_step' dimension carries the initialisation time at time_step = -1
+        self.da = ds.predictors.isel(time_step=-1) if 'time_step' in ds.dims else ds.predictors
+        self._input_sel = input_sel or {}
+        self._output_sel = output_sel or {}
+        self._input_time_steps = input_time_steps
+        self._output_time_steps = output_time_steps
+        self._interval = interval
+        if load == 'minimal':
+            self.da.load()
+        self.input_da = self.da.sel(**self._input_sel)
+        self.output_da = self.da.sel(**self._output_sel)
+        if load == 'required':
+            self.input_da.load()
+            self.output_da.load()
+        self.on_epoch_end()
+        self._add_insolation = int(add_insolation)
+        if add_insolation:
+            sol = insolation(self.da.sample.values, self.da.lat.values, self.da.lon.values)
+            self.insolation_da = LabeledArray(sol, {'sample': self.da.sample.values, 'lat': self.da.lat.values,
+                                                    'lon': self.da.lon.values}, ('sample', 'lat', 'lon'))
+
+    # -- shapes ------------------------------------------------------------------------------------------------------ #
+    @property
+    def batch_size(self):
+        return self._batch_size
+
+    @property
+    def shape(self):
+        """(time_step, [variable, level,] lat, lon) of the inputs; excludes insolation"""
+        return (self._input_time_steps,) + tuple(self.input_da.shape[1:])
+
+    @property
+    def n_features(self):
+        return (int(np.prod(self.shape)) +
+                int(np.prod(self.shape[-2:])) * self._input_time_steps * self._add_insolation)
+
+    @property
+    def dense_shape(self):
+        if self._keep_time_axis:
+            return (self.shape[0], self.n_features // self.shape[0])
+        return (self.n_features,)
+
+    def _conv_shape(self, keep_time_axis, insolation_channels):
+        s = self.shape
+        if keep_time_axis:
+            return (self._input_time_steps, int(np.prod(s[1:-2])) + insolation_channels) + tuple(s[-2:])
+        return (int(np.prod(s[:-2])) + self._input_time_steps * insolation_channels,) + tuple(self.input_da.shape[-2:])
+
+    @property
+    def convolution_shape(self):
+        """(channels, y, x), or (time_step, channels, y, x) for a recurrent model; includes the insolation channel(s)"""
+        return self._conv_shape(self._keep_time_axis, self._add_insolation)
+
+    @property
+    def shape_2d(self):
+        return self._conv_shape(False, self._add_insolation)
+
+    @property
+    def output_shape(self):
+        return (self._output_time_steps,) + tuple(self.output_da.shape[1:])
+
+    @property
+    def output_n_features(self):
+        return int(np.prod(self.output_shape))
+
+    @property
+    def output_dense_shape(self):
+        if self._keep_time_axis:
+            return (self.output_shape[0], self.output_n_features // self.output_shape[0])
+        return (self.output_n_features,)
+
+    def _out_conv_shape(self, keep_time_axis):
+        s = self.output_shape
+        if keep_time_axis:
+            return (self._output_time_steps, int(np.prod(s[1:-2]))) + tuple(s[-2:])
+        return (int(np.prod(s[:-2])),) + tuple(self.output_da.shape[-2:])
+
+    @property
+    def output_convolution_shape(self):
+        return self._out_conv_shape(self._keep_time_axis)
+
+    @property
+    def output_shape_2d(self):
+        return self._out_conv_shape(False)
+
+    # -- batches ----------------------------------------------------------------------------------------------------- #
+    def on_epoch_end(self):
+        self._indices = np.arange(self._n_sample)
+        if self._shuffle:
+            np.random.shuffle(self._indices)
+
+    def _window(self, da, samples, first, steps):
+        """(n, steps, ...) block: for every sample index the `steps` consecutive series states starting at +first."""
+        v = da.values
+        return np.stack([v[samples + first + n] for n in range(steps)], axis=1)
+
+    def _finish(self, p, t, scale_and_impute):
+        if self._remove_nan:
+            p, t = delete_nan_samples(p, t)
+        return self._finish_no_nan(p, t, scale_and_impute)
+
+    def _finish_no_nan(self, p, t, scale_and_impute):
+        if scale_and_impute:
+            if self._impute_missing:
+                p, t = self.model.imputer_transform(p, t)
+            p, t = self.model.scaler_transform(p, t)
+        n = p.shape[0]            # the surviving count (the reference keeps the pre-deletion one and fails to reshape)
+        if self._is_convolutional:
+            p = p.reshape((n,) + self.convolution_shape)
+            t = t.reshape((n,) + self.output_convolution_shape)
+        elif self._keep_time_axis:
+            p = p.reshape((n,) + self.dense_shape)
+            t = t.reshape((n,) + self.output_dense_shape)
+        return p, t
+
+    def generate(self, samples, scale_and_impute=True):
+        """(predictors, targets) for the given series indices; an empty list means every sample.  With `sequence` the
+        targets are a list of arrays (one per forecast block)."""
+        samples = np.arange(self._n_sample, dtype=int) if len(samples) == 0 else np.array(samples, dtype=int)
+        n_sample = len(samples)
+        p = self._window(self.input_da, samples, 0, self._input_time_steps)
+        if self._add_insolation:
+            # insolation rides as one extra channel per input time step, behind the variables of that step
+            s = self._conv_shape(True, 0)
+            sol = self._window(self.insolation_da, samples, 0, self._input_time_steps)
+            p = np.concatenate([p.reshape((n_sample,) + s), sol[:, :, np.newaxis]], axis=2)
+        p = p.reshape((n_sample, -1))
+        first = self._input_time_steps + self._interval - 1
+        if self._sequence is None:
+            t = self._window(self.output_da, samples, first, self._output_time_steps).reshape((n_sample, -1))
+            return self._finish(p, t, scale_and_impute)
+        blocks = [self._window(self.output_da, samples, first + self._output_time_steps * k,
+                               self._output_time_steps).reshape((n_sample, -1)) for k in range(self._sequence)]
+        if self._remove_nan:
+            # one joint decision per sample (the reference filters inside the loop and loses the row alignment between
+            # the predictors and the later target blocks as soon as a sample is actually dropped)
+            bad = np.isnan(p).any(axis=1)
+            for t in blocks:
+                bad |= np.isnan(t).any(axis=1)
+            if bad.any():
+                keep = np.flatnonzero(~bad)
+                p, blocks = p[keep], [t[keep] for t in blocks]
+        targets = []
+        p_out = None
+        for t in blocks:
+            pk, t = self._finish_no_nan(p, t, scale_and_impute)
+            p_out = pk if p_out is None else p_out
+            targets.append(t)
+        p = p_out
+        return p, targets
+
+    def __len__(self):
+        return int(np.ceil(self._n_sample / self._batch_size))
+
+    def __getitem__(self, index):
+        if int(index) < 0:
+            index = len(self) + index
+        if index >= len(self) or index < 0:        # the reference's `index > len(self)` lets index == len through
             raise IndexError('batch index out of range')
         return self.generate(self._indices[index * self._batch_size:(index + 1) * self._batch_size])
 

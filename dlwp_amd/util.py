@@ -98,3 +98,40 @@ def load_model(file_name, history=False, custom_objects=None, gpus=1):
         with open('%s.history' % file_name, 'rb') as f:
             return model, pickle.load(f)
     return model
+
+
+def day_of_year(date):
+    """Fractional day of the year of a timestamp, 0.0 at 1 Jan 00:00 (reference DLWP/util.py:300-302)."""
+    import pandas as pd
+    date = pd.Timestamp(date)
+    return (date - pd.Timestamp(date.year, 1, 1)).total_seconds() / 86400.
+
+
+def insolation(dates, lat, lon, S=1.):
+    """Approximate top-of-atmosphere insolation (date, lat, lon), float32 -- reference DLWP/util.py:305-352: fixed 1995
+    orbital constants, first-order longitude of the earth on its orbit, declination, hour angle from day fraction +
+    longitude, inverse-square distance factor; negative (night-side) values clipped to 0.  lat / lon: both 1-D (a
+    regular grid) or both 2-D of one shape, degrees.  Unlike the reference, 2-D `lat` is not modified in place."""
+    lat, lon = np.asarray(lat, dtype=np.float64), np.asarray(lon, dtype=np.float64)
+    if lat.ndim != lon.ndim:
+        raise ValueError("'lat' and 'lon' must either both be 1d or both be 2d'")
+    if lat.ndim == 2 and lat.shape != lon.shape:
+        raise ValueError('shape mismatch between lat (%s) and lon (%s)' % (lat.shape, lon.shape))
+    if lat.ndim == 1:
+        lon, lat = np.meshgrid(lon, lat)
+    eps = 23.4441 * np.pi / 180.        # obliquity
+    ecc = 0.016715                      # eccentricity
+    om = 282.7 * np.pi / 180.           # longitude of perihelion
+    beta = np.sqrt(1 - ecc ** 2.)
+    days = np.array([day_of_year(d) for d in np.asarray(dates).ravel()], dtype=np.float64)
+    lambda_m0 = ecc * (1. + beta) * np.sin(om)
+    lambda_m = lambda_m0 + 2. * np.pi * (days - 80.5) / 365.
+    lambda_ = lambda_m + 2. * ecc * np.sin(lambda_m - om)
+    dec = np.arcsin(np.sin(eps) * np.sin(lambda_))
+    h = 2 * np.pi * (days[:, None, None] + lon / 360.)
+    rho = (1. - ecc ** 2.) / (1. + ecc * np.cos(lambda_ - om))
+    latr = lat * (np.pi / 180.)
+    sol = S * (np.sin(latr[None, ...]) * np.sin(dec[:, None, None]) -
+               np.cos(latr[None, ...]) * np.cos(dec[:, None, None]) * np.cos(h)) * rho[:, None, None] ** -2.
+    sol[sol < 0.] = 0.
+    return sol.astype(np.float32)

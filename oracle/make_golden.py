@@ -141,9 +141,67 @@ def _install_stubs():
     keras.engine.base_layer = mod('keras.engine.base_layer', InputSpec=InputSpec)
     keras.models = mod('keras.models', Model=Model, Sequential=Model)
     mod('tensorflow', pad=None)
-    mod('xarray')
+    mod('xarray', DataArray=FakeDataArray)
     mod('dask')
     mod('netCDF4', default_fillvals={'f4': 9.969209968386869e+36})
+
+
+class FakeDataArray(object):
+    """What the reference's SeriesDataGenerator touches of an xarray DataArray: values / shape, label selection on named
+    dimensions (.sel), .isel(time_step=-1), .load(), and the coordinate variables .sample / .lat / .lon (each with
+    .values).  Also the constructor form xr.DataArray(values, coords=..., dims=...) (generators.py:418-422)."""
+
+    def __init__(self, values, coords=None, dims=None):
+        self.values = np.asarray(values)
+        self.dims = tuple(dims)
+        self.coords = {k: (v.values if isinstance(v, FakeDataArray._Coord) else np.asarray(v)) for k, v in coords.items()}
+
+    class _Coord(object):
+        def __init__(self, values):
+            self.values = values
+
+    @property
+    def shape(self):
+        return self.values.shape
+
+    def __getattr__(self, name):
+        coords = self.__dict__.get('coords', {})
+        if name in coords:
+            return FakeDataArray._Coord(coords[name])
+        raise AttributeError(name)
+
+    def load(self):
+        return self
+
+    def sel(self, **sel):
+        out = self
+        for dim, labels in sel.items():
+            ax = out.dims.index(dim)
+            have = list(out.coords[dim])
+            idx = [have.index(l) for l in labels]
+            coords = dict(out.coords)
+            coords[dim] = np.asarray(out.coords[dim])[idx]
+            out = FakeDataArray(np.take(out.values, idx, axis=ax), coords, out.dims)
+        return out
+
+    def isel(self, **isel):
+        out = self
+        for dim, i in isel.items():
+            ax = out.dims.index(dim)
+            coords = {k: v for k, v in out.coords.items() if k != dim}
+            out = FakeDataArray(np.take(out.values, i, axis=ax), coords, tuple(d for d in out.dims if d != dim))
+        return out
+
+
+class FakeSeriesDS(object):
+    """Dataset with the single variable 'predictors' (a continuous time series) the SeriesDataGenerator expects."""
+
+    def __init__(self, da):
+        self.predictors = da
+        self.dims = dict(zip(da.dims, da.shape))
+
+    def load(self):
+        return self
 
 
 class FakeDS(object):
@@ -341,6 +399,62 @@ def main():
         gen['split_%s_train' % method] = np.asarray(tr, dtype=np.int64)
         gen['split_%s_test' % method] = np.asarray(te, dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, 'generator.npz'), **gen)
+
+    # ----- series generator + insolation (generators.py:323-629, util.py:300-352) --------------------------------- #
+    import pandas as pd
+    from DLWP.model.generators import SeriesDataGenerator
+    from DLWP.util import insolation
+    np.int = int                         # generators.py:531 uses the alias numpy >= 1.24 removed
+    ser = {}
+    n_t = 14
+    dates = pd.date_range('2003-02-27 00:00', periods=n_t, freq='6H')       # crosses a month boundary
+    lat = np.linspace(87.5, -87.5, 6)
+    lon = np.arange(0., 360., 45.)
+    S = rng.standard_normal((n_t, 2, 2, 6, 8)).astype(np.float32)            # (sample, variable, level, lat, lon)
+    ser['S'], ser['lat'], ser['lon'] = S, lat, lon
+    ser['dates'] = dates.values.astype('datetime64[s]').astype(np.int64)       # seconds since the epoch
+    ser['insolation'] = insolation(dates.values, lat.copy(), lon.copy())
+    ser['insolation_S2'] = insolation(dates.values[:3], lat.copy(), lon.copy(), S=2.)
+
+    def series_ds():
+        da = FakeDataArray(S, {'sample': dates.values, 'variable': np.array(['z', 't']), 'level': np.array([500, 850]),
+                               'lat': lat.copy(), 'lon': lon.copy()}, ('sample', 'variable', 'level', 'lat', 'lon'))
+        return FakeSeriesDS(da)
+    cases = {
+        'a': dict(rec=False, kw=dict(input_time_steps=2, output_time_steps=2, batch_size=4)),
+        'b': dict(rec=True, kw=dict(input_time_steps=2, output_time_steps=2, batch_size=4)),
+        'c': dict(rec=False, kw=dict(input_sel={'variable': ['z']}, output_sel={'variable': ['t'], 'level': [850]},
+                                     input_time_steps=3, output_time_steps=1, interval=2, batch_size=5)),
+        'd': dict(rec=False, kw=dict(input_time_steps=2, output_time_steps=2, add_insolation=True, batch_size=4)),
+        'e': dict(rec=True, kw=dict(input_time_steps=2, output_time_steps=2, add_insolation=True, batch_size=4)),
+        'f': dict(rec=False, kw=dict(input_time_steps=2, output_time_steps=2, sequence=3, batch_size=3)),
+        'g': dict(rec=False, kw=dict(input_time_steps=1, output_time_steps=1, batch_size=6, shuffle=True)),
+    }
+    for tag, case in cases.items():
+        m = DLWPNeuralNet(is_convolutional=True, is_recurrent=case['rec'], time_dim=case['kw']['input_time_steps'],
+                          scaler_type=None, scale_targets=False)
+        np.random.seed(7)
+        g = SeriesDataGenerator(m, series_ds(), **case['kw'])
+        ser['%s_len' % tag] = np.int64(len(g))
+        for prop in ('shape', 'dense_shape', 'convolution_shape', 'shape_2d', 'output_shape', 'output_dense_shape',
+                     'output_convolution_shape', 'output_shape_2d'):
+            ser['%s_%s' % (tag, prop)] = np.asarray(getattr(g, prop), dtype=np.int64)
+        ser['%s_n_features' % tag] = np.int64(g.n_features)
+        ser['%s_output_n_features' % tag] = np.int64(g.output_n_features)
+        ser['%s_indices' % tag] = np.asarray(g._indices, dtype=np.int64)
+        for b in (0, len(g) - 1):
+            X, y = g[b]
+            ser['%s_X%d' % (tag, b)] = X
+            if isinstance(y, list):
+                for k, yy in enumerate(y):
+                    ser['%s_y%d_%d' % (tag, b, k)] = yy
+            else:
+                ser['%s_y%d' % (tag, b)] = y
+        Xa, ya = g.generate([], scale_and_impute=False)
+        ser['%s_Xall' % tag] = Xa
+        if not isinstance(ya, list):
+            ser['%s_yall' % tag] = ya
+    np.savez_compressed(os.path.join(OUT, 'series.npz'), **ser)
 
     # ----- custom losses (numpy-K evaluation of the reference formulas) ----------------------------------------- #
     los = {}
