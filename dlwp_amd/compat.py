@@ -30,7 +30,7 @@ def _module(name, **attrs):
 def install(force=False):
     from . import custom, engine, layers, regularizers, training, util
     from . import model as model_pkg
-    from .model import generators, models
+    from .model import extensions, generators, models
     have_keras = 'keras' in sys.modules or importlib.util.find_spec('keras') is not None
     have_dlwp = 'DLWP' in sys.modules or importlib.util.find_spec('DLWP') is not None
     if (have_keras or have_dlwp) and not force:
@@ -53,7 +53,8 @@ def install(force=False):
     dlwp.util = _module('DLWP.util', **{k: v for k, v in vars(util).items() if not k.startswith('_')})
     dlwp.model = _module('DLWP.model', DLWPNeuralNet=models.DLWPNeuralNet, DLWPFunctional=models.DLWPFunctional,
                          DataGenerator=generators.DataGenerator, ArrayDataset=generators.ArrayDataset,
-                         SeriesDataGenerator=generators.SeriesDataGenerator)
+                         SeriesDataGenerator=generators.SeriesDataGenerator,
+                         TimeSeriesEstimator=extensions.TimeSeriesEstimator)
     dlwp.model.models = _module('DLWP.model.models', DLWPNeuralNet=models.DLWPNeuralNet,
                                 DLWPFunctional=models.DLWPFunctional)
     dlwp.model.generators = _module('DLWP.model.generators', DataGenerator=generators.DataGenerator,

@@ -1,3 +1,4 @@
 from .models import DLWPNeuralNet, DLWPFunctional  # noqa: F401
 from .generators import (DataGenerator, ArrayDataset, SeriesDataGenerator, SeriesDataset,  # noqa: F401
                          LabeledArray)
+from .extensions import TimeSeriesEstimator  # noqa: F401

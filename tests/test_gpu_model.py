@@ -588,3 +588,38 @@ def test_convlstm_train_step_matches_autograd_oracle_with_l2():
     for _ in range(20):
         vals = d.model.train_on_batch(x, y)
     assert vals[0] < first
+
+
+def test_time_series_estimator_runs_the_device_rollout_for_matching_io():
+    """examples/validate.py:191-205: SeriesDataGenerator + TimeSeriesEstimator.  With identical inputs and outputs the
+    estimator is the plain rollout (device hipGraph) plus coordinates; with an insolation input it steps on the host,
+    one fused device forward per step."""
+    from dlwp_amd.model import SeriesDataGenerator, SeriesDataset, TimeSeriesEstimator
+    rng = np.random.default_rng(41)
+    n_t, h, w = 14, 16, 24
+    dates = (np.datetime64('2010-01-01T00') + np.arange(n_t) * np.timedelta64(6, 'h')).astype('datetime64[s]')
+    series = rng.standard_normal((n_t, 2, 1, h, w)).astype(np.float32)
+    ds = SeriesDataset(series, {'sample': dates, 'variable': np.array(['z', 't']), 'level': np.array([500]),
+                                'lat': np.linspace(80., -80., h), 'lon': np.arange(0., 360., 15.)},
+                       ('sample', 'variable', 'level', 'lat', 'lon'))
+    d = _build(unet_layers((4, h, w), widths=(8, 16, 16, 16, 8)), time_dim=2)
+    _weights_of(d.model, rng)
+    g = SeriesDataGenerator(d, ds, input_time_steps=2, output_time_steps=2, batch_size=4)
+    est = TimeSeriesEstimator(d, g)
+    out = est.predict(6)
+    n = g._n_sample
+    assert out.shape == (6, n, 2, 1, h, w)
+    X, _ = g.generate([], scale_and_impute=False)
+    ser = d.predict_timeseries(X, 6)                                  # (6, n, 2, h, w)
+    valid0 = n - 4
+    assert np.array_equal(out.values[:, :valid0, :, 0], ser[:, :valid0])
+    assert np.isnan(out.values[2:4, n - 2:]).all() and np.isfinite(out.values[:2]).all()
+    # insolation as an extra input channel per time step: in != out -> host stepping around the device forward
+    d2 = _build(unet_layers((6, h, w), widths=(8, 16, 16, 16, 8), cout=4), time_dim=2)
+    _weights_of(d2.model, rng)
+    g2 = SeriesDataGenerator(d2, ds, input_time_steps=2, output_time_steps=2, add_insolation=True, batch_size=4)
+    out2 = TimeSeriesEstimator(d2, g2).predict(4)
+    X2, _ = g2.generate([], scale_and_impute=False)
+    first = d2.predict(X2).reshape(n, 2, 2, h, w)
+    assert np.array_equal(out2.values[0, :, :, 0], first[:, 0]) and np.array_equal(out2.values[1, :, :, 0], first[:, 1])
+    assert np.isfinite(out2.values[2:, :n - 2]).all()
