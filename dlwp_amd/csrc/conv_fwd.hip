@@ -240,8 +240,22 @@ int launch_direct(dlwp_handle_t h, ConvArgs& a, const dlwp_conv2d* cd, hipStream
 
 }  // namespace
 
+bool dlwp_conv2d_is_winograd(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
+  dlwp_shape4 ys;
+  if (!h || !cd || xs.n <= 0 || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return false;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys);
+  const int ci = choose_config(a, cd, h->cu_count);
+  return ci >= 0 && registry().entries[ci].pack < 0;
+}
+
+int dlwp_wino_transform(const void* w, float* u, int cin, int cout, hipStream_t s) {
+  wino_filter_transform_f32<<<dlwp_ceil_div((long long)cin * cout, 256), 256, 0, s>>>((const float*)w, u, cin, cout);
+  DLWP_LAUNCH_CHECK("wino_filter_transform_f32");
+  return DLWP_OK;
+}
+
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
-                       const dlwp_conv2d* cd, int dtype, hipStream_t s) {
+                       const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre) {
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
@@ -267,12 +281,16 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   a.cout_tiles = e.pack > 0 ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
   const long long grid = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
   DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
-  if (e.pack < 0) {  // Winograd: transform the filters into the handle's scratch, then multiply
-    float* u = dlwp_wino_scratch(h, (size_t)a.Cin * a.Cout * 16, s);
-    if (!u) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: no scratch for the transformed filters");
-    wino_filter_transform_f32<<<dlwp_ceil_div((long long)a.Cin * a.Cout, 256), 256, 0, s>>>(a.w, u, a.Cin, a.Cout);
-    DLWP_LAUNCH_CHECK("wino_filter_transform_f32");
-    a.w = u;
+  if (e.pack < 0) {  // Winograd: transform the filters (into the handle's scratch unless the caller did), then multiply
+    if (u_pre) {
+      a.w = u_pre;
+    } else {
+      float* u = dlwp_wino_scratch(h, (size_t)a.Cin * a.Cout * 16, s);
+      if (!u) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: no scratch for the transformed filters");
+      const int rc2 = dlwp_wino_transform(a.w, u, a.Cin, a.Cout, s);
+      if (rc2 != DLWP_OK) return rc2;
+      a.w = u;
+    }
   }
   e.launch(a, (int)grid, s);
   DLWP_LAUNCH_CHECK("conv2d_fwd_mfma_f32");

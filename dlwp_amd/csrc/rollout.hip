@@ -13,18 +13,19 @@ struct dlwp_rollout {
   hipGraph_t graph;
   hipGraphExec_t exec;
   int calls, n_ops;
+  float* wino_u;  // transformed filters of the Winograd layers: written once at the head of every graph launch
 };
 
 namespace {
 
 int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, const void* w, const void* b, int dtype,
-               hipStream_t s, void* const* aux = nullptr) {
+               hipStream_t s, void* const* aux = nullptr, const float* u_pre = nullptr) {
   switch (op.kind) {
     case DLWP_OP_LSTM_GATES:
       return dlwp_convlstm_gates(h, src, aux[0], aux[1], aux[2], dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w,
                                  op.conv.out_c_off, op.conv.out_c_total, op.conv.act, op.aux[3], dtype, (void*)s);
     case DLWP_OP_CONV2D:
-      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, dtype, s);
+      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, dtype, s, u_pre);
     case DLWP_OP_PAD2D:
       // NCHW: outer = n*c rows-of-W planes; NHWC: xs = (n, 1, h, w) and conv.in_c_total carries the inner (channel) run
       return dlwp_pad2d_fwd(h, src, dst, op.xs.n * op.xs.c, op.xs.h, op.xs.w,
@@ -79,9 +80,23 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
     return (char*)series + ((size_t)call * n_outputs + o) * slot_elems * esz;
   };
 
-  // the Winograd convolutions keep their transformed filters in a scratch buffer of the handle: allocate it now,
-  // allocation is not possible while the stream is capturing
+  // Winograd layers: the weights do not change inside one graph launch, so their filter transforms run ONCE at the head
+  // of the graph (into buffers the rollout owns) instead of once per forward; the handle's scratch stays the fallback
   (void)dlwp_wino_scratch(h, 1, nullptr);
+  std::vector<long long> u_off(n_ops, -1);
+  long long u_floats = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const dlwp_op& op = plan[i];
+    if (op.kind == DLWP_OP_CONV2D && dlwp_conv2d_is_winograd(h, op.xs, &op.conv)) {
+      u_off[i] = u_floats;
+      u_floats += (long long)op.xs.c * op.conv.cout * 16;
+    }
+  }
+  float* wino_u = nullptr;
+  if (u_floats > 0 && hipMalloc(&wino_u, (size_t)u_floats * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    wino_u = nullptr;  // fall back to the per-forward transform
+  }
 
   hipStream_t cap;
   DLWP_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
@@ -92,6 +107,9 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
     DLWP_FAIL(DLWP_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
   }
   int rc = DLWP_OK;
+  if (wino_u)
+    for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
+      if (u_off[i] >= 0) rc = dlwp_wino_transform(buffers[plan[i].w], wino_u + u_off[i], plan[i].xs.c, plan[i].conv.cout, cap);
   for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
       const dlwp_op& op = plan[i];
@@ -100,20 +118,26 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
       void* aux[3] = {nullptr, nullptr, nullptr};
       if (op.kind == DLWP_OP_LSTM_GATES)
         for (int k = 0; k < 3; ++k) aux[k] = op.aux[k] == DLWP_BUF_NONE ? nullptr : buffers[op.aux[k]];
-      rc = enqueue_op(h, op, resolve(op.src, t, true), resolve(op.dst, t, false), w, b, dtype, cap, aux);
+      rc = enqueue_op(h, op, resolve(op.src, t, true), resolve(op.dst, t, false), w, b, dtype, cap, aux,
+                      (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr);
     }
   }
   e = hipStreamEndCapture(cap, &graph);
   (void)hipStreamDestroy(cap);
   if (rc != DLWP_OK) {
     if (graph) (void)hipGraphDestroy(graph);
+    if (wino_u) (void)hipFree(wino_u);
     return rc;  // error string already set by the failing op
   }
-  if (e != hipSuccess) DLWP_FAIL(DLWP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) {
+    if (wino_u) (void)hipFree(wino_u);
+    DLWP_FAIL(DLWP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  }
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {
     (void)hipGraphDestroy(graph);
+    if (wino_u) (void)hipFree(wino_u);
     DLWP_FAIL(DLWP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
   }
   dlwp_rollout* r = new dlwp_rollout();
@@ -122,6 +146,7 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
   r->exec = exec;
   r->calls = calls;
   r->n_ops = n_ops;
+  r->wino_u = wino_u;
   *out = r;
   return DLWP_OK;
 }
@@ -136,6 +161,7 @@ int dlwp_rollout_destroy(dlwp_rollout_t r) {
   if (!r) return DLWP_OK;
   if (r->exec) (void)hipGraphExecDestroy(r->exec);
   if (r->graph) (void)hipGraphDestroy(r->graph);
+  if (r->wino_u) (void)hipFree(r->wino_u);
   delete r;
   return DLWP_OK;
 }
