@@ -22,6 +22,11 @@ ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
 OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES = 0, 1, 2, 3, 4, 5
 BUF_NONE = -1000
+
+
+def dtype_io(dt_in, dt_out):
+    """DLWP_DTYPE_IO(in, out) of include/dlwp_hip.h: storage of a launch's input / output activations"""
+    return 0x10000 | dt_in | (dt_out << 8)
 BUF_STATE_IN = -1
 
 

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void wino_filter_transform_f32(const float* __
 int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void* y, dlwp_shape4 xs,
              const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
   DLWP_CHECK_ARG(h && cd && (xs.n == 0 || (x && w && y)), "%s: null handle or pointer", fn);
-  DLWP_CHECK_ARG(dtype == DLWP_F32, "%s: dtype %d not supported", fn, dtype);
+  DLWP_CHECK_ARG((unsigned)DLWP_DTYPE_IN(dtype) <= 1u && (unsigned)DLWP_DTYPE_OUT(dtype) <= 1u && (dtype & ~0x1ffff) == 0,
+                 "%s: dtype 0x%x not supported", fn, dtype);
   DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, "%s: bad input shape (%d,%d,%d,%d)", fn, xs.n, xs.c,
                  xs.h, xs.w);
   if (dlwp_conv2d_out_shape(xs, cd, ys) != DLWP_OK) return DLWP_EINVAL;
@@ -93,8 +94,10 @@ int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void
 }
 
 ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs, const dlwp_conv2d* cd,
-                   dlwp_shape4 ys) {
+                   dlwp_shape4 ys, int dtype = DLWP_F32) {
   ConvArgs a;
+  a.in_bf16 = DLWP_DTYPE_IN(dtype) == DLWP_BF16;
+  a.out_bf16 = DLWP_DTYPE_OUT(dtype) == DLWP_BF16;
   a.x = (const float*)x;
   a.w = (const float*)w;
   a.bias = (const float*)bias;
@@ -213,17 +216,22 @@ __global__ __launch_bounds__(256) void conv2d_fwd_direct_f32(const ConvArgs a, i
         for (int ci = 0; ci < a.Cin; ++ci) {
           const float* xp = xn + (long long)ci * plane;
           float xv;
-          if (a.src_mode == DLWP_SRC_UPSAMPLE2) xv = xp[(rs >> 1) * a.Ws + (cs >> 1)];
+          auto at = [&](long long o) {
+            return a.in_bf16 ? bf16_bits_to_f32(((const bf16_t*)a.x)[(xp - a.x) + o]) : xp[o];
+          };
+          if (a.src_mode == DLWP_SRC_UPSAMPLE2) xv = at((long long)(rs >> 1) * a.Ws + (cs >> 1));
           else if (a.src_mode == DLWP_SRC_MAXPOOL2) {
-            const float* s = xp + (rs * 2) * a.Ws + cs * 2;
-            xv = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[a.Ws], s[a.Ws + 1]));
-          } else xv = xp[rs * a.Ws + cs];
+            const long long o = (long long)(rs * 2) * a.Ws + cs * 2;
+            xv = fmaxf(fmaxf(at(o), at(o + 1)), fmaxf(at(o + a.Ws), at(o + a.Ws + 1)));
+          } else xv = at((long long)rs * a.Ws + cs);
           acc = fmaf(xv, wp[(long long)ci * a.Cout], acc);
         }
       }
     }
     if (a.bias) acc += a.bias[co];
-    a.y[(((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho + oh) * a.Wo + ow] = act_apply(acc, a.act);
+    const long long yo = (((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho + oh) * a.Wo + ow;
+    if (a.out_bf16) ((bf16_t*)a.y)[yo] = f32_to_bf16(act_apply(acc, a.act));
+    else a.y[yo] = act_apply(acc, a.act);
   }
 }
 
@@ -260,7 +268,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   int rc = validate("dlwp_conv2d_fwd", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
   if (xs.n == 0) return DLWP_OK;
-  ConvArgs a = make_args(x, w, bias, y, xs, cd, ys);
+  ConvArgs a = make_args(x, w, bias, y, xs, cd, ys, dtype);
   const int ci = choose_config(a, cd, h->cu_count);
   if (ci < 0) {
     if (g_forced_cfg >= 0) DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", g_forced_cfg);
@@ -361,7 +369,7 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const 
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd_direct", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
-  ConvArgs a = make_args(x, w, bias, y, xs, cd, ys);
+  ConvArgs a = make_args(x, w, bias, y, xs, cd, ys, dtype);
   return launch_direct(h, a, cd, (hipStream_t)stream);
 }
 

@@ -33,6 +33,7 @@ struct ConvArgs {
   int pad_top, pad_left, mode_h, mode_w;
   int src_mode, act;
   int tiles_h, tiles_w, cout_tiles;
+  int in_bf16, out_bf16;  // storage of x / y: 0 = float32, 1 = bfloat16 (arithmetic is fp32 either way; w, bias fp32)
 };
 
 template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool POOL_ = false>
@@ -86,6 +87,18 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+// ---- bfloat16 storage helpers: a bf16 is the upper half of the fp32 with the same value; fp32 -> bf16 rounds to nearest
+//      even in hardware (v_cvt_pk_bf16_f32)
+typedef unsigned short bf16_t;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned bits16) { return __builtin_bit_cast(float, bits16 << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return __builtin_bit_cast(bf16_t, (__bf16)v); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, bf2));
+}
+
 template <class C>
 __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -137,6 +150,7 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
   }
   const long long plane = (long long)a.Hs * a.Ws;
   const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
+  const bf16_t* xn16 = (const bf16_t*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;  // if a.in_bf16
 
   // ---- weight-slot bookkeeping: each thread owns NWV 16-byte slots of the [tap][ci][BN] weight chunk
   constexpr int V4 = C::BN / 4;
@@ -189,11 +203,20 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
 
   auto prefetch = [&](int c0) {
     if constexpr (!C::POOL) {
+      if (a.in_bf16) {  // raw 16 bits now, widened when the chunk is written to LDS
 #pragma unroll
-      for (int ci = 0; ci < C::CK; ++ci) {
-        const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
+        for (int ci = 0; ci < C::CK; ++ci) {
+          const bf16_t* xp = xn16 + (long long)min(c0 + ci, a.Cin - 1) * plane;
 #pragma unroll
-        for (int q = 0; q < C::NPOS; ++q) xr[ci][q][0] = xp[goff[q]];
+          for (int q = 0; q < C::NPOS; ++q) xr[ci][q][0] = __builtin_bit_cast(float, (unsigned)xp[goff[q]]);
+        }
+      } else {
+#pragma unroll
+        for (int ci = 0; ci < C::CK; ++ci) {
+          const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
+#pragma unroll
+          for (int q = 0; q < C::NPOS; ++q) xr[ci][q][0] = xp[goff[q]];
+        }
       }
     }
     if (w_vec) {
@@ -212,15 +235,32 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       f32x2 pv[C::CK][C::NPOS][2];
       const bool ws_even = (a.Ws & 1) == 0;
+      if (a.in_bf16) {  // a row pair of the window = one 32-bit load when the stored width is even
 #pragma unroll
-      for (int ci = 0; ci < C::CK; ++ci) {
-        const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
+        for (int ci = 0; ci < C::CK; ++ci) {
+          const bf16_t* xp = xn16 + (long long)min(c0 + ci, a.Cin - 1) * plane;
 #pragma unroll
-        for (int q = 0; q < C::NPOS; ++q) {
-          const float* sp = xp + goff[q];
-          pv[ci][q][0] = *(const f32x2*)sp;
-          if (ws_even) pv[ci][q][1] = *(const f32x2*)(sp + a.Ws);
-          else pv[ci][q][1] = (f32x2){sp[a.Ws], sp[a.Ws + 1]};
+          for (int q = 0; q < C::NPOS; ++q) {
+            const bf16_t* sp = xp + goff[q];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const bf16_t* rp = sp + r * a.Ws;
+              const unsigned two = ws_even ? *(const unsigned*)rp : ((unsigned)rp[0] | ((unsigned)rp[1] << 16));
+              pv[ci][q][r] = (f32x2){bf16_bits_to_f32(two & 0xffffu), __builtin_bit_cast(float, two & 0xffff0000u)};
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ci = 0; ci < C::CK; ++ci) {
+          const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
+#pragma unroll
+          for (int q = 0; q < C::NPOS; ++q) {
+            const float* sp = xp + goff[q];
+            pv[ci][q][0] = *(const f32x2*)sp;
+            if (ws_even) pv[ci][q][1] = *(const f32x2*)(sp + a.Ws);
+            else pv[ci][q][1] = (f32x2){sp[a.Ws], sp[a.Ws + 1]};
+          }
         }
       }
 #pragma unroll
@@ -239,7 +279,8 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
         const bool c_ok = c0 + ci < a.Cin;
 #pragma unroll
         for (int q = 0; q < C::NPOS; ++q) {
-          const float v = (c_ok && gok[q]) ? xr[ci][q][0] : 0.f;
+          const float raw = a.in_bf16 ? bf16_bits_to_f32(__builtin_bit_cast(unsigned, xr[ci][q][0])) : xr[ci][q][0];
+          const float v = (c_ok && gok[q]) ? raw : 0.f;
           xs[((q == C::NPOS - 1 && loff[q] == C::TRASH) ? 0 : ci * C::PS) + loff[q]] = v;
         }
       }
@@ -307,12 +348,14 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
   // ---- epilogue: bias + activation, 4 consecutive pixels of one channel per lane
   const bool vec_store = (C::TW % 4 == 0) && ((a.Wo & 3) == 0);
   float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;
+  bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;  // if a.out_bf16
 #pragma unroll
   for (int g = 0; g < C::BNF; ++g) {
     const int co = n0 + g * 16 + (lane & 15);
     if (co >= a.Cout) continue;
     const float bv = a.bias ? a.bias[co] : 0.f;
     float* yc = yn + (long long)co * a.Ho * a.Wo;
+    bf16_t* yc16 = yn16 + (long long)co * a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < C::FA; ++i) {
       const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
@@ -323,14 +366,20 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
       if (vec_store) {
         const int row = p / C::TW, col = p - row * C::TW;
         const int oh = i0 + row, ow = j0 + col;
-        if (oh < a.Ho && ow < a.Wo) *(f32x4*)(yc + (long long)oh * a.Wo + ow) = o;
+        if (oh < a.Ho && ow < a.Wo) {
+          if (a.out_bf16) *(u32x2*)(yc16 + (long long)oh * a.Wo + ow) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+          else *(f32x4*)(yc + (long long)oh * a.Wo + ow) = o;
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pp = p + r;
           const int row = pp / C::TW, col = pp - row * C::TW;
           const int oh = i0 + row, ow = j0 + col;
-          if (pp < C::P && oh < a.Ho && ow < a.Wo) yc[(long long)oh * a.Wo + ow] = o[r];
+          if (pp < C::P && oh < a.Ho && ow < a.Wo) {
+            if (a.out_bf16) yc16[(long long)oh * a.Wo + ow] = f32_to_bf16(o[r]);
+            else yc[(long long)oh * a.Wo + ow] = o[r];
+          }
         }
       }
     }

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
   }
   const long long plane = (long long)a.Hs * a.Ws;
   const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
+  const bf16_t* xn16 = (const bf16_t*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;  // if a.in_bf16
 
   // ---- weight-slot bookkeeping: scalar slots of the expanded [tap'=(u,t)][ci][j=(co,s)] chunk
   int wsrc[C::NWS], wci[C::NWS];
@@ -122,11 +123,20 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
   float xr[C::CK][C::NPOS];
   float wr[C::NWS];
   auto prefetch = [&](int c0) {
+    if (a.in_bf16) {  // raw 16 bits now, widened when the chunk is written to LDS
 #pragma unroll
-    for (int ci = 0; ci < C::CK; ++ci) {
-      const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
+      for (int ci = 0; ci < C::CK; ++ci) {
+        const bf16_t* xp = xn16 + (long long)min(c0 + ci, a.Cin - 1) * plane;
 #pragma unroll
-      for (int q = 0; q < C::NPOS; ++q) xr[ci][q] = xp[goff[q]];
+        for (int q = 0; q < C::NPOS; ++q) xr[ci][q] = __builtin_bit_cast(float, (unsigned)xp[goff[q]]);
+      }
+    } else {
+#pragma unroll
+      for (int ci = 0; ci < C::CK; ++ci) {
+        const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
+#pragma unroll
+        for (int q = 0; q < C::NPOS; ++q) xr[ci][q] = xp[goff[q]];
+      }
     }
 #pragma unroll
     for (int k = 0; k < C::NWS; ++k) wr[k] = a.w[wsrc[k] + (long long)min(c0 + wci[k], a.Cin - 1) * a.Cout];
@@ -137,7 +147,8 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
       const bool c_ok = c0 + ci < a.Cin;
 #pragma unroll
       for (int q = 0; q < C::NPOS; ++q) {
-        const float v = (c_ok && gok[q]) ? xr[ci][q] : 0.f;
+        const float raw = a.in_bf16 ? bf16_bits_to_f32(__builtin_bit_cast(unsigned, xr[ci][q])) : xr[ci][q];
+        const float v = (c_ok && gok[q]) ? raw : 0.f;
         xs[((q == C::NPOS - 1 && loff[q] == C::X_FLOATS + C::W_FLOATS) ? 0 : ci * C::PS) + loff[q]] = v;
       }
     }
@@ -186,6 +197,7 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
   if (co < a.Cout) {
     const float bv = a.bias ? a.bias[co] : 0.f;
     float* yc = a.y + (((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho) * a.Wo;
+    bf16_t* yc16 = (bf16_t*)a.y + (((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho) * a.Wo;  // if a.out_bf16
 #pragma unroll
     for (int i = 0; i < C::FA; ++i) {
 #pragma unroll
@@ -193,7 +205,11 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
         const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4 + r;
         const int row = p / C::TWS, c = p - row * C::TWS;
         const int oh = i0 + row, ow = j0 + c * C::S + s;
-        if (p < C::P && oh < a.Ho && ow < a.Wo) yc[(long long)oh * a.Wo + ow] = act_apply(acc[i][r] + bv, a.act);
+        if (p < C::P && oh < a.Ho && ow < a.Wo) {
+          const float o = act_apply(acc[i][r] + bv, a.act);
+          if (a.out_bf16) yc16[(long long)oh * a.Wo + ow] = f32_to_bf16(o);
+          else yc[(long long)oh * a.Wo + ow] = o;
+        }
       }
     }
   }

@@ -36,8 +36,9 @@
 #include <type_traits>
 #include "conv_fwd_kernel.h"
 
-template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_>
+template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false>
 struct WinoCfg {
+  static constexpr bool IN16 = IN16_;  // input stored as bfloat16 (the loop stays branch-free: one instance per input type)
   static constexpr int DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, BNF = BNF_, CK = CK_;
   static constexpr int NT = WAVES * 64;
   static constexpr int LR = TH + 2 * DIL, LC = TW + 2 * DIL;
@@ -105,12 +106,13 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
     const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
     const bool ok = rs >= 0 && cs >= 0;
     const int g = (a.src_mode == DLWP_SRC_UPSAMPLE2) ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
-    goff[q] = ok ? (unsigned)g * 4u : 0x7ffffff0u;
+    goff[q] = ok ? (unsigned)g * (C::IN16 ? 2u : 4u) : 0x7ffffff0u;
     loff[q] = (((lr % C::DIL) * C::DIL + lc % C::DIL) * C::LRP + lr / C::DIL) * C::LCP + lc / C::DIL;
   }
   const long long plane = (long long)a.Hs * a.Ws;
-  const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
-  const unsigned plane_bytes = (unsigned)plane * 4u;
+  constexpr int ESZ = C::IN16 ? 2 : 4;
+  const char* xn = (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * ESZ;
+  const unsigned plane_bytes = (unsigned)plane * ESZ;
 
   // ---- this lane's tile (= its MFMA A-operand row) and the LDS offset of the tile's 4x4 patch origin, channel l>>4
   int v_src;
@@ -148,9 +150,12 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
   // element i of the chunk starting at channel c0 (uniform; clamped to the last chunk): one buffer descriptor per plane
   auto load_x = [&](int c0, int i) {
     const int ci = i / C::NPOS, q = i - ci * C::NPOS;
-    const float* xp = xn + (long long)(min(c0, last_c0) + ci) * plane;
+    const char* xp = xn + (long long)(min(c0, last_c0) + ci) * plane * ESZ;
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, plane_bytes, 0x00020000);
-    xr[ci][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, goff[q], 0, 0));
+    if constexpr (C::IN16)  // 16 raw bits (0 out of range), widened when they are written to LDS
+      xr[ci][q] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, goff[q], 0, 0));
+    else
+      xr[ci][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, goff[q], 0, 0));
   };
   auto load_u = [&](int c0, int k, int r) {
     const int soff = (min(c0, last_c0) * 4 + r) * a.Cout * 16;
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
   };
   auto stage_x = [&](int xdst, int i) {
     const int ci = i / C::NPOS, q = i - ci * C::NPOS;
-    lds[xdst + ci * C::PS + loff[q]] = xr[ci][q];
+    lds[xdst + ci * C::PS + loff[q]] = C::IN16 ? bf16_bits_to_f32(__builtin_bit_cast(unsigned, xr[ci][q])) : xr[ci][q];
   };
   auto stage_u = [&](int udst, int k, int r) {
     *(f32x4*)(lds + udst + u_dst[k] + r * C::CK * C::BN * 4) = ur[k][r & 1];
@@ -328,6 +333,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
   }
   __syncthreads();
   float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
+  bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;  // if a.out_bf16
   constexpr int NOUT = C::BN * C::TH * C::TW / 4 / C::NT;
 #pragma unroll
   for (int k = 0; k < NOUT; ++k) {
@@ -337,7 +343,20 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
     const int oh = i0 + row, ow = j0 + colx;
     if (oh >= a.Ho || ow >= a.Wo) continue;
     const f32x4 o = *(const f32x4*)(lds + co * C::OPS + rem);
-    float* yp = yn + ((long long)co * a.Ho + oh) * a.Wo + ow;
+    const long long yoff = ((long long)co * a.Ho + oh) * a.Wo + ow;
+    if (a.out_bf16) {
+      bf16_t* yp = yn16 + yoff;
+      if (ow + 3 < a.Wo && ((a.Wo & 1) == 0)) {   // 4-byte aligned pairs when the row length is even
+        *(unsigned*)yp = pack_bf16x2(o[0], o[1]);
+        *(unsigned*)(yp + 2) = pack_bf16x2(o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ow + r < a.Wo) yp[r] = f32_to_bf16(o[r]);
+      }
+      continue;
+    }
+    float* yp = yn + yoff;
     if (ow + 3 < a.Wo) {
       *(f32x4*)yp = o;
     } else {
@@ -361,10 +380,23 @@ static int wino_prepare() {
   return 0;
 }
 
+// launches the float32- or the bfloat16-input instance of one geometry
+template <class C32, class C16>
+static void wino_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
+  if (a.in_bf16) wino_launch_thunk<C16>(a, grid, s);
+  else wino_launch_thunk<C32>(a, grid, s);
+}
+
+template <class C32, class C16>
+static int wino_prepare_both() {
+  const int e = wino_prepare<C32>();
+  return e != 0 ? e : wino_prepare<C16>();
+}
+
 // registry entry: ks = 3, fa = 0, pack = -1 marks a Winograd instance (a.w = the transformed filter)
-#define WINO_ENTRY(DIL, TH, TW, WAVES, BNF, CK)                                                        \
-  {                                                                                                     \
-    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1,      \
-        &wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>>,                                       \
-        &wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>>                                             \
+#define WINO_ENTRY(DIL, TH, TW, WAVES, BNF, CK)                                                                         \
+  {                                                                                                                      \
+    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1,                       \
+        &wino_launch_either<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>, WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>,           \
+        &wino_prepare_both<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>, WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>             \
   }

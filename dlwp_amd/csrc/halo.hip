@@ -167,6 +167,34 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
   }
 }
 
+// bfloat16 storage (config 4): the maximum of bf16 values is one of them, so the result is exact; a 2x2 window is two
+// 32-bit loads when the row length is even
+__global__ __launch_bounds__(256) void maxpool2_fwd_bf16_kernel(const unsigned short* __restrict__ x,
+                                                                unsigned short* __restrict__ y, long long planes, int H,
+                                                                int W) {
+  const int H2 = H / 2, W2 = W / 2;
+  const long long total = planes * H2 * W2;
+  const bool even = (W & 1) == 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % W2);
+    const long long q = i / W2;
+    const int r = (int)(q % H2);
+    const long long p = q / H2;
+    const unsigned short* s = x + (p * H + 2 * r) * W + 2 * j;
+    unsigned a, b;
+    if (even) {
+      a = *(const unsigned*)s;
+      b = *(const unsigned*)(s + W);
+    } else {
+      a = (unsigned)s[0] | ((unsigned)s[1] << 16);
+      b = (unsigned)s[W] | ((unsigned)s[W + 1] << 16);
+    }
+    const float m = fmaxf(fmaxf(__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u)),
+                          fmaxf(__builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xffff0000u)));
+    y[i] = (unsigned short)(__builtin_bit_cast(unsigned, m) >> 16);
+  }
+}
+
 // one thread per 2x2 window (incl. the partial windows of an odd edge, which receive zero gradient)
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ dx, long long planes, int H, int W) {
@@ -330,10 +358,18 @@ int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, 
 
 int dlwp_maxpool2_fwd(dlwp_handle_t h, const void* x, void* y, dlwp_shape4 xs, int dtype, void* stream) {
   const bool x_ok = x && y;
+  const bool bf16 = dtype == DLWP_BF16;
+  if (bf16) dtype = DLWP_F32;  // the shared argument check knows fp32 only; this entry point also stores bf16
   POOL_ARGS_OK("dlwp_maxpool2_fwd");
   const long long planes = (long long)xs.n * xs.c;
   const long long total = planes * (xs.h / 2) * (xs.w / 2);
   if (total == 0) return DLWP_OK;
+  if (bf16) {
+    maxpool2_fwd_bf16_kernel<<<grid_for(total, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>(
+        (const unsigned short*)x, (unsigned short*)y, planes, xs.h, xs.w);
+    DLWP_LAUNCH_CHECK("maxpool2_fwd_bf16_kernel");
+    return DLWP_OK;
+  }
   maxpool2_fwd_kernel<<<grid_for(total, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)y,
                                                                                           planes, xs.h, xs.w);
   DLWP_LAUNCH_CHECK("maxpool2_fwd_kernel");

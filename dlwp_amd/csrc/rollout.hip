@@ -25,13 +25,13 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
       return dlwp_convlstm_gates(h, src, aux[0], aux[1], aux[2], dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w,
                                  op.conv.out_c_off, op.conv.out_c_total, op.conv.act, op.aux[3], dtype, (void*)s);
     case DLWP_OP_CONV2D:
-      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, dtype, s, u_pre);
+      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre);  // aux[0]: per-op storage
     case DLWP_OP_PAD2D:
       // NCHW: outer = n*c rows-of-W planes; NHWC: xs = (n, 1, h, w) and conv.in_c_total carries the inner (channel) run
       return dlwp_pad2d_fwd(h, src, dst, op.xs.n * op.xs.c, op.xs.h, op.xs.w,
                             op.conv.in_c_total > 1 ? op.conv.in_c_total : 1, op.pad, dtype, (void*)s);
     case DLWP_OP_MAXPOOL2:
-      return dlwp_maxpool2_fwd(h, src, dst, op.xs, dtype, (void*)s);
+      return dlwp_maxpool2_fwd(h, src, dst, op.xs, op.aux[0], (void*)s);
     case DLWP_OP_UPSAMPLE2:
       return dlwp_upsample2_fwd(h, src, dst, op.xs, dtype, (void*)s);
     case DLWP_OP_COPYCH:

@@ -26,10 +26,11 @@ def default_device():
 class Executor(object):
     """Runs a Plan on one device for a given batch size.  Buffers are cached per batch size."""
 
-    def __init__(self, plan, device):
+    def __init__(self, plan, device, activation_dtype='float32'):
         self.plan, self.device = plan, device
         self._bufs = {}
         self._descs = None
+        self._bf16 = set(plan.bf16_buffers()) if activation_dtype == 'bfloat16' else set()
 
     # -- buffers ----------------------------------------------------------------------------------------------------- #
     def scratch(self, n):
@@ -37,7 +38,8 @@ class Executor(object):
         if b is None:
             if len(self._bufs) > 4:
                 self._bufs.clear()
-            b = [torch.empty((n,) + s, dtype=torch.float32, device=self.device) for s in self.plan.buffers]
+            b = [torch.empty((n,) + s, dtype=torch.bfloat16 if i in self._bf16 else torch.float32, device=self.device)
+                 for i, s in enumerate(self.plan.buffers)]
             self._bufs[n] = b
         return b
 
@@ -128,6 +130,10 @@ class Executor(object):
             if op.kind == 'conv':
                 o.w, o.b = widx[id(op.layer)]
                 o.conv = d
+                o.aux[0] = _lib.dtype_io(_lib.BF16 if op.src in self._bf16 else _lib.F32,
+                                         _lib.BF16 if op.dst in self._bf16 else _lib.F32)
+            elif op.kind == 'maxpool':
+                o.aux[0] = _lib.BF16 if op.src in self._bf16 else _lib.F32
             elif op.kind == 'pad':
                 o.pad = d
                 if op.inner > 1:
@@ -210,10 +216,33 @@ class Model(object):
                 continue
             t.layer.build(t.inputs[0].shape, self.device, rng)
         self.plan = P.build_plan(self.inputs, self.outputs)
-        self.executor = Executor(self.plan, self.device)
+        self.activation_dtype = getattr(self, 'activation_dtype', 'float32')
+        self.executor = Executor(self.plan, self.device, self.activation_dtype)
+        self._train_executor = None
         self.input_shape = (None,) + tuple(self.inputs[0].shape)
         shapes = [(None,) + tuple(o.shape) for o in self.outputs]
         self.output_shape = shapes[0] if len(shapes) == 1 else shapes
+
+    # -- storage type of the activations between the layers (inference) ------------------------------------------------- #
+    def set_activation_dtype(self, dtype):
+        """'float32' (default) or 'bfloat16': how predict / predict_timeseries store the tensors BETWEEN convolutions
+        (BASELINE.json config 4).  Model inputs, outputs, weights and all arithmetic stay float32; training always runs
+        on float32 activations."""
+        if dtype not in ('float32', 'bfloat16'):
+            raise ValueError("activation dtype must be 'float32' or 'bfloat16'")
+        if dtype != self.activation_dtype:
+            self.activation_dtype = dtype
+            self.executor = Executor(self.plan, self.device, dtype)
+            self.__dict__.pop('_rollouts', None)
+        return self
+
+    @property
+    def train_executor(self):
+        if self.activation_dtype == 'float32':
+            return self.executor
+        if self._train_executor is None:
+            self._train_executor = Executor(self.plan, self.device, 'float32')
+        return self._train_executor
 
     # -- weights ----------------------------------------------------------------------------------------------------- #
     @property

@@ -35,6 +35,20 @@ def _check_f32(*ts):
             raise ValueError('expected contiguous float32 tensors, got %s contiguous=%s' % (t.dtype, t.is_contiguous()))
 
 
+def _check_act(*ts):
+    """activation tensors: contiguous float32 or bfloat16 (storage types of the forward convolutions / max-pooling)"""
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous():
+            raise ValueError('expected contiguous float32 / bfloat16 tensors, got %s contiguous=%s' %
+                             (t.dtype, t.is_contiguous()))
+
+
+def storage_code(t):
+    return _lib.BF16 if t.dtype == torch.bfloat16 else _lib.F32
+
+
 def make_pad(top=0, bottom=0, left=0, right=0, mode_h=PAD_ZERO, mode_w=PAD_ZERO):
     return Pad2d(int(top), int(bottom), int(left), int(right), int(mode_h), int(mode_w))
 
@@ -86,7 +100,8 @@ def pad2d_bwd(dy, x_shape, pad, channels_last=False):
 def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None):
     """x: stored input (n, in_c_total, h, w); the conv reads `x_channels` (default: all) channels from cd.in_c_off.
     Returns (n, out_c_total, ho, wo); writes channels [out_c_off, out_c_off+cout)."""
-    _check_f32(x, w_hwio, bias)
+    _check_act(x, out)
+    _check_f32(w_hwio, bias)
     n, c_total, h, w = x.shape
     cin = int(x_channels) if x_channels is not None else c_total
     if tuple(w_hwio.shape) != (cd.kh, cd.kw, cin, cd.cout):
@@ -102,16 +117,19 @@ def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None):
     elif tuple(out.shape) != (n, oc, ys.h, ys.w):
         raise ValueError('output buffer shape %s != %s' % (tuple(out.shape), (n, oc, ys.h, ys.w)))
     fn = _lib.lib.dlwp_conv2d_fwd_direct if direct else _lib.lib.dlwp_conv2d_fwd
-    _lib.check(fn(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(bias), _ptr(out), xs, ctypes.byref(cd), _lib.F32,
+    dt = _lib.dtype_io(storage_code(x), storage_code(out))      # storage of x / y; arithmetic is fp32 either way
+    _lib.check(fn(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(bias), _ptr(out), xs, ctypes.byref(cd), dt,
                   _stream(x)))
     return out
 
 
 def maxpool2(x, out=None):
-    _check_f32(x)
+    _check_act(x, out)
     n, c, h, w = x.shape
     y = out if out is not None else torch.empty((n, c, h // 2, w // 2), dtype=x.dtype, device=x.device)
-    _lib.check(_lib.lib.dlwp_maxpool2_fwd(_lib.handle(_dev(x)), _ptr(x), _ptr(y), Shape4(n, c, h, w), _lib.F32,
+    if y.dtype != x.dtype:
+        raise ValueError('maxpool2: input %s and output %s storage differ' % (x.dtype, y.dtype))
+    _lib.check(_lib.lib.dlwp_maxpool2_fwd(_lib.handle(_dev(x)), _ptr(x), _ptr(y), Shape4(n, c, h, w), storage_code(x),
                                           _stream(x)))
     return y
 

@@ -142,6 +142,37 @@ class Plan(object):
             tot += (kh * kw * lay.kernel.shape[2] * lay.filters + lay.filters) * itemsize if lay.kernel is not None else 0
         return tot
 
+    def bf16_buffers(self):
+        """Scratch buffers that may be stored as bfloat16 (config 4: bf16 activations between the layers): written by a
+        Conv2D or a max-pooling of such a buffer and read only by convolutions / max-pooling.  Model inputs and outputs,
+        the ConvLSTM2D state tensors and anything a copy / pad / up-sampling kernel touches stay float32."""
+        ok = {}
+        for op in self.ops:
+            for b, role in ((op.src, 'r'), (op.dst, 'w')):
+                if b < 0:
+                    continue
+                good = (op.kind == 'conv' and (role == 'r' or not isinstance(op.layer, L._ConvPart))) or op.kind == 'maxpool'
+                if op.kind == 'conv' and isinstance(op.layer, L._ConvPart) and role == 'r' and op.layer.which != 'kernel':
+                    good = False        # the recurrent convolution reads the float32 h sequence
+                ok[b] = ok.get(b, True) and good
+            if op.kind == 'lstm':
+                for b in (op.src, op.dst) + tuple(x for x in op.aux if x is not None):
+                    if b >= 0:
+                        ok[b] = False
+        changed = True
+        while changed:                  # a pooled copy is bf16 only if its source is (and vice versa)
+            changed = False
+            for op in self.ops:
+                if op.kind == 'maxpool' and op.src >= 0 and op.dst >= 0 and ok.get(op.src, False) != ok.get(op.dst, False):
+                    ok[op.src] = ok[op.dst] = False
+                    changed = True
+                if op.kind == 'maxpool' and (op.src < 0 or op.dst < 0):
+                    for b in (op.src, op.dst):
+                        if b >= 0 and ok.get(b, False):
+                            ok[b] = False
+                            changed = True
+        return sorted(b for b, v in ok.items() if v)
+
     def describe(self):
         return '\n'.join(repr(op) for op in self.ops)
 

@@ -176,7 +176,7 @@ class Trainer(object):
     def _forward_loss(self, x, ys, want_grad, weight_scale=1.0):
         """Returns (outs, loss table [n_out, 7] on device: col 0 custom-loss value, 1 mse, 2 mae, dys or None)."""
         from . import ops
-        outs = self.model.executor.run(x)
+        outs = self.model.train_executor.run(x)
         n_out = len(outs)
         if self._loss_out is None or self._loss_out.shape[0] != n_out:
             self._loss_out = torch.zeros((n_out, 7), dtype=torch.float32, device=self.device)
@@ -248,7 +248,7 @@ class Trainer(object):
         from . import _lib, ops
         plan = self.plan
         n = x.shape[0]
-        bufs = self.model.executor.scratch(n)
+        bufs = self.model.train_executor.scratch(n)
         x = x.reshape((n,) + plan._in_store)
 
         def tensor(i):
@@ -297,7 +297,7 @@ class Trainer(object):
                 raise NotImplementedError('partially overlapping channel windows in the backward pass')
 
         touched_layers = set()
-        descs = self.model.executor._descriptors()
+        descs = self.model.train_executor._descriptors()
         for op, d in reversed(list(zip(plan.ops, descs))):
             if op.dst not in grads:
                 continue                      # nothing downstream of this op contributes to the loss

@@ -13,7 +13,10 @@
  *     stated; the library never allocates, frees or retains them (rollout objects excepted: buffers captured in a
  *     rollout graph must outlive it).
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it.  No host synchronisation inside.
- *   - dtype: DLWP_F32 (0) everywhere in this version.  (DLWP_BF16 = 1 reserved.)
+ *   - dtype: the STORAGE type of activation tensors.  DLWP_F32 everywhere; the forward convolutions and
+ *     dlwp_maxpool2_fwd also take DLWP_BF16 and, for the convolutions, DLWP_DTYPE_IO(in, out) with different input and
+ *     output storage (config 4: bf16 activations between the layers, fp32 state at the model boundary).  Weights, biases
+ *     and all arithmetic (MFMA accumulate, activation) are fp32; fp32 -> bf16 rounds to nearest even.
  */
 #ifndef DLWP_HIP_H
 #define DLWP_HIP_H
@@ -32,6 +35,9 @@ extern "C" {
 
 #define DLWP_F32  0
 #define DLWP_BF16 1
+#define DLWP_DTYPE_IO(in, out) (0x10000 | (in) | ((out) << 8))   /* input / output storage of one launch */
+#define DLWP_DTYPE_IN(d)  (((d) & 0x10000) ? ((d) & 0xff) : (d))
+#define DLWP_DTYPE_OUT(d) (((d) & 0x10000) ? (((d) >> 8) & 0xff) : (d))
 
 /* per-axis halo modes */
 #define DLWP_PAD_ZERO 0   /* keras.layers.ZeroPadding2D                                  (examples/train.py:163)   */
@@ -206,7 +212,9 @@ typedef struct {
   dlwp_conv2d conv;         /* DLWP_OP_CONV2D; for DLWP_OP_COPYCH: in_c_off/in_c_total/out_c_off/out_c_total */
   dlwp_pad2d pad;           /* DLWP_OP_PAD2D (NHWC: xs = (n,1,h,w) and conv.in_c_total = channels)          */
   int aux[4];               /* DLWP_OP_LSTM_GATES: src = zx, dst = h buffer (window conv.out_c_off/out_c_total), xs =
-                             * (n, F, h, w), aux = {zh | -1000, c_prev | -1000, c_out, rec_act}, conv.act = activation */
+                             * (n, F, h, w), aux = {zh | -1000, c_prev | -1000, c_out, rec_act}, conv.act = activation.
+                             * DLWP_OP_CONV2D / DLWP_OP_MAXPOOL2: aux[0] = storage dtype of this op's tensors (DLWP_F32,
+                             * DLWP_BF16 or DLWP_DTYPE_IO(in, out)); the rollout's own dtype describes state and series */
 } dlwp_op;
 #define DLWP_BUF_NONE (-1000)
 typedef struct dlwp_rollout* dlwp_rollout_t;

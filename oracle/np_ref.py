@@ -350,10 +350,21 @@ def init_weights(layers, in_channels, rng):
     return out
 
 
-def run_layers(layers, x, weights, record=None):
+def round_bf16(a):
+    """Round float values to the nearest bfloat16 (ties to even) and return them as float64: what a bf16 store + load
+    of a float32 value does (v_cvt_pk_bf16_f32)."""
+    f = np.ascontiguousarray(a, dtype=np.float32)
+    u = f.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)
+    out = r.view(np.float32).astype(np.float64)
+    return np.where(np.isnan(f), np.nan, out)
+
+
+def run_layers(layers, x, weights, record=None, bf16_activations=False):
     """Execute a sequential stack exactly as the reference graph is laid out (one op per layer, unfused)."""
     x = np.asarray(x, dtype=np.float64)
     wi = 0
+    n_weighted = sum(1 for nm, _, _ in layers if nm in ('Conv2D', 'ConvLSTM2D'))
     for name, args, kwargs in layers:
         args, kwargs = args or (), kwargs or {}
         fmt = kwargs.get('data_format', 'channels_first')
@@ -368,6 +379,8 @@ def run_layers(layers, x, weights, record=None):
             w, b = weights[wi]
             wi += 1
             x = conv2d(x, w, b, dil, act or 'linear')
+            if bf16_activations and wi < n_weighted:
+                x = round_bf16(x)       # config 4: every Conv2D output except the model output is stored as bfloat16
         elif name == 'PeriodicPadding3D':
             x = periodic_padding3d(x, args[0] if args else kwargs.get('padding', (1, 1, 1)), fmt)
         elif name == 'ZeroPadding3D':

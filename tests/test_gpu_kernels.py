@@ -311,3 +311,52 @@ def test_convlstm_gates_match_oracle(ops, n, f, h, w, first, rec):
     got = host(h_out)
     assert np.abs(got[:, f:2 * f] - h_want).max() < 2e-6
     assert np.all(got[:, :f] == 7.0) and np.all(got[:, 2 * f:] == 7.0)
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# bfloat16 storage of the activations (BASELINE.json config 4); arithmetic stays fp32
+# ----------------------------------------------------------------------------------------------------------------- #
+
+BF16_CASES = [
+    # (n, cin, h, w, cout, k, dil, src_mode)         kernel family the shape selects
+    (2, 4, 12, 20, 32, 3, 2, 0),                     # direct MFMA (cin = 4)
+    (2, 24, 12, 20, 64, 3, 1, 0),                    # Winograd
+    (2, 32, 12, 20, 32, 3, 2, 1),                    # Winograd, dilation 2, fused up-sampling
+    (2, 20, 12, 20, 36, 3, 1, 2),                    # direct MFMA with the pooled loader (ragged channels)
+    (2, 32, 12, 20, 4, 5, 1, 0),                     # packed-N 5x5 output layer
+    (1, 3, 9, 11, 5, 7, 1, 0),                       # no MFMA instance: the one-thread-per-output kernel
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+@pytest.mark.parametrize('io', [('bf16', 'bf16'), ('f32', 'bf16'), ('bf16', 'f32')])
+def test_conv2d_bfloat16_storage(ops, case, io):
+    n, cin, h, w, cout, k, dil, src = case
+    rng = np.random.default_rng(sum(case))
+    x = np_ref.round_bf16(rng.standard_normal((n, cin, h, w))).astype(np.float32)     # exactly representable inputs
+    wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    p = dil * (k - 1) // 2
+    pads = (p, p, p, p)
+    want = _conv_ref(x, wt, b, dil, pads, 0, 1, 'tanh', src)
+    cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH, src_mode=src)
+    xd = dev(x).to(torch.bfloat16) if io[0] == 'bf16' else dev(x)
+    out = torch.empty(want.shape, dtype=torch.bfloat16 if io[1] == 'bf16' else torch.float32, device='cuda')
+    ops.conv2d(xd, dev(wt), dev(b), cd, out=out)
+    got = out.to(torch.float32).cpu().numpy()
+    if io[1] == 'f32':
+        _check_conv(ops, got, want, 'bf16 in')
+    else:
+        # the stored value is the fp32 result rounded to bf16: at most one bf16 ulp (2^-8 relative) from the oracle, and
+        # almost everywhere exactly the oracle's own rounding
+        assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 1e-6)
+        assert np.mean(got == np_ref.round_bf16(want)) > 0.99
+
+
+def test_maxpool2_bfloat16_is_exact(ops):
+    rng = np.random.default_rng(77)
+    for shape in ((3, 5, 8, 12), (2, 3, 9, 7)):
+        x = np_ref.round_bf16(rng.standard_normal(shape)).astype(np.float32)
+        got = ops.maxpool2(dev(x).to(torch.bfloat16))
+        assert got.dtype == torch.bfloat16
+        assert np.array_equal(got.to(torch.float32).cpu().numpy(), np_ref.maxpool2(x))

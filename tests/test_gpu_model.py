@@ -623,3 +623,54 @@ def test_time_series_estimator_runs_the_device_rollout_for_matching_io():
     first = d2.predict(X2).reshape(n, 2, 2, h, w)
     assert np.array_equal(out2.values[0, :, :, 0], first[:, 0]) and np.array_equal(out2.values[1, :, :, 0], first[:, 1])
     assert np.isfinite(out2.values[2:, :n - 2]).all()
+
+
+def test_bfloat16_activation_storage_matches_the_rounding_oracle():
+    """BASELINE.json config 4: bf16 activations between the layers, fp32 at the model boundary.  Oracle = the float64
+    graph with every intermediate Conv2D output rounded to bf16 (ties to even)."""
+    rng = np.random.default_rng(51)
+    cs = (4, 16, 24)
+    layers = unet_layers(cs)
+    d = _build(layers, time_dim=2)
+    weights = _weights_of(d.model, rng)
+    x = rng.standard_normal((5,) + cs).astype(np.float32)
+    y32 = d.predict(x)
+    d.model.set_activation_dtype('bfloat16')
+    assert [b.dtype for b in d.model.executor.scratch(5)] == [torch.bfloat16] * len(d.model.plan.buffers)
+    y16 = d.predict(x)
+    want = np_ref.run_layers(layers, x, weights, bf16_activations=True)
+    assert y16.dtype == np.float32 and y16.shape == y32.shape
+    # different summation order -> a few intermediate values round to the neighbouring bf16; the effect on the output is
+    # far below the bf16-vs-fp32 difference itself
+    assert _rel(y16, want) < 4e-3
+    assert 1e-4 < _rel(y16, y32) < 3e-2
+    # rollout: captured graph == host loop over predict(), bit for bit, in bf16 mode too
+    series = d.predict_timeseries(x, 4)
+    p, ser = x, []
+    for _ in range(2):
+        p = d.predict(p)
+        ser.append(p)
+    assert np.array_equal(series, np_ref._merge_time(np.stack(ser), 2, 5, 2, cs, False))
+    # training is unaffected (float32 activations), and switching back restores the float32 results exactly
+    d.model.train_on_batch(x, x)
+    d.model.set_activation_dtype('float32')
+    assert d.predict(x).dtype == np.float32
+
+
+def test_bfloat16_storage_with_the_recurrent_front_end():
+    from dlwp_amd.model import DLWPNeuralNet
+    from tests.nets import lstm_unet_layers
+    rng = np.random.default_rng(52)
+    cs = (2, 2, 16, 24)
+    layers = lstm_unet_layers(cs, widths=(16, 32, 64, 32, 16))
+    np.random.seed(5)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(layers, loss='mse', optimizer='adam')
+    weights = _lstm_weights(d.model, rng)
+    x = rng.standard_normal((3,) + cs).astype(np.float32)
+    d.model.set_activation_dtype('bfloat16')
+    kinds = {i: b.dtype for i, b in enumerate(d.model.executor.scratch(3))}
+    assert kinds[0] == torch.float32 and torch.bfloat16 in kinds.values()        # LSTM state fp32, conv stack bf16
+    got = d.predict(x)
+    want = np_ref.run_layers(layers, x, weights, bf16_activations=True)
+    assert _rel(got, want) < 4e-3
