@@ -17,6 +17,7 @@
 // LDS stage.  Both LDS strides are chosen == 16 (mod 32) floats so the two 16-lane halves of a ds_read_b32 lane group
 // (k and k+1) fall on disjoint banks.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -65,20 +66,36 @@ struct ConvCfg {
 // denominator in x^2.  Max error 4e-7 absolute (6.6 ulp next to saturation), 2.4e-7 relative for small |x|; ~17 VALU ops
 // instead of the ~50 of the libm tanhf.
 __device__ __forceinline__ float dlwp_tanh(float x) {
-  if (x != x) return x;
-  x = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
-  const float x2 = x * x;
+  const float xc = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
+  const float x2 = xc * xc;
   float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
   p = fmaf(x2, p, -8.60467152213735e-11f);
   p = fmaf(x2, p, 5.12229709037114e-08f);
   p = fmaf(x2, p, 1.48572235717979e-05f);
   p = fmaf(x2, p, 6.37261928875436e-04f);
   p = fmaf(x2, p, 4.89352455891786e-03f);
-  p = x * p;
+  p = xc * p;
   float q = fmaf(x2, 1.19825839466702e-06f, 1.18534705686654e-04f);
   q = fmaf(x2, q, 2.26843463243900e-03f);
   q = fmaf(x2, q, 4.89352518554385e-03f);
-  return p * __builtin_amdgcn_rcpf(q);
+  const float r = p * __builtin_amdgcn_rcpf(q);
+  return (x != x) ? x : r;  // the clamp would swallow a NaN; a select, not a branch (this sits in every conv epilogue)
+}
+
+// activation with a compile-time kind: the epilogues dispatch ONCE on the runtime value (act_dispatch) instead of
+// branching per output element
+template <int ACT>
+__device__ __forceinline__ float act_apply_c(float v) {
+  if constexpr (ACT == DLWP_ACT_TANH) return dlwp_tanh(v);
+  else if constexpr (ACT == DLWP_ACT_RELU) return fmaxf(v, 0.f);
+  else return v;
+}
+
+template <class F>
+__device__ __forceinline__ void act_dispatch(int act, F&& f) {
+  if (act == DLWP_ACT_TANH) f(std::integral_constant<int, DLWP_ACT_TANH>{});
+  else if (act == DLWP_ACT_RELU) f(std::integral_constant<int, DLWP_ACT_RELU>{});
+  else f(std::integral_constant<int, DLWP_ACT_LINEAR>{});
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -346,44 +363,47 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
   }
 
   // ---- epilogue: bias + activation, 4 consecutive pixels of one channel per lane
-  const bool vec_store = (C::TW % 4 == 0) && ((a.Wo & 3) == 0);
-  float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;
-  bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;  // if a.out_bf16
-#pragma unroll
-  for (int g = 0; g < C::BNF; ++g) {
-    const int co = n0 + g * 16 + (lane & 15);
-    if (co >= a.Cout) continue;
-    const float bv = a.bias ? a.bias[co] : 0.f;
-    float* yc = yn + (long long)co * a.Ho * a.Wo;
-    bf16_t* yc16 = yn16 + (long long)co * a.Ho * a.Wo;
-#pragma unroll
-    for (int i = 0; i < C::FA; ++i) {
-      const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
-      if (p >= C::P) continue;
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = act_apply(acc[i][g][r] + bv, a.act);
-      if (vec_store) {
-        const int row = p / C::TW, col = p - row * C::TW;
-        const int oh = i0 + row, ow = j0 + col;
-        if (oh < a.Ho && ow < a.Wo) {
-          if (a.out_bf16) *(u32x2*)(yc16 + (long long)oh * a.Wo + ow) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-          else *(f32x4*)(yc + (long long)oh * a.Wo + ow) = o;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int pp = p + r;
-          const int row = pp / C::TW, col = pp - row * C::TW;
+  act_dispatch(a.act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    const bool vec_store = (C::TW % 4 == 0) && ((a.Wo & 3) == 0);
+    float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;
+    bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;  // if a.out_bf16
+  #pragma unroll
+    for (int g = 0; g < C::BNF; ++g) {
+      const int co = n0 + g * 16 + (lane & 15);
+      if (co >= a.Cout) continue;
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      float* yc = yn + (long long)co * a.Ho * a.Wo;
+      bf16_t* yc16 = yn16 + (long long)co * a.Ho * a.Wo;
+  #pragma unroll
+      for (int i = 0; i < C::FA; ++i) {
+        const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
+        if (p >= C::P) continue;
+        f32x4 o;
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = act_apply_c<ACT>(acc[i][g][r] + bv);
+        if (vec_store) {
+          const int row = p / C::TW, col = p - row * C::TW;
           const int oh = i0 + row, ow = j0 + col;
-          if (pp < C::P && oh < a.Ho && ow < a.Wo) {
-            if (a.out_bf16) yc16[(long long)oh * a.Wo + ow] = f32_to_bf16(o[r]);
-            else yc[(long long)oh * a.Wo + ow] = o[r];
+          if (oh < a.Ho && ow < a.Wo) {
+            if (a.out_bf16) *(u32x2*)(yc16 + (long long)oh * a.Wo + ow) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            else *(f32x4*)(yc + (long long)oh * a.Wo + ow) = o;
+          }
+        } else {
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pp = p + r;
+            const int row = pp / C::TW, col = pp - row * C::TW;
+            const int oh = i0 + row, ow = j0 + col;
+            if (pp < C::P && oh < a.Ho && ow < a.Wo) {
+              if (a.out_bf16) yc16[(long long)oh * a.Wo + ow] = f32_to_bf16(o[r]);
+              else yc[(long long)oh * a.Wo + ow] = o[r];
+            }
           }
         }
       }
     }
-  }
+  });
 }
 
 // ---- registry of compiled tile configurations ------------------------------------------------------------------- //

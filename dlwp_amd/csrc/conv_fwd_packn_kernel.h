@@ -192,27 +192,30 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
   }
 
   // ---- epilogue: lane (co, s) holds 4 super-pixels; pixel column = S*c' + s
-  const int j = lane & 15;
-  const int co = j / C::S, s = j - co * C::S;
-  if (co < a.Cout) {
-    const float bv = a.bias ? a.bias[co] : 0.f;
-    float* yc = a.y + (((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho) * a.Wo;
-    bf16_t* yc16 = (bf16_t*)a.y + (((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho) * a.Wo;  // if a.out_bf16
-#pragma unroll
-    for (int i = 0; i < C::FA; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4 + r;
-        const int row = p / C::TWS, c = p - row * C::TWS;
-        const int oh = i0 + row, ow = j0 + c * C::S + s;
-        if (p < C::P && oh < a.Ho && ow < a.Wo) {
-          const float o = act_apply(acc[i][r] + bv, a.act);
-          if (a.out_bf16) yc16[(long long)oh * a.Wo + ow] = f32_to_bf16(o);
-          else yc[(long long)oh * a.Wo + ow] = o;
+  act_dispatch(a.act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    const int j = lane & 15;
+    const int co = j / C::S, s = j - co * C::S;
+    if (co < a.Cout) {
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      float* yc = a.y + (((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho) * a.Wo;
+      bf16_t* yc16 = (bf16_t*)a.y + (((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho) * a.Wo;  // if a.out_bf16
+  #pragma unroll
+      for (int i = 0; i < C::FA; ++i) {
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4 + r;
+          const int row = p / C::TWS, c = p - row * C::TWS;
+          const int oh = i0 + row, ow = j0 + c * C::S + s;
+          if (p < C::P && oh < a.Ho && ow < a.Wo) {
+            const float o = act_apply_c<ACT>(acc[i][r] + bv);
+            if (a.out_bf16) yc16[(long long)oh * a.Wo + ow] = f32_to_bf16(o);
+            else yc[(long long)oh * a.Wo + ow] = o;
+          }
         }
       }
     }
-  }
+  });
 }
 
 template <class C>

@@ -301,36 +301,39 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
   __syncthreads();  // every wave is out of the loop: LDS becomes the output staging area
 
   // ---- output transform Y = A^T M A in registers, bias + activation, then [co][row][col] through LDS
-#pragma unroll
-  for (int g = 0; g < C::BNF; ++g) {
-    const int col = g * 16 + (lane & 15);
-    const float bv = a.bias ? a.bias[n0 + col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int t = wave * 16 + (lane >> 4) * 4 + r;
-      if (t >= C::T) continue;
-      const int pc = t / (C::RTH * C::RTW), rem = t - pc * (C::RTH * C::RTW);
-      const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
-      const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
-      float m[4][4];
-#pragma unroll
-      for (int xy = 0; xy < 16; ++xy) m[xy >> 2][xy & 3] = acc[xy][g][r];
-      float s[2][4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {  // A^T m
-        s[0][c] = m[0][c] + m[1][c] + m[2][c];
-        s[1][c] = m[1][c] - m[2][c] - m[3][c];
-      }
-      float* op = lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
-#pragma unroll
-      for (int aa = 0; aa < 2; ++aa) {
-        const float y0 = act_apply(s[aa][0] + s[aa][1] + s[aa][2] + bv, a.act);
-        const float y1 = act_apply(s[aa][1] - s[aa][2] - s[aa][3] + bv, a.act);
-        op[aa * C::DIL * C::TW] = y0;
-        op[aa * C::DIL * C::TW + C::DIL] = y1;
+  act_dispatch(a.act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+  #pragma unroll
+    for (int g = 0; g < C::BNF; ++g) {
+      const int col = g * 16 + (lane & 15);
+      const float bv = a.bias ? a.bias[n0 + col] : 0.f;
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = wave * 16 + (lane >> 4) * 4 + r;
+        if (t >= C::T) continue;
+        const int pc = t / (C::RTH * C::RTW), rem = t - pc * (C::RTH * C::RTW);
+        const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
+        const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
+        float m[4][4];
+  #pragma unroll
+        for (int xy = 0; xy < 16; ++xy) m[xy >> 2][xy & 3] = acc[xy][g][r];
+        float s[2][4];
+  #pragma unroll
+        for (int c = 0; c < 4; ++c) {  // A^T m
+          s[0][c] = m[0][c] + m[1][c] + m[2][c];
+          s[1][c] = m[1][c] - m[2][c] - m[3][c];
+        }
+        float* op = lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
+  #pragma unroll
+        for (int aa = 0; aa < 2; ++aa) {
+          const float y0 = act_apply_c<ACT>(s[aa][0] + s[aa][1] + s[aa][2] + bv);
+          const float y1 = act_apply_c<ACT>(s[aa][1] - s[aa][2] - s[aa][3] + bv);
+          op[aa * C::DIL * C::TW] = y0;
+          op[aa * C::DIL * C::TW + C::DIL] = y1;
+        }
       }
     }
-  }
+  });
   __syncthreads();
   float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
   bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;  // if a.out_bf16
