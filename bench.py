@@ -68,7 +68,7 @@ def time_layers(model, members, iters=5):
     """Per-launch duration of every kernel of one forward, HIP events on the stream the kernels are launched on."""
     from dlwp_amd import ops
     ex = model.executor
-    plan = model.plan
+    plan = ex.plan                                      # the inference plan (pooling in the producers' epilogues)
     x = torch.randn((members,) + plan._in_store, device=model.device)
     outs = ex.run(x)                                    # fills every scratch buffer with realistic data
     bufs = ex.scratch(members)
@@ -103,8 +103,9 @@ def time_layers(model, members, iters=5):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         kh, kw = lay.kernel_size
-        co, ho, wo = op.out_shape
+        co, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape     # FLOPs: what the convolution computes
         flops = 2.0 * ho * wo * co * op.xs[0] * kh * kw * members
+        co, ho, wo = op.out_shape                                             # bytes: what it stores
         nbytes = (float(src.element_size()) * members * op.xs[0] * op.xs[1] * op.xs[2] +
                   float(dst.element_size()) * members * co * ho * wo + 4.0 * kh * kw * op.xs[0] * co)
         from dlwp_amd import _lib
@@ -201,7 +202,7 @@ def main():
     net = d.model
     net.set_activation_dtype(a.activation_dtype)
     flops_fwd = net.plan.conv_flops_per_sample()
-    bytes_fwd = net.plan.algorithmic_bytes_per_sample()
+    bytes_fwd = net.infer_plan.algorithmic_bytes_per_sample()
     weights_np = [(w, b) for w, b in zip(net.get_weights()[0::2], net.get_weights()[1::2])]
 
     # members: one base state + 0.01 * N(0,1) perturbations, different per rank
@@ -246,7 +247,7 @@ def main():
                                '%d-forward (14-day) predict_timeseries rollout as one hipGraph, %d members per GPU'
                                % (grid[0], grid[1], a.channels, a.forwards, a.members),
                    'members_per_gpu': a.members, 'forwards_per_rollout': a.forwards, 'time_dim': 2,
-                   'grid': list(grid), 'channels': a.channels, 'launches_per_forward': net.plan.n_launches,
+                   'grid': list(grid), 'channels': a.channels, 'launches_per_forward': net.infer_plan.n_launches,
                    'parallelism': 'members sharded over %d GPU(s), no collective' % world},
         'forwards_per_s': fwd_per_s,
         'conv_mflop_per_forward_per_member': flops_fwd / 1e6,

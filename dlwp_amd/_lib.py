@@ -47,7 +47,7 @@ class Conv2d(ctypes.Structure):
     _fields_ = [('cout', ctypes.c_int), ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('dil_h', ctypes.c_int),
                 ('dil_w', ctypes.c_int), ('halo', Pad2d), ('act', ctypes.c_int), ('in_c_off', ctypes.c_int),
                 ('in_c_total', ctypes.c_int), ('out_c_off', ctypes.c_int), ('out_c_total', ctypes.c_int),
-                ('src_mode', ctypes.c_int)]
+                ('src_mode', ctypes.c_int), ('out_pool', ctypes.c_int)]
 
 
 class Op(ctypes.Structure):
@@ -100,6 +100,7 @@ _sig('dlwp_conv2d_config_info', [_i, _P(_i), _P(_i)])
 _sig('dlwp_conv2d_force_config', [_i])
 _sig('dlwp_conv2d_set_winograd', [_i])
 _sig('dlwp_conv2d_prefers_unfused_pool', [_i, _i, _i, _i, _i, _i])
+_sig('dlwp_conv2d_supports_out_pool', [Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _i, _P(_sz)])
 _sig('dlwp_conv2d_bwd_data', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])

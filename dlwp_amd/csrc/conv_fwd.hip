@@ -108,8 +108,11 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
   a.Ws = xs.w;
   a.H = dlwp_src_dim(xs.h, cd->src_mode);
   a.W = dlwp_src_dim(xs.w, cd->src_mode);
-  a.Ho = ys.h;
-  a.Wo = ys.w;
+  a.out_pool = cd->out_pool;
+  a.Hp = ys.h;   // what is stored
+  a.Wp = ys.w;
+  a.Ho = a.H + cd->halo.top + cd->halo.bottom - cd->dil_h * (cd->kh - 1);   // the convolution's own output
+  a.Wo = a.W + cd->halo.left + cd->halo.right - cd->dil_w * (cd->kw - 1);
   a.Cout = cd->cout;
   a.in_c_off = cd->in_c_off;
   a.in_c_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
@@ -164,6 +167,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     const bool pool = cd->src_mode == DLWP_SRC_MAXPOOL2;
     const bool pack_ok = e.pack <= 0 || (cd->cout <= 16 / e.pack);
     if (e.pack < 0 && !winograd_wanted(a, cd)) return -1;  // Winograd instances: whole channel chunks only
+    if (cd->out_pool && !e.out_pool) return -1;
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? g_forced_cfg
                : -1;
@@ -174,7 +178,8 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
   if (want_wino) {  // fall back to the direct family when no Winograd instance matches (dilation / pooled loader)
     bool any = false;
     for (const ConvKernelEntry& e : r.entries)
-      any = any || (e.pack < 0 && e.dil == cd->dil_h && (e.pool != 0) == (cd->src_mode == DLWP_SRC_MAXPOOL2));
+      any = any || (e.pack < 0 && e.dil == cd->dil_h && (e.pool != 0) == (cd->src_mode == DLWP_SRC_MAXPOOL2) &&
+                    (!cd->out_pool || e.out_pool));
     want_wino = any;
   }
   for (int i = 0; i < (int)r.entries.size(); ++i) {
@@ -183,6 +188,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if ((e.pool != 0) != (cd->src_mode == DLWP_SRC_MAXPOOL2)) continue;  // pooled loader <-> POOL instances only
     if (e.pack > 0 && cd->cout > 16 / e.pack) continue;                    // packed-N instances cover cout <= 16/S
     if ((e.pack < 0) != want_wino) continue;                               // kernel family fixed by the layer geometry
+    if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     const double c = config_cost(e, a, cu_count);
     if (best < 0 || c < best_cost) {
       best = i;
@@ -272,6 +278,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   const int ci = choose_config(a, cd, h->cu_count);
   if (ci < 0) {
     if (g_forced_cfg >= 0) DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", g_forced_cfg);
+    if (cd->out_pool) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel with a pooling epilogue for this layer");
     return launch_direct(h, a, cd, s);  // kernel sizes without an MFMA tile configuration
   }
   Registry& r = registry();
@@ -352,10 +359,12 @@ int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys
                  cd->in_c_off, cd->in_c_off + xs.c, in_total);
   DLWP_CHECK_ARG(cd->out_c_off >= 0 && cd->out_c_off + cd->cout <= out_total,
                  "conv2d: output channel window [%d,%d) of %d", cd->out_c_off, cd->out_c_off + cd->cout, out_total);
+  DLWP_CHECK_ARG(cd->out_pool == 0 || cd->out_pool == 1, "conv2d: out_pool must be 0 or 1");
+  DLWP_CHECK_ARG(!cd->out_pool || (ho >= 2 && wo >= 2), "conv2d: out_pool on a %dx%d output", ho, wo);
   ys->n = xs.n;
   ys->c = cd->cout;
-  ys->h = ho;
-  ys->w = wo;
+  ys->h = cd->out_pool ? ho / 2 : ho;
+  ys->w = cd->out_pool ? wo / 2 : wo;
   return DLWP_OK;
 }
 
@@ -369,6 +378,7 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const 
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd_direct", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
+  DLWP_CHECK_ARG(!cd->out_pool, "dlwp_conv2d_fwd_direct: out_pool is not supported by this kernel");
   ConvArgs a = make_args(x, w, bias, y, xs, cd, ys, dtype);
   return launch_direct(h, a, cd, (hipStream_t)stream);
 }
@@ -392,6 +402,17 @@ int dlwp_conv2d_prefers_unfused_pool(int cin, int cout, int kh, int kw, int dil_
           cout % 32 == 0 && (size_t)cin * cout * 16 <= WINO_SCRATCH_FLOATS)
              ? 1
              : 0;
+}
+
+int dlwp_conv2d_supports_out_pool(dlwp_shape4 xs, const dlwp_conv2d* cd) {
+  if (!cd || xs.c <= 0 || xs.h <= 0 || xs.w <= 0) return 0;
+  dlwp_conv2d c2 = *cd;
+  c2.out_pool = 1;
+  dlwp_shape4 ys;
+  if (xs.n <= 0) xs.n = 1;
+  if (dlwp_conv2d_out_shape(xs, &c2, &ys) != DLWP_OK) return 0;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, &c2, ys);
+  return choose_config(a, &c2, 256) >= 0 ? 1 : 0;
 }
 
 int dlwp_conv2d_set_winograd(int enable) {

@@ -34,6 +34,7 @@ struct ConvArgs {
   int pad_top, pad_left, mode_h, mode_w;
   int src_mode, act;
   int tiles_h, tiles_w, cout_tiles;
+  int out_pool, Hp, Wp;   // epilogue 2x2 max-pooling: y is (N, out_c_total, Hp, Wp) = (Ho/2, Wo/2)
   int in_bf16, out_bf16;  // storage of x / y: 0 = float32, 1 = bfloat16 (arithmetic is fp32 either way; w, bias fp32)
 };
 
@@ -56,6 +57,8 @@ struct ConvCfg {
   static constexpr int P = TH * TW;
   static constexpr int MPAD = 16 * FA * WAVES;
   static constexpr int NPOS = (LR * LC + NT - 1) / NT;
+  // a wave's FA fragments are exactly two tile rows -> the 2x2 pooling window of an output lives in ONE lane
+  static constexpr bool POOL_EPI = !POOL_ && (TW == 8 * FA) && (TH == 2 * WAVES) && (FA % 2 == 0);
   static_assert(MPAD >= P, "tile pixels must fit the wave/fragment decomposition");
   static_assert(CK % 4 == 0, "channel chunk must be a multiple of the MFMA K (4)");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
@@ -365,6 +368,46 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
   // ---- epilogue: bias + activation, 4 consecutive pixels of one channel per lane
   act_dispatch(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
+    if (a.out_pool) {
+      // MaxPooling2D(2) in the epilogue (instances where a wave owns two whole tile rows): fragment i and i + FA/2 hold
+      // the same columns of rows 2w and 2w+1, registers (0,1) and (2,3) are horizontal neighbours.  bias and the
+      // (monotonic) activation are applied after the maximum: 4x fewer tanh.
+      if constexpr (C::POOL_EPI) {
+        const int pr = (i0 >> 1) + wave;
+        if (pr < a.Hp) {
+#pragma unroll
+          for (int g = 0; g < C::BNF; ++g) {
+            const int co = n0 + g * 16 + (lane & 15);
+            if (co >= a.Cout) continue;
+            const float bv = a.bias ? a.bias[co] : 0.f;
+            const long long yo = (((long long)n * a.out_c_total + a.out_c_off + co) * a.Hp + pr) * a.Wp;
+#pragma unroll
+            for (int i = 0; i < C::FA / 2; ++i) {
+              const int pc = (j0 >> 1) + i * 8 + (lane >> 4) * 2;
+              const f32x4 u = acc[i][g], d = acc[i + C::FA / 2][g];
+              const float o0 = act_apply_c<ACT>(fmaxf(fmaxf(u[0], u[1]), fmaxf(d[0], d[1])) + bv);
+              const float o1 = act_apply_c<ACT>(fmaxf(fmaxf(u[2], u[3]), fmaxf(d[2], d[3])) + bv);
+              if (a.out_bf16) {
+                bf16_t* yp = (bf16_t*)a.y + yo + pc;
+                if (pc + 1 < a.Wp && (a.Wp & 1) == 0) *(unsigned*)yp = pack_bf16x2(o0, o1);
+                else {
+                  if (pc < a.Wp) yp[0] = f32_to_bf16(o0);
+                  if (pc + 1 < a.Wp) yp[1] = f32_to_bf16(o1);
+                }
+              } else {
+                float* yp = a.y + yo + pc;
+                if (pc + 1 < a.Wp && (a.Wp & 1) == 0) *(u32x2*)yp = (u32x2){__builtin_bit_cast(unsigned, o0), __builtin_bit_cast(unsigned, o1)};
+                else {
+                  if (pc < a.Wp) yp[0] = o0;
+                  if (pc + 1 < a.Wp) yp[1] = o1;
+                }
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
     const bool vec_store = (C::TW % 4 == 0) && ((a.Wo & 3) == 0);
     float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;
     bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;  // if a.out_bf16
@@ -410,6 +453,7 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
 struct ConvKernelEntry {
   int ks, dil, th, tw, waves, fa, bnf, ck, lds_bytes, pool;
   int pack;  // 0 = plain kernel; S > 0 = packed-N kernel for cout <= 16/S (conv_fwd_packn_kernel.h), bnf unused
+  int out_pool;  // 1 = the instance can apply MaxPooling2D(2) in its epilogue (dlwp_conv2d.out_pool)
   void (*launch)(const ConvArgs&, int grid, hipStream_t s);
   int (*prepare)();
 };
@@ -431,6 +475,7 @@ static int conv_prepare() {
 #define CONV_ENTRY_P(KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL)                                                   \
   {                                                                                                                \
     KS, DIL, TH, TW, WAVES, FA, BNF, CK, ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>::LDS_BYTES, POOL, 0,   \
+        ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>::POOL_EPI ? 1 : 0,                                      \
         &conv_launch_thunk<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>>,                                    \
         &conv_prepare<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>>                                          \
   }

@@ -234,7 +234,7 @@ static int packn_prepare() {
 // registry entry: bnf = 0 and `pack` = S mark a packed-N instance (covers cout <= 16/S)
 #define PACKN_ENTRY(KS, DIL, TH, TW, WAVES, FA, CK, S)                                                        \
   {                                                                                                            \
-    KS, DIL, TH, TW, WAVES, FA, 0, CK, PackCfg<KS, DIL, TH, TW, WAVES, FA, CK, S>::LDS_BYTES, 0, S,            \
+    KS, DIL, TH, TW, WAVES, FA, 0, CK, PackCfg<KS, DIL, TH, TW, WAVES, FA, CK, S>::LDS_BYTES, 0, S, 0,         \
         &packn_launch_thunk<PackCfg<KS, DIL, TH, TW, WAVES, FA, CK, S>>,                                       \
         &packn_prepare<PackCfg<KS, DIL, TH, TW, WAVES, FA, CK, S>>                                             \
   }

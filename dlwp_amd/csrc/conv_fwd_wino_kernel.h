@@ -303,11 +303,11 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
   // ---- output transform Y = A^T M A in registers, bias + activation, then [co][row][col] through LDS
   act_dispatch(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
-  #pragma unroll
+#pragma unroll
     for (int g = 0; g < C::BNF; ++g) {
       const int col = g * 16 + (lane & 15);
       const float bv = a.bias ? a.bias[n0 + col] : 0.f;
-  #pragma unroll
+#pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int t = wave * 16 + (lane >> 4) * 4 + r;
         if (t >= C::T) continue;
@@ -315,16 +315,24 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
         const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
         const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
         float m[4][4];
-  #pragma unroll
+#pragma unroll
         for (int xy = 0; xy < 16; ++xy) m[xy >> 2][xy & 3] = acc[xy][g][r];
         float s[2][4];
-  #pragma unroll
+#pragma unroll
         for (int c = 0; c < 4; ++c) {  // A^T m
           s[0][c] = m[0][c] + m[1][c] + m[2][c];
           s[1][c] = m[1][c] - m[2][c] - m[3][c];
         }
+        if constexpr (C::DIL == 1) {
+          if (a.out_pool) {  // MaxPooling2D(2): the lane's 2x2 output tile IS one pooling window; activation after the max
+            const float m0 = fmaxf(s[0][0] + s[0][1] + s[0][2], s[0][1] - s[0][2] - s[0][3]);
+            const float m1 = fmaxf(s[1][0] + s[1][1] + s[1][2], s[1][1] - s[1][2] - s[1][3]);
+            lds[col * C::OPS + ti * (C::TW / 2) + tj] = act_apply_c<ACT>(fmaxf(m0, m1) + bv);
+            continue;
+          }
+        }
         float* op = lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
-  #pragma unroll
+#pragma unroll
         for (int aa = 0; aa < 2; ++aa) {
           const float y0 = act_apply_c<ACT>(s[aa][0] + s[aa][1] + s[aa][2] + bv);
           const float y1 = act_apply_c<ACT>(s[aa][1] - s[aa][2] - s[aa][3] + bv);
@@ -335,6 +343,43 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
     }
   });
   __syncthreads();
+  if constexpr (C::DIL == 1) {
+    if (a.out_pool) {  // pooled tile [co][TH/2][TW/2] -> 16-byte row segments of the (Hp, Wp) output
+      constexpr int PW = C::TW / 2, PP = (C::TH / 2) * PW;
+      static_assert((C::BN * PP / 4) % C::NT == 0 && PW % 4 == 0, "pooled output staging: whole float4 per thread");
+      const long long ybase = ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Hp * a.Wp;
+#pragma unroll
+      for (int k = 0; k < C::BN * PP / 4 / C::NT; ++k) {
+        const int e = (k * C::NT + tid) * 4;
+        const int co = e / PP, rem = e - co * PP;
+        const int row = rem / PW, colx = rem - row * PW;
+        const int oh = (i0 >> 1) + row, ow = (j0 >> 1) + colx;
+        if (oh >= a.Hp || ow >= a.Wp) continue;
+        const f32x4 o = *(const f32x4*)(lds + co * C::OPS + rem);
+        const long long yoff = ybase + ((long long)co * a.Hp + oh) * a.Wp + ow;
+        if (a.out_bf16) {
+          bf16_t* yp = (bf16_t*)a.y + yoff;
+          if (ow + 3 < a.Wp && ((a.Wp & 1) == 0)) {
+            *(unsigned*)yp = pack_bf16x2(o[0], o[1]);
+            *(unsigned*)(yp + 2) = pack_bf16x2(o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (ow + r < a.Wp) yp[r] = f32_to_bf16(o[r]);
+          }
+        } else {
+          float* yp = a.y + yoff;
+          if (ow + 3 < a.Wp) *(f32x4*)yp = o;
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (ow + r < a.Wp) yp[r] = o[r];
+          }
+        }
+      }
+      return;
+    }
+  }
   float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
   bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;  // if a.out_bf16
   constexpr int NOUT = C::BN * C::TH * C::TW / 4 / C::NT;
@@ -399,7 +444,7 @@ static int wino_prepare_both() {
 // registry entry: ks = 3, fa = 0, pack = -1 marks a Winograd instance (a.w = the transformed filter)
 #define WINO_ENTRY(DIL, TH, TW, WAVES, BNF, CK)                                                                         \
   {                                                                                                                      \
-    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1,                       \
+    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1, (DIL) == 1 ? 1 : 0,   \
         &wino_launch_either<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>, WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>,           \
         &wino_prepare_both<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>, WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>             \
   }

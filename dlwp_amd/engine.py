@@ -55,7 +55,8 @@ class Executor(object):
                     lay = op.layer
                     kh, kw = lay.kernel_size
                     descs.append(ops.make_conv(lay.filters, kh, kw, lay.dilation_rate, ops.make_pad(*op.halo), op.act,
-                                               op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode))
+                                               op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode,
+                                               op.out_pool))
                 elif op.kind == 'pad':
                     descs.append(ops.make_pad(*op.halo))
                 else:
@@ -215,9 +216,10 @@ class Model(object):
             if isinstance(t.layer, L.InputLayer):
                 continue
             t.layer.build(t.inputs[0].shape, self.device, rng)
-        self.plan = P.build_plan(self.inputs, self.outputs)
+        self.plan = P.build_plan(self.inputs, self.outputs)                       # training: every activation kept
+        self.infer_plan = P.build_plan(self.inputs, self.outputs, inference=True)   # predict / rollout
         self.activation_dtype = getattr(self, 'activation_dtype', 'float32')
-        self.executor = Executor(self.plan, self.device, self.activation_dtype)
+        self.executor = Executor(self.infer_plan, self.device, self.activation_dtype)
         self._train_executor = None
         self.input_shape = (None,) + tuple(self.inputs[0].shape)
         shapes = [(None,) + tuple(o.shape) for o in self.outputs]
@@ -232,16 +234,17 @@ class Model(object):
             raise ValueError("activation dtype must be 'float32' or 'bfloat16'")
         if dtype != self.activation_dtype:
             self.activation_dtype = dtype
-            self.executor = Executor(self.plan, self.device, dtype)
+            self.executor = Executor(self.infer_plan, self.device, dtype)
             self.__dict__.pop('_rollouts', None)
         return self
 
     @property
     def train_executor(self):
-        if self.activation_dtype == 'float32':
-            return self.executor
+        """Executor of the training plan: float32 activations, every pre-pooling tensor materialised."""
         if self._train_executor is None:
-            self._train_executor = Executor(self.plan, self.device, 'float32')
+            same = self.activation_dtype == 'float32' and len(self.infer_plan.ops) == len(self.plan.ops) and \
+                not any(op.out_pool for op in self.infer_plan.ops)
+            self._train_executor = self.executor if same else Executor(self.plan, self.device, 'float32')
         return self._train_executor
 
     # -- weights ----------------------------------------------------------------------------------------------------- #
@@ -276,8 +279,8 @@ class Model(object):
                                      lay.count_params()))
         pr('=' * 72)
         pr('Total params: %d' % self.count_params())
-        pr('fused launches per forward: %d (%d conv)' % (self.plan.n_launches,
-                                                         sum(1 for o in self.plan.ops if o.kind == 'conv')))
+        pr('fused launches per forward: %d (%d conv)' % (self.infer_plan.n_launches,
+                                                         sum(1 for o in self.infer_plan.ops if o.kind == 'conv')))
         pr('_' * 72)
 
     def reset_states(self):

@@ -54,10 +54,16 @@ def make_pad(top=0, bottom=0, left=0, right=0, mode_h=PAD_ZERO, mode_w=PAD_ZERO)
 
 
 def make_conv(cout, kh, kw, dil=1, halo=None, act=ACT_LINEAR, in_c_off=0, in_c_total=0, out_c_off=0, out_c_total=0,
-              src_mode=SRC_DIRECT):
+              src_mode=SRC_DIRECT, out_pool=False):
     dh, dw = (dil, dil) if isinstance(dil, int) else dil
     return Conv2d(int(cout), int(kh), int(kw), int(dh), int(dw), halo if halo is not None else make_pad(), int(act),
-                  int(in_c_off), int(in_c_total), int(out_c_off), int(out_c_total), int(src_mode))
+                  int(in_c_off), int(in_c_total), int(out_c_off), int(out_c_total), int(src_mode), int(bool(out_pool)))
+
+
+def supports_out_pool(xs_chw, cd):
+    """Planner hint: can a compiled kernel apply a following MaxPooling2D(2) in this convolution's epilogue?"""
+    return bool(_lib.lib.dlwp_conv2d_supports_out_pool(Shape4(1, int(xs_chw[0]), int(xs_chw[1]), int(xs_chw[2])),
+                                                       ctypes.byref(cd)))
 
 
 def conv_out_shape(xs, cd):

@@ -79,6 +79,7 @@ class PlanOp(object):
         self.out_shape = kw.pop('out_shape', None)   # per-sample (c, h, w) this op produces (window it writes)
         # lstm only: src = zx buffer, dst = h buffer; aux = (zh buffer | None, c_prev buffer | None, c_out buffer)
         self.aux = kw.pop('aux', None)
+        self.out_pool = kw.pop('out_pool', False)   # conv only: MaxPooling2D(2) applied in the epilogue (inference plans)
         self.rec_act = kw.pop('rec_act', 0)
         assert not kw, kw
 
@@ -88,10 +89,10 @@ class PlanOp(object):
             extra = ' aux%r h[%d:+%d/%d] act%d rec%d' % (self.aux, self.out_c_off, self.xs[0], self.out_c_total, self.act,
                                                         self.rec_act)
         if self.kind == 'conv':
-            extra = ' %s k%s d%s src%d halo%s act%d cin[%d:+%d/%d] cout[%d:+%d/%d]' % (
+            extra = ' %s k%s d%s src%d halo%s act%d cin[%d:+%d/%d] cout[%d:+%d/%d]%s' % (
                 self.layer.name, self.layer.kernel_size, self.layer.dilation_rate, self.src_mode, tuple(self.halo),
                 self.act, self.in_c_off, self.xs[0], self.in_c_total, self.out_c_off, self.layer.filters,
-                self.out_c_total)
+                self.out_c_total, ' +pool' if self.out_pool else '')
         return '<%s %s -> %s xs=%s%s>' % (self.kind, self.src, self.dst, self.xs, extra)
 
 
@@ -125,7 +126,7 @@ class Plan(object):
         for op in self.ops:
             if op.kind == 'conv':
                 kh, kw = op.layer.kernel_size
-                co, ho, wo = op.out_shape
+                co, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape
                 tot += 2 * ho * wo * co * op.xs[0] * kh * kw
         return tot
 
@@ -223,8 +224,21 @@ def toposort(outputs):
     return order
 
 
-def build_plan(inputs, outputs):
-    """inputs: [KTensor] (exactly one), outputs: [KTensor].  Returns a Plan."""
+def _supports_out_pool(op):
+    try:
+        from . import ops
+        lay = op.layer
+        cd = ops.make_conv(lay.filters, lay.kernel_size[0], lay.kernel_size[1], lay.dilation_rate, ops.make_pad(*op.halo),
+                           op.act, op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode)
+        return ops.supports_out_pool(op.xs, cd)
+    except (ImportError, OSError, AttributeError):
+        return False
+
+
+def build_plan(inputs, outputs, inference=False):
+    """inputs: [KTensor] (exactly one), outputs: [KTensor].  Returns a Plan.  inference=True additionally moves a
+    MaxPooling2D(2) that is the only consumer of a convolution into that convolution's epilogue (the pre-pooling tensor
+    is never written; the training plan keeps it because the backward pass needs it)."""
     if len(inputs) != 1:
         raise NotImplementedError('exactly one model input is supported')
     plan = Plan()
@@ -255,8 +269,14 @@ def build_plan(inputs, outputs):
     plan._in_store = store_of(x_in.shape)
     views = {}
 
+    producer = {}                      # scratch buffer -> the conv op that wrote all of it
+
     def emit(op):
         plan.ops.append(op)
+        if op.kind == 'conv' and op.dst >= 0 and op.out_c_off == 0 and op.out_c_total == op.layer.filters:
+            producer[op.dst] = op
+        elif op.dst in producer:
+            del producer[op.dst]
         if op.kind == 'conv' and op.layer not in plan.conv_layers:
             plan.conv_layers.append(op.layer)
         return op
@@ -407,7 +427,18 @@ def build_plan(inputs, outputs):
                 raise NotImplementedError('%s on a reshaped tensor' % lay.name)
             if not v.plain:
                 v = materialize(v)
-            views[t.uid] = v.copy(src_mode=SRC_MAXPOOL2 if isinstance(lay, L.MaxPooling2D) else SRC_UPSAMPLE2)
+            prod = producer.get(v.buf) if (inference and isinstance(lay, L.MaxPooling2D) and v.full and not outs) else None
+            if (prod is not None and consumers[t.inputs[0].uid] == 1 and not isinstance(prod.layer, L._ConvPart)
+                    and not prod.out_pool and _supports_out_pool(prod)):
+                # the pooling runs in the producing convolution's epilogue: its buffer now holds the pooled tensor
+                prod.out_pool = True
+                c, h2, w2 = v.c, v.h // 2, v.w // 2
+                prod.conv_out_shape = prod.out_shape        # what the convolution computes (FLOP accounting)
+                prod.out_shape = (c, h2, w2)                # what it stores
+                plan.buffers[v.buf] = (c, h2, w2)
+                views[t.uid] = View(v.buf, 0, c, c, h2, w2)
+            else:
+                views[t.uid] = v.copy(src_mode=SRC_MAXPOOL2 if isinstance(lay, L.MaxPooling2D) else SRC_UPSAMPLE2)
         elif isinstance(lay, L.ChannelSlice):
             v = ins[0]
             if v.shape is not None:

@@ -69,6 +69,8 @@ typedef struct {
   int in_c_off, in_c_total;       /* read channels [off, off+xs.c) of a buffer that has in_c_total channels (slice_layer) */
   int out_c_off, out_c_total;     /* write channels [off, off+cout) of a buffer with out_c_total channels (concatenate)   */
   int src_mode;                   /* DLWP_SRC_*: xs describes the STORED tensor; the conv sees it transformed */
+  int out_pool;                   /* 1: the epilogue also applies MaxPooling2D(2) -- y is (n, cout, ho/2, wo/2) (forward /
+                                   * inference only; ask dlwp_conv2d_supports_out_pool first)                          */
 } dlwp_conv2d;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
@@ -113,6 +115,9 @@ int dlwp_conv2d_set_winograd(int enable);   /* 3x3 layers with cin % 8 == 0, cou
  * the pooled tensor materialised by dlwp_maxpool2_fwd (the Winograd family has no pooled loader) than with the pooling
  * fused into the direct kernel's loader; 0 otherwise. */
 int dlwp_conv2d_prefers_unfused_pool(int cin, int cout, int kh, int kw, int dil_h, int dil_w);
+/* Planner hint (host logic): 1 when a compiled kernel can apply a following MaxPooling2D(2) in the epilogue of this
+ * convolution (cd->out_pool = 1): the pre-pooling tensor is then never written. */
+int dlwp_conv2d_supports_out_pool(dlwp_shape4 xs, const dlwp_conv2d* cd);
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 
 /* ---- backward of the fused Conv2D: the two halves of the Keras train step behind DLWPNeuralNet.fit / fit_generator

@@ -29,7 +29,7 @@ def test_struct_layouts_match_the_header():
     # sizes implied by include/dlwp_hip.h (all-int structs, no padding)
     assert ctypes.sizeof(_lib.Shape4) == 16
     assert ctypes.sizeof(_lib.Pad2d) == 24
-    assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 6 * 4
+    assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 7 * 4
     assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24 + 4 * 4   # + aux[4]
 
 

@@ -360,3 +360,49 @@ def test_maxpool2_bfloat16_is_exact(ops):
         got = ops.maxpool2(dev(x).to(torch.bfloat16))
         assert got.dtype == torch.bfloat16
         assert np.array_equal(got.to(torch.float32).cpu().numpy(), np_ref.maxpool2(x))
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# MaxPooling2D(2) in the producing convolution's epilogue (inference plans)
+# ----------------------------------------------------------------------------------------------------------------- #
+
+@pytest.mark.parametrize('case', [
+    # (n, cin, h, w, cout, k, dil, act)
+    (2, 4, 16, 40, 32, 3, 2, 'tanh'),            # direct MFMA, the first U-Net layer (8x32 tiles: a wave = two rows)
+    (2, 4, 19, 37, 20, 3, 2, 'tanh'),            # ragged: odd output size (floor), partial channel fragment
+    (2, 32, 16, 40, 64, 3, 1, 'tanh'),           # Winograd: the lane's 2x2 tile is the pooling window
+    (3, 24, 13, 27, 32, 3, 1, 'relu'),           # Winograd, odd sizes
+    (2, 16, 12, 20, 32, 3, 1, 'linear'),
+])
+@pytest.mark.parametrize('out16', [False, True])
+def test_conv2d_with_pooling_epilogue(ops, case, out16):
+    n, cin, h, w, cout, k, dil, act = case
+    rng = np.random.default_rng(sum(case[:7]))
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    p = dil * (k - 1) // 2
+    pads = (p, p, p, p)
+    want = np_ref.maxpool2(_conv_ref(x, wt, b, dil, pads, 0, 1, act, 0))
+    actc = {'tanh': ops.ACT_TANH, 'relu': ops.ACT_RELU, 'linear': ops.ACT_LINEAR}[act]
+    cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, 0, 1), actc, out_pool=True)
+    assert ops.supports_out_pool((cin, h, w), ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, 0, 1), actc))
+    ys = ops.conv_out_shape(ops.Shape4(n, cin, h, w), cd)
+    assert (ys.h, ys.w) == (h // 2, w // 2)
+    out = torch.full(want.shape, float('nan'), dtype=torch.bfloat16 if out16 else torch.float32, device='cuda')
+    ops.conv2d(dev(x), dev(wt), dev(b), cd, out=out)
+    got = out.to(torch.float32).cpu().numpy()
+    if out16:
+        assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 1e-6)
+    else:
+        _check_conv(ops, got, want, 'pooled epilogue')
+
+
+def test_pooling_epilogue_is_refused_where_no_kernel_has_one(ops):
+    cd = ops.make_conv(4, 7, 7, 1, ops.make_pad(3, 3, 3, 3, 0, 1), ops.ACT_LINEAR)       # 7x7: no MFMA instance at all
+    assert not ops.supports_out_pool((8, 16, 40), cd)
+    cd.out_pool = 1
+    x = torch.zeros((1, 8, 16, 40), device='cuda')
+    from dlwp_amd._lib import DlwpError
+    with pytest.raises(DlwpError, match="pooling epilogue"):
+        ops.conv2d(x, torch.zeros((7, 7, 8, 4), device='cuda'), None, cd)

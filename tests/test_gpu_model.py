@@ -636,7 +636,7 @@ def test_bfloat16_activation_storage_matches_the_rounding_oracle():
     x = rng.standard_normal((5,) + cs).astype(np.float32)
     y32 = d.predict(x)
     d.model.set_activation_dtype('bfloat16')
-    assert [b.dtype for b in d.model.executor.scratch(5)] == [torch.bfloat16] * len(d.model.plan.buffers)
+    assert [b.dtype for b in d.model.executor.scratch(5)] == [torch.bfloat16] * len(d.model.infer_plan.buffers)
     y16 = d.predict(x)
     want = np_ref.run_layers(layers, x, weights, bf16_activations=True)
     assert y16.dtype == np.float32 and y16.shape == y32.shape

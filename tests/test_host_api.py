@@ -468,3 +468,18 @@ def test_recurrent_model_file_round_trip(tmp_path):
     lstm = [lay for lay in d2.model.layers if isinstance(lay, L.ConvLSTM2D)][0]
     assert lstm.kernel_regularizer.l2 == 1e-4 and lstm.return_sequences and lstm.dilation_rate == (2, 2)
     assert all(np.array_equal(a, b) for a, b in zip(d.model.get_weights(), d2.model.get_weights()))
+
+
+def test_inference_plan_moves_the_pooling_into_the_producers():
+    """predict / predict_timeseries run `model.infer_plan`: a MaxPooling2D(2) that is the only consumer of a convolution is
+    applied in that convolution's epilogue, so the reference's 22 layers are 6 launches again and the pre-pooling tensors
+    are never written; the training plan keeps them (the backward pass needs them)."""
+    d = _dlwp(time_dim=2)
+    d.build_model(unet_layers((4, 88, 180)), loss='mse', optimizer='adam', gpus=1)
+    ip = d.model.infer_plan
+    assert [op.kind for op in ip.ops] == ['conv'] * 6
+    assert [op.out_pool for op in ip.ops] == [True, True, False, False, False, False]
+    assert ip.buffers[0] == (32, 44, 90) and ip.buffers[1] == (64, 22, 45)
+    assert ip.conv_flops_per_sample() == d.model.plan.conv_flops_per_sample() == 1597685760
+    assert not any(op.out_pool for op in d.model.plan.ops) and len(d.model.plan.ops) == 8
+    assert d.model.executor.plan is ip and d.model.train_executor.plan is d.model.plan
