@@ -48,7 +48,7 @@ def measured_traffic(cfg_tuple, members):
     import glob
     ks, dil, th, tw, waves, fa, bnf, ck, pool = cfg_tuple[:9]
     if fa == 0:
-        key = 'WinoCfg<%d, %d, %d, %d, %d, %d>' % (dil, th, tw, waves, bnf, ck)
+        key = 'WinoCfg<%d, %d, %d, %d, %d, %d' % (dil, th, tw, waves, bnf, ck)      # (+ the input-storage flag)
     elif bnf < 0:
         key = 'PackCfg<%d, %d, %d, %d, %d, %d, %d, %d>' % (ks, dil, th, tw, waves, fa, ck, -bnf)
     else:
