@@ -674,3 +674,26 @@ def test_bfloat16_storage_with_the_recurrent_front_end():
     got = d.predict(x)
     want = np_ref.run_layers(layers, x, weights, bf16_activations=True)
     assert _rel(got, want) < 4e-3
+
+
+def test_recurrent_reference_style_example_runs_end_to_end():
+    """examples/train_recurrent_and_validate.py: the reference's default flow (ConvLSTM2D front end + l2, SeriesDataGenerator
+    with insolation, latitude-weighted anomaly-correlation loss, fit_generator, TimeSeriesEstimator) through the compat shim."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples',
+                        'train_recurrent_and_validate.py')
+    spec = importlib.util.spec_from_file_location('train_recurrent_and_validate', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = ['x', '--grid', '16x24', '--times', '64', '--epochs', '2', '--batch-size', '8', '--forecast-steps', '4']
+    try:
+        hist, series = mod.main()
+    finally:
+        sys.argv = argv
+    assert len(hist['loss']) == 2 and np.isfinite(hist['loss']).all() and 'val_loss' in hist
+    assert series.dims == ('f_hour', 'time', 'variable', 'level', 'lat', 'lon')
+    assert series.shape == (4, 13, 2, 1, 16, 24)
+    assert np.isfinite(series.values[:2]).all()                        # later steps run out of data for the last samples
