@@ -232,26 +232,39 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
   }
 }
 
-// out[i] = sum_s slabs[s][i]  (fixed order: 8 interleaved partial sums over s, combined in a fixed tree), optionally
-// out += (accumulate).  8 independent loads in flight per thread.
+// out[i] = sum_s slabs[s][i], optionally out += (accumulate).  Weight tensors are small (<= 74 k elements for the U-Net)
+// while S is in the hundreds, so the work is spread over slab GROUPS as well as elements: a block = 64 vector elements x
+// 4 slab groups; each thread sums its group's slabs (s = g, g+4, ...) with 8 independent loads in flight, the 4 group
+// sums are combined through LDS in a fixed order -> deterministic, atomic-free, 4x the blocks of a one-thread-per-
+// element reduction.
 template <int VEC>
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            long long n, int S, int accumulate) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  __shared__ vec_t red[4][64];
   const long long nv = n / VEC;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < nv; base += (long long)gridDim.x * 64) {
+    const long long i = base + e;
     vec_t part[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) part[j] = (vec_t)(0.f);
-    int k = 0;
-    for (; k + 8 <= S; k += 8) {
+    if (i < nv) {
+      int k = g;
+      for (; k + 28 < S; k += 32) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) part[j] += *(const vec_t*)(slabs + (long long)(k + j) * n + i * VEC);
+        for (int j = 0; j < 8; ++j) part[j] += *(const vec_t*)(slabs + (long long)(k + 4 * j) * n + i * VEC);
+      }
+      for (int j = 0; k < S; k += 4, ++j) part[j] += *(const vec_t*)(slabs + (long long)k * n + i * VEC);
     }
-    for (int j = 0; k < S; ++k, ++j) part[j] += *(const vec_t*)(slabs + (long long)k * n + i * VEC);
-    vec_t s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-    if (accumulate) s += *(const vec_t*)(out + i * VEC);
-    *(vec_t*)(out + i * VEC) = s;
+    red[g][e] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+    __syncthreads();
+    if (g == 0 && i < nv) {
+      vec_t s = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+      if (accumulate) s += *(const vec_t*)(out + i * VEC);
+      *(vec_t*)(out + i * VEC) = s;
+    }
+    __syncthreads();
   }
 }
 
@@ -296,9 +309,9 @@ int dlwp_launch_flip_transpose(dlwp_handle_t h, const float* w, float* wt, int k
 int dlwp_launch_reduce_slabs(dlwp_handle_t h, const float* slabs, float* out, long long n, int S, int accumulate,
                              hipStream_t s) {
   if (n % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0)
-    reduce_slabs_kernel<4><<<grid_for(n / 4, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);
+    reduce_slabs_kernel<4><<<grid_for(n, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);   // 64 vec4 / block
   else
-    reduce_slabs_kernel<1><<<grid_for(n, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);
+    reduce_slabs_kernel<1><<<grid_for(n * 4, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);
   DLWP_LAUNCH_CHECK("reduce_slabs_kernel");
   return DLWP_OK;
 }
