@@ -406,3 +406,55 @@ def test_pooling_epilogue_is_refused_where_no_kernel_has_one(ops):
     from dlwp_amd._lib import DlwpError
     with pytest.raises(DlwpError, match="pooling epilogue"):
         ops.conv2d(x, torch.zeros((7, 7, 8, 4), device='cuda'), None, cd)
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# seeded random sweep over every kernel family / loader / epilogue combination
+# ----------------------------------------------------------------------------------------------------------------- #
+
+def test_conv2d_random_shapes_against_oracle(ops):
+    """60 seeded random layer geometries (odd sizes, ragged channels, both dilations, all loaders, both halo modes,
+    pooling epilogue where a kernel has one, mixed bf16 / fp32 storage) against the float64 oracle."""
+    rng = np.random.default_rng(20240607)
+    n_pool = n_wino = 0
+    for case in range(60):
+        k = int(rng.choice([3, 3, 3, 5]))
+        dil = int(rng.choice([1, 2])) if k == 3 else 1
+        cin = int(rng.choice([1, 3, 4, 8, 16, 20, 24, 32, 40]))
+        cout = int(rng.choice([2, 4, 12, 32, 36, 64, 96]))
+        src = int(rng.choice([0, 0, 1, 2]))
+        h, w = int(rng.integers(6, 30)), int(rng.integers(8, 50))
+        if src == 2:
+            h, w = h + 6, w + 8
+        n = int(rng.integers(1, 4))
+        mode_h, mode_w = int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2]))
+        act = str(rng.choice(['tanh', 'linear', 'relu']))
+        p = dil * (k - 1) // 2
+        pads = (p, p, p, p)
+        hh, ww = (h * 2, w * 2) if src == 1 else ((h // 2, w // 2) if src == 2 else (h, w))
+        if (mode_h == 1 and p > hh) or (mode_w == 1 and p > ww):
+            continue
+        x = np_ref.round_bf16(rng.standard_normal((n, cin, h, w))).astype(np.float32)
+        wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
+        b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        actc = {'tanh': ops.ACT_TANH, 'relu': ops.ACT_RELU, 'linear': ops.ACT_LINEAR}[act]
+        cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, mode_h, mode_w), actc, src_mode=src)
+        want = _conv_ref(x, wt, b, dil, pads, mode_h, mode_w, act, src)
+        pool = bool(rng.integers(0, 2)) and ops.supports_out_pool((cin, h, w), cd) and min(want.shape[2:]) >= 2
+        if pool:
+            cd.out_pool = 1
+            want = np_ref.maxpool2(want)
+            n_pool += 1
+        in16, out16 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        xd = dev(x).to(torch.bfloat16) if in16 else dev(x)
+        out = torch.full(want.shape, float('nan'), dtype=torch.bfloat16 if out16 else torch.float32, device='cuda')
+        ops.conv2d(xd, dev(wt), dev(b), cd, out=out)
+        got = out.to(torch.float32).cpu().numpy()
+        what = 'case %d: n%d %d->%d k%d d%d src%d %dx%d modes %d/%d %s pool%d io %d/%d' % (
+            case, n, cin, cout, k, dil, src, h, w, mode_h, mode_w, act, pool, in16, out16)
+        if out16:
+            assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 2e-6), what
+        else:
+            _check_conv(ops, got, want, what)
+        n_wino += int(k == 3 and cin % 8 == 0 and cout % 32 == 0 and src != 2)
+    assert n_pool >= 3 and n_wino >= 5          # the sweep really reaches the pooled epilogues and the Winograd family
