@@ -13,6 +13,9 @@
  *     stated; the library never allocates, frees or retains them (rollout objects excepted: buffers captured in a
  *     rollout graph must outlive it).
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it.  No host synchronisation inside.
+ *     The Winograd convolutions keep their transformed filters in ONE scratch buffer of the handle (32 MB, allocated at the
+ *     first use): launches that share a handle must be ordered on one stream at a time (use one handle per stream
+ *     otherwise).  A rollout graph owns its own copy.
  *   - dtype: the STORAGE type of activation tensors.  DLWP_F32 everywhere; the forward convolutions and
  *     dlwp_maxpool2_fwd also take DLWP_BF16 and, for the convolutions, DLWP_DTYPE_IO(in, out) with different input and
  *     output storage (config 4: bf16 activations between the layers, fp32 state at the model boundary).  Weights, biases
