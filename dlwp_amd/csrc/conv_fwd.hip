@@ -50,7 +50,8 @@ bool winograd_enabled() {
 constexpr size_t WINO_SCRATCH_FLOATS = 8u << 20;  // 32 MB: Cin*Cout <= 512K
 bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
   return winograd_enabled() && cd->kh == 3 && cd->kw == 3 && cd->dil_h == cd->dil_w && a.Cin % 8 == 0 &&
-         a.Cout % 32 == 0 && cd->src_mode != DLWP_SRC_MAXPOOL2 && (long long)a.Hs * a.Ws < (1ll << 28) &&
+         a.Cout % 32 == 0 && cd->src_mode != DLWP_SRC_MAXPOOL2 &&
+         (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&   // channel offsets inside a sample: 32-bit byte offsets
          (size_t)a.Cin * a.Cout * 16 <= WINO_SCRATCH_FLOATS;
 }
 

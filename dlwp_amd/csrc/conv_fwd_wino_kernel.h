@@ -147,15 +147,21 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a
 
   float xr[C::CK][C::NPOS];
   f32x4 ur[C::NUI][2];  // two xy quads at a time: (0,1) loaded a chunk ahead, (2,3) half a chunk ahead
-  // element i of the chunk starting at channel c0 (uniform; clamped to the last chunk): one buffer descriptor per plane
+  // element i of the chunk starting at channel c0 (uniform; clamped to the last chunk).  ONE buffer descriptor for the
+  // sample's channel window (num_records = Cin planes); the channel is selected by the SCALAR offset, so a load costs one
+  // s_add instead of ~10 scalar instructions of per-plane descriptor arithmetic -- the wave's own issue slots are what
+  // this loop runs out of.  The zero halo's lane offset (0x7ffffff0) is beyond num_records whatever the channel, and a
+  // valid lane offset + channel offset stays inside it, so the result does not depend on whether the hardware's range
+  // check includes the scalar offset.
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)a.Cin * plane_bytes, 0x00020000);
   auto load_x = [&](int c0, int i) {
     const int ci = i / C::NPOS, q = i - ci * C::NPOS;
-    const char* xp = xn + (long long)(min(c0, last_c0) + ci) * plane * ESZ;
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, plane_bytes, 0x00020000);
+    const unsigned soff = (unsigned)(min(c0, last_c0) + ci) * plane_bytes;
     if constexpr (C::IN16)  // 16 raw bits (0 out of range), widened when they are written to LDS
-      xr[ci][q] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, goff[q], 0, 0));
+      xr[ci][q] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0));
     else
-      xr[ci][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, goff[q], 0, 0));
+      xr[ci][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0));
   };
   auto load_u = [&](int c0, int k, int r) {
     const int soff = (min(c0, last_c0) * 4 + r) * a.Cout * 16;
