@@ -64,11 +64,20 @@ struct ConvCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
 
-// tanh as the rational 13/6 minimax approximation Eigen (and therefore TensorFlow's CPU and GPU kernels, i.e. what the
-// reference's Keras Conv2D(activation='tanh') actually evaluates) uses: clamp to +-7.905, odd numerator / even
-// denominator in x^2.  Max error 4e-7 absolute (6.6 ulp next to saturation), 2.4e-7 relative for small |x|; ~17 VALU ops
-// instead of the ~50 of the libm tanhf.
+// tanh(x) = sign(x) (1 - t) / (1 + t),  t = e^{-2|x|} = exp2(-2 log2(e) |x|): two transcendental instructions (v_exp_f32,
+// v_rcp_f32) + 4 vector ops.  The epilogues are vector-bound (the fp32 MFMA shares the SIMD's lanes with them), and tanh
+// on every output was their largest item; the rational 13/6 approximation Eigen / TensorFlow evaluate (what the
+// reference's Keras Conv2D(activation='tanh') computes: 17 vector ops, max abs error 3.0e-7 measured on gfx950) is kept
+// below as dlwp_tanh_rational.  Measured over [-12, 12]: max abs error 1.3e-7; the subtraction 1 - t loses RELATIVE
+// accuracy for tiny arguments (2.4e-4 at |x| = 2.4e-4), below that tanh(x) = x to 2e-8 relative and x is returned.
 __device__ __forceinline__ float dlwp_tanh(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * ax);
+  const float r = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
+  return ax < 2.44140625e-4f ? x : copysignf(r, x);  // NaN: the compare is false and r is NaN
+}
+
+__device__ __forceinline__ float dlwp_tanh_rational(float x) {
   const float xc = fminf(fmaxf(x, -7.90531110763549805f), 7.90531110763549805f);
   const float x2 = xc * xc;
   float p = fmaf(x2, -2.76076847742355e-16f, 2.00018790482477e-13f);
@@ -82,7 +91,7 @@ __device__ __forceinline__ float dlwp_tanh(float x) {
   q = fmaf(x2, q, 2.26843463243900e-03f);
   q = fmaf(x2, q, 4.89352518554385e-03f);
   const float r = p * __builtin_amdgcn_rcpf(q);
-  return (x != x) ? x : r;  // the clamp would swallow a NaN; a select, not a branch (this sits in every conv epilogue)
+  return (x != x) ? x : r;
 }
 
 // activation with a compile-time kind: the epilogues dispatch ONCE on the runtime value (act_dispatch) instead of
