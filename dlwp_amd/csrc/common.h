@@ -62,10 +62,11 @@ __host__ __device__ static inline int dlwp_map_coord(int p, int n, int mode) {
 }
 
 // internal launchers shared between the public entry points and the rollout graph builder
-// u_pre: filters already transformed by dlwp_wino_transform for this (w, cd) -- the rollout graph transforms once per
+// u_pre: weights already prepared by dlwp_conv2d_prep for this (w, xs, cd) -- the rollout graph transforms once per
 // launch instead of once per forward; NULL = transform into the handle's scratch right before the multiply
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre = nullptr);
-// does this convolution run on the Winograd family (=> it can take pre-transformed filters of cin*cout*16 floats)?
-bool dlwp_conv2d_is_winograd(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd);
-int dlwp_wino_transform(const void* w, float* u, int cin, int cout, hipStream_t s);
+// prepared weights of the Winograd / packed-N families: floats needed for this layer (0 = the kernel reads HWIO), and
+// the kernel that builds them
+size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd);
+int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, hipStream_t s);

@@ -83,6 +83,30 @@ __global__ __launch_bounds__(256) void wino_filter_transform_f32(const float* __
 
 
 
+// Expanded weights of a packed-N instance (conv_fwd_packn_kernel.h): out[chunk][WCH], element r < TAPS'*CK*16 of a chunk
+// is W'[(u,t,ci)][(co,s)] = w[u, (t-s)/d, ci, co] where that tap exists (and ci < Cin, co < Cout), else 0.
+__global__ __launch_bounds__(256) void packn_expand_weights_f32(const float* __restrict__ w, float* __restrict__ out,
+                                                                int Cin, int Cout, int ks, int dil, int S, int ck, int wch,
+                                                                int n_chunks) {
+  const int kwe = (ks - 1) * dil + S;
+  const int wfl = ks * kwe * ck * 16;
+  const long long total = (long long)n_chunks * wch;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int chunk = (int)(e / wch), r = (int)(e - (long long)chunk * wch);
+    float v = 0.f;
+    if (r < wfl) {
+      const int j = r & 15, row = r >> 4;
+      const int tap = row / ck, ci = row - tap * ck;
+      const int u = tap / kwe, t = tap - u * kwe;
+      const int co = j / S, s = j - co * S;
+      const int dv = t - s, vv = dv / dil, c = chunk * ck + ci;
+      if (dv >= 0 && dv - vv * dil == 0 && vv < ks && co < Cout && c < Cin)
+        v = w[((long long)(u * ks + vv) * Cin + c) * Cout + co];
+    }
+    out[e] = v;
+  }
+}
+
 int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void* y, dlwp_shape4 xs,
              const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
   DLWP_CHECK_ARG(h && cd && (xs.n == 0 || (x && w && y)), "%s: null handle or pointer", fn);
@@ -255,18 +279,46 @@ int launch_direct(dlwp_handle_t h, ConvArgs& a, const dlwp_conv2d* cd, hipStream
 
 }  // namespace
 
-bool dlwp_conv2d_is_winograd(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
+// Two kernel families read PREPARED weights instead of the HWIO tensor: Winograd (U = G g G^T, Cin*Cout*16 floats) and
+// packed-N (the expanded, zero-padded [chunk][WCH] layout of the chosen instance).  dlwp_conv2d_prep_floats says how many
+// floats the layer needs (0: none), dlwp_conv2d_prep builds them; dlwp_launch_conv2d does both into the handle's scratch
+// unless the caller (the rollout graph: once per launch, not once per forward) passes them in.
+static const ConvKernelEntry* entry_for(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
   dlwp_shape4 ys;
-  if (!h || !cd || xs.n <= 0 || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return false;
+  if (!h || !cd || xs.n <= 0 || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return nullptr;
   ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys);
   const int ci = choose_config(a, cd, h->cu_count);
-  return ci >= 0 && registry().entries[ci].pack < 0;
+  return ci >= 0 ? &registry().entries[ci] : nullptr;
 }
 
-int dlwp_wino_transform(const void* w, float* u, int cin, int cout, hipStream_t s) {
-  wino_filter_transform_f32<<<dlwp_ceil_div((long long)cin * cout, 256), 256, 0, s>>>((const float*)w, u, cin, cout);
-  DLWP_LAUNCH_CHECK("wino_filter_transform_f32");
+static size_t prep_floats_of(const ConvKernelEntry& e, int cin, int cout) {
+  if (e.pack < 0) return (size_t)cin * cout * 16;
+  if (e.pack > 0) return (size_t)dlwp_ceil_div(cin, e.ck) * e.prep_chunk_floats;
+  return 0;
+}
+
+static int prep_with(const ConvKernelEntry& e, const void* w, float* dst, int cin, int cout, hipStream_t s) {
+  if (e.pack < 0) {
+    wino_filter_transform_f32<<<dlwp_ceil_div((long long)cin * cout, 256), 256, 0, s>>>((const float*)w, dst, cin, cout);
+    DLWP_LAUNCH_CHECK("wino_filter_transform_f32");
+  } else if (e.pack > 0) {
+    const int n_chunks = dlwp_ceil_div(cin, e.ck);
+    const long long total = (long long)n_chunks * e.prep_chunk_floats;
+    packn_expand_weights_f32<<<dlwp_ceil_div(total, 256), 256, 0, s>>>((const float*)w, dst, cin, cout, e.ks, e.dil, e.pack,
+                                                                       e.ck, e.prep_chunk_floats, n_chunks);
+    DLWP_LAUNCH_CHECK("packn_expand_weights_f32");
+  }
   return DLWP_OK;
+}
+
+size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
+  const ConvKernelEntry* e = entry_for(h, xs, cd);
+  return e ? prep_floats_of(*e, xs.c, cd->cout) : 0;
+}
+
+int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, hipStream_t s) {
+  const ConvKernelEntry* e = entry_for(h, xs, cd);
+  return e ? prep_with(*e, w, dst, xs.c, cd->cout, s) : DLWP_OK;
 }
 
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
@@ -297,13 +349,13 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   a.cout_tiles = e.pack > 0 ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
   const long long grid = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
   DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
-  if (e.pack < 0) {  // Winograd: transform the filters (into the handle's scratch unless the caller did), then multiply
+  if (e.pack != 0) {  // Winograd / packed-N: prepared weights (into the handle's scratch unless the caller built them)
     if (u_pre) {
       a.w = u_pre;
     } else {
-      float* u = dlwp_wino_scratch(h, (size_t)a.Cin * a.Cout * 16, s);
-      if (!u) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: no scratch for the transformed filters");
-      const int rc2 = dlwp_wino_transform(a.w, u, a.Cin, a.Cout, s);
+      float* u = dlwp_wino_scratch(h, prep_floats_of(e, a.Cin, a.Cout), s);
+      if (!u) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: no scratch for the prepared weights");
+      const int rc2 = prep_with(e, a.w, u, a.Cin, a.Cout, s);
       if (rc2 != DLWP_OK) return rc2;
       a.w = u;
     }

@@ -463,6 +463,7 @@ struct ConvKernelEntry {
   int ks, dil, th, tw, waves, fa, bnf, ck, lds_bytes, pool;
   int pack;  // 0 = plain kernel; S > 0 = packed-N kernel for cout <= 16/S (conv_fwd_packn_kernel.h), bnf unused
   int out_pool;  // 1 = the instance can apply MaxPooling2D(2) in its epilogue (dlwp_conv2d.out_pool)
+  int prep_chunk_floats;  // packed-N: floats per channel chunk of the pre-expanded weights (0: the kernel reads HWIO)
   void (*launch)(const ConvArgs&, int grid, hipStream_t s);
   int (*prepare)();
 };
@@ -484,7 +485,7 @@ static int conv_prepare() {
 #define CONV_ENTRY_P(KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL)                                                   \
   {                                                                                                                \
     KS, DIL, TH, TW, WAVES, FA, BNF, CK, ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>::LDS_BYTES, POOL, 0,   \
-        ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>::POOL_EPI ? 1 : 0,                                      \
+        ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>::POOL_EPI ? 1 : 0, 0,                                   \
         &conv_launch_thunk<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>>,                                    \
         &conv_prepare<ConvCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, POOL>>                                          \
   }

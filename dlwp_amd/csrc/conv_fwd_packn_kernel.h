@@ -30,12 +30,15 @@ struct PackCfg {
   static constexpr int PS = PS_RAW + (((16 - PS_RAW % 32) % 32) + 32) % 32;  // == 16 (mod 32)
   static constexpr int X_FLOATS = CK * PS;
   static constexpr int W_FLOATS = TAPS * CK * 16;
-  static constexpr int LDS_BYTES = (X_FLOATS + W_FLOATS + 4) * 4;
+  // the expanded weights of one channel chunk arrive pre-built (packn_expand_weights_f32) and padded to whole float4 per
+  // thread, so staging them is unconditional 16-byte loads and stores
+  static constexpr int NWV = (W_FLOATS / 4 + WAVES * 64 - 1) / (WAVES * 64);
+  static constexpr int WCH = NWV * 4 * WAVES * 64;
+  static constexpr int LDS_BYTES = (X_FLOATS + WCH + 4) * 4;
   static constexpr int TWS = TW / S;
   static constexpr int P = TH * TWS;  // super-pixels per tile
   static constexpr int MPAD = 16 * FA * WAVES;
   static constexpr int NPOS = (LR * LC + NT - 1) / NT;
-  static constexpr int NWS = (W_FLOATS + NT - 1) / NT;
   static_assert(TW % S == 0, "tile width must be a multiple of the shift count");
   static_assert(MPAD >= P, "tile super-pixels must fit the wave/fragment decomposition");
   static_assert(CK % 4 == 0 && LDS_BYTES <= 160 * 1024, "bad channel chunk / LDS size");
@@ -62,48 +65,38 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
   const int n = L / a.tiles_h;
   const int i0 = th * C::TH, j0 = tw * C::TW;
 
-  // ---- input loader bookkeeping (same scheme as the plain kernel; LDS columns de-interleaved by S)
-  int goff[C::NPOS], loff[C::NPOS];
-  bool gok[C::NPOS];
+  // ---- input loader bookkeeping (LDS columns de-interleaved by S).  Buffer loads: the lane offset of a zero-halo
+  //      position is out of range and reads 0, so the loop has no selects and no 64-bit address arithmetic (the fp32 MFMA
+  //      shares the SIMD's lanes with every vector instruction: staging VALU is matrix time lost).  The lanes past the
+  //      tile of the last pass repeat element 0 (same value written twice).
+  constexpr int ESZ_MAX = 4;
+  unsigned goff[C::NPOS];
+  int loff[C::NPOS];
+  const unsigned esz = a.in_bf16 ? 2u : 4u;
 #pragma unroll
   for (int q = 0; q < C::NPOS; ++q) {
-    const int s = tid + q * C::NT;
-    const bool in_tile = (q < C::NPOS - 1) || s < C::LR * C::LC;
+    int s = tid + q * C::NT;
+    if (q == C::NPOS - 1 && s >= C::LR * C::LC) s = 0;
     const int lr = s / C::LC, lc = s - lr * C::LC;
     const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
     const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
-    const bool ok = in_tile && rs >= 0 && cs >= 0;
-    int g = 0;
-    if (ok) {
-      if (a.src_mode == DLWP_SRC_UPSAMPLE2) g = (rs >> 1) * a.Ws + (cs >> 1);
-      else g = rs * a.Ws + cs;
-    }
-    goff[q] = g;
-    gok[q] = ok;
-    loff[q] = in_tile ? lr * C::LCS + (lc % C::S) * C::Q + lc / C::S : C::X_FLOATS + C::W_FLOATS;
+    const bool ok = rs >= 0 && cs >= 0;
+    const int g = (a.src_mode == DLWP_SRC_UPSAMPLE2) ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
+    goff[q] = ok ? (unsigned)g * esz : 0x7ffffff0u;
+    loff[q] = lr * C::LCS + (lc % C::S) * C::Q + lc / C::S;
   }
+  (void)ESZ_MAX;
   const long long plane = (long long)a.Hs * a.Ws;
-  const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
-  const bf16_t* xn16 = (const bf16_t*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;  // if a.in_bf16
-
-  // ---- weight-slot bookkeeping: scalar slots of the expanded [tap'=(u,t)][ci][j=(co,s)] chunk
-  int wsrc[C::NWS], wci[C::NWS];
-  bool wok[C::NWS];
-#pragma unroll
-  for (int k = 0; k < C::NWS; ++k) {
-    const int e = tid + k * C::NT;
-    const int j = e & 15;
-    const int row = e >> 4;  // tap'*CK + ci
-    const int tap = row / C::CK, ci = row - tap * C::CK;
-    const int u = tap / C::KWE, t = tap - u * C::KWE;
-    const int co = j / C::S, s = j - co * C::S;
-    const int dv = t - s;
-    const int v = dv / C::DIL;
-    const bool ok = e < C::W_FLOATS && dv >= 0 && dv - v * C::DIL == 0 && v < C::KS && co < a.Cout;
-    wok[k] = ok;
-    wci[k] = ci;
-    wsrc[k] = ok ? ((u * C::KS + v) * a.Cin) * a.Cout + co : 0;
-  }
+  const unsigned plane_bytes = (unsigned)plane * esz;
+  const char* xn = (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * esz;
+  // one descriptor for the sample's channel window, the channel is the scalar offset (channels past Cin are clamped: their
+  // expanded weights are zero)
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)a.Cin * plane_bytes, 0x00020000);
+  // a.w = the expanded weights [chunk][WCH] built by packn_expand_weights_f32 for THIS instance
+  const int n_chunks = (a.Cin + C::CK - 1) / C::CK;
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)n_chunks * C::WCH * 4u, 0x00020000);
 
   // ---- MFMA fragment bookkeeping: rows = super-pixels
   int abase[C::FA];
@@ -121,43 +114,32 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
   for (int i = 0; i < C::FA; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float xr[C::CK][C::NPOS];
-  float wr[C::NWS];
+  f32x4 wr[C::NWV];
   auto prefetch = [&](int c0) {
-    if (a.in_bf16) {  // raw 16 bits now, widened when the chunk is written to LDS
-#pragma unroll
-      for (int ci = 0; ci < C::CK; ++ci) {
-        const bf16_t* xp = xn16 + (long long)min(c0 + ci, a.Cin - 1) * plane;
-#pragma unroll
-        for (int q = 0; q < C::NPOS; ++q) xr[ci][q] = __builtin_bit_cast(float, (unsigned)xp[goff[q]]);
-      }
-    } else {
-#pragma unroll
-      for (int ci = 0; ci < C::CK; ++ci) {
-        const float* xp = xn + (long long)min(c0 + ci, a.Cin - 1) * plane;
-#pragma unroll
-        for (int q = 0; q < C::NPOS; ++q) xr[ci][q] = xp[goff[q]];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < C::NWS; ++k) wr[k] = a.w[wsrc[k] + (long long)min(c0 + wci[k], a.Cin - 1) * a.Cout];
-  };
-  auto commit = [&](int c0) {
 #pragma unroll
     for (int ci = 0; ci < C::CK; ++ci) {
-      const bool c_ok = c0 + ci < a.Cin;
+      const unsigned soff = (unsigned)min(c0 + ci, a.Cin - 1) * plane_bytes;
 #pragma unroll
       for (int q = 0; q < C::NPOS; ++q) {
-        const float raw = a.in_bf16 ? bf16_bits_to_f32(__builtin_bit_cast(unsigned, xr[ci][q])) : xr[ci][q];
-        const float v = (c_ok && gok[q]) ? raw : 0.f;
-        xs[((q == C::NPOS - 1 && loff[q] == C::X_FLOATS + C::W_FLOATS) ? 0 : ci * C::PS) + loff[q]] = v;
+        if (a.in_bf16)  // 16 raw bits now, widened when the chunk is written to LDS
+          xr[ci][q] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0));
+        else
+          xr[ci][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0));
       }
     }
+    const unsigned wsoff = (unsigned)(c0 / C::CK) * (C::WCH * 4u);
 #pragma unroll
-    for (int k = 0; k < C::NWS; ++k) {
-      const int e = tid + k * C::NT;
-      const float v = (wok[k] && c0 + wci[k] < a.Cin) ? wr[k] : 0.f;
-      if (k < C::NWS - 1 || e < C::W_FLOATS) ws[e] = v;
-    }
+    for (int k = 0; k < C::NWV; ++k)
+      wr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (unsigned)(tid + k * C::NT) * 16u, wsoff, 0));
+  };
+  auto commit = [&](int) {
+#pragma unroll
+    for (int ci = 0; ci < C::CK; ++ci)
+#pragma unroll
+      for (int q = 0; q < C::NPOS; ++q)
+        xs[ci * C::PS + loff[q]] = a.in_bf16 ? bf16_bits_to_f32(__builtin_bit_cast(unsigned, xr[ci][q])) : xr[ci][q];
+#pragma unroll
+    for (int k = 0; k < C::NWV; ++k) *(f32x4*)(ws + (tid + k * C::NT) * 4) = wr[k];
   };
 
   prefetch(0);
@@ -235,6 +217,7 @@ static int packn_prepare() {
 #define PACKN_ENTRY(KS, DIL, TH, TW, WAVES, FA, CK, S)                                                        \
   {                                                                                                            \
     KS, DIL, TH, TW, WAVES, FA, 0, CK, PackCfg<KS, DIL, TH, TW, WAVES, FA, CK, S>::LDS_BYTES, 0, S, 0,         \
+        PackCfg<KS, DIL, TH, TW, WAVES, FA, CK, S>::WCH,                                                       \
         &packn_launch_thunk<PackCfg<KS, DIL, TH, TW, WAVES, FA, CK, S>>,                                       \
         &packn_prepare<PackCfg<KS, DIL, TH, TW, WAVES, FA, CK, S>>                                             \
   }

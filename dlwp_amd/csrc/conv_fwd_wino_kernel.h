@@ -450,7 +450,7 @@ static int wino_prepare_both() {
 // registry entry: ks = 3, fa = 0, pack = -1 marks a Winograd instance (a.w = the transformed filter)
 #define WINO_ENTRY(DIL, TH, TW, WAVES, BNF, CK)                                                                         \
   {                                                                                                                      \
-    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1, (DIL) == 1 ? 1 : 0,   \
+    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1, (DIL) == 1 ? 1 : 0, 0, \
         &wino_launch_either<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>, WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>,           \
         &wino_prepare_both<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>, WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>             \
   }

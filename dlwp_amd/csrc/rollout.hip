@@ -80,16 +80,17 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
     return (char*)series + ((size_t)call * n_outputs + o) * slot_elems * esz;
   };
 
-  // Winograd layers: the weights do not change inside one graph launch, so their filter transforms run ONCE at the head
+  // Winograd / packed-N layers: the weights do not change inside one graph launch, so their preparation runs ONCE at the head
   // of the graph (into buffers the rollout owns) instead of once per forward; the handle's scratch stays the fallback
   (void)dlwp_wino_scratch(h, 1, nullptr);
   std::vector<long long> u_off(n_ops, -1);
   long long u_floats = 0;
   for (int i = 0; i < n_ops; ++i) {
     const dlwp_op& op = plan[i];
-    if (op.kind == DLWP_OP_CONV2D && dlwp_conv2d_is_winograd(h, op.xs, &op.conv)) {
+    const long long need = op.kind == DLWP_OP_CONV2D ? (long long)dlwp_conv2d_prep_floats(h, op.xs, &op.conv) : 0;
+    if (need > 0) {
       u_off[i] = u_floats;
-      u_floats += (long long)op.xs.c * op.conv.cout * 16;
+      u_floats += (need + 63) & ~63ll;   // 256-byte aligned
     }
   }
   float* wino_u = nullptr;
@@ -109,7 +110,7 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
   int rc = DLWP_OK;
   if (wino_u)
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
-      if (u_off[i] >= 0) rc = dlwp_wino_transform(buffers[plan[i].w], wino_u + u_off[i], plan[i].xs.c, plan[i].conv.cout, cap);
+      if (u_off[i] >= 0) rc = dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, cap);
   for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
       const dlwp_op& op = plan[i];
