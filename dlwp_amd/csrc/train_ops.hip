@@ -117,7 +117,10 @@ struct LossArgs {
   const float* row_w;     // (H) or null
   long long n;            // all elements
   int chw, H, W;
-  int kind, reg;          // reg: 0 none, 1 mse, 2 mae
+  int kind, reg;          // reg: 0 none, 1 mse, 2 mae, 3 'global' mean, 4 'spatial' means
+  int HW, planes;         // h*w, n*c
+  const float* plane;     // reg 4: per-plane sums {sum w*yp, sum w*yt} (workspace)
+  const float* extra;     // reg 3: {sum w*yp, sum w*yt} over everything (workspace)
 };
 
 __device__ __forceinline__ void loss_terms(const LossArgs& a, long long i, float& d, float& dw, float& P, float& T,
@@ -133,7 +136,7 @@ __device__ __forceinline__ void loss_terms(const LossArgs& a, long long i, float
 }
 
 __global__ __launch_bounds__(256) void loss_stats_partial_kernel(const LossArgs a, float* __restrict__ partial) {
-  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x) {
     float d, dw, P, T, w;
     loss_terms(a, i, d, dw, P, T, w);
@@ -144,35 +147,64 @@ __global__ __launch_bounds__(256) void loss_stats_partial_kernel(const LossArgs 
     s[4] += P * T;
     s[5] += P * P;
     s[6] += T * T;
+    s[7] += w * a.yp[i];
+    s[8] += w * a.yt[i];
   }
   float z = 0.f;
   block_sum2(s[0], s[1]);
   block_sum2(s[2], s[3]);
   block_sum2(s[4], s[5]);
-  block_sum2(s[6], z);
+  block_sum2(s[6], s[7]);
+  block_sum2(s[8], z);
   if (threadIdx.x == 0)
-    for (int k = 0; k < 7; ++k) partial[7 * blockIdx.x + k] = s[k];
+    for (int k = 0; k < 9; ++k) partial[9 * blockIdx.x + k] = s[k];
+}
+
+// regularize_mean = 'spatial': per (sample, channel) plane sums of the weighted prediction / target, one block per plane
+__global__ __launch_bounds__(256) void loss_plane_sums_kernel(const LossArgs a, float* __restrict__ plane) {
+  const long long base = (long long)blockIdx.x * a.HW;
+  float sp = 0.f, st = 0.f;
+  for (int j = threadIdx.x; j < a.HW; j += 256) {
+    const float w = a.row_w ? a.row_w[(j / a.W) % a.H] : 1.f;
+    sp += w * a.yp[base + j];
+    st += w * a.yt[base + j];
+  }
+  block_sum2(sp, st);
+  if (threadIdx.x == 0) {
+    plane[2 * blockIdx.x] = sp;
+    plane[2 * blockIdx.x + 1] = st;
+  }
 }
 
 __global__ __launch_bounds__(256) void loss_stats_final_kernel(const float* __restrict__ partial, int nblocks,
-                                                               long long n, int kind, int reg, float* __restrict__ stats) {
-  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                                               long long n, int kind, int reg, const float* __restrict__ plane,
+                                                               int planes, int hw, float* __restrict__ extra,
+                                                               float* __restrict__ stats) {
+  float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < nblocks; i += 256)
-    for (int k = 0; k < 7; ++k) s[k] += partial[7 * i + k];
-  float z = 0.f;
+    for (int k = 0; k < 9; ++k) s[k] += partial[9 * i + k];
+  float z = 0.f, sp_reg = 0.f;
+  if (reg == 4)  // 'spatial': mean over planes of |(mean_t - mean_p) / mean_t|   (the 1/hw factors cancel)
+    for (int i = threadIdx.x; i < planes; i += 256) sp_reg += fabsf((plane[2 * i + 1] - plane[2 * i]) / plane[2 * i + 1]);
   block_sum2(s[0], s[1]);
   block_sum2(s[2], s[3]);
   block_sum2(s[4], s[5]);
-  block_sum2(s[6], z);
+  block_sum2(s[6], s[7]);
+  block_sum2(s[8], sp_reg);
   if (threadIdx.x == 0) {
     const float inv_n = 1.0f / (float)n;
     const float mse_w = s[2] * inv_n, mae_w = s[3] * inv_n;
     float loss, regv = 0.f;
+    extra[0] = s[7];
+    extra[1] = s[8];
     if (kind == 0) {
       loss = mse_w;
     } else {
       const float acc = s[4] / sqrtf(s[5] * s[6]);   // the 1/n factors cancel
-      regv = reg == 1 ? mse_w : (reg == 2 ? mae_w : 0.f);
+      if (reg == 1) regv = mse_w;
+      else if (reg == 2) regv = mae_w;
+      else if (reg == 3) regv = fabsf((s[8] - s[7]) / s[8]);   // 'global': |(mean_t - mean_p) / mean_t|
+      else if (reg == 4) regv = sp_reg / (float)planes;
       loss = regv - acc;
     }
     stats[0] = loss;
@@ -201,6 +233,14 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const LossArgs a, const 
       g = -(T - ratio * P) * inv_norm;
       if (a.reg == 1) g += 2.f * dw * inv_n;
       else if (a.reg == 2) g += (dw > 0.f ? 1.f : (dw < 0.f ? -1.f : 0.f)) * inv_n;
+      else if (a.reg == 3) {  // d/dyp' |(St - Sp)/St| = -sign(q) / St
+        const float sp = a.extra[0], st = a.extra[1], q = (st - sp) / st;
+        g += (q > 0.f ? -1.f : (q < 0.f ? 1.f : 0.f)) / st;
+      } else if (a.reg == 4) {  // per plane: -sign(q_nc) / St_nc, averaged over the planes
+        const long long pl = i / a.HW;
+        const float sp = a.plane[2 * pl], st = a.plane[2 * pl + 1], q = (st - sp) / st;
+        g += (q > 0.f ? -1.f : (q < 0.f ? 1.f : 0.f)) / (st * (float)a.planes);
+      }
     }
     dy[i] = loss_weight * w * g;
   }
@@ -360,14 +400,17 @@ int dlwp_mse_mae(dlwp_handle_t h, const void* y_pred, const void* y_true, size_t
   return DLWP_OK;
 }
 
-size_t dlwp_loss_workspace(dlwp_handle_t h) { return h ? (size_t)h->cu_count * 8 * 7 * sizeof(float) : 0; }
+// partial sums (9 per block) + 2 global sums + 2 per (sample, channel) plane
+size_t dlwp_loss_workspace(dlwp_handle_t h, int n, int c) {
+  return h ? ((size_t)h->cu_count * 8 * 9 + 2 + 2 * (size_t)(n > 0 ? n : 0) * (size_t)(c > 0 ? c : 0)) * sizeof(float) : 0;
+}
 
 int dlwp_loss_custom(dlwp_handle_t h, const void* y_pred, const void* y_true, int n, int c, int hh, int ww,
                      const void* mean, const void* row_weights, int kind, int regularize, void* stats7, void* dy,
                      float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream) {
   DLWP_CHECK_ARG(h && y_pred && y_true && stats7 && ws, "dlwp_loss_custom: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n > 0 && c > 0 && hh > 0 && ww > 0, "dlwp_loss_custom: bad dtype / shape");
-  DLWP_CHECK_ARG((kind == 0 || kind == 1) && regularize >= 0 && regularize <= 2, "dlwp_loss_custom: bad kind / regularizer");
+  DLWP_CHECK_ARG((kind == 0 || kind == 1) && regularize >= 0 && regularize <= 4, "dlwp_loss_custom: bad kind / regularizer");
   LossArgs a;
   a.yp = (const float*)y_pred;
   a.yt = (const float*)y_true;
@@ -379,11 +422,20 @@ int dlwp_loss_custom(dlwp_handle_t h, const void* y_pred, const void* y_true, in
   a.W = ww;
   a.kind = kind;
   a.reg = regularize;
+  a.HW = hh * ww;
+  a.planes = n * c;
   const int grid = grid_for(a.n, h->cu_count);
-  DLWP_CHECK_ARG(ws_bytes >= (size_t)grid * 7 * sizeof(float), "dlwp_loss_custom: workspace too small");
+  DLWP_CHECK_ARG(ws_bytes >= dlwp_loss_workspace(h, n, c), "dlwp_loss_custom: workspace too small (%zu < %zu)", ws_bytes,
+                 dlwp_loss_workspace(h, n, c));
+  float* partial = (float*)ws;
+  float* extra = partial + (size_t)h->cu_count * 8 * 9;
+  float* plane = extra + 2;
+  a.extra = extra;
+  a.plane = plane;
   hipStream_t s = (hipStream_t)stream;
-  loss_stats_partial_kernel<<<grid, 256, 0, s>>>(a, (float*)ws);
-  loss_stats_final_kernel<<<1, 256, 0, s>>>((const float*)ws, grid, a.n, kind, regularize, (float*)stats7);
+  loss_stats_partial_kernel<<<grid, 256, 0, s>>>(a, partial);
+  if (regularize == 4) loss_plane_sums_kernel<<<a.planes, 256, 0, s>>>(a, plane);
+  loss_stats_final_kernel<<<1, 256, 0, s>>>(partial, grid, a.n, kind, regularize, plane, a.planes, a.HW, extra, (float*)stats7);
   if (dy) loss_grad_kernel<<<grid, 256, 0, s>>>(a, (const float*)stats7, (float*)dy, loss_weight);
   DLWP_LAUNCH_CHECK("loss_custom kernels");
   return DLWP_OK;

@@ -96,17 +96,14 @@ def latitude_weights(lats, weighting='cosine'):
 def anomaly_correlation_loss(mean=None, regularize_mean='mse', reverse=True):
     """Anomaly-correlation loss, `regularizer - ACC` (reference custom.py:1036-1088; the default loss of
     examples/train.py).  mean: climatology of shape (1,) + output shape, or None.  regularize_mean: None | 'mse' | 'mae'
-    ('global' / 'spatial' are not lowered to the device yet)."""
+    | 'global' | 'spatial'."""
     if mean is not None:
         assert len(mean.shape) > 1
         assert mean.shape[0] == 1
     if regularize_mean is not None:
         assert regularize_mean in ['global', 'spatial', 'mse', 'mae']
         reverse = True
-        if regularize_mean in ('global', 'spatial'):
-            raise NotImplementedError("regularize_mean=%r is not implemented on the HIP path ('mse', 'mae', None are)"
-                                      % regularize_mean)
-    reg = {None: 0, 'mse': 1, 'mae': 2}[regularize_mean]
+    reg = {None: 0, 'mse': 1, 'mae': 2, 'global': 3, 'spatial': 4}[regularize_mean]
     return LossSpec(1, reg, None if mean is None else np.asarray(mean)[0], None, 1.0 if reverse else -1.0, 'acc_loss')
 
 

@@ -343,7 +343,7 @@ def loss_custom(y_pred, y_true, stats7, dy=None, loss_weight=1.0, mean=None, row
     n, c, hh, ww = y_pred.shape
     d = _dev(y_pred)
     h = _lib.handle(d)
-    ws = workspace(y_pred.device, _lib.lib.dlwp_loss_workspace(h))
+    ws = workspace(y_pred.device, _lib.lib.dlwp_loss_workspace(h, n, c))
     _lib.check(_lib.lib.dlwp_loss_custom(h, _ptr(y_pred), _ptr(y_true), n, c, hh, ww, _ptr(mean), _ptr(row_weights),
                                          int(kind), int(regularize), _ptr(stats7), _ptr(dy), float(loss_weight), _ptr(ws),
                                          ws.numel(), _lib.F32, _stream(y_pred)))

@@ -155,10 +155,12 @@ int    dlwp_mse_mae(dlwp_handle_t, const void* y_pred, const void* y_true, size_
  *   kind 0: mean((w (yp-yt))^2)                           -- latitude_weighted_loss(mse) (DLWP/custom.py:956-991)
  *   kind 1: regularizer - ACC,  ACC = mean(PT)/sqrt(mean(P^2) mean(T^2)), P = w*yp - mean, T = w*yt - mean
  *           -- anomaly_correlation_loss(mean, regularize_mean, reverse=True) (custom.py:1036-1088), optionally wrapped
- *           in latitude_weighted_loss (examples/train.py:224-234).  regularize: 0 none, 1 'mse', 2 'mae'.
+ *           in latitude_weighted_loss (examples/train.py:224-234).  regularize: 0 none, 1 'mse', 2 'mae', 3 'global'
+ *           (|(mean(T') - mean(P'))/mean(T')| over everything), 4 'spatial' (the same per (sample, channel) plane, averaged),
+ *           P' = w*yp, T' = w*yt.
  *   y: (n, c, h, w);  mean: (c, h, w) or null;  row_weights: (h) or null.
  *   stats7 (device) <- {loss, mse, mae, S_pt, S_pp, S_tt, regularizer value};  dy (nullable) <- loss_weight * dL/dyp.   */
-size_t dlwp_loss_workspace(dlwp_handle_t);
+size_t dlwp_loss_workspace(dlwp_handle_t, int n, int c);
 int    dlwp_loss_custom(dlwp_handle_t, const void* y_pred, const void* y_true, int n, int c, int h, int w,
                         const void* mean, const void* row_weights, int kind, int regularize, void* stats7, void* dy,
                         float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream);

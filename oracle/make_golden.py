@@ -467,6 +467,13 @@ def main():
             fn = rc.anomaly_correlation_loss(climo if use_mean else None, regularize_mean=reg, reverse=True)
             v = fn(yt, yp)
             los['acc_%s_%d' % (reg, int(use_mean))] = np.asarray(np.mean(v), dtype=np.float64)
+    # mean-ratio regularisers ('global', 'spatial') divide by the mean of the truth: fields with a non-zero mean
+    ytp, ypp = (yt + 3.0).astype(np.float32), (yp + 3.1).astype(np.float32)
+    los['y_true_pos'], los['y_pred_pos'] = ytp, ypp
+    for reg in ('global', 'spatial'):
+        for use_mean in (False, True):
+            fn = rc.anomaly_correlation_loss(climo + 3.0 if use_mean else None, regularize_mean=reg, reverse=True)
+            los['accpos_%s_%d' % (reg, int(use_mean))] = np.asarray(np.mean(fn(ytp, ypp)), dtype=np.float64)
     lats = np.linspace(87.5, -87.5, 6).astype(np.float32)
     los['lats'] = lats
     for weighting in ('cosine', 'midlatitude'):

@@ -589,6 +589,9 @@ def anomaly_correlation_loss(y_true, y_pred, mean=None, regularize_mean='mse'):
         m = np.mean(np.abs(yp - yt))
     elif regularize_mean == 'global':
         m = np.abs((yt.mean() - yp.mean()) / yt.mean())
+    elif regularize_mean == 'spatial':
+        mt, mp = yt.mean(axis=(-2, -1)), yp.mean(axis=(-2, -1))
+        m = np.mean(np.abs((mt - mp) / mt))
     else:
         raise ValueError(regularize_mean)
     return float(m - a)

@@ -464,6 +464,44 @@ def test_custom_losses_match_reference_goldens_and_autograd(golden):
             p = torch.tensor(yp, dtype=torch.float64, requires_grad=True)
             torch_loss(spec, p).backward()
             assert np.abs(dy - p.grad.numpy()).max() <= 2e-5 * np.abs(p.grad.numpy()).max(), (reg, use_mean)
+    # 'global' / 'spatial' mean-ratio regularisers (custom.py:1070-1074) on fields with a non-zero mean, also under latitude
+    # weights
+    ytp, ypp = g['y_true_pos'], g['y_pred_pos']
+    yp_keep, yt_keep = (ypd, ytd), (yp, yt)
+    ypd, ytd = torch.from_numpy(ypp).cuda(), torch.from_numpy(ytp).cuda()
+    yp, yt = ypp, ytp
+
+    def torch_loss_ratio(spec, p):
+        t = torch.tensor(ytp, dtype=torch.float64)
+        w = torch.ones(1, dtype=torch.float64) if spec.row_weights is None else \
+            torch.tensor(spec.row_weights, dtype=torch.float64)[None, None, :, None]
+        m = torch.zeros(1, dtype=torch.float64) if spec.mean is None else torch.tensor(spec.mean, dtype=torch.float64)[None]
+        pw, tw = p * w, t * w
+        P, T = pw - m, tw - m
+        a = (P * T).mean() / torch.sqrt((P * P).mean() * (T * T).mean())
+        if spec.regularize == 3:
+            reg = ((tw.mean() - pw.mean()) / tw.mean()).abs()
+        else:
+            mt, mp = tw.mean(dim=(-2, -1)), pw.mean(dim=(-2, -1))
+            reg = ((mt - mp) / mt).abs().mean()
+        return spec.scale * (reg - a)
+    for reg in ('global', 'spatial'):
+        for use_mean in (False, True):
+            spec = custom.anomaly_correlation_loss((climo + 3.0) if use_mean else None, regularize_mean=reg)
+            val, dy, st = run(spec)
+            assert val == pytest.approx(float(g['accpos_%s_%d' % (reg, int(use_mean))]), rel=2e-5, abs=2e-6), (reg, use_mean)
+            p = torch.tensor(ypp, dtype=torch.float64, requires_grad=True)
+            torch_loss_ratio(spec, p).backward()
+            assert np.abs(dy - p.grad.numpy()).max() <= 2e-5 * np.abs(p.grad.numpy()).max(), (reg, use_mean)
+        spec = custom.latitude_weighted_loss(custom.anomaly_correlation_loss(climo + 3.0, regularize_mean=reg), lats,
+                                             (4, 6, 8), axis=-2, weighting='cosine')
+        val, dy, _ = run(spec)
+        p = torch.tensor(ypp, dtype=torch.float64, requires_grad=True)
+        ref = torch_loss_ratio(spec, p)
+        ref.backward()
+        assert val == pytest.approx(float(ref.detach()), rel=2e-5)
+        assert np.abs(dy - p.grad.numpy()).max() <= 2e-5 * np.abs(p.grad.numpy()).max()
+    (ypd, ytd), (yp, yt) = yp_keep, yt_keep
     for weighting in ('cosine', 'midlatitude'):
         spec = custom.latitude_weighted_loss(None, lats, (4, 6, 8), axis=-2, weighting=weighting)
         val, dy, _ = run(spec)

@@ -382,8 +382,10 @@ def test_save_and_load_model_round_trip(tmp_path):
     sp = d4.model.loss
     assert isinstance(sp, custom.LossSpec) and (sp.kind, sp.regularize, sp.scale) == (1, 1, 1.0)
     assert np.array_equal(sp.mean, climo[0]) and np.allclose(sp.row_weights, custom.latitude_weights(lats, 'midlatitude'))
-    with pytest.raises(NotImplementedError):
-        custom.anomaly_correlation_loss(None, regularize_mean='global')
+    assert custom.anomaly_correlation_loss(None, regularize_mean='global').regularize == 3
+    assert custom.anomaly_correlation_loss(None, regularize_mean='spatial').regularize == 4
+    with pytest.raises(AssertionError):
+        custom.anomaly_correlation_loss(None, regularize_mean='median')
     # functional graph with shared layers and skips
     x0, y = _skip_model((4, 8, 12))
     m = Model(inputs=x0, outputs=y)

@@ -162,6 +162,12 @@ def test_custom_losses_match_reference(golden):
             want = float(g['acc_%s_%d' % (reg, int(use_mean))])
             got = np_ref.anomaly_correlation_loss(yt, yp, climo if use_mean else None, reg)
             assert np.isclose(got, want, rtol=2e-5, atol=2e-6), (reg, use_mean, got, want)
+    # the mean-ratio regularisers on fields with a non-zero mean
+    for reg in ('global', 'spatial'):
+        for use_mean in (False, True):
+            want = float(g['accpos_%s_%d' % (reg, int(use_mean))])
+            got = np_ref.anomaly_correlation_loss(g['y_true_pos'], g['y_pred_pos'], (climo + 3.0) if use_mean else None, reg)
+            assert np.isclose(got, want, rtol=2e-5, atol=2e-6), (reg, use_mean, got, want)
     for weighting in ('cosine', 'midlatitude'):
         w = np_ref.latitude_weights(g['lats'], weighting)[None, None, :, None]
         got = np.mean((yt * w - yp * w) ** 2)
