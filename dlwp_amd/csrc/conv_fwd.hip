@@ -191,7 +191,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     const ConvKernelEntry& e = r.entries[g_forced_cfg];
     const bool pool = cd->src_mode == DLWP_SRC_MAXPOOL2;
     const bool pack_ok = e.pack <= 0 || (cd->cout <= 16 / e.pack);
-    if (e.pack < 0 && !winograd_wanted(a, cd)) return -1;  // Winograd instances: whole channel chunks only
+    if (e.pack < 0 && (!winograd_wanted(a, cd) || a.Cout % (16 * e.bnf) != 0)) return -1;  // whole channel chunks only
     if (cd->out_pool && !e.out_pool) return -1;
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? g_forced_cfg
@@ -213,6 +213,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if ((e.pool != 0) != (cd->src_mode == DLWP_SRC_MAXPOOL2)) continue;  // pooled loader <-> POOL instances only
     if (e.pack > 0 && cd->cout > 16 / e.pack) continue;                    // packed-N instances cover cout <= 16/S
     if ((e.pack < 0) != want_wino) continue;                               // kernel family fixed by the layer geometry
+    if (e.pack < 0 && a.Cout % (16 * e.bnf) != 0) continue;                // Winograd: whole output-channel tiles only
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     const double c = config_cost(e, a, cu_count);
     if (best < 0 || c < best_cost) {

@@ -61,18 +61,22 @@ struct WinoCfg {
   static constexpr int NXI = CK * NPOS;            // input elements per thread and chunk
   static constexpr int NUI = (CK * BN) / NT;       // (ci, co) filter items per thread
   static constexpr int NWI = 4 * NUI;              // float4 filter loads per thread and chunk
-  static constexpr int HL = 32;                    // MFMAs per channel group
+  static constexpr int HL = 16 * BNF;               // MFMAs per channel group
+  // BNF = 2: two waves per SIMD (256 VGPRs each).  BNF = 4 (64 output channels per block: the input tile staged and
+  // transformed once for twice the matrix work, 256 accumulator registers, ONE wave per SIMD) compiles but measured 1.56x
+  // SLOWER on the 128->64 layer (1.075 vs 0.689 ms): a single wave cannot cover its own waits; no instance is registered.
+  static constexpr int WAVES_PER_SIMD = BNF == 2 ? 2 : 1;
   static_assert(TH % (2 * DIL) == 0 && TW % (2 * DIL) == 0, "region must be whole 2x2 tiles on every parity class");
   static_assert(TPAD >= T, "tiles must fit the wave decomposition");
-  static_assert(CK == 8 && BNF == 2, "the pipeline is written for two channel groups of 4 and 32 output channels");
+  static_assert(CK == 8 && (BNF == 2 || BNF == 4), "the pipeline is written for two channel groups of 4 and 32 / 64 output channels");
   static_assert((CK * BN) % NT == 0 && NUI >= 1, "every thread owns NUI whole (ci, co) items");
   static_assert((TH * TW) % 4 == 0 && (BN * TH * TW / 4) % NT == 0, "output staging: whole float4 per thread");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
 
 template <class C>
-// __launch_bounds__(threads, waves per SIMD): 2 waves per SIMD = 256 VGPRs
-__global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_wino_f32(const ConvArgs a) {
+// __launch_bounds__(threads, waves per SIMD)
+__global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int US0 = 2 * C::X_FLOATS;
   const int tid = threadIdx.x;
