@@ -99,6 +99,8 @@ _sig('dlwp_conv2d_num_configs', [])
 _sig('dlwp_conv2d_config_info', [_i, _P(_i), _P(_i)])
 _sig('dlwp_conv2d_force_config', [_i])
 _sig('dlwp_conv2d_set_winograd', [_i])
+_sig('dlwp_conv2d_set_bf16_mfma', [_i])
+_sig('dlwp_conv2d_uses_bf16_weights', [Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_prefers_unfused_pool', [_i, _i, _i, _i, _i, _i])
 _sig('dlwp_conv2d_supports_out_pool', [Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])

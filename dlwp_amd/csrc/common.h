@@ -66,7 +66,8 @@ __host__ __device__ static inline int dlwp_map_coord(int p, int n, int mode) {
 // launch instead of once per forward; NULL = transform into the handle's scratch right before the multiply
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre = nullptr);
-// prepared weights of the Winograd / packed-N families: floats needed for this layer (0 = the kernel reads HWIO), and
+// prepared weights of the Winograd / packed-N / bf16-MFMA families: floats needed for this layer (0 = the kernel reads HWIO), and
 // the kernel that builds them
-size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd);
-int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, hipStream_t s);
+size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
+int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype,
+                     hipStream_t s);

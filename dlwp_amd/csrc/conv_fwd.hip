@@ -8,6 +8,7 @@
 const ConvKernelEntry* dlwp_conv_table_k3d1(int* n);
 const ConvKernelEntry* dlwp_conv_table_k3d2(int* n);
 const ConvKernelEntry* dlwp_conv_table_k5d1(int* n);
+const ConvKernelEntry* dlwp_conv_table_bf16(int* n);
 
 namespace {
 
@@ -21,6 +22,8 @@ struct Registry {
     t = dlwp_conv_table_k3d2(&n);
     entries.insert(entries.end(), t, t + n);
     t = dlwp_conv_table_k5d1(&n);
+    entries.insert(entries.end(), t, t + n);
+    t = dlwp_conv_table_bf16(&n);
     entries.insert(entries.end(), t, t + n);
     prepared.assign(entries.size(), 0);
   }
@@ -53,6 +56,60 @@ bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
          a.Cout % 32 == 0 && cd->src_mode != DLWP_SRC_MAXPOOL2 &&
          (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&   // channel offsets inside a sample: 32-bit byte offsets
          (size_t)a.Cin * a.Cout * 16 <= WINO_SCRATCH_FLOATS;
+}
+
+// ConvKernelEntry::pack: 0 plain, S > 0 packed-N, -1 Winograd, -2 bf16-MFMA
+inline bool is_wino(const ConvKernelEntry& e) { return e.pack == -1; }
+inline bool is_bf16(const ConvKernelEntry& e) { return e.pack == -2; }
+
+// bf16-MFMA family (conv_fwd_bf16_kernel.h): the input is stored as bf16; whole column pairs (even width, periodic or
+// zero column halo), no pooled loader / pooling epilogue, enough input channels to fill a K slice.  Like Winograd the
+// family follows from the layer (geometry + storage type) only.  DLWP_BF16_MFMA=0 / dlwp_conv2d_set_bf16_mfma(0): off.
+int g_bf16_mfma = -1;
+bool bf16_mfma_enabled() {
+  if (g_bf16_mfma < 0) {
+    const char* e = getenv("DLWP_BF16_MFMA");
+    g_bf16_mfma = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_bf16_mfma != 0;
+}
+size_t bf16_prep_floats(const ConvKernelEntry& e, int cin, int cout) {
+  return (size_t)dlwp_ceil_div(cout, 16 * e.bnf) * dlwp_ceil_div(cin, e.ck) * e.prep_chunk_floats;
+}
+bool bf16_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
+  return bf16_mfma_enabled() && a.in_bf16 && cd->kh == cd->kw && cd->dil_h == cd->dil_w && a.Cin >= 12 &&
+         cd->src_mode != DLWP_SRC_MAXPOOL2 && !cd->out_pool && (a.W & 1) == 0 && cd->halo.mode_w != DLWP_PAD_EDGE &&
+         (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29);
+}
+
+// Arranged weights of a bf16-MFMA instance (conv_fwd_bf16_kernel.h):
+// out[(ct, chunk)][WCH] (16-byte units): unit ((tap*NO + oct)*BN + col) holds the 8 bf16 weights of channels
+// chunk*CK + oct*8 .. +7, tap, output channel ct*BN + col; zero outside Cin / Cout.
+__global__ __launch_bounds__(256) void bf16_arrange_weights(const float* __restrict__ w, unsigned* __restrict__ out, int Cin,
+                                                            int Cout, int taps, int ck, int bn, int wch, int n_chunks,
+                                                            int n_ct) {
+  const int no = ck / 8;
+  const long long total = (long long)n_ct * n_chunks * wch;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int r = (int)(e % wch);
+    const long long q = e / wch;
+    const int chunk = (int)(q % n_chunks), ct = (int)(q / n_chunks);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < taps * no * bn) {
+      const int col = r % bn, row = r / bn;
+      const int oct = row % no, tap = row / no;
+      const int co = ct * bn + col;
+      if (co < Cout) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ci = chunk * ck + oct * 8 + j;
+          if (ci < Cin) v[j] = w[((long long)tap * Cin + ci) * Cout + co];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[4 * e + j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+  }
 }
 
 // U = G g G^T for all (ci, co): u[((ci*4 + r)*Cout + co)*4 + c] = U[r][c]; HWIO weights in.
@@ -161,7 +218,13 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
 // chip runs one round, which steers small batches toward small tiles.
 double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   const long long tiles = (long long)dlwp_ceil_div(a.Ho, e.th) * dlwp_ceil_div(a.Wo, e.tw);
-  const bool wino = e.pack < 0;
+  const bool wino = is_wino(e);
+  if (is_bf16(e)) {  // staging-bound rather than MFMA-bound: padded channel work x output-channel passes, small tiles last
+    const double blocks = (double)tiles * dlwp_ceil_div(a.Cout, 16 * e.bnf) * a.N;
+    const double per_block = (double)dlwp_ceil_div(a.Cin, e.ck) * e.ck * (e.th + 2) * (e.tw + 4) * (1.0 + 0.15 * e.bnf);
+    const double per_cu = blocks / cu_count;
+    return (per_cu < 1.0 ? 1.0 : per_cu) * per_block;
+  }
   const int bnf = e.pack > 0 ? 1 : e.bnf;
   const int kwe = e.pack > 0 ? (e.ks - 1) * e.dil + e.pack : e.ks;  // packed-N: effective kernel width
   const long long cout_tiles = e.pack > 0 ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
@@ -191,7 +254,8 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     const ConvKernelEntry& e = r.entries[g_forced_cfg];
     const bool pool = cd->src_mode == DLWP_SRC_MAXPOOL2;
     const bool pack_ok = e.pack <= 0 || (cd->cout <= 16 / e.pack);
-    if (e.pack < 0 && (!winograd_wanted(a, cd) || a.Cout % (16 * e.bnf) != 0)) return -1;  // whole channel chunks only
+    if (is_wino(e) && (!winograd_wanted(a, cd) || a.Cout % (16 * e.bnf) != 0)) return -1;  // whole channel chunks only
+    if (is_bf16(e) && (!bf16_wanted(a, cd) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
     if (cd->out_pool && !e.out_pool) return -1;
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? g_forced_cfg
@@ -199,11 +263,16 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
   }
   int best = -1;
   double best_cost = 0;
-  bool want_wino = winograd_wanted(a, cd);
+  bool want_bf16 = false;
+  if (bf16_wanted(a, cd))
+    for (const ConvKernelEntry& e : r.entries)
+      want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h &&
+                                bf16_prep_floats(e, a.Cin, a.Cout) <= WINO_SCRATCH_FLOATS);
+  bool want_wino = !want_bf16 && winograd_wanted(a, cd);
   if (want_wino) {  // fall back to the direct family when no Winograd instance matches (dilation / pooled loader)
     bool any = false;
     for (const ConvKernelEntry& e : r.entries)
-      any = any || (e.pack < 0 && e.dil == cd->dil_h && (e.pool != 0) == (cd->src_mode == DLWP_SRC_MAXPOOL2) &&
+      any = any || (is_wino(e) && e.dil == cd->dil_h && (e.pool != 0) == (cd->src_mode == DLWP_SRC_MAXPOOL2) &&
                     (!cd->out_pool || e.out_pool));
     want_wino = any;
   }
@@ -212,8 +281,9 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
     if ((e.pool != 0) != (cd->src_mode == DLWP_SRC_MAXPOOL2)) continue;  // pooled loader <-> POOL instances only
     if (e.pack > 0 && cd->cout > 16 / e.pack) continue;                    // packed-N instances cover cout <= 16/S
-    if ((e.pack < 0) != want_wino) continue;                               // kernel family fixed by the layer geometry
-    if (e.pack < 0 && a.Cout % (16 * e.bnf) != 0) continue;                // Winograd: whole output-channel tiles only
+    if (is_wino(e) != want_wino || is_bf16(e) != want_bf16) continue;      // kernel family fixed by the layer
+    if (is_wino(e) && a.Cout % (16 * e.bnf) != 0) continue;                // Winograd: whole output-channel tiles only
+    if (is_bf16(e) && bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS) continue;
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     const double c = config_cost(e, a, cu_count);
     if (best < 0 || c < best_cost) {
@@ -284,22 +354,29 @@ int launch_direct(dlwp_handle_t h, ConvArgs& a, const dlwp_conv2d* cd, hipStream
 // packed-N (the expanded, zero-padded [chunk][WCH] layout of the chosen instance).  dlwp_conv2d_prep_floats says how many
 // floats the layer needs (0: none), dlwp_conv2d_prep builds them; dlwp_launch_conv2d does both into the handle's scratch
 // unless the caller (the rollout graph: once per launch, not once per forward) passes them in.
-static const ConvKernelEntry* entry_for(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
+static const ConvKernelEntry* entry_for(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
   dlwp_shape4 ys;
   if (!h || !cd || xs.n <= 0 || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return nullptr;
-  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys);
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys, dtype);
   const int ci = choose_config(a, cd, h->cu_count);
   return ci >= 0 ? &registry().entries[ci] : nullptr;
 }
 
 static size_t prep_floats_of(const ConvKernelEntry& e, int cin, int cout) {
-  if (e.pack < 0) return (size_t)cin * cout * 16;
+  if (is_wino(e)) return (size_t)cin * cout * 16;
+  if (is_bf16(e)) return bf16_prep_floats(e, cin, cout);
   if (e.pack > 0) return (size_t)dlwp_ceil_div(cin, e.ck) * e.prep_chunk_floats;
   return 0;
 }
 
 static int prep_with(const ConvKernelEntry& e, const void* w, float* dst, int cin, int cout, hipStream_t s) {
-  if (e.pack < 0) {
+  if (is_bf16(e)) {
+    const int n_chunks = dlwp_ceil_div(cin, e.ck), n_ct = dlwp_ceil_div(cout, 16 * e.bnf), wch = e.prep_chunk_floats / 4;
+    const long long total = (long long)n_ct * n_chunks * wch;
+    bf16_arrange_weights<<<dlwp_ceil_div(total, 256), 256, 0, s>>>((const float*)w, (unsigned*)dst, cin, cout, e.ks * e.ks,
+                                                                   e.ck, 16 * e.bnf, wch, n_chunks, n_ct);
+    DLWP_LAUNCH_CHECK("bf16_arrange_weights");
+  } else if (is_wino(e)) {
     wino_filter_transform_f32<<<dlwp_ceil_div((long long)cin * cout, 256), 256, 0, s>>>((const float*)w, dst, cin, cout);
     DLWP_LAUNCH_CHECK("wino_filter_transform_f32");
   } else if (e.pack > 0) {
@@ -312,13 +389,14 @@ static int prep_with(const ConvKernelEntry& e, const void* w, float* dst, int ci
   return DLWP_OK;
 }
 
-size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
-  const ConvKernelEntry* e = entry_for(h, xs, cd);
+size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
+  const ConvKernelEntry* e = entry_for(h, xs, cd, dtype);
   return e ? prep_floats_of(*e, xs.c, cd->cout) : 0;
 }
 
-int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, hipStream_t s) {
-  const ConvKernelEntry* e = entry_for(h, xs, cd);
+int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype,
+                     hipStream_t s) {
+  const ConvKernelEntry* e = entry_for(h, xs, cd, dtype);
   return e ? prep_with(*e, w, dst, xs.c, cd->cout, s) : DLWP_OK;
 }
 
@@ -445,7 +523,9 @@ int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes) {
   DLWP_CHECK_ARG(i >= 0 && i < (int)r.entries.size() && info9, "dlwp_conv2d_config_info: index %d out of range", i);
   const ConvKernelEntry& e = r.entries[i];
   // cout_frags < 0: packed-N instance with S = -cout_frags shifts; frags_per_wave == 0: Winograd instance
-  const int v[9] = {e.ks, e.dil, e.th, e.tw, e.waves, e.pack < 0 ? 0 : e.fa, e.pack > 0 ? -e.pack : e.bnf, e.ck, e.pool};
+  // pooled_loader == 2: bf16-MFMA instance (runs only on bf16-stored inputs)
+  const int v[9] = {e.ks, e.dil, e.th, e.tw, e.waves, is_wino(e) ? 0 : e.fa, e.pack > 0 ? -e.pack : e.bnf, e.ck,
+                    is_bf16(e) ? 2 : e.pool};
   for (int k = 0; k < 9; ++k) info9[k] = v[k];
   if (lds_bytes) *lds_bytes = e.lds_bytes;
   return DLWP_OK;
@@ -467,6 +547,22 @@ int dlwp_conv2d_supports_out_pool(dlwp_shape4 xs, const dlwp_conv2d* cd) {
   if (dlwp_conv2d_out_shape(xs, &c2, &ys) != DLWP_OK) return 0;
   ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, &c2, ys);
   return choose_config(a, &c2, 256) >= 0 ? 1 : 0;
+}
+
+int dlwp_conv2d_uses_bf16_weights(dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
+  if (!cd || xs.c <= 0 || xs.h <= 0 || xs.w <= 0) return 0;
+  dlwp_shape4 ys;
+  if (xs.n <= 0) xs.n = 1;
+  if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return 0;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys, dtype);
+  const int ci = choose_config(a, cd, 256);
+  return (ci >= 0 && is_bf16(registry().entries[ci])) ? 1 : 0;
+}
+
+int dlwp_conv2d_set_bf16_mfma(int enable) {
+  const int prev = bf16_mfma_enabled() ? 1 : 0;
+  g_bf16_mfma = enable ? 1 : 0;
+  return prev;
 }
 
 int dlwp_conv2d_set_winograd(int enable) {

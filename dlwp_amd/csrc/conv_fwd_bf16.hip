@@ -1,0 +1,18 @@
+// conv_fwd_bf16.hip -- tile configurations of the bf16-MFMA convolution (conv_fwd_bf16_kernel.h): layers whose INPUT is
+// stored as bfloat16 (BASELINE.json config 4: "deeper Conv2D/ConvLSTM2D stack, bf16").
+#include "conv_fwd_bf16_kernel.h"
+static const ConvKernelEntry k_table[] = {
+    BF16_ENTRY(3, 1, 8, 32, 4, 4, 2, 32),
+    BF16_ENTRY(3, 1, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY(3, 1, 8, 32, 4, 4, 2, 48),
+    BF16_ENTRY(3, 1, 8, 32, 4, 4, 4, 32),
+    BF16_ENTRY(3, 1, 4, 32, 2, 4, 2, 32),
+    BF16_ENTRY(3, 2, 8, 32, 4, 4, 2, 32),
+    BF16_ENTRY(3, 2, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY(5, 1, 8, 32, 4, 4, 1, 16),
+    BF16_ENTRY(5, 1, 8, 32, 4, 4, 1, 32),
+};
+const ConvKernelEntry* dlwp_conv_table_bf16(int* n) {
+  *n = (int)(sizeof(k_table) / sizeof(k_table[0]));
+  return k_table;
+}

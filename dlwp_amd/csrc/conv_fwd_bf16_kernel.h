@@ -1,0 +1,287 @@
+// conv_fwd_bf16_kernel.h -- Conv2D forward on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16), gfx950.
+//
+// BASELINE.json config 4 stores the activations between the layers as bfloat16.  A bf16 x bf16 product is exact in fp32 and
+// the accumulation is fp32, so this kernel computes the same sums as the fp32 kernels do on bf16-stored inputs -- with the
+// weights rounded to bf16 as well (they are the B operand) -- at 16x the matrix rate of the exact-fp32 MFMA.  Used when
+// the INPUT tensor is stored as bf16 (DLWP_BF16 / DLWP_DTYPE_IO(DLWP_BF16, *)); the first layer of a model (fp32 state in)
+// and everything this family does not cover stay on the fp32 families.
+//
+// Implicit GEMM as in conv_fwd_kernel.h (pixels on MFMA rows, output channels on columns, haloed input tile in LDS, every
+// fragment address = lane base + immediate) with K = (tap, 32-channel slice): lane group g = lane>>4 supplies the 8
+// consecutive channels 8g..8g+7 of its pixel (A) / output channel (B), so both LDS tiles keep channel OCTETS in 16 bytes:
+//     xo[ci/8][row][col] : 8 x bf16          wo[tap][ci/8][cout] : 8 x bf16
+// and a fragment is one ds_read_b128 (conflict-free: octet-plane strides are multiples of 256 B, see the b128 lane groups
+// in MI355X_MICROARCH.md).  A 16-channel remainder slice (CK = 16, 48) runs v_mfma_f32_16x16x16_bf16 on the two halves of
+// an octet (ds_read_b64).  The input is NCHW bf16 in HBM: a thread owns COLUMN PAIRS -- one dword per channel plane
+// (hardware zero for the halo) -- and turns the 8 dwords of an octet into two 16-byte LDS stores with 8 v_perm.  The
+// weights arrive pre-arranged per (cout tile, channel chunk) by bf16_arrange_weights (rounded to bf16, zero-padded):
+// 16-byte loads and stores.
+#pragma once
+#include "conv_fwd_kernel.h"
+
+template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_>
+struct BfCfg {
+  static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, FA = FA_, BNF = BNF_, CK = CK_;
+  static constexpr int NT = WAVES * 64;
+  static constexpr int LR = TH + DIL * (KS - 1);
+  static constexpr int LC = (TW + DIL * (KS - 1) + 2) & ~1;  // + the alignment column of an odd left halo, even
+  static constexpr int LCH = LC / 2;                          // column pairs per row
+  static constexpr int NPAIR = LR * LCH;
+  static constexpr int NPP = (NPAIR + NT - 1) / NT;           // pairs per thread
+  static constexpr int PSO = (LR * LC + 15) & ~15;            // octet-plane stride, 16-byte units
+  static constexpr int NO = CK / 8;
+  static constexpr int N32 = CK / 32, N16 = (CK % 32) / 16;   // K=32 and K=16 MFMA steps per tap
+  static constexpr int BN = 16 * BNF;
+  static constexpr int TAPS = KS * KS;
+  static constexpr int X_U4 = NO * PSO;
+  static constexpr int W_U4 = TAPS * NO * BN;
+  static constexpr int NWV = (W_U4 + NT - 1) / NT;            // 16-byte weight loads per thread and chunk
+  static constexpr int WCH = NWV * NT;                         // padded chunk, 16-byte units
+  static constexpr int LDS_BYTES = (X_U4 + WCH) * 16;
+  static constexpr int P = TH * TW;
+  static constexpr int MPAD = 16 * FA * WAVES;
+  static_assert(MPAD >= P, "tile pixels must fit the wave/fragment decomposition");
+  static_assert(CK % 16 == 0, "channel chunk = whole 16-channel MFMA slices");
+  static_assert(LDS_BYTES <= 160 * 1024, "bad LDS geometry");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned lds32[];
+  u32x4* xo = (u32x4*)lds32;
+  u32x4* wo = xo + C::X_U4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int L;
+  {
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int xcd = b & 7, idx = b >> 3, q = nb >> 3, r = nb & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tw = L % a.tiles_w;
+  L /= a.tiles_w;
+  const int th = L % a.tiles_h;
+  L /= a.tiles_h;
+  const int ct = L % a.cout_tiles;
+  const int n = L / a.cout_tiles;
+  const int i0 = th * C::TH, j0 = tw * C::TW, n0 = ct * C::BN;
+  const bool ups = a.src_mode == DLWP_SRC_UPSAMPLE2;
+  const int e_al = a.pad_left & 1;   // the LDS tile starts one column early when the left halo is odd: even source columns
+
+  // ---- loader bookkeeping: a thread owns COLUMN PAIRS (even source column + its neighbour: one dword of a bf16 plane; W
+  //      is even and the column halo is periodic or zero, so a pair is inside or outside as a whole; for the up-sampling
+  //      source both columns are the same element).  Out of range = hardware zero.  Lanes past the tile repeat pair 0.
+  unsigned goff[C::NPP];
+  int lpos[C::NPP];
+#pragma unroll
+  for (int q = 0; q < C::NPP; ++q) {
+    int s = tid + q * C::NT;
+    if (q == C::NPP - 1 && s >= C::NPAIR) s = 0;
+    const int lr = s / C::LCH, lc = 2 * (s - lr * C::LCH);
+    const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
+    const int cs = dlwp_map_coord(j0 + lc - a.pad_left - e_al, a.W, a.mode_w);
+    const bool ok = rs >= 0 && cs >= 0;
+    const int g = ups ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
+    goff[q] = ok ? (unsigned)g * 2u : 0x7ffffff0u;
+    lpos[q] = lr * C::LC + lc;
+  }
+  const long long plane = (long long)a.Hs * a.Ws;
+  const unsigned plane_bytes = (unsigned)plane * 2u;
+  const char* xn = (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * 2;
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)a.Cin * plane_bytes, 0x00020000);
+  const int n_chunks = (a.Cin + C::CK - 1) / C::CK;
+  // a.w = bf16_arrange_weights output for THIS instance: [cout tile][chunk][WCH]
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.w, 0, (unsigned)a.cout_tiles * (unsigned)n_chunks * (unsigned)C::WCH * 16u, 0x00020000);
+  const unsigned w_tile_off = (unsigned)ct * (unsigned)n_chunks * (unsigned)C::WCH * 16u;
+
+  // ---- MFMA fragment bookkeeping: rows = pixels.  K=32 steps: lane group g reads octet 4s+g (16-byte units).  K=16
+  //      steps: lane group g reads half g&1 of octet 4*N32 + (g>>1) (8-byte units).
+  int abase[C::FA], abase_h[C::N16 ? C::FA : 1];
+#pragma unroll
+  for (int i = 0; i < C::FA; ++i) {
+    int p = (wave * C::FA + i) * 16 + (lane & 15);
+    if (p >= C::P) p = 0;
+    const int r = p / C::TW, c = p - r * C::TW;
+    abase[i] = r * C::LC + c + e_al + (lane >> 4) * C::PSO;
+    if (C::N16) abase_h[i] = 2 * (r * C::LC + c + e_al + (4 * C::N32 + (lane >> 5)) * C::PSO) + ((lane >> 4) & 1);
+  }
+  const int bbase = (lane >> 4) * C::BN + (lane & 15);
+  const int bbase_h = 2 * ((4 * C::N32 + (lane >> 5)) * C::BN + (lane & 15)) + ((lane >> 4) & 1);
+
+  f32x4 acc[C::FA][C::BNF];
+#pragma unroll
+  for (int i = 0; i < C::FA; ++i)
+#pragma unroll
+    for (int g = 0; g < C::BNF; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- register-staged pipeline as in the fp32 kernel: loads of chunk c+1 in flight under the MFMAs of chunk c
+  unsigned xr[C::CK][C::NPP];
+  u32x4 wr[C::NWV];
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int c = 0; c < C::CK; ++c) {
+      // channels past Cin are clamped to a real plane: their weights are zero
+      const unsigned soff = (unsigned)min(c0 + c, a.Cin - 1) * plane_bytes;
+      if (ups) {
+#pragma unroll
+        for (int q = 0; q < C::NPP; ++q) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0);
+      } else {
+#pragma unroll
+        for (int q = 0; q < C::NPP; ++q) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0);
+      }
+    }
+    const unsigned wsoff = w_tile_off + (unsigned)(c0 / C::CK) * (C::WCH * 16u);
+#pragma unroll
+    for (int k = 0; k < C::NWV; ++k)
+      wr[k] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (unsigned)(tid + k * C::NT) * 16u, wsoff, 0);
+  };
+  auto commit = [&]() {
+    if (ups) {   // both columns of the pair are the same source element
+#pragma unroll
+      for (int c = 0; c < C::CK; ++c)
+#pragma unroll
+        for (int q = 0; q < C::NPP; ++q) xr[c][q] = __builtin_amdgcn_perm(xr[c][q], xr[c][q], 0x01000100u);
+    }
+#pragma unroll
+    for (int o = 0; o < C::NO; ++o)
+#pragma unroll
+      for (int q = 0; q < C::NPP; ++q) {
+        u32x4 lo, hi;   // column p / column p+1: channels 8o .. 8o+7
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lo[j] = __builtin_amdgcn_perm(xr[o * 8 + 2 * j + 1][q], xr[o * 8 + 2 * j][q], 0x05040100u);
+          hi[j] = __builtin_amdgcn_perm(xr[o * 8 + 2 * j + 1][q], xr[o * 8 + 2 * j][q], 0x07060302u);
+        }
+        xo[o * C::PSO + lpos[q]] = lo;
+        xo[o * C::PSO + lpos[q] + 1] = hi;
+      }
+#pragma unroll
+    for (int k = 0; k < C::NWV; ++k) wo[tid + k * C::NT] = wr[k];
+  };
+
+  prefetch(0);
+  for (int c0 = 0; c0 < a.Cin; c0 += C::CK) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (c0 + C::CK < a.Cin) prefetch(c0 + C::CK);
+    constexpr int SPT = C::N32 + C::N16;   // steps per tap: N32 x (K=32), then N16 x (K=16)
+    constexpr int NSTEPS = SPT * C::TAPS;
+    u32x4 af[2][C::FA], bf[2][C::BNF];
+    auto load_frags = [&](int step, int buf) {
+      const int tap = step / SPT, sub = step - tap * SPT;
+      const int u = tap / C::KS, vv = tap - u * C::KS;
+      const int toff = u * C::DIL * C::LC + vv * C::DIL;
+      if (sub < C::N32) {
+#pragma unroll
+        for (int i = 0; i < C::FA; ++i) af[buf][i] = xo[abase[i] + sub * 4 * C::PSO + toff];
+#pragma unroll
+        for (int g = 0; g < C::BNF; ++g) bf[buf][g] = wo[bbase + (tap * C::NO + sub * 4) * C::BN + g * 16];
+      } else {
+#pragma unroll
+        for (int i = 0; i < C::FA; ++i) {
+          const u32x2 v = ((const u32x2*)xo)[abase_h[i] + 2 * toff];
+          af[buf][i] = (u32x4){v[0], v[1], 0u, 0u};
+        }
+#pragma unroll
+        for (int g = 0; g < C::BNF; ++g) {
+          const u32x2 v = ((const u32x2*)wo)[bbase_h + 2 * (tap * C::NO * C::BN + g * 16)];
+          bf[buf][g] = (u32x4){v[0], v[1], 0u, 0u};
+        }
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int step = 0; step < NSTEPS; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < NSTEPS) load_frags(step + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool k32 = (step % SPT) < C::N32;
+#pragma unroll
+      for (int i = 0; i < C::FA; ++i)
+#pragma unroll
+        for (int g = 0; g < C::BNF; ++g) {
+          if (k32)
+            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[cur][i]),
+                                                                __builtin_bit_cast(bf16x8, bf[cur][g]), acc[i][g], 0, 0, 0);
+          else
+            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
+                __builtin_bit_cast(s16x4, (u32x2){af[cur][i][0], af[cur][i][1]}),
+                __builtin_bit_cast(s16x4, (u32x2){bf[cur][g][0], bf[cur][g][1]}), acc[i][g], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- epilogue: bias + activation, 4 consecutive pixels of one channel per lane (as the fp32 kernel)
+  act_dispatch(a.act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    const bool vec_store = (C::TW % 4 == 0) && ((a.Wo & 3) == 0);
+#pragma unroll
+    for (int g = 0; g < C::BNF; ++g) {
+      const int co = n0 + g * 16 + (lane & 15);
+      if (co >= a.Cout) continue;
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      const long long ybase = ((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho * a.Wo;
+#pragma unroll
+      for (int i = 0; i < C::FA; ++i) {
+        const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
+        if (p >= C::P) continue;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = act_apply_c<ACT>(acc[i][g][r] + bv);
+        if (vec_store) {
+          const int row = p / C::TW, col = p - row * C::TW;
+          const int oh = i0 + row, ow = j0 + col;
+          if (oh < a.Ho && ow < a.Wo) {
+            const long long yo = ybase + (long long)oh * a.Wo + ow;
+            if (a.out_bf16) *(u32x2*)((bf16_t*)a.y + yo) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            else *(f32x4*)(a.y + yo) = o;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pp = p + r;
+            const int row = pp / C::TW, col = pp - row * C::TW;
+            const int oh = i0 + row, ow = j0 + col;
+            if (pp < C::P && oh < a.Ho && ow < a.Wo) {
+              const long long yo = ybase + (long long)oh * a.Wo + ow;
+              if (a.out_bf16) ((bf16_t*)a.y)[yo] = f32_to_bf16(o[r]);
+              else a.y[yo] = o[r];
+            }
+          }
+        }
+      }
+    }
+  });
+}
+
+template <class C>
+static void bf16_launch_thunk(const ConvArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((conv2d_fwd_mfma_bf16<C>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
+}
+
+template <class C>
+static int bf16_prepare() {
+  if (C::LDS_BYTES > 64 * 1024)
+    return (int)hipFuncSetAttribute((const void*)conv2d_fwd_mfma_bf16<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    C::LDS_BYTES);
+  return 0;
+}
+
+// registry entry: pack = -2 marks a bf16-MFMA instance (input stored as bf16; a.w = bf16_arrange_weights output);
+// prep_chunk_floats = floats per (cout tile, channel chunk) of the arranged weights
+#define BF16_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK)                                                     \
+  {                                                                                                          \
+    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::LDS_BYTES, 0, -2, 0,    \
+        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::WCH * 4,                                                 \
+        &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>,                                      \
+        &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>                                            \
+  }

@@ -87,7 +87,7 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
   long long u_floats = 0;
   for (int i = 0; i < n_ops; ++i) {
     const dlwp_op& op = plan[i];
-    const long long need = op.kind == DLWP_OP_CONV2D ? (long long)dlwp_conv2d_prep_floats(h, op.xs, &op.conv) : 0;
+    const long long need = op.kind == DLWP_OP_CONV2D ? (long long)dlwp_conv2d_prep_floats(h, op.xs, &op.conv, op.aux[0]) : 0;
     if (need > 0) {
       u_off[i] = u_floats;
       u_floats += (need + 63) & ~63ll;   // 256-byte aligned
@@ -110,7 +110,7 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
   int rc = DLWP_OK;
   if (wino_u)
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
-      if (u_off[i] >= 0) rc = dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, cap);
+      if (u_off[i] >= 0) rc = dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, plan[i].aux[0], cap);
   for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
       const dlwp_op& op = plan[i];

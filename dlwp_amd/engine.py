@@ -64,6 +64,19 @@ class Executor(object):
             self._descs = descs
         return self._descs
 
+    def bf16_weight_layers(self, n=1):
+        """The Conv2D layers this executor multiplies with bf16-rounded weights: the ones whose input buffer is stored as
+        bfloat16 and whose geometry the bf16 matrix-core kernels cover (include/dlwp_hip.h:
+        dlwp_conv2d_uses_bf16_weights).  Empty with float32 activation storage."""
+        from . import _lib, ops
+        out = []
+        for op, d in zip(self.plan.ops, self._descriptors()):
+            if op.kind == 'conv' and op.src in self._bf16:
+                dt = _lib.dtype_io(_lib.BF16, _lib.BF16 if op.dst in self._bf16 else _lib.F32)
+                if ops.uses_bf16_weights((n,) + tuple(op.xs), d, dt):
+                    out.append(op.layer)
+        return out
+
     # -- eager forward ----------------------------------------------------------------------------------------------- #
     def run(self, x, outs=None):
         """x: device tensor (n, ...) matching the model input; returns the list of output tensors (stored layout)."""

@@ -250,6 +250,18 @@ def set_winograd(enable):
     _lib.lib.dlwp_conv2d_set_winograd(1 if enable else 0)
 
 
+def set_bf16_mfma(enable):
+    """Convolutions whose input is stored as bfloat16 multiply on the bf16 matrix cores (weights rounded to bf16) by
+    default; False keeps them on the fp32 families.  Returns the previous setting."""
+    return bool(_lib.lib.dlwp_conv2d_set_bf16_mfma(1 if enable else 0))
+
+
+def uses_bf16_weights(xs, cd, dtype):
+    """Does conv2d on an input of shape xs = (n, c, h, w) stored as `dtype` (a _lib.dtype_io code) multiply with weights
+    rounded to bfloat16 (the bf16 matrix-core kernels)?  Host logic only."""
+    return bool(_lib.lib.dlwp_conv2d_uses_bf16_weights(_lib.Shape4(*[int(v) for v in xs]), ctypes.byref(cd), int(dtype)))
+
+
 # ------------------------------------------------------------------------------------------------------------------ #
 # training kernels
 # ------------------------------------------------------------------------------------------------------------------ #

@@ -107,13 +107,20 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const vo
 /* tuning hooks (tools/tune_conv.py, tests): enumerate the compiled MFMA tile configurations, force one for the calling
  * thread (-1 = heuristic), ask which one the heuristic picks (-1 = direct kernel).  info9 = {ks, dil, th, tw, waves,
  * frags_per_wave (0: Winograd instance), cout_frags (< 0: packed-N instance for cout <= 16/-cout_frags), channel_chunk,
- * pooled_loader}.
+ * pooled_loader (2: bf16-MFMA instance, only for inputs stored as bf16)}.
  * Not part of the drop-in surface.                                                                                  */
 int dlwp_conv2d_num_configs(void);
 int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes);
 int dlwp_conv2d_force_config(int i);
 int dlwp_conv2d_set_winograd(int enable);   /* 3x3 layers with cin % 8 == 0, cout % 32 == 0: Winograd F(2x2,3x3)
                                               * (default) or the direct implicit GEMM */
+int dlwp_conv2d_set_bf16_mfma(int enable);  /* layers whose INPUT is stored as bf16 (even width, >= 12 channels, no
+                                              * pooling fused in): multiply on the bf16 matrix cores with the weights
+                                              * rounded to bf16 (default), or keep the fp32 families.  Returns the
+                                              * previous setting. */
+/* Host logic: 1 when dlwp_conv2d_fwd(xs, cd, dtype) multiplies with bf16-rounded weights (the bf16-MFMA family), else 0:
+ * what a caller comparing against an fp32-weight computation needs to know. */
+int dlwp_conv2d_uses_bf16_weights(dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
 /* Planner hint (pure host logic, no device): 1 when a convolution of this geometry behind a MaxPooling2D runs faster with
  * the pooled tensor materialised by dlwp_maxpool2_fwd (the Winograd family has no pooled loader) than with the pooling
  * fused into the direct kernel's loader; 0 otherwise. */

@@ -360,8 +360,11 @@ def round_bf16(a):
     return np.where(np.isnan(f), np.nan, out)
 
 
-def run_layers(layers, x, weights, record=None, bf16_activations=False):
-    """Execute a sequential stack exactly as the reference graph is laid out (one op per layer, unfused)."""
+def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_weights=()):
+    """Execute a sequential stack exactly as the reference graph is laid out (one op per layer, unfused).
+    bf16_activations: every Conv2D output except the model output is rounded to bfloat16 (the product's config-4 storage);
+    bf16_weights: indices (among the weighted layers) of the Conv2D layers whose kernel is rounded to bfloat16 as well
+    (the layers the product runs on the bf16 matrix cores)."""
     x = np.asarray(x, dtype=np.float64)
     wi = 0
     n_weighted = sum(1 for nm, _, _ in layers if nm in ('Conv2D', 'ConvLSTM2D'))
@@ -377,6 +380,8 @@ def run_layers(layers, x, weights, record=None, bf16_activations=False):
         elif name == 'Conv2D':
             _, _, dil, act = _conv_args(args, kwargs)
             w, b = weights[wi]
+            if wi in bf16_weights:
+                w = round_bf16(w)
             wi += 1
             x = conv2d(x, w, b, dil, act or 'linear')
             if bf16_activations and wi < n_weighted:

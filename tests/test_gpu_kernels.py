@@ -203,6 +203,8 @@ def test_conv2d_every_compiled_tile_configuration(ops):
     problems = {}
     try:
         for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds) in enumerate(cfgs):
+            if pool == 2:
+                continue                                # bf16 matrix-core instances: test_conv2d_bf16_mfma_* below
             cmax = 16 // (-bnf) if bnf < 0 else 0       # packed-N instances cover cout <= 16/S
             wino = fa == 0                              # Winograd instances: whole chunks of 8 in / 32 out channels
             key = (ks, dil, pool, cmax, wino)
@@ -328,9 +330,25 @@ BF16_CASES = [
 ]
 
 
+def _weights_as_multiplied(ops, wt, x_shape, cd, in16, out16):
+    """The kernel the oracle has to use: rounded to bfloat16 when the layer runs on the bf16 matrix cores."""
+    from dlwp_amd import _lib
+    dt = _lib.dtype_io(_lib.BF16 if in16 else _lib.F32, _lib.BF16 if out16 else _lib.F32)
+    if ops.uses_bf16_weights(x_shape, cd, dt):
+        return np_ref.round_bf16(wt), True
+    return wt, False
+
+
+@pytest.fixture(params=[True, False], ids=['bf16-mfma', 'fp32-families'])
+def bf16_mfma(request, ops):
+    prev = ops.set_bf16_mfma(request.param)
+    yield request.param
+    ops.set_bf16_mfma(prev)
+
+
 @pytest.mark.parametrize('case', BF16_CASES)
 @pytest.mark.parametrize('io', [('bf16', 'bf16'), ('f32', 'bf16'), ('bf16', 'f32')])
-def test_conv2d_bfloat16_storage(ops, case, io):
+def test_conv2d_bfloat16_storage(ops, case, io, bf16_mfma):
     n, cin, h, w, cout, k, dil, src = case
     rng = np.random.default_rng(sum(case))
     x = np_ref.round_bf16(rng.standard_normal((n, cin, h, w))).astype(np.float32)     # exactly representable inputs
@@ -338,8 +356,10 @@ def test_conv2d_bfloat16_storage(ops, case, io):
     b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
     p = dil * (k - 1) // 2
     pads = (p, p, p, p)
-    want = _conv_ref(x, wt, b, dil, pads, 0, 1, 'tanh', src)
     cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH, src_mode=src)
+    w_ref, on16 = _weights_as_multiplied(ops, wt, x.shape, cd, io[0] == 'bf16', io[1] == 'bf16')
+    assert on16 == (bf16_mfma and io[0] == 'bf16' and cin >= 12 and src != 2 and k in (3, 5))
+    want = _conv_ref(x, w_ref, b, dil, pads, 0, 1, 'tanh', src)
     xd = dev(x).to(torch.bfloat16) if io[0] == 'bf16' else dev(x)
     out = torch.empty(want.shape, dtype=torch.bfloat16 if io[1] == 'bf16' else torch.float32, device='cuda')
     ops.conv2d(xd, dev(wt), dev(b), cd, out=out)
@@ -351,6 +371,116 @@ def test_conv2d_bfloat16_storage(ops, case, io):
         # almost everywhere exactly the oracle's own rounding
         assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 1e-6)
         assert np.mean(got == np_ref.round_bf16(want)) > 0.99
+
+
+BF16_MFMA_CASES = [
+    # (n, cin, c_off, c_total, h, w, cout, k, dil, pads(t,b,l,r), mode_h, mode_w, act, src_mode, out16)
+    (2, 32, 0, 32, 19, 50, 36, 3, 1, (1, 1, 1, 1), 0, 1, 'tanh', 0, True),      # odd left halo, ragged cout and tiles
+    (2, 48, 0, 48, 20, 72, 32, 3, 1, (1, 1, 1, 1), 0, 1, 'tanh', 0, True),      # config-4 conv2d_1 channels (32 + 16)
+    (1, 24, 8, 40, 11, 34, 96, 3, 1, (1, 1, 1, 1), 0, 0, 'linear', 0, False),   # ConvLSTM recurrent conv: zero 'same', window
+    (2, 20, 0, 20, 9, 12, 7, 3, 2, (2, 2, 2, 2), 2, 1, 'relu', 0, True),        # dilation 2, edge rows, ragged channels
+    (2, 16, 0, 16, 7, 9, 40, 3, 1, (1, 1, 1, 1), 0, 1, 'tanh', 1, True),        # fused up-sampling from an ODD width
+    (1, 64, 0, 64, 12, 20, 32, 3, 2, (2, 2, 2, 2), 0, 1, 'tanh', 1, False),     # dilated + up-sampled, two chunks
+    (2, 16, 0, 16, 10, 16, 4, 5, 1, (2, 2, 2, 2), 0, 1, 'linear', 0, False),    # 5x5 output layer
+    (1, 33, 0, 33, 8, 14, 17, 3, 1, (0, 2, 3, 0), 1, 1, 'tanh', 0, True),       # asymmetric halo, periodic rows, cin = 33
+    (3, 12, 0, 12, 5, 6, 16, 3, 1, (1, 1, 1, 1), 0, 0, 'tanh', 0, True),        # tiny grid, fewest channels
+]
+
+
+@pytest.mark.parametrize('case', BF16_MFMA_CASES)
+def test_conv2d_bf16_mfma_family(ops, case):
+    """Layers with bf16-stored input on the bf16 matrix cores: bf16 x bf16 products are exact in fp32 and the sums are
+    fp32, so against the oracle run on the bf16-ROUNDED weights the fp32 tolerance of the other families holds."""
+    n, cin, c_off, c_tot, h, w, cout, k, dil, pads, mh, mw, act, src, out16 = case
+    rng = np.random.default_rng(sum(pads) + cin + cout + h)
+    xfull = np_ref.round_bf16(rng.standard_normal((n, c_tot, h, w))).astype(np.float32)
+    wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    actc = {'tanh': ops.ACT_TANH, 'relu': ops.ACT_RELU, 'linear': ops.ACT_LINEAR}[act]
+    cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, mh, mw), actc, in_c_off=c_off, in_c_total=c_tot,
+                       src_mode=src)
+    w_ref, on16 = _weights_as_multiplied(ops, wt, (n, cin, h, w), cd, True, out16)
+    assert on16, 'this geometry should select the bf16 matrix-core family'
+    want = _conv_ref(xfull[:, c_off:c_off + cin], w_ref, b, dil, pads, mh, mw, act, src)
+    out = torch.full(want.shape, float('nan'), dtype=torch.bfloat16 if out16 else torch.float32, device='cuda')
+    ops.conv2d(dev(xfull).to(torch.bfloat16), dev(wt), dev(b), cd, out=out, x_channels=cin)
+    got = out.to(torch.float32).cpu().numpy()
+    if out16:
+        assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 2e-6)
+        assert np.mean(got == np_ref.round_bf16(want)) > 0.99
+    else:
+        _check_conv(ops, got, want, 'bf16 mfma')
+    # the fp32 families on the same bf16 input differ only by the weight rounding (2^-9 relative per weight)
+    prev = ops.set_bf16_mfma(False)
+    try:
+        out32 = torch.empty(want.shape, dtype=torch.float32, device='cuda')
+        ops.conv2d(dev(xfull).to(torch.bfloat16), dev(wt), dev(b), cd, out=out32, x_channels=cin)
+    finally:
+        ops.set_bf16_mfma(prev)
+    assert np.abs(out32.cpu().numpy() - want).max() < 2e-2 * max(1.0, np.abs(want).max())
+
+
+def test_conv2d_bf16_mfma_every_compiled_tile_configuration(ops):
+    rng = np.random.default_rng(77)
+    cfgs = ops.conv_configs()
+    problems = {}
+    seen = 0
+    try:
+        for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds) in enumerate(cfgs):
+            if pool != 2:
+                continue
+            seen += 1
+            key = (ks, dil)
+            if key not in problems:
+                n, cin, h, w, cout = 2, 52, 19, 50, 36        # ragged tiles, ragged chunks for CK = 16 / 32 / 48
+                x = np_ref.round_bf16(rng.standard_normal((n, cin, h, w))).astype(np.float32)
+                wt = np_ref.glorot_uniform((ks, ks, cin, cout), rng)
+                b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+                p = dil * (ks - 1) // 2
+                pads = (p, p, p, p)
+                want = _conv_ref(x, np_ref.round_bf16(wt), b, dil, pads, 0, 1, 'tanh', 0)
+                problems[key] = (dev(x).to(torch.bfloat16), dev(wt), dev(b), pads, want, cout)
+            xd, wd, bd, pads, want, cout = problems[key]
+            ops.force_conv_config(i)
+            cd = ops.make_conv(cout, ks, ks, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH)
+            out = torch.empty(want.shape, dtype=torch.float32, device='cuda')
+            ops.conv2d(xd, wd, bd, cd, out=out)
+            _check_conv(ops, out.cpu().numpy(), want, 'config %d %r' % (i, cfgs[i]))
+    finally:
+        ops.force_conv_config(-1)
+    assert seen >= 4
+
+
+def test_conv2d_bf16_mfma_full_size_properties(ops):
+    """BASELINE.json config 4's largest layer (180x360, 48 -> 32 channels): linearity in the input, longitude-shift
+    equivariance (bit for bit: the family is translation invariant in even shifts... and in every shift) and batch
+    invariance."""
+    rng = np.random.default_rng(8)
+    n, cin, h, w, cout = 2, 48, 180, 360, 32
+    x = np_ref.round_bf16(0.5 * rng.standard_normal((n, cin, h, w))).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_LINEAR)
+    xd = dev(x).to(torch.bfloat16)
+    y = ops.conv2d(xd, dev(wt), None, cd)
+    assert y.dtype == torch.bfloat16
+    yf = torch.empty(y.shape, dtype=torch.float32, device='cuda')
+    ops.conv2d(xd, dev(wt), None, cd, out=yf)
+    # shift by an odd and an even number of columns: same sums in the same order
+    for s in (1, 46):
+        ys = torch.empty_like(yf)
+        ops.conv2d(torch.roll(xd, s, dims=3).contiguous(), dev(wt), None, cd, out=ys)
+        assert torch.equal(ys, torch.roll(yf, s, dims=3))
+    # batch invariance: sample 1 alone == sample 1 inside the batch
+    y1 = torch.empty((1,) + tuple(yf.shape[1:]), dtype=torch.float32, device='cuda')
+    ops.conv2d(xd[1:2].contiguous(), dev(wt), None, cd, out=y1)
+    assert torch.equal(y1[0], yf[1])
+    # linearity: conv(2x) == 2 conv(x) exactly (a power of two)
+    y2 = torch.empty_like(yf)
+    ops.conv2d((xd * 2).contiguous(), dev(wt), None, cd, out=y2)
+    assert torch.equal(y2, 2 * yf)
+    # against the oracle on a corner crop that includes the periodic seam and the zero pole rows
+    want = _conv_ref(x[:1], np_ref.round_bf16(wt), np.zeros(cout, np.float32), 1, (1, 1, 1, 1), 0, 1, 'linear', 0)
+    _check_conv(ops, yf[:1].cpu().numpy(), want, 'full size')
 
 
 def test_maxpool2_bfloat16_is_exact(ops):
@@ -416,7 +546,7 @@ def test_conv2d_random_shapes_against_oracle(ops):
     """60 seeded random layer geometries (odd sizes, ragged channels, both dilations, all loaders, both halo modes,
     pooling epilogue where a kernel has one, mixed bf16 / fp32 storage) against the float64 oracle."""
     rng = np.random.default_rng(20240607)
-    n_pool = n_wino = 0
+    n_pool = n_wino = n_bf16 = 0
     for case in range(60):
         k = int(rng.choice([3, 3, 3, 5]))
         dil = int(rng.choice([1, 2])) if k == 3 else 1
@@ -441,11 +571,16 @@ def test_conv2d_random_shapes_against_oracle(ops):
         cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, mode_h, mode_w), actc, src_mode=src)
         want = _conv_ref(x, wt, b, dil, pads, mode_h, mode_w, act, src)
         pool = bool(rng.integers(0, 2)) and ops.supports_out_pool((cin, h, w), cd) and min(want.shape[2:]) >= 2
+        in16, out16 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         if pool:
             cd.out_pool = 1
+        w_ref, on16 = _weights_as_multiplied(ops, wt, x.shape, cd, in16, out16)
+        n_bf16 += int(on16)
+        if on16:
+            want = _conv_ref(x, w_ref, b, dil, pads, mode_h, mode_w, act, src)
+        if pool:
             want = np_ref.maxpool2(want)
             n_pool += 1
-        in16, out16 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         xd = dev(x).to(torch.bfloat16) if in16 else dev(x)
         out = torch.full(want.shape, float('nan'), dtype=torch.bfloat16 if out16 else torch.float32, device='cuda')
         ops.conv2d(xd, dev(wt), dev(b), cd, out=out)
@@ -457,4 +592,5 @@ def test_conv2d_random_shapes_against_oracle(ops):
         else:
             _check_conv(ops, got, want, what)
         n_wino += int(k == 3 and cin % 8 == 0 and cout % 32 == 0 and src != 2)
-    assert n_pool >= 3 and n_wino >= 5          # the sweep really reaches the pooled epilogues and the Winograd family
+    # the sweep really reaches the pooled epilogues, the Winograd family and the bf16 matrix-core family
+    assert n_pool >= 3 and n_wino >= 5 and n_bf16 >= 2, (n_pool, n_wino, n_bf16)

@@ -43,6 +43,14 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
 
 
+def _bf16_weight_indices(model, n):
+    """Indices (among the weighted layers, the oracle's numbering) of the layers the product multiplies with bf16-rounded
+    kernels: bf16-stored input on the bf16 matrix cores."""
+    weighted = [lay for lay in model.layers if len(lay._weights)]
+    on16 = model.executor.bf16_weight_layers(n)
+    return set(i for i, lay in enumerate(weighted) if any(lay is o for o in on16))
+
+
 def test_unet_forward_matches_float64_oracle():
     rng = np.random.default_rng(0)
     cs = (4, 16, 24)
@@ -676,7 +684,9 @@ def test_bfloat16_activation_storage_matches_the_rounding_oracle():
     d.model.set_activation_dtype('bfloat16')
     assert [b.dtype for b in d.model.executor.scratch(5)] == [torch.bfloat16] * len(d.model.infer_plan.buffers)
     y16 = d.predict(x)
-    want = np_ref.run_layers(layers, x, weights, bf16_activations=True)
+    on16 = _bf16_weight_indices(d.model, 5)
+    assert len(on16) >= 2                      # the 16x24 / 8x12 layers with >= 12 input channels
+    want = np_ref.run_layers(layers, x, weights, bf16_activations=True, bf16_weights=on16)
     assert y16.dtype == np.float32 and y16.shape == y32.shape
     # different summation order -> a few intermediate values round to the neighbouring bf16; the effect on the output is
     # far below the bf16-vs-fp32 difference itself
@@ -710,7 +720,8 @@ def test_bfloat16_storage_with_the_recurrent_front_end():
     kinds = {i: b.dtype for i, b in enumerate(d.model.executor.scratch(3))}
     assert kinds[0] == torch.float32 and torch.bfloat16 in kinds.values()        # LSTM state fp32, conv stack bf16
     got = d.predict(x)
-    want = np_ref.run_layers(layers, x, weights, bf16_activations=True)
+    want = np_ref.run_layers(layers, x, weights, bf16_activations=True,
+                             bf16_weights=_bf16_weight_indices(d.model, 3))
     assert _rel(got, want) < 4e-3
 
 
