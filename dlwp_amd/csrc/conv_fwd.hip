@@ -63,7 +63,7 @@ inline bool is_wino(const ConvKernelEntry& e) { return e.pack == -1; }
 inline bool is_bf16(const ConvKernelEntry& e) { return e.pack == -2; }
 
 // bf16-MFMA family (conv_fwd_bf16_kernel.h): the input is stored as bf16; whole column pairs (even width, periodic or
-// zero column halo), no pooled loader / pooling epilogue, enough input channels to fill a K slice.  Like Winograd the
+// zero column halo), no pooled loader, enough input channels to fill a K slice.  Like Winograd the
 // family follows from the layer (geometry + storage type) only.  DLWP_BF16_MFMA=0 / dlwp_conv2d_set_bf16_mfma(0): off.
 int g_bf16_mfma = -1;
 bool bf16_mfma_enabled() {
@@ -78,8 +78,9 @@ size_t bf16_prep_floats(const ConvKernelEntry& e, int cin, int cout) {
 }
 bool bf16_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
   return bf16_mfma_enabled() && a.in_bf16 && cd->kh == cd->kw && cd->dil_h == cd->dil_w && a.Cin >= 12 &&
-         cd->src_mode != DLWP_SRC_MAXPOOL2 && !cd->out_pool && (a.W & 1) == 0 && cd->halo.mode_w != DLWP_PAD_EDGE &&
-         (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29);
+         cd->src_mode != DLWP_SRC_MAXPOOL2 && (a.W & 1) == 0 && cd->halo.mode_w != DLWP_PAD_EDGE &&
+         (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&    // 32-bit byte offsets inside a sample, in ...
+         (long long)a.Ho * a.Wo * a.Cout < (1ll << 28);            // ... and out
 }
 
 // Arranged weights of a bf16-MFMA instance (conv_fwd_bf16_kernel.h):
@@ -266,7 +267,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
   bool want_bf16 = false;
   if (bf16_wanted(a, cd))
     for (const ConvKernelEntry& e : r.entries)
-      want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h &&
+      want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h && (!cd->out_pool || e.out_pool) &&
                                 bf16_prep_floats(e, a.Cin, a.Cout) <= WINO_SCRATCH_FLOATS);
   bool want_wino = !want_bf16 && winograd_wanted(a, cd);
   if (want_wino) {  // fall back to the direct family when no Winograd instance matches (dilation / pooled loader)

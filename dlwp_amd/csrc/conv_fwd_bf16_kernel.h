@@ -40,6 +40,8 @@ struct BfCfg {
   static constexpr int LDS_BYTES = (X_U4 + WCH) * 16;
   static constexpr int P = TH * TW;
   static constexpr int MPAD = 16 * FA * WAVES;
+  // a wave's FA fragments are exactly two tile rows -> the 2x2 pooling window of an output lives in ONE lane
+  static constexpr bool POOL_EPI = (TW == 8 * FA) && (TH == 2 * WAVES) && (FA % 2 == 0);
   static_assert(MPAD >= P, "tile pixels must fit the wave/fragment decomposition");
   static_assert(CK % 16 == 0, "channel chunk = whole 16-channel MFMA slices");
   static_assert(LDS_BYTES <= 160 * 1024, "bad LDS geometry");
@@ -116,10 +118,14 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
   const int bbase_h = 2 * ((4 * C::N32 + (lane >> 5)) * C::BN + (lane & 15)) + ((lane >> 4) & 1);
 
   f32x4 acc[C::FA][C::BNF];
+  float bias_v[C::BNF];   // loaded here: the latency hides under the main loop
 #pragma unroll
-  for (int i = 0; i < C::FA; ++i)
+  for (int g = 0; g < C::BNF; ++g) {
+    const int co = n0 + g * 16 + (lane & 15);
+    bias_v[g] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
 #pragma unroll
-    for (int g = 0; g < C::BNF; ++g) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < C::FA; ++i) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   // ---- register-staged pipeline as in the fp32 kernel: loads of chunk c+1 in flight under the MFMAs of chunk c
   unsigned xr[C::CK][C::NPP];
@@ -220,42 +226,89 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
     }
   }
 
-  // ---- epilogue: bias + activation, 4 consecutive pixels of one channel per lane (as the fp32 kernel)
+  // ---- epilogue: bias + activation (+ MaxPooling2D(2)), 4 consecutive pixels of one channel per lane.  Stores go through
+  //      a buffer descriptor over this sample's output window with 32-bit offsets: out-of-range channels / pixels get an
+  //      offset past the end and the hardware drops the store -- no branches, no 64-bit address arithmetic.
+  const unsigned esz = a.out_bf16 ? 2u : 4u;
+  const unsigned oplane = (unsigned)(a.Hp * a.Wp);   // == Ho*Wo without the pooling epilogue
+  void* yn = (char*)a.y + ((long long)n * a.out_c_total + a.out_c_off) * (long long)oplane * esz;
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(yn, 0, (unsigned)a.Cout * oplane * esz, 0x00020000);
+  constexpr unsigned DROP = 0x7ffffff0u;
+  unsigned coff[C::BNF];   // element offset of the lane's channel plane, or DROP
+#pragma unroll
+  for (int g = 0; g < C::BNF; ++g) {
+    const int co = n0 + g * 16 + (lane & 15);
+    coff[g] = co < a.Cout ? (unsigned)co * oplane : DROP;
+  }
   act_dispatch(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
-    const bool vec_store = (C::TW % 4 == 0) && ((a.Wo & 3) == 0);
+    if constexpr (C::POOL_EPI) {
+      if (a.out_pool) {
+        // a wave's fragments are two whole tile rows: fragment i and i + FA/2 hold the same columns of rows 2w and 2w+1,
+        // registers (0,1) and (2,3) are horizontal neighbours.  Bias and the (monotonic) activation after the maximum.
+        const int pr = (i0 >> 1) + wave;
+        const bool pair = (a.Wp & 1) == 0;
 #pragma unroll
-    for (int g = 0; g < C::BNF; ++g) {
-      const int co = n0 + g * 16 + (lane & 15);
-      if (co >= a.Cout) continue;
-      const float bv = a.bias ? a.bias[co] : 0.f;
-      const long long ybase = ((long long)n * a.out_c_total + a.out_c_off + co) * a.Ho * a.Wo;
+        for (int i = 0; i < C::FA / 2; ++i) {
+          const int pc = (j0 >> 1) + i * 8 + (lane >> 4) * 2;
+          const unsigned poff = (unsigned)(pr * a.Wp + pc);
+          const bool ok0 = pr < a.Hp && pc < a.Wp, ok1 = pr < a.Hp && pc + 1 < a.Wp;
 #pragma unroll
-      for (int i = 0; i < C::FA; ++i) {
-        const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
-        if (p >= C::P) continue;
+          for (int g = 0; g < C::BNF; ++g) {
+            const f32x4 u = acc[i][g], d = acc[i + C::FA / 2][g];
+            const float o0 = act_apply_c<ACT>(fmaxf(fmaxf(u[0], u[1]), fmaxf(d[0], d[1])) + bias_v[g]);
+            const float o1 = act_apply_c<ACT>(fmaxf(fmaxf(u[2], u[3]), fmaxf(d[2], d[3])) + bias_v[g]);
+            const unsigned e = coff[g] + poff;
+            const unsigned off0 = (ok0 && coff[g] != DROP) ? e * esz : DROP;
+            const unsigned off1 = (ok1 && coff[g] != DROP) ? (e + 1) * esz : DROP;
+            if (a.out_bf16) {
+              if (pair) __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(o0, o1), y_rsrc, off0, 0, 0);
+              else {
+                __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(o0), y_rsrc, off0, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(o1), y_rsrc, off1, 0, 0);
+              }
+            } else {
+              if (pair)
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    (u32x2){__builtin_bit_cast(unsigned, o0), __builtin_bit_cast(unsigned, o1)}, y_rsrc, off0, 0, 0);
+              else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o0), y_rsrc, off0, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o1), y_rsrc, off1, 0, 0);
+              }
+            }
+          }
+        }
+        return;
+      }
+    }
+    const bool quad = (a.Wo & 3) == 0;   // 4 consecutive pixels: one store, all inside or all outside
+#pragma unroll
+    for (int i = 0; i < C::FA; ++i) {
+      const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
+      const int row = p / C::TW, col = p - row * C::TW;
+      const int oh = i0 + row, ow = j0 + col;
+      const unsigned poff = (unsigned)(oh * a.Wo + ow);
+      const bool rok = p < C::P && oh < a.Ho;
+#pragma unroll
+      for (int g = 0; g < C::BNF; ++g) {
         f32x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = act_apply_c<ACT>(acc[i][g][r] + bv);
-        if (vec_store) {
-          const int row = p / C::TW, col = p - row * C::TW;
-          const int oh = i0 + row, ow = j0 + col;
-          if (oh < a.Ho && ow < a.Wo) {
-            const long long yo = ybase + (long long)oh * a.Wo + ow;
-            if (a.out_bf16) *(u32x2*)((bf16_t*)a.y + yo) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-            else *(f32x4*)(a.y + yo) = o;
-          }
+        for (int r = 0; r < 4; ++r) o[r] = act_apply_c<ACT>(acc[i][g][r] + bias_v[g]);
+        const unsigned e = coff[g] + poff;
+        const bool cok = rok && coff[g] != DROP;
+        if (quad) {
+          const unsigned off = (cok && ow < a.Wo) ? e * esz : DROP;
+          if (a.out_bf16)
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, y_rsrc, off, 0, 0);
+          else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), y_rsrc, off, 0, 0);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int pp = p + r;
-            const int row = pp / C::TW, col = pp - row * C::TW;
-            const int oh = i0 + row, ow = j0 + col;
-            if (pp < C::P && oh < a.Ho && ow < a.Wo) {
-              const long long yo = ybase + (long long)oh * a.Wo + ow;
-              if (a.out_bf16) ((bf16_t*)a.y)[yo] = f32_to_bf16(o[r]);
-              else a.y[yo] = o[r];
-            }
+            const unsigned off = (cok && ow + r < a.Wo) ? (e + r) * esz : DROP;
+            const float v = o[r];   // (a scalar copy: __builtin_bit_cast on a vector ELEMENT reads element 0 with this hipcc)
+            if (a.out_bf16) __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(v), y_rsrc, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, off, 0, 0);
           }
         }
       }
@@ -280,7 +333,8 @@ static int bf16_prepare() {
 // prep_chunk_floats = floats per (cout tile, channel chunk) of the arranged weights
 #define BF16_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK)                                                     \
   {                                                                                                          \
-    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::LDS_BYTES, 0, -2, 0,    \
+    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::LDS_BYTES, 0, -2,       \
+        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::POOL_EPI ? 1 : 0,                                        \
         BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::WCH * 4,                                                 \
         &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>,                                      \
         &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>                                            \

@@ -33,7 +33,8 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   }
 }
 
-template <int VEC>
+// H16: h is stored as bfloat16 (config 4: the convolutions reading it run on the bf16 matrix cores); c stays float32
+template <int VEC, bool H16>
 __global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __restrict__ zx, const float* __restrict__ zh,
                                                              const float* __restrict__ c_prev, float* __restrict__ c_out,
                                                              float* __restrict__ h_out, int n, int f, int hw, int h_c_off,
@@ -63,7 +64,13 @@ __global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __rest
       h[k] = rec_apply(z[3][k], rec_act) * act_apply(cv, act);
     }
     store_vec<VEC>(c_out + s * f * hw + r, c);
-    store_vec<VEC>(h_out + (s * h_c_total + h_c_off) * hw + r, h);
+    if constexpr (H16) {
+      bf16_t* hp = (bf16_t*)h_out + (s * h_c_total + h_c_off) * hw + r;
+      if constexpr (VEC == 4) *(u32x2*)hp = (u32x2){pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3])};
+      else *hp = f32_to_bf16(h[0]);
+    } else {
+      store_vec<VEC>(h_out + (s * h_c_total + h_c_off) * hw + r, h);
+    }
   }
 }
 
@@ -113,7 +120,9 @@ extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* 
                                    void* h_out, int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act,
                                    int dtype, void* stream) {
   DLWP_CHECK_ARG(h != nullptr, "dlwp_convlstm_gates: null handle");
-  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_convlstm_gates: dtype %d not supported", dtype);
+  DLWP_CHECK_ARG(DLWP_DTYPE_IN(dtype) == DLWP_F32 && (unsigned)DLWP_DTYPE_OUT(dtype) <= 1u && (dtype & ~0x1ffff) == 0,
+                 "dlwp_convlstm_gates: dtype 0x%x not supported (float32, or float32 in / bfloat16 h out)", dtype);
+  const bool h16 = DLWP_DTYPE_OUT(dtype) == DLWP_BF16;
   DLWP_CHECK_ARG(n >= 0 && f > 0 && hw > 0, "dlwp_convlstm_gates: bad sizes n=%d f=%d hw=%d", n, f, hw);
   DLWP_CHECK_ARG(h_c_off >= 0 && h_c_off + f <= h_c_total, "dlwp_convlstm_gates: h window [%d,%d) of %d", h_c_off,
                  h_c_off + f, h_c_total);
@@ -127,12 +136,14 @@ extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* 
   const long long cap = (long long)h->cu_count * 16;
   const int grid = (int)(blocks < cap ? blocks : cap);
   hipStream_t s = (hipStream_t)stream;
-  if (vec4)
-    convlstm_gates_kernel<4><<<grid, 256, 0, s>>>((const float*)zx, (const float*)zh, (const float*)c_prev, (float*)c_out,
-                                                  (float*)h_out, n, f, hw, h_c_off, h_c_total, act, rec_act);
-  else
-    convlstm_gates_kernel<1><<<grid, 256, 0, s>>>((const float*)zx, (const float*)zh, (const float*)c_prev, (float*)c_out,
-                                                  (float*)h_out, n, f, hw, h_c_off, h_c_total, act, rec_act);
+#define DLWP_GATES(V, H)                                                                                                \
+  convlstm_gates_kernel<V, H><<<grid, 256, 0, s>>>((const float*)zx, (const float*)zh, (const float*)c_prev, (float*)c_out, \
+                                                   (float*)h_out, n, f, hw, h_c_off, h_c_total, act, rec_act)
+  if (vec4 && h16) DLWP_GATES(4, true);
+  else if (vec4) DLWP_GATES(4, false);
+  else if (h16) DLWP_GATES(1, true);
+  else DLWP_GATES(1, false);
+#undef DLWP_GATES
   DLWP_LAUNCH_CHECK("convlstm_gates_kernel");
   return DLWP_OK;
 }

@@ -160,7 +160,7 @@ class Executor(object):
                 zh, cp, co = op.aux
                 o.aux[0] = zh if zh is not None else _lib.BUF_NONE
                 o.aux[1] = cp if cp is not None else _lib.BUF_NONE
-                o.aux[2], o.aux[3] = co, op.rec_act
+                o.aux[2], o.aux[3] = co, op.rec_act + (256 if op.dst in self._bf16 else 0)
                 o.conv.act = op.act
                 o.conv.out_c_off, o.conv.out_c_total = op.out_c_off, op.out_c_total
         ptrs = (ctypes.c_void_p * max(1, len(table)))(*[t.data_ptr() for t in table])

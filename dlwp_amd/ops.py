@@ -180,8 +180,11 @@ REC_HARD_SIGMOID, REC_SIGMOID = 0, 1
 
 def convlstm_gates(zx, zh, c_prev, c_out, h_out, f, h_c_off=0, act=1, rec_act=REC_HARD_SIGMOID):
     """ConvLSTM2D cell update: zx/zh (n, 4F, h, w) gate pre-activations (zh, c_prev may be None on the first step),
-    c_out (n, F, h, w), h written to channels [h_c_off, +F) of h_out (n, h_c_total, h, w)."""
-    _check_f32(zx, c_out, h_out)
+    c_out (n, F, h, w), h written to channels [h_c_off, +F) of h_out (n, h_c_total, h, w); h_out may be a bfloat16
+    tensor (the convolutions reading it then run on the bf16 matrix cores), everything else is float32."""
+    _check_f32(zx, c_out)
+    if h_out.dtype not in (torch.float32, torch.bfloat16) or not h_out.is_contiguous():
+        raise ValueError('convlstm_gates: h_out must be a contiguous float32 or bfloat16 tensor')
     n, f4, h, w = zx.shape
     if f4 != 4 * f or tuple(c_out.shape) != (n, f, h, w) or tuple(h_out.shape[2:]) != (h, w) or h_out.shape[0] != n:
         raise ValueError('convlstm_gates: inconsistent shapes zx %r c_out %r h_out %r (F=%d)' %
@@ -193,7 +196,7 @@ def convlstm_gates(zx, zh, c_prev, c_out, h_out, f, h_c_off=0, act=1, rec_act=RE
     _lib.check(_lib.lib.dlwp_convlstm_gates(_lib.handle(_dev(zx)), _ptr(zx), _ptr(zh) if zh is not None else nul,
                                             _ptr(c_prev) if c_prev is not None else nul, _ptr(c_out), _ptr(h_out), n,
                                             int(f), h * w, int(h_c_off), h_out.shape[1], int(act), int(rec_act),
-                                            _lib.F32, _stream(zx)))
+                                            _lib.dtype_io(_lib.F32, storage_code(h_out)), _stream(zx)))
     return h_out
 
 

@@ -145,20 +145,24 @@ class Plan(object):
 
     def bf16_buffers(self):
         """Scratch buffers that may be stored as bfloat16 (config 4: bf16 activations between the layers): written by a
-        Conv2D or a max-pooling of such a buffer and read only by convolutions / max-pooling.  Model inputs and outputs,
-        the ConvLSTM2D state tensors and anything a copy / pad / up-sampling kernel touches stay float32."""
+        Conv2D, by the ConvLSTM2D cell update (the h sequence) or by a max-pooling of such a buffer, and read only by
+        convolutions / max-pooling.  Model inputs and outputs, the ConvLSTM2D gate pre-activations and cell state, and
+        anything a copy / pad / up-sampling kernel touches stay float32."""
         ok = {}
         for op in self.ops:
             for b, role in ((op.src, 'r'), (op.dst, 'w')):
                 if b < 0:
                     continue
-                good = (op.kind == 'conv' and (role == 'r' or not isinstance(op.layer, L._ConvPart))) or op.kind == 'maxpool'
-                if op.kind == 'conv' and isinstance(op.layer, L._ConvPart) and role == 'r' and op.layer.which != 'kernel':
-                    good = False        # the recurrent convolution reads the float32 h sequence
+                if op.kind == 'conv':
+                    good = role == 'r' or not isinstance(op.layer, L._ConvPart)   # zx / zh stay float32
+                elif op.kind == 'lstm':
+                    good = role == 'w'                                            # h may be bf16, zx may not
+                else:
+                    good = op.kind == 'maxpool'
                 ok[b] = ok.get(b, True) and good
             if op.kind == 'lstm':
-                for b in (op.src, op.dst) + tuple(x for x in op.aux if x is not None):
-                    if b >= 0:
+                for b in op.aux:                                                  # zh, c_prev, c_out
+                    if b is not None and b >= 0:
                         ok[b] = False
         changed = True
         while changed:                  # a pooled copy is bf16 only if its source is (and vice versa)

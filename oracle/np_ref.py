@@ -274,13 +274,17 @@ def zero_padding3d(x, padding, data_format='channels_first'):
 
 
 def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', activation='tanh',
-                recurrent_activation='hard_sigmoid', return_sequences=True):
+                recurrent_activation='hard_sigmoid', return_sequences=True, bf16_h=False, bf16_recurrent_kernel=False):
     """x: (N, T, C, H, W) channels_first, already padded for the 'valid' input convolution.  kernel (kh,kw,C,4F),
     recurrent_kernel (kh,kw,F,4F), bias (4F,); gate order i, f, c, o.  Per step (ConvLSTM2DCell.call):
         z  = conv(x_t, kernel, dilation, padding) + bias + conv(h_{t-1}, recurrent_kernel, 'same', no dilation)
         i, f, o = rec_act(z_i), rec_act(z_f), rec_act(z_o);  c_t = f*c_{t-1} + i*act(z_c);  h_t = o*act(c_t)
-    with h_{-1} = c_{-1} = 0.  Returns (N, T, F, Ho, Wo) or the last h (N, F, Ho, Wo)."""
+    with h_{-1} = c_{-1} = 0.  Returns (N, T, F, Ho, Wo) or the last h (N, F, Ho, Wo).
+    bf16_h / bf16_recurrent_kernel: the product's config-4 storage -- every h_t rounded to bfloat16 when it is stored
+    (c_t stays float32) and the recurrent kernel rounded to bfloat16 (bf16 matrix cores on the recurrent convolution)."""
     x = np.asarray(x, dtype=np.float64)
+    if bf16_recurrent_kernel:
+        recurrent_kernel = round_bf16(recurrent_kernel)
     n, t_len = x.shape[:2]
     kh, kw, _, f4 = kernel.shape
     f = f4 // 4
@@ -304,6 +308,8 @@ def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', 
             c_new = c_new + rec(zf) * c
         c = c_new
         h = rec(zo) * activate(c, activation)
+        if bf16_h:
+            h = round_bf16(h)
         outs.append(h)
     return np.stack(outs, axis=1) if return_sequences else h
 
@@ -360,11 +366,12 @@ def round_bf16(a):
     return np.where(np.isnan(f), np.nan, out)
 
 
-def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_weights=()):
+def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_weights=(), bf16_h=False):
     """Execute a sequential stack exactly as the reference graph is laid out (one op per layer, unfused).
     bf16_activations: every Conv2D output except the model output is rounded to bfloat16 (the product's config-4 storage);
     bf16_weights: indices (among the weighted layers) of the Conv2D layers whose kernel is rounded to bfloat16 as well
-    (the layers the product runs on the bf16 matrix cores)."""
+    (the layers the product runs on the bf16 matrix cores; for a ConvLSTM2D: its recurrent kernel); bf16_h: the ConvLSTM2D
+    hidden state is stored as bfloat16."""
     x = np.asarray(x, dtype=np.float64)
     wi = 0
     n_weighted = sum(1 for nm, _, _ in layers if nm in ('Conv2D', 'ConvLSTM2D'))
@@ -395,7 +402,8 @@ def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_wei
             k, r, b = weights[wi]
             wi += 1
             x = conv_lstm2d(x, k, r, b, dil, kwargs.get('padding', 'valid'), act or 'tanh',
-                            kwargs.get('recurrent_activation', 'hard_sigmoid'), kwargs.get('return_sequences', False))
+                            kwargs.get('recurrent_activation', 'hard_sigmoid'), kwargs.get('return_sequences', False),
+                            bf16_h=bf16_h, bf16_recurrent_kernel=(wi - 1) in bf16_weights)
         elif name == 'MaxPooling2D':
             x = maxpool2(x)
         elif name == 'UpSampling2D':

@@ -313,6 +313,13 @@ def test_convlstm_gates_match_oracle(ops, n, f, h, w, first, rec):
     got = host(h_out)
     assert np.abs(got[:, f:2 * f] - h_want).max() < 2e-6
     assert np.all(got[:, :f] == 7.0) and np.all(got[:, 2 * f:] == 7.0)
+    # h stored as bfloat16 (config 4): the same values rounded once; c is float32 and unchanged
+    c16 = torch.empty((n, f, h, w), device='cuda')
+    h16 = torch.full((n, 3 * f, h, w), 7.0, device='cuda', dtype=torch.bfloat16)
+    ops.convlstm_gates(dev(zx), None if zh is None else dev(zh), None if cp is None else dev(cp), c16, h16, f,
+                       h_c_off=f, act=ops.ACT_TANH, rec_act=ops.REC_HARD_SIGMOID if rec == 'hard_sigmoid' else ops.REC_SIGMOID)
+    assert torch.equal(c16, c_out)
+    assert torch.equal(h16, h_out.to(torch.bfloat16))
 
 
 # ----------------------------------------------------------------------------------------------------------------- #
@@ -418,6 +425,30 @@ def test_conv2d_bf16_mfma_family(ops, case):
     finally:
         ops.set_bf16_mfma(prev)
     assert np.abs(out32.cpu().numpy() - want).max() < 2e-2 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 20, 36, 64, 1), (1, 48, 19, 50, 32, 2), (2, 16, 9, 14, 40, 1)])
+@pytest.mark.parametrize('out16', [True, False])
+def test_conv2d_bf16_mfma_pooling_epilogue(ops, shape, out16):
+    """MaxPooling2D(2) applied in the epilogue of the bf16 matrix-core kernel (odd output sizes drop the last row /
+    column as Keras does)."""
+    n, cin, h, w, cout, dil = shape
+    rng = np.random.default_rng(sum(shape))
+    x = np_ref.round_bf16(rng.standard_normal((n, cin, h, w))).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    pads = (dil, dil, dil, dil)
+    cd = ops.make_conv(cout, 3, 3, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH, out_pool=1)
+    w_ref, on16 = _weights_as_multiplied(ops, wt, x.shape, cd, True, out16)
+    assert on16
+    want = np_ref.maxpool2(_conv_ref(x, w_ref, b, dil, pads, 0, 1, 'tanh', 0))
+    out = torch.full(want.shape, float('nan'), dtype=torch.bfloat16 if out16 else torch.float32, device='cuda')
+    ops.conv2d(dev(x).to(torch.bfloat16), dev(wt), dev(b), cd, out=out)
+    got = out.to(torch.float32).cpu().numpy()
+    if out16:
+        assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 2e-6)
+    else:
+        _check_conv(ops, got, want, 'bf16 mfma pooled')
 
 
 def test_conv2d_bf16_mfma_every_compiled_tile_configuration(ops):

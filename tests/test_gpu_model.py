@@ -48,7 +48,7 @@ def _bf16_weight_indices(model, n):
     kernels: bf16-stored input on the bf16 matrix cores."""
     weighted = [lay for lay in model.layers if len(lay._weights)]
     on16 = model.executor.bf16_weight_layers(n)
-    return set(i for i, lay in enumerate(weighted) if any(lay is o for o in on16))
+    return set(i for i, lay in enumerate(weighted) if any(lay is o or getattr(o, 'parent', None) is lay for o in on16))
 
 
 def test_unet_forward_matches_float64_oracle():
@@ -709,7 +709,7 @@ def test_bfloat16_storage_with_the_recurrent_front_end():
     from dlwp_amd.model import DLWPNeuralNet
     from tests.nets import lstm_unet_layers
     rng = np.random.default_rng(52)
-    cs = (2, 2, 16, 24)
+    cs = (2, 4, 16, 24)                 # F = 16 recurrent channels: enough for a bf16 matrix-core K slice
     layers = lstm_unet_layers(cs, widths=(16, 32, 64, 32, 16))
     np.random.seed(5)
     d = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
@@ -718,11 +718,20 @@ def test_bfloat16_storage_with_the_recurrent_front_end():
     x = rng.standard_normal((3,) + cs).astype(np.float32)
     d.model.set_activation_dtype('bfloat16')
     kinds = {i: b.dtype for i, b in enumerate(d.model.executor.scratch(3))}
-    assert kinds[0] == torch.float32 and torch.bfloat16 in kinds.values()        # LSTM state fp32, conv stack bf16
+    # gate pre-activations and cell state float32; the h sequence and the convolution stack bfloat16
+    plan = d.model.infer_plan
+    h_buf = [op.dst for op in plan.ops if op.kind == 'lstm'][0]
+    c_bufs = [op.aux[2] for op in plan.ops if op.kind == 'lstm']
+    z_bufs = [op.src for op in plan.ops if op.kind == 'lstm']
+    assert kinds[h_buf] == torch.bfloat16 and all(kinds[b] == torch.float32 for b in c_bufs + z_bufs)
+    on16 = _bf16_weight_indices(d.model, 3)
+    assert 0 in on16 and 1 in on16          # the recurrent convolution and the first Conv2D read the bf16 h sequence
     got = d.predict(x)
-    want = np_ref.run_layers(layers, x, weights, bf16_activations=True,
-                             bf16_weights=_bf16_weight_indices(d.model, 3))
+    want = np_ref.run_layers(layers, x, weights, bf16_activations=True, bf16_weights=on16, bf16_h=True)
     assert _rel(got, want) < 4e-3
+    # rollout graph == eager forward, bit for bit, with the bf16 h sequence too
+    series = d.predict_timeseries(x, 2, keep_time_dim=True)
+    assert np.array_equal(np.asarray(series)[0].reshape(got.shape), got)
 
 
 def test_recurrent_reference_style_example_runs_end_to_end():

@@ -26,10 +26,13 @@ def main():
     ap.add_argument('--variables', type=int, default=6)
     ap.add_argument('--activation-dtype', default='bfloat16', choices=['float32', 'bfloat16'])
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--no-bf16-mfma', action='store_true', help='keep bf16-stored layers on the fp32 kernel families')
     a = ap.parse_args()
     from dlwp_amd import ops
     from dlwp_amd.model import DLWPNeuralNet
     from tests.nets import lstm_unet_layers
+    if a.no_bf16_mfma:
+        ops.set_bf16_mfma(False)
     h, w = (int(v) for v in a.grid.split('x'))
     cs = (2, a.variables, h, w)
     np.random.seed(1234)
@@ -85,7 +88,9 @@ def main():
             kh, kw = op.layer.kernel_size
             co_, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape
             fl = 2.0 * ho * wo * co_ * op.xs[0] * kh * kw * a.members
+            on16 = any(op.layer is l16 for l16 in ex.bf16_weight_layers(a.members))
             row.update(layer=op.layer.name, cin=op.xs[0], cout=co_, k=kh, tflops=round(fl / ms / 1e9, 1),
+                       family='bf16 mfma' if on16 else 'fp32 mfma',
                        frac_of_mfma_f32_peak=round(fl / ms / 1e9 / MFMA_F32_PEAK, 3), bound='mfma')
         else:
             f = op.xs[0]
@@ -101,8 +106,10 @@ def main():
     t_conv = sum(r['ms'] for r in rows if r['bound'] == 'mfma')
     t_hbm = sum(r['ms'] for r in rows if r['bound'] == 'hbm')
     out = {'config': 'cfg4: %dx%d, %d variables x 2 steps, ConvLSTM2D front end + U-Net (%d params), %s activation storage, '
-                     'fp32 arithmetic, %d members, %d-forward rollout' % (h, w, a.variables, net.count_params(),
-                                                                         a.activation_dtype, a.members, a.forwards),
+                     '%s, %d members, %d-forward rollout' % (
+               h, w, a.variables, net.count_params(), a.activation_dtype,
+               'fp32 arithmetic' if (a.no_bf16_mfma or a.activation_dtype == 'float32') else
+               'bf16 matrix cores (fp32 accumulation) on the layers with bf16-stored input', a.members, a.forwards),
            'six_hour_steps_per_s': a.members * a.forwards * 2 / dt, 'ms_per_forward': 1e3 * dt / a.forwards,
            'finite': finite, 'launches_per_forward': len(plan.ops),
            'split_ms_per_forward': {'convolutions (MFMA-bound)': round(t_conv, 4), 'element-wise (HBM-bound)': round(t_hbm, 4)},
