@@ -24,9 +24,13 @@ OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES = 0, 1,
 BUF_NONE = -1000
 
 
-def dtype_io(dt_in, dt_out):
-    """DLWP_DTYPE_IO(in, out) of include/dlwp_hip.h: storage of a launch's input / output activations"""
-    return 0x10000 | dt_in | (dt_out << 8)
+COMPUTE_BF16 = 0x20000
+
+
+def dtype_io(dt_in, dt_out, compute_bf16=False):
+    """DLWP_DTYPE_IO(in, out) of include/dlwp_hip.h: storage of a launch's input / output activations;
+    compute_bf16: | DLWP_COMPUTE_BF16 (a float32-stored convolution input may be rounded to bfloat16)"""
+    return 0x10000 | dt_in | (dt_out << 8) | (COMPUTE_BF16 if compute_bf16 else 0)
 BUF_STATE_IN = -1
 
 

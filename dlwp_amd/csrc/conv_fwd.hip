@@ -62,7 +62,8 @@ bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
 inline bool is_wino(const ConvKernelEntry& e) { return e.pack == -1; }
 inline bool is_bf16(const ConvKernelEntry& e) { return e.pack == -2; }
 
-// bf16-MFMA family (conv_fwd_bf16_kernel.h): the input is stored as bf16; whole column pairs (even width, periodic or
+// bf16-MFMA family (conv_fwd_bf16_kernel.h): the input is stored as bf16 (or as float32 with DLWP_COMPUTE_BF16: the
+// loader rounds it); whole column pairs (even width, periodic or
 // zero column halo), no pooled loader, enough input channels to fill a K slice.  Like Winograd the
 // family follows from the layer (geometry + storage type) only.  DLWP_BF16_MFMA=0 / dlwp_conv2d_set_bf16_mfma(0): off.
 int g_bf16_mfma = -1;
@@ -77,7 +78,8 @@ size_t bf16_prep_floats(const ConvKernelEntry& e, int cin, int cout) {
   return (size_t)dlwp_ceil_div(cout, 16 * e.bnf) * dlwp_ceil_div(cin, e.ck) * e.prep_chunk_floats;
 }
 bool bf16_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
-  return bf16_mfma_enabled() && a.in_bf16 && cd->kh == cd->kw && cd->dil_h == cd->dil_w && a.Cin >= 12 &&
+  return bf16_mfma_enabled() && (a.in_bf16 ? a.Cin >= 12 : (a.compute_bf16 && a.Cin >= 4)) && cd->kh == cd->kw &&
+         cd->dil_h == cd->dil_w &&
          cd->src_mode != DLWP_SRC_MAXPOOL2 && (a.W & 1) == 0 && cd->halo.mode_w != DLWP_PAD_EDGE &&
          (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&    // 32-bit byte offsets inside a sample, in ...
          (long long)a.Ho * a.Wo * a.Cout < (1ll << 28);            // ... and out
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(256) void packn_expand_weights_f32(const float* __r
 int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void* y, dlwp_shape4 xs,
              const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
   DLWP_CHECK_ARG(h && cd && (xs.n == 0 || (x && w && y)), "%s: null handle or pointer", fn);
-  DLWP_CHECK_ARG((unsigned)DLWP_DTYPE_IN(dtype) <= 1u && (unsigned)DLWP_DTYPE_OUT(dtype) <= 1u && (dtype & ~0x1ffff) == 0,
+  DLWP_CHECK_ARG((unsigned)DLWP_DTYPE_IN(dtype & ~DLWP_COMPUTE_BF16) <= 1u &&
+                     (unsigned)DLWP_DTYPE_OUT(dtype & ~DLWP_COMPUTE_BF16) <= 1u && (dtype & ~0x3ffff) == 0,
                  "%s: dtype 0x%x not supported", fn, dtype);
   DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, "%s: bad input shape (%d,%d,%d,%d)", fn, xs.n, xs.c,
                  xs.h, xs.w);
@@ -179,6 +182,8 @@ int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void
 ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs, const dlwp_conv2d* cd,
                    dlwp_shape4 ys, int dtype = DLWP_F32) {
   ConvArgs a;
+  a.compute_bf16 = (dtype & DLWP_COMPUTE_BF16) ? 1 : 0;
+  dtype &= ~DLWP_COMPUTE_BF16;
   a.in_bf16 = DLWP_DTYPE_IN(dtype) == DLWP_BF16;
   a.out_bf16 = DLWP_DTYPE_OUT(dtype) == DLWP_BF16;
   a.x = (const float*)x;
@@ -220,11 +225,18 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
 double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   const long long tiles = (long long)dlwp_ceil_div(a.Ho, e.th) * dlwp_ceil_div(a.Wo, e.tw);
   const bool wino = is_wino(e);
-  if (is_bf16(e)) {  // staging-bound rather than MFMA-bound: padded channel work x output-channel passes, small tiles last
-    const double blocks = (double)tiles * dlwp_ceil_div(a.Cout, 16 * e.bnf) * a.N;
-    const double per_block = (double)dlwp_ceil_div(a.Cin, e.ck) * e.ck * (e.th + 2) * (e.tw + 4) * (1.0 + 0.15 * e.bnf);
-    const double per_cu = blocks / cu_count;
-    return (per_cu < 1.0 ? 1.0 : per_cu) * per_block;
+  if (is_bf16(e)) {
+    // Not MFMA-bound (instruction issue and staging are): padded (channel x output-channel) work per pixel, with the
+    // measured preferences of tools/bench_bf16_conv.py (profiles/r1i_bf16_conv_layers.json): 32 output channels per
+    // block, 32-channel chunks for 3x3 (16 for 5x5), 8x32 tiles.
+    const double cout_pad = (double)dlwp_ceil_div(a.Cout, 16 * e.bnf) * 16 * e.bnf;
+    const double cin_pad = (double)dlwp_ceil_div(a.Cin, e.ck) * e.ck;
+    double pen = 1.0;
+    if (e.bnf == 4) pen *= 1.15;
+    if (e.ck == 16) pen *= e.ks == 3 ? 1.12 : 0.93;
+    if (e.ck == 48) pen *= 1.3;
+    if (e.waves < 4) pen *= 1.1;
+    return (double)tiles * e.th * e.tw * a.N * (cin_pad + 24.0) * (cout_pad + 16.0) * pen;
   }
   const int bnf = e.pack > 0 ? 1 : e.bnf;
   const int kwe = e.pack > 0 ? (e.ks - 1) * e.dil + e.pack : e.ks;  // packed-N: effective kernel width
@@ -256,7 +268,8 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     const bool pool = cd->src_mode == DLWP_SRC_MAXPOOL2;
     const bool pack_ok = e.pack <= 0 || (cd->cout <= 16 / e.pack);
     if (is_wino(e) && (!winograd_wanted(a, cd) || a.Cout % (16 * e.bnf) != 0)) return -1;  // whole channel chunks only
-    if (is_bf16(e) && (!bf16_wanted(a, cd) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
+    if (is_bf16(e) && (!bf16_wanted(a, cd) || (e.in32 != 0) == (a.in_bf16 != 0) ||
+                       bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
     if (cd->out_pool && !e.out_pool) return -1;
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? g_forced_cfg
@@ -268,6 +281,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
   if (bf16_wanted(a, cd))
     for (const ConvKernelEntry& e : r.entries)
       want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h && (!cd->out_pool || e.out_pool) &&
+                                (e.in32 != 0) == !a.in_bf16 &&
                                 bf16_prep_floats(e, a.Cin, a.Cout) <= WINO_SCRATCH_FLOATS);
   bool want_wino = !want_bf16 && winograd_wanted(a, cd);
   if (want_wino) {  // fall back to the direct family when no Winograd instance matches (dilation / pooled loader)
@@ -284,7 +298,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if (e.pack > 0 && cd->cout > 16 / e.pack) continue;                    // packed-N instances cover cout <= 16/S
     if (is_wino(e) != want_wino || is_bf16(e) != want_bf16) continue;      // kernel family fixed by the layer
     if (is_wino(e) && a.Cout % (16 * e.bnf) != 0) continue;                // Winograd: whole output-channel tiles only
-    if (is_bf16(e) && bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS) continue;
+    if (is_bf16(e) && ((e.in32 != 0) == (a.in_bf16 != 0) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) continue;
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     const double c = config_cost(e, a, cu_count);
     if (best < 0 || c < best_cost) {
@@ -524,9 +538,9 @@ int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes) {
   DLWP_CHECK_ARG(i >= 0 && i < (int)r.entries.size() && info9, "dlwp_conv2d_config_info: index %d out of range", i);
   const ConvKernelEntry& e = r.entries[i];
   // cout_frags < 0: packed-N instance with S = -cout_frags shifts; frags_per_wave == 0: Winograd instance
-  // pooled_loader == 2: bf16-MFMA instance (runs only on bf16-stored inputs)
+  // pooled_loader == 2: bf16-MFMA instance for bf16-stored inputs; 3: for float32-stored inputs (DLWP_COMPUTE_BF16)
   const int v[9] = {e.ks, e.dil, e.th, e.tw, e.waves, is_wino(e) ? 0 : e.fa, e.pack > 0 ? -e.pack : e.bnf, e.ck,
-                    is_bf16(e) ? 2 : e.pool};
+                    is_bf16(e) ? (e.in32 ? 3 : 2) : e.pool};
   for (int k = 0; k < 9; ++k) info9[k] = v[k];
   if (lds_bytes) *lds_bytes = e.lds_bytes;
   return DLWP_OK;

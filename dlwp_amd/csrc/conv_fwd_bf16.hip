@@ -11,6 +11,10 @@ static const ConvKernelEntry k_table[] = {
     BF16_ENTRY(3, 2, 8, 32, 4, 4, 2, 16),
     BF16_ENTRY(5, 1, 8, 32, 4, 4, 1, 16),
     BF16_ENTRY(5, 1, 8, 32, 4, 4, 1, 32),
+    // float32-stored input rounded in the loader (the ConvLSTM2D input convolution of config 4: 6 channels in)
+    BF16_ENTRY_IN32(3, 1, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY_IN32(3, 2, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY_IN32(5, 1, 8, 32, 4, 4, 1, 16),
 };
 const ConvKernelEntry* dlwp_conv_table_bf16(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));

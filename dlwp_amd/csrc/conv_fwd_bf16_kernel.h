@@ -18,9 +18,12 @@
 // 16-byte loads and stores.
 #pragma once
 #include "conv_fwd_kernel.h"
+#include <type_traits>
 
-template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_>
+// IN32: the input is stored as float32 and rounded to bf16 while it is staged (the caller allowed it: DLWP_COMPUTE_BF16)
+template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool IN32_ = false>
 struct BfCfg {
+  static constexpr bool IN32 = IN32_;
   static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, FA = FA_, BNF = BNF_, CK = CK_;
   static constexpr int NT = WAVES * 64;
   static constexpr int LR = TH + DIL * (KS - 1);
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
   const int n = L / a.cout_tiles;
   const int i0 = th * C::TH, j0 = tw * C::TW, n0 = ct * C::BN;
   const bool ups = a.src_mode == DLWP_SRC_UPSAMPLE2;
+  constexpr unsigned ESZ_IN = C::IN32 ? 4u : 2u;
   const int e_al = a.pad_left & 1;   // the LDS tile starts one column early when the left halo is odd: even source columns
 
   // ---- loader bookkeeping: a thread owns COLUMN PAIRS (even source column + its neighbour: one dword of a bf16 plane; W
@@ -89,12 +93,12 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
     const int cs = dlwp_map_coord(j0 + lc - a.pad_left - e_al, a.W, a.mode_w);
     const bool ok = rs >= 0 && cs >= 0;
     const int g = ups ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
-    goff[q] = ok ? (unsigned)g * 2u : 0x7ffffff0u;
+    goff[q] = ok ? (unsigned)g * ESZ_IN : 0x7ffffff0u;
     lpos[q] = lr * C::LC + lc;
   }
   const long long plane = (long long)a.Hs * a.Ws;
-  const unsigned plane_bytes = (unsigned)plane * 2u;
-  const char* xn = (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * 2;
+  const unsigned plane_bytes = (unsigned)plane * ESZ_IN;
+  const char* xn = (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * ESZ_IN;
   const __amdgpu_buffer_rsrc_t x_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)a.Cin * plane_bytes, 0x00020000);
   const int n_chunks = (a.Cin + C::CK - 1) / C::CK;
@@ -128,19 +132,28 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
   }
 
   // ---- register-staged pipeline as in the fp32 kernel: loads of chunk c+1 in flight under the MFMAs of chunk c
-  unsigned xr[C::CK][C::NPP];
+  // raw column pairs in flight: one dword of a bf16 plane, or two floats of a float32 plane (IN32)
+  typedef typename std::conditional<C::IN32, u32x2, unsigned>::type xraw_t;
+  xraw_t xr[C::CK][C::NPP];
   u32x4 wr[C::NWV];
   auto prefetch = [&](int c0) {
 #pragma unroll
     for (int c = 0; c < C::CK; ++c) {
-      // channels past Cin are clamped to a real plane: their weights are zero
-      const unsigned soff = (unsigned)min(c0 + c, a.Cin - 1) * plane_bytes;
-      if (ups) {
+      if (c0 + c < a.Cin) {   // uniform: channels past Cin are not fetched (their weights are zero as well)
+        const unsigned soff = (unsigned)(c0 + c) * plane_bytes;
 #pragma unroll
-        for (int q = 0; q < C::NPP; ++q) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0);
+        for (int q = 0; q < C::NPP; ++q) {
+          if constexpr (C::IN32) {
+            if (ups) xr[c][q] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0), 0u};
+            else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, goff[q], soff, 0);
+          } else {
+            if (ups) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0);
+            else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0);
+          }
+        }
       } else {
 #pragma unroll
-        for (int q = 0; q < C::NPP; ++q) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0);
+        for (int q = 0; q < C::NPP; ++q) xr[c][q] = xraw_t{};
       }
     }
     const unsigned wsoff = w_tile_off + (unsigned)(c0 / C::CK) * (C::WCH * 16u);
@@ -148,13 +161,21 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
     for (int k = 0; k < C::NWV; ++k)
       wr[k] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (unsigned)(tid + k * C::NT) * 16u, wsoff, 0);
   };
-  auto commit = [&]() {
-    if (ups) {   // both columns of the pair are the same source element
-#pragma unroll
-      for (int c = 0; c < C::CK; ++c)
-#pragma unroll
-        for (int q = 0; q < C::NPP; ++q) xr[c][q] = __builtin_amdgcn_perm(xr[c][q], xr[c][q], 0x01000100u);
+  // the pair as two bf16 in one dword (column p in the low half)
+  auto pair_bits = [&](const xraw_t& v) -> unsigned {
+    if constexpr (C::IN32) {
+      const float lo = __builtin_bit_cast(float, v[0]), hi = __builtin_bit_cast(float, ups ? v[0] : v[1]);
+      return pack_bf16x2(lo, hi);
+    } else {
+      return ups ? __builtin_amdgcn_perm(v, v, 0x01000100u) : v;   // up-sampling: both columns are the same element
     }
+  };
+  auto commit = [&]() {
+    unsigned xd[C::CK][C::NPP];
+#pragma unroll
+    for (int c = 0; c < C::CK; ++c)
+#pragma unroll
+      for (int q = 0; q < C::NPP; ++q) xd[c][q] = pair_bits(xr[c][q]);
 #pragma unroll
     for (int o = 0; o < C::NO; ++o)
 #pragma unroll
@@ -162,8 +183,8 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
         u32x4 lo, hi;   // column p / column p+1: channels 8o .. 8o+7
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          lo[j] = __builtin_amdgcn_perm(xr[o * 8 + 2 * j + 1][q], xr[o * 8 + 2 * j][q], 0x05040100u);
-          hi[j] = __builtin_amdgcn_perm(xr[o * 8 + 2 * j + 1][q], xr[o * 8 + 2 * j][q], 0x07060302u);
+          lo[j] = __builtin_amdgcn_perm(xd[o * 8 + 2 * j + 1][q], xd[o * 8 + 2 * j][q], 0x05040100u);
+          hi[j] = __builtin_amdgcn_perm(xd[o * 8 + 2 * j + 1][q], xd[o * 8 + 2 * j][q], 0x07060302u);
         }
         xo[o * C::PSO + lpos[q]] = lo;
         xo[o * C::PSO + lpos[q] + 1] = hi;
@@ -329,13 +350,15 @@ static int bf16_prepare() {
   return 0;
 }
 
-// registry entry: pack = -2 marks a bf16-MFMA instance (input stored as bf16; a.w = bf16_arrange_weights output);
-// prep_chunk_floats = floats per (cout tile, channel chunk) of the arranged weights
-#define BF16_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK)                                                     \
-  {                                                                                                          \
-    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::LDS_BYTES, 0, -2,       \
-        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::POOL_EPI ? 1 : 0,                                        \
-        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>::WCH * 4,                                                 \
-        &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>,                                      \
-        &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK>>                                            \
+// registry entry: pack = -2 marks a bf16-MFMA instance (a.w = bf16_arrange_weights output); in32 = 1: float32-stored input,
+// rounded to bf16 in the loader; prep_chunk_floats = floats per (cout tile, channel chunk) of the arranged weights
+#define BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32)                                                   \
+  {                                                                                                                \
+    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>::LDS_BYTES, 0, -2,       \
+        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>::POOL_EPI ? 1 : 0,                                        \
+        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>::WCH * 4,                                                 \
+        &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>>,                                      \
+        &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>>, IN32 ? 1 : 0                              \
   }
+#define BF16_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, false)
+#define BF16_ENTRY_IN32(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, true)

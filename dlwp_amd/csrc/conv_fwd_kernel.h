@@ -35,7 +35,8 @@ struct ConvArgs {
   int src_mode, act;
   int tiles_h, tiles_w, cout_tiles;
   int out_pool, Hp, Wp;   // epilogue 2x2 max-pooling: y is (N, out_c_total, Hp, Wp) = (Ho/2, Wo/2)
-  int in_bf16, out_bf16;  // storage of x / y: 0 = float32, 1 = bfloat16 (arithmetic is fp32 either way; w, bias fp32)
+  int in_bf16, out_bf16;  // storage of x / y: 0 = float32, 1 = bfloat16 (w, bias fp32)
+  int compute_bf16;       // DLWP_COMPUTE_BF16: a float32-stored input may be rounded to bf16 for the bf16 matrix cores
 };
 
 template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool POOL_ = false>
@@ -466,6 +467,7 @@ struct ConvKernelEntry {
   int prep_chunk_floats;  // packed-N: floats per channel chunk of the pre-expanded weights (0: the kernel reads HWIO)
   void (*launch)(const ConvArgs&, int grid, hipStream_t s);
   int (*prepare)();
+  int in32 = 0;  // bf16-MFMA instances: 1 = the input is stored as float32 and rounded to bf16 by the loader
 };
 
 template <class C>

@@ -33,8 +33,23 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
   }
 }
 
-// H16: h is stored as bfloat16 (config 4: the convolutions reading it run on the bf16 matrix cores); c stays float32
-template <int VEC, bool H16>
+// bf16-stored gate pre-activations (Z16): 4 values = 8 bytes
+template <int VEC>
+__device__ __forceinline__ void load_vec_bf16(const bf16_t* p, float (&out)[VEC]) {
+  if constexpr (VEC == 4) {
+    const u32x2 v = *(const u32x2*)p;
+    out[0] = bf16_bits_to_f32(v[0] & 0xffffu);
+    out[1] = bf16_bits_to_f32(v[0] >> 16);
+    out[2] = bf16_bits_to_f32(v[1] & 0xffffu);
+    out[3] = bf16_bits_to_f32(v[1] >> 16);
+  } else {
+    out[0] = bf16_bits_to_f32(*p);
+  }
+}
+
+// H16: h is stored as bfloat16 (config 4: the convolutions reading it run on the bf16 matrix cores); Z16: so are the gate
+// pre-activations zx / zh.  The cell state c stays float32 and the arithmetic is float32.
+template <int VEC, bool H16, bool Z16>
 __global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __restrict__ zx, const float* __restrict__ zh,
                                                              const float* __restrict__ c_prev, float* __restrict__ c_out,
                                                              float* __restrict__ h_out, int n, int f, int hw, int h_c_off,
@@ -47,10 +62,12 @@ __global__ __launch_bounds__(256) void convlstm_gates_kernel(const float* __rest
     float z[4][VEC], cp[VEC], c[VEC], h[VEC];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      load_vec<VEC>(zx + zb + (long long)g * f * hw, z[g]);
+      if constexpr (Z16) load_vec_bf16<VEC>((const bf16_t*)zx + zb + (long long)g * f * hw, z[g]);
+      else load_vec<VEC>(zx + zb + (long long)g * f * hw, z[g]);
       if (zh) {
         float t[VEC];
-        load_vec<VEC>(zh + zb + (long long)g * f * hw, t);
+        if constexpr (Z16) load_vec_bf16<VEC>((const bf16_t*)zh + zb + (long long)g * f * hw, t);
+        else load_vec<VEC>(zh + zb + (long long)g * f * hw, t);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) z[g][k] += t[k];
       }
@@ -120,9 +137,9 @@ extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* 
                                    void* h_out, int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act,
                                    int dtype, void* stream) {
   DLWP_CHECK_ARG(h != nullptr, "dlwp_convlstm_gates: null handle");
-  DLWP_CHECK_ARG(DLWP_DTYPE_IN(dtype) == DLWP_F32 && (unsigned)DLWP_DTYPE_OUT(dtype) <= 1u && (dtype & ~0x1ffff) == 0,
-                 "dlwp_convlstm_gates: dtype 0x%x not supported (float32, or float32 in / bfloat16 h out)", dtype);
-  const bool h16 = DLWP_DTYPE_OUT(dtype) == DLWP_BF16;
+  DLWP_CHECK_ARG((unsigned)DLWP_DTYPE_IN(dtype) <= 1u && (unsigned)DLWP_DTYPE_OUT(dtype) <= 1u && (dtype & ~0x1ffff) == 0,
+                 "dlwp_convlstm_gates: dtype 0x%x not supported", dtype);
+  const bool h16 = DLWP_DTYPE_OUT(dtype) == DLWP_BF16, z16 = DLWP_DTYPE_IN(dtype) == DLWP_BF16;
   DLWP_CHECK_ARG(n >= 0 && f > 0 && hw > 0, "dlwp_convlstm_gates: bad sizes n=%d f=%d hw=%d", n, f, hw);
   DLWP_CHECK_ARG(h_c_off >= 0 && h_c_off + f <= h_c_total, "dlwp_convlstm_gates: h window [%d,%d) of %d", h_c_off,
                  h_c_off + f, h_c_total);
@@ -136,13 +153,20 @@ extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* 
   const long long cap = (long long)h->cu_count * 16;
   const int grid = (int)(blocks < cap ? blocks : cap);
   hipStream_t s = (hipStream_t)stream;
-#define DLWP_GATES(V, H)                                                                                                \
-  convlstm_gates_kernel<V, H><<<grid, 256, 0, s>>>((const float*)zx, (const float*)zh, (const float*)c_prev, (float*)c_out, \
-                                                   (float*)h_out, n, f, hw, h_c_off, h_c_total, act, rec_act)
-  if (vec4 && h16) DLWP_GATES(4, true);
-  else if (vec4) DLWP_GATES(4, false);
-  else if (h16) DLWP_GATES(1, true);
-  else DLWP_GATES(1, false);
+#define DLWP_GATES(V, H, Z)                                                                                         \
+  convlstm_gates_kernel<V, H, Z><<<grid, 256, 0, s>>>((const float*)zx, (const float*)zh, (const float*)c_prev,      \
+                                                      (float*)c_out, (float*)h_out, n, f, hw, h_c_off, h_c_total, act, \
+                                                      rec_act)
+#define DLWP_GATES_V(V)                               \
+  do {                                                \
+    if (h16 && z16) DLWP_GATES(V, true, true);        \
+    else if (h16) DLWP_GATES(V, true, false);         \
+    else if (z16) DLWP_GATES(V, false, true);         \
+    else DLWP_GATES(V, false, false);                 \
+  } while (0)
+  if (vec4) DLWP_GATES_V(4);
+  else DLWP_GATES_V(1);
+#undef DLWP_GATES_V
 #undef DLWP_GATES
   DLWP_LAUNCH_CHECK("convlstm_gates_kernel");
   return DLWP_OK;

@@ -24,7 +24,8 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
     case DLWP_OP_LSTM_GATES:
       return dlwp_convlstm_gates(h, src, aux[0], aux[1], aux[2], dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w,
                                  op.conv.out_c_off, op.conv.out_c_total, op.conv.act, op.aux[3] & 0xff,
-                                 (op.aux[3] >> 8) ? DLWP_DTYPE_IO(DLWP_F32, DLWP_BF16) : dtype, (void*)s);
+                                 DLWP_DTYPE_IO((op.aux[3] & 512) ? DLWP_BF16 : DLWP_F32, (op.aux[3] & 256) ? DLWP_BF16 : DLWP_F32),
+                                 (void*)s);
     case DLWP_OP_CONV2D:
       return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre);  // aux[0]: per-op storage
     case DLWP_OP_PAD2D:

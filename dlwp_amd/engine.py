@@ -64,6 +64,14 @@ class Executor(object):
             self._descs = descs
         return self._descs
 
+    def _conv_dtype(self, op):
+        """dtype code of a convolution launch: storage of its input / output buffers; in bfloat16 mode a float32-stored
+        input (the model state) feeding a bf16-stored output may be rounded to bf16 by the kernel (DLWP_COMPUTE_BF16)."""
+        from . import _lib
+        in16, out16 = op.src in self._bf16, op.dst in self._bf16
+        return _lib.dtype_io(_lib.BF16 if in16 else _lib.F32, _lib.BF16 if out16 else _lib.F32,
+                             compute_bf16=(out16 and not in16))
+
     def bf16_weight_layers(self, n=1):
         """The Conv2D layers this executor multiplies with bf16-rounded weights: the ones whose input buffer is stored as
         bfloat16 and whose geometry the bf16 matrix-core kernels cover (include/dlwp_hip.h:
@@ -71,10 +79,8 @@ class Executor(object):
         from . import _lib, ops
         out = []
         for op, d in zip(self.plan.ops, self._descriptors()):
-            if op.kind == 'conv' and op.src in self._bf16:
-                dt = _lib.dtype_io(_lib.BF16, _lib.BF16 if op.dst in self._bf16 else _lib.F32)
-                if ops.uses_bf16_weights((n,) + tuple(op.xs), d, dt):
-                    out.append(op.layer)
+            if op.kind == 'conv' and ops.uses_bf16_weights((n,) + tuple(op.xs), d, self._conv_dtype(op)):
+                out.append(op.layer)
         return out
 
     # -- eager forward ----------------------------------------------------------------------------------------------- #
@@ -95,7 +101,8 @@ class Executor(object):
         for op, d in zip(self.plan.ops, self._descriptors()):
             src, dst = res(op.src), res(op.dst)
             if op.kind == 'conv':
-                ops.conv2d(src, op.layer.kernel, op.layer.bias, d, out=dst, x_channels=op.xs[0])
+                ops.conv2d(src, op.layer.kernel, op.layer.bias, d, out=dst, x_channels=op.xs[0],
+                           compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16))
             elif op.kind == 'pad':
                 if op.inner > 1:
                     hh, ww = op.xs[1], op.xs[2]
@@ -144,8 +151,7 @@ class Executor(object):
             if op.kind == 'conv':
                 o.w, o.b = widx[id(op.layer)]
                 o.conv = d
-                o.aux[0] = _lib.dtype_io(_lib.BF16 if op.src in self._bf16 else _lib.F32,
-                                         _lib.BF16 if op.dst in self._bf16 else _lib.F32)
+                o.aux[0] = self._conv_dtype(op)
             elif op.kind == 'maxpool':
                 o.aux[0] = _lib.BF16 if op.src in self._bf16 else _lib.F32
             elif op.kind == 'pad':
@@ -160,7 +166,8 @@ class Executor(object):
                 zh, cp, co = op.aux
                 o.aux[0] = zh if zh is not None else _lib.BUF_NONE
                 o.aux[1] = cp if cp is not None else _lib.BUF_NONE
-                o.aux[2], o.aux[3] = co, op.rec_act + (256 if op.dst in self._bf16 else 0)
+                o.aux[2], o.aux[3] = co, op.rec_act + (256 if op.dst in self._bf16 else 0) + \
+                    (512 if op.src in self._bf16 else 0)
                 o.conv.act = op.act
                 o.conv.out_c_off, o.conv.out_c_total = op.out_c_off, op.out_c_total
         ptrs = (ctypes.c_void_p * max(1, len(table)))(*[t.data_ptr() for t in table])

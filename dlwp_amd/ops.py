@@ -103,9 +103,10 @@ def pad2d_bwd(dy, x_shape, pad, channels_last=False):
     return dx
 
 
-def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None):
+def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute_bf16=False):
     """x: stored input (n, in_c_total, h, w); the conv reads `x_channels` (default: all) channels from cd.in_c_off.
-    Returns (n, out_c_total, ho, wo); writes channels [out_c_off, out_c_off+cout)."""
+    Returns (n, out_c_total, ho, wo); writes channels [out_c_off, out_c_off+cout).  compute_bf16: a float32 x may be
+    rounded to bfloat16 so that the layer runs on the bf16 matrix cores (DLWP_COMPUTE_BF16)."""
     _check_act(x, out)
     _check_f32(w_hwio, bias)
     n, c_total, h, w = x.shape
@@ -123,7 +124,7 @@ def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None):
     elif tuple(out.shape) != (n, oc, ys.h, ys.w):
         raise ValueError('output buffer shape %s != %s' % (tuple(out.shape), (n, oc, ys.h, ys.w)))
     fn = _lib.lib.dlwp_conv2d_fwd_direct if direct else _lib.lib.dlwp_conv2d_fwd
-    dt = _lib.dtype_io(storage_code(x), storage_code(out))      # storage of x / y; arithmetic is fp32 either way
+    dt = _lib.dtype_io(storage_code(x), storage_code(out), compute_bf16)      # storage of x / y
     _lib.check(fn(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(bias), _ptr(out), xs, ctypes.byref(cd), dt,
                   _stream(x)))
     return out
@@ -180,23 +181,25 @@ REC_HARD_SIGMOID, REC_SIGMOID = 0, 1
 
 def convlstm_gates(zx, zh, c_prev, c_out, h_out, f, h_c_off=0, act=1, rec_act=REC_HARD_SIGMOID):
     """ConvLSTM2D cell update: zx/zh (n, 4F, h, w) gate pre-activations (zh, c_prev may be None on the first step),
-    c_out (n, F, h, w), h written to channels [h_c_off, +F) of h_out (n, h_c_total, h, w); h_out may be a bfloat16
-    tensor (the convolutions reading it then run on the bf16 matrix cores), everything else is float32."""
-    _check_f32(zx, c_out)
-    if h_out.dtype not in (torch.float32, torch.bfloat16) or not h_out.is_contiguous():
-        raise ValueError('convlstm_gates: h_out must be a contiguous float32 or bfloat16 tensor')
+    c_out (n, F, h, w), h written to channels [h_c_off, +F) of h_out (n, h_c_total, h, w); h_out and zx / zh (both the
+    same type) may be bfloat16 tensors (config 4 storage), the cell state is float32."""
+    _check_f32(c_out)
+    for t in (h_out, zx):
+        if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous():
+            raise ValueError('convlstm_gates: zx / h_out must be contiguous float32 or bfloat16 tensors')
     n, f4, h, w = zx.shape
     if f4 != 4 * f or tuple(c_out.shape) != (n, f, h, w) or tuple(h_out.shape[2:]) != (h, w) or h_out.shape[0] != n:
         raise ValueError('convlstm_gates: inconsistent shapes zx %r c_out %r h_out %r (F=%d)' %
                          (tuple(zx.shape), tuple(c_out.shape), tuple(h_out.shape), f))
-    for t in (zh, c_prev):
-        if t is not None:
-            _check_f32(t)
+    if c_prev is not None:
+        _check_f32(c_prev)
+    if zh is not None and (zh.dtype != zx.dtype or not zh.is_contiguous()):
+        raise ValueError('convlstm_gates: zh must be stored like zx')
     nul = ctypes.c_void_p(0)
     _lib.check(_lib.lib.dlwp_convlstm_gates(_lib.handle(_dev(zx)), _ptr(zx), _ptr(zh) if zh is not None else nul,
                                             _ptr(c_prev) if c_prev is not None else nul, _ptr(c_out), _ptr(h_out), n,
                                             int(f), h * w, int(h_c_off), h_out.shape[1], int(act), int(rec_act),
-                                            _lib.dtype_io(_lib.F32, storage_code(h_out)), _stream(zx)))
+                                            _lib.dtype_io(storage_code(zx), storage_code(h_out)), _stream(zx)))
     return h_out
 
 

@@ -145,25 +145,23 @@ class Plan(object):
 
     def bf16_buffers(self):
         """Scratch buffers that may be stored as bfloat16 (config 4: bf16 activations between the layers): written by a
-        Conv2D, by the ConvLSTM2D cell update (the h sequence) or by a max-pooling of such a buffer, and read only by
-        convolutions / max-pooling.  Model inputs and outputs, the ConvLSTM2D gate pre-activations and cell state, and
-        anything a copy / pad / up-sampling kernel touches stay float32."""
+        convolution (Conv2D output, ConvLSTM2D gate pre-activations), by the ConvLSTM2D cell update (the h sequence) or
+        by a max-pooling of such a buffer, and read only by convolutions / max-pooling / the cell update.  Model inputs
+        and outputs, the ConvLSTM2D cell state, and anything a copy / pad / up-sampling kernel touches stay float32."""
         ok = {}
         for op in self.ops:
             for b, role in ((op.src, 'r'), (op.dst, 'w')):
-                if b < 0:
-                    continue
-                if op.kind == 'conv':
-                    good = role == 'r' or not isinstance(op.layer, L._ConvPart)   # zx / zh stay float32
-                elif op.kind == 'lstm':
-                    good = role == 'w'                                            # h may be bf16, zx may not
-                else:
-                    good = op.kind == 'maxpool'
-                ok[b] = ok.get(b, True) and good
+                if b >= 0:
+                    ok[b] = ok.get(b, True) and op.kind in ('conv', 'maxpool', 'lstm')
             if op.kind == 'lstm':
-                for b in op.aux:                                                  # zh, c_prev, c_out
+                zh, cp, co = op.aux
+                for b in (cp, co):                                                # the cell state stays float32
                     if b is not None and b >= 0:
                         ok[b] = False
+        for op in self.ops:                                                       # zx and zh of a step: the same type
+            if op.kind == 'lstm' and op.aux[0] is not None and op.src >= 0 and op.aux[0] >= 0:
+                both = ok.get(op.src, False) and ok.get(op.aux[0], False)
+                ok[op.src] = ok[op.aux[0]] = both
         changed = True
         while changed:                  # a pooled copy is bf16 only if its source is (and vice versa)
             changed = False

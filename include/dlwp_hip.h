@@ -41,6 +41,8 @@ extern "C" {
 #define DLWP_DTYPE_IO(in, out) (0x10000 | (in) | ((out) << 8))   /* input / output storage of one launch */
 #define DLWP_DTYPE_IN(d)  (((d) & 0x10000) ? ((d) & 0xff) : (d))
 #define DLWP_DTYPE_OUT(d) (((d) & 0x10000) ? (((d) >> 8) & 0xff) : (d))
+#define DLWP_COMPUTE_BF16 0x20000   /* OR-ed into a convolution's dtype: a float32-stored INPUT may be rounded to bfloat16
+                                     * so that the layer runs on the bf16 matrix cores (config 4's first layers)        */
 
 /* per-axis halo modes */
 #define DLWP_PAD_ZERO 0   /* keras.layers.ZeroPadding2D                                  (examples/train.py:163)   */
@@ -199,7 +201,8 @@ int dlwp_series_merge_time(dlwp_handle_t, const void* series, void* out, int t, 
  *      (h = c = 0).   c = rec(z_f)*c_prev + rec(z_i)*act(z_c);  h = rec(z_o)*act(c).   c_out: dense (n, F, h*w); h is
  *      written to channels [h_c_off, +F) of an h_c_total-channel buffer (the return_sequences output (T*F, h, w)).
  *      act: DLWP_ACT_*; rec_act: 0 = hard_sigmoid (Keras default), 1 = sigmoid.  dtype: DLWP_F32, or
- *      DLWP_DTYPE_IO(DLWP_F32, DLWP_BF16) = h stored as bfloat16 (zx, zh, c stay float32).                             */
+ *      DLWP_DTYPE_IO(z, h) = storage of the gate pre-activations zx / zh and of h (DLWP_F32 | DLWP_BF16 each); the cell
+ *      state c and the arithmetic are float32.                                                                        */
 int dlwp_convlstm_gates(dlwp_handle_t, const void* zx, const void* zh, const void* c_prev, void* c_out, void* h_out,
                         int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act, int dtype, void* stream);
 /* backward of the cell update (one step of back-propagation through time behind DLWPNeuralNet.fit on the recurrent
@@ -230,8 +233,8 @@ typedef struct {
   dlwp_conv2d conv;         /* DLWP_OP_CONV2D; for DLWP_OP_COPYCH: in_c_off/in_c_total/out_c_off/out_c_total */
   dlwp_pad2d pad;           /* DLWP_OP_PAD2D (NHWC: xs = (n,1,h,w) and conv.in_c_total = channels)          */
   int aux[4];               /* DLWP_OP_LSTM_GATES: src = zx, dst = h buffer (window conv.out_c_off/out_c_total), xs =
-                             * (n, F, h, w), aux = {zh | -1000, c_prev | -1000, c_out, rec_act + 256 * (1 if the h buffer
-                             * is stored as bfloat16)}, conv.act = activation.
+                             * (n, F, h, w), aux = {zh | -1000, c_prev | -1000, c_out, rec_act + 256 * (h buffer stored as
+                             * bfloat16) + 512 * (zx / zh stored as bfloat16)}, conv.act = activation.
                              * DLWP_OP_CONV2D / DLWP_OP_MAXPOOL2: aux[0] = storage dtype of this op's tensors (DLWP_F32,
                              * DLWP_BF16 or DLWP_DTYPE_IO(in, out)); the rollout's own dtype describes state and series */
 } dlwp_op;

@@ -274,17 +274,21 @@ def zero_padding3d(x, padding, data_format='channels_first'):
 
 
 def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', activation='tanh',
-                recurrent_activation='hard_sigmoid', return_sequences=True, bf16_h=False, bf16_recurrent_kernel=False):
+                recurrent_activation='hard_sigmoid', return_sequences=True, bf16_storage=False, bf16_kernels=()):
     """x: (N, T, C, H, W) channels_first, already padded for the 'valid' input convolution.  kernel (kh,kw,C,4F),
     recurrent_kernel (kh,kw,F,4F), bias (4F,); gate order i, f, c, o.  Per step (ConvLSTM2DCell.call):
         z  = conv(x_t, kernel, dilation, padding) + bias + conv(h_{t-1}, recurrent_kernel, 'same', no dilation)
         i, f, o = rec_act(z_i), rec_act(z_f), rec_act(z_o);  c_t = f*c_{t-1} + i*act(z_c);  h_t = o*act(c_t)
     with h_{-1} = c_{-1} = 0.  Returns (N, T, F, Ho, Wo) or the last h (N, F, Ho, Wo).
-    bf16_h / bf16_recurrent_kernel: the product's config-4 storage -- every h_t rounded to bfloat16 when it is stored
-    (c_t stays float32) and the recurrent kernel rounded to bfloat16 (bf16 matrix cores on the recurrent convolution)."""
+    The product's config-4 mode: bf16_storage -- the gate pre-activations conv(x_t) + bias and conv(h_{t-1}) and every h_t
+    are rounded to bfloat16 when they are stored (c_t and the gate arithmetic stay float32); bf16_kernels -- which of the
+    two convolutions ('kernel', 'recurrent') run on the bf16 matrix cores: their kernel and input are rounded to bf16."""
     x = np.asarray(x, dtype=np.float64)
-    if bf16_recurrent_kernel:
+    if 'kernel' in bf16_kernels:
+        kernel, x = round_bf16(kernel), round_bf16(x)
+    if 'recurrent' in bf16_kernels:
         recurrent_kernel = round_bf16(recurrent_kernel)
+    rnd = round_bf16 if bf16_storage else (lambda v: v)
     n, t_len = x.shape[:2]
     kh, kw, _, f4 = kernel.shape
     f = f4 // 4
@@ -297,19 +301,17 @@ def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', 
         if padding == 'same':
             ph, pw = dilation * (kh - 1), dilation * (kw - 1)
             xt = np.pad(xt, ((0, 0), (0, 0), (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)))
-        z = conv2d(xt, kernel, bias, dilation, 'linear')
+        z = rnd(conv2d(xt, kernel, bias, dilation, 'linear'))
         if h is not None:
             hp = np.pad(h, ((0, 0), (0, 0), ((rkh - 1) // 2, rkh - 1 - (rkh - 1) // 2),
                             ((rkw - 1) // 2, rkw - 1 - (rkw - 1) // 2)))
-            z = z + conv2d(hp, recurrent_kernel, None, 1, 'linear')
+            z = z + rnd(conv2d(hp, recurrent_kernel, None, 1, 'linear'))
         zi, zf, zc, zo = z[:, :f], z[:, f:2 * f], z[:, 2 * f:3 * f], z[:, 3 * f:]
         c_new = rec(zi) * activate(zc, activation)
         if c is not None:
             c_new = c_new + rec(zf) * c
         c = c_new
-        h = rec(zo) * activate(c, activation)
-        if bf16_h:
-            h = round_bf16(h)
+        h = rnd(rec(zo) * activate(c, activation))
         outs.append(h)
     return np.stack(outs, axis=1) if return_sequences else h
 
@@ -366,12 +368,13 @@ def round_bf16(a):
     return np.where(np.isnan(f), np.nan, out)
 
 
-def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_weights=(), bf16_h=False):
+def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_weights=(), bf16_lstm=None):
     """Execute a sequential stack exactly as the reference graph is laid out (one op per layer, unfused).
     bf16_activations: every Conv2D output except the model output is rounded to bfloat16 (the product's config-4 storage);
     bf16_weights: indices (among the weighted layers) of the Conv2D layers whose kernel is rounded to bfloat16 as well
-    (the layers the product runs on the bf16 matrix cores; for a ConvLSTM2D: its recurrent kernel); bf16_h: the ConvLSTM2D
-    hidden state is stored as bfloat16."""
+    and whose input is rounded to bfloat16 (a no-op unless it is the float32 model input): the layers the product runs on
+    the bf16 matrix cores; bf16_lstm: None, or the subset of ('kernel', 'recurrent') of the ConvLSTM2D convolutions that
+    run on the bf16 matrix cores -- the ConvLSTM2D then also stores zx, zh and h as bfloat16 (conv_lstm2d)."""
     x = np.asarray(x, dtype=np.float64)
     wi = 0
     n_weighted = sum(1 for nm, _, _ in layers if nm in ('Conv2D', 'ConvLSTM2D'))
@@ -388,7 +391,7 @@ def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_wei
             _, _, dil, act = _conv_args(args, kwargs)
             w, b = weights[wi]
             if wi in bf16_weights:
-                w = round_bf16(w)
+                w, x = round_bf16(w), round_bf16(x)
             wi += 1
             x = conv2d(x, w, b, dil, act or 'linear')
             if bf16_activations and wi < n_weighted:
@@ -403,7 +406,7 @@ def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_wei
             wi += 1
             x = conv_lstm2d(x, k, r, b, dil, kwargs.get('padding', 'valid'), act or 'tanh',
                             kwargs.get('recurrent_activation', 'hard_sigmoid'), kwargs.get('return_sequences', False),
-                            bf16_h=bf16_h, bf16_recurrent_kernel=(wi - 1) in bf16_weights)
+                            bf16_storage=bf16_lstm is not None, bf16_kernels=bf16_lstm or ())
         elif name == 'MaxPooling2D':
             x = maxpool2(x)
         elif name == 'UpSampling2D':

@@ -203,7 +203,7 @@ def test_conv2d_every_compiled_tile_configuration(ops):
     problems = {}
     try:
         for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds) in enumerate(cfgs):
-            if pool == 2:
+            if pool >= 2:
                 continue                                # bf16 matrix-core instances: test_conv2d_bf16_mfma_* below
             cmax = 16 // (-bnf) if bnf < 0 else 0       # packed-N instances cover cout <= 16/S
             wino = fa == 0                              # Winograd instances: whole chunks of 8 in / 32 out channels
@@ -320,6 +320,19 @@ def test_convlstm_gates_match_oracle(ops, n, f, h, w, first, rec):
                        h_c_off=f, act=ops.ACT_TANH, rec_act=ops.REC_HARD_SIGMOID if rec == 'hard_sigmoid' else ops.REC_SIGMOID)
     assert torch.equal(c16, c_out)
     assert torch.equal(h16, h_out.to(torch.bfloat16))
+    # gate pre-activations stored as bfloat16 too: the float32 arithmetic on the rounded values
+    zx16 = dev(zx).to(torch.bfloat16)
+    zh16 = None if zh is None else dev(zh).to(torch.bfloat16)
+    cz = torch.empty((n, f, h, w), device='cuda')
+    hz = torch.full((n, 3 * f, h, w), 7.0, device='cuda', dtype=torch.bfloat16)
+    ops.convlstm_gates(zx16, zh16, None if cp is None else dev(cp), cz, hz, f, h_c_off=f, act=ops.ACT_TANH,
+                       rec_act=ops.REC_HARD_SIGMOID if rec == 'hard_sigmoid' else ops.REC_SIGMOID)
+    z = np_ref.round_bf16(zx) + (0 if zh is None else np_ref.round_bf16(zh))
+    c_want = r(z[:, :f]) * np.tanh(z[:, 2 * f:3 * f]) + (0 if cp is None else r(z[:, f:2 * f]) * cp)
+    h_want = r(z[:, 3 * f:]) * np.tanh(c_want)
+    assert np.abs(host(cz) - c_want).max() < 2e-6
+    hg = hz.to(torch.float32).cpu().numpy()[:, f:2 * f]
+    assert np.all(np.abs(hg - h_want) <= 2.0 ** -8 * np.abs(h_want) + 2e-6)
 
 
 # ----------------------------------------------------------------------------------------------------------------- #
@@ -337,10 +350,10 @@ BF16_CASES = [
 ]
 
 
-def _weights_as_multiplied(ops, wt, x_shape, cd, in16, out16):
+def _weights_as_multiplied(ops, wt, x_shape, cd, in16, out16, compute_bf16=False):
     """The kernel the oracle has to use: rounded to bfloat16 when the layer runs on the bf16 matrix cores."""
     from dlwp_amd import _lib
-    dt = _lib.dtype_io(_lib.BF16 if in16 else _lib.F32, _lib.BF16 if out16 else _lib.F32)
+    dt = _lib.dtype_io(_lib.BF16 if in16 else _lib.F32, _lib.BF16 if out16 else _lib.F32, compute_bf16)
     if ops.uses_bf16_weights(x_shape, cd, dt):
         return np_ref.round_bf16(wt), True
     return wt, False
@@ -451,6 +464,49 @@ def test_conv2d_bf16_mfma_pooling_epilogue(ops, shape, out16):
         _check_conv(ops, got, want, 'bf16 mfma pooled')
 
 
+IN32_CASES = [
+    # (n, cin, c_off, c_total, h, w, cout, k, dil, pads, mode_h, mode_w, act, src, pool, out16)
+    (2, 6, 6, 12, 13, 20, 96, 3, 2, (2, 2, 2, 2), 0, 1, 'linear', 0, False, True),   # ConvLSTM2D input conv, step 1 of 2
+    (2, 4, 0, 4, 16, 36, 32, 3, 2, (2, 2, 2, 2), 0, 1, 'tanh', 0, True, True),       # U-Net first layer + pooling
+    (1, 8, 0, 8, 9, 14, 20, 5, 1, (2, 2, 2, 2), 0, 1, 'tanh', 0, False, False),      # 5x5, float32 out
+    (2, 5, 0, 5, 7, 10, 33, 3, 1, (1, 1, 1, 1), 2, 0, 'relu', 1, False, True),       # up-sampled source, ragged
+    (1, 20, 0, 20, 11, 18, 16, 3, 1, (1, 1, 1, 1), 0, 1, 'tanh', 0, False, True),    # two 16-channel chunks
+]
+
+
+@pytest.mark.parametrize('case', IN32_CASES)
+def test_conv2d_bf16_mfma_on_float32_input(ops, case):
+    """DLWP_COMPUTE_BF16: a float32-stored input (the model state in config 4) is rounded to bfloat16 by the loader and
+    the layer runs on the bf16 matrix cores.  Oracle: the float64 convolution of the ROUNDED input and kernel."""
+    n, cin, c_off, c_tot, h, w, cout, k, dil, pads, mh, mw, act, src, pool, out16 = case
+    rng = np.random.default_rng(cin * 7 + cout + h)
+    xfull = rng.standard_normal((n, c_tot, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    actc = {'tanh': ops.ACT_TANH, 'relu': ops.ACT_RELU, 'linear': ops.ACT_LINEAR}[act]
+    cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, mh, mw), actc, in_c_off=c_off, in_c_total=c_tot,
+                       src_mode=src, out_pool=1 if pool else 0)
+    w_ref, on16 = _weights_as_multiplied(ops, wt, (n, cin, h, w), cd, False, out16, compute_bf16=True)
+    assert on16
+    assert not _weights_as_multiplied(ops, wt, (n, cin, h, w), cd, False, out16)[1]      # only when the caller allows it
+    want = _conv_ref(np_ref.round_bf16(xfull[:, c_off:c_off + cin]), w_ref, b, dil, pads, mh, mw, act, src)
+    if pool:
+        want = np_ref.maxpool2(want)
+    out = torch.full(want.shape, float('nan'), dtype=torch.bfloat16 if out16 else torch.float32, device='cuda')
+    ops.conv2d(dev(xfull), dev(wt), dev(b), cd, out=out, x_channels=cin, compute_bf16=True)
+    got = out.to(torch.float32).cpu().numpy()
+    if out16:
+        assert np.all(np.abs(got - want) <= 2.0 ** -8 * np.abs(want) + 2e-6)
+        assert np.mean(got == np_ref.round_bf16(want)) > 0.99
+    else:
+        _check_conv(ops, got, want, 'bf16 mfma, float32 in')
+    # without the flag the same call keeps the float32 arithmetic on the unrounded input
+    out2 = torch.empty(want.shape, dtype=torch.float32, device='cuda')
+    ops.conv2d(dev(xfull), dev(wt), dev(b), cd, out=out2, x_channels=cin)
+    exact = _conv_ref(xfull[:, c_off:c_off + cin], wt, b, dil, pads, mh, mw, act, src)
+    _check_conv(ops, out2.cpu().numpy(), np_ref.maxpool2(exact) if pool else exact, 'fp32 families')
+
+
 def test_conv2d_bf16_mfma_every_compiled_tile_configuration(ops):
     rng = np.random.default_rng(77)
     cfgs = ops.conv_configs()
@@ -458,24 +514,26 @@ def test_conv2d_bf16_mfma_every_compiled_tile_configuration(ops):
     seen = 0
     try:
         for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds) in enumerate(cfgs):
-            if pool != 2:
+            if pool < 2:
                 continue
             seen += 1
-            key = (ks, dil)
+            in32 = pool == 3                                  # float32-stored input, rounded by the loader
+            key = (ks, dil, in32)
             if key not in problems:
                 n, cin, h, w, cout = 2, 52, 19, 50, 36        # ragged tiles, ragged chunks for CK = 16 / 32 / 48
-                x = np_ref.round_bf16(rng.standard_normal((n, cin, h, w))).astype(np.float32)
+                x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+                xr = np_ref.round_bf16(x).astype(np.float32)
                 wt = np_ref.glorot_uniform((ks, ks, cin, cout), rng)
                 b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
                 p = dil * (ks - 1) // 2
                 pads = (p, p, p, p)
-                want = _conv_ref(x, np_ref.round_bf16(wt), b, dil, pads, 0, 1, 'tanh', 0)
-                problems[key] = (dev(x).to(torch.bfloat16), dev(wt), dev(b), pads, want, cout)
+                want = _conv_ref(xr, np_ref.round_bf16(wt), b, dil, pads, 0, 1, 'tanh', 0)
+                problems[key] = (dev(x) if in32 else dev(xr).to(torch.bfloat16), dev(wt), dev(b), pads, want, cout)
             xd, wd, bd, pads, want, cout = problems[key]
             ops.force_conv_config(i)
             cd = ops.make_conv(cout, ks, ks, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH)
             out = torch.empty(want.shape, dtype=torch.float32, device='cuda')
-            ops.conv2d(xd, wd, bd, cd, out=out)
+            ops.conv2d(xd, wd, bd, cd, out=out, compute_bf16=in32)
             _check_conv(ops, out.cpu().numpy(), want, 'config %d %r' % (i, cfgs[i]))
     finally:
         ops.force_conv_config(-1)

@@ -17,6 +17,7 @@ from dlwp_amd import ops  # noqa: E402
 def layers(h, w):
     # (name, cin, cout, k, dil, src_mode, stored_h, stored_w, zero_cols)
     return [
+        ('lstm_in 6->96 d2 f32in', 6, 96, 3, 2, 0, h, w, False),
         ('lstm_rec 24->96', 24, 96, 3, 1, 0, h, w, True),
         ('conv2d_1 48->32 d2', 48, 32, 3, 2, 0, h, w, False),
         ('conv2d_2 32->64', 32, 64, 3, 1, 0, h // 2, w // 2, False),
@@ -52,7 +53,10 @@ def main():
     rng = np.random.default_rng(0)
     res = {}
     for name, cin, cout, k, dil, src, sh, sw, zc in layers(h, w):
-        x = torch.from_numpy(rng.standard_normal((a.batch, cin, sh, sw)).astype(np.float32)).cuda().to(torch.bfloat16)
+        f32in = 'f32in' in name
+        x = torch.from_numpy(rng.standard_normal((a.batch, cin, sh, sw)).astype(np.float32)).cuda()
+        if not f32in:
+            x = x.to(torch.bfloat16)
         wt = torch.from_numpy((rng.standard_normal((k, k, cin, cout)) * 0.05).astype(np.float32)).cuda()
         b = torch.zeros(cout, device='cuda')
         p = dil * (k - 1) // 2
@@ -64,15 +68,15 @@ def main():
         byts = 2.0 * (x.numel() + out.numel())
         row = {}
         prev = ops.set_bf16_mfma(False)
-        row['fp32 families'] = timed(lambda: ops.conv2d(x, wt, b, cd, out=out), a.iters)
+        row['fp32 families'] = timed(lambda: ops.conv2d(x, wt, b, cd, out=out, compute_bf16=f32in), a.iters)
         ops.set_bf16_mfma(True)
-        row['bf16 heuristic'] = timed(lambda: ops.conv2d(x, wt, b, cd, out=out), a.iters)
+        row['bf16 heuristic'] = timed(lambda: ops.conv2d(x, wt, b, cd, out=out, compute_bf16=f32in), a.iters)
         for i, c in enumerate(cfgs):
-            if c[8] != 2 or (c[0], c[1]) != (k, dil):
+            if c[8] != (3 if f32in else 2) or (c[0], c[1]) != (k, dil):
                 continue
             ops.force_conv_config(i)
             try:
-                row['cfg%d %r' % (i, c[2:8])] = timed(lambda: ops.conv2d(x, wt, b, cd, out=out), a.iters)
+                row['cfg%d %r' % (i, c[2:8])] = timed(lambda: ops.conv2d(x, wt, b, cd, out=out, compute_bf16=f32in), a.iters)
             except Exception as e:      # noqa: BLE001
                 row['cfg%d' % i] = str(e)
             finally:

@@ -63,7 +63,9 @@ def main():
     for op, desc in zip(plan.ops, ex._descriptors()):
         src, dst = res(op.src), res(op.dst)
         if op.kind == 'conv':
-            fn = lambda: ops.conv2d(src, op.layer.kernel, op.layer.bias, desc, out=dst, x_channels=op.xs[0])  # noqa: E731
+            c16 = op.dst in ex._bf16 and op.src not in ex._bf16      # as Executor.run: float32 state rounded by the loader
+            fn = lambda: ops.conv2d(src, op.layer.kernel, op.layer.bias, desc, out=dst, x_channels=op.xs[0],  # noqa: E731
+                                    compute_bf16=c16)
         elif op.kind == 'lstm':
             zh, cp, co = op.aux
             fn = lambda: ops.convlstm_gates(src, res(zh) if zh is not None else None, res(cp) if cp is not None else None,  # noqa: E731
@@ -97,7 +99,9 @@ def main():
             hw = op.xs[1] * op.xs[2]
             if op.kind == 'lstm':
                 zh, cp, co = op.aux
-                nb = a.members * hw * f * 4.0 * ((8 if zh is not None else 4) + (1 if cp is not None else 0) + 2)
+                zsz, hsz = src.element_size(), dst.element_size()      # zx / zh and h storage; the cell state is float32
+                nb = a.members * hw * f * ((8 if zh is not None else 4) * zsz + (1 if cp is not None else 0) * 4.0 +
+                                           4.0 + hsz)
             else:
                 nb = float(src.numel() * src.element_size() + dst.numel() * dst.element_size()) if op.kind == 'maxpool' \
                     else 2.0 * a.members * f * hw * 4.0
