@@ -198,6 +198,9 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void*
   DLWP_CHECK_ARG(ws_bytes >= (size_t)c.nslabs * wn * sizeof(float), "dlwp_conv2d_bwd_weight: workspace %zu < %zu", ws_bytes,
                  (size_t)c.nslabs * wn * sizeof(float));
   DLWP_CHECK_ARG(xs.n > 0, "dlwp_conv2d_bwd_weight: empty batch");
+  // the kernel addresses a sample's channel window with 32-bit byte offsets
+  DLWP_CHECK_ARG((long long)xs.c * xs.h * xs.w < (1ll << 29) && (long long)cd->cout * ys.h * ys.w < (1ll << 29),
+                 "dlwp_conv2d_bwd_weight: a sample's tensors must stay below 2 GiB");
   const WgradKernelEntry& e = k_wgrad[c.idx];
   if (!g_wg_prepared[c.idx]) {
     std::lock_guard<std::mutex> lock(g_wg_mutex);

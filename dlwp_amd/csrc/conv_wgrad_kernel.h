@@ -11,8 +11,9 @@
 // share of the (image, spatial tile) list ("split-K over pixels") and writes ONE partial slab at the end; a second
 // kernel sums the slabs in a fixed order -> deterministic, atomic-free.
 // LDS plane strides are == 2 (mod 32) floats: lanes (ci, k) of one ds_read_b32 group then hit 32 distinct banks.
-// All global loads are unconditional on clamped addresses (no exec-mask branch per load); fragments are
-// double-buffered in registers with the reads of pixel quad q+1 pinned in front of the MFMAs of quad q.
+// All global loads are raw buffer loads (hardware zeros for halo positions and ragged channels, no exec-mask branch, no
+// select); fragments are double-buffered in registers with the reads of pixel quad q+1 pinned in front of the MFMAs of
+// quad q.
 #pragma once
 #include "conv_fwd_kernel.h"
 
@@ -91,75 +92,117 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
   const int wn = wave % C::NT, wp = wave / C::NT;
   const int b_lane = (wn * 16 + (lane & 15)) * C::PSZ + (lane >> 4);
 
-  // tile-independent part of the loader bookkeeping
-  int x_lr[C::NPOS], x_lc[C::NPOS];
+  // ---- loader.  The matrix pipe and the vector ALU of a SIMD do not overlap for fp32 MFMA, so the
+  //      per-tile vector work is kept minimal: everything tile-independent is precomputed (LDS addresses, the dz offset of
+  //      every element a thread owns), the tile walk is incremental (no division), all fetches are raw buffer loads with a
+  //      per-sample descriptor -- channels past Cin / Cout and halo positions fall outside the descriptor or get an
+  //      out-of-range offset and come back as hardware zeros, so nothing is clamped or selected afterwards.
+  int x_lr[C::NPOS], x_lc[C::NPOS], x_lds[C::NPOS];
 #pragma unroll
   for (int k = 0; k < C::NPOS; ++k) {
     const int s = min(tid + k * C::NTHREADS, C::LR * C::LC - 1);  // surplus threads duplicate the last position
     x_lr[k] = s / C::LC;
     x_lc[k] = s - x_lr[k] * C::LC;
+    x_lds[k] = x_lr[k] * C::LC + x_lc[k];
   }
-  int z_co[C::NZ], z_r[C::NZ], z_c[C::NZ];
+  unsigned z_off[C::NZ];   // byte offset of element k inside the (sample, cout tile) window of dz, relative to the tile origin
+  int z_lds[C::NZ], z_r[C::NZ], z_c[C::NZ];
 #pragma unroll
   for (int k = 0; k < C::NZ; ++k) {
     const int e = tid + k * C::NTHREADS;
-    z_co[k] = e / C::P;
-    const int p = e - z_co[k] * C::P;
+    const int zc = e / C::P;
+    const int p = e - zc * C::P;
     z_r[k] = p / C::TW;
     z_c[k] = p - z_r[k] * C::TW;
+    z_off[k] = ((unsigned)zc * (unsigned)oplane + (unsigned)(z_r[k] * a.Wo + z_c[k])) * 4u;
+    z_lds[k] = zc * C::PSZ + z_r[k] * C::TW + z_c[k];
   }
+  const unsigned plane_bytes = (unsigned)plane * 4u, oplane_bytes = (unsigned)oplane * 4u;
+  const int x_chans = min(C::CI, a.Cin - ci0), z_chans = min(16 * C::NT, a.Cout - co0);
+  // a halo coordinate wraps at most once when halo + tile fit the axis; tiny axes take the general (%) mapping
+  const bool fast_h = a.H >= C::LR + a.pad_top, fast_w = a.W >= C::LC + a.pad_left;
+  auto map_axis = [&](int p, int n, int mode, bool fast) -> int {
+    if (!fast) return dlwp_map_coord(p, n, mode);
+    if (mode == DLWP_PAD_ZERO) return (unsigned)p < (unsigned)n ? p : -1;
+    if (mode == DLWP_PAD_EDGE) return min(max(p, 0), n - 1);
+    return p < 0 ? p + n : (p >= n ? p - n : p);
+  };
 
   // register-staged pipeline over tiles: the loads of tile t+1 are in flight under tile t's MFMA loop
   float xv[C::NPOS][C::CI], zv[C::NZ];
-  bool xok[C::NPOS], zok[C::NZ];
-  auto prefetch = [&](int tile) {
-    int q = tile;
-    const int tw = q % a.tiles_w;
+  int tw_i, th_i, n_i;   // the tile the next prefetch fetches (incremental walk)
+  {
+    int q = t_begin;
+    tw_i = q % a.tiles_w;
     q /= a.tiles_w;
-    const int th = q % a.tiles_h;
-    const int n = q / a.tiles_h;
-    const int i0 = th * C::TH, j0 = tw * C::TW;
-    const float* xn = a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane;
+    th_i = q % a.tiles_h;
+    n_i = q / a.tiles_h;
+  }
+  auto prefetch = [&]() {
+    const int i0 = th_i * C::TH, j0 = tw_i * C::TW;
+    const float* xn = a.x + ((long long)n_i * a.in_c_total + a.in_c_off + ci0) * plane;
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)x_chans * plane_bytes, 0x00020000);
 #pragma unroll
     for (int k = 0; k < C::NPOS; ++k) {
-      const int rs = dlwp_map_coord(i0 + x_lr[k] - a.pad_top, a.H, a.mode_h);
-      const int cs = dlwp_map_coord(j0 + x_lc[k] - a.pad_left, a.W, a.mode_w);
-      xok[k] = rs >= 0 && cs >= 0;
-      int g = 0;
-      if (xok[k]) {
-        if (a.src_mode == DLWP_SRC_UPSAMPLE2) g = (rs >> 1) * a.Ws + (cs >> 1);
-        else if (a.src_mode == DLWP_SRC_MAXPOOL2) g = (rs * 2) * a.Ws + cs * 2;
-        else g = rs * a.Ws + cs;
-      }
+      const int rs = map_axis(i0 + x_lr[k] - a.pad_top, a.H, a.mode_h, fast_h);
+      const int cs = map_axis(j0 + x_lc[k] - a.pad_left, a.W, a.mode_w, fast_w);
+      int g;
+      if (a.src_mode == DLWP_SRC_UPSAMPLE2) g = (rs >> 1) * a.Ws + (cs >> 1);
+      else if (a.src_mode == DLWP_SRC_MAXPOOL2) g = (rs * 2) * a.Ws + cs * 2;
+      else g = rs * a.Ws + cs;
+      const unsigned goff = (rs >= 0 && cs >= 0) ? (unsigned)g * 4u : 0x7ffffff0u;
 #pragma unroll
       for (int ci = 0; ci < C::CI; ++ci) {
-        const float* sp = xn + (long long)min(ci0 + ci, a.Cin - 1) * plane + g;
-        if (a.src_mode == DLWP_SRC_MAXPOOL2) xv[k][ci] = fmaxf(fmaxf(sp[0], sp[1]), fmaxf(sp[a.Ws], sp[a.Ws + 1]));
-        else xv[k][ci] = sp[0];
+        const unsigned so = (unsigned)ci * plane_bytes;
+        if (a.src_mode == DLWP_SRC_MAXPOOL2) {
+          const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff, so, 0));
+          const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff + 4u, so, 0));
+          const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff + a.Ws * 4u, so, 0));
+          const float v3 =
+              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff + a.Ws * 4u + 4u, so, 0));
+          xv[k][ci] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+        } else {
+          xv[k][ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff, so, 0));
+        }
       }
     }
-    const float* zn = a.dz + ((long long)n * a.dz_c_total + a.dz_c_off) * oplane;
+    const float* zn = a.dz + ((long long)n_i * a.dz_c_total + a.dz_c_off + co0) * oplane;
+    const __amdgpu_buffer_rsrc_t z_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)zn, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
+    const unsigned tile_off = (unsigned)(i0 * a.Wo + j0) * 4u;
+    if (i0 + C::TH <= a.Ho && j0 + C::TW <= a.Wo) {   // interior tile: no per-element work at all
 #pragma unroll
-    for (int k = 0; k < C::NZ; ++k) {
-      const int oh = i0 + z_r[k], ow = j0 + z_c[k];
-      zok[k] = oh < a.Ho && ow < a.Wo && co0 + z_co[k] < a.Cout;
-      const int co = min(co0 + z_co[k], a.Cout - 1);
-      zv[k] = zn[(long long)co * oplane + (long long)min(oh, a.Ho - 1) * a.Wo + min(ow, a.Wo - 1)];
+      for (int k = 0; k < C::NZ; ++k)
+        zv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, z_off[k], tile_off, 0));
+    } else {
+#pragma unroll
+      for (int k = 0; k < C::NZ; ++k) {
+        const bool ok = i0 + z_r[k] < a.Ho && j0 + z_c[k] < a.Wo;
+        zv[k] = __builtin_bit_cast(float,
+                                   __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? z_off[k] : 0x7ffffff0u, tile_off, 0));
+      }
+    }
+    if (++tw_i == a.tiles_w) {
+      tw_i = 0;
+      if (++th_i == a.tiles_h) {
+        th_i = 0;
+        ++n_i;
+      }
     }
   };
 
-  if (t_begin < t_end) prefetch(t_begin);
+  if (t_begin < t_end) prefetch();
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();  // previous tile consumed
 #pragma unroll
     for (int k = 0; k < C::NPOS; ++k)
 #pragma unroll
-      for (int ci = 0; ci < C::CI; ++ci)
-        xs[ci * C::PSX + x_lr[k] * C::LC + x_lc[k]] = (xok[k] && ci0 + ci < a.Cin) ? xv[k][ci] : 0.f;
+      for (int ci = 0; ci < C::CI; ++ci) xs[ci * C::PSX + x_lds[k]] = xv[k][ci];
 #pragma unroll
-    for (int k = 0; k < C::NZ; ++k) zs[z_co[k] * C::PSZ + z_r[k] * C::TW + z_c[k]] = zok[k] ? zv[k] : 0.f;
+    for (int k = 0; k < C::NZ; ++k) zs[z_lds[k]] = zv[k];
     __syncthreads();
-    if (tile + 1 < t_end) prefetch(tile + 1);
+    if (tile + 1 < t_end) prefetch();
 
     // ---- pixel quads: 1 B fragment + MF A fragments -> MF MFMAs, double-buffered
     float af[2][C::MF], bf[2];

@@ -277,13 +277,22 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 // 4 slab groups; each thread sums its group's slabs (s = g, g+4, ...) with 8 independent loads in flight, the 4 group
 // sums are combined through LDS in a fixed order -> deterministic, atomic-free, 4x the blocks of a one-thread-per-
 // element reduction.
+// Small tensors with thousands of slabs (the 5x5 output layer: 3 200 floats x 4 096 slabs) would leave the chip to a dozen
+// blocks, so the launcher splits the slab list into gridDim.y chunks: chunk y sums slabs [y*cs, (y+1)*cs) IN PLACE into
+// its own first slab (only this block row reads that range), and a second launch sums the gridDim.y chunk sums (slab
+// stride cs*n) into `out`.  Two fixed-order passes: still deterministic.
 template <int VEC>
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                           long long n, int S, int accumulate) {
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(float* slabs_all, float* out_final, long long n, int S_all,
+                                                           long long stride, int cs, int accumulate) {
   typedef float vec_t __attribute__((ext_vector_type(VEC)));
   __shared__ vec_t red[4][64];
   const long long nv = n / VEC;
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  // chunked first pass (cs > 0): this block row's slabs and in-place destination; otherwise all slabs -> out_final
+  const float* slabs = cs > 0 ? slabs_all + (long long)blockIdx.y * cs * stride : slabs_all;
+  const int S = cs > 0 ? min(cs, S_all - (int)blockIdx.y * cs) : S_all;
+  float* out = cs > 0 ? slabs_all + (long long)blockIdx.y * cs * stride : out_final;
+  n = stride;   // distance between consecutive slabs, in floats
   for (long long base = (long long)blockIdx.x * 64; base < nv; base += (long long)gridDim.x * 64) {
     const long long i = base + e;
     vec_t part[8];
@@ -346,12 +355,23 @@ int dlwp_launch_flip_transpose(dlwp_handle_t h, const float* w, float* wt, int k
   return DLWP_OK;
 }
 
-int dlwp_launch_reduce_slabs(dlwp_handle_t h, const float* slabs, float* out, long long n, int S, int accumulate,
+int dlwp_launch_reduce_slabs(dlwp_handle_t h, float* slabs, float* out, long long n, int S, int accumulate,
                              hipStream_t s) {
-  if (n % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0)
-    reduce_slabs_kernel<4><<<grid_for(n, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);   // 64 vec4 / block
-  else
-    reduce_slabs_kernel<1><<<grid_for(n * 4, h->cu_count), 256, 0, s>>>(slabs, out, n, S, accumulate);
+  const bool v4 = n % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0;
+  const int gx = v4 ? grid_for(n, h->cu_count) : grid_for(n * 4, h->cu_count);   // 64 vector elements per block
+  long long stride = n;
+  if (gx < 128 && S >= 64) {   // few elements, many slabs: chunked first pass, in place
+    int Y = 512 / gx;
+    if (Y > S / 16) Y = S / 16;
+    const int cs = (S + Y - 1) / Y;
+    Y = (S + cs - 1) / cs;
+    if (v4) reduce_slabs_kernel<4><<<dim3(gx, Y), 256, 0, s>>>(slabs, nullptr, n, S, n, cs, 0);
+    else reduce_slabs_kernel<1><<<dim3(gx, Y), 256, 0, s>>>(slabs, nullptr, n, S, n, cs, 0);
+    stride = (long long)cs * n;
+    S = Y;
+  }
+  if (v4) reduce_slabs_kernel<4><<<gx, 256, 0, s>>>(slabs, out, n, S, stride, 0, accumulate);
+  else reduce_slabs_kernel<1><<<gx, 256, 0, s>>>(slabs, out, n, S, stride, 0, accumulate);
   DLWP_LAUNCH_CHECK("reduce_slabs_kernel");
   return DLWP_OK;
 }

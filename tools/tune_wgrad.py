@@ -18,11 +18,14 @@ def main():
     ap.add_argument('--grid', default='88x180')
     ap.add_argument('--cin', type=int, default=4)
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--layers', default='')
     a = ap.parse_args()
     h, w = (int(v) for v in a.grid.split('x'))
     cfgs = ops.wgrad_configs()
     rng = np.random.default_rng(0)
     for name, cin, cout, k, dil, src, sh, sw in unet_layers(a.cin, h, w):
+        if a.layers and name not in a.layers.split(','):
+            continue
         x = torch.from_numpy(rng.standard_normal((a.batch, cin, sh, sw)).astype(np.float32)).cuda()
         p = dil * (k - 1) // 2
         cd = ops.make_conv(cout, k, k, dil, ops.make_pad(p, p, p, p, ops.PAD_ZERO, ops.PAD_WRAP), ops.ACT_TANH, src_mode=src)
