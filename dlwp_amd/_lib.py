@@ -113,6 +113,7 @@ _sig('dlwp_conv2d_bwd_data', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _
 _sig('dlwp_conv2d_bwd_weight', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _i, _vp, _sz, _vp])
 _sig('dlwp_conv2d_wgrad_num_configs', [])
 _sig('dlwp_conv2d_wgrad_config_info', [_i, _P(_i), _P(_i)])
+_sig('dlwp_conv2d_wgrad_pick_config', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_wgrad_force_config', [_i])
 _sig('dlwp_act_bwd', [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp])
 _sig('dlwp_bias_grad_workspace', [_i], _sz)

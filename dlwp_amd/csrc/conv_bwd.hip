@@ -7,7 +7,7 @@
 
 int dlwp_launch_flip_transpose(dlwp_handle_t h, const float* w, float* wt, int kh, int kw, int cin, int cout,
                                hipStream_t s);
-int dlwp_launch_reduce_slabs(dlwp_handle_t h, const float* slabs, float* out, long long n, int S, int accumulate,
+int dlwp_launch_reduce_slabs(dlwp_handle_t h, float* slabs, float* out, long long n, int S, int accumulate,
                              hipStream_t s);
 
 namespace {
@@ -51,15 +51,22 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
     const double co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
     const double ci_groups = dlwp_ceil_div(Cin, e.cib);
     const double mfrags = (e.ks * e.ks * e.cib + 15) / 16;
-    // padded MFMA count per image (all waves) + staging traffic (x tile re-read per co tile, dz tile per ci group)
-    const int lr = e.th + e.dil * (e.ks - 1), lc = e.tw + e.dil * (e.ks - 1);
-    const double mfma = tiles * (e.th * e.tw / 4.0) * mfrags * e.nt * co_tiles * ci_groups;
-    const double stage = tiles * co_tiles * ci_groups * ((double)e.cib * lr * lc + 16.0 * e.nt * e.th * e.tw);
+    // Cycles of one (tile, cout tile, channel group) on a CU -- fitted to tools/tune_wgrad.py sweeps with the wide-load
+    // staging (profiles/r1i_wgrad_tile_sweep_b64.txt; within ~6 % on the config-2 layers):
+    //   matrix pipe: every wave issues (pixel quads / PW) x mfrags MFMAs of 32 cycles, waves/4 waves per SIMD;
+    //   staging:     ~22 cycles of the texture-address path per wave-wide load (x: column pairs per channel, dz: quads),
+    //                about 60 % of it not hidden under the MFMAs of the co-resident workgroups;
+    //   fixed:       barriers / tile walk, shared among the resident workgroups (LDS-bound residency).
+    const int lr = e.th + e.dil * (e.ks - 1), lch = (e.tw + e.dil * (e.ks - 1) + 2) / 2;
+    const double t_mfma = 2.0 * e.nt * e.th * e.tw * mfrags;
+    const double loads = (double)dlwp_ceil_div(lr * lch, 64) * e.cib + 16.0 * e.nt * e.th * e.tw / 256.0;
     int resident = (160 * 1024) / e.lds_bytes;
     if (resident > 16 / e.waves) resident = 16 / e.waves;
     if (resident < 1) resident = 1;
-    const double imbalance = (e.waves % 4) ? 1.25 : 1.0;  // 1- and 2-wave workgroups leave SIMDs idle (measured)
-    const double c = mfma * (1.0 + 0.3 / resident) * imbalance + 0.02 * stage;
+    double pen = (e.waves % 4) ? 1.25 : 1.0;   // 1- and 2-wave workgroups leave SIMDs idle (measured)
+    if (mfrags >= 25) pen *= 1.12;               // 100 accumulator registers: one wave per SIMD
+    if (e.nt == 4 && e.tw == 32) pen *= 1.15;    // measured: 59 % matrix-pipe use where the 48-wide tiles reach 70 %
+    const double c = tiles * co_tiles * ci_groups * (t_mfma + 0.6 * 22.0 * loads + 1500.0 / resident) * pen;
     if (best < 0 || c < best_cost) {
       best = i;
       best_cost = c;
@@ -241,7 +248,7 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void*
   const int grid = c.ci_groups * c.co_tiles * c.splits;
   e.launch(a, grid, (hipStream_t)stream);
   DLWP_LAUNCH_CHECK("conv2d_wgrad_mfma_f32");
-  return dlwp_launch_reduce_slabs(h, (const float*)ws, (float*)dw, wn, c.nslabs, accumulate, (hipStream_t)stream);
+  return dlwp_launch_reduce_slabs(h, (float*)ws, (float*)dw, wn, c.nslabs, accumulate, (hipStream_t)stream);
 }
 
 int dlwp_conv2d_wgrad_num_configs(void) { return N_WGRAD; }
@@ -258,6 +265,13 @@ int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes) {
 int dlwp_conv2d_wgrad_force_config(int i) {
   g_forced_wgrad = i;
   return DLWP_OK;
+}
+
+int dlwp_conv2d_wgrad_pick_config(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
+  dlwp_shape4 ys;
+  WgChoice c;
+  if (!h || !cd || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return -1;
+  return pick_wgrad(h, xs.n, xs.c, cd->cout, ys.h, ys.w, cd, &c) ? c.idx : -1;
 }
 
 }  // extern "C"

@@ -164,8 +164,9 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
   // the pair as two bf16 in one dword (column p in the low half)
   auto pair_bits = [&](const xraw_t& v) -> unsigned {
     if constexpr (C::IN32) {
-      const float lo = __builtin_bit_cast(float, v[0]), hi = __builtin_bit_cast(float, ups ? v[0] : v[1]);
-      return pack_bf16x2(lo, hi);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 f = __builtin_bit_cast(f32x2, v);   // (whole vector: bit_cast on a vector ELEMENT is unreliable here)
+      return pack_bf16x2(f[0], ups ? f[0] : f[1]);
     } else {
       return ups ? __builtin_amdgcn_perm(v, v, 0x01000100u) : v;   // up-sampling: both columns are the same element
     }

@@ -17,6 +17,9 @@
 #pragma once
 #include "conv_fwd_kernel.h"
 
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+
 struct WgradArgs {
   const float* x;
   const float* dz;
@@ -37,7 +40,9 @@ struct WgCfg {
   static constexpr int MF = (KS_ * KS_ * CIB_ + 15) / 16;
   static constexpr int WAVES = NT * PW;  // wave = (cout fragment, pixel-quad residue class); PW > 1 -> PW slabs per split
   static constexpr int NTHREADS = WAVES * 64;
-  static constexpr int LR = TH + DIL * (KS - 1), LC = TW + DIL * (KS - 1);
+  // LDS tile: + 2 columns so that it can start on an even source column whatever the left halo (column-pair loads)
+  static constexpr int LR = TH + DIL * (KS - 1), LC = TW + DIL * (KS - 1) + 2;
+  static constexpr int LCH = LC / 2, NPAIR = LR * LCH;
   static constexpr int PSX_RAW = LR * LC;
   static constexpr int PSX = PSX_RAW + (((2 - PSX_RAW % 32) % 32) + 32) % 32;  // == 2 (mod 32)
   static constexpr int P = TH * TW;
@@ -46,12 +51,13 @@ struct WgCfg {
   static constexpr int X_FLOATS = CI * PSX;
   static constexpr int Z_FLOATS = 16 * NT * PSZ;
   static constexpr int LDS_BYTES = (X_FLOATS + Z_FLOATS) * 4;
-  static constexpr int NPOS = (LR * LC + NTHREADS - 1) / NTHREADS;
-  static constexpr int NZ = (16 * NT * P + NTHREADS - 1) / NTHREADS;  // dz elements per thread per tile (= 16*P/64)
+  static constexpr int NPP = (NPAIR + NTHREADS - 1) / NTHREADS;       // x column pairs per thread per tile
+  static constexpr int NZ4 = (16 * NT * P) / (4 * NTHREADS);          // dz pixel quads per thread per tile
   static constexpr int QUADS = P / 4;
   static_assert(TW % 4 == 0, "pixel quads must not straddle rows");
   static_assert(QUADS % (2 * PW) == 0, "the quad loop is unrolled by 2 per pixel-wave");
-  static_assert((16 * NT * P) % NTHREADS == 0, "dz tile must divide evenly over the threads");
+  static_assert((16 * NT * P) % (4 * NTHREADS) == 0, "dz tile must divide evenly over the threads, in pixel quads");
+  static_assert(TW % 4 == 0 && LC % 2 == 0, "quads / pairs must not straddle rows");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
 
@@ -87,49 +93,57 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
     const int m = f * 16 + (lane & 15);
     const int tap = m / C::CI < C::TAPS ? m / C::CI : 0, ci = m % C::CI;
     const int u = tap / C::KS, v = tap - u * C::KS;
-    a_off[f] = ci * C::PSX + u * C::DIL * C::LC + v * C::DIL + (lane >> 4);
+    a_off[f] = ci * C::PSX + u * C::DIL * C::LC + v * C::DIL + (lane >> 4) + (a.pad_left & 1);
   }
   const int wn = wave % C::NT, wp = wave / C::NT;
   const int b_lane = (wn * 16 + (lane & 15)) * C::PSZ + (lane >> 4);
 
-  // ---- loader.  The matrix pipe and the vector ALU of a SIMD do not overlap for fp32 MFMA, so the
-  //      per-tile vector work is kept minimal: everything tile-independent is precomputed (LDS addresses, the dz offset of
-  //      every element a thread owns), the tile walk is incremental (no division), all fetches are raw buffer loads with a
-  //      per-sample descriptor -- channels past Cin / Cout and halo positions fall outside the descriptor or get an
-  //      out-of-range offset and come back as hardware zeros, so nothing is clamped or selected afterwards.
-  int x_lr[C::NPOS], x_lc[C::NPOS], x_lds[C::NPOS];
+  // ---- loader.  The matrix pipe and the vector ALU of a SIMD do not overlap for fp32 MFMA, and the
+  //      texture-address path takes ~20 cycles per wave-wide load whatever its width (profiles/r1i_wgrad_knockout.txt: the
+  //      68 dword loads per thread and tile of the first version cost 35 % of the kernel), so the per-tile work is kept
+  //      minimal: everything tile-independent is precomputed, the tile walk is incremental (no division), and the
+  //      fetches are WIDE raw buffer loads -- x as column pairs (8 bytes; the LDS tile starts on an even source column),
+  //      dz as pixel quads (16 bytes) -- with a per-sample descriptor: channels past Cin / Cout and halo positions fall
+  //      outside it (or get an out-of-range offset) and come back as hardware zeros, nothing is clamped or selected
+  //      afterwards.  Odd widths / 'edge' column halos (pairs that are not contiguous in memory) and output widths that
+  //      are not a multiple of 4 take the element-wise forms of the same loads.
+  const int e_al = a.pad_left & 1;
+  int x_lr[C::NPP], x_lc[C::NPP], x_lds[C::NPP];
 #pragma unroll
-  for (int k = 0; k < C::NPOS; ++k) {
-    const int s = min(tid + k * C::NTHREADS, C::LR * C::LC - 1);  // surplus threads duplicate the last position
-    x_lr[k] = s / C::LC;
-    x_lc[k] = s - x_lr[k] * C::LC;
+  for (int k = 0; k < C::NPP; ++k) {
+    const int s = min(tid + k * C::NTHREADS, C::NPAIR - 1);  // surplus threads duplicate the last pair
+    x_lr[k] = s / C::LCH;
+    x_lc[k] = 2 * (s - x_lr[k] * C::LCH);
     x_lds[k] = x_lr[k] * C::LC + x_lc[k];
   }
-  unsigned z_off[C::NZ];   // byte offset of element k inside the (sample, cout tile) window of dz, relative to the tile origin
-  int z_lds[C::NZ], z_r[C::NZ], z_c[C::NZ];
+  unsigned z_off[C::NZ4];   // byte offset of quad k inside the (sample, cout tile) window of dz, relative to the tile origin
+  int z_lds[C::NZ4], z_r[C::NZ4], z_c[C::NZ4];
 #pragma unroll
-  for (int k = 0; k < C::NZ; ++k) {
+  for (int k = 0; k < C::NZ4; ++k) {
     const int e = tid + k * C::NTHREADS;
-    const int zc = e / C::P;
-    const int p = e - zc * C::P;
+    const int zc = e / (C::P / 4);
+    const int p = (e - zc * (C::P / 4)) * 4;
     z_r[k] = p / C::TW;
     z_c[k] = p - z_r[k] * C::TW;
     z_off[k] = ((unsigned)zc * (unsigned)oplane + (unsigned)(z_r[k] * a.Wo + z_c[k])) * 4u;
-    z_lds[k] = zc * C::PSZ + z_r[k] * C::TW + z_c[k];
+    z_lds[k] = zc * C::PSZ + p;
   }
   const unsigned plane_bytes = (unsigned)plane * 4u, oplane_bytes = (unsigned)oplane * 4u;
   const int x_chans = min(C::CI, a.Cin - ci0), z_chans = min(16 * C::NT, a.Cout - co0);
   // a halo coordinate wraps at most once when halo + tile fit the axis; tiny axes take the general (%) mapping
-  const bool fast_h = a.H >= C::LR + a.pad_top, fast_w = a.W >= C::LC + a.pad_left;
+  const bool fast_h = a.H >= C::LR + a.pad_top, fast_w = a.W >= C::LC + a.pad_left + 1;
   auto map_axis = [&](int p, int n, int mode, bool fast) -> int {
     if (!fast) return dlwp_map_coord(p, n, mode);
     if (mode == DLWP_PAD_ZERO) return (unsigned)p < (unsigned)n ? p : -1;
     if (mode == DLWP_PAD_EDGE) return min(max(p, 0), n - 1);
     return p < 0 ? p + n : (p >= n ? p - n : p);
   };
+  const bool pair_x = (a.W & 1) == 0 && a.mode_w != DLWP_PAD_EDGE;   // an even column and its neighbour: one 8-byte load
+  const bool quad_z = (a.Wo & 3) == 0;                                // 4 pixels of dz: one 16-byte load
+  constexpr unsigned DROP = 0x7ffffff0u;
 
   // register-staged pipeline over tiles: the loads of tile t+1 are in flight under tile t's MFMA loop
-  float xv[C::NPOS][C::CI], zv[C::NZ];
+  float xv[C::NPP][C::CI][2], zv[C::NZ4][4];
   int tw_i, th_i, n_i;   // the tile the next prefetch fetches (incremental walk)
   {
     int q = t_begin;
@@ -143,27 +157,57 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
     const float* xn = a.x + ((long long)n_i * a.in_c_total + a.in_c_off + ci0) * plane;
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)x_chans * plane_bytes, 0x00020000);
+    auto ld1 = [&](unsigned off, unsigned so) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, so, 0));
+    };
+    // one source element (after the src transform) at (rs, cs); rs / cs < 0: outside (zero halo)
+    auto elem = [&](int rs, int cs, unsigned so) -> float {
+      const bool ok = rs >= 0 && cs >= 0;
+      if (a.src_mode == DLWP_SRC_UPSAMPLE2) return ld1(ok ? (unsigned)((rs >> 1) * a.Ws + (cs >> 1)) * 4u : DROP, so);
+      if (a.src_mode == DLWP_SRC_MAXPOOL2) {
+        const unsigned g = ok ? (unsigned)((rs * 2) * a.Ws + cs * 2) * 4u : DROP;
+        return fmaxf(fmaxf(ld1(g, so), ld1(g + 4u, so)), fmaxf(ld1(g + a.Ws * 4u, so), ld1(g + a.Ws * 4u + 4u, so)));
+      }
+      return ld1(ok ? (unsigned)(rs * a.Ws + cs) * 4u : DROP, so);
+    };
 #pragma unroll
-    for (int k = 0; k < C::NPOS; ++k) {
+    for (int k = 0; k < C::NPP; ++k) {
       const int rs = map_axis(i0 + x_lr[k] - a.pad_top, a.H, a.mode_h, fast_h);
-      const int cs = map_axis(j0 + x_lc[k] - a.pad_left, a.W, a.mode_w, fast_w);
-      int g;
-      if (a.src_mode == DLWP_SRC_UPSAMPLE2) g = (rs >> 1) * a.Ws + (cs >> 1);
-      else if (a.src_mode == DLWP_SRC_MAXPOOL2) g = (rs * 2) * a.Ws + cs * 2;
-      else g = rs * a.Ws + cs;
-      const unsigned goff = (rs >= 0 && cs >= 0) ? (unsigned)g * 4u : 0x7ffffff0u;
+      const int c0 = j0 + x_lc[k] - a.pad_left - e_al;
+      if (pair_x) {
+        const int cs = map_axis(c0, a.W, a.mode_w, fast_w);   // even; cs + 1 is its neighbour in memory
+        const bool ok = rs >= 0 && cs >= 0;
+        if (a.src_mode == DLWP_SRC_DIRECT) {
+          const unsigned g = ok ? (unsigned)(rs * a.Ws + cs) * 4u : DROP;
 #pragma unroll
-      for (int ci = 0; ci < C::CI; ++ci) {
-        const unsigned so = (unsigned)ci * plane_bytes;
-        if (a.src_mode == DLWP_SRC_MAXPOOL2) {
-          const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff, so, 0));
-          const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff + 4u, so, 0));
-          const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff + a.Ws * 4u, so, 0));
-          const float v3 =
-              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff + a.Ws * 4u + 4u, so, 0));
-          xv[k][ci] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-        } else {
-          xv[k][ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff, so, 0));
+          for (int ci = 0; ci < C::CI; ++ci) {
+            // (whole-vector bit_cast: on a vector ELEMENT this hipcc's __builtin_bit_cast reads element 0)
+            const wg_f32x2 v =
+                __builtin_bit_cast(wg_f32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, g, (unsigned)ci * plane_bytes, 0));
+            xv[k][ci][0] = v[0];
+            xv[k][ci][1] = v[1];
+          }
+        } else if (a.src_mode == DLWP_SRC_UPSAMPLE2) {
+          const unsigned g = ok ? (unsigned)((rs >> 1) * a.Ws + (cs >> 1)) * 4u : DROP;
+#pragma unroll
+          for (int ci = 0; ci < C::CI; ++ci) xv[k][ci][0] = xv[k][ci][1] = ld1(g, (unsigned)ci * plane_bytes);
+        } else {   // 2x2 max-pooling of the stored tensor: the pair = 2 rows x 4 raw columns
+          const unsigned g = ok ? (unsigned)((rs * 2) * a.Ws + cs * 2) * 4u : DROP;
+#pragma unroll
+          for (int ci = 0; ci < C::CI; ++ci) {
+            const wg_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, g, (unsigned)ci * plane_bytes, 0);
+            const wg_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, g + a.Ws * 4u, (unsigned)ci * plane_bytes, 0);
+            const f32x4 tf = __builtin_bit_cast(f32x4, t), bf4 = __builtin_bit_cast(f32x4, b);
+            xv[k][ci][0] = fmaxf(fmaxf(tf[0], tf[1]), fmaxf(bf4[0], bf4[1]));
+            xv[k][ci][1] = fmaxf(fmaxf(tf[2], tf[3]), fmaxf(bf4[2], bf4[3]));
+          }
+        }
+      } else {
+        const int cs0 = map_axis(c0, a.W, a.mode_w, fast_w), cs1 = map_axis(c0 + 1, a.W, a.mode_w, fast_w);
+#pragma unroll
+        for (int ci = 0; ci < C::CI; ++ci) {
+          xv[k][ci][0] = elem(rs, cs0, (unsigned)ci * plane_bytes);
+          xv[k][ci][1] = elem(rs, cs1, (unsigned)ci * plane_bytes);
         }
       }
     }
@@ -171,16 +215,23 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
     const __amdgpu_buffer_rsrc_t z_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)zn, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
     const unsigned tile_off = (unsigned)(i0 * a.Wo + j0) * 4u;
-    if (i0 + C::TH <= a.Ho && j0 + C::TW <= a.Wo) {   // interior tile: no per-element work at all
+    const bool interior = i0 + C::TH <= a.Ho && j0 + C::TW <= a.Wo;   // no per-element work at all
 #pragma unroll
-      for (int k = 0; k < C::NZ; ++k)
-        zv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, z_off[k], tile_off, 0));
-    } else {
+    for (int k = 0; k < C::NZ4; ++k) {
+      const bool rok = interior || i0 + z_r[k] < a.Ho;
+      if (quad_z) {   // Wo % 4 == 0: a quad is inside or outside as a whole
+        const bool ok = rok && (interior || j0 + z_c[k] < a.Wo);
+        const f32x4 v =
+            __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, ok ? z_off[k] : DROP, tile_off, 0));
 #pragma unroll
-      for (int k = 0; k < C::NZ; ++k) {
-        const bool ok = i0 + z_r[k] < a.Ho && j0 + z_c[k] < a.Wo;
-        zv[k] = __builtin_bit_cast(float,
-                                   __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? z_off[k] : 0x7ffffff0u, tile_off, 0));
+        for (int r = 0; r < 4; ++r) zv[k][r] = v[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = rok && j0 + z_c[k] + r < a.Wo;
+          zv[k][r] = __builtin_bit_cast(
+              float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? z_off[k] + 4u * r : DROP, tile_off, 0));
+        }
       }
     }
     if (++tw_i == a.tiles_w) {
@@ -196,11 +247,16 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();  // previous tile consumed
 #pragma unroll
-    for (int k = 0; k < C::NPOS; ++k)
+    for (int k = 0; k < C::NPP; ++k)
 #pragma unroll
-      for (int ci = 0; ci < C::CI; ++ci) xs[ci * C::PSX + x_lds[k]] = xv[k][ci];
+      for (int ci = 0; ci < C::CI; ++ci)
+        *(u32x2*)(xs + ci * C::PSX + x_lds[k]) =
+            (u32x2){__builtin_bit_cast(unsigned, xv[k][ci][0]), __builtin_bit_cast(unsigned, xv[k][ci][1])};
 #pragma unroll
-    for (int k = 0; k < C::NZ; ++k) zs[z_lds[k]] = zv[k];
+    for (int k = 0; k < C::NZ4; ++k) {
+      *(u32x2*)(zs + z_lds[k]) = (u32x2){__builtin_bit_cast(unsigned, zv[k][0]), __builtin_bit_cast(unsigned, zv[k][1])};
+      *(u32x2*)(zs + z_lds[k] + 2) = (u32x2){__builtin_bit_cast(unsigned, zv[k][2]), __builtin_bit_cast(unsigned, zv[k][3])};
+    }
     __syncthreads();
     if (tile + 1 < t_end) prefetch();
 

@@ -147,6 +147,7 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* d
 int dlwp_conv2d_wgrad_num_configs(void);                                   /* tuning hooks, as for the forward */
 int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes);      /* {ks, dil, th, tw, cout_frags, waves} */
 int dlwp_conv2d_wgrad_force_config(int i);
+int dlwp_conv2d_wgrad_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);   /* the heuristic's choice, -1: none */
 
 /* ---- the rest of the train step: Keras 'mse' loss + 'mae' metric (examples/train.py:240, train_functional.py:285),
  *      activation backward, bias gradient, Keras-2.2-form Adam (restated by the reference at DLWP/custom.py:34-40) and
