@@ -417,6 +417,41 @@ def test_conv_backward_kernels_against_oracle_all_halo_modes():
         assert np.abs(dwd.cpu().numpy() - dw_ref).max() <= 2e-5 * max(1., np.abs(dw_ref).max()), case
 
 
+def test_conv_weight_gradient_every_compiled_tile_configuration():
+    """Force each weight-gradient tile configuration in turn: ragged tiles, ragged channel groups, odd AND even widths
+    (column-pair loads vs their element-wise form), output widths that are / are not multiples of 4 (pixel-quad loads),
+    periodic + zero halo, direct / pooled / up-sampled source."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(17)
+    cfgs = ops.wgrad_configs()
+    geoms = [(3, 19, 50, 0), (2, 11, 21, 0), (2, 18, 44, 2), (2, 7, 13, 1)]      # (n, h, w stored, src_mode)
+    cache = {}
+    try:
+        for i, (ks, dil, th, tw, nt, waves, lds) in enumerate(cfgs):
+            for gi, (n, h, w, src) in enumerate(geoms):
+                key = (ks, dil, gi)
+                if key not in cache:
+                    cin, cout = 20, 36
+                    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+                    xs64 = np.asarray(x, np.float64)
+                    xt = {0: xs64, 1: np_ref.upsample2(xs64), 2: np_ref.maxpool2(xs64)}[src]
+                    p = dil * (ks - 1) // 2
+                    pads = (p, p, p, p)
+                    xp = np_ref.pad2d_modes(xt, pads, 0, 1)
+                    dz = rng.standard_normal((n, cout, xt.shape[2], xt.shape[3])).astype(np.float32)
+                    _, dw_ref, _ = np_ref.conv2d_grads(xp, np.zeros((ks, ks, cin, cout)), dz, dil)
+                    cache[key] = (torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda(), dw_ref, pads, cin, cout)
+                xd, dzd, dw_ref, pads, cin, cout = cache[key]
+                cd = ops.make_conv(cout, ks, ks, dil, ops.make_pad(*pads, 0, 1), ops.ACT_LINEAR, src_mode=src)
+                dwd = torch.empty((ks, ks, cin, cout), dtype=torch.float32, device='cuda')
+                ops.force_wgrad_config(i)
+                ops.conv2d_bwd_weight(xd, dzd, dwd, cd, _lib.Shape4(n, cin, h, w))
+                err = np.abs(dwd.cpu().numpy() - dw_ref).max()
+                assert err <= 2e-5 * max(1., np.abs(dw_ref).max()), (i, cfgs[i], geoms[gi], err)
+    finally:
+        ops.force_wgrad_config(-1)
+
+
 def test_reference_style_example_script_runs_end_to_end(tmp_path):
     """examples/train_and_forecast.py is written with the reference's imports (DLWP.*, keras.*) through the compat shim:
     data generator -> build_model -> fit_generator with callbacks -> save / load -> predict_timeseries."""
