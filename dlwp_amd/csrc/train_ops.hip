@@ -64,6 +64,47 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __r
   if (threadIdx.x == 0) partial[c * BIAS_SPLIT + sidx] = s;
 }
 
+// act_bwd + bias_grad_partial in one pass over a channel window: dz = dy * act'(y) written in place of / next to dy, and
+// the per-channel partial sums of dz taken from registers -- the bias gradient then costs no second read of dz.  Block
+// (c, s) owns slice s of the N*hw elements of channel c (slices are multiples of 4 elements: float4 accesses when
+// hw % 4 == 0); a fixed two-stage tree like bias_grad_partial_kernel's (deterministic; the per-thread order differs).
+template <int VEC>
+__global__ __launch_bounds__(256) void act_bwd_bias_partial_kernel(const float* __restrict__ y, const float* dy, float* dz,
+                                                                   float* __restrict__ partial, int N, int c_off,
+                                                                   int c_total, int hw, int act) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const int c = blockIdx.x, sidx = blockIdx.y;
+  const long long per = (long long)N * hw;
+  long long chunk = (per + BIAS_SPLIT - 1) / BIAS_SPLIT;
+  chunk = (chunk + 3) & ~3ll;
+  const long long lo = sidx * chunk, hi = lo + chunk < per ? lo + chunk : per;
+  float s = 0.f, dummy = 0.f;
+  for (long long base = lo; base < hi;) {
+    const long long n = base / hw;
+    const int p0 = (int)(base - n * hw);
+    const int p1 = (int)((hi - base) < (long long)(hw - p0) ? p0 + (hi - base) : hw);
+    const long long plane = (n * c_total + c_off + c) * hw;
+    for (int p = p0 + (int)threadIdx.x * VEC; p < p1; p += 256 * VEC) {
+      const vec_t g = *(const vec_t*)(dy + plane + p);
+      vec_t r = g;
+      if (act == DLWP_ACT_TANH) {
+        const vec_t t = *(const vec_t*)(y + plane + p);
+        r = g * (1.f - t * t);
+      } else if (act == DLWP_ACT_RELU) {
+        const vec_t t = *(const vec_t*)(y + plane + p);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) r[k] = t[k] > 0.f ? g[k] : 0.f;
+      }
+      *(vec_t*)(dz + plane + p) = r;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) s += r[k];
+    }
+    base += p1 - p0;
+  }
+  block_sum2(s, dummy);
+  if (threadIdx.x == 0) partial[c * BIAS_SPLIT + sidx] = s;
+}
+
 __global__ __launch_bounds__(64) void bias_grad_final_kernel(const float* __restrict__ partial, float* __restrict__ db) {
   const float v = wave_sum(partial[blockIdx.x * BIAS_SPLIT + threadIdx.x]);
   if (threadIdx.x == 0) db[blockIdx.x] = v;
@@ -400,6 +441,24 @@ int dlwp_bias_grad(dlwp_handle_t h, const void* dz, void* db, int n, int c, int 
                                                                               c_total, hw);
   bias_grad_final_kernel<<<c, 64, 0, (hipStream_t)stream>>>((const float*)ws, (float*)db);
   DLWP_LAUNCH_CHECK("bias_grad kernels");
+  return DLWP_OK;
+}
+
+int dlwp_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dy, void* dz, void* db, int n, int c, int c_off,
+                           int c_total, int hw, int act, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && dy && dz && db && ws && (y || act == DLWP_ACT_LINEAR), "dlwp_act_bwd_bias_grad: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32 && (unsigned)act <= 2u && n >= 0 && c > 0 && hw > 0 && c_off >= 0 && c_off + c <= c_total,
+                 "dlwp_act_bwd_bias_grad: bad arguments");
+  DLWP_CHECK_ARG(ws_bytes >= dlwp_bias_grad_workspace(c), "dlwp_act_bwd_bias_grad: workspace too small");
+  const bool v4 = hw % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dz | (uintptr_t)y) & 15) == 0;
+  if (v4)
+    act_bwd_bias_partial_kernel<4><<<dim3(c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
+        (const float*)y, (const float*)dy, (float*)dz, (float*)ws, n, c_off, c_total, hw, act);
+  else
+    act_bwd_bias_partial_kernel<1><<<dim3(c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
+        (const float*)y, (const float*)dy, (float*)dz, (float*)ws, n, c_off, c_total, hw, act);
+  bias_grad_final_kernel<<<c, 64, 0, (hipStream_t)stream>>>((const float*)ws, (float*)db);
+  DLWP_LAUNCH_CHECK("act_bwd_bias_grad kernels");
   return DLWP_OK;
 }
 

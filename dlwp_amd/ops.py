@@ -343,6 +343,18 @@ def bias_grad(dz, db, c, c_off=0):
     return db
 
 
+def act_bwd_bias_grad(y, dy, act, db, c, c_off=0, out=None):
+    """dz = dy * act'(y) on channels [c_off, c_off + c) and db = sum of dz over (n, h, w), in one pass (dz may be dy)."""
+    _check_f32(y, dy, db)
+    dz = out if out is not None else torch.empty_like(dy)
+    n, c_total, h, w = dy.shape
+    ws = workspace2(dy.device, _lib.lib.dlwp_bias_grad_workspace(int(c)))
+    _lib.check(_lib.lib.dlwp_act_bwd_bias_grad(_lib.handle(_dev(dy)), _ptr(y), _ptr(dy), _ptr(dz), _ptr(db), n, int(c),
+                                               int(c_off), c_total, h * w, int(act), _ptr(ws), ws.numel(), _lib.F32,
+                                               _stream(dy)))
+    return dz
+
+
 def mse_mae(y_pred, y_true, out2, dy=None, loss_weight=1.0):
     """out2 (device, 2 floats) <- [mse, mae]; dy <- loss_weight * 2 (y_pred - y_true) / numel."""
     _check_f32(y_pred, y_true, out2, dy)

@@ -306,13 +306,17 @@ class Trainer(object):
             if op.kind == 'conv':
                 lay = op.layer
                 y = tensor(op.dst)
-                if lay.activation != 'linear':
+                acc = id(lay) in touched_layers
+                fused_bias = (lay.activation != 'linear' and lay.bias is not None and not acc and
+                              gD.shape[1] == lay.filters and tuple(y.shape) == tuple(gD.shape))
+                if fused_bias:         # dz in place of dy and the bias gradient from the same pass
+                    ops.act_bwd_bias_grad(y, gD, op.act, self._grad_view(lay, 'bias'), lay.filters, out=gD)
+                elif lay.activation != 'linear':
                     ops.act_bwd(y, gD, op.act, out=gD)          # dz in place of dy
                 dz = gD
                 xs = _lib.Shape4(n, op.xs[0], op.xs[1], op.xs[2])
-                acc = id(lay) in touched_layers
                 ops.conv2d_bwd_weight(src, dz, self._grad_view(lay, 'kernel'), d, xs, accumulate=acc)
-                if lay.bias is not None:
+                if lay.bias is not None and not fused_bias:
                     gb = self._grad_view(lay, 'bias')
                     if acc:
                         tmp = torch.empty_like(gb)

@@ -158,6 +158,10 @@ int    dlwp_act_bwd(dlwp_handle_t, const void* y, const void* dy, void* dz, size
 size_t dlwp_bias_grad_workspace(int c);
 int    dlwp_bias_grad(dlwp_handle_t, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, void* ws,
                       size_t ws_bytes, int dtype, void* stream);
+/* dlwp_act_bwd on channels [c_off, c_off+c) of a (n, c_total, hw) tensor and dlwp_bias_grad of the result in one pass:
+ * dz = dy * act'(y) (dz may alias dy), db[c] = sum of dz over (n, hw), by a fixed (bit-reproducible) reduction tree.       */
+int    dlwp_act_bwd_bias_grad(dlwp_handle_t, const void* y, const void* dy, void* dz, void* db, int n, int c, int c_off,
+                              int c_total, int hw, int act, void* ws, size_t ws_bytes, int dtype, void* stream);
 size_t dlwp_mse_mae_workspace(dlwp_handle_t);
 int    dlwp_mse_mae(dlwp_handle_t, const void* y_pred, const void* y_true, size_t n, void* out2, void* dy,
                     float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -417,6 +417,28 @@ def test_conv_backward_kernels_against_oracle_all_halo_modes():
         assert np.abs(dwd.cpu().numpy() - dw_ref).max() <= 2e-5 * max(1., np.abs(dw_ref).max()), case
 
 
+def test_fused_activation_backward_and_bias_gradient_equal_the_two_separate_kernels():
+    """dlwp_act_bwd_bias_grad == dlwp_act_bwd followed by dlwp_bias_grad: dz bit for bit, db to float32 rounding (fixed
+    but differently ordered partial sums), on a channel window, with vector (hw % 4 == 0) and scalar planes, in place."""
+    from dlwp_amd import ops
+    rng = np.random.default_rng(3)
+    for (n, c_total, h, w, c, c_off) in [(5, 12, 6, 10, 12, 0), (3, 9, 7, 9, 4, 3), (64, 32, 11, 20, 32, 0)]:
+        for act in (ops.ACT_TANH, ops.ACT_RELU):
+            y = torch.from_numpy(np.tanh(rng.standard_normal((n, c_total, h, w))).astype(np.float32)).cuda()
+            dy = torch.from_numpy(rng.standard_normal((n, c_total, h, w)).astype(np.float32)).cuda()
+            dz_ref = ops.act_bwd(y, dy, act)
+            db_ref = torch.empty(c, device='cuda')
+            ops.bias_grad(dz_ref, db_ref, c, c_off)
+            g = dy.clone()
+            db = torch.empty(c, device='cuda')
+            ops.act_bwd_bias_grad(y, g, act, db, c, c_off, out=g)
+            assert torch.equal(g[:, c_off:c_off + c], dz_ref[:, c_off:c_off + c])
+            assert torch.equal(g[:, :c_off], dy[:, :c_off]) and torch.equal(g[:, c_off + c:], dy[:, c_off + c:])
+            assert torch.allclose(db, db_ref, rtol=1e-5, atol=1e-4)
+            want = dz_ref[:, c_off:c_off + c].double().sum(dim=(0, 2, 3))
+            assert torch.allclose(db.double(), want, rtol=1e-5, atol=1e-4)
+
+
 def test_conv_weight_gradient_every_compiled_tile_configuration():
     """Force each weight-gradient tile configuration in turn: ragged tiles, ragged channel groups, odd AND even widths
     (column-pair loads vs their element-wise form), output widths that are / are not multiples of 4 (pixel-quad loads),
