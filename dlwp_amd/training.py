@@ -275,6 +275,11 @@ class Trainer(object):
 
         def deposit(buf, c_off, c, dense):
             """Put `dense` (n, c, h, w) into window [c_off, +c) of grad[buf]: overwrite on first touch, add after."""
+            if grads.get(buf) is None and c_off == 0 and tuple(dense.shape) == tuple(tensor(buf).shape) and \
+                    dense.is_contiguous():
+                grads[buf] = dense            # first gradient of the whole tensor: adopt it, no copy
+                written[buf] = [(0, c)]
+                return
             g = grad_of(buf)
             full = c_off == 0 and c == g.shape[1]
             if not overlaps(buf, c_off, c):
