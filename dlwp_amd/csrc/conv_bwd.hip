@@ -30,6 +30,9 @@ const WgradKernelEntry k_wgrad[] = {
     WGRAD_ENTRY_C(3, 2, 8, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 2, 4, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 2, 8, 32, 2, 2, 8),
     WGRAD_ENTRY_C(3, 1, 8, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 1, 8, 32, 2, 2, 8), WGRAD_ENTRY_C(5, 1, 8, 32, 2, 2, 4),
     WGRAD_ENTRY_C(5, 1, 8, 32, 2, 2, 8), WGRAD_ENTRY_C(5, 1, 8, 32, 1, 4, 8),
+    // packed-N (conv_wgrad_kernel.h): <= 4 output channels, the MFMA columns hold 4 channels x 4 column shifts
+    WGRAD_ENTRY_K(5, 1, 8, 32, 1, 4, 8, 4), WGRAD_ENTRY_K(5, 1, 8, 32, 1, 4, 16, 4), WGRAD_ENTRY_K(5, 1, 4, 32, 1, 4, 16, 4),
+    WGRAD_ENTRY_K(3, 1, 8, 32, 1, 4, 16, 4),
 };
 constexpr int N_WGRAD = (int)(sizeof(k_wgrad) / sizeof(k_wgrad[0]));
 char g_wg_prepared[N_WGRAD] = {0};
@@ -47,10 +50,12 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
     const WgradKernelEntry& e = k_wgrad[i];
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
     if (g_forced_wgrad >= 0 && i != g_forced_wgrad) continue;
-    const double tiles = (double)dlwp_ceil_div(Ho, e.th) * dlwp_ceil_div(Wo, e.tw);
+    if (e.pack && Cout > e.pack) continue;   // packed-N instances: at most 4 output channels
+    const double tiles = (double)dlwp_ceil_div(Ho, e.th) * dlwp_ceil_div(Wo + (e.pack ? e.pack - 1 : 0), e.tw);
     const double co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
     const double ci_groups = dlwp_ceil_div(Cin, e.cib);
-    const double mfrags = (e.ks * e.ks * e.cib + 15) / 16;
+    const int vtaps = e.pack ? e.ks * ((e.ks + e.pack - 1) / e.pack) : e.ks * e.ks;
+    const double mfrags = (vtaps * e.cib + 15) / 16;
     // Cycles of one (tile, cout tile, channel group) on a CU -- fitted to tools/tune_wgrad.py sweeps with the wide-load
     // staging (profiles/r1i_wgrad_tile_sweep_b64.txt; within ~6 % on the config-2 layers):
     //   matrix pipe: every wave issues (pixel quads / PW) x mfrags MFMAs of 32 cycles, waves/4 waves per SIMD;
@@ -65,6 +70,7 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
     if (resident < 1) resident = 1;
     double pen = (e.waves % 4) ? 1.25 : 1.0;   // 1- and 2-wave workgroups leave SIMDs idle (measured)
     if (mfrags >= 25) pen *= 1.12;               // 100 accumulator registers: one wave per SIMD
+    if (e.pack && e.cib > 8) pen *= 1.2;         // measured: the 8-channel packed instance is 1.25x the 16-channel one
     if (e.nt == 4 && e.tw == 32) pen *= 1.15;    // measured: 59 % matrix-pipe use where the 48-wide tiles reach 70 %
     const double c = tiles * co_tiles * ci_groups * (t_mfma + 0.6 * 22.0 * loads + 1500.0 / resident) * pen;
     if (best < 0 || c < best_cost) {
@@ -76,7 +82,7 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
   const WgradKernelEntry& e = k_wgrad[best];
   out->idx = best;
   out->tiles_h = dlwp_ceil_div(Ho, e.th);
-  out->tiles_w = dlwp_ceil_div(Wo, e.tw);
+  out->tiles_w = dlwp_ceil_div(Wo + (e.pack ? e.pack - 1 : 0), e.tw);   // packed-N: every (pixel, shift) pair once
   out->ci_groups = dlwp_ceil_div(Cin, e.cib);
   out->co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
   const long long total_tiles = (long long)N * out->tiles_h * out->tiles_w;
@@ -256,7 +262,8 @@ int dlwp_conv2d_wgrad_num_configs(void) { return N_WGRAD; }
 int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes) {
   DLWP_CHECK_ARG(i >= 0 && i < N_WGRAD && info6, "dlwp_conv2d_wgrad_config_info: index out of range");
   const WgradKernelEntry& e = k_wgrad[i];
-  const int v[6] = {e.ks, e.dil, e.th, e.tw, e.nt, e.waves};  // waves = nt * pixel-split waves
+  // cout_frags < 0: packed-N instance for cout <= -cout_frags (conv_wgrad_kernel.h); waves = nt * pixel-split waves
+  const int v[6] = {e.ks, e.dil, e.th, e.tw, e.pack ? -e.pack : e.nt, e.waves};
   for (int k = 0; k < 6; ++k) info6[k] = v[k];
   if (lds_bytes) *lds_bytes = e.lds_bytes;
   return DLWP_OK;

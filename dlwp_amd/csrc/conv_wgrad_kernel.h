@@ -30,14 +30,24 @@ struct WgradArgs {
   int tiles_h, tiles_w, total_tiles, splits, ci_groups, co_tiles;
 };
 
-template <int KS_, int DIL_, int TH_, int TW_, int NT_, int PW_ = 1, int CIB_ = 16>
+// PACK = 4: the "packed-N" form for layers with <= 4 output channels (the 5x5 output layer).  The 16 MFMA columns hold
+// (co, s) = 4 output channels x 4 column shifts of dz instead of 16 output channels of which 12 would be padding:
+//   B[(co, s), pixel] = dz[co, pixel - s]      A[(u, v0, ci), pixel] = x[ci, pixel + (u, v0)],  v0 in {0, 4, ...}
+//   D[(u, v0, ci), (co, s)] = sum_pixel A B = dW[u, v0 + s, ci, co]
+// so a 5-wide kernel row needs 2 "virtual taps" (v0 = 0, 4) instead of 5: 10 x CI accumulator rows instead of 25 x CI.
+// The dz tile carries 4 extra columns on its left; the tile grid is laid over Wo + 3 columns so that every (pixel, s) pair
+// is visited once.
+template <int KS_, int DIL_, int TH_, int TW_, int NT_, int PW_ = 1, int CIB_ = 16, int PACK_ = 0>
 struct WgCfg {
-  static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, NT = NT_, PW = PW_;
+  static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, NT = NT_, PW = PW_, PACK = PACK_;
+  static constexpr int NV0 = PACK ? (KS_ + PACK_ - 1) / PACK_ : KS_;   // virtual taps per kernel row
+  static constexpr int VT = KS_ * NV0;                                   // accumulator row groups (virtual taps)
+  static_assert(PACK_ == 0 || (PACK_ == 4 && NT_ == 1 && DIL_ == 1), "packed-N: 4 shifts, one cout fragment, no dilation");
   // CIB input channels per block.  The 16 rows of an M fragment are (tap, ci) pairs, ci fastest: with CIB = 16 one
   // fragment = one tap x 16 channels; with CIB = 4 (first layer: cin = 4) one fragment = 4 taps x 4 channels, so a
   // 3x3 kernel needs 3 fragments instead of 9 and the LDS tile holds 4 channel planes instead of 16.
   static constexpr int CI = CIB_;
-  static constexpr int MF = (KS_ * KS_ * CIB_ + 15) / 16;
+  static constexpr int MF = (VT * CIB_ + 15) / 16;
   static constexpr int WAVES = NT * PW;  // wave = (cout fragment, pixel-quad residue class); PW > 1 -> PW slabs per split
   static constexpr int NTHREADS = WAVES * 64;
   // LDS tile: + 2 columns so that it can start on an even source column whatever the left halo (column-pair loads)
@@ -46,17 +56,23 @@ struct WgCfg {
   static constexpr int PSX_RAW = LR * LC;
   static constexpr int PSX = PSX_RAW + (((2 - PSX_RAW % 32) % 32) + 32) % 32;  // == 2 (mod 32)
   static constexpr int P = TH * TW;
-  static constexpr int PSZ = P + (((2 - P % 32) % 32) + 32) % 32;  // == 2 (mod 32)
+  static constexpr int ZC = PACK ? 4 : 16 * NT;          // dz channels staged per tile
+  static constexpr int ZW = PACK ? TW + 4 : TW;          // dz tile row length in LDS (4 columns of left halo when packed)
+  static constexpr int PZ = TH * ZW;
+  // channel-plane stride of the dz tile: == 2 (mod 32); packed: == 8 (mod 32) (4 channels x 7 distinct k - s offsets)
+  static constexpr int ZMOD = PACK ? 8 : 2;
+  static constexpr int PSZ = PZ + (((ZMOD - PZ % 32) % 32) + 32) % 32;
   static constexpr int TAPS = KS * KS;
   static constexpr int X_FLOATS = CI * PSX;
-  static constexpr int Z_FLOATS = 16 * NT * PSZ;
+  static constexpr int Z_FLOATS = ZC * PSZ;
   static constexpr int LDS_BYTES = (X_FLOATS + Z_FLOATS) * 4;
   static constexpr int NPP = (NPAIR + NTHREADS - 1) / NTHREADS;       // x column pairs per thread per tile
-  static constexpr int NZ4 = (16 * NT * P) / (4 * NTHREADS);          // dz pixel quads per thread per tile
+  static constexpr int ZQUADS = ZC * PZ / 4;
+  static constexpr int NZ4 = (ZQUADS + NTHREADS - 1) / NTHREADS;       // dz pixel quads per thread per tile
   static constexpr int QUADS = P / 4;
   static_assert(TW % 4 == 0, "pixel quads must not straddle rows");
   static_assert(QUADS % (2 * PW) == 0, "the quad loop is unrolled by 2 per pixel-wave");
-  static_assert((16 * NT * P) % (4 * NTHREADS) == 0, "dz tile must divide evenly over the threads, in pixel quads");
+  static_assert(PACK || ZQUADS % NTHREADS == 0, "dz tile must divide evenly over the threads, in pixel quads");
   static_assert(TW % 4 == 0 && LC % 2 == 0, "quads / pairs must not straddle rows");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
@@ -91,12 +107,14 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
 #pragma unroll
   for (int f = 0; f < C::MF; ++f) {
     const int m = f * 16 + (lane & 15);
-    const int tap = m / C::CI < C::TAPS ? m / C::CI : 0, ci = m % C::CI;
-    const int u = tap / C::KS, v = tap - u * C::KS;
+    const int tap = m / C::CI < C::VT ? m / C::CI : 0, ci = m % C::CI;
+    const int u = tap / C::NV0, v = (tap - u * C::NV0) * (C::PACK ? C::PACK : 1);
     a_off[f] = ci * C::PSX + u * C::DIL * C::LC + v * C::DIL + (lane >> 4) + (a.pad_left & 1);
   }
   const int wn = wave % C::NT, wp = wave / C::NT;
-  const int b_lane = (wn * 16 + (lane & 15)) * C::PSZ + (lane >> 4);
+  // B lane: output channel (row of the dz tile) and, packed, the column shift s = lane & 3 (the tile has 4 halo columns)
+  const int b_lane = C::PACK ? ((lane & 15) >> 2) * C::PSZ + 4 - (lane & 3) + (lane >> 4)
+                             : (wn * 16 + (lane & 15)) * C::PSZ + (lane >> 4);
 
   // ---- loader.  The matrix pipe and the vector ALU of a SIMD do not overlap for fp32 MFMA, and the
   //      texture-address path takes ~20 cycles per wave-wide load whatever its width (profiles/r1i_wgrad_knockout.txt: the
@@ -120,16 +138,16 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
   int z_lds[C::NZ4], z_r[C::NZ4], z_c[C::NZ4];
 #pragma unroll
   for (int k = 0; k < C::NZ4; ++k) {
-    const int e = tid + k * C::NTHREADS;
-    const int zc = e / (C::P / 4);
-    const int p = (e - zc * (C::P / 4)) * 4;
-    z_r[k] = p / C::TW;
-    z_c[k] = p - z_r[k] * C::TW;
-    z_off[k] = ((unsigned)zc * (unsigned)oplane + (unsigned)(z_r[k] * a.Wo + z_c[k])) * 4u;
+    const int e = min(tid + k * C::NTHREADS, C::ZQUADS - 1);   // (packed: surplus threads repeat the last quad)
+    const int zc = e / (C::PZ / 4);
+    const int p = (e - zc * (C::PZ / 4)) * 4;
+    z_r[k] = p / C::ZW;
+    z_c[k] = p - z_r[k] * C::ZW - (C::PACK ? 4 : 0);           // column relative to the tile origin (packed: from -4)
+    z_off[k] = (unsigned)(zc * (int)oplane + z_r[k] * a.Wo + p - z_r[k] * C::ZW) * 4u;   // from the tile's first LDS column
     z_lds[k] = zc * C::PSZ + p;
   }
   const unsigned plane_bytes = (unsigned)plane * 4u, oplane_bytes = (unsigned)oplane * 4u;
-  const int x_chans = min(C::CI, a.Cin - ci0), z_chans = min(16 * C::NT, a.Cout - co0);
+  const int x_chans = min(C::CI, a.Cin - ci0), z_chans = min(C::ZC, a.Cout - co0);
   // a halo coordinate wraps at most once when halo + tile fit the axis; tiny axes take the general (%) mapping
   const bool fast_h = a.H >= C::LR + a.pad_top, fast_w = a.W >= C::LC + a.pad_left + 1;
   auto map_axis = [&](int p, int n, int mode, bool fast) -> int {
@@ -214,23 +232,39 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
     const float* zn = a.dz + ((long long)n_i * a.dz_c_total + a.dz_c_off + co0) * oplane;
     const __amdgpu_buffer_rsrc_t z_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)zn, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
-    const unsigned tile_off = (unsigned)(i0 * a.Wo + j0) * 4u;
-    const bool interior = i0 + C::TH <= a.Ho && j0 + C::TW <= a.Wo;   // no per-element work at all
+    // byte offset of the tile's first LDS column (packed: 4 columns left of the tile, negative at the left image edge)
+    const int tile_off = (i0 * a.Wo + j0 - (C::PACK ? 4 : 0)) * 4;
+    // no per-element work at all on interior tiles (packed: the 4 halo columns must exist as well)
+    const bool interior = i0 + C::TH <= a.Ho && j0 + C::TW <= a.Wo && (!C::PACK || j0 >= 4);
+    if (interior) {
 #pragma unroll
-    for (int k = 0; k < C::NZ4; ++k) {
-      const bool rok = interior || i0 + z_r[k] < a.Ho;
-      if (quad_z) {   // Wo % 4 == 0: a quad is inside or outside as a whole
-        const bool ok = rok && (interior || j0 + z_c[k] < a.Wo);
-        const f32x4 v =
-            __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, ok ? z_off[k] : DROP, tile_off, 0));
+      for (int k = 0; k < C::NZ4; ++k) {
+        if (quad_z) {
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, z_off[k], (unsigned)tile_off, 0));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zv[k][r] = v[r];
-      } else {
+          for (int r = 0; r < 4; ++r) zv[k][r] = v[r];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = rok && j0 + z_c[k] + r < a.Wo;
-          zv[k][r] = __builtin_bit_cast(
-              float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? z_off[k] + 4u * r : DROP, tile_off, 0));
+          for (int r = 0; r < 4; ++r)
+            zv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, z_off[k] + 4u * r, (unsigned)tile_off, 0));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < C::NZ4; ++k) {
+        const bool rok = i0 + z_r[k] < a.Ho;
+        const unsigned off = (unsigned)((int)z_off[k] + tile_off);   // >= 0 wherever the element exists
+        if (quad_z) {   // Wo % 4 == 0: a quad is inside or outside as a whole
+          const bool ok = rok && (unsigned)(j0 + z_c[k]) < (unsigned)a.Wo;
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, ok ? off : DROP, 0, 0));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zv[k][r] = v[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = rok && (unsigned)(j0 + z_c[k] + r) < (unsigned)a.Wo;
+            zv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? off + 4u * r : DROP, 0, 0));
+          }
         }
       }
     }
@@ -266,7 +300,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
       const int p = qd * 4;
       const int r = p / C::TW, c = p - r * C::TW;
       const int xb = r * C::LC + c;
-      bf[buf] = zs[b_lane + p];
+      bf[buf] = zs[b_lane + r * C::ZW + c];
 #pragma unroll
       for (int t = 0; t < C::MF; ++t) af[buf][t] = xs[xb + a_off[t]];
     };
@@ -287,19 +321,26 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
 
   // ---- one partial slab per (block split, pixel-wave)
   float* slab = a.slabs + (long long)(split * C::PW + wp) * C::TAPS * a.Cin * a.Cout;
-  const int co = co0 + wn * 16 + (lane & 15);
+  const int co = C::PACK ? co0 + ((lane & 15) >> 2) : co0 + wn * 16 + (lane & 15);
 #pragma unroll
   for (int f = 0; f < C::MF; ++f)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = f * 16 + (lane >> 4) * 4 + r;
-      const int t = m / C::CI, ci = ci0 + m % C::CI;
-      if (t < C::TAPS && ci < a.Cin && co < a.Cout) slab[((long long)t * a.Cin + ci) * a.Cout + co] = acc[f][r];
+      const int vt = m / C::CI, ci = ci0 + m % C::CI;
+      int t = vt;   // kernel tap u*KS + v
+      bool tok = vt < C::VT;
+      if (C::PACK) {
+        const int u = vt / C::NV0, v = (vt - u * C::NV0) * C::PACK + (lane & 3);
+        t = u * C::KS + v;
+        tok = tok && v < C::KS;
+      }
+      if (tok && ci < a.Cin && co < a.Cout) slab[((long long)t * a.Cin + ci) * a.Cout + co] = acc[f][r];
     }
 }
 
 struct WgradKernelEntry {
-  int ks, dil, th, tw, nt, waves, lds_bytes, pw, cib;
+  int ks, dil, th, tw, nt, waves, lds_bytes, pw, cib, pack;
   void (*launch)(const WgradArgs&, int grid, hipStream_t s);
   int (*prepare)();
 };
@@ -317,10 +358,12 @@ static int wgrad_prepare() {
   return 0;
 }
 
-#define WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, PW, CIB)                                                                    \
+#define WGRAD_ENTRY_K(KS, DIL, TH, TW, NT, PW, CIB, PACK)                                                              \
   {                                                                                                                     \
-    KS, DIL, TH, TW, NT, NT * PW, WgCfg<KS, DIL, TH, TW, NT, PW, CIB>::LDS_BYTES, PW, CIB,                              \
-        &wgrad_launch_thunk<WgCfg<KS, DIL, TH, TW, NT, PW, CIB>>, &wgrad_prepare<WgCfg<KS, DIL, TH, TW, NT, PW, CIB>>   \
+    KS, DIL, TH, TW, NT, NT * PW, WgCfg<KS, DIL, TH, TW, NT, PW, CIB, PACK>::LDS_BYTES, PW, CIB, PACK,                  \
+        &wgrad_launch_thunk<WgCfg<KS, DIL, TH, TW, NT, PW, CIB, PACK>>,                                                 \
+        &wgrad_prepare<WgCfg<KS, DIL, TH, TW, NT, PW, CIB, PACK>>                                                       \
   }
+#define WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, PW, CIB) WGRAD_ENTRY_K(KS, DIL, TH, TW, NT, PW, CIB, 0)
 #define WGRAD_ENTRY_P(KS, DIL, TH, TW, NT, PW) WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, PW, 16)
 #define WGRAD_ENTRY(KS, DIL, TH, TW, NT) WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, 1, 16)

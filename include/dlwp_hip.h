@@ -145,7 +145,8 @@ int dlwp_conv2d_bwd_data(dlwp_handle_t, const void* dz, const void* w, void* dx,
 int dlwp_conv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 int dlwp_conv2d_wgrad_num_configs(void);                                   /* tuning hooks, as for the forward */
-int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes);      /* {ks, dil, th, tw, cout_frags, waves} */
+int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes);      /* {ks, dil, th, tw, cout_frags (< 0: packed-N
+                                                                             * instance for cout <= -cout_frags), waves} */
 int dlwp_conv2d_wgrad_force_config(int i);
 int dlwp_conv2d_wgrad_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);   /* the heuristic's choice, -1: none */
 

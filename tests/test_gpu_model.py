@@ -451,9 +451,9 @@ def test_conv_weight_gradient_every_compiled_tile_configuration():
     try:
         for i, (ks, dil, th, tw, nt, waves, lds) in enumerate(cfgs):
             for gi, (n, h, w, src) in enumerate(geoms):
-                key = (ks, dil, gi)
+                key = (ks, dil, gi, nt < 0)
                 if key not in cache:
-                    cin, cout = 20, 36
+                    cin, cout = (20, 36) if nt > 0 else (20, 3)     # packed-N instances: at most 4 output channels
                     x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
                     xs64 = np.asarray(x, np.float64)
                     xt = {0: xs64, 1: np_ref.upsample2(xs64), 2: np_ref.maxpool2(xs64)}[src]

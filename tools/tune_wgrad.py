@@ -36,7 +36,7 @@ def main():
         flops = 2.0 * a.batch * ys.h * ys.w * cout * cin * k * k
         rows = []
         for i, c in [(-1, None)] + list(enumerate(cfgs)):
-            if c is not None and (c[0], c[1]) != (k, dil):
+            if c is not None and ((c[0], c[1]) != (k, dil) or (c[4] < 0 and cout > -c[4])):
                 continue
             ops.force_wgrad_config(i)
             try:
