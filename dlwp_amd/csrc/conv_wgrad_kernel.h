@@ -232,39 +232,26 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
     const float* zn = a.dz + ((long long)n_i * a.dz_c_total + a.dz_c_off + co0) * oplane;
     const __amdgpu_buffer_rsrc_t z_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)zn, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
-    // byte offset of the tile's first LDS column (packed: 4 columns left of the tile, negative at the left image edge)
+    // byte offset of the tile's first LDS column (packed: 4 columns left of the tile, negative at the left image edge,
+    // so the packed form adds it to the element offset itself; the plain form passes it as the scalar offset)
     const int tile_off = (i0 * a.Wo + j0 - (C::PACK ? 4 : 0)) * 4;
-    // no per-element work at all on interior tiles (packed: the 4 halo columns must exist as well)
+    // no per-element checks on interior tiles (packed: the 4 halo columns must exist as well)
     const bool interior = i0 + C::TH <= a.Ho && j0 + C::TW <= a.Wo && (!C::PACK || j0 >= 4);
-    if (interior) {
 #pragma unroll
-      for (int k = 0; k < C::NZ4; ++k) {
-        if (quad_z) {
-          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, z_off[k], (unsigned)tile_off, 0));
+    for (int k = 0; k < C::NZ4; ++k) {
+      const bool rok = interior || i0 + z_r[k] < a.Ho;
+      const unsigned voff = C::PACK ? (unsigned)((int)z_off[k] + tile_off) : z_off[k];   // >= 0 wherever the element exists
+      const unsigned soff = C::PACK ? 0u : (unsigned)tile_off;
+      if (quad_z) {   // Wo % 4 == 0: a quad is inside or outside as a whole
+        const bool ok = rok && (interior || (unsigned)(j0 + z_c[k]) < (unsigned)a.Wo);
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, ok ? voff : DROP, soff, 0));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) zv[k][r] = v[r];
-        } else {
+        for (int r = 0; r < 4; ++r) zv[k][r] = v[r];
+      } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            zv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, z_off[k] + 4u * r, (unsigned)tile_off, 0));
-        }
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < C::NZ4; ++k) {
-        const bool rok = i0 + z_r[k] < a.Ho;
-        const unsigned off = (unsigned)((int)z_off[k] + tile_off);   // >= 0 wherever the element exists
-        if (quad_z) {   // Wo % 4 == 0: a quad is inside or outside as a whole
-          const bool ok = rok && (unsigned)(j0 + z_c[k]) < (unsigned)a.Wo;
-          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, ok ? off : DROP, 0, 0));
-#pragma unroll
-          for (int r = 0; r < 4; ++r) zv[k][r] = v[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = rok && (unsigned)(j0 + z_c[k] + r) < (unsigned)a.Wo;
-            zv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? off + 4u * r : DROP, 0, 0));
-          }
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = rok && (unsigned)(j0 + z_c[k] + r) < (unsigned)a.Wo;
+          zv[k][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? voff + 4u * r : DROP, soff, 0));
         }
       }
     }
