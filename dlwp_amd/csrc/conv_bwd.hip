@@ -33,6 +33,9 @@ const WgradKernelEntry k_wgrad[] = {
     // packed-N (conv_wgrad_kernel.h): <= 4 output channels, the MFMA columns hold 4 channels x 4 column shifts
     WGRAD_ENTRY_K(5, 1, 8, 32, 1, 4, 8, 4), WGRAD_ENTRY_K(5, 1, 8, 32, 1, 4, 16, 4), WGRAD_ENTRY_K(5, 1, 4, 32, 1, 4, 16, 4),
     WGRAD_ENTRY_K(3, 1, 8, 32, 1, 4, 16, 4),
+    // Winograd F(2x2,3x3) weight gradient (conv_wgrad_kernel.h)
+    WGRAD_ENTRY_W(1, 8, 32, 2, 4), WGRAD_ENTRY_W(1, 4, 32, 2, 4), WGRAD_ENTRY_W(1, 4, 48, 2, 4), WGRAD_ENTRY_W(1, 4, 16, 2, 4),
+    WGRAD_ENTRY_W(2, 8, 32, 2, 4), WGRAD_ENTRY_W(2, 4, 32, 2, 4), WGRAD_ENTRY_W(2, 4, 48, 2, 4), WGRAD_ENTRY_W(2, 4, 36, 2, 3),
 };
 constexpr int N_WGRAD = (int)(sizeof(k_wgrad) / sizeof(k_wgrad[0]));
 char g_wg_prepared[N_WGRAD] = {0};
@@ -63,13 +66,15 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
     //                about 60 % of it not hidden under the MFMAs of the co-resident workgroups;
     //   fixed:       barriers / tile walk, shared among the resident workgroups (LDS-bound residency).
     const int lr = e.th + e.dil * (e.ks - 1), lch = (e.tw + e.dil * (e.ks - 1) + 2) / 2;
-    const double t_mfma = 2.0 * e.nt * e.th * e.tw * mfrags;
+    // Winograd: 16 MFMAs per 4 tiles and cout fragment (8 cycles per pixel and fragment instead of 18) + ~35 % transforms
+    const double t_mfma = e.wino ? 10.8 * e.nt * e.th * e.tw : 2.0 * e.nt * e.th * e.tw * mfrags;
     const double loads = (double)dlwp_ceil_div(lr * lch, 64) * e.cib + 16.0 * e.nt * e.th * e.tw / 256.0;
     int resident = (160 * 1024) / e.lds_bytes;
     if (resident > 16 / e.waves) resident = 16 / e.waves;
     if (resident < 1) resident = 1;
     double pen = (e.waves % 4) ? 1.25 : 1.0;   // 1- and 2-wave workgroups leave SIMDs idle (measured)
     if (mfrags >= 25) pen *= 1.12;               // 100 accumulator registers: one wave per SIMD
+    if (e.wino && e.th >= 8) pen *= 1.3;         // measured: the 8-row Winograd tiles spill registers at 2 waves per SIMD
     if (e.pack && e.cib > 8) pen *= 1.2;         // measured: the 8-channel packed instance is 1.25x the 16-channel one
     if (e.nt == 4 && e.tw == 32) pen *= 1.15;    // measured: 59 % matrix-pipe use where the 48-wide tiles reach 70 %
     const double c = tiles * co_tiles * ci_groups * (t_mfma + 0.6 * 22.0 * loads + 1500.0 / resident) * pen;

@@ -37,9 +37,16 @@ struct WgradArgs {
 // so a 5-wide kernel row needs 2 "virtual taps" (v0 = 0, 4) instead of 5: 10 x CI accumulator rows instead of 25 x CI.
 // The dz tile carries 4 extra columns on its left; the tile grid is laid over Wo + 3 columns so that every (pixel, s) pair
 // is visited once.
-template <int KS_, int DIL_, int TH_, int TW_, int NT_, int PW_ = 1, int CIB_ = 16, int PACK_ = 0>
+// WINO = 1: Winograd F(2x2, 3x3) weight gradient (3x3 kernels).  With Y = A^T [(G g G^T) (.) (B^T d B)] A per 2x2 output tile,
+//   dL/dg = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G :
+// a lane transforms the 4x4 input patch of its (channel, tile) and the 2x2 dz patch of its (output channel, tile) in
+// registers and issues ONE MFMA per Winograd position (16) and cout fragment, with K = 4 tiles: 16 multiplies per tile
+// and channel pair where the direct form does 36.  Tiles of a dilated convolution are taken inside the d x d parity
+// sub-lattices.  Loader, LDS tiles, tile walk and slabs are the direct form's; every wave owns all NT cout fragments
+// and a share of the tile quads (PW slabs per split).
+template <int KS_, int DIL_, int TH_, int TW_, int NT_, int PW_ = 1, int CIB_ = 16, int PACK_ = 0, int WINO_ = 0>
 struct WgCfg {
-  static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, NT = NT_, PW = PW_, PACK = PACK_;
+  static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, NT = NT_, PW = PW_, PACK = PACK_, WINO = WINO_;
   static constexpr int NV0 = PACK ? (KS_ + PACK_ - 1) / PACK_ : KS_;   // virtual taps per kernel row
   static constexpr int VT = KS_ * NV0;                                   // accumulator row groups (virtual taps)
   static_assert(PACK_ == 0 || (PACK_ == 4 && NT_ == 1 && DIL_ == 1), "packed-N: 4 shifts, one cout fragment, no dilation");
@@ -48,7 +55,13 @@ struct WgCfg {
   // 3x3 kernel needs 3 fragments instead of 9 and the LDS tile holds 4 channel planes instead of 16.
   static constexpr int CI = CIB_;
   static constexpr int MF = (VT * CIB_ + 15) / 16;
-  static constexpr int WAVES = NT * PW;  // wave = (cout fragment, pixel-quad residue class); PW > 1 -> PW slabs per split
+  // wave = (cout fragment, pixel-quad residue class); PW > 1 -> PW slabs per split.  Winograd: wave = tile-quad class only
+  static constexpr int WAVES = WINO ? PW : NT * PW;
+  static constexpr int NACC = WINO ? 16 * NT : MF;     // accumulator fragments per wave
+  static constexpr int NQW = TH * TW / 16;             // Winograd: quads of 2x2-output tiles per block tile
+  static_assert(!WINO_ || (KS_ == 3 && CIB_ == 16 && PACK_ == 0 && TH_ % (2 * DIL_) == 0 && TW_ % (2 * DIL_) == 0 &&
+                           (TH_ * TW_ / 16) % PW_ == 0),
+                "Winograd weight gradient: 3x3, 16 channels per block, whole tile quads per wave");
   static constexpr int NTHREADS = WAVES * 64;
   // LDS tile: + 2 columns so that it can start on an even source column whatever the left halo (column-pair loads)
   static constexpr int LR = TH + DIL * (KS - 1), LC = TW + DIL * (KS - 1) + 2;
@@ -78,7 +91,7 @@ struct WgCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const WgradArgs a) {
+__device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;
   float* zs = lds + C::X_FLOATS;
@@ -96,9 +109,9 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
   const int t_begin = split * per;
   const int t_end = min(a.total_tiles, t_begin + per);
 
-  f32x4 acc[C::MF];
+  f32x4 acc[C::NACC];
 #pragma unroll
-  for (int t = 0; t < C::MF; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < C::NACC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const long long plane = (long long)a.Hs * a.Ws;
   const long long oplane = (long long)a.Ho * a.Wo;
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
     const int u = tap / C::NV0, v = (tap - u * C::NV0) * (C::PACK ? C::PACK : 1);
     a_off[f] = ci * C::PSX + u * C::DIL * C::LC + v * C::DIL + (lane >> 4) + (a.pad_left & 1);
   }
-  const int wn = wave % C::NT, wp = wave / C::NT;
+  const int wn = C::WINO ? 0 : wave % C::NT, wp = C::WINO ? wave : wave / C::NT;
   // B lane: output channel (row of the dz tile) and, packed, the column shift s = lane & 3 (the tile has 4 halo columns)
   const int b_lane = C::PACK ? ((lane & 15) >> 2) * C::PSZ + 4 - (lane & 3) + (lane >> 4)
                              : (wn * 16 + (lane & 15)) * C::PSZ + (lane >> 4);
@@ -281,6 +294,52 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
     __syncthreads();
     if (tile + 1 < t_end) prefetch();
 
+    if constexpr (C::WINO) {
+      // ---- tile quads: lane (ci | co = lane & 15, tile k = lane >> 4 of the quad) transforms its own patches
+      constexpr int D = C::DIL, TYN = C::TH / (2 * D), TXN = C::TW / (2 * D);
+      for (int q = wp; q < C::NQW; q += C::PW) {
+        const int t = 4 * q + (lane >> 4);
+        const int tx = t % TXN, rest = t / TXN;
+        const int ty = rest % TYN, par = rest / TYN;
+        const int r0 = D * 2 * ty + par / D, c0 = D * 2 * tx + par % D;
+        const float* xa = xs + (lane & 15) * C::PSX + r0 * C::LC + c0 + e_al;
+        float d[4][4], tc[4][4], V[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[i][j] = xa[D * (i * C::LC + j)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // B^T d
+          tc[0][j] = d[0][j] - d[2][j];
+          tc[1][j] = d[1][j] + d[2][j];
+          tc[2][j] = d[2][j] - d[1][j];
+          tc[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // (B^T d) B
+          V[i][0] = tc[i][0] - tc[i][2];
+          V[i][1] = tc[i][1] + tc[i][2];
+          V[i][2] = tc[i][2] - tc[i][1];
+          V[i][3] = tc[i][1] - tc[i][3];
+        }
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) {
+          const float* zb = zs + (nt * 16 + (lane & 15)) * C::PSZ + r0 * C::TW + c0;
+          const float y00 = zb[0], y01 = zb[D], y10 = zb[D * C::TW], y11 = zb[D * C::TW + D];
+          // A dY: rows (y0), (y0 + y1), (y0 - y1), (-y1); then each row (p, q) -> (p, p + q, p - q, -q)
+          const float rp[4] = {y00, y00 + y10, y00 - y10, -y10}, rq[4] = {y01, y01 + y11, y01 - y11, -y11};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float m4[4] = {rp[i], rp[i] + rq[i], rp[i] - rq[i], -rq[i]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[(i * 4 + j) * C::NT + nt] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(V[i][j], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
+          }
+        }
+      }
+      continue;
+    }
     // ---- pixel quads: 1 B fragment + MF A fragments -> MF MFMAs, double-buffered
     float af[2][C::MF], bf[2];
     auto load_quad = [&](int qd, int buf) {
@@ -308,6 +367,36 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
 
   // ---- one partial slab per (block split, pixel-wave)
   float* slab = a.slabs + (long long)(split * C::PW + wp) * C::TAPS * a.Cin * a.Cout;
+  if constexpr (C::WINO) {   // dg = G^T dU G per (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) {
+      const int co = co0 + nt * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + (lane >> 4) * 4 + r;
+        float T[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float u0 = acc[(0 * 4 + j) * C::NT + nt][r], u1 = acc[(1 * 4 + j) * C::NT + nt][r],
+                      u2 = acc[(2 * 4 + j) * C::NT + nt][r], u3 = acc[(3 * 4 + j) * C::NT + nt][r];
+          T[0][j] = u0 + 0.5f * (u1 + u2);
+          T[1][j] = 0.5f * (u1 - u2);
+          T[2][j] = 0.5f * (u1 + u2) + u3;
+        }
+        if (ci < a.Cin && co < a.Cout) {
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const float g0 = T[u][0] + 0.5f * (T[u][1] + T[u][2]), g1 = 0.5f * (T[u][1] - T[u][2]),
+                        g2 = 0.5f * (T[u][1] + T[u][2]) + T[u][3];
+            slab[((long long)(u * 3 + 0) * a.Cin + ci) * a.Cout + co] = g0;
+            slab[((long long)(u * 3 + 1) * a.Cin + ci) * a.Cout + co] = g1;
+            slab[((long long)(u * 3 + 2) * a.Cin + ci) * a.Cout + co] = g2;
+          }
+        }
+      }
+    }
+    return;
+  }
   const int co = C::PACK ? co0 + ((lane & 15) >> 2) : co0 + wn * 16 + (lane & 15);
 #pragma unroll
   for (int f = 0; f < C::MF; ++f)
@@ -326,30 +415,51 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const Wgrad
     }
 }
 
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_mfma_f32(const WgradArgs a) {
+  conv2d_wgrad_body<C>(a);
+}
+
+// the Winograd form keeps 64 accumulator registers per cout fragment: capped at 256 registers so that two waves share a
+// SIMD (one wave per SIMD cannot cover its own LDS latency)
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, 2) void conv2d_wgrad_wino_f32(const WgradArgs a) {
+  conv2d_wgrad_body<C>(a);
+}
+
 struct WgradKernelEntry {
-  int ks, dil, th, tw, nt, waves, lds_bytes, pw, cib, pack;
+  int ks, dil, th, tw, nt, waves, lds_bytes, pw, cib, pack, wino;
   void (*launch)(const WgradArgs&, int grid, hipStream_t s);
   int (*prepare)();
 };
 
 template <class C>
 static void wgrad_launch_thunk(const WgradArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((conv2d_wgrad_mfma_f32<C>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, s, a);
+  if constexpr (C::WINO) hipLaunchKernelGGL((conv2d_wgrad_wino_f32<C>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, s, a);
+  else hipLaunchKernelGGL((conv2d_wgrad_mfma_f32<C>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, s, a);
 }
 
 template <class C>
 static int wgrad_prepare() {
-  if (C::LDS_BYTES > 64 * 1024)
-    return (int)hipFuncSetAttribute((const void*)conv2d_wgrad_mfma_f32<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    C::LDS_BYTES);
+  if (C::LDS_BYTES > 64 * 1024) {
+    const void* f;
+    if constexpr (C::WINO) f = (const void*)conv2d_wgrad_wino_f32<C>;
+    else f = (const void*)conv2d_wgrad_mfma_f32<C>;
+    return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  }
   return 0;
 }
 
 #define WGRAD_ENTRY_K(KS, DIL, TH, TW, NT, PW, CIB, PACK)                                                              \
   {                                                                                                                     \
-    KS, DIL, TH, TW, NT, NT * PW, WgCfg<KS, DIL, TH, TW, NT, PW, CIB, PACK>::LDS_BYTES, PW, CIB, PACK,                  \
+    KS, DIL, TH, TW, NT, NT * PW, WgCfg<KS, DIL, TH, TW, NT, PW, CIB, PACK>::LDS_BYTES, PW, CIB, PACK, 0,               \
         &wgrad_launch_thunk<WgCfg<KS, DIL, TH, TW, NT, PW, CIB, PACK>>,                                                 \
         &wgrad_prepare<WgCfg<KS, DIL, TH, TW, NT, PW, CIB, PACK>>                                                       \
+  }
+#define WGRAD_ENTRY_W(DIL, TH, TW, NT, PW)                                                                             \
+  {                                                                                                                     \
+    3, DIL, TH, TW, NT, PW, WgCfg<3, DIL, TH, TW, NT, PW, 16, 0, 1>::LDS_BYTES, PW, 16, 0, 1,                           \
+        &wgrad_launch_thunk<WgCfg<3, DIL, TH, TW, NT, PW, 16, 0, 1>>, &wgrad_prepare<WgCfg<3, DIL, TH, TW, NT, PW, 16, 0, 1>> \
   }
 #define WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, PW, CIB) WGRAD_ENTRY_K(KS, DIL, TH, TW, NT, PW, CIB, 0)
 #define WGRAD_ENTRY_P(KS, DIL, TH, TW, NT, PW) WGRAD_ENTRY_C(KS, DIL, TH, TW, NT, PW, 16)
