@@ -417,6 +417,37 @@ def test_conv_backward_kernels_against_oracle_all_halo_modes():
         assert np.abs(dwd.cpu().numpy() - dw_ref).max() <= 2e-5 * max(1., np.abs(dw_ref).max()), case
 
 
+def test_conv_weight_gradient_full_size_properties():
+    """Size-independent properties of dlwp_conv2d_bwd_weight at BASELINE.json's full 88x180 grid (config 2, layer 5
+    shape; the Winograd weight-gradient kernel): linearity in dz, additivity over the batch, and the adjoint identity
+    <conv(x; w), dz> == <w, dW(x, dz)> against the forward kernel."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(23)
+    n, cin, h, w, cout = 4, 64, 88, 180, 32
+    x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32)).cuda()
+    dz1 = torch.from_numpy(rng.standard_normal((n, cout, h, w)).astype(np.float32)).cuda()
+    dz2 = torch.from_numpy(rng.standard_normal((n, cout, h, w)).astype(np.float32)).cuda()
+    cd = ops.make_conv(cout, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_LINEAR)
+    xs = _lib.Shape4(n, cin, h, w)
+
+    def dw_of(xx, dz, shape=xs):
+        out = torch.empty((3, 3, cin, cout), dtype=torch.float32, device='cuda')
+        ops.conv2d_bwd_weight(xx, dz, out, cd, shape)
+        return out
+    a, b = dw_of(x, dz1), dw_of(x, dz2)
+    scale = float(a.abs().max())
+    assert float((dw_of(x, dz1 + dz2) - (a + b)).abs().max()) <= 2e-5 * scale * 2           # linear in dz
+    assert float((dw_of(x, 2 * dz1) - 2 * a).abs().max()) == 0.0                              # exactly, for a power of two
+    halves = dw_of(x[:2].contiguous(), dz1[:2].contiguous(), _lib.Shape4(2, cin, h, w)) + \
+        dw_of(x[2:].contiguous(), dz1[2:].contiguous(), _lib.Shape4(2, cin, h, w))
+    assert float((halves - a).abs().max()) <= 2e-5 * scale                                     # additive over samples
+    wt = torch.from_numpy(np_ref.glorot_uniform((3, 3, cin, cout), rng)).cuda()
+    y = ops.conv2d(x, wt, None, cd)
+    lhs = float((y.double() * dz1.double()).sum())
+    rhs = float((wt.double() * a.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), float(y.double().abs().sum()) * 1e-3)       # adjoint of the forward conv
+
+
 def test_fused_activation_backward_and_bias_gradient_equal_the_two_separate_kernels():
     """dlwp_act_bwd_bias_grad == dlwp_act_bwd followed by dlwp_bias_grad: dz bit for bit, db to float32 rounding (fixed
     but differently ordered partial sums), on a channel window, with vector (hw % 4 == 0) and scalar planes, in place."""
@@ -766,6 +797,22 @@ def test_bfloat16_activation_storage_matches_the_rounding_oracle():
     d.model.train_on_batch(x, x)
     d.model.set_activation_dtype('float32')
     assert d.predict(x).dtype == np.float32
+
+
+def test_bfloat16_mode_is_batch_invariant_and_deterministic():
+    """The kernel family AND the tile instance of the bf16 matrix-core path follow from the layer alone (never from the
+    batch size): a member's forecast does not depend on its batch mates, and repeated runs are bit-identical."""
+    rng = np.random.default_rng(61)
+    cs = (4, 16, 24)
+    d = _build(unet_layers(cs), time_dim=2)
+    _weights_of(d.model, rng)
+    d.model.set_activation_dtype('bfloat16')
+    x = rng.standard_normal((7,) + cs).astype(np.float32)
+    y = d.predict(x)
+    assert np.array_equal(y, d.predict(x))
+    for lo, hi in ((0, 1), (2, 5), (6, 7)):
+        assert np.array_equal(d.predict(x[lo:hi]), y[lo:hi])
+    d.model.set_activation_dtype('float32')
 
 
 def test_bfloat16_storage_with_the_recurrent_front_end():
