@@ -1,5 +1,7 @@
 """GPU parity at the model level, through the reference's own API (DLWPNeuralNet / DLWPFunctional build_model, predict,
 predict_timeseries, fit, evaluate) with everything below it running in libdlwp_hip.so, against the oracle."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -415,6 +417,47 @@ def test_conv_backward_kernels_against_oracle_all_halo_modes():
         case = (cin, cout, k, dil, pads, mh, mw, src)
         assert np.abs(dxd.cpu().numpy() - dx_ref).max() <= 2e-5 * max(1., np.abs(dx_ref).max()), case
         assert np.abs(dwd.cpu().numpy() - dw_ref).max() <= 2e-5 * max(1., np.abs(dw_ref).max()), case
+
+
+def test_conv_weight_gradient_random_shapes_against_oracle():
+    """40 seeded random layer geometries through the heuristic's choice of weight-gradient kernel (direct, packed-N,
+    Winograd): odd sizes, ragged channels, both dilations, all halo modes, all source modes, asymmetric halos."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(20240611)
+    kinds = set()
+    cfgs = ops.wgrad_configs()
+    for case in range(40):
+        k = int(rng.choice([3, 3, 3, 5]))
+        dil = int(rng.choice([1, 2])) if k == 3 else 1
+        cin = int(rng.choice([1, 3, 4, 8, 16, 20, 32, 40]))
+        cout = int(rng.choice([2, 4, 12, 32, 36, 64]))
+        src = int(rng.choice([0, 0, 1, 2]))
+        n = int(rng.integers(1, 4))
+        h, w = int(rng.integers(6, 26)), int(rng.integers(8, 44))
+        if src == 2:
+            h, w = h + 6, w + 8
+        mode_h, mode_w = int(rng.choice([0, 1, 2])), int(rng.choice([0, 1, 2]))
+        p = dil * (k - 1) // 2
+        pads = (p, p, p, p) if rng.integers(0, 3) else (p, p + 1, p + 1, p)       # sometimes asymmetric
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        xs64 = np.asarray(x, np.float64)
+        xt = {0: xs64, 1: np_ref.upsample2(xs64), 2: np_ref.maxpool2(xs64)}[src]
+        if (mode_h == 1 and max(pads[:2]) > xt.shape[2]) or (mode_w == 1 and max(pads[2:]) > xt.shape[3]):
+            continue
+        xp = np_ref.pad2d_modes(xt, pads, mode_h, mode_w)
+        ho, wo = xp.shape[2] - dil * (k - 1), xp.shape[3] - dil * (k - 1)
+        dz = rng.standard_normal((n, cout, ho, wo)).astype(np.float32)
+        _, dw_ref, _ = np_ref.conv2d_grads(xp, np.zeros((k, k, cin, cout)), dz, dil)
+        cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, mode_h, mode_w), ops.ACT_LINEAR, src_mode=src)
+        xs = _lib.Shape4(n, cin, h, w)
+        pick = _lib.lib.dlwp_conv2d_wgrad_pick_config(_lib.handle(0), xs, ctypes.byref(cd))
+        assert pick >= 0
+        kinds.add('packed' if cfgs[pick][4] < 0 else 'other')
+        dwd = torch.empty((k, k, cin, cout), dtype=torch.float32, device='cuda')
+        ops.conv2d_bwd_weight(torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda(), dwd, cd, xs)
+        err = np.abs(dwd.cpu().numpy() - dw_ref).max()
+        assert err <= 3e-5 * max(1., np.abs(dw_ref).max()), (case, n, cin, cout, k, dil, src, h, w, pads, mode_h, mode_w, pick, err)
+    assert 'packed' in kinds and 'other' in kinds
 
 
 def test_conv_weight_gradient_full_size_properties():
