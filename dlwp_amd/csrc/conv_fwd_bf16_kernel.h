@@ -136,28 +136,29 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
   typedef typename std::conditional<C::IN32, u32x2, unsigned>::type xraw_t;
   xraw_t xr[C::CK][C::NPP];
   u32x4 wr[C::NWV];
+  int staged_live = C::NO;   // octets of the staged chunk that hold real channels (the others are zero)
   auto prefetch = [&](int c0) {
     // channels past Cin lie outside the descriptor (its size is Cin planes): the hardware returns zeros for them, so the
-    // loop needs no clamp and no branch (a per-channel branch cost ~10 scalar instructions each: 40 % of this kernel's
-    // instruction stream on the first version)
-    if (ups) {
+    // channel loop needs no clamp and no branch (a per-channel branch cost ~10 scalar instructions each: 40 % of this
+    // kernel's instruction stream on the first version); whole OCTETS past Cin are skipped (one uniform branch each):
+    // the 6-channel ConvLSTM2D input convolution fetches 8 planes, not 16
+    staged_live = min(C::NO, (a.Cin - c0 + 7) >> 3);
 #pragma unroll
-      for (int c = 0; c < C::CK; ++c) {
+    for (int o = 0; o < C::NO; ++o) {
+      if (o >= staged_live) continue;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const int c = o * 8 + cc;
         const unsigned soff = (unsigned)(c0 + c) * plane_bytes;
 #pragma unroll
         for (int q = 0; q < C::NPP; ++q) {
-          if constexpr (C::IN32) xr[c][q] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0), 0u};
-          else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < C::CK; ++c) {
-        const unsigned soff = (unsigned)(c0 + c) * plane_bytes;
-#pragma unroll
-        for (int q = 0; q < C::NPP; ++q) {
-          if constexpr (C::IN32) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, goff[q], soff, 0);
-          else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0);
+          if (ups) {
+            if constexpr (C::IN32) xr[c][q] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0), 0u};
+            else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0);
+          } else {
+            if constexpr (C::IN32) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, goff[q], soff, 0);
+            else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0);
+          }
         }
       }
     }
@@ -178,31 +179,36 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
     }
   };
   auto commit = [&]() {
-    unsigned xd[C::CK][C::NPP];
-    if (ups) {
 #pragma unroll
-      for (int c = 0; c < C::CK; ++c)
+    for (int o = 0; o < C::NO; ++o) {
+      if (o >= staged_live) {   // no such channels: zeros
 #pragma unroll
-        for (int q = 0; q < C::NPP; ++q) xd[c][q] = pair_bits(xr[c][q], std::true_type{});
-    } else {
-#pragma unroll
-      for (int c = 0; c < C::CK; ++c)
-#pragma unroll
-        for (int q = 0; q < C::NPP; ++q) xd[c][q] = pair_bits(xr[c][q], std::false_type{});
-    }
-#pragma unroll
-    for (int o = 0; o < C::NO; ++o)
+        for (int q = 0; q < C::NPP; ++q) {
+          xo[o * C::PSO + lpos[q]] = (u32x4){0u, 0u, 0u, 0u};
+          xo[o * C::PSO + lpos[q] + 1] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < C::NPP; ++q) {
+        unsigned xd[8];
+        if (ups) {
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) xd[cc] = pair_bits(xr[o * 8 + cc][q], std::true_type{});
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) xd[cc] = pair_bits(xr[o * 8 + cc][q], std::false_type{});
+        }
         u32x4 lo, hi;   // column p / column p+1: channels 8o .. 8o+7
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          lo[j] = __builtin_amdgcn_perm(xd[o * 8 + 2 * j + 1][q], xd[o * 8 + 2 * j][q], 0x05040100u);
-          hi[j] = __builtin_amdgcn_perm(xd[o * 8 + 2 * j + 1][q], xd[o * 8 + 2 * j][q], 0x07060302u);
+          lo[j] = __builtin_amdgcn_perm(xd[2 * j + 1], xd[2 * j], 0x05040100u);
+          hi[j] = __builtin_amdgcn_perm(xd[2 * j + 1], xd[2 * j], 0x07060302u);
         }
         xo[o * C::PSO + lpos[q]] = lo;
         xo[o * C::PSO + lpos[q] + 1] = hi;
       }
+    }
 #pragma unroll
     for (int k = 0; k < C::NWV; ++k) wo[tid + k * C::NT] = wr[k];
   };
