@@ -236,6 +236,7 @@ double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
     if (e.ck == 16) pen *= e.ks == 3 ? 1.12 : 0.93;
     if (e.ck == 48) pen *= 1.3;
     if (e.waves < 4) pen *= 1.1;
+    if (e.tw == 64) pen *= 0.93;
     return (double)tiles * e.th * e.tw * a.N * (cin_pad + 24.0) * (cout_pad + 16.0) * pen;
   }
   const int bnf = e.pack > 0 ? 1 : e.bnf;

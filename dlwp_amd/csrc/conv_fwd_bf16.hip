@@ -15,6 +15,9 @@ static const ConvKernelEntry k_table[] = {
     BF16_ENTRY_IN32(3, 1, 8, 32, 4, 4, 2, 16),
     BF16_ENTRY_IN32(3, 2, 8, 32, 4, 4, 2, 16),
     BF16_ENTRY_IN32(5, 1, 8, 32, 4, 4, 1, 16),
+    // 4 x 64 tiles: 8-11 % faster than 8 x 32 on the dilation-1 layers whose width they tile well (a tile row of bf16
+    // output is then a whole 128-byte line); slower with dilation 2 (measured, profiles/r1i_bf16_conv_layers_*)
+    BF16_ENTRY(3, 1, 4, 64, 4, 4, 2, 32),
 };
 const ConvKernelEntry* dlwp_conv_table_bf16(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));
