@@ -93,18 +93,22 @@ def time_layers(model, members, iters=5):
                          'flops': 0.0, 'bytes': nb})
             continue
         lay = op.layer
+        kern, bias = ex.conv_weights(op)       # the layer's, or the phase-summed kernels of a restated decoder layer
         for _ in range(2):
-            ops.conv2d(src, lay.kernel, lay.bias, d, out=dst, x_channels=op.xs[0])
+            ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.conv2d(src, lay.kernel, lay.bias, d, out=dst, x_channels=op.xs[0])
+            ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0])
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        kh, kw = lay.kernel_size
+        _, (kh, kw), dil_run = op.conv_geometry
         co, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape     # FLOPs: what the convolution computes
         flops = 2.0 * ho * wo * co * op.xs[0] * kh * kw * members
+        executed = flops
+        if op.alg_flops is not None:           # restated layer: ALGORITHMIC FLOPs are those of the reference's layer
+            flops = float(op.alg_flops) * members
         co, ho, wo = op.out_shape                                             # bytes: what it stores
         nbytes = (float(src.element_size()) * members * op.xs[0] * op.xs[1] * op.xs[2] +
                   float(dst.element_size()) * members * co * ho * wo + 4.0 * kh * kw * op.xs[0] * co)
@@ -113,9 +117,12 @@ def time_layers(model, members, iters=5):
         pick = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(model.device.index or 0),
                                                 _lib.Shape4(members, op.xs[0], op.xs[1], op.xs[2]), ctypes.byref(d))
         cfg = ops.conv_configs()[pick] if pick >= 0 else None
-        rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': lay.dilation_rate[0], 'tile_cfg': cfg,
+        rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': dil_run[0], 'tile_cfg': cfg,
                      'out': [ho, wo], 'ms': ms, 'tflops': flops / ms / 1e9, 'gbs': nbytes / ms / 1e6,
                      'flops': flops, 'bytes': nbytes})
+        if op.alg_flops is not None:
+            rows[-1]['restated'] = ('on the low-resolution source of the UpSampling2D in front (dlwp_amd/plan.py): '
+                                    'executes %.3f of the algorithmic multiplies' % (executed / flops))
     return rows
 
 

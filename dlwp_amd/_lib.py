@@ -20,7 +20,7 @@ F32, BF16 = 0, 1
 PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
-OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES = 0, 1, 2, 3, 4, 5
+OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES, OP_PHASE_WEIGHTS, OP_DEPTH2SPACE = 0, 1, 2, 3, 4, 5, 6, 7
 BUF_NONE = -1000
 
 
@@ -103,6 +103,9 @@ _sig('dlwp_conv2d_num_configs', [])
 _sig('dlwp_conv2d_config_info', [_i, _P(_i), _P(_i)])
 _sig('dlwp_conv2d_force_config', [_i])
 _sig('dlwp_conv2d_set_winograd', [_i])
+_sig('dlwp_phase_geometry', [_i, _i, _P(_i), _P(_i), _P(_i)])
+_sig('dlwp_phase_weights', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp])
+_sig('dlwp_depth_to_space2', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_conv2d_set_bf16_mfma', [_i])
 _sig('dlwp_conv2d_uses_bf16_weights', [Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_prefers_unfused_pool', [_i, _i, _i, _i, _i, _i])

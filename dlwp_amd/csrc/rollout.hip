@@ -36,6 +36,12 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
       return dlwp_maxpool2_fwd(h, src, dst, op.xs, op.aux[0], (void*)s);
     case DLWP_OP_UPSAMPLE2:
       return dlwp_upsample2_fwd(h, src, dst, op.xs, dtype, (void*)s);
+    case DLWP_OP_DEPTH2SPACE:
+      return dlwp_depth_to_space2(h, src, dst, op.xs.n, op.xs.c, op.xs.h, op.xs.w, op.conv.out_c_off,
+                                  op.conv.out_c_total > 0 ? op.conv.out_c_total : op.xs.c, dtype, (void*)s);
+    case DLWP_OP_PHASE_WEIGHTS:   // src / dst / b / aux[0] are parameter buffers (resolved by the caller)
+      return dlwp_phase_weights(h, src, b, dst, aux ? aux[0] : nullptr, op.conv.kh, op.conv.kw, op.xs.c, op.conv.cout,
+                                op.conv.halo.top, op.conv.halo.left, dtype, (void*)s);
     case DLWP_OP_COPYCH:
       return dlwp_copy_channels(h, src, dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w, op.conv.in_c_off,
                                 op.conv.in_c_total, op.conv.out_c_off, op.conv.out_c_total, dtype, (void*)s);
@@ -65,6 +71,10 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
     if (op.kind == DLWP_OP_CONV2D)
       DLWP_CHECK_ARG(op.w >= 0 && op.w < n_buffers && op.b >= -1 && op.b < n_buffers,
                      "rollout op %d: weight/bias buffer out of range", i);
+    if (op.kind == DLWP_OP_PHASE_WEIGHTS)
+      DLWP_CHECK_ARG(op.src >= 0 && op.dst >= 0 && op.b >= -1 && op.b < n_buffers &&
+                         (op.aux[0] == DLWP_BUF_NONE || (op.aux[0] >= 0 && op.aux[0] < n_buffers)),
+                     "rollout op %d: phase-weights buffers out of range", i);
     if (op.kind == DLWP_OP_LSTM_GATES)
       for (int k = 0; k < 3; ++k)
         DLWP_CHECK_ARG((k < 2 && op.aux[k] == DLWP_BUF_NONE) || (op.aux[k] >= 0 && op.aux[k] < n_buffers),
@@ -110,12 +120,20 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
     DLWP_FAIL(DLWP_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
   }
   int rc = DLWP_OK;
+  // derived (phase-summed) kernels first: the convolutions reading them may be prepared right below
+  for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
+    if (plan[i].kind == DLWP_OP_PHASE_WEIGHTS) {
+      const dlwp_op& op = plan[i];
+      void* aux1[3] = {op.aux[0] == DLWP_BUF_NONE ? nullptr : buffers[op.aux[0]], nullptr, nullptr};
+      rc = enqueue_op(h, op, buffers[op.src], buffers[op.dst], nullptr, op.b >= 0 ? buffers[op.b] : nullptr, dtype, cap, aux1);
+    }
   if (wino_u)
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
       if (u_off[i] >= 0) rc = dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, plan[i].aux[0], cap);
   for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
       const dlwp_op& op = plan[i];
+      if (op.kind == DLWP_OP_PHASE_WEIGHTS) continue;   // done once, at the head of the graph
       const void* w = op.kind == DLWP_OP_CONV2D ? buffers[op.w] : nullptr;
       const void* b = (op.kind == DLWP_OP_CONV2D && op.b >= 0) ? buffers[op.b] : nullptr;
       void* aux[3] = {nullptr, nullptr, nullptr};

@@ -31,6 +31,7 @@ class Executor(object):
         self._bufs = {}
         self._descs = None
         self._bf16 = set(plan.bf16_buffers()) if activation_dtype == 'bfloat16' else set()
+        self._phase = None       # derived (phase-summed) kernels of plan.phase_params: [(w2, b2 | None)]
 
     # -- buffers ----------------------------------------------------------------------------------------------------- #
     def scratch(self, n):
@@ -46,15 +47,28 @@ class Executor(object):
     def alloc_outputs(self, n):
         return [torch.empty((n,) + s, dtype=torch.float32, device=self.device) for s in self.plan.output_store]
 
+    def phase_buffers(self):
+        """Device tensors of the derived kernels (plan.phase_params), allocated once; filled by the 'phasew' ops."""
+        if self._phase is None:
+            self._phase = [(torch.empty(p['w2_shape'], dtype=torch.float32, device=self.device),
+                            torch.empty(p['w2_shape'][3], dtype=torch.float32, device=self.device) if p['bias'] else None)
+                           for p in self.plan.phase_params]
+        return self._phase
+
+    def conv_weights(self, op):
+        """(kernel, bias) tensors a conv launch multiplies with: the layer's, or the derived ones of a restated layer."""
+        if op.wparam is not None:
+            return self.phase_buffers()[op.wparam]
+        return op.layer.kernel, op.layer.bias
+
     def _descriptors(self):
         from . import ops
         if self._descs is None:
             descs = []
             for op in self.plan.ops:
                 if op.kind == 'conv':
-                    lay = op.layer
-                    kh, kw = lay.kernel_size
-                    descs.append(ops.make_conv(lay.filters, kh, kw, lay.dilation_rate, ops.make_pad(*op.halo), op.act,
+                    f, (kh, kw), dil = op.conv_geometry
+                    descs.append(ops.make_conv(f, kh, kw, dil, ops.make_pad(*op.halo), op.act,
                                                op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode,
                                                op.out_pool))
                 elif op.kind == 'pad':
@@ -101,8 +115,15 @@ class Executor(object):
         for op, d in zip(self.plan.ops, self._descriptors()):
             src, dst = res(op.src), res(op.dst)
             if op.kind == 'conv':
-                ops.conv2d(src, op.layer.kernel, op.layer.bias, d, out=dst, x_channels=op.xs[0],
+                kern, bias = self.conv_weights(op)
+                ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0],
                            compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16))
+            elif op.kind == 'phasew':
+                w2, b2 = self.phase_buffers()[op.wparam]
+                ops.phase_weights(op.layer.kernel, op.layer.bias, op.halo.top, op.halo.left, w2=w2, b2=b2)
+                continue
+            elif op.kind == 'd2s':
+                ops.depth_to_space2(src, op.xs[0], out=dst, c_off=op.out_c_off)
             elif op.kind == 'pad':
                 if op.inner > 1:
                     hh, ww = op.xs[1], op.xs[2]
@@ -141,17 +162,34 @@ class Executor(object):
             table.append(lay.kernel)
             if lay.bias is not None:
                 table.append(lay.bias)
+        pidx = []                                  # derived (phase-summed) kernels: (w2 index, b2 index | -1)
+        for w2, b2 in self.phase_buffers():
+            pidx.append((len(table), len(table) + 1 if b2 is not None else -1))
+            table.append(w2)
+            if b2 is not None:
+                table.append(b2)
         kind = {'conv': _lib.OP_CONV2D, 'pad': _lib.OP_PAD2D, 'maxpool': _lib.OP_MAXPOOL2,
-                'upsample': _lib.OP_UPSAMPLE2, 'copy': _lib.OP_COPYCH, 'lstm': _lib.OP_LSTM_GATES}
+                'upsample': _lib.OP_UPSAMPLE2, 'copy': _lib.OP_COPYCH, 'lstm': _lib.OP_LSTM_GATES,
+                'phasew': _lib.OP_PHASE_WEIGHTS, 'd2s': _lib.OP_DEPTH2SPACE}
         arr = (_lib.Op * len(self.plan.ops))()
         for k, (op, d) in enumerate(zip(self.plan.ops, self._descriptors())):
             o = arr[k]
             o.kind, o.src, o.dst, o.w, o.b = kind[op.kind], op.src, op.dst, -1, -1
             o.xs = _lib.Shape4(n, *op.xs)
             if op.kind == 'conv':
-                o.w, o.b = widx[id(op.layer)]
+                o.w, o.b = pidx[op.wparam] if op.wparam is not None else widx[id(op.layer)]
                 o.conv = d
                 o.aux[0] = self._conv_dtype(op)
+            elif op.kind == 'phasew':                  # kernel -> derived kernel, once at the head of the graph
+                o.src, o.b = widx[id(op.layer)]
+                o.dst, b2i = pidx[op.wparam]
+                o.aux[0] = b2i if b2i >= 0 else _lib.BUF_NONE
+                kh, kw = op.layer.kernel_size
+                o.conv.cout, o.conv.kh, o.conv.kw = op.layer.filters, kh, kw
+                o.conv.halo.top, o.conv.halo.left = op.halo.top, op.halo.left
+                o.xs = _lib.Shape4(n, op.xs[0], 1, 1)
+            elif op.kind == 'd2s':
+                o.conv.out_c_off, o.conv.out_c_total = op.out_c_off, op.out_c_total
             elif op.kind == 'maxpool':
                 o.aux[0] = _lib.BF16 if op.src in self._bf16 else _lib.F32
             elif op.kind == 'pad':

@@ -262,6 +262,44 @@ def set_bf16_mfma(enable):
     return bool(_lib.lib.dlwp_conv2d_set_bf16_mfma(1 if enable else 0))
 
 
+def phase_geometry(k, pad):
+    """(k2, lo, hi): the window of distinct source offsets [lo, hi] (size k2) that the k taps of a convolution on a 2x
+    up-sampled axis reach, for the two output phases, with a top / left halo of `pad` on the up-sampled axis."""
+    offs = [(a + u - pad) // 2 for a in (0, 1) for u in range(k)]
+    return max(offs) - min(offs) + 1, min(offs), max(offs)
+
+
+def phase_weights(w_hwio, bias, pad_top, pad_left, w2=None, b2=None):
+    """Kernels of a Conv2D on a 2x up-sampled tensor restated on the tensor itself: (kh2, kw2, cin, 4*cout) with column
+    (2a + b)*cout + co for output phase (a, b), and the bias repeated per phase (include/dlwp_hip.h: dlwp_phase_weights)."""
+    _check_f32(w_hwio, bias)
+    kh, kw, cin, cout = w_hwio.shape
+    kh2, kw2 = phase_geometry(kh, pad_top)[0], phase_geometry(kw, pad_left)[0]
+    if w2 is None:
+        w2 = torch.empty((kh2, kw2, cin, 4 * cout), dtype=torch.float32, device=w_hwio.device)
+    if b2 is None and bias is not None:
+        b2 = torch.empty(4 * cout, dtype=torch.float32, device=w_hwio.device)
+    _lib.check(_lib.lib.dlwp_phase_weights(_lib.handle(_dev(w_hwio)), _ptr(w_hwio), _ptr(bias), _ptr(w2), _ptr(b2), kh, kw,
+                                           cin, cout, int(pad_top), int(pad_left), _lib.F32, _stream(w_hwio)))
+    return w2, b2
+
+
+def depth_to_space2(src, f, out=None, c_off=0):
+    """(n, 4F, h, w) phase-major -> (n, F, 2h, 2w): out[:, c_off + co, 2i + a, 2j + b] = src[:, (2a + b)*F + co, i, j]."""
+    _check_f32(src)
+    n, c4, h, w = src.shape
+    if c4 != 4 * f:
+        raise ValueError('depth_to_space2: %d channels is not 4 x %d' % (c4, f))
+    if out is None:
+        out = torch.empty((n, f, 2 * h, 2 * w), dtype=torch.float32, device=src.device)
+    _check_f32(out)
+    if tuple(out.shape[2:]) != (2 * h, 2 * w) or out.shape[0] != n:
+        raise ValueError('depth_to_space2: output shape %r' % (tuple(out.shape),))
+    _lib.check(_lib.lib.dlwp_depth_to_space2(_lib.handle(_dev(src)), _ptr(src), _ptr(out), n, int(f), h, w, int(c_off),
+                                             out.shape[1], _lib.F32, _stream(src)))
+    return out
+
+
 def uses_bf16_weights(xs, cd, dtype):
     """Does conv2d on an input of shape xs = (n, c, h, w) stored as `dtype` (a _lib.dtype_io code) multiply with weights
     rounded to bfloat16 (the bf16 matrix-core kernels)?  Host logic only."""

@@ -62,7 +62,7 @@ class View(object):
 
 
 class PlanOp(object):
-    """One launch.  kind in {'conv','pad','maxpool','upsample','copy','lstm'}."""
+    """One launch.  kind in {'conv','pad','maxpool','upsample','copy','lstm','phasew','d2s'}."""
 
     def __init__(self, kind, src, dst, xs, **kw):
         self.kind, self.src, self.dst = kind, src, dst
@@ -81,7 +81,19 @@ class PlanOp(object):
         self.aux = kw.pop('aux', None)
         self.out_pool = kw.pop('out_pool', False)   # conv only: MaxPooling2D(2) applied in the epilogue (inference plans)
         self.rec_act = kw.pop('rec_act', 0)
+        # conv restated on a low-resolution source (inference plans; build_plan): geometry that overrides the layer's
+        self.dil = kw.pop('dil', None)            # dilation (dh, dw)
+        self.ksize = kw.pop('ksize', None)        # kernel size (kh, kw)
+        self.filters = kw.pop('filters', None)    # output channels
+        self.wparam = kw.pop('wparam', None)      # index into plan.phase_params: derived kernel / bias instead of the layer's
+        self.alg_flops = kw.pop('alg_flops', None)   # algorithmic FLOPs per sample of the ORIGINAL layer
         assert not kw, kw
+
+    @property
+    def conv_geometry(self):
+        """(filters, (kh, kw), (dh, dw)) this conv launch runs with."""
+        lay = self.layer
+        return (self.filters or lay.filters, tuple(self.ksize or lay.kernel_size), tuple(self.dil or lay.dilation_rate))
 
     def __repr__(self):
         extra = ''
@@ -89,10 +101,11 @@ class PlanOp(object):
             extra = ' aux%r h[%d:+%d/%d] act%d rec%d' % (self.aux, self.out_c_off, self.xs[0], self.out_c_total, self.act,
                                                         self.rec_act)
         if self.kind == 'conv':
-            extra = ' %s k%s d%s src%d halo%s act%d cin[%d:+%d/%d] cout[%d:+%d/%d]%s' % (
-                self.layer.name, self.layer.kernel_size, self.layer.dilation_rate, self.src_mode, tuple(self.halo),
-                self.act, self.in_c_off, self.xs[0], self.in_c_total, self.out_c_off, self.layer.filters,
-                self.out_c_total, ' +pool' if self.out_pool else '')
+            f, ks, dil = self.conv_geometry
+            extra = ' %s k%s d%s src%d halo%s act%d cin[%d:+%d/%d] cout[%d:+%d/%d]%s%s' % (
+                self.layer.name, ks, dil, self.src_mode, tuple(self.halo),
+                self.act, self.in_c_off, self.xs[0], self.in_c_total, self.out_c_off, f,
+                self.out_c_total, ' +pool' if self.out_pool else '', ' phase-kernels' if self.wparam is not None else '')
         return '<%s %s -> %s xs=%s%s>' % (self.kind, self.src, self.dst, self.xs, extra)
 
 
@@ -104,6 +117,7 @@ class Plan(object):
         self.output_shapes = []  # per-sample logical shapes of the model outputs
         self.output_store = []   # per-sample stored (c, h, w) of each output slot
         self.conv_layers = []    # unique Conv2D layers in first-use order
+        self.phase_params = []   # derived (phase-summed) kernels: dicts layer, w2_shape, b2 (bool), pad_top, pad_left
 
     def new_buffer(self, c, h, w):
         self.buffers.append((int(c), int(h), int(w)))
@@ -125,6 +139,9 @@ class Plan(object):
         tot = 0
         for op in self.ops:
             if op.kind == 'conv':
+                if op.alg_flops is not None:
+                    tot += op.alg_flops
+                    continue
                 kh, kw = op.layer.kernel_size
                 co, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape
                 tot += 2 * ho * wo * co * op.xs[0] * kh * kw
@@ -211,6 +228,13 @@ def _prefers_unfused_pool(cin, lay):
         return False
 
 
+def _phase_geometry(k, pad):
+    """(k2, lo, hi): the distinct source offsets [lo, hi] the k taps of an axis reach on a 2x up-sampled tensor with a
+    top / left halo of `pad` (csrc/phase.hip, ops.phase_geometry)."""
+    offs = [(a + u - pad) // 2 for a in (0, 1) for u in range(k)]
+    return max(offs) - min(offs) + 1, min(offs), max(offs)
+
+
 def toposort(outputs):
     order, seen = [], set()
 
@@ -229,8 +253,8 @@ def toposort(outputs):
 def _supports_out_pool(op):
     try:
         from . import ops
-        lay = op.layer
-        cd = ops.make_conv(lay.filters, lay.kernel_size[0], lay.kernel_size[1], lay.dilation_rate, ops.make_pad(*op.halo),
+        f, ks, dil = op.conv_geometry
+        cd = ops.make_conv(f, ks[0], ks[1], dil, ops.make_pad(*op.halo),
                            op.act, op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode)
         return ops.supports_out_pool(op.xs, cd)
     except (ImportError, OSError, AttributeError):
@@ -496,15 +520,56 @@ def build_plan(inputs, outputs, inference=False):
             _, hl, wl = v.copy(halo=halo).logical
             ho = hl - lay.dilation_rate[0] * (lay.kernel_size[0] - 1)
             wo = wl - lay.dilation_rate[1] * (lay.kernel_size[1] - 1)
-            if outs:
+            kh, kw = lay.kernel_size
+            alg = 2 * ho * wo * lay.filters * v.c * kh * kw
+            # ---- inference: a convolution on a 2x nearest-neighbour up-sampled tensor, restated on the tensor itself.
+            # (a) dilation 2, even halo: tap u of output row 2i + a reads source row i + u - top/2 whatever a is, so the
+            #     result is UpSampling2D(conv with dilation 1 and half the halo on the low-resolution tensor): a quarter
+            #     of the multiplies, and the up-sampling stays lazy for the consumer.
+            if (inference and v.src_mode == SRC_UPSAMPLE2 and tuple(lay.dilation_rate) == (2, 2) and
+                    all(p % 2 == 0 for p in halo[:4]) and ho % 2 == 0 and wo % 2 == 0):
+                h2 = Halo(halo.top // 2, halo.bottom // 2, halo.left // 2, halo.right // 2, halo.mode_h, halo.mode_w)
+                dst = plan.new_buffer(lay.filters, ho // 2, wo // 2)
+                emit(PlanOp('conv', v.buf, dst, (v.c, v.h, v.w), layer=lay, halo=h2, src_mode=SRC_DIRECT,
+                            act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
+                            out_c_total=lay.filters, out_shape=(lay.filters, ho // 2, wo // 2), dil=(1, 1), alg_flops=alg))
+                views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho // 2, wo // 2, src_mode=SRC_UPSAMPLE2)
+            # (b) dilation 1: the k taps of an axis fall on k2 < k distinct source pixels; each of the 4 output phases is
+            #     a k2 x k2 kernel of summed weights over the SAME window, so the layer runs as one convolution with
+            #     4 x filters channels on the low-resolution tensor + a depth-to-space interleave (csrc/phase.hip).
+            elif (inference and v.src_mode == SRC_UPSAMPLE2 and tuple(lay.dilation_rate) == (1, 1) and
+                  ho == 2 * v.h and wo == 2 * v.w and
+                  _phase_geometry(kh, halo.top)[0] * _phase_geometry(kw, halo.left)[0] < kh * kw):
+                (kh2, lo_h, hi_h), (kw2, lo_w, hi_w) = _phase_geometry(kh, halo.top), _phase_geometry(kw, halo.left)
+                h2 = Halo(-lo_h, hi_h, -lo_w, hi_w, halo.mode_h, halo.mode_w)
+                pidx = len(plan.phase_params)
+                plan.phase_params.append({'layer': lay, 'w2_shape': (kh2, kw2, v.c, 4 * lay.filters),
+                                          'bias': lay.use_bias, 'pad_top': halo.top, 'pad_left': halo.left})
+                emit(PlanOp('phasew', STATE_IN, STATE_IN, (v.c, 0, 0), layer=lay, wparam=pidx, halo=halo,
+                            out_shape=(0, 0, 0)))
+                tmp = plan.new_buffer(4 * lay.filters, v.h, v.w)
+                emit(PlanOp('conv', v.buf, tmp, (v.c, v.h, v.w), layer=lay, halo=h2, src_mode=SRC_DIRECT,
+                            act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
+                            out_c_total=4 * lay.filters, out_shape=(4 * lay.filters, v.h, v.w), dil=(1, 1),
+                            ksize=(kh2, kw2), filters=4 * lay.filters, wparam=pidx, alg_flops=alg))
+                if outs:
+                    dst = OUT(outs[0])
+                    plan.output_store[outs[0]] = (lay.filters, ho, wo)
+                else:
+                    dst = plan.new_buffer(lay.filters, ho, wo)
+                emit(PlanOp('d2s', tmp, dst, (lay.filters, v.h, v.w), out_c_off=0, out_c_total=lay.filters,
+                            out_shape=(lay.filters, ho, wo)))
+                views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)
+            else:
+              if outs:
                 dst = OUT(outs[0])
                 plan.output_store[outs[0]] = (lay.filters, ho, wo)
-            else:
+              else:
                 dst = plan.new_buffer(lay.filters, ho, wo)
-            emit(PlanOp('conv', v.buf, dst, (v.c, v.h, v.w), layer=lay, halo=halo, src_mode=v.src_mode,
+              emit(PlanOp('conv', v.buf, dst, (v.c, v.h, v.w), layer=lay, halo=halo, src_mode=v.src_mode,
                         act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
                         out_c_total=lay.filters, out_shape=(lay.filters, ho, wo)))
-            views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)
+              views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)
         else:
             raise NotImplementedError('layer %s (%s) has no HIP lowering' % (lay.name, type(lay).__name__))
 

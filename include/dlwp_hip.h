@@ -201,6 +201,19 @@ int dlwp_copy_channels(dlwp_handle_t, const void* src, void* dst, int n, int c, 
 int dlwp_series_merge_time(dlwp_handle_t, const void* series, void* out, int t, int n, int time_dim, int v, int hw,
                            int dtype, void* stream);
 
+/* ---- Conv2D on a 2x nearest-neighbour up-sampled tensor, restated on the tensor itself (the decoder layers
+ *      UpSampling2D -> padding -> Conv2D of examples/train.py:191-219, Azure/train_tf.py:247-268): the k x k taps fall on few
+ *      distinct source pixels, so each of the 4 output phases is a small kernel of summed weights on the low-resolution
+ *      tensor; the 4 phases run as ONE convolution with 4*cout channels + a depth-to-space interleave (phase.hip).
+ *      dlwp_phase_geometry: per axis, the window [lo, hi] of source offsets and its size k2 for kernel size k and the
+ *      top / left halo `pad` of the up-sampled tensor.  dlwp_phase_weights: w (kh,kw,cin,cout), bias -> w2
+ *      (kh2,kw2,cin,4*cout), b2 (4*cout, nullable) with column (2a+b)*cout + co for output phase (a, b).                */
+int dlwp_phase_geometry(int k, int pad, int* k2, int* lo, int* hi);
+int dlwp_phase_weights(dlwp_handle_t, const void* w, const void* bias, void* w2, void* b2, int kh, int kw, int cin, int cout,
+                       int pad_top, int pad_left, int dtype, void* stream);
+int dlwp_depth_to_space2(dlwp_handle_t, const void* src, void* dst, int n, int f, int h, int w, int c_off, int c_total,
+                         int dtype, void* stream);
+
 /* ---- ConvLSTM2D cell update (keras ConvLSTM2DCell.call; call sites examples/train.py:148-155,
  *      examples/train_functional.py:207-219).  zx / zh: (n, 4F, h*w) gate pre-activations i | f | c | o from the input
  *      convolution (+bias) and the recurrent 'same' convolution of h_{t-1}; zh and c_prev may be NULL on the first step
@@ -231,6 +244,11 @@ int dlwp_convlstm_gates_bwd(dlwp_handle_t, const void* zx, const void* zh, const
 #define DLWP_OP_UPSAMPLE2  3
 #define DLWP_OP_COPYCH     4
 #define DLWP_OP_LSTM_GATES 5
+#define DLWP_OP_PHASE_WEIGHTS 6   /* src = kernel buffer, w = -1 | bias buffer index in b, dst = w2 buffer, aux[0] = b2 buffer |
+                                   * -1000; conv = {cout, kh, kw, halo.top, halo.left}, xs.c = cin.  Run ONCE at the head of
+                                   * the rollout graph (the weights do not change inside a launch). */
+#define DLWP_OP_DEPTH2SPACE 7     /* src (n, 4F, h, w) -> dst window [conv.out_c_off, +F) of conv.out_c_total channels at
+                                   * (2h, 2w); xs = (n, F, h, w) */
 typedef struct {
   int kind;                 /* DLWP_OP_*                                                                  */
   int src, dst;             /* buffer indices                                                              */

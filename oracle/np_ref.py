@@ -328,6 +328,42 @@ def init_conv_lstm_weights(cin, filters, ks, rng):
 
 
 # ------------------------------------------------------------------------------------------------------------------ #
+# Conv2D on a 2x nearest-neighbour up-sampled tensor restated on the tensor itself (the product's inference plan does
+# this for the decoder layers of examples/train.py:191-219; csrc/phase.hip).  Restated here independently, from the
+# definition: tap u of output row 2i + a reads up-sampled row 2i + a + u - pad, i.e. source row i + floor((a+u-pad)/2).
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def phase_weights(w_hwio, bias, pad_top, pad_left):
+    """w (kh,kw,cin,cout) -> (w2 (kh2,kw2,cin,4*cout), b2 (4*cout) | None, (lo_h, hi_h, lo_w, hi_w)): column
+    (2a + b)*cout + co of w2 is the kernel of output phase (a, b) on the low-resolution tensor."""
+    w = np.asarray(w_hwio, dtype=np.float64)
+    kh, kw, cin, cout = w.shape
+    off_h = [[(a + u - pad_top) // 2 for u in range(kh)] for a in (0, 1)]
+    off_w = [[(b + v - pad_left) // 2 for v in range(kw)] for b in (0, 1)]
+    lo_h, hi_h = min(min(r) for r in off_h), max(max(r) for r in off_h)
+    lo_w, hi_w = min(min(r) for r in off_w), max(max(r) for r in off_w)
+    w2 = np.zeros((hi_h - lo_h + 1, hi_w - lo_w + 1, cin, 4 * cout))
+    for a in (0, 1):
+        for b in (0, 1):
+            col = (2 * a + b) * cout
+            for u in range(kh):
+                for v in range(kw):
+                    w2[off_h[a][u] - lo_h, off_w[b][v] - lo_w, :, col:col + cout] += w[u, v]
+    b2 = None if bias is None else np.tile(np.asarray(bias, dtype=np.float64), 4)
+    return w2, b2, (lo_h, hi_h, lo_w, hi_w)
+
+
+def depth_to_space2(y, cout):
+    """(N, 4*cout, H, W) phase-major -> (N, cout, 2H, 2W)."""
+    n, c4, h, w = y.shape
+    out = np.zeros((n, cout, 2 * h, 2 * w), dtype=y.dtype)
+    for a in (0, 1):
+        for b in (0, 1):
+            out[:, :, a::2, b::2] = y[:, (2 * a + b) * cout:(2 * a + b + 1) * cout]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
 # a tiny interpreter for the reference's (layer_name, args, kwargs) stacks  (examples/train.py:142-221)
 # ------------------------------------------------------------------------------------------------------------------ #
 

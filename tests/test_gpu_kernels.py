@@ -683,3 +683,52 @@ def test_conv2d_random_shapes_against_oracle(ops):
         n_wino += int(k == 3 and cin % 8 == 0 and cout % 32 == 0 and src != 2)
     # the sweep really reaches the pooled epilogues, the Winograd family and the bf16 matrix-core family
     assert n_pool >= 3 and n_wino >= 5 and n_bf16 >= 2, (n_pool, n_wino, n_bf16)
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# Conv2D on an up-sampled tensor restated on its source: derived kernels and the depth-to-space interleave
+# ----------------------------------------------------------------------------------------------------------------- #
+
+@pytest.mark.parametrize('k,pt,pl', [(5, 2, 2), (3, 1, 1), (7, 3, 3), (5, 1, 2), (4, 1, 2)])
+def test_phase_weights_match_the_oracle_restatement(ops, k, pt, pl):
+    rng = np.random.default_rng(k * 10 + pt)
+    w = rng.standard_normal((k, k, 6, 5)).astype(np.float32)
+    b = rng.standard_normal(5).astype(np.float32)
+    w2_ref, b2_ref, (lo_h, hi_h, lo_w, hi_w) = np_ref.phase_weights(w, b, pt, pl)
+    assert ops.phase_geometry(k, pt) == (hi_h - lo_h + 1, lo_h, hi_h) and ops.phase_geometry(k, pl) == (hi_w - lo_w + 1, lo_w, hi_w)
+    w2, b2 = ops.phase_weights(dev(w), dev(b), pt, pl)
+    assert tuple(w2.shape) == w2_ref.shape
+    assert np.abs(host(w2) - w2_ref).max() < 1e-6 and np.array_equal(host(b2), b2_ref.astype(np.float32))
+    w2n, b2n = ops.phase_weights(dev(w), None, pt, pl)
+    assert b2n is None and torch.equal(w2n, w2)
+
+
+def test_depth_to_space_is_exact(ops):
+    rng = np.random.default_rng(4)
+    for n, f, h, w in ((2, 4, 5, 7), (1, 3, 1, 1), (3, 1, 8, 6)):
+        y = rng.standard_normal((n, 4 * f, h, w)).astype(np.float32)
+        got = host(ops.depth_to_space2(dev(y), f))
+        assert np.array_equal(got, np_ref.depth_to_space2(y, f))
+        out = torch.full((n, f + 3, 2 * h, 2 * w), 7.0, device='cuda')
+        ops.depth_to_space2(dev(y), f, out=out, c_off=2)
+        o = host(out)
+        assert np.array_equal(o[:, 2:2 + f], np_ref.depth_to_space2(y, f)) and np.all(o[:, :2] == 7.0) and np.all(o[:, 2 + f:] == 7.0)
+
+
+@pytest.mark.parametrize('k,dil,pads,mh,mw', [(5, 1, (2, 2, 2, 2), 0, 1), (5, 1, (2, 2, 2, 2), 2, 0), (7, 1, (3, 3, 3, 3), 1, 1)])
+def test_conv_on_upsampled_source_restated_path_equals_the_fused_upsampling_loader(ops, k, dil, pads, mh, mw):
+    """The two ways the library can run UpSampling2D -> padding -> Conv2D: the loader that up-samples on the fly, and the
+    phase kernels on the source + depth-to-space.  Same function (fp32 rounding apart), both against the oracle."""
+    rng = np.random.default_rng(k)
+    n, cin, h, w, cout = 2, 16, 9, 14, 4
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    want = _conv_ref(x, wt, b, dil, pads, mh, mw, 'tanh', 1)
+    cd = ops.make_conv(cout, k, k, dil, ops.make_pad(*pads, mh, mw), ops.ACT_TANH, src_mode=1)
+    _check_conv(ops, host(ops.conv2d(dev(x), dev(wt), dev(b), cd)), want, 'fused loader')
+    w2, b2 = ops.phase_weights(dev(wt), dev(b), pads[0], pads[2])
+    (k2h, lo_h, hi_h), (k2w, lo_w, hi_w) = ops.phase_geometry(k, pads[0]), ops.phase_geometry(k, pads[2])
+    cd2 = ops.make_conv(4 * cout, k2h, k2w, 1, ops.make_pad(-lo_h, hi_h, -lo_w, hi_w, mh, mw), ops.ACT_TANH)
+    got = host(ops.depth_to_space2(ops.conv2d(dev(x), w2, b2, cd2), cout))
+    _check_conv(ops, got, want, 'restated')

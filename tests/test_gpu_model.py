@@ -819,7 +819,10 @@ def test_bfloat16_activation_storage_matches_the_rounding_oracle():
     x = rng.standard_normal((5,) + cs).astype(np.float32)
     y32 = d.predict(x)
     d.model.set_activation_dtype('bfloat16')
-    assert [b.dtype for b in d.model.executor.scratch(5)] == [torch.bfloat16] * len(d.model.infer_plan.buffers)
+    # every scratch buffer is bf16 except the phase-major output of the restated 5x5 layer (read by depth-to-space)
+    d2s_src = set(op.src for op in d.model.infer_plan.ops if op.kind == 'd2s')
+    assert [b.dtype for b in d.model.executor.scratch(5)] == \
+        [torch.float32 if i in d2s_src else torch.bfloat16 for i in range(len(d.model.infer_plan.buffers))]
     y16 = d.predict(x)
     on16 = _bf16_weight_indices(d.model, 5)
     assert 0 in on16 and len(on16) >= 3        # the first layer too: its float32 input is rounded by the loader
@@ -827,7 +830,9 @@ def test_bfloat16_activation_storage_matches_the_rounding_oracle():
     assert y16.dtype == np.float32 and y16.shape == y32.shape
     # different summation order -> a few intermediate values round to the neighbouring bf16; the effect on the output is
     # far below the bf16-vs-fp32 difference itself
-    assert _rel(y16, want) < 4e-3
+    # (the restated 5x5 output layer multiplies with bf16-rounded SUMS of taps where the oracle sums bf16-rounded taps:
+    # another 2^-9-relative effect of the same kind)
+    assert _rel(y16, want) < 6e-3
     assert 1e-4 < _rel(y16, y32) < 3e-2
     # rollout: captured graph == host loop over predict(), bit for bit, in bf16 mode too
     series = d.predict_timeseries(x, 4)

@@ -131,3 +131,27 @@ def test_conv_lstm2d_numpy_and_torch_restatements_agree():
     z = np_ref.conv2d(xp[:, 0], k, b, 2, 'linear')
     c0 = np_ref.hard_sigmoid(z[:, :8]) * np.tanh(z[:, 16:24])
     assert np.abs(a[:, :8] - np_ref.hard_sigmoid(z[:, 24:]) * np.tanh(c0)).max() < 1e-12
+
+
+def test_conv_on_upsampled_tensor_equals_its_restatement_on_the_source():
+    """np_ref.phase_weights / depth_to_space2 (what the product's inference plan does with the decoder layers) against the
+    definition: conv(pad(upsample2(x)), w) for 5x5 / 3x3 / 7x7 kernels, symmetric and asymmetric halos, every halo mode;
+    and the dilation-2 identity conv_d2(pad_2p(upsample2(x))) == upsample2(conv_d1(pad_p(x)))."""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((2, 5, 6, 8))
+    for k, pads in ((5, (2, 2, 2, 2)), (3, (1, 1, 1, 1)), (7, (3, 3, 3, 3)), (5, (1, 3, 2, 2)), (4, (1, 2, 2, 1))):
+        for mh, mw in ((0, 1), (1, 1), (2, 0), (0, 2)):
+            w = rng.standard_normal((k, k, 5, 3))
+            b = rng.standard_normal(3)
+            want = np_ref.conv2d(np_ref.pad2d_modes(np_ref.upsample2(x), pads, mh, mw), w, b, 1, 'tanh')
+            if want.shape[2:] != (12, 16):
+                continue                                   # only 'same' geometries are restated
+            w2, b2, (lo_h, hi_h, lo_w, hi_w) = np_ref.phase_weights(w, b, pads[0], pads[2])
+            y = np_ref.conv2d(np_ref.pad2d_modes(x, (-lo_h, hi_h, -lo_w, hi_w), mh, mw), w2, b2, 1, 'tanh')
+            got = np_ref.depth_to_space2(y, 3)
+            assert np.abs(got - want).max() < 1e-12, (k, pads, mh, mw)
+    w = rng.standard_normal((3, 3, 5, 4))
+    for mh, mw in ((0, 1), (1, 1), (2, 2)):
+        want = np_ref.conv2d(np_ref.pad2d_modes(np_ref.upsample2(x), (2, 2, 2, 2), mh, mw), w, None, 2, 'tanh')
+        got = np_ref.upsample2(np_ref.conv2d(np_ref.pad2d_modes(x, (1, 1, 1, 1), mh, mw), w, None, 1, 'tanh'))
+        assert np.abs(got - want).max() < 1e-12

@@ -64,7 +64,8 @@ def main():
         src, dst = res(op.src), res(op.dst)
         if op.kind == 'conv':
             c16 = op.dst in ex._bf16 and op.src not in ex._bf16      # as Executor.run: float32 state rounded by the loader
-            fn = lambda: ops.conv2d(src, op.layer.kernel, op.layer.bias, desc, out=dst, x_channels=op.xs[0],  # noqa: E731
+            kern, bias = ex.conv_weights(op)
+            fn = lambda: ops.conv2d(src, kern, bias, desc, out=dst, x_channels=op.xs[0],  # noqa: E731
                                     compute_bf16=c16)
         elif op.kind == 'lstm':
             zh, cp, co = op.aux
@@ -90,6 +91,8 @@ def main():
             kh, kw = op.layer.kernel_size
             co_, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape
             fl = 2.0 * ho * wo * co_ * op.xs[0] * kh * kw * a.members
+            if op.alg_flops is not None:       # decoder layer restated on its low-resolution source: algorithmic FLOPs
+                fl = float(op.alg_flops) * a.members
             on16 = any(op.layer is l16 for l16 in ex.bf16_weight_layers(a.members))
             row.update(layer=op.layer.name, cin=op.xs[0], cout=co_, k=kh, tflops=round(fl / ms / 1e9, 1),
                        family='bf16 mfma' if on16 else 'fp32 mfma',
