@@ -10,6 +10,7 @@ pad on the same axis with another mode, ...) is it materialised with the standal
 A plan is pure host data (no device access): it can be built and inspected on a machine without a GPU.
 """
 import collections
+import os
 
 from . import layers as L
 
@@ -226,6 +227,11 @@ def _prefers_unfused_pool(cin, lay):
                                         lay.dilation_rate[0], lay.dilation_rate[1])
     except (ImportError, OSError, AttributeError):
         return False
+
+
+# Inference plans restate a Conv2D that reads a 2x up-sampled tensor on the low-resolution tensor (see build_plan).
+# DLWP_RESTATE_UPSAMPLED=0 keeps the reference's own formulation (the fused up-sampling loader) for A/B comparisons.
+RESTATE_UPSAMPLED = os.environ.get('DLWP_RESTATE_UPSAMPLED', '1') != '0'
 
 
 def _phase_geometry(k, pad):
@@ -526,7 +532,8 @@ def build_plan(inputs, outputs, inference=False):
             # (a) dilation 2, even halo: tap u of output row 2i + a reads source row i + u - top/2 whatever a is, so the
             #     result is UpSampling2D(conv with dilation 1 and half the halo on the low-resolution tensor): a quarter
             #     of the multiplies, and the up-sampling stays lazy for the consumer.
-            if (inference and v.src_mode == SRC_UPSAMPLE2 and tuple(lay.dilation_rate) == (2, 2) and
+            restate = inference and RESTATE_UPSAMPLED and v.src_mode == SRC_UPSAMPLE2
+            if (restate and tuple(lay.dilation_rate) == (2, 2) and
                     all(p % 2 == 0 for p in halo[:4]) and ho % 2 == 0 and wo % 2 == 0):
                 h2 = Halo(halo.top // 2, halo.bottom // 2, halo.left // 2, halo.right // 2, halo.mode_h, halo.mode_w)
                 dst = plan.new_buffer(lay.filters, ho // 2, wo // 2)
@@ -537,7 +544,7 @@ def build_plan(inputs, outputs, inference=False):
             # (b) dilation 1: the k taps of an axis fall on k2 < k distinct source pixels; each of the 4 output phases is
             #     a k2 x k2 kernel of summed weights over the SAME window, so the layer runs as one convolution with
             #     4 x filters channels on the low-resolution tensor + a depth-to-space interleave (csrc/phase.hip).
-            elif (inference and v.src_mode == SRC_UPSAMPLE2 and tuple(lay.dilation_rate) == (1, 1) and
+            elif (restate and tuple(lay.dilation_rate) == (1, 1) and
                   ho == 2 * v.h and wo == 2 * v.w and
                   _phase_geometry(kh, halo.top)[0] * _phase_geometry(kw, halo.left)[0] < kh * kw):
                 (kh2, lo_h, hi_h), (kw2, lo_w, hi_w) = _phase_geometry(kh, halo.top), _phase_geometry(kw, halo.left)
