@@ -255,7 +255,11 @@ def main():
                                % (grid[0], grid[1], a.channels, a.forwards, a.members),
                    'members_per_gpu': a.members, 'forwards_per_rollout': a.forwards, 'time_dim': 2,
                    'grid': list(grid), 'channels': a.channels, 'launches_per_forward': net.infer_plan.n_launches,
-                   'parallelism': 'members sharded over %d GPU(s), no collective' % world},
+                   'parallelism': 'members sharded over %d GPU(s), no collective' % world,
+                   'inference_plan': ('Winograd F(2x2,3x3) on the 3x3 layers; the decoder layers that read an up-sampled '
+                                      'tensor are restated on the low-resolution tensor (same function, DESIGN.md 5.7; '
+                                      'DLWP_RESTATE_UPSAMPLED=0 runs the reference formulation); FLOP figures are '
+                                      'algorithmic (the reference graph, SURVEY.md 8d)')},
         'forwards_per_s': fwd_per_s,
         'conv_mflop_per_forward_per_member': flops_fwd / 1e6,
         'forward': {'achieved_tflops': fwd_per_s * flops_fwd / 1e12 / world,
