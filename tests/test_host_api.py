@@ -35,9 +35,12 @@ def test_build_model_accepts_reference_triples_and_fuses_to_six_launches():
     plan = d.model.plan
     assert [op.kind for op in plan.ops] == ['conv'] * 6         # 22 reference layers -> 6 fused launches
     assert plan.conv_flops_per_sample() == 1597685760           # 1 597.7 MFLOP
-    assert [op.src_mode for op in plan.ops] == [0, 2, 2, 1, 1, 0]
+    # layer 5 (3x3, dilation 2, on an up-sampled tensor) is its own up-sampling identity: a dilation-1 layer on the
+    # 44x90 tensor (halo 1), whose output layer 6 reads through the up-sampling loader
+    assert [op.src_mode for op in plan.ops] == [0, 2, 2, 1, 0, 1]
     assert all(op.halo.mode_h == P.PAD_ZERO and op.halo.mode_w == P.PAD_WRAP for op in plan.ops)
-    assert [op.halo.left for op in plan.ops] == [2, 1, 1, 1, 2, 2]
+    assert [op.halo.left for op in plan.ops] == [2, 1, 1, 1, 1, 2]
+    assert plan.ops[4].conv_geometry == (32, (3, 3), (1, 1)) and plan.ops[4].out_shape == (32, 44, 90)
     assert plan.ops[-1].dst == P.OUT(0) and plan.ops[0].src == P.STATE_IN
     assert d.model.metrics_names == ['loss', 'mean_absolute_error']
     names = [lay.name for lay in d.base_model.layers]
@@ -52,8 +55,8 @@ def test_default_plan_pools_once_in_front_of_the_winograd_layers():
     plan = d.model.plan
     assert [op.kind for op in plan.ops] == ['conv', 'maxpool', 'conv', 'maxpool', 'conv', 'conv', 'conv', 'conv']
     assert plan.conv_flops_per_sample() == 1597685760
-    assert [op.src_mode for op in plan.ops if op.kind == 'conv'] == [0, 0, 0, 1, 1, 0]
-    assert [op.halo.left for op in plan.ops if op.kind == 'conv'] == [2, 1, 1, 1, 2, 2]
+    assert [op.src_mode for op in plan.ops if op.kind == 'conv'] == [0, 0, 0, 1, 0, 1]      # (layer 5 restated, see above)
+    assert [op.halo.left for op in plan.ops if op.kind == 'conv'] == [2, 1, 1, 1, 1, 2]
 
 
 def test_build_model_argument_errors_match_the_reference():
@@ -146,7 +149,8 @@ def test_planner_skip_unet_slices_are_free_and_concat_is_a_copy():
     finally:
         ops.set_winograd(True)
     kinds = [op.kind for op in m.plan.ops]
-    assert kinds.count('conv') == 6 and kinds.count('copy') == 4 and set(kinds) == {'conv', 'copy'}
+    # (c5 -- dilation 2 on an up-sampled tensor -- is computed at low resolution; its up-sampling lands in the concat buffer)
+    assert kinds.count('conv') == 6 and kinds.count('copy') == 4 and set(kinds) == {'conv', 'copy', 'upsample'}
     convs = [op for op in m.plan.ops if op.kind == 'conv']
     assert (convs[1].in_c_off, convs[1].xs[0], convs[1].in_c_total) == (0, 16, 32)     # slice_layer(0,16) read in place
     assert (convs[2].in_c_off, convs[2].xs[0], convs[2].in_c_total) == (0, 32, 64)
