@@ -106,6 +106,8 @@ _sig('dlwp_conv2d_set_winograd', [_i])
 _sig('dlwp_phase_geometry', [_i, _i, _P(_i), _P(_i), _P(_i)])
 _sig('dlwp_phase_weights', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_depth_to_space2', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp])
+_sig('dlwp_space_to_depth2', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp])
+_sig('dlwp_phase_weights_bwd', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_conv2d_set_bf16_mfma', [_i])
 _sig('dlwp_conv2d_uses_bf16_weights', [Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_prefers_unfused_pool', [_i, _i, _i, _i, _i, _i])

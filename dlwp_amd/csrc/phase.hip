@@ -63,6 +63,54 @@ __global__ __launch_bounds__(256) void depth_to_space2_kernel(const float* __res
   }
 }
 
+// backward of phase_weights_kernel (a linear map): dw[u][v][ci][co] (+)= sum over phases of
+// dw2[off_a(u) - lo_h][off_b(v) - lo_w][ci][(2a + b)*cout + co]; db[co] (+)= sum over phases of db2[ph*cout + co]
+__global__ __launch_bounds__(256) void phase_weights_bwd_kernel(const float* __restrict__ dw2, const float* __restrict__ db2,
+                                                                float* __restrict__ dw, float* __restrict__ db, int kh,
+                                                                int kw, int cin, int cout, int pt, int pl, int kw2, int lo_h,
+                                                                int lo_w, int accumulate) {
+  const long long total = (long long)kh * kw * cin * cout;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int co = (int)(e % cout);
+    long long q = e / cout;
+    const int ci = (int)(q % cin);
+    q /= cin;
+    const int v = (int)(q % kw), u = (int)(q / kw);
+    float s = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const int du = floordiv2((ph >> 1) + u - pt) - lo_h, dv = floordiv2((ph & 1) + v - pl) - lo_w;
+      s += dw2[(((long long)du * kw2 + dv) * cin + ci) * (4 * cout) + ph * cout + co];
+    }
+    dw[e] = accumulate ? dw[e] + s : s;
+  }
+  if (db && db2 && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < cout; c += 256) {
+      const float s = (db2[c] + db2[cout + c]) + (db2[2 * cout + c] + db2[3 * cout + c]);
+      db[c] = accumulate ? db[c] + s : s;
+    }
+}
+
+// inverse of depth_to_space2_kernel: dst[n][(2a + b)*F + co][i][j] = src[n][c_off + co][2i + a][2j + b]
+__global__ __launch_bounds__(256) void space_to_depth2_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              long long total, int F, int h, int w, int c_off, int c_total) {
+  const long long hw = (long long)h * w;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int j = (int)(e % w);
+    long long q = e / w;
+    const int i = (int)(q % h);
+    q /= h;
+    const int co = (int)(q % F);
+    const long long n = q / F;
+    const float* s = src + ((n * c_total + c_off + co) * 2 * h + 2 * i) * (2ll * w) + 2 * j;
+    float* d = dst + (n * 4 * F + co) * hw + (long long)i * w + j;
+    d[0] = s[0];
+    d[(long long)F * hw] = s[1];
+    d[2ll * F * hw] = s[2 * w];
+    d[3ll * F * hw] = s[2 * w + 1];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -98,6 +146,39 @@ int dlwp_phase_weights(dlwp_handle_t h, const void* w, const void* bias, void* w
                                                                       (float*)b2, kh, kw, cin, cout, pad_top, pad_left, kh2,
                                                                       kw2, lo_h, lo_w);
   DLWP_LAUNCH_CHECK("phase_weights_kernel");
+  return DLWP_OK;
+}
+
+int dlwp_phase_weights_bwd(dlwp_handle_t h, const void* dw2, const void* db2, void* dw, void* db, int kh, int kw, int cin,
+                           int cout, int pad_top, int pad_left, int accumulate, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && dw2 && dw, "dlwp_phase_weights_bwd: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32 && kh > 0 && kw > 0 && cin > 0 && cout > 0 && pad_top >= 0 && pad_left >= 0,
+                 "dlwp_phase_weights_bwd: bad arguments");
+  int kh2, kw2, lo_h, lo_w, hi;
+  dlwp_phase_geometry(kh, pad_top, &kh2, &lo_h, &hi);
+  dlwp_phase_geometry(kw, pad_left, &kw2, &lo_w, &hi);
+  const long long total = (long long)kh * kw * cin * cout;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  phase_weights_bwd_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const float*)dw2, (const float*)db2, (float*)dw,
+                                                                          (float*)db, kh, kw, cin, cout, pad_top, pad_left,
+                                                                          kw2, lo_h, lo_w, accumulate ? 1 : 0);
+  DLWP_LAUNCH_CHECK("phase_weights_bwd_kernel");
+  return DLWP_OK;
+}
+
+int dlwp_space_to_depth2(dlwp_handle_t h, const void* src, void* dst, int n, int f, int hh, int ww, int c_off, int c_total,
+                         int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && (n == 0 || (src && dst)), "dlwp_space_to_depth2: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32 && n >= 0 && f > 0 && hh > 0 && ww > 0 && c_off >= 0 && c_off + f <= c_total,
+                 "dlwp_space_to_depth2: bad arguments");
+  const long long total = (long long)n * f * hh * ww;
+  if (total == 0) return DLWP_OK;
+  long long blocks = (total + 255) / 256;
+  const long long cap = (long long)h->cu_count * 16;
+  space_to_depth2_kernel<<<(int)(blocks < cap ? blocks : cap), 256, 0, (hipStream_t)stream>>>(
+      (const float*)src, (float*)dst, total, f, hh, ww, c_off, c_total);
+  DLWP_LAUNCH_CHECK("space_to_depth2_kernel");
   return DLWP_OK;
 }
 

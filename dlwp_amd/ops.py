@@ -300,6 +300,26 @@ def depth_to_space2(src, f, out=None, c_off=0):
     return out
 
 
+def space_to_depth2(src, f, c_off=0):
+    """(n, c_total, 2h, 2w)[c_off:+f] -> (n, 4f, h, w) phase-major: the adjoint (= inverse) of depth_to_space2."""
+    _check_f32(src)
+    n, c_total, h2, w2 = src.shape
+    out = torch.empty((n, 4 * f, h2 // 2, w2 // 2), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib.dlwp_space_to_depth2(_lib.handle(_dev(src)), _ptr(src), _ptr(out), n, int(f), h2 // 2, w2 // 2,
+                                             int(c_off), c_total, _lib.F32, _stream(src)))
+    return out
+
+
+def phase_weights_bwd(dw2, db2, dw, db, pad_top, pad_left, accumulate=False):
+    """Adjoint of phase_weights: dw (kh,kw,cin,cout) (+)= gather of dw2 over the 4 phases; db (+)= fold of db2."""
+    _check_f32(dw2, dw, db2, db)
+    kh, kw, cin, cout = dw.shape
+    _lib.check(_lib.lib.dlwp_phase_weights_bwd(_lib.handle(_dev(dw2)), _ptr(dw2), _ptr(db2), _ptr(dw), _ptr(db), kh, kw, cin,
+                                               cout, int(pad_top), int(pad_left), 1 if accumulate else 0, _lib.F32,
+                                               _stream(dw2)))
+    return dw
+
+
 def uses_bf16_weights(xs, cd, dtype):
     """Does conv2d on an input of shape xs = (n, c, h, w) stored as `dtype` (a _lib.dtype_io code) multiply with weights
     rounded to bfloat16 (the bf16 matrix-core kernels)?  Host logic only."""

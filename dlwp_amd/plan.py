@@ -532,8 +532,9 @@ def build_plan(inputs, outputs, inference=False):
             # (a) dilation 2, even halo: tap u of output row 2i + a reads source row i + u - top/2 whatever a is, so the
             #     result is UpSampling2D(conv with dilation 1 and half the halo on the low-resolution tensor): a quarter
             #     of the multiplies, and the up-sampling stays lazy for the consumer.
-            # (a) is a plain graph identity -- it also serves the training plan (forward, data and weight gradient of the
-            # layer then run on the low-resolution tensors); (b) needs derived kernels: inference plans only
+            # both serve the training plan as well: (a) is a plain graph identity (forward, data and weight gradient of
+            # the layer then run on the low-resolution tensors); (b) trains through the adjoints of its two linear maps
+            # (dlwp_phase_weights_bwd, dlwp_space_to_depth2; training.py)
             restate = RESTATE_UPSAMPLED and v.src_mode == SRC_UPSAMPLE2
             if (restate and tuple(lay.dilation_rate) == (2, 2) and
                     all(p % 2 == 0 for p in halo[:4]) and ho % 2 == 0 and wo % 2 == 0):
@@ -546,7 +547,7 @@ def build_plan(inputs, outputs, inference=False):
             # (b) dilation 1: the k taps of an axis fall on k2 < k distinct source pixels; each of the 4 output phases is
             #     a k2 x k2 kernel of summed weights over the SAME window, so the layer runs as one convolution with
             #     4 x filters channels on the low-resolution tensor + a depth-to-space interleave (csrc/phase.hip).
-            elif (restate and inference and tuple(lay.dilation_rate) == (1, 1) and
+            elif (restate and tuple(lay.dilation_rate) == (1, 1) and
                   ho == 2 * v.h and wo == 2 * v.w and
                   _phase_geometry(kh, halo.top)[0] * _phase_geometry(kw, halo.left)[0] < kh * kw):
                 (kh2, lo_h, hi_h), (kw2, lo_w, hi_w) = _phase_geometry(kh, halo.top), _phase_geometry(kw, halo.left)

@@ -308,11 +308,18 @@ class Trainer(object):
                 continue                      # nothing downstream of this op contributes to the loss
             gD = grads[op.dst]
             src = tensor(op.src)
+            if op.kind == 'd2s':               # adjoint of the depth-to-space interleave of a restated decoder layer
+                grads[op.src] = ops.space_to_depth2(gD, op.xs[0], c_off=op.out_c_off)
+                written[op.src] = [(0, 4 * op.xs[0])]
+                continue
             if op.kind == 'conv':
                 lay = op.layer
                 y = tensor(op.dst)
                 acc = id(lay) in touched_layers
-                fused_bias = (lay.activation != 'linear' and lay.bias is not None and not acc and
+                derived = op.wparam is not None        # the layer runs with phase-summed kernels (plan.phase_params)
+                kern = self.model.train_executor.conv_weights(op)[0]
+                n_out = op.conv_geometry[0]
+                fused_bias = (lay.activation != 'linear' and lay.bias is not None and not acc and not derived and
                               gD.shape[1] == lay.filters and tuple(y.shape) == tuple(gD.shape))
                 if fused_bias:         # dz in place of dy and the bias gradient from the same pass
                     ops.act_bwd_bias_grad(y, gD, op.act, self._grad_view(lay, 'bias'), lay.filters, out=gD)
@@ -320,8 +327,20 @@ class Trainer(object):
                     ops.act_bwd(y, gD, op.act, out=gD)          # dz in place of dy
                 dz = gD
                 xs = _lib.Shape4(n, op.xs[0], op.xs[1], op.xs[2])
-                ops.conv2d_bwd_weight(src, dz, self._grad_view(lay, 'kernel'), d, xs, accumulate=acc)
-                if lay.bias is not None and not fused_bias:
+                if derived:                # gradients of the derived kernels, folded back onto the layer's own
+                    pp = plan.phase_params[op.wparam]
+                    dw2 = torch.empty(tuple(kern.shape), dtype=torch.float32, device=self.device)
+                    ops.conv2d_bwd_weight(src, dz, dw2, d, xs)
+                    db2 = None
+                    if lay.bias is not None:
+                        db2 = torch.empty(n_out, dtype=torch.float32, device=self.device)
+                        ops.bias_grad(dz, db2, n_out)
+                    ops.phase_weights_bwd(dw2, db2, self._grad_view(lay, 'kernel'),
+                                          self._grad_view(lay, 'bias') if lay.bias is not None else None,
+                                          pp['pad_top'], pp['pad_left'], accumulate=acc)
+                else:
+                    ops.conv2d_bwd_weight(src, dz, self._grad_view(lay, 'kernel'), d, xs, accumulate=acc)
+                if lay.bias is not None and not fused_bias and not derived:
                     gb = self._grad_view(lay, 'bias')
                     if acc:
                         tmp = torch.empty_like(gb)
@@ -339,19 +358,19 @@ class Trainer(object):
                 if op.src_mode == P.SRC_DIRECT:
                     g = grad_of(op.src)
                     if not overlaps(op.src, op.in_c_off, cin):
-                        ops.conv2d_bwd_data(dz, lay.kernel, d, xs, g)        # writes its channel window in place
+                        ops.conv2d_bwd_data(dz, kern, d, xs, g)              # writes its channel window in place
                         written.setdefault(op.src, []).append((op.in_c_off, cin))
                     else:
                         dd = ops.make_conv(d.cout, d.kh, d.kw, (d.dil_h, d.dil_w), d.halo, d.act, 0, 0, d.out_c_off,
                                            d.out_c_total, d.src_mode)
                         tmp = torch.empty((n, cin) + tuple(src.shape[2:]), dtype=torch.float32, device=self.device)
-                        ops.conv2d_bwd_data(dz, lay.kernel, dd, xs, tmp)
+                        ops.conv2d_bwd_data(dz, kern, dd, xs, tmp)
                         deposit(op.src, op.in_c_off, cin, tmp)
                 else:
                     hin = 2 * op.xs[1] if op.src_mode == P.SRC_UPSAMPLE2 else op.xs[1] // 2
                     win = 2 * op.xs[2] if op.src_mode == P.SRC_UPSAMPLE2 else op.xs[2] // 2
                     tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
-                    ops.conv2d_bwd_data(dz, lay.kernel, d, xs, tmp)
+                    ops.conv2d_bwd_data(dz, kern, d, xs, tmp)
                     if op.src_mode == P.SRC_UPSAMPLE2:
                         dense = ops.upsample2_bwd(tmp)
                     else:

@@ -213,6 +213,12 @@ int dlwp_phase_weights(dlwp_handle_t, const void* w, const void* bias, void* w2,
                        int pad_top, int pad_left, int dtype, void* stream);
 int dlwp_depth_to_space2(dlwp_handle_t, const void* src, void* dst, int n, int f, int h, int w, int c_off, int c_total,
                          int dtype, void* stream);
+/* their adjoints, for the training step: dW (+)= the gather of dW2 over the phases (db likewise, nullable pair), and the
+ * inverse interleave (n, c_total, 2h, 2w)[c_off:+f] -> (n, 4f, h, w) of a gradient.                                     */
+int dlwp_phase_weights_bwd(dlwp_handle_t, const void* dw2, const void* db2, void* dw, void* db, int kh, int kw, int cin,
+                           int cout, int pad_top, int pad_left, int accumulate, int dtype, void* stream);
+int dlwp_space_to_depth2(dlwp_handle_t, const void* src, void* dst, int n, int f, int h, int w, int c_off, int c_total,
+                         int dtype, void* stream);
 
 /* ---- ConvLSTM2D cell update (keras ConvLSTM2DCell.call; call sites examples/train.py:148-155,
  *      examples/train_functional.py:207-219).  zx / zh: (n, 4F, h*w) gate pre-activations i | f | c | o from the input

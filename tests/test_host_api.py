@@ -33,14 +33,17 @@ def test_build_model_accepts_reference_triples_and_fuses_to_six_launches():
     assert d.model.count_params() == 188996
     assert d.model.output_shape == (None, 4, 88, 180)
     plan = d.model.plan
-    assert [op.kind for op in plan.ops] == ['conv'] * 6         # 22 reference layers -> 6 fused launches
+    # 22 reference layers -> 6 fused convolutions (+ the derived kernels and the interleave of the restated output layer)
+    assert [op.kind for op in plan.ops] == ['conv'] * 5 + ['phasew', 'conv', 'd2s']
     assert plan.conv_flops_per_sample() == 1597685760           # 1 597.7 MFLOP
+    convs = [op for op in plan.ops if op.kind == 'conv']
     # layer 5 (3x3, dilation 2, on an up-sampled tensor) is its own up-sampling identity: a dilation-1 layer on the
-    # 44x90 tensor (halo 1), whose output layer 6 reads through the up-sampling loader
-    assert [op.src_mode for op in plan.ops] == [0, 2, 2, 1, 0, 1]
-    assert all(op.halo.mode_h == P.PAD_ZERO and op.halo.mode_w == P.PAD_WRAP for op in plan.ops)
-    assert [op.halo.left for op in plan.ops] == [2, 1, 1, 1, 1, 2]
-    assert plan.ops[4].conv_geometry == (32, (3, 3), (1, 1)) and plan.ops[4].out_shape == (32, 44, 90)
+    # 44x90 tensor (halo 1); layer 6 (5x5 on that up-sampled output) runs as 3x3 phase kernels on the same 44x90 tensor
+    assert [op.src_mode for op in convs] == [0, 2, 2, 1, 0, 0]
+    assert all(op.halo.mode_h == P.PAD_ZERO and op.halo.mode_w == P.PAD_WRAP for op in convs)
+    assert [op.halo.left for op in convs] == [2, 1, 1, 1, 1, 1]
+    assert convs[4].conv_geometry == (32, (3, 3), (1, 1)) and convs[4].out_shape == (32, 44, 90)
+    assert convs[5].conv_geometry == (16, (3, 3), (1, 1)) and convs[5].wparam == 0
     assert plan.ops[-1].dst == P.OUT(0) and plan.ops[0].src == P.STATE_IN
     assert d.model.metrics_names == ['loss', 'mean_absolute_error']
     names = [lay.name for lay in d.base_model.layers]
@@ -53,10 +56,11 @@ def test_default_plan_pools_once_in_front_of_the_winograd_layers():
     d = _dlwp(time_dim=2)
     d.build_model(unet_layers((4, 88, 180)), loss='mse', optimizer='adam', gpus=1)
     plan = d.model.plan
-    assert [op.kind for op in plan.ops] == ['conv', 'maxpool', 'conv', 'maxpool', 'conv', 'conv', 'conv', 'conv']
+    assert [op.kind for op in plan.ops] == ['conv', 'maxpool', 'conv', 'maxpool', 'conv', 'conv', 'conv', 'phasew', 'conv',
+                                            'd2s']
     assert plan.conv_flops_per_sample() == 1597685760
-    assert [op.src_mode for op in plan.ops if op.kind == 'conv'] == [0, 0, 0, 1, 0, 1]      # (layer 5 restated, see above)
-    assert [op.halo.left for op in plan.ops if op.kind == 'conv'] == [2, 1, 1, 1, 1, 2]
+    assert [op.src_mode for op in plan.ops if op.kind == 'conv'] == [0, 0, 0, 1, 0, 0]      # (layers 5, 6 restated, see above)
+    assert [op.halo.left for op in plan.ops if op.kind == 'conv'] == [2, 1, 1, 1, 1, 1]
 
 
 def test_build_model_argument_errors_match_the_reference():
@@ -497,5 +501,5 @@ def test_inference_plan_moves_the_pooling_into_the_producers():
     assert tuple(convs[5].halo)[:4] == (1, 1, 1, 1) and ip.ops[-1].out_shape == (4, 88, 180)
     # the ALGORITHMIC count is the reference graph's, whatever is executed
     assert ip.conv_flops_per_sample() == d.model.plan.conv_flops_per_sample() == 1597685760
-    assert not any(op.out_pool for op in d.model.plan.ops) and len(d.model.plan.ops) == 8
+    assert not any(op.out_pool for op in d.model.plan.ops) and len(d.model.plan.ops) == 10
     assert d.model.executor.plan is ip and d.model.train_executor.plan is d.model.plan
