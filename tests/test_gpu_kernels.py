@@ -732,3 +732,28 @@ def test_conv_on_upsampled_source_restated_path_equals_the_fused_upsampling_load
     cd2 = ops.make_conv(4 * cout, k2h, k2w, 1, ops.make_pad(-lo_h, hi_h, -lo_w, hi_w, mh, mw), ops.ACT_TANH)
     got = host(ops.depth_to_space2(ops.conv2d(dev(x), w2, b2, cd2), cout))
     _check_conv(ops, got, want, 'restated')
+
+
+@pytest.mark.parametrize('k,pt,pl', [(5, 2, 2), (3, 1, 1), (5, 1, 2)])
+def test_phase_weights_adjoint_and_space_to_depth(ops, k, pt, pl):
+    """dlwp_phase_weights_bwd is the transpose of the (linear) map w -> w2: <w2(w), g2> == <w, bwd(g2)> and bias likewise;
+    dlwp_space_to_depth2 inverts dlwp_depth_to_space2 exactly."""
+    rng = np.random.default_rng(k + pt)
+    cin, cout = 5, 3
+    w = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    w2, b2 = ops.phase_weights(dev(w), dev(b), pt, pl)
+    g2 = rng.standard_normal(tuple(w2.shape)).astype(np.float32)
+    gb2 = rng.standard_normal(4 * cout).astype(np.float32)
+    dw = torch.empty((k, k, cin, cout), device='cuda')
+    db = torch.empty(cout, device='cuda')
+    ops.phase_weights_bwd(dev(g2), dev(gb2), dw, db, pt, pl)
+    lhs = float((w2.double().cpu().numpy() * g2).sum()) + float((b2.double().cpu().numpy() * gb2).sum())
+    rhs = float((w.astype(np.float64) * host(dw)).sum()) + float((b.astype(np.float64) * host(db)).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    dw_acc = dw.clone()
+    ops.phase_weights_bwd(dev(g2), dev(gb2), dw_acc, db.clone(), pt, pl, accumulate=True)
+    assert torch.allclose(dw_acc, 2 * dw)
+    y = rng.standard_normal((2, 4 * cout, 5, 7)).astype(np.float32)
+    hi = ops.depth_to_space2(dev(y), cout)
+    assert np.array_equal(host(ops.space_to_depth2(hi, cout)), y)
