@@ -36,9 +36,16 @@
 #include <type_traits>
 #include "conv_fwd_kernel.h"
 
-template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false>
+// UPS: the source is a 2x nearest-neighbour up-sampled tensor read through the fused loader, with an ODD top and left halo
+// (the 'same' 3x3 case).  Rows 1 and 2 of every 4x4 patch are then the same source row (and columns 1, 2 the same source
+// column), so row 2 of B^T d -- d2 - d1 -- and column 2 of (B^T d) B are exactly zero: 7 of the 16 Winograd positions
+// contribute nothing and their MFMAs (and U fragment loads) are left out -- 9 multiplies per 2x2 output tile and channel
+// pair instead of 16 (direct: 36), bit-identical results.
+template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false, bool UPS_ = false>
 struct WinoCfg {
   static constexpr bool IN16 = IN16_;  // input stored as bfloat16 (the loop stays branch-free: one instance per input type)
+  static constexpr bool UPS = UPS_;
+  static_assert(!UPS_ || DIL_ == 1, "the up-sampled-source variant is the dilation-1 case");
   static constexpr int DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, BNF = BNF_, CK = CK_;
   static constexpr int NT = WAVES * 64;
   static constexpr int LR = TH + 2 * DIL, LC = TW + 2 * DIL;
@@ -240,7 +247,8 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     // ================= channel group 0 ==================================================================
 #pragma unroll
     for (int s = 0; s < HL; ++s) {
-      if (s % GS == 0) load_frags(ucur, s / GS == 3 ? 1 : 0, (s / GS + 1) & 3, (s / GS + 1) & 1);
+      if (s % GS == 0 && !(C::UPS && ((s / GS + 1) & 3) == 2))   // (UPS: transformed-filter row 2 is never multiplied)
+        load_frags(ucur, s / GS == 3 ? 1 : 0, (s / GS + 1) & 3, (s / GS + 1) & 1);
       if (s < 8) vt_read(xcur, 1, s);
       if (s >= 8 && s < 24) {  // registers (chunk k+1) -> xs[nxt]
 #pragma unroll
@@ -259,8 +267,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
       }
       {
         const int xq = s / (4 * C::BNF), j = (s / C::BNF) & 3, g = s % C::BNF;
-        acc[xq * 4 + j][g] =
-            __builtin_amdgcn_mfma_f32_16x16x4f32(v[0][xq * 4 + j], bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
+        if (!(C::UPS && (xq == 2 || j == 2)))   // (folds at compile time: s is an unrolled constant)
+          acc[xq * 4 + j][g] =
+              __builtin_amdgcn_mfma_f32_16x16x4f32(v[0][xq * 4 + j], bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (s == 23) {
@@ -272,8 +281,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
 #pragma unroll
     for (int s = 0; s < HL; ++s) {
       if (s % GS == 0) {
-        if (s / GS < 3) load_frags(ucur, 1, s / GS + 1, (s / GS + 1) & 1);
-        else load_frags(unxt, 0, 0, 0);  // first fragments of the next chunk (after barrier B)
+        if (s / GS < 3) {
+          if (!(C::UPS && s / GS + 1 == 2)) load_frags(ucur, 1, s / GS + 1, (s / GS + 1) & 1);
+        } else load_frags(unxt, 0, 0, 0);  // first fragments of the next chunk (after barrier B)
       }
       if (s < 8) vt_read(xnxt, 0, s);
       if (s >= 16 && s < 16 + 2 * C::NUI) stage_u(unxt, (s - 16) >> 1, 2 + ((s - 16) & 1));  // xy quads 2,3 of chunk k+1
@@ -289,8 +299,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
       }
       {
         const int xq = s / (4 * C::BNF), j = (s / C::BNF) & 3, g = s % C::BNF;
-        acc[xq * 4 + j][g] =
-            __builtin_amdgcn_mfma_f32_16x16x4f32(v[1][xq * 4 + j], bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
+        if (!(C::UPS && (xq == 2 || j == 2)))
+          acc[xq * 4 + j][g] =
+              __builtin_amdgcn_mfma_f32_16x16x4f32(v[1][xq * 4 + j], bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (s == 23) {
@@ -438,23 +449,35 @@ static int wino_prepare() {
   return 0;
 }
 
-// launches the float32- or the bfloat16-input instance of one geometry
-template <class C32, class C16>
+// launches the float32- or the bfloat16-input instance of one geometry; dilation 1 on an up-sampled source with odd top /
+// left halos takes the variant that leaves out the 7 identically-zero Winograd positions (WinoCfg::UPS)
+template <int DIL, int TH, int TW, int WAVES, int BNF, int CK>
 static void wino_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
-  if (a.in_bf16) wino_launch_thunk<C16>(a, grid, s);
-  else wino_launch_thunk<C32>(a, grid, s);
+  if constexpr (DIL == 1) {
+    if (a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1)) {
+      if (a.in_bf16) wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true, true>>(a, grid, s);
+      else wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, true>>(a, grid, s);
+      return;
+    }
+  }
+  if (a.in_bf16) wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>(a, grid, s);
+  else wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false>>(a, grid, s);
 }
 
-template <class C32, class C16>
+template <int DIL, int TH, int TW, int WAVES, int BNF, int CK>
 static int wino_prepare_both() {
-  const int e = wino_prepare<C32>();
-  return e != 0 ? e : wino_prepare<C16>();
+  int e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false>>();
+  if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>();
+  if constexpr (DIL == 1) {
+    if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, true>>();
+    if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true, true>>();
+  }
+  return e;
 }
 
 // registry entry: ks = 3, fa = 0, pack = -1 marks a Winograd instance (a.w = the transformed filter)
 #define WINO_ENTRY(DIL, TH, TW, WAVES, BNF, CK)                                                                         \
   {                                                                                                                      \
     3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1, (DIL) == 1 ? 1 : 0, 0, \
-        &wino_launch_either<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>, WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>,           \
-        &wino_prepare_both<WinoCfg<DIL, TH, TW, WAVES, BNF, CK>, WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>             \
+        &wino_launch_either<DIL, TH, TW, WAVES, BNF, CK>, &wino_prepare_both<DIL, TH, TW, WAVES, BNF, CK>                \
   }
