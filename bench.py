@@ -120,6 +120,9 @@ def time_layers(model, members, iters=5):
         rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': dil_run[0], 'tile_cfg': cfg,
                      'out': [ho, wo], 'ms': ms, 'tflops': flops / ms / 1e9, 'gbs': nbytes / ms / 1e6,
                      'flops': flops, 'bytes': nbytes})
+        # Winograd on an up-sampled source with odd halos leaves out the 7 identically-zero positions (WinoCfg::UPS)
+        rows[-1]['wino_multiplies_per_tile'] = 9 if (kh == 3 and op.src_mode == 1 and tuple(dil_run) == (1, 1) and
+                                                     op.halo.top % 2 == 1 and op.halo.left % 2 == 1) else 16
         if op.alg_flops is not None:
             rows[-1]['restated'] = ('on the low-resolution source of the UpSampling2D in front (dlwp_amd/plan.py): '
                                     'executes %.3f of the algorithmic multiplies' % (executed / flops))
@@ -287,8 +290,12 @@ def main():
             th_, tw_ = dom['tile_cfg'][2], dom['tile_cfg'][3]
             ho_, wo_ = dom['out']
             pad = (-(-ho_ // th_) * th_) * (-(-wo_ // tw_) * tw_) / float(ho_ * wo_)
-            out['roofline']['algorithm'] = 'winograd F(2x2,3x3): 2.25x fewer multiplies than the algorithmic count'
-            out['roofline']['executed_frac'] = dom['tflops'] / 2.25 * pad / PEAK_F32_MFMA_TFLOPS
+            mult = dom.get('wino_multiplies_per_tile', 16)
+            out['roofline']['algorithm'] = ('winograd F(2x2,3x3): %d multiplies per 2x2 output tile and channel pair where '
+                                            'the algorithmic count is 36%s' %
+                                            (mult, ' (up-sampled source: 7 of the 16 positions are identically zero)'
+                                             if mult == 9 else ''))
+            out['roofline']['executed_frac'] = dom['tflops'] * mult / 36.0 * pad / PEAK_F32_MFMA_TFLOPS
         if dom.get('tile_cfg'):
             tr, src = measured_traffic(dom['tile_cfg'], a.members)
             out['roofline']['traffic'] = tr
