@@ -44,9 +44,14 @@ struct WgradArgs {
 // and channel pair where the direct form does 36.  Tiles of a dilated convolution are taken inside the d x d parity
 // sub-lattices.  Loader, LDS tiles, tile walk and slabs are the direct form's; every wave owns all NT cout fragments
 // and a share of the tile quads (PW slabs per split).
+// WINO = 2: the same on a 2x up-sampled source with odd top / left halos (dilation 1): rows 1, 2 of every input patch are
+// the same source row, so row 2 and column 2 of B^T d B are exactly zero and 7 of the 16 positions are left out (as in
+// the forward kernel's WinoCfg::UPS); chosen at launch time from the layer.
 template <int KS_, int DIL_, int TH_, int TW_, int NT_, int PW_ = 1, int CIB_ = 16, int PACK_ = 0, int WINO_ = 0>
 struct WgCfg {
   static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, NT = NT_, PW = PW_, PACK = PACK_, WINO = WINO_;
+  static constexpr bool WUPS = WINO_ == 2;
+  static_assert(WINO_ != 2 || DIL_ == 1, "up-sampled-source Winograd weight gradient: dilation 1");
   static constexpr int NV0 = PACK ? (KS_ + PACK_ - 1) / PACK_ : KS_;   // virtual taps per kernel row
   static constexpr int VT = KS_ * NV0;                                   // accumulator row groups (virtual taps)
   static_assert(PACK_ == 0 || (PACK_ == 4 && NT_ == 1 && DIL_ == 1), "packed-N: 4 shifts, one cout fragment, no dilation");
@@ -333,8 +338,9 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
             const float m4[4] = {rp[i], rp[i] + rq[i], rp[i] - rq[i], -rq[i]};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc[(i * 4 + j) * C::NT + nt] =
-                  __builtin_amdgcn_mfma_f32_16x16x4f32(V[i][j], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
+              if (!(C::WUPS && (i == 2 || j == 2)))
+                acc[(i * 4 + j) * C::NT + nt] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(V[i][j], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
           }
         }
       }
@@ -435,6 +441,13 @@ struct WgradKernelEntry {
 
 template <class C>
 static void wgrad_launch_thunk(const WgradArgs& a, int grid, hipStream_t s) {
+  if constexpr (C::WINO == 1 && C::DIL == 1) {
+    if (a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1)) {   // 9 of the 16 positions
+      typedef WgCfg<C::KS, C::DIL, C::TH, C::TW, C::NT, C::PW, C::CI, C::PACK, 2> CU;
+      hipLaunchKernelGGL((conv2d_wgrad_wino_f32<CU>), dim3(grid), dim3(CU::NTHREADS), CU::LDS_BYTES, s, a);
+      return;
+    }
+  }
   if constexpr (C::WINO) hipLaunchKernelGGL((conv2d_wgrad_wino_f32<C>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, s, a);
   else hipLaunchKernelGGL((conv2d_wgrad_mfma_f32<C>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, s, a);
 }
@@ -445,7 +458,14 @@ static int wgrad_prepare() {
     const void* f;
     if constexpr (C::WINO) f = (const void*)conv2d_wgrad_wino_f32<C>;
     else f = (const void*)conv2d_wgrad_mfma_f32<C>;
-    return (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    int e = (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if constexpr (C::WINO == 1 && C::DIL == 1) {
+      typedef WgCfg<C::KS, C::DIL, C::TH, C::TW, C::NT, C::PW, C::CI, C::PACK, 2> CU;
+      if (e == 0)
+        e = (int)hipFuncSetAttribute((const void*)conv2d_wgrad_wino_f32<CU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     CU::LDS_BYTES);
+    }
+    return e;
   }
   return 0;
 }
