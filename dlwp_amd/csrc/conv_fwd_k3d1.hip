@@ -15,6 +15,12 @@ static const ConvKernelEntry k_table[] = {
     CONV_ENTRY(3, 1, 8, 32, 4, 4, 4, 8),
     CONV_ENTRY(3, 1, 8, 32, 4, 4, 2, 4),
     CONV_ENTRY(3, 1, 8, 32, 4, 4, 1, 8),
+    // 16 output channels (the restated 5x5 output layer: 4 phases x 4 fields)
+    CONV_ENTRY(3, 1, 8, 32, 4, 4, 1, 16),
+    CONV_ENTRY(3, 1, 4, 45, 4, 3, 1, 8),
+    CONV_ENTRY(3, 1, 4, 45, 4, 3, 1, 16),
+    CONV_ENTRY(3, 1, 11, 45, 8, 4, 1, 8),
+    CONV_ENTRY(3, 1, 4, 90, 6, 4, 1, 8),
     CONV_ENTRY(3, 1, 4, 16, 4, 1, 2, 8),
     CONV_ENTRY(3, 1, 4, 16, 4, 1, 1, 4),
     // instances with the fused 2x2 max-pooling loader (U-Net layers 2 and 3)
