@@ -151,8 +151,9 @@ int dlwp_conv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d
 // dz: (n, out_c_total, ho, wo), channels [out_c_off, +cout).  For src_mode == DIRECT dx may be a channel window
 // [in_c_off, +cin) of a buffer with in_c_total channels (the stored tensor's gradient); otherwise it is dense and the
 // caller applies dlwp_upsample2_bwd / dlwp_maxpool2_bwd.
-int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
-                         const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream) {
+// stored != 0: gradient w.r.t. the STORED tensor of a DLWP_SRC_UPSAMPLE2 layer (2x2 sum fused into the epilogue)
+static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
+                                const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream, int stored) {
   DLWP_CHECK_ARG(h && dz && w && dx && cd && ws, "dlwp_conv2d_bwd_data: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_conv2d_bwd_data: dtype %d not supported", dtype);
   size_t need = 0;
@@ -180,9 +181,12 @@ int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* d
   g.in_c_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
   g.src_mode = DLWP_SRC_DIRECT;
   dlwp_shape4 zs = {xs.n, cd->cout, ys.h, ys.w};
+  if (stored && !(cd->src_mode == DLWP_SRC_UPSAMPLE2 && same_halo_fast_path(cd)))
+    DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_bwd_data_stored: needs an up-sampled source and a symmetric wrap / zero halo");
   if (same_halo_fast_path(cd)) {
     // symmetric 'same' halo with wrap / zero modes: the adjoint is the same fused conv on the flipped kernel
     g.halo = cd->halo;
+    g.out_pool = stored ? 2 : 0;  // adjoint of the nearest up-sampling = 2x2 sum of the dense gradient
     g.out_c_off = window ? cd->in_c_off : 0;
     g.out_c_total = window ? cd->in_c_total : xs.c;
     return dlwp_launch_conv2d(h, dz, wt, nullptr, dx, zs, &g, dtype, s);
@@ -198,6 +202,16 @@ int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* d
   rc = dlwp_launch_conv2d(h, dz, wt, nullptr, padded, zs, &g, dtype, s);
   if (rc != DLWP_OK) return rc;
   return dlwp_pad2d_bwd(h, padded, dx, xs.n * xs.c, hin, win, 1, cd->halo, dtype, stream);
+}
+
+int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
+                         const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  return conv2d_bwd_data_impl(h, dz, w, dx, xs, cd, dtype, ws, ws_bytes, stream, 0);
+}
+
+int dlwp_conv2d_bwd_data_stored(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
+                                const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  return conv2d_bwd_data_impl(h, dz, w, dx, xs, cd, dtype, ws, ws_bytes, stream, 1);
 }
 
 // dw: (kh, kw, cin, cout) Keras HWIO.  accumulate != 0 adds to dw instead of overwriting (shared layers).

@@ -272,14 +272,16 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if (is_bf16(e) && (!bf16_wanted(a, cd) || (e.in32 != 0) == (a.in_bf16 != 0) ||
                        bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
     if (cd->out_pool && !e.out_pool) return -1;
+    if (cd->out_pool == 2 && !is_wino(e)) return -1;  // the 2x2 sum epilogue lives in the Winograd family
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? g_forced_cfg
                : -1;
   }
   int best = -1;
   double best_cost = 0;
+  const bool sum_pool = cd->out_pool == 2;  // 2x2 sum epilogue (data gradient of an up-sampled source): Winograd only
   bool want_bf16 = false;
-  if (bf16_wanted(a, cd))
+  if (!sum_pool && bf16_wanted(a, cd))
     for (const ConvKernelEntry& e : r.entries)
       want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h && (!cd->out_pool || e.out_pool) &&
                                 (e.in32 != 0) == !a.in_bf16 &&
@@ -292,6 +294,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
                     (!cd->out_pool || e.out_pool));
     want_wino = any;
   }
+  if (sum_pool && !want_wino) return -1;
   for (int i = 0; i < (int)r.entries.size(); ++i) {
     const ConvKernelEntry& e = r.entries[i];
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
@@ -421,6 +424,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
+  DLWP_CHECK_ARG(cd->out_pool != 2 || !bias, "dlwp_conv2d_fwd: the 2x2 sum epilogue takes no bias");
   if (xs.n == 0) return DLWP_OK;
   ConvArgs a = make_args(x, w, bias, y, xs, cd, ys, dtype);
   const int ci = choose_config(a, cd, h->cu_count);
@@ -507,8 +511,10 @@ int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys
                  cd->in_c_off, cd->in_c_off + xs.c, in_total);
   DLWP_CHECK_ARG(cd->out_c_off >= 0 && cd->out_c_off + cd->cout <= out_total,
                  "conv2d: output channel window [%d,%d) of %d", cd->out_c_off, cd->out_c_off + cd->cout, out_total);
-  DLWP_CHECK_ARG(cd->out_pool == 0 || cd->out_pool == 1, "conv2d: out_pool must be 0 or 1");
+  DLWP_CHECK_ARG(cd->out_pool >= 0 && cd->out_pool <= 2, "conv2d: out_pool must be 0, 1 or 2");
   DLWP_CHECK_ARG(!cd->out_pool || (ho >= 2 && wo >= 2), "conv2d: out_pool on a %dx%d output", ho, wo);
+  DLWP_CHECK_ARG(cd->out_pool != 2 || (cd->act == DLWP_ACT_LINEAR && ho % 2 == 0 && wo % 2 == 0),
+                 "conv2d: the 2x2 sum epilogue needs a linear activation and an even %dx%d output", ho, wo);
   ys->n = xs.n;
   ys->c = cd->cout;
   ys->h = cd->out_pool ? ho / 2 : ho;

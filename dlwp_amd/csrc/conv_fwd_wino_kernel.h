@@ -345,6 +345,11 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
           s[1][c] = m[1][c] - m[2][c] - m[3][c];
         }
         if constexpr (C::DIL == 1) {
+          if (a.out_pool == 2) {  // 2x2 sum: 1^T A^T M A 1 with A 1 = (1, 2, 0, -1) -- row / column 2 of M drop out
+            const float t0 = s[0][0] + s[1][0], t1 = s[0][1] + s[1][1], t3 = s[0][3] + s[1][3];
+            lds[col * C::OPS + ti * (C::TW / 2) + tj] = t0 + 2.f * t1 - t3;
+            continue;
+          }
           if (a.out_pool) {  // MaxPooling2D(2): the lane's 2x2 output tile IS one pooling window; activation after the max
             const float m0 = fmaxf(s[0][0] + s[0][1] + s[0][2], s[0][1] - s[0][2] - s[0][3]);
             const float m1 = fmaxf(s[1][0] + s[1][1] + s[1][2], s[1][1] - s[1][2] - s[1][3]);
@@ -454,7 +459,9 @@ static int wino_prepare() {
 template <int DIL, int TH, int TW, int WAVES, int BNF, int CK>
 static void wino_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
   if constexpr (DIL == 1) {
-    if (a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1)) {
+    // positions with a row / column index 2 are never needed: the source makes them zero (up-sampled, odd halo) or the
+    // 2x2 sum epilogue does not read them
+    if ((a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1)) || a.out_pool == 2) {
       if (a.in_bf16) wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true, true>>(a, grid, s);
       else wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, true>>(a, grid, s);
       return;

@@ -374,6 +374,21 @@ def conv2d_bwd_data(dz, w_hwio, cd, xs, dx):
     return dx
 
 
+def conv2d_bwd_data_stored(dz, w_hwio, cd, xs, dx):
+    """Up-sampled sources: gradient w.r.t. the stored tensor (n, cin, xs.h, xs.w) in one kernel.  Returns False when the
+    layer has no kernel with the summing epilogue (nothing was written; use conv2d_bwd_data + upsample2_bwd)."""
+    _check_f32(dz, w_hwio, dx)
+    d = _dev(dz)
+    need = conv_bwd_workspace_bytes(d, xs, cd, 0)
+    ws = workspace(dz.device, need)
+    rc = _lib.lib.dlwp_conv2d_bwd_data_stored(_lib.handle(d), _ptr(dz), _ptr(w_hwio), _ptr(dx), xs, ctypes.byref(cd),
+                                              _lib.F32, _ptr(ws), ws.numel(), _stream(dz))
+    if rc == _lib.EUNSUPPORTED:
+        return False
+    _lib.check(rc)
+    return True
+
+
 def conv2d_bwd_weight(x, dz, dw, cd, xs, accumulate=False):
     _check_f32(x, dz, dw)
     d = _dev(x)

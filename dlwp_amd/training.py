@@ -369,11 +369,15 @@ class Trainer(object):
                 else:
                     hin = 2 * op.xs[1] if op.src_mode == P.SRC_UPSAMPLE2 else op.xs[1] // 2
                     win = 2 * op.xs[2] if op.src_mode == P.SRC_UPSAMPLE2 else op.xs[2] // 2
-                    tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
-                    ops.conv2d_bwd_data(dz, kern, d, xs, tmp)
-                    if op.src_mode == P.SRC_UPSAMPLE2:
-                        dense = ops.upsample2_bwd(tmp)
+                    if op.src_mode == P.SRC_UPSAMPLE2:    # 2x2 sum fused into the data-gradient kernel where it can be
+                        dense = torch.empty((n, cin, op.xs[1], op.xs[2]), dtype=torch.float32, device=self.device)
+                        if not ops.conv2d_bwd_data_stored(dz, kern, d, xs, dense):
+                            tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
+                            ops.conv2d_bwd_data(dz, kern, d, xs, tmp)
+                            dense = ops.upsample2_bwd(tmp)
                     else:
+                        tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
+                        ops.conv2d_bwd_data(dz, kern, d, xs, tmp)
                         if op.in_c_off == 0 and cin == c_total:
                             xw = src
                         else:

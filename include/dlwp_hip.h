@@ -75,7 +75,9 @@ typedef struct {
   int out_c_off, out_c_total;     /* write channels [off, off+cout) of a buffer with out_c_total channels (concatenate)   */
   int src_mode;                   /* DLWP_SRC_*: xs describes the STORED tensor; the conv sees it transformed */
   int out_pool;                   /* 1: the epilogue also applies MaxPooling2D(2) -- y is (n, cout, ho/2, wo/2) (forward /
-                                   * inference only; ask dlwp_conv2d_supports_out_pool first)                          */
+                                   * inference only; ask dlwp_conv2d_supports_out_pool first).  2: 2x2 SUM instead of the
+                                   * max (linear activation, no bias; DLWP_EUNSUPPORTED when no kernel instance has it):
+                                   * the adjoint of UpSampling2D(2), see dlwp_conv2d_bwd_data_stored                   */
 } dlwp_conv2d;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
@@ -142,6 +144,11 @@ int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd
 int dlwp_conv2d_bwd_workspace(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int pass, size_t* bytes);
 int dlwp_conv2d_bwd_data(dlwp_handle_t, const void* dz, const void* w, void* dx, dlwp_shape4 xs, const dlwp_conv2d* cd,
                          int dtype, void* ws, size_t ws_bytes, void* stream);
+/* DLWP_SRC_UPSAMPLE2 layers only: dx = dL/d(STORED tensor), (n, cin, xs.h, xs.w) -- bwd_data followed by
+ * dlwp_upsample2_bwd in one kernel (the dense gradient is never written).  DLWP_EUNSUPPORTED when the layer has no kernel
+ * instance with the summing epilogue; the caller then takes the two-call route.                                        */
+int dlwp_conv2d_bwd_data_stored(dlwp_handle_t, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
+                                const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream);
 int dlwp_conv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
 int dlwp_conv2d_wgrad_num_configs(void);                                   /* tuning hooks, as for the forward */

@@ -419,6 +419,39 @@ def test_conv_backward_kernels_against_oracle_all_halo_modes():
         assert np.abs(dwd.cpu().numpy() - dw_ref).max() <= 2e-5 * max(1., np.abs(dw_ref).max()), case
 
 
+def test_data_gradient_of_an_upsampled_source_with_the_fused_sum_epilogue():
+    """dlwp_conv2d_bwd_data_stored == dlwp_conv2d_bwd_data followed by dlwp_upsample2_bwd (float64 oracle); layers without
+    a summing kernel report 'unsupported' and leave the two-call route to the caller."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(12)
+    for cin, cout, h, w, mh, mw, expect in [(32, 16, 6, 10, 0, 1, True), (64, 24, 11, 23, 0, 1, True),
+                                            (96, 8, 5, 45, 0, 0, True), (8, 16, 6, 10, 0, 1, False),
+                                            (128, 64, 22, 45, 0, 1, True)]:
+        n = 2
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+        xt = np_ref.upsample2(np.asarray(x, np.float64))
+        xp = np_ref.pad2d_modes(xt, (1, 1, 1, 1), mh, mw)
+        dz = rng.standard_normal((n, cout, 2 * h, 2 * w)).astype(np.float32)
+        dxp, _, _ = np_ref.conv2d_grads(xp, wt, dz, 1)
+        dx_ref = np_ref.pad2d_modes_grad(dxp, xt.shape, (1, 1, 1, 1), mh, mw)
+        dx_ref = dx_ref.reshape(n, cin, h, 2, w, 2).sum(axis=(3, 5))
+        cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, mh, mw), ops.ACT_LINEAR, src_mode=ops.SRC_UPSAMPLE2)
+        xs = _lib.Shape4(n, cin, h, w)
+        dxd = torch.full((n, cin, h, w), float('nan'), dtype=torch.float32, device='cuda')
+        dzd, wd = torch.from_numpy(dz).cuda(), torch.from_numpy(wt).cuda()
+        ok = ops.conv2d_bwd_data_stored(dzd, wd, cd, xs, dxd)
+        assert ok == expect, (cin, cout)
+        if not ok:
+            assert torch.isnan(dxd).all()
+            continue
+        two = ops.upsample2_bwd(ops.conv2d_bwd_data(dzd, wd, cd, xs, torch.empty((n, cin, 2 * h, 2 * w), device='cuda')))
+        torch.cuda.synchronize()
+        scale = max(1., np.abs(dx_ref).max())
+        assert np.abs(dxd.cpu().numpy() - dx_ref).max() <= 4e-5 * scale, (cin, cout, h, w)
+        assert (dxd - two).abs().max().item() <= 4e-5 * scale
+
+
 def test_conv_weight_gradient_random_shapes_against_oracle():
     """40 seeded random layer geometries through the heuristic's choice of weight-gradient kernel (direct, packed-N,
     Winograd): odd sizes, ragged channels, both dilations, all halo modes, all source modes, asymmetric halos."""
