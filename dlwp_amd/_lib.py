@@ -125,6 +125,7 @@ _sig('dlwp_act_bwd', [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp])
 _sig('dlwp_bias_grad_workspace', [_i], _sz)
 _sig('dlwp_bias_grad', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp])
 _sig('dlwp_act_bwd_bias_grad', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp])
+_sig('dlwp_pool_act_bwd_bias_grad', [_vp, _vp, _vp, _vp, _vp, Shape4, _i, _vp, _sz, _i, _vp])
 _sig('dlwp_mse_mae_workspace', [_vp], _sz)
 _sig('dlwp_mse_mae', [_vp, _vp, _vp, _sz, _vp, _vp, ctypes.c_float, _vp, _sz, _i, _vp])
 _sig('dlwp_loss_workspace', [_vp, _i, _i], _sz)

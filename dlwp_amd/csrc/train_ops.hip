@@ -105,6 +105,65 @@ __global__ __launch_bounds__(256) void act_bwd_bias_partial_kernel(const float* 
   if (threadIdx.x == 0) partial[c * BIAS_SPLIT + sidx] = s;
 }
 
+// maxpool2_bwd + act_bwd + bias_grad_partial in one pass: the pooled tensor's gradient dp (n, c, H/2, W/2) goes to the first
+// maximum of each 2x2 window of y (row-major order, as maxpool2_bwd_kernel) times act'(y); everything else, including an
+// odd last row / column, gets zero.  One thread per window; block (c, s) owns slice s of the channel's N*Hc*Wc windows.
+template <bool PAIR>
+__global__ __launch_bounds__(256) void pool_act_bwd_bias_partial_kernel(const float* __restrict__ y,
+                                                                        const float* __restrict__ dp, float* __restrict__ dz,
+                                                                        float* __restrict__ partial, int N, int C, int H, int W,
+                                                                        int act) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const int c = blockIdx.x, sidx = blockIdx.y;
+  const int H2 = H / 2, W2 = W / 2, Hc = (H + 1) / 2, Wc = (W + 1) / 2;
+  const long long per = (long long)N * Hc * Wc;
+  const long long chunk = (per + BIAS_SPLIT - 1) / BIAS_SPLIT;
+  const long long lo = sidx * chunk, hi = lo + chunk < per ? lo + chunk : per;
+  float s = 0.f, dummy = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int j = (int)(i % Wc);
+    const long long q = i / Wc;
+    const int r = (int)(q % Hc);
+    const long long p = (q / Hc) * C + c;  // plane (n, c)
+    const long long o = (p * H + 2 * r) * W + 2 * j;
+    if (r < H2 && j < W2) {
+      float v[4];
+      if (PAIR) {
+        const f2 t0 = *(const f2*)(y + o), t1 = *(const f2*)(y + o + W);
+        v[0] = t0[0]; v[1] = t0[1]; v[2] = t1[0]; v[3] = t1[1];
+      } else {
+        v[0] = y[o]; v[1] = y[o + 1]; v[2] = y[o + W]; v[3] = y[o + W + 1];
+      }
+      int arg = 0;
+      float m = v[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k] > m) { m = v[k]; arg = k; }
+      float g = dp[(p * H2 + r) * W2 + j];
+      if (act == DLWP_ACT_TANH) g *= 1.f - m * m;
+      else if (act == DLWP_ACT_RELU) g = m > 0.f ? g : 0.f;
+      s += g;
+      if (PAIR) {
+        *(f2*)(dz + o) = f2{arg == 0 ? g : 0.f, arg == 1 ? g : 0.f};
+        *(f2*)(dz + o + W) = f2{arg == 2 ? g : 0.f, arg == 3 ? g : 0.f};
+      } else {
+        dz[o] = arg == 0 ? g : 0.f;
+        dz[o + 1] = arg == 1 ? g : 0.f;
+        dz[o + W] = arg == 2 ? g : 0.f;
+        dz[o + W + 1] = arg == 3 ? g : 0.f;
+      }
+    } else {
+      const bool has_c = 2 * j + 1 < W, has_r = 2 * r + 1 < H;
+      dz[o] = 0.f;
+      if (has_c) dz[o + 1] = 0.f;
+      if (has_r) dz[o + W] = 0.f;
+      if (has_r && has_c) dz[o + W + 1] = 0.f;
+    }
+  }
+  block_sum2(s, dummy);
+  if (threadIdx.x == 0) partial[c * BIAS_SPLIT + sidx] = s;
+}
+
 __global__ __launch_bounds__(64) void bias_grad_final_kernel(const float* __restrict__ partial, float* __restrict__ db) {
   const float v = wave_sum(partial[blockIdx.x * BIAS_SPLIT + threadIdx.x]);
   if (threadIdx.x == 0) db[blockIdx.x] = v;
@@ -459,6 +518,26 @@ int dlwp_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dy, void*
         (const float*)y, (const float*)dy, (float*)dz, (float*)ws, n, c_off, c_total, hw, act);
   bias_grad_final_kernel<<<c, 64, 0, (hipStream_t)stream>>>((const float*)ws, (float*)db);
   DLWP_LAUNCH_CHECK("act_bwd_bias_grad kernels");
+  return DLWP_OK;
+}
+
+int dlwp_pool_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dp, void* dz, void* db, dlwp_shape4 ys, int act,
+                                void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && y && dp && dz && ws, "dlwp_pool_act_bwd_bias_grad: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32 && (unsigned)act <= 2u && ys.n >= 0 && ys.c > 0 && ys.h >= 2 && ys.w >= 2,
+                 "dlwp_pool_act_bwd_bias_grad: bad arguments");
+  DLWP_CHECK_ARG(ws_bytes >= dlwp_bias_grad_workspace(ys.c), "dlwp_pool_act_bwd_bias_grad: workspace too small");
+  DLWP_CHECK_ARG(y != dz, "dlwp_pool_act_bwd_bias_grad: dz must not alias y");
+  if (ys.n == 0) return DLWP_OK;
+  const bool pair = ys.w % 2 == 0 && (((uintptr_t)y | (uintptr_t)dz) & 7) == 0;
+  if (pair)
+    pool_act_bwd_bias_partial_kernel<true><<<dim3(ys.c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
+        (const float*)y, (const float*)dp, (float*)dz, (float*)ws, ys.n, ys.c, ys.h, ys.w, act);
+  else
+    pool_act_bwd_bias_partial_kernel<false><<<dim3(ys.c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
+        (const float*)y, (const float*)dp, (float*)dz, (float*)ws, ys.n, ys.c, ys.h, ys.w, act);
+  if (db) bias_grad_final_kernel<<<ys.c, 64, 0, (hipStream_t)stream>>>((const float*)ws, (float*)db);
+  DLWP_LAUNCH_CHECK("pool_act_bwd_bias_grad kernels");
   return DLWP_OK;
 }
 

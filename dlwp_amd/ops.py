@@ -428,6 +428,20 @@ def act_bwd_bias_grad(y, dy, act, db, c, c_off=0, out=None):
     return dz
 
 
+def pool_act_bwd_bias_grad(y, dp, act, db=None):
+    """Backward of MaxPooling2D(2) + activation (+ bias gradient) of the convolution that produced y, in one pass:
+    returns dz (shape of y) from the pooled tensor's gradient dp."""
+    _check_f32(y, dp, db)
+    n, c, h, w = y.shape
+    assert tuple(dp.shape) == (n, c, h // 2, w // 2) and y.is_contiguous() and dp.is_contiguous()
+    dz = torch.empty_like(y)
+    ws = workspace2(y.device, _lib.lib.dlwp_bias_grad_workspace(int(c)))
+    _lib.check(_lib.lib.dlwp_pool_act_bwd_bias_grad(_lib.handle(_dev(y)), _ptr(y), _ptr(dp), _ptr(dz),
+                                                    _ptr(db), _lib.Shape4(n, c, h, w), int(act),
+                                                    _ptr(ws), ws.numel(), _lib.F32, _stream(y)))
+    return dz
+
+
 def mse_mae(y_pred, y_true, out2, dy=None, loss_weight=1.0):
     """out2 (device, 2 floats) <- [mse, mae]; dy <- loss_weight * 2 (y_pred - y_true) / numel."""
     _check_f32(y_pred, y_true, out2, dy)

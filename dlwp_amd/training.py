@@ -262,7 +262,17 @@ class Trainer(object):
         def overlaps(buf, c_off, c):
             return any(not (c_off + c <= o or o + k <= c_off) for o, k in written.get(buf, []))
 
+        # buffer id -> gradient of its MaxPooling2D(2) image, when that is the only gradient so far: the producing
+        # convolution then takes pooling + activation backward (+ bias gradient) in one pass
+        pending_pool = {}
+
+        def materialise(buf):
+            gp = pending_pool.pop(buf, None)
+            if gp is not None:
+                deposit(buf, 0, gp.shape[1], ops.maxpool2_bwd(tensor(buf), gp))
+
         def grad_of(buf):
+            materialise(buf)
             g = grads.get(buf)
             if g is None:
                 g = torch.empty_like(tensor(buf))
@@ -275,6 +285,7 @@ class Trainer(object):
 
         def deposit(buf, c_off, c, dense):
             """Put `dense` (n, c, h, w) into window [c_off, +c) of grad[buf]: overwrite on first touch, add after."""
+            materialise(buf)
             if grads.get(buf) is None and c_off == 0 and tuple(dense.shape) == tuple(tensor(buf).shape) and \
                     dense.is_contiguous():
                 grads[buf] = dense            # first gradient of the whole tensor: adopt it, no copy
@@ -304,9 +315,18 @@ class Trainer(object):
         touched_layers = set()
         descs = self.model.train_executor._descriptors()
         for op, d in reversed(list(zip(plan.ops, descs))):
-            if op.dst not in grads:
+            pooled_grad = None
+            if op.dst in pending_pool:
+                lay = op.layer if op.kind == 'conv' else None
+                if (lay is not None and op.wparam is None and op.out_c_off == 0 and
+                        op.conv_geometry[0] == tensor(op.dst).shape[1] and
+                        (lay.bias is None or id(lay) not in touched_layers)):
+                    pooled_grad = pending_pool.pop(op.dst)
+                else:
+                    materialise(op.dst)
+            if op.dst not in grads and pooled_grad is None:
                 continue                      # nothing downstream of this op contributes to the loss
-            gD = grads[op.dst]
+            gD = grads.get(op.dst)
             src = tensor(op.src)
             if op.kind == 'd2s':               # adjoint of the depth-to-space interleave of a restated decoder layer
                 grads[op.src] = ops.space_to_depth2(gD, op.xs[0], c_off=op.out_c_off)
@@ -319,9 +339,13 @@ class Trainer(object):
                 derived = op.wparam is not None        # the layer runs with phase-summed kernels (plan.phase_params)
                 kern = self.model.train_executor.conv_weights(op)[0]
                 n_out = op.conv_geometry[0]
-                fused_bias = (lay.activation != 'linear' and lay.bias is not None and not acc and not derived and
-                              gD.shape[1] == lay.filters and tuple(y.shape) == tuple(gD.shape))
-                if fused_bias:         # dz in place of dy and the bias gradient from the same pass
+                fused_bias = (pooled_grad is None and lay.activation != 'linear' and lay.bias is not None and not acc and
+                              not derived and gD.shape[1] == lay.filters and tuple(y.shape) == tuple(gD.shape))
+                if pooled_grad is not None:    # the layer's only reader is MaxPooling2D(2): its backward rides along
+                    fused_bias = lay.bias is not None
+                    gD = ops.pool_act_bwd_bias_grad(y, pooled_grad, op.act,
+                                                    self._grad_view(lay, 'bias') if fused_bias else None)
+                elif fused_bias:       # dz in place of dy and the bias gradient from the same pass
                     ops.act_bwd_bias_grad(y, gD, op.act, self._grad_view(lay, 'bias'), lay.filters, out=gD)
                 elif lay.activation != 'linear':
                     ops.act_bwd(y, gD, op.act, out=gD)          # dz in place of dy
@@ -424,7 +448,10 @@ class Trainer(object):
             elif op.kind == 'maxpool':
                 if op.src == P.STATE_IN:
                     continue
-                deposit(op.src, 0, src.shape[1], ops.maxpool2_bwd(src, gD))
+                if op.src >= 0 and op.src not in grads and op.src not in pending_pool:
+                    pending_pool[op.src] = gD
+                else:
+                    deposit(op.src, 0, src.shape[1], ops.maxpool2_bwd(src, gD))
             elif op.kind == 'upsample':
                 if op.src == P.STATE_IN:
                     continue

@@ -170,6 +170,11 @@ int    dlwp_bias_grad(dlwp_handle_t, const void* dz, void* db, int n, int c, int
  * dz = dy * act'(y) (dz may alias dy), db[c] = sum of dz over (n, hw), by a fixed (bit-reproducible) reduction tree.       */
 int    dlwp_act_bwd_bias_grad(dlwp_handle_t, const void* y, const void* dy, void* dz, void* db, int n, int c, int c_off,
                               int c_total, int hw, int act, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* dlwp_maxpool2_bwd + dlwp_act_bwd + dlwp_bias_grad in one pass, for a Conv2D whose only reader is MaxPooling2D(2)
+ * (DLWP/model/models.py:188-228 train step of the U-Net encoders): y (n,c,h,w) the conv's output, dp (n,c,h/2,w/2) the
+ * pooled tensor's gradient, dz (n,c,h,w) <- dL/d(pre-activation), db[c] (nullable) <- sum of dz.  ws as dlwp_bias_grad.  */
+int    dlwp_pool_act_bwd_bias_grad(dlwp_handle_t, const void* y, const void* dp, void* dz, void* db, dlwp_shape4 ys, int act,
+                                   void* ws, size_t ws_bytes, int dtype, void* stream);
 size_t dlwp_mse_mae_workspace(dlwp_handle_t);
 int    dlwp_mse_mae(dlwp_handle_t, const void* y_pred, const void* y_true, size_t n, void* out2, void* dy,
                     float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream);

@@ -546,6 +546,27 @@ def test_fused_activation_backward_and_bias_gradient_equal_the_two_separate_kern
             assert torch.allclose(db.double(), want, rtol=1e-5, atol=1e-4)
 
 
+def test_fused_pooling_activation_backward_equals_the_three_separate_kernels():
+    """dlwp_pool_act_bwd_bias_grad == dlwp_maxpool2_bwd, dlwp_act_bwd, dlwp_bias_grad in turn: dz bit for bit (ties
+    included: the first maximum of a window takes the gradient), db to float32 rounding; even and odd planes."""
+    from dlwp_amd import ops
+    rng = np.random.default_rng(4)
+    for (n, c, h, w) in [(3, 5, 6, 10), (2, 4, 7, 9), (4, 3, 8, 11), (64, 32, 22, 44)]:
+        for act in (ops.ACT_TANH, ops.ACT_RELU, ops.ACT_LINEAR):
+            yv = np.tanh(rng.standard_normal((n, c, h, w))).astype(np.float32)
+            yv[rng.random(yv.shape) < 0.3] = 0.25          # plenty of ties inside windows
+            y = torch.from_numpy(yv).cuda()
+            dp = torch.from_numpy(rng.standard_normal((n, c, h // 2, w // 2)).astype(np.float32)).cuda()
+            dz_ref = ops.act_bwd(y, ops.maxpool2_bwd(y, dp), act) if act != ops.ACT_LINEAR else ops.maxpool2_bwd(y, dp)
+            db_ref = torch.empty(c, device='cuda')
+            ops.bias_grad(dz_ref, db_ref, c)
+            db = torch.empty(c, device='cuda')
+            dz = ops.pool_act_bwd_bias_grad(y, dp, act, db)
+            assert torch.equal(dz, dz_ref), (n, c, h, w, act)
+            assert torch.allclose(db, db_ref, rtol=1e-5, atol=1e-4)
+            assert torch.equal(ops.pool_act_bwd_bias_grad(y, dp, act), dz_ref)       # without a bias
+
+
 def test_conv_weight_gradient_every_compiled_tile_configuration():
     """Force each weight-gradient tile configuration in turn: ragged tiles, ragged channel groups, odd AND even widths
     (column-pair loads vs their element-wise form), output widths that are / are not multiples of 4 (pixel-quad loads),
