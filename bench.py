@@ -41,14 +41,14 @@ def build_model(grid, cin, seed=1234):
     return d
 
 
-def measured_traffic(cfg_tuple, members):
+def measured_traffic(cfg_tuple, members, ups=False):
     """HBM bytes per launch of a conv tile configuration from the committed rocprofv3 --pmc passes
     (profiles/*hbm_traffic_b256.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes, 256 members),
     scaled to `members`.  None when that configuration was not profiled."""
     import glob
     ks, dil, th, tw, waves, fa, bnf, ck, pool = cfg_tuple[:9]
     if fa == 0:
-        key = 'WinoCfg<%d, %d, %d, %d, %d, %d' % (dil, th, tw, waves, bnf, ck)      # (+ the input-storage flag)
+        key = 'WinoCfg<%d, %d, %d, %d, %d, %d, false, %s>' % (dil, th, tw, waves, bnf, ck, 'true' if ups else 'false')
     elif bnf < 0:
         key = 'PackCfg<%d, %d, %d, %d, %d, %d, %d, %d>' % (ks, dil, th, tw, waves, fa, ck, -bnf)
     else:
@@ -297,7 +297,7 @@ def main():
                                              if mult == 9 else ''))
             out['roofline']['executed_frac'] = dom['tflops'] * mult / 36.0 * pad / PEAK_F32_MFMA_TFLOPS
         if dom.get('tile_cfg'):
-            tr, src = measured_traffic(dom['tile_cfg'], a.members)
+            tr, src = measured_traffic(dom['tile_cfg'], a.members, ups=dom.get('wino_multiplies_per_tile') == 9)
             out['roofline']['traffic'] = tr
             out['roofline']['traffic_source'] = src
         out['layers'] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k not in ('flops', 'bytes')}
