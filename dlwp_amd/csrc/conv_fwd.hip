@@ -58,6 +58,11 @@ bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
          (size_t)a.Cin * a.Cout * 16 <= WINO_SCRATCH_FLOATS;
 }
 
+// the launch takes a WinoCfg::UPS variant (conv_fwd_wino_kernel.h, wino_launch_either)
+inline bool wino_skips_row2(const ConvArgs& a) {
+  return (a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1)) || a.out_pool == 2;
+}
+
 // ConvKernelEntry::pack: 0 plain, S > 0 packed-N, -1 Winograd, -2 bf16-MFMA
 inline bool is_wino(const ConvKernelEntry& e) { return e.pack == -1; }
 inline bool is_bf16(const ConvKernelEntry& e) { return e.pack == -2; }
@@ -246,6 +251,20 @@ double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   // MFMA steps per wave: direct = taps per 4-channel group; Winograd = 16 transformed positions per 4-channel group
   const double ksteps = (double)dlwp_ceil_div(a.Cin, e.ck) * (e.ck / 4) * (wino ? 16 : e.ks * kwe);
   const double work = (double)e.waves * e.fa * bnf * ksteps * (wino ? 1.3 : 1.0);  // MFMAs of one workgroup (+ transforms)
+  if (wino && wino_skips_row2(a)) {
+    // 9-position variants (WinoCfg::UPS): 143 registers at 32 output channels -> 3 waves per SIMD, 2 at 64 channels; LDS
+    // without filter row 2.  Measured on L4 (r1m): the CU's throughput per (block x 32 channels) barely depends on the
+    // mix (6.4 vs 5.9 us), so what decides is how evenly the blocks fill whole rounds of resident slots.
+    const int lds = e.lds_bytes - 4096 * e.bnf;
+    int res = (160 * 1024) / lds;
+    const int by_regs = (e.bnf == 2 ? 12 : 8) / e.waves;
+    if (res > by_regs) res = by_regs;
+    if (res < 1) res = 1;
+    const double per = blocks / cu_count;
+    const double rounds_q = per <= res ? 1.0 : (double)(long long)((per + res - 1e-9) / res);
+    const double co = per < 1.0 ? 1.0 : (per < res ? per : (double)res);
+    return rounds_q * co * (double)e.waves * bnf * ksteps * (e.bnf == 4 ? 0.93 : 1.0) * (e.waves < 4 ? 1.15 : 1.0);
+  }
   int resident = (160 * 1024) / e.lds_bytes;
   if (resident > 16 / e.waves) resident = 16 / e.waves;
   if (resident > 8) resident = 8;
@@ -302,6 +321,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if (e.pack > 0 && cd->cout > 16 / e.pack) continue;                    // packed-N instances cover cout <= 16/S
     if (is_wino(e) != want_wino || is_bf16(e) != want_bf16) continue;      // kernel family fixed by the layer
     if (is_wino(e) && a.Cout % (16 * e.bnf) != 0) continue;                // Winograd: whole output-channel tiles only
+    if (is_wino(e) && e.bnf == 4 && !wino_skips_row2(a)) continue;         // 64-channel blocks: 9-position variants only
     if (is_bf16(e) && ((e.in32 != 0) == (a.in_bf16 != 0) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) continue;
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     const double c = config_cost(e, a, cu_count);

@@ -39,6 +39,7 @@ static const ConvKernelEntry k_table[] = {
     PACKN_ENTRY(3, 1, 8, 32, 4, 2, 8, 2),
     // Winograd F(2x2,3x3) instances (conv_fwd_wino_kernel.h): DIL TH TW WAVES BNF CK
     WINO_ENTRY(1, 8, 32, 4, 2, 8),
+    WINO_ENTRY(1, 8, 32, 4, 4, 8),   // 64 output channels: selected for the UPS variants only (9 live positions)
     WINO_ENTRY(1, 4, 64, 4, 2, 8),
     WINO_ENTRY(1, 8, 16, 2, 2, 8),
     WINO_ENTRY(1, 4, 32, 2, 2, 8),

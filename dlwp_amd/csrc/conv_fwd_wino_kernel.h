@@ -59,7 +59,10 @@ struct WinoCfg {
   static constexpr int TPAD = 16 * WAVES;
   static constexpr int BN = 16 * BNF;
   static constexpr int X_FLOATS = CK * PS;
-  static constexpr int U_FLOATS = 16 * CK * BN;    // us[xy/4][ci][co][xy%4]
+  // us[xy/4][ci][co][xy%4]; the UPS variants never multiply transformed-filter row 2 (xy/4 == 2): they keep rows 0, 1, 3
+  // only, which brings a BNF = 2 block under a third of the CU's LDS (3 blocks per CU at its 143 registers)
+  static constexpr int UQ = UPS_ ? 3 : 4;
+  static constexpr int U_FLOATS = UQ * 4 * CK * BN;
   static constexpr int OPS = TH * TW + 4;          // output staging: plane stride of one channel
   static constexpr int O_FLOATS = BN * OPS;
   static constexpr int L_FLOATS = (2 * X_FLOATS + 2 * U_FLOATS) > O_FLOATS ? (2 * X_FLOATS + 2 * U_FLOATS) : O_FLOATS;
@@ -72,7 +75,7 @@ struct WinoCfg {
   // BNF = 2: two waves per SIMD (256 VGPRs each).  BNF = 4 (64 output channels per block: the input tile staged and
   // transformed once for twice the matrix work, 256 accumulator registers, ONE wave per SIMD) compiles but measured 1.56x
   // SLOWER on the 128->64 layer (1.075 vs 0.689 ms): a single wave cannot cover its own waits; no instance is registered.
-  static constexpr int WAVES_PER_SIMD = BNF == 2 ? 2 : 1;
+  static constexpr int WAVES_PER_SIMD = BNF == 2 ? (UPS_ ? 3 : 2) : (UPS_ ? 2 : 1);
   static_assert(TH % (2 * DIL) == 0 && TW % (2 * DIL) == 0, "region must be whole 2x2 tiles on every parity class");
   static_assert(TPAD >= T, "tiles must fit the wave decomposition");
   static_assert(CK == 8 && (BNF == 2 || BNF == 4), "the pipeline is written for two channel groups of 4 and 32 / 64 output channels");
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
       xr[ci][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0));
   };
   auto load_u = [&](int c0, int k, int r) {
+    if (C::UPS && r == 2) return;  // (r is an unrolled constant)
     const int soff = (min(c0, last_c0) * 4 + r) * a.Cout * 16;
     ur[k][r & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off[k], soff, 0));
   };
@@ -183,7 +187,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     lds[xdst + ci * C::PS + loff[q]] = C::IN16 ? bf16_bits_to_f32(__builtin_bit_cast(unsigned, xr[ci][q])) : xr[ci][q];
   };
   auto stage_u = [&](int udst, int k, int r) {
-    *(f32x4*)(lds + udst + u_dst[k] + r * C::CK * C::BN * 4) = ur[k][r & 1];
+    if (C::UPS && r == 2) return;
+    const int slot = C::UPS && r == 3 ? 2 : r;
+    *(f32x4*)(lds + udst + u_dst[k] + slot * C::CK * C::BN * 4) = ur[k][r & 1];
   };
   // input transform V = B^T d B of this lane's own A-operand elements, channel group c4 (channels (l>>4) + 4*c4)
   float v[2][16];
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   auto load_frags = [&](int usrc, int c4, int xq, int buf) {
 #pragma unroll
     for (int g = 0; g < C::BNF; ++g)
-      bf[buf][g] = *(const f32x4*)(lds + usrc + b_lane + ((xq * C::CK + c4 * 4) * C::BN + g * 16) * 4);
+      bf[buf][g] = *(const f32x4*)(lds + usrc + b_lane + (((C::UPS && xq == 3 ? 2 : xq) * C::CK + c4 * 4) * C::BN + g * 16) * 4);
   };
 
   // ---- prologue: chunk 0 staged, chunk 1 in registers, V(group 0, chunk 0) and the first B fragments loaded
