@@ -94,12 +94,14 @@ def time_layers(model, members, iters=5):
             continue
         lay = op.layer
         kern, bias = ex.conv_weights(op)       # the layer's, or the phase-summed kernels of a restated decoder layer
+        # weights prepared once, as in the rollout graph (dlwp_conv2d_prepare): the events bracket the conv kernel only
+        prep = ops.conv2d_prepare(src, kern, d, out_dtype=dst.dtype, x_channels=op.xs[0])
         for _ in range(2):
-            ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0])
+            ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], prepared=prep)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0])
+            ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], prepared=prep)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters

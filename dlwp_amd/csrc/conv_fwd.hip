@@ -547,6 +547,25 @@ int dlwp_conv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void* b
   return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream);
 }
 
+size_t dlwp_conv2d_prepared_bytes(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
+  if (!h || !cd) return 0;
+  return dlwp_conv2d_prep_floats(h, xs, cd, dtype) * sizeof(float);
+}
+
+int dlwp_conv2d_prepare(dlwp_handle_t h, const void* w, void* prepared, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype,
+                        void* stream) {
+  DLWP_CHECK_ARG(h && w && prepared && cd, "dlwp_conv2d_prepare: null handle or pointer");
+  return dlwp_conv2d_prep(h, w, (float*)prepared, xs, cd, dtype, (hipStream_t)stream);
+}
+
+int dlwp_conv2d_fwd_prepared(dlwp_handle_t h, const void* x, const void* w, const void* prepared, const void* bias, void* y,
+                             dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && cd, "dlwp_conv2d_fwd_prepared: null handle or descriptor");
+  DLWP_CHECK_ARG(prepared || dlwp_conv2d_prep_floats(h, xs, cd, dtype) == 0,
+                 "dlwp_conv2d_fwd_prepared: this layer runs on prepared weights (dlwp_conv2d_prepare)");
+  return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream, (const float*)prepared);
+}
+
 int dlwp_conv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int dtype, void* stream) {
   dlwp_shape4 ys;

@@ -103,10 +103,31 @@ def pad2d_bwd(dy, x_shape, pad, channels_last=False):
     return dx
 
 
-def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute_bf16=False):
+def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=False):
+    """Prepared weights for conv2d(x, ...) calls with exactly this input shape / storage (dlwp_conv2d_prepare), or None
+    when the layer's kernel reads the HWIO weights directly."""
+    _check_f32(w_hwio)
+    n, c_total, h, w = x.shape
+    cin = int(x_channels) if x_channels is not None else c_total
+    if cd.in_c_total == 0 and cin != c_total:
+        cd.in_c_total = c_total
+    xs = Shape4(n, cin, h, w)
+    out_code = storage_code(x) if out_dtype is None else {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[out_dtype]
+    dt = _lib.dtype_io(storage_code(x), out_code, compute_bf16)
+    nbytes = _lib.lib.dlwp_conv2d_prepared_bytes(_lib.handle(_dev(x)), xs, ctypes.byref(cd), dt)
+    if nbytes == 0:
+        return None
+    u = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib.dlwp_conv2d_prepare(_lib.handle(_dev(x)), _ptr(w_hwio), _ptr(u), xs, ctypes.byref(cd), dt,
+                                            _stream(x)))
+    return u
+
+
+def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute_bf16=False, prepared=None):
     """x: stored input (n, in_c_total, h, w); the conv reads `x_channels` (default: all) channels from cd.in_c_off.
     Returns (n, out_c_total, ho, wo); writes channels [out_c_off, out_c_off+cout).  compute_bf16: a float32 x may be
-    rounded to bfloat16 so that the layer runs on the bf16 matrix cores (DLWP_COMPUTE_BF16)."""
+    rounded to bfloat16 so that the layer runs on the bf16 matrix cores (DLWP_COMPUTE_BF16).  prepared: the tensor
+    conv2d_prepare returned for this call (the weights are then not transformed again)."""
     _check_act(x, out)
     _check_f32(w_hwio, bias)
     n, c_total, h, w = x.shape
@@ -125,6 +146,10 @@ def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute
         raise ValueError('output buffer shape %s != %s' % (tuple(out.shape), (n, oc, ys.h, ys.w)))
     fn = _lib.lib.dlwp_conv2d_fwd_direct if direct else _lib.lib.dlwp_conv2d_fwd
     dt = _lib.dtype_io(storage_code(x), storage_code(out), compute_bf16)      # storage of x / y
+    if prepared is not None and not direct:
+        _lib.check(_lib.lib.dlwp_conv2d_fwd_prepared(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(prepared),
+                                                     _ptr(bias), _ptr(out), xs, ctypes.byref(cd), dt, _stream(x)))
+        return out
     _lib.check(fn(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(bias), _ptr(out), xs, ctypes.byref(cd), dt,
                   _stream(x)))
     return out

@@ -104,6 +104,16 @@ int dlwp_pad2d_bwd(dlwp_handle_t, const void* dy, void* dx, int outer, int h, in
 int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys);
 int dlwp_conv2d_fwd(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                     const dlwp_conv2d* cd, int dtype, void* stream);
+/* Weight-stationary use (model.predict over many batches, the rollout of DLWP/model/models.py:263-310): some kernel
+ * families read the weights in a prepared layout (Winograd G g G^T, packed-N expansion, bf16 arrangement), which
+ * dlwp_conv2d_fwd builds in the handle's scratch before every launch (~5 us).  dlwp_conv2d_prepare builds it once into
+ * caller-owned device memory of dlwp_conv2d_prepared_bytes() bytes (0: the layer's kernel reads HWIO directly; then
+ * `prepared` may be NULL); it is valid for exactly this (xs incl. xs.n, cd, dtype) and until the weights change.        */
+size_t dlwp_conv2d_prepared_bytes(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
+int dlwp_conv2d_prepare(dlwp_handle_t, const void* w, void* prepared, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype,
+                        void* stream);
+int dlwp_conv2d_fwd_prepared(dlwp_handle_t, const void* x, const void* w, const void* prepared, const void* bias, void* y,
+                             dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, void* stream);
 /* same contract, one thread per output element on the vector ALU: any kernel size; used as the in-library cross-check */
 int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int dtype, void* stream);

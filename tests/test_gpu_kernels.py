@@ -286,6 +286,25 @@ def test_conv2d_batch_invariance(ops):
             assert np.array_equal(one[0], full[i])
 
 
+def test_conv2d_with_prepared_weights_is_bit_identical(ops):
+    """dlwp_conv2d_prepare + dlwp_conv2d_fwd_prepared == dlwp_conv2d_fwd: Winograd (plain and up-sampled source), packed-N
+    (5x5, 4 output channels), bf16 arrangement, and a direct layer that needs no preparation (prepared is None)."""
+    rng = np.random.default_rng(31)
+    cases = [(16, 64, 3, 1, 0, False, True), (64, 64, 3, 1, 1, False, True), (32, 4, 5, 1, 0, False, None),
+             (16, 48, 3, 1, 0, False, False), (32, 32, 3, 1, 0, True, True)]
+    for cin, cout, k, dil, src, cbf16, expect_prep in cases:
+        x = dev(rng.standard_normal((3, cin, 16, 36)).astype(np.float32))
+        wt = dev(np_ref.glorot_uniform((k, k, cin, cout), rng))
+        b = dev(rng.standard_normal(cout).astype(np.float32))
+        p = dil * (k - 1) // 2
+        cd = ops.make_conv(cout, k, k, dil, ops.make_pad(p, p, p, p, 0, 1), ops.ACT_TANH, src_mode=src)
+        prep = ops.conv2d_prepare(x, wt, cd, compute_bf16=cbf16)
+        assert expect_prep is None or (prep is not None) == expect_prep, (cin, cout, k)
+        want = ops.conv2d(x, wt, b, cd, compute_bf16=cbf16)
+        got = ops.conv2d(x, wt, b, cd, compute_bf16=cbf16, prepared=prep)
+        assert torch.equal(got, want), (cin, cout, k)
+
+
 # ----------------------------------------------------------------------------------------------------------------- #
 # ConvLSTM2D cell update
 # ----------------------------------------------------------------------------------------------------------------- #
