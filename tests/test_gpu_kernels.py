@@ -229,6 +229,44 @@ def test_conv2d_every_compiled_tile_configuration(ops):
         ops.force_conv_config(-1)
 
 
+def test_winograd_nine_position_variants_of_every_instance(ops):
+    """The WinoCfg::UPS variants (up-sampled source with an odd halo; 2x2 summing epilogue) of every dilation-1 Winograd
+    instance, forced in turn, against the float64 oracle -- and bit-identical across instances."""
+    rng = np.random.default_rng(98)
+    cfgs = ops.conv_configs()
+    n, cin, h, w, cout = 2, 24, 9, 26, 64
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    want_up = _conv_ref(x, wt, b, 1, (1, 1, 1, 1), 0, 1, 'tanh', 1)
+    xh = rng.standard_normal((n, cin, 2 * h, 2 * w)).astype(np.float32)
+    want_sum = _conv_ref(xh, wt, None, 1, (1, 1, 1, 1), 0, 1, 'linear', 0).reshape(n, cout, h, 2, w, 2).sum(axis=(3, 5))
+    seen_up, seen_sum, tried = None, None, 0
+    try:
+        for i, c in enumerate(cfgs):
+            ks, dil, fa, pool = c[0], c[1], c[5], c[8]
+            if not (ks == 3 and dil == 1 and fa == 0 and pool < 2):
+                continue
+            tried += 1
+            ops.force_conv_config(i)
+            cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, src_mode=1)
+            got = ops.conv2d(dev(x), dev(wt), dev(b), cd)
+            _check_conv(ops, host(got), want_up, 'up-sampled source, config %d %r' % (i, c))
+            assert seen_up is None or torch.equal(got, seen_up), 'config %d differs from the other Winograd instances' % i
+            seen_up = got
+            cs = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_LINEAR)
+            cs.out_pool = 2
+            got = ops.conv2d(dev(xh), dev(wt), None, cs)
+            assert tuple(got.shape) == (n, cout, h, w)
+            scale = max(1.0, float(np.abs(want_sum).max()))
+            assert np.abs(host(got) - want_sum).max() <= 4e-5 * scale, 'summing epilogue, config %d %r' % (i, c)
+            assert seen_sum is None or torch.equal(got, seen_sum)
+            seen_sum = got
+    finally:
+        ops.force_conv_config(-1)
+    assert tried >= 4
+
+
 def test_conv2d_channel_windows_slice_and_concat(ops):
     """slice_layer on the input side and concatenate on the output side without copies (custom.py:675-692)."""
     rng = np.random.default_rng(5)
