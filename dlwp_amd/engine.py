@@ -367,6 +367,27 @@ class Model(object):
         chunk = int(batch_size) if batch_size else 2048
         chunk = max(1, min(max(chunk, 256), n)) if n else 1
         results = None
+        if n > chunk and self.device.type == 'cuda':
+            # several chunks: results go into pinned host arrays on a copy stream, under the next chunk's kernels
+            copy_stream = torch.cuda.Stream(device=self.device)
+            pinned = None
+            for lo in range(0, n, chunk):
+                xd = torch.from_numpy(x[lo:lo + chunk]).to(self.device, non_blocking=False)
+                outs = self.predict_on_device(xd)
+                outs = outs if isinstance(outs, list) else [outs]
+                if pinned is None:
+                    pinned = [torch.empty((n,) + tuple(o.shape[1:]), dtype=torch.float32, pin_memory=True) for o in outs]
+                done = torch.cuda.Event()
+                done.record()
+                copy_stream.wait_event(done)
+                with torch.cuda.stream(copy_stream):
+                    for r, o in zip(pinned, outs):
+                        r[lo:lo + chunk].copy_(o.contiguous(), non_blocking=True)
+                for o in outs:
+                    o.record_stream(copy_stream)
+            copy_stream.synchronize()
+            results = [r.numpy() for r in pinned]
+            return results[0] if len(results) == 1 else results
         for lo in range(0, n, chunk):
             xd = torch.from_numpy(x[lo:lo + chunk]).to(self.device, non_blocking=False)
             outs = self.predict_on_device(xd)

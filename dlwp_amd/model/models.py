@@ -52,26 +52,57 @@ class _Wrapper(object):
         return (hasattr(net, 'rollout_on_device') and tuple(predictors.shape[1:]) == tuple(net.inputs[0].shape)
                 and all(tuple(o.shape) == tuple(net.inputs[0].shape) for o in net.outputs))
 
-    def _rollout_device(self, predictors, calls, keep_time_dim, return_device=False):
-        """All `calls` model applications in one hipGraph; merge of the time axis on the device too."""
-        import torch
+    def _rollout_chunk(self, x, calls, keep_time_dim, fresh=False):
+        """All `calls` model applications of the members in device tensor x as one hipGraph; merge of the time axis on the
+        device too.  fresh: the result must not alias the graph's cached series buffer."""
         from .. import ops
-        net = self.model
-        x = predictors if isinstance(predictors, torch.Tensor) else \
-            torch.from_numpy(np.ascontiguousarray(predictors, dtype=np.float32)).to(net.device)
-        series = net.rollout_on_device(x, calls)                 # (calls*n_out, N) + state shape
+        series = self.model.rollout_on_device(x, calls)          # (calls*n_out, N) + state shape
         n_slots, n_sample = series.shape[0], series.shape[1]
+        fs = tuple(series.shape[3:]) if self.is_recurrent else tuple(series.shape[2:])
         if keep_time_dim:
-            fs = tuple(series.shape[3:]) if self.is_recurrent else tuple(series.shape[2:])
             out = series.reshape((n_slots, n_sample, self.time_dim, -1) + fs[1:])
-        else:
-            flat = series.reshape((n_slots, n_sample, -1) + tuple(series.shape[-2:]))
-            out = ops.series_merge_time(flat.contiguous(), self.time_dim)
-            fs = tuple(series.shape[3:]) if self.is_recurrent else tuple(series.shape[2:])
-            out = out.reshape((n_slots * self.time_dim, n_sample, -1) + fs[1:])
-        if return_device:
-            return out
-        return out.cpu().numpy()
+            return out.clone() if fresh else out
+        flat = series.reshape((n_slots, n_sample, -1) + tuple(series.shape[-2:]))
+        out = ops.series_merge_time(flat.contiguous(), self.time_dim)
+        return out.reshape((n_slots * self.time_dim, n_sample, -1) + fs[1:])
+
+    #: members per hipGraph launch when the series goes back to the host: the device-to-host copy of one chunk runs
+    #: on its own stream under the rollout of the next (results do not depend on the chunking: tests/test_gpu_model.py)
+    host_chunk_members = 64
+
+    def _rollout_device(self, predictors, calls, keep_time_dim, return_device=False):
+        import torch
+        net = self.model
+        on_host = not isinstance(predictors, torch.Tensor)
+        n = int(predictors.shape[0])
+        chunk = int(self.host_chunk_members)
+        if return_device or n < 2 * chunk:
+            x = predictors if not on_host else \
+                torch.from_numpy(np.ascontiguousarray(predictors, dtype=np.float32)).to(net.device)
+            out = self._rollout_chunk(x, calls, keep_time_dim)
+            return out if return_device else out.cpu().numpy()
+        # large ensembles: pipelined over member chunks into ONE pinned host array (time first, as the reference returns
+        # it); slot t of a chunk is a contiguous block of it, so every copy is a plain asynchronous DMA
+        parts = -(-n // chunk)
+        chunk = -(-n // parts)                       # even chunks: one graph shape (plus at most one remainder shape)
+        xh = np.ascontiguousarray(predictors, dtype=np.float32) if on_host else None
+        copy_stream = torch.cuda.Stream(device=net.device)
+        host = None
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            xc = torch.from_numpy(xh[lo:hi]).to(net.device) if on_host else predictors[lo:hi]
+            out = self._rollout_chunk(xc, calls, keep_time_dim, fresh=True)
+            if host is None:
+                host = torch.empty((out.shape[0], n) + tuple(out.shape[2:]), dtype=torch.float32, pin_memory=True)
+            done = torch.cuda.Event()
+            done.record()
+            copy_stream.wait_event(done)
+            with torch.cuda.stream(copy_stream):
+                for t in range(out.shape[0]):
+                    host[t, lo:hi].copy_(out[t], non_blocking=True)
+            out.record_stream(copy_stream)
+        copy_stream.synchronize()
+        return host.numpy()
 
 
 class DLWPNeuralNet(_Wrapper):

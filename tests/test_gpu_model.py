@@ -133,6 +133,28 @@ def test_predict_timeseries_graph_equals_host_loop_and_tracks_the_oracle():
     assert np.array_equal(seq[0], d.predict(x).reshape(5, 2, 2, 16, 24)[:, 0])
 
 
+def test_predict_timeseries_pipelined_host_copy_is_bit_identical():
+    """Large ensembles go back to the host chunk by chunk (pinned array, copy stream under the next chunk's rollout):
+    same bits as one launch, for both output layouts, ragged last chunk, device or host predictors."""
+    import torch
+    rng = np.random.default_rng(5)
+    cs = (4, 16, 24)
+    d = _build(unet_layers(cs), time_dim=2)
+    _weights_of(d.model, rng)
+    x = rng.standard_normal((7,) + cs).astype(np.float32)
+    whole = d.predict_timeseries(x, 6)
+    whole_kept = d.predict_timeseries(x, 6, keep_time_dim=True)
+    d.host_chunk_members = 2                    # 7 members -> chunks of 2, 2, 2, 1
+    try:
+        assert np.array_equal(d.predict_timeseries(x, 6), whole)
+        assert np.array_equal(d.predict_timeseries(x, 6, keep_time_dim=True), whole_kept)
+        assert np.array_equal(d.predict_timeseries(torch.from_numpy(x).cuda(), 6), whole)
+        dev = d.predict_timeseries(x, 6, return_device=True)
+        assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), whole)
+    finally:
+        d.host_chunk_members = 64
+
+
 def test_member_sharding_is_bit_identical():
     """Ensemble members are independent: a rollout of a shard equals the same rows of the full rollout (what lets the
     8-GPU run be compared member by member with the 1-GPU run)."""
