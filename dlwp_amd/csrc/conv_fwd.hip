@@ -253,8 +253,7 @@ double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   const double work = (double)e.waves * e.fa * bnf * ksteps * (wino ? 1.3 : 1.0);  // MFMAs of one workgroup (+ transforms)
   if (wino && wino_skips_row2(a)) {
     // 9-position variants (WinoCfg::UPS): 143 registers at 32 output channels -> 3 waves per SIMD, 2 at 64 channels; LDS
-    // without filter row 2.  Measured on L4 (r1m): the CU's throughput per (block x 32 channels) barely depends on the
-    // mix (6.4 vs 5.9 us), so what decides is how evenly the blocks fill whole rounds of resident slots.
+    // without filter row 2.  What decides between them is how the blocks fill whole rounds of resident slots.
     const int lds = e.lds_bytes - 4096 * e.bnf;
     int res = (160 * 1024) / lds;
     const int by_regs = (e.bnf == 2 ? 12 : 8) / e.waves;
@@ -263,7 +262,10 @@ double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
     const double per = blocks / cu_count;
     const double rounds_q = per <= res ? 1.0 : (double)(long long)((per + res - 1e-9) / res);
     const double co = per < 1.0 ? 1.0 : (per < res ? per : (double)res);
-    return rounds_q * co * (double)e.waves * bnf * ksteps * (e.bnf == 4 ? 0.93 : 1.0) * (e.waves < 4 ? 1.15 : 1.0);
+    // a round of `co` co-resident blocks takes base x (1 + 0.5 (co - 1)): 38.3 us for three 32-channel blocks, 47.4 us for
+    // two 64-channel ones (L4, 256 members) -> a lone 64-channel block costs 1.65 x a lone 32-channel one
+    const double base = (double)e.waves / 4.0 * ksteps * (e.bnf == 4 ? 1.65 : 1.0) * (e.waves < 4 ? 1.15 : 1.0);
+    return rounds_q * base * (1.0 + 0.5 * (co - 1.0));
   }
   int resident = (160 * 1024) / e.lds_bytes;
   if (resident > 16 / e.waves) resident = 16 / e.waves;
