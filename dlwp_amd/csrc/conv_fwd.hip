@@ -457,17 +457,36 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   }
   Registry& r = registry();
   const ConvKernelEntry& e = r.entries[ci];
-  if (!r.prepared[ci]) {
-    std::lock_guard<std::mutex> lock(g_prepare_mutex);
-    if (!r.prepared[ci]) {
-      const int pe = e.prepare();
-      if (pe != 0) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: hipFuncSetAttribute failed (%d)", pe);
-      r.prepared[ci] = 1;
+  auto ensure_prepared = [&](int idx) -> int {
+    if (!r.prepared[idx]) {
+      std::lock_guard<std::mutex> lock(g_prepare_mutex);
+      if (!r.prepared[idx]) {
+        const int pe = r.entries[idx].prepare();
+        if (pe != 0) return pe;
+        r.prepared[idx] = 1;
+      }
     }
-  }
+    return 0;
+  };
+  if (ensure_prepared(ci) != 0) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: hipFuncSetAttribute failed");
   a.tiles_h = dlwp_ceil_div(a.Ho, e.th);
   a.tiles_w = dlwp_ceil_div(a.Wo, e.tw);
   a.cout_tiles = e.pack > 0 ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  a.col0 = 0;
+  // Winograd, 32-wide tiles on a map whose last column tile would be at most half used (22x45: 13 of 32 columns): the
+  // whole column tiles go to this instance, the rest to a 16-wide two-wave instance in a second launch (every Winograd
+  // instance reads the same prepared filters and gives the same bits).  Only when the launches fill the chip more than
+  // twice over -- at small batches a second launch costs more than the idle lanes.
+  int narrow = -1;
+  if (g_forced_cfg < 0 && is_wino(e) && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3 &&
+      (long long)a.N * a.tiles_h * (a.Wo / 32) * a.cout_tiles >= 4ll * h->cu_count) {
+    for (int i = 0; i < (int)r.entries.size() && narrow < 0; ++i) {
+      const ConvKernelEntry& p = r.entries[i];
+      if (is_wino(p) && p.dil == e.dil && p.tw == 16 && p.th == 8 && p.bnf == 2 && (!cd->out_pool || p.out_pool)) narrow = i;
+    }
+    if (narrow >= 0 && ensure_prepared(narrow) != 0) narrow = -1;
+  }
+  if (narrow >= 0) a.tiles_w = a.Wo / 32;
   const long long grid = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
   DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
   if (e.pack != 0) {  // Winograd / packed-N: prepared weights (into the handle's scratch unless the caller built them)
@@ -482,6 +501,14 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
     }
   }
   e.launch(a, (int)grid, s);
+  if (narrow >= 0) {
+    const ConvKernelEntry& p = r.entries[narrow];
+    a.col0 = (a.Wo / 32) * 32;
+    a.tiles_h = dlwp_ceil_div(a.Ho, p.th);
+    a.tiles_w = 1;
+    a.cout_tiles = dlwp_ceil_div(a.Cout, 16 * p.bnf);
+    p.launch(a, (int)((long long)a.tiles_h * a.cout_tiles * a.N), s);
+  }
   DLWP_LAUNCH_CHECK("conv2d_fwd_mfma_f32");
   return DLWP_OK;
 }

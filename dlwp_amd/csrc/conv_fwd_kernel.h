@@ -37,6 +37,7 @@ struct ConvArgs {
   int out_pool, Hp, Wp;   // epilogue 2x2 max-pooling: y is (N, out_c_total, Hp, Wp) = (Ho/2, Wo/2)
   int in_bf16, out_bf16;  // storage of x / y: 0 = float32, 1 = bfloat16 (w, bias fp32)
   int compute_bf16;       // DLWP_COMPUTE_BF16: a float32-stored input may be rounded to bf16 for the bf16 matrix cores
+  int col0 = 0;           // Winograd: first output column of this launch (a wide-tile launch + a narrow one for the rest)
 };
 
 template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool POOL_ = false>

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   L /= a.tiles_h;
   const int ct = L % a.cout_tiles;
   const int n = L / a.cout_tiles;
-  const int i0 = th * C::TH, j0 = tw * C::TW, n0 = ct * C::BN;
+  const int i0 = th * C::TH, j0 = a.col0 + tw * C::TW, n0 = ct * C::BN;
 
   // ---- input loader bookkeeping: byte offset inside a channel plane (0x7ffffff0 = out of range = reads 0) and the LDS
   //      slot; the lanes past the tile of the last pass repeat element 0 (same value written twice: harmless)

@@ -267,6 +267,32 @@ def test_winograd_nine_position_variants_of_every_instance(ops):
     assert tried >= 4
 
 
+def test_winograd_wide_plus_narrow_launch_is_bit_identical(ops):
+    """A 22x45 map at a batch that fills the chip: the 32 whole columns go to the 8x32 instance, the last 13 to the 16-wide
+    one in a second launch.  Same bits as the single forced instance; plain, pooled-epilogue and up-sampled launches."""
+    rng = np.random.default_rng(97)
+    cfgs = ops.conv_configs()
+    wide = [i for i, c in enumerate(cfgs) if c[0] == 3 and c[1] == 1 and c[5] == 0 and c[2:5] == (8, 32, 4) and c[6] == 2]
+    assert wide
+    for src, hw, pool in ((0, (22, 45), False), (0, (22, 90), True), (1, (11, 45), False), (0, (22, 77), False)):
+        n, cin, cout = 96, 16, 128
+        x = dev(rng.standard_normal((n, cin) + hw).astype(np.float32))
+        wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+        b = dev((0.1 * rng.standard_normal(cout)).astype(np.float32))
+        cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, src_mode=src, out_pool=pool)
+        got = ops.conv2d(x, wt, b, cd)
+        ops.force_conv_config(wide[0])
+        try:
+            want = ops.conv2d(x, wt, b, cd)
+        finally:
+            ops.force_conv_config(-1)
+        assert torch.equal(got, want), (src, hw, pool)
+        ref = _conv_ref(host(x[:1]), host(wt), host(b), 1, (1, 1, 1, 1), 0, 1, 'tanh', src)
+        if pool:
+            ref = np_ref.maxpool2(ref)
+        _check_conv(ops, host(got[:1]), ref)
+
+
 def test_conv2d_channel_windows_slice_and_concat(ops):
     """slice_layer on the input side and concatenate on the output side without copies (custom.py:675-692)."""
     rng = np.random.default_rng(5)
