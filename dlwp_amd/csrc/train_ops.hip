@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void loss_stats_final_kernel(const float* __re
   float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < nblocks; i += 256)
     for (int k = 0; k < 9; ++k) s[k] += partial[9 * i + k];
-  float z = 0.f, sp_reg = 0.f;
+  float sp_reg = 0.f;
   if (reg == 4)  // 'spatial': mean over planes of |(mean_t - mean_p) / mean_t|   (the 1/hw factors cancel)
     for (int i = threadIdx.x; i < planes; i += 256) sp_reg += fabsf((plane[2 * i + 1] - plane[2 * i]) / plane[2 * i + 1]);
   block_sum2(s[0], s[1]);
