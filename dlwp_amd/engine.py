@@ -19,6 +19,8 @@ from . import plan as P
 def default_device():
     if torch.cuda.is_available():
         idx = int(os.environ.get('LOCAL_RANK', torch.cuda.current_device()))
+        if idx >= torch.cuda.device_count() and os.environ.get('DLWP_SHARE_GPUS') == '1':
+            idx %= torch.cuda.device_count()          # testing only, see parallel.init
         return torch.device('cuda', idx)
     return torch.device('cpu')     # weights can be held for planning / inspection; every compute call will raise
 

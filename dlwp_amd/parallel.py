@@ -56,12 +56,15 @@ def init(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        if local >= ndev and os.environ.get('DLWP_SHARE_GPUS') == '1':
+            local %= ndev          # testing only: several ranks on one GPU (needs DLWP_DIST_BACKEND=gloo, RCCL refuses)
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        backend = backend or os.environ.get('DLWP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         kwargs = {}
         if backend == 'nccl':
             kwargs['device_id'] = torch.device('cuda', local)
