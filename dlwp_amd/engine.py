@@ -14,6 +14,7 @@ import torch
 
 from . import layers as L
 from . import plan as P
+from .util import host_result_buffer
 
 
 def default_device():
@@ -378,7 +379,7 @@ class Model(object):
                 outs = self.predict_on_device(xd)
                 outs = outs if isinstance(outs, list) else [outs]
                 if pinned is None:
-                    pinned = [torch.empty((n,) + tuple(o.shape[1:]), dtype=torch.float32, pin_memory=True) for o in outs]
+                    pinned = [host_result_buffer((n,) + tuple(o.shape[1:])) for o in outs]
                 done = torch.cuda.Event()
                 done.record()
                 copy_stream.wait_event(done)

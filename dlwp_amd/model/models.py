@@ -93,7 +93,7 @@ class _Wrapper(object):
             xc = torch.from_numpy(xh[lo:hi]).to(net.device) if on_host else predictors[lo:hi]
             out = self._rollout_chunk(xc, calls, keep_time_dim, fresh=True)
             if host is None:
-                host = torch.empty((out.shape[0], n) + tuple(out.shape[2:]), dtype=torch.float32, pin_memory=True)
+                host = util.host_result_buffer((out.shape[0], n) + tuple(out.shape[2:]))
             done = torch.cuda.Event()
             done.record()
             copy_stream.wait_event(done)

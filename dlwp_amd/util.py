@@ -135,3 +135,13 @@ def insolation(dates, lat, lon, S=1.):
                np.cos(latr[None, ...]) * np.cos(dec[:, None, None]) * np.cos(h)) * rho[:, None, None] ** -2.
     sol[sol < 0.] = 0.
     return sol.astype(np.float32)
+
+
+def host_result_buffer(shape):
+    """float32 host tensor for results copied back from the device: page-locked (asynchronous DMA on a copy stream) when
+    the host allows it, pageable otherwise (the copies then simply run synchronously)."""
+    import torch
+    try:
+        return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32, pin_memory=True)
+    except RuntimeError:
+        return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32)
