@@ -627,6 +627,10 @@ class Trainer(object):
         val = None
         if validation_data is not None:
             vx, vy = validation_data[0], validation_data[1]
+            if not isinstance(vx, torch.Tensor):       # uploaded once, evaluated after every epoch
+                vys = list(vy) if isinstance(vy, (list, tuple)) else [vy]
+                vx, vys, _ = self._make_resident(np.asarray(vx), vys)
+                vy = vys if isinstance(vy, (list, tuple)) else vys[0]
             val = lambda: self.evaluate(vx, vy, batch_size=batch_size, verbose=0, as_list=True)  # noqa: E731
         return self._run_epochs(epochs, initial_epoch, batches, None, val, callbacks, verbose, None)
 
