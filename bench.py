@@ -260,6 +260,7 @@ def main():
                                % (grid[0], grid[1], a.channels, a.forwards, a.members),
                    'members_per_gpu': a.members, 'forwards_per_rollout': a.forwards, 'time_dim': 2,
                    'grid': list(grid), 'channels': a.channels, 'launches_per_forward': net.infer_plan.n_launches,
+                   'launch_note': 'plan operations; a Winograd layer on a 22x45 map takes a second (16-wide) launch for its ragged last column tile at chip-filling batches',
                    'parallelism': 'members sharded over %d GPU(s), no collective' % world,
                    'inference_plan': ('Winograd F(2x2,3x3) on the 3x3 layers; the decoder layers that read an up-sampled '
                                       'tensor are restated on the low-resolution tensor (same function, DESIGN.md 5.7; '
