@@ -293,7 +293,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if (is_bf16(e) && (!bf16_wanted(a, cd) || (e.in32 != 0) == (a.in_bf16 != 0) ||
                        bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
     if (cd->out_pool && !e.out_pool) return -1;
-    if (cd->out_pool == 2 && !is_wino(e)) return -1;  // the 2x2 sum epilogue lives in the Winograd family
+    if (cd->out_pool == 2 && !(is_wino(e) && e.dil == 1)) return -1;  // the 2x2 sum epilogue: dilation-1 Winograd instances
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? g_forced_cfg
                : -1;
@@ -315,7 +315,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
                     (!cd->out_pool || e.out_pool));
     want_wino = any;
   }
-  if (sum_pool && !want_wino) return -1;
+  if (sum_pool && !(want_wino && cd->dil_h == 1)) return -1;
   for (int i = 0; i < (int)r.entries.size(); ++i) {
     const ConvKernelEntry& e = r.entries[i];
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;

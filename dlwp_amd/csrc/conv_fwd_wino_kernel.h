@@ -375,8 +375,11 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     }
   });
   __syncthreads();
-  if constexpr (C::DIL == 1) {
-    if (a.out_pool) {  // pooled tile [co][TH/2][TW/2] -> 16-byte row segments of the (Hp, Wp) output
+  {
+    // dilation 1: the staging area holds the pooled tile [co][TH/2][TW/2] (the lane's 2x2 tile was one pooling window);
+    // dilation 2: it holds the full activated tile [co][TH][TW] (a window's four outputs come from four parity classes, i.e.
+    // four lanes) and the maximum is taken here -- either way 16-byte row segments of the (Hp, Wp) output
+    if (a.out_pool) {
       constexpr int PW = C::TW / 2, PP = (C::TH / 2) * PW;
       static_assert((C::BN * PP / 4) % C::NT == 0 && PW % 4 == 0, "pooled output staging: whole float4 per thread");
       const long long ybase = ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Hp * a.Wp;
@@ -387,7 +390,16 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         const int row = rem / PW, colx = rem - row * PW;
         const int oh = (i0 >> 1) + row, ow = (j0 >> 1) + colx;
         if (oh >= a.Hp || ow >= a.Wp) continue;
-        const f32x4 o = *(const f32x4*)(lds + co * C::OPS + rem);
+        f32x4 o;
+        if constexpr (C::DIL == 1) {
+          o = *(const f32x4*)(lds + co * C::OPS + rem);
+        } else {
+          const float* p0 = lds + co * C::OPS + (2 * row) * C::TW + 2 * colx;
+          const f32x4 a0 = *(const f32x4*)p0, a1 = *(const f32x4*)(p0 + 4);
+          const f32x4 b0 = *(const f32x4*)(p0 + C::TW), b1 = *(const f32x4*)(p0 + C::TW + 4);
+          o = (f32x4){fmaxf(fmaxf(a0[0], a0[1]), fmaxf(b0[0], b0[1])), fmaxf(fmaxf(a0[2], a0[3]), fmaxf(b0[2], b0[3])),
+                      fmaxf(fmaxf(a1[0], a1[1]), fmaxf(b1[0], b1[1])), fmaxf(fmaxf(a1[2], a1[3]), fmaxf(b1[2], b1[3]))};
+        }
         const long long yoff = ybase + ((long long)co * a.Hp + oh) * a.Wp + ow;
         if (a.out_bf16) {
           bf16_t* yp = (bf16_t*)a.y + yoff;
@@ -491,6 +503,6 @@ static int wino_prepare_both() {
 // registry entry: ks = 3, fa = 0, pack = -1 marks a Winograd instance (a.w = the transformed filter)
 #define WINO_ENTRY(DIL, TH, TW, WAVES, BNF, CK)                                                                         \
   {                                                                                                                      \
-    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1, (DIL) == 1 ? 1 : 0, 0, \
+    3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1, 1, 0,                  \
         &wino_launch_either<DIL, TH, TW, WAVES, BNF, CK>, &wino_prepare_both<DIL, TH, TW, WAVES, BNF, CK>                \
   }

@@ -675,6 +675,8 @@ def test_maxpool2_bfloat16_is_exact(ops):
     (2, 32, 16, 40, 64, 3, 1, 'tanh'),           # Winograd: the lane's 2x2 tile is the pooling window
     (3, 24, 13, 27, 32, 3, 1, 'relu'),           # Winograd, odd sizes
     (2, 16, 12, 20, 32, 3, 1, 'linear'),
+    (2, 48, 16, 72, 32, 3, 2, 'tanh'),           # Winograd, dilation 2: the window's outputs sit in four lanes -> max from LDS
+    (3, 16, 13, 37, 64, 3, 2, 'relu'),           # ... odd sizes
 ])
 @pytest.mark.parametrize('out16', [False, True])
 def test_conv2d_with_pooling_epilogue(ops, case, out16):
