@@ -151,7 +151,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   const __amdgpu_buffer_rsrc_t u_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cin * a.Cout * 64, 0x00020000);
   const int b_lane = ((lane >> 4) * C::BN + (lane & 15)) * 4;
-  const int last_c0 = a.Cin - C::CK;
+  const int last_c0 = ((a.Cin + C::CK - 1) / C::CK - 1) * C::CK;   // (Cin may be ragged: the planes past it read 0)
 
   f32x4 acc[16][C::BNF];
 #pragma unroll

@@ -293,6 +293,34 @@ def test_winograd_wide_plus_narrow_launch_is_bit_identical(ops):
         _check_conv(ops, host(got[:1]), ref)
 
 
+@pytest.mark.parametrize('cin', [5, 6, 7, 13, 22, 30])
+@pytest.mark.parametrize('dil,src', [(1, 0), (2, 0), (1, 1)])
+def test_winograd_with_ragged_input_channels(ops, cin, dil, src):
+    """Input-channel counts that are not multiples of 8 run zero-padded to whole chunks (the ConvLSTM2D input convolution of
+    config 4 has 6): out-of-range planes and filter rows read as 0.  9 or 12 input channels stay on the direct family,
+    whose chunks of 4 waste less."""
+    import ctypes
+    from dlwp_amd import _lib
+    rng = np.random.default_rng(100 + cin)
+    n, h, w, cout = 2, 13, 38, 64
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    pads = (dil, dil, dil, dil)
+    cd = ops.make_conv(cout, 3, 3, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH, src_mode=src)
+    pick = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(0), ops.Shape4(n, cin, h, w), ctypes.byref(cd))
+    assert pick >= 0 and ops.conv_configs()[pick][5] == 0, 'expected a Winograd instance'
+    # the planes behind the window must not leak in: poison what follows the last channel
+    xd = torch.full((n, cin + 3, h, w), 1e6, dtype=torch.float32, device='cuda')
+    xd[:, :cin] = dev(x)
+    got = ops.conv2d(xd, dev(wt), dev(b), cd, x_channels=cin)
+    _check_conv(ops, host(got), _conv_ref(x, wt, b, dil, pads, 0, 1, 'tanh', src), 'cin %d' % cin)
+    for c_direct in (9, 12):
+        c9 = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
+        p9 = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(0), ops.Shape4(n, c_direct, h, w), ctypes.byref(c9))
+        assert p9 < 0 or ops.conv_configs()[p9][5] != 0
+
+
 def test_conv2d_channel_windows_slice_and_concat(ops):
     """slice_layer on the input side and concatenate on the output side without copies (custom.py:675-692)."""
     rng = np.random.default_rng(5)
