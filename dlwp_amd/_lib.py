@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlwp_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dlwp_hip.h')
 
-OK, EINVAL, EUNSUPPORTED, EHIP = 0, -1, -2, -3
+OK, EINVAL, EUNSUPPORTED, EHIP, ERCCL = 0, -1, -2, -3, -4
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
@@ -147,6 +147,12 @@ _sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _P(_vp)])
 _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
+_sig('dlwp_comm_unique_id', [_vp, _P(_sz)])
+_sig('dlwp_comm_init_rank', [_P(_vp), _i, _i, _i, _vp, _sz])
+_sig('dlwp_comm_info', [_vp, _P(_i), _P(_i), _P(_i)])
+_sig('dlwp_allreduce_sum_f32', [_vp, _vp, _sz, _vp])
+_sig('dlwp_broadcast_f32', [_vp, _vp, _sz, _i, _vp])
+_sig('dlwp_comm_destroy', [_vp])
 
 
 def check(rc):

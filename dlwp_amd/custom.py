@@ -126,6 +126,11 @@ def latitude_weighted_loss(loss_function=None, lats=None, output_shape=(), axis=
     return LossSpec(0, 0, None, w, 1.0, 'lat_loss')
 
 
+# compatibility names (reference custom.py:1091-1093): what load_model's custom_objects of older scripts look up
+lat_loss = latitude_weighted_loss()
+acc_loss = anomaly_correlation_loss()
+
+
 # ------------------------------------------------------------------------------------------------------------------ #
 # callbacks (host-side plumbing of examples/train.py:253-263)
 # ------------------------------------------------------------------------------------------------------------------ #

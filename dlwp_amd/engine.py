@@ -326,6 +326,8 @@ class Model(object):
                 k += m
         if k != len(arrays):
             raise ValueError('model has %d weight arrays, got %d' % (k, len(arrays)))
+        if self._trainer is not None:          # data parallel: replicas re-align on rank 0's at the next training step
+            self._trainer._params_dirty = True
 
     def count_params(self):
         return int(sum(lay.count_params() for lay in self.layers))

@@ -449,13 +449,23 @@ class DeviceLoader(object):
 
     A worker thread runs gen[i+1] (numpy gather on the host) and stages it into one of two pinned buffers while the
     consumer works on batch i; the H2D copies are issued on a private copy stream and the consumer's stream waits on
-    their event, so compute and transfer overlap.  `order` optionally restricts / permutes the batch indices (rank
-    sharding for data-parallel training)."""
+    their event, so compute and transfer overlap.  y may be one array or a list of arrays (SeriesDataGenerator with
+    `sequence`, the multi-output DLWPFunctional models): every target gets its own staging buffers and comes out as a
+    list of device tensors.
 
-    def __init__(self, generator, device, order=None, depth=2):
+    `order` optionally restricts / permutes the batch indices.  `shard=(rank, world)` is the data-parallel feed: batch i is
+    still the GLOBAL batch i of the generator (same index list on every rank -- the trainer broadcasts rank 0's), but this
+    rank gathers and uploads ONLY its contiguous row shard of it (parallel.shard_bounds, the cut
+    keras.utils.multi_gpu_model makes inside one process, reference models.py:104-109).  Generators with the
+    DataGenerator protocol (`_indices`, `_batch_size`, `generate(samples)`) gather just those samples; any other
+    Sequence is asked for the whole batch and sliced on the host before the upload.  iter_batches() yields
+    (X, y, n_global) so the training step can weight ragged shards exactly."""
+
+    def __init__(self, generator, device, order=None, depth=2, shard=None):
         import torch
         self.gen, self.device, self.depth = generator, device, max(2, int(depth))
         self.order = list(range(len(generator))) if order is None else list(order)
+        self.shard = None if shard is None or int(shard[1]) <= 1 else (int(shard[0]), int(shard[1]))
         self._torch = torch
         self._copy_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
         self._slots = [None] * self.depth
@@ -463,41 +473,74 @@ class DeviceLoader(object):
     def __len__(self):
         return len(self.order)
 
-    def _stage(self, slot, X, y):
+    # -- host side: this rank's rows of global batch `idx` -------------------------------------------------------------- #
+    def _fetch(self, idx):
+        """(X, [targets], was_list, n_global) as float32 numpy arrays"""
+        from ..parallel import shard_bounds
+        gen = self.gen
+        if self.shard is None:
+            X, y = gen[idx]
+            n_global = int(np.asarray(X).shape[0])
+        elif all(hasattr(gen, a) for a in ('_indices', '_batch_size', 'generate')):
+            bs = int(gen._batch_size)
+            if int(idx) < 0:
+                idx = len(gen) + int(idx)
+            samples = gen._indices[idx * bs:(idx + 1) * bs]
+            n_global = len(samples)
+            lo, hi = shard_bounds(n_global, *self.shard)
+            if hi > lo:
+                X, y = gen.generate(samples[lo:hi])
+            else:                               # no rows for this rank: right trailing shape, zero rows
+                X, y = gen.generate(samples[:1])      # (generate([]) would mean "every sample")
+                X = X[:0]
+                y = [t[:0] for t in y] if isinstance(y, (list, tuple)) else y[:0]
+        else:
+            X, y = gen[idx]
+            n_global = int(np.asarray(X).shape[0])
+            lo, hi = shard_bounds(n_global, *self.shard)
+            X = X[lo:hi]
+            y = [t[lo:hi] for t in y] if isinstance(y, (list, tuple)) else y[lo:hi]
+        was_list = isinstance(y, (list, tuple))
+        ys = [np.ascontiguousarray(t, dtype=np.float32) for t in (y if was_list else [y])]
+        return np.ascontiguousarray(X, dtype=np.float32), ys, was_list, n_global
+
+    # -- staging ---------------------------------------------------------------------------------------------------------- #
+    def _stage(self, slot, arrays):
+        """arrays: [X, y0, y1, ...] -> device tensors of the same shapes, through this slot's pinned buffers"""
         torch = self._torch
         bufs = self._slots[slot]
-        need = (tuple(X.shape), tuple(y.shape))
-        if bufs is None or bufs['cap'][0] < X.size or bufs['cap'][1] < y.size:
+        sizes = [max(1, a.size) for a in arrays]
+        if bufs is None or len(bufs['cap']) != len(sizes) or any(c < s for c, s in zip(bufs['cap'], sizes)):
             pin = self.device.type == 'cuda'
-            bufs = {'cap': (X.size, y.size),
-                    'hx': torch.empty(X.size, dtype=torch.float32, pin_memory=pin),
-                    'hy': torch.empty(y.size, dtype=torch.float32, pin_memory=pin),
-                    'dx': torch.empty(X.size, dtype=torch.float32, device=self.device),
-                    'dy': torch.empty(y.size, dtype=torch.float32, device=self.device),
+            bufs = {'cap': sizes,
+                    'host': [torch.empty(s, dtype=torch.float32, pin_memory=pin) for s in sizes],
+                    'dev': [torch.empty(s, dtype=torch.float32, device=self.device) for s in sizes],
                     'ev': torch.cuda.Event() if pin else None, 'free': None}
             self._slots[slot] = bufs
         if bufs['ev'] is not None and bufs.get('recorded'):
             bufs['ev'].synchronize()        # the previous H2D copy out of this pinned slot must have drained
-        hx = bufs['hx'][:X.size].view(need[0])
-        hy = bufs['hy'][:y.size].view(need[1])
-        hx.numpy()[...] = X
-        hy.numpy()[...] = y
-        dx = bufs['dx'][:X.size].view(need[0])
-        dy = bufs['dy'][:y.size].view(need[1])
+        hs, ds = [], []
+        for a, hbuf, dbuf in zip(arrays, bufs['host'], bufs['dev']):
+            h = hbuf[:a.size].view(a.shape)
+            h.numpy()[...] = a
+            hs.append(h)
+            ds.append(dbuf[:a.size].view(a.shape))
         if self._copy_stream is not None:
             if bufs['free'] is not None:
                 self._copy_stream.wait_event(bufs['free'])      # the consumer is done with this slot's device buffers
             with torch.cuda.stream(self._copy_stream):
-                dx.copy_(hx, non_blocking=True)
-                dy.copy_(hy, non_blocking=True)
+                for d, h in zip(ds, hs):
+                    d.copy_(h, non_blocking=True)
                 bufs['ev'].record(self._copy_stream)
                 bufs['recorded'] = True
         else:
-            dx.copy_(hx)
-            dy.copy_(hy)
-        return dx, dy, bufs
+            for d, h in zip(ds, hs):
+                d.copy_(h)
+        return ds, bufs
 
-    def __iter__(self):
+    def iter_batches(self):
+        """yields (X, y, n_global): device tensors of this rank's rows (y a list when the generator gives a list) and
+        the size of the global batch they belong to"""
         torch = self._torch
         results = {}
         lock = threading.Condition()
@@ -509,12 +552,10 @@ class DeviceLoader(object):
                     with lock:
                         while k - state['consumed'] >= self.depth:
                             lock.wait()
-                    X, y = self.gen[idx]
-                    X = np.ascontiguousarray(X, dtype=np.float32)
-                    y = np.ascontiguousarray(y, dtype=np.float32)
-                    item = self._stage(k % self.depth, X, y)
+                    X, ys, was_list, n_global = self._fetch(idx)
+                    ds, bufs = self._stage(k % self.depth, [X] + ys)
                     with lock:
-                        results[k] = item
+                        results[k] = (ds, bufs, was_list, n_global)
                         lock.notify_all()
             except BaseException as e:  # noqa: BLE001
                 with lock:
@@ -530,10 +571,10 @@ class DeviceLoader(object):
                     lock.wait()
                 if 'error' in results:
                     raise results['error']
-                dx, dy, bufs = results.pop(k)
+                ds, bufs, was_list, n_global = results.pop(k)
             if bufs['ev'] is not None:
                 torch.cuda.current_stream(self.device).wait_event(bufs['ev'])
-            yield dx, dy
+            yield ds[0], (ds[1:] if was_list else ds[1]), n_global
             if bufs['ev'] is not None:
                 done = torch.cuda.Event()
                 done.record(torch.cuda.current_stream(self.device))
@@ -542,3 +583,7 @@ class DeviceLoader(object):
                 state['consumed'] = k + 1
                 lock.notify_all()
         th.join()
+
+    def __iter__(self):
+        for X, y, _ in self.iter_batches():
+            yield X, y

@@ -28,9 +28,12 @@ def _layer_config(lay):
         if isinstance(lay.kernel_regularizer, L1L2):
             cfg['kernel_regularizer'] = {'l2': lay.kernel_regularizer.l2}
     elif isinstance(lay, L.Conv2D):
+        from .regularizers import L1L2
         cfg.update(filters=lay.filters, kernel_size=list(lay.kernel_size), padding=lay.padding,
                    data_format=lay.data_format, dilation_rate=list(lay.dilation_rate), activation=lay.activation,
                    use_bias=lay.use_bias)
+        if isinstance(lay.kernel_regularizer, L1L2):
+            cfg['kernel_regularizer'] = {'l2': lay.kernel_regularizer.l2}
     elif isinstance(lay, (L.MaxPooling2D, L.UpSampling2D)):
         cfg.update(data_format=lay.data_format)
     elif isinstance(lay, L.Reshape):
@@ -94,6 +97,12 @@ def save_model_file(model, path):
             arrays['__loss_mean__'] = model.loss.mean
         if model.loss.row_weights is not None:
             arrays['__loss_row_weights__'] = model.loss.row_weights
+    # optimizer slots (Adam m / v, SGD velocity), as keras save_model keeps the optimizer weights: a resumed run continues
+    # with the moments that belong to `iterations` (flat buffers in the order of the weights above)
+    tr = getattr(model, '_trainer', None)
+    if tr is not None and tr.opt_state is not None:
+        for k, t in enumerate(tr.opt_state):
+            arrays['__opt_state_%d__' % k] = t.detach().cpu().numpy()
     buf = io.BytesIO()
     np.savez(buf, __arch__=np.frombuffer(json.dumps(arch).encode('utf-8'), dtype=np.uint8), **arrays)
     with open(path, 'wb') as f:
@@ -153,4 +162,14 @@ def load_model_file(path, custom_objects=None, device=None):
             loss = C.LossSpec(sp['kind'], sp['regularize'], data['__loss_mean__'] if sp['has_mean'] else None,
                               data['__loss_row_weights__'] if sp['has_row_weights'] else None, sp['scale'], sp['name'])
         model.compile(optimizer=opt, loss=loss, metrics=comp['metrics'], loss_weights=comp['loss_weights'])
+        slots = []
+        while '__opt_state_%d__' % len(slots) in data.files:
+            slots.append(data['__opt_state_%d__' % len(slots)])
+        tr = model._trainer
+        if slots and all(a.size == tr.flat_params.numel() for a in slots):
+            import torch
+            tr.opt_state = tuple(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(model.device)
+                                 for a in slots)
+        elif iters:
+            opt.iterations = 0      # a file without the moments: restart the bias correction with them (m = v = 0)
     return model

@@ -139,12 +139,32 @@ class Trainer(object):
             self.metrics_names = (['loss'] + ['%s_loss' % nm for nm in out_names] +
                                   ['%s_%s' % (nm, mk) for nm in out_names for mk in self.metric_keys])
         self.flat_params, self.entries = flatten_parameters(model)
-        self.flat_grads = torch.zeros_like(self.flat_params)
+        # gradients + (behind them) the [n_out, 7] loss table of a data-parallel step: ONE buffer, ONE all-reduce
+        n_par = self.flat_params.numel()
+        self._flat_exchange = torch.zeros(n_par + 7 * n_out, dtype=torch.float32, device=self.device)
+        self.flat_grads = self._flat_exchange[:n_par]
+        self._loss_tail = self._flat_exchange[n_par:].view(n_out, 7)
         self.opt_state = None
         self.dp = getattr(model, '_dp', None)
         self._grad_bufs = {}
         self._loss_out = None
         self._loss_consts = None      # device copies of a custom loss's climatology / latitude weights
+        self._params_dirty = False    # set by Model.set_weights / load: replicas re-align at the next collective step
+        self.sync_parameters()
+
+    # -- replicas ------------------------------------------------------------------------------------------------------ #
+    def sync_parameters(self):
+        """Data parallel: every replica takes rank 0's parameters (and optimizer state).  Layers draw their initial
+        weights from per-process random streams, so without this the replicas would apply the same summed gradient to
+        different weights (keras.utils.multi_gpu_model has ONE weight set by construction, models.py:104-109)."""
+        dp = self.dp
+        self._params_dirty = False
+        if dp is None or dp.world <= 1:
+            return
+        dp.broadcast_(self.flat_params)
+        if self.opt_state is not None:
+            for t in self.opt_state:
+                dp.broadcast_(t)
 
     # -- helpers ------------------------------------------------------------------------------------------------------ #
     def _grad_view(self, layer, name):
@@ -225,18 +245,18 @@ class Trainer(object):
             tot += l2 * float(torch.dot(w, w))
         return tot
 
-    def _report(self, loss_vals):
-        """[loss, (per-output losses), metrics...] as python floats from the device loss table."""
+    def _report(self, loss_vals, reg=None):
+        """[loss, (per-output losses), metrics...] as python floats from the device loss table; reg: the kernel
+        regularisers' penalty that belongs to it (None: at the current weights)."""
         v = loss_vals.detach().cpu().numpy().astype(np.float64)
-        return self._report_from(v)
+        return self._report_from(v, reg)
 
-    def _report_from(self, v):
+    def _report_from(self, v, reg=None):
         n_out = v.shape[0]
         if self.loss_kind == 'custom':
             per_out = [float(self.model.loss.scale * v[o, 0]) for o in range(n_out)]
         else:
             per_out = [float(v[o, 1]) for o in range(n_out)]
-        reg = getattr(self, '_reg_at_step', None)
         total = float(sum(w * l for w, l in zip(self.loss_weights, per_out))) + (self._regularizer_loss() if reg is None else reg)
         col = {'mean_squared_error': 1, 'mean_absolute_error': 2}
         if n_out == 1:
@@ -482,39 +502,61 @@ class Trainer(object):
         opt.iterations += 1
 
     # -- public steps -------------------------------------------------------------------------------------------------- #
+    def _host_rows(self, a, lo, hi):
+        """rows [lo, hi) of a host array / device tensor WITHOUT touching the others (no upload of foreign rows)"""
+        return a[lo:hi]
+
     def train_on_batch(self, x, y, return_device=False):
-        """One optimisation step on a GLOBAL batch.  Under data parallelism every rank passes the same global batch and
-        trains on its own row shard; the reported loss is the global-batch value on every rank."""
-        x = self._to_device(x)
-        n_global = x.shape[0]
-        ys = self._targets(y, n_global)
-        scale = 1.0
+        """One optimisation step on a GLOBAL batch.  Under data parallelism every rank passes the same global batch (the
+        Keras contract: one script, run by every rank) and trains on its own row shard -- only those rows are uploaded;
+        the reported loss is the global-batch value on every rank.  Loaders that hold only the local rows call
+        train_on_shard."""
+        n_global = int(x.shape[0])
         dp = self.dp
         if dp is not None and dp.world > 1:
             lo, hi = dp.shard(n_global)
-            x = x[lo:hi].contiguous()
-            ys = [t[lo:hi].contiguous() for t in ys]
-            # local means are averaged over ranks: weight each by its share so ragged shards stay exact
-            scale = (hi - lo) * dp.world / float(n_global)
-        outs, loss_vals, dys = self._forward_loss(x, ys, True, scale)
-        self._backward(x, outs, dys)
-        self._add_regularizer_gradients()
-        self._reg_at_step = self._regularizer_loss()      # Keras reports the penalty at the weights the step started from
-        if dp is not None and dp.world > 1:
-            dp.all_reduce_sum_(self.flat_grads)
+            ys = list(y) if isinstance(y, (list, tuple)) else [y]
+            x = self._host_rows(x, lo, hi)
+            ys = [self._host_rows(t, lo, hi) for t in ys]
+            return self.train_on_shard(x, ys if isinstance(y, (list, tuple)) else ys[0], n_global, return_device)
+        return self.train_on_shard(x, y, n_global, return_device)
+
+    def train_on_shard(self, x, y, n_global, return_device=False):
+        """One optimisation step given THIS RANK's rows of a global batch of n_global samples (all of them when not data
+        parallel).  Collective under data parallelism: every rank must call it, also with zero rows."""
+        from . import ops
+        x = self._to_device(x)
+        n_local = int(x.shape[0])
+        dp = self.dp if (self.dp is not None and self.dp.world > 1) else None
+        if dp is None and n_local != int(n_global):
+            raise ValueError('%d rows given for a batch of %d without data parallelism' % (n_local, n_global))
+        if dp is not None and self._params_dirty:
+            self.sync_parameters()
+        # local means are averaged over ranks: weight each by its share so ragged shards stay exact
+        scale = 1.0 if dp is None else n_local * dp.world / float(n_global)
+        if n_local > 0:
+            ys = self._targets(y, n_local)
+            outs, loss_vals, dys = self._forward_loss(x, ys, True, scale)
+            self._backward(x, outs, dys)
+            self._add_regularizer_gradients()
+        else:                               # a rank without rows still takes part in the exchange
+            self._flat_exchange.zero_()
+            loss_vals = None
+        reg = self._regularizer_loss()      # Keras reports the penalty at the weights the step started from
+        if dp is not None:
+            if loss_vals is not None:
+                ops.axpby(loss_vals.view(-1), self._loss_tail.view(-1), scale, 0.0)
+            dp.all_reduce_sum_(self._flat_exchange)        # gradients and loss table: one collective
             self._apply(1.0 / dp.world)
-            loss_vals = dp.mean_loss(loss_vals * scale)
+            loss_vals = self._loss_tail
+            ops.axpby(loss_vals.view(-1), loss_vals.view(-1), 0.0, 1.0 / dp.world)
         else:
             self._apply(1.0)
         if return_device:
-            return loss_vals
-        try:
-            return self._report(loss_vals)
-        finally:
-            self._reg_at_step = None
+            return loss_vals, reg
+        return self._report(loss_vals, reg)
 
     def test_on_batch(self, x, y):
-        self._reg_at_step = None
         x = self._to_device(x)
         ys = self._targets(y, x.shape[0])
         _, loss_vals, _ = self._forward_loss(x, ys, False)
@@ -552,21 +594,23 @@ class Trainer(object):
             sums = None
             seen = 0
             pending = []
-            for bi, (X, y) in enumerate(batches_fn(epoch)):
-                self._call(cbs, 'on_batch_begin', bi, {'batch': bi, 'size': int(X.shape[0])})
-                lv = self.train_on_batch(X, y, return_device=True).clone()
-                pending.append((lv, int(X.shape[0])))
+            for bi, (X, y, n_glob) in enumerate(batches_fn(epoch)):      # X, y: this rank's rows of a batch of n_glob
+                self._call(cbs, 'on_batch_begin', bi, {'batch': bi, 'size': n_glob})
+                lv, reg = self.train_on_shard(X, y, n_glob, return_device=True)
+                pending.append((lv.clone(), n_glob, reg))
                 # convert lazily: one host sync per epoch unless a callback wants per-batch logs
                 if any(getattr(type(c), 'on_batch_end', Callback.on_batch_end) is not Callback.on_batch_end
                        for c in cbs if isinstance(c, Callback)) or any(not isinstance(c, Callback) for c in cbs):
-                    vals = self._report(lv)
-                    self._call(cbs, 'on_batch_end', bi, dict(zip(self.metrics_names, vals), batch=bi, size=int(X.shape[0])))
+                    vals = self._report(lv, reg)
+                    self._call(cbs, 'on_batch_end', bi, dict(zip(self.metrics_names, vals), batch=bi, size=n_glob))
                 if self.model.stop_training:
                     break
-            for lv, bs in pending:
-                vals = np.asarray(self._report(lv), dtype=np.float64)
-                sums = vals * bs if sums is None else sums + vals * bs
-                seen += bs
+            if pending:                  # one device-to-host copy for the whole epoch's loss tables
+                tables = torch.stack([lv for lv, _, _ in pending]).cpu().numpy().astype(np.float64)
+                for tab, (_, bs, reg) in zip(tables, pending):
+                    vals = np.asarray(self._report_from(tab, reg), dtype=np.float64)
+                    sums = vals * bs if sums is None else sums + vals * bs
+                    seen += bs
             logs = dict(zip(self.metrics_names, (sums / max(seen, 1)).tolist())) if sums is not None else {}
             if validate_fn is not None:
                 vvals = validate_fn()
@@ -611,18 +655,26 @@ class Trainer(object):
         ys = list(y) if isinstance(y, (list, tuple)) else [y]
         x, ys, resident = self._make_resident(x, ys)
 
+        dp = self.dp if (self.dp is not None and self.dp.world > 1) else None
+
         def batches(epoch):
             idx = np.arange(n)
             if shuffle:
                 np.random.shuffle(idx)
+            if dp is not None:             # one shuffle for all replicas: rank 0's
+                idx = dp.broadcast_indices(idx)
             for lo in range(0, n, batch_size):
                 sel = idx[lo:lo + batch_size]
+                n_glob = len(sel)
+                if dp is not None:         # this rank's rows of the global batch; nothing else is gathered or uploaded
+                    a, b = dp.shard(n_glob)
+                    sel = sel[a:b]
                 if resident:           # the batch is gathered in HBM: no host copy, no PCIe transfer per step
-                    sel = torch.from_numpy(sel).to(self.device)
+                    sel = torch.from_numpy(np.ascontiguousarray(sel)).to(self.device)
                     yield x.index_select(0, sel), ([t.index_select(0, sel) for t in ys] if len(ys) > 1
-                                                   else ys[0].index_select(0, sel))
+                                                   else ys[0].index_select(0, sel)), n_glob
                 else:
-                    yield x[sel], ([t[sel] for t in ys] if len(ys) > 1 else ys[0][sel])
+                    yield x[sel], ([t[sel] for t in ys] if len(ys) > 1 else ys[0][sel]), n_glob
 
         val = None
         if validation_data is not None:
@@ -639,14 +691,22 @@ class Trainer(object):
         from .model.generators import DeviceLoader
         steps = int(steps_per_epoch) if steps_per_epoch is not None else len(generator)
 
+        dp = self.dp if (self.dp is not None and self.dp.world > 1) else None
+        shard = None if dp is None else (dp.rank, dp.world)
+
         def batches(epoch):
             order = list(range(steps))
-            if self.device.type == 'cuda':
-                for X, y in DeviceLoader(generator, self.device, order=order):
-                    yield X, y
+            if dp is not None and hasattr(generator, '_indices'):
+                # the generators shuffle with the process-global numpy RandomState (reference generators.py:103-106):
+                # replicas must cut THE SAME batch i, so every rank takes rank 0's index list for this epoch
+                generator._indices = dp.broadcast_indices(generator._indices)
+            if self.device.type == 'cuda' or shard is not None:
+                for X, y, n_glob in DeviceLoader(generator, self.device, order=order, shard=shard).iter_batches():
+                    yield X, y, n_glob
             else:
                 for i in order:
-                    yield generator[i]
+                    X, y = generator[i]
+                    yield X, y, int(X.shape[0])
 
         def end():
             if hasattr(generator, 'on_epoch_end'):
@@ -676,7 +736,8 @@ class Trainer(object):
 
     def evaluate(self, x, y, batch_size=None, verbose=1, as_list=False):
         batch_size = int(batch_size or 32)
-        batch_size = max(batch_size, 256)        # the result does not depend on it; larger chunks fill the GPU
+        if self.loss_kind != 'custom':           # per-element means do not depend on it; larger chunks fill the GPU.
+            batch_size = max(batch_size, 256)    # The anomaly-correlation loss is a whole-batch statistic: keep Keras' batches
         n = x.shape[0]
         ys = list(y) if isinstance(y, (list, tuple)) else [y]
         sums, seen = None, 0

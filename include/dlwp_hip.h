@@ -8,7 +8,7 @@
  *
  * Conventions
  *   - every function returns int: 0 ok, DLWP_EINVAL (-1) bad argument, DLWP_EUNSUPPORTED (-2), DLWP_EHIP (-3) HIP
- *     runtime error; dlwp_last_error() returns a thread-local message for the last non-zero return.
+ *     runtime error, DLWP_ERCCL (-4) RCCL error; dlwp_last_error() returns a thread-local message for the last non-zero return.
  *   - all tensor pointers are CALLER-OWNED DEVICE memory (e.g. torch-ROCm storage), dense, row-major, NCHW unless
  *     stated; the library never allocates, frees or retains them (rollout objects excepted: buffers captured in a
  *     rollout graph must outlive it).
@@ -35,6 +35,7 @@ extern "C" {
 #define DLWP_EINVAL       (-1)
 #define DLWP_EUNSUPPORTED (-2)
 #define DLWP_EHIP         (-3)
+#define DLWP_ERCCL        (-4)
 
 #define DLWP_F32  0
 #define DLWP_BF16 1
@@ -297,6 +298,24 @@ int dlwp_rollout_create(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* con
                         dlwp_rollout_t* out);
 int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
 int dlwp_rollout_destroy(dlwp_rollout_t);
+
+/* ---- data parallel training: replaces keras.utils.multi_gpu_model (DLWP/model/models.py:104-109, 365-372; batch =
+ *      n_gpu x batch, Azure/train_tf.py:163-164).  One process per GPU; every rank holds the whole (< 1 MB) weight set and
+ *      trains on its rows of the global batch; the ONE flat fp32 gradient buffer is summed by ONE RCCL all-reduce over
+ *      xGMI per step, enqueued on the training stream right behind the last weight-gradient kernel, and dlwp_adam_keras
+ *      (grad_scale = 1/world) consumes it on the same stream.  RCCL is bound with dlopen at the first dlwp_comm_* call
+ *      (the process' already-loaded librccl.so.1 if there is one), so single-GPU use never touches it.
+ *      dlwp_comm_unique_id: id == NULL -> *id_bytes = size needed (128); otherwise rank 0 fills id and the CALLER ships
+ *      the bytes to the other ranks (any channel: the launcher's TCP store, MPI, a file).  dlwp_comm_init_rank is
+ *      collective over all `world` ranks; `device` is the HIP device of the calling rank.  Buffers are device memory;
+ *      both collectives are in place and asynchronous on `stream`.                                                    */
+typedef struct dlwp_comm* dlwp_comm_t;
+int dlwp_comm_unique_id(void* id, size_t* id_bytes);
+int dlwp_comm_init_rank(dlwp_comm_t* comm, int device, int world, int rank, const void* unique_id, size_t id_bytes);
+int dlwp_comm_info(dlwp_comm_t, int* world, int* rank, int* rccl_version);
+int dlwp_allreduce_sum_f32(dlwp_comm_t, void* flat, size_t n, void* stream);
+int dlwp_broadcast_f32(dlwp_comm_t, void* flat, size_t n, int root, void* stream);   /* replicas start identical */
+int dlwp_comm_destroy(dlwp_comm_t);
 
 #ifdef __cplusplus
 }

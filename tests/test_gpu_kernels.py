@@ -184,7 +184,7 @@ CASES = [
 @pytest.mark.parametrize('case', CASES)
 def test_conv2d_fused_vs_float64_oracle(ops, case):
     n, cin, h, w, cout, k, dil, pads, mh, mw, act, src = case
-    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    rng = np.random.default_rng(1000 + CASES.index(case))      # fixed per case: a failure reproduces with the same inputs
     x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
     wt = np_ref.glorot_uniform((k, k, cin, cout), rng)
     b = (0.1 * rng.standard_normal(cout)).astype(np.float32)

@@ -59,8 +59,11 @@ def _worker(rank, world, port, n_global, ret):
     full, full_loss = grads_of(x, y, 1.0)
     b = torch.full((3,), float(rank))
     dp.broadcast_(b, src=0)
+    # the epoch's shuffle: every rank draws its own permutation, all must leave with rank 0's
+    perm = dp.broadcast_indices(np.random.RandomState(100 + rank).permutation(11))
     ret[rank] = {'shard': (lo, hi), 'err': float((flat - full).abs().max()), 'gmax': float(full.abs().max()),
-                 'loss_err': abs(float(loss[0]) - full_loss), 'bcast': b.tolist()}
+                 'loss_err': abs(float(loss[0]) - full_loss), 'bcast': b.tolist(), 'perm': perm.tolist(),
+                 'rccl_abi': dp.uses_rccl_abi()}
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -84,6 +87,8 @@ def test_gloo_world2_dp_step_equals_single_process_step(n_global):
         assert res[r]['err'] <= 1e-12 * max(1.0, res[r]['gmax']), res[r]
         assert res[r]['loss_err'] < 1e-12
         assert res[r]['bcast'] == [0.0, 0.0, 0.0]
+        assert res[r]['perm'] == np.random.RandomState(100).permutation(11).tolist()
+        assert res[r]['rccl_abi'] is False          # gloo group: collectives stay in torch.distributed
 
 
 def test_shard_bounds_partition_rows_exactly():
@@ -132,3 +137,81 @@ def test_device_loader_host_path_preserves_order_and_content():
             return gen[i]
     with pytest.raises(KeyError):
         list(DeviceLoader(Boom(), torch.device('cpu')))
+
+
+def test_device_loader_rank_shards_partition_every_global_batch():
+    """The data-parallel feed: rank r of w gathers ONLY rows shard_bounds(n_batch, r, w) of global batch i, in the
+    generator's own (shuffled) sample order; the shards of all ranks concatenate to the batch a single process sees."""
+    from dlwp_amd.model import ArrayDataset, DataGenerator, DLWPNeuralNet
+    from dlwp_amd.model.generators import DeviceLoader
+    from dlwp_amd.parallel import shard_bounds
+    rng = np.random.default_rng(3)
+    P = rng.standard_normal((23, 2, 2, 5, 6)).astype(np.float32)
+    T = rng.standard_normal((23, 2, 2, 5, 6)).astype(np.float32)
+    d = DLWPNeuralNet(is_convolutional=True, time_dim=2, scaler_type=None, scale_targets=False)
+    np.random.seed(5)
+    gen = DataGenerator(d, ArrayDataset(P, T), batch_size=8, shuffle=True)
+    gathered = []
+    orig = gen.generate
+
+    def spy(samples, *a, **k):
+        gathered.append(len(samples))
+        return orig(samples, *a, **k)
+    for world in (2, 3):
+        parts = []
+        for rank in range(world):
+            gen.generate = spy
+            rows = [(X.clone().numpy(), y.clone().numpy(), n)
+                    for X, y, n in DeviceLoader(gen, torch.device('cpu'), shard=(rank, world)).iter_batches()]
+            gen.generate = orig
+            parts.append(rows)
+        assert max(gathered) <= -(-8 // world)          # no rank ever gathered more than its share of a batch
+        del gathered[:]
+        for i in range(len(gen)):
+            Xf, yf = gen[i]
+            assert all(parts[r][i][2] == Xf.shape[0] for r in range(world))
+            assert np.array_equal(np.concatenate([parts[r][i][0] for r in range(world)]), Xf)
+            assert np.array_equal(np.concatenate([parts[r][i][1] for r in range(world)]), yf)
+            for r in range(world):
+                lo, hi = shard_bounds(Xf.shape[0], r, world)
+                assert parts[r][i][0].shape[0] == hi - lo
+
+
+def test_device_loader_list_targets_and_empty_shards():
+    """Multi-output generators (SeriesDataGenerator(sequence=K)) hand a LIST of target arrays: each is staged on its own
+    and comes out as a list.  A rank whose shard of a short batch is empty gets zero-row tensors of the right shape."""
+    from dlwp_amd.model.generators import DeviceLoader
+
+    class Seq(object):
+        _batch_size = 4
+
+        def __init__(self, n):
+            self._indices = np.arange(n)[::-1].copy()
+            self.data = np.arange(n * 6, dtype=np.float32).reshape(n, 2, 3)
+
+        def __len__(self):
+            return -(-len(self._indices) // self._batch_size)
+
+        def generate(self, samples):
+            assert len(samples) > 0
+            x = self.data[np.asarray(samples)]
+            return x, [x + 1, x * 2, x - 3]
+
+        def __getitem__(self, i):
+            return self.generate(self._indices[i * 4:(i + 1) * 4])
+    gen = Seq(9)                                      # batches of 4, 4, 1
+    whole = list(DeviceLoader(gen, torch.device('cpu')))
+    assert len(whole) == 3 and isinstance(whole[0][1], list) and len(whole[0][1]) == 3
+    for world in (2, 3):
+        for i in range(3):
+            Xs, ys = [], [[], [], []]
+            for rank in range(world):
+                X, y, n = list(DeviceLoader(gen, torch.device('cpu'), order=[i], shard=(rank, world)).iter_batches())[0]
+                assert n == gen[i][0].shape[0] and isinstance(y, list) and len(y) == 3
+                assert tuple(X.shape[1:]) == (2, 3) and all(tuple(t.shape) == tuple(X.shape) for t in y)
+                Xs.append(X.clone().numpy())
+                for k in range(3):
+                    ys[k].append(y[k].clone().numpy())
+            assert np.array_equal(np.concatenate(Xs), gen[i][0])
+            for k in range(3):
+                assert np.array_equal(np.concatenate(ys[k]), gen[i][1][k])
