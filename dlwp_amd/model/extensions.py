@@ -5,7 +5,9 @@ It steps a model forward over EVERY sample of a generator, feeding predictions b
 inputs and outputs need not coincide (variable / level selection, fewer output than input time steps, an insolation
 input channel that is known analytically).  The reference expresses the feedback with xarray label arithmetic
 (`reindex`, `.loc[...] = ...`); xarray is absent from this image, so the same bookkeeping is restated on plain index
-arithmetic -- PARITY UNPINNED (nothing of the reference's version can be executed here).  What it reduces to, with
+arithmetic.  Pinned by tests/golden/estimator.npz: the reference's own predict() run by oracle/make_golden.py under a
+numpy-backed stub of the xarray calls it makes (13 cases: same / fewer / more output steps, variable selections,
+insolation, interval, impute, keep_time_dim, varlev datasets).  What it reduces to, with
 k = es + interval - 1 series steps covered per model call:
 
     p_{s+1}[i] = p_s[i + k]              rows re-indexed to the later start time; the last k rows run out of data (NaN,
@@ -120,13 +122,12 @@ class TimeSeriesEstimator(object):
                                                       **kwargs).reshape((-1,) + t_shape)[:effective_steps]
         elif same_io and not impute:
             # every input channel and time step is replaced by the prediction: the plain autoregressive rollout, which
-            # DLWPNeuralNet.predict_timeseries keeps on the device (one hipGraph).  Rows whose inputs would run past the
-            # end of the data are blanked afterwards, as the re-indexing does step by step in the general case.
+            # DLWPNeuralNet.predict_timeseries keeps on the device (one hipGraph).  The reference's re-indexing blanks the
+            # rows past the end of the data and then overwrites ALL of them with the forecast (extensions.py:214-240), so
+            # every row stays finite at every lead -- pinned by tests/golden/estimator.npz ('same', 'varlev_same').
             series = self.model.predict_timeseries(p.reshape(p_shape), effective_steps * self.model.time_dim,
                                                    keep_time_dim=True, **kwargs)
             result[:] = np.asarray(series).reshape((effective_steps,) + t_shape)
-            for s in range(1, effective_steps):
-                result[s, max(n - s * k, 0):] = np.nan
         else:
             sample_now = sample_coord.copy()
             for s in range(effective_steps):
@@ -175,10 +176,14 @@ class TimeSeriesEstimator(object):
         if lat is not None:
             coords['lat'], coords['lon'] = lat, lon
         if not self._uses_varlev:
-            var, lev = self._output_sel['variable'], self._output_sel['level']
+            # the reference unstacks a pandas MultiIndex.from_product((variable, level)) (extensions.py:298-302): the new
+            # coordinates are the index LEVELS, i.e. the labels in sorted order, not in selection order
+            var, lev = np.asarray(self._output_sel['variable']), np.asarray(self._output_sel['level'])
             ax = dims.index('varlev')
             result = result.reshape(result.shape[:ax] + (len(var), len(lev)) + result.shape[ax + 1:])
+            vo, lo = np.argsort(var, kind='stable'), np.argsort(lev, kind='stable')
+            result = np.take(np.take(result, vo, axis=ax), lo, axis=ax + 1)
             dims = dims[:ax] + ['variable', 'level'] + dims[ax + 1:]
             coords.pop('varlev')
-            coords.update({'variable': np.asarray(var), 'level': np.asarray(lev)})
+            coords.update({'variable': var[vo], 'level': lev[lo]})
         return LabeledArray(result, coords, tuple(dims))

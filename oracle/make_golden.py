@@ -146,19 +146,83 @@ def _install_stubs():
     mod('netCDF4', default_fillvals={'f4': 9.969209968386869e+36})
 
 
+class _Coord(np.ndarray):
+    """A coordinate variable: a 1-d ndarray that also answers `.values`; picking one element gives a _Scalar (the 0-d
+    DataArray xarray returns), so `ds['sample'][1] - ds['sample'][0]` has `.values` and scales by integers
+    (reference extensions.py:51, 257-262)."""
+
+    def __new__(cls, a):
+        return np.asarray(a).view(cls)
+
+    @property
+    def values(self):
+        return np.asarray(self)
+
+    def __getitem__(self, i):
+        r = np.ndarray.__getitem__(self, i)
+        return r if isinstance(r, np.ndarray) else _Scalar(r)
+
+
+class _Scalar(object):
+    """0-d coordinate value (datetime64 / timedelta64): `.values`, +, -, * with numbers, arrays and coordinates."""
+    __array_ufunc__ = None            # numpy defers to the reflected operators below
+
+    def __init__(self, v):
+        self.values = v.values if isinstance(v, _Scalar) else v
+
+    @staticmethod
+    def _raw(o):
+        return o.values if isinstance(o, (_Scalar, _Coord)) else o
+
+    @staticmethod
+    def _wrap(v):
+        return _Coord(v) if isinstance(v, np.ndarray) and v.ndim > 0 else _Scalar(v)
+
+    def __add__(self, o):
+        return self._wrap(self.values + self._raw(o))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._wrap(self.values - self._raw(o))
+
+    def __rsub__(self, o):
+        return self._wrap(self._raw(o) - self.values)
+
+    def __mul__(self, o):
+        return self._wrap(self.values * self._raw(o))
+
+    __rmul__ = __mul__
+
+
+def _plain(c):
+    """coordinate given as _Coord / FakeDataArray / range / list -> plain ndarray"""
+    if isinstance(c, FakeDataArray):
+        return np.asarray(c.values)
+    if isinstance(c, (_Coord, _Scalar)):
+        return np.asarray(c.values)
+    return np.asarray(list(c)) if isinstance(c, range) else np.asarray(c)
+
+
 class FakeDataArray(object):
-    """What the reference's SeriesDataGenerator touches of an xarray DataArray: values / shape, label selection on named
-    dimensions (.sel), .isel(time_step=-1), .load(), and the coordinate variables .sample / .lat / .lon (each with
-    .values).  Also the constructor form xr.DataArray(values, coords=..., dims=...) (generators.py:418-422)."""
+    """What the reference touches of an xarray DataArray.  SeriesDataGenerator (generators.py:323-629): values / shape,
+    label selection on named dimensions (.sel), .isel(time_step=-1), .load(), the coordinate variables .sample / .lat /
+    .lon (each with .values), and the constructor xr.DataArray(values, coords=..., dims=...).  TimeSeriesEstimator.predict
+    (extensions.py:136-303) on top of that: coords given as a LIST aligned with dims, positional [...] get / set (views
+    into the same memory, as numpy basic indexing gives xarray), .loc[{dim: label | labels}] get / set, .reindex(sample=
+    new labels) (rows without a match become NaN), .isel(dim=slice), .assign_coords(varlev=MultiIndex) + .unstack('varlev')
+    (new coordinates = the MultiIndex LEVELS, i.e. sorted, missing combinations NaN) and .transpose(*dims)."""
 
     def __init__(self, values, coords=None, dims=None):
-        self.values = np.asarray(values)
+        self.values = values if isinstance(values, np.ndarray) else np.asarray(values)
         self.dims = tuple(dims)
-        self.coords = {k: (v.values if isinstance(v, FakeDataArray._Coord) else np.asarray(v)) for k, v in coords.items()}
-
-    class _Coord(object):
-        def __init__(self, values):
-            self.values = values
+        if isinstance(coords, dict):
+            self.coords = {k: (v if type(v).__name__ == 'MultiIndex' else _plain(v)) for k, v in coords.items()}
+        else:
+            self.coords = {d: _plain(c) for d, c in zip(self.dims, coords)}
+        for d in self.dims:
+            if d in self.coords and type(self.coords[d]).__name__ != 'MultiIndex':
+                assert len(self.coords[d]) == self.values.shape[self.dims.index(d)], (d, self.values.shape)
 
     @property
     def shape(self):
@@ -167,7 +231,7 @@ class FakeDataArray(object):
     def __getattr__(self, name):
         coords = self.__dict__.get('coords', {})
         if name in coords:
-            return FakeDataArray._Coord(coords[name])
+            return _Coord(coords[name])
         raise AttributeError(name)
 
     def load(self):
@@ -188,17 +252,134 @@ class FakeDataArray(object):
         out = self
         for dim, i in isel.items():
             ax = out.dims.index(dim)
-            coords = {k: v for k, v in out.coords.items() if k != dim}
-            out = FakeDataArray(np.take(out.values, i, axis=ax), coords, tuple(d for d in out.dims if d != dim))
+            if isinstance(i, slice):
+                coords = dict(out.coords)
+                coords[dim] = coords[dim][i]
+                out = FakeDataArray(out.values[(slice(None),) * ax + (i,)], coords, out.dims)
+            else:
+                coords = {k: v for k, v in out.coords.items() if k != dim}
+                out = FakeDataArray(np.take(out.values, i, axis=ax), coords, tuple(d for d in out.dims if d != dim))
         return out
+
+    # -- positional access: views, as xarray over numpy basic indexing ------------------------------------------------- #
+    def __getitem__(self, key):
+        key = key if isinstance(key, tuple) else (key,)
+        key = key + (slice(None),) * (len(self.dims) - len(key))
+        coords, dims = {}, []
+        for d, k in zip(self.dims, key):
+            if isinstance(k, slice):
+                dims.append(d)
+                if d in self.coords:
+                    coords[d] = self.coords[d][k]
+            else:
+                assert isinstance(k, (int, np.integer)), 'positional lists are not needed by the reference'
+        return FakeDataArray(self.values[key], coords, dims)
+
+    def __setitem__(self, key, value):
+        self.values[key] = _plain(value)
+
+    # -- label access -------------------------------------------------------------------------------------------------- #
+    class _Loc(object):
+        def __init__(self, da):
+            self.da = da
+
+        def _index(self, sel):
+            """per dimension: int (scalar label), list of ints (label list) or slice(None)"""
+            da, out = self.da, []
+            for d in da.dims:
+                if d not in sel:
+                    out.append(slice(None))
+                    continue
+                lab = sel[d]
+                have = list(da.coords[d])
+                if isinstance(lab, (_Coord, FakeDataArray, np.ndarray, list, tuple)) and np.ndim(_plain(lab)) > 0:
+                    out.append([have.index(l) for l in _plain(lab)])
+                else:
+                    out.append(have.index(_plain(lab)[()] if isinstance(lab, (np.ndarray, _Scalar)) else lab))
+            return out
+
+        def __getitem__(self, sel):
+            da, idx = self.da, self._index(sel)
+            if all(not isinstance(i, list) for i in idx):        # scalars only: a VIEW (so `.loc[..][..] = v` lands)
+                coords = {d: da.coords[d] for d, i in zip(da.dims, idx) if isinstance(i, slice) and d in da.coords}
+                return FakeDataArray(da.values[tuple(idx)], coords, [d for d, i in zip(da.dims, idx) if isinstance(i, slice)])
+            vals, coords, dims = da.values, {}, []
+            for ax in range(len(da.dims) - 1, -1, -1):            # right to left so that axes keep their numbers
+                i = idx[ax]
+                if not isinstance(i, slice):
+                    vals = np.take(vals, i, axis=ax)
+            for d, i in zip(da.dims, idx):
+                if isinstance(i, int):
+                    continue
+                dims.append(d)
+                if d in da.coords:
+                    coords[d] = da.coords[d][i] if isinstance(i, list) else da.coords[d]
+            return FakeDataArray(vals, coords, dims)
+
+        def __setitem__(self, sel, value):
+            da, idx = self.da, self._index(sel)
+            mesh = np.ix_(*[np.arange(n) if isinstance(i, slice) else np.atleast_1d(i) for i, n in zip(idx, da.values.shape)])
+            block = tuple(n if isinstance(i, slice) else len(np.atleast_1d(i)) for i, n in zip(idx, da.values.shape))
+            v = _plain(value)           # positional, as xarray assigns once the coordinates are consistent
+            da.values[mesh] = v.reshape(block) if v.size == int(np.prod(block)) else np.broadcast_to(v, block)
+
+    @property
+    def loc(self):
+        return FakeDataArray._Loc(self)
+
+    def reindex(self, sample=None, method=None):
+        assert method is None and self.dims[0] == 'sample'
+        new = _plain(sample)
+        have = {k: i for i, k in enumerate(self.coords['sample'].tolist())}
+        vals = np.full((len(new),) + self.values.shape[1:], np.nan, dtype=self.values.dtype)
+        for r, lab in enumerate(new.tolist()):
+            if lab in have:
+                vals[r] = self.values[have[lab]]
+        coords = dict(self.coords)
+        coords['sample'] = new
+        return FakeDataArray(vals, coords, self.dims)
+
+    def assign_coords(self, **kw):
+        coords = dict(self.coords)
+        coords.update(kw)
+        return FakeDataArray(self.values, coords, self.dims)
+
+    def unstack(self, dim):
+        mi = self.coords[dim]
+        ax = self.dims.index(dim)
+        l0, l1 = [np.asarray(l) for l in mi.levels]
+        c0, c1 = [np.asarray(c) for c in mi.codes]
+        shape = self.values.shape[:ax] + (len(l0), len(l1)) + self.values.shape[ax + 1:]
+        vals = np.full(shape, np.nan, dtype=self.values.dtype)
+        for j in range(self.values.shape[ax]):
+            vals[(slice(None),) * ax + (c0[j], c1[j])] = np.take(self.values, j, axis=ax)
+        coords = {k: v for k, v in self.coords.items() if k != dim}
+        coords[mi.names[0]], coords[mi.names[1]] = l0, l1
+        return FakeDataArray(vals, coords, self.dims[:ax] + (mi.names[0], mi.names[1]) + self.dims[ax + 1:])
+
+    def transpose(self, *dims):
+        perm = [self.dims.index(d) for d in dims]
+        return FakeDataArray(self.values.transpose(perm), self.coords, dims)
 
 
 class FakeSeriesDS(object):
-    """Dataset with the single variable 'predictors' (a continuous time series) the SeriesDataGenerator expects."""
+    """Dataset with the single variable 'predictors' (a continuous time series) the SeriesDataGenerator expects; for
+    TimeSeriesEstimator also .variables, .coords, ds['sample'] and the coordinate attributes .sample / .lat / .lon."""
 
     def __init__(self, da):
         self.predictors = da
         self.dims = dict(zip(da.dims, da.shape))
+        self.variables = {'predictors': da}
+        self.coords = {k: _Coord(v) for k, v in da.coords.items()}
+
+    def __getitem__(self, name):
+        return _Coord(self.predictors.coords[name])
+
+    def __getattr__(self, name):
+        da = self.__dict__.get('predictors')
+        if da is not None and name in da.coords:
+            return _Coord(da.coords[name])
+        raise AttributeError(name)
 
     def load(self):
         return self
@@ -455,6 +636,47 @@ def main():
         if not isinstance(ya, list):
             ser['%s_yall' % tag] = ya
     np.savez_compressed(os.path.join(OUT, 'series.npz'), **ser)
+
+    # ----- TimeSeriesEstimator.predict (extensions.py:136-303) under the xarray stub ---------------------------------- #
+    from DLWP.model.extensions import TimeSeriesEstimator
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import estimator_cases as EC
+    est = {}
+
+    def varlev_ds():
+        labels = np.array(['%s/%d' % (v, l) for v in ('z', 't') for l in (500, 850)])
+        da = FakeDataArray(S.reshape(n_t, 4, 6, 8).copy(), {'sample': dates.values, 'varlev': labels, 'lat': lat.copy(),
+                                                           'lon': lon.copy()}, ('sample', 'varlev', 'lat', 'lon'))
+        return FakeSeriesDS(da)
+
+    def run_case(tag, case, make_ds):
+        kw = case['gen']
+        m = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=kw['input_time_steps'], scaler_type=None,
+                          scale_targets=False)
+        g = SeriesDataGenerator(m, make_ds(), **kw)
+        c_in, c_out = int(g.convolution_shape[0]), int(g.output_convolution_shape[0])
+        m.model = types.SimpleNamespace(predict=EC.mixing_model(c_in, c_out))
+        with __import__('warnings').catch_warnings():
+            __import__('warnings').simplefilter('ignore')
+            out = TimeSeriesEstimator(m, g).predict(**case['predict'])
+        est['%s_values' % tag] = np.asarray(out.values, dtype=np.float32)
+        est['%s_dims' % tag] = np.array(list(out.dims))
+        for d in out.dims:
+            c = np.asarray(out.coords[d])
+            if c.dtype.kind == 'M':
+                c = c.astype('datetime64[s]').astype(np.int64)
+            elif c.dtype.kind == 'm':
+                c = c.astype('timedelta64[s]').astype(np.int64)
+            elif c.dtype.kind == 'O':
+                c = np.array([str(v) for v in c])
+            est['%s_coord_%s' % (tag, d)] = c
+        est['%s_channels' % tag] = np.asarray([c_in, c_out], dtype=np.int64)
+
+    for tag, case in EC.CASES.items():
+        run_case(tag, case, series_ds)
+    for tag, case in EC.VARLEV_CASES.items():
+        run_case(tag, case, varlev_ds)
+    np.savez_compressed(os.path.join(OUT, 'estimator.npz'), **est)
 
     # ----- custom losses (numpy-K evaluation of the reference formulas) ----------------------------------------- #
     los = {}

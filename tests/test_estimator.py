@@ -1,6 +1,7 @@
-"""TimeSeriesEstimator (reference DLWP/model/extensions.py:21-303) on CPU with stub models whose forecasts can be written
-down by hand.  The reference's version needs xarray (absent): parity is unpinned; these tests pin the index arithmetic the
-restatement documents."""
+"""TimeSeriesEstimator (reference DLWP/model/extensions.py:21-303) on CPU.  Pinned: tests/golden/estimator.npz holds what
+the REFERENCE's own predict() returns for the cases of oracle/estimator_cases.py (oracle/make_golden.py executes it under a
+numpy-backed stub of the few xarray calls it makes); the parametrised test at the end compares values and coordinates.
+The tests in front of it use stub models whose forecasts can be written down by hand."""
 import types
 
 import numpy as np
@@ -41,15 +42,17 @@ def test_same_inputs_and_outputs_is_the_plain_autoregressive_rollout():
     assert np.array_equal(out.coords['f_hour'], DT * np.arange(1, 6))
     assert np.array_equal(out.coords['time'], DATES[:n] + DT)               # initialisation = last input time
     # sample i, lead f (in steps): the series value at time index i + 1 + f; z500 = 100 + index
+    # every row stays finite at every lead: the forecast overwrites all channels of all rows (the golden 'same' case pins
+    # this against the reference).  Variables come back in SORTED label order ('t' before 'z'), as xarray's unstack gives.
+    assert list(out.coords['variable']) == ['t', 'z'] and list(out.coords['level']) == [500, 850]
     for f in range(5):
-        valid = n - (f // 2) * 2                             # later calls run out of inputs for the last rows
         want = 100 + np.arange(n) + 1 + (f + 1)
-        got = out.values[f, :, 0, 0, 0, 0]
-        assert np.array_equal(got[:valid], want[:valid].astype(np.float32)) and np.isnan(got[valid:]).all()
-    # equals DLWPNeuralNet.predict_timeseries on the same inputs (where defined)
+        assert np.array_equal(out.values[f, :, 1, 0, 0, 0], want.astype(np.float32))        # z500
+        assert np.array_equal(out.values[f, :, 0, 1, 0, 0], (want + 110).astype(np.float32))  # t850 = 200 + 10 + index
+    # equals DLWPNeuralNet.predict_timeseries on the same inputs (selection order z, t -> sorted t, z)
     X, _ = g.generate([], scale_and_impute=False)
-    ser = d.predict_timeseries(X, 5)
-    assert np.array_equal(out.values[:5, :5].reshape(5, 5, 4, H, W), ser[:5, :5].reshape(5, 5, 4, H, W))
+    ser = d.predict_timeseries(X, 5)[:5].reshape(5, n, 2, 2, H, W)
+    assert np.array_equal(out.values, ser[:, :, ::-1])
     kept = est.predict(4, keep_time_dim=True)
     assert kept.dims == ('f_hour', 'time', 'time_step', 'variable', 'level', 'lat', 'lon') and kept.shape[0] == 2
     assert np.array_equal(kept.coords['f_hour'], np.array([DT, 3 * DT]))
@@ -119,3 +122,58 @@ def test_argument_checks():
         TimeSeriesEstimator(d, object())
     with pytest.raises(ValueError, match='positive integer'):
         TimeSeriesEstimator(d, g).predict(0)
+
+
+# ----------------------------------------------------------------------------------------------------------------- #
+# pinned: the reference's own TimeSeriesEstimator.predict, executed by oracle/make_golden.py under a numpy-backed xarray
+# stub (reindex / .loc / unstack semantics restated there), on the cases of oracle/estimator_cases.py
+# ----------------------------------------------------------------------------------------------------------------- #
+
+def _golden_dataset(series, varlev):
+    from dlwp_amd.model import SeriesDataset
+    S = series['S']
+    dates = series['dates'].astype('datetime64[s]')
+    lat, lon = series['lat'].copy(), series['lon'].copy()
+    if varlev:
+        labels = np.array(['%s/%d' % (v, l) for v in ('z', 't') for l in (500, 850)])
+        return SeriesDataset(S.reshape(S.shape[0], 4, 6, 8).copy(), {'sample': dates, 'varlev': labels, 'lat': lat, 'lon': lon},
+                             ('sample', 'varlev', 'lat', 'lon'))
+    return SeriesDataset(S.copy(), {'sample': dates, 'variable': np.array(['z', 't']), 'level': np.array([500, 850]),
+                                    'lat': lat, 'lon': lon}, ('sample', 'variable', 'level', 'lat', 'lon'))
+
+
+def _estimator_cases():
+    from oracle import estimator_cases as EC
+    return [(k, v, False) for k, v in EC.CASES.items()] + [(k, v, True) for k, v in EC.VARLEV_CASES.items()]
+
+
+@pytest.mark.parametrize('tag,case,varlev', _estimator_cases(), ids=[c[0] for c in _estimator_cases()])
+def test_predict_equals_the_reference_estimator(golden, tag, case, varlev):
+    import warnings
+    from oracle import estimator_cases as EC
+    g = golden('estimator')
+    kw = case['gen']
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=kw['input_time_steps'], scaler_type=None,
+                      scale_targets=False)
+    gen = SeriesDataGenerator(d, _golden_dataset(golden('series'), varlev), **kw)
+    c_in, c_out = [int(v) for v in g['%s_channels' % tag]]
+    assert (int(gen.convolution_shape[0]), int(gen.output_convolution_shape[0])) == (c_in, c_out)
+    d.model = types.SimpleNamespace(predict=EC.mixing_model(c_in, c_out))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out = TimeSeriesEstimator(d, gen).predict(**case['predict'])
+    want = g['%s_values' % tag]
+    assert list(out.dims) == [str(v) for v in g['%s_dims' % tag]]
+    assert out.values.dtype == np.float32 and out.values.shape == want.shape
+    assert np.array_equal(np.isnan(out.values), np.isnan(want))
+    assert np.allclose(out.values, want, rtol=0, atol=2e-6, equal_nan=True)       # einsum summation order only
+    for dim in out.dims:
+        c = np.asarray(out.coords[dim])
+        ref = g['%s_coord_%s' % (tag, dim)]
+        if c.dtype.kind == 'M':
+            c = c.astype('datetime64[s]').astype(np.int64)
+        elif c.dtype.kind == 'm':
+            c = c.astype('timedelta64[s]').astype(np.int64)
+        elif c.dtype.kind in 'OU':
+            c, ref = np.array([str(v) for v in c]), np.array([str(v) for v in ref])
+        assert np.array_equal(c, ref), dim
