@@ -7,19 +7,34 @@ Azure/train_tf.py:208-268 (4 -> 32 -> 64 -> 128 -> 64 -> 32 -> 4, 188 996 parame
 on the closed 88 x 180 grid (nominal 91 x 180 does not close under two 2x poolings), float32, built through
 DLWPNeuralNet.build_model from the reference's own (name, args, kwargs) triples; a 14-day rollout = 28 forwards x
 time_dim 2 = 56 six-hour steps per member.  One "step" of this benchmark = ONE such rollout of all members on this GPU =
-one hipGraph launch (168 fused conv kernels).  Members are sharded across ranks, no collective (weak scaling).
+one hipGraph launch.  Members are sharded across ranks, no collective (weak scaling).
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Prints one JSON line on rank 0.  `value` = members x 56 x K x N / wall  [6-h forecast steps / s], state resident in HBM.
-`roofline`: the dominant kernel of the forward (largest share of time), timed live with HIP events on the launch stream;
-`cpu_baseline`: the unfused torch-CPU restatement of the reference graph + its host rollout loop (oracle/torch_ref.py),
-timed on this node's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+Prints ONE JSON line on rank 0.
+  value      members x 56 x K x N / wall  [6-h forecast steps / s], state resident in HBM.
+  roofline   the kernel with the largest share of the forward's time (all its launches), timed live with HIP events on the
+             launch stream.  `achieved` / `frac` are the matrix-core FLOPs the kernel EXECUTES (dlwp_conv2d_launch_info:
+             the padded GEMM volume of its MFMA instructions == SQ_INSTS_MFMA x 2048 of a rocprofv3 --pmc pass) over the
+             fp32 MFMA peak -- never above 1.  `algorithmic_tflops` is the reference layer's direct-convolution FLOP count
+              over the same time and `algorithmic_speedup` their ratio: what Winograd F(2x2,3x3) and the
+             restated decoder layers save.  `traffic`: HBM bytes per launch from the committed rocprofv3 --pmc summary of
+             THIS kernel source (null when the summary was taken from other source: profiles/*hbm_traffic*.json carries a
+             hash of dlwp_amd/csrc).
+  sub_records   the same API at the other operating points of SURVEY.md 8d and the verdict: members 1 and 8, the
+             host-visible (numpy in / numpy out, PCIe-inclusive) rollout, layer 1 alone at the nominal 91 x 180, the
+             config-3 training step (global batch 64, data parallel over the ranks with the RCCL all-reduce of the C ABI)
+             and the config-5 ensemble (1 degree, 12 channels, 32 members IN TOTAL over the ranks: strong scaling).
+  cpu_baseline  the unfused torch-CPU restatement of the reference graph + its host rollout loop (oracle/torch_ref.py),
+             timed on this node's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
+import ctypes
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,39 +44,107 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # v_mfma_f32_16x16x32_bf16 dense
 PEAK_HBM_GBS = 8000.0
 
 
-def build_model(grid, cin, seed=1234):
+def build_model(grid, cin, seed=1234, gpus=1, lr=None):
     from dlwp_amd.model import DLWPNeuralNet
-    from tests.nets import unet_layers
+    from dlwp_amd.presets import unet_layers
+    from dlwp_amd.training import Adam
     np.random.seed(seed)
     d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
-    d.build_model(unet_layers((cin,) + grid), loss='mse', optimizer='adam', metrics=['mae'], gpus=1)
+    d.build_model(unet_layers((cin,) + grid), loss='mse', optimizer='adam' if lr is None else Adam(lr=lr),
+                  metrics=['mae'], gpus=gpus)
     return d
 
 
-def measured_traffic(cfg_tuple, members, ups=False):
-    """HBM bytes per launch of a conv tile configuration from the committed rocprofv3 --pmc passes
-    (profiles/*hbm_traffic_b256.json: FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes, 256 members),
-    scaled to `members`.  None when that configuration was not profiled."""
-    import glob
-    ks, dil, th, tw, waves, fa, bnf, ck, pool = cfg_tuple[:9]
+# --------------------------------------------------------------------------------------------------------------------- #
+# kernel-level timing and the roofline
+# --------------------------------------------------------------------------------------------------------------------- #
+
+def kernel_source_hash():
+    """a PMC summary in profiles/ is only quoted for the kernel source it was measured on"""
+    from dlwp_amd import _lib
+    return _lib.kernel_source_hash()
+
+
+def config_symbol(cfg, ups=False):
+    """kernel symbol of a tile configuration tuple (dlwp_conv2d_config_info), as rocprofv3 prints it"""
+    ks, dil, th, tw, waves, fa, bnf, ck, pool = cfg[:9]
     if fa == 0:
-        key = 'WinoCfg<%d, %d, %d, %d, %d, %d, false, %s>' % (dil, th, tw, waves, bnf, ck, 'true' if ups else 'false')
-    elif bnf < 0:
-        key = 'PackCfg<%d, %d, %d, %d, %d, %d, %d, %d>' % (ks, dil, th, tw, waves, fa, ck, -bnf)
-    else:
-        key = 'ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %s>' % (ks, dil, th, tw, waves, fa, bnf, ck, 'true' if pool else 'false')
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_b256.json')), reverse=True):
+        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s> >' % (dil, th, tw, waves, bnf, ck,
+                                                                                  'true' if ups else 'false')
+    if bnf < 0:
+        return 'conv2d_fwd_packn_f32<PackCfg<%d, %d, %d, %d, %d, %d, %d, %d> >' % (ks, dil, th, tw, waves, fa, ck, -bnf)
+    if pool >= 2:
+        return 'conv2d_fwd_mfma_bf16<...%dx%d, %d waves>' % (th, tw, waves)
+    return 'conv2d_fwd_mfma_f32<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %s> >' % (ks, dil, th, tw, waves, fa, bnf, ck,
+                                                                               'true' if pool else 'false')
+
+
+def measured_traffic(symbol, members):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/*hbm_traffic*.json: FETCH_SIZE
+    x2 [gfx950 correction] + WRITE_SIZE, separate passes), scaled to `members`.  Only a summary measured on the current
+    kernel source counts (its `_meta.source_sha`); otherwise (None, reason)."""
+    sha = kernel_source_hash()
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic*.json')), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
+        meta = d.get('_meta', {})
         for name, e in d.items():
-            if key in name and 'hbm_read_bytes' in e and 'hbm_write_bytes' in e:
-                return (e['hbm_read_bytes'] + e['hbm_write_bytes']) * members / 256.0, os.path.basename(f)
-    return None, None
+            if name != '_meta' and symbol in name and 'hbm_read_bytes' in e and 'hbm_write_bytes' in e:
+                if meta.get('source_sha') != sha:
+                    stale = stale or os.path.basename(f)
+                    continue
+                scale = members / float(meta.get('members', 256))
+                return (e['hbm_read_bytes'] + e['hbm_write_bytes']) * scale, os.path.basename(f)
+    return None, ('stale: %s was measured on other kernel source' % stale) if stale else 'no PMC summary for this kernel'
+
+
+def pmc_mfma_crosscheck(rows, members):
+    """Analytic executed-MFMA counts against SQ_INSTS_MFMA of the newest profiles/*mfma_busy.json measured on this source
+    (per kernel symbol: mean over its launches in one forward).  Returns {symbol: {analytic, counter, busy_frac}}."""
+    sha = kernel_source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*mfma_busy*.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        meta = d.get('_meta', {})
+        if meta.get('source_sha') != sha or int(meta.get('members', 256)) != members:
+            continue
+        out = {'file': os.path.basename(f)}
+        by = {}
+        for r in rows:
+            for sym, fl in r.get('launch_flops', []):
+                by.setdefault(sym, []).append(fl / 2048.0)
+        for sym, counts in by.items():
+            for name, e in d.items():
+                if name != '_meta' and sym in name and 'SQ_INSTS_MFMA' in e:
+                    ent = {'analytic_mfma_per_launch': sum(counts) / len(counts), 'SQ_INSTS_MFMA': e['SQ_INSTS_MFMA']}
+                    if e.get('GRBM_GUI_ACTIVE'):
+                        # busy cycles are summed over 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                        ent['mfma_pipe_busy_frac'] = e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / \
+                            (e['GRBM_GUI_ACTIVE'] / 8.0)
+                    out[sym] = ent
+        return out
+    return None
+
+
+def _time_calls(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
 
 
 def time_layers(model, members, iters=5):
@@ -72,70 +155,99 @@ def time_layers(model, members, iters=5):
     x = torch.randn((members,) + plan._in_store, device=model.device)
     outs = ex.run(x)                                    # fills every scratch buffer with realistic data
     bufs = ex.scratch(members)
+    cfgs = ops.conv_configs()
     rows = []
     for op, d in zip(plan.ops, ex._descriptors()):
-        if op.kind not in ('conv', 'maxpool'):
+        if op.kind not in ('conv', 'maxpool', 'd2s'):
             continue
         src = x if op.src == -1 else (bufs[op.src] if op.src >= 0 else outs[-2 - op.src])
         dst = bufs[op.dst] if op.dst >= 0 else outs[-2 - op.dst]
-        if op.kind == 'maxpool':        # the pooling in front of a Winograd layer: an HBM-bound pass
-            for _ in range(2):
-                ops.maxpool2(src, out=dst)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                ops.maxpool2(src, out=dst)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / iters
-            nb = float(src.numel() * src.element_size() + dst.numel() * dst.element_size())
-            rows.append({'layer': 'maxpool2 %dx%d' % (op.xs[1], op.xs[2]), 'kind': 'hbm', 'ms': ms, 'gbs': nb / ms / 1e6,
-                         'flops': 0.0, 'bytes': nb})
+        if op.kind in ('maxpool', 'd2s'):        # HBM-bound passes left in the forward
+            if op.kind == 'maxpool':
+                fn = lambda: ops.maxpool2(src, out=dst)  # noqa: E731
+                name = 'maxpool2 %dx%d' % (op.xs[1], op.xs[2])
+                nb = float(src.numel() * src.element_size() + dst.numel() * dst.element_size())
+            else:
+                fn = lambda: ops.depth_to_space2(src, op.xs[0], out=dst, c_off=op.out_c_off)  # noqa: E731
+                name = 'depth_to_space2 %dx%d' % (op.xs[1], op.xs[2])
+                nb = 2.0 * src.numel() * src.element_size()
+            ms = _time_calls(fn, iters)
+            rows.append({'layer': name, 'kind': 'hbm', 'ms': ms, 'gbs': nb / ms / 1e6, 'flops': 0.0, 'bytes': nb,
+                         'executed_flops': 0.0})
             continue
         lay = op.layer
         kern, bias = ex.conv_weights(op)       # the layer's, or the phase-summed kernels of a restated decoder layer
         # weights prepared once, as in the rollout graph (dlwp_conv2d_prepare): the events bracket the conv kernel only
         prep = ops.conv2d_prepare(src, kern, d, out_dtype=dst.dtype, x_channels=op.xs[0])
-        for _ in range(2):
-            ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], prepared=prep)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], prepared=prep)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
+        ms = _time_calls(lambda: ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], prepared=prep), iters)
         _, (kh, kw), dil_run = op.conv_geometry
         co, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape     # FLOPs: what the convolution computes
         flops = 2.0 * ho * wo * co * op.xs[0] * kh * kw * members
-        executed = flops
         if op.alg_flops is not None:           # restated layer: ALGORITHMIC FLOPs are those of the reference's layer
             flops = float(op.alg_flops) * members
         co, ho, wo = op.out_shape                                             # bytes: what it stores
         nbytes = (float(src.element_size()) * members * op.xs[0] * op.xs[1] * op.xs[2] +
                   float(dst.element_size()) * members * co * ho * wo + 4.0 * kh * kw * op.xs[0] * co)
-        from dlwp_amd import _lib
-        import ctypes
-        pick = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(model.device.index or 0),
-                                                _lib.Shape4(members, op.xs[0], op.xs[1], op.xs[2]), ctypes.byref(d))
-        cfg = ops.conv_configs()[pick] if pick >= 0 else None
+        ups = (kh == 3 and op.src_mode == 1 and tuple(dil_run) == (1, 1) and op.halo.top % 2 == 1 and
+               op.halo.left % 2 == 1)
+        info = ops.conv_launch_info((members, op.xs[0], op.xs[1], op.xs[2]), d, ex._conv_dtype(op),
+                                    model.device.index or 0)
+        launch_flops = [(config_symbol(cfgs[i[0]], ups) if i[0] >= 0 else 'conv2d_fwd_direct_f32', i[3]) for i in info]
+        cfg = cfgs[info[0][0]] if info and info[0][0] >= 0 else None
         rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': dil_run[0], 'tile_cfg': cfg,
-                     'out': [ho, wo], 'ms': ms, 'tflops': flops / ms / 1e9, 'gbs': nbytes / ms / 1e6,
-                     'flops': flops, 'bytes': nbytes})
-        # Winograd on an up-sampled source with odd halos leaves out the 7 identically-zero positions (WinoCfg::UPS)
-        rows[-1]['wino_multiplies_per_tile'] = 9 if (kh == 3 and op.src_mode == 1 and tuple(dil_run) == (1, 1) and
-                                                     op.halo.top % 2 == 1 and op.halo.left % 2 == 1) else 16
+                     'kernel': launch_flops[0][0], 'launches': len(info), 'out': [ho, wo], 'ms': ms,
+                     'algorithmic_tflops': flops / ms / 1e9, 'executed_tflops': sum(i[3] for i in info) / ms / 1e9,
+                     'gbs': nbytes / ms / 1e6, 'flops': flops, 'bytes': nbytes,
+                     'executed_flops': sum(i[3] for i in info), 'launch_flops': launch_flops,
+                     'bf16_matrix': bool(info and info[0][4])})
         if op.alg_flops is not None:
-            rows[-1]['restated'] = ('on the low-resolution source of the UpSampling2D in front (dlwp_amd/plan.py): '
-                                    'executes %.3f of the algorithmic multiplies' % (executed / flops))
+            rows[-1]['restated'] = 'on the low-resolution source of the UpSampling2D in front (DESIGN.md 5.7)'
     return rows
 
+
+def roofline_of(rows, members):
+    """The kernel (all launches of one symbol inside a forward) with the largest share of the forward's time."""
+    tot = sum(r['ms'] for r in rows)
+    groups = {}
+    for r in rows:
+        if r.get('kind') == 'hbm':
+            continue
+        groups.setdefault(r['kernel'], []).append(r)
+    sym, rs = max(groups.items(), key=lambda kv: sum(r['ms'] for r in kv[1]))
+    ms = sum(r['ms'] for r in rs)
+    n_launch = len(rs)
+    executed = sum(r['executed_flops'] for r in rs)
+    algorithmic = sum(r['flops'] for r in rs)
+    peak = PEAK_BF16_MFMA_TFLOPS if rs[0]['bf16_matrix'] else PEAK_F32_MFMA_TFLOPS
+    achieved = executed / ms / 1e9
+    out = {'bound': 'mfma', 'kernel': sym,
+           'layers': ['%s (%d->%d, %dx%d dil %d, out %dx%d)' % (r['layer'], r['cin'], r['cout'], r['k'], r['k'], r['dil'],
+                                                                 r['out'][0], r['out'][1]) for r in rs],
+           'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+           'definition': 'matrix-core FLOPs the kernel executes (MFMA instructions x 2048, tile and channel padding '
+                         'included) / HIP-event time / dense fp32 MFMA peak',
+           'algorithmic_tflops': algorithmic / ms / 1e9, 'algorithmic_speedup': algorithmic / executed,
+           'launches_per_forward': n_launch, 'launch_ms': ms / n_launch,
+           'executed_flops_per_launch': executed / n_launch, 'algorithmic_flops_per_launch': algorithmic / n_launch,
+           'algorithmic_bytes_per_launch': sum(r['bytes'] for r in rs) / n_launch,
+           'share_of_forward_time': ms / tot, 'traffic_unit': 'bytes per launch'}
+    if any(r['launches'] > 1 for r in rs):
+        out['note'] = ('layers on a 45-column map hand their ragged last column tile to a 16-wide instance in a second '
+                       'launch; its time and FLOPs are inside these figures')
+    tr, src = measured_traffic(sym, members)
+    out['traffic'], out['traffic_source'] = tr, src
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+# CPU baseline
+# --------------------------------------------------------------------------------------------------------------------- #
 
 def cpu_baseline(grid, cin, forwards, weights, budget_s=12.0):
     """The reference's CPU path as restated in oracle/torch_ref.py: unfused pad-copy / zero-pad-copy / conv / bias /
     tanh / pool / upsample in torch-CPU float32 + the host rollout loop with a full state copy per step."""
     from oracle import torch_ref
-    from tests.nets import unet_layers
+    from dlwp_amd.presets import unet_layers
     layers = unet_layers((cin,) + grid)
     tw = torch_ref.to_torch_weights(weights)
     rng = np.random.default_rng(0)
@@ -185,6 +297,120 @@ def cpu_baseline(grid, cin, forwards, weights, budget_s=12.0):
             'cpu': name, 'first_call_s': t1 - t0}
 
 
+# --------------------------------------------------------------------------------------------------------------------- #
+# sub-records
+# --------------------------------------------------------------------------------------------------------------------- #
+
+def _sync_time(fn, reps, barrier=None, world=1, dev=None):
+    """wall time of `reps` calls bracketed by synchronize (+ barrier) on both sides; MAX over ranks"""
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def sub_small_batches(net, grid, cin, forwards):
+    """latency end of the same rollout: 1 and 8 members per GPU (N = 1 and N = 8)"""
+    out = {}
+    for m in (1, 8):
+        s0 = torch.randn((m, cin) + grid, device=net.device)
+        net.rollout_on_device(s0, forwards)
+        dt = _sync_time(lambda: net.rollout_on_device(s0, forwards), 10)
+        out['members_%d' % m] = {'value': m * forwards * 2 * 10 / dt, 'unit': '6-h forecast steps/s',
+                                 'ms_per_rollout': 1e3 * dt / 10, 'ms_per_forward': 1e3 * dt / 10 / forwards}
+    return out
+
+
+def sub_host_visible(d, grid, cin, members, forwards):
+    """the API exactly as the reference exposes it: numpy in, numpy out (PCIe both ways, pinned result array)"""
+    x = np.random.default_rng(0).standard_normal((members, cin) + grid).astype(np.float32)
+    out = d.predict_timeseries(x, 2 * forwards)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = d.predict_timeseries(x, 2 * forwards)
+        times.append(time.perf_counter() - t0)
+    return {'value': members * forwards * 2 / min(times), 'unit': '6-h forecast steps/s', 'members': members,
+            'series_bytes': int(out.nbytes), 's_per_call': min(times),
+            'note': 'DLWPNeuralNet.predict_timeseries(numpy) -> numpy; the series returns in member chunks into a pinned '
+                    'host array on a copy stream under the next chunk\'s hipGraph launch'}
+
+
+def sub_layer1_nominal(net, members):
+    """layer 1 (4 -> 32, 3x3 dilation 2, periodic + zero halo, tanh) alone at the NOMINAL 91 x 180 grid"""
+    from dlwp_amd import _lib, ops
+    lay = [l for l in net.layers if hasattr(l, 'kernel')][0]
+    cd = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, _lib.PAD_ZERO, _lib.PAD_WRAP), _lib.ACT_TANH)
+    x = torch.randn((members, 4, 91, 180), device=net.device)
+    y = torch.empty((members, 32, 91, 180), device=net.device)
+    ms = _time_calls(lambda: ops.conv2d(x, lay.kernel, lay.bias, cd, out=y), 10)
+    info = ops.conv_launch_info((members, 4, 91, 180), cd, None, net.device.index or 0)
+    ex = sum(i[3] for i in info)
+    alg = 2.0 * 91 * 180 * 32 * 4 * 9 * members
+    nb = 4.0 * members * (4 + 32) * 91 * 180
+    return {'ms': ms, 'members': members, 'executed_tflops': ex / ms / 1e9, 'mfma_frac': ex / ms / 1e9 / PEAK_F32_MFMA_TFLOPS,
+            'algorithmic_tflops': alg / ms / 1e9, 'algorithmic_gbs': nb / ms / 1e6, 'hbm_frac': nb / ms / 1e6 / PEAK_HBM_GBS,
+            'bound': 'hbm (AI 16 F/B < ridge 20)', 'note': 'full 91x180 output written (no pooling epilogue)'}
+
+
+def sub_train(grid, cin, world, rank, barrier, dev, global_batch=64, steps=20, warmup=3):
+    """BASELINE config 3: the same U-Net, training, GLOBAL batch 64 ('mse', Adam), data parallel over the ranks: each rank
+    trains on its 64 / N rows, one all-reduce of the flat gradient buffer per step (RCCL through dlwp_allreduce_sum_f32).
+    Strong scaling: the global batch is fixed."""
+    from dlwp_amd.parallel import shard_bounds
+    d = build_model(grid, cin, gpus=world, lr=1e-4)
+    tr = d.model._trainer
+    lo, hi = shard_bounds(global_batch, rank, world)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((global_batch, cin) + grid, generator=g)[lo:hi].to(dev)
+    y = torch.randn((global_batch, cin) + grid, generator=g)[lo:hi].to(dev)
+    for _ in range(warmup):
+        tr.train_on_shard(x, y, global_batch, return_device=True)
+    dt = _sync_time(lambda: tr.train_on_shard(x, y, global_batch, return_device=True), steps, barrier, world, dev)
+    lv, _ = tr.train_on_shard(x, y, global_batch, return_device=True)
+    flops = 3.0 * d.model.plan.conv_flops_per_sample() * global_batch * steps
+    rec = {'value': global_batch * steps / dt, 'unit': 'samples/s', 'scaling': 'strong', 'global_batch': global_batch,
+           'batch_per_gpu': hi - lo, 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
+           'algorithmic_tflops_per_gpu': flops / dt / 1e12 / world, 'loss': float(lv[0, 1].item()),
+           'all_reduce': ('none (single rank)' if world == 1 else
+                          ('RCCL via dlwp_allreduce_sum_f32 (C ABI), %d floats incl. the loss table'
+                           % tr._flat_exchange.numel() if tr.dp.uses_rccl_abi() else 'torch.distributed (%s)' % tr.dp.backend))}
+    return rec
+
+
+def sub_cfg5(world, rank, barrier, dev, total_members=32, forwards=40):
+    """BASELINE config 5: 1-degree 180 x 360 x 12-channel U-Net, a 32-member perturbed-IC ensemble IN TOTAL, 40 forwards
+    (80 six-hour steps) as one hipGraph per rank; members sharded over the ranks (4 per GPU at 8).  Strong scaling."""
+    from dlwp_amd.parallel import shard_bounds
+    grid, cin = (180, 360), 12
+    d = build_model(grid, cin)
+    net = d.model
+    lo, hi = shard_bounds(total_members, rank, world)
+    base = torch.randn((1, cin) + grid, generator=torch.Generator().manual_seed(0))
+    pert = torch.randn((total_members, cin) + grid, generator=torch.Generator().manual_seed(1))
+    s0 = (base + 0.01 * pert)[lo:hi].contiguous().to(dev)
+    ser = net.rollout_on_device(s0, forwards)
+    dt = _sync_time(lambda: net.rollout_on_device(s0, forwards), 3, barrier, world, dev)
+    flops = net.plan.conv_flops_per_sample()
+    return {'value': total_members * forwards * 2 * 3 / dt, 'unit': '6-h forecast steps/s', 'scaling': 'strong',
+            'total_members': total_members, 'members_per_gpu': hi - lo, 'forwards': forwards,
+            'ms_per_rollout': 1e3 * dt / 3, 'finite': bool(torch.isfinite(ser[-1]).all().item()),
+            'algorithmic_tflops_per_gpu': total_members * forwards * 3 * flops / dt / 1e12 / world}
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -195,6 +421,10 @@ def main():
     ap.add_argument('--grid', default='88x180')
     ap.add_argument('--channels', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the sub-records (members 1/8, host-visible, layer 1, '
+                                                             'training, config 5)')
+    ap.add_argument('--extras-timeout', type=float, default=240.0,
+                    help='N > 1: seconds the collective sub-records may take before the line is printed without them')
     ap.add_argument('--activation-dtype', default='float32', choices=['float32', 'bfloat16'],
                     help="storage of the tensors between the layers (BASELINE config 4 uses bfloat16; the headline "
                          "config 2 is float32)")
@@ -260,55 +490,75 @@ def main():
                                % (grid[0], grid[1], a.channels, a.forwards, a.members),
                    'members_per_gpu': a.members, 'forwards_per_rollout': a.forwards, 'time_dim': 2,
                    'grid': list(grid), 'channels': a.channels, 'launches_per_forward': net.infer_plan.n_launches,
-                   'launch_note': 'plan operations; a Winograd layer on a 22x45 map takes a second (16-wide) launch for its ragged last column tile at chip-filling batches',
                    'parallelism': 'members sharded over %d GPU(s), no collective' % world,
                    'inference_plan': ('Winograd F(2x2,3x3) on the 3x3 layers; the decoder layers that read an up-sampled '
                                       'tensor are restated on the low-resolution tensor (same function, DESIGN.md 5.7; '
-                                      'DLWP_RESTATE_UPSAMPLED=0 runs the reference formulation); FLOP figures are '
-                                      'algorithmic (the reference graph, SURVEY.md 8d)')},
+                                      'DLWP_RESTATE_UPSAMPLED=0 runs the reference formulation)')},
         'forwards_per_s': fwd_per_s,
         'conv_mflop_per_forward_per_member': flops_fwd / 1e6,
-        'forward': {'achieved_tflops': fwd_per_s * flops_fwd / 1e12 / world,
-                    'mfma_util_frac': fwd_per_s * flops_fwd / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
-                    'algorithmic_gbs': fwd_per_s * bytes_fwd / 1e9 / world, 'per_gpu': True},
         'finite': finite,
     }
+    state = {'printed': False}
+    lock = threading.Lock()
+
+    def emit():
+        with lock:
+            if not state['printed'] and rank == 0:
+                print(json.dumps(out))
+                sys.stdout.flush()
+            state['printed'] = True
+
     if rank == 0:
         rows = time_layers(net, a.members)
-        tot = sum(r['ms'] for r in rows)
-        dom = max((r for r in rows if r.get('kind') != 'hbm'), key=lambda r: r['ms'])
-        wino = bool(dom.get('tile_cfg')) and dom['tile_cfg'][5] == 0
-        out['roofline'] = {'bound': 'mfma', 'kernel': '%s (%s: %d->%d, %dx%d dil %d, %dx%d)' %
-                           ('conv2d_fwd_wino_f32' if wino else 'conv2d_fwd_mfma_f32',
-                            dom['layer'], dom['cin'], dom['cout'], dom['k'], dom['k'], dom['dil'], dom['out'][0], dom['out'][1]),
-                           'achieved': dom['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': dom['tflops'] / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'traffic_unit': 'bytes per launch',
-                           'algorithmic_bytes_per_launch': dom['bytes'],
-                           'launch_ms': dom['ms'], 'algorithmic_flops_per_launch': dom['flops'],
-                           'share_of_forward_time': dom['ms'] / tot}
-        if wino:
-            # Winograd F(2x2,3x3): the kernel executes 16 multiplies per 2x2 outputs and input channel where the
-            # algorithmic (direct) count is 36 -- `achieved`/`frac` are algorithmic FLOPs as the contract asks and may
-            # exceed the dense peak; `executed_frac` is what the matrix cores actually issue (tile padding included)
-            th_, tw_ = dom['tile_cfg'][2], dom['tile_cfg'][3]
-            ho_, wo_ = dom['out']
-            pad = (-(-ho_ // th_) * th_) * (-(-wo_ // tw_) * tw_) / float(ho_ * wo_)
-            mult = dom.get('wino_multiplies_per_tile', 16)
-            out['roofline']['algorithm'] = ('winograd F(2x2,3x3): %d multiplies per 2x2 output tile and channel pair where '
-                                            'the algorithmic count is 36%s' %
-                                            (mult, ' (up-sampled source: 7 of the 16 positions are identically zero)'
-                                             if mult == 9 else ''))
-            out['roofline']['executed_frac'] = dom['tflops'] * mult / 36.0 * pad / PEAK_F32_MFMA_TFLOPS
-        if dom.get('tile_cfg'):
-            tr, src = measured_traffic(dom['tile_cfg'], a.members, ups=dom.get('wino_multiplies_per_tile') == 9)
-            out['roofline']['traffic'] = tr
-            out['roofline']['traffic_source'] = src
-        out['layers'] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k not in ('flops', 'bytes')}
-                         for r in rows]
-        out['forward']['sum_of_kernel_ms'] = tot
-        if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(grid, a.channels, a.forwards, weights_np)
-        print(json.dumps(out))
+        executed_fwd = sum(r['executed_flops'] for r in rows) / a.members          # per member per forward
+        per_gpu_fwd_per_s = fwd_per_s / world
+        out['forward'] = {
+            'executed_tflops': per_gpu_fwd_per_s * executed_fwd / 1e12,
+            'mfma_util_frac': per_gpu_fwd_per_s * executed_fwd / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            'algorithmic_tflops': per_gpu_fwd_per_s * flops_fwd / 1e12,
+            'algorithmic_speedup': flops_fwd / executed_fwd,
+            'algorithmic_gbs': per_gpu_fwd_per_s * bytes_fwd / 1e9, 'hbm_frac': per_gpu_fwd_per_s * bytes_fwd / 1e9 / PEAK_HBM_GBS,
+            'per_gpu': True, 'sum_of_kernel_ms': sum(r['ms'] for r in rows),
+            'ms_per_forward_in_graph': 1e3 * dt / a.steps / a.forwards,
+            'definition': 'executed = matrix-core FLOPs the kernels issue (MFMA x 2048, padding included); mfma_util_frac = '
+                          'executed / wall / 157.3 TFLOP/s; algorithmic = direct-convolution FLOPs of the reference graph '
+                          '(1597.7 MFLOP per forward per member)'}
+        out['roofline'] = roofline_of(rows, a.members)
+        cc = pmc_mfma_crosscheck(rows, a.members)
+        if cc:
+            out['roofline']['pmc_crosscheck'] = cc
+        out['layers'] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
+                          if k not in ('flops', 'bytes', 'executed_flops', 'launch_flops', 'bf16_matrix')} for r in rows]
+    if not a.no_extras:
+        sub = {}
+        if rank == 0:
+            try:
+                sub.update(sub_small_batches(net, grid, a.channels, a.forwards))
+                sub['host_visible'] = sub_host_visible(d, grid, a.channels, a.members, a.forwards)
+                if grid == (88, 180) and a.channels == 4:
+                    sub['layer1_at_91x180'] = sub_layer1_nominal(net, a.members)
+            except Exception as e:  # noqa: BLE001  (a sub-record must never cost the headline line)
+                sub['error_local'] = repr(e)
+        out['sub_records'] = sub
+        # the collective sub-records: every rank takes part; a watchdog prints the line without them if they stall
+        if world > 1:
+            def watchdog():
+                time.sleep(a.extras_timeout)
+                sub['error_collective'] = 'timed out after %.0f s' % a.extras_timeout
+                emit()
+                os._exit(0)
+            threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            del series
+            net.__dict__.pop('_rollouts', None)
+            torch.cuda.empty_cache()
+            sub['train_cfg3'] = sub_train(grid if grid == (88, 180) else (88, 180), 4, world, rank, barrier, dev)
+            sub['ensemble_cfg5'] = sub_cfg5(world, rank, barrier, dev)
+        except Exception as e:  # noqa: BLE001
+            sub['error_collective'] = repr(e)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(grid, a.channels, a.forwards, weights_np)
+    emit()
     barrier()
 
 

@@ -59,12 +59,29 @@ class Op(ctypes.Structure):
                 ('b', ctypes.c_int), ('xs', Shape4), ('conv', Conv2d), ('pad', Pad2d), ('aux', ctypes.c_int * 4)]
 
 
+class LaunchInfo(ctypes.Structure):
+    _fields_ = [('config', ctypes.c_int), ('grid', ctypes.c_int), ('block_threads', ctypes.c_int),
+                ('matrix_flops', ctypes.c_double), ('bf16_matrix', ctypes.c_int)]
+
+
 class DlwpError(RuntimeError):
     """A non-zero status from libdlwp_hip.so (message from dlwp_last_error())."""
 
     def __init__(self, code, message):
         super(DlwpError, self).__init__('libdlwp_hip error %d: %s' % (code, message))
         self.code = code
+
+
+def kernel_source_hash():
+    """sha256[:16] over dlwp_amd/csrc/*.{h,hip}: profiles/*.json summaries carry it so that a counter measurement is
+    only quoted for the kernel source it was taken on (bench.py, tools/parse_pmc.py)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.h')) + glob.glob(os.path.join(_HERE, 'csrc', '*.hip'))):
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def declared_symbols(header_path=HEADER_PATH):
@@ -116,6 +133,7 @@ _sig('dlwp_conv2d_uses_bf16_weights', [Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_prefers_unfused_pool', [_i, _i, _i, _i, _i, _i])
 _sig('dlwp_conv2d_supports_out_pool', [Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
+_sig('dlwp_conv2d_launch_info', [_vp, Shape4, _P(Conv2d), _i, _P(LaunchInfo), _P(_i)])
 _sig('dlwp_conv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _i, _P(_sz)])
 _sig('dlwp_conv2d_bwd_data', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])
 _sig('dlwp_conv2d_bwd_data_stored', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])

@@ -449,6 +449,79 @@ int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs,
   return e ? prep_with(*e, w, dst, xs.c, cd->cout, s) : DLWP_OK;
 }
 
+namespace {
+
+// What one dlwp_conv2d_fwd call launches: the chosen instance and, for a Winograd layer on a map whose last 32-column
+// tile would be at most half used, a second (16-wide) instance for the ragged columns.
+struct LaunchPlan {
+  int primary = -1, narrow = -1;       // registry indices (-1: none; primary -1 = the one-thread-per-output kernel)
+  int tiles_h = 0, tiles_w = 0, cout_tiles = 0;
+  long long grid = 0;
+  int n_tiles_h = 0, n_cout_tiles = 0, col0 = 0;   // the narrow launch
+  long long n_grid = 0;
+};
+
+// Matrix-core work of `grid` workgroups of instance e on layer a: the padded GEMM volume the MFMA instructions actually
+// multiply (tile, channel-chunk and output-channel padding included), in FLOP = 2 x multiply-adds.  It equals
+// SQ_INSTS_MFMA x 2048 for the fp32 families (v_mfma_f32_16x16x4_f32; checked against profiles/*_mfma_busy.json).
+double executed_matrix_flops(const ConvKernelEntry& e, const ConvArgs& a, long long grid) {
+  const double chunks = (double)dlwp_ceil_div(a.Cin, e.ck);
+  double rows, cols, k;
+  if (is_wino(e)) {                    // 16 (9 on an up-sampled source / the 2x2-sum epilogue) GEMMs: tiles x cout x channels
+    rows = (double)e.waves * 16.0 * (wino_skips_row2(a) ? 9.0 : 16.0);
+    cols = 16.0 * e.bnf;
+    k = chunks * e.ck;
+  } else if (is_bf16(e)) {
+    rows = (double)e.th * e.tw;
+    cols = 16.0 * e.bnf;
+    k = chunks * e.ck * e.ks * e.ks;
+  } else if (e.pack > 0) {             // packed-N: cout x S column shifts fill the 16 columns, effective kernel ks x kwe
+    rows = (double)e.waves * e.fa * 16.0;
+    cols = 16.0;
+    k = chunks * e.ck * e.ks * ((e.ks - 1) * e.dil + e.pack);
+  } else {
+    rows = (double)e.waves * e.fa * 16.0;
+    cols = 16.0 * e.bnf;
+    k = chunks * e.ck * e.ks * e.ks;
+  }
+  return 2.0 * rows * cols * k * (double)grid;
+}
+
+int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, LaunchPlan* lp) {
+  Registry& r = registry();
+  const int ci = choose_config(a, cd, h->cu_count);
+  lp->primary = ci;
+  if (ci < 0) return DLWP_OK;
+  const ConvKernelEntry& e = r.entries[ci];
+  lp->tiles_h = dlwp_ceil_div(a.Ho, e.th);
+  lp->tiles_w = dlwp_ceil_div(a.Wo, e.tw);
+  lp->cout_tiles = e.pack > 0 ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  // Winograd, 32-wide tiles on a map whose last column tile would be at most half used (22x45: 13 of 32 columns): the
+  // whole column tiles go to this instance, the rest to a 16-wide two-wave instance in a second launch (every Winograd
+  // instance reads the same prepared filters and gives the same bits).  Only when the launches fill the chip more than
+  // twice over -- at small batches a second launch costs more than the idle lanes.
+  if (g_forced_cfg < 0 && is_wino(e) && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3 &&
+      (long long)a.N * lp->tiles_h * (a.Wo / 32) * lp->cout_tiles >= 4ll * h->cu_count) {
+    for (int i = 0; i < (int)r.entries.size() && lp->narrow < 0; ++i) {
+      const ConvKernelEntry& p = r.entries[i];
+      if (is_wino(p) && p.dil == e.dil && p.tw == 16 && p.th == 8 && p.bnf == 2 && (!cd->out_pool || p.out_pool))
+        lp->narrow = i;
+    }
+  }
+  if (lp->narrow >= 0) {
+    const ConvKernelEntry& p = r.entries[lp->narrow];
+    lp->tiles_w = a.Wo / 32;
+    lp->col0 = (a.Wo / 32) * 32;
+    lp->n_tiles_h = dlwp_ceil_div(a.Ho, p.th);
+    lp->n_cout_tiles = dlwp_ceil_div(a.Cout, 16 * p.bnf);
+    lp->n_grid = (long long)lp->n_tiles_h * lp->n_cout_tiles * a.N;
+  }
+  lp->grid = (long long)lp->tiles_h * lp->tiles_w * lp->cout_tiles * a.N;
+  return DLWP_OK;
+}
+
+}  // namespace (second part)
+
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre) {
   dlwp_shape4 ys;
@@ -457,7 +530,9 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   DLWP_CHECK_ARG(cd->out_pool != 2 || !bias, "dlwp_conv2d_fwd: the 2x2 sum epilogue takes no bias");
   if (xs.n == 0) return DLWP_OK;
   ConvArgs a = make_args(x, w, bias, y, xs, cd, ys, dtype);
-  const int ci = choose_config(a, cd, h->cu_count);
+  LaunchPlan lp;
+  plan_launch(h, a, cd, &lp);
+  const int ci = lp.primary;
   if (ci < 0) {
     if (g_forced_cfg >= 0) DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", g_forced_cfg);
     if (cd->out_pool) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel with a pooling epilogue for this layer");
@@ -476,27 +551,13 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
     }
     return 0;
   };
-  if (ensure_prepared(ci) != 0) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: hipFuncSetAttribute failed");
-  a.tiles_h = dlwp_ceil_div(a.Ho, e.th);
-  a.tiles_w = dlwp_ceil_div(a.Wo, e.tw);
-  a.cout_tiles = e.pack > 0 ? 1 : dlwp_ceil_div(a.Cout, 16 * e.bnf);
+  if (ensure_prepared(ci) != 0 || (lp.narrow >= 0 && ensure_prepared(lp.narrow) != 0))
+    DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: hipFuncSetAttribute failed");
+  a.tiles_h = lp.tiles_h;
+  a.tiles_w = lp.tiles_w;
+  a.cout_tiles = lp.cout_tiles;
   a.col0 = 0;
-  // Winograd, 32-wide tiles on a map whose last column tile would be at most half used (22x45: 13 of 32 columns): the
-  // whole column tiles go to this instance, the rest to a 16-wide two-wave instance in a second launch (every Winograd
-  // instance reads the same prepared filters and gives the same bits).  Only when the launches fill the chip more than
-  // twice over -- at small batches a second launch costs more than the idle lanes.
-  int narrow = -1;
-  if (g_forced_cfg < 0 && is_wino(e) && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3 &&
-      (long long)a.N * a.tiles_h * (a.Wo / 32) * a.cout_tiles >= 4ll * h->cu_count) {
-    for (int i = 0; i < (int)r.entries.size() && narrow < 0; ++i) {
-      const ConvKernelEntry& p = r.entries[i];
-      if (is_wino(p) && p.dil == e.dil && p.tw == 16 && p.th == 8 && p.bnf == 2 && (!cd->out_pool || p.out_pool)) narrow = i;
-    }
-    if (narrow >= 0 && ensure_prepared(narrow) != 0) narrow = -1;
-  }
-  if (narrow >= 0) a.tiles_w = a.Wo / 32;
-  const long long grid = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
-  DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
+  DLWP_CHECK_ARG(lp.grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
   if (e.pack != 0) {  // Winograd / packed-N: prepared weights (into the handle's scratch unless the caller built them)
     if (u_pre) {
       a.w = u_pre;
@@ -508,14 +569,14 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
       a.w = u;
     }
   }
-  e.launch(a, (int)grid, s);
-  if (narrow >= 0) {
-    const ConvKernelEntry& p = r.entries[narrow];
-    a.col0 = (a.Wo / 32) * 32;
-    a.tiles_h = dlwp_ceil_div(a.Ho, p.th);
+  e.launch(a, (int)lp.grid, s);
+  if (lp.narrow >= 0) {
+    const ConvKernelEntry& p = r.entries[lp.narrow];
+    a.col0 = lp.col0;
+    a.tiles_h = lp.n_tiles_h;
     a.tiles_w = 1;
-    a.cout_tiles = dlwp_ceil_div(a.Cout, 16 * p.bnf);
-    p.launch(a, (int)((long long)a.tiles_h * a.cout_tiles * a.N), s);
+    a.cout_tiles = lp.n_cout_tiles;
+    p.launch(a, (int)lp.n_grid, s);
   }
   DLWP_LAUNCH_CHECK("conv2d_fwd_mfma_f32");
   return DLWP_OK;
@@ -670,6 +731,36 @@ int dlwp_conv2d_set_winograd(int enable) {
 
 int dlwp_conv2d_force_config(int i) {
   g_forced_cfg = i;
+  return DLWP_OK;
+}
+
+int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, dlwp_launch_info* out2,
+                            int* n_launches) {
+  DLWP_CHECK_ARG(h && cd && out2 && n_launches, "dlwp_conv2d_launch_info: null pointer");
+  dlwp_shape4 ys;
+  if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return DLWP_EINVAL;
+  *n_launches = 0;
+  if (xs.n <= 0) return DLWP_OK;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys, dtype);
+  LaunchPlan lp;
+  plan_launch(h, a, cd, &lp);
+  if (lp.primary < 0) {               // one thread per output on the vector ALU: no matrix-core work
+    const long long total = (long long)a.N * a.Cout * a.Ho * a.Wo;
+    const long long want = (total + 255) / 256, cap = (long long)h->cu_count * 16;
+    out2[0] = dlwp_launch_info{-1, (int)(want < cap ? want : cap), 256, 0.0, 0};
+    *n_launches = 1;
+    return DLWP_OK;
+  }
+  Registry& r = registry();
+  const ConvKernelEntry& e = r.entries[lp.primary];
+  out2[0] = dlwp_launch_info{lp.primary, (int)lp.grid, 64 * e.waves, executed_matrix_flops(e, a, lp.grid),
+                             is_bf16(e) ? 1 : 0};
+  *n_launches = 1;
+  if (lp.narrow >= 0) {
+    const ConvKernelEntry& p = r.entries[lp.narrow];
+    out2[1] = dlwp_launch_info{lp.narrow, (int)lp.n_grid, 64 * p.waves, executed_matrix_flops(p, a, lp.n_grid), 0};
+    *n_launches = 2;
+  }
   return DLWP_OK;
 }
 

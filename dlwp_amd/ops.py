@@ -267,6 +267,17 @@ def conv_configs():
     return out
 
 
+def conv_launch_info(x_shape, cd, dtype=None, device_index=0):
+    """What conv2d on a stored input of shape (n, cin, h, w) launches: [(config index, grid, block threads, executed
+    matrix-core FLOPs, on the bf16 matrix cores?)], one entry per kernel launch (dlwp_conv2d_launch_info)."""
+    out = (_lib.LaunchInfo * 2)()
+    n = ctypes.c_int(0)
+    _lib.check(_lib.lib.dlwp_conv2d_launch_info(_lib.handle(device_index), Shape4(*[int(v) for v in x_shape]),
+                                                ctypes.byref(cd), _lib.F32 if dtype is None else int(dtype), out,
+                                                ctypes.byref(n)))
+    return [(o.config, o.grid, o.block_threads, o.matrix_flops, bool(o.bf16_matrix)) for o in out[:n.value]]
+
+
 def force_conv_config(i):
     _lib.lib.dlwp_conv2d_force_config(int(i))
 

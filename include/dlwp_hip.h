@@ -144,6 +144,19 @@ int dlwp_conv2d_prefers_unfused_pool(int cin, int cout, int kh, int kw, int dil_
  * convolution (cd->out_pool = 1): the pre-pooling tensor is then never written. */
 int dlwp_conv2d_supports_out_pool(dlwp_shape4 xs, const dlwp_conv2d* cd);
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
+/* Measurement hook (bench.py's roofline): what dlwp_conv2d_fwd(xs, cd, dtype) launches -- one kernel, or two when a Winograd
+ * layer hands its ragged last column tile to a narrower instance -- and the matrix-core work each launch EXECUTES: the
+ * padded GEMM volume its MFMA instructions multiply, 2 FLOP per multiply-add, tile / channel padding included and with
+ * Winograd's 16 (9) multiplies per 2x2 outputs instead of the direct 36.  For the fp32 families this is exactly
+ * SQ_INSTS_MFMA x 2048 (v_mfma_f32_16x16x4_f32) of a rocprofv3 --pmc pass.  config: index for dlwp_conv2d_config_info
+ * (-1: the one-thread-per-output vector kernel, no matrix work).  out2 must hold 2 entries.                              */
+typedef struct {
+  int config, grid, block_threads;
+  double matrix_flops;
+  int bf16_matrix;            /* 1: v_mfma_f32_16x16x32_bf16 (peak 2.5 PFLOP/s), 0: fp32 matrix cores (157.3 TFLOP/s) */
+} dlwp_launch_info;
+int dlwp_conv2d_launch_info(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, dlwp_launch_info* out2,
+                            int* n_launches);
 
 /* ---- backward of the fused Conv2D: the two halves of the Keras train step behind DLWPNeuralNet.fit / fit_generator
  *      (DLWP/model/models.py:188-228).  dz = dL/d(pre-activation), (n, out_c_total, ho, wo) window [out_c_off,+cout).

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-HBM_PEAK_GBS, MFMA_F32_PEAK = 8000.0, 157.3
+HBM_PEAK_GBS, MFMA_F32_PEAK, MFMA_BF16_PEAK = 8000.0, 157.3, 2500.0     # MI355X_MICROARCH.md, dense
 
 
 def main():
@@ -30,7 +30,7 @@ def main():
     a = ap.parse_args()
     from dlwp_amd import ops
     from dlwp_amd.model import DLWPNeuralNet
-    from tests.nets import lstm_unet_layers
+    from dlwp_amd.presets import lstm_unet_layers
     if a.no_bf16_mfma:
         ops.set_bf16_mfma(False)
     h, w = (int(v) for v in a.grid.split('x'))
@@ -94,9 +94,16 @@ def main():
             if op.alg_flops is not None:       # decoder layer restated on its low-resolution source: algorithmic FLOPs
                 fl = float(op.alg_flops) * a.members
             on16 = any(op.layer is l16 for l16 in ex.bf16_weight_layers(a.members))
-            row.update(layer=op.layer.name, cin=op.xs[0], cout=co_, k=kh, tflops=round(fl / ms / 1e9, 1),
-                       family='bf16 mfma' if on16 else 'fp32 mfma',
-                       frac_of_mfma_f32_peak=round(fl / ms / 1e9 / MFMA_F32_PEAK, 3), bound='mfma')
+            # executed = what the matrix cores issue (padding included; Winograd's 16 / 9 multiplies per 2x2 outputs)
+            info = ops.conv_launch_info((a.members,) + tuple(op.xs), desc, ex._conv_dtype(op), dev.index or 0)
+            ex_fl = sum(i[3] for i in info)
+            peak = MFMA_BF16_PEAK if on16 else MFMA_F32_PEAK
+            nb = float(src.element_size()) * a.members * op.xs[0] * op.xs[1] * op.xs[2] + \
+                float(dst.element_size()) * a.members * int(np.prod(op.out_shape))
+            row.update(layer=op.layer.name, cin=op.xs[0], cout=co_, k=kh, algorithmic_tflops=round(fl / ms / 1e9, 1),
+                       executed_tflops=round(ex_fl / ms / 1e9, 1), family='bf16 mfma' if on16 else 'fp32 mfma',
+                       frac_of_matrix_peak=round(ex_fl / ms / 1e9 / peak, 3), matrix_peak_tflops=peak,
+                       gbs=round(nb / ms / 1e6, 1), frac_of_hbm_peak=round(nb / ms / 1e6 / HBM_PEAK_GBS, 3), bound='mfma')
         else:
             f = op.xs[0]
             hw = op.xs[1] * op.xs[2]

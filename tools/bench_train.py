@@ -26,7 +26,7 @@ def main():
     a = ap.parse_args()
     from dlwp_amd import parallel
     from dlwp_amd.model import DLWPNeuralNet
-    from tests.nets import unet_layers
+    from dlwp_amd.presets import unet_layers
     rank, world, local = parallel.init()
     grid = tuple(int(v) for v in a.grid.split('x'))
     np.random.seed(1234)

@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $CMD > $OUT/${TAG}_stats_bench.json 2> $OUT/stats.err
 cp $OUT/stats/s_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
