@@ -73,6 +73,9 @@ def config_symbol(cfg, ups=False):
     """kernel symbol of a tile configuration tuple (dlwp_conv2d_config_info), as rocprofv3 prints it"""
     ks, dil, th, tw, waves, fa, bnf, ck, pool = cfg[:9]
     if fa == 0:
+        split = len(cfg) > 10 and cfg[10] and not ups
+        if split:          # the 16-position case of these entries: positions split over two waves per tile fragment
+            return 'conv2d_fwd_wino2_f32<WinoSplitCfg<%d, %d, %d, %d, %d, %d, false> >' % (dil, th, tw, waves, bnf, ck)
         return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s> >' % (dil, th, tw, waves, bnf, ck,
                                                                                   'true' if ups else 'false')
     if bnf < 0:

@@ -121,6 +121,7 @@ _sig('dlwp_conv2d_prepare', [_vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
 _sig('dlwp_conv2d_fwd_prepared', [_vp, _vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
 _sig('dlwp_conv2d_num_configs', [])
 _sig('dlwp_conv2d_config_info', [_i, _P(_i), _P(_i)])
+_sig('dlwp_conv2d_config_flags', [_i])
 _sig('dlwp_conv2d_force_config', [_i])
 _sig('dlwp_conv2d_set_winograd', [_i])
 _sig('dlwp_phase_geometry', [_i, _i, _P(_i), _P(_i), _P(_i)])

@@ -61,6 +61,16 @@ __host__ __device__ static inline int dlwp_map_coord(int p, int n, int mode) {
   return q < 0 ? q + n : q;
 }
 
+// The conv loaders' version: p comes from a tile walk, p in [-n, n + halo) wherever its value matters (the validated halo
+// is <= n); positions further out belong to outputs that are never stored and only need SOME valid address.  No integer division (the generic % costs ~24 vector instructions per coordinate, and the
+// fp32 matrix instructions share the SIMD's lanes with the vector ALU: every vector instruction is matrix time lost).
+__device__ static inline int dlwp_map_coord_tile(int p, int n, int mode) {
+  if (p >= 0 && p < n) return p;
+  if (mode == DLWP_PAD_ZERO) return -1;
+  if (mode == DLWP_PAD_EDGE) return p < 0 ? 0 : n - 1;
+  return p < 0 ? max(p + n, 0) : min(p - n, n - 1);   // DLWP_PAD_WRAP
+}
+
 // internal launchers shared between the public entry points and the rollout graph builder
 // u_pre: weights already prepared by dlwp_conv2d_prep for this (w, xs, cd) -- the rollout graph transforms once per
 // launch instead of once per forward; NULL = transform into the handle's scratch right before the multiply

@@ -55,12 +55,13 @@ constexpr size_t WINO_SCRATCH_FLOATS = 8u << 20;  // 32 MB: Cin*Cout <= 512K
 // loads return 0 for the input planes and the transformed filters alike) when the padded Winograd multiplies are at most
 // half of what the direct family executes with its chunks of 4 (measured: 6 channels 0.094 vs 0.104 ms, ratio 0.44;
 // 12 channels 0.205 vs 0.181 ms, ratio 0.59)
-bool wino_channels_ok(int cin, int cout) {
+// output channels: whole tiles of 32 (conv_fwd_wino_kernel.h) or of 16 (the position-split instances, conv_fwd_wino2_kernel.h)
+bool wino_channels_ok(int cin, int cout, int dil) {
   const int pad8 = dlwp_ceil_div(cin, 8) * 8, pad4 = dlwp_ceil_div(cin, 4) * 4;
-  return cout % 32 == 0 && cin >= 5 && pad8 * 16 * 2 <= pad4 * 36;
+  return (cout % 32 == 0 || (cout % 16 == 0 && dil == 1)) && cin >= 5 && pad8 * 16 * 2 <= pad4 * 36;
 }
 bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
-  return winograd_enabled() && cd->kh == 3 && cd->kw == 3 && cd->dil_h == cd->dil_w && wino_channels_ok(a.Cin, a.Cout) &&
+  return winograd_enabled() && cd->kh == 3 && cd->kw == 3 && cd->dil_h == cd->dil_w && wino_channels_ok(a.Cin, a.Cout, cd->dil_h) &&
          cd->src_mode != DLWP_SRC_MAXPOOL2 &&
          (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&   // channel offsets inside a sample: 32-bit byte offsets
          (size_t)a.Cin * a.Cout * 16 <= WINO_SCRATCH_FLOATS;
@@ -298,6 +299,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     const bool pool = cd->src_mode == DLWP_SRC_MAXPOOL2;
     const bool pack_ok = e.pack <= 0 || (cd->cout <= 16 / e.pack);
     if (is_wino(e) && (!winograd_wanted(a, cd) || a.Cout % (16 * e.bnf) != 0)) return -1;  // whole channel chunks only
+    if (is_wino(e) && e.bnf == 1 && wino_skips_row2(a)) return -1;  // 16-channel blocks have no 9-position variant
     if (is_bf16(e) && (!bf16_wanted(a, cd) || (e.in32 != 0) == (a.in_bf16 != 0) ||
                        bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
     if (cd->out_pool && !e.out_pool) return -1;
@@ -320,7 +322,8 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     bool any = false;
     for (const ConvKernelEntry& e : r.entries)
       any = any || (is_wino(e) && e.dil == cd->dil_h && (e.pool != 0) == (cd->src_mode == DLWP_SRC_MAXPOOL2) &&
-                    (!cd->out_pool || e.out_pool));
+                    (!cd->out_pool || e.out_pool) && a.Cout % (16 * e.bnf) == 0 &&
+                    !(e.bnf == 4 && !wino_skips_row2(a)) && !(e.bnf == 1 && (wino_skips_row2(a) || a.Cout % 32 == 0)));
     want_wino = any;
   }
   if (sum_pool && !(want_wino && cd->dil_h == 1)) return -1;
@@ -332,6 +335,9 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
     if (is_wino(e) != want_wino || is_bf16(e) != want_bf16) continue;      // kernel family fixed by the layer
     if (is_wino(e) && a.Cout % (16 * e.bnf) != 0) continue;                // Winograd: whole output-channel tiles only
     if (is_wino(e) && e.bnf == 4 && !wino_skips_row2(a)) continue;         // 64-channel blocks: 9-position variants only
+    if (is_wino(e) && e.bnf == 1 && wino_skips_row2(a)) continue;          // 16-channel blocks: no 9-position variant
+    if (is_wino(e) && e.bnf == 1 && a.Cout % 32 == 0) continue;            // ... and only for layers the 32-channel kernel cannot tile
+                                                                           // (the two kernels round differently: one kind per layer)
     if (is_bf16(e) && ((e.in32 != 0) == (a.in_bf16 != 0) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) continue;
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     const double c = config_cost(e, a, cu_count);
@@ -504,7 +510,7 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
       (long long)a.N * lp->tiles_h * (a.Wo / 32) * lp->cout_tiles >= 4ll * h->cu_count) {
     for (int i = 0; i < (int)r.entries.size() && lp->narrow < 0; ++i) {
       const ConvKernelEntry& p = r.entries[i];
-      if (is_wino(p) && p.dil == e.dil && p.tw == 16 && p.th == 8 && p.bnf == 2 && (!cd->out_pool || p.out_pool))
+      if (is_wino(p) && p.dil == e.dil && p.tw == 16 && p.th == 8 && p.bnf == e.bnf && (!cd->out_pool || p.out_pool))
         lp->narrow = i;
     }
   }
@@ -690,9 +696,15 @@ int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes) {
   return DLWP_OK;
 }
 
+int dlwp_conv2d_config_flags(int i) {
+  Registry& r = registry();
+  if (i < 0 || i >= (int)r.entries.size()) return 0;
+  return (is_wino(r.entries[i]) && r.entries[i].split) ? 1 : 0;
+}
+
 int dlwp_conv2d_prefers_unfused_pool(int cin, int cout, int kh, int kw, int dil_h, int dil_w) {
   return (winograd_enabled() && kh == 3 && kw == 3 && dil_h == dil_w && (dil_h == 1 || dil_h == 2) &&
-          wino_channels_ok(cin, cout) && (size_t)cin * cout * 16 <= WINO_SCRATCH_FLOATS)
+          wino_channels_ok(cin, cout, dil_h) && (size_t)cin * cout * 16 <= WINO_SCRATCH_FLOATS)
              ? 1
              : 0;
 }
@@ -753,12 +765,15 @@ int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
   }
   Registry& r = registry();
   const ConvKernelEntry& e = r.entries[lp.primary];
-  out2[0] = dlwp_launch_info{lp.primary, (int)lp.grid, 64 * e.waves, executed_matrix_flops(e, a, lp.grid),
+  auto threads = [&](const ConvKernelEntry& k) {   // the position-split Winograd kernel runs two waves per fragment
+    return 64 * k.waves * ((is_wino(k) && k.split && !wino_skips_row2(a)) ? 2 : 1);
+  };
+  out2[0] = dlwp_launch_info{lp.primary, (int)lp.grid, threads(e), executed_matrix_flops(e, a, lp.grid),
                              is_bf16(e) ? 1 : 0};
   *n_launches = 1;
   if (lp.narrow >= 0) {
     const ConvKernelEntry& p = r.entries[lp.narrow];
-    out2[1] = dlwp_launch_info{lp.narrow, (int)lp.n_grid, 64 * p.waves, executed_matrix_flops(p, a, lp.n_grid), 0};
+    out2[1] = dlwp_launch_info{lp.narrow, (int)lp.n_grid, threads(p), executed_matrix_flops(p, a, lp.n_grid), 0};
     *n_launches = 2;
   }
   return DLWP_OK;

@@ -89,8 +89,8 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
     int s = tid + q * C::NT;
     if (q == C::NPP - 1 && s >= C::NPAIR) s = 0;
     const int lr = s / C::LCH, lc = 2 * (s - lr * C::LCH);
-    const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
-    const int cs = dlwp_map_coord(j0 + lc - a.pad_left - e_al, a.W, a.mode_w);
+    const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
+    const int cs = dlwp_map_coord_tile(j0 + lc - a.pad_left - e_al, a.W, a.mode_w);
     const bool ok = rs >= 0 && cs >= 0;
     const int g = ups ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
     goff[q] = ok ? (unsigned)g * ESZ_IN : 0x7ffffff0u;

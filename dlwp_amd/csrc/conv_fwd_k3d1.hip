@@ -1,6 +1,6 @@
 // conv_fwd_k3d1.hip -- 3x3, dilation 1 tile configurations (U-Net layers 2-4: examples/train.py:174-199).
 #include "conv_fwd_packn_kernel.h"
-#include "conv_fwd_wino_kernel.h"
+#include "conv_fwd_wino2_kernel.h"
 //                         KS DIL TH  TW  WAVES FA BNF CK
 static const ConvKernelEntry k_table[] = {
     CONV_ENTRY(3, 1, 4, 45, 4, 3, 2, 16),
@@ -43,6 +43,11 @@ static const ConvKernelEntry k_table[] = {
     WINO_ENTRY(1, 4, 64, 4, 2, 8),
     WINO_ENTRY(1, 8, 16, 2, 2, 8),
     WINO_ENTRY(1, 4, 32, 2, 2, 8),
+    // 16 output channels per block (the restated output layer: 32 -> 4 fields x 4 phases): positions split over two
+    // waves per tile fragment (conv_fwd_wino2_kernel.h)
+    WINO2_ENTRY(1, 8, 32, 4, 1, 8),
+    WINO2_ENTRY(1, 4, 64, 4, 1, 8),
+    WINO2_ENTRY(1, 8, 16, 2, 1, 8),
 };
 const ConvKernelEntry* dlwp_conv_table_k3d1(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));

@@ -38,7 +38,18 @@ struct ConvArgs {
   int in_bf16, out_bf16;  // storage of x / y: 0 = float32, 1 = bfloat16 (w, bias fp32)
   int compute_bf16;       // DLWP_COMPUTE_BF16: a float32-stored input may be rounded to bf16 for the bf16 matrix cores
   int col0 = 0;           // Winograd: first output column of this launch (a wide-tile launch + a narrow one for the rest)
+#ifdef DLWP_PHASE_TIMING  // tools/microbench/wino_phase_timing.hip only: s_memtime stamps of wave 0, 8 per block
+  long long* dbg = nullptr;
+#endif
 };
+#ifdef DLWP_PHASE_TIMING
+#define DLWP_STAMP(k)                                                                                   \
+  do {                                                                                                  \
+    if (a.dbg && threadIdx.x == 0) a.dbg[(long long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define DLWP_STAMP(k) do { } while (0)
+#endif
 
 template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool POOL_ = false>
 struct ConvCfg {
@@ -66,17 +77,19 @@ struct ConvCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
 
-// tanh(x) = sign(x) (1 - t) / (1 + t),  t = e^{-2|x|} = exp2(-2 log2(e) |x|): two transcendental instructions (v_exp_f32,
-// v_rcp_f32) + 4 vector ops.  The epilogues are vector-bound (the fp32 MFMA shares the SIMD's lanes with them), and tanh
-// on every output was their largest item; the rational 13/6 approximation Eigen / TensorFlow evaluate (what the
-// reference's Keras Conv2D(activation='tanh') computes: 17 vector ops, max abs error 3.0e-7 measured on gfx950) is kept
-// below as dlwp_tanh_rational.  Measured over [-12, 12]: max abs error 1.3e-7; the subtraction 1 - t loses RELATIVE
-// accuracy for tiny arguments (2.4e-4 at |x| = 2.4e-4), below that tanh(x) = x to 2e-8 relative and x is returned.
+// tanh(x) = 2 / (1 + t) - 1,  t = e^{-2x} = exp2(-2 log2(e) x): v_mul, v_exp_f32, v_add, v_rcp_f32, v_fma -- FIVE vector
+// instructions.  The epilogues are vector-bound: on gfx950 the fp32 matrix instruction and the vector ALU exclude each
+// other on a SIMD (tools/microbench/mfma_valu_overlap.hip: 8 MFMA + 32 FMA per iteration take the SUM of the two alone, from
+// the same wave or from another wave of the SIMD), so every vector instruction of an epilogue is matrix time lost, and
+// tanh on every output is the epilogues' largest item.  The form used before, sign(x)(1 - t)/(1 + t) on |x| with a small-
+// argument branch, took 9; the rational 13/6 approximation Eigen / TensorFlow evaluate (what the reference's Keras
+// Conv2D(activation='tanh') computes) takes 17 and is kept below as dlwp_tanh_rational.  Saturation is exact (t -> inf:
+// rcp -> 0 -> -1; t -> 0: 1), NaN propagates.  Absolute error <= 2.4e-7 over [-12, 12] (tests/test_gpu_kernels.py measures
+// it): one rounding of 1 + t, 1 ulp of v_rcp_f32, one of the fma; the RELATIVE accuracy of results near zero is that
+// absolute figure over |x|, which the parity bar (1e-5 of the output scale) does not ask for.
 __device__ __forceinline__ float dlwp_tanh(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * ax);
-  const float r = (1.f - t) * __builtin_amdgcn_rcpf(1.f + t);
-  return ax < 2.44140625e-4f ? x : copysignf(r, x);  // NaN: the compare is false and r is NaN
+  const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * x);
+  return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + t), -1.f);
 }
 
 __device__ __forceinline__ float dlwp_tanh_rational(float x) {
@@ -166,8 +179,8 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
     // only the last position of a thread can fall outside the tile (NPOS = ceil(LR*LC / NT))
     const bool in_tile = (q < C::NPOS - 1) || s < C::LR * C::LC;
     const int lr = s / C::LC, lc = s - lr * C::LC;
-    const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
-    const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
+    const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
+    const int cs = dlwp_map_coord_tile(j0 + lc - a.pad_left, a.W, a.mode_w);
     const bool ok = in_tile && rs >= 0 && cs >= 0;
     int g = 0;
     if (ok) {
@@ -469,6 +482,8 @@ struct ConvKernelEntry {
   void (*launch)(const ConvArgs&, int grid, hipStream_t s);
   int (*prepare)();
   int in32 = 0;  // bf16-MFMA instances: 1 = the input is stored as float32 and rounded to bf16 by the loader
+  int split = 0; // Winograd: 1 = the 16-position case runs conv_fwd_wino2_kernel.h (positions split over two waves per
+                 // tile fragment: 2 x waves x 64 threads); the 9-position variants are the same for both
 };
 
 template <class C>

@@ -78,8 +78,8 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArg
     int s = tid + q * C::NT;
     if (q == C::NPOS - 1 && s >= C::LR * C::LC) s = 0;
     const int lr = s / C::LC, lc = s - lr * C::LC;
-    const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
-    const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
+    const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
+    const int cs = dlwp_map_coord_tile(j0 + lc - a.pad_left, a.W, a.mode_w);
     const bool ok = rs >= 0 && cs >= 0;
     const int g = (a.src_mode == DLWP_SRC_UPSAMPLE2) ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
     goff[q] = ok ? (unsigned)g * esz : 0x7ffffff0u;

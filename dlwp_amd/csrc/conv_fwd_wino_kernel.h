@@ -92,6 +92,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DLWP_STAMP(0);
 
   int L;
   {
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     int s = tid + q * C::NT;
     if (q == C::NPOS - 1 && s >= C::LR * C::LC) s = 0;
     const int lr = s / C::LC, lc = s - lr * C::LC;
-    const int rs = dlwp_map_coord(i0 + lr - a.pad_top, a.H, a.mode_h);
-    const int cs = dlwp_map_coord(j0 + lc - a.pad_left, a.W, a.mode_w);
+    const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
+    const int cs = dlwp_map_coord_tile(j0 + lc - a.pad_left, a.W, a.mode_w);
     const bool ok = rs >= 0 && cs >= 0;
     const int g = (a.src_mode == DLWP_SRC_UPSAMPLE2) ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
     goff[q] = ok ? (unsigned)g * (C::IN16 ? 2u : 4u) : 0x7ffffff0u;
@@ -153,11 +154,14 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   const int b_lane = ((lane >> 4) * C::BN + (lane & 15)) * 4;
   const int last_c0 = ((a.Cin + C::CK - 1) / C::CK - 1) * C::CK;   // (Cin may be ragged: the planes past it read 0)
 
+  // (Measured, r2e: starting the accumulation from a literal-zero C operand in a peeled first chunk instead of clearing the
+  // accumulators -- 128 v_mov per lane -- costs 23 registers and a third copy of the loop body and gained nothing.)
   f32x4 acc[16][C::BNF];
 #pragma unroll
   for (int xy = 0; xy < 16; ++xy)
 #pragma unroll
-    for (int g = 0; g < C::BNF; ++g) acc[xy][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < C::BNF; ++g)
+      if (!(C::UPS && (xy / 4 == 2 || xy % 4 == 2))) acc[xy][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float xr[C::CK][C::NPOS];
   f32x4 ur[C::NUI][2];  // two xy quads at a time: (0,1) loaded a chunk ahead, (2,3) half a chunk ahead
@@ -220,16 +224,27 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   };
 
   // ---- prologue: chunk 0 staged, chunk 1 in registers, V(group 0, chunk 0) and the first B fragments loaded
+  //      Every global load of chunk 0 -- the input tile AND all four filter quads -- is in flight before the first wait
+  //      (the loop's two filter staging slots would serialise three memory latencies here; the prologue has the registers
+  //      for all four quads, nothing else is live yet).
 #pragma unroll
   for (int i = 0; i < C::NXI; ++i) load_x(0, i);
+  {
+    f32x4 up[C::NUI][4];
 #pragma unroll
-  for (int i = 0; i < C::NXI; ++i) stage_x(0, i);
+    for (int k = 0; k < C::NUI; ++k)
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+      for (int r = 0; r < 4; ++r)
+        if (!(C::UPS && r == 2))
+          up[k][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off[k], r * a.Cout * 16, 0));
 #pragma unroll
-    for (int h = 0; h < 2 * C::NUI; ++h) load_u(0, h >> 1, (h & 1) + 2 * half);
+    for (int i = 0; i < C::NXI; ++i) stage_x(0, i);
 #pragma unroll
-    for (int h = 0; h < 2 * C::NUI; ++h) stage_u(US0, h >> 1, (h & 1) + 2 * half);
+    for (int k = 0; k < C::NUI; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!(C::UPS && r == 2))
+          *(f32x4*)(lds + US0 + u_dst[k] + (C::UPS && r == 3 ? 2 : r) * C::CK * C::BN * 4) = up[k][r];
   }
   __syncthreads();
 #pragma unroll
@@ -317,6 +332,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     }
   };
   static_assert(C::NUI <= 2, "filter staging slots");
+  DLWP_STAMP(1);
   {
     int c0 = 0;
     for (; c0 + C::CK < a.Cin; c0 += 2 * C::CK) {
@@ -325,56 +341,81 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     }
     if (c0 < a.Cin) chunk(std::integral_constant<int, 0>{}, c0);
   }
+  DLWP_STAMP(2);
   __syncthreads();  // every wave is out of the loop: LDS becomes the output staging area
+  DLWP_STAMP(3);
 
-  // ---- output transform Y = A^T M A in registers, bias + activation, then [co][row][col] through LDS
+  // ---- output transform Y = A^T M A in registers, bias + activation, then [co][row][col] through LDS.  One straight-line
+  //      path per (activation, pooling kind): the runtime switches are taken ONCE, outside the loops over the lane's 4 x BNF
+  //      (tile, channel) pairs -- every vector instruction here is matrix time lost (see dlwp_tanh)
   act_dispatch(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
+    auto for_tiles = [&](auto&& body) {
 #pragma unroll
-    for (int g = 0; g < C::BNF; ++g) {
-      const int col = g * 16 + (lane & 15);
-      const float bv = a.bias ? a.bias[n0 + col] : 0.f;
+      for (int g = 0; g < C::BNF; ++g) {
+        const int col = g * 16 + (lane & 15);
+        const float bv = a.bias ? a.bias[n0 + col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = wave * 16 + (lane >> 4) * 4 + r;
-        if (t >= C::T) continue;
-        const int pc = t / (C::RTH * C::RTW), rem = t - pc * (C::RTH * C::RTW);
-        const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
-        const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
-        float m[4][4];
-#pragma unroll
-        for (int xy = 0; xy < 16; ++xy) m[xy >> 2][xy & 3] = acc[xy][g][r];
-        float s[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {  // A^T m
-          s[0][c] = m[0][c] + m[1][c] + m[2][c];
-          s[1][c] = m[1][c] - m[2][c] - m[3][c];
-        }
-        if constexpr (C::DIL == 1) {
-          if (a.out_pool == 2) {  // 2x2 sum: 1^T A^T M A 1 with A 1 = (1, 2, 0, -1) -- row / column 2 of M drop out
-            const float t0 = s[0][0] + s[1][0], t1 = s[0][1] + s[1][1], t3 = s[0][3] + s[1][3];
-            lds[col * C::OPS + ti * (C::TW / 2) + tj] = t0 + 2.f * t1 - t3;
-            continue;
+        for (int r = 0; r < 4; ++r) {
+          const int t = wave * 16 + (lane >> 4) * 4 + r;
+          if constexpr (C::T < C::TPAD) {
+            if (t >= C::T) continue;
           }
-          if (a.out_pool) {  // MaxPooling2D(2): the lane's 2x2 output tile IS one pooling window; activation after the max
-            const float m0 = fmaxf(s[0][0] + s[0][1] + s[0][2], s[0][1] - s[0][2] - s[0][3]);
-            const float m1 = fmaxf(s[1][0] + s[1][1] + s[1][2], s[1][1] - s[1][2] - s[1][3]);
-            lds[col * C::OPS + ti * (C::TW / 2) + tj] = act_apply_c<ACT>(fmaxf(m0, m1) + bv);
-            continue;
-          }
-        }
-        float* op = lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
+          const int pc = t / (C::RTH * C::RTW), rem = t - pc * (C::RTH * C::RTW);
+          const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
+          const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
+          // A^T m.  UPS: row 2 / column 2 of M were never multiplied (they are identically zero) and their registers
+          // hold nothing -- the terms are left out, not added as zeros
+          float s[2][4];
 #pragma unroll
-        for (int aa = 0; aa < 2; ++aa) {
-          const float y0 = act_apply_c<ACT>(s[aa][0] + s[aa][1] + s[aa][2] + bv);
-          const float y1 = act_apply_c<ACT>(s[aa][1] - s[aa][2] - s[aa][3] + bv);
-          op[aa * C::DIL * C::TW] = y0;
-          op[aa * C::DIL * C::TW + C::DIL] = y1;
+          for (int c = 0; c < 4; ++c) {
+            if (C::UPS && c == 2) {
+              s[0][c] = s[1][c] = 0.f;    // (never read below)
+            } else if (C::UPS) {
+              s[0][c] = acc[0 * 4 + c][g][r] + acc[1 * 4 + c][g][r];
+              s[1][c] = acc[1 * 4 + c][g][r] - acc[3 * 4 + c][g][r];
+            } else {
+              s[0][c] = acc[0 * 4 + c][g][r] + acc[1 * 4 + c][g][r] + acc[2 * 4 + c][g][r];
+              s[1][c] = acc[1 * 4 + c][g][r] - acc[2 * 4 + c][g][r] - acc[3 * 4 + c][g][r];
+            }
+          }
+          body(s, col, bv, ti, tj, pi, pj);
         }
       }
+    };
+    if constexpr (C::DIL == 1) {
+      if (a.out_pool == 2) {  // 2x2 sum: 1^T A^T M A 1 with A 1 = (1, 2, 0, -1) -- row / column 2 of M drop out
+        for_tiles([&](const float (&s)[2][4], int col, float, int ti, int tj, int, int) {
+          const float t0 = s[0][0] + s[1][0], t1 = s[0][1] + s[1][1], t3 = s[0][3] + s[1][3];
+          lds[col * C::OPS + ti * (C::TW / 2) + tj] = t0 + 2.f * t1 - t3;
+        });
+        return;
+      }
+      if (a.out_pool) {  // MaxPooling2D(2): the lane's 2x2 output tile IS one pooling window; activation after the max
+        for_tiles([&](const float (&s)[2][4], int col, float bv, int ti, int tj, int, int) {
+          const float m0 = C::UPS ? fmaxf(s[0][0] + s[0][1], s[0][1] - s[0][3])
+                                  : fmaxf(s[0][0] + s[0][1] + s[0][2], s[0][1] - s[0][2] - s[0][3]);
+          const float m1 = C::UPS ? fmaxf(s[1][0] + s[1][1], s[1][1] - s[1][3])
+                                  : fmaxf(s[1][0] + s[1][1] + s[1][2], s[1][1] - s[1][2] - s[1][3]);
+          lds[col * C::OPS + ti * (C::TW / 2) + tj] = act_apply_c<ACT>(fmaxf(m0, m1) + bv);
+        });
+        return;
+      }
     }
+    for_tiles([&](const float (&s)[2][4], int col, float bv, int ti, int tj, int pi, int pj) {
+      float* op = lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa) {
+        const float y0 = act_apply_c<ACT>((C::UPS ? s[aa][0] + s[aa][1] : s[aa][0] + s[aa][1] + s[aa][2]) + bv);
+        const float y1 = act_apply_c<ACT>((C::UPS ? s[aa][1] - s[aa][3] : s[aa][1] - s[aa][2] - s[aa][3]) + bv);
+        op[aa * C::DIL * C::TW] = y0;
+        op[aa * C::DIL * C::TW + C::DIL] = y1;
+      }
+    });
   });
+  DLWP_STAMP(4);
   __syncthreads();
+  DLWP_STAMP(5);
   {
     // dilation 1: the staging area holds the pooled tile [co][TH/2][TW/2] (the lane's 2x2 tile was one pooling window);
     // dilation 2: it holds the full activated tile [co][TH][TW] (a window's four outputs come from four parity classes, i.e.
@@ -421,6 +462,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
           }
         }
       }
+      DLWP_STAMP(6);
       return;
     }
   }
@@ -457,6 +499,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         if (ow + r < a.Wo) yp[r] = o[r];
     }
   }
+  DLWP_STAMP(6);
 }
 
 template <class C>

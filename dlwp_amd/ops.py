@@ -256,14 +256,14 @@ def series_merge_time(series, time_dim):
 
 
 def conv_configs():
-    """[(ks, dil, th, tw, waves, frags_per_wave, cout_frags, channel_chunk, pooled_loader, lds_bytes)] of the compiled
-    MFMA tiles."""
+    """[(ks, dil, th, tw, waves, frags_per_wave, cout_frags, channel_chunk, pooled_loader, lds_bytes, flags)] of the
+    compiled MFMA tiles (flags bit 0: position-split Winograd instance, dlwp_conv2d_config_flags)."""
     out = []
     info = (ctypes.c_int * 9)()
     lds = ctypes.c_int()
     for i in range(_lib.lib.dlwp_conv2d_num_configs()):
         _lib.check(_lib.lib.dlwp_conv2d_config_info(i, info, ctypes.byref(lds)))
-        out.append(tuple(info) + (lds.value,))
+        out.append(tuple(info) + (lds.value, int(_lib.lib.dlwp_conv2d_config_flags(i))))
     return out
 
 
@@ -529,7 +529,7 @@ def wgrad_configs():
     lds = ctypes.c_int()
     for i in range(_lib.lib.dlwp_conv2d_wgrad_num_configs()):
         _lib.check(_lib.lib.dlwp_conv2d_wgrad_config_info(i, info, ctypes.byref(lds)))
-        out.append(tuple(info) + (lds.value,))
+        out.append(tuple(info) + (lds.value, int(_lib.lib.dlwp_conv2d_config_flags(i))))
     return out
 
 

@@ -126,6 +126,8 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const vo
  * Not part of the drop-in surface.                                                                                  */
 int dlwp_conv2d_num_configs(void);
 int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes);
+int dlwp_conv2d_config_flags(int i);        /* bit 0: Winograd instance whose 16-position case splits the positions over two
+                                              * waves per tile fragment (conv_fwd_wino2_kernel.h: 2 x waves x 64 threads) */
 int dlwp_conv2d_force_config(int i);
 int dlwp_conv2d_set_winograd(int enable);   /* 3x3 layers with cin % 8 == 0, cout % 32 == 0: Winograd F(2x2,3x3)
                                               * (default) or the direct implicit GEMM */

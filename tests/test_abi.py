@@ -60,7 +60,7 @@ def test_compiled_tile_configurations_cover_the_unet_layers():
     kinds = {(c[0], c[1]) for c in cfgs}
     assert {(3, 1), (3, 2), (5, 1)} <= kinds
     for c in cfgs:
-        ks, dil, th, tw, waves, fa, bnf, ck, pool, lds = c
+        ks, dil, th, tw, waves, fa, bnf, ck, pool, lds, flags = c
         pixels = th * tw if bnf > 0 else th * tw // (-bnf)          # packed-N instances tile super-pixels
         if fa == 0:                                                 # Winograd instance: 2x2 tiles, one fragment / wave
             pixels, fa = th * tw // 4, 1

@@ -202,7 +202,7 @@ def test_conv2d_every_compiled_tile_configuration(ops):
     cfgs = ops.conv_configs()
     problems = {}
     try:
-        for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds) in enumerate(cfgs):
+        for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds, flags) in enumerate(cfgs):
             if pool >= 2:
                 continue                                # bf16 matrix-core instances: test_conv2d_bf16_mfma_* below
             cmax = 16 // (-bnf) if bnf < 0 else 0       # packed-N instances cover cout <= 16/S
@@ -245,7 +245,7 @@ def test_winograd_nine_position_variants_of_every_instance(ops):
     try:
         for i, c in enumerate(cfgs):
             ks, dil, fa, pool = c[0], c[1], c[5], c[8]
-            if not (ks == 3 and dil == 1 and fa == 0 and pool < 2):
+            if not (ks == 3 and dil == 1 and fa == 0 and pool < 2) or c[6] == 1:   # (16-channel blocks: no such variant)
                 continue
             tried += 1
             ops.force_conv_config(i)
@@ -265,6 +265,49 @@ def test_winograd_nine_position_variants_of_every_instance(ops):
     finally:
         ops.force_conv_config(-1)
     assert tried >= 4
+
+
+@pytest.mark.parametrize('pool,in16', [(False, False), (True, False), (False, True)])
+def test_winograd_position_split_instances_for_16_output_channels(ops, pool, in16):
+    """conv_fwd_wino2_kernel.h (layers with 16 output channels per block, e.g. the restated output layer 32 -> 4 x 4): two
+    waves per tile fragment, 8 of the 16 transformed positions each, partial output transforms combined through LDS.
+    Every tile shape gives the same bits (the heuristic picks by batch size, so a member's forecast must not depend on
+    it) and equals the float64 oracle to fp32 round-off; plain and pooled epilogues, float32 and bfloat16 input; 16 and 48
+    output channels (one and three channel tiles)."""
+    rng = np.random.default_rng(96)
+    cfgs = ops.conv_configs()
+    for cout in (16, 48):
+        n, cin, h, w = 3, 24, 20, 70
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        if in16:
+            x = np_ref.round_bf16(x).astype(np.float32)
+        wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+        b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        want = _conv_ref(x, wt, b, 1, (1, 1, 1, 1), 0, 1, 'tanh', 0)
+        if pool:
+            want = np_ref.maxpool2(want)
+        xd = dev(x).to(torch.bfloat16) if in16 else dev(x)
+        cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, out_pool=pool)
+        seen, tried = None, 0
+        try:
+            for i, c in enumerate(cfgs):
+                if not (c[0] == 3 and c[1] == 1 and c[5] == 0 and c[6] == 1 and c[10] & 1):
+                    continue
+                tried += 1
+                ops.force_conv_config(i)
+                got = ops.conv2d(xd, dev(wt), dev(b), cd, out=torch.empty(want.shape, dtype=torch.float32, device='cuda'))
+                _check_conv(ops, host(got), want, 'config %d %r' % (i, c))
+                assert seen is None or torch.equal(got, seen), 'split instance %d %r differs from the others' % (i, c)
+                seen = got
+        finally:
+            ops.force_conv_config(-1)
+        assert tried >= 2
+        if not in16:      # the heuristic's choice is one of them (a bfloat16-stored input goes to the bf16 matrix-core family)
+            import ctypes
+            from dlwp_amd import _lib
+            pick = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(0), ops.Shape4(n, cin, h, w), ctypes.byref(cd))
+            assert pick >= 0 and cfgs[pick][10] & 1, 'expected a position-split Winograd instance, got %r' % (cfgs[pick],)
+            assert torch.equal(ops.conv2d(xd, dev(wt), dev(b), cd, out=torch.empty_like(seen)), seen)
 
 
 def test_winograd_wide_plus_narrow_launch_is_bit_identical(ops):
@@ -380,10 +423,11 @@ def test_conv2d_batch_invariance(ops):
 
 def test_conv2d_with_prepared_weights_is_bit_identical(ops):
     """dlwp_conv2d_prepare + dlwp_conv2d_fwd_prepared == dlwp_conv2d_fwd: Winograd (plain and up-sampled source), packed-N
-    (5x5, 4 output channels), bf16 arrangement, and a direct layer that needs no preparation (prepared is None)."""
+    (5x5, 4 output channels), bf16 arrangement, a direct layer that needs no preparation (prepared is None: 40 output channels
+    are not whole Winograd channel tiles) and the 16-channel position-split Winograd instance (48 = 3 tiles)."""
     rng = np.random.default_rng(31)
     cases = [(16, 64, 3, 1, 0, False, True), (64, 64, 3, 1, 1, False, True), (32, 4, 5, 1, 0, False, None),
-             (16, 48, 3, 1, 0, False, False), (32, 32, 3, 1, 0, True, True)]
+             (16, 40, 3, 1, 0, False, False), (16, 48, 3, 1, 0, False, True), (32, 32, 3, 1, 0, True, True)]
     for cin, cout, k, dil, src, cbf16, expect_prep in cases:
         x = dev(rng.standard_normal((3, cin, 16, 36)).astype(np.float32))
         wt = dev(np_ref.glorot_uniform((k, k, cin, cout), rng))
@@ -624,7 +668,7 @@ def test_conv2d_bf16_mfma_every_compiled_tile_configuration(ops):
     problems = {}
     seen = 0
     try:
-        for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds) in enumerate(cfgs):
+        for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds, flags) in enumerate(cfgs):
             if pool < 2:
                 continue
             seen += 1

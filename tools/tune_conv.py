@@ -25,6 +25,9 @@ def unet_layers(cin, h, w):
         # the pooled layers as the default plan runs them: plain source written by dlwp_maxpool2_fwd
         ('L2p', 32, 64, 3, 1, 0, h // 2, w // 2),
         ('L3p', 64, 128, 3, 1, 0, h // 4, w // 4),
+        # ... and as the inference plan runs them: MaxPooling2D(2) in the epilogue (name ends with 'o')
+        ('L1o', cin, 32, 3, 2, 0, h, w),
+        ('L2o', 32, 64, 3, 1, 0, h // 2, w // 2),
     ]
 
 
@@ -50,13 +53,13 @@ def main():
         b = torch.zeros(cout, device='cuda')
         p = dil * (k - 1) // 2
         cd = ops.make_conv(cout, k, k, dil, ops.make_pad(p, p, p, p, ops.PAD_ZERO, ops.PAD_WRAP), ops.ACT_TANH,
-                           src_mode=src)
+                           src_mode=src, out_pool=name.endswith('o'))
         ys = ops.conv_out_shape(ops.Shape4(a.batch, cin, sh, sw), cd)
         out = torch.empty((a.batch, cout, ys.h, ys.w), device='cuda')
-        flops = 2.0 * a.batch * ys.h * ys.w * cout * cin * k * k
+        flops = 2.0 * a.batch * ys.h * ys.w * cout * cin * k * k * (4 if name.endswith('o') else 1)
         rows = []
         for i, c in enumerate(cfgs):
-            if (c[0], c[1]) != (k, dil) or bool(c[8]) != (src == 2) or (c[6] < 0 and cout > 16 // (-c[6])):
+            if (c[0], c[1]) != (k, dil) or (c[8] == 1) != (src == 2) or c[8] >= 2 or (c[6] < 0 and cout > 16 // (-c[6])):
                 continue
             if a.cfg != -2 and i != a.cfg:
                 continue
