@@ -164,6 +164,7 @@ _sig('dlwp_convlstm_gates_bwd', [_vp] * 9 + [_i] * 8 + [_vp])
 _sig('dlwp_copy_channels', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _P(_vp)])
+_sig('dlwp_rollout_create_grouped', [_vp, _P(Op), _i, _P(_vp), _i, _P(_sz), _i, _vp, _vp, _sz, _i, _i, _i, _P(_vp)])
 _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
 _sig('dlwp_comm_unique_id', [_vp, _P(_sz)])

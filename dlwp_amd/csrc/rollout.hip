@@ -57,7 +57,38 @@ extern "C" {
 int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
                         const void* state0, void* series, size_t slot_elems, int calls, int n_outputs, int dtype,
                         dlwp_rollout_t* out) {
-  DLWP_CHECK_ARG(h && plan && out && state0 && series, "dlwp_rollout_create: null handle or pointer");
+  return dlwp_rollout_create_grouped(h, plan, n_ops, buffers, n_buffers, nullptr, 1, state0, series, slot_elems, calls,
+                                     n_outputs, dtype, out);
+}
+
+// Members (the batch axis) are independent, so the rollout may be captured as `groups` parallel chains of members / groups
+// members each: graph branches that the hardware schedules side by side.  A chain's kernels have 1 / groups of the
+// workgroups; at small batches (config 5: 4 members per GPU) a single chain leaves every launch with a partly filled last
+// round of workgroups and a drained GPU at every kernel boundary -- branches at different layers fill those gaps with
+// each other's work.  Same kernels, same per-member arithmetic (the kernel family never depends on the batch size).
+int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_ops, void* const* buffers, int n_buffers,
+                                const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
+                                size_t slot_elems, int calls, int n_outputs, int dtype, dlwp_rollout_t* out) {
+  DLWP_CHECK_ARG(h && plan_in && out && state0 && series, "dlwp_rollout_create: null handle or pointer");
+  DLWP_CHECK_ARG(groups >= 1 && groups <= 64, "dlwp_rollout_create: %d member groups", groups);
+  DLWP_CHECK_ARG(groups == 1 || buffer_sample_bytes, "dlwp_rollout_create: member groups need the per-member buffer sizes");
+  int members = 0;
+  for (int i = 0; i < n_ops; ++i)
+    if (plan_in[i].kind != DLWP_OP_PHASE_WEIGHTS) {
+      members = plan_in[i].xs.n;
+      break;
+    }
+  DLWP_CHECK_ARG(members > 0 && members % groups == 0, "dlwp_rollout_create: %d members do not split into %d equal groups",
+                 members, groups);
+  const int gn = members / groups;
+  // the plan of ONE group: every member-indexed op runs on gn members (tile choice and prepared weights follow from that)
+  std::vector<dlwp_op> gplan(plan_in, plan_in + n_ops);
+  for (int i = 0; i < n_ops; ++i)
+    if (gplan[i].kind != DLWP_OP_PHASE_WEIGHTS) {
+      DLWP_CHECK_ARG(gplan[i].xs.n == members, "rollout op %d: batch %d differs from %d", i, gplan[i].xs.n, members);
+      gplan[i].xs.n = gn;
+    }
+  const dlwp_op* plan = gplan.data();
   DLWP_CHECK_ARG(n_ops > 0 && calls > 0 && n_outputs > 0 && slot_elems > 0, "dlwp_rollout_create: bad sizes");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_rollout_create: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(n_buffers == 0 || buffers, "dlwp_rollout_create: null buffer table");
@@ -81,15 +112,18 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
                        "rollout op %d: aux buffer %d out of range", i, op.aux[k]);
   }
   const size_t esz = sizeof(float);
-  auto resolve = [&](int idx, int call, bool is_src) -> void* {
-    if (idx >= 0) return buffers[idx];
+  DLWP_CHECK_ARG(slot_elems % members == 0, "dlwp_rollout_create: slot of %zu elements for %d members", slot_elems, members);
+  const size_t member_elems = slot_elems / members;
+  // buffer of member group g (first member g * gn): scratch buffers by their per-member size, state / series by slot layout
+  auto resolve = [&](int idx, int call, int g) -> void* {
+    const size_t lo = (size_t)g * gn;
+    if (idx >= 0) return (char*)buffers[idx] + (buffer_sample_bytes ? lo * buffer_sample_bytes[idx] : 0);
     if (idx == DLWP_BUF_STATE_IN) {
-      if (call == 0) return const_cast<void*>(state0);
-      return (char*)series + ((size_t)call * n_outputs - 1) * slot_elems * esz;
+      if (call == 0) return (char*)const_cast<void*>(state0) + lo * member_elems * esz;
+      return (char*)series + (((size_t)call * n_outputs - 1) * slot_elems + lo * member_elems) * esz;
     }
     const int o = -2 - idx;  // DLWP_BUF_OUT(o)
-    (void)is_src;
-    return (char*)series + ((size_t)call * n_outputs + o) * slot_elems * esz;
+    return (char*)series + (((size_t)call * n_outputs + o) * slot_elems + lo * member_elems) * esz;
   };
 
   // Winograd / packed-N layers: the weights do not change inside one graph launch, so their preparation runs ONCE at the head
@@ -130,20 +164,50 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
   if (wino_u)
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
       if (u_off[i] >= 0) rc = dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, plan[i].aux[0], cap);
-  for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
-    for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
-      const dlwp_op& op = plan[i];
-      if (op.kind == DLWP_OP_PHASE_WEIGHTS) continue;   // done once, at the head of the graph
-      const void* w = op.kind == DLWP_OP_CONV2D ? buffers[op.w] : nullptr;
-      const void* b = (op.kind == DLWP_OP_CONV2D && op.b >= 0) ? buffers[op.b] : nullptr;
-      void* aux[3] = {nullptr, nullptr, nullptr};
-      if (op.kind == DLWP_OP_LSTM_GATES)
-        for (int k = 0; k < 3; ++k) aux[k] = op.aux[k] == DLWP_BUF_NONE ? nullptr : buffers[op.aux[k]];
-      rc = enqueue_op(h, op, resolve(op.src, t, true), resolve(op.dst, t, false), w, b, dtype, cap, aux,
-                      (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr);
+  // one chain of `calls` forwards per member group; groups > 1: parallel branches forked after the weight preparation
+  auto chain = [&](int g, hipStream_t s) {
+    for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
+      for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
+        const dlwp_op& op = plan[i];
+        if (op.kind == DLWP_OP_PHASE_WEIGHTS) continue;   // done once, at the head of the graph
+        const void* w = op.kind == DLWP_OP_CONV2D ? buffers[op.w] : nullptr;
+        const void* b = (op.kind == DLWP_OP_CONV2D && op.b >= 0) ? buffers[op.b] : nullptr;
+        void* aux[3] = {nullptr, nullptr, nullptr};
+        if (op.kind == DLWP_OP_LSTM_GATES)
+          for (int k = 0; k < 3; ++k) aux[k] = op.aux[k] == DLWP_BUF_NONE ? nullptr : resolve(op.aux[k], t, g);
+        rc = enqueue_op(h, op, resolve(op.src, t, g), resolve(op.dst, t, g), w, b, dtype, s, aux,
+                        (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr);
+      }
     }
+  };
+  std::vector<hipStream_t> branch;
+  std::vector<hipEvent_t> events;
+  if (groups == 1) {
+    chain(0, cap);
+  } else {
+    hipEvent_t fork = nullptr;
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventRecord(fork, cap) != hipSuccess) rc = DLWP_EHIP;
+    if (fork) events.push_back(fork);
+    for (int g = 0; g < groups && rc == DLWP_OK; ++g) {
+      hipStream_t s = cap;
+      if (g > 0) {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { rc = DLWP_EHIP; break; }
+        branch.push_back(s);
+        if (hipStreamWaitEvent(s, fork, 0) != hipSuccess) { rc = DLWP_EHIP; break; }   // joins the capture
+      }
+      chain(g, s);
+      if (g > 0 && rc == DLWP_OK) {
+        hipEvent_t done = nullptr;
+        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess || hipEventRecord(done, s) != hipSuccess ||
+            hipStreamWaitEvent(cap, done, 0) != hipSuccess) rc = DLWP_EHIP;
+        if (done) events.push_back(done);
+      }
+    }
+    if (rc == DLWP_EHIP) dlwp_set_error("dlwp_rollout_create: forking the capture into %d member groups failed", groups);
   }
   e = hipStreamEndCapture(cap, &graph);
+  for (hipStream_t s : branch) (void)hipStreamDestroy(s);
+  for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
   (void)hipStreamDestroy(cap);
   if (rc != DLWP_OK) {
     if (graph) (void)hipGraphDestroy(graph);

@@ -148,7 +148,19 @@ class Executor(object):
         return outs
 
     # -- hipGraph rollout -------------------------------------------------------------------------------------------- #
-    def make_rollout(self, state0, series, calls):
+    @staticmethod
+    def member_groups(n):
+        """How many parallel member chains a rollout of n members is captured as (dlwp_rollout_create_grouped).  Members are
+        independent, so chains at different layers could fill the gaps each other's launches leave (partly filled last
+        rounds of workgroups, kernel boundaries).  Measured on one MI355X (profiles/r2i_rollout_member_groups.txt): within
+        run-to-run noise of a single chain at 4 members of config 5 (49.1 k vs 45.0 / 47.5 k steps/s with 2 / 4 chains) and
+        +4 ... +7 % at 32 - 64 members -- the default stays ONE chain; DLWP_ROLLOUT_GROUPS=g asks for g."""
+        g = max(1, min(int(os.environ.get('DLWP_ROLLOUT_GROUPS', '1')), max(n, 1)))
+        while n % g:
+            g -= 1
+        return g
+
+    def make_rollout(self, state0, series, calls, groups=None):
         """Capture `calls` model applications.  state0: (n,)+input store; series: (calls*n_out, n)+store, contiguous."""
         from . import _lib, ops
         n = state0.shape[0]
@@ -215,9 +227,14 @@ class Executor(object):
         slot = int(np.prod(self.plan._in_store)) * n
         out = ctypes.c_void_p()
         dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        _lib.check(_lib.lib.dlwp_rollout_create(_lib.handle(dev), arr, len(self.plan.ops), ptrs, len(table),
-                                                ctypes.c_void_p(state0.data_ptr()), ctypes.c_void_p(series.data_ptr()),
-                                                slot, int(calls), n_out, _lib.F32, ctypes.byref(out)))
+        groups = self.member_groups(n) if groups is None else int(groups)
+        nbuf = len(bufs)
+        sample_bytes = (ctypes.c_size_t * max(1, len(table)))(
+            *[(t[0].numel() * t.element_size() if (i < nbuf and n > 0) else 0) for i, t in enumerate(table)])
+        _lib.check(_lib.lib.dlwp_rollout_create_grouped(_lib.handle(dev), arr, len(self.plan.ops), ptrs, len(table),
+                                                        sample_bytes, groups, ctypes.c_void_p(state0.data_ptr()),
+                                                        ctypes.c_void_p(series.data_ptr()), slot, int(calls), n_out,
+                                                        _lib.F32, ctypes.byref(out)))
         return RolloutGraph(out, keep=(table, state0, series, arr, ptrs), device=self.device)
 
 

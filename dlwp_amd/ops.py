@@ -529,7 +529,7 @@ def wgrad_configs():
     lds = ctypes.c_int()
     for i in range(_lib.lib.dlwp_conv2d_wgrad_num_configs()):
         _lib.check(_lib.lib.dlwp_conv2d_wgrad_config_info(i, info, ctypes.byref(lds)))
-        out.append(tuple(info) + (lds.value, int(_lib.lib.dlwp_conv2d_config_flags(i))))
+        out.append(tuple(info) + (lds.value,))
     return out
 
 

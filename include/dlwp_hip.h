@@ -311,6 +311,13 @@ typedef struct dlwp_rollout* dlwp_rollout_t;
 int dlwp_rollout_create(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
                         const void* state0, void* series, size_t slot_elems, int calls, int n_outputs, int dtype,
                         dlwp_rollout_t* out);
+/* The same with the members (xs.n of the ops) split into `groups` equal parts captured as parallel graph branches:
+ * members are independent, so a small ensemble (config 5: 4 members per GPU) runs as several chains whose kernels fill the
+ * gaps each other's launches leave.  buffer_sample_bytes[i] = bytes ONE member occupies in scratch buffer i (0 for weight
+ * / bias buffers); the member count must be a multiple of groups.  groups = 1 is dlwp_rollout_create.                  */
+int dlwp_rollout_create_grouped(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
+                                const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
+                                size_t slot_elems, int calls, int n_outputs, int dtype, dlwp_rollout_t* out);
 int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
 int dlwp_rollout_destroy(dlwp_rollout_t);
 

@@ -171,6 +171,30 @@ def test_member_sharding_is_bit_identical():
         assert np.array_equal(d.predict_timeseries(members[lo:hi], 6), full[:, lo:hi])
 
 
+def test_rollout_captured_as_parallel_member_chains_is_bit_identical():
+    """dlwp_rollout_create_grouped: the members split into equal groups captured as parallel graph branches (each chain runs
+    the plan on its own members of every buffer) -- same forecasts, bit for bit, as one chain."""
+    rng = np.random.default_rng(6)
+    cs = (4, 16, 24)
+    d = _build(unet_layers(cs), time_dim=2)
+    _weights_of(d.model, rng)
+    net = d.model
+    x = torch.from_numpy(rng.standard_normal((6,) + cs).astype(np.float32)).to(net.device)
+    want = net.rollout_on_device(x, 5, graph_cache=False).clone()
+    for groups in (2, 3, 6):
+        s0 = torch.empty_like(x)
+        ser = torch.empty_like(want)
+        g = net.executor.make_rollout(s0, ser, 5, groups=groups)
+        s0.copy_(x)
+        g.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(ser, want), groups
+        g.close()
+    from dlwp_amd._lib import DlwpError
+    with pytest.raises(DlwpError, match='equal groups'):
+        net.executor.make_rollout(torch.empty_like(x), torch.empty_like(want), 5, groups=4)
+
+
 def test_functional_skip_unet_and_chained_outputs():
     from dlwp_amd import custom, layers as L
     from dlwp_amd.engine import Model
@@ -870,9 +894,10 @@ def test_time_series_estimator_runs_the_device_rollout_for_matching_io():
     assert out.shape == (6, n, 2, 1, h, w)
     X, _ = g.generate([], scale_and_impute=False)
     ser = d.predict_timeseries(X, 6)                                  # (6, n, 2, h, w)
-    valid0 = n - 4
-    assert np.array_equal(out.values[:, :valid0, :, 0], ser[:, :valid0])
-    assert np.isnan(out.values[2:4, n - 2:]).all() and np.isfinite(out.values[:2]).all()
+    # every row at every lead (the forecast overwrites all inputs: tests/golden/estimator.npz 'same'); the variables come
+    # back in sorted label order ('t', 'z'), as the reference's unstack gives them
+    assert list(out.coords['variable']) == ['t', 'z']
+    assert np.array_equal(out.values[:, :, ::-1, 0], ser) and np.isfinite(out.values).all()
     # insolation as an extra input channel per time step: in != out -> host stepping around the device forward
     d2 = _build(unet_layers((6, h, w), widths=(8, 16, 16, 16, 8), cout=4), time_dim=2)
     _weights_of(d2.model, rng)
@@ -880,7 +905,7 @@ def test_time_series_estimator_runs_the_device_rollout_for_matching_io():
     out2 = TimeSeriesEstimator(d2, g2).predict(4)
     X2, _ = g2.generate([], scale_and_impute=False)
     first = d2.predict(X2).reshape(n, 2, 2, h, w)
-    assert np.array_equal(out2.values[0, :, :, 0], first[:, 0]) and np.array_equal(out2.values[1, :, :, 0], first[:, 1])
+    assert np.array_equal(out2.values[0, :, ::-1, 0], first[:, 0]) and np.array_equal(out2.values[1, :, ::-1, 0], first[:, 1])
     assert np.isfinite(out2.values[2:, :n - 2]).all()
 
 
