@@ -13,6 +13,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 static inline int grid_for(long long work_items, int block, int cu_count) {
   long long want = (work_items + block - 1) / block;
   long long cap = (long long)cu_count * 8;
@@ -101,7 +103,94 @@ __global__ __launch_bounds__(256) void pad2d_fwd_kernel(const float* __restrict_
   }
 }
 
-// pad2d backward (adjoint), gather form: every dx element sums the dy positions that were copies of it.
+// pad2d backward (adjoint), row-staged like the forward: a wave owns ROWS dx rows at a time, pulls their INTERIOR dy rows
+// (row h + top of the padded gradient: where all but 2 * halo / H of the rows get everything from) into its LDS slice with
+// aligned vector loads -- every dy byte of those rows read once, coalesced -- and emits the dx rows with aligned vector
+// stores whose lanes add the column images (interior column + wrapped / clamped halo columns) out of LDS.  The few dx rows
+// that are also the image of halo ROWS (the first / last `bottom` / `top` rows of a periodic axis, row 0 / H-1 of an edge
+// axis) add those rows straight from global memory.  Fixed summation order per element: deterministic.
+template <int VEC, bool INNER1>
+__global__ __launch_bounds__(256) void pad2d_bwd_rows_kernel(const float* __restrict__ dy, float* __restrict__ dx, int outer,
+                                                             int H, int W, int inner, int Ho, int Wo, int top, int bottom,
+                                                             int left, int right, int mode_h, int mode_w, int row_lds) {
+  constexpr int ROWS = 4;
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* slot = lds + wave * ROWS * row_lds;
+  const int RI = W * inner, RO = Wo * inner;
+  const int RIV = RI / VEC, ROV = RO / VEC;
+  const long long n_rows = (long long)outer * H;
+  const long long stride = (long long)gridDim.x * 4 * ROWS;
+  // sum of the dy columns of one dy row (rp: LDS or global) that are images of dx column w, channel ch
+  auto col_sum = [&](const float* rp, int w, int ch) {
+    const int in = INNER1 ? 1 : inner;
+    float s = rp[(w + left) * in + ch];
+    if (mode_w == DLWP_PAD_WRAP) {
+      if (w >= W - left) s += rp[(w - (W - left)) * in + ch];
+      if (w < right) s += rp[(left + W + w) * in + ch];
+    } else if (mode_w == DLWP_PAD_EDGE) {
+      if (w == 0)
+        for (int c = 0; c < left; ++c) s += rp[c * in + ch];
+      if (w == W - 1)
+        for (int c = left + W; c < Wo; ++c) s += rp[c * in + ch];
+    }
+    return s;
+  };
+  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * ROWS; r0 < n_rows; r0 += stride) {
+    for (int j = lane; j < ROWS * ROV; j += 64) {
+      const int k = (j >= ROV) + (j >= 2 * ROV) + (j >= 3 * ROV);
+      const int c = (j - k * ROV) * VEC;
+      const long long r = r0 + k;
+      if (r < n_rows) {
+        const long long o = r / H;
+        const int hh = (int)(r - o * H);
+        *(vec_t*)(slot + k * row_lds + c) = *(const vec_t*)(dy + (o * Ho + hh + top) * RO + c);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = lane; j < ROWS * RIV; j += 64) {
+      const int k = (j >= RIV) + (j >= 2 * RIV) + (j >= 3 * RIV);
+      const int c = (j - k * RIV) * VEC;
+      const long long r = r0 + k;
+      if (r >= n_rows) continue;
+      const long long o = r / H;
+      const int hh = (int)(r - o * H);
+      const float* row = slot + k * row_lds;
+      const float* img = dy + o * Ho * RO;        // this image's padded gradient, for the halo-row images
+      vec_t v;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        const int e = c + q;
+        int w = e, ch = 0;
+        if (!INNER1) {
+          w = e / inner;
+          ch = e - w * inner;
+        }
+        float acc = col_sum(row, w, ch);
+        if (mode_h == DLWP_PAD_WRAP) {
+          if (hh >= H - top) acc += col_sum(img + (long long)(hh - (H - top)) * RO, w, ch);
+          if (hh < bottom) acc += col_sum(img + (long long)(top + H + hh) * RO, w, ch);
+        } else if (mode_h == DLWP_PAD_EDGE) {
+          if (hh == 0)
+            for (int rr = 0; rr < top; ++rr) acc += col_sum(img + (long long)rr * RO, w, ch);
+          if (hh == H - 1)
+            for (int rr = top + H; rr < Ho; ++rr) acc += col_sum(img + (long long)rr * RO, w, ch);
+        }
+        v[q] = acc;
+      }
+      *(vec_t*)(dx + r * RI + c) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// pad2d backward, gather form (rows too long for the LDS-staged kernel): every dx element sums the dy positions that
+// were copies of it.
 __global__ __launch_bounds__(256) void pad2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int outer,
                                                         int H, int W, int inner, int Ho, int Wo, int top, int bottom,
                                                         int left, int right, int mode_h, int mode_w) {
@@ -243,6 +332,37 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const float* __restr
   }
 }
 
+// even W: a thread takes a PAIR of source elements (one 8-byte load) and writes two 16-byte row segments {a, a, b, b}
+__global__ __launch_bounds__(256) void upsample2_fwd_pair_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 long long planes, int H, int W) {
+  const int Wh = W / 2, W2 = 2 * W;
+  const long long total = planes * H * Wh;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Wh);
+    const long long q = i / Wh;  // = p*H + r
+    const f32x2 v = *(const f32x2*)(x + q * W + 2 * j);
+    float* d = y + (2 * q) * W2 + 4 * j;   // 16-byte aligned: 2q*2W and 4j are multiples of 4
+    const f32x4 vv = {v[0], v[0], v[1], v[1]};
+    *(f32x4*)d = vv;
+    *(f32x4*)(d + W2) = vv;
+  }
+}
+
+// even W: two outputs per thread from two 16-byte loads
+__global__ __launch_bounds__(256) void upsample2_bwd_pair_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 long long planes, int H, int W) {
+  const int Wh = W / 2, W2 = 2 * W;
+  const long long total = planes * H * Wh;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Wh);
+    const long long q = i / Wh;
+    const float* s = dy + (2 * q) * W2 + 4 * j;
+    const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + W2);
+    const f32x2 o = {(a[0] + a[1]) + (b[0] + b[1]), (a[2] + a[3]) + (b[2] + b[3])};   // same association as the scalar form
+    *(f32x2*)(dx + q * W + 2 * j) = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                             long long planes, int H, int W) {
   const long long total = planes * H * W;
@@ -281,7 +401,6 @@ __global__ __launch_bounds__(256) void copy_runs_kernel(const float* __restrict_
   }
 }
 
-static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" {
 
@@ -341,6 +460,37 @@ int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, 
   DLWP_CHECK_ARG(p.mode_h != DLWP_PAD_WRAP || (p.top <= H && p.bottom <= H), "dlwp_pad2d_bwd: periodic rows exceed H");
   DLWP_CHECK_ARG(p.mode_w != DLWP_PAD_WRAP || (p.left <= W && p.right <= W), "dlwp_pad2d_bwd: periodic cols exceed W");
   if (outer == 0) return DLWP_OK;
+  {
+    // row-staged kernel whenever 4 waves x 4 padded rows fit in LDS (every shape of the reference's networks does)
+    const int Ho = H + p.top + p.bottom, Wo = W + p.left + p.right;
+    const long long RI = (long long)W * inner, RO = (long long)Wo * inner;
+    const int row_lds = (int)((RO + 3) / 4 * 4);
+    const size_t lds_bytes = (size_t)row_lds * 4 * 4 * sizeof(float);
+    if (lds_bytes <= (size_t)h->lds_bytes && lds_bytes <= 64 * 1024) {
+      const long long n_rows = (long long)outer * H;
+      int grid = (int)((n_rows + 15) / 16);
+      const int cap = h->cu_count * 8;
+      if (grid > cap) grid = cap;
+      const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(dy) && aligned16(dx);
+      const bool vec2 = (RI % 2 == 0) && (RO % 2 == 0) && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 7) == 0;
+      hipStream_t s = (hipStream_t)stream;
+#define PADB_LAUNCH(V, I1)                                                                                              \
+  pad2d_bwd_rows_kernel<V, I1><<<grid, 256, lds_bytes, s>>>((const float*)dy, (float*)dx, outer, H, W, inner, Ho, Wo,   \
+                                                            p.top, p.bottom, p.left, p.right, p.mode_h, p.mode_w, row_lds)
+      if (inner == 1) {
+        if (vec) PADB_LAUNCH(4, true);
+        else if (vec2) PADB_LAUNCH(2, true);
+        else PADB_LAUNCH(1, true);
+      } else {
+        if (vec) PADB_LAUNCH(4, false);
+        else if (vec2) PADB_LAUNCH(2, false);
+        else PADB_LAUNCH(1, false);
+      }
+#undef PADB_LAUNCH
+      DLWP_LAUNCH_CHECK("pad2d_bwd_rows_kernel");
+      return DLWP_OK;
+    }
+  }
   const long long total = (long long)outer * H * W * inner;
   pad2d_bwd_kernel<<<grid_for(total, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>(
       (const float*)dy, (float*)dx, outer, H, W, inner, H + p.top + p.bottom, W + p.left + p.right, p.top, p.bottom,
@@ -396,8 +546,12 @@ int dlwp_upsample2_fwd(dlwp_handle_t h, const void* x, void* y, dlwp_shape4 xs, 
   const long long total = planes * xs.h * xs.w;
   if (total == 0) return DLWP_OK;
   DLWP_CHECK_ARG((((uintptr_t)y) & 7) == 0, "dlwp_upsample2_fwd: output must be 8-byte aligned");
-  upsample2_fwd_kernel<<<grid_for(total, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)y,
-                                                                                           planes, xs.h, xs.w);
+  if ((xs.w & 1) == 0 && aligned16(y) && (((uintptr_t)x) & 7) == 0)
+    upsample2_fwd_pair_kernel<<<grid_for(total / 2, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>(
+        (const float*)x, (float*)y, planes, xs.h, xs.w);
+  else
+    upsample2_fwd_kernel<<<grid_for(total, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)y,
+                                                                                             planes, xs.h, xs.w);
   DLWP_LAUNCH_CHECK("upsample2_fwd_kernel");
   return DLWP_OK;
 }
@@ -410,8 +564,12 @@ int dlwp_upsample2_bwd(dlwp_handle_t h, const void* dy, void* dx, dlwp_shape4 xs
   const long long total = planes * xs.h * xs.w;
   if (total == 0) return DLWP_OK;
   DLWP_CHECK_ARG((((uintptr_t)dy) & 7) == 0, "dlwp_upsample2_bwd: dy must be 8-byte aligned");
-  upsample2_bwd_kernel<<<grid_for(total, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>((const float*)dy, (float*)dx,
-                                                                                           planes, xs.h, xs.w);
+  if ((xs.w & 1) == 0 && aligned16(dy) && (((uintptr_t)dx) & 7) == 0)
+    upsample2_bwd_pair_kernel<<<grid_for(total / 2, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>(
+        (const float*)dy, (float*)dx, planes, xs.h, xs.w);
+  else
+    upsample2_bwd_kernel<<<grid_for(total, 256, h->cu_count), 256, 0, (hipStream_t)stream>>>((const float*)dy, (float*)dx,
+                                                                                             planes, xs.h, xs.w);
   DLWP_LAUNCH_CHECK("upsample2_bwd_kernel");
   return DLWP_OK;
 }
