@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'libdlwp_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dlwp_hip.h')
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ERCCL = 0, -1, -2, -3, -4
+OPT_WINOGRAD, OPT_BF16_MFMA, OPT_FORCE_CONV_CONFIG, OPT_FORCE_WGRAD_CONFIG = 0, 1, 2, 3
 F32, BF16 = 0, 1
 PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
@@ -111,6 +112,8 @@ _sig('dlwp_last_error', [], ctypes.c_char_p)
 _sig('dlwp_create', [_P(_vp), _i])
 _sig('dlwp_destroy', [_vp])
 _sig('dlwp_device_info', [_vp, _P(_i), _P(_i), ctypes.c_char_p, _sz])
+_sig('dlwp_set_option', [_vp, _i, _i, _P(_i)])
+_sig('dlwp_set_default_option', [_i, _i, _P(_i)])
 _sig('dlwp_pad2d_fwd', [_vp, _vp, _vp, _i, _i, _i, _i, Pad2d, _i, _vp])
 _sig('dlwp_pad2d_bwd', [_vp, _vp, _vp, _i, _i, _i, _i, Pad2d, _i, _vp])
 _sig('dlwp_conv2d_out_shape', [Shape4, _P(Conv2d), _P(Shape4)])
@@ -122,17 +125,14 @@ _sig('dlwp_conv2d_fwd_prepared', [_vp, _vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2
 _sig('dlwp_conv2d_num_configs', [])
 _sig('dlwp_conv2d_config_info', [_i, _P(_i), _P(_i)])
 _sig('dlwp_conv2d_config_flags', [_i])
-_sig('dlwp_conv2d_force_config', [_i])
-_sig('dlwp_conv2d_set_winograd', [_i])
 _sig('dlwp_phase_geometry', [_i, _i, _P(_i), _P(_i), _P(_i)])
 _sig('dlwp_phase_weights', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_depth_to_space2', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_space_to_depth2', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_phase_weights_bwd', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
-_sig('dlwp_conv2d_set_bf16_mfma', [_i])
-_sig('dlwp_conv2d_uses_bf16_weights', [Shape4, _P(Conv2d), _i])
-_sig('dlwp_conv2d_prefers_unfused_pool', [_i, _i, _i, _i, _i, _i])
-_sig('dlwp_conv2d_supports_out_pool', [Shape4, _P(Conv2d)])
+_sig('dlwp_conv2d_uses_bf16_weights', [_vp, Shape4, _P(Conv2d), _i])
+_sig('dlwp_conv2d_prefers_unfused_pool', [_vp, _i, _i, _i, _i, _i, _i])
+_sig('dlwp_conv2d_supports_out_pool', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_launch_info', [_vp, Shape4, _P(Conv2d), _i, _P(LaunchInfo), _P(_i)])
 _sig('dlwp_conv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _i, _P(_sz)])
@@ -142,7 +142,6 @@ _sig('dlwp_conv2d_bwd_weight', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _i, 
 _sig('dlwp_conv2d_wgrad_num_configs', [])
 _sig('dlwp_conv2d_wgrad_config_info', [_i, _P(_i), _P(_i)])
 _sig('dlwp_conv2d_wgrad_pick_config', [_vp, Shape4, _P(Conv2d)])
-_sig('dlwp_conv2d_wgrad_force_config', [_i])
 _sig('dlwp_act_bwd', [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp])
 _sig('dlwp_bias_grad_workspace', [_i], _sz)
 _sig('dlwp_bias_grad', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp])
@@ -163,8 +162,9 @@ _sig('dlwp_convlstm_gates', [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _
 _sig('dlwp_convlstm_gates_bwd', [_vp] * 9 + [_i] * 8 + [_vp])
 _sig('dlwp_copy_channels', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])
-_sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _P(_vp)])
-_sig('dlwp_rollout_create_grouped', [_vp, _P(Op), _i, _P(_vp), _i, _P(_sz), _i, _vp, _vp, _sz, _i, _i, _i, _P(_vp)])
+_sig('dlwp_rollout_workspace_bytes', [_vp, _P(Op), _i, _i], _sz)
+_sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _vp, _sz, _P(_vp)])
+_sig('dlwp_rollout_create_grouped', [_vp, _P(Op), _i, _P(_vp), _i, _P(_sz), _i, _vp, _vp, _sz, _i, _i, _i, _vp, _sz, _P(_vp)])
 _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
 _sig('dlwp_comm_unique_id', [_vp, _P(_sz)])
@@ -182,6 +182,25 @@ def check(rc):
 
 
 _handles = {}
+
+
+def handle_or_none(device_index=None):
+    """The handle of a device if there is a GPU, else None: the planner hints are pure host logic and run with the default
+    options on a machine without one (CPU tests build plans)."""
+    if not torch.cuda.is_available():
+        return None
+    return handle(torch.cuda.current_device() if device_index is None else device_index)
+
+
+def set_option(option, value, device_index=None):
+    """dlwp_set_option on the handle of `device_index` (default: the current device); returns the previous value."""
+    prev = ctypes.c_int(0)
+    if not torch.cuda.is_available():      # no device, no handle: the defaults the handle-less planner hints use
+        check(lib.dlwp_set_default_option(int(option), int(value), ctypes.byref(prev)))
+        return prev.value
+    check(lib.dlwp_set_option(handle(torch.cuda.current_device() if device_index is None else device_index), int(option),
+                              int(value), ctypes.byref(prev)))
+    return prev.value
 
 
 def handle(device_index=0):

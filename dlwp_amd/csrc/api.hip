@@ -1,5 +1,6 @@
 // api.hip -- handle lifetime, error string, version.
 #include "common.h"
+#include <cstdlib>
 #include <string>
 
 static thread_local char g_err[512] = "";
@@ -11,9 +12,45 @@ void dlwp_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static dlwp_options& default_options_rw() {
+  static dlwp_options d = [] {
+    dlwp_options o;
+    const char* e = getenv("DLWP_WINOGRAD");
+    o.winograd = (e && e[0] == '0') ? 0 : 1;
+    e = getenv("DLWP_BF16_MFMA");
+    o.bf16_mfma = (e && e[0] == '0') ? 0 : 1;
+    return o;
+  }();
+  return d;
+}
+const dlwp_options& dlwp_default_options() { return default_options_rw(); }
+
+static int set_in(dlwp_options& o, int option, int value, int* previous, const char* fn) {
+  int* slot = nullptr;
+  switch (option) {
+    case DLWP_OPT_WINOGRAD: slot = &o.winograd; value = value ? 1 : 0; break;
+    case DLWP_OPT_BF16_MFMA: slot = &o.bf16_mfma; value = value ? 1 : 0; break;
+    case DLWP_OPT_FORCE_CONV_CONFIG: slot = &o.forced_cfg; break;
+    case DLWP_OPT_FORCE_WGRAD_CONFIG: slot = &o.forced_wgrad; break;
+    default: DLWP_FAIL(DLWP_EINVAL, "%s: unknown option %d", fn, option);
+  }
+  if (previous) *previous = *slot;
+  *slot = value;
+  return DLWP_OK;
+}
+
 extern "C" {
 
-int dlwp_version(void) { return 100; }  // 0.1.0
+int dlwp_version(void) { return 200; }  // 0.2.0
+
+int dlwp_set_option(dlwp_handle_t h, int option, int value, int* previous) {
+  DLWP_CHECK_ARG(h != nullptr, "dlwp_set_option: null handle");
+  return set_in(h->opt, option, value, previous, "dlwp_set_option");
+}
+
+int dlwp_set_default_option(int option, int value, int* previous) {
+  return set_in(default_options_rw(), option, value, previous, "dlwp_set_default_option");
+}
 
 const char* dlwp_last_error(void) { return g_err; }
 
@@ -28,6 +65,7 @@ int dlwp_create(dlwp_handle_t* out, int device) {
     DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
               prop.gcnArchName);
   dlwp_handle* h = new dlwp_handle();
+  h->opt = dlwp_default_options();
   h->device = device;
   h->cu_count = prop.multiProcessorCount;
   h->lds_bytes = (int)prop.sharedMemPerBlock;

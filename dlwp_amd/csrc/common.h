@@ -6,7 +6,16 @@
 #include <cstring>
 #include "../../include/dlwp_hip.h"
 
+// Per-handle switches (dlwp_set_option): nothing about kernel selection is process-global, so two handles -- two threads,
+// two streams -- never see each other's settings.  dlwp_default_options(): what a fresh handle (and the handle-less host
+// logic) starts from: DLWP_WINOGRAD / DLWP_BF16_MFMA in the environment, read once.
+struct dlwp_options {
+  int winograd = 1, bf16_mfma = 1, forced_cfg = -1, forced_wgrad = -1;
+};
+const dlwp_options& dlwp_default_options();
+
 struct dlwp_handle {
+  dlwp_options opt;
   int device;
   int cu_count;
   int lds_bytes;

@@ -40,7 +40,6 @@ const WgradKernelEntry k_wgrad[] = {
 constexpr int N_WGRAD = (int)(sizeof(k_wgrad) / sizeof(k_wgrad[0]));
 char g_wg_prepared[N_WGRAD] = {0};
 std::mutex g_wg_mutex;
-thread_local int g_forced_wgrad = -1;
 
 struct WgChoice {
   int idx, splits, nslabs, tiles_h, tiles_w, ci_groups, co_tiles;
@@ -52,7 +51,7 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
   for (int i = 0; i < N_WGRAD; ++i) {
     const WgradKernelEntry& e = k_wgrad[i];
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
-    if (g_forced_wgrad >= 0 && i != g_forced_wgrad) continue;
+    if (h->opt.forced_wgrad >= 0 && i != h->opt.forced_wgrad) continue;
     if (e.pack && Cout > e.pack) continue;   // packed-N instances: at most 4 output channels
     const double tiles = (double)dlwp_ceil_div(Ho, e.th) * dlwp_ceil_div(Wo + (e.pack ? e.pack - 1 : 0), e.tw);
     const double co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
@@ -285,11 +284,6 @@ int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes) {
   const int v[6] = {e.ks, e.dil, e.th, e.tw, e.pack ? -e.pack : e.nt, e.waves};
   for (int k = 0; k < 6; ++k) info6[k] = v[k];
   if (lds_bytes) *lds_bytes = e.lds_bytes;
-  return DLWP_OK;
-}
-
-int dlwp_conv2d_wgrad_force_config(int i) {
-  g_forced_wgrad = i;
   return DLWP_OK;
 }
 

@@ -34,20 +34,10 @@ Registry& registry() {
 }
 std::mutex g_prepare_mutex;
 
-// forced configuration for tuning sweeps (-1 = heuristic); per-thread so concurrent handles do not interfere
-thread_local int g_forced_cfg = -1;
-
-// Winograd on/off (process-wide; DLWP_WINOGRAD=0 in the environment or dlwp_conv2d_set_winograd(0) disables it).
-// The kernel FAMILY is chosen from the layer geometry only -- never from the batch size -- so a sample's result does not
-// depend on its batch mates (within a family every tile configuration is bit-identical).
-int g_winograd = -1;
-bool winograd_enabled() {
-  if (g_winograd < 0) {
-    const char* e = getenv("DLWP_WINOGRAD");
-    g_winograd = (e && e[0] == '0') ? 0 : 1;
-  }
-  return g_winograd != 0;
-}
+// Kernel-selection switches come with the call (dlwp_options of the handle: Winograd on/off, bf16 matrix cores on/off, a
+// forced configuration for tuning sweeps).  The kernel FAMILY is chosen from the layer geometry only -- never from the batch
+// size -- so a sample's result does not depend on its batch mates (within a family every tile configuration is
+// bit-identical).
 // geometry the Winograd instances cover: 3x3, whole channel chunks (8 in, 32 out), no pooled loader, planes addressable
 // with 32-bit byte offsets, filters that fit the handle's scratch
 constexpr size_t WINO_SCRATCH_FLOATS = 8u << 20;  // 32 MB: Cin*Cout <= 512K
@@ -60,8 +50,8 @@ bool wino_channels_ok(int cin, int cout, int dil) {
   const int pad8 = dlwp_ceil_div(cin, 8) * 8, pad4 = dlwp_ceil_div(cin, 4) * 4;
   return (cout % 32 == 0 || (cout % 16 == 0 && dil == 1)) && cin >= 5 && pad8 * 16 * 2 <= pad4 * 36;
 }
-bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
-  return winograd_enabled() && cd->kh == 3 && cd->kw == 3 && cd->dil_h == cd->dil_w && wino_channels_ok(a.Cin, a.Cout, cd->dil_h) &&
+bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd, const dlwp_options& o) {
+  return o.winograd && cd->kh == 3 && cd->kw == 3 && cd->dil_h == cd->dil_w && wino_channels_ok(a.Cin, a.Cout, cd->dil_h) &&
          cd->src_mode != DLWP_SRC_MAXPOOL2 &&
          (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&   // channel offsets inside a sample: 32-bit byte offsets
          (size_t)a.Cin * a.Cout * 16 <= WINO_SCRATCH_FLOATS;
@@ -79,20 +69,12 @@ inline bool is_bf16(const ConvKernelEntry& e) { return e.pack == -2; }
 // bf16-MFMA family (conv_fwd_bf16_kernel.h): the input is stored as bf16 (or as float32 with DLWP_COMPUTE_BF16: the
 // loader rounds it); whole column pairs (even width, periodic or
 // zero column halo), no pooled loader, enough input channels to fill a K slice.  Like Winograd the
-// family follows from the layer (geometry + storage type) only.  DLWP_BF16_MFMA=0 / dlwp_conv2d_set_bf16_mfma(0): off.
-int g_bf16_mfma = -1;
-bool bf16_mfma_enabled() {
-  if (g_bf16_mfma < 0) {
-    const char* e = getenv("DLWP_BF16_MFMA");
-    g_bf16_mfma = (e && e[0] == '0') ? 0 : 1;
-  }
-  return g_bf16_mfma != 0;
-}
+// family follows from the layer (geometry + storage type) only.  DLWP_BF16_MFMA=0 / dlwp_set_option(DLWP_OPT_BF16_MFMA, 0): off.
 size_t bf16_prep_floats(const ConvKernelEntry& e, int cin, int cout) {
   return (size_t)dlwp_ceil_div(cout, 16 * e.bnf) * dlwp_ceil_div(cin, e.ck) * e.prep_chunk_floats;
 }
-bool bf16_wanted(const ConvArgs& a, const dlwp_conv2d* cd) {
-  return bf16_mfma_enabled() && (a.in_bf16 ? a.Cin >= 12 : (a.compute_bf16 && a.Cin >= 4)) && cd->kh == cd->kw &&
+bool bf16_wanted(const ConvArgs& a, const dlwp_conv2d* cd, const dlwp_options& o) {
+  return o.bf16_mfma && (a.in_bf16 ? a.Cin >= 12 : (a.compute_bf16 && a.Cin >= 4)) && cd->kh == cd->kw &&
          cd->dil_h == cd->dil_w &&
          cd->src_mode != DLWP_SRC_MAXPOOL2 && (a.W & 1) == 0 && cd->halo.mode_w != DLWP_PAD_EDGE &&
          (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&    // 32-bit byte offsets inside a sample, in ...
@@ -291,33 +273,34 @@ double config_cost(const ConvKernelEntry& e, const ConvArgs& a, int cu_count) {
   return rounds * (work * (1.0 + 0.3 / overlap) * imbalance + 0.01 * stage);
 }
 
-int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count) {
+int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const dlwp_options& o) {
+  const int forced = o.forced_cfg;
   Registry& r = registry();
-  if (g_forced_cfg >= 0) {
-    if (g_forced_cfg >= (int)r.entries.size()) return -1;
-    const ConvKernelEntry& e = r.entries[g_forced_cfg];
+  if (forced >= 0) {
+    if (forced >= (int)r.entries.size()) return -1;
+    const ConvKernelEntry& e = r.entries[forced];
     const bool pool = cd->src_mode == DLWP_SRC_MAXPOOL2;
     const bool pack_ok = e.pack <= 0 || (cd->cout <= 16 / e.pack);
-    if (is_wino(e) && (!winograd_wanted(a, cd) || a.Cout % (16 * e.bnf) != 0)) return -1;  // whole channel chunks only
+    if (is_wino(e) && (!winograd_wanted(a, cd, o) || a.Cout % (16 * e.bnf) != 0)) return -1;  // whole channel chunks only
     if (is_wino(e) && e.bnf == 1 && wino_skips_row2(a)) return -1;  // 16-channel blocks have no 9-position variant
-    if (is_bf16(e) && (!bf16_wanted(a, cd) || (e.in32 != 0) == (a.in_bf16 != 0) ||
+    if (is_bf16(e) && (!bf16_wanted(a, cd, o) || (e.in32 != 0) == (a.in_bf16 != 0) ||
                        bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
     if (cd->out_pool && !e.out_pool) return -1;
     if (cd->out_pool == 2 && !(is_wino(e) && e.dil == 1)) return -1;  // the 2x2 sum epilogue: dilation-1 Winograd instances
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
-               ? g_forced_cfg
+               ? forced
                : -1;
   }
   int best = -1;
   double best_cost = 0;
   const bool sum_pool = cd->out_pool == 2;  // 2x2 sum epilogue (data gradient of an up-sampled source): Winograd only
   bool want_bf16 = false;
-  if (!sum_pool && bf16_wanted(a, cd))
+  if (!sum_pool && bf16_wanted(a, cd, o))
     for (const ConvKernelEntry& e : r.entries)
       want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h && (!cd->out_pool || e.out_pool) &&
                                 (e.in32 != 0) == !a.in_bf16 &&
                                 bf16_prep_floats(e, a.Cin, a.Cout) <= WINO_SCRATCH_FLOATS);
-  bool want_wino = !want_bf16 && winograd_wanted(a, cd);
+  bool want_wino = !want_bf16 && winograd_wanted(a, cd, o);
   if (want_wino) {  // fall back to the direct family when no Winograd instance matches (dilation / pooled loader)
     bool any = false;
     for (const ConvKernelEntry& e : r.entries)
@@ -413,7 +396,7 @@ static const ConvKernelEntry* entry_for(dlwp_handle_t h, dlwp_shape4 xs, const d
   dlwp_shape4 ys;
   if (!h || !cd || xs.n <= 0 || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return nullptr;
   ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys, dtype);
-  const int ci = choose_config(a, cd, h->cu_count);
+  const int ci = choose_config(a, cd, h->cu_count, h->opt);
   return ci >= 0 ? &registry().entries[ci] : nullptr;
 }
 
@@ -495,7 +478,8 @@ double executed_matrix_flops(const ConvKernelEntry& e, const ConvArgs& a, long l
 
 int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, LaunchPlan* lp) {
   Registry& r = registry();
-  const int ci = choose_config(a, cd, h->cu_count);
+  const int forced = h->opt.forced_cfg;
+  const int ci = choose_config(a, cd, h->cu_count, h->opt);
   lp->primary = ci;
   if (ci < 0) return DLWP_OK;
   const ConvKernelEntry& e = r.entries[ci];
@@ -506,7 +490,7 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
   // whole column tiles go to this instance, the rest to a 16-wide two-wave instance in a second launch (every Winograd
   // instance reads the same prepared filters and gives the same bits).  Only when the launches fill the chip more than
   // twice over -- at small batches a second launch costs more than the idle lanes.
-  if (g_forced_cfg < 0 && is_wino(e) && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3 &&
+  if (forced < 0 && is_wino(e) && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3 &&
       (long long)a.N * lp->tiles_h * (a.Wo / 32) * lp->cout_tiles >= 4ll * h->cu_count) {
     for (int i = 0; i < (int)r.entries.size() && lp->narrow < 0; ++i) {
       const ConvKernelEntry& p = r.entries[i];
@@ -540,7 +524,8 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   plan_launch(h, a, cd, &lp);
   const int ci = lp.primary;
   if (ci < 0) {
-    if (g_forced_cfg >= 0) DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", g_forced_cfg);
+    if (h->opt.forced_cfg >= 0)
+      DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", h->opt.forced_cfg);
     if (cd->out_pool) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel with a pooling epilogue for this layer");
     return launch_direct(h, a, cd, s);  // kernel sizes without an MFMA tile configuration
   }
@@ -702,14 +687,15 @@ int dlwp_conv2d_config_flags(int i) {
   return (is_wino(r.entries[i]) && r.entries[i].split) ? 1 : 0;
 }
 
-int dlwp_conv2d_prefers_unfused_pool(int cin, int cout, int kh, int kw, int dil_h, int dil_w) {
-  return (winograd_enabled() && kh == 3 && kw == 3 && dil_h == dil_w && (dil_h == 1 || dil_h == 2) &&
+int dlwp_conv2d_prefers_unfused_pool(dlwp_handle_t h, int cin, int cout, int kh, int kw, int dil_h, int dil_w) {
+  const dlwp_options& o = h ? h->opt : dlwp_default_options();
+  return (o.winograd && kh == 3 && kw == 3 && dil_h == dil_w && (dil_h == 1 || dil_h == 2) &&
           wino_channels_ok(cin, cout, dil_h) && (size_t)cin * cout * 16 <= WINO_SCRATCH_FLOATS)
              ? 1
              : 0;
 }
 
-int dlwp_conv2d_supports_out_pool(dlwp_shape4 xs, const dlwp_conv2d* cd) {
+int dlwp_conv2d_supports_out_pool(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
   if (!cd || xs.c <= 0 || xs.h <= 0 || xs.w <= 0) return 0;
   dlwp_conv2d c2 = *cd;
   c2.out_pool = 1;
@@ -717,33 +703,17 @@ int dlwp_conv2d_supports_out_pool(dlwp_shape4 xs, const dlwp_conv2d* cd) {
   if (xs.n <= 0) xs.n = 1;
   if (dlwp_conv2d_out_shape(xs, &c2, &ys) != DLWP_OK) return 0;
   ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, &c2, ys);
-  return choose_config(a, &c2, 256) >= 0 ? 1 : 0;
+  return choose_config(a, &c2, 256, h ? h->opt : dlwp_default_options()) >= 0 ? 1 : 0;
 }
 
-int dlwp_conv2d_uses_bf16_weights(dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
+int dlwp_conv2d_uses_bf16_weights(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
   if (!cd || xs.c <= 0 || xs.h <= 0 || xs.w <= 0) return 0;
   dlwp_shape4 ys;
   if (xs.n <= 0) xs.n = 1;
   if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return 0;
   ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys, dtype);
-  const int ci = choose_config(a, cd, 256);
+  const int ci = choose_config(a, cd, 256, h ? h->opt : dlwp_default_options());
   return (ci >= 0 && is_bf16(registry().entries[ci])) ? 1 : 0;
-}
-
-int dlwp_conv2d_set_bf16_mfma(int enable) {
-  const int prev = bf16_mfma_enabled() ? 1 : 0;
-  g_bf16_mfma = enable ? 1 : 0;
-  return prev;
-}
-
-int dlwp_conv2d_set_winograd(int enable) {
-  g_winograd = enable ? 1 : 0;
-  return DLWP_OK;
-}
-
-int dlwp_conv2d_force_config(int i) {
-  g_forced_cfg = i;
-  return DLWP_OK;
 }
 
 int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, dlwp_launch_info* out2,
@@ -784,7 +754,7 @@ int dlwp_conv2d_pick_config(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
   dlwp_shape4 ys;
   if (!h || !cd || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return -2;
   ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys);
-  return choose_config(a, cd, h->cu_count);
+  return choose_config(a, cd, h->cu_count, h->opt);
 }
 
 }  // extern "C"

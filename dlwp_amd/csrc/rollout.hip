@@ -13,7 +13,7 @@ struct dlwp_rollout {
   hipGraph_t graph;
   hipGraphExec_t exec;
   int calls, n_ops;
-  float* wino_u;  // transformed filters of the Winograd layers: written once at the head of every graph launch
+  float* wino_u;  // caller's workspace: prepared weights (Winograd / packed-N / bf16), written once at the head of every launch
 };
 
 namespace {
@@ -54,11 +54,37 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
 
 extern "C" {
 
+// floats of prepared weights the plan's convolutions need when every member-indexed op runs on `gn` members
+static long long prepared_floats(dlwp_handle_t h, const dlwp_op* plan, int n_ops, int gn, std::vector<long long>* offsets) {
+  long long total = 0;
+  if (offsets) offsets->assign(n_ops, -1);
+  for (int i = 0; i < n_ops; ++i) {
+    if (plan[i].kind != DLWP_OP_CONV2D) continue;
+    dlwp_shape4 xs = plan[i].xs;
+    xs.n = gn;
+    const long long need = (long long)dlwp_conv2d_prep_floats(h, xs, &plan[i].conv, plan[i].aux[0]);
+    if (need > 0) {
+      if (offsets) (*offsets)[i] = total;
+      total += (need + 63) & ~63ll;   // 256-byte aligned
+    }
+  }
+  return total;
+}
+
+size_t dlwp_rollout_workspace_bytes(dlwp_handle_t h, const dlwp_op* plan, int n_ops, int groups) {
+  if (!h || !plan || n_ops <= 0 || groups < 1) return 0;
+  int members = 0;
+  for (int i = 0; i < n_ops && !members; ++i)
+    if (plan[i].kind != DLWP_OP_PHASE_WEIGHTS) members = plan[i].xs.n;
+  if (members <= 0 || members % groups) return 0;
+  return (size_t)prepared_floats(h, plan, n_ops, members / groups, nullptr) * sizeof(float);
+}
+
 int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
                         const void* state0, void* series, size_t slot_elems, int calls, int n_outputs, int dtype,
-                        dlwp_rollout_t* out) {
+                        void* workspace, size_t workspace_bytes, dlwp_rollout_t* out) {
   return dlwp_rollout_create_grouped(h, plan, n_ops, buffers, n_buffers, nullptr, 1, state0, series, slot_elems, calls,
-                                     n_outputs, dtype, out);
+                                     n_outputs, dtype, workspace, workspace_bytes, out);
 }
 
 // Members (the batch axis) are independent, so the rollout may be captured as `groups` parallel chains of members / groups
@@ -68,7 +94,8 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
 // each other's work.  Same kernels, same per-member arithmetic (the kernel family never depends on the batch size).
 int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_ops, void* const* buffers, int n_buffers,
                                 const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
-                                size_t slot_elems, int calls, int n_outputs, int dtype, dlwp_rollout_t* out) {
+                                size_t slot_elems, int calls, int n_outputs, int dtype, void* workspace,
+                                size_t workspace_bytes, dlwp_rollout_t* out) {
   DLWP_CHECK_ARG(h && plan_in && out && state0 && series, "dlwp_rollout_create: null handle or pointer");
   DLWP_CHECK_ARG(groups >= 1 && groups <= 64, "dlwp_rollout_create: %d member groups", groups);
   DLWP_CHECK_ARG(groups == 1 || buffer_sample_bytes, "dlwp_rollout_create: member groups need the per-member buffer sizes");
@@ -126,24 +153,14 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
     return (char*)series + (((size_t)call * n_outputs + o) * slot_elems + lo * member_elems) * esz;
   };
 
-  // Winograd / packed-N layers: the weights do not change inside one graph launch, so their preparation runs ONCE at the head
-  // of the graph (into buffers the rollout owns) instead of once per forward; the handle's scratch stays the fallback
-  (void)dlwp_wino_scratch(h, 1, nullptr);
-  std::vector<long long> u_off(n_ops, -1);
-  long long u_floats = 0;
-  for (int i = 0; i < n_ops; ++i) {
-    const dlwp_op& op = plan[i];
-    const long long need = op.kind == DLWP_OP_CONV2D ? (long long)dlwp_conv2d_prep_floats(h, op.xs, &op.conv, op.aux[0]) : 0;
-    if (need > 0) {
-      u_off[i] = u_floats;
-      u_floats += (need + 63) & ~63ll;   // 256-byte aligned
-    }
-  }
-  float* wino_u = nullptr;
-  if (u_floats > 0 && hipMalloc(&wino_u, (size_t)u_floats * sizeof(float)) != hipSuccess) {
-    (void)hipGetLastError();
-    wino_u = nullptr;  // fall back to the per-forward transform
-  }
+  // Winograd / packed-N / bf16 layers: the weights do not change inside one graph launch, so their preparation runs ONCE at
+  // the head of the graph, into the CALLER's workspace (dlwp_rollout_workspace_bytes): the library allocates nothing here
+  std::vector<long long> u_off;
+  const long long u_floats = prepared_floats(h, plan, n_ops, gn, &u_off);
+  DLWP_CHECK_ARG(u_floats == 0 || (workspace && workspace_bytes >= (size_t)u_floats * sizeof(float)),
+                 "dlwp_rollout_create: workspace of %zu bytes, %lld needed (dlwp_rollout_workspace_bytes)", workspace_bytes,
+                 u_floats * (long long)sizeof(float));
+  float* wino_u = u_floats > 0 ? (float*)workspace : nullptr;
 
   hipStream_t cap;
   DLWP_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
@@ -211,18 +228,15 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
   (void)hipStreamDestroy(cap);
   if (rc != DLWP_OK) {
     if (graph) (void)hipGraphDestroy(graph);
-    if (wino_u) (void)hipFree(wino_u);
     return rc;  // error string already set by the failing op
   }
   if (e != hipSuccess) {
-    if (wino_u) (void)hipFree(wino_u);
     DLWP_FAIL(DLWP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
   }
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {
     (void)hipGraphDestroy(graph);
-    if (wino_u) (void)hipFree(wino_u);
     DLWP_FAIL(DLWP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
   }
   dlwp_rollout* r = new dlwp_rollout();
@@ -246,7 +260,6 @@ int dlwp_rollout_destroy(dlwp_rollout_t r) {
   if (!r) return DLWP_OK;
   if (r->exec) (void)hipGraphExecDestroy(r->exec);
   if (r->graph) (void)hipGraphDestroy(r->graph);
-  if (r->wino_u) (void)hipFree(r->wino_u);
   delete r;
   return DLWP_OK;
 }

@@ -231,11 +231,15 @@ class Executor(object):
         nbuf = len(bufs)
         sample_bytes = (ctypes.c_size_t * max(1, len(table)))(
             *[(t[0].numel() * t.element_size() if (i < nbuf and n > 0) else 0) for i, t in enumerate(table)])
+        # prepared weights (Winograd / packed-N / bf16 layouts) live in memory WE own: the library allocates nothing
+        ws_bytes = int(_lib.lib.dlwp_rollout_workspace_bytes(_lib.handle(dev), arr, len(self.plan.ops), groups))
+        ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib.dlwp_rollout_create_grouped(_lib.handle(dev), arr, len(self.plan.ops), ptrs, len(table),
                                                         sample_bytes, groups, ctypes.c_void_p(state0.data_ptr()),
                                                         ctypes.c_void_p(series.data_ptr()), slot, int(calls), n_out,
-                                                        _lib.F32, ctypes.byref(out)))
-        return RolloutGraph(out, keep=(table, state0, series, arr, ptrs), device=self.device)
+                                                        _lib.F32, ctypes.c_void_p(ws.data_ptr()), ws_bytes,
+                                                        ctypes.byref(out)))
+        return RolloutGraph(out, keep=(table, state0, series, arr, ptrs, ws), device=self.device)
 
 
 class RolloutGraph(object):

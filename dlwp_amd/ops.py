@@ -62,7 +62,7 @@ def make_conv(cout, kh, kw, dil=1, halo=None, act=ACT_LINEAR, in_c_off=0, in_c_t
 
 def supports_out_pool(xs_chw, cd):
     """Planner hint: can a compiled kernel apply a following MaxPooling2D(2) in this convolution's epilogue?"""
-    return bool(_lib.lib.dlwp_conv2d_supports_out_pool(Shape4(1, int(xs_chw[0]), int(xs_chw[1]), int(xs_chw[2])),
+    return bool(_lib.lib.dlwp_conv2d_supports_out_pool(_lib.handle_or_none(), Shape4(1, int(xs_chw[0]), int(xs_chw[1]), int(xs_chw[2])),
                                                        ctypes.byref(cd)))
 
 
@@ -279,23 +279,23 @@ def conv_launch_info(x_shape, cd, dtype=None, device_index=0):
 
 
 def force_conv_config(i):
-    _lib.lib.dlwp_conv2d_force_config(int(i))
+    _lib.set_option(_lib.OPT_FORCE_CONV_CONFIG, int(i))
 
 
 def prefers_unfused_pool(cin, cout, kh, kw, dil_h, dil_w):
     """Planner hint: materialise a MaxPooling2D in front of this convolution instead of fusing it into the loader?"""
-    return bool(_lib.lib.dlwp_conv2d_prefers_unfused_pool(cin, cout, kh, kw, dil_h, dil_w))
+    return bool(_lib.lib.dlwp_conv2d_prefers_unfused_pool(_lib.handle_or_none(), cin, cout, kh, kw, dil_h, dil_w))
 
 
 def set_winograd(enable):
     """3x3 convolutions with >= 16 input and output channels run as Winograd F(2x2,3x3) by default."""
-    _lib.lib.dlwp_conv2d_set_winograd(1 if enable else 0)
+    _lib.set_option(_lib.OPT_WINOGRAD, 1 if enable else 0)
 
 
 def set_bf16_mfma(enable):
     """Convolutions whose input is stored as bfloat16 multiply on the bf16 matrix cores (weights rounded to bf16) by
     default; False keeps them on the fp32 families.  Returns the previous setting."""
-    return bool(_lib.lib.dlwp_conv2d_set_bf16_mfma(1 if enable else 0))
+    return bool(_lib.set_option(_lib.OPT_BF16_MFMA, 1 if enable else 0))
 
 
 def phase_geometry(k, pad):
@@ -359,7 +359,8 @@ def phase_weights_bwd(dw2, db2, dw, db, pad_top, pad_left, accumulate=False):
 def uses_bf16_weights(xs, cd, dtype):
     """Does conv2d on an input of shape xs = (n, c, h, w) stored as `dtype` (a _lib.dtype_io code) multiply with weights
     rounded to bfloat16 (the bf16 matrix-core kernels)?  Host logic only."""
-    return bool(_lib.lib.dlwp_conv2d_uses_bf16_weights(_lib.Shape4(*[int(v) for v in xs]), ctypes.byref(cd), int(dtype)))
+    return bool(_lib.lib.dlwp_conv2d_uses_bf16_weights(_lib.handle_or_none(), _lib.Shape4(*[int(v) for v in xs]),
+                                                       ctypes.byref(cd), int(dtype)))
 
 
 # ------------------------------------------------------------------------------------------------------------------ #
@@ -534,4 +535,4 @@ def wgrad_configs():
 
 
 def force_wgrad_config(i):
-    _lib.lib.dlwp_conv2d_wgrad_force_config(int(i))
+    _lib.set_option(_lib.OPT_FORCE_WGRAD_CONFIG, int(i))

@@ -15,7 +15,8 @@
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it.  No host synchronisation inside.
  *     The Winograd convolutions keep their transformed filters in ONE scratch buffer of the handle (32 MB, allocated at the
  *     first use): launches that share a handle must be ordered on one stream at a time (use one handle per stream
- *     otherwise).  A rollout graph owns its own copy.
+ *     otherwise, or dlwp_conv2d_prepare into caller memory).  A rollout graph prepares into caller memory as well
+ *     (dlwp_rollout_workspace_bytes).  Kernel-selection switches live in the handle (dlwp_set_option).
  *   - dtype: the STORAGE type of activation tensors.  DLWP_F32 everywhere; the forward convolutions and
  *     dlwp_maxpool2_fwd also take DLWP_BF16 and, for the convolutions, DLWP_DTYPE_IO(in, out) with different input and
  *     output storage (config 4: bf16 activations between the layers, fp32 state at the model boundary).  Weights, biases
@@ -87,6 +88,19 @@ const char* dlwp_last_error(void);
 int         dlwp_create(dlwp_handle_t* h, int device);   /* one handle per device; thread-compatible */
 int         dlwp_destroy(dlwp_handle_t h);
 int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, char* arch, size_t arch_len);
+/* Per-handle switches: nothing about kernel selection is process-global, so handles (threads, streams) never see each
+ * other's settings.  A new handle starts from the environment (DLWP_WINOGRAD=0, DLWP_BF16_MFMA=0 switch the families off).
+ * `previous` (nullable) receives the old value.                                                                       */
+#define DLWP_OPT_WINOGRAD           0  /* 3x3 layers with whole channel tiles: Winograd F(2x2,3x3) (1, default) or the direct
+                                        * implicit GEMM (0)                                                                */
+#define DLWP_OPT_BF16_MFMA          1  /* layers whose INPUT is stored as bf16 (even width, >= 12 channels, no pooling fused
+                                        * in): multiply on the bf16 matrix cores with bf16-rounded weights (1, default)     */
+#define DLWP_OPT_FORCE_CONV_CONFIG  2  /* tuning sweeps / tests: run this forward tile configuration (-1 = heuristic)      */
+#define DLWP_OPT_FORCE_WGRAD_CONFIG 3  /* ... this weight-gradient configuration                                           */
+int         dlwp_set_option(dlwp_handle_t h, int option, int value, int* previous);
+/* the defaults themselves: what handles created AFTERWARDS start from, and what the handle-less host logic (planner hints
+ * called with a NULL handle, e.g. on a machine without a GPU) uses.  Existing handles are not touched.                 */
+int         dlwp_set_default_option(int option, int value, int* previous);
 
 /* ---- halo padding: DLWP.custom.PeriodicPadding2D.call (custom.py:191-214), FillPadding2D.call (custom.py:359-402),
  *      keras ZeroPadding2D.  Generic [outer, H, W, inner] view: NCHW -> outer=N*C, inner=1; NHWC -> outer=N, inner=C.
@@ -119,8 +133,8 @@ int dlwp_conv2d_fwd_prepared(dlwp_handle_t, const void* x, const void* w, const 
 int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int dtype, void* stream);
 
-/* tuning hooks (tools/tune_conv.py, tests): enumerate the compiled MFMA tile configurations, force one for the calling
- * thread (-1 = heuristic), ask which one the heuristic picks (-1 = direct kernel).  info9 = {ks, dil, th, tw, waves,
+/* tuning hooks (tools/tune_conv.py, tests): enumerate the compiled MFMA tile configurations, ask which one the heuristic
+ * picks (-1 = direct kernel); DLWP_OPT_FORCE_CONV_CONFIG forces one.  info9 = {ks, dil, th, tw, waves,
  * frags_per_wave (0: Winograd instance), cout_frags (< 0: packed-N instance for cout <= 16/-cout_frags), channel_chunk,
  * pooled_loader (2: bf16-MFMA instance, only for inputs stored as bf16)}.
  * Not part of the drop-in surface.                                                                                  */
@@ -128,23 +142,17 @@ int dlwp_conv2d_num_configs(void);
 int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes);
 int dlwp_conv2d_config_flags(int i);        /* bit 0: Winograd instance whose 16-position case splits the positions over two
                                               * waves per tile fragment (conv_fwd_wino2_kernel.h: 2 x waves x 64 threads) */
-int dlwp_conv2d_force_config(int i);
-int dlwp_conv2d_set_winograd(int enable);   /* 3x3 layers with cin % 8 == 0, cout % 32 == 0: Winograd F(2x2,3x3)
-                                              * (default) or the direct implicit GEMM */
-int dlwp_conv2d_set_bf16_mfma(int enable);  /* layers whose INPUT is stored as bf16 (even width, >= 12 channels, no
-                                              * pooling fused in): multiply on the bf16 matrix cores with the weights
-                                              * rounded to bf16 (default), or keep the fp32 families.  Returns the
-                                              * previous setting. */
-/* Host logic: 1 when dlwp_conv2d_fwd(xs, cd, dtype) multiplies with bf16-rounded weights (the bf16-MFMA family), else 0:
- * what a caller comparing against an fp32-weight computation needs to know. */
-int dlwp_conv2d_uses_bf16_weights(dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
-/* Planner hint (pure host logic, no device): 1 when a convolution of this geometry behind a MaxPooling2D runs faster with
+/* Host logic (no device work; handle nullable = default options): 1 when dlwp_conv2d_fwd(xs, cd, dtype) multiplies with
+ * bf16-rounded weights (the bf16-MFMA family), else 0: what a caller comparing against an fp32-weight computation needs to
+ * know. */
+int dlwp_conv2d_uses_bf16_weights(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
+/* Planner hint (host logic, handle nullable): 1 when a convolution of this geometry behind a MaxPooling2D runs faster with
  * the pooled tensor materialised by dlwp_maxpool2_fwd (the Winograd family has no pooled loader) than with the pooling
  * fused into the direct kernel's loader; 0 otherwise. */
-int dlwp_conv2d_prefers_unfused_pool(int cin, int cout, int kh, int kw, int dil_h, int dil_w);
-/* Planner hint (host logic): 1 when a compiled kernel can apply a following MaxPooling2D(2) in the epilogue of this
- * convolution (cd->out_pool = 1): the pre-pooling tensor is then never written. */
-int dlwp_conv2d_supports_out_pool(dlwp_shape4 xs, const dlwp_conv2d* cd);
+int dlwp_conv2d_prefers_unfused_pool(dlwp_handle_t, int cin, int cout, int kh, int kw, int dil_h, int dil_w);
+/* Planner hint (host logic, handle nullable): 1 when a compiled kernel can apply a following MaxPooling2D(2) in the epilogue
+ * of this convolution (cd->out_pool = 1): the pre-pooling tensor is then never written. */
+int dlwp_conv2d_supports_out_pool(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 /* Measurement hook (bench.py's roofline): what dlwp_conv2d_fwd(xs, cd, dtype) launches -- one kernel, or two when a Winograd
  * layer hands its ragged last column tile to a narrower instance -- and the matrix-core work each launch EXECUTES: the
@@ -180,7 +188,6 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* d
 int dlwp_conv2d_wgrad_num_configs(void);                                   /* tuning hooks, as for the forward */
 int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes);      /* {ks, dil, th, tw, cout_frags (< 0: packed-N
                                                                              * instance for cout <= -cout_frags), waves} */
-int dlwp_conv2d_wgrad_force_config(int i);
 int dlwp_conv2d_wgrad_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);   /* the heuristic's choice, -1: none */
 
 /* ---- the rest of the train step: Keras 'mse' loss + 'mae' metric (examples/train.py:240, train_functional.py:285),
@@ -308,16 +315,21 @@ typedef struct {
 } dlwp_op;
 #define DLWP_BUF_NONE (-1000)
 typedef struct dlwp_rollout* dlwp_rollout_t;
+/* workspace: caller-owned device memory of dlwp_rollout_workspace_bytes() bytes that must outlive the rollout -- the
+ * prepared weights of the Winograd / packed-N / bf16 layers live there, rebuilt by the first kernels of every launch (the
+ * weights may change between launches).  The library allocates no device memory for a rollout.                        */
+size_t dlwp_rollout_workspace_bytes(dlwp_handle_t, const dlwp_op* plan, int n_ops, int groups);
 int dlwp_rollout_create(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
                         const void* state0, void* series, size_t slot_elems, int calls, int n_outputs, int dtype,
-                        dlwp_rollout_t* out);
+                        void* workspace, size_t workspace_bytes, dlwp_rollout_t* out);
 /* The same with the members (xs.n of the ops) split into `groups` equal parts captured as parallel graph branches:
- * members are independent, so a small ensemble (config 5: 4 members per GPU) runs as several chains whose kernels fill the
- * gaps each other's launches leave.  buffer_sample_bytes[i] = bytes ONE member occupies in scratch buffer i (0 for weight
- * / bias buffers); the member count must be a multiple of groups.  groups = 1 is dlwp_rollout_create.                  */
+ * members are independent, so an ensemble can run as several chains whose kernels fill the gaps each other's launches
+ * leave.  buffer_sample_bytes[i] = bytes ONE member occupies in scratch buffer i (0 for weight / bias buffers); the member
+ * count must be a multiple of groups.  groups = 1 is dlwp_rollout_create.                                               */
 int dlwp_rollout_create_grouped(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
                                 const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
-                                size_t slot_elems, int calls, int n_outputs, int dtype, dlwp_rollout_t* out);
+                                size_t slot_elems, int calls, int n_outputs, int dtype, void* workspace,
+                                size_t workspace_bytes, dlwp_rollout_t* out);
 int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
 int dlwp_rollout_destroy(dlwp_rollout_t);
 
