@@ -360,6 +360,33 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   }
 }
 
+// The same update inside a captured training step (hipGraph): the step number cannot be a launch argument there, so it
+// lives in device memory.  adam_step_kernel (one thread) turns *iteration into lr_t -- the same double-precision formula the
+// host evaluates in dlwp_adam_keras -- and advances it; adam_dev_kernel reads lr_t from memory.
+__global__ void adam_step_kernel(long long* __restrict__ iteration, float* __restrict__ lr_t_out, float lr, float b1,
+                                 float b2, float decay) {
+  const long long it = *iteration;
+  const double t = (double)it + 1.0;
+  const double lr_ = (double)lr / (1.0 + (double)decay * (double)it);
+  *lr_t_out = (float)(lr_ * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  *iteration = it + 1;
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                       const float* __restrict__ g, long long n,
+                                                       const float* __restrict__ lr_t_p, float b1, float b2, float eps,
+                                                       float grad_scale) {
+  const float lr_t = *lr_t_p;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
 // plain SGD with optional momentum (keras.optimizers.SGD): v = mom*v - lr*g ; p += v
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ vel,
                                                   const float* __restrict__ g, long long n, float lr, float momentum,
@@ -610,6 +637,18 @@ int dlwp_adam_keras(dlwp_handle_t h, void* p, void* m, void* v, const void* g, s
   adam_kernel<<<grid_for((long long)n, h->cu_count), 256, 0, (hipStream_t)stream>>>(
       (float*)p, (float*)m, (float*)v, (const float*)g, (long long)n, (float)lr_t, beta_1, beta_2, epsilon, grad_scale);
   DLWP_LAUNCH_CHECK("adam_kernel");
+  return DLWP_OK;
+}
+
+int dlwp_adam_keras_dev(dlwp_handle_t h, void* p, void* m, void* v, const void* g, size_t n, float lr, float beta_1,
+                        float beta_2, float epsilon, float decay, long long* iteration_dev, float* lr_t_scratch,
+                        float grad_scale, void* stream) {
+  DLWP_CHECK_ARG(h && p && m && v && g && iteration_dev && lr_t_scratch, "dlwp_adam_keras_dev: null handle or pointer");
+  if (n == 0) return DLWP_OK;
+  adam_step_kernel<<<1, 1, 0, (hipStream_t)stream>>>(iteration_dev, lr_t_scratch, lr, beta_1, beta_2, decay);
+  adam_dev_kernel<<<grid_for((long long)n, h->cu_count), 256, 0, (hipStream_t)stream>>>(
+      (float*)p, (float*)m, (float*)v, (const float*)g, (long long)n, lr_t_scratch, beta_1, beta_2, epsilon, grad_scale);
+  DLWP_LAUNCH_CHECK("adam_dev_kernel");
   return DLWP_OK;
 }
 

@@ -510,6 +510,18 @@ def adam_keras(p, m, v, g, iteration, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon
                                         beta_2, epsilon, decay, int(iteration), grad_scale, _stream(p)))
 
 
+def adam_keras_dev(p, m, v, g, iteration_dev, lr_t_scratch, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, decay=0.0,
+                   grad_scale=1.0):
+    """adam_keras with the step number in device memory (int64 tensor of one element, advanced by the call) -- the form a
+    captured training step replays."""
+    _check_f32(p, m, v, g, lr_t_scratch)
+    if iteration_dev.dtype != torch.int64 or iteration_dev.numel() != 1:
+        raise ValueError('iteration_dev must be one int64 on the device')
+    _lib.check(_lib.lib.dlwp_adam_keras_dev(_lib.handle(_dev(p)), _ptr(p), _ptr(m), _ptr(v), _ptr(g), p.numel(), lr, beta_1,
+                                            beta_2, epsilon, decay, _ptr(iteration_dev), _ptr(lr_t_scratch), grad_scale,
+                                            _stream(p)))
+
+
 def sgd_keras(p, vel, g, iteration, lr=0.01, momentum=0.0, decay=0.0, grad_scale=1.0):
     _check_f32(p, vel, g)
     _lib.check(_lib.lib.dlwp_sgd_keras(_lib.handle(_dev(p)), _ptr(p), _ptr(vel), _ptr(g), p.numel(), lr, momentum, decay,

@@ -7,6 +7,7 @@ all-reduce of ONE flat gradient buffer per step (RCCL over xGMI on the GPU box, 
 Reference: keras Model.fit / fit_generator / evaluate as driven by DLWP/model/models.py:188-228, 303-316 and
 examples/train.py:240,258-263,274; loss / metric / optimizer strings of examples/train.py:240.
 """
+import os
 import time
 
 import numpy as np
@@ -150,6 +151,10 @@ class Trainer(object):
         self._loss_out = None
         self._loss_consts = None      # device copies of a custom loss's climatology / latitude weights
         self._params_dirty = False    # set by Model.set_weights / load: replicas re-align at the next collective step
+        self._graphs = {}             # (n_local, n_global) -> captured training step (see _graph_step)
+        self._graph_seen = {}
+        self._iter_dev = None         # Adam's step number on the device (advanced inside the captured step)
+        self._iter_shadow = None
         self.sync_parameters()
 
     # -- replicas ------------------------------------------------------------------------------------------------------ #
@@ -521,6 +526,77 @@ class Trainer(object):
             return self.train_on_shard(x, ys if isinstance(y, (list, tuple)) else ys[0], n_global, return_device)
         return self.train_on_shard(x, y, n_global, return_device)
 
+    # -- the step as a hipGraph --------------------------------------------------------------------------------------------- #
+    #: a batch shape seen this many times is captured (the first steps run eagerly: lazy allocations, scratch buffers)
+    graph_after = 2
+
+    def _graph_ok(self):
+        """Forward + loss + backward (+ optimizer) of one step are ~60 launches from Python: at 8 samples per GPU (config 3 on
+        8 GPUs) the host cannot issue them as fast as the GPU retires them.  A step whose launch sequence does not depend on
+        the data is captured once per batch shape (torch.cuda.CUDAGraph around our C-ABI launches: its private pool keeps the
+        per-op gradient buffers at fixed addresses) and replayed with one hipGraphLaunch.  Not captured: kernel regularisers
+        (their penalty is read back to the host every step), SGD with decay (its rate is a launch argument), steps on the CPU
+        device, DLWP_TRAIN_GRAPH=0."""
+        opt = self.model.optimizer
+        if self.device.type != 'cuda' or os.environ.get('DLWP_TRAIN_GRAPH', '1') == '0':
+            return False
+        if any(True for _ in self._regularized()):
+            return False
+        return isinstance(opt, Adam) or (isinstance(opt, SGD) and opt.decay == 0.0)
+
+    def _capture_step(self, x, ys, n_global, scale, dp):
+        from . import ops
+        opt = self.model.optimizer
+        gx = x.clone()
+        gys = [t.clone() for t in ys]
+        if self._iter_dev is None:
+            self._iter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._lr_t = torch.zeros(1, dtype=torch.float32, device=self.device)
+        if self.opt_state is None:
+            raise RuntimeError('the optimizer slots must exist before the step is captured')
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            outs, loss_vals, dys = self._forward_loss(gx, gys, True, scale)
+            self._backward(gx, outs, dys)
+            if dp is not None:       # the exchange and the update stay outside: a collective in between
+                ops.axpby(loss_vals.view(-1), self._loss_tail.view(-1), scale, 0.0)
+            elif isinstance(opt, Adam):
+                m, v = self.opt_state
+                ops.adam_keras_dev(self.flat_params, m, v, self.flat_grads, self._iter_dev, self._lr_t, opt.lr, opt.beta_1,
+                                   opt.beta_2, opt.epsilon, opt.decay, 1.0)
+            else:
+                ops.sgd_keras(self.flat_params, self.opt_state[0], self.flat_grads, 0, opt.lr, opt.momentum, 0.0, 1.0)
+        # everything the captured launches point into must outlive the graph, whatever the caches do later
+        keep = (outs, loss_vals, dys, dict(ops._workspaces), dict(ops._workspaces2),
+                self.model.train_executor.scratch(int(x.shape[0])), self.model.train_executor.phase_buffers())
+        return {'graph': g, 'x': gx, 'ys': gys, 'loss': loss_vals, 'keep': keep}
+
+    def _graph_step(self, x, ys, n_global, scale, dp):
+        """Replays (capturing first, if needed) the step for this batch shape.  Returns the device loss table, or None when
+        this shape has not been seen often enough yet (the caller then runs the step eagerly)."""
+        key = (int(x.shape[0]), int(n_global), 0 if dp is None else dp.world)
+        ent = self._graphs.get(key)
+        if ent is None:
+            seen = self._graph_seen.get(key, 0) + 1
+            self._graph_seen[key] = seen
+            if seen <= self.graph_after:
+                return None
+            if len(self._graphs) >= 4:
+                self._graphs.clear()
+            ent = self._graphs[key] = self._capture_step(x, ys, n_global, scale, dp)
+        opt = self.model.optimizer
+        ent['x'].copy_(x)
+        for dst, src in zip(ent['ys'], ys):
+            dst.copy_(src)
+        if dp is None and isinstance(opt, Adam) and self._iter_shadow != opt.iterations:
+            self._iter_dev.fill_(int(opt.iterations))          # (after load_model / a manual change / eager steps)
+        ent['graph'].replay()
+        if dp is None:
+            opt.iterations += 1
+            self._iter_shadow = opt.iterations
+        return ent['loss']
+
     def train_on_shard(self, x, y, n_global, return_device=False):
         """One optimisation step given THIS RANK's rows of a global batch of n_global samples (all of them when not data
         parallel).  Collective under data parallelism: every rank must call it, also with zero rows."""
@@ -532,6 +608,19 @@ class Trainer(object):
             raise ValueError('%d rows given for a batch of %d without data parallelism' % (n_local, n_global))
         if dp is not None and self._params_dirty:
             self.sync_parameters()
+        if n_local > 0 and self._graph_ok():
+            scale_g = 1.0 if dp is None else n_local * dp.world / float(n_global)
+            x = x.reshape((n_local,) + tuple(x.shape[1:]))
+            loss_vals = self._graph_step(x, self._targets(y, n_local), n_global, scale_g, dp)
+            if loss_vals is not None:
+                if dp is not None:
+                    dp.all_reduce_sum_(self._flat_exchange)
+                    self._apply(1.0 / dp.world)
+                    loss_vals = self._loss_tail
+                    ops.axpby(loss_vals.view(-1), loss_vals.view(-1), 0.0, 1.0 / dp.world)
+                if return_device:
+                    return loss_vals, 0.0
+                return self._report(loss_vals, 0.0)
         # local means are averaged over ranks: weight each by its share so ragged shards stay exact
         scale = 1.0 if dp is None else n_local * dp.world / float(n_global)
         if n_local > 0:

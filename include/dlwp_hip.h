@@ -226,6 +226,11 @@ int    dlwp_loss_custom(dlwp_handle_t, const void* y_pred, const void* y_true, i
                         float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream);
 int    dlwp_adam_keras(dlwp_handle_t, void* p, void* m, void* v, const void* g, size_t n, float lr, float beta_1,
                        float beta_2, float epsilon, float decay, long long iteration, float grad_scale, void* stream);
+/* dlwp_adam_keras for a training step captured as a hipGraph: the step number is read from (and advanced in) device memory
+ * -- *iteration_dev plays `iteration`, lr_t_scratch is one device float the update reads its step size from.              */
+int    dlwp_adam_keras_dev(dlwp_handle_t, void* p, void* m, void* v, const void* g, size_t n, float lr, float beta_1,
+                           float beta_2, float epsilon, float decay, long long* iteration_dev, float* lr_t_scratch,
+                           float grad_scale, void* stream);
 int    dlwp_sgd_keras(dlwp_handle_t, void* p, void* vel, const void* g, size_t n, float lr, float momentum, float decay,
                       long long iteration, float grad_scale, void* stream);
 int    dlwp_axpby(dlwp_handle_t, const void* x, void* y, size_t n, float a, float b, void* stream);   /* y = a*x + b*y */

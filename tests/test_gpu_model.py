@@ -362,6 +362,46 @@ def test_train_step_gradients_loss_and_adam_match_autograd_oracle():
     assert ev[0] == pytest.approx(np_ref.mse(y, out1), rel=1e-3) and ev[1] == pytest.approx(np_ref.mae(y, out1), rel=1e-3)
 
 
+def test_captured_training_step_equals_the_eager_step(monkeypatch):
+    """A batch shape seen more than twice runs as one captured hipGraph (Trainer._graph_step: forward, loss, backward and the
+    Adam update with the step number in device memory).  Same kernels, same order: weights, reported loss and the step
+    counter follow the eager run (the only arithmetic difference is lr_t, evaluated in double on the device instead of on
+    the host); a second batch shape gets its own graph; set_weights / evaluate in between do not disturb it."""
+    rng = np.random.default_rng(12)
+    cs = (4, 16, 24)
+    layers = unet_layers(cs, widths=(8, 16, 16, 16, 8))
+    xs = [rng.standard_normal((n,) + cs).astype(np.float32) for n in (6, 6, 6, 4, 6, 4, 4, 6, 4, 6)]
+    ys = [rng.standard_normal(x.shape).astype(np.float32) for x in xs]
+
+    def run(graph):
+        monkeypatch.setenv('DLWP_TRAIN_GRAPH', '1' if graph else '0')
+        d = _build(layers, time_dim=2, seed=3)
+        tr = d.model._trainer
+        logs = [d.model.train_on_batch(x, y) for x, y in zip(xs, ys)]
+        ev = d.evaluate(xs[0], ys[0], verbose=0)
+        logs.append(d.model.train_on_batch(xs[0], ys[0]))
+        return d, tr, logs, ev
+    de, tre, logs_e, ev_e = run(False)
+    dg, trg, logs_g, ev_g = run(True)
+    assert not tre._graphs and sorted(k[0] for k in trg._graphs) == [4, 6]
+    assert dg.model.optimizer.iterations == de.model.optimizer.iterations == len(xs) + 1
+    for a, b in zip(logs_g, logs_e):
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-7), (a, b)
+    assert np.allclose(ev_g, ev_e, rtol=1e-5)
+    for a, b in zip(dg.model.get_weights(), de.model.get_weights()):
+        assert np.abs(a - b).max() <= 2e-7 * (len(xs) + 1)
+    # a restored step counter is picked up by the captured step
+    dg.model.optimizer.iterations = 1000
+    de.model.optimizer.iterations = 1000
+    monkeypatch.setenv('DLWP_TRAIN_GRAPH', '1')
+    lg = dg.model.train_on_batch(xs[0], ys[0])
+    monkeypatch.setenv('DLWP_TRAIN_GRAPH', '0')
+    le = de.model.train_on_batch(xs[0], ys[0])
+    assert np.allclose(lg, le, rtol=1e-5) and dg.model.optimizer.iterations == 1001
+    for a, b in zip(dg.model.get_weights(), de.model.get_weights()):
+        assert np.abs(a - b).max() <= 2e-7 * (len(xs) + 2)
+
+
 def test_fit_and_fit_generator_reduce_the_loss():
     from dlwp_amd import custom
     from dlwp_amd.model import ArrayDataset, DataGenerator
