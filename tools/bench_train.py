@@ -32,7 +32,6 @@ def main():
     np.random.seed(1234)
     d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
     d.build_model(unet_layers((a.channels,) + grid), loss='mse', optimizer='adam', metrics=['mae'], gpus=world)
-    parallel.sync_parameters(d.model)
     dev = d.model.device
     g = torch.Generator().manual_seed(0)
     n_global = a.batch * world
@@ -46,7 +45,7 @@ def main():
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        lv = tr.train_on_batch(x, y, return_device=True)
+        lv, _ = tr.train_on_batch(x, y, return_device=True)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
