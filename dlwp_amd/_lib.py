@@ -18,7 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dlwp_hip.h')
 OK, EINVAL, EUNSUPPORTED, EHIP, ERCCL = 0, -1, -2, -3, -4
 OPT_WINOGRAD, OPT_BF16_MFMA, OPT_FORCE_CONV_CONFIG, OPT_FORCE_WGRAD_CONFIG = 0, 1, 2, 3
 F32, BF16 = 0, 1
-PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
+PAD_ZERO, PAD_WRAP, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC = 0, 1, 2, 3, 4
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
 OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES, OP_PHASE_WEIGHTS, OP_DEPTH2SPACE = 0, 1, 2, 3, 4, 5, 6, 7

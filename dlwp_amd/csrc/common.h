@@ -66,8 +66,18 @@ __host__ __device__ static inline int dlwp_map_coord(int p, int n, int mode) {
   if (p >= 0 && p < n) return p;
   if (mode == DLWP_PAD_ZERO) return -1;
   if (mode == DLWP_PAD_EDGE) return p < 0 ? 0 : n - 1;
+  if (mode == DLWP_PAD_REFLECT) return p < 0 ? -p : 2 * n - 2 - p;        // (validated: pad <= n - 1)
+  if (mode == DLWP_PAD_SYMMETRIC) return p < 0 ? -p - 1 : 2 * n - 1 - p;  // (validated: pad <= n)
   int q = p % n;             // DLWP_PAD_WRAP
   return q < 0 ? q + n : q;
+}
+
+// halo amounts a mode can serve on an axis of length n (the reference's slices / tf.pad reject larger ones too)
+static inline bool dlwp_pad_fits(int lo, int hi, int n, int mode) {
+  const int m = lo > hi ? lo : hi;
+  if (mode == DLWP_PAD_WRAP || mode == DLWP_PAD_SYMMETRIC) return m <= n;
+  if (mode == DLWP_PAD_REFLECT) return m <= n - 1;
+  return true;
 }
 
 // The conv loaders' version: p comes from a tile walk, p in [-n, n + halo) wherever its value matters (the validated halo
@@ -77,6 +87,8 @@ __device__ static inline int dlwp_map_coord_tile(int p, int n, int mode) {
   if (p >= 0 && p < n) return p;
   if (mode == DLWP_PAD_ZERO) return -1;
   if (mode == DLWP_PAD_EDGE) return p < 0 ? 0 : n - 1;
+  if (mode == DLWP_PAD_REFLECT) return p < 0 ? min(-p, n - 1) : max(2 * n - 2 - p, 0);
+  if (mode == DLWP_PAD_SYMMETRIC) return p < 0 ? min(-p - 1, n - 1) : max(2 * n - 1 - p, 0);
   return p < 0 ? max(p + n, 0) : min(p - n, n - 1);   // DLWP_PAD_WRAP
 }
 

@@ -108,8 +108,8 @@ bool same_halo_fast_path(const dlwp_conv2d* cd) {
   const int th = cd->dil_h * (cd->kh - 1), tw = cd->dil_w * (cd->kw - 1);
   if ((th & 1) || (tw & 1)) return false;
   if (p.top != th / 2 || p.bottom != th / 2 || p.left != tw / 2 || p.right != tw / 2) return false;
-  const bool mh_ok = p.mode_h != DLWP_PAD_EDGE || th == 0;
-  const bool mw_ok = p.mode_w != DLWP_PAD_EDGE || tw == 0;
+  const bool mh_ok = p.mode_h == DLWP_PAD_ZERO || p.mode_h == DLWP_PAD_WRAP || th == 0;   // (edge / mirror halos: fold back)
+  const bool mw_ok = p.mode_w == DLWP_PAD_ZERO || p.mode_w == DLWP_PAD_WRAP || tw == 0;
   return mh_ok && mw_ok;
 }
 

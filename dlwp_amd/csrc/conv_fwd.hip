@@ -76,7 +76,8 @@ size_t bf16_prep_floats(const ConvKernelEntry& e, int cin, int cout) {
 bool bf16_wanted(const ConvArgs& a, const dlwp_conv2d* cd, const dlwp_options& o) {
   return o.bf16_mfma && (a.in_bf16 ? a.Cin >= 12 : (a.compute_bf16 && a.Cin >= 4)) && cd->kh == cd->kw &&
          cd->dil_h == cd->dil_w &&
-         cd->src_mode != DLWP_SRC_MAXPOOL2 && (a.W & 1) == 0 && cd->halo.mode_w != DLWP_PAD_EDGE &&
+         cd->src_mode != DLWP_SRC_MAXPOOL2 && (a.W & 1) == 0 &&
+         (cd->halo.mode_w == DLWP_PAD_ZERO || cd->halo.mode_w == DLWP_PAD_WRAP) &&
          (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&    // 32-bit byte offsets inside a sample, in ...
          (long long)a.Ho * a.Wo * a.Cout < (1ll << 28);            // ... and out
 }
@@ -603,13 +604,13 @@ int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys
   DLWP_CHECK_ARG((unsigned)cd->act <= 2u, "conv2d: unknown activation %d", cd->act);
   const dlwp_pad2d& p = cd->halo;
   DLWP_CHECK_ARG(p.top >= 0 && p.bottom >= 0 && p.left >= 0 && p.right >= 0, "conv2d: negative halo");
-  DLWP_CHECK_ARG((unsigned)p.mode_h <= 2u && (unsigned)p.mode_w <= 2u, "conv2d: unknown halo mode");
+  DLWP_CHECK_ARG((unsigned)p.mode_h <= 4u && (unsigned)p.mode_w <= 4u, "conv2d: unknown halo mode");
   const int hin = dlwp_src_dim(xs.h, cd->src_mode), win = dlwp_src_dim(xs.w, cd->src_mode);
   DLWP_CHECK_ARG(hin > 0 && win > 0, "conv2d: empty input after the src transform");
-  DLWP_CHECK_ARG(p.mode_h != DLWP_PAD_WRAP || (p.top <= hin && p.bottom <= hin),
-                 "conv2d: periodic row halo (%d,%d) exceeds H=%d", p.top, p.bottom, hin);
-  DLWP_CHECK_ARG(p.mode_w != DLWP_PAD_WRAP || (p.left <= win && p.right <= win),
-                 "conv2d: periodic column halo (%d,%d) exceeds W=%d", p.left, p.right, win);
+  DLWP_CHECK_ARG(dlwp_pad_fits(p.top, p.bottom, hin, p.mode_h), "conv2d: row halo (%d,%d) of mode %d exceeds H=%d", p.top,
+                 p.bottom, p.mode_h, hin);
+  DLWP_CHECK_ARG(dlwp_pad_fits(p.left, p.right, win, p.mode_w), "conv2d: column halo (%d,%d) of mode %d exceeds W=%d", p.left,
+                 p.right, p.mode_w, win);
   const int ho = hin + p.top + p.bottom - cd->dil_h * (cd->kh - 1);
   const int wo = win + p.left + p.right - cd->dil_w * (cd->kw - 1);
   DLWP_CHECK_ARG(ho > 0 && wo > 0, "conv2d: kernel %dx%d (dilation %dx%d) larger than the padded input %dx%d", cd->kh,

@@ -35,6 +35,8 @@ __device__ __forceinline__ int pad_map_col(int p, int n, int mode) {
   if (p >= 0 && p < n) return p;
   if (mode == DLWP_PAD_ZERO) return -1;
   if (mode == DLWP_PAD_EDGE) return p < 0 ? 0 : n - 1;
+  if (mode == DLWP_PAD_REFLECT) return p < 0 ? -p : 2 * n - 2 - p;
+  if (mode == DLWP_PAD_SYMMETRIC) return p < 0 ? -p - 1 : 2 * n - 1 - p;
   return p < 0 ? p + n : p - n;
 }
 
@@ -135,6 +137,11 @@ __global__ __launch_bounds__(256) void pad2d_bwd_rows_kernel(const float* __rest
         for (int c = 0; c < left; ++c) s += rp[c * in + ch];
       if (w == W - 1)
         for (int c = left + W; c < Wo; ++c) s += rp[c * in + ch];
+    } else if (mode_w >= DLWP_PAD_REFLECT) {   // mirror halos: every halo column is the image of exactly one column
+      for (int c = 0; c < left; ++c)
+        if (pad_map_col(c - left, W, mode_w) == w) s += rp[c * in + ch];
+      for (int c = left + W; c < Wo; ++c)
+        if (pad_map_col(c - left, W, mode_w) == w) s += rp[c * in + ch];
     }
     return s;
   };
@@ -179,6 +186,11 @@ __global__ __launch_bounds__(256) void pad2d_bwd_rows_kernel(const float* __rest
             for (int rr = 0; rr < top; ++rr) acc += col_sum(img + (long long)rr * RO, w, ch);
           if (hh == H - 1)
             for (int rr = top + H; rr < Ho; ++rr) acc += col_sum(img + (long long)rr * RO, w, ch);
+        } else if (mode_h >= DLWP_PAD_REFLECT) {
+          for (int rr = 0; rr < top; ++rr)
+            if (pad_map_col(rr - top, H, mode_h) == hh) acc += col_sum(img + (long long)rr * RO, w, ch);
+          for (int rr = top + H; rr < Ho; ++rr)
+            if (pad_map_col(rr - top, H, mode_h) == hh) acc += col_sum(img + (long long)rr * RO, w, ch);
         }
         v[q] = acc;
       }
@@ -213,6 +225,11 @@ __global__ __launch_bounds__(256) void pad2d_bwd_kernel(const float* __restrict_
     } else if (mode_h == DLWP_PAD_EDGE) {
       if (h == 0) { r_lo = 0; r_hi = top - 1; }
       if (h == H - 1) { r_lo2 = top + H; r_hi2 = Ho - 1; }
+    } else if (mode_h >= DLWP_PAD_REFLECT) {   // a row is the mirror image of at most one top and one bottom halo row
+      const int a = mode_h == DLWP_PAD_REFLECT ? top - h : top - 1 - h;
+      const int b = mode_h == DLWP_PAD_REFLECT ? top + 2 * H - 2 - h : top + 2 * H - 1 - h;
+      if (a >= 0 && a < top) rows[nr++] = a;
+      if (b >= top + H && b < Ho) rows[nr++] = b;
     }
     cols[nc++] = w + left;
     if (mode_w == DLWP_PAD_WRAP) {
@@ -221,6 +238,11 @@ __global__ __launch_bounds__(256) void pad2d_bwd_kernel(const float* __restrict_
     } else if (mode_w == DLWP_PAD_EDGE) {
       if (w == 0) { c_lo = 0; c_hi = left - 1; }
       if (w == W - 1) { c_lo2 = left + W; c_hi2 = Wo - 1; }
+    } else if (mode_w >= DLWP_PAD_REFLECT) {
+      const int a = mode_w == DLWP_PAD_REFLECT ? left - w : left - 1 - w;
+      const int b = mode_w == DLWP_PAD_REFLECT ? left + 2 * W - 2 - w : left + 2 * W - 1 - w;
+      if (a >= 0 && a < left) cols[nc++] = a;
+      if (b >= left + W && b < Wo) cols[nc++] = b;
     }
     const float* base = dy + (long long)o * Ho * Wo * inner + ch;
     float acc = 0.f;
@@ -412,12 +434,15 @@ int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, in
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_pad2d_fwd: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(outer >= 0 && H > 0 && W > 0 && inner > 0, "dlwp_pad2d_fwd: bad shape");
   DLWP_CHECK_ARG(p.top >= 0 && p.bottom >= 0 && p.left >= 0 && p.right >= 0, "dlwp_pad2d_fwd: negative padding");
-  DLWP_CHECK_ARG((unsigned)p.mode_h <= 2u && (unsigned)p.mode_w <= 2u, "dlwp_pad2d_fwd: unknown pad mode");
-  // the reference's slices do not tile (custom.py:197-200): wrap padding larger than the axis is an error there too
+  DLWP_CHECK_ARG((unsigned)p.mode_h <= 4u && (unsigned)p.mode_w <= 4u, "dlwp_pad2d_fwd: unknown pad mode");
+  // the reference's slices do not tile (custom.py:197-200): wrap padding larger than the axis is an error there too;
+  // tf.pad rejects REFLECT amounts >= the axis and SYMMETRIC amounts > the axis
   DLWP_CHECK_ARG(p.mode_h != DLWP_PAD_WRAP || (p.top <= H && p.bottom <= H),
                  "dlwp_pad2d_fwd: periodic row padding (%d,%d) exceeds H=%d", p.top, p.bottom, H);
   DLWP_CHECK_ARG(p.mode_w != DLWP_PAD_WRAP || (p.left <= W && p.right <= W),
                  "dlwp_pad2d_fwd: periodic column padding (%d,%d) exceeds W=%d", p.left, p.right, W);
+  DLWP_CHECK_ARG(dlwp_pad_fits(p.top, p.bottom, H, p.mode_h) && dlwp_pad_fits(p.left, p.right, W, p.mode_w),
+                 "dlwp_pad2d_fwd: mirror padding exceeds the axis");
   if (outer == 0) return DLWP_OK;
   const int Ho = H + p.top + p.bottom, Wo = W + p.left + p.right;
   const long long RI = (long long)W * inner, RO = (long long)Wo * inner;
@@ -456,9 +481,11 @@ int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, 
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_pad2d_bwd: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(outer >= 0 && H > 0 && W > 0 && inner > 0, "dlwp_pad2d_bwd: bad shape");
   DLWP_CHECK_ARG(p.top >= 0 && p.bottom >= 0 && p.left >= 0 && p.right >= 0, "dlwp_pad2d_bwd: negative padding");
-  DLWP_CHECK_ARG((unsigned)p.mode_h <= 2u && (unsigned)p.mode_w <= 2u, "dlwp_pad2d_bwd: unknown pad mode");
+  DLWP_CHECK_ARG((unsigned)p.mode_h <= 4u && (unsigned)p.mode_w <= 4u, "dlwp_pad2d_bwd: unknown pad mode");
   DLWP_CHECK_ARG(p.mode_h != DLWP_PAD_WRAP || (p.top <= H && p.bottom <= H), "dlwp_pad2d_bwd: periodic rows exceed H");
   DLWP_CHECK_ARG(p.mode_w != DLWP_PAD_WRAP || (p.left <= W && p.right <= W), "dlwp_pad2d_bwd: periodic cols exceed W");
+  DLWP_CHECK_ARG(dlwp_pad_fits(p.top, p.bottom, H, p.mode_h) && dlwp_pad_fits(p.left, p.right, W, p.mode_w),
+                 "dlwp_pad2d_bwd: mirror padding exceeds the axis");
   if (outer == 0) return DLWP_OK;
   {
     // row-staged kernel whenever 4 waves x 4 padded rows fit in LDS (every shape of the reference's networks does)

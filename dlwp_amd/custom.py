@@ -36,6 +36,37 @@ class FillPadding2D(_layers._Pad2DBase):
     mode = 2
 
 
+class TFPadding2D(_layers._Pad2DBase):
+    """tf.pad as a layer (reference DLWP/custom.py:527-600): mode 'CONSTANT' (zeros), 'REFLECT' (mirror without the border
+    element) or 'SYMMETRIC' (mirror with it); same padding argument forms as ZeroPadding2D.  Like every halo here it is a
+    lazy view fused into the consuming convolution's loader.  A non-zero `constant_values` is not lowered."""
+
+    def __init__(self, padding=(1, 1), data_format=None, mode='CONSTANT', constant_values=0., **kwargs):
+        super(TFPadding2D, self).__init__(padding=padding, data_format=data_format, **kwargs)
+        modes = {'CONSTANT': 0, 'REFLECT': 3, 'SYMMETRIC': 4}
+        if str(mode).upper() not in modes:
+            raise ValueError("TFPadding2D mode must be one of 'CONSTANT', 'REFLECT', 'SYMMETRIC', got %r" % (mode,))
+        self.tf_mode = str(mode).upper()
+        self.mode = modes[self.tf_mode]
+        self.constant_values = float(constant_values)
+        if self.mode == 0 and self.constant_values != 0.:
+            raise NotImplementedError('TFPadding2D: a non-zero constant_values is not implemented (zeros are)')
+
+    def compute_output_shape(self, s):
+        out = super(TFPadding2D, self).compute_output_shape(s)
+        (t, b), (l, r) = self.padding
+        h, w = (s[1], s[2]) if self.data_format == 'channels_first' else (s[0], s[1])
+        lim_h, lim_w = (h - 1, w - 1) if self.mode == 3 else (h, w)
+        if self.mode and (max(t, b) > lim_h or max(l, r) > lim_w):      # tf.pad's own limits
+            raise ValueError('%s: %s padding %r exceeds the input size %dx%d' % (self.name, self.tf_mode, self.padding, h, w))
+        return out
+
+    def get_config(self):
+        cfg = super(TFPadding2D, self).get_config()
+        cfg.update({'mode': self.tf_mode, 'constant_values': self.constant_values})
+        return cfg
+
+
 class PeriodicPadding3D(_layers._Pad3DBase):
     """Periodic padding of the three trailing axes (reference DLWP/custom.py:217-306; last axis first, then the middle one
     of the already padded tensor, then the first).  On the HIP path it pads the (T, C, H, W) input of ConvLSTM2D

@@ -7,7 +7,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_LINEAR, ACT_RELU, ACT_TANH, PAD_EDGE, PAD_WRAP, PAD_ZERO, SRC_DIRECT, SRC_MAXPOOL2,  # noqa: F401
+from ._lib import (ACT_LINEAR, ACT_RELU, ACT_TANH, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC, PAD_WRAP, PAD_ZERO,  # noqa: F401
+                   SRC_DIRECT, SRC_MAXPOOL2,
                    SRC_UPSAMPLE2, Conv2d, Pad2d, Shape4)
 
 ACTIVATIONS = {None: ACT_LINEAR, 'linear': ACT_LINEAR, 'tanh': ACT_TANH, 'relu': ACT_RELU}

@@ -14,7 +14,7 @@ import os
 
 from . import layers as L
 
-PAD_ZERO, PAD_WRAP, PAD_EDGE = 0, 1, 2
+PAD_ZERO, PAD_WRAP, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC = 0, 1, 2, 3, 4
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
 ACT = {'linear': 0, None: 0, 'tanh': 1, 'relu': 2}
 STATE_IN = -1
@@ -535,7 +535,11 @@ def build_plan(inputs, outputs, inference=False):
             # both serve the training plan as well: (a) is a plain graph identity (forward, data and weight gradient of
             # the layer then run on the low-resolution tensors); (b) trains through the adjoints of its two linear maps
             # (dlwp_phase_weights_bwd, dlwp_space_to_depth2; training.py)
-            restate = RESTATE_UPSAMPLED and v.src_mode == SRC_UPSAMPLE2
+            # (a mirror halo WITHOUT the border element -- TFPadding2D 'REFLECT' -- does not commute with the up-sampling:
+            #  up-sampled coordinate 2n reflects to source n - 1, low-resolution coordinate n to n - 2; the layer then keeps
+            #  the reference's formulation.  'SYMMETRIC', periodic, zero and edge halos commute.)
+            restate = (RESTATE_UPSAMPLED and v.src_mode == SRC_UPSAMPLE2 and
+                       halo.mode_h != PAD_REFLECT and halo.mode_w != PAD_REFLECT)
             if (restate and tuple(lay.dilation_rate) == (2, 2) and
                     all(p % 2 == 0 for p in halo[:4]) and ho % 2 == 0 and wo % 2 == 0):
                 h2 = Halo(halo.top // 2, halo.bottom // 2, halo.left // 2, halo.right // 2, halo.mode_h, halo.mode_w)

@@ -19,6 +19,8 @@ def _layer_config(lay):
         cfg['input_shape'] = list(lay.batch_input_shape[1:])
     elif isinstance(lay, (L._Pad2DBase, L._Pad3DBase)):
         cfg.update(padding=[list(p) for p in lay.padding], data_format=lay.data_format)
+        if hasattr(lay, 'tf_mode'):          # TFPadding2D
+            cfg.update(mode=lay.tf_mode, constant_values=lay.constant_values)
     elif isinstance(lay, L.ConvLSTM2D):
         from .regularizers import L1L2
         cfg.update(filters=lay.filters, kernel_size=list(lay.kernel_size), padding=lay.padding,

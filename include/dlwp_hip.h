@@ -50,6 +50,8 @@ extern "C" {
 #define DLWP_PAD_ZERO 0   /* keras.layers.ZeroPadding2D                                  (examples/train.py:163)   */
 #define DLWP_PAD_WRAP 1   /* DLWP.custom.PeriodicPadding2D                               (DLWP/custom.py:139-214)  */
 #define DLWP_PAD_EDGE 2   /* DLWP.custom.FillPadding2D (pole rows)                       (DLWP/custom.py:309-402)  */
+#define DLWP_PAD_REFLECT   3   /* DLWP.custom.TFPadding2D(mode='REFLECT'):   tf.pad mirror WITHOUT the border element  */
+#define DLWP_PAD_SYMMETRIC 4   /* DLWP.custom.TFPadding2D(mode='SYMMETRIC'): tf.pad mirror WITH it (custom.py:527-600) */
 
 #define DLWP_ACT_LINEAR 0
 #define DLWP_ACT_TANH   1

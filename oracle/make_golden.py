@@ -704,6 +704,25 @@ def main():
         los['latw_%s' % weighting] = np.asarray(np.mean(fn(yt, yp)), dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, 'losses.npz'), **los)
 
+    # ----- forecast error measures (DLWP/model/verify.py:17-102; plain numpy in the reference too) -------------------- #
+    from DLWP.model import verify as rv
+    ver = {}
+    fc = rng.standard_normal((5, 9, 2, 6, 8)).astype(np.float32)          # (forecast step, sample, var, lat, lon)
+    va = rng.standard_normal((9, 2, 6, 8)).astype(np.float32)
+    va5 = rng.standard_normal((5, 9, 2, 6, 8)).astype(np.float32)
+    fc[2, 3, 0, 1, 1] = np.nan                                             # nanmean semantics
+    va[7, 1, 2, 2] = np.nan
+    ver['forecast'], ver['valid'], ver['valid_steps'] = fc, va, va5
+    for method in ('mse', 'mae', 'rmse'):
+        ver['fe_series_%s' % method] = rv.forecast_error(fc, va, method=method)
+        ver['fe_series_axis_%s' % method] = rv.forecast_error(fc, va, method=method, axis=(0, 2, 3))
+        ver['fe_steps_%s' % method] = rv.forecast_error(fc, va5, method=method)
+        ver['fe_steps_axis_%s' % method] = rv.forecast_error(fc, va5, method=method, axis=(1, 3, 4))
+        ver['pe_%s' % method] = rv.persistence_error(fc[0], va, 4, method=method)
+        ver['pe_axis_%s' % method] = rv.persistence_error(fc[0], va, 4, method=method, axis=0)
+        ver['ce_%s' % method] = rv.climo_error(va, 3, method=method)
+    np.savez_compressed(os.path.join(OUT, 'verify.npz'), **ver)
+
     for f in sorted(os.listdir(OUT)):
         print('%-16s %8d bytes' % (f, os.path.getsize(os.path.join(OUT, f))))
 

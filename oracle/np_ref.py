@@ -99,8 +99,11 @@ def pad2d_modes(x, pads, mode_h, mode_w):
     """Per-axis-mode pad of an NCHW tensor -- the form the fused HIP halo uses (include/dlwp_hip.h dlwp_pad2d).
     pads = (top, bottom, left, right).  Equivalent to composing the layer functions above one axis at a time."""
     t, b, l, r = pads
-    fn = {PAD_ZERO: lambda a, ax, lo, hi: np.pad(a, [(lo, hi) if i == ax else (0, 0) for i in range(a.ndim)]),
-          PAD_WRAP: _wrap_axis, PAD_EDGE: _edge_axis}
+    def np_mode(name):
+        return lambda a, ax, lo, hi: np.pad(a, [(lo, hi) if i == ax else (0, 0) for i in range(a.ndim)], mode=name)
+    # 3 / 4: tf.pad 'REFLECT' / 'SYMMETRIC' (TFPadding2D, reference custom.py:527-600) == numpy's modes of the same names
+    fn = {PAD_ZERO: np_mode('constant'), PAD_WRAP: _wrap_axis, PAD_EDGE: _edge_axis, 3: np_mode('reflect'),
+          4: np_mode('symmetric')}
     y = fn[mode_w](x, x.ndim - 1, l, r)
     return fn[mode_h](y, x.ndim - 2, t, b)
 
@@ -124,6 +127,12 @@ def pad2d_modes_grad(dy, x_shape, pads, mode_h, mode_w):
                 core[..., 0] += a[..., :lo].sum(-1)
             if hi:
                 core[..., n - 1] += a[..., lo + n:].sum(-1)
+        elif mode in (3, 4):       # mirror halos: padded position p is the image of one interior position
+            off = 0 if mode == 3 else 1
+            for p in range(lo):
+                core[..., lo - p - off] += a[..., p]
+            for p in range(lo + n, lo + n + hi):
+                core[..., 2 * n - 2 + off - (p - lo)] += a[..., p]
         return np.moveaxis(core, -1, axis)
     g = fold(np.asarray(dy, dtype=np.float64), dy.ndim - 2, t, b, H, mode_h)
     return fold(g, dy.ndim - 1, l, r, W, mode_w)
@@ -423,6 +432,10 @@ def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_wei
             x = fill_padding2d(x, args[0] if args else kwargs.get('padding', (1, 1)), fmt)
         elif name == 'ZeroPadding2D':
             x = zero_padding2d(x, args[0] if args else kwargs.get('padding', (1, 1)), fmt)
+        elif name == 'TFPadding2D':      # tf.pad(mode) on the two spatial axes (custom.py:585-590), channels_first
+            (t, b), (l, r) = normalize_padding(args[0] if args else kwargs.get('padding', (1, 1)), 2)
+            m = {'CONSTANT': PAD_ZERO, 'REFLECT': 3, 'SYMMETRIC': 4}[kwargs.get('mode', 'CONSTANT').upper()]
+            x = pad2d_modes(x, (t, b, l, r), m, m)
         elif name == 'Conv2D':
             _, _, dil, act = _conv_args(args, kwargs)
             w, b = weights[wi]

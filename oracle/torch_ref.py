@@ -54,6 +54,16 @@ def run_layers(layers, x, tweights, record=None):
         args, kwargs = args or (), kwargs or {}
         if name in ('PeriodicPadding2D', 'ZeroPadding2D', 'FillPadding2D'):
             x = _pad_layer(x, name, args[0] if args else kwargs.get('padding', (1, 1)))
+        elif name == 'TFPadding2D':
+            (t, b), (l, r) = np_ref.normalize_padding(args[0] if args else kwargs.get('padding', (1, 1)), 2)
+            mode = kwargs.get('mode', 'CONSTANT').upper()
+            if mode == 'CONSTANT':
+                x = F.pad(x, (l, r, t, b))
+            elif mode == 'REFLECT':
+                x = F.pad(x, (l, r, t, b), mode='reflect')
+            else:       # SYMMETRIC: mirror with the border element = flipped border strips
+                x = torch.cat([x[..., :l].flip(-1), x, x[..., x.shape[-1] - r:].flip(-1)], dim=-1)
+                x = torch.cat([x[..., :t, :].flip(-2), x, x[..., x.shape[-2] - b:, :].flip(-2)], dim=-2)
         elif name == 'Conv2D':
             _, _, dil, act = np_ref._conv_args(args, kwargs)
             w, b = tweights[wi]

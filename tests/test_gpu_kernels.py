@@ -70,8 +70,8 @@ def test_pad2d_rejects_periodic_pad_larger_than_axis(ops):
 def test_pad2d_all_modes_fwd_bwd(ops, shape):
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal(shape).astype(np.float32)
-    for mh in (0, 1, 2):
-        for mw in (0, 1, 2):
+    for mh in (0, 1, 2, 3, 4):           # zero, periodic, edge, tf.pad REFLECT, tf.pad SYMMETRIC
+        for mw in (0, 1, 2, 3, 4):
             pads = (2, 1, 3, 2) if shape[-1] % 4 else (2, 2, 2, 2)
             p = ops.make_pad(*pads, mh, mw)
             want = np_ref.pad2d_modes(x, pads, mh, mw)
@@ -178,6 +178,10 @@ CASES = [
     (1, 4, 10, 14, 8, 3, 1, (0, 0, 0, 0), 0, 0, 'linear', 0),         # plain valid conv, output smaller than input
     (1, 12, 10, 20, 32, 3, 2, (2, 2, 2, 2), 2, 2, 'tanh', 0),         # fill both axes, cin=12
     (3, 4, 8, 36, 32, 3, 2, (2, 2, 2, 2), 0, 1, 'tanh', 0),
+    (2, 8, 12, 20, 32, 3, 1, (1, 1, 1, 1), 3, 3, 'tanh', 0),          # TFPadding2D REFLECT halo, Winograd family
+    (2, 6, 9, 14, 20, 5, 1, (2, 2, 2, 2), 4, 3, 'linear', 0),          # SYMMETRIC rows, REFLECT columns, direct family
+    (2, 8, 6, 10, 32, 3, 1, (1, 1, 1, 1), 4, 4, 'tanh', 1),            # SYMMETRIC halo on an up-sampled source
+    (1, 8, 12, 20, 16, 3, 2, (2, 2, 2, 2), 3, 1, 'relu', 2),           # REFLECT rows on a pooled source, dilation 2
 ]
 
 

@@ -264,6 +264,48 @@ def test_functional_skip_unet_and_chained_outputs():
     assert np.array_equal(ts, np_ref._merge_time(np.stack(slots), 4, 3, 2, cs, False))
 
 
+def test_tf_padding2d_modes_forward_and_training_match_the_oracle():
+    """TFPadding2D (reference DLWP/custom.py:527-600: tf.pad CONSTANT / REFLECT / SYMMETRIC) as the halo of a small
+    encoder-decoder: fused into the convolution loaders, forward against the float64 oracle (numpy's pad modes of the same
+    names), one train step's loss and gradients against torch autograd.  The REFLECT layer behind the UpSampling2D is not
+    restated on its low-resolution source (that identity does not hold for a mirror without the border element)."""
+    rng = np.random.default_rng(23)
+    cs = (3, 12, 20)
+
+    def blk(f, k, mode, act):
+        return [('TFPadding2D', (k // 2,), dict(CF, mode=mode)),
+                ('Conv2D', (f, k), dict(CF, padding='valid', activation=act))]
+    layers = blk(16, 3, 'REFLECT', 'tanh')
+    layers[0][2]['input_shape'] = cs
+    layers += [('MaxPooling2D', (2,), dict(CF))] + blk(32, 3, 'SYMMETRIC', 'tanh') + [('UpSampling2D', (2,), dict(CF))]
+    layers += blk(16, 3, 'REFLECT', 'tanh') + blk(3, 5, 'SYMMETRIC', 'linear') + blk(3, 3, 'CONSTANT', 'linear')
+    layers = tuple(layers)
+    d = _build(layers, time_dim=1)
+    assert all(op.kind in ('conv', 'maxpool') for op in d.model.infer_plan.ops if op.kind not in ('phasew', 'd2s'))
+    weights = _weights_of(d.model, rng)
+    x = rng.standard_normal((3,) + cs).astype(np.float32)
+    got = d.predict(x)
+    want = np_ref.run_layers(layers, x, weights)
+    assert got.shape == want.shape and _rel(got, want) < FWD_TOL
+    y = rng.standard_normal(got.shape).astype(np.float32)
+    tw = torch_ref.to_torch_weights(weights, dtype=torch.float64, requires_grad=True)
+    out = torch_ref.run_layers(layers, torch.tensor(x, dtype=torch.float64), tw)
+    assert _rel(out.detach().numpy(), want) < 1e-12                      # the two oracles agree on the mirror modes
+    loss = ((out - torch.tensor(y, dtype=torch.float64)) ** 2).mean()
+    loss.backward()
+    vals = d.model.train_on_batch(x, y)
+    assert vals[0] == pytest.approx(float(loss.detach()), rel=2e-5)
+    tr = d.model._trainer
+    off = 0
+    for w, b in tw:
+        for g_ref in (w.grad.numpy().transpose(2, 3, 1, 0), b.grad.numpy()):
+            g = tr.flat_grads[off:off + g_ref.size].cpu().numpy().reshape(g_ref.shape)
+            off += g_ref.size
+            assert np.abs(g - g_ref).max() <= 2e-4 * max(np.abs(g_ref).max(), 1e-6), g_ref.shape
+    with pytest.raises(NotImplementedError, match='constant_values'):
+        _build((('TFPadding2D', (1,), dict(CF, mode='CONSTANT', constant_values=1.0, input_shape=cs)),))
+
+
 def test_standalone_layers_run_when_nothing_fuses():
     """Padding-only / pooling-tail models exercise the standalone kernels through build_model (both data formats)."""
     rng = np.random.default_rng(6)
@@ -481,7 +523,8 @@ def test_conv_backward_kernels_against_oracle_all_halo_modes():
     cases = [  # cin, cout, k, dil, pads, mh, mw, src
         (8, 24, 3, 1, (1, 1, 1, 1), 0, 1, 0), (20, 36, 3, 2, (2, 2, 2, 2), 0, 1, 0), (6, 4, 5, 1, (2, 2, 2, 2), 0, 1, 0),
         (8, 16, 3, 1, (1, 1, 1, 1), 0, 1, 1), (8, 16, 3, 1, (1, 1, 1, 1), 0, 1, 2), (5, 7, 3, 2, (2, 1, 3, 2), 2, 1, 0),
-        (4, 8, 3, 1, (0, 0, 0, 0), 0, 0, 0), (6, 8, 3, 1, (1, 1, 1, 1), 2, 2, 0), (33, 40, 3, 1, (1, 1, 1, 1), 1, 1, 0)]
+        (4, 8, 3, 1, (0, 0, 0, 0), 0, 0, 0), (6, 8, 3, 1, (1, 1, 1, 1), 2, 2, 0), (33, 40, 3, 1, (1, 1, 1, 1), 1, 1, 0),
+        (8, 32, 3, 1, (1, 1, 1, 1), 3, 3, 0), (6, 8, 5, 1, (2, 2, 2, 2), 4, 3, 0), (8, 16, 3, 1, (1, 1, 1, 1), 4, 1, 1)]
     for cin, cout, k, dil, pads, mh, mw, src in cases:
         n, h, w = 3, 12, 20
         x = rng.standard_normal((n, cin, h, w)).astype(np.float32)

@@ -172,3 +172,25 @@ def test_custom_losses_match_reference(golden):
         w = np_ref.latitude_weights(g['lats'], weighting)[None, None, :, None]
         got = np.mean((yt * w - yp * w) ** 2)
         assert np.isclose(got, float(g['latw_%s' % weighting]), rtol=2e-5)
+
+
+def test_forecast_error_measures_equal_the_reference(golden):
+    """dlwp_amd.model.verify (forecast_error / persistence_error / climo_error) against the reference's own functions
+    (DLWP/model/verify.py:17-102) run by oracle/make_golden.py: both verification layouts, explicit axes, NaN samples."""
+    from dlwp_amd.model import verify
+    g = golden('verify')
+    fc, va, va5 = g['forecast'], g['valid'], g['valid_steps']
+    for method in ('mse', 'mae', 'rmse'):
+        cases = {'fe_series_%s': verify.forecast_error(fc, va, method=method),
+                 'fe_series_axis_%s': verify.forecast_error(fc, va, method=method, axis=(0, 2, 3)),
+                 'fe_steps_%s': verify.forecast_error(fc, va5, method=method),
+                 'fe_steps_axis_%s': verify.forecast_error(fc, va5, method=method, axis=(1, 3, 4)),
+                 'pe_%s': verify.persistence_error(fc[0], va, 4, method=method),
+                 'pe_axis_%s': verify.persistence_error(fc[0], va, 4, method=method, axis=0),
+                 'ce_%s': verify.climo_error(va, 3, method=method)}
+        for key, got in cases.items():
+            want = g[key % method]
+            assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True), key % method
+    import pytest
+    with pytest.raises(ValueError, match="'method' must be"):
+        verify.forecast_error(fc, va, method='bias')
