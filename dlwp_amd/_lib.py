@@ -185,6 +185,13 @@ def check(rc):
 _handles = {}
 
 
+#: held while a training step is being stream-captured (Trainer._capture_step) and by every other thread of this package
+#: that issues device work (DeviceLoader's staging thread): HIP aborts a capture that another thread's stream operations
+#: run into
+import threading  # noqa: E402
+capture_lock = threading.RLock()
+
+
 def handle_or_none(device_index=None):
     """The handle of a device if there is a GPU, else None: the planner hints are pure host logic and run with the default
     options on a machine without one (CPU tests build plans)."""

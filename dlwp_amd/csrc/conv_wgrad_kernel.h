@@ -169,12 +169,14 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
   // a halo coordinate wraps at most once when halo + tile fit the axis; tiny axes take the general (%) mapping
   const bool fast_h = a.H >= C::LR + a.pad_top, fast_w = a.W >= C::LC + a.pad_left + 1;
   auto map_axis = [&](int p, int n, int mode, bool fast) -> int {
+    if (mode >= DLWP_PAD_REFLECT) return dlwp_map_coord_tile(p, n, mode);   // mirror halos (clamped outside their range)
     if (!fast) return dlwp_map_coord(p, n, mode);
     if (mode == DLWP_PAD_ZERO) return (unsigned)p < (unsigned)n ? p : -1;
     if (mode == DLWP_PAD_EDGE) return min(max(p, 0), n - 1);
     return p < 0 ? p + n : (p >= n ? p - n : p);
   };
-  const bool pair_x = (a.W & 1) == 0 && a.mode_w != DLWP_PAD_EDGE;   // an even column and its neighbour: one 8-byte load
+  // an even column and its neighbour: one 8-byte load (zero / periodic halos keep neighbours adjacent; edge and mirror do not)
+  const bool pair_x = (a.W & 1) == 0 && (a.mode_w == DLWP_PAD_ZERO || a.mode_w == DLWP_PAD_WRAP);
   const bool quad_z = (a.Wo & 3) == 0;                                // 4 pixels of dz: one 16-byte load
   constexpr unsigned DROP = 0x7ffffff0u;
 

@@ -526,13 +526,15 @@ class DeviceLoader(object):
             hs.append(h)
             ds.append(dbuf[:a.size].view(a.shape))
         if self._copy_stream is not None:
-            if bufs['free'] is not None:
-                self._copy_stream.wait_event(bufs['free'])      # the consumer is done with this slot's device buffers
-            with torch.cuda.stream(self._copy_stream):
-                for d, h in zip(ds, hs):
-                    d.copy_(h, non_blocking=True)
-                bufs['ev'].record(self._copy_stream)
-                bufs['recorded'] = True
+            from .._lib import capture_lock
+            with capture_lock:          # never while the consumer thread is capturing its training step as a graph
+                if bufs['free'] is not None:
+                    self._copy_stream.wait_event(bufs['free'])      # the consumer is done with this slot's device buffers
+                with torch.cuda.stream(self._copy_stream):
+                    for d, h in zip(ds, hs):
+                        d.copy_(h, non_blocking=True)
+                    bufs['ev'].record(self._copy_stream)
+                    bufs['recorded'] = True
         else:
             for d, h in zip(ds, hs):
                 d.copy_(h)

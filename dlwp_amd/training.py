@@ -531,14 +531,15 @@ class Trainer(object):
     graph_after = 2
 
     def _graph_ok(self):
-        """Forward + loss + backward (+ optimizer) of one step are ~60 launches from Python: at 8 samples per GPU (config 3 on
-        8 GPUs) the host cannot issue them as fast as the GPU retires them.  A step whose launch sequence does not depend on
-        the data is captured once per batch shape (torch.cuda.CUDAGraph around our C-ABI launches: its private pool keeps the
-        per-op gradient buffers at fixed addresses) and replayed with one hipGraphLaunch.  Not captured: kernel regularisers
-        (their penalty is read back to the host every step), SGD with decay (its rate is a launch argument), steps on the CPU
-        device, DLWP_TRAIN_GRAPH=0."""
+        """Opt-in (DLWP_TRAIN_GRAPH=1): forward + loss + backward (+ optimizer) of one step are ~60 launches from Python; a
+        step whose launch sequence does not depend on the data is captured once per batch shape (torch.cuda.CUDAGraph around
+        our C-ABI launches: its private pool keeps the per-op gradient buffers at fixed addresses) and replayed with one
+        hipGraphLaunch.  Measured on one MI355X (profiles/r2k_train_graph_ab.txt): 1.86 vs 1.84 ms / step at 64 samples and
+        0.569 vs 0.557 ms at 8 -- the asynchronous launches already run ahead of the GPU, the step is bound by its ~60 short
+        kernels, not by the host -- so the default stays eager.  Never captured: kernel regularisers (their penalty is read
+        back to the host every step), SGD with decay (its rate is a launch argument), steps on the CPU device."""
         opt = self.model.optimizer
-        if self.device.type != 'cuda' or os.environ.get('DLWP_TRAIN_GRAPH', '1') == '0':
+        if self.device.type != 'cuda' or os.environ.get('DLWP_TRAIN_GRAPH', '0') != '1':
             return False
         if any(True for _ in self._regularized()):
             return False
@@ -554,9 +555,10 @@ class Trainer(object):
             self._lr_t = torch.zeros(1, dtype=torch.float32, device=self.device)
         if self.opt_state is None:
             raise RuntimeError('the optimizer slots must exist before the step is captured')
+        from ._lib import capture_lock
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        with capture_lock, torch.cuda.graph(g, capture_error_mode='thread_local'):
             outs, loss_vals, dys = self._forward_loss(gx, gys, True, scale)
             self._backward(gx, outs, dys)
             if dp is not None:       # the exchange and the update stay outside: a collective in between
