@@ -264,6 +264,51 @@ def test_functional_skip_unet_and_chained_outputs():
     assert np.array_equal(ts, np_ref._merge_time(np.stack(slots), 4, 3, 2, cs, False))
 
 
+def test_fit_generator_with_sequence_targets_of_a_multi_output_model():
+    """examples/train_functional.py flow: SeriesDataGenerator(sequence=2) hands a LIST of target arrays per batch and a
+    DLWPFunctional model with two chained outputs trains on them through fit_generator -- i.e. through the DeviceLoader,
+    which stages every target on its own.  The device feed equals feeding the generator's batches by hand."""
+    from dlwp_amd import layers as L
+    from dlwp_amd.engine import Model
+    from dlwp_amd.model import DLWPFunctional, SeriesDataGenerator, SeriesDataset
+    from dlwp_amd.training import Adam
+    rng = np.random.default_rng(15)
+    n_t, h, w = 30, 12, 16
+    dates = (np.datetime64('2012-01-01T00') + np.arange(n_t) * np.timedelta64(6, 'h')).astype('datetime64[s]')
+    series = np.cumsum(0.3 * rng.standard_normal((n_t, 2, 1, h, w)), axis=0).astype(np.float32)
+    ds = SeriesDataset(series, {'sample': dates, 'variable': np.array(['z', 't']), 'level': np.array([500]),
+                                'lat': np.linspace(60., -60., h), 'lon': np.arange(0., 360., 22.5)},
+                       ('sample', 'variable', 'level', 'lat', 'lon'))
+
+    def build():
+        np.random.seed(8)
+        x0 = L.Input(shape=(4, h, w))
+        c1 = L.Conv2D(8, 3, padding='same', activation='tanh', **CF)
+        c2 = L.Conv2D(4, 3, padding='same', activation='linear', **CF)
+        o1 = c2(c1(x0))
+        o2 = c2(c1(o1))
+        f = DLWPFunctional(is_convolutional=True, time_dim=2)
+        f.build_model(Model(inputs=x0, outputs=[o1, o2]), loss='mse', loss_weights=[0.5, 0.5], optimizer=Adam(lr=2e-3),
+                      metrics=['mae'])
+        return f
+    f = build()
+    gen = SeriesDataGenerator(f, ds, input_time_steps=2, output_time_steps=2, sequence=2, batch_size=6)
+    X, y = gen[0]
+    assert isinstance(y, list) and len(y) == 2 and y[0].shape == X.shape == (6, 4, h, w)
+    hist = f.fit_generator(gen, epochs=3, verbose=0)
+    losses = f.model.history.history['loss']
+    assert len(losses) == 3 and np.isfinite(losses).all() and losses[-1] < losses[0]
+    # the same three epochs, batches fed by hand
+    g = build()
+    for _ in range(3):
+        for i in range(len(gen)):
+            Xi, yi = gen[i]
+            g.model.train_on_batch(Xi, yi)
+    assert g.model.optimizer.iterations == f.model.optimizer.iterations == 3 * len(gen)
+    for a, b in zip(f.model.get_weights(), g.model.get_weights()):
+        assert np.array_equal(a, b)
+
+
 def test_tf_padding2d_modes_forward_and_training_match_the_oracle():
     """TFPadding2D (reference DLWP/custom.py:527-600: tf.pad CONSTANT / REFLECT / SYMMETRIC) as the halo of a small
     encoder-decoder: fused into the convolution loaders, forward against the float64 oracle (numpy's pad modes of the same
