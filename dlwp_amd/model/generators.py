@@ -245,56 +245,68 @@ class SeriesDataGenerator(object):
     the last input step; `sequence` = K gives a list of K consecutive target blocks (multi-output functional models).
     Same constructor, properties and batch layout as the reference (DLWP/model/generators.py:323-629)."""
 
+    #: how much of the dataset is read into memory up front: the whole file / the selected variables / only the series
+    LOAD_MODES = ('full', 'required', 'minimal')
+
     def __init__(self, model, ds, input_sel=None, output_sel=None, input_time_steps=1, output_time_steps=1,
                  sequence=None, interval=1, add_insolation=False, batch_size=32, shuffle=False, remove_nan=True,
                  load='required'):
-        self.model = model
         if not hasattr(ds, 'predictors'):
             raise ValueError("dataset must have 'predictors' variable")
-        assert int(input_time_steps) > 0
-        assert int(output_time_steps) > 0
-        assert int(batch_size) > 0
-        assert int(interval) > 0
-        if sequence is not None:
-            assert int(sequence) > 0
-        if load and load not in ['full', 'required', 'minimal']:
-            if isinstance(load, bool):
-                load = 'required'
-            else:
-                raise ValueError("'load' must be one of 'full', 'required', or 'minimal'")
-        self.ds = ds
-        if load == 'full':
-            ds.load()
-        self._batch_size = batch_size
-        self._shuffle = shuffle
-        self._remove_nan = remove_nan
-        self._is_convolutional = model.is_convolutional
-        self._keep_time_axis = model.is_recurrent
-        self._impute_missing = model.impute
+        for value in (input_time_steps, output_time_steps, batch_size, interval) + (() if sequence is None else (sequence,)):
+            assert int(value) > 0
+        load = self._load_mode(load)
+        self.model, self.ds = model, ds
+        self._set_model_flags(model)
+        self._batch_size, self._shuffle, self._remove_nan = batch_size, shuffle, remove_nan
+        self._set_window(ds.dims['sample'], input_time_steps, output_time_steps, interval, sequence)
+        self._select(ds, input_sel, output_sel, load)
         self._indices = []
-        self._sequence = sequence
-        n_out = output_time_steps * (sequence if sequence is not None else 1)
-        self._n_sample = ds.dims['sample'] - input_time_steps - n_out + 2 - interval
-        # a file written with a 'time_step' dimension carries the initialisation time at time_step = -1
-        self.da = ds.predictors.isel(time_step=-1) if 'time_step' in ds.dims else ds.predictors
-        self._input_sel = input_sel or {}
-        self._output_sel = output_sel or {}
-        self._input_time_steps = input_time_steps
-        self._output_time_steps = output_time_steps
-        self._interval = interval
-        if load == 'minimal':
-            self.da.load()
-        self.input_da = self.da.sel(**self._input_sel)
-        self.output_da = self.da.sel(**self._output_sel)
-        if load == 'required':
-            self.input_da.load()
-            self.output_da.load()
         self.on_epoch_end()
         self._add_insolation = int(add_insolation)
         if add_insolation:
-            sol = insolation(self.da.sample.values, self.da.lat.values, self.da.lon.values)
-            self.insolation_da = LabeledArray(sol, {'sample': self.da.sample.values, 'lat': self.da.lat.values,
-                                                    'lon': self.da.lon.values}, ('sample', 'lat', 'lon'))
+            self.insolation_da = self._insolation_series(self.da)
+
+    @classmethod
+    def _load_mode(cls, load):
+        """True / False are accepted for the reference's older boolean argument (both mean 'required')."""
+        if not load or load in cls.LOAD_MODES:
+            return load
+        if isinstance(load, bool):
+            return 'required'
+        raise ValueError("'load' must be one of 'full', 'required', or 'minimal'")
+
+    def _set_model_flags(self, model):
+        self._is_convolutional = model.is_convolutional
+        self._keep_time_axis = model.is_recurrent
+        self._impute_missing = model.impute
+
+    def _set_window(self, n_series, t_in, t_out, interval, sequence):
+        """A sample = t_in input steps, a gap of interval - 1 steps, then t_out target steps, `sequence` times over: the
+        number of start positions that fit the series (reference generators.py:389)."""
+        self._input_time_steps, self._output_time_steps = t_in, t_out
+        self._interval, self._sequence = interval, sequence
+        span = t_in + (interval - 1) + t_out * (sequence or 1)
+        self._n_sample = n_series - span + 1
+
+    def _select(self, ds, input_sel, output_sel, load):
+        """The series itself and its input / output variable selections, loaded as far as `load` asks.  A file written with
+        a 'time_step' dimension carries the initialisation time at time_step = -1."""
+        if load == 'full':
+            ds.load()
+        self.da = ds.predictors.isel(time_step=-1) if 'time_step' in ds.dims else ds.predictors
+        if load == 'minimal':
+            self.da.load()
+        self._input_sel, self._output_sel = input_sel or {}, output_sel or {}
+        self.input_da, self.output_da = self.da.sel(**self._input_sel), self.da.sel(**self._output_sel)
+        if load == 'required':
+            self.input_da.load()
+            self.output_da.load()
+
+    @staticmethod
+    def _insolation_series(da):
+        times, lat, lon = da.sample.values, da.lat.values, da.lon.values
+        return LabeledArray(insolation(times, lat, lon), {'sample': times, 'lat': lat, 'lon': lon}, ('sample', 'lat', 'lon'))
 
     # -- shapes ------------------------------------------------------------------------------------------------------ #
     @property
