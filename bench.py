@@ -151,7 +151,11 @@ def _time_calls(fn, iters=5, warm=2):
 
 
 def time_layers(model, members, iters=5):
-    """Per-launch duration of every kernel of one forward, HIP events on the stream the kernels are launched on."""
+    """Per-launch duration of every kernel of one forward, HIP events on the stream the kernels are launched on.  Two
+    figures per launch: `ms` -- events between the launches of an eager forward (a layer's input was just written by the
+    layer in front and partly sits in the 256 MB Infinity Cache: the situation inside the rollout graph, and what rocprofv3
+    reports for the graph's kernels), and `ms_isolated` -- the layer alone, back to back (its working set comes from HBM
+    every time)."""
     from dlwp_amd import ops
     ex = model.executor
     plan = ex.plan                                      # the inference plan (pooling in the producers' epilogues)
@@ -159,7 +163,7 @@ def time_layers(model, members, iters=5):
     outs = ex.run(x)                                    # fills every scratch buffer with realistic data
     bufs = ex.scratch(members)
     cfgs = ops.conv_configs()
-    rows = []
+    rows, seq = [], []
     for op, d in zip(plan.ops, ex._descriptors()):
         if op.kind not in ('conv', 'maxpool', 'd2s'):
             continue
@@ -167,22 +171,25 @@ def time_layers(model, members, iters=5):
         dst = bufs[op.dst] if op.dst >= 0 else outs[-2 - op.dst]
         if op.kind in ('maxpool', 'd2s'):        # HBM-bound passes left in the forward
             if op.kind == 'maxpool':
-                fn = lambda: ops.maxpool2(src, out=dst)  # noqa: E731
+                fn = lambda src=src, dst=dst: ops.maxpool2(src, out=dst)  # noqa: E731
                 name = 'maxpool2 %dx%d' % (op.xs[1], op.xs[2])
                 nb = float(src.numel() * src.element_size() + dst.numel() * dst.element_size())
             else:
-                fn = lambda: ops.depth_to_space2(src, op.xs[0], out=dst, c_off=op.out_c_off)  # noqa: E731
+                fn = lambda src=src, dst=dst, op=op: ops.depth_to_space2(src, op.xs[0], out=dst, c_off=op.out_c_off)  # noqa: E731
                 name = 'depth_to_space2 %dx%d' % (op.xs[1], op.xs[2])
                 nb = 2.0 * src.numel() * src.element_size()
             ms = _time_calls(fn, iters)
-            rows.append({'layer': name, 'kind': 'hbm', 'ms': ms, 'gbs': nb / ms / 1e6, 'flops': 0.0, 'bytes': nb,
-                         'executed_flops': 0.0})
+            rows.append({'layer': name, 'kind': 'hbm', 'ms_isolated': ms, 'flops': 0.0, 'bytes': nb, 'executed_flops': 0.0})
+            seq.append(fn)
             continue
         lay = op.layer
         kern, bias = ex.conv_weights(op)       # the layer's, or the phase-summed kernels of a restated decoder layer
         # weights prepared once, as in the rollout graph (dlwp_conv2d_prepare): the events bracket the conv kernel only
         prep = ops.conv2d_prepare(src, kern, d, out_dtype=dst.dtype, x_channels=op.xs[0])
-        ms = _time_calls(lambda: ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], prepared=prep), iters)
+        fn = lambda src=src, kern=kern, bias=bias, d=d, dst=dst, op=op, prep=prep: ops.conv2d(  # noqa: E731
+            src, kern, bias, d, out=dst, x_channels=op.xs[0], prepared=prep)
+        ms = _time_calls(fn, iters)
+        seq.append(fn)
         _, (kh, kw), dil_run = op.conv_geometry
         co, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape     # FLOPs: what the convolution computes
         flops = 2.0 * ho * wo * co * op.xs[0] * kh * kw * members
@@ -198,13 +205,31 @@ def time_layers(model, members, iters=5):
         launch_flops = [(config_symbol(cfgs[i[0]], ups) if i[0] >= 0 else 'conv2d_fwd_direct_f32', i[3]) for i in info]
         cfg = cfgs[info[0][0]] if info and info[0][0] >= 0 else None
         rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': dil_run[0], 'tile_cfg': cfg,
-                     'kernel': launch_flops[0][0], 'launches': len(info), 'out': [ho, wo], 'ms': ms,
-                     'algorithmic_tflops': flops / ms / 1e9, 'executed_tflops': sum(i[3] for i in info) / ms / 1e9,
-                     'gbs': nbytes / ms / 1e6, 'flops': flops, 'bytes': nbytes,
+                     'kernel': launch_flops[0][0], 'launches': len(info), 'out': [ho, wo], 'ms_isolated': ms,
+                     'flops': flops, 'bytes': nbytes,
                      'executed_flops': sum(i[3] for i in info), 'launch_flops': launch_flops,
                      'bf16_matrix': bool(info and info[0][4])})
         if op.alg_flops is not None:
             rows[-1]['restated'] = 'on the low-resolution source of the UpSampling2D in front (DESIGN.md 5.7)'
+    # the launches in forward order, an event in front of each
+    n = len(seq)
+    for _ in range(2):
+        for fn in seq:
+            fn()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(iters)]
+    for it in range(iters):
+        for k, fn in enumerate(seq):
+            evs[it][k].record()
+            fn()
+        evs[it][n].record()
+    torch.cuda.synchronize()
+    for k, r in enumerate(rows):
+        ms = sum(evs[it][k].elapsed_time(evs[it][k + 1]) for it in range(iters)) / iters
+        r['ms'] = ms
+        r['gbs'] = r['bytes'] / ms / 1e6
+        if r.get('kind') != 'hbm':
+            r['algorithmic_tflops'] = r['flops'] / ms / 1e9
+            r['executed_tflops'] = r['executed_flops'] / ms / 1e9
     return rows
 
 
@@ -223,14 +248,16 @@ def roofline_of(rows, members):
     algorithmic = sum(r['flops'] for r in rs)
     peak = PEAK_BF16_MFMA_TFLOPS if rs[0]['bf16_matrix'] else PEAK_F32_MFMA_TFLOPS
     achieved = executed / ms / 1e9
+    ms_iso = sum(r['ms_isolated'] for r in rs)
     out = {'bound': 'mfma', 'kernel': sym,
            'layers': ['%s (%d->%d, %dx%d dil %d, out %dx%d)' % (r['layer'], r['cin'], r['cout'], r['k'], r['k'], r['dil'],
                                                                  r['out'][0], r['out'][1]) for r in rs],
            'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
            'definition': 'matrix-core FLOPs the kernel executes (MFMA instructions x 2048, tile and channel padding '
-                         'included) / HIP-event time / dense fp32 MFMA peak',
+                         'included) / HIP-event time of its launches inside a forward / dense fp32 MFMA peak',
            'algorithmic_tflops': algorithmic / ms / 1e9, 'algorithmic_speedup': algorithmic / executed,
            'launches_per_forward': n_launch, 'launch_ms': ms / n_launch,
+           'launch_ms_isolated': ms_iso / n_launch, 'frac_isolated': executed / ms_iso / 1e9 / peak,
            'executed_flops_per_launch': executed / n_launch, 'algorithmic_flops_per_launch': algorithmic / n_launch,
            'algorithmic_bytes_per_launch': sum(r['bytes'] for r in rs) / n_launch,
            'share_of_forward_time': ms / tot, 'traffic_unit': 'bytes per launch'}
@@ -562,6 +589,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(grid, a.channels, a.forwards, weights_np)
     emit()
+    if world > 1 and 'error_collective' in out.get('sub_records', {}):
+        os._exit(0)                  # a rank may be gone: no barrier to wait in
     barrier()
 
 

@@ -21,6 +21,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct ConvArgs {
   const float* x;
@@ -116,6 +117,47 @@ __device__ __forceinline__ float act_apply_c(float v) {
   if constexpr (ACT == DLWP_ACT_TANH) return dlwp_tanh(v);
   else if constexpr (ACT == DLWP_ACT_RELU) return fmaxf(v, 0.f);
   else return v;
+}
+
+// ---- packed fp32 (v_pk_*_f32: two fp32 operations per lane and issue slot, 64-bit register pairs).  The fp32 matrix
+//      instruction and the vector ALU exclude each other on a SIMD, so every vector instruction saved in a transform or an
+//      epilogue is matrix time gained; IEEE results are those of the scalar instructions.  hipcc selects v_pk_add / mul /
+//      fma for <2 x float> arithmetic but scalarises a vector SUBTRACTION and builds swizzled / negated operands with
+//      v_xor + v_mov, so those forms are written with the instruction's own op_sel / neg modifiers.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// Winograd input transform of one patch row (d0 d1 | d2 d3) -> (d0 - d2, d1 + d2) and (d2 - d1, d1 - d3)
+__device__ __forceinline__ f32x2 pk_wino_t01(f32x2 d01, f32x2 d23) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(d01), "v"(d23));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_wino_t23(f32x2 d01, f32x2 d23) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(d23), "v"(d01));
+  return r;
+}
+// activation of two values: the same instructions as act_apply_c per value, the full-rate ones packed
+template <int ACT>
+__device__ __forceinline__ f32x2 act_apply2_c(f32x2 v) {
+  if constexpr (ACT == DLWP_ACT_TANH) {
+    const f32x2 z = v * (f32x2){-2.885390081777927f, -2.885390081777927f};
+    const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + (f32x2){1.f, 1.f};
+    const f32x2 r = (f32x2){__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return __builtin_elementwise_fma(r, (f32x2){2.f, 2.f}, (f32x2){-1.f, -1.f});
+  } else if constexpr (ACT == DLWP_ACT_RELU) {
+    return (f32x2){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
+  } else {
+    return v;
+  }
 }
 
 template <class F>

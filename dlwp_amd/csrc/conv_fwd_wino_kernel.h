@@ -173,6 +173,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   // check includes the scalar offset.
   const __amdgpu_buffer_rsrc_t x_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)a.Cin * plane_bytes, 0x00020000);
+  // (Measured, r2p: the loads the last two chunks issue have no chunk of this tile left to fetch; aiming them at chunks 0 / 1
+  // of the tile that the NEXT workgroup of this XCD slot will start with -- an L2 prefetch at no instruction cost -- changed
+  // nothing, 401.9 vs 403.1 k steps/s: the prologue does not wait for memory.  They stay clamped re-reads.)
   auto load_x = [&](int c0, int i) {
     const int ci = i / C::NPOS, q = i - ci * C::NPOS;
     const unsigned soff = (unsigned)(min(c0, last_c0) + ci) * plane_bytes;
@@ -195,26 +198,37 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     const int slot = C::UPS && r == 3 ? 2 : r;
     *(f32x4*)(lds + udst + u_dst[k] + slot * C::CK * C::BN * 4) = ur[k][r & 1];
   };
-  // input transform V = B^T d B of this lane's own A-operand elements, channel group c4 (channels (l>>4) + 4*c4)
-  float v[2][16];
-  float d[4][4], t[4][4];
+  // input transform V = B^T d B of this lane's own A-operand elements, channel group c4 (channels (l>>4) + 4*c4), on
+  // COLUMN PAIRS in packed fp32: 16 v_pk_add_f32 per patch instead of 32 v_add / v_sub (the loop's only vector work)
+  f32x2 v2[2][8];               // V[r][2h], V[r][2h+1] at [r * 2 + h]
+  f32x2 d2[4][2], t2[4][2];     // patch rows / d B rows as (columns 0 1 | columns 2 3)
+  // UPS: column 2 of d B and of V is never multiplied -- the (2, 3) pairs would carry a dead half through 10 registers the
+  // 64-channel variant does not have, so column 3 stays scalar there (same instruction count: a half-used pair = one add)
+  float t3[4], v3[2][4];
   auto vt_read = [&](int xsrc, int c4, int part) {  // 8 parts: row part/2, columns 2*(part%2) and +1 (one ds_read_b64)
     const float* dp = lds + xsrc + v_src + c4 * 4 * C::PS;
-    const int r = part >> 1, c0 = (part & 1) * 2;
-    d[r][c0] = dp[r * C::LCP + c0];
-    d[r][c0 + 1] = dp[r * C::LCP + c0 + 1];
+    const int r = part >> 1, h = part & 1;
+    d2[r][h] = *(const f32x2*)(dp + r * C::LCP + 2 * h);
   };
-  auto vt_rows = [&](int r) {  // d B, one patch row
-    t[r][0] = d[r][0] - d[r][2];
-    t[r][1] = d[r][1] + d[r][2];
-    t[r][2] = d[r][2] - d[r][1];
-    t[r][3] = d[r][1] - d[r][3];
+  auto vt_rows = [&](int r) {  // d B, one patch row: (d0 - d2, d1 + d2 | d2 - d1, d1 - d3)
+    t2[r][0] = pk_wino_t01(d2[r][0], d2[r][1]);
+    if constexpr (C::UPS) t3[r] = d2[r][0].y - d2[r][1].y;
+    else t2[r][1] = pk_wino_t23(d2[r][0], d2[r][1]);
   };
-  auto vt_cols = [&](int c4, int c) {  // B^T (d B), one column
-    v[c4][0 * 4 + c] = t[0][c] - t[2][c];
-    v[c4][1 * 4 + c] = t[1][c] + t[2][c];
-    v[c4][2 * 4 + c] = t[2][c] - t[1][c];
-    v[c4][3 * 4 + c] = t[1][c] - t[3][c];
+  auto vt_cols = [&](int c4, int r) {  // row r of B^T (d B)
+    if (C::UPS && r == 2) return;   // (never multiplied)
+#pragma unroll
+    for (int h = 0; h < (C::UPS ? 1 : 2); ++h)
+      v2[c4][r * 2 + h] = r == 0   ? pk_sub(t2[0][h], t2[2][h])
+                          : r == 1 ? pk_add(t2[1][h], t2[2][h])
+                          : r == 2 ? pk_sub(t2[2][h], t2[1][h])
+                                   : pk_sub(t2[1][h], t2[3][h]);
+    if constexpr (C::UPS) v3[c4][r] = r == 0 ? t3[0] - t3[2] : r == 1 ? t3[1] + t3[2] : t3[1] - t3[3];
+  };
+  // MFMA A operand: V position (xq, j) of channel group c4
+  auto v_at = [&](int c4, int xq, int j) -> float {
+    if (C::UPS && j == 3) return v3[c4][xq];
+    return v2[c4][xq * 2 + (j >> 1)][j & 1];
   };
   f32x4 bf[2][C::BNF];
   auto load_frags = [&](int usrc, int c4, int xq, int buf) {
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         const int xq = s / (4 * C::BNF), j = (s / C::BNF) & 3, g = s % C::BNF;
         if (!(C::UPS && (xq == 2 || j == 2)))   // (folds at compile time: s is an unrolled constant)
           acc[xq * 4 + j][g] =
-              __builtin_amdgcn_mfma_f32_16x16x4f32(v[0][xq * 4 + j], bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x4f32(v_at(0, xq, j), bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (s == 23) {
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         const int xq = s / (4 * C::BNF), j = (s / C::BNF) & 3, g = s % C::BNF;
         if (!(C::UPS && (xq == 2 || j == 2)))
           acc[xq * 4 + j][g] =
-              __builtin_amdgcn_mfma_f32_16x16x4f32(v[1][xq * 4 + j], bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
+              __builtin_amdgcn_mfma_f32_16x16x4f32(v_at(1, xq, j), bf[xq & 1][g][j], acc[xq * 4 + j][g], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (s == 23) {
@@ -348,68 +362,83 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   // ---- output transform Y = A^T M A in registers, bias + activation, then [co][row][col] through LDS.  One straight-line
   //      path per (activation, pooling kind): the runtime switches are taken ONCE, outside the loops over the lane's 4 x BNF
   //      (tile, channel) pairs -- every vector instruction here is matrix time lost (see dlwp_tanh)
+  //      The lane's four tiles are handled as two PAIRS (registers r, r+1 of every accumulator = tiles t, t+1 = horizontal
+  //      neighbours of one tile row) in packed fp32: half the vector instructions.
+  static_assert(C::RTW % 2 == 0 && C::T % 2 == 0, "tile pairs: neighbours in one tile row");
   act_dispatch(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
     auto for_tiles = [&](auto&& body) {
 #pragma unroll
       for (int g = 0; g < C::BNF; ++g) {
         const int col = g * 16 + (lane & 15);
-        const float bv = a.bias ? a.bias[n0 + col] : 0.f;
+        const float bv1 = a.bias ? a.bias[n0 + col] : 0.f;
+        const f32x2 bv = (f32x2){bv1, bv1};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int t = wave * 16 + (lane >> 4) * 4 + r;
+        for (int r = 0; r < 4; r += 2) {
+          const int t = wave * 16 + (lane >> 4) * 4 + r;   // and t + 1
           if constexpr (C::T < C::TPAD) {
             if (t >= C::T) continue;
           }
           const int pc = t / (C::RTH * C::RTW), rem = t - pc * (C::RTH * C::RTW);
           const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
           const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
+          auto m = [&](int xy) -> f32x2 { return r == 0 ? acc[xy][g].xy : acc[xy][g].zw; };
           // A^T m.  UPS: row 2 / column 2 of M were never multiplied (they are identically zero) and their registers
           // hold nothing -- the terms are left out, not added as zeros
-          float s[2][4];
+          f32x2 s[2][4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             if (C::UPS && c == 2) {
-              s[0][c] = s[1][c] = 0.f;    // (never read below)
+              s[0][c] = s[1][c] = (f32x2){0.f, 0.f};    // (never read below)
             } else if (C::UPS) {
-              s[0][c] = acc[0 * 4 + c][g][r] + acc[1 * 4 + c][g][r];
-              s[1][c] = acc[1 * 4 + c][g][r] - acc[3 * 4 + c][g][r];
+              s[0][c] = pk_add(m(0 * 4 + c), m(1 * 4 + c));
+              s[1][c] = pk_sub(m(1 * 4 + c), m(3 * 4 + c));
             } else {
-              s[0][c] = acc[0 * 4 + c][g][r] + acc[1 * 4 + c][g][r] + acc[2 * 4 + c][g][r];
-              s[1][c] = acc[1 * 4 + c][g][r] - acc[2 * 4 + c][g][r] - acc[3 * 4 + c][g][r];
+              s[0][c] = pk_add(pk_add(m(0 * 4 + c), m(1 * 4 + c)), m(2 * 4 + c));
+              s[1][c] = pk_sub(pk_sub(m(1 * 4 + c), m(2 * 4 + c)), m(3 * 4 + c));
             }
           }
           body(s, col, bv, ti, tj, pi, pj);
         }
       }
     };
+    // (A^T M A)[aa][0] and [aa][1] of the tile pair
+    auto y_even = [&](const f32x2 (&s)[2][4], int aa) -> f32x2 {
+      return C::UPS ? pk_add(s[aa][0], s[aa][1]) : pk_add(pk_add(s[aa][0], s[aa][1]), s[aa][2]);
+    };
+    auto y_odd = [&](const f32x2 (&s)[2][4], int aa) -> f32x2 {
+      return C::UPS ? pk_sub(s[aa][1], s[aa][3]) : pk_sub(pk_sub(s[aa][1], s[aa][2]), s[aa][3]);
+    };
     if constexpr (C::DIL == 1) {
       if (a.out_pool == 2) {  // 2x2 sum: 1^T A^T M A 1 with A 1 = (1, 2, 0, -1) -- row / column 2 of M drop out
-        for_tiles([&](const float (&s)[2][4], int col, float, int ti, int tj, int, int) {
-          const float t0 = s[0][0] + s[1][0], t1 = s[0][1] + s[1][1], t3 = s[0][3] + s[1][3];
-          lds[col * C::OPS + ti * (C::TW / 2) + tj] = t0 + 2.f * t1 - t3;
+        for_tiles([&](const f32x2 (&s)[2][4], int col, f32x2, int ti, int tj, int, int) {
+          const f32x2 t0 = pk_add(s[0][0], s[1][0]), t1 = pk_add(s[0][1], s[1][1]), t3 = pk_add(s[0][3], s[1][3]);
+          const f32x2 o = pk_sub(__builtin_elementwise_fma((f32x2){2.f, 2.f}, t1, t0), t3);
+          *(f32x2*)(lds + col * C::OPS + ti * (C::TW / 2) + tj) = o;
         });
         return;
       }
-      if (a.out_pool) {  // MaxPooling2D(2): the lane's 2x2 output tile IS one pooling window; activation after the max
-        for_tiles([&](const float (&s)[2][4], int col, float bv, int ti, int tj, int, int) {
-          const float m0 = C::UPS ? fmaxf(s[0][0] + s[0][1], s[0][1] - s[0][3])
-                                  : fmaxf(s[0][0] + s[0][1] + s[0][2], s[0][1] - s[0][2] - s[0][3]);
-          const float m1 = C::UPS ? fmaxf(s[1][0] + s[1][1], s[1][1] - s[1][3])
-                                  : fmaxf(s[1][0] + s[1][1] + s[1][2], s[1][1] - s[1][2] - s[1][3]);
-          lds[col * C::OPS + ti * (C::TW / 2) + tj] = act_apply_c<ACT>(fmaxf(m0, m1) + bv);
+      if (a.out_pool) {  // MaxPooling2D(2): a lane's 2x2 output tile IS one pooling window; activation after the max
+        for_tiles([&](const f32x2 (&s)[2][4], int col, f32x2 bv, int ti, int tj, int, int) {
+          const f32x2 y00 = y_even(s, 0), y01 = y_odd(s, 0), y10 = y_even(s, 1), y11 = y_odd(s, 1);
+          const f32x2 mx = (f32x2){fmaxf(fmaxf(y00.x, y01.x), fmaxf(y10.x, y11.x)),
+                                   fmaxf(fmaxf(y00.y, y01.y), fmaxf(y10.y, y11.y))};
+          *(f32x2*)(lds + col * C::OPS + ti * (C::TW / 2) + tj) = act_apply2_c<ACT>(mx + bv);
         });
         return;
       }
     }
-    for_tiles([&](const float (&s)[2][4], int col, float bv, int ti, int tj, int pi, int pj) {
+    for_tiles([&](const f32x2 (&s)[2][4], int col, f32x2 bv, int ti, int tj, int pi, int pj) {
       float* op = lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
-        const float y0 = act_apply_c<ACT>((C::UPS ? s[aa][0] + s[aa][1] : s[aa][0] + s[aa][1] + s[aa][2]) + bv);
-        const float y1 = act_apply_c<ACT>((C::UPS ? s[aa][1] - s[aa][3] : s[aa][1] - s[aa][2] - s[aa][3]) + bv);
-        op[aa * C::DIL * C::TW] = y0;
-        op[aa * C::DIL * C::TW + C::DIL] = y1;
+        const f32x2 y0 = act_apply2_c<ACT>(y_even(s, aa) + bv);
+        const f32x2 y1 = act_apply2_c<ACT>(y_odd(s, aa) + bv);
+        float* q = op + aa * C::DIL * C::TW;
+        q[0] = y0.x;                  // tile t:     columns 0, DIL
+        q[2 * C::DIL] = y0.y;         // tile t + 1: columns 2 DIL, 3 DIL
+        q[C::DIL] = y1.x;
+        q[3 * C::DIL] = y1.y;
       }
     });
   });
