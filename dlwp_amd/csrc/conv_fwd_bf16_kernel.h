@@ -51,7 +51,7 @@ struct BfCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) {
+__global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs a) {
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -297,8 +297,9 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
 #pragma unroll
           for (int g = 0; g < C::BNF; ++g) {
             const f32x4 u = acc[i][g], d = acc[i + C::FA / 2][g];
-            const float o0 = act_apply_c<ACT>(fmaxf(fmaxf(u[0], u[1]), fmaxf(d[0], d[1])) + bias_v[g]);
-            const float o1 = act_apply_c<ACT>(fmaxf(fmaxf(u[2], u[3]), fmaxf(d[2], d[3])) + bias_v[g]);
+            const f32x2 o01 = act_apply2_c<ACT>((f32x2){fmaxf(fmaxf(u[0], u[1]), fmaxf(d[0], d[1])),
+                                                         fmaxf(fmaxf(u[2], u[3]), fmaxf(d[2], d[3]))} + (f32x2){bias_v[g], bias_v[g]});
+            const float o0 = o01.x, o1 = o01.y;
             const unsigned e = coff[g] + poff;
             const unsigned off0 = (ok0 && coff[g] != DROP) ? e * esz : DROP;
             const unsigned off1 = (ok1 && coff[g] != DROP) ? (e + 1) * esz : DROP;
@@ -333,8 +334,11 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_bf16(const ConvArgs a) 
 #pragma unroll
       for (int g = 0; g < C::BNF; ++g) {
         f32x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = act_apply_c<ACT>(acc[i][g][r] + bias_v[g]);
+{
+          const f32x2 bb = (f32x2){bias_v[g], bias_v[g]};
+          const f32x2 lo = act_apply2_c<ACT>(acc[i][g].xy + bb), hi = act_apply2_c<ACT>(acc[i][g].zw + bb);
+          o = (f32x4){lo.x, lo.y, hi.x, hi.y};
+        }
         const unsigned e = coff[g] + poff;
         const bool cok = rok && coff[g] != DROP;
         if (quad) {

@@ -186,7 +186,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 
 template <class C>
-__global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
+__global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_f32(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;
   float* ws = lds + C::X_FLOATS;
@@ -451,8 +451,9 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
             for (int i = 0; i < C::FA / 2; ++i) {
               const int pc = (j0 >> 1) + i * 8 + (lane >> 4) * 2;
               const f32x4 u = acc[i][g], d = acc[i + C::FA / 2][g];
-              const float o0 = act_apply_c<ACT>(fmaxf(fmaxf(u[0], u[1]), fmaxf(d[0], d[1])) + bv);
-              const float o1 = act_apply_c<ACT>(fmaxf(fmaxf(u[2], u[3]), fmaxf(d[2], d[3])) + bv);
+              const f32x2 o01 = act_apply2_c<ACT>((f32x2){fmaxf(fmaxf(u[0], u[1]), fmaxf(d[0], d[1])),
+                                                           fmaxf(fmaxf(u[2], u[3]), fmaxf(d[2], d[3]))} + (f32x2){bv, bv});
+              const float o0 = o01.x, o1 = o01.y;
               if (a.out_bf16) {
                 bf16_t* yp = (bf16_t*)a.y + yo + pc;
                 if (pc + 1 < a.Wp && (a.Wp & 1) == 0) *(unsigned*)yp = pack_bf16x2(o0, o1);
@@ -489,8 +490,11 @@ __global__ __launch_bounds__(C::NT) void conv2d_fwd_mfma_f32(const ConvArgs a) {
         const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
         if (p >= C::P) continue;
         f32x4 o;
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = act_apply_c<ACT>(acc[i][g][r] + bv);
+        {
+          const f32x2 bb = (f32x2){bv, bv};
+          const f32x2 lo = act_apply2_c<ACT>(acc[i][g].xy + bb), hi = act_apply2_c<ACT>(acc[i][g].zw + bb);
+          o = (f32x4){lo.x, lo.y, hi.x, hi.y};
+        }
         if (vec_store) {
           const int row = p / C::TW, col = p - row * C::TW;
           const int oh = i0 + row, ow = j0 + col;

@@ -45,7 +45,7 @@ struct PackCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NT) void conv2d_fwd_packn_mfma_f32(const ConvArgs a) {
+__global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_packn_mfma_f32(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;
   float* ws = lds + C::X_FLOATS;
