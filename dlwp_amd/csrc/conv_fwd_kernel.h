@@ -177,6 +177,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 //      even in hardware (v_cvt_pk_bf16_f32)
 typedef unsigned short bf16_t;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned bits16) { return __builtin_bit_cast(float, bits16 << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return __builtin_bit_cast(bf16_t, (__bf16)v); }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {

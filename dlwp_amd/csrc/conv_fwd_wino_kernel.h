@@ -445,16 +445,54 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   DLWP_STAMP(4);
   __syncthreads();
   DLWP_STAMP(5);
-  {
+  // ---- stores: 16-byte row segments of the (pooled) output.  The float32 paths go through a buffer descriptor over this
+  //      block's BN output planes: a thread's staging slot and its output pixel do not depend on the pass k (only the
+  //      channel does: + CS planes per pass, a SCALAR offset), so a pass is one ds_read_b128 and one buffer_store_dwordx4
+  //      -- no vector arithmetic, no branches; what is outside the map gets an offset past the descriptor and the hardware
+  //      drops it.  (Per-pass 64-bit address arithmetic and bounds branches were ~13 vector instructions per store, each
+  //      waiting behind the co-resident wave's 32-cycle MFMAs: the store phase was 4-7 k cycles of a block's life.)
+  constexpr unsigned DROP = 0x7ffffff0u;
+  if (a.out_pool) {
     // dilation 1: the staging area holds the pooled tile [co][TH/2][TW/2] (the lane's 2x2 tile was one pooling window);
     // dilation 2: it holds the full activated tile [co][TH][TW] (a window's four outputs come from four parity classes, i.e.
-    // four lanes) and the maximum is taken here -- either way 16-byte row segments of the (Hp, Wp) output
-    if (a.out_pool) {
-      constexpr int PW = C::TW / 2, PP = (C::TH / 2) * PW;
-      static_assert((C::BN * PP / 4) % C::NT == 0 && PW % 4 == 0, "pooled output staging: whole float4 per thread");
+    // four lanes) and the maximum is taken here
+    constexpr int PW = C::TW / 2, PP = (C::TH / 2) * PW;
+    static_assert((C::BN * PP / 4) % C::NT == 0 && PW % 4 == 0, "pooled output staging: whole float4 per thread");
+    constexpr int NPASS = C::BN * PP / 4 / C::NT;
+    if (C::DIL == 1 && !a.out_bf16) {
+      static_assert((4 * C::NT) % PP == 0, "a pass advances every thread by whole channels");
+      constexpr int CS = 4 * C::NT / PP;
+      const int e0 = tid * 4, cb = e0 / PP, rem = e0 - cb * PP;
+      const int row = rem / PW, colx = rem - row * PW;
+      const int oh = (i0 >> 1) + row, ow = (j0 >> 1) + colx;
+      const unsigned plane_b = (unsigned)(a.Hp * a.Wp) * 4u;
+      float* yb = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Hp * a.Wp;
+      const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)C::BN * plane_b, 0x00020000);
+      const unsigned pix = (unsigned)(oh * a.Wp + ow) * 4u + (unsigned)cb * plane_b;
+      const bool rok = oh < a.Hp;
+      const unsigned voff_q = (rok && ow + 3 < a.Wp) ? pix : DROP;
+      const float* lp = lds + cb * C::OPS + rem;
+#pragma unroll
+      for (int k = 0; k < NPASS; ++k)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)(lp + k * CS * C::OPS)), y_rsrc, voff_q,
+                                               (unsigned)(k * CS) * plane_b, 0);
+      if (((j0 >> 1) + PW > a.Wp) && (a.Wp & 3)) {   // (uniform) the map's right edge cuts a quad: element stores there
+        const bool edge = rok && ow < a.Wp && ow + 3 >= a.Wp;
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+          const f32x4 o = *(const f32x4*)(lp + k * CS * C::OPS);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = o[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc,
+                                                  (edge && ow + r < a.Wp) ? pix + 4u * r : DROP, (unsigned)(k * CS) * plane_b, 0);
+          }
+        }
+      }
+    } else {
       const long long ybase = ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Hp * a.Wp;
 #pragma unroll
-      for (int k = 0; k < C::BN * PP / 4 / C::NT; ++k) {
+      for (int k = 0; k < NPASS; ++k) {
         const int e = (k * C::NT + tid) * 4;
         const int co = e / PP, rem = e - co * PP;
         const int row = rem / PW, colx = rem - row * PW;
@@ -491,13 +529,46 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
           }
         }
       }
-      DLWP_STAMP(6);
-      return;
     }
+    DLWP_STAMP(6);
+    return;
   }
-  float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
-  bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;  // if a.out_bf16
   constexpr int NOUT = C::BN * C::TH * C::TW / 4 / C::NT;
+  if (!a.out_bf16) {
+    constexpr int PL = C::TH * C::TW;
+    static_assert((4 * C::NT) % PL == 0, "a pass advances every thread by whole channels");
+    constexpr int CS = 4 * C::NT / PL;
+    const int e0 = tid * 4, cb = e0 / PL, rem = e0 - cb * PL;
+    const int row = rem / C::TW, colx = rem - row * C::TW;
+    const int oh = i0 + row, ow = j0 + colx;
+    const unsigned plane_b = (unsigned)(a.Ho * a.Wo) * 4u;
+    float* yb = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)C::BN * plane_b, 0x00020000);
+    const unsigned pix = (unsigned)(oh * a.Wo + ow) * 4u + (unsigned)cb * plane_b;
+    const bool rok = oh < a.Ho;
+    const unsigned voff_q = (rok && ow + 3 < a.Wo) ? pix : DROP;
+    const float* lp = lds + cb * C::OPS + rem;
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)(lp + k * CS * C::OPS)), y_rsrc, voff_q,
+                                             (unsigned)(k * CS) * plane_b, 0);
+    if ((j0 + C::TW > a.Wo) && (a.Wo & 3)) {   // (uniform) the map's right edge cuts a quad: element stores there
+      const bool edge = rok && ow < a.Wo && ow + 3 >= a.Wo;
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) {
+        const f32x4 o = *(const f32x4*)(lp + k * CS * C::OPS);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = o[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc,
+                                                (edge && ow + r < a.Wo) ? pix + 4u * r : DROP, (unsigned)(k * CS) * plane_b, 0);
+        }
+      }
+    }
+    DLWP_STAMP(6);
+    return;
+  }
+  bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
 #pragma unroll
   for (int k = 0; k < NOUT; ++k) {
     const int e = (k * C::NT + tid) * 4;
@@ -506,26 +577,14 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     const int oh = i0 + row, ow = j0 + colx;
     if (oh >= a.Ho || ow >= a.Wo) continue;
     const f32x4 o = *(const f32x4*)(lds + co * C::OPS + rem);
-    const long long yoff = ((long long)co * a.Ho + oh) * a.Wo + ow;
-    if (a.out_bf16) {
-      bf16_t* yp = yn16 + yoff;
-      if (ow + 3 < a.Wo && ((a.Wo & 1) == 0)) {   // 4-byte aligned pairs when the row length is even
-        *(unsigned*)yp = pack_bf16x2(o[0], o[1]);
-        *(unsigned*)(yp + 2) = pack_bf16x2(o[2], o[3]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (ow + r < a.Wo) yp[r] = f32_to_bf16(o[r]);
-      }
-      continue;
-    }
-    float* yp = yn + yoff;
-    if (ow + 3 < a.Wo) {
-      *(f32x4*)yp = o;
+    bf16_t* yp = yn16 + ((long long)co * a.Ho + oh) * a.Wo + ow;
+    if (ow + 3 < a.Wo && ((a.Wo & 1) == 0)) {   // 4-byte aligned pairs when the row length is even
+      *(unsigned*)yp = pack_bf16x2(o[0], o[1]);
+      *(unsigned*)(yp + 2) = pack_bf16x2(o[2], o[3]);
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (ow + r < a.Wo) yp[r] = o[r];
+        if (ow + r < a.Wo) yp[r] = f32_to_bf16(o[r]);
     }
   }
   DLWP_STAMP(6);

@@ -151,11 +151,14 @@ class Executor(object):
     @staticmethod
     def member_groups(n):
         """How many parallel member chains a rollout of n members is captured as (dlwp_rollout_create_grouped).  Members are
-        independent, so chains at different layers could fill the gaps each other's launches leave (partly filled last
-        rounds of workgroups, kernel boundaries).  Measured on one MI355X (profiles/r2i_rollout_member_groups.txt): within
-        run-to-run noise of a single chain at 4 members of config 5 (49.1 k vs 45.0 / 47.5 k steps/s with 2 / 4 chains) and
-        +4 ... +7 % at 32 - 64 members -- the default stays ONE chain; DLWP_ROLLOUT_GROUPS=g asks for g."""
-        g = max(1, min(int(os.environ.get('DLWP_ROLLOUT_GROUPS', '1')), max(n, 1)))
+        independent, so chains at different layers fill the gaps each other's launches leave (partly filled last rounds of
+        workgroups, the drain at every kernel boundary).  Measured on one MI355X (profiles/r2i_rollout_member_groups.txt,
+        r2q): two chains +7 % at 64 members (361.8 -> 387.4 k steps/s), +4 % at 32 members of config 5, +1.3 % at 256
+        (400.6 -> 405.7 k); four or eight chains lose again (389 k at 256: the launches get too small); within noise or
+        worse below 32 members.  Default: TWO chains from 32 members on, one below; DLWP_ROLLOUT_GROUPS=g asks for g."""
+        env = os.environ.get('DLWP_ROLLOUT_GROUPS')
+        g = int(env) if env else (2 if n >= 32 else 1)
+        g = max(1, min(g, max(n, 1)))
         while n % g:
             g -= 1
         return g
