@@ -52,7 +52,7 @@ class Conv2d(ctypes.Structure):
     _fields_ = [('cout', ctypes.c_int), ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('dil_h', ctypes.c_int),
                 ('dil_w', ctypes.c_int), ('halo', Pad2d), ('act', ctypes.c_int), ('in_c_off', ctypes.c_int),
                 ('in_c_total', ctypes.c_int), ('out_c_off', ctypes.c_int), ('out_c_total', ctypes.c_int),
-                ('src_mode', ctypes.c_int), ('out_pool', ctypes.c_int)]
+                ('src_mode', ctypes.c_int), ('out_pool', ctypes.c_int), ('out_d2s', ctypes.c_int)]
 
 
 class Op(ctypes.Structure):
@@ -133,6 +133,7 @@ _sig('dlwp_phase_weights_bwd', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
 _sig('dlwp_conv2d_uses_bf16_weights', [_vp, Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_prefers_unfused_pool', [_vp, _i, _i, _i, _i, _i, _i])
 _sig('dlwp_conv2d_supports_out_pool', [_vp, Shape4, _P(Conv2d)])
+_sig('dlwp_conv2d_supports_out_d2s', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_launch_info', [_vp, Shape4, _P(Conv2d), _i, _P(LaunchInfo), _P(_i)])
 _sig('dlwp_conv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _i, _P(_sz)])

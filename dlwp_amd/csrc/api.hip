@@ -41,7 +41,7 @@ static int set_in(dlwp_options& o, int option, int value, int* previous, const c
 
 extern "C" {
 
-int dlwp_version(void) { return 200; }  // 0.2.0
+int dlwp_version(void) { return 201; }  // 0.2.1
 
 int dlwp_set_option(dlwp_handle_t h, int option, int value, int* previous) {
   DLWP_CHECK_ARG(h != nullptr, "dlwp_set_option: null handle");

@@ -194,6 +194,7 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
   a.H = dlwp_src_dim(xs.h, cd->src_mode);
   a.W = dlwp_src_dim(xs.w, cd->src_mode);
   a.out_pool = cd->out_pool;
+  a.out_d2s = cd->out_d2s;
   a.Hp = ys.h;   // what is stored
   a.Wp = ys.w;
   a.Ho = a.H + cd->halo.top + cd->halo.bottom - cd->dil_h * (cd->kh - 1);   // the convolution's own output
@@ -202,7 +203,7 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
   a.in_c_off = cd->in_c_off;
   a.in_c_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
   a.out_c_off = cd->out_c_off;
-  a.out_c_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
+  a.out_c_total = cd->out_c_total > 0 ? cd->out_c_total : (cd->out_d2s ? cd->cout / 4 : cd->cout);
   a.pad_top = cd->halo.top;
   a.pad_left = cd->halo.left;
   a.mode_h = cd->halo.mode_h;
@@ -288,6 +289,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
                        bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
     if (cd->out_pool && !e.out_pool) return -1;
     if (cd->out_pool == 2 && !(is_wino(e) && e.dil == 1)) return -1;  // the 2x2 sum epilogue: dilation-1 Winograd instances
+    if (cd->out_d2s && !(is_wino(e) && e.split)) return -1;           // interleaved phase stores: the 16-channel instances
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? forced
                : -1;
@@ -324,6 +326,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
                                                                            // (the two kernels round differently: one kind per layer)
     if (is_bf16(e) && ((e.in32 != 0) == (a.in_bf16 != 0) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) continue;
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
+    if (cd->out_d2s && !(is_wino(e) && e.split)) continue;                 // interleaved phase stores: the 16-channel instances
     const double c = config_cost(e, a, cu_count);
     if (best < 0 || c < best_cost) {
       best = i;
@@ -528,6 +531,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
     if (h->opt.forced_cfg >= 0)
       DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", h->opt.forced_cfg);
     if (cd->out_pool) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel with a pooling epilogue for this layer");
+    if (cd->out_d2s) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel stores this layer's phase channels interleaved");
     return launch_direct(h, a, cd, s);  // kernel sizes without an MFMA tile configuration
   }
   Registry& r = registry();
@@ -616,19 +620,22 @@ int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys
   DLWP_CHECK_ARG(ho > 0 && wo > 0, "conv2d: kernel %dx%d (dilation %dx%d) larger than the padded input %dx%d", cd->kh,
                  cd->kw, cd->dil_h, cd->dil_w, hin + p.top + p.bottom, win + p.left + p.right);
   const int in_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
-  const int out_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
   DLWP_CHECK_ARG(cd->in_c_off >= 0 && cd->in_c_off + xs.c <= in_total, "conv2d: input channel window [%d,%d) of %d",
                  cd->in_c_off, cd->in_c_off + xs.c, in_total);
-  DLWP_CHECK_ARG(cd->out_c_off >= 0 && cd->out_c_off + cd->cout <= out_total,
-                 "conv2d: output channel window [%d,%d) of %d", cd->out_c_off, cd->out_c_off + cd->cout, out_total);
+  DLWP_CHECK_ARG(cd->out_d2s == 0 || (cd->out_d2s == 1 && cd->out_pool == 0 && cd->cout % 4 == 0),
+                 "conv2d: out_d2s needs 4 F output channels and no pooling epilogue");
+  const int out_fields = cd->out_d2s ? cd->cout / 4 : cd->cout;
+  const int out_total = cd->out_c_total > 0 ? cd->out_c_total : out_fields;
+  DLWP_CHECK_ARG(cd->out_c_off >= 0 && cd->out_c_off + out_fields <= out_total,
+                 "conv2d: output channel window [%d,%d) of %d", cd->out_c_off, cd->out_c_off + out_fields, out_total);
   DLWP_CHECK_ARG(cd->out_pool >= 0 && cd->out_pool <= 2, "conv2d: out_pool must be 0, 1 or 2");
   DLWP_CHECK_ARG(!cd->out_pool || (ho >= 2 && wo >= 2), "conv2d: out_pool on a %dx%d output", ho, wo);
   DLWP_CHECK_ARG(cd->out_pool != 2 || (cd->act == DLWP_ACT_LINEAR && ho % 2 == 0 && wo % 2 == 0),
                  "conv2d: the 2x2 sum epilogue needs a linear activation and an even %dx%d output", ho, wo);
   ys->n = xs.n;
-  ys->c = cd->cout;
-  ys->h = cd->out_pool ? ho / 2 : ho;
-  ys->w = cd->out_pool ? wo / 2 : wo;
+  ys->c = out_fields;
+  ys->h = cd->out_pool ? ho / 2 : (cd->out_d2s ? 2 * ho : ho);
+  ys->w = cd->out_pool ? wo / 2 : (cd->out_d2s ? 2 * wo : wo);
   return DLWP_OK;
 }
 
@@ -661,7 +668,7 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const 
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd_direct", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
-  DLWP_CHECK_ARG(!cd->out_pool, "dlwp_conv2d_fwd_direct: out_pool is not supported by this kernel");
+  DLWP_CHECK_ARG(!cd->out_pool && !cd->out_d2s, "dlwp_conv2d_fwd_direct: out_pool / out_d2s are not supported by this kernel");
   ConvArgs a = make_args(x, w, bias, y, xs, cd, ys, dtype);
   return launch_direct(h, a, cd, (hipStream_t)stream);
 }
@@ -700,6 +707,17 @@ int dlwp_conv2d_supports_out_pool(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_co
   if (!cd || xs.c <= 0 || xs.h <= 0 || xs.w <= 0) return 0;
   dlwp_conv2d c2 = *cd;
   c2.out_pool = 1;
+  dlwp_shape4 ys;
+  if (xs.n <= 0) xs.n = 1;
+  if (dlwp_conv2d_out_shape(xs, &c2, &ys) != DLWP_OK) return 0;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, &c2, ys);
+  return choose_config(a, &c2, 256, h ? h->opt : dlwp_default_options()) >= 0 ? 1 : 0;
+}
+
+int dlwp_conv2d_supports_out_d2s(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {
+  if (!cd || xs.c <= 0 || xs.h <= 0 || xs.w <= 0 || cd->out_pool || cd->cout % 4) return 0;
+  dlwp_conv2d c2 = *cd;
+  c2.out_d2s = 1;
   dlwp_shape4 ys;
   if (xs.n <= 0) xs.n = 1;
   if (dlwp_conv2d_out_shape(xs, &c2, &ys) != DLWP_OK) return 0;

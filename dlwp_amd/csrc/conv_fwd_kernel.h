@@ -39,6 +39,7 @@ struct ConvArgs {
   int in_bf16, out_bf16;  // storage of x / y: 0 = float32, 1 = bfloat16 (w, bias fp32)
   int compute_bf16;       // DLWP_COMPUTE_BF16: a float32-stored input may be rounded to bf16 for the bf16 matrix cores
   int col0 = 0;           // Winograd: first output column of this launch (a wide-tile launch + a narrow one for the rest)
+  int out_d2s = 0;        // the 4 F output channels are 2x2 phases: stored interleaved, y = (N, out_c_total, 2 Ho, 2 Wo)
 #ifdef DLWP_PHASE_TIMING  // tools/microbench/wino_phase_timing.hip only: s_memtime stamps of wave 0, 8 per block
   long long* dbg = nullptr;
 #endif

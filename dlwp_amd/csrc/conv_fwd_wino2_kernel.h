@@ -338,9 +338,62 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino2_f32
     }
     return;
   }
+  constexpr int NOUT = C::BN * C::TH * C::TW / 4 / C::NT;
+  if (a.out_d2s) {
+    // The 4 F channels are the 2x2 phases of F fields, phase-major (include/dlwp_hip.h: dlwp_conv2d.out_d2s): channel
+    // (2a + b) F + f at (i, j) is field f at (2 i + a, 2 j + b) of the (N, out_c_total, 2 Ho, 2 Wo) output -- what
+    // dlwp_depth_to_space2 would produce in a pass of its own.  A thread's 4 consecutive pixels land 8 bytes apart (the
+    // other column phase fills the gaps): element stores through a buffer descriptor, out-of-map lanes dropped.
+    const int F = a.Cout >> 2;
+    float* yb = a.y + ((long long)n * a.out_c_total + a.out_c_off) * (4ll * a.Ho * a.Wo);
+    const unsigned plane_b = (unsigned)(4 * a.Ho * a.Wo) * 4u;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)F * plane_b, 0x00020000);
+    constexpr unsigned DROP = 0x7ffffff0u;
+    if (4 * F <= C::BN && (a.Wo & 1) == 0) {
+      // all four phases of a field are in this block: a thread takes the two COLUMN phases (b = 0, 1) of a row phase a --
+      // planes (2a) F + f and (2a + 1) F + f -- and stores pixel pairs as 16 contiguous bytes
+      constexpr int PL = C::TH * C::TW, NP = (C::BN / 2) * PL / 4;   // items: (row phase, field) x pixel quads
+#pragma unroll
+      for (int k = 0; k < (NP + C::NT - 1) / C::NT; ++k) {
+        const int e = (k * C::NT + tid) * 4;
+        if (NP % C::NT != 0 && e >= NP * 4) continue;
+        const int pf = e / PL, rem = e - pf * PL;            // pf = a * F + f  (a < 2, f < F; entries past 2 F are padding)
+        const int aa = pf / F, f = pf - aa * F;
+        const int row = rem / C::TW, colx = rem - row * C::TW;
+        const int oh = i0 + row, ow = j0 + colx;
+        const bool ok = aa < 2 && oh < a.Ho;
+        const int c0 = min((2 * aa) * F + f, C::BN - 1), c1 = min((2 * aa + 1) * F + f, C::BN - 1);
+        const f32x4 o0 = *(const f32x4*)(lds + c0 * C::OPS + rem), o1 = *(const f32x4*)(lds + c1 * C::OPS + rem);
+        const unsigned base = (unsigned)f * plane_b + (unsigned)((2 * oh + aa) * (2 * a.Wo) + 2 * ow) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){o0[0], o1[0], o0[1], o1[1]}), y_rsrc,
+                                               (ok && ow + 1 < a.Wo) ? base : DROP, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){o0[2], o1[2], o0[3], o1[3]}), y_rsrc,
+                                               (ok && ow + 3 < a.Wo) ? base + 16u : DROP, 0, 0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+      const int e = (k * C::NT + tid) * 4;
+      const int col = e / (C::TH * C::TW), rem = e - col * (C::TH * C::TW);
+      const int row = rem / C::TW, colx = rem - row * C::TW;
+      const int oh = i0 + row, ow = j0 + colx;
+      const int co = n0 + col;
+      const int ph = co / F, f = co - ph * F;
+      const f32x4 o = *(const f32x4*)(lds + col * C::OPS + rem);
+      const bool ok = oh < a.Ho && co < a.Cout;
+      const unsigned base = (unsigned)f * plane_b + (unsigned)((2 * oh + (ph >> 1)) * (2 * a.Wo) + 2 * ow + (ph & 1)) * 4u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = o[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, (ok && ow + r < a.Wo) ? base + 8u * r : DROP,
+                                              0, 0);
+      }
+    }
+    return;
+  }
   float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
   bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;  // if a.out_bf16
-  constexpr int NOUT = C::BN * C::TH * C::TW / 4 / C::NT;
 #pragma unroll
   for (int k = 0; k < NOUT; ++k) {
     const int e = (k * C::NT + tid) * 4;

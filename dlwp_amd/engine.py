@@ -73,7 +73,7 @@ class Executor(object):
                     f, (kh, kw), dil = op.conv_geometry
                     descs.append(ops.make_conv(f, kh, kw, dil, ops.make_pad(*op.halo), op.act,
                                                op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode,
-                                               op.out_pool))
+                                               op.out_pool, op.out_d2s))
                 elif op.kind == 'pad':
                     descs.append(ops.make_pad(*op.halo))
                 else:
@@ -319,6 +319,9 @@ class Model(object):
             raise ValueError("activation dtype must be 'float32' or 'bfloat16'")
         if dtype != self.activation_dtype:
             self.activation_dtype = dtype
+            # interleaved phase stores (dlwp_conv2d.out_d2s) belong to the float32 Winograd kernels; with bfloat16 storage
+            # the restated layers run on the bf16 matrix cores and keep the separate depth-to-space pass
+            self.infer_plan = P.build_plan(self.inputs, self.outputs, inference=True, fuse_d2s=(dtype == 'float32'))
             self.executor = Executor(self.infer_plan, self.device, dtype)
             self.__dict__.pop('_rollouts', None)
         return self
@@ -328,7 +331,7 @@ class Model(object):
         """Executor of the training plan: float32 activations, every pre-pooling tensor materialised."""
         if self._train_executor is None:
             same = self.activation_dtype == 'float32' and len(self.infer_plan.ops) == len(self.plan.ops) and \
-                not any(op.out_pool for op in self.infer_plan.ops)
+                not any(op.out_pool or op.out_d2s for op in self.infer_plan.ops)
             self._train_executor = self.executor if same else Executor(self.plan, self.device, 'float32')
         return self._train_executor
 

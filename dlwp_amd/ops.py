@@ -55,16 +55,23 @@ def make_pad(top=0, bottom=0, left=0, right=0, mode_h=PAD_ZERO, mode_w=PAD_ZERO)
 
 
 def make_conv(cout, kh, kw, dil=1, halo=None, act=ACT_LINEAR, in_c_off=0, in_c_total=0, out_c_off=0, out_c_total=0,
-              src_mode=SRC_DIRECT, out_pool=False):
+              src_mode=SRC_DIRECT, out_pool=False, out_d2s=False):
     dh, dw = (dil, dil) if isinstance(dil, int) else dil
     return Conv2d(int(cout), int(kh), int(kw), int(dh), int(dw), halo if halo is not None else make_pad(), int(act),
-                  int(in_c_off), int(in_c_total), int(out_c_off), int(out_c_total), int(src_mode), int(bool(out_pool)))
+                  int(in_c_off), int(in_c_total), int(out_c_off), int(out_c_total), int(src_mode), int(bool(out_pool)),
+                  int(bool(out_d2s)))
 
 
 def supports_out_pool(xs_chw, cd):
     """Planner hint: can a compiled kernel apply a following MaxPooling2D(2) in this convolution's epilogue?"""
     return bool(_lib.lib.dlwp_conv2d_supports_out_pool(_lib.handle_or_none(), Shape4(1, int(xs_chw[0]), int(xs_chw[1]), int(xs_chw[2])),
                                                        ctypes.byref(cd)))
+
+
+def supports_out_d2s(xs_chw, cd):
+    """Planner hint: can a compiled kernel store this convolution's 4 F phase channels interleaved (depth-to-space)?"""
+    return bool(_lib.lib.dlwp_conv2d_supports_out_d2s(_lib.handle_or_none(), Shape4(1, int(xs_chw[0]), int(xs_chw[1]), int(xs_chw[2])),
+                                                      ctypes.byref(cd)))
 
 
 def conv_out_shape(xs, cd):
@@ -140,7 +147,7 @@ def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute
         cd.in_c_total = c_total
     xs = Shape4(n, cin, h, w)
     ys = conv_out_shape(xs, cd)
-    oc = cd.out_c_total if cd.out_c_total > 0 else cd.cout
+    oc = cd.out_c_total if cd.out_c_total > 0 else ys.c
     if out is None:
         out = torch.empty((n, oc, ys.h, ys.w), dtype=x.dtype, device=x.device)
     elif tuple(out.shape) != (n, oc, ys.h, ys.w):

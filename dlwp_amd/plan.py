@@ -81,6 +81,7 @@ class PlanOp(object):
         # lstm only: src = zx buffer, dst = h buffer; aux = (zh buffer | None, c_prev buffer | None, c_out buffer)
         self.aux = kw.pop('aux', None)
         self.out_pool = kw.pop('out_pool', False)   # conv only: MaxPooling2D(2) applied in the epilogue (inference plans)
+        self.out_d2s = kw.pop('out_d2s', False)     # conv only: the 4 F phase channels stored interleaved (inference plans)
         self.rec_act = kw.pop('rec_act', 0)
         # conv restated on a low-resolution source (inference plans; build_plan): geometry that overrides the layer's
         self.dil = kw.pop('dil', None)            # dilation (dh, dw)
@@ -170,7 +171,7 @@ class Plan(object):
         for op in self.ops:
             for b, role in ((op.src, 'r'), (op.dst, 'w')):
                 if b >= 0:
-                    ok[b] = ok.get(b, True) and op.kind in ('conv', 'maxpool', 'lstm')
+                    ok[b] = ok.get(b, True) and op.kind in ('conv', 'maxpool', 'lstm') and not (role == 'w' and op.out_d2s)
             if op.kind == 'lstm':
                 zh, cp, co = op.aux
                 for b in (cp, co):                                                # the cell state stays float32
@@ -267,7 +268,17 @@ def _supports_out_pool(op):
         return False
 
 
-def build_plan(inputs, outputs, inference=False):
+def _supports_out_d2s(xs, f4, ks, halo, act, in_c_off, in_c_total):
+    """can the restated layer's convolution store its 4 F phase channels interleaved (dlwp_conv2d.out_d2s)?"""
+    try:
+        from . import ops
+        cd = ops.make_conv(f4, ks[0], ks[1], 1, ops.make_pad(*halo), act, in_c_off, in_c_total, 0, 0, SRC_DIRECT)
+        return ops.supports_out_d2s(xs, cd)
+    except (ImportError, OSError, AttributeError):
+        return False
+
+
+def build_plan(inputs, outputs, inference=False, fuse_d2s=True):
     """inputs: [KTensor] (exactly one), outputs: [KTensor].  Returns a Plan.  inference=True additionally moves a
     MaxPooling2D(2) that is the only consumer of a convolution into that convolution's epilogue (the pre-pooling tensor
     is never written; the training plan keeps it because the backward pass needs it)."""
@@ -561,18 +572,28 @@ def build_plan(inputs, outputs, inference=False):
                                           'bias': lay.use_bias, 'pad_top': halo.top, 'pad_left': halo.left})
                 emit(PlanOp('phasew', STATE_IN, STATE_IN, (v.c, 0, 0), layer=lay, wparam=pidx, halo=halo,
                             out_shape=(0, 0, 0)))
-                tmp = plan.new_buffer(4 * lay.filters, v.h, v.w)
-                emit(PlanOp('conv', v.buf, tmp, (v.c, v.h, v.w), layer=lay, halo=h2, src_mode=SRC_DIRECT,
-                            act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
-                            out_c_total=4 * lay.filters, out_shape=(4 * lay.filters, v.h, v.w), dil=(1, 1),
-                            ksize=(kh2, kw2), filters=4 * lay.filters, wparam=pidx, alg_flops=alg))
+                fold = inference and fuse_d2s and _supports_out_d2s((v.c, v.h, v.w), 4 * lay.filters, (kh2, kw2), h2,
+                                                           ACT[lay.activation], v.c_off, v.c_total)
                 if outs:
                     dst = OUT(outs[0])
                     plan.output_store[outs[0]] = (lay.filters, ho, wo)
                 else:
                     dst = plan.new_buffer(lay.filters, ho, wo)
-                emit(PlanOp('d2s', tmp, dst, (lay.filters, v.h, v.w), out_c_off=0, out_c_total=lay.filters,
-                            out_shape=(lay.filters, ho, wo)))
+                if fold:         # the convolution's epilogue stores the phases interleaved: no depth-to-space pass
+                    op = PlanOp('conv', v.buf, dst, (v.c, v.h, v.w), layer=lay, halo=h2, src_mode=SRC_DIRECT,
+                                act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
+                                out_c_total=lay.filters, out_shape=(lay.filters, ho, wo), dil=(1, 1),
+                                ksize=(kh2, kw2), filters=4 * lay.filters, wparam=pidx, alg_flops=alg, out_d2s=True)
+                    op.conv_out_shape = (4 * lay.filters, v.h, v.w)
+                    emit(op)
+                else:
+                    tmp = plan.new_buffer(4 * lay.filters, v.h, v.w)
+                    emit(PlanOp('conv', v.buf, tmp, (v.c, v.h, v.w), layer=lay, halo=h2, src_mode=SRC_DIRECT,
+                                act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
+                                out_c_total=4 * lay.filters, out_shape=(4 * lay.filters, v.h, v.w), dil=(1, 1),
+                                ksize=(kh2, kw2), filters=4 * lay.filters, wparam=pidx, alg_flops=alg))
+                    emit(PlanOp('d2s', tmp, dst, (lay.filters, v.h, v.w), out_c_off=0, out_c_total=lay.filters,
+                                out_shape=(lay.filters, ho, wo)))
                 views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)
             else:
               if outs:

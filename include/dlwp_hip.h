@@ -82,6 +82,11 @@ typedef struct {
                                    * inference only; ask dlwp_conv2d_supports_out_pool first).  2: 2x2 SUM instead of the
                                    * max (linear activation, no bias; DLWP_EUNSUPPORTED when no kernel instance has it):
                                    * the adjoint of UpSampling2D(2), see dlwp_conv2d_bwd_data_stored                   */
+  int out_d2s;                    /* 1: the cout = 4 F channels are the 2x2 PHASES of F fields, phase-major (channel
+                                   * (2a + b) F + f = field f at rows 2i + a, columns 2j + b): the epilogue stores them
+                                   * interleaved -- y is (n, out_c_total, 2 ho, 2 wo), channels [out_c_off, out_c_off + F) --
+                                   * which is dlwp_depth_to_space2 without the pass (inference; ask
+                                   * dlwp_conv2d_supports_out_d2s first; not with out_pool)                             */
 } dlwp_conv2d;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
@@ -155,6 +160,8 @@ int dlwp_conv2d_prefers_unfused_pool(dlwp_handle_t, int cin, int cout, int kh, i
 /* Planner hint (host logic, handle nullable): 1 when a compiled kernel can apply a following MaxPooling2D(2) in the epilogue
  * of this convolution (cd->out_pool = 1): the pre-pooling tensor is then never written. */
 int dlwp_conv2d_supports_out_pool(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
+/* ... and 1 when a compiled kernel can store the 2x2 phase channels of this convolution interleaved (cd->out_d2s = 1). */
+int dlwp_conv2d_supports_out_d2s(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 /* Measurement hook (bench.py's roofline): what dlwp_conv2d_fwd(xs, cd, dtype) launches -- one kernel, or two when a Winograd
  * layer hands its ragged last column tile to a narrower instance -- and the matrix-core work each launch EXECUTES: the

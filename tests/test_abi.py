@@ -29,7 +29,7 @@ def test_struct_layouts_match_the_header():
     # sizes implied by include/dlwp_hip.h (all-int structs, no padding)
     assert ctypes.sizeof(_lib.Shape4) == 16
     assert ctypes.sizeof(_lib.Pad2d) == 24
-    assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 7 * 4
+    assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 8 * 4      # ... src_mode, out_pool, out_d2s
     assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24 + 4 * 4   # + aux[4]
 
 
@@ -52,6 +52,12 @@ def test_conv_out_shape_and_validation_without_a_device():
         ops.conv_out_shape(_lib.Shape4(1, 1, 3, 3), ops.make_conv(4, 5, 5))
     with pytest.raises(_lib.DlwpError, match='output channel window'):
         ops.conv_out_shape(_lib.Shape4(1, 1, 8, 8), ops.make_conv(4, 3, 3, out_c_off=2, out_c_total=4))
+    # interleaved phase stores: 4 F channels -> F fields at twice the resolution, window counted in fields
+    ys = ops.conv_out_shape(_lib.Shape4(2, 8, 10, 12), ops.make_conv(16, 3, 3, halo=ops.make_pad(1, 1, 1, 1), out_c_off=1,
+                                                                   out_c_total=5, out_d2s=True))
+    assert (ys.n, ys.c, ys.h, ys.w) == (2, 4, 20, 24)
+    with pytest.raises(_lib.DlwpError, match='out_d2s'):
+        ops.conv_out_shape(_lib.Shape4(1, 1, 8, 8), ops.make_conv(6, 3, 3, out_d2s=True))
 
 
 def test_compiled_tile_configurations_cover_the_unet_layers():

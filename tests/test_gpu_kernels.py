@@ -314,6 +314,45 @@ def test_winograd_position_split_instances_for_16_output_channels(ops, pool, in1
             assert torch.equal(ops.conv2d(xd, dev(wt), dev(b), cd, out=torch.empty_like(seen)), seen)
 
 
+@pytest.mark.parametrize('fields,hw', [(4, (20, 70)), (12, (19, 45)), (4, (44, 90))])
+def test_winograd_phase_channels_stored_interleaved(ops, fields, hw):
+    """dlwp_conv2d.out_d2s: the 4 F output channels are the 2x2 phases of F fields (phase-major) and the 16-channel Winograd
+    instances store them interleaved into (n, c_total, 2 ho, 2 wo) -- the same bits as the convolution followed by
+    dlwp_depth_to_space2, ragged edges and a channel window of a wider output included; every tile shape agrees."""
+    rng = np.random.default_rng(98)
+    cfgs = ops.conv_configs()
+    n, cin = 3, 24
+    h, w = hw
+    cout = 4 * fields
+    x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+    wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+    b = dev((0.1 * rng.standard_normal(cout)).astype(np.float32))
+    plain = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
+    assert ops.supports_out_d2s((cin, h, w), plain)
+    y4 = ops.conv2d(x, wt, b, plain)
+    want = torch.full((n, fields + 3, 2 * h, 2 * w), 7.0, device='cuda')
+    ops.depth_to_space2(y4, fields, out=want, c_off=2)
+    ref = np_ref.depth_to_space2(_conv_ref(host(x), host(wt), host(b), 1, (1, 1, 1, 1), 0, 1, 'tanh', 0), fields)
+    _check_conv(ops, host(want[:, 2:2 + fields]), ref, 'unfused reference path')
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, out_c_off=2, out_c_total=fields + 3,
+                       out_d2s=True)
+    tried = 0
+    try:
+        for i, c in enumerate([None] + list(cfgs)):
+            if c is not None and not (c[0] == 3 and c[1] == 1 and c[5] == 0 and c[6] == 1 and c[10] & 1):
+                continue
+            ops.force_conv_config(i - 1)
+            tried += 1
+            got = ops.conv2d(x, wt, b, cd, out=torch.full_like(want, 7.0))
+            assert torch.equal(got, want), 'config %r: interleaved stores differ from conv + depth_to_space2' % (c,)
+    finally:
+        ops.force_conv_config(-1)
+    assert tried >= 3
+    # layers the 16-channel instances do not take keep the separate pass
+    assert not ops.supports_out_d2s((cin, h, w), ops.make_conv(32, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH))
+    assert not ops.supports_out_d2s((cin, h, w), ops.make_conv(16, 5, 5, 1, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH))
+
+
 def test_winograd_wide_plus_narrow_launch_is_bit_identical(ops):
     """A 22x45 map at a batch that fills the chip: the 32 whole columns go to the 8x32 instance, the last 13 to the 16-wide
     one in a second launch.  Same bits as the single forced instance; plain, pooled-epilogue and up-sampled launches."""

@@ -488,8 +488,9 @@ def test_inference_plan_moves_the_pooling_into_the_producers():
     d.build_model(unet_layers((4, 88, 180)), loss='mse', optimizer='adam', gpus=1)
     ip = d.model.infer_plan
     # 6 convolutions; the 5x5 output layer reads an up-sampled tensor and is restated on its low-resolution source:
-    # derived kernels ('phasew', once per graph launch) + a 3x3 convolution with 4 x 4 channels + depth-to-space
-    assert [op.kind for op in ip.ops] == ['conv'] * 5 + ['phasew', 'conv', 'd2s']
+    # derived kernels ('phasew', once per graph launch) + a 3x3 convolution with 4 x 4 phase channels whose epilogue stores
+    # them interleaved (dlwp_conv2d.out_d2s: no depth-to-space pass)
+    assert [op.kind for op in ip.ops] == ['conv'] * 5 + ['phasew', 'conv']
     convs = [op for op in ip.ops if op.kind == 'conv']
     assert [op.out_pool for op in convs] == [True, True, False, False, False, False]
     assert ip.buffers[0] == (32, 44, 90) and ip.buffers[1] == (64, 22, 45)
@@ -498,7 +499,8 @@ def test_inference_plan_moves_the_pooling_into_the_producers():
     assert tuple(convs[4].halo)[:4] == (1, 1, 1, 1) and convs[4].out_shape == (32, 44, 90)
     # layer 6 (5x5 on the up-sampled output of layer 5): 3x3 phase kernels, 16 = 4 phases x 4 channels
     assert convs[5].conv_geometry == (16, (3, 3), (1, 1)) and convs[5].xs == (32, 44, 90) and convs[5].wparam == 0
-    assert tuple(convs[5].halo)[:4] == (1, 1, 1, 1) and ip.ops[-1].out_shape == (4, 88, 180)
+    assert tuple(convs[5].halo)[:4] == (1, 1, 1, 1) and ip.ops[-1].out_shape == (4, 88, 180) and convs[5].out_d2s
+    assert convs[5].conv_out_shape == (16, 44, 90) and [op.kind for op in d.model.plan.ops][-2:] == ['conv', 'd2s']
     # the ALGORITHMIC count is the reference graph's, whatever is executed
     assert ip.conv_flops_per_sample() == d.model.plan.conv_flops_per_sample() == 1597685760
     assert not any(op.out_pool for op in d.model.plan.ops) and len(d.model.plan.ops) == 10
