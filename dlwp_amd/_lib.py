@@ -52,7 +52,8 @@ class Conv2d(ctypes.Structure):
     _fields_ = [('cout', ctypes.c_int), ('kh', ctypes.c_int), ('kw', ctypes.c_int), ('dil_h', ctypes.c_int),
                 ('dil_w', ctypes.c_int), ('halo', Pad2d), ('act', ctypes.c_int), ('in_c_off', ctypes.c_int),
                 ('in_c_total', ctypes.c_int), ('out_c_off', ctypes.c_int), ('out_c_total', ctypes.c_int),
-                ('src_mode', ctypes.c_int), ('out_pool', ctypes.c_int), ('out_d2s', ctypes.c_int)]
+                ('src_mode', ctypes.c_int), ('out_pool', ctypes.c_int), ('out_d2s', ctypes.c_int),
+                ('lstm_f', ctypes.c_int), ('lstm_rec_act', ctypes.c_int)]
 
 
 class Op(ctypes.Structure):
@@ -161,6 +162,8 @@ _sig('dlwp_maxpool2_bwd', [_vp, _vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_upsample2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_upsample2_bwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_convlstm_gates', [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
+_sig('dlwp_convlstm_conv_fwd', [_vp] * 9 + [Shape4, _P(Conv2d), _i, _vp])
+_sig('dlwp_convlstm_conv_supported', [_vp, Shape4, _P(Conv2d), _i])
 _sig('dlwp_convlstm_gates_bwd', [_vp] * 9 + [_i] * 8 + [_vp])
 _sig('dlwp_copy_channels', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])

@@ -95,8 +95,15 @@ __device__ static inline int dlwp_map_coord_tile(int p, int n, int mode) {
 // internal launchers shared between the public entry points and the rollout graph builder
 // u_pre: weights already prepared by dlwp_conv2d_prep for this (w, xs, cd) -- the rollout graph transforms once per
 // launch instead of once per forward; NULL = transform into the handle's scratch right before the multiply
+// lstm: the extra tensors of a convolution with the ConvLSTM2D cell update in its epilogue (cd->lstm_f > 0; y = h buffer)
+struct dlwp_lstm_io {
+  const void* z_add;     // bfloat16 (n, 4F, ho, wo) or NULL
+  const void* c_prev;    // float32 (n, F, ho, wo) or NULL
+  void* c_out;           // float32 (n, F, ho, wo)
+};
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
-                       const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre = nullptr);
+                       const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre = nullptr,
+                       const dlwp_lstm_io* lstm = nullptr);
 // prepared weights of the Winograd / packed-N / bf16-MFMA families: floats needed for this layer (0 = the kernel reads HWIO), and
 // the kernel that builds them
 size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);

@@ -122,7 +122,7 @@ extern "C" {
 // pass: 0 = bwd_data, 1 = bwd_weight
 int dlwp_conv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int pass, size_t* bytes) {
   DLWP_CHECK_ARG(h && cd && bytes, "dlwp_conv2d_bwd_workspace: null pointer");
-  DLWP_CHECK_ARG(!cd->out_d2s, "conv2d backward: out_d2s descriptors are forward-only");
+  DLWP_CHECK_ARG(!cd->out_d2s && !cd->lstm_f, "conv2d backward: out_d2s / lstm_f descriptors are forward-only");
   DLWP_CHECK_ARG(!cd->out_pool, "conv2d backward: out_pool descriptors are forward-only (the backward pass needs the "
                                 "pre-pooling activations)");
   dlwp_shape4 ys;
@@ -219,7 +219,7 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void*
                            const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
   DLWP_CHECK_ARG(h && x && dz && dw && cd && ws, "dlwp_conv2d_bwd_weight: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_conv2d_bwd_weight: dtype %d not supported", dtype);
-  DLWP_CHECK_ARG(!cd->out_pool && !cd->out_d2s, "dlwp_conv2d_bwd_weight: out_pool / out_d2s descriptors are forward-only");
+  DLWP_CHECK_ARG(!cd->out_pool && !cd->out_d2s && !cd->lstm_f, "dlwp_conv2d_bwd_weight: out_pool / out_d2s / lstm_f descriptors are forward-only");
   dlwp_shape4 ys;
   if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return DLWP_EINVAL;
   WgChoice c;

@@ -85,9 +85,10 @@ bool bf16_wanted(const ConvArgs& a, const dlwp_conv2d* cd, const dlwp_options& o
 // Arranged weights of a bf16-MFMA instance (conv_fwd_bf16_kernel.h):
 // out[(ct, chunk)][WCH] (16-byte units): unit ((tap*NO + oct)*BN + col) holds the 8 bf16 weights of channels
 // chunk*CK + oct*8 .. +7, tap, output channel ct*BN + col; zero outside Cin / Cout.
+// lstm_f > 0 (gates epilogue): tile ct = hidden channels 16 ct .. +15, column col = gate col / 16, hidden channel col % 16.
 __global__ __launch_bounds__(256) void bf16_arrange_weights(const float* __restrict__ w, unsigned* __restrict__ out, int Cin,
                                                             int Cout, int taps, int ck, int bn, int wch, int n_chunks,
-                                                            int n_ct) {
+                                                            int n_ct, int lstm_f) {
   const int no = ck / 8;
   const long long total = (long long)n_ct * n_chunks * wch;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -98,8 +99,9 @@ __global__ __launch_bounds__(256) void bf16_arrange_weights(const float* __restr
     if (r < taps * no * bn) {
       const int col = r % bn, row = r / bn;
       const int oct = row % no, tap = row / no;
-      const int co = ct * bn + col;
-      if (co < Cout) {
+      const int hc = ct * 16 + (col & 15);
+      const int co = lstm_f ? (col >> 4) * lstm_f + hc : ct * bn + col;
+      if (lstm_f ? hc < lstm_f : co < Cout) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int ci = chunk * ck + oct * 8 + j;
@@ -195,6 +197,8 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
   a.W = dlwp_src_dim(xs.w, cd->src_mode);
   a.out_pool = cd->out_pool;
   a.out_d2s = cd->out_d2s;
+  a.lstm_f = cd->lstm_f;
+  a.rec_act = cd->lstm_rec_act;
   a.Hp = ys.h;   // what is stored
   a.Wp = ys.w;
   a.Ho = a.H + cd->halo.top + cd->halo.bottom - cd->dil_h * (cd->kh - 1);   // the convolution's own output
@@ -203,7 +207,7 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
   a.in_c_off = cd->in_c_off;
   a.in_c_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
   a.out_c_off = cd->out_c_off;
-  a.out_c_total = cd->out_c_total > 0 ? cd->out_c_total : (cd->out_d2s ? cd->cout / 4 : cd->cout);
+  a.out_c_total = cd->out_c_total > 0 ? cd->out_c_total : (cd->out_d2s ? cd->cout / 4 : (cd->lstm_f ? cd->lstm_f : cd->cout));
   a.pad_top = cd->halo.top;
   a.pad_left = cd->halo.left;
   a.mode_h = cd->halo.mode_h;
@@ -290,6 +294,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     if (cd->out_pool && !e.out_pool) return -1;
     if (cd->out_pool == 2 && !(is_wino(e) && e.dil == 1)) return -1;  // the 2x2 sum epilogue: dilation-1 Winograd instances
     if (cd->out_d2s && !(is_wino(e) && e.split)) return -1;           // interleaved phase stores: the 16-channel instances
+    if ((cd->lstm_f != 0) != (is_bf16(e) && e.gates)) return -1;        // gates epilogue <-> the GATES instances
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? forced
                : -1;
@@ -301,8 +306,10 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
   if (!sum_pool && bf16_wanted(a, cd, o))
     for (const ConvKernelEntry& e : r.entries)
       want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h && (!cd->out_pool || e.out_pool) &&
+                                (cd->lstm_f != 0) == (e.gates != 0) &&
                                 (e.in32 != 0) == !a.in_bf16 &&
                                 bf16_prep_floats(e, a.Cin, a.Cout) <= WINO_SCRATCH_FLOATS);
+  if (cd->lstm_f && !want_bf16) return -1;
   bool want_wino = !want_bf16 && winograd_wanted(a, cd, o);
   if (want_wino) {  // fall back to the direct family when no Winograd instance matches (dilation / pooled loader)
     bool any = false;
@@ -327,7 +334,12 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     if (is_bf16(e) && ((e.in32 != 0) == (a.in_bf16 != 0) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) continue;
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     if (cd->out_d2s && !(is_wino(e) && e.split)) continue;                 // interleaved phase stores: the 16-channel instances
-    const double c = config_cost(e, a, cu_count);
+    if ((cd->lstm_f != 0) != (is_bf16(e) && e.gates)) continue;            // gates epilogue <-> the GATES instances
+    double c = config_cost(e, a, cu_count);
+    // cell-update instances: the epilogue's ~45 vector operations per hidden value want waves, not tile size -- the 4 x 32
+    // tiles (two fragments per wave) with 16-channel chunks run 3-4 waves per SIMD (114-132 registers) against two for the
+    // 8 x 32 / 32-channel ones (measured on config 4, tools/tune_lstm_conv.py: 0.100 vs 0.128 ms on the recurrent convolution)
+    if (e.gates) c *= (e.th == 4 ? 0.7 : 1.0) * (e.ck == 16 ? 0.7 : 1.0);
     if (best < 0 || c < best_cost) {
       best = i;
       best_cost = c;
@@ -411,12 +423,12 @@ static size_t prep_floats_of(const ConvKernelEntry& e, int cin, int cout) {
   return 0;
 }
 
-static int prep_with(const ConvKernelEntry& e, const void* w, float* dst, int cin, int cout, hipStream_t s) {
+static int prep_with(const ConvKernelEntry& e, const void* w, float* dst, int cin, int cout, hipStream_t s, int lstm_f = 0) {
   if (is_bf16(e)) {
     const int n_chunks = dlwp_ceil_div(cin, e.ck), n_ct = dlwp_ceil_div(cout, 16 * e.bnf), wch = e.prep_chunk_floats / 4;
     const long long total = (long long)n_ct * n_chunks * wch;
     bf16_arrange_weights<<<dlwp_ceil_div(total, 256), 256, 0, s>>>((const float*)w, (unsigned*)dst, cin, cout, e.ks * e.ks,
-                                                                   e.ck, 16 * e.bnf, wch, n_chunks, n_ct);
+                                                                   e.ck, 16 * e.bnf, wch, n_chunks, n_ct, lstm_f);
     DLWP_LAUNCH_CHECK("bf16_arrange_weights");
   } else if (is_wino(e)) {
     wino_filter_transform_f32<<<dlwp_ceil_div((long long)cin * cout, 256), 256, 0, s>>>((const float*)w, dst, cin, cout);
@@ -439,7 +451,7 @@ size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2
 int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype,
                      hipStream_t s) {
   const ConvKernelEntry* e = entry_for(h, xs, cd, dtype);
-  return e ? prep_with(*e, w, dst, xs.c, cd->cout, s) : DLWP_OK;
+  return e ? prep_with(*e, w, dst, xs.c, cd->cout, s, cd->lstm_f) : DLWP_OK;
 }
 
 namespace {
@@ -517,13 +529,22 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
 }  // namespace (second part)
 
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
-                       const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre) {
+                       const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre, const dlwp_lstm_io* lstm) {
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
   DLWP_CHECK_ARG(cd->out_pool != 2 || !bias, "dlwp_conv2d_fwd: the 2x2 sum epilogue takes no bias");
+  DLWP_CHECK_ARG((cd->lstm_f > 0) == (lstm != nullptr),
+                 "dlwp_conv2d_fwd: a descriptor with lstm_f goes through dlwp_convlstm_conv_fwd (and only such a one)");
   if (xs.n == 0) return DLWP_OK;
   ConvArgs a = make_args(x, w, bias, y, xs, cd, ys, dtype);
+  if (lstm) {
+    DLWP_CHECK_ARG(lstm->c_out != nullptr, "dlwp_convlstm_conv_fwd: null c_out");
+    if (a.Wo % 4 != 0) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_convlstm_conv_fwd: output width %d is not a multiple of 4", a.Wo);
+    a.zadd = lstm->z_add;
+    a.c_prev = (const float*)lstm->c_prev;
+    a.c_out = (float*)lstm->c_out;
+  }
   LaunchPlan lp;
   plan_launch(h, a, cd, &lp);
   const int ci = lp.primary;
@@ -532,6 +553,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
       DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", h->opt.forced_cfg);
     if (cd->out_pool) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel with a pooling epilogue for this layer");
     if (cd->out_d2s) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel stores this layer's phase channels interleaved");
+    if (cd->lstm_f) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_convlstm_conv_fwd: no bf16 matrix-core instance covers this layer");
     return launch_direct(h, a, cd, s);  // kernel sizes without an MFMA tile configuration
   }
   Registry& r = registry();
@@ -560,7 +582,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
     } else {
       float* u = dlwp_wino_scratch(h, prep_floats_of(e, a.Cin, a.Cout), s);
       if (!u) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: no scratch for the prepared weights");
-      const int rc2 = prep_with(e, a.w, u, a.Cin, a.Cout, s);
+      const int rc2 = prep_with(e, a.w, u, a.Cin, a.Cout, s, cd->lstm_f);
       if (rc2 != DLWP_OK) return rc2;
       a.w = u;
     }
@@ -624,7 +646,11 @@ int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys
                  cd->in_c_off, cd->in_c_off + xs.c, in_total);
   DLWP_CHECK_ARG(cd->out_d2s == 0 || (cd->out_d2s == 1 && cd->out_pool == 0 && cd->cout % 4 == 0),
                  "conv2d: out_d2s needs 4 F output channels and no pooling epilogue");
-  const int out_fields = cd->out_d2s ? cd->cout / 4 : cd->cout;
+  DLWP_CHECK_ARG(cd->lstm_f >= 0 && (cd->lstm_f == 0 || (cd->cout == 4 * cd->lstm_f && !cd->out_pool && !cd->out_d2s &&
+                                                          (unsigned)cd->lstm_rec_act <= 1u)),
+                 "conv2d: lstm_f = %d needs cout = 4 F (got %d), no pooling / phase epilogue, rec_act 0 or 1", cd->lstm_f,
+                 cd->cout);
+  const int out_fields = cd->out_d2s ? cd->cout / 4 : (cd->lstm_f ? cd->lstm_f : cd->cout);
   const int out_total = cd->out_c_total > 0 ? cd->out_c_total : out_fields;
   DLWP_CHECK_ARG(cd->out_c_off >= 0 && cd->out_c_off + out_fields <= out_total,
                  "conv2d: output channel window [%d,%d) of %d", cd->out_c_off, cd->out_c_off + out_fields, out_total);
@@ -663,12 +689,30 @@ int dlwp_conv2d_fwd_prepared(dlwp_handle_t h, const void* x, const void* w, cons
   return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream, (const float*)prepared);
 }
 
+int dlwp_convlstm_conv_fwd(dlwp_handle_t h, const void* x, const void* w, const void* prepared, const void* bias,
+                           const void* z_add, const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs,
+                           const dlwp_conv2d* cd, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && cd && cd->lstm_f > 0, "dlwp_convlstm_conv_fwd: null handle / descriptor, or lstm_f not set");
+  const dlwp_lstm_io io{z_add, c_prev, c_out};
+  return dlwp_launch_conv2d(h, x, w, bias, h_out, xs, cd, dtype, (hipStream_t)stream, (const float*)prepared, &io);
+}
+
+int dlwp_convlstm_conv_supported(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
+  if (!cd || cd->lstm_f <= 0 || xs.c <= 0 || xs.h <= 0 || xs.w <= 0) return 0;
+  dlwp_shape4 ys;
+  if (xs.n <= 0) xs.n = 1;
+  if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK || ys.w % 4 != 0) return 0;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys, dtype);
+  return choose_config(a, cd, 256, h ? h->opt : dlwp_default_options()) >= 0 ? 1 : 0;
+}
+
 int dlwp_conv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int dtype, void* stream) {
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd_direct", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
-  DLWP_CHECK_ARG(!cd->out_pool && !cd->out_d2s, "dlwp_conv2d_fwd_direct: out_pool / out_d2s are not supported by this kernel");
+  DLWP_CHECK_ARG(!cd->out_pool && !cd->out_d2s && !cd->lstm_f,
+                 "dlwp_conv2d_fwd_direct: out_pool / out_d2s / lstm_f are not supported by this kernel");
   ConvArgs a = make_args(x, w, bias, y, xs, cd, ys, dtype);
   return launch_direct(h, a, cd, (hipStream_t)stream);
 }
@@ -692,7 +736,7 @@ int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes) {
 int dlwp_conv2d_config_flags(int i) {
   Registry& r = registry();
   if (i < 0 || i >= (int)r.entries.size()) return 0;
-  return (is_wino(r.entries[i]) && r.entries[i].split) ? 1 : 0;
+  return ((is_wino(r.entries[i]) && r.entries[i].split) ? 1 : 0) | (r.entries[i].gates ? 2 : 0);
 }
 
 int dlwp_conv2d_prefers_unfused_pool(dlwp_handle_t h, int cin, int cout, int kh, int kw, int dil_h, int dil_w) {

@@ -15,6 +15,17 @@ static const ConvKernelEntry k_table[] = {
     BF16_ENTRY_IN32(3, 1, 8, 32, 4, 4, 2, 16),
     BF16_ENTRY_IN32(3, 2, 8, 32, 4, 4, 2, 16),
     BF16_ENTRY_IN32(5, 1, 8, 32, 4, 4, 1, 16),
+    // 64-channel blocks = 4 gates x 16 hidden channels: the ConvLSTM2D input convolution with the cell update in its epilogue
+    BF16_ENTRY_GATES_IN32(3, 2, 8, 32, 4, 4, 16),
+    BF16_ENTRY_GATES_IN32(3, 1, 8, 32, 4, 4, 16),
+    BF16_ENTRY_GATES(3, 1, 8, 32, 4, 4, 32),
+    BF16_ENTRY_GATES(3, 1, 8, 32, 4, 4, 16),
+    BF16_ENTRY_GATES(3, 2, 8, 32, 4, 4, 32),
+    // 4 x 32 tiles, two fragments per wave: 32 accumulator registers instead of 64 (three waves per SIMD)
+    BF16_ENTRY_GATES_IN32(3, 2, 4, 32, 4, 2, 16),
+    BF16_ENTRY_GATES_IN32(3, 1, 4, 32, 4, 2, 16),
+    BF16_ENTRY_GATES(3, 1, 4, 32, 4, 2, 32),
+    BF16_ENTRY_GATES(3, 1, 4, 32, 4, 2, 16),
     // 4 x 64 tiles: 8-11 % faster than 8 x 32 on the dilation-1 layers whose width they tile well (a tile row of bf16
     // output is then a whole 128-byte line); slower with dilation 2 (measured, profiles/r1i_bf16_conv_layers_*)
     BF16_ENTRY(3, 1, 4, 64, 4, 4, 2, 32),

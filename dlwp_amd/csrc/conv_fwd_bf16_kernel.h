@@ -21,9 +21,12 @@
 #include <type_traits>
 
 // IN32: the input is stored as float32 and rounded to bf16 while it is staged (the caller allowed it: DLWP_COMPUTE_BF16)
-template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool IN32_ = false>
+// GATES: the instance of a ConvLSTM2D step -- 64-channel blocks = 4 gates x 16 hidden channels, cell update in the epilogue
+template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool IN32_ = false, bool GATES_ = false>
 struct BfCfg {
   static constexpr bool IN32 = IN32_;
+  static constexpr bool GATES = GATES_;
+  static_assert(!GATES_ || BNF_ == 4, "gates epilogue: fragment column group g = gate g");
   static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, FA = FA_, BNF = BNF_, CK = CK_;
   static constexpr int NT = WAVES * 64;
   static constexpr int LR = TH + DIL * (KS - 1);
@@ -125,8 +128,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
   float bias_v[C::BNF];   // loaded here: the latency hides under the main loop
 #pragma unroll
   for (int g = 0; g < C::BNF; ++g) {
-    const int co = n0 + g * 16 + (lane & 15);
-    bias_v[g] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    // gates epilogue (a.lstm_f): block ct = hidden channels 16 ct .. +15, fragment column group g = gate g
+    const int co = a.lstm_f ? g * a.lstm_f + ct * 16 + (lane & 15) : n0 + g * 16 + (lane & 15);
+    const bool cok = a.lstm_f ? ct * 16 + (lane & 15) < a.lstm_f : co < a.Cout;
+    bias_v[g] = (a.bias && cok) ? a.bias[co] : 0.f;
 #pragma unroll
     for (int i = 0; i < C::FA; ++i) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -267,6 +272,84 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
     }
   }
 
+  // ---- ConvLSTM2D step: the cell update of keras ConvLSTM2DCell.call on the accumulators.  A lane holds the four gate
+  //      pre-activations (i, f, c~, o = fragment column groups 0..3) of ONE hidden channel for 4 consecutive pixels:
+  //      z = conv + bias (+ the other convolution's stored pre-activations);  c = f c_prev + i act(z_c);  h = o act(c).
+  //      The 4F-channel z tensor is neither written nor read back (HBM: 8 F -> 2.5 F values per pixel on a first step).
+  if constexpr (C::GATES) {
+    // what the cell update reads besides the accumulators -- the other convolution's stored pre-activations (bf16, 4 gates x 4
+    // pixels) and c_prev (4 pixels) per fragment: ALL fragments' loads are issued before the first use (one memory round trip
+    // per block, not one per fragment), and only here, where the main loop's staging registers are free (fetched before
+    // the loop they cost 48 registers through it: 256 + spills, two waves per SIMD)
+    u32x2 zpre[C::FA][4];
+    f32x4 cpre[C::FA];
+    {
+      const int F = a.lstm_f, ch = ct * 16 + (lane & 15);
+      const unsigned hw = (unsigned)(a.Ho * a.Wo);
+      const __amdgpu_buffer_rsrc_t z_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((const char*)a.zadd + (long long)n * 4 * F * hw * 2), 0, a.zadd ? (unsigned)(4 * F) * hw * 2u : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t cp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.c_prev + (long long)n * F * hw), 0, a.c_prev ? (unsigned)F * hw * 4u : 0u, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < C::FA; ++i) {
+        const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
+        const int row = p / C::TW, col = p - row * C::TW;
+        const int oh = i0 + row, ow = j0 + col;
+        const bool ok = ch < F && p < C::P && oh < a.Ho && ow < a.Wo;
+        const unsigned pix = (unsigned)(oh * a.Wo + ow);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)   // (a null z_add / c_prev has an empty descriptor: the loads return zeros)
+          zpre[i][g] = __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, ok ? ((unsigned)(g * F + ch) * hw + pix) * 2u : 0x7ffffff0u, 0, 0);
+        cpre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cp_rsrc, ok ? ((unsigned)ch * hw + pix) * 4u : 0x7ffffff0u, 0, 0));
+      }
+    }
+    {
+      const int F = a.lstm_f, ch = ct * 16 + (lane & 15);
+      const unsigned hw = (unsigned)(a.Ho * a.Wo);
+      constexpr unsigned DROP = 0x7ffffff0u;
+      const __amdgpu_buffer_rsrc_t co_rsrc =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.c_out + (long long)n * F * hw), 0, (unsigned)F * hw * 4u, 0x00020000);
+      const unsigned hsz = a.out_bf16 ? 2u : 4u;
+      const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((char*)a.y + ((long long)n * a.out_c_total + a.out_c_off) * (long long)hw * hsz), 0, (unsigned)F * hw * hsz,
+          0x00020000);
+#pragma unroll
+      for (int i = 0; i < C::FA; ++i) {
+        const int p = (wave * C::FA + i) * 16 + (lane >> 4) * 4;
+        const int row = p / C::TW, col = p - row * C::TW;
+        const int oh = i0 + row, ow = j0 + col;
+        // (the host takes this path for Wo % 4 == 0 only: a pixel quad is inside or outside as a whole)
+        const bool ok = ch < F && p < C::P && oh < a.Ho && ow < a.Wo;
+        const unsigned pix = (unsigned)(oh * a.Wo + ow);
+        float z[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x2 v = zpre[i][g];
+          const float za[4] = {bf16_bits_to_f32(v[0] & 0xffffu), bf16_bits_to_f32(v[0] >> 16), bf16_bits_to_f32(v[1] & 0xffffu),
+                               bf16_bits_to_f32(v[1] >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[g][r] = acc[i][g][r] + bias_v[g] + za[r];
+        }
+        const f32x4 cp = cpre[i];
+        f32x4 cn, hn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float cv = dlwp_rec_apply(z[0][r], a.rec_act) * act_apply(z[2][r], a.act);
+          if (a.c_prev) cv = fmaf(dlwp_rec_apply(z[1][r], a.rec_act), cp[r], cv);
+          cn[r] = cv;
+          hn[r] = dlwp_rec_apply(z[3][r], a.rec_act) * act_apply(cv, a.act);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cn), co_rsrc, ok ? ((unsigned)ch * hw + pix) * 4u : DROP, 0, 0);
+        if (a.out_bf16)
+          __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3])}, h_rsrc,
+                                                ok ? ((unsigned)ch * hw + pix) * 2u : DROP, 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hn), h_rsrc, ok ? ((unsigned)ch * hw + pix) * 4u : DROP, 0, 0);
+      }
+      return;
+    }
+  }
+
   // ---- epilogue: bias + activation (+ MaxPooling2D(2)), 4 consecutive pixels of one channel per lane.  Stores go through
   //      a buffer descriptor over this sample's output window with 32-bit offsets: out-of-range channels / pixels get an
   //      offset past the end and the hardware drops the store -- no branches, no 64-bit address arithmetic.
@@ -376,13 +459,15 @@ static int bf16_prepare() {
 
 // registry entry: pack = -2 marks a bf16-MFMA instance (a.w = bf16_arrange_weights output); in32 = 1: float32-stored input,
 // rounded to bf16 in the loader; prep_chunk_floats = floats per (cout tile, channel chunk) of the arranged weights
-#define BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32)                                                   \
-  {                                                                                                                \
-    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>::LDS_BYTES, 0, -2,       \
-        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>::POOL_EPI ? 1 : 0,                                        \
-        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>::WCH * 4,                                                 \
-        &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>>,                                      \
-        &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32>>, IN32 ? 1 : 0                              \
+#define BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES)                                                     \
+  {                                                                                                                         \
+    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>::LDS_BYTES, 0, -2,         \
+        (!GATES && BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>::POOL_EPI) ? 1 : 0,                              \
+        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>::WCH * 4,                                                   \
+        &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>>,                                        \
+        &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>>, IN32 ? 1 : 0, 0, GATES ? 1 : 0              \
   }
-#define BF16_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, false)
-#define BF16_ENTRY_IN32(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, true)
+#define BF16_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, false, false)
+#define BF16_ENTRY_IN32(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, true, false)
+#define BF16_ENTRY_GATES(KS, DIL, TH, TW, WAVES, FA, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, 4, CK, false, true)
+#define BF16_ENTRY_GATES_IN32(KS, DIL, TH, TW, WAVES, FA, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, 4, CK, true, true)

@@ -40,6 +40,13 @@ struct ConvArgs {
   int compute_bf16;       // DLWP_COMPUTE_BF16: a float32-stored input may be rounded to bf16 for the bf16 matrix cores
   int col0 = 0;           // Winograd: first output column of this launch (a wide-tile launch + a narrow one for the rest)
   int out_d2s = 0;        // the 4 F output channels are 2x2 phases: stored interleaved, y = (N, out_c_total, 2 Ho, 2 Wo)
+  // ConvLSTM2D cell update in the epilogue (bf16 matrix-core instances with 64-channel blocks, conv_fwd_bf16_kernel.h):
+  // Cout = 4 lstm_f gate pre-activations z = conv + bias (+ zadd) are never stored; y = the h buffer (channel window
+  // out_c_off / out_c_total), c_prev / c_out the float32 cell state.  0: plain convolution.
+  int lstm_f = 0, rec_act = 0;
+  const void* zadd = nullptr;
+  const float* c_prev = nullptr;
+  float* c_out = nullptr;
 #ifdef DLWP_PHASE_TIMING  // tools/microbench/wino_phase_timing.hip only: s_memtime stamps of wave 0, 8 per block
   long long* dbg = nullptr;
 #endif
@@ -118,6 +125,12 @@ __device__ __forceinline__ float act_apply_c(float v) {
   if constexpr (ACT == DLWP_ACT_TANH) return dlwp_tanh(v);
   else if constexpr (ACT == DLWP_ACT_RELU) return fmaxf(v, 0.f);
   else return v;
+}
+
+// recurrent activation of keras ConvLSTM2D: 0 = hard_sigmoid (the default), 1 = sigmoid
+__device__ __forceinline__ float dlwp_rec_apply(float z, int rec_act) {
+  if (rec_act == 0) return fminf(fmaxf(fmaf(0.2f, z, 0.5f), 0.f), 1.f);
+  return 1.f / (1.f + __expf(-z));
 }
 
 // ---- packed fp32 (v_pk_*_f32: two fp32 operations per lane and issue slot, 64-bit register pairs).  The fp32 matrix
@@ -532,6 +545,7 @@ struct ConvKernelEntry {
   int in32 = 0;  // bf16-MFMA instances: 1 = the input is stored as float32 and rounded to bf16 by the loader
   int split = 0; // Winograd: 1 = the 16-position case runs conv_fwd_wino2_kernel.h (positions split over two waves per
                  // tile fragment: 2 x waves x 64 threads); the 9-position variants are the same for both
+  int gates = 0; // bf16-MFMA instances: 1 = ConvLSTM2D cell update in the epilogue (dlwp_conv2d.lstm_f), and only that
 };
 
 template <class C>

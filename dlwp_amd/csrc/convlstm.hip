@@ -8,10 +8,7 @@
 
 namespace {
 
-__device__ __forceinline__ float rec_apply(float z, int rec_act) {
-  if (rec_act == 0) return fminf(fmaxf(fmaf(0.2f, z, 0.5f), 0.f), 1.f);  // keras hard_sigmoid
-  return 1.f / (1.f + __expf(-z));
-}
+__device__ __forceinline__ float rec_apply(float z, int rec_act) { return dlwp_rec_apply(z, rec_act); }
 
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float* p, float (&out)[VEC]) {

@@ -27,6 +27,10 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
                                  DLWP_DTYPE_IO((op.aux[3] & 512) ? DLWP_BF16 : DLWP_F32, (op.aux[3] & 256) ? DLWP_BF16 : DLWP_F32),
                                  (void*)s);
     case DLWP_OP_CONV2D:
+      if (op.conv.lstm_f > 0) {   // cell update in the epilogue: aux[1..3] = z_add | NONE, c_prev | NONE, c_out; dst = h buffer
+        const dlwp_lstm_io io{aux[0], aux[1], aux[2]};
+        return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre, &io);
+      }
       return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre);  // aux[0]: per-op storage
     case DLWP_OP_PAD2D:
       // NCHW: outer = n*c rows-of-W planes; NHWC: xs = (n, 1, h, w) and conv.in_c_total carries the inner (channel) run
@@ -137,6 +141,10 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
       for (int k = 0; k < 3; ++k)
         DLWP_CHECK_ARG((k < 2 && op.aux[k] == DLWP_BUF_NONE) || (op.aux[k] >= 0 && op.aux[k] < n_buffers),
                        "rollout op %d: aux buffer %d out of range", i, op.aux[k]);
+    if (op.kind == DLWP_OP_CONV2D && op.conv.lstm_f > 0)
+      for (int k = 1; k <= 3; ++k)
+        DLWP_CHECK_ARG((k < 3 && op.aux[k] == DLWP_BUF_NONE) || (op.aux[k] >= 0 && op.aux[k] < n_buffers),
+                       "rollout op %d: cell-update buffer %d out of range", i, op.aux[k]);
   }
   const size_t esz = sizeof(float);
   DLWP_CHECK_ARG(slot_elems % members == 0, "dlwp_rollout_create: slot of %zu elements for %d members", slot_elems, members);
@@ -192,6 +200,8 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
         void* aux[3] = {nullptr, nullptr, nullptr};
         if (op.kind == DLWP_OP_LSTM_GATES)
           for (int k = 0; k < 3; ++k) aux[k] = op.aux[k] == DLWP_BUF_NONE ? nullptr : resolve(op.aux[k], t, g);
+        if (op.kind == DLWP_OP_CONV2D && op.conv.lstm_f > 0)
+          for (int k = 0; k < 3; ++k) aux[k] = op.aux[k + 1] == DLWP_BUF_NONE ? nullptr : resolve(op.aux[k + 1], t, g);
         rc = enqueue_op(h, op, resolve(op.src, t, g), resolve(op.dst, t, g), w, b, dtype, s, aux,
                         (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr);
       }

@@ -73,7 +73,7 @@ class Executor(object):
                     f, (kh, kw), dil = op.conv_geometry
                     descs.append(ops.make_conv(f, kh, kw, dil, ops.make_pad(*op.halo), op.act,
                                                op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode,
-                                               op.out_pool, op.out_d2s))
+                                               op.out_pool, op.out_d2s, op.lstm_f, op.rec_act))
                 elif op.kind == 'pad':
                     descs.append(ops.make_pad(*op.halo))
                 else:
@@ -117,7 +117,13 @@ class Executor(object):
             return outs[-2 - i]
         for op, d in zip(self.plan.ops, self._descriptors()):
             src, dst = res(op.src), res(op.dst)
-            if op.kind == 'conv':
+            if op.kind == 'conv' and op.lstm_f:
+                kern, bias = self.conv_weights(op)
+                za, cp, co = op.aux
+                ops.convlstm_conv(src, kern, bias, d, dst, res(co), z_add=res(za) if za is not None else None,
+                                  c_prev=res(cp) if cp is not None else None, x_channels=op.xs[0],
+                                  compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16))
+            elif op.kind == 'conv':
                 kern, bias = self.conv_weights(op)
                 ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0],
                            compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16))
@@ -198,6 +204,11 @@ class Executor(object):
                 o.w, o.b = pidx[op.wparam] if op.wparam is not None else widx[id(op.layer)]
                 o.conv = d
                 o.aux[0] = self._conv_dtype(op)
+                if op.lstm_f:                          # cell update in the epilogue: z_add | NONE, c_prev | NONE, c_out
+                    za, cp, co = op.aux
+                    o.aux[1] = za if za is not None else _lib.BUF_NONE
+                    o.aux[2] = cp if cp is not None else _lib.BUF_NONE
+                    o.aux[3] = co
             elif op.kind == 'phasew':                  # kernel -> derived kernel, once at the head of the graph
                 o.src, o.b = widx[id(op.layer)]
                 o.dst, b2i = pidx[op.wparam]
@@ -321,7 +332,14 @@ class Model(object):
             self.activation_dtype = dtype
             # interleaved phase stores (dlwp_conv2d.out_d2s) belong to the float32 Winograd kernels; with bfloat16 storage
             # the restated layers run on the bf16 matrix cores and keep the separate depth-to-space pass
-            self.infer_plan = P.build_plan(self.inputs, self.outputs, inference=True, fuse_d2s=(dtype == 'float32'))
+            # ... and the ConvLSTM2D cell update rides in a convolution's epilogue there (dlwp_convlstm_conv_fwd), provided
+            # the h sequence really is stored as bfloat16
+            bf = dtype == 'bfloat16'
+            self.infer_plan = P.build_plan(self.inputs, self.outputs, inference=True, fuse_d2s=not bf,
+                                           fuse_lstm=bf and os.environ.get('DLWP_LSTM_FUSE', '1') != '0')
+            if bf and any(op.kind == 'conv' and op.lstm_f and op.dst not in self.infer_plan.bf16_buffers()
+                          for op in self.infer_plan.ops):
+                self.infer_plan = P.build_plan(self.inputs, self.outputs, inference=True, fuse_d2s=False)
             self.executor = Executor(self.infer_plan, self.device, dtype)
             self.__dict__.pop('_rollouts', None)
         return self

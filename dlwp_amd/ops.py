@@ -55,11 +55,11 @@ def make_pad(top=0, bottom=0, left=0, right=0, mode_h=PAD_ZERO, mode_w=PAD_ZERO)
 
 
 def make_conv(cout, kh, kw, dil=1, halo=None, act=ACT_LINEAR, in_c_off=0, in_c_total=0, out_c_off=0, out_c_total=0,
-              src_mode=SRC_DIRECT, out_pool=False, out_d2s=False):
+              src_mode=SRC_DIRECT, out_pool=False, out_d2s=False, lstm_f=0, lstm_rec_act=0):
     dh, dw = (dil, dil) if isinstance(dil, int) else dil
     return Conv2d(int(cout), int(kh), int(kw), int(dh), int(dw), halo if halo is not None else make_pad(), int(act),
                   int(in_c_off), int(in_c_total), int(out_c_off), int(out_c_total), int(src_mode), int(bool(out_pool)),
-                  int(bool(out_d2s)))
+                  int(bool(out_d2s)), int(lstm_f), int(lstm_rec_act))
 
 
 def supports_out_pool(xs_chw, cd):
@@ -161,6 +161,43 @@ def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute
     _lib.check(fn(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(bias), _ptr(out), xs, ctypes.byref(cd), dt,
                   _stream(x)))
     return out
+
+
+def convlstm_conv_supported(xs_chw, cd, in_bf16, compute_bf16=False):
+    """Planner hint: can this convolution (cd.lstm_f set) carry the ConvLSTM2D cell update in its epilogue, given the storage
+    of its input (bfloat16, or float32 rounded by the loader)?"""
+    dt = _lib.dtype_io(_lib.BF16 if in_bf16 else _lib.F32, _lib.BF16, compute_bf16)
+    return bool(_lib.lib.dlwp_convlstm_conv_supported(_lib.handle_or_none(), Shape4(1, int(xs_chw[0]), int(xs_chw[1]), int(xs_chw[2])),
+                                                      ctypes.byref(cd), dt))
+
+
+def convlstm_conv(x, w_hwio, bias, cd, h_out, c_out, z_add=None, c_prev=None, x_channels=None, compute_bf16=False,
+                  prepared=None):
+    """One of the two convolutions of a ConvLSTM2D step with the cell update in its epilogue (dlwp_convlstm_conv_fwd):
+    z = conv(x) + bias (+ z_add) is not stored; writes c_out (float32 (n, F, ho, wo)) and channels [cd.out_c_off, +F) of
+    h_out.  z_add: bfloat16 (n, 4F, ho, wo) or None; c_prev: float32 or None."""
+    _check_f32(w_hwio, bias, c_out, c_prev)
+    n, c_total, h, w = x.shape
+    cin = int(x_channels) if x_channels is not None else c_total
+    f = int(cd.lstm_f)
+    if tuple(w_hwio.shape) != (cd.kh, cd.kw, cin, 4 * f):
+        raise ValueError('kernel shape %s does not match (kh,kw,cin,4F)=(%d,%d,%d,%d)' % (tuple(w_hwio.shape), cd.kh, cd.kw, cin, 4 * f))
+    if cd.in_c_total == 0 and cin != c_total:
+        cd.in_c_total = c_total
+    xs = Shape4(n, cin, h, w)
+    ys = conv_out_shape(xs, cd)
+    if tuple(c_out.shape) != (n, f, ys.h, ys.w) or tuple(h_out.shape[2:]) != (ys.h, ys.w) or h_out.shape[0] != n:
+        raise ValueError('convlstm_conv: c_out %s / h_out %s do not match (%d, %d, %d, %d)' %
+                         (tuple(c_out.shape), tuple(h_out.shape), n, f, ys.h, ys.w))
+    if z_add is not None and (z_add.dtype != torch.bfloat16 or tuple(z_add.shape) != (n, 4 * f, ys.h, ys.w)):
+        raise ValueError('convlstm_conv: z_add must be bfloat16 (n, 4F, ho, wo)')
+    if c_prev is not None and tuple(c_prev.shape) != tuple(c_out.shape):
+        raise ValueError('convlstm_conv: c_prev shape')
+    dt = _lib.dtype_io(storage_code(x), storage_code(h_out), compute_bf16)
+    _lib.check(_lib.lib.dlwp_convlstm_conv_fwd(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(prepared), _ptr(bias),
+                                               _ptr(z_add), _ptr(c_prev), _ptr(c_out), _ptr(h_out), xs, ctypes.byref(cd), dt,
+                                               _stream(x)))
+    return h_out
 
 
 def maxpool2(x, out=None):

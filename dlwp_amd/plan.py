@@ -83,6 +83,9 @@ class PlanOp(object):
         self.out_pool = kw.pop('out_pool', False)   # conv only: MaxPooling2D(2) applied in the epilogue (inference plans)
         self.out_d2s = kw.pop('out_d2s', False)     # conv only: the 4 F phase channels stored interleaved (inference plans)
         self.rec_act = kw.pop('rec_act', 0)
+        # conv with the ConvLSTM2D cell update in its epilogue (bfloat16 inference plans): lstm_f = F hidden channels, dst = the h
+        # buffer, aux = (z_add buffer | None, c_prev buffer | None, c_out buffer), act / rec_act = the cell's activations
+        self.lstm_f = kw.pop('lstm_f', 0)
         # conv restated on a low-resolution source (inference plans; build_plan): geometry that overrides the layer's
         self.dil = kw.pop('dil', None)            # dilation (dh, dw)
         self.ksize = kw.pop('ksize', None)        # kernel size (kh, kw)
@@ -108,6 +111,8 @@ class PlanOp(object):
                 self.layer.name, ks, dil, self.src_mode, tuple(self.halo),
                 self.act, self.in_c_off, self.xs[0], self.in_c_total, self.out_c_off, f,
                 self.out_c_total, ' +pool' if self.out_pool else '', ' phase-kernels' if self.wparam is not None else '')
+            if self.lstm_f:
+                extra += ' +cell-update F=%d aux%r rec%d' % (self.lstm_f, self.aux, self.rec_act)
         return '<%s %s -> %s xs=%s%s>' % (self.kind, self.src, self.dst, self.xs, extra)
 
 
@@ -172,11 +177,13 @@ class Plan(object):
             for b, role in ((op.src, 'r'), (op.dst, 'w')):
                 if b >= 0:
                     ok[b] = ok.get(b, True) and op.kind in ('conv', 'maxpool', 'lstm') and not (role == 'w' and op.out_d2s)
-            if op.kind == 'lstm':
+            if op.kind == 'lstm' or (op.kind == 'conv' and op.lstm_f):
                 zh, cp, co = op.aux
                 for b in (cp, co):                                                # the cell state stays float32
                     if b is not None and b >= 0:
                         ok[b] = False
+                if op.kind == 'conv' and zh is not None and zh >= 0:             # (read by this convolution's epilogue)
+                    ok[zh] = ok.get(zh, True)
         for op in self.ops:                                                       # zx and zh of a step: the same type
             if op.kind == 'lstm' and op.aux[0] is not None and op.src >= 0 and op.aux[0] >= 0:
                 both = ok.get(op.src, False) and ok.get(op.aux[0], False)
@@ -278,7 +285,18 @@ def _supports_out_d2s(xs, f4, ks, halo, act, in_c_off, in_c_total):
         return False
 
 
-def build_plan(inputs, outputs, inference=False, fuse_d2s=True):
+def _supports_lstm_conv(xs, part, halo, src_mode, act, rec_act, f, in_c_off, in_c_total, out_c_off, out_c_total, in_bf16):
+    """can this convolution of a ConvLSTM2D step carry the cell update in its epilogue (dlwp_convlstm_conv_fwd)?"""
+    try:
+        from . import ops
+        cd = ops.make_conv(4 * f, part.kernel_size[0], part.kernel_size[1], tuple(part.dilation_rate), ops.make_pad(*halo), act,
+                           in_c_off, in_c_total, out_c_off, out_c_total, src_mode, lstm_f=f, lstm_rec_act=rec_act)
+        return ops.convlstm_conv_supported(xs, cd, in_bf16, compute_bf16=not in_bf16)
+    except (ImportError, OSError, AttributeError):
+        return False
+
+
+def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False):
     """inputs: [KTensor] (exactly one), outputs: [KTensor].  Returns a Plan.  inference=True additionally moves a
     MaxPooling2D(2) that is the only consumer of a convolution into that convolution's epilogue (the pre-pooling tensor
     is never written; the training plan keeps it because the backward pass needs it)."""
@@ -443,11 +461,35 @@ def build_plan(inputs, outputs, inference=False, fuse_d2s=True):
             hbuf = plan.new_buffer(t_len * f, ho, wo)           # h_0 .. h_{T-1}, the return_sequences output
             # every step keeps its own pre-activations and cell state: they are the saved activations of the backward
             # pass (dlwp_convlstm_gates_bwd) -- T is the reference's time_dim (2), so this costs little
-            zxs = [plan.new_buffer(4 * f, ho, wo) for _ in range(t_len)]
-            zhs = [None] + [plan.new_buffer(4 * f, ho, wo) for _ in range(t_len - 1)]
             cbufs = [plan.new_buffer(f, ho, wo) for _ in range(t_len)]
             rk = ((lay.kernel_size[0] - 1) // 2, (lay.kernel_size[1] - 1) // 2)
-            for step in range(t_len):
+            rec_code = {'hard_sigmoid': 0, 'sigmoid': 1}[lay.recurrent_activation]
+            rhalo = Halo(rk[0], rk[0], rk[1], rk[1], PAD_ZERO, PAD_ZERO)
+            # bfloat16 inference: the convolution that completes a step's pre-activations applies the cell update in its
+            # epilogue (the input convolution on the first step, the recurrent one afterwards): z_h (z_x on the first step)
+            # is never stored and the gate kernel disappears.  The model input feeds the input convolution as float32.
+            fused = (inference and fuse_lstm and v.buf == STATE_IN and
+                     _supports_lstm_conv((cin, v.h, v.w), lay.input_part, halo, v.src_mode, ACT[lay.activation], rec_code, f,
+                                         v.c_off, v.c_total, 0, t_len * f, False) and
+                     (t_len == 1 or _supports_lstm_conv((f, ho, wo), lay.recurrent_part, rhalo, SRC_DIRECT, ACT[lay.activation],
+                                                        rec_code, f, 0, t_len * f, f, t_len * f, True)))
+            zxs = [None if (fused and step == 0) else plan.new_buffer(4 * f, ho, wo) for step in range(t_len)]
+            zhs = [None] + [None if fused else plan.new_buffer(4 * f, ho, wo) for _ in range(t_len - 1)]
+            for step in range(t_len if fused else 0):
+                if step == 0:
+                    emit(PlanOp('conv', v.buf, hbuf, (cin, v.h, v.w), layer=lay.input_part, halo=halo, src_mode=v.src_mode,
+                                act=ACT[lay.activation], rec_act=rec_code, lstm_f=f, aux=(None, None, cbufs[0]),
+                                in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0, out_c_total=t_len * f,
+                                out_shape=(f, ho, wo)))
+                    continue
+                emit(PlanOp('conv', v.buf, zxs[step], (cin, v.h, v.w), layer=lay.input_part, halo=halo,
+                            src_mode=v.src_mode, act=0, in_c_off=v.c_off + step * cin, in_c_total=v.c_total, out_c_off=0,
+                            out_c_total=4 * f, out_shape=(4 * f, ho, wo)))
+                emit(PlanOp('conv', hbuf, hbuf, (f, ho, wo), layer=lay.recurrent_part, halo=rhalo, src_mode=SRC_DIRECT,
+                            act=ACT[lay.activation], rec_act=rec_code, lstm_f=f, aux=(zxs[step], cbufs[step - 1], cbufs[step]),
+                            in_c_off=(step - 1) * f, in_c_total=t_len * f, out_c_off=step * f, out_c_total=t_len * f,
+                            out_shape=(f, ho, wo)))
+            for step in range(0 if fused else t_len):
                 emit(PlanOp('conv', v.buf, zxs[step], (cin, v.h, v.w), layer=lay.input_part, halo=halo,
                             src_mode=v.src_mode, act=0, in_c_off=v.c_off + step * cin, in_c_total=v.c_total, out_c_off=0,
                             out_c_total=4 * f, out_shape=(4 * f, ho, wo)))

@@ -87,6 +87,11 @@ typedef struct {
                                    * interleaved -- y is (n, out_c_total, 2 ho, 2 wo), channels [out_c_off, out_c_off + F) --
                                    * which is dlwp_depth_to_space2 without the pass (inference; ask
                                    * dlwp_conv2d_supports_out_d2s first; not with out_pool)                             */
+  int lstm_f, lstm_rec_act;       /* lstm_f = F > 0: this convolution completes the gate pre-activations of a ConvLSTM2D step
+                                   * (cout = 4 F, gates i f c o) and its epilogue applies the cell update of
+                                   * dlwp_convlstm_gates -- see dlwp_convlstm_conv_fwd, the only entry that takes such a
+                                   * descriptor; act = the cell activation, lstm_rec_act = 0 hard_sigmoid | 1 sigmoid; the
+                                   * output window (out_c_off, out_c_total) is that of h (F channels).  0: plain Conv2D     */
 } dlwp_conv2d;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
@@ -148,7 +153,9 @@ int dlwp_conv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const vo
 int dlwp_conv2d_num_configs(void);
 int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes);
 int dlwp_conv2d_config_flags(int i);        /* bit 0: Winograd instance whose 16-position case splits the positions over two
-                                              * waves per tile fragment (conv_fwd_wino2_kernel.h: 2 x waves x 64 threads) */
+                                              * waves per tile fragment (conv_fwd_wino2_kernel.h: 2 x waves x 64 threads);
+                                              * bit 1: bf16 instance with the ConvLSTM2D cell update in its epilogue
+                                              * (dlwp_conv2d.lstm_f; takes only such layers) */
 /* Host logic (no device work; handle nullable = default options): 1 when dlwp_conv2d_fwd(xs, cd, dtype) multiplies with
  * bf16-rounded weights (the bf16-MFMA family), else 0: what a caller comparing against an fp32-weight computation needs to
  * know. */
@@ -287,6 +294,18 @@ int dlwp_space_to_depth2(dlwp_handle_t, const void* src, void* dst, int n, int f
  *      act: DLWP_ACT_*; rec_act: 0 = hard_sigmoid (Keras default), 1 = sigmoid.  dtype: DLWP_F32, or
  *      DLWP_DTYPE_IO(z, h) = storage of the gate pre-activations zx / zh and of h (DLWP_F32 | DLWP_BF16 each); the cell
  *      state c and the arithmetic are float32.                                                                        */
+/* A ConvLSTM2D step with the cell update in the convolution's epilogue (bfloat16 inference, BASELINE config 4): the 4F gate
+ * pre-activations z = conv(x; w) + bias + z_add are NOT stored; the epilogue writes c_out (float32, (n, F, ho, wo)) and h_t
+ * (channels [cd->out_c_off, +F) of an out_c_total-channel buffer, storage DLWP_DTYPE_OUT(dtype)).  z_add: the other
+ * convolution's stored pre-activations, bfloat16 (n, 4F, ho, wo), or NULL (first step: no recurrent term); c_prev: float32
+ * (n, F, ho, wo) or NULL.  cd->lstm_f = F, cd->cout = 4F.  Runs on the bf16 matrix-core instances with 64-channel blocks
+ * (4 gates x 16 hidden channels per block): ask dlwp_convlstm_conv_supported first (needs wo % 4 == 0 and a layer the bf16
+ * family covers).  prepared: NULL, or the buffer dlwp_conv2d_prepare filled for (xs, cd, dtype).
+ * Replaces: one of the two convolutions of a step + dlwp_convlstm_gates (keras ConvLSTM2DCell.call).                      */
+int dlwp_convlstm_conv_fwd(dlwp_handle_t, const void* x, const void* w, const void* prepared, const void* bias,
+                           const void* z_add, const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs,
+                           const dlwp_conv2d* cd, int dtype, void* stream);
+int dlwp_convlstm_conv_supported(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
 int dlwp_convlstm_gates(dlwp_handle_t, const void* zx, const void* zh, const void* c_prev, void* c_out, void* h_out,
                         int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act, int dtype, void* stream);
 /* backward of the cell update (one step of back-propagation through time behind DLWPNeuralNet.fit on the recurrent
@@ -325,7 +344,9 @@ typedef struct {
                              * (n, F, h, w), aux = {zh | -1000, c_prev | -1000, c_out, rec_act + 256 * (h buffer stored as
                              * bfloat16) + 512 * (zx / zh stored as bfloat16)}, conv.act = activation.
                              * DLWP_OP_CONV2D / DLWP_OP_MAXPOOL2: aux[0] = storage dtype of this op's tensors (DLWP_F32,
-                             * DLWP_BF16 or DLWP_DTYPE_IO(in, out)); the rollout's own dtype describes state and series */
+                             * DLWP_BF16 or DLWP_DTYPE_IO(in, out)); the rollout's own dtype describes state and series.
+                             * DLWP_OP_CONV2D with conv.lstm_f > 0 (dlwp_convlstm_conv_fwd): dst = h buffer, aux[1..3] =
+                             * {z_add | -1000, c_prev | -1000, c_out}                                                  */
 } dlwp_op;
 #define DLWP_BUF_NONE (-1000)
 typedef struct dlwp_rollout* dlwp_rollout_t;

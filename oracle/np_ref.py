@@ -283,7 +283,8 @@ def zero_padding3d(x, padding, data_format='channels_first'):
 
 
 def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', activation='tanh',
-                recurrent_activation='hard_sigmoid', return_sequences=True, bf16_storage=False, bf16_kernels=()):
+                recurrent_activation='hard_sigmoid', return_sequences=True, bf16_storage=False, bf16_kernels=(),
+                fused_cell_update=False):
     """x: (N, T, C, H, W) channels_first, already padded for the 'valid' input convolution.  kernel (kh,kw,C,4F),
     recurrent_kernel (kh,kw,F,4F), bias (4F,); gate order i, f, c, o.  Per step (ConvLSTM2DCell.call):
         z  = conv(x_t, kernel, dilation, padding) + bias + conv(h_{t-1}, recurrent_kernel, 'same', no dilation)
@@ -291,7 +292,10 @@ def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', 
     with h_{-1} = c_{-1} = 0.  Returns (N, T, F, Ho, Wo) or the last h (N, F, Ho, Wo).
     The product's config-4 mode: bf16_storage -- the gate pre-activations conv(x_t) + bias and conv(h_{t-1}) and every h_t
     are rounded to bfloat16 when they are stored (c_t and the gate arithmetic stay float32); bf16_kernels -- which of the
-    two convolutions ('kernel', 'recurrent') run on the bf16 matrix cores: their kernel and input are rounded to bf16."""
+    two convolutions ('kernel', 'recurrent') run on the bf16 matrix cores: their kernel and input are rounded to bf16;
+    fused_cell_update -- the convolution that completes a step's pre-activations (the input convolution on the first step,
+    the recurrent one afterwards) applies the cell update in its epilogue (dlwp_convlstm_conv_fwd): ITS pre-activations are
+    never stored, hence not rounded; the other convolution's (the input convolution's from the second step on) are."""
     x = np.asarray(x, dtype=np.float64)
     if 'kernel' in bf16_kernels:
         kernel, x = round_bf16(kernel), round_bf16(x)
@@ -310,11 +314,14 @@ def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', 
         if padding == 'same':
             ph, pw = dilation * (kh - 1), dilation * (kw - 1)
             xt = np.pad(xt, ((0, 0), (0, 0), (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)))
-        z = rnd(conv2d(xt, kernel, bias, dilation, 'linear'))
+        z = conv2d(xt, kernel, bias, dilation, 'linear')
+        if not (fused_cell_update and h is None):
+            z = rnd(z)
         if h is not None:
             hp = np.pad(h, ((0, 0), (0, 0), ((rkh - 1) // 2, rkh - 1 - (rkh - 1) // 2),
                             ((rkw - 1) // 2, rkw - 1 - (rkw - 1) // 2)))
-            z = z + rnd(conv2d(hp, recurrent_kernel, None, 1, 'linear'))
+            zh = conv2d(hp, recurrent_kernel, None, 1, 'linear')
+            z = z + (zh if fused_cell_update else rnd(zh))
         zi, zf, zc, zo = z[:, :f], z[:, f:2 * f], z[:, 2 * f:3 * f], z[:, 3 * f:]
         c_new = rec(zi) * activate(zc, activation)
         if c is not None:
@@ -413,7 +420,7 @@ def round_bf16(a):
     return np.where(np.isnan(f), np.nan, out)
 
 
-def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_weights=(), bf16_lstm=None):
+def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_weights=(), bf16_lstm=None, lstm_fused=False):
     """Execute a sequential stack exactly as the reference graph is laid out (one op per layer, unfused).
     bf16_activations: every Conv2D output except the model output is rounded to bfloat16 (the product's config-4 storage);
     bf16_weights: indices (among the weighted layers) of the Conv2D layers whose kernel is rounded to bfloat16 as well
@@ -455,7 +462,7 @@ def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_wei
             wi += 1
             x = conv_lstm2d(x, k, r, b, dil, kwargs.get('padding', 'valid'), act or 'tanh',
                             kwargs.get('recurrent_activation', 'hard_sigmoid'), kwargs.get('return_sequences', False),
-                            bf16_storage=bf16_lstm is not None, bf16_kernels=bf16_lstm or ())
+                            bf16_storage=bf16_lstm is not None, bf16_kernels=bf16_lstm or (), fused_cell_update=lstm_fused)
         elif name == 'MaxPooling2D':
             x = maxpool2(x)
         elif name == 'UpSampling2D':

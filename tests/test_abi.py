@@ -29,7 +29,7 @@ def test_struct_layouts_match_the_header():
     # sizes implied by include/dlwp_hip.h (all-int structs, no padding)
     assert ctypes.sizeof(_lib.Shape4) == 16
     assert ctypes.sizeof(_lib.Pad2d) == 24
-    assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 8 * 4      # ... src_mode, out_pool, out_d2s
+    assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 10 * 4     # ... src_mode, out_pool, out_d2s, lstm_f, lstm_rec_act
     assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24 + 4 * 4   # + aux[4]
 
 

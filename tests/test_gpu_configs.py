@@ -112,7 +112,10 @@ def test_cfg4_recurrent_stack_at_180x360_float32_and_bfloat16():
     on16 = _bf16_weight_indices(d.model, 1)
     parts = _bf16_lstm_parts(d.model, 1)
     got16 = d.predict(x[:1])
-    want16 = np_ref.run_layers(layers, x[:1], weights, bf16_activations=True, bf16_weights=on16, bf16_lstm=parts)
+    fused = any(op.kind == 'conv' and op.lstm_f for op in d.model.infer_plan.ops)   # cell update in the convolutions' epilogues
+    assert fused
+    want16 = np_ref.run_layers(layers, x[:1], weights, bf16_activations=True, bf16_weights=on16, bf16_lstm=parts,
+                               lstm_fused=fused)
     assert _rel(got16, want16) < 1e-2
     assert float(np.abs(got16 - want16).mean()) < 1e-3 * max(1.0, float(np.abs(want16).max()))
     # and the rollout graph replays exactly that forward

@@ -353,6 +353,72 @@ def test_winograd_phase_channels_stored_interleaved(ops, fields, hw):
     assert not ops.supports_out_d2s((cin, h, w), ops.make_conv(16, 5, 5, 1, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH))
 
 
+@pytest.mark.parametrize('f,hw,first', [(24, (20, 72), True), (24, (20, 72), False), (16, (16, 24), False), (40, (9, 44), False)])
+def test_convlstm_cell_update_in_the_convolution_epilogue(ops, f, hw, first):
+    """dlwp_convlstm_conv_fwd (bfloat16 inference): the convolution that completes a step's gate pre-activations applies the
+    cell update in its epilogue.  Against the float64 oracle with the product's roundings (bf16 input / kernel / stored z_add,
+    float32 cell state) and against the unfused sequence conv -> bf16 z -> dlwp_convlstm_gates (which rounds z once more)."""
+    rng = np.random.default_rng(99)
+    n = 3
+    h, w = hw
+    if first:       # input convolution: float32 model input rounded by the loader, dilation 2, periodic + zero halo
+        cin, dil, halo = 6, 2, (2, 2, 2, 2, 0, 1)
+        x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+        xq = np_ref.round_bf16(host(x))
+    else:           # recurrent convolution: bf16 h, 'same' zero halo
+        cin, dil, halo = f, 1, (1, 1, 1, 1, 0, 0)
+        xq = np_ref.round_bf16(rng.standard_normal((n, cin, h, w)))
+        x = dev(xq.astype(np.float32)).to(torch.bfloat16)
+    wt = np_ref.glorot_uniform((3, 3, cin, 4 * f), rng)
+    b = (0.1 * rng.standard_normal(4 * f)).astype(np.float32)
+    b[f:2 * f] += 1.0
+    zadd = None if first else np_ref.round_bf16(0.5 * rng.standard_normal((n, 4 * f, h, w)))
+    cprev = None if first else rng.standard_normal((n, f, h, w)).astype(np.float32)
+    cd = ops.make_conv(4 * f, 3, 3, dil, ops.make_pad(*halo), ops.ACT_TANH, out_c_off=f, out_c_total=3 * f, lstm_f=f)
+    assert ops.convlstm_conv_supported((cin, h, w), cd, in_bf16=not first, compute_bf16=first)
+    h_out = torch.full((n, 3 * f, h, w), 7.0, device='cuda').to(torch.bfloat16)
+    c_out = torch.empty((n, f, h, w), device='cuda')
+    ops.convlstm_conv(x, dev(wt), dev(b), cd, h_out, c_out, z_add=dev(zadd.astype(np.float32)).to(torch.bfloat16) if zadd is not None else None,
+                      c_prev=dev(cprev) if cprev is not None else None, compute_bf16=first)
+    # oracle: exact products of bf16 values, float accumulation
+    z = _conv_ref(xq, np_ref.round_bf16(wt), b, dil, halo[:4], halo[4], halo[5], 'linear', 0)
+    if zadd is not None:
+        z = z + zadd
+    zi, zf, zc, zo = z[:, :f], z[:, f:2 * f], z[:, 2 * f:3 * f], z[:, 3 * f:]
+    c_want = np_ref.hard_sigmoid(zi) * np.tanh(zc) + (np_ref.hard_sigmoid(zf) * cprev if cprev is not None else 0.0)
+    h_want = np_ref.hard_sigmoid(zo) * np.tanh(c_want)
+    assert np.abs(host(c_out) - c_want).max() < 2e-5 * max(1.0, np.abs(c_want).max())
+    got_h = host(h_out.float())
+    assert np.abs(got_h[:, f:2 * f] - h_want).max() < 4.1e-3          # one bf16 ulp of values below 1
+    assert np.all(got_h[:, :f] == 7.0) and np.all(got_h[:, 2 * f:] == 7.0)   # the window only
+    # unfused: conv -> bf16 z -> gate kernel
+    plain = ops.make_conv(4 * f, 3, 3, dil, ops.make_pad(*halo), ops.ACT_LINEAR)
+    zx = ops.conv2d(x, dev(wt), dev(b), plain, out=torch.empty((n, 4 * f, h, w), device='cuda', dtype=torch.bfloat16), compute_bf16=first)
+    h2 = torch.zeros((n, 3 * f, h, w), device='cuda', dtype=torch.bfloat16)
+    c2 = torch.empty_like(c_out)
+    ops.convlstm_gates(zx, dev(zadd.astype(np.float32)).to(torch.bfloat16) if zadd is not None else None,
+                       dev(cprev) if cprev is not None else None, c2, h2, f, h_c_off=f, act=ops.ACT_TANH, rec_act=0)
+    assert np.abs(host(c2) - host(c_out)).max() < 2e-2 and np.abs(host(h2.float())[:, f:2 * f] - got_h[:, f:2 * f]).max() < 2e-2
+    # every compiled cell-update instance of this geometry (tile shape, channel chunk): same result up to summation order
+    tried = 0
+    try:
+        for i, c in enumerate(ops.conv_configs()):
+            if not (c[10] & 2 and c[1] == dil and (c[8] == 3) == first):
+                continue
+            ops.force_conv_config(i)
+            h3, c3 = torch.zeros_like(h_out), torch.empty_like(c_out)
+            ops.convlstm_conv(x, dev(wt), dev(b), cd, h3, c3, z_add=dev(zadd.astype(np.float32)).to(torch.bfloat16) if zadd is not None else None,
+                              c_prev=dev(cprev) if cprev is not None else None, compute_bf16=first)
+            assert np.abs(host(c3) - c_want).max() < 2e-5 * max(1.0, np.abs(c_want).max()), 'config %d %r' % (i, c)
+            assert np.abs(host(h3.float())[:, f:2 * f] - h_want).max() < 4.1e-3, 'config %d %r' % (i, c)
+            tried += 1
+    finally:
+        ops.force_conv_config(-1)
+    assert tried >= 2
+    # widths that are not a multiple of 4 keep the separate gate kernel
+    assert not ops.convlstm_conv_supported((cin, h, w + 2), cd, in_bf16=not first, compute_bf16=first)
+
+
 def test_winograd_wide_plus_narrow_launch_is_bit_identical(ops):
     """A 22x45 map at a batch that fills the chip: the 32 whole columns go to the 8x32 instance, the last 13 to the 16-wide
     one in a second launch.  Same bits as the single forced instance; plain, pooled-epilogue and up-sampled launches."""
@@ -712,7 +778,7 @@ def test_conv2d_bf16_mfma_every_compiled_tile_configuration(ops):
     seen = 0
     try:
         for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds, flags) in enumerate(cfgs):
-            if pool < 2:
+            if pool < 2 or flags & 2:                         # (bit 1: cell-update instances, test_convlstm_cell_update_...)
                 continue
             seen += 1
             in32 = pool == 3                                  # float32-stored input, rounded by the loader

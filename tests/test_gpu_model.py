@@ -1105,19 +1105,36 @@ def test_bfloat16_storage_with_the_recurrent_front_end():
     x = rng.standard_normal((3,) + cs).astype(np.float32)
     d.model.set_activation_dtype('bfloat16')
     kinds = {i: b.dtype for i, b in enumerate(d.model.executor.scratch(3))}
-    # gate pre-activations and cell state float32; the h sequence and the convolution stack bfloat16
+    # cell state float32; the h sequence, the stored gate pre-activations and the convolution stack bfloat16.  The cell
+    # update rides in the epilogue of the convolution that completes a step's pre-activations (dlwp_convlstm_conv_fwd):
+    # input convolution on the first step, recurrent convolution on the second -- no gate kernel, one stored z tensor
     plan = d.model.infer_plan
-    h_buf = [op.dst for op in plan.ops if op.kind == 'lstm'][0]
-    c_bufs = [op.aux[2] for op in plan.ops if op.kind == 'lstm']
-    z_bufs = [op.src for op in plan.ops if op.kind == 'lstm']
+    fused = [op for op in plan.ops if op.kind == 'conv' and op.lstm_f]
+    assert [op.kind for op in plan.ops][:3] == ['conv', 'conv', 'conv'] and len(fused) == 2 and fused[0].aux[:2] == (None, None)
+    assert not any(op.kind == 'lstm' for op in plan.ops)
+    h_buf, c_bufs, z_bufs = fused[0].dst, [op.aux[2] for op in fused], [fused[1].aux[0]]
+    assert fused[1].dst == h_buf and fused[1].src == h_buf and fused[1].aux[1] == c_bufs[0]
     assert kinds[h_buf] == torch.bfloat16 and all(kinds[b] == torch.float32 for b in c_bufs)
     assert all(kinds[b] == torch.bfloat16 for b in z_bufs)
     on16 = _bf16_weight_indices(d.model, 3)
     parts = _bf16_lstm_parts(d.model, 3)
     assert 1 in on16 and set(parts) == {'kernel', 'recurrent'}   # both ConvLSTM convolutions and the first Conv2D
     got = d.predict(x)
-    want = np_ref.run_layers(layers, x, weights, bf16_activations=True, bf16_weights=on16, bf16_lstm=parts)
+    want = np_ref.run_layers(layers, x, weights, bf16_activations=True, bf16_weights=on16, bf16_lstm=parts, lstm_fused=True)
     assert _rel(got, want) < 4e-3
+    # ... and the separate gate kernel (DLWP_LSTM_FUSE=0: the plan of the float32 mode, stored and rounded z_x, z_h) agrees
+    # with it to the rounding of those tensors
+    import os
+    os.environ['DLWP_LSTM_FUSE'] = '0'
+    try:
+        d.model.set_activation_dtype('float32').set_activation_dtype('bfloat16')
+        assert any(op.kind == 'lstm' for op in d.model.infer_plan.ops)
+        unfused = d.predict(x)
+        assert _rel(unfused, np_ref.run_layers(layers, x, weights, bf16_activations=True, bf16_weights=on16, bf16_lstm=parts)) < 4e-3
+        assert _rel(unfused, got) < 8e-3
+    finally:
+        del os.environ['DLWP_LSTM_FUSE']
+        d.model.set_activation_dtype('float32').set_activation_dtype('bfloat16')
     # rollout graph == eager forward, bit for bit, with the bf16 h sequence too
     series = d.predict_timeseries(x, 2, keep_time_dim=True)
     assert np.array_equal(np.asarray(series)[0].reshape(got.shape), got)

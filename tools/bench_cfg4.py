@@ -62,7 +62,13 @@ def main():
     rows = []
     for op, desc in zip(plan.ops, ex._descriptors()):
         src, dst = res(op.src), res(op.dst)
-        if op.kind == 'conv':
+        if op.kind == 'conv' and op.lstm_f:                          # cell update in the convolution's epilogue
+            c16 = op.dst in ex._bf16 and op.src not in ex._bf16
+            kern, bias = ex.conv_weights(op)
+            za, cp, co = op.aux
+            fn = lambda: ops.convlstm_conv(src, kern, bias, desc, dst, res(co), z_add=res(za) if za is not None else None,  # noqa: E731
+                                           c_prev=res(cp) if cp is not None else None, x_channels=op.xs[0], compute_bf16=c16)
+        elif op.kind == 'conv':
             c16 = op.dst in ex._bf16 and op.src not in ex._bf16      # as Executor.run: float32 state rounded by the loader
             kern, bias = ex.conv_weights(op)
             fn = lambda: ops.conv2d(src, kern, bias, desc, out=dst, x_channels=op.xs[0],  # noqa: E731
@@ -100,6 +106,13 @@ def main():
             peak = MFMA_BF16_PEAK if on16 else MFMA_F32_PEAK
             nb = float(src.element_size()) * a.members * op.xs[0] * op.xs[1] * op.xs[2] + \
                 float(dst.element_size()) * a.members * int(np.prod(op.out_shape))
+            if op.lstm_f:      # + the stored pre-activations it reads (bf16), c_prev in, c out (float32)
+                za, cp, co = op.aux
+                hw_ = op.out_shape[1] * op.out_shape[2]
+                nb += a.members * hw_ * op.lstm_f * ((8.0 if za is not None else 0.0) + (4.0 if cp is not None else 0.0) + 4.0)
+                row['cell_update'] = 'in the epilogue (dlwp_convlstm_conv_fwd)'
+                co_ = 4 * op.lstm_f
+                fl = 2.0 * ho * wo * co_ * op.xs[0] * kh * kw * a.members
             row.update(layer=op.layer.name, cin=op.xs[0], cout=co_, k=kh, algorithmic_tflops=round(fl / ms / 1e9, 1),
                        executed_tflops=round(ex_fl / ms / 1e9, 1), family='bf16 mfma' if on16 else 'fp32 mfma',
                        frac_of_matrix_peak=round(ex_fl / ms / 1e9 / peak, 3), matrix_peak_tflops=peak,

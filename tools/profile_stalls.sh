@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"
+CMD=${STALL_CMD:-"python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"}
 (rocprofv3 --list-avail 2>/dev/null || rocprofv3-avail list 2>/dev/null) | grep -o "SQ_[A-Z0-9_]*" | sort -u > $OUT/${TAG}_sq_counters.txt
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
