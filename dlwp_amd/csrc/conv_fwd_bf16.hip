@@ -29,6 +29,8 @@ static const ConvKernelEntry k_table[] = {
     // 4 x 64 tiles: 8-11 % faster than 8 x 32 on the dilation-1 layers whose width they tile well (a tile row of bf16
     // output is then a whole 128-byte line); slower with dilation 2 (measured, profiles/r1i_bf16_conv_layers_*)
     BF16_ENTRY(3, 1, 4, 64, 4, 4, 2, 32),
+    // (r2: 4 x 32 tiles with two fragments per wave -- 80-110 registers, more waves per SIMD -- were measured on every layer of
+    //  config 4, tools/bench_bf16_conv.py: 3-20 % slower than these; only the cell-update instances above gain from them)
 };
 const ConvKernelEntry* dlwp_conv_table_bf16(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));

@@ -72,7 +72,7 @@ def main():
         ops.set_bf16_mfma(True)
         row['bf16 heuristic'] = timed(lambda: ops.conv2d(x, wt, b, cd, out=out, compute_bf16=f32in), a.iters)
         for i, c in enumerate(cfgs):
-            if c[8] != (3 if f32in else 2) or (c[0], c[1]) != (k, dil):
+            if c[8] != (3 if f32in else 2) or (c[0], c[1]) != (k, dil) or c[10] & 2:     # (bit 1: cell-update instances)
                 continue
             ops.force_conv_config(i)
             try:
