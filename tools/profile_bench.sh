@@ -10,6 +10,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# One member chain for the profiled rollout: with the default two chains (Executor.member_groups) the graph's kernels run on
+# half the members each and two at a time, so their traced durations and per-dispatch counters are not those of the
+# 256-member launches bench.py prices in its roofline record.
+export DLWP_ROLLOUT_GROUPS=1
 CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $CMD > $OUT/${TAG}_stats_bench.json 2> $OUT/stats.err
 cp $OUT/stats/s_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null

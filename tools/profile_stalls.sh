@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export DLWP_ROLLOUT_GROUPS=1   # (as tools/profile_bench.sh: 256-member launches, one at a time)
 CMD=${STALL_CMD:-"python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"}
 (rocprofv3 --list-avail 2>/dev/null || rocprofv3-avail list 2>/dev/null) | grep -o "SQ_[A-Z0-9_]*" | sort -u > $OUT/${TAG}_sq_counters.txt
 i=0
