@@ -1,6 +1,7 @@
 // conv_fwd.hip -- Conv2D forward: argument validation, tile-configuration choice, launch; plus the direct
 // (one thread per output) vector-ALU kernel that covers every kernel size and serves as an in-library cross-check.
 // Reference call sites: examples/train.py:164-169 ... 214-219, Azure/train_tf.py:213-268.
+#include <cstdlib>
 #include "conv_fwd_kernel.h"
 #include <mutex>
 #include <vector>
@@ -464,6 +465,7 @@ struct LaunchPlan {
   long long grid = 0;
   int n_tiles_h = 0, n_cout_tiles = 0, col0 = 0;   // the narrow launch
   long long n_grid = 0;
+  int pair_vw = 0;                                   // > 0: sample pairs side by side, virtual sample width (no narrow launch)
 };
 
 // Matrix-core work of `grid` workgroups of instance e on layer a: the padded GEMM volume the MFMA instructions actually
@@ -506,8 +508,25 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
   // whole column tiles go to this instance, the rest to a 16-wide two-wave instance in a second launch (every Winograd
   // instance reads the same prepared filters and gives the same bits).  Only when the launches fill the chip more than
   // twice over -- at small batches a second launch costs more than the idle lanes.
-  if (forced < 0 && is_wino(e) && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3 &&
-      (long long)a.N * lp->tiles_h * (a.Wo / 32) * lp->cout_tiles >= 4ll * h->cu_count) {
+  // ... or, better, two samples side by side (float32 out, plain source, dilation 1, an even batch): on a 22x45 map a sample
+  // pair is a virtual row of 2 x 48 = 3 x 32 columns -- the gap of 3 holds the halos -- and everything runs on the wide
+  // instance (the narrow launch's two-wave blocks reach 1.2 waves per SIMD: two 16 KB filter buffers per block).
+  static const bool pairs_enabled = !(getenv("DLWP_WINO_PAIRS") && atoi(getenv("DLWP_WINO_PAIRS")) == 0);   // (A/B switch)
+  const bool ragged_w = is_wino(e) && !e.split && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3 &&
+                        (long long)a.N * lp->tiles_h * (a.Wo / 32) * lp->cout_tiles >= 4ll * h->cu_count;
+  if (forced < 0 && ragged_w && e.dil == 1 && cd->src_mode == DLWP_SRC_DIRECT && !cd->out_pool && !cd->out_d2s && !a.out_bf16 &&
+      a.N % 2 == 0 && a.Cin % e.ck == 0 && a.Cout % (16 * e.bnf) == 0 && a.Wo == a.W && !wino_skips_row2(a) && pairs_enabled) {
+    const int vw = dlwp_ceil_div(a.W + cd->halo.left + cd->halo.right, 16) * 16;
+    // byte offsets inside a sample PAIR stay 32-bit
+    if ((2 * vw) % 32 == 0 && vw - a.W >= cd->halo.left + cd->halo.right &&
+        (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 28) && (long long)a.Ho * a.Wo * a.out_c_total < (1ll << 28)) {
+      lp->pair_vw = vw;
+      lp->tiles_w = 2 * vw / 32;
+      lp->grid = (long long)lp->tiles_h * lp->tiles_w * lp->cout_tiles * (a.N / 2);
+      return DLWP_OK;
+    }
+  }
+  if (forced < 0 && ragged_w) {
     for (int i = 0; i < (int)r.entries.size() && lp->narrow < 0; ++i) {
       const ConvKernelEntry& p = r.entries[i];
       if (is_wino(p) && p.dil == e.dil && p.tw == 16 && p.th == 8 && p.bnf == e.bnf && (!cd->out_pool || p.out_pool))
@@ -575,6 +594,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   a.tiles_w = lp.tiles_w;
   a.cout_tiles = lp.cout_tiles;
   a.col0 = 0;
+  a.pair_vw = lp.pair_vw;
   DLWP_CHECK_ARG(lp.grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
   if (e.pack != 0) {  // Winograd / packed-N: prepared weights (into the handle's scratch unless the caller built them)
     if (u_pre) {

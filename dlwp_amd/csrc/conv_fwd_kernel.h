@@ -40,6 +40,8 @@ struct ConvArgs {
   int compute_bf16;       // DLWP_COMPUTE_BF16: a float32-stored input may be rounded to bf16 for the bf16 matrix cores
   int col0 = 0;           // Winograd: first output column of this launch (a wide-tile launch + a narrow one for the rest)
   int out_d2s = 0;        // the 4 F output channels are 2x2 phases: stored interleaved, y = (N, out_c_total, 2 Ho, 2 Wo)
+  int pair_vw = 0;        // Winograd, narrow maps: two samples side by side in a VIRTUAL row of 2 pair_vw columns (sample k at
+                          // [k pair_vw, k pair_vw + W)); the grid then counts sample PAIRS (conv_fwd_wino_kernel.h)
   // ConvLSTM2D cell update in the epilogue (bf16 matrix-core instances with 64-channel blocks, conv_fwd_bf16_kernel.h):
   // Cout = 4 lstm_f gate pre-activations z = conv + bias (+ zadd) are never stored; y = the h buffer (channel window
   // out_c_off / out_c_total), c_prev / c_out the float32 cell state.  0: plain convolution.

@@ -118,15 +118,32 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     if (q == C::NPOS - 1 && s >= C::LR * C::LC) s = 0;
     const int lr = s / C::LC, lc = s - lr * C::LC;
     const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
-    const int cs = dlwp_map_coord_tile(j0 + lc - a.pad_left, a.W, a.mode_w);
+    int vc = j0 + lc - a.pad_left, img = 0;
+    if (a.pair_vw) {
+      // Two samples side by side (a.pair_vw): virtual column vc -> sample k = floor(vc / VW), column c = vc - k VW.  The gap
+      // VW - W between the samples holds sample k's right halo (c = W ...: through the halo map, like any column past the
+      // edge) and, in its last pad_left columns, sample k + 1's LEFT halo (c - VW = -pad_left ... -1); what lies between
+      // feeds only outputs that are not stored.  The host guarantees VW - W >= left + right halo.
+      const int t = vc + a.pair_vw;                    // >= 0
+      img = t / a.pair_vw - 1;
+      vc = t - (img + 1) * a.pair_vw;
+      if (vc >= a.pair_vw - a.pad_left) {
+        vc -= a.pair_vw;
+        ++img;
+      }
+      if ((unsigned)img > 1u) vc = -a.W - 1;           // no such sample: zero (only unstored outputs read it)
+    }
+    const int cs = (vc < -a.W) ? -1 : dlwp_map_coord_tile(vc, a.W, a.mode_w);
     const bool ok = rs >= 0 && cs >= 0;
     const int g = (a.src_mode == DLWP_SRC_UPSAMPLE2) ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
-    goff[q] = ok ? (unsigned)g * (C::IN16 ? 2u : 4u) : 0x7ffffff0u;
+    goff[q] = ok ? (unsigned)g * (C::IN16 ? 2u : 4u) + (unsigned)img * ((unsigned)a.in_c_total * (unsigned)(a.Hs * a.Ws) * (C::IN16 ? 2u : 4u))
+                 : 0x7ffffff0u;
     loff[q] = (((lr % C::DIL) * C::DIL + lc % C::DIL) * C::LRP + lr / C::DIL) * C::LCP + lc / C::DIL;
   }
   const long long plane = (long long)a.Hs * a.Ws;
   constexpr int ESZ = C::IN16 ? 2 : 4;
-  const char* xn = (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * ESZ;
+  const int n_s = a.pair_vw ? 2 * n : n;          // first (only) sample of this block
+  const char* xn = (const char*)a.x + ((long long)n_s * a.in_c_total + a.in_c_off) * plane * ESZ;
   const unsigned plane_bytes = (unsigned)plane * ESZ;
 
   // ---- this lane's tile (= its MFMA A-operand row) and the LDS offset of the tile's 4x4 patch origin, channel l>>4
@@ -171,8 +188,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   // this loop runs out of.  The zero halo's lane offset (0x7ffffff0) is beyond num_records whatever the channel, and a
   // valid lane offset + channel offset stays inside it, so the result does not depend on whether the hardware's range
   // check includes the scalar offset.
-  const __amdgpu_buffer_rsrc_t x_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)a.Cin * plane_bytes, 0x00020000);
+  // (a sample pair: the window reaches over the second sample's channels; Cin is then a whole number of chunks -- host)
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)xn, 0, (unsigned)a.Cin * plane_bytes + (a.pair_vw ? (unsigned)a.in_c_total * plane_bytes : 0u), 0x00020000);
   // (Measured, r2p: the loads the last two chunks issue have no chunk of this tile left to fetch; aiming them at chunks 0 / 1
   // of the tile that the NEXT workgroup of this XCD slot will start with -- an L2 prefetch at no instruction cost -- changed
   // nothing, 401.9 vs 403.1 k steps/s: the prologue does not wait for memory.  They stay clamped re-reads.)
@@ -540,11 +558,17 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     constexpr int CS = 4 * C::NT / PL;
     const int e0 = tid * 4, cb = e0 / PL, rem = e0 - cb * PL;
     const int row = rem / C::TW, colx = rem - row * C::TW;
-    const int oh = i0 + row, ow = j0 + colx;
+    const int oh = i0 + row;
+    int ow = j0 + colx, img = 0;
+    if (a.pair_vw) {            // virtual column -> (sample of the pair, column); a quad never straddles two samples
+      img = ow >= a.pair_vw ? 1 : 0;
+      ow -= img * a.pair_vw;
+    }
     const unsigned plane_b = (unsigned)(a.Ho * a.Wo) * 4u;
-    float* yb = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)C::BN * plane_b, 0x00020000);
-    const unsigned pix = (unsigned)(oh * a.Wo + ow) * 4u + (unsigned)cb * plane_b;
+    float* yb = a.y + ((long long)n_s * a.out_c_total + a.out_c_off + n0) * a.Ho * a.Wo;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)yb, 0, (unsigned)C::BN * plane_b + (a.pair_vw ? (unsigned)a.out_c_total * plane_b : 0u), 0x00020000);
+    const unsigned pix = (unsigned)(oh * a.Wo + ow) * 4u + (unsigned)cb * plane_b + (unsigned)img * (unsigned)a.out_c_total * plane_b;
     const bool rok = oh < a.Ho;
     const unsigned voff_q = (rok && ow + 3 < a.Wo) ? pix : DROP;
     const float* lp = lds + cb * C::OPS + rem;
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     for (int k = 0; k < NOUT; ++k)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)(lp + k * CS * C::OPS)), y_rsrc, voff_q,
                                              (unsigned)(k * CS) * plane_b, 0);
-    if ((j0 + C::TW > a.Wo) && (a.Wo & 3)) {   // (uniform) the map's right edge cuts a quad: element stores there
+    if ((a.pair_vw || j0 + C::TW > a.Wo) && (a.Wo & 3)) {   // (uniform) a map's right edge cuts a quad: element stores there
       const bool edge = rok && ow < a.Wo && ow + 3 >= a.Wo;
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) {

@@ -439,10 +439,30 @@ def test_winograd_wide_plus_narrow_launch_is_bit_identical(ops):
         finally:
             ops.force_conv_config(-1)
         assert torch.equal(got, want), (src, hw, pool)
-        ref = _conv_ref(host(x[:1]), host(wt), host(b), 1, (1, 1, 1, 1), 0, 1, 'tanh', src)
+        ref = _conv_ref(host(x[:2]), host(wt), host(b), 1, (1, 1, 1, 1), 0, 1, 'tanh', src)
         if pool:
             ref = np_ref.maxpool2(ref)
-        _check_conv(ops, host(got[:1]), ref)
+        _check_conv(ops, host(got[:2]), ref)
+    # float32, plain source, even batch on a 22x45 map: SAMPLE PAIRS side by side (a virtual row of 2 x 48 = 3 x 32 columns,
+    # the gap holds the halos) on the wide instance -- the case above; here with channel windows on both sides, a zero
+    # column halo, and an odd batch (which keeps the wide + narrow launches): always the bits of the single instance
+    for n, mode_w in ((96, 1), (96, 0), (95, 1)):
+        cin, cout, hw = 16, 64, (22, 45)
+        xw = dev(rng.standard_normal((n, cin + 5) + hw).astype(np.float32))
+        wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+        b = dev((0.1 * rng.standard_normal(cout)).astype(np.float32))
+        cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, mode_w), ops.ACT_TANH, in_c_off=3, in_c_total=cin + 5,
+                           out_c_off=2, out_c_total=cout + 7)
+        got = ops.conv2d(xw, wt, b, cd, out=torch.full((n, cout + 7) + hw, 5.0, device='cuda'), x_channels=cin)
+        ops.force_conv_config(wide[0])
+        try:
+            want = ops.conv2d(xw, wt, b, cd, out=torch.full((n, cout + 7) + hw, 5.0, device='cuda'), x_channels=cin)
+        finally:
+            ops.force_conv_config(-1)
+        assert torch.equal(got, want), (n, mode_w)
+        ref = _conv_ref(host(xw[-3:, 3:3 + cin]), host(wt), host(b), 1, (1, 1, 1, 1), 0, mode_w, 'tanh', 0)
+        _check_conv(ops, host(got[-3:, 2:2 + cout]), ref)
+        assert bool((got[:, :2] == 5.0).all()) and bool((got[:, 2 + cout:] == 5.0).all())
 
 
 @pytest.mark.parametrize('cin', [5, 6, 7, 13, 22, 30])
