@@ -512,9 +512,10 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
   // pair is a virtual row of 2 x 48 = 3 x 32 columns -- the gap of 3 holds the halos -- and everything runs on the wide
   // instance (the narrow launch's two-wave blocks reach 1.2 waves per SIMD: two 16 KB filter buffers per block).
   static const bool pairs_enabled = !(getenv("DLWP_WINO_PAIRS") && atoi(getenv("DLWP_WINO_PAIRS")) == 0);   // (A/B switch)
-  const bool ragged_w = is_wino(e) && !e.split && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3 &&
-                        (long long)a.N * lp->tiles_h * (a.Wo / 32) * lp->cout_tiles >= 4ll * h->cu_count;
-  if (forced < 0 && ragged_w && e.dil == 1 && cd->src_mode == DLWP_SRC_DIRECT && !cd->out_pool && !cd->out_d2s && !a.out_bf16 &&
+  const bool ragged = is_wino(e) && !e.split && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3;
+  const bool ragged_w = ragged && (long long)a.N * lp->tiles_h * (a.Wo / 32) * lp->cout_tiles >= 4ll * h->cu_count;
+  // (pairs cost no second launch and run 3 column tiles per pair instead of 2 per sample: at every batch size)
+  if (forced < 0 && ragged && e.dil == 1 && cd->src_mode == DLWP_SRC_DIRECT && !cd->out_pool && !cd->out_d2s && !a.out_bf16 &&
       a.N % 2 == 0 && a.Cin % e.ck == 0 && a.Cout % (16 * e.bnf) == 0 && a.Wo == a.W && !wino_skips_row2(a) && pairs_enabled) {
     const int vw = dlwp_ceil_div(a.W + cd->halo.left + cd->halo.right, 16) * 16;
     // byte offsets inside a sample PAIR stay 32-bit
