@@ -30,6 +30,8 @@ const WgradKernelEntry k_wgrad[] = {
     WGRAD_ENTRY_C(3, 2, 8, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 2, 4, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 2, 8, 32, 2, 2, 8),
     WGRAD_ENTRY_C(3, 1, 8, 32, 2, 2, 4), WGRAD_ENTRY_C(3, 1, 8, 32, 2, 2, 8), WGRAD_ENTRY_C(5, 1, 8, 32, 2, 2, 4),
     WGRAD_ENTRY_C(5, 1, 8, 32, 2, 2, 8), WGRAD_ENTRY_C(5, 1, 8, 32, 1, 4, 8),
+    // (r2: 32 input channels per block -- twice the reuse of the dz tile per staged byte -- measured on layers 2 / 3: 0.175 ms
+    //  and worse against 0.104 / 0.128 ms for the Winograd instances below; not registered)
     // packed-N (conv_wgrad_kernel.h): <= 4 output channels, the MFMA columns hold 4 channels x 4 column shifts
     WGRAD_ENTRY_K(5, 1, 8, 32, 1, 4, 8, 4), WGRAD_ENTRY_K(5, 1, 8, 32, 1, 4, 16, 4), WGRAD_ENTRY_K(5, 1, 4, 32, 1, 4, 16, 4),
     WGRAD_ENTRY_K(3, 1, 8, 32, 1, 4, 16, 4),

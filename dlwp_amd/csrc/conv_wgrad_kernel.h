@@ -28,7 +28,15 @@ struct WgradArgs {
   int in_c_off, in_c_total, dz_c_off, dz_c_total;
   int pad_top, pad_left, mode_h, mode_w, src_mode;
   int tiles_h, tiles_w, total_tiles, splits, ci_groups, co_tiles;
+#ifdef DLWP_PHASE_TIMING  // tools/microbench/wgrad_phase_timing.hip only: per-block sums of s_memtime differences, 8 per block
+  long long* dbg = nullptr;
+#endif
 };
+#ifdef DLWP_PHASE_TIMING
+#define DLWP_WG_T(k) do { const long long t_now = __builtin_amdgcn_s_memtime(); wg_ph[k] += t_now - wg_t; wg_t = t_now; } while (0)
+#else
+#define DLWP_WG_T(k) do { } while (0)
+#endif
 
 // PACK = 4: the "packed-N" form for layers with <= 4 output channels (the 5x5 output layer).  The 16 MFMA columns hold
 // (co, s) = 4 output channels x 4 column shifts of dz instead of 16 output channels of which 12 would be padding:
@@ -104,7 +112,15 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  int b = blockIdx.x;
+  // XCD-aware block order (workgroups go round-robin over the 8 XCDs, each with its own L2): an XCD gets a contiguous range
+  // of the (split, cout tile, channel group) order, so the workgroups that read the same x tile (other cout tiles) and the
+  // same dz tile (other channel groups) run on ONE L2 at about the same time
+  int b;
+  {
+    const int bi = blockIdx.x, nb = gridDim.x;
+    const int xcd = bi & 7, idx = bi >> 3, q = nb >> 3, r = nb & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int cig = b % a.ci_groups;
   b /= a.ci_groups;
   const int cot = b % a.co_tiles;
@@ -180,6 +196,10 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
   const bool quad_z = (a.Wo & 3) == 0;                                // 4 pixels of dz: one 16-byte load
   constexpr unsigned DROP = 0x7ffffff0u;
 
+#ifdef DLWP_PHASE_TIMING
+  long long wg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wg_t = __builtin_amdgcn_s_memtime();
+  const long long wg_t0 = wg_t;
+#endif
   // register-staged pipeline over tiles: the loads of tile t+1 are in flight under tile t's MFMA loop
   float xv[C::NPP][C::CI][2], zv[C::NZ4][4];
   int tw_i, th_i, n_i;   // the tile the next prefetch fetches (incremental walk)
@@ -249,6 +269,7 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
         }
       }
     }
+    DLWP_WG_T(4);   // x loads issued
     const float* zn = a.dz + ((long long)n_i * a.dz_c_total + a.dz_c_off + co0) * oplane;
     const __amdgpu_buffer_rsrc_t z_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)zn, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
@@ -285,8 +306,10 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
   };
 
   if (t_begin < t_end) prefetch();
+  DLWP_WG_T(0);
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();  // previous tile consumed
+    DLWP_WG_T(1);
 #pragma unroll
     for (int k = 0; k < C::NPP; ++k)
 #pragma unroll
@@ -298,8 +321,11 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
       *(u32x2*)(zs + z_lds[k]) = (u32x2){__builtin_bit_cast(unsigned, zv[k][0]), __builtin_bit_cast(unsigned, zv[k][1])};
       *(u32x2*)(zs + z_lds[k] + 2) = (u32x2){__builtin_bit_cast(unsigned, zv[k][2]), __builtin_bit_cast(unsigned, zv[k][3])};
     }
+    DLWP_WG_T(2);   // staging written (includes the wait for the prefetched loads)
     __syncthreads();
+    DLWP_WG_T(3);
     if (tile + 1 < t_end) prefetch();
+    DLWP_WG_T(6);   // dz loads issued + tile walk
 
     if constexpr (C::WINO) {
       // ---- tile quads: lane (ci | co = lane & 15, tile k = lane >> 4 of the quad) transforms its own patches
@@ -346,6 +372,7 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
           }
         }
       }
+      DLWP_WG_T(5);
       continue;
     }
     // ---- pixel quads: 1 B fragment + MF A fragments -> MF MFMAs, double-buffered
@@ -373,6 +400,12 @@ __device__ __forceinline__ void conv2d_wgrad_body(const WgradArgs& a) {
     }
   }
 
+#ifdef DLWP_PHASE_TIMING
+  if (a.dbg && threadIdx.x == 0) {
+    for (int k = 0; k < 7; ++k) a.dbg[(long long)blockIdx.x * 8 + k] = wg_ph[k];
+    a.dbg[(long long)blockIdx.x * 8 + 7] = t_end - t_begin;
+  }
+#endif
   // ---- one partial slab per (block split, pixel-wave)
   float* slab = a.slabs + (long long)(split * C::PW + wp) * C::TAPS * a.Cin * a.Cout;
   if constexpr (C::WINO) {   // dg = G^T dU G per (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
