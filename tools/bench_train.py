@@ -20,7 +20,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--batch', type=int, default=64, help='samples per GPU per step')
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=15)
     ap.add_argument('--grid', default='88x180')
     ap.add_argument('--channels', type=int, default=4)
     a = ap.parse_args()

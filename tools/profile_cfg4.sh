@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/tools/bench_cfg4.py --members $M --iters 5"
+CMD="python $R/tools/bench_cfg4.py --members $M --iters 10"
 $CMD > $OUT/${TAG}_cfg4_bf16_m${M}.json 2> /dev/null
 rocprofv3 --kernel-trace --stats -d $OUT/cfg4_stats -o s --output-format csv -- $CMD > /dev/null 2> $OUT/cfg4_stats.err
 cp $(find $OUT/cfg4_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_cfg4_bf16_m${M}_kernel_stats.csv 2>/dev/null
