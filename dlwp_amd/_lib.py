@@ -22,6 +22,7 @@ PAD_ZERO, PAD_WRAP, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC = 0, 1, 2, 3, 4
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
 OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES, OP_PHASE_WEIGHTS, OP_DEPTH2SPACE = 0, 1, 2, 3, 4, 5, 6, 7
+OP_ROWCONV2D = 8
 BUF_NONE = -1000
 
 
@@ -144,6 +145,12 @@ _sig('dlwp_conv2d_bwd_weight', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _i, 
 _sig('dlwp_conv2d_wgrad_num_configs', [])
 _sig('dlwp_conv2d_wgrad_config_info', [_i, _P(_i), _P(_i)])
 _sig('dlwp_conv2d_wgrad_pick_config', [_vp, Shape4, _P(Conv2d)])
+_sig('dlwp_rowconv2d_fwd', [_vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
+_sig('dlwp_rowconv2d_fwd_direct', [_vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
+_sig('dlwp_rowconv2d_uses_matrix_cores', [_vp, Shape4, _P(Conv2d), _i])
+_sig('dlwp_rowconv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _P(_sz)])
+_sig('dlwp_rowconv2d_bwd_data', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])
+_sig('dlwp_rowconv2d_bwd_weight', [_vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _i, _vp])
 _sig('dlwp_act_bwd', [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp])
 _sig('dlwp_bias_grad_workspace', [_i], _sz)
 _sig('dlwp_bias_grad', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp])

@@ -32,6 +32,8 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
         return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre, &io);
       }
       return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre);  // aux[0]: per-op storage
+    case DLWP_OP_ROWCONV2D:     // RowConnected2D: float32 buffers, weights read as stored (nothing to prepare)
+      return dlwp_rowconv2d_fwd(h, src, w, b, dst, op.xs, &op.conv, DLWP_F32, (void*)s);
     case DLWP_OP_PAD2D:
       // NCHW: outer = n*c rows-of-W planes; NHWC: xs = (n, 1, h, w) and conv.in_c_total carries the inner (channel) run
       return dlwp_pad2d_fwd(h, src, dst, op.xs.n * op.xs.c, op.xs.h, op.xs.w,
@@ -130,7 +132,7 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
                    op.src);
     DLWP_CHECK_ARG(op.dst != DLWP_BUF_STATE_IN && op.dst >= DLWP_BUF_OUT(n_outputs - 1) && op.dst < n_buffers,
                    "rollout op %d: dst buffer %d out of range", i, op.dst);
-    if (op.kind == DLWP_OP_CONV2D)
+    if (op.kind == DLWP_OP_CONV2D || op.kind == DLWP_OP_ROWCONV2D)
       DLWP_CHECK_ARG(op.w >= 0 && op.w < n_buffers && op.b >= -1 && op.b < n_buffers,
                      "rollout op %d: weight/bias buffer out of range", i);
     if (op.kind == DLWP_OP_PHASE_WEIGHTS)
@@ -195,8 +197,9 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
       for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
         const dlwp_op& op = plan[i];
         if (op.kind == DLWP_OP_PHASE_WEIGHTS) continue;   // done once, at the head of the graph
-        const void* w = op.kind == DLWP_OP_CONV2D ? buffers[op.w] : nullptr;
-        const void* b = (op.kind == DLWP_OP_CONV2D && op.b >= 0) ? buffers[op.b] : nullptr;
+        const bool weighted = op.kind == DLWP_OP_CONV2D || op.kind == DLWP_OP_ROWCONV2D;
+        const void* w = weighted ? buffers[op.w] : nullptr;
+        const void* b = (weighted && op.b >= 0) ? buffers[op.b] : nullptr;
         void* aux[3] = {nullptr, nullptr, nullptr};
         if (op.kind == DLWP_OP_LSTM_GATES)
           for (int k = 0; k < 3; ++k) aux[k] = op.aux[k] == DLWP_BUF_NONE ? nullptr : resolve(op.aux[k], t, g);

@@ -1,0 +1,674 @@
+// rowconv.hip -- DLWP.custom.RowConnected2D / row_conv2d (reference DLWP/custom.py:695-837, 840-896) on the CDNA4 matrix
+// cores, fp32 (gfx950).  The layer is a Conv2D whose filters are shared along a row only: output row r is the 'valid'
+// convolution of input rows [r, r + kh) with ITS OWN kernel w[r] (kh, kw, cin, cout) (custom.py:879-888); the reference
+// runs it as Ho separate K.conv2d calls on row slices + a concatenate.  Call sites: the optional last layer of the
+// functional U-Net (examples/train_functional.py:191-196, Azure/train_func.py:230): 5x5, 'valid', linear, channels_first,
+// behind PeriodicPadding2D((0, 2)) + ZeroPadding2D((2, 0)) -- that halo is resolved by the loaders here, as everywhere.
+//
+// Per output row the work is a skinny GEMM  D[pixel, cout] = A[pixel, (ky, kx, ci)] B_r[(ky, kx, ci), cout]  with cout = 2 ...
+// 12 at the call sites (the model's output fields).  v_mfma_f32_16x16x4_f32 wants 16 columns, so:
+//   forward      cout <= 8: PACKED columns -- the 16 MFMA columns hold P = 16 / cout_p ADJACENT pixels x cout_p channels
+//                (cout_p = cout rounded up to a power of two), the rows of a fragment are 16 groups of P pixels, and the k
+//                index runs over (ky, u, ci) with u = p + kx in [0, kw + P - 1): B_r[(ky, u, ci), p cout_p + co] =
+//                w[r][ky][u - p][ci][co] (zero outside the kernel).  K grows by (kw + P - 1) / kw, the pixels per
+//                instruction by P: cout = 4, 5x5: 2.5 x fewer matrix instructions than padding cout to 16.
+//                cout > 8: plain 16-column fragments (P = 1).
+//   data grad    pixels x cin with k = (ky, kx, co): cin fills the columns, no padding beyond co -> multiple of 4.
+//   weight grad  one workgroup per (row, ky): D[(kx, ci), co] = sum over (sample, column) -- a fixed summation order, so
+//                the result is bit-reproducible (as dlwp_conv2d_bwd_weight).
+// All three stage their operands in LDS ([channel][row][column] slabs, halo resolved while staging) and read fragments
+// with one ds_read_b32 per operand; strides are == 16 (mod 32) resp. == 2 (mod 32) floats so the two 16-lane halves of a
+// read fall on disjoint banks.  Anything these tilings do not cover (LDS footprint) runs on one-thread-per-output vector
+// kernels, which are also the in-library cross-check (dlwp_rowconv2d_fwd_direct).
+//
+// The bias is stored as the reference creates it, (rows, 1, cout) (custom.py:812).  K.bias_add (custom.py:834) is Keras:
+// for channels_first its tensorflow backend RESHAPES a rank-3 bias to (1, cout, rows, 1), so channel co, row r receives
+// flat element co * rows + r.  Third-party semantics, unpinned (oracle/np_ref.py: row_bias_channels_first).
+#include "conv_fwd_kernel.h"
+
+namespace {
+
+constexpr int kMaxSlots = 7;   // column slots of 64 lanes a staged row may need (<= 448 columns)
+
+struct RowArgs {
+  const float* x;      // forward / weight grad: input (n, in_c_total, H, W); data grad: unused
+  const float* w;      // (Ho, kh, kw, Cin, Cout)
+  const float* bias;   // (Ho, 1, Cout) stored, read as [co * Ho + r]; nullable
+  float* y;            // forward: output; data grad: dxp (n, Cin, Hp, Wp); weight grad: dw
+  const float* dz;     // gradients: (n, out_c_total, Ho, Wo) window [out_c_off, +Cout)
+  float* db;           // weight grad: bias gradient (nullable)
+  int N, Cin, H, W, Ho, Wo, Cout, kh, kw;
+  int in_c_off, in_c_total, out_c_off, out_c_total;
+  int pad_top, pad_left, mode_h, mode_w, act, accumulate;
+  int Hp, Wp;          // padded input size (data grad)
+  // tiling (filled by the planners below)
+  int P_log2, cp_log2, U, CK, FX, S, n_cb, n_sg, n_cg, TW_in;
+  int Q, RS, PS, SS, w_off;   // LDS strides / offsets in floats
+  int NF;                     // data grad: cin fragments per workgroup; weight grad: M fragments per workgroup
+  int n_mg;                   // weight grad: M groups
+};
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ------------------------------------------------------------------------------------------------------------------ //
+// forward
+// ------------------------------------------------------------------------------------------------------------------ //
+__global__ __launch_bounds__(128) void rowconv2d_fwd_mfma(const RowArgs a) {
+  extern __shared__ float lds[];
+  float* xs = lds;
+  float* ws = lds + a.w_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  int b = blockIdx.x;
+  const int cb = b % a.n_cb; b /= a.n_cb;
+  const int cg = b % a.n_cg; b /= a.n_cg;
+  const int sg = b % a.n_sg; b /= a.n_sg;
+  const int r = b;
+  const int P = 1 << a.P_log2, cout_p = 1 << a.cp_log2;
+  const int s0 = sg * a.S, x0 = (cb * a.FX * 16) << a.P_log2, co0 = cg * 16;
+
+  // the columns this lane stages, the same for every staged row: source column (halo resolved; -1 = zero) and LDS position
+  // (columns de-interleaved by c mod P, so that the stride-P fragment reads below are contiguous)
+  int ix[kMaxSlots], pos[kMaxSlots];
+#pragma unroll
+  for (int j = 0; j < kMaxSlots; ++j) {
+    const int col = lane + 64 * j;
+    ix[j] = col < a.TW_in ? dlwp_map_coord_tile(x0 + col - a.pad_left, a.W, a.mode_w) : -2;
+    pos[j] = (col & (P - 1)) * a.Q + (col >> a.P_log2);
+  }
+  // this wave's fragments: f = wave + 2 i  ->  (sample s, column fragment fx)
+  const int m = lane & 15, kq = lane >> 4;
+  const int n_frag = a.S * a.FX;
+  int abase[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int f = min(wave + 2 * i, n_frag - 1);
+    abase[i] = (f / a.FX) * a.SS + kq * a.PS + (f % a.FX) * 16 + m;
+  }
+  const int nf = (n_frag - wave + 1) / 2;     // fragments of this wave (0 .. 3)
+  f32x4 acc[3] = {};
+
+  const int ck_log2 = a.CK == 8 ? 3 : 2, sc_total = a.S * a.CK, c4n = a.CK >> 2;
+  for (int c0 = 0; c0 < a.Cin; c0 += a.CK) {
+    // ---- stage CK channels x kh rows x TW_in columns of S samples
+    for (int sc = wave; sc < sc_total; sc += 2) {             // (sample, channel) planes, CK a power of two
+      const int ci = sc & (a.CK - 1), s = sc >> ck_log2;
+      const int n = s0 + s, c = c0 + ci;
+      const bool okp = n < a.N && c < a.Cin;
+      const float* plane = a.x + ((size_t)(okp ? n : 0) * a.in_c_total + a.in_c_off + (okp ? c : 0)) * a.H * a.W;
+      float* dplane = xs + s * a.SS + ci * a.PS;
+      for (int ky = 0; ky < a.kh; ++ky) {
+        const int iy = dlwp_map_coord_tile(r + ky - a.pad_top, a.H, a.mode_h);
+        const bool ok = okp && iy >= 0;
+        const float* src = plane + (size_t)(ok ? iy : 0) * a.W;
+        float* dst = dplane + ky * a.RS;
+#pragma unroll
+        for (int j = 0; j < kMaxSlots; ++j)
+          if (ix[j] != -2) dst[pos[j]] = (ok && ix[j] >= 0) ? src[ix[j]] : 0.f;
+      }
+    }
+    // ---- this row's filters for these channels, expanded to the packed columns: ws[((ky U + u) CK + ci) 16 + column]
+    for (int ky = 0; ky < a.kh; ++ky)
+      for (int u = wave; u < a.U; u += 2) {
+      const int pr = ky * a.U + u;
+      for (int e = lane; e < a.CK * 16; e += 64) {
+        const int col = e & 15, ci = e >> 4;
+        const int p = col >> a.cp_log2, co = col & (cout_p - 1);
+        const int kx = u - p, c = c0 + ci, cog = co0 + co;
+        float v = 0.f;
+        if (kx >= 0 && kx < a.kw && c < a.Cin && cog < a.Cout)
+          v = a.w[((((size_t)r * a.kh + ky) * a.kw + kx) * a.Cin + c) * a.Cout + cog];
+        ws[pr * a.CK * 16 + e] = v;
+      }
+    }
+    __syncthreads();
+    int kstep = 0;
+    for (int ky = 0; ky < a.kh; ++ky)
+      for (int u = 0; u < a.U; ++u) {
+        const int soff = ky * a.RS + (u & (P - 1)) * a.Q + (u >> a.P_log2);
+        for (int c4 = 0; c4 < c4n; ++c4, ++kstep) {
+          const float bv = ws[kstep * 64 + lane];
+          const int o = soff + c4 * 4 * a.PS;
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            if (i < nf) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[abase[i] + o], bv, acc[i], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+  }
+  // ---- epilogue: lane holds rows 4 (lane >> 4) + j of column lane & 15
+  const int col = lane & 15, p = col >> a.cp_log2, co = col & (cout_p - 1), cog = co0 + co;
+  if (cog >= a.Cout) return;
+  const float bb = a.bias ? a.bias[(size_t)cog * a.Ho + r] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (i >= nf) break;
+    const int f = wave + 2 * i, s = f / a.FX, fx = f % a.FX, n = s0 + s;
+    if (n >= a.N) continue;
+    float* yr = a.y + (((size_t)n * a.out_c_total + a.out_c_off + cog) * a.Ho + r) * a.Wo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ox = x0 + ((fx * 16 + 4 * kq + j) << a.P_log2) + p;
+      if (ox < a.Wo) yr[ox] = act_apply(acc[i][j] + bb, a.act);
+    }
+  }
+}
+
+// one thread per output element: any geometry; the cross-check of the kernel above
+__global__ void rowconv2d_fwd_simple(const RowArgs a) {
+  const long long total = (long long)a.N * a.Cout * a.Ho * a.Wo;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % a.Wo);
+    long long t = e / a.Wo;
+    const int r = (int)(t % a.Ho); t /= a.Ho;
+    const int co = (int)(t % a.Cout);
+    const int n = (int)(t / a.Cout);
+    float acc = a.bias ? a.bias[(size_t)co * a.Ho + r] : 0.f;
+    for (int ky = 0; ky < a.kh; ++ky) {
+      const int iy = dlwp_map_coord(r + ky - a.pad_top, a.H, a.mode_h);
+      if (iy < 0) continue;
+      for (int kx = 0; kx < a.kw; ++kx) {
+        const int ixx = dlwp_map_coord(ox + kx - a.pad_left, a.W, a.mode_w);
+        if (ixx < 0) continue;
+        const float* xp = a.x + ((size_t)n * a.in_c_total + a.in_c_off) * a.H * a.W + (size_t)iy * a.W + ixx;
+        const float* wp = a.w + (((size_t)r * a.kh + ky) * a.kw + kx) * a.Cin * a.Cout + co;
+        for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[(size_t)c * a.H * a.W], wp[(size_t)c * a.Cout], acc);
+      }
+    }
+    a.y[(((size_t)n * a.out_c_total + a.out_c_off + co) * a.Ho + r) * a.Wo + ox] = act_apply(acc, a.act);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ //
+// data gradient on the PADDED grid: dxp[n, ci, py, px] = sum_{ky, kx, co} dz[n, co, py - ky, px - kx] w[py - ky][ky][kx][ci][co]
+// (the halo is folded back onto the stored tensor by dlwp_pad2d_bwd afterwards)
+// ------------------------------------------------------------------------------------------------------------------ //
+__global__ __launch_bounds__(128) void rowconv2d_dgrad_mfma(const RowArgs a) {
+  extern __shared__ float lds[];
+  float* zs = lds;                 // [s][co][ky][col], col <-> output column x0 - (kw - 1) + col
+  float* ws = lds + a.w_off;       // [kstep][nf][kq][ci]
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  int b = blockIdx.x;
+  const int cb = b % a.n_cb; b /= a.n_cb;
+  const int cg = b % a.n_cg; b /= a.n_cg;
+  const int sg = b % a.n_sg; b /= a.n_sg;
+  const int py = b;
+  const int s0 = sg * a.S, x0 = cb * a.FX * 16, ci0 = cg * a.NF * 16;
+  const int cpad = a.CK;           // cout rounded up to a multiple of 4
+  // ---- dz rows py - ky of S samples
+  for (int s = 0; s < a.S; ++s)
+    for (int co = wave; co < cpad; co += 2) {
+      const int n = s0 + s;
+      const bool okp = n < a.N && co < a.Cout;
+      const float* plane = a.dz + ((size_t)(okp ? n : 0) * a.out_c_total + a.out_c_off + (okp ? co : 0)) * a.Ho * a.Wo;
+      for (int ky = 0; ky < a.kh; ++ky) {
+        const int r = py - ky;
+        const bool ok = okp && r >= 0 && r < a.Ho;
+        const float* src = plane + (size_t)(ok ? r : 0) * a.Wo;
+        float* dst = zs + s * a.SS + co * a.PS + ky * a.RS;
+        for (int col = lane; col < a.TW_in; col += 64) {
+          const int ox = x0 - (a.kw - 1) + col;
+          dst[col] = (ok && ox >= 0 && ox < a.Wo) ? src[ox] : 0.f;
+        }
+      }
+    }
+  // ---- filters of the rows that reach py: ws[(((ky kw + kx) C4 + c4) NF + nf) 64 + kq 16 + ci]
+  const int c4n = cpad >> 2;
+  for (int ky = 0; ky < a.kh; ++ky) {
+    const int r = py - ky;
+    for (int kx = wave; kx < a.kw; kx += 2)
+      for (int c4 = 0; c4 < c4n; ++c4) {
+        const int ks = (ky * a.kw + kx) * c4n + c4;
+        const int co = c4 * 4 + (lane >> 4);
+        for (int g = 0; g < a.NF; ++g) {
+          const int c = ci0 + g * 16 + (lane & 15);
+          float v = 0.f;
+          if (r >= 0 && r < a.Ho && co < a.Cout && c < a.Cin)
+            v = a.w[((((size_t)r * a.kh + ky) * a.kw + kx) * a.Cin + c) * a.Cout + co];
+          ws[(ks * a.NF + g) * 64 + lane] = v;
+        }
+      }
+  }
+  __syncthreads();
+  const int m = lane & 15, kq = lane >> 4;
+  const int n_frag = a.S * a.FX;
+  int abase[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int f = min(wave + 2 * i, n_frag - 1);
+    abase[i] = (f / a.FX) * a.SS + kq * a.PS + (f % a.FX) * 16 + m + (a.kw - 1);
+  }
+  const int nfr = (n_frag - wave + 1) / 2;
+  f32x4 acc[3][2] = {};
+  int kstep = 0;
+  for (int ky = 0; ky < a.kh; ++ky)
+    for (int kx = 0; kx < a.kw; ++kx)
+      for (int c4 = 0; c4 < c4n; ++c4, ++kstep) {
+        const int o = c4 * 4 * a.PS + ky * a.RS - kx;
+        float bv[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) bv[g] = g < a.NF ? ws[(kstep * a.NF + g) * 64 + lane] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (i < nfr) {
+            const float av = zs[abase[i] + o];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+              if (g < a.NF) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[g], acc[i][g], 0, 0, 0);
+          }
+      }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (i >= nfr) break;
+    const int f = wave + 2 * i, s = f / a.FX, fx = f % a.FX, n = s0 + s;
+    if (n >= a.N) continue;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int c = ci0 + g * 16 + m;
+      if (g >= a.NF || c >= a.Cin) continue;
+      float* dr = a.y + (((size_t)n * a.Cin + c) * a.Hp + py) * a.Wp;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int px = x0 + fx * 16 + 4 * kq + j;
+        if (px < a.Wp) dr[px] = acc[i][g][j];
+      }
+    }
+  }
+}
+
+__global__ void rowconv2d_dgrad_simple(const RowArgs a) {
+  const long long total = (long long)a.N * a.Cin * a.Hp * a.Wp;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int px = (int)(e % a.Wp);
+    long long t = e / a.Wp;
+    const int py = (int)(t % a.Hp); t /= a.Hp;
+    const int c = (int)(t % a.Cin);
+    const int n = (int)(t / a.Cin);
+    float acc = 0.f;
+    for (int ky = 0; ky < a.kh; ++ky) {
+      const int r = py - ky;
+      if (r < 0 || r >= a.Ho) continue;
+      for (int kx = 0; kx < a.kw; ++kx) {
+        const int ox = px - kx;
+        if (ox < 0 || ox >= a.Wo) continue;
+        const float* zp = a.dz + (((size_t)n * a.out_c_total + a.out_c_off) * a.Ho + r) * a.Wo + ox;
+        const float* wp = a.w + ((((size_t)r * a.kh + ky) * a.kw + kx) * a.Cin + c) * a.Cout;
+        for (int co = 0; co < a.Cout; ++co) acc = fmaf(zp[(size_t)co * a.Ho * a.Wo], wp[co], acc);
+      }
+    }
+    a.y[e] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ //
+// weight gradient: one workgroup per (row r, ky, M group, cout group); D[(kx, ci), co] = sum_{n, ox} xp[n, ci, r + ky, ox + kx]
+// dz[n, co, r, ox], samples and columns in a fixed order
+// ------------------------------------------------------------------------------------------------------------------ //
+__global__ __launch_bounds__(256) void rowconv2d_wgrad_mfma(const RowArgs a) {
+  extern __shared__ float lds[];
+  float* xs = lds;              // [ci (cin padded to 16)][col], col <-> padded column
+  float* zs = lds + a.w_off;    // [co (16)][ox]
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  int b = blockIdx.x;
+  const int mg = b % a.n_mg; b /= a.n_mg;
+  const int cg = b % a.n_cg; b /= a.n_cg;
+  const int ky = b % a.kh;
+  const int r = b / a.kh;
+  const int co0 = cg * 16;
+  const int C16 = (a.Cin + 15) >> 4, cin_pad = C16 * 16;
+  const int m_total = a.kw * C16;                       // M fragments of the (kx, ci) axis
+  const int mf0 = mg * a.NF;
+  const int n_frag = min(a.NF, m_total - mf0);          // this workgroup's fragments, 3 per wave at most
+  int ix[kMaxSlots];
+#pragma unroll
+  for (int j = 0; j < kMaxSlots; ++j) {
+    const int col = lane + 64 * j;
+    ix[j] = col < a.TW_in ? dlwp_map_coord_tile(col - a.pad_left, a.W, a.mode_w) : -2;
+  }
+  const int m = lane & 15, kq = lane >> 4;
+  int abase[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int f = mf0 + min(wave + 4 * i, n_frag - 1);
+    abase[i] = ((f % C16) * 16 + m) * a.PS + (f / C16) + kq;      // channel row, + kx, + k within the step
+  }
+  const int nfr = n_frag > wave ? (n_frag - wave + 3) / 4 : 0;
+  const int zbase = m * a.PS + kq;
+  f32x4 acc[3] = {};
+  const int iy = dlwp_map_coord_tile(r + ky - a.pad_top, a.H, a.mode_h);
+  const int ksteps = (a.Wo + 3) >> 2, wo4 = ksteps * 4;
+  for (int n = 0; n < a.N; ++n) {
+    for (int c = wave; c < cin_pad; c += 4) {
+      const bool ok = c < a.Cin && iy >= 0;
+      const float* src = a.x + (((size_t)n * a.in_c_total + a.in_c_off + (ok ? c : 0)) * a.H + (ok ? iy : 0)) * a.W;
+      float* dst = xs + c * a.PS;
+#pragma unroll
+      for (int j = 0; j < kMaxSlots; ++j)
+        if (ix[j] != -2) dst[lane + 64 * j] = (ok && ix[j] >= 0) ? src[ix[j]] : 0.f;
+    }
+    for (int co = wave; co < 16; co += 4) {
+      const bool ok = co0 + co < a.Cout;
+      const float* src = a.dz + (((size_t)n * a.out_c_total + a.out_c_off + (ok ? co0 + co : 0)) * a.Ho + r) * a.Wo;
+      float* dst = zs + co * a.PS;
+      for (int ox = lane; ox < wo4; ox += 64) dst[ox] = (ok && ox < a.Wo) ? src[ox] : 0.f;
+    }
+    __syncthreads();
+    for (int kc = 0; kc < ksteps; ++kc) {
+      const float bv = zs[zbase + 4 * kc];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (i < nfr) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[abase[i] + 4 * kc], bv, acc[i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int co = co0 + m;    // D column = lane & 15
+  if (co >= a.Cout) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (i >= nfr) break;
+    const int f = mf0 + wave + 4 * i, kx = f / C16, c16 = f % C16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c16 * 16 + 4 * kq + j;
+      if (c >= a.Cin) continue;
+      float* d = a.y + ((((size_t)r * a.kh + ky) * a.kw + kx) * a.Cin + c) * a.Cout + co;
+      *d = a.accumulate ? *d + acc[i][j] : acc[i][j];
+    }
+  }
+}
+
+__global__ void rowconv2d_wgrad_simple(const RowArgs a) {
+  const long long total = (long long)a.Ho * a.kh * a.kw * a.Cin * a.Cout;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(e % a.Cout);
+    long long t = e / a.Cout;
+    const int c = (int)(t % a.Cin); t /= a.Cin;
+    const int kx = (int)(t % a.kw); t /= a.kw;
+    const int ky = (int)(t % a.kh);
+    const int r = (int)(t / a.kh);
+    const int iy = dlwp_map_coord(r + ky - a.pad_top, a.H, a.mode_h);
+    float acc = 0.f;
+    if (iy >= 0)
+      for (int n = 0; n < a.N; ++n) {
+        const float* xp = a.x + (((size_t)n * a.in_c_total + a.in_c_off + c) * a.H + iy) * a.W;
+        const float* zp = a.dz + (((size_t)n * a.out_c_total + a.out_c_off + co) * a.Ho + r) * a.Wo;
+        for (int ox = 0; ox < a.Wo; ++ox) {
+          const int ixx = dlwp_map_coord(ox + kx - a.pad_left, a.W, a.mode_w);
+          if (ixx >= 0) acc = fmaf(xp[ixx], zp[ox], acc);
+        }
+      }
+    a.y[e] = a.accumulate ? a.y[e] + acc : acc;
+  }
+}
+
+// bias gradient in the stored layout: db[co * Ho + r] = sum_{n, ox} dz[n, co, r, ox]; one workgroup per element, fixed tree
+__global__ __launch_bounds__(256) void rowconv2d_bias_grad(const RowArgs a) {
+  __shared__ float red[256];
+  const int r = blockIdx.x % a.Ho, co = blockIdx.x / a.Ho;
+  float s = 0.f;
+  const int total = a.N * a.Wo;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int n = e / a.Wo, ox = e % a.Wo;
+    s += a.dz[(((size_t)n * a.out_c_total + a.out_c_off + co) * a.Ho + r) * a.Wo + ox];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* d = a.db + (size_t)co * a.Ho + r;
+    *d = a.accumulate ? *d + red[0] : red[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ //
+// host side
+// ------------------------------------------------------------------------------------------------------------------ //
+constexpr int kLdsBudget = 64 * 1024;   // per workgroup: two or more workgroups per CU (160 KB)
+
+int round_mod32(int v, int residue) {    // smallest value >= v that is == residue (mod 32)
+  int q = v + ((residue - v) % 32 + 32) % 32;
+  return q;
+}
+
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+int validate_row(const char* fn, dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
+  DLWP_CHECK_ARG(h && cd, "%s: null handle or descriptor", fn);
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "%s: float32 only (dtype 0x%x)", fn, dtype);
+  DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, "%s: bad input shape (%d,%d,%d,%d)", fn, xs.n, xs.c, xs.h,
+                 xs.w);
+  if (dlwp_conv2d_out_shape(xs, cd, ys) != DLWP_OK) return DLWP_EINVAL;
+  if (cd->dil_h != 1 || cd->dil_w != 1 || cd->src_mode != DLWP_SRC_DIRECT || cd->out_pool || cd->out_d2s || cd->lstm_f)
+    DLWP_FAIL(DLWP_EUNSUPPORTED, "%s: a row-connected layer has dilation 1, a directly stored input and a plain epilogue", fn);
+  return DLWP_OK;
+}
+
+RowArgs base_args(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4 ys) {
+  RowArgs a;
+  memset(&a, 0, sizeof(a));
+  a.N = xs.n; a.Cin = xs.c; a.H = xs.h; a.W = xs.w;
+  a.Ho = ys.h; a.Wo = ys.w; a.Cout = cd->cout; a.kh = cd->kh; a.kw = cd->kw;
+  a.in_c_off = cd->in_c_off;
+  a.in_c_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
+  a.out_c_off = cd->out_c_off;
+  a.out_c_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
+  a.pad_top = cd->halo.top; a.pad_left = cd->halo.left; a.mode_h = cd->halo.mode_h; a.mode_w = cd->halo.mode_w;
+  a.act = cd->act;
+  a.Hp = xs.h + cd->halo.top + cd->halo.bottom;
+  a.Wp = xs.w + cd->halo.left + cd->halo.right;
+  return a;
+}
+
+// forward tiling; returns the LDS bytes, 0 when the matrix-core kernel does not cover the geometry
+size_t plan_fwd(RowArgs& a) {
+  int cout_p = 16;
+  if (a.Cout <= 8) {
+    cout_p = 1;
+    while (cout_p < a.Cout) cout_p *= 2;
+  }
+  const int P = 16 / cout_p;
+  a.P_log2 = ilog2(P);
+  a.cp_log2 = ilog2(cout_p);
+  a.U = a.kw + P - 1;
+  a.n_cg = P == 1 ? dlwp_ceil_div(a.Cout, 16) : 1;
+  const int n_frag_x = dlwp_ceil_div(a.Wo, 16 * P);
+  a.FX = n_frag_x < 6 ? n_frag_x : 6;
+  if (n_frag_x > 6) {                      // even out the column blocks: 12 -> 6 + 6, 23 -> 6 6 6 5, 7 -> 4 + 3
+    const int nb = dlwp_ceil_div(n_frag_x, 6);
+    a.FX = dlwp_ceil_div(n_frag_x, nb);
+  }
+  a.n_cb = dlwp_ceil_div(n_frag_x, a.FX);
+  a.S = 6 / a.FX;
+  if (a.S < 1) a.S = 1;
+  if (a.S > a.N) a.S = a.N > 0 ? a.N : 1;
+  a.n_sg = dlwp_ceil_div(a.N, a.S);
+  a.TW_in = a.FX * 16 * P + a.kw - 1;
+  if (a.TW_in > 64 * kMaxSlots) return 0;
+  const int q_min = a.FX * 16 + ((a.U - 1) >> a.P_log2) + 1;
+  // staging writes 32 consecutive columns = 32 / P consecutive positions in each of the P groups: a group stride that is an
+  // odd multiple of 32 / P keeps the groups on disjoint banks
+  a.Q = q_min;
+  if (P > 1) {
+    const int step = 64 / P;
+    a.Q = q_min + ((step / 2 - q_min) % step + step) % step;
+  }
+  a.RS = a.Q * P;
+  a.PS = round_mod32(a.kh * a.RS, 16);
+  for (a.CK = 8; a.CK >= 4; a.CK -= 4) {
+    if (a.CK == 8 && a.Cin <= 4) continue;
+    a.SS = a.CK * a.PS;
+    a.w_off = a.S * a.SS;
+    const size_t bytes = ((size_t)a.w_off + (size_t)a.kh * a.U * a.CK * 16) * sizeof(float);
+    if (bytes <= (size_t)kLdsBudget) return bytes;
+  }
+  return 0;
+}
+
+size_t plan_dgrad(RowArgs& a) {
+  a.CK = (a.Cout + 3) & ~3;                      // co padded to whole k steps
+  const int cfr = dlwp_ceil_div(a.Cin, 16);
+  a.NF = cfr < 2 ? cfr : 2;
+  a.n_cg = dlwp_ceil_div(cfr, a.NF);
+  const int n_frag_x = dlwp_ceil_div(a.Wp, 16);
+  a.FX = n_frag_x < 6 ? n_frag_x : dlwp_ceil_div(n_frag_x, dlwp_ceil_div(n_frag_x, 6));
+  a.n_cb = dlwp_ceil_div(n_frag_x, a.FX);
+  a.S = 6 / a.FX;
+  if (a.S < 1) a.S = 1;
+  if (a.S > a.N) a.S = a.N > 0 ? a.N : 1;
+  a.n_sg = dlwp_ceil_div(a.N, a.S);
+  a.TW_in = a.FX * 16 + a.kw - 1;
+  a.RS = a.TW_in;
+  a.PS = round_mod32(a.kh * a.RS, 16);
+  a.SS = a.CK * a.PS;
+  a.w_off = a.S * a.SS;
+  const size_t bytes = ((size_t)a.w_off + (size_t)a.kh * a.kw * (a.CK / 4) * a.NF * 64) * sizeof(float);
+  return bytes <= (size_t)kLdsBudget ? bytes : 0;
+}
+
+size_t plan_wgrad(RowArgs& a) {
+  const int c16 = dlwp_ceil_div(a.Cin, 16);
+  const int m_total = a.kw * c16;
+  a.n_mg = dlwp_ceil_div(m_total, 12);
+  a.NF = dlwp_ceil_div(m_total, a.n_mg);           // <= 12 fragments per workgroup: 3 per wave
+  a.n_cg = dlwp_ceil_div(a.Cout, 16);
+  const int wo4 = (a.Wo + 3) & ~3;
+  a.TW_in = wo4 + a.kw - 1;
+  if (a.TW_in > 64 * kMaxSlots) return 0;
+  a.PS = round_mod32(a.TW_in, 2);
+  a.w_off = c16 * 16 * a.PS;
+  const size_t bytes = ((size_t)a.w_off + 16 * (size_t)a.PS) * sizeof(float);
+  return bytes <= 96 * 1024 ? bytes : 0;
+}
+
+template <class K>
+int set_lds(K kernel, size_t bytes) {
+  return bytes > 48 * 1024
+             ? (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+             : 0;
+}
+
+int grid_1d(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 65535 * 16 ? 65535 * 16 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int dlwp_rowconv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                       const dlwp_conv2d* cd, int dtype, void* stream) {
+  dlwp_shape4 ys;
+  if (int rc = validate_row("dlwp_rowconv2d_fwd", h, xs, cd, dtype, &ys)) return rc;
+  DLWP_CHECK_ARG(xs.n == 0 || (x && w && y), "dlwp_rowconv2d_fwd: null pointer");
+  if (xs.n == 0) return DLWP_OK;
+  RowArgs a = base_args(xs, cd, ys);
+  a.x = (const float*)x; a.w = (const float*)w; a.bias = (const float*)bias; a.y = (float*)y;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = plan_fwd(a);
+  if (lds == 0) {
+    hipLaunchKernelGGL(rowconv2d_fwd_simple, dim3(grid_1d((long long)a.N * a.Cout * a.Ho * a.Wo, 256)), dim3(256), 0, s, a);
+    DLWP_LAUNCH_CHECK("rowconv2d_fwd_simple");
+    return DLWP_OK;
+  }
+  DLWP_HIP((hipError_t)set_lds(rowconv2d_fwd_mfma, lds));
+  const long long grid = (long long)a.Ho * a.n_sg * a.n_cg * a.n_cb;
+  DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_rowconv2d_fwd: grid too large");
+  hipLaunchKernelGGL(rowconv2d_fwd_mfma, dim3((unsigned)grid), dim3(128), lds, s, a);
+  DLWP_LAUNCH_CHECK("rowconv2d_fwd_mfma");
+  return DLWP_OK;
+}
+
+int dlwp_rowconv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                              const dlwp_conv2d* cd, int dtype, void* stream) {
+  dlwp_shape4 ys;
+  if (int rc = validate_row("dlwp_rowconv2d_fwd_direct", h, xs, cd, dtype, &ys)) return rc;
+  DLWP_CHECK_ARG(xs.n == 0 || (x && w && y), "dlwp_rowconv2d_fwd_direct: null pointer");
+  if (xs.n == 0) return DLWP_OK;
+  RowArgs a = base_args(xs, cd, ys);
+  a.x = (const float*)x; a.w = (const float*)w; a.bias = (const float*)bias; a.y = (float*)y;
+  hipLaunchKernelGGL(rowconv2d_fwd_simple, dim3(grid_1d((long long)a.N * a.Cout * a.Ho * a.Wo, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  DLWP_LAUNCH_CHECK("rowconv2d_fwd_simple");
+  return DLWP_OK;
+}
+
+int dlwp_rowconv2d_uses_matrix_cores(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int pass) {
+  dlwp_shape4 ys;
+  if (!cd || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return 0;
+  RowArgs a = base_args(xs, cd, ys);
+  return (pass == 0 ? plan_fwd(a) : (pass == 1 ? plan_dgrad(a) : plan_wgrad(a))) != 0;
+}
+
+int dlwp_rowconv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, size_t* bytes) {
+  DLWP_CHECK_ARG(cd && bytes, "dlwp_rowconv2d_bwd_workspace: null pointer");
+  const dlwp_pad2d& p = cd->halo;
+  const bool halo = p.top || p.bottom || p.left || p.right;
+  *bytes = halo ? (size_t)xs.n * xs.c * (xs.h + p.top + p.bottom) * (xs.w + p.left + p.right) * sizeof(float) : 0;
+  return DLWP_OK;
+}
+
+int dlwp_rowconv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs, const dlwp_conv2d* cd,
+                            int dtype, void* ws, size_t ws_bytes, void* stream) {
+  dlwp_shape4 ys;
+  if (int rc = validate_row("dlwp_rowconv2d_bwd_data", h, xs, cd, dtype, &ys)) return rc;
+  DLWP_CHECK_ARG(xs.n == 0 || (dz && w && dx), "dlwp_rowconv2d_bwd_data: null pointer");
+  if (xs.n == 0) return DLWP_OK;
+  size_t need = 0;
+  dlwp_rowconv2d_bwd_workspace(h, xs, cd, &need);
+  DLWP_CHECK_ARG(need == 0 || (ws && ws_bytes >= need), "dlwp_rowconv2d_bwd_data: workspace of %zu bytes needed, %zu given",
+                 need, ws_bytes);
+  RowArgs a = base_args(xs, cd, ys);
+  a.dz = (const float*)dz; a.w = (const float*)w;
+  a.y = need ? (float*)ws : (float*)dx;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = plan_dgrad(a);
+  if (lds == 0) {
+    hipLaunchKernelGGL(rowconv2d_dgrad_simple, dim3(grid_1d((long long)a.N * a.Cin * a.Hp * a.Wp, 256)), dim3(256), 0, s, a);
+    DLWP_LAUNCH_CHECK("rowconv2d_dgrad_simple");
+  } else {
+    DLWP_HIP((hipError_t)set_lds(rowconv2d_dgrad_mfma, lds));
+    const long long grid = (long long)a.Hp * a.n_sg * a.n_cg * a.n_cb;
+    DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_rowconv2d_bwd_data: grid too large");
+    hipLaunchKernelGGL(rowconv2d_dgrad_mfma, dim3((unsigned)grid), dim3(128), lds, s, a);
+    DLWP_LAUNCH_CHECK("rowconv2d_dgrad_mfma");
+  }
+  if (need) return dlwp_pad2d_bwd(h, ws, dx, xs.n * xs.c, xs.h, xs.w, 1, cd->halo, DLWP_F32, stream);
+  return DLWP_OK;
+}
+
+int dlwp_rowconv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void* dw, void* db, dlwp_shape4 xs,
+                              const dlwp_conv2d* cd, int accumulate, int dtype, void* stream) {
+  dlwp_shape4 ys;
+  if (int rc = validate_row("dlwp_rowconv2d_bwd_weight", h, xs, cd, dtype, &ys)) return rc;
+  DLWP_CHECK_ARG(x && dz && dw, "dlwp_rowconv2d_bwd_weight: null pointer");
+  RowArgs a = base_args(xs, cd, ys);
+  a.x = (const float*)x; a.dz = (const float*)dz; a.y = (float*)dw; a.db = (float*)db;
+  a.accumulate = accumulate ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = xs.n > 0 ? plan_wgrad(a) : 0;
+  if (lds == 0) {
+    hipLaunchKernelGGL(rowconv2d_wgrad_simple, dim3(grid_1d((long long)a.Ho * a.kh * a.kw * a.Cin * a.Cout, 256)), dim3(256),
+                       0, s, a);
+    DLWP_LAUNCH_CHECK("rowconv2d_wgrad_simple");
+  } else {
+    DLWP_HIP((hipError_t)set_lds(rowconv2d_wgrad_mfma, lds));
+    const long long grid = (long long)a.Ho * a.kh * a.n_cg * a.n_mg;
+    DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_rowconv2d_bwd_weight: grid too large");
+    hipLaunchKernelGGL(rowconv2d_wgrad_mfma, dim3((unsigned)grid), dim3(256), lds, s, a);
+    DLWP_LAUNCH_CHECK("rowconv2d_wgrad_mfma");
+  }
+  if (db) {
+    hipLaunchKernelGGL(rowconv2d_bias_grad, dim3((unsigned)(a.Cout * a.Ho)), dim3(256), 0, s, a);
+    DLWP_LAUNCH_CHECK("rowconv2d_bias_grad");
+  }
+  return DLWP_OK;
+}
+
+}  // extern "C"

@@ -6,6 +6,8 @@ The DLWP.custom names on the hot path, as descriptions for the HIP back end.
                                                             or the standalone LDS-staged pad kernel)
   FillPadding2D       reference DLWP/custom.py:309-402   -> halo mode EDGE (pole-row replication)
   slice_layer         reference DLWP/custom.py:675-692   -> a channel window, resolved as an input-channel offset
+  RowConnected2D      reference DLWP/custom.py:695-837   -> per-row filters: dlwp_rowconv2d_fwd / _bwd_data / _bwd_weight
+  row_conv2d          reference DLWP/custom.py:840-896   -> the same launch on device tensors
   EarlyStoppingMin    reference DLWP/custom.py:99-136
   RNNResetStates      reference DLWP/custom.py:94-96
   History             keras.callbacks.History (what examples/train.py:253 passes)
@@ -14,6 +16,7 @@ import numpy as np
 
 from . import layers as _layers
 from .layers import Layer  # noqa: F401  (re-export: custom layers subclass it)
+from .layers import RowConnected2D  # noqa: F401  (DLWP.custom.RowConnected2D; the class lives with the other weighted layers)
 
 
 class PeriodicPadding2D(_layers._Pad2DBase):
@@ -98,6 +101,27 @@ def slice_layer(start, end, step=None, axis=1):
 # ------------------------------------------------------------------------------------------------------------------ #
 # custom losses (reference DLWP/custom.py:899-1093): descriptions consumed by the HIP loss kernels (dlwp_loss_custom)
 # ------------------------------------------------------------------------------------------------------------------ #
+
+def row_conv2d(inputs, kernel, kernel_size, strides, output_shape, data_format=None):
+    """DLWP.custom.row_conv2d (reference DLWP/custom.py:840-896) on DEVICE tensors: the 2-D convolution whose weights are
+    shared only along rows.  inputs: (batch, channels, rows, cols) for 'channels_first', (batch, rows, cols, channels) for
+    'channels_last' (Keras' default when data_format is None); kernel: (output_rows, kh, kw, channels, filters);
+    output_shape: (output_row, output_col), checked.  One launch (dlwp_rowconv2d_fwd) instead of output_row convolutions
+    and a concatenate.  Strides other than 1 are not implemented (the reference never passes them)."""
+    from . import ops
+    from .layers import normalize_data_format
+    fmt = normalize_data_format(data_format)
+    if tuple(strides) != (1, 1):
+        raise NotImplementedError('row_conv2d: only strides (1, 1) are implemented')
+    x = inputs if fmt == 'channels_first' else inputs.permute(0, 3, 1, 2).contiguous()
+    kh, kw = kernel_size
+    if tuple(kernel.shape[1:3]) != (kh, kw):
+        raise ValueError('row_conv2d: kernel %r does not have kernel_size %r' % (tuple(kernel.shape), (kh, kw)))
+    y = ops.rowconv2d(x.contiguous(), kernel.contiguous(), None, ops.make_conv(kernel.shape[-1], kh, kw, 1))
+    if tuple(y.shape[2:]) != tuple(output_shape):
+        raise ValueError('row_conv2d: output is %r, output_shape says %r' % (tuple(y.shape[2:]), tuple(output_shape)))
+    return y if fmt == 'channels_first' else y.permute(0, 2, 3, 1).contiguous()
+
 
 class LossSpec(object):
     """What `anomaly_correlation_loss(...)` / `latitude_weighted_loss(...)` return: a description the trainer lowers to

@@ -69,7 +69,7 @@ class Executor(object):
         if self._descs is None:
             descs = []
             for op in self.plan.ops:
-                if op.kind == 'conv':
+                if op.kind in ('conv', 'rowconv'):
                     f, (kh, kw), dil = op.conv_geometry
                     descs.append(ops.make_conv(f, kh, kw, dil, ops.make_pad(*op.halo), op.act,
                                                op.in_c_off, op.in_c_total, op.out_c_off, op.out_c_total, op.src_mode,
@@ -127,6 +127,8 @@ class Executor(object):
                 kern, bias = self.conv_weights(op)
                 ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0],
                            compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16))
+            elif op.kind == 'rowconv':
+                ops.rowconv2d(src, op.layer.kernel, op.layer.bias, d, out=dst, x_channels=op.xs[0])
             elif op.kind == 'phasew':
                 w2, b2 = self.phase_buffers()[op.wparam]
                 ops.phase_weights(op.layer.kernel, op.layer.bias, op.halo.top, op.halo.left, w2=w2, b2=b2)
@@ -194,7 +196,7 @@ class Executor(object):
                 table.append(b2)
         kind = {'conv': _lib.OP_CONV2D, 'pad': _lib.OP_PAD2D, 'maxpool': _lib.OP_MAXPOOL2,
                 'upsample': _lib.OP_UPSAMPLE2, 'copy': _lib.OP_COPYCH, 'lstm': _lib.OP_LSTM_GATES,
-                'phasew': _lib.OP_PHASE_WEIGHTS, 'd2s': _lib.OP_DEPTH2SPACE}
+                'phasew': _lib.OP_PHASE_WEIGHTS, 'd2s': _lib.OP_DEPTH2SPACE, 'rowconv': _lib.OP_ROWCONV2D}
         arr = (_lib.Op * len(self.plan.ops))()
         for k, (op, d) in enumerate(zip(self.plan.ops, self._descriptors())):
             o = arr[k]
@@ -209,6 +211,10 @@ class Executor(object):
                     o.aux[1] = za if za is not None else _lib.BUF_NONE
                     o.aux[2] = cp if cp is not None else _lib.BUF_NONE
                     o.aux[3] = co
+            elif op.kind == 'rowconv':                 # RowConnected2D: float32 buffers, per-row weights as stored
+                o.w, o.b = widx[id(op.layer)]
+                o.conv = d
+                o.aux[0] = _lib.F32
             elif op.kind == 'phasew':                  # kernel -> derived kernel, once at the head of the graph
                 o.src, o.b = widx[id(op.layer)]
                 o.dst, b2i = pidx[op.wparam]
@@ -388,7 +394,7 @@ class Model(object):
         pr('=' * 72)
         pr('Total params: %d' % self.count_params())
         pr('fused launches per forward: %d (%d conv)' % (self.infer_plan.n_launches,
-                                                         sum(1 for o in self.infer_plan.ops if o.kind == 'conv')))
+                                                         sum(1 for o in self.infer_plan.ops if o.kind in ('conv', 'rowconv'))))
         pr('_' * 72)
 
     def reset_states(self):

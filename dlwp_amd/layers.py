@@ -272,6 +272,93 @@ class Conv2D(Layer):
         return cfg
 
 
+class RowConnected2D(Layer):
+    """DLWP.custom.RowConnected2D (reference DLWP/custom.py:695-837; a keras LocallyConnected2D subclass): a convolution whose
+    filters are shared along a row only.  kernel (output_rows, kh, kw, cin, filters), bias (output_rows, 1, filters)
+    (custom.py:800-816), glorot_uniform / zeros as Keras initialises them for those shapes (every axis in front of the last
+    two counts as receptive field).  As in the reference only padding='valid' exists; on the HIP path the layer needs
+    strides 1 and data_format='channels_first' (the call sites: examples/train_functional.py:191-196)."""
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding='valid', data_format=None, activation=None,
+                 use_bias=True, kernel_initializer='glorot_uniform', bias_initializer='zeros', kernel_regularizer=None,
+                 bias_regularizer=None, activity_regularizer=None, kernel_constraint=None, bias_constraint=None, **kwargs):
+        super(RowConnected2D, self).__init__(**kwargs)
+        self.filters = int(filters)
+        ks = (kernel_size, kernel_size) if isinstance(kernel_size, (int, np.integer)) else tuple(kernel_size)
+        st = (strides, strides) if isinstance(strides, (int, np.integer)) else tuple(strides)
+        if len(ks) != 2 or len(st) != 2:
+            raise ValueError('kernel_size / strides must be an int or a pair')
+        if str(padding).lower() != 'valid':        # keras LocallyConnected2D.__init__
+            raise ValueError('Invalid border mode for LocallyConnected2D (only "valid" is supported): ' + str(padding))
+        if tuple(st) != (1, 1):
+            raise NotImplementedError('RowConnected2D: only strides=1 is implemented (the reference never strides it)')
+        if callable(activation):
+            activation = getattr(activation, '__name__', None)
+        if activation not in (None, 'linear', 'tanh', 'relu'):
+            raise NotImplementedError('RowConnected2D activation %r is not implemented (linear, tanh, relu are)' % (activation,))
+        if kernel_initializer not in ('glorot_uniform', 'zeros') or bias_initializer not in ('zeros',):
+            raise NotImplementedError('initialisers: kernel glorot_uniform|zeros, bias zeros')
+        self.kernel_size = tuple(int(k) for k in ks)
+        self.strides = (1, 1)
+        self.padding = 'valid'
+        self.dilation_rate = (1, 1)
+        self.data_format = normalize_data_format(data_format)
+        if self.data_format != 'channels_first':
+            raise NotImplementedError("RowConnected2D: data_format='channels_first' is required (pass it explicitly, as the "
+                                      "reference scripts do; Keras' default is channels_last)")
+        self.activation = activation or 'linear'
+        self.use_bias = bool(use_bias)
+        self.kernel_initializer = kernel_initializer
+        self.kernel_regularizer = kernel_regularizer
+        self.kernel = None
+        self.bias = None
+        self.output_row = self.output_col = None
+        self.kernel_shape = None
+
+    def compute_output_shape(self, s):
+        if len(s) != 3:
+            raise ValueError('%s expects 4D input, got per-sample shape %r' % (self.name, s))
+        c, h, w = s
+        ho, wo = h - self.kernel_size[0] + 1, w - self.kernel_size[1] + 1
+        if ho <= 0 or wo <= 0:
+            raise ValueError('%s: kernel %r does not fit the input %r' % (self.name, self.kernel_size, s))
+        return (self.filters, ho, wo)
+
+    def build(self, input_shape, device, rng):
+        """input_shape: per-sample (cin, h, w) AFTER the halo in front -- the row count of the weights is the output height
+        (custom.py:794-805)."""
+        import torch
+        cin, h, w = (int(v) for v in input_shape)
+        kh, kw = self.kernel_size
+        rows, cols = h - kh + 1, w - kw + 1
+        if self.built:
+            if tuple(self.kernel.shape) != (rows, kh, kw, cin, self.filters):
+                raise ValueError('%s was built for a kernel of shape %r, now called on an input that needs %r' %
+                                 (self.name, tuple(self.kernel.shape), (rows, kh, kw, cin, self.filters)))
+            return
+        self.output_row, self.output_col = rows, cols
+        self.kernel_shape = (rows, kh, kw, cin, self.filters)
+        if self.kernel_initializer == 'glorot_uniform':
+            rf = rows * kh * kw                       # keras.initializers._compute_fans on a rank-5 shape
+            limit = math.sqrt(6.0 / (rf * cin + rf * self.filters))
+            k = rng.uniform(-limit, limit, size=self.kernel_shape).astype(np.float32)
+        else:
+            k = np.zeros(self.kernel_shape, dtype=np.float32)
+        self.kernel = torch.from_numpy(k).to(device)
+        self._weights = [('kernel', self.kernel)]
+        if self.use_bias:
+            self.bias = torch.zeros((rows, 1, self.filters), dtype=torch.float32, device=device)
+            self._weights.append(('bias', self.bias))
+        self.built = True
+
+    def get_config(self):
+        cfg = super(RowConnected2D, self).get_config()
+        cfg.update({'filters': self.filters, 'kernel_size': self.kernel_size, 'strides': self.strides,
+                    'padding': self.padding, 'data_format': self.data_format, 'activation': self.activation,
+                    'use_bias': self.use_bias})
+        return cfg
+
+
 class _Pad3DBase(Layer):
     """ZeroPadding3D / PeriodicPadding3D argument handling (keras ZeroPadding3D forms).  On the HIP path these layers
     pad the recurrent (T, C, H, W) tensor in front of ConvLSTM2D (examples/train.py:144-147): channels_first makes T the

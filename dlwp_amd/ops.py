@@ -456,6 +456,60 @@ def conv2d_bwd_data(dz, w_hwio, cd, xs, dx):
     return dx
 
 
+# ---- RowConnected2D (reference DLWP/custom.py:695-896) ------------------------------------------------------------------ #
+def rowconv2d(x, kernel, bias, cd, out=None, direct=False, x_channels=None):
+    """RowConnected2D.call / row_conv2d, channels_first: x stored (n, in_c_total, h, w); kernel (ho, kh, kw, cin, cout) --
+    one filter set per OUTPUT ROW (custom.py:800-805); bias the stored (ho, 1, cout) array or None.  Returns
+    (n, out_c_total, ho, wo), channels [out_c_off, +cout) written.  direct=True: the vector-ALU cross-check kernel."""
+    _check_f32(x, kernel, bias, out)
+    n, c_total, h, w = x.shape
+    cin = int(x_channels) if x_channels is not None else c_total
+    if cd.in_c_total == 0 and cin != c_total:
+        cd.in_c_total = c_total
+    xs = Shape4(n, cin, h, w)
+    ys = conv_out_shape(xs, cd)
+    if tuple(kernel.shape) != (ys.h, cd.kh, cd.kw, cin, cd.cout):
+        raise ValueError('kernel shape %s does not match (rows,kh,kw,cin,cout)=%r' %
+                         (tuple(kernel.shape), (ys.h, cd.kh, cd.kw, cin, cd.cout)))
+    if bias is not None and bias.numel() != ys.h * cd.cout:
+        raise ValueError('bias of %d elements, expected (rows, 1, cout) = %d' % (bias.numel(), ys.h * cd.cout))
+    oc = cd.out_c_total if cd.out_c_total > 0 else ys.c
+    if out is None:
+        out = torch.empty((n, oc, ys.h, ys.w), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (n, oc, ys.h, ys.w):
+        raise ValueError('output buffer shape %s != %s' % (tuple(out.shape), (n, oc, ys.h, ys.w)))
+    fn = _lib.lib.dlwp_rowconv2d_fwd_direct if direct else _lib.lib.dlwp_rowconv2d_fwd
+    _lib.check(fn(_lib.handle(_dev(x)), _ptr(x), _ptr(kernel), _ptr(bias), _ptr(out), xs, ctypes.byref(cd), _lib.F32,
+                  _stream(x)))
+    return out
+
+
+def rowconv2d_uses_matrix_cores(xs_nchw, cd, which=0):
+    """Host logic: does pass `which` (0 forward, 1 data gradient, 2 weight gradient) of this geometry run on the MFMA kernels?"""
+    return bool(_lib.lib.dlwp_rowconv2d_uses_matrix_cores(_lib.handle_or_none(), Shape4(*[int(v) for v in xs_nchw]),
+                                                          ctypes.byref(cd), int(which)))
+
+
+def rowconv2d_bwd_data(dz, kernel, cd, xs, dx):
+    """dx: dense (n, cin, h, w) <- dL/dx of the row-connected layer (halo adjoint included)."""
+    _check_f32(dz, kernel, dx)
+    d = _dev(dz)
+    need = ctypes.c_size_t(0)
+    _lib.check(_lib.lib.dlwp_rowconv2d_bwd_workspace(_lib.handle(d), xs, ctypes.byref(cd), ctypes.byref(need)))
+    ws = workspace(dz.device, need.value)
+    _lib.check(_lib.lib.dlwp_rowconv2d_bwd_data(_lib.handle(d), _ptr(dz), _ptr(kernel), _ptr(dx), xs, ctypes.byref(cd),
+                                                _lib.F32, _ptr(ws), ws.numel(), _stream(dz)))
+    return dx
+
+
+def rowconv2d_bwd_weight(x, dz, dw, db, cd, xs, accumulate=False):
+    """dw (rows, kh, kw, cin, cout), db (rows, 1, cout) or None <- gradients of the kernel and the stored bias."""
+    _check_f32(x, dz, dw, db)
+    _lib.check(_lib.lib.dlwp_rowconv2d_bwd_weight(_lib.handle(_dev(x)), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), xs,
+                                                  ctypes.byref(cd), 1 if accumulate else 0, _lib.F32, _stream(x)))
+    return dw
+
+
 def conv2d_bwd_data_stored(dz, w_hwio, cd, xs, dx):
     """Up-sampled sources: gradient w.r.t. the stored tensor (n, cin, xs.h, xs.w) in one kernel.  Returns False when the
     layer has no kernel with the summing epilogue (nothing was written; use conv2d_bwd_data + upsample2_bwd)."""

@@ -12,6 +12,8 @@ A plan is pure host data (no device access): it can be built and inspected on a 
 import collections
 import os
 
+import numpy as np
+
 from . import layers as L
 
 PAD_ZERO, PAD_WRAP, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC = 0, 1, 2, 3, 4
@@ -63,7 +65,7 @@ class View(object):
 
 
 class PlanOp(object):
-    """One launch.  kind in {'conv','pad','maxpool','upsample','copy','lstm','phasew','d2s'}."""
+    """One launch.  kind in {'conv','rowconv','pad','maxpool','upsample','copy','lstm','phasew','d2s'}."""
 
     def __init__(self, kind, src, dst, xs, **kw):
         self.kind, self.src, self.dst = kind, src, dst
@@ -105,7 +107,7 @@ class PlanOp(object):
         if self.kind == 'lstm':
             extra = ' aux%r h[%d:+%d/%d] act%d rec%d' % (self.aux, self.out_c_off, self.xs[0], self.out_c_total, self.act,
                                                         self.rec_act)
-        if self.kind == 'conv':
+        if self.kind in ('conv', 'rowconv'):
             f, ks, dil = self.conv_geometry
             extra = ' %s k%s d%s src%d halo%s act%d cin[%d:+%d/%d] cout[%d:+%d/%d]%s%s' % (
                 self.layer.name, ks, dil, self.src_mode, tuple(self.halo),
@@ -145,7 +147,7 @@ class Plan(object):
         """sum over conv ops of 2*Ho*Wo*Cout*Cin*kh*kw."""
         tot = 0
         for op in self.ops:
-            if op.kind == 'conv':
+            if op.kind in ('conv', 'rowconv'):
                 if op.alg_flops is not None:
                     tot += op.alg_flops
                     continue
@@ -163,8 +165,8 @@ class Plan(object):
             co, ho, wo = op.out_shape
             tot += co * ho * wo * itemsize
         for lay in self.conv_layers:
-            kh, kw = lay.kernel_size
-            tot += (kh * kw * lay.kernel.shape[2] * lay.filters + lay.filters) * itemsize if lay.kernel is not None else 0
+            if lay.kernel is not None:
+                tot += (int(np.prod(lay.kernel.shape)) + (int(np.prod(lay.bias.shape)) if lay.bias is not None else 0)) * itemsize
         return tot
 
     def bf16_buffers(self):
@@ -338,7 +340,7 @@ def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False)
             producer[op.dst] = op
         elif op.dst in producer:
             del producer[op.dst]
-        if op.kind == 'conv' and op.layer not in plan.conv_layers:
+        if op.kind in ('conv', 'rowconv') and op.layer not in plan.conv_layers:
             plan.conv_layers.append(op.layer)
         return op
 
@@ -647,6 +649,29 @@ def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False)
                         act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
                         out_c_total=lay.filters, out_shape=(lay.filters, ho, wo)))
               views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)
+        elif isinstance(lay, L.RowConnected2D):
+            # DLWP.custom.RowConnected2D (reference custom.py:695-837): per-row filters, dlwp_rowconv2d_fwd.  Its kernels read a
+            # stored float32 tensor (a lazy pooling / up-sampling in front is materialised); the halo stays in the loader.
+            v = ins[0]
+            if v.shape is not None and len(v.shape) != 3:
+                raise NotImplementedError('%s on a non-3D tensor %r' % (lay.name, v.shape))
+            if v.src_mode != SRC_DIRECT:
+                v = materialize(v.copy(halo=NO_HALO)).copy(halo=v.halo)
+            _, hl, wl = v.logical
+            kh, kw = lay.kernel_size
+            ho, wo = hl - kh + 1, wl - kw + 1
+            if tuple(lay.kernel.shape) != (ho, kh, kw, v.c, lay.filters):
+                raise ValueError('%s: kernel %r does not fit the input (%d rows of output, %d channels)' %
+                                 (lay.name, tuple(lay.kernel.shape), ho, v.c))
+            if outs:
+                dst = OUT(outs[0])
+                plan.output_store[outs[0]] = (lay.filters, ho, wo)
+            else:
+                dst = plan.new_buffer(lay.filters, ho, wo)
+            emit(PlanOp('rowconv', v.buf, dst, (v.c, v.h, v.w), layer=lay, halo=v.halo, src_mode=SRC_DIRECT,
+                        act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
+                        out_c_total=lay.filters, out_shape=(lay.filters, ho, wo)))
+            views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)
         else:
             raise NotImplementedError('layer %s (%s) has no HIP lowering' % (lay.name, type(lay).__name__))
 

@@ -36,6 +36,12 @@ def _layer_config(lay):
                    use_bias=lay.use_bias)
         if isinstance(lay.kernel_regularizer, L1L2):
             cfg['kernel_regularizer'] = {'l2': lay.kernel_regularizer.l2}
+    elif isinstance(lay, L.RowConnected2D):
+        from .regularizers import L1L2
+        cfg.update(filters=lay.filters, kernel_size=list(lay.kernel_size), strides=list(lay.strides), padding=lay.padding,
+                   data_format=lay.data_format, activation=lay.activation, use_bias=lay.use_bias)
+        if isinstance(lay.kernel_regularizer, L1L2):
+            cfg['kernel_regularizer'] = {'l2': lay.kernel_regularizer.l2}
     elif isinstance(lay, (L.MaxPooling2D, L.UpSampling2D)):
         cfg.update(data_format=lay.data_format)
     elif isinstance(lay, L.Reshape):
@@ -130,7 +136,7 @@ def load_model_file(path, custom_objects=None, device=None):
         cls = registry[spec['class']]
         if 'padding' in cfg and isinstance(cfg['padding'], list):
             cfg['padding'] = tuple(tuple(p) for p in cfg['padding'])
-        for k in ('kernel_size', 'dilation_rate', 'target_shape', 'input_shape'):
+        for k in ('kernel_size', 'dilation_rate', 'strides', 'target_shape', 'input_shape'):
             if k in cfg and isinstance(cfg[k], list):
                 cfg[k] = tuple(cfg[k])
         if isinstance(cfg.get('kernel_regularizer'), dict):

@@ -434,6 +434,24 @@ class Trainer(object):
                             ops.copy_channels(src, xw, cin, op.in_c_off, 0)
                         dense = ops.maxpool2_bwd(xw, tmp)
                     deposit(op.src, op.in_c_off, cin, dense)
+            elif op.kind == 'rowconv':         # RowConnected2D (reference custom.py:695-837): per-row filters
+                lay = op.layer
+                y = tensor(op.dst)
+                acc = id(lay) in touched_layers
+                if lay.activation != 'linear':
+                    ops.act_bwd(y, gD, op.act, out=gD)          # dz in place of dy
+                dz = gD
+                xs = _lib.Shape4(n, op.xs[0], op.xs[1], op.xs[2])
+                ops.rowconv2d_bwd_weight(src, dz, self._grad_view(lay, 'kernel'),
+                                         self._grad_view(lay, 'bias') if lay.bias is not None else None, d, xs,
+                                         accumulate=acc)
+                touched_layers.add(id(lay))
+                if op.src == P.STATE_IN:
+                    continue
+                cin = op.xs[0]
+                dense = torch.empty((n, cin) + tuple(src.shape[2:]), dtype=torch.float32, device=self.device)
+                ops.rowconv2d_bwd_data(dz, lay.kernel, d, xs, dense)
+                deposit(op.src, op.in_c_off, cin, dense)
             elif op.kind == 'lstm':
                 zh_i, cp_i, co_i = op.aux
                 f = op.xs[0]

@@ -206,6 +206,33 @@ int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes);      /* {k
                                                                              * instance for cout <= -cout_frags), waves} */
 int dlwp_conv2d_wgrad_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);   /* the heuristic's choice, -1: none */
 
+/* ---- DLWP.custom.RowConnected2D.call / row_conv2d (DLWP/custom.py:825-837, 840-896): a Conv2D whose filters are shared
+ *      along a row only -- output row r is the 'valid' convolution of input rows [r, r + kh) with its own kernel w[r]
+ *      (custom.py:879-888: one K.conv2d per row slice + concatenate); the optional last layer of the functional U-Net
+ *      (examples/train_functional.py:191-196).  The descriptor is dlwp_conv2d with dilation 1, DLWP_SRC_DIRECT and a plain
+ *      epilogue (halo, channel windows, bias, activation as for dlwp_conv2d_fwd; the output shape is dlwp_conv2d_out_shape's).
+ *      w: (ho, kh, kw, cin, cout) -- custom.py:800-805; bias: the stored (ho, 1, cout) array of custom.py:812, which
+ *      K.bias_add (Keras 2.2, tensorflow backend) reshapes to (1, cout, ho, 1) for channels_first: channel co, row r
+ *      receives flat element co * ho + r (nullable).  float32 only; stride 1 (the reference's call sites).
+ *      bwd_data : dx (n, cin, h, w) dense <- dL/dx; the halo's adjoint is applied through a padded temporary of
+ *                 dlwp_rowconv2d_bwd_workspace() bytes (0 without a halo).
+ *      bwd_weight: dw (ho, kh, kw, cin, cout) and db (nullable; the stored (ho, 1, cout) layout) from x and dz =
+ *                 dL/d(pre-activation), summed over samples and columns in a fixed order (bit-reproducible); accumulate != 0
+ *                 adds to dw / db.
+ *      _fwd_direct: one thread per output on the vector ALU, the in-library cross-check.
+ *      dlwp_rowconv2d_uses_matrix_cores (host logic): 1 when pass 0 = forward | 1 = data | 2 = weight gradient of this
+ *      geometry runs on the MFMA kernels, 0 when it takes the vector-ALU route (LDS footprint).                           */
+int dlwp_rowconv2d_fwd(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                       const dlwp_conv2d* cd, int dtype, void* stream);
+int dlwp_rowconv2d_fwd_direct(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
+                              const dlwp_conv2d* cd, int dtype, void* stream);
+int dlwp_rowconv2d_uses_matrix_cores(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int pass);
+int dlwp_rowconv2d_bwd_workspace(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, size_t* bytes);
+int dlwp_rowconv2d_bwd_data(dlwp_handle_t, const void* dz, const void* w, void* dx, dlwp_shape4 xs, const dlwp_conv2d* cd,
+                            int dtype, void* ws, size_t ws_bytes, void* stream);
+int dlwp_rowconv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* dw, void* db, dlwp_shape4 xs,
+                              const dlwp_conv2d* cd, int accumulate, int dtype, void* stream);
+
 /* ---- the rest of the train step: Keras 'mse' loss + 'mae' metric (examples/train.py:240, train_functional.py:285),
  *      activation backward, bias gradient, Keras-2.2-form Adam (restated by the reference at DLWP/custom.py:34-40) and
  *      SGD on flat parameter buffers.  Reductions use fixed trees: bit-reproducible.
@@ -333,6 +360,7 @@ int dlwp_convlstm_gates_bwd(dlwp_handle_t, const void* zx, const void* zh, const
                                    * the rollout graph (the weights do not change inside a launch). */
 #define DLWP_OP_DEPTH2SPACE 7     /* src (n, 4F, h, w) -> dst window [conv.out_c_off, +F) of conv.out_c_total channels at
                                    * (2h, 2w); xs = (n, F, h, w) */
+#define DLWP_OP_ROWCONV2D  8      /* dlwp_rowconv2d_fwd: src, dst, w, b, xs, conv as for DLWP_OP_CONV2D (float32 buffers) */
 typedef struct {
   int kind;                 /* DLWP_OP_*                                                                  */
   int src, dst;             /* buffer indices                                                              */

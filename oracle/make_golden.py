@@ -116,8 +116,61 @@ def _install_stubs():
         def __init__(self, **kwargs):
             self.__dict__.update(kwargs)
 
+    def _conv2d_valid(x, kernel, strides=(1, 1), padding='valid', data_format=None, dilation_rate=(1, 1)):
+        """K.conv2d as Keras documents it: cross-correlation, 'valid', kernel (kh, kw, cin, cout).  float64 direct sum
+        (our restatement of the third-party op; it only carries the reference's row slicing / kernel indexing)."""
+        assert padding == 'valid' and tuple(dilation_rate) == (1, 1)
+        x = np.asarray(x, dtype=np.float64)
+        if data_format == 'channels_last':
+            x = x.transpose(0, 3, 1, 2)
+        k = np.asarray(kernel, dtype=np.float64)
+        kh, kw = k.shape[:2]
+        sr, sc = strides
+        ho, wo = (x.shape[2] - kh) // sr + 1, (x.shape[3] - kw) // sc + 1
+        y = np.zeros((x.shape[0], k.shape[3], ho, wo))
+        for u in range(kh):
+            for v in range(kw):
+                y += np.einsum('nchw,co->nohw', x[:, :, u:u + (ho - 1) * sr + 1:sr, v:v + (wo - 1) * sc + 1:sc], k[u, v])
+        return y if data_format != 'channels_last' else y.transpose(0, 2, 3, 1)
+
+    def _bias_add(x, bias, data_format=None):
+        """keras.backend.bias_add (tensorflow backend, Keras 2.2) for a 4-D x: a rank-1 bias broadcasts over the channel
+        axis; a rank-3 bias is RESHAPED to (1, b[2], b[0], b[1]) for channels_first, (1,) + shape for channels_last."""
+        bs = tuple(np.shape(bias))
+        assert x.ndim == 4 and len(bs) in (1, 3)
+        if data_format == 'channels_first':
+            shp = (1, bs[0], 1, 1) if len(bs) == 1 else (1, bs[2]) + bs[:2]
+        else:
+            shp = (1, 1, 1, bs[0]) if len(bs) == 1 else (1,) + bs
+        return x + np.reshape(bias, shp)
+
+    K.conv2d = _conv2d_valid
+    K.bias_add = _bias_add
+
     class LocallyConnected2D(Layer):
-        pass
+        """keras.layers.local.LocallyConnected2D.__init__ -- argument normalisation only -- and an add_weight that hands
+        out the arrays the generator prepared (`weight_source`: name -> callable(shape))."""
+        weight_source = None
+
+        def __init__(self, filters, kernel_size, strides=(1, 1), padding='valid', data_format=None, activation=None,
+                     use_bias=True, kernel_initializer='glorot_uniform', bias_initializer='zeros',
+                     kernel_regularizer=None, bias_regularizer=None, activity_regularizer=None, kernel_constraint=None,
+                     bias_constraint=None, **kwargs):
+            super(LocallyConnected2D, self).__init__(**kwargs)
+            self.filters = filters
+            self.kernel_size = _normalize_tuple(kernel_size, 2)
+            self.strides = _normalize_tuple(strides, 2)
+            self.padding = padding.lower()
+            if self.padding != 'valid':
+                raise ValueError('Invalid border mode for LocallyConnected2D (only "valid" is supported): ' + padding)
+            self.data_format = K.normalize_data_format(data_format)
+            self.activation = {None: (lambda v: v), 'linear': (lambda v: v), 'tanh': np.tanh}[activation]
+            self.use_bias = use_bias
+            self.kernel_initializer, self.bias_initializer = kernel_initializer, bias_initializer
+            self.kernel_regularizer = self.bias_regularizer = self.kernel_constraint = self.bias_constraint = None
+
+        def add_weight(self, shape=None, initializer=None, name=None, regularizer=None, constraint=None):
+            return type(self).weight_source[name](tuple(shape))
 
     class Model(object):
         pass
@@ -135,7 +188,9 @@ def _install_stubs():
     keras.losses = mod('keras.losses',
                        mean_absolute_error=lambda t, p: np.mean(np.abs(p - t), axis=-1),
                        mean_squared_error=lambda t, p: np.mean(np.square(p - t), axis=-1))
-    conv_utils = types.SimpleNamespace(normalize_tuple=lambda v, n, name: _normalize_tuple(v, n))
+    conv_utils = types.SimpleNamespace(
+        normalize_tuple=lambda v, n, name: _normalize_tuple(v, n),
+        conv_output_length=lambda n, k, padding, stride, dilation=1: (n - (k - 1) * dilation - 1 + stride) // stride)
     keras.utils = mod('keras.utils', conv_utils=conv_utils, multi_gpu_model=lambda m, gpus=1: m, Sequence=object)
     keras.engine = mod('keras.engine')
     keras.engine.base_layer = mod('keras.engine.base_layer', InputSpec=InputSpec)
@@ -722,6 +777,44 @@ def main():
         ver['pe_axis_%s' % method] = rv.persistence_error(fc[0], va, 4, method=method, axis=0)
         ver['ce_%s' % method] = rv.climo_error(va, 3, method=method)
     np.savez_compressed(os.path.join(OUT, 'verify.npz'), **ver)
+
+    # ----- RowConnected2D (DLWP/custom.py:695-896): the reference's build() / call() / row_conv2d run as written; K.conv2d
+    #       and K.bias_add underneath are the stub's restatement of Keras (third-party, unpinned) ------------------------ #
+    rrng = np.random.default_rng(20190815)
+    row = {}
+    row_cases = [   # (input (n, c, h, w), filters, kernel_size, strides, activation, use_bias)
+        ((2, 3, 9, 10), 4, 5, (1, 1), None, True),          # the call-site form: 5x5, linear (train_functional.py:192)
+        ((2, 5, 7, 12), 2, (3, 5), (1, 1), 'tanh', True),
+        ((1, 2, 6, 8), 3, 3, (1, 1), 'linear', False),
+        ((2, 2, 11, 13), 3, 3, (2, 2), None, True),         # equal strides: one output row per slice
+        ((1, 4, 5, 9), 12, (5, 3), (1, 1), None, True),     # a single output row
+    ]
+    row['n'] = np.int64(len(row_cases))
+    for i, (shp, filters, ks, st, act, use_bias) in enumerate(row_cases):
+        made = {}
+
+        def src(name):
+            def f(shape):
+                made[name] = rrng.standard_normal(shape).astype(np.float32) * (0.2 if name == 'kernel' else 1.0)
+                return made[name]
+            return f
+        rc.RowConnected2D.weight_source = {'kernel': src('kernel'), 'bias': src('bias')}
+        lay = rc.RowConnected2D(filters, ks, strides=st, padding='valid', activation=act, use_bias=use_bias,
+                                data_format='channels_first')
+        lay.build((None,) + shp[1:])
+        xr = rrng.standard_normal(shp).astype(np.float32)
+        yr = lay.call(xr)
+        row['%d_x' % i], row['%d_kernel' % i], row['%d_y' % i] = xr, made['kernel'], np.asarray(yr, dtype=np.float64)
+        if use_bias:
+            row['%d_bias' % i] = made['bias']
+        row['%d_kernel_shape' % i] = np.asarray(lay.kernel_shape, dtype=np.int64)
+        row['%d_out_rc' % i] = np.asarray([lay.output_row, lay.output_col], dtype=np.int64)
+        row['%d_strides' % i] = np.asarray(st, dtype=np.int64)
+        row['%d_act' % i] = np.str_(act or 'linear')
+        # the same through the functional form with channels_last data (row_conv2d's other branch, :885, :893)
+        row['%d_y_cl' % i] = np.asarray(rc.row_conv2d(xr.transpose(0, 2, 3, 1), made['kernel'], lay.kernel_size, lay.strides,
+                                                      (lay.output_row, lay.output_col), 'channels_last'), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'row_connected.npz'), **row)
 
     for f in sorted(os.listdir(OUT)):
         print('%-16s %8d bytes' % (f, os.path.getsize(os.path.join(OUT, f))))

@@ -181,6 +181,64 @@ def conv2d_grads(x, w_hwio, dz, dilation=1):
     return dx, dw, dz.sum(axis=(0, 2, 3))
 
 
+def row_conv2d(x, kernel, strides=(1, 1)):
+    """DLWP.custom.row_conv2d, channels_first (reference DLWP/custom.py:840-896): output row i is the 'valid' convolution
+    of the input rows slice(i * stride_row, i * stride_col + kh) (:881 -- the END uses the COLUMN stride; identical for
+    equal strides, which is all the call sites pass) with kernel[i] (kh, kw, cin, cout), strides applied inside that
+    convolution (:887); the rows are concatenated along the row axis (:891).  x: (n, cin, h, w); kernel: (rows, kh, kw, cin,
+    cout).  float64 direct sum; K.conv2d itself is third-party (Keras cross-correlation)."""
+    x = np.asarray(x, dtype=np.float64)
+    k = np.asarray(kernel, dtype=np.float64)
+    rows, kh, kw, cin, cout = k.shape
+    sr, sc = strides
+    out = []
+    for i in range(rows):
+        xi = x[:, :, i * sr:i * sc + kh, :]
+        hi, wi = xi.shape[2], xi.shape[3]
+        ho, wo = (hi - kh) // sr + 1, (wi - kw) // sc + 1
+        y = np.zeros((x.shape[0], cout, ho, wo), dtype=np.float64)
+        for u in range(kh):
+            for v in range(kw):
+                patch = xi[:, :, u:u + (ho - 1) * sr + 1:sr, v:v + (wo - 1) * sc + 1:sc]
+                y += np.einsum('nchw,co->nohw', patch, k[i, u, v], optimize=True)
+        out.append(y)
+    return np.concatenate(out, axis=2)
+
+
+def row_bias_channels_first(bias, rows, filters):
+    """How the (rows, 1, filters) bias of RowConnected2D (reference DLWP/custom.py:812) lands on a channels_first output:
+    K.bias_add (:834) is third-party -- Keras 2.2's tensorflow backend RESHAPES (does not transpose) a bias of rank
+    ndim(x) - 1 to (1, filters, rows, 1) for 'channels_first', so output channel f, row r receives flat element
+    f * rows + r of the stored array.  Returns that (filters, rows) view.  UNPINNED (Keras semantics)."""
+    return np.asarray(bias).reshape(-1)[:rows * filters].reshape(filters, rows)
+
+
+def row_connected2d(x, kernel, bias=None, activation='linear', strides=(1, 1)):
+    """RowConnected2D.call, channels_first (reference DLWP/custom.py:825-837): row_conv2d, bias add, activation."""
+    y = row_conv2d(x, kernel, strides)
+    if bias is not None:
+        rows, filters = np.asarray(kernel).shape[0], np.asarray(kernel).shape[-1]
+        y = y + row_bias_channels_first(np.asarray(bias, dtype=np.float64), rows, filters)[None, :, :, None]
+    return activate(y, activation)
+
+
+def row_connected2d_grads(x, kernel, dz):
+    """Gradients of row_conv2d (stride 1) w.r.t. x, the kernel and the stored (rows, 1, filters) bias, given dz."""
+    x = np.asarray(x, dtype=np.float64)
+    k = np.asarray(kernel, dtype=np.float64)
+    dz = np.asarray(dz, dtype=np.float64)
+    rows, kh, kw, cin, cout = k.shape
+    wo = dz.shape[3]
+    dx, dk = np.zeros_like(x), np.zeros_like(k)
+    for i in range(rows):
+        for u in range(kh):
+            for v in range(kw):
+                dx[:, :, i + u, v:v + wo] += np.einsum('now,co->ncw', dz[:, :, i, :], k[i, u, v], optimize=True)
+                dk[i, u, v] = np.einsum('ncw,now->co', x[:, :, i + u, v:v + wo], dz[:, :, i, :], optimize=True)
+    db = dz.sum(axis=(0, 3)).reshape(-1).reshape(rows, 1, cout)     # (filters, rows) flat -> the stored shape (see above)
+    return dx, dk, db
+
+
 def activate(z, activation):
     if activation in (None, 'linear'):
         return z
@@ -400,6 +458,8 @@ def init_weights(layers, in_channels, rng):
             filters, ks, _, _ = _conv_args(args or (), kwargs or {})
             out.append((glorot_uniform(ks + (c, filters), rng), np.zeros(filters, dtype=np.float32)))
             c = filters
+        elif name == 'RowConnected2D':       # needs the output row count: init_row_connected_weights()
+            raise ValueError('init_weights: give RowConnected2D weights through init_row_connected_weights (row count)')
         elif name == 'ConvLSTM2D':
             # in_channels is then the per-time-step channel count C of the (T, C, H, W) input
             filters, ks, _, _ = _conv_args(args or (), kwargs or {})
@@ -408,6 +468,19 @@ def init_weights(layers, in_channels, rng):
         elif name == 'Reshape':
             c = (args or kwargs['target_shape'])[0][0] if args else kwargs['target_shape'][0]
     return out
+
+
+def init_row_connected_weights(rows, ks, cin, filters, rng, bias_scale=0.):
+    """Keras glorot_uniform on the (rows, kh, kw, cin, filters) kernel of RowConnected2D (reference DLWP/custom.py:800-810):
+    keras.initializers._compute_fans treats every axis in front of the last two as receptive field, so
+    fan_in = rows kh kw cin, fan_out = rows kh kw filters.  Bias (rows, 1, filters): zeros (Keras default) or, for tests
+    that must see the bias layout, uniform(-bias_scale, bias_scale)."""
+    kh, kw = ks
+    limit = np.sqrt(6.0 / (rows * kh * kw * (cin + filters)))
+    k = rng.uniform(-limit, limit, size=(rows, kh, kw, cin, filters)).astype(np.float32)
+    b = rng.uniform(-bias_scale, bias_scale, size=(rows, 1, filters)).astype(np.float32) if bias_scale else \
+        np.zeros((rows, 1, filters), dtype=np.float32)
+    return k, b
 
 
 def round_bf16(a):
@@ -429,7 +502,7 @@ def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_wei
     run on the bf16 matrix cores -- the ConvLSTM2D then also stores zx, zh and h as bfloat16 (conv_lstm2d)."""
     x = np.asarray(x, dtype=np.float64)
     wi = 0
-    n_weighted = sum(1 for nm, _, _ in layers if nm in ('Conv2D', 'ConvLSTM2D'))
+    n_weighted = sum(1 for nm, _, _ in layers if nm in ('Conv2D', 'ConvLSTM2D', 'RowConnected2D'))
     for name, args, kwargs in layers:
         args, kwargs = args or (), kwargs or {}
         fmt = kwargs.get('data_format', 'channels_first')
@@ -463,6 +536,11 @@ def run_layers(layers, x, weights, record=None, bf16_activations=False, bf16_wei
             x = conv_lstm2d(x, k, r, b, dil, kwargs.get('padding', 'valid'), act or 'tanh',
                             kwargs.get('recurrent_activation', 'hard_sigmoid'), kwargs.get('return_sequences', False),
                             bf16_storage=bf16_lstm is not None, bf16_kernels=bf16_lstm or (), fused_cell_update=lstm_fused)
+        elif name == 'RowConnected2D':
+            _, _, _, act = _conv_args(args, kwargs)
+            w, b = weights[wi]
+            wi += 1
+            x = row_connected2d(x, w, b, act or 'linear')
         elif name == 'MaxPooling2D':
             x = maxpool2(x)
         elif name == 'UpSampling2D':

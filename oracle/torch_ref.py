@@ -42,6 +42,10 @@ def to_torch_weights(weights, dtype=torch.float32, requires_grad=False):
                        (torch.tensor(np.asarray(b), dtype=dtype, requires_grad=requires_grad),))
             continue
         w, b = item
+        if np.ndim(w) == 5:     # RowConnected2D: (rows, kh, kw, cin, cout) and the stored (rows, 1, cout) bias, kept as stored
+            out.append((torch.tensor(np.asarray(w), dtype=dtype, requires_grad=requires_grad),
+                        torch.tensor(np.asarray(b), dtype=dtype, requires_grad=requires_grad)))
+            continue
         wt = torch.tensor(np.ascontiguousarray(np.transpose(w, (3, 2, 0, 1))), dtype=dtype, requires_grad=requires_grad)
         bt = torch.tensor(np.asarray(b), dtype=dtype, requires_grad=requires_grad)
         out.append((wt, bt))
@@ -70,6 +74,17 @@ def run_layers(layers, x, tweights, record=None):
             wi += 1
             x = F.conv2d(x, w, None, stride=1, padding=0, dilation=dil)
             x = x + b.view(1, -1, 1, 1)
+            if act == 'tanh':
+                x = torch.tanh(x)
+            elif act == 'relu':
+                x = torch.relu(x)
+        elif name == 'RowConnected2D':      # reference DLWP/custom.py:825-896: one convolution per output row, concatenated
+            _, _, _, act = np_ref._conv_args(args, kwargs)
+            w, b = tweights[wi]
+            wi += 1
+            rows, kh = w.shape[0], w.shape[1]
+            x = torch.cat([F.conv2d(x[:, :, r:r + kh, :], w[r].permute(3, 2, 0, 1)) for r in range(rows)], dim=2)
+            x = x + b.reshape(-1).reshape(w.shape[4], rows)[None, :, :, None]       # K.bias_add's reshape (np_ref)
             if act == 'tanh':
                 x = torch.tanh(x)
             elif act == 'relu':
