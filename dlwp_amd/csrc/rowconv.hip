@@ -53,11 +53,20 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // ------------------------------------------------------------------------------------------------------------------ //
 // forward
 // ------------------------------------------------------------------------------------------------------------------ //
-__global__ __launch_bounds__(128) void rowconv2d_fwd_mfma(const RowArgs a) {
+// Staging is latency-bound unless many loads are in flight: every round issues the loads of TWO (sample, channel) planes
+// -- kh rows x NSLOT column slots each -- resp. of two k columns of filters before the first of them is stored to LDS
+// (measured, tools/bench_rowconv.py at 256 x (32, 88, 180) -> 4: one load per wait 4.8 ms, batched rounds 2.2 ms, + straight-
+// line MFMA loop 1.4 ms, + the k sum split over two wave pairs, below).
+constexpr int kKhMax = 5;      // kernel rows the matrix-core kernels unroll (taller kernels: vector kernels)
+
+template <int NSLOT, int C4N>
+__global__ __launch_bounds__(256, 3) void rowconv2d_fwd_mfma(const RowArgs a) {
   extern __shared__ float lds[];
   float* xs = lds;
   float* ws = lds + a.w_off;
-  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  // 4 waves: all of them stage; wave & 1 picks the fragments, wave >> 1 the half of the k steps it multiplies (the two
+  // partial sums meet in LDS at the end) -- twice the waves to hide the staging latency behind, half the serial work each
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), fw = wave & 1, kpar = wave >> 1;
   int b = blockIdx.x;
   const int cb = b % a.n_cb; b /= a.n_cb;
   const int cg = b % a.n_cg; b /= a.n_cg;
@@ -66,75 +75,193 @@ __global__ __launch_bounds__(128) void rowconv2d_fwd_mfma(const RowArgs a) {
   const int P = 1 << a.P_log2, cout_p = 1 << a.cp_log2;
   const int s0 = sg * a.S, x0 = (cb * a.FX * 16) << a.P_log2, co0 = cg * 16;
 
-  // the columns this lane stages, the same for every staged row: source column (halo resolved; -1 = zero) and LDS position
-  // (columns de-interleaved by c mod P, so that the stride-P fragment reads below are contiguous)
-  int ix[kMaxSlots], pos[kMaxSlots];
+  // the columns this lane stages, the same for every staged row: source column (halo resolved; -1 = zero, -2 = none) and
+  // LDS position (columns de-interleaved by c mod P, so that the stride-P fragment reads below are contiguous)
+  int ix[NSLOT], pos[NSLOT];
 #pragma unroll
-  for (int j = 0; j < kMaxSlots; ++j) {
+  for (int j = 0; j < NSLOT; ++j) {
     const int col = lane + 64 * j;
     ix[j] = col < a.TW_in ? dlwp_map_coord_tile(x0 + col - a.pad_left, a.W, a.mode_w) : -2;
     pos[j] = (col & (P - 1)) * a.Q + (col >> a.P_log2);
   }
-  // this wave's fragments: f = wave + 2 i  ->  (sample s, column fragment fx)
+  // the rows this block reads, the same for every plane: source row of kernel row ky (-1 = zero)
+  int iy[kKhMax];
+#pragma unroll
+  for (int ky = 0; ky < kKhMax; ++ky) iy[ky] = ky < a.kh ? dlwp_map_coord_tile(r + ky - a.pad_top, a.H, a.mode_h) : -1;
+  // filter element this lane expands: column of the packed B operand -> (pixel p, channel co); two channel rows per lane
+  // when CK = 8 (lane -> ci = lane >> 4 and ci + 4)
+  const int bcol = lane & 15, bp = bcol >> a.cp_log2, bco = co0 + (bcol & (cout_p - 1)), bci = lane >> 4;
+  // this wave's fragments: f = fw + 2 i  ->  (sample s, column fragment fx)
   const int m = lane & 15, kq = lane >> 4;
   const int n_frag = a.S * a.FX;
   int abase[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int f = min(wave + 2 * i, n_frag - 1);
+    const int f = min(fw + 2 * i, n_frag - 1);
     abase[i] = (f / a.FX) * a.SS + kq * a.PS + (f % a.FX) * 16 + m;
   }
-  const int nf = (n_frag - wave + 1) / 2;     // fragments of this wave (0 .. 3)
+  const int nf = (n_frag - fw + 1) / 2;       // fragments of this wave (0 .. 3)
   f32x4 acc[3] = {};
 
-  const int ck_log2 = a.CK == 8 ? 3 : 2, sc_total = a.S * a.CK, c4n = a.CK >> 2;
-  for (int c0 = 0; c0 < a.Cin; c0 += a.CK) {
-    // ---- stage CK channels x kh rows x TW_in columns of S samples
-    for (int sc = wave; sc < sc_total; sc += 2) {             // (sample, channel) planes, CK a power of two
-      const int ci = sc & (a.CK - 1), s = sc >> ck_log2;
-      const int n = s0 + s, c = c0 + ci;
-      const bool okp = n < a.N && c < a.Cin;
-      const float* plane = a.x + ((size_t)(okp ? n : 0) * a.in_c_total + a.in_c_off + (okp ? c : 0)) * a.H * a.W;
-      float* dplane = xs + s * a.SS + ci * a.PS;
-      for (int ky = 0; ky < a.kh; ++ky) {
-        const int iy = dlwp_map_coord_tile(r + ky - a.pad_top, a.H, a.mode_h);
-        const bool ok = okp && iy >= 0;
-        const float* src = plane + (size_t)(ok ? iy : 0) * a.W;
-        float* dst = dplane + ky * a.RS;
+  constexpr int CK = 4 * C4N, ck_log2 = C4N == 2 ? 3 : 2;      // channels per stage (host: a.CK)
+  constexpr int PB = NSLOT > 4 ? 1 : 2;                        // planes per staging round (registers)
+  const int sc_total = a.S * CK;
+  // Loads go through buffer descriptors: a lane offset beyond num_records reads 0.0 without a branch (zero halo, absent
+  // samples / channels / kernel taps), the plane / kernel row is chosen by the scalar offset.  x: the S samples' channel
+  // windows; w: this row's (kh, kw, cin, cout) filters.
+  constexpr unsigned DROP = 0x7ffffff0u;
+  const unsigned plane_b = (unsigned)a.H * (unsigned)a.W * 4u;
+  const unsigned wrow_b = (unsigned)a.kw * (unsigned)a.Cin * (unsigned)a.Cout * 4u;      // bytes of one kernel row
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + ((size_t)s0 * a.in_c_total + a.in_c_off) * a.H * a.W), 0,
+      (unsigned)min(a.S, a.N - s0) * (unsigned)a.in_c_total * plane_b - (unsigned)a.in_c_off * plane_b, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)r * a.kh * a.kw * a.Cin * a.Cout), 0, (unsigned)a.kh * wrow_b, 0x00020000);
+  unsigned goff[NSLOT];
 #pragma unroll
-        for (int j = 0; j < kMaxSlots; ++j)
-          if (ix[j] != -2) dst[pos[j]] = (ok && ix[j] >= 0) ? src[ix[j]] : 0.f;
+  for (int j = 0; j < NSLOT; ++j) goff[j] = ix[j] >= 0 ? (unsigned)ix[j] * 4u : DROP;
+  // One staging round per chunk and wave (host: S CK <= 4 PB planes, i.e. one per wave and PB slot; the first 8 k columns of
+  // filters): the loads of chunk c + 1 are issued right after the barrier that releases chunk c to the matrix cores and
+  // land in registers while the MFMA loop runs -- both phases are latency-bound per wave, and serialised they add up
+  // (measured at 256 x (32, 88, 180) -> 4: staging alone 0.49 ms, MFMA loop alone 0.49 ms, one after the other 0.85 ms).
+  float v[PB][kKhMax][NSLOT], wv[2][kKhMax][2];
+  float* dplane[PB];
+  auto issue_loads = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int scq = wave + 4 * q;
+      const int ci = scq & (CK - 1), s = scq >> ck_log2;
+      const int c = c0 + ci;
+      const bool okp = scq < sc_total && s0 + s < a.N && c < a.Cin;
+      const unsigned pl = (unsigned)(s * a.in_c_total + c) * plane_b;      // byte offset of the plane in the descriptor
+      dplane[q] = xs + s * a.SS + ci * a.PS;
+#pragma unroll
+      for (int ky = 0; ky < kKhMax; ++ky) {
+        const bool ok = okp && iy[ky] >= 0;
+        const unsigned so = ok ? pl + (unsigned)iy[ky] * (unsigned)a.W * 4u : 0u;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j)
+          v[q][ky][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, ok ? goff[j] : DROP, so, 0));
       }
     }
-    // ---- this row's filters for these channels, expanded to the packed columns: ws[((ky U + u) CK + ci) 16 + column]
-    for (int ky = 0; ky < a.kh; ++ky)
-      for (int u = wave; u < a.U; u += 2) {
-      const int pr = ky * a.U + u;
-      for (int e = lane; e < a.CK * 16; e += 64) {
-        const int col = e & 15, ci = e >> 4;
-        const int p = col >> a.cp_log2, co = col & (cout_p - 1);
-        const int kx = u - p, c = c0 + ci, cog = co0 + co;
-        float v = 0.f;
-        if (kx >= 0 && kx < a.kw && c < a.Cin && cog < a.Cout)
-          v = a.w[((((size_t)r * a.kh + ky) * a.kw + kx) * a.Cin + c) * a.Cout + cog];
-        ws[pr * a.CK * 16 + e] = v;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int u = wave + 4 * q, kx = u - bp;
+      const bool oku = u < a.U && kx >= 0 && kx < a.kw && bco < a.Cout;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int c = c0 + bci + 4 * h2;
+        const bool okc = oku && c < a.Cin && (h2 == 0 || C4N == 2);
+        const unsigned vo = okc ? (unsigned)((kx * a.Cin + c) * a.Cout + bco) * 4u : DROP;
+#pragma unroll
+        for (int ky = 0; ky < kKhMax; ++ky)
+          wv[q][ky][h2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, ky < a.kh ? vo : DROP,
+                                                                                       (unsigned)ky * wrow_b, 0));
+      }
+    }
+  };
+  issue_loads(0);
+  for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+    // ---- the chunk's registers -> LDS: xs[s][ci][ky][de-interleaved column], ws[((ky U + u) CK + ci) 16 + packed column]
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      if (wave + 4 * q >= sc_total) break;
+#pragma unroll
+      for (int ky = 0; ky < kKhMax; ++ky) {
+        if (ky >= a.kh) break;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j)
+          if (ix[j] != -2) dplane[q][ky * a.RS + pos[j]] = v[q][ky][j];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int u = wave + 4 * q;
+      if (u >= a.U) break;
+#pragma unroll
+      for (int ky = 0; ky < kKhMax; ++ky) {
+        if (ky >= a.kh) break;
+        float* dst = ws + (ky * a.U + u) * CK * 16 + lane;
+        dst[0] = wv[q][ky][0];
+        if (C4N == 2) dst[64] = wv[q][ky][1];
+      }
+    }
+    // (more than 8 k columns -- 8 or 16 pixels per instruction row, cout <= 2: the rest is fetched here, unpipelined)
+    for (int u = wave + 8; u < a.U; u += 4) {
+      const int kx = u - bp;
+#pragma unroll
+      for (int h2 = 0; h2 < C4N; ++h2) {
+        const int c = c0 + bci + 4 * h2;
+        const bool okc = kx >= 0 && kx < a.kw && bco < a.Cout && c < a.Cin;
+        const unsigned vo = okc ? (unsigned)((kx * a.Cin + c) * a.Cout + bco) * 4u : DROP;
+        float t[kKhMax];
+#pragma unroll
+        for (int ky = 0; ky < kKhMax; ++ky)
+          t[ky] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, ky < a.kh ? vo : DROP, (unsigned)ky * wrow_b, 0));
+#pragma unroll
+        for (int ky = 0; ky < kKhMax; ++ky)
+          if (ky < a.kh) ws[(ky * a.U + u) * CK * 16 + lane + 64 * h2] = t[ky];
       }
     }
     __syncthreads();
-    int kstep = 0;
-    for (int ky = 0; ky < a.kh; ++ky)
-      for (int u = 0; u < a.U; ++u) {
-        const int soff = ky * a.RS + (u & (P - 1)) * a.Q + (u >> a.P_log2);
-        for (int c4 = 0; c4 < c4n; ++c4, ++kstep) {
-          const float bv = ws[kstep * 64 + lane];
-          const int o = soff + c4 * 4 * a.PS;
+    issue_loads(c0 + CK);      // (past the last chunk every lane offset is out of range: nothing is fetched)
+    // every wave multiplies 3 fragments (a wave that owns fewer repeats its last one; the epilogue drops the copy) over the
+    // (ky, u) pairs of its parity.  Two k columns per iteration, all their LDS reads issued before the first MFMA: a wave
+    // that waits for every operand separately spends ~4 x the matrix time per step (measured: 0.61 -> see DESIGN.md)
+    for (int ky = 0; ky < a.kh; ++ky) {
+      const int rowo = ky * a.RS;
+      const float* wrow = ws + ky * a.U * CK * 16 + lane;
+      int u = (kpar + ky * a.U) & 1;
+      for (; u + 2 < a.U; u += 4) {
+        float bv[2][C4N], av[2][C4N][3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
-            if (i < nf) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[abase[i] + o], bv, acc[i], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+          const int uu = u + 2 * h;
+          const int soff = rowo + (uu & (P - 1)) * a.Q + (uu >> a.P_log2);
+#pragma unroll
+          for (int c4 = 0; c4 < C4N; ++c4) {
+            bv[h][c4] = wrow[(uu * C4N + c4) * 64];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) av[h][c4][i] = xs[abase[i] + soff + c4 * 4 * a.PS];
+          }
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int c4 = 0; c4 < C4N; ++c4)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][c4][i], bv[h][c4], acc[i], 0, 0, 0);
       }
+      for (; u < a.U; u += 2) {
+        const int soff = rowo + (u & (P - 1)) * a.Q + (u >> a.P_log2);
+        float bv[C4N], av[C4N][3];
+#pragma unroll
+        for (int c4 = 0; c4 < C4N; ++c4) {
+          bv[c4] = wrow[(u * C4N + c4) * 64];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) av[c4][i] = xs[abase[i] + soff + c4 * 4 * a.PS];
+        }
+#pragma unroll
+        for (int c4 = 0; c4 < C4N; ++c4)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c4][i], bv[c4], acc[i], 0, 0, 0);
+      }
+    }
     __syncthreads();
   }
+  // ---- the two halves of the k sum meet: waves 2, 3 hand theirs over through LDS (the staging area is free now)
+  if (kpar == 1) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xs[((fw * 3 + i) * 4 + j) * 64 + lane] = acc[i][j];
+  }
+  __syncthreads();
+  if (kpar == 1) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] += xs[((fw * 3 + i) * 4 + j) * 64 + lane];
   // ---- epilogue: lane holds rows 4 (lane >> 4) + j of column lane & 15
   const int col = lane & 15, p = col >> a.cp_log2, co = col & (cout_p - 1), cog = co0 + co;
   if (cog >= a.Cout) return;
@@ -142,7 +269,7 @@ __global__ __launch_bounds__(128) void rowconv2d_fwd_mfma(const RowArgs a) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (i >= nf) break;
-    const int f = wave + 2 * i, s = f / a.FX, fx = f % a.FX, n = s0 + s;
+    const int f = fw + 2 * i, s = f / a.FX, fx = f % a.FX, n = s0 + s;
     if (n >= a.N) continue;
     float* yr = a.y + (((size_t)n * a.out_c_total + a.out_c_off + cog) * a.Ho + r) * a.Wo;
 #pragma unroll
@@ -182,7 +309,8 @@ __global__ void rowconv2d_fwd_simple(const RowArgs a) {
 // data gradient on the PADDED grid: dxp[n, ci, py, px] = sum_{ky, kx, co} dz[n, co, py - ky, px - kx] w[py - ky][ky][kx][ci][co]
 // (the halo is folded back onto the stored tensor by dlwp_pad2d_bwd afterwards)
 // ------------------------------------------------------------------------------------------------------------------ //
-__global__ __launch_bounds__(128) void rowconv2d_dgrad_mfma(const RowArgs a) {
+template <int NF>
+__global__ __launch_bounds__(128, 3) void rowconv2d_dgrad_mfma(const RowArgs a) {
   extern __shared__ float lds[];
   float* zs = lds;                 // [s][co][ky][col], col <-> output column x0 - (kw - 1) + col
   float* ws = lds + a.w_off;       // [kstep][nf][kq][ci]
@@ -192,41 +320,82 @@ __global__ __launch_bounds__(128) void rowconv2d_dgrad_mfma(const RowArgs a) {
   const int cg = b % a.n_cg; b /= a.n_cg;
   const int sg = b % a.n_sg; b /= a.n_sg;
   const int py = b;
-  const int s0 = sg * a.S, x0 = cb * a.FX * 16, ci0 = cg * a.NF * 16;
+  const int s0 = sg * a.S, x0 = cb * a.FX * 16, ci0 = cg * NF * 16;
   const int cpad = a.CK;           // cout rounded up to a multiple of 4
-  // ---- dz rows py - ky of S samples
-  for (int s = 0; s < a.S; ++s)
-    for (int co = wave; co < cpad; co += 2) {
-      const int n = s0 + s;
-      const bool okp = n < a.N && co < a.Cout;
-      const float* plane = a.dz + ((size_t)(okp ? n : 0) * a.out_c_total + a.out_c_off + (okp ? co : 0)) * a.Ho * a.Wo;
-      for (int ky = 0; ky < a.kh; ++ky) {
+  constexpr unsigned DROP = 0x7ffffff0u;
+  // ---- dz rows py - ky of S samples, through a buffer descriptor over the S samples' channel windows (out-of-range lane
+  //      offsets read 0.0): all kh rows x 2 column slots of TWO (sample, channel) planes are in flight per round
+  const unsigned zplane_b = (unsigned)a.Ho * (unsigned)a.Wo * 4u;
+  const __amdgpu_buffer_rsrc_t z_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.dz + ((size_t)s0 * a.out_c_total + a.out_c_off) * a.Ho * a.Wo), 0,
+      (unsigned)min(a.S, a.N - s0) * (unsigned)a.out_c_total * zplane_b - (unsigned)a.out_c_off * zplane_b, 0x00020000);
+  unsigned goff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ox = x0 - (a.kw - 1) + lane + 64 * j;
+    goff[j] = (lane + 64 * j < a.TW_in && ox >= 0 && ox < a.Wo) ? (unsigned)ox * 4u : DROP;
+  }
+  const int planes = a.S * cpad;
+  for (int pc = wave; pc < planes; pc += 4) {
+    float v[2][kKhMax][2];
+    float* dplane[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int pq = pc + 2 * q, s = pq / cpad, co = pq - s * cpad;
+      const bool okp = pq < planes && s0 + s < a.N && co < a.Cout;
+      const unsigned pl = (unsigned)(s * a.out_c_total + co) * zplane_b;
+      dplane[q] = zs + s * a.SS + co * a.PS;
+#pragma unroll
+      for (int ky = 0; ky < kKhMax; ++ky) {
         const int r = py - ky;
-        const bool ok = okp && r >= 0 && r < a.Ho;
-        const float* src = plane + (size_t)(ok ? r : 0) * a.Wo;
-        float* dst = zs + s * a.SS + co * a.PS + ky * a.RS;
-        for (int col = lane; col < a.TW_in; col += 64) {
-          const int ox = x0 - (a.kw - 1) + col;
-          dst[col] = (ok && ox >= 0 && ox < a.Wo) ? src[ox] : 0.f;
-        }
+        const bool ok = okp && ky < a.kh && r >= 0 && r < a.Ho;
+        const unsigned so = ok ? pl + (unsigned)r * (unsigned)a.Wo * 4u : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          v[q][ky][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? goff[j] : DROP, so, 0));
       }
     }
-  // ---- filters of the rows that reach py: ws[(((ky kw + kx) C4 + c4) NF + nf) 64 + kq 16 + ci]
-  const int c4n = cpad >> 2;
-  for (int ky = 0; ky < a.kh; ++ky) {
-    const int r = py - ky;
-    for (int kx = wave; kx < a.kw; kx += 2)
-      for (int c4 = 0; c4 < c4n; ++c4) {
-        const int ks = (ky * a.kw + kx) * c4n + c4;
-        const int co = c4 * 4 + (lane >> 4);
-        for (int g = 0; g < a.NF; ++g) {
-          const int c = ci0 + g * 16 + (lane & 15);
-          float v = 0.f;
-          if (r >= 0 && r < a.Ho && co < a.Cout && c < a.Cin)
-            v = a.w[((((size_t)r * a.kh + ky) * a.kw + kx) * a.Cin + c) * a.Cout + co];
-          ws[(ks * a.NF + g) * 64 + lane] = v;
-        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (pc + 2 * q >= planes) break;
+#pragma unroll
+      for (int ky = 0; ky < kKhMax; ++ky) {
+        if (ky >= a.kh) break;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (lane + 64 * j < a.TW_in) dplane[q][ky * a.RS + lane + 64 * j] = v[q][ky][j];
       }
+    }
+  }
+  // ---- filters of the rows that reach py: ws[(((ky kw + kx) C4 + c4) NF + g) 64 + kq 16 + ci]; one (kx, c4) pair per
+  //      round: kh rows x NF channel groups in flight
+  const int c4n = cpad >> 2;
+  const unsigned tap_b = (unsigned)a.Cin * (unsigned)a.Cout * 4u;
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)a.Ho * (unsigned)a.kh * (unsigned)a.kw * tap_b, 0x00020000);
+  for (int t = wave; t < a.kw * c4n; t += 2) {
+    const int kx = t / c4n, c4 = t - kx * c4n;
+    const int co = c4 * 4 + (lane >> 4);
+    float wv[kKhMax][NF];
+#pragma unroll
+    for (int g = 0; g < NF; ++g) {
+      const int c = ci0 + g * 16 + (lane & 15);
+      const unsigned vo = (co < a.Cout && c < a.Cin) ? (unsigned)(c * a.Cout + co) * 4u : DROP;
+#pragma unroll
+      for (int ky = 0; ky < kKhMax; ++ky) {
+        const int r = py - ky;
+        const bool ok = ky < a.kh && r >= 0 && r < a.Ho;
+        wv[ky][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  w_rsrc, ok ? vo : DROP, ok ? (unsigned)((r * a.kh + ky) * a.kw + kx) * tap_b : 0u, 0));
+      }
+    }
+#pragma unroll
+    for (int ky = 0; ky < kKhMax; ++ky) {
+      if (ky >= a.kh) break;
+      const int ks = (ky * a.kw + kx) * c4n + c4;
+#pragma unroll
+      for (int g = 0; g < NF; ++g) ws[(ks * NF + g) * 64 + lane] = wv[ky][g];
+    }
   }
   __syncthreads();
   const int m = lane & 15, kq = lane >> 4;
@@ -238,33 +407,34 @@ __global__ __launch_bounds__(128) void rowconv2d_dgrad_mfma(const RowArgs a) {
     abase[i] = (f / a.FX) * a.SS + kq * a.PS + (f % a.FX) * 16 + m + (a.kw - 1);
   }
   const int nfr = (n_frag - wave + 1) / 2;
-  f32x4 acc[3][2] = {};
-  int kstep = 0;
+  // every wave multiplies 3 fragments (one that owns fewer repeats its last; the copy is dropped below): straight-line body
+  f32x4 acc[3][NF] = {};
   for (int ky = 0; ky < a.kh; ++ky)
-    for (int kx = 0; kx < a.kw; ++kx)
-      for (int c4 = 0; c4 < c4n; ++c4, ++kstep) {
-        const int o = c4 * 4 * a.PS + ky * a.RS - kx;
-        float bv[2];
+    for (int kx = 0; kx < a.kw; ++kx) {
+      const float* wk = ws + (ky * a.kw + kx) * c4n * NF * 64 + lane;
+      const int o0 = ky * a.RS - kx;
+      for (int c4 = 0; c4 < c4n; ++c4) {
+        const int o = o0 + c4 * 4 * a.PS;
+        float bv[NF];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) bv[g] = g < a.NF ? ws[(kstep * a.NF + g) * 64 + lane] : 0.f;
+        for (int g = 0; g < NF; ++g) bv[g] = wk[(c4 * NF + g) * 64];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-          if (i < nfr) {
-            const float av = zs[abase[i] + o];
+        for (int i = 0; i < 3; ++i) {
+          const float av = zs[abase[i] + o];
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-              if (g < a.NF) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[g], acc[i][g], 0, 0, 0);
-          }
+          for (int g = 0; g < NF; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[g], acc[i][g], 0, 0, 0);
+        }
       }
+    }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (i >= nfr) break;
     const int f = wave + 2 * i, s = f / a.FX, fx = f % a.FX, n = s0 + s;
     if (n >= a.N) continue;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NF; ++g) {
       const int c = ci0 + g * 16 + m;
-      if (g >= a.NF || c >= a.Cin) continue;
+      if (c >= a.Cin) continue;
       float* dr = a.y + (((size_t)n * a.Cin + c) * a.Hp + py) * a.Wp;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -303,7 +473,8 @@ __global__ void rowconv2d_dgrad_simple(const RowArgs a) {
 // weight gradient: one workgroup per (row r, ky, M group, cout group); D[(kx, ci), co] = sum_{n, ox} xp[n, ci, r + ky, ox + kx]
 // dz[n, co, r, ox], samples and columns in a fixed order
 // ------------------------------------------------------------------------------------------------------------------ //
-__global__ __launch_bounds__(256) void rowconv2d_wgrad_mfma(const RowArgs a) {
+template <int NSLOT>
+__global__ __launch_bounds__(256, 2) void rowconv2d_wgrad_mfma(const RowArgs a) {
   extern __shared__ float lds[];
   float* xs = lds;              // [ci (cin padded to 16)][col], col <-> padded column
   float* zs = lds + a.w_off;    // [co (16)][ox]
@@ -318,11 +489,17 @@ __global__ __launch_bounds__(256) void rowconv2d_wgrad_mfma(const RowArgs a) {
   const int m_total = a.kw * C16;                       // M fragments of the (kx, ci) axis
   const int mf0 = mg * a.NF;
   const int n_frag = min(a.NF, m_total - mf0);          // this workgroup's fragments, 3 per wave at most
-  int ix[kMaxSlots];
+  constexpr unsigned DROP = 0x7ffffff0u;
+  const int iy = dlwp_map_coord_tile(r + ky - a.pad_top, a.H, a.mode_h);
+  const int ksteps = (a.Wo + 3) >> 2, wo4 = ksteps * 4;
+  // lane offsets of the column slots (0.0 beyond the descriptors: zero halo, columns past Wo)
+  unsigned xoff[NSLOT], zoff[NSLOT];
 #pragma unroll
-  for (int j = 0; j < kMaxSlots; ++j) {
+  for (int j = 0; j < NSLOT; ++j) {
     const int col = lane + 64 * j;
-    ix[j] = col < a.TW_in ? dlwp_map_coord_tile(col - a.pad_left, a.W, a.mode_w) : -2;
+    const int ixx = col < a.TW_in ? dlwp_map_coord_tile(col - a.pad_left, a.W, a.mode_w) : -1;
+    xoff[j] = (ixx >= 0 && iy >= 0) ? (unsigned)ixx * 4u : DROP;
+    zoff[j] = col < a.Wo ? (unsigned)col * 4u : DROP;
   }
   const int m = lane & 15, kq = lane >> 4;
   int abase[3];
@@ -334,29 +511,57 @@ __global__ __launch_bounds__(256) void rowconv2d_wgrad_mfma(const RowArgs a) {
   const int nfr = n_frag > wave ? (n_frag - wave + 3) / 4 : 0;
   const int zbase = m * a.PS + kq;
   f32x4 acc[3] = {};
-  const int iy = dlwp_map_coord_tile(r + ky - a.pad_top, a.H, a.mode_h);
-  const int ksteps = (a.Wo + 3) >> 2, wo4 = ksteps * 4;
+  const unsigned xplane_b = (unsigned)a.H * (unsigned)a.W * 4u, zplane_b = (unsigned)a.Ho * (unsigned)a.Wo * 4u;
+  const unsigned xrow_b = (unsigned)max(iy, 0) * (unsigned)a.W * 4u, zrow_b = (unsigned)r * (unsigned)a.Wo * 4u;
   for (int n = 0; n < a.N; ++n) {
-    for (int c = wave; c < cin_pad; c += 4) {
-      const bool ok = c < a.Cin && iy >= 0;
-      const float* src = a.x + (((size_t)n * a.in_c_total + a.in_c_off + (ok ? c : 0)) * a.H + (ok ? iy : 0)) * a.W;
-      float* dst = xs + c * a.PS;
+    // one sample's channel window per descriptor; 4 channel rows (x) resp. 4 channel rows of dz in flight per round
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + ((size_t)n * a.in_c_total + a.in_c_off) * a.H * a.W), 0, (unsigned)a.Cin * xplane_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t z_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.dz + ((size_t)n * a.out_c_total + a.out_c_off + co0) * a.Ho * a.Wo), 0,
+        (unsigned)min(16, a.Cout - co0) * zplane_b, 0x00020000);
+    for (int c0 = wave; c0 < cin_pad; c0 += 16) {
+      float v[4][NSLOT];
 #pragma unroll
-      for (int j = 0; j < kMaxSlots; ++j)
-        if (ix[j] != -2) dst[lane + 64 * j] = (ok && ix[j] >= 0) ? src[ix[j]] : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + 4 * q;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j)
+          v[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, c < a.Cin ? xoff[j] : DROP,
+                                                                                   (unsigned)min(c, a.Cin - 1) * xplane_b + xrow_b, 0));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + 4 * q;
+        if (c >= cin_pad) break;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j)
+          if (lane + 64 * j < a.TW_in) xs[c * a.PS + lane + 64 * j] = v[q][j];
+      }
     }
-    for (int co = wave; co < 16; co += 4) {
-      const bool ok = co0 + co < a.Cout;
-      const float* src = a.dz + (((size_t)n * a.out_c_total + a.out_c_off + (ok ? co0 + co : 0)) * a.Ho + r) * a.Wo;
-      float* dst = zs + co * a.PS;
-      for (int ox = lane; ox < wo4; ox += 64) dst[ox] = (ok && ox < a.Wo) ? src[ox] : 0.f;
+    {
+      float v[4][NSLOT];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = wave + 4 * q;
+        const bool ok = co0 + co < a.Cout;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j)
+          v[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? zoff[j] : DROP,
+                                                                                   (ok ? (unsigned)co * zplane_b : 0u) + zrow_b, 0));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j)
+          if (lane + 64 * j < wo4) zs[(wave + 4 * q) * a.PS + lane + 64 * j] = v[q][j];
     }
     __syncthreads();
+    // every wave multiplies 3 fragments (one that owns fewer repeats its last): straight-line body
     for (int kc = 0; kc < ksteps; ++kc) {
       const float bv = zs[zbase + 4 * kc];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-        if (i < nfr) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[abase[i] + 4 * kc], bv, acc[i], 0, 0, 0);
+      for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[abase[i] + 4 * kc], bv, acc[i], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -489,7 +694,7 @@ size_t plan_fwd(RowArgs& a) {
   if (a.S > a.N) a.S = a.N > 0 ? a.N : 1;
   a.n_sg = dlwp_ceil_div(a.N, a.S);
   a.TW_in = a.FX * 16 * P + a.kw - 1;
-  if (a.TW_in > 64 * kMaxSlots) return 0;
+  if (a.TW_in > 64 * kMaxSlots || a.kh > kKhMax) return 0;
   const int q_min = a.FX * 16 + ((a.U - 1) >> a.P_log2) + 1;
   // staging writes 32 consecutive columns = 32 / P consecutive positions in each of the P groups: a group stride that is an
   // odd multiple of 32 / P keeps the groups on disjoint banks
@@ -500,11 +705,17 @@ size_t plan_fwd(RowArgs& a) {
   }
   a.RS = a.Q * P;
   a.PS = round_mod32(a.kh * a.RS, 16);
+  const int plane_cap = dlwp_ceil_div(a.TW_in, 64) > 4 ? 4 : 8;   // (sample, channel) planes of one staging round (registers)
+  if (a.S > plane_cap / 4) {
+    a.S = plane_cap / 4;
+    a.n_sg = dlwp_ceil_div(a.N, a.S);
+  }
   for (a.CK = 8; a.CK >= 4; a.CK -= 4) {
-    if (a.CK == 8 && a.Cin <= 4) continue;
+    if ((a.CK == 8 && a.Cin <= 4) || a.S * a.CK > plane_cap) continue;
     a.SS = a.CK * a.PS;
     a.w_off = a.S * a.SS;
-    const size_t bytes = ((size_t)a.w_off + (size_t)a.kh * a.U * a.CK * 16) * sizeof(float);
+    size_t bytes = ((size_t)a.w_off + (size_t)a.kh * a.U * a.CK * 16) * sizeof(float);
+    if (bytes < 2 * 3 * 4 * 64 * sizeof(float)) bytes = 2 * 3 * 4 * 64 * sizeof(float);    // the k halves' hand-over area
     if (bytes <= (size_t)kLdsBudget) return bytes;
   }
   return 0;
@@ -528,6 +739,7 @@ size_t plan_dgrad(RowArgs& a) {
   a.SS = a.CK * a.PS;
   a.w_off = a.S * a.SS;
   const size_t bytes = ((size_t)a.w_off + (size_t)a.kh * a.kw * (a.CK / 4) * a.NF * 64) * sizeof(float);
+  if (a.kh > kKhMax || (double)a.Ho * a.kh * a.kw * a.Cin * a.Cout * 4.0 >= 2.0e9) return 0;    // unrolled rows; 32-bit descriptor offsets
   return bytes <= (size_t)kLdsBudget ? bytes : 0;
 }
 
@@ -577,11 +789,23 @@ int dlwp_rowconv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void
     DLWP_LAUNCH_CHECK("rowconv2d_fwd_simple");
     return DLWP_OK;
   }
-  DLWP_HIP((hipError_t)set_lds(rowconv2d_fwd_mfma, lds));
   const long long grid = (long long)a.Ho * a.n_sg * a.n_cg * a.n_cb;
   DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_rowconv2d_fwd: grid too large");
-  hipLaunchKernelGGL(rowconv2d_fwd_mfma, dim3((unsigned)grid), dim3(128), lds, s, a);
-  DLWP_LAUNCH_CHECK("rowconv2d_fwd_mfma");
+  const int slots = dlwp_ceil_div(a.TW_in, 64);
+  auto launch = [&](auto kernel) -> int {
+    DLWP_HIP((hipError_t)set_lds(kernel, lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    DLWP_LAUNCH_CHECK("rowconv2d_fwd_mfma");
+    return DLWP_OK;
+  };
+  if (a.CK == 8) {
+    if (slots <= 2) return launch(rowconv2d_fwd_mfma<2, 2>);
+    if (slots <= 4) return launch(rowconv2d_fwd_mfma<4, 2>);
+    return launch(rowconv2d_fwd_mfma<kMaxSlots, 2>);
+  }
+  if (slots <= 2) return launch(rowconv2d_fwd_mfma<2, 1>);
+  if (slots <= 4) return launch(rowconv2d_fwd_mfma<4, 1>);
+  return launch(rowconv2d_fwd_mfma<kMaxSlots, 1>);
   return DLWP_OK;
 }
 
@@ -633,10 +857,15 @@ int dlwp_rowconv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void
     hipLaunchKernelGGL(rowconv2d_dgrad_simple, dim3(grid_1d((long long)a.N * a.Cin * a.Hp * a.Wp, 256)), dim3(256), 0, s, a);
     DLWP_LAUNCH_CHECK("rowconv2d_dgrad_simple");
   } else {
-    DLWP_HIP((hipError_t)set_lds(rowconv2d_dgrad_mfma, lds));
     const long long grid = (long long)a.Hp * a.n_sg * a.n_cg * a.n_cb;
     DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_rowconv2d_bwd_data: grid too large");
-    hipLaunchKernelGGL(rowconv2d_dgrad_mfma, dim3((unsigned)grid), dim3(128), lds, s, a);
+    if (a.NF == 2) {
+      DLWP_HIP((hipError_t)set_lds(rowconv2d_dgrad_mfma<2>, lds));
+      hipLaunchKernelGGL(rowconv2d_dgrad_mfma<2>, dim3((unsigned)grid), dim3(128), lds, s, a);
+    } else {
+      DLWP_HIP((hipError_t)set_lds(rowconv2d_dgrad_mfma<1>, lds));
+      hipLaunchKernelGGL(rowconv2d_dgrad_mfma<1>, dim3((unsigned)grid), dim3(128), lds, s, a);
+    }
     DLWP_LAUNCH_CHECK("rowconv2d_dgrad_mfma");
   }
   if (need) return dlwp_pad2d_bwd(h, ws, dx, xs.n * xs.c, xs.h, xs.w, 1, cd->halo, DLWP_F32, stream);
@@ -658,11 +887,16 @@ int dlwp_rowconv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, vo
                        0, s, a);
     DLWP_LAUNCH_CHECK("rowconv2d_wgrad_simple");
   } else {
-    DLWP_HIP((hipError_t)set_lds(rowconv2d_wgrad_mfma, lds));
     const long long grid = (long long)a.Ho * a.kh * a.n_cg * a.n_mg;
     DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_rowconv2d_bwd_weight: grid too large");
-    hipLaunchKernelGGL(rowconv2d_wgrad_mfma, dim3((unsigned)grid), dim3(256), lds, s, a);
-    DLWP_LAUNCH_CHECK("rowconv2d_wgrad_mfma");
+    const int slots = dlwp_ceil_div(a.TW_in, 64);
+    auto launch = [&](auto kernel) -> int {
+      DLWP_HIP((hipError_t)set_lds(kernel, lds));
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+      DLWP_LAUNCH_CHECK("rowconv2d_wgrad_mfma");
+      return DLWP_OK;
+    };
+    if (int rc = slots <= 3 ? launch(rowconv2d_wgrad_mfma<3>) : launch(rowconv2d_wgrad_mfma<kMaxSlots>)) return rc;
   }
   if (db) {
     hipLaunchKernelGGL(rowconv2d_bias_grad, dim3((unsigned)(a.Cout * a.Ho)), dim3(256), 0, s, a);
