@@ -473,7 +473,10 @@ __global__ void rowconv2d_dgrad_simple(const RowArgs a) {
 // weight gradient: one workgroup per (row r, ky, M group, cout group); D[(kx, ci), co] = sum_{n, ox} xp[n, ci, r + ky, ox + kx]
 // dz[n, co, r, ox], samples and columns in a fixed order
 // ------------------------------------------------------------------------------------------------------------------ //
-template <int NSLOT>
+// XR = channel rows of x a wave fetches per sample (cin padded to 16, / 4 waves): 4 or 8 -> the NEXT sample's rows are
+// fetched into registers while this sample's k loop runs (as the forward kernel does per chunk); 0 -> any channel count,
+// rounds of 4 rows fetched and stored before the k loop.
+template <int NSLOT, int XR>
 __global__ __launch_bounds__(256, 2) void rowconv2d_wgrad_mfma(const RowArgs a) {
   extern __shared__ float lds[];
   float* xs = lds;              // [ci (cin padded to 16)][col], col <-> padded column
@@ -513,52 +516,96 @@ __global__ __launch_bounds__(256, 2) void rowconv2d_wgrad_mfma(const RowArgs a) 
   f32x4 acc[3] = {};
   const unsigned xplane_b = (unsigned)a.H * (unsigned)a.W * 4u, zplane_b = (unsigned)a.Ho * (unsigned)a.Wo * 4u;
   const unsigned xrow_b = (unsigned)max(iy, 0) * (unsigned)a.W * 4u, zrow_b = (unsigned)r * (unsigned)a.Wo * 4u;
-  for (int n = 0; n < a.N; ++n) {
-    // one sample's channel window per descriptor; 4 channel rows (x) resp. 4 channel rows of dz in flight per round
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.x + ((size_t)n * a.in_c_total + a.in_c_off) * a.H * a.W), 0, (unsigned)a.Cin * xplane_b, 0x00020000);
-    const __amdgpu_buffer_rsrc_t z_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.dz + ((size_t)n * a.out_c_total + a.out_c_off + co0) * a.Ho * a.Wo), 0,
-        (unsigned)min(16, a.Cout - co0) * zplane_b, 0x00020000);
-    for (int c0 = wave; c0 < cin_pad; c0 += 16) {
-      float v[4][NSLOT];
+  // one sample's channel window per descriptor (a sample past the batch: zero records, everything reads 0.0)
+  auto x_desc = [&](int n) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((size_t)min(n, a.N - 1) * a.in_c_total + a.in_c_off) * a.H * a.W), 0,
+                                             n < a.N ? (unsigned)a.Cin * xplane_b : 0u, 0x00020000);
+  };
+  auto z_desc = [&](int n) {
+    return __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.dz + ((size_t)min(n, a.N - 1) * a.out_c_total + a.out_c_off + co0) * a.Ho * a.Wo), 0,
+        n < a.N ? (unsigned)min(16, a.Cout - co0) * zplane_b : 0u, 0x00020000);
+  };
+  constexpr int XRR = XR > 0 ? XR : 4;
+  float xv[XRR][NSLOT], zv[4][NSLOT];
+  auto issue_z = [&](int n) {
+    const __amdgpu_buffer_rsrc_t z_rsrc = z_desc(n);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = c0 + 4 * q;
+    for (int q = 0; q < 4; ++q) {
+      const int co = wave + 4 * q;
+      const bool ok = co0 + co < a.Cout;
 #pragma unroll
-        for (int j = 0; j < NSLOT; ++j)
-          v[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, c < a.Cin ? xoff[j] : DROP,
-                                                                                   (unsigned)min(c, a.Cin - 1) * xplane_b + xrow_b, 0));
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = c0 + 4 * q;
-        if (c >= cin_pad) break;
-#pragma unroll
-        for (int j = 0; j < NSLOT; ++j)
-          if (lane + 64 * j < a.TW_in) xs[c * a.PS + lane + 64 * j] = v[q][j];
-      }
+      for (int j = 0; j < NSLOT; ++j)
+        zv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? zoff[j] : DROP,
+                                                                                  (ok ? (unsigned)co * zplane_b : 0u) + zrow_b, 0));
     }
-    {
-      float v[4][NSLOT];
+  };
+  auto issue_x = [&](int n, int c0) {      // rows c0 + 4 q
+    const __amdgpu_buffer_rsrc_t x_rsrc = x_desc(n);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = wave + 4 * q;
-        const bool ok = co0 + co < a.Cout;
+    for (int q = 0; q < XRR; ++q) {
+      const int c = c0 + 4 * q;
 #pragma unroll
-        for (int j = 0; j < NSLOT; ++j)
-          v[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? zoff[j] : DROP,
-                                                                                   (ok ? (unsigned)co * zplane_b : 0u) + zrow_b, 0));
+      for (int j = 0; j < NSLOT; ++j)
+        xv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, c < a.Cin ? xoff[j] : DROP,
+                                                                                  (unsigned)min(c, a.Cin - 1) * xplane_b + xrow_b, 0));
+    }
+  };
+  auto store_x = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q < XRR; ++q) {
+      const int c = c0 + 4 * q;
+      if (c >= cin_pad) break;
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j)
+        if (lane + 64 * j < a.TW_in) xs[c * a.PS + lane + 64 * j] = xv[q][j];
+    }
+  };
+  auto store_z = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < NSLOT; ++j)
+        if (lane + 64 * j < wo4) zs[(wave + 4 * q) * a.PS + lane + 64 * j] = zv[q][j];
+  };
+  if (XR > 0) {
+    issue_x(0, wave);
+    issue_z(0);
+  }
+  for (int n = 0; n < a.N; ++n) {
+    if (XR > 0) {
+      store_x(wave);
+      store_z();
+    } else {
+      for (int c0 = wave; c0 < cin_pad; c0 += 16) {
+        issue_x(n, c0);
+        store_x(c0);
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < NSLOT; ++j)
-          if (lane + 64 * j < wo4) zs[(wave + 4 * q) * a.PS + lane + 64 * j] = v[q][j];
+      issue_z(n);
+      store_z();
     }
     __syncthreads();
-    // every wave multiplies 3 fragments (one that owns fewer repeats its last): straight-line body
-    for (int kc = 0; kc < ksteps; ++kc) {
+    if (XR > 0) {      // the next sample's rows: in flight during the k loop
+      issue_x(n + 1, wave);
+      issue_z(n + 1);
+    }
+    // every wave multiplies 3 fragments (one that owns fewer repeats its last); two k steps per iteration, their 8 LDS
+    // reads issued before the first MFMA
+    int kc = 0;
+    for (; kc + 1 < ksteps; kc += 2) {
+      float bv[2], av[2][3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bv[h] = zs[zbase + 4 * (kc + h)];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) av[h][i] = xs[abase[i] + 4 * (kc + h)];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][i], bv[h], acc[i], 0, 0, 0);
+    }
+    if (kc < ksteps) {
       const float bv = zs[zbase + 4 * kc];
 #pragma unroll
       for (int i = 0; i < 3; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[abase[i] + 4 * kc], bv, acc[i], 0, 0, 0);
@@ -896,7 +943,13 @@ int dlwp_rowconv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, vo
       DLWP_LAUNCH_CHECK("rowconv2d_wgrad_mfma");
       return DLWP_OK;
     };
-    if (int rc = slots <= 3 ? launch(rowconv2d_wgrad_mfma<3>) : launch(rowconv2d_wgrad_mfma<kMaxSlots>)) return rc;
+    const int xr = a.Cin <= 16 ? 4 : (a.Cin <= 32 ? 8 : 0);     // channel rows per wave and sample held in registers
+    int rc;
+    if (slots <= 3)
+      rc = xr == 4 ? launch(rowconv2d_wgrad_mfma<3, 4>) : (xr == 8 ? launch(rowconv2d_wgrad_mfma<3, 8>) : launch(rowconv2d_wgrad_mfma<3, 0>));
+    else
+      rc = xr == 4 ? launch(rowconv2d_wgrad_mfma<kMaxSlots, 4>) : launch(rowconv2d_wgrad_mfma<kMaxSlots, 0>);
+    if (rc) return rc;
   }
   if (db) {
     hipLaunchKernelGGL(rowconv2d_bias_grad, dim3((unsigned)(a.Cout * a.Ho)), dim3(256), 0, s, a);
