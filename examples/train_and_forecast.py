@@ -4,7 +4,7 @@ The reference's examples/train.py + examples/plot_forecasts.py flow (non-recurre
 imports, on synthetic data (the reanalysis files are not part of either repository).  Only two things differ from a
 reference script: the first import line, and ArrayDataset standing in for xarray.open_dataset.
 
-    python examples/train_and_forecast.py [--grid 36x72] [--samples 256] [--epochs 3]
+    python examples/train_and_forecast.py [--grid 36x72] [--samples 256] [--epochs 3] [--latitude-dependent]
 """
 import argparse
 import os
@@ -30,6 +30,8 @@ def main():
     ap.add_argument('--epochs', type=int, default=3)
     ap.add_argument('--batch-size', type=int, default=64)
     ap.add_argument('--model-file', default='/tmp/dlwp_amd_example')
+    ap.add_argument('--latitude-dependent', action='store_true',
+                    help="the output layer is DLWP.custom.RowConnected2D (examples/train_functional.py:53, 191-196)")
     a = ap.parse_args()
     lat, lon = (int(v) for v in a.grid.split('x'))
 
@@ -62,7 +64,11 @@ def main():
     layers += [('MaxPooling2D', (2,), dict(cf))] + list(block(1, 128, 3, 1, 'tanh'))
     layers += [('UpSampling2D', (2,), dict(cf))] + list(block(1, 64, 3, 1, 'tanh'))
     layers += [('UpSampling2D', (2,), dict(cf))] + list(block(2, 32, 3, 2, 'tanh'))
-    layers += list(block(2, cs[0], 5, 1, 'linear'))
+    if a.latitude_dependent:        # per-latitude filters in the output layer (examples/train_functional.py:191-196)
+        layers += [('PeriodicPadding2D', ((0, 2),), dict(cf)), ('ZeroPadding2D', ((2, 0),), dict(cf)),
+                   ('RowConnected2D', (cs[0], 5), dict(cf, padding='valid', activation='linear'))]
+    else:
+        layers += list(block(2, cs[0], 5, 1, 'linear'))
     try:
         dlwp.build_model(tuple(layers), loss=mean_squared_error, optimizer='adam', metrics=['mae'], gpus=1)
     except ValueError:

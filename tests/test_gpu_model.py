@@ -794,6 +794,15 @@ def test_reference_style_example_script_runs_end_to_end(tmp_path):
     finally:
         sys.argv = argv
     assert len(score) == 2 and np.isfinite(score[0]) and series.shape == (8, 12, 2, 16, 24)
+    # ... and with the reference's `latitude_dependent` switch: RowConnected2D as the output layer, looked up by name in
+    # DLWP.custom, trained, saved, reloaded and rolled out
+    sys.argv = ['x', '--grid', '16x24', '--samples', '48', '--epochs', '2', '--batch-size', '16', '--model-file',
+                os.path.join(str(tmp_path), 'mrow'), '--latitude-dependent']
+    try:
+        score, series = mod.main()
+    finally:
+        sys.argv = argv
+    assert len(score) == 2 and np.isfinite(score[0]) and series.shape == (8, 12, 2, 16, 24)
 
 
 def test_custom_losses_match_reference_goldens_and_autograd(golden):
