@@ -418,6 +418,29 @@ def sub_cfg4(members=8, forwards=4):
             'launches_per_forward': net.infer_plan.n_launches, 'finite': bool(torch.isfinite(ser[-1]).all().item())}
 
 
+def sub_row_connected(grid, cin, members, forwards):
+    """The same U-Net with the reference's `latitude_dependent` output layer (DLWP.custom.RowConnected2D, per-latitude filters:
+    examples/train_functional.py:53, 191-196; csrc/rowconv.hip), same rollout.  Per-pass timings: tools/bench_rowconv.py."""
+    from dlwp_amd.model import DLWPNeuralNet
+    from dlwp_amd.presets import unet_layers
+    np.random.seed(1234)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(unet_layers((cin,) + tuple(grid), latitude_dependent=True), loss='mse', optimizer='adam')
+    net = d.model
+    ws = net.get_weights()
+    net.set_weights([w * 0.5 if w.ndim > 3 else w for w in ws])      # keep a 28-forward rollout finite
+    x = torch.randn((members, cin) + tuple(grid), device=net.device)
+    ser = net.rollout_on_device(x, forwards)
+    for _ in range(2):
+        net.rollout_on_device(x, forwards)
+    reps = 3
+    dt = _sync_time(lambda: net.rollout_on_device(x, forwards), reps)
+    return {'value': members * forwards * 2 * reps / dt, 'unit': '6-h forecast steps/s', 'members': members,
+            'ms_per_forward': 1e3 * dt / reps / forwards, 'launches_per_forward': net.infer_plan.n_launches,
+            'output_layer': 'RowConnected2D(%d, 5): %d parameters of %d' % (cin, net.layers[-1].count_params(), net.count_params()),
+            'finite': bool(torch.isfinite(ser[-1]).all().item())}
+
+
 def sub_train(grid, cin, world, rank, barrier, dev, global_batch=64, steps=20, warmup=15):
     """BASELINE config 3: the same U-Net, training, GLOBAL batch 64 ('mse', Adam), data parallel over the ranks: each rank
     trains on its 64 / N rows, one all-reduce of the flat gradient buffer per step (RCCL through dlwp_allreduce_sum_f32).
@@ -594,6 +617,7 @@ def main():
                     sub['layer1_at_91x180'] = sub_layer1_nominal(net, a.members)
                 if world == 1:
                     sub['recurrent_cfg4_bf16'] = sub_cfg4()
+                    sub['row_connected_output_layer'] = sub_row_connected(grid, a.channels, a.members, a.forwards)
             except Exception as e:  # noqa: BLE001  (a sub-record must never cost the headline line)
                 sub['error_local'] = repr(e)
         out['sub_records'] = sub

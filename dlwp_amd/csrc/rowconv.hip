@@ -37,7 +37,8 @@ struct RowArgs {
   float* y;            // forward: output; data grad: dxp (n, Cin, Hp, Wp); weight grad: dw
   const float* dz;     // gradients: (n, out_c_total, Ho, Wo) window [out_c_off, +Cout)
   float* db;           // weight grad: bias gradient (nullable)
-  int N, Cin, H, W, Ho, Wo, Cout, kh, kw;
+  int N, Cin, H, W, Ho, Wo, Cout, kh, kw;   // H, W: the input as the layer sees it (before the halo)
+  int Hs, Ws, ups;     // stored input: (Hs, Ws) = (H, W) >> ups; ups = 1: keras UpSampling2D(2) in front, resolved by the loaders
   int in_c_off, in_c_total, out_c_off, out_c_total;
   int pad_top, pad_left, mode_h, mode_w, act, accumulate;
   int Hp, Wp;          // padded input size (data grad)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 3) void rowconv2d_fwd_mfma(const RowArgs a) {
 #pragma unroll
   for (int j = 0; j < NSLOT; ++j) {
     const int col = lane + 64 * j;
-    ix[j] = col < a.TW_in ? dlwp_map_coord_tile(x0 + col - a.pad_left, a.W, a.mode_w) : -2;
+    ix[j] = col < a.TW_in ? dlwp_map_coord_tile(x0 + col - a.pad_left, a.W, a.mode_w) : -2;      // (seen column)
     pos[j] = (col & (P - 1)) * a.Q + (col >> a.P_log2);
   }
   // the rows this block reads, the same for every plane: source row of kernel row ky (-1 = zero)
@@ -110,16 +111,16 @@ __global__ __launch_bounds__(256, 3) void rowconv2d_fwd_mfma(const RowArgs a) {
   // samples / channels / kernel taps), the plane / kernel row is chosen by the scalar offset.  x: the S samples' channel
   // windows; w: this row's (kh, kw, cin, cout) filters.
   constexpr unsigned DROP = 0x7ffffff0u;
-  const unsigned plane_b = (unsigned)a.H * (unsigned)a.W * 4u;
+  const unsigned plane_b = (unsigned)a.Hs * (unsigned)a.Ws * 4u;
   const unsigned wrow_b = (unsigned)a.kw * (unsigned)a.Cin * (unsigned)a.Cout * 4u;      // bytes of one kernel row
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(a.x + ((size_t)s0 * a.in_c_total + a.in_c_off) * a.H * a.W), 0,
+      (void*)(a.x + ((size_t)s0 * a.in_c_total + a.in_c_off) * a.Hs * a.Ws), 0,
       (unsigned)min(a.S, a.N - s0) * (unsigned)a.in_c_total * plane_b - (unsigned)a.in_c_off * plane_b, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)r * a.kh * a.kw * a.Cin * a.Cout), 0, (unsigned)a.kh * wrow_b, 0x00020000);
   unsigned goff[NSLOT];
 #pragma unroll
-  for (int j = 0; j < NSLOT; ++j) goff[j] = ix[j] >= 0 ? (unsigned)ix[j] * 4u : DROP;
+  for (int j = 0; j < NSLOT; ++j) goff[j] = ix[j] >= 0 ? (unsigned)(ix[j] >> a.ups) * 4u : DROP;
   // One staging round per chunk and wave (host: S CK <= 4 PB planes, i.e. one per wave and PB slot; the first 8 k columns of
   // filters): the loads of chunk c + 1 are issued right after the barrier that releases chunk c to the matrix cores and
   // land in registers while the MFMA loop runs -- both phases are latency-bound per wave, and serialised they add up
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void rowconv2d_fwd_mfma(const RowArgs a) {
 #pragma unroll
       for (int ky = 0; ky < kKhMax; ++ky) {
         const bool ok = okp && iy[ky] >= 0;
-        const unsigned so = ok ? pl + (unsigned)iy[ky] * (unsigned)a.W * 4u : 0u;
+        const unsigned so = ok ? pl + (unsigned)(iy[ky] >> a.ups) * (unsigned)a.Ws * 4u : 0u;
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j)
           v[q][ky][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, ok ? goff[j] : DROP, so, 0));
@@ -296,9 +297,9 @@ __global__ void rowconv2d_fwd_simple(const RowArgs a) {
       for (int kx = 0; kx < a.kw; ++kx) {
         const int ixx = dlwp_map_coord(ox + kx - a.pad_left, a.W, a.mode_w);
         if (ixx < 0) continue;
-        const float* xp = a.x + ((size_t)n * a.in_c_total + a.in_c_off) * a.H * a.W + (size_t)iy * a.W + ixx;
+        const float* xp = a.x + ((size_t)n * a.in_c_total + a.in_c_off) * a.Hs * a.Ws + (size_t)(iy >> a.ups) * a.Ws + (ixx >> a.ups);
         const float* wp = a.w + (((size_t)r * a.kh + ky) * a.kw + kx) * a.Cin * a.Cout + co;
-        for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[(size_t)c * a.H * a.W], wp[(size_t)c * a.Cout], acc);
+        for (int c = 0; c < a.Cin; ++c) acc = fmaf(xp[(size_t)c * a.Hs * a.Ws], wp[(size_t)c * a.Cout], acc);
       }
     }
     a.y[(((size_t)n * a.out_c_total + a.out_c_off + co) * a.Ho + r) * a.Wo + ox] = act_apply(acc, a.act);
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void rowconv2d_wgrad_mfma(const RowArgs a) 
   for (int j = 0; j < NSLOT; ++j) {
     const int col = lane + 64 * j;
     const int ixx = col < a.TW_in ? dlwp_map_coord_tile(col - a.pad_left, a.W, a.mode_w) : -1;
-    xoff[j] = (ixx >= 0 && iy >= 0) ? (unsigned)ixx * 4u : DROP;
+    xoff[j] = (ixx >= 0 && iy >= 0) ? (unsigned)(ixx >> a.ups) * 4u : DROP;
     zoff[j] = col < a.Wo ? (unsigned)col * 4u : DROP;
   }
   const int m = lane & 15, kq = lane >> 4;
@@ -514,11 +515,11 @@ __global__ __launch_bounds__(256, 2) void rowconv2d_wgrad_mfma(const RowArgs a) 
   const int nfr = n_frag > wave ? (n_frag - wave + 3) / 4 : 0;
   const int zbase = m * a.PS + kq;
   f32x4 acc[3] = {};
-  const unsigned xplane_b = (unsigned)a.H * (unsigned)a.W * 4u, zplane_b = (unsigned)a.Ho * (unsigned)a.Wo * 4u;
-  const unsigned xrow_b = (unsigned)max(iy, 0) * (unsigned)a.W * 4u, zrow_b = (unsigned)r * (unsigned)a.Wo * 4u;
+  const unsigned xplane_b = (unsigned)a.Hs * (unsigned)a.Ws * 4u, zplane_b = (unsigned)a.Ho * (unsigned)a.Wo * 4u;
+  const unsigned xrow_b = (unsigned)(max(iy, 0) >> a.ups) * (unsigned)a.Ws * 4u, zrow_b = (unsigned)r * (unsigned)a.Wo * 4u;
   // one sample's channel window per descriptor (a sample past the batch: zero records, everything reads 0.0)
   auto x_desc = [&](int n) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((size_t)min(n, a.N - 1) * a.in_c_total + a.in_c_off) * a.H * a.W), 0,
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((size_t)min(n, a.N - 1) * a.in_c_total + a.in_c_off) * a.Hs * a.Ws), 0,
                                              n < a.N ? (unsigned)a.Cin * xplane_b : 0u, 0x00020000);
   };
   auto z_desc = [&](int n) {
@@ -641,11 +642,11 @@ __global__ void rowconv2d_wgrad_simple(const RowArgs a) {
     float acc = 0.f;
     if (iy >= 0)
       for (int n = 0; n < a.N; ++n) {
-        const float* xp = a.x + (((size_t)n * a.in_c_total + a.in_c_off + c) * a.H + iy) * a.W;
+        const float* xp = a.x + (((size_t)n * a.in_c_total + a.in_c_off + c) * a.Hs + (iy >> a.ups)) * a.Ws;
         const float* zp = a.dz + (((size_t)n * a.out_c_total + a.out_c_off + co) * a.Ho + r) * a.Wo;
         for (int ox = 0; ox < a.Wo; ++ox) {
           const int ixx = dlwp_map_coord(ox + kx - a.pad_left, a.W, a.mode_w);
-          if (ixx >= 0) acc = fmaf(xp[ixx], zp[ox], acc);
+          if (ixx >= 0) acc = fmaf(xp[ixx >> a.ups], zp[ox], acc);
         }
       }
     a.y[e] = a.accumulate ? a.y[e] + acc : acc;
@@ -690,21 +691,26 @@ int ilog2(int v) {
   return l;
 }
 
-int validate_row(const char* fn, dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
+int validate_row(const char* fn, dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys,
+                 bool upsampled_ok = true) {
   DLWP_CHECK_ARG(h && cd, "%s: null handle or descriptor", fn);
   DLWP_CHECK_ARG(dtype == DLWP_F32, "%s: float32 only (dtype 0x%x)", fn, dtype);
   DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, "%s: bad input shape (%d,%d,%d,%d)", fn, xs.n, xs.c, xs.h,
                  xs.w);
   if (dlwp_conv2d_out_shape(xs, cd, ys) != DLWP_OK) return DLWP_EINVAL;
-  if (cd->dil_h != 1 || cd->dil_w != 1 || cd->src_mode != DLWP_SRC_DIRECT || cd->out_pool || cd->out_d2s || cd->lstm_f)
-    DLWP_FAIL(DLWP_EUNSUPPORTED, "%s: a row-connected layer has dilation 1, a directly stored input and a plain epilogue", fn);
+  if (cd->dil_h != 1 || cd->dil_w != 1 || cd->src_mode == DLWP_SRC_MAXPOOL2 || cd->out_pool || cd->out_d2s || cd->lstm_f ||
+      (cd->src_mode == DLWP_SRC_UPSAMPLE2 && !upsampled_ok))
+    DLWP_FAIL(DLWP_EUNSUPPORTED, "%s: a row-connected layer has dilation 1, a stored (or 2x up-sampled: forward and weight "
+              "gradient) input and a plain epilogue", fn);
   return DLWP_OK;
 }
 
 RowArgs base_args(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4 ys) {
   RowArgs a;
   memset(&a, 0, sizeof(a));
-  a.N = xs.n; a.Cin = xs.c; a.H = xs.h; a.W = xs.w;
+  a.N = xs.n; a.Cin = xs.c; a.Hs = xs.h; a.Ws = xs.w;
+  a.ups = cd->src_mode == DLWP_SRC_UPSAMPLE2 ? 1 : 0;
+  a.H = xs.h << a.ups; a.W = xs.w << a.ups;
   a.Ho = ys.h; a.Wo = ys.w; a.Cout = cd->cout; a.kh = cd->kh; a.kw = cd->kw;
   a.in_c_off = cd->in_c_off;
   a.in_c_total = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
@@ -712,8 +718,8 @@ RowArgs base_args(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4 ys) {
   a.out_c_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
   a.pad_top = cd->halo.top; a.pad_left = cd->halo.left; a.mode_h = cd->halo.mode_h; a.mode_w = cd->halo.mode_w;
   a.act = cd->act;
-  a.Hp = xs.h + cd->halo.top + cd->halo.bottom;
-  a.Wp = xs.w + cd->halo.left + cd->halo.right;
+  a.Hp = a.H + cd->halo.top + cd->halo.bottom;
+  a.Wp = a.W + cd->halo.left + cd->halo.right;
   return a;
 }
 
@@ -888,7 +894,7 @@ int dlwp_rowconv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_con
 int dlwp_rowconv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs, const dlwp_conv2d* cd,
                             int dtype, void* ws, size_t ws_bytes, void* stream) {
   dlwp_shape4 ys;
-  if (int rc = validate_row("dlwp_rowconv2d_bwd_data", h, xs, cd, dtype, &ys)) return rc;
+  if (int rc = validate_row("dlwp_rowconv2d_bwd_data", h, xs, cd, dtype, &ys, false)) return rc;
   DLWP_CHECK_ARG(xs.n == 0 || (dz && w && dx), "dlwp_rowconv2d_bwd_data: null pointer");
   if (xs.n == 0) return DLWP_OK;
   size_t need = 0;

@@ -651,11 +651,12 @@ def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False)
               views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)
         elif isinstance(lay, L.RowConnected2D):
             # DLWP.custom.RowConnected2D (reference custom.py:695-837): per-row filters, dlwp_rowconv2d_fwd.  Its kernels read a
-            # stored float32 tensor (a lazy pooling / up-sampling in front is materialised); the halo stays in the loader.
+            # stored float32 tensor, directly or 2x up-sampled (a lazy pooling in front is materialised); the halo stays in the
+            # loader.
             v = ins[0]
             if v.shape is not None and len(v.shape) != 3:
                 raise NotImplementedError('%s on a non-3D tensor %r' % (lay.name, v.shape))
-            if v.src_mode != SRC_DIRECT:
+            if v.src_mode == SRC_MAXPOOL2:           # (a 2x up-sampling in front is resolved by the row kernels' loaders)
                 v = materialize(v.copy(halo=NO_HALO)).copy(halo=v.halo)
             _, hl, wl = v.logical
             kh, kw = lay.kernel_size
@@ -668,7 +669,7 @@ def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False)
                 plan.output_store[outs[0]] = (lay.filters, ho, wo)
             else:
                 dst = plan.new_buffer(lay.filters, ho, wo)
-            emit(PlanOp('rowconv', v.buf, dst, (v.c, v.h, v.w), layer=lay, halo=v.halo, src_mode=SRC_DIRECT,
+            emit(PlanOp('rowconv', v.buf, dst, (v.c, v.h, v.w), layer=lay, halo=v.halo, src_mode=v.src_mode,
                         act=ACT[lay.activation], in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0,
                         out_c_total=lay.filters, out_shape=(lay.filters, ho, wo)))
             views[t.uid] = View(dst, 0, lay.filters, lay.filters, ho, wo)

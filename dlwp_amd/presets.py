@@ -11,8 +11,10 @@ def _block(k, filters, ks, dil, act):
             ('Conv2D', (filters, ks), dict(CF, dilation_rate=dil, padding='valid', activation=act))]
 
 
-def unet_layers(cs, widths=(32, 64, 128, 64, 32), cout=None):
-    """Sequential U-Net of Azure/train_tf.py:208-268 / examples/train.py:159-219 (non-recurrent part)."""
+def unet_layers(cs, widths=(32, 64, 128, 64, 32), cout=None, latitude_dependent=False):
+    """Sequential U-Net of Azure/train_tf.py:208-268 / examples/train.py:159-219 (non-recurrent part).
+    latitude_dependent: the output layer is DLWP.custom.RowConnected2D instead of Conv2D, the switch of
+    examples/train_functional.py:53, 191-196."""
     cout = cs[0] if cout is None else cout
     w1, w2, w3, w4, w5 = widths
     layers = _block(2, w1, 3, 2, 'tanh')
@@ -21,7 +23,11 @@ def unet_layers(cs, widths=(32, 64, 128, 64, 32), cout=None):
     layers += [('MaxPooling2D', (2,), dict(CF))] + _block(1, w3, 3, 1, 'tanh')
     layers += [('UpSampling2D', (2,), dict(CF))] + _block(1, w4, 3, 1, 'tanh')
     layers += [('UpSampling2D', (2,), dict(CF))] + _block(2, w5, 3, 2, 'tanh')
-    layers += _block(2, cout, 5, 1, 'linear')
+    if latitude_dependent:
+        layers += [('PeriodicPadding2D', ((0, 2),), dict(CF)), ('ZeroPadding2D', ((2, 0),), dict(CF)),
+                   ('RowConnected2D', (cout, 5), dict(CF, padding='valid', activation='linear'))]
+    else:
+        layers += _block(2, cout, 5, 1, 'linear')
     return tuple(layers)
 
 

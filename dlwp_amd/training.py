@@ -449,8 +449,15 @@ class Trainer(object):
                 if op.src == P.STATE_IN:
                     continue
                 cin = op.xs[0]
-                dense = torch.empty((n, cin) + tuple(src.shape[2:]), dtype=torch.float32, device=self.device)
-                ops.rowconv2d_bwd_data(dz, lay.kernel, d, xs, dense)
+                if op.src_mode == P.SRC_UPSAMPLE2:     # gradient of the up-sampled tensor, then the 2x2 sums of its adjoint
+                    dd = ops.make_conv(d.cout, d.kh, d.kw, 1, d.halo, d.act, 0, 0, d.out_c_off, d.out_c_total)
+                    up = torch.empty((n, cin, 2 * op.xs[1], 2 * op.xs[2]), dtype=torch.float32, device=self.device)
+                    ops.rowconv2d_bwd_data(dz, lay.kernel, dd, _lib.Shape4(n, cin, 2 * op.xs[1], 2 * op.xs[2]), up)
+                    dense = ops.upsample2_bwd(up)
+                else:
+                    dd = ops.make_conv(d.cout, d.kh, d.kw, 1, d.halo, d.act, 0, 0, d.out_c_off, d.out_c_total)
+                    dense = torch.empty((n, cin) + tuple(src.shape[2:]), dtype=torch.float32, device=self.device)
+                    ops.rowconv2d_bwd_data(dz, lay.kernel, dd, xs, dense)
                 deposit(op.src, op.in_c_off, cin, dense)
             elif op.kind == 'lstm':
                 zh_i, cp_i, co_i = op.aux

@@ -209,13 +209,15 @@ int dlwp_conv2d_wgrad_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv
 /* ---- DLWP.custom.RowConnected2D.call / row_conv2d (DLWP/custom.py:825-837, 840-896): a Conv2D whose filters are shared
  *      along a row only -- output row r is the 'valid' convolution of input rows [r, r + kh) with its own kernel w[r]
  *      (custom.py:879-888: one K.conv2d per row slice + concatenate); the optional last layer of the functional U-Net
- *      (examples/train_functional.py:191-196).  The descriptor is dlwp_conv2d with dilation 1, DLWP_SRC_DIRECT and a plain
- *      epilogue (halo, channel windows, bias, activation as for dlwp_conv2d_fwd; the output shape is dlwp_conv2d_out_shape's).
+ *      (examples/train_functional.py:191-196).  The descriptor is dlwp_conv2d with dilation 1, DLWP_SRC_DIRECT -- or, for the
+ *      forward and the weight gradient, DLWP_SRC_UPSAMPLE2: the loaders resolve a keras UpSampling2D(2) in front -- and a
+ *      plain epilogue (halo, channel windows, bias, activation as for dlwp_conv2d_fwd; output shape: dlwp_conv2d_out_shape).
  *      w: (ho, kh, kw, cin, cout) -- custom.py:800-805; bias: the stored (ho, 1, cout) array of custom.py:812, which
  *      K.bias_add (Keras 2.2, tensorflow backend) reshapes to (1, cout, ho, 1) for channels_first: channel co, row r
  *      receives flat element co * ho + r (nullable).  float32 only; stride 1 (the reference's call sites).
- *      bwd_data : dx (n, cin, h, w) dense <- dL/dx; the halo's adjoint is applied through a padded temporary of
- *                 dlwp_rowconv2d_bwd_workspace() bytes (0 without a halo).
+ *      bwd_data : dx (n, cin, h, w) dense <- dL/dx (DLWP_SRC_DIRECT descriptors; behind an up-sampling the caller describes
+ *                 the up-sampled tensor and finishes with dlwp_upsample2_bwd); the halo's adjoint is applied through a padded
+ *                 temporary of dlwp_rowconv2d_bwd_workspace() bytes (0 without a halo).
  *      bwd_weight: dw (ho, kh, kw, cin, cout) and db (nullable; the stored (ho, 1, cout) layout) from x and dz =
  *                 dL/d(pre-activation), summed over samples and columns in a fixed order (bit-reproducible); accumulate != 0
  *                 adds to dw / db.

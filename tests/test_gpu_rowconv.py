@@ -94,6 +94,29 @@ def test_forward_golden_vectors_of_the_reference(ops, golden):
     assert seen >= 4
 
 
+def test_upsampled_source_in_the_loaders(ops):
+    """keras UpSampling2D(2) in front (the decoder's output layer reads an up-sampled tensor): forward and weight gradient read
+    the stored low-resolution tensor; same numbers as on the materialised up-sampled one."""
+    from dlwp_amd._lib import Shape4
+    rng = np.random.default_rng(11)
+    for (n, cin, h, w, cout, k) in ((3, 32, 11, 18, 4, 5), (2, 8, 6, 45, 12, 3)):
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        pad = k // 2
+        ho, wo = 2 * h, 2 * w
+        kern, b = np_ref.init_row_connected_weights(ho, (k, k), cin, cout, rng, bias_scale=0.3)
+        cd = ops.make_conv(cout, k, k, 1, ops.make_pad(pad, pad, pad, pad, 0, 1), ops.ACT_LINEAR, src_mode=ops.SRC_UPSAMPLE2)
+        xup = np_ref.upsample2(x.astype(np.float64))
+        ref = np_ref.row_connected2d(np_ref.pad2d_modes(xup, (pad,) * 4, 0, 1), kern, b)
+        for direct in (False, True):
+            close(host(ops.rowconv2d(dev(x), dev(kern), dev(b), cd, direct=direct)), ref, 'upsampled forward direct=%s' % direct)
+        dz = rng.standard_normal((n, cout, ho, wo)).astype(np.float32)
+        _, dk, db = np_ref.row_connected2d_grads(np_ref.pad2d_modes(xup, (pad,) * 4, 0, 1), kern, dz)
+        dw, dbt = torch.empty(kern.shape, device='cuda'), torch.empty((ho, 1, cout), device='cuda')
+        ops.rowconv2d_bwd_weight(dev(x), dev(dz), dw, dbt, cd, Shape4(n, cin, h, w))
+        close(host(dw), dk, 'upsampled dw')
+        close(host(dbt), db, 'upsampled db')
+
+
 def test_channel_windows(ops):
     """slice_layer in front (input channel window) and concatenate behind (output channel window), as for Conv2D."""
     rng = np.random.default_rng(7)
