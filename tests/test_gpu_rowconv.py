@@ -315,3 +315,26 @@ def test_row_conv2d_function_on_device_tensors(golden):
     close(host(y), g['%d_y_cl' % i], 'channels_last')
     with pytest.raises(NotImplementedError):
         custom.row_conv2d(dev(x), dev(k), (5, 5), (2, 2), out_rc, 'channels_first')
+
+
+def test_bfloat16_activation_mode_keeps_the_row_connected_layer_in_float32():
+    """Model.set_activation_dtype('bfloat16') (BASELINE config 4): the buffers the row kernels touch stay float32; the rest of
+    the stack stores bfloat16 -- the forecast moves by bf16 rounding only, and the rollout graph still equals the host loop."""
+    cs = (4, 12, 20)
+    d, pairs = _build_row_model(cs, seed=5)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((4,) + cs).astype(np.float32)
+    y32 = d.predict(x)
+    d.model.set_activation_dtype('bfloat16')
+    plan = d.model.infer_plan
+    rc = [op for op in plan.ops if op.kind == 'rowconv'][0]
+    assert rc.src not in d.model.executor._bf16 and len(d.model.executor._bf16) >= 1
+    y16 = d.predict(x)
+    assert np.isfinite(y16).all()
+    assert np.abs(y16 - y32).max() <= 3e-2 * max(np.abs(y32).max(), 1.0)
+    assert np.abs(y16 - y32).max() > 0          # (it really ran in the other storage mode)
+    series = d.predict_timeseries(x, 4)
+    p = d.predict(x)
+    assert np.array_equal(series[0:2].transpose(1, 0, 2, 3, 4).reshape(p.shape), p)
+    d.model.set_activation_dtype('float32')
+    assert np.array_equal(d.predict(x), y32)
