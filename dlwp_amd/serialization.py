@@ -1,6 +1,7 @@
 """
-Model files.  The reference writes `<name>.keras` as Keras HDF5 (DLWP/util.py:126-153); h5py is absent here, so the same
-file name holds a numpy .npz archive instead: a JSON description of the layer graph + compile arguments, and every
+Model files.  The reference writes `<name>.keras` as Keras HDF5 (DLWP/util.py:126-153); h5py is absent here, so files written
+by THIS package hold a numpy .npz archive under the same name (Keras HDF5 checkpoints are READ: import_keras_hdf5, through the
+pure-numpy container reader dlwp_amd.hdf5_lite): a JSON description of the layer graph + compile arguments, and every
 weight array in KERAS LAYOUT (conv kernels (kh, kw, cin, cout), biases (cout,)) under the Keras-style key
 `<layer name>/<weight name>` -- an offline converter can move real Keras checkpoints in either direction.
 """
@@ -117,10 +118,157 @@ def save_model_file(model, path):
         f.write(buf.getvalue())
 
 
+# ------------------------------------------------------------------------------------------------------------------ #
+# Keras HDF5 checkpoints: what the reference's save_model writes as '<name>.keras' (DLWP/util.py:126-153: model.save)
+# ------------------------------------------------------------------------------------------------------------------ #
+
+def _keras_layer_kwargs(cls, cfg):
+    """A Keras layer config (keras `Layer.get_config()` as stored in `model_config`) -> constructor arguments of this
+    package's layer of the same name: initialisers / constraints / activity regularisers are dropped (the weights come from the
+    file), `batch_input_shape` becomes `input_shape`, an l2 kernel regulariser is kept, unknown keys the constructor does not
+    take are ignored."""
+    import inspect
+    from .regularizers import L1L2
+    kw = {}
+    params = inspect.signature(cls.__init__).parameters
+    for k, v in cfg.items():
+        if k == 'batch_input_shape':
+            if v is not None:
+                kw['input_shape'] = tuple(v[1:])
+            continue
+        if k in ('dtype', 'sparse') or k.endswith('_initializer') or k.endswith('_constraint') or k == 'activity_regularizer':
+            continue
+        if k.endswith('_regularizer'):
+            if isinstance(v, dict) and k == 'kernel_regularizer':
+                c = v.get('config', {})
+                if c.get('l1', 0.0):
+                    raise NotImplementedError('l1 kernel regulariser in the checkpoint')
+                kw[k] = L1L2(l2=float(c.get('l2', 0.0)))
+            continue
+        if k not in params and k not in ('name', 'trainable'):      # (the base Layer takes name / trainable / input_shape)
+            continue
+        if isinstance(v, list):
+            v = tuple(tuple(e) if isinstance(e, list) else e for e in v)
+        kw[k] = v
+    return kw
+
+
+def import_keras_hdf5(path, custom_objects=None, device=None, compile=True):
+    """Build a Model from a Keras 2.x HDF5 checkpoint (`keras.models.save_model` layout: root attribute `model_config` = JSON
+    of the Sequential / functional graph, group `model_weights/<layer>/<weight names>`, optional `training_config`).  The
+    container is read by dlwp_amd.hdf5_lite (no h5py for this interpreter).  Layers are looked up by class name in
+    keras.layers / DLWP.custom as this package provides them; a `Lambda` (the reference's slice_layer) carries marshalled
+    Python bytecode and cannot be imported -- NotImplementedError names it."""
+    from . import custom as C
+    from . import engine, hdf5_lite
+    from . import layers as L
+    f = hdf5_lite.File(path)
+
+    def text(v):
+        return v.decode('utf-8') if isinstance(v, (bytes, np.bytes_)) else str(v)
+
+    def attr_list(group, name):      # keras.engine.saving.load_attributes_from_hdf5_group: large lists are split into chunks
+        if name in group.attrs:
+            return [text(n) for n in np.asarray(group.attrs[name]).reshape(-1)]
+        out, k = [], 0
+        while '%s%d' % (name, k) in group.attrs:
+            out += [text(n) for n in np.asarray(group.attrs['%s%d' % (name, k)]).reshape(-1)]
+            k += 1
+        return out
+    if 'model_config' not in f.attrs:
+        raise ValueError('%s holds no model_config (a weights-only file? build the model and use load_weights semantics)' % path)
+    config = json.loads(text(f.attrs['model_config']))
+    registry = {}
+    for mod in (L, C):
+        registry.update({k: v for k, v in vars(mod).items() if isinstance(v, type)})
+    registry.update(custom_objects or {})
+
+    def make(spec):
+        cname = spec['class_name']
+        if cname == 'Lambda':
+            raise NotImplementedError('layer %r is a keras Lambda (marshalled Python code, e.g. DLWP.custom.slice_layer): rebuild '
+                                      'the graph with dlwp_amd.custom.slice_layer and load the weights by name'
+                                      % spec['config'].get('name'))
+        if cname not in registry:
+            raise NotImplementedError('layer class %r of the checkpoint has no counterpart here' % cname)
+        cls = registry[cname]
+        return cls(**_keras_layer_kwargs(cls, spec['config']))
+    cls_name, mc = config['class_name'], config['config']
+    layer_specs = mc if isinstance(mc, list) else mc['layers']          # Keras < 2.2.3 stored a Sequential as a bare list
+    by_name = {}
+    if cls_name == 'Sequential':
+        objs = []
+        for spec in layer_specs:
+            if spec['class_name'] == 'InputLayer':
+                continue
+            objs.append(make(spec))
+            by_name[spec['config']['name']] = objs[-1]
+        first = layer_specs[0]['config']
+        shp = first.get('batch_input_shape')
+        if shp is None:
+            raise ValueError('the first layer of the Sequential checkpoint has no batch_input_shape')
+        t = L.Input(shape=tuple(shp[1:]))
+        x0 = t
+        for lay in objs:
+            t = lay(t)
+        model = engine.Model(inputs=x0, outputs=t, name=mc.get('name') if isinstance(mc, dict) else None, device=device)
+    elif cls_name == 'Model':
+        tensors = {}                                   # (layer name, node index) -> output tensor
+        pending = []
+        for spec in layer_specs:
+            nm = spec['name']
+            if spec['class_name'] == 'InputLayer':
+                tensors[(nm, 0)] = L.Input(shape=tuple(spec['config']['batch_input_shape'][1:]), name=nm)
+                continue
+            by_name[nm] = make(spec)
+            for k, node in enumerate(spec['inbound_nodes']):
+                pending.append((nm, k, [(i[0], i[1]) for i in node]))
+        while pending:                                 # nodes in dependency order, whatever order the file lists them in
+            progressed = False
+            for item in list(pending):
+                nm, k, srcs = item
+                if all(s in tensors for s in srcs):
+                    ins = [tensors[s] for s in srcs]
+                    tensors[(nm, k)] = by_name[nm](ins if isinstance(by_name[nm], L.Concatenate) or len(ins) > 1 else ins[0])
+                    pending.remove(item)
+                    progressed = True
+            if not progressed:
+                raise ValueError('the checkpoint graph has a cycle or a missing layer')
+        model = engine.Model(inputs=[tensors[(i[0], i[1])] for i in mc['input_layers']],
+                             outputs=[tensors[(o[0], o[1])] for o in mc['output_layers']], name=mc.get('name'), device=device)
+    else:
+        raise NotImplementedError('checkpoint of a %r' % cls_name)
+    # ---- weights, by layer name: model_weights/<layer>/<weight name>, in the order of the layer's weight_names attribute
+    mw = f['model_weights'] if 'model_weights' in f else f
+    for lname in attr_list(mw, 'layer_names'):
+        g = mw[lname]
+        names = attr_list(g, 'weight_names')
+        if not names:
+            continue
+        if lname not in by_name:
+            raise ValueError('checkpoint layer %r holds weights but is not in the graph' % lname)
+        by_name[lname].set_weights([np.asarray(g[n][...]) for n in names])
+    tc = f.attrs.get('training_config') if compile else None
+    if tc is not None:
+        tc = json.loads(text(tc))
+        from . import training
+        oc = tc.get('optimizer_config', {})
+        ocls = getattr(training, oc.get('class_name', 'Adam'), None)
+        loss = tc.get('loss')
+        if ocls is not None and isinstance(loss, str) and loss in ('mse', 'mean_squared_error', 'mae', 'mean_absolute_error'):
+            ocfg = {k: v for k, v in oc.get('config', {}).items() if isinstance(v, (int, float))}
+            metrics = [m for m in (tc.get('metrics') or []) if m in ('mae', 'mse', 'mean_absolute_error', 'mean_squared_error')]
+            model.compile(optimizer=ocls(**ocfg), loss=loss, metrics=metrics, loss_weights=tc.get('loss_weights'))
+    return model
+
+
 def load_model_file(path, custom_objects=None, device=None):
     from . import custom as C
     from . import engine
     from . import layers as L
+    from . import hdf5_lite
+    if hdf5_lite.is_hdf5(path):          # a real Keras checkpoint (reference DLWP/util.py:141-144)
+        return import_keras_hdf5(path, custom_objects=custom_objects, device=device)
     with open(path, 'rb') as f:
         data = np.load(io.BytesIO(f.read()), allow_pickle=False)
     arch = json.loads(bytes(data['__arch__']).decode('utf-8'))

@@ -1170,3 +1170,33 @@ def test_recurrent_reference_style_example_runs_end_to_end():
     assert series.dims == ('f_hour', 'time', 'variable', 'level', 'lat', 'lon')
     assert series.shape == (4, 13, 2, 1, 16, 24)
     assert np.isfinite(series.values[:2]).all()                        # later steps run out of data for the last samples
+
+
+def test_imported_keras_hdf5_checkpoint_forecasts_like_the_oracle():
+    """A Keras HDF5 checkpoint (reference DLWP/util.py:141-144 writes them; tests/golden/keras_sequential.h5 comes out of a real
+    libhdf5) imported through dlwp_amd.hdf5_lite: the rebuilt model's forecast equals the oracle run on the file's weights."""
+    import os
+    from dlwp_amd import serialization
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    m = serialization.load_model_file(os.path.join(golden, 'keras_sequential.h5'))
+    e = np.load(os.path.join(golden, 'keras_h5_expected.npz'))
+    pairs = [(e['seq|conv2d_1/kernel'], e['seq|conv2d_1/bias']), (e['seq|conv2d_2/kernel'], e['seq|conv2d_2/bias'])]
+    layers = (('PeriodicPadding2D', ((0, 2),), CF), ('ZeroPadding2D', ((2, 0),), CF),
+              ('Conv2D', (8, 5), dict(CF, activation='tanh')), ('MaxPooling2D', (2,), CF), ('UpSampling2D', (2,), CF),
+              ('PeriodicPadding2D', ((0, 1),), CF), ('ZeroPadding2D', ((1, 0),), CF),
+              ('Conv2D', (2, 3), dict(CF, activation='linear')))
+    x = np.random.default_rng(3).standard_normal((5, 2, 10, 12)).astype(np.float32)
+    ref = np_ref.run_layers(layers, x, pairs)
+    got = m.predict(x)
+    assert _rel(got, ref) <= FWD_TOL
+    mf = serialization.import_keras_hdf5(os.path.join(golden, 'keras_functional.h5'))
+    xf = np.random.default_rng(4).standard_normal((3, 3, 8, 12)).astype(np.float32)
+    k, b = e['fun|shared/kernel'], e['fun|shared/bias']
+    blk = (('PeriodicPadding2D', ((0, 1),), CF), ('ZeroPadding2D', ((1, 0),), CF), ('Conv2D', (3, 3), dict(CF, activation='tanh')))
+    h1 = np_ref.run_layers(blk, xf, [(k, b)])
+    h2 = np_ref.run_layers(blk, h1, [(k, b)])
+    cat = np.concatenate([h1, h2], axis=1)
+    out = np_ref.run_layers((('PeriodicPadding2D', ((0, 2),), CF), ('ZeroPadding2D', ((2, 0),), CF),
+                             ('RowConnected2D', (3, 5), dict(CF, activation='linear'))), cat,
+                            [(e['fun|row/kernel'], e['fun|row/bias'])])
+    assert _rel(mf.predict(xf), out) <= FWD_TOL
