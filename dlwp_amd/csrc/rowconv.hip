@@ -368,34 +368,44 @@ __global__ __launch_bounds__(128, 3) void rowconv2d_dgrad_mfma(const RowArgs a) 
       }
     }
   }
-  // ---- filters of the rows that reach py: ws[(((ky kw + kx) C4 + c4) NF + g) 64 + kq 16 + ci]; one (kx, c4) pair per
-  //      round: kh rows x NF channel groups in flight
+  // ---- filters of the rows that reach py: ws[(((ky kw + kx) C4 + c4) NF + g) 64 + kq 16 + ci]; two (kx, c4) pairs per
+  //      round: 2 x kh rows x NF channel groups in flight
   const int c4n = cpad >> 2;
   const unsigned tap_b = (unsigned)a.Cin * (unsigned)a.Cout * 4u;
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)a.Ho * (unsigned)a.kh * (unsigned)a.kw * tap_b, 0x00020000);
-  for (int t = wave; t < a.kw * c4n; t += 2) {
-    const int kx = t / c4n, c4 = t - kx * c4n;
-    const int co = c4 * 4 + (lane >> 4);
-    float wv[kKhMax][NF];
+  for (int t0 = wave; t0 < a.kw * c4n; t0 += 4) {       // (kx, c4) pairs t0 and t0 + 2 per round
+    float wv[2][kKhMax][NF];
 #pragma unroll
-    for (int g = 0; g < NF; ++g) {
-      const int c = ci0 + g * 16 + (lane & 15);
-      const unsigned vo = (co < a.Cout && c < a.Cin) ? (unsigned)(c * a.Cout + co) * 4u : DROP;
+    for (int q = 0; q < 2; ++q) {
+      const int t = t0 + 2 * q;
+      const int kx = t / c4n, c4 = t - kx * c4n;
+      const int co = c4 * 4 + (lane >> 4);
 #pragma unroll
-      for (int ky = 0; ky < kKhMax; ++ky) {
-        const int r = py - ky;
-        const bool ok = ky < a.kh && r >= 0 && r < a.Ho;
-        wv[ky][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                  w_rsrc, ok ? vo : DROP, ok ? (unsigned)((r * a.kh + ky) * a.kw + kx) * tap_b : 0u, 0));
+      for (int g = 0; g < NF; ++g) {
+        const int c = ci0 + g * 16 + (lane & 15);
+        const unsigned vo = (t < a.kw * c4n && co < a.Cout && c < a.Cin) ? (unsigned)(c * a.Cout + co) * 4u : DROP;
+#pragma unroll
+        for (int ky = 0; ky < kKhMax; ++ky) {
+          const int r = py - ky;
+          const bool ok = ky < a.kh && r >= 0 && r < a.Ho;
+          wv[q][ky][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                       w_rsrc, ok ? vo : DROP, ok ? (unsigned)((r * a.kh + ky) * a.kw + kx) * tap_b : 0u, 0));
+        }
       }
     }
 #pragma unroll
-    for (int ky = 0; ky < kKhMax; ++ky) {
-      if (ky >= a.kh) break;
-      const int ks = (ky * a.kw + kx) * c4n + c4;
+    for (int q = 0; q < 2; ++q) {
+      const int t = t0 + 2 * q;
+      if (t >= a.kw * c4n) break;
+      const int kx = t / c4n, c4 = t - kx * c4n;
 #pragma unroll
-      for (int g = 0; g < NF; ++g) ws[(ks * NF + g) * 64 + lane] = wv[ky][g];
+      for (int ky = 0; ky < kKhMax; ++ky) {
+        if (ky >= a.kh) break;
+        const int ks = (ky * a.kw + kx) * c4n + c4;
+#pragma unroll
+        for (int g = 0; g < NF; ++g) ws[(ks * NF + g) * 64 + lane] = wv[q][ky][g];
+      }
     }
   }
   __syncthreads();
@@ -758,6 +768,8 @@ size_t plan_fwd(RowArgs& a) {
   }
   a.RS = a.Q * P;
   a.PS = round_mod32(a.kh * a.RS, 16);
+  if ((double)a.in_c_total * a.Hs * a.Ws * 8.0 >= 2.0e9 || (double)a.kh * a.kw * a.Cin * a.Cout * 4.0 >= 2.0e9)
+    return 0;                               // 32-bit descriptor offsets (two samples' channel windows; one row's filters)
   const int plane_cap = dlwp_ceil_div(a.TW_in, 64) > 4 ? 4 : 8;   // (sample, channel) planes of one staging round (registers)
   if (a.S > plane_cap / 4) {
     a.S = plane_cap / 4;
@@ -792,7 +804,9 @@ size_t plan_dgrad(RowArgs& a) {
   a.SS = a.CK * a.PS;
   a.w_off = a.S * a.SS;
   const size_t bytes = ((size_t)a.w_off + (size_t)a.kh * a.kw * (a.CK / 4) * a.NF * 64) * sizeof(float);
-  if (a.kh > kKhMax || (double)a.Ho * a.kh * a.kw * a.Cin * a.Cout * 4.0 >= 2.0e9) return 0;    // unrolled rows; 32-bit descriptor offsets
+  if (a.kh > kKhMax || (double)a.Ho * a.kh * a.kw * a.Cin * a.Cout * 4.0 >= 2.0e9 ||
+      (double)a.S * a.out_c_total * a.Ho * a.Wo * 4.0 >= 2.0e9)
+    return 0;                               // unrolled rows; 32-bit descriptor offsets
   return bytes <= (size_t)kLdsBudget ? bytes : 0;
 }
 
@@ -804,7 +818,7 @@ size_t plan_wgrad(RowArgs& a) {
   a.n_cg = dlwp_ceil_div(a.Cout, 16);
   const int wo4 = (a.Wo + 3) & ~3;
   a.TW_in = wo4 + a.kw - 1;
-  if (a.TW_in > 64 * kMaxSlots) return 0;
+  if (a.TW_in > 64 * kMaxSlots || (double)a.Cin * a.Hs * a.Ws * 4.0 >= 2.0e9 || (double)a.Ho * a.Wo * 64.0 >= 2.0e9) return 0;
   a.PS = round_mod32(a.TW_in, 2);
   a.w_off = c16 * 16 * a.PS;
   const size_t bytes = ((size_t)a.w_off + 16 * (size_t)a.PS) * sizeof(float);
