@@ -157,15 +157,19 @@ class Executor(object):
 
     # -- hipGraph rollout -------------------------------------------------------------------------------------------- #
     @staticmethod
-    def member_groups(n):
+    def member_groups(n, pixels=15840):
         """How many parallel member chains a rollout of n members is captured as (dlwp_rollout_create_grouped).  Members are
         independent, so chains at different layers fill the gaps each other's launches leave (partly filled last rounds of
         workgroups, the drain at every kernel boundary).  Measured on one MI355X (profiles/r2i_rollout_member_groups.txt,
         r2q): two chains +7 % at 64 members (361.8 -> 387.4 k steps/s), +4 % at 32 members of config 5, +1.3 % at 256
         (400.6 -> 405.7 k); four or eight chains lose again (389 k at 256: the launches get too small); within noise or
-        worse below 32 members.  Default: TWO chains from 32 members on, one below; DLWP_ROLLOUT_GROUPS=g asks for g."""
+        worse below 32 members of the 88 x 180 grid.  Default: TWO chains from members x grid points >= 0.5 M on (32 members of
+        that grid, 8 of the 1-degree grid), one below; DLWP_ROLLOUT_GROUPS=g asks for g."""
+        # what decides is the work per launch, members x grid points: 32 members of the 88 x 180 grid = 0.5 M points; the 1-degree
+        # recurrent stack (config 4, 180 x 360) gains from 8 members on (r2y: 44.2 -> 45.8 k steps/s at 8, 48.2 -> 50.5 k at 16,
+        # four chains 44.4 k), 4 members of config 5 (0.26 M points) do not
         env = os.environ.get('DLWP_ROLLOUT_GROUPS')
-        g = int(env) if env else (2 if n >= 32 else 1)
+        g = int(env) if env else (2 if n * int(pixels) >= 500000 else 1)
         g = max(1, min(g, max(n, 1)))
         while n % g:
             g -= 1
@@ -247,7 +251,7 @@ class Executor(object):
         slot = int(np.prod(self.plan._in_store)) * n
         out = ctypes.c_void_p()
         dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        groups = self.member_groups(n) if groups is None else int(groups)
+        groups = self.member_groups(n, self.plan._in_store[1] * self.plan._in_store[2]) if groups is None else int(groups)
         nbuf = len(bufs)
         sample_bytes = (ctypes.c_size_t * max(1, len(table)))(
             *[(t[0].numel() * t.element_size() if (i < nbuf and n > 0) else 0) for i, t in enumerate(table)])
