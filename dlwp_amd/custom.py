@@ -11,6 +11,7 @@ The DLWP.custom names on the hot path, as descriptions for the HIP back end.
   EarlyStoppingMin    reference DLWP/custom.py:99-136
   RNNResetStates      reference DLWP/custom.py:94-96
   History             keras.callbacks.History (what examples/train.py:253 passes)
+  RunHistory, Adam- / SGDLearningRateTracker, BatchHistory   reference DLWP/custom.py:32-91
 """
 import numpy as np
 
@@ -249,6 +250,43 @@ class BatchHistory(Callback):
     def on_batch_end(self, batch, logs=None):
         for k, v in (logs or {}).items():
             self.history[self.epoch].setdefault(k, []).append(v)
+
+
+class RunHistory(History):
+    """History that also forwards every epoch's metrics to a run logger -- any object with `log(name, value)`, e.g. an AzureML
+    `Run` (reference DLWP/custom.py:71-91; call sites Azure/train_tf.py:376, Azure/train_func.py:348)."""
+
+    def __init__(self, run):
+        super(RunHistory, self).__init__()
+        self.epoch, self.history, self.run = [], {}, run
+
+    def on_epoch_end(self, epoch, logs=None):
+        super(RunHistory, self).on_epoch_end(epoch, logs)
+        for k, v in (logs or {}).items():
+            self.run.log(k, v)
+
+
+def _effective_lr(optimizer):
+    """lr / (1 + decay * iterations): the rate Keras' optimisers step with after `iterations` updates."""
+    return float(optimizer.lr) / (1.0 + float(optimizer.decay) * float(optimizer.iterations))
+
+
+class AdamLearningRateTracker(Callback):
+    """Prints Adam's bias-corrected step size at the end of every epoch (reference DLWP/custom.py:32-41); `last_lr` keeps it."""
+
+    def on_epoch_end(self, epoch, logs=None, beta_1=0.9, beta_2=0.999):
+        opt = self.model.optimizer
+        t = float(opt.iterations) + 1.0
+        self.last_lr = _effective_lr(opt) * np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t)
+        print(' - LR: {:.6f}'.format(self.last_lr))
+
+
+class SGDLearningRateTracker(Callback):
+    """Prints SGD's decayed learning rate at the end of every epoch (reference DLWP/custom.py:44-51)."""
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.last_lr = _effective_lr(self.model.optimizer)
+        print(' - LR: {:.6f}'.format(self.last_lr))
 
 
 class RNNResetStates(Callback):

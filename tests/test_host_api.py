@@ -505,3 +505,26 @@ def test_inference_plan_moves_the_pooling_into_the_producers():
     assert ip.conv_flops_per_sample() == d.model.plan.conv_flops_per_sample() == 1597685760
     assert not any(op.out_pool for op in d.model.plan.ops) and len(d.model.plan.ops) == 10
     assert d.model.executor.plan is ip and d.model.train_executor.plan is d.model.plan
+
+
+def test_remaining_reference_callbacks():
+    """RunHistory (custom.py:71-91), Adam / SGD learning-rate trackers (custom.py:32-51)."""
+    logged = []
+    run = types.SimpleNamespace(log=lambda k, v: logged.append((k, v)))
+    h = custom.RunHistory(run)
+    h.on_train_begin()
+    h.on_epoch_end(0, {'loss': 2.0, 'val_loss': 3.0})
+    h.on_epoch_end(1, {'loss': 1.0})
+    assert h.history == {'loss': [2.0, 1.0], 'val_loss': [3.0]} and h.epoch == [0, 1]
+    assert logged == [('loss', 2.0), ('val_loss', 3.0), ('loss', 1.0)]
+    opt = types.SimpleNamespace(lr=1e-3, decay=0.01, iterations=100)
+    t = custom.AdamLearningRateTracker()
+    t.model = types.SimpleNamespace(optimizer=opt)
+    t.on_epoch_end(0)
+    want = (1e-3 / (1 + 0.01 * 100)) * np.sqrt(1 - 0.999 ** 101) / (1 - 0.9 ** 101)
+    assert t.last_lr == pytest.approx(want, rel=1e-12)
+    s = custom.SGDLearningRateTracker()
+    s.model = t.model
+    s.on_epoch_end(0)
+    assert s.last_lr == pytest.approx(5e-4, rel=1e-12)
+    assert util.get_from_class('DLWP.custom', 'RunHistory') is custom.RunHistory
