@@ -5,6 +5,7 @@ The DLWP.custom names on the hot path, as descriptions for the HIP back end.
   PeriodicPadding2D   reference DLWP/custom.py:139-214   -> halo mode WRAP (fused into the next Conv2D's LDS loader,
                                                             or the standalone LDS-staged pad kernel)
   FillPadding2D       reference DLWP/custom.py:309-402   -> halo mode EDGE (pole-row replication)
+  TFPadding2D / 3D    reference DLWP/custom.py:527-672   -> halo modes ZERO / REFLECT / SYMMETRIC
   slice_layer         reference DLWP/custom.py:675-692   -> a channel window, resolved as an input-channel offset
   RowConnected2D      reference DLWP/custom.py:695-837   -> per-row filters: dlwp_rowconv2d_fwd / _bwd_data / _bwd_weight
   row_conv2d          reference DLWP/custom.py:840-896   -> the same launch on device tensors
@@ -89,6 +90,27 @@ class PeriodicPadding3D(_layers._Pad3DBase):
 class FillPadding3D(_layers._Pad3DBase):
     """Edge-replicating 3-D padding (reference DLWP/custom.py:405-520)."""
     mode = 2
+
+
+class TFPadding3D(_layers._Pad3DBase):
+    """tf.pad on the three trailing axes as a layer (reference DLWP/custom.py:602-672): mode 'CONSTANT' (zeros), 'REFLECT' or
+    'SYMMETRIC'; like the other 3-D pads it is lowered as a halo of the (T*C, H, W) store (the first axis is not padded)."""
+
+    def __init__(self, padding=(1, 1, 1), data_format=None, mode='CONSTANT', constant_values=0., **kwargs):
+        super(TFPadding3D, self).__init__(padding=padding, data_format=data_format, **kwargs)
+        modes = {'CONSTANT': 0, 'REFLECT': 3, 'SYMMETRIC': 4}
+        if str(mode).upper() not in modes:
+            raise ValueError("TFPadding3D mode must be one of 'CONSTANT', 'REFLECT', 'SYMMETRIC', got %r" % (mode,))
+        self.tf_mode = str(mode).upper()
+        self.mode = modes[self.tf_mode]
+        self.constant_values = float(constant_values)
+        if self.mode == 0 and self.constant_values != 0.:
+            raise NotImplementedError('TFPadding3D: a non-zero constant_values is not implemented (zeros are)')
+
+    def get_config(self):
+        cfg = super(TFPadding3D, self).get_config()
+        cfg.update({'mode': self.tf_mode, 'constant_values': self.constant_values})
+        return cfg
 
 
 def slice_layer(start, end, step=None, axis=1):

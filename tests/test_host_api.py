@@ -528,3 +528,19 @@ def test_remaining_reference_callbacks():
     s.on_epoch_end(0)
     assert s.last_lr == pytest.approx(5e-4, rel=1e-12)
     assert util.get_from_class('DLWP.custom', 'RunHistory') is custom.RunHistory
+
+
+def test_tf_padding3d_lowers_to_a_mirror_halo_of_the_recurrent_front_end():
+    """TFPadding3D (reference custom.py:602-672) in front of ConvLSTM2D: a REFLECT halo of the (T*C, H, W) store, fused into
+    the input convolution's loader like PeriodicPadding3D."""
+    x0 = L.Input(shape=(2, 3, 8, 12))
+    y = L.ConvLSTM2D(4, 3, padding='valid', return_sequences=True, **CF)(
+        custom.TFPadding3D((0, 1, 1), mode='REFLECT', **CF)(x0))
+    m = Model(inputs=x0, outputs=y)
+    convs = [op for op in m.plan.ops if op.kind == 'conv']
+    assert tuple(convs[0].halo) == (1, 1, 1, 1, 3, 3) and m.output_shape == (None, 2, 4, 8, 12)
+    assert not any(op.kind == 'pad' for op in m.plan.ops)
+    with pytest.raises(ValueError):
+        custom.TFPadding3D((0, 1, 1), mode='WRAP', **CF)
+    with pytest.raises(NotImplementedError):
+        Model(inputs=x0, outputs=custom.TFPadding3D((1, 0, 0), **CF)(x0))       # padding of the first (channel) axis
