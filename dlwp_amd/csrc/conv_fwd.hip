@@ -341,6 +341,18 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     // tiles (two fragments per wave) with 16-channel chunks run 3-4 waves per SIMD (114-132 registers) against two for the
     // 8 x 32 / 32-channel ones (measured on config 4, tools/tune_lstm_conv.py: 0.100 vs 0.128 ms on the recurrent convolution)
     if (e.gates) c *= (e.th == 4 ? 0.7 : 1.0) * (e.ck == 16 ? 0.7 : 1.0);
+    // Winograd, grids of a few members: the two-wave instances (8 x 16, 4 x 32 tiles) lose to the four-wave ones although
+    // they make more workgroups -- every workgroup fetches the whole 16 x cin x cout-tile block of transformed filters, with
+    // half the threads to do it and twice the workgroups re-reading it from L2.  Measured (tools/tune_plan.py, r2z): 64 ->
+    // 128 at 22 x 45, 8 members: 0.0253 ms (8 x 16, two waves) vs 0.0186 (8 x 32); 64 -> 32 at 44 x 90: 0.0251 vs 0.0178;
+    // 128 -> 64 on the up-sampled 22 x 45 at 4 members: 0.0296 vs 0.0230.  One member alone is the exception (0.0128 vs
+    // 0.013+: nothing to share), and from two full rounds of workgroups on the model above decides as before.
+    if (is_wino(e) && !e.split && e.waves < 4 && a.N >= 2) {
+      const long long blocks = (long long)dlwp_ceil_div(a.Ho, e.th) * dlwp_ceil_div(a.Wo, e.tw) * dlwp_ceil_div(a.Cout, 16 * e.bnf) * a.N;
+      // (the 9-position variants' model above scales with waves / 4: there the factor has to undo that, and the measured
+      //  crossover is earlier -- 128 -> 64 at 8 members: two-wave 0.0312 vs 0.0329)
+      if (wino_skips_row2(a) ? blocks < 2ll * cu_count : blocks < 4ll * cu_count) c *= wino_skips_row2(a) ? 2.0 : 1.5;
+    }
     if (best < 0 || c < best_cost) {
       best = i;
       best_cost = c;
