@@ -157,6 +157,21 @@ def main():
         names = [('layer_with_a_long_name_%05d' % i).encode('utf8') for i in range(3000)]
         save_attr_list(f.create_group('chunks'), 'layer_names', names)
         expected['con|chunk_names'] = np.asarray(names)
+    # ---- the newest file format (libver='latest': superblock 3, version-2 object headers, link messages): what the reader
+    #      covers of it (compact groups, contiguous data) and what it must refuse by name (dense groups, new chunk indexes)
+    with h5py.File(os.path.join(OUT, 'keras_container_latest.h5'), 'w', libver='latest') as f:
+        f.attrs['a'] = np.arange(3)
+        g = f.create_group('g')
+        a = rng.standard_normal((4, 5)).astype(np.float32)
+        g.create_dataset('x', data=a)
+        expected['new|g/x'] = a
+        g.create_dataset('y', data=np.arange(6, dtype=np.int16))
+        expected['new|g/y'] = np.arange(6, dtype=np.int16)
+        g.attrs['names'] = np.array([b'ab', b'cde'])
+        f.create_dataset('chunked', data=np.arange(20.).reshape(4, 5), chunks=(2, 5))
+        many = f.create_group('many')
+        for i in range(30):
+            many.create_dataset('d%02d' % i, data=np.full(2, i))
     np.savez_compressed(os.path.join(OUT, 'keras_h5_expected.npz'), **expected)
     for fn in sorted(os.listdir(OUT)):
         if fn.startswith('keras_'):

@@ -61,6 +61,18 @@ def test_reader_container_features():
     assert not hdf5_lite.is_hdf5(os.path.join(GOLDEN, 'padding.npz'))
 
 
+def test_reader_on_the_newest_file_format_covers_compact_groups_and_names_what_it_refuses():
+    f = hdf5_lite.File(os.path.join(GOLDEN, 'keras_container_latest.h5'))      # superblock 3, 'OHDR' headers, link messages
+    exp = _expected('new')
+    assert sorted(f.keys()) == ['chunked', 'g', 'many'] and np.array_equal(f.attrs['a'], np.arange(3))
+    assert np.array_equal(f['g/x'][...], exp['g/x']) and np.array_equal(f['g/y'][...], exp['g/y'])
+    assert list(f['g'].attrs['names']) == [b'ab', b'cde']
+    with pytest.raises(NotImplementedError, match='dense link storage'):
+        f['many']
+    with pytest.raises(NotImplementedError, match='chunk'):
+        f['chunked'][...]
+
+
 def test_import_sequential_checkpoint():
     m = serialization.load_model_file(os.path.join(GOLDEN, 'keras_sequential.h5'))      # routed by the file signature
     exp = _expected('seq')
