@@ -290,6 +290,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     const bool pack_ok = e.pack <= 0 || (cd->cout <= 16 / e.pack);
     if (is_wino(e) && (!winograd_wanted(a, cd, o) || a.Cout % (16 * e.bnf) != 0)) return -1;  // whole channel chunks only
     if (is_wino(e) && e.bnf == 1 && wino_skips_row2(a)) return -1;  // 16-channel blocks have no 9-position variant
+    if (is_wino(e) && e.split && (e.split == 2) != (a.Cout % 32 == 0)) return -1;   // one arithmetic per kind of layer (below)
     if (is_bf16(e) && (!bf16_wanted(a, cd, o) || (e.in32 != 0) == (a.in_bf16 != 0) ||
                        bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) return -1;
     if (cd->out_pool && !e.out_pool) return -1;
@@ -330,8 +331,16 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     if (is_wino(e) && a.Cout % (16 * e.bnf) != 0) continue;                // Winograd: whole output-channel tiles only
     if (is_wino(e) && e.bnf == 4 && !wino_skips_row2(a)) continue;         // 64-channel blocks: 9-position variants only
     if (is_wino(e) && e.bnf == 1 && wino_skips_row2(a)) continue;          // 16-channel blocks: no 9-position variant
-    if (is_wino(e) && e.bnf == 1 && a.Cout % 32 == 0) continue;            // ... and only for layers the 32-channel kernel cannot tile
-                                                                           // (the two kernels round differently: one kind per layer)
+    // ... the position-split instances (split = 1, their own cheaper arithmetic) only for layers the 32-channel kernel cannot
+    // tile -- the two round differently: one kind per layer -- and their COMPAT variants (split = 2: the 32-channel kernel's
+    // arithmetic, the same bits) only for layers it CAN tile, while that kernel's grid is under half a workgroup per CU: 2 - 4 x
+    // the workgroups, each fetching half the filter block.  Measured (bench.py --members m, r2z): 1 member 28.7 -> 30.1 k
+    // steps/s, 4 members 102.5 -> 106.1 k; with the bound at two workgroups per CU 8 members lost 3 % (172.6 -> 166.7 k: the
+    // COMPAT arithmetic costs the split kernel its edge there), 16 members gained 0.3 %
+    if (is_wino(e) && e.split == 1 && a.Cout % 32 == 0) continue;
+    if (is_wino(e) && e.split == 2 &&
+        (a.Cout % 32 != 0 || cd->out_d2s ||
+         2ll * dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * (a.Cout / 32) * a.N >= (long long)cu_count)) continue;
     if (is_bf16(e) && ((e.in32 != 0) == (a.in_bf16 != 0) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) continue;
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     if (cd->out_d2s && !(is_wino(e) && e.split)) continue;                 // interleaved phase stores: the 16-channel instances
@@ -769,7 +778,8 @@ int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes) {
 int dlwp_conv2d_config_flags(int i) {
   Registry& r = registry();
   if (i < 0 || i >= (int)r.entries.size()) return 0;
-  return ((is_wino(r.entries[i]) && r.entries[i].split) ? 1 : 0) | (r.entries[i].gates ? 2 : 0);
+  return ((is_wino(r.entries[i]) && r.entries[i].split) ? 1 : 0) | (r.entries[i].gates ? 2 : 0) |
+         ((is_wino(r.entries[i]) && r.entries[i].split == 2) ? 4 : 0);
 }
 
 int dlwp_conv2d_prefers_unfused_pool(dlwp_handle_t h, int cin, int cout, int kh, int kw, int dil_h, int dil_w) {

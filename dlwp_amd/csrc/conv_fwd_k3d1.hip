@@ -48,6 +48,9 @@ static const ConvKernelEntry k_table[] = {
     WINO2_ENTRY(1, 8, 32, 4, 1, 8),
     WINO2_ENTRY(1, 4, 64, 4, 1, 8),
     WINO2_ENTRY(1, 8, 16, 2, 1, 8),
+    // ... in the 32-channel kernel's arithmetic (same bits), for layers with whole 32-channel tiles while their grid is small
+    WINO2C_ENTRY(1, 8, 32, 4, 1, 8),
+    WINO2C_ENTRY(1, 8, 16, 2, 1, 8),
 };
 const ConvKernelEntry* dlwp_conv_table_k3d1(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));

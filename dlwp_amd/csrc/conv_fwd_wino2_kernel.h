@@ -25,9 +25,14 @@
 #pragma once
 #include "conv_fwd_wino_kernel.h"
 
-template <int DIL_, int TH_, int TW_, int FRAGS_, int BNF_, int CK_, bool IN16_ = false>
+// COMPAT_: both transforms are evaluated in conv_fwd_wino_kernel.h's order of operations -- the SAME BITS as that kernel, so a
+// layer with whole 32-channel tiles may run here while its grid is small (more, lighter workgroups) and there otherwise, and a
+// member's forecast does not depend on the batch it is in.  Costs 4 adds per half in the input transform and a wider
+// hand-over between the halves (8 floats per (tile, channel) in two rounds): the layers that always run here (16 / 48 output
+// channels: the restated output layer) keep the cheaper arithmetic (measured r2z: with it on that layer, 421 -> 411 k steps/s).
+template <int DIL_, int TH_, int TW_, int FRAGS_, int BNF_, int CK_, bool IN16_ = false, bool COMPAT_ = false>
 struct WinoSplitCfg {
-  static constexpr bool IN16 = IN16_;
+  static constexpr bool IN16 = IN16_, COMPAT = COMPAT_;
   static constexpr int DIL = DIL_, TH = TH_, TW = TW_, FRAGS = FRAGS_, BNF = BNF_, CK = CK_;
   static constexpr int NT = 2 * FRAGS * 64;       // two waves (position halves) per tile fragment
   static constexpr int LR = TH + 2 * DIL, LC = TW + 2 * DIL;
@@ -173,23 +178,42 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino2_f32
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[r][c] = dp[r * C::LCP + c];
       float rw[2][4];    // B^T d: the two transformed rows of this half
+      float tr[3][4];    // COMPAT: d B of this half's three patch rows
+      if constexpr (C::COMPAT) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if constexpr (HALF == 0) {      // patch rows 0, 1, 2:  row 0 = d0 - d2,  row 1 = d1 + d2
-          rw[0][c] = d[0][c] - d[2][c];
-          rw[1][c] = d[1][c] + d[2][c];
-        } else {                        // patch rows 1, 2, 3:  row 2 = d2 - d1,  row 3 = d1 - d3
-          rw[0][c] = d[1][c] - d[0][c];
-          rw[1][c] = d[0][c] - d[2][c];
+        for (int r = 0; r < 3; ++r) {
+          tr[r][0] = d[r][0] - d[r][2];
+          tr[r][1] = d[r][1] + d[r][2];
+          tr[r][2] = d[r][2] - d[r][1];
+          tr[r][3] = d[r][1] - d[r][3];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if constexpr (HALF == 0) {      // patch rows 0, 1, 2:  row 0 = d0 - d2,  row 1 = d1 + d2
+            rw[0][c] = d[0][c] - d[2][c];
+            rw[1][c] = d[1][c] + d[2][c];
+          } else {                        // patch rows 1, 2, 3:  row 2 = d2 - d1,  row 3 = d1 - d3
+            rw[0][c] = d[1][c] - d[0][c];
+            rw[1][c] = d[0][c] - d[2][c];
+          }
         }
       }
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
-        float v[4];                     // (B^T d) B
-        v[0] = rw[rr][0] - rw[rr][2];
-        v[1] = rw[rr][1] + rw[rr][2];
-        v[2] = rw[rr][2] - rw[rr][1];
-        v[3] = rw[rr][1] - rw[rr][3];
+        float v[4];                     // (B^T d) B -- COMPAT: B^T (d B), the other kernel's order
+        if constexpr (C::COMPAT) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if constexpr (HALF == 0) v[c] = rr == 0 ? tr[0][c] - tr[2][c] : tr[1][c] + tr[2][c];
+            else v[c] = rr == 0 ? tr[1][c] - tr[0][c] : tr[0][c] - tr[2][c];
+          }
+        } else {
+          v[0] = rw[rr][0] - rw[rr][2];
+          v[1] = rw[rr][1] + rw[rr][2];
+          v[2] = rw[rr][2] - rw[rr][1];
+          v[3] = rw[rr][1] - rw[rr][3];
+        }
         f32x4 bf[C::BNF];
 #pragma unroll
         for (int g = 0; g < C::BNF; ++g)
@@ -224,6 +248,97 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino2_f32
   else main_loop(std::integral_constant<int, 1>{});
   __syncthreads();  // every wave is out of the loop: LDS becomes the output staging area
 
+  // ---- COMPAT: Y = A^T M A with exactly the arithmetic of conv_fwd_wino_kernel.h: s0[c] = (m0 + m1) + m2, s1[c] = (m1 - m2)
+  //      - m3 per column c, then y[a][0] = (s[a][0] + s[a][1]) + s[a][2], y[a][1] = (s[a][1] - s[a][2]) - s[a][3].  Half 0
+  //      (rows 0, 1 of M) hands (m0 + m1) and m1 over through the tile's own 4 output slots, columns 0, 1 then 2, 3; half 1
+  //      (rows 2, 3) completes, adds the bias, activates (pools).
+  if constexpr (C::COMPAT) {
+    auto slot = [&](int g, int r, int& col, int& ti, int& tj) -> float* {
+      col = g * 16 + (lane & 15);
+      const int t = frag * 16 + (lane >> 4) * 4 + r;
+      const int pc = t / (C::RTH * C::RTW), rem = t - pc * (C::RTH * C::RTW);
+      ti = rem / C::RTW;
+      tj = rem - ti * C::RTW;
+      const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
+      return lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
+    };
+    float hs0[C::BNF][4][4], hm1[C::BNF][4][4];     // half 1: (m0 + m1) and m1 of half 0, per (g, r, c)
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      if (half == 0) {
+#pragma unroll
+        for (int g = 0; g < C::BNF; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int col, ti, tj;
+            float* op = slot(g, r, col, ti, tj);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int c = 2 * round + k;
+              const float m0 = acc[c][g][r], m1 = acc[4 + c][g][r];
+              op[k * C::DIL * C::TW] = m0 + m1;
+              op[k * C::DIL * C::TW + C::DIL] = m1;
+            }
+          }
+      }
+      __syncthreads();
+      if (half == 1) {
+#pragma unroll
+        for (int g = 0; g < C::BNF; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int col, ti, tj;
+            const float* op = slot(g, r, col, ti, tj);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              hs0[g][r][2 * round + k] = op[k * C::DIL * C::TW];
+              hm1[g][r][2 * round + k] = op[k * C::DIL * C::TW + C::DIL];
+            }
+          }
+      }
+      __syncthreads();
+    }
+    act_dispatch(a.act, [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      if (half == 1) {
+#pragma unroll
+        for (int g = 0; g < C::BNF; ++g) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int col, ti, tj;
+            float* op = slot(g, r, col, ti, tj);
+            const float bv = a.bias ? a.bias[n0 + col] : 0.f;
+            float sv[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float m2 = acc[c][g][r], m3 = acc[4 + c][g][r];
+              sv[0][c] = hs0[g][r][c] + m2;
+              sv[1][c] = (hm1[g][r][c] - m2) - m3;
+            }
+            float y[2][2];
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+              y[aa][0] = (sv[aa][0] + sv[aa][1]) + sv[aa][2];
+              y[aa][1] = (sv[aa][1] - sv[aa][2]) - sv[aa][3];
+            }
+            if constexpr (C::DIL == 1) {
+              if (a.out_pool) {  // MaxPooling2D(2): the 2x2 tile IS one pooling window; activation after the maximum
+                const float mx = fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[1][0], y[1][1]));
+                lds[C::O_FLOATS + col * ((C::TH / 2) * (C::TW / 2)) + ti * (C::TW / 2) + tj] = act_apply_c<ACT>(mx + bv);
+                continue;
+              }
+            }
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+              op[aa * C::DIL * C::TW] = act_apply_c<ACT>(y[aa][0] + bv);
+              op[aa * C::DIL * C::TW + C::DIL] = act_apply_c<ACT>(y[aa][1] + bv);
+            }
+          }
+        }
+      }
+    });
+    __syncthreads();
+  } else {
   // ---- output transform: the partial 2x2 tile of this half's 8 positions; half 0 parks it, half 1 completes it
   act_dispatch(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
@@ -290,6 +405,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino2_f32
       __syncthreads();
     }
   });
+  }
 
   // ---- stores: 16-byte row segments of the (pooled) output
   if (a.out_pool) {
@@ -442,7 +558,7 @@ static int wino2_prepare() {
 // One registry entry = one tile geometry, running the position-split kernel of this file (2 x FRAGS waves).  (A BNF = 2
 // entry would hand an up-sampled source with odd halos, or the 2x2-sum epilogue, to the 9-position variant of
 // conv_fwd_wino_kernel.h; the registered BNF = 1 entries are not offered those layers, conv_fwd.hip.)
-template <int DIL, int TH, int TW, int FRAGS, int BNF, int CK>
+template <int DIL, int TH, int TW, int FRAGS, int BNF, int CK, bool COMPAT = false>
 static void wino2_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
   if constexpr (DIL == 1 && BNF >= 2) {
     if ((a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1)) || a.out_pool == 2) {
@@ -451,14 +567,14 @@ static void wino2_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
       return;
     }
   }
-  if (a.in_bf16) wino2_launch_thunk<WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK, true>>(a, grid, s);
-  else wino2_launch_thunk<WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK, false>>(a, grid, s);
+  if (a.in_bf16) wino2_launch_thunk<WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK, true, COMPAT>>(a, grid, s);
+  else wino2_launch_thunk<WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK, false, COMPAT>>(a, grid, s);
 }
 
-template <int DIL, int TH, int TW, int FRAGS, int BNF, int CK>
+template <int DIL, int TH, int TW, int FRAGS, int BNF, int CK, bool COMPAT = false>
 static int wino2_prepare_both() {
-  int e = wino2_prepare<WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK, false>>();
-  if (e == 0) e = wino2_prepare<WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK, true>>();
+  int e = wino2_prepare<WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK, false, COMPAT>>();
+  if (e == 0) e = wino2_prepare<WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK, true, COMPAT>>();
   if constexpr (DIL == 1 && BNF >= 2) {
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, FRAGS, BNF, CK, false, true>>();
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, FRAGS, BNF, CK, true, true>>();
@@ -471,4 +587,10 @@ static int wino2_prepare_both() {
   {                                                                                                                      \
     3, DIL, TH, TW, FRAGS, 0, BNF, CK, WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK>::LDS_BYTES, false, -1, 1, 0,            \
         &wino2_launch_either<DIL, TH, TW, FRAGS, BNF, CK>, &wino2_prepare_both<DIL, TH, TW, FRAGS, BNF, CK>, 0, 1        \
+  }
+// ... and the COMPAT variant (split = 2): the same bits as conv_fwd_wino_kernel.h
+#define WINO2C_ENTRY(DIL, TH, TW, FRAGS, BNF, CK)                                                                        \
+  {                                                                                                                      \
+    3, DIL, TH, TW, FRAGS, 0, BNF, CK, WinoSplitCfg<DIL, TH, TW, FRAGS, BNF, CK>::LDS_BYTES, false, -1, 1, 0,            \
+        &wino2_launch_either<DIL, TH, TW, FRAGS, BNF, CK, true>, &wino2_prepare_both<DIL, TH, TW, FRAGS, BNF, CK, true>, 0, 2        \
   }

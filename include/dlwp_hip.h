@@ -155,7 +155,10 @@ int dlwp_conv2d_config_info(int i, int* info9, int* lds_bytes);
 int dlwp_conv2d_config_flags(int i);        /* bit 0: Winograd instance whose 16-position case splits the positions over two
                                               * waves per tile fragment (conv_fwd_wino2_kernel.h: 2 x waves x 64 threads);
                                               * bit 1: bf16 instance with the ConvLSTM2D cell update in its epilogue
-                                              * (dlwp_conv2d.lstm_f; takes only such layers) */
+                                              * (dlwp_conv2d.lstm_f; takes only such layers);
+                                              * bit 2: position-split instance evaluated in the 32-channel kernel's order of
+                                              * operations (same bits as that kernel): for layers with whole 32-channel tiles on
+                                              * small grids, where the plain split instances (bit 0 alone) are not offered */
 /* Host logic (no device work; handle nullable = default options): 1 when dlwp_conv2d_fwd(xs, cd, dtype) multiplies with
  * bf16-rounded weights (the bf16-MFMA family), else 0: what a caller comparing against an fp32-weight computation needs to
  * know. */

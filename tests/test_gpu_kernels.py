@@ -211,12 +211,13 @@ def test_conv2d_every_compiled_tile_configuration(ops):
                 continue                                # bf16 matrix-core instances: test_conv2d_bf16_mfma_* below
             cmax = 16 // (-bnf) if bnf < 0 else 0       # packed-N instances cover cout <= 16/S
             wino = fa == 0                              # Winograd instances: whole chunks of 8 in / 32 out channels
-            key = (ks, dil, pool, cmax, wino)
+            plain_split = (flags & 5) == 1              # position-split Winograd, own arithmetic: layers WITHOUT whole 32-channel tiles
+            key = (ks, dil, pool, cmax, wino, plain_split)
             src = 2 if pool else 0                      # pooled-loader instances only run the fused max-pool source
             if key not in problems:
                 n, cin, h, w, cout = 2, 20, (39 if pool else 19), (101 if pool else 50), (36 if not cmax else max(1, cmax - 1))
                 if wino:
-                    cin, cout = 24, 64
+                    cin, cout = 24, (48 if plain_split else 64)
                 x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
                 wt = np_ref.glorot_uniform((ks, ks, cin, cout), rng)
                 b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
@@ -295,8 +296,8 @@ def test_winograd_position_split_instances_for_16_output_channels(ops, pool, in1
         seen, tried = None, 0
         try:
             for i, c in enumerate(cfgs):
-                if not (c[0] == 3 and c[1] == 1 and c[5] == 0 and c[6] == 1 and c[10] & 1):
-                    continue
+                if not (c[0] == 3 and c[1] == 1 and c[5] == 0 and c[6] == 1 and c[10] & 1) or c[10] & 4:
+                    continue              # (bit 2: the variants for 32-channel layers, not offered here)
                 tried += 1
                 ops.force_conv_config(i)
                 got = ops.conv2d(xd, dev(wt), dev(b), cd, out=torch.empty(want.shape, dtype=torch.float32, device='cuda'))
@@ -312,6 +313,51 @@ def test_winograd_position_split_instances_for_16_output_channels(ops, pool, in1
             pick = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(0), ops.Shape4(n, cin, h, w), ctypes.byref(cd))
             assert pick >= 0 and cfgs[pick][10] & 1, 'expected a position-split Winograd instance, got %r' % (cfgs[pick],)
             assert torch.equal(ops.conv2d(xd, dev(wt), dev(b), cd, out=torch.empty_like(seen)), seen)
+
+
+@pytest.mark.parametrize('pool', [False, True])
+def test_winograd_compat_split_instances_give_the_bits_of_the_32_channel_kernel(ops, pool):
+    """A layer with whole 32-channel tiles runs on conv_fwd_wino_kernel.h, or -- while its grid is small -- on the COMPAT
+    position-split instances of conv_fwd_wino2_kernel.h, which evaluate both transforms in that kernel's order of operations:
+    every such instance gives the SAME BITS (plain and pooled epilogue, tanh, ragged map, two channel tiles), so a member's
+    forecast does not depend on the batch it is in; the plain split instances (their own arithmetic) are refused for such a
+    layer; a 2-member grid really takes a COMPAT instance, a 256-member one the 32-channel kernel."""
+    import ctypes
+    from dlwp_amd import _lib
+    rng = np.random.default_rng(99)
+    cfgs = ops.conv_configs()
+    n, cin, h, w, cout = 2, 40, 22, 46, 64
+    x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+    wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+    b = dev((0.1 * rng.standard_normal(cout)).astype(np.float32))
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, out_pool=pool)
+    want = _conv_ref(host(x), host(wt), host(b), 1, (1, 1, 1, 1), 0, 1, 'tanh', 0)
+    if pool:
+        want = np_ref.maxpool2(want)
+    seen, kinds, refused = None, set(), 0
+    try:
+        for i, c in enumerate(cfgs):
+            if not (c[0] == 3 and c[1] == 1 and c[5] == 0 and c[8] < 2 and c[6] in (1, 2)):
+                continue
+            ops.force_conv_config(i)
+            try:
+                got = ops.conv2d(x, wt, b, cd)
+            except _lib.DlwpError:
+                refused += (c[10] & 5) == 1   # (a plain split instance, or an instance without this epilogue)
+                continue
+            _check_conv(ops, host(got), want, 'config %d %r' % (i, c))
+            assert seen is None or torch.equal(got, seen), 'Winograd instance %d %r differs from the others' % (i, c)
+            seen = got
+            assert not (c[10] & 1) or c[10] & 4
+            kinds.add(c[10] & 1)
+    finally:
+        ops.force_conv_config(-1)
+    assert kinds == {0, 1} and refused >= 3, (kinds, refused)
+    pick = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(0), ops.Shape4(n, cin, h, w), ctypes.byref(cd))
+    assert cfgs[pick][10] & 1, 'a 2-member grid should run on a COMPAT split instance, got %r' % (cfgs[pick],)
+    big = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(0), ops.Shape4(256, cin, h, w), ctypes.byref(cd))
+    assert not cfgs[big][10] & 1 and cfgs[big][6] == 2
+    assert torch.equal(ops.conv2d(x, wt, b, cd), seen)
 
 
 @pytest.mark.parametrize('fields,hw', [(4, (20, 70)), (12, (19, 45)), (4, (44, 90))])
@@ -339,7 +385,7 @@ def test_winograd_phase_channels_stored_interleaved(ops, fields, hw):
     tried = 0
     try:
         for i, c in enumerate([None] + list(cfgs)):
-            if c is not None and not (c[0] == 3 and c[1] == 1 and c[5] == 0 and c[6] == 1 and c[10] & 1):
+            if c is not None and (not (c[0] == 3 and c[1] == 1 and c[5] == 0 and c[6] == 1 and c[10] & 1) or c[10] & 4):
                 continue
             ops.force_conv_config(i - 1)
             tried += 1
