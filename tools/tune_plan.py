@@ -33,16 +33,21 @@ def main():
     ap.add_argument('--channels', type=int, default=4)
     ap.add_argument('--members', type=int, default=4)
     ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--recurrent-bf16', action='store_true',
+                    help='BASELINE config 4: ConvLSTM2D front end + U-Net on (2, channels / 2, H, W), bfloat16 activation storage')
     a = ap.parse_args()
     from dlwp_amd import ops
     from dlwp_amd._lib import DlwpError
     from dlwp_amd.model import DLWPNeuralNet
-    from dlwp_amd.presets import unet_layers
+    from dlwp_amd.presets import lstm_unet_layers, unet_layers
     h, w = (int(v) for v in a.grid.split('x'))
     np.random.seed(1234)
-    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
-    d.build_model(unet_layers((a.channels, h, w)), loss='mse', optimizer='adam')
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=a.recurrent_bf16, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(lstm_unet_layers((2, a.channels // 2, h, w)) if a.recurrent_bf16 else unet_layers((a.channels, h, w)),
+                  loss='mse', optimizer='adam')
     net = d.model
+    if a.recurrent_bf16:
+        net.set_activation_dtype('bfloat16')
     ex, plan = net.executor, net.infer_plan
     n = a.members
     x = torch.randn((n,) + plan._in_store, device=net.device)
@@ -58,12 +63,18 @@ def main():
             continue
         kern, bias = ex.conv_weights(op)
         src, dst = res(op.src), res(op.dst)
+        c16 = op.dst in ex._bf16 and op.src not in ex._bf16      # float32 state rounded by the loader (Executor.run)
 
         def fn():
-            ops.conv2d(src, kern, bias, desc, out=dst, x_channels=op.xs[0])
+            if op.lstm_f:
+                za, cp, co = op.aux
+                ops.convlstm_conv(src, kern, bias, desc, dst, res(co), z_add=res(za) if za is not None else None,
+                                  c_prev=res(cp) if cp is not None else None, x_channels=op.xs[0], compute_bf16=c16)
+            else:
+                ops.conv2d(src, kern, bias, desc, out=dst, x_channels=op.xs[0], compute_bf16=c16)
         ops.force_conv_config(-1)
         base = timed(fn, a.iters)
-        pick = ops.conv_launch_info((n,) + tuple(op.xs), desc, None, net.device.index or 0)
+        pick = ops.conv_launch_info((n,) + tuple(op.xs), desc, ex._conv_dtype(op), net.device.index or 0)
         rows = []
         for i in range(len(cfgs)):
             ops.force_conv_config(i)
