@@ -338,3 +338,70 @@ def test_bfloat16_activation_mode_keeps_the_row_connected_layer_in_float32():
     assert np.array_equal(series[0:2].transpose(1, 0, 2, 3, 4).reshape(p.shape), p)
     d.model.set_activation_dtype('float32')
     assert np.array_equal(d.predict(x), y32)
+
+
+def test_functional_skip_unet_with_the_latitude_dependent_output_layer():
+    """examples/train_functional.py with latitude_dependent = True (:53, 191-196) and skip_connections = True (:248-275): the
+    RowConnected2D output layer reads the concatenation of the decoder and the first skip; DLWPFunctional with two chained
+    outputs (integration_steps = 2: the SAME layer objects applied twice), predict against the oracle, the rollout against the
+    host loop, and training through both applications of the shared row-connected kernel."""
+    from dlwp_amd import custom, layers as L
+    from dlwp_amd.engine import Model
+    from dlwp_amd.model import DLWPFunctional
+    rng = np.random.default_rng(15)
+    cs = (4, 16, 24)
+    x0 = L.Input(shape=cs)
+    pp2, zp2 = custom.PeriodicPadding2D((0, 2), **CF), L.ZeroPadding2D((2, 0), **CF)
+    pp1, zp1 = custom.PeriodicPadding2D((0, 1), **CF), L.ZeroPadding2D((1, 0), **CF)
+    pool, up = L.MaxPooling2D(2, **CF), L.UpSampling2D(2, **CF)
+    c1 = L.Conv2D(32, 3, dilation_rate=2, activation='tanh', **CF)
+    c2 = L.Conv2D(32, 3, activation='tanh', **CF)
+    c5 = L.Conv2D(16, 3, dilation_rate=2, activation='tanh', **CF)
+    row = custom.RowConnected2D(cs[0], 5, padding='valid', activation='linear', **CF)
+    s11, s12 = custom.slice_layer(0, 16, axis=1), custom.slice_layer(16, 32, axis=1)
+
+    def net(x):
+        x = c1(pp2(zp2(x)))
+        x, x1 = s11(x), s12(x)
+        x = c2(pp1(zp1(pool(x))))
+        x = c5(pp2(zp2(up(x))))
+        x = L.concatenate([x, x1], axis=1)
+        return row(pp2(zp2(x)))
+    outs = [net(x0)]
+    outs.append(net(outs[0]))
+    np.random.seed(15)
+    m = Model(inputs=x0, outputs=outs)
+    f = DLWPFunctional(is_convolutional=True, time_dim=2)
+    f.build_model(m, loss='mse', loss_weights=[0.5, 0.5], optimizer='adam', metrics=['mae'])
+    ws = m.get_weights()
+    assert [w.shape for w in ws][-2:] == [(16, 5, 5, 32, 4), (16, 1, 4)]
+    ws = [w if i % 2 == 0 else (0.1 * rng.standard_normal(w.shape)).astype(np.float32) for i, w in enumerate(ws)]
+    m.set_weights(ws)
+    p1, p2, p5, pr = [(ws[i], ws[i + 1]) for i in range(0, 8, 2)]
+
+    def ref(x):
+        def halo(t, k):
+            return np_ref.zero_padding2d(np_ref.periodic_padding2d(t, (0, k)), (k, 0))
+        a = np_ref.conv2d(halo(x, 2), *p1, 2, 'tanh')
+        a, a1 = a[:, :16], a[:, 16:]
+        b = np_ref.conv2d(halo(np_ref.maxpool2(a), 1), *p2, 1, 'tanh')
+        g = np_ref.conv2d(halo(np_ref.upsample2(b), 2), *p5, 2, 'tanh')
+        return np_ref.row_connected2d(halo(np.concatenate([g, a1], axis=1), 2), *pr)
+    x = rng.standard_normal((3,) + cs).astype(np.float32)
+    y1, y2 = f.predict(x)
+    r1 = ref(x.astype(np.float64))
+    assert np.abs(y1 - r1).max() <= 2e-5 * max(np.abs(r1).max(), 1.0)
+    assert np.abs(y2 - ref(r1)).max() <= 8e-5 * max(np.abs(r1).max(), 1.0)
+    ts = f.predict_timeseries(x, 5)
+    p, slots = x, []
+    for _ in range(2):
+        o1, o2 = f.predict(p)
+        slots += [o1, o2]
+        p = o2
+    assert np.array_equal(ts, np_ref._merge_time(np.stack(slots), 4, 3, 2, cs, False))
+    # training: the shared row-connected kernel collects the gradients of both applications
+    yt = [rng.standard_normal((3,) + cs).astype(np.float32) for _ in range(2)]
+    l0 = m.test_on_batch(x, yt)[0]
+    for _ in range(12):
+        m.train_on_batch(x, yt)
+    assert m.test_on_batch(x, yt)[0] < l0
