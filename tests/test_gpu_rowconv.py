@@ -405,3 +405,48 @@ def test_functional_skip_unet_with_the_latitude_dependent_output_layer():
     for _ in range(12):
         m.train_on_batch(x, yt)
     assert m.test_on_batch(x, yt)[0] < l0
+
+
+def test_random_geometries_against_the_oracle(ops):
+    """Seeded sweep over the planners' corner cases: kernel sizes 1 ... 5 x 1 ... 7, 1 ... 40 output fields (every packing
+    factor, several 16-channel groups), channel counts that are not multiples of 4, widths from one fragment to several column
+    blocks, batches that do not fill the sample groups, every halo mode, asymmetric halos -- forward and all three gradients."""
+    from dlwp_amd._lib import Shape4
+    rng = np.random.default_rng(2024)
+    n_mfma = 0
+    for trial in range(30):
+        kh, kw = int(rng.integers(1, 6)), int(rng.integers(1, 8))
+        if trial >= 28:                 # taller than the matrix-core kernels unroll: the vector-ALU kernels of all three passes
+            kh = 6 + (trial - 28)
+        cout = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 16, 17, 33, 40]))
+        cin = int(rng.choice([1, 3, 4, 6, 8, 13, 24]))
+        n = int(rng.integers(1, 6))
+        h = int(rng.integers(kh, kh + 9))
+        w = int(rng.choice([kw, kw + 3, 17, 33, 70, 131]))
+        mh, mw = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+        lim_h = h - 1 if mh == 3 else h
+        lim_w = w - 1 if mw == 3 else w
+        t, b = (int(rng.integers(0, min(3, lim_h) + 1)) for _ in range(2))
+        l, r = (int(rng.integers(0, min(4, lim_w) + 1)) for _ in range(2))
+        ho, wo = h + t + b - kh + 1, w + l + r - kw + 1
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        k, bias = np_ref.init_row_connected_weights(ho, (kh, kw), cin, cout, rng, bias_scale=0.5)
+        k = (k * 3).astype(np.float32)
+        cd = ops.make_conv(cout, kh, kw, 1, ops.make_pad(t, b, l, r, mh, mw), ops.ACT_TANH)
+        on_mfma = [ops.rowconv2d_uses_matrix_cores((n, cin, h, w), cd, which) for which in (0, 1, 2)]
+        assert kh <= 5 or not (on_mfma[0] or on_mfma[1]), (kh, kw)
+        n_mfma += sum(on_mfma)
+        what = 'trial %d: k%dx%d cin %d cout %d n %d %dx%d halo %r modes %r' % (trial, kh, kw, cin, cout, n, h, w, (t, b, l, r), (mh, mw))
+        xp = np_ref.pad2d_modes(x.astype(np.float64), (t, b, l, r), mh, mw)
+        close(host(ops.rowconv2d(dev(x), dev(k), dev(bias), cd)), np_ref.row_connected2d(xp, k, bias, 'tanh'), what)
+        dz = rng.standard_normal((n, cout, ho, wo)).astype(np.float32)
+        dxp, dk, db = np_ref.row_connected2d_grads(xp, k, dz)
+        xs = Shape4(n, cin, h, w)
+        dx = torch.empty((n, cin, h, w), device='cuda')
+        ops.rowconv2d_bwd_data(dev(dz), dev(k), cd, xs, dx)
+        close(host(dx), np_ref.pad2d_modes_grad(dxp, x.shape, (t, b, l, r), mh, mw), what + ' dx')
+        dw, dbt = torch.empty(k.shape, device='cuda'), torch.empty((ho, 1, cout), device='cuda')
+        ops.rowconv2d_bwd_weight(dev(x), dev(dz), dw, dbt, cd, xs)
+        close(host(dw), dk, what + ' dw')
+        close(host(dbt), db, what + ' db')
+    assert n_mfma >= 70          # (of 90 passes: the rest are the LDS-footprint and kernel-height fall-backs)
