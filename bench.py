@@ -108,6 +108,43 @@ def measured_traffic(symbol, members):
     return None, ('stale: %s was measured on other kernel source' % stale) if stale else 'no PMC summary for this kernel'
 
 
+def rocprof_launch_ms(symbol, members):
+    """Average duration of `symbol` in the newest committed `rocprofv3 --kernel-trace --stats` summary
+    (profiles/*kernel_stats.csv) of the bench command, with the file's name and whether it was taken on the kernel source
+    this library was built from (tools/profile_bench.sh writes <tag>_kernel_stats.meta.json; older summaries are matched
+    through the <tag>_mfma_busy.json of the same tag).  bench.py never runs rocprofv3 itself: this is a lookup."""
+    import csv
+    sha = kernel_source_hash()
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*kernel_stats.csv')), reverse=True):
+        base = os.path.basename(f)
+        if any(t in base for t in ('train', 'cfg4', 'cfg5', 'rowconv', 'pad')):
+            continue
+        tag = base[:base.index('kernel_stats')]
+        meta = None
+        for mf in (f[:-4] + '.meta.json', os.path.join(ROOT, 'profiles', tag + 'mfma_busy.json')):
+            try:
+                meta = json.load(open(mf))
+                meta = meta.get('_meta', meta)
+                break
+            except (OSError, ValueError):
+                continue
+        if meta is None or int(meta.get('members', 256)) != members:
+            continue
+        same = meta.get('source_sha') == sha
+        try:
+            for r in csv.DictReader(open(f)):
+                if symbol in r['Name']:
+                    ent = {'file': base, 'avg_ms': float(r['AverageNs']) / 1e6, 'calls': int(r['Calls']), 'same_source': same}
+                    if same:
+                        return ent
+                    best = best or ent
+                    break
+        except (OSError, KeyError, ValueError):
+            continue
+    return best
+
+
 def pmc_mfma_crosscheck(rows, members):
     """Analytic executed-MFMA counts against SQ_INSTS_MFMA of the newest profiles/*mfma_busy.json measured on this source
     (per kernel symbol: mean over its launches in one forward).  Returns {symbol: {analytic, counter, busy_frac}}."""
@@ -233,6 +270,42 @@ def time_layers(model, members, iters=5):
     return rows
 
 
+def executed_per_forward(net, members):
+    """Matrix-core FLOPs ONE forward of `members` members executes (dlwp_conv2d_launch_info of every convolution launch of
+    the inference plan: MFMA instructions x their FLOPs, tile and channel padding included), split by matrix-core type.
+    No kernel is run.  Returns (fp32-MFMA FLOPs, bf16-MFMA FLOPs)."""
+    from dlwp_amd import ops
+    ex = net.executor
+    f32 = b16 = 0.0
+    for op, d in zip(ex.plan.ops, ex._descriptors()):
+        if op.kind != 'conv':
+            continue
+        for i in ops.conv_launch_info((members, op.xs[0], op.xs[1], op.xs[2]), d, ex._conv_dtype(op), net.device.index or 0):
+            if i[4]:
+                b16 += i[3]
+            else:
+                f32 += i[3]
+    return f32, b16
+
+
+def operating_point(net, members, forwards_per_s_per_gpu):
+    """`frac` of a sub-record: executed matrix-core FLOP/s of this GPU over the dense peak of the cores they run on, and
+    the fused-forward algorithmic bytes (sum over launches of in + out + weights) over the HBM peak."""
+    f32, b16 = executed_per_forward(net, members)
+    itemsize = 2 if getattr(net, 'activation_dtype', 'float32') == 'bfloat16' else 4
+    nbytes = float(net.infer_plan.algorithmic_bytes_per_sample(itemsize)) * members
+    fwd = forwards_per_s_per_gpu / float(members)               # forwards of the whole member batch per second
+    out = {'executed_tflops': (f32 + b16) * fwd / 1e12,
+           'frac': f32 * fwd / 1e12 / PEAK_F32_MFMA_TFLOPS + b16 * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+           'frac_definition': 'time share the executed MFMA work needs at the dense peak of its matrix cores '
+                              '(fp32 157.3 TFLOP/s%s)' % (', bf16 2500 TFLOP/s' if b16 else ''),
+           'algorithmic_gbs': nbytes * fwd / 1e9, 'hbm_frac': nbytes * fwd / 1e9 / PEAK_HBM_GBS}
+    if b16:
+        out['bf16_tflops'] = b16 * fwd / 1e12
+        out['bf16_mfma_frac'] = b16 * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS
+    return out
+
+
 def roofline_of(rows, members):
     """The kernel (all launches of one symbol inside a forward) with the largest share of the forward's time."""
     tot = sum(r['ms'] for r in rows)
@@ -254,7 +327,9 @@ def roofline_of(rows, members):
                                                                  r['out'][0], r['out'][1]) for r in rs],
            'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
            'definition': 'matrix-core FLOPs the kernel executes (MFMA instructions x 2048, tile and channel padding '
-                         'included) / HIP-event time of its launches inside a forward / dense fp32 MFMA peak',
+                         'included) / HIP-event time of its launches inside a forward / dense fp32 MFMA peak; `traffic` and '
+                         '`rocprof` are LOOKUPS in the committed rocprofv3 summaries under profiles/ (counters cannot be read '
+                         'inside this run), quoted only with the hash of the kernel source they were measured on',
            'algorithmic_tflops': algorithmic / ms / 1e9, 'algorithmic_speedup': algorithmic / executed,
            'launches_per_forward': n_launch, 'launch_ms': ms / n_launch,
            'launch_ms_isolated': ms_iso / n_launch, 'frac_isolated': executed / ms_iso / 1e9 / peak,
@@ -266,6 +341,12 @@ def roofline_of(rows, members):
                        'launch; its time and FLOPs are inside these figures')
     tr, src = measured_traffic(sym, members)
     out['traffic'], out['traffic_source'] = tr, src
+    rp = rocprof_launch_ms(sym, members)
+    if rp:
+        out['rocprof'] = dict(rp, frac_at_rocprof_avg=executed / n_launch / rp['avg_ms'] / 1e9 / peak,
+                              launch_ms_over_rocprof=(ms / n_launch) / rp['avg_ms'],
+                              note='HIP events between the launches of an eager forward include the launch gap; rocprofv3 '
+                                   'times the kernel alone inside the rollout graph')
     return out
 
 
@@ -381,6 +462,7 @@ def sub_small_batches(net, grid, cin, forwards):
         dt = _sync_time(lambda: net.rollout_on_device(s0, forwards), reps)
         out['members_%d' % m] = {'value': m * forwards * 2 * reps / dt, 'unit': '6-h forecast steps/s',
                                  'ms_per_rollout': 1e3 * dt / reps, 'ms_per_forward': 1e3 * dt / reps / forwards}
+        out['members_%d' % m].update(operating_point(net, m, m * forwards * reps / dt))
     return out
 
 
@@ -432,9 +514,11 @@ def sub_cfg4(members=8, forwards=4):
     _warm_until_steady(lambda: net.rollout_on_device(x, forwards), batch=10)   # the model was built on the host, the GPU sat idle
     reps = 30
     dt = _sync_time(lambda: net.rollout_on_device(x, forwards), reps)
-    return {'value': members * forwards * 2 * reps / dt, 'unit': '6-h forecast steps/s', 'members': members, 'forwards': forwards,
-            'ms_per_forward': 1e3 * dt / reps / forwards, 'dtype': 'bf16 storage and matrix cores, f32 accumulation and cell state',
-            'launches_per_forward': net.infer_plan.n_launches, 'finite': bool(torch.isfinite(ser[-1]).all().item())}
+    rec = {'value': members * forwards * 2 * reps / dt, 'unit': '6-h forecast steps/s', 'members': members, 'forwards': forwards,
+           'ms_per_forward': 1e3 * dt / reps / forwards, 'dtype': 'bf16 storage and matrix cores, f32 accumulation and cell state',
+           'launches_per_forward': net.infer_plan.n_launches, 'finite': bool(torch.isfinite(ser[-1]).all().item())}
+    rec.update(operating_point(net, members, members * forwards * reps / dt))
+    return rec
 
 
 def sub_row_connected(grid, cin, members, forwards):
@@ -459,7 +543,7 @@ def sub_row_connected(grid, cin, members, forwards):
             'finite': bool(torch.isfinite(ser[-1]).all().item())}
 
 
-def sub_train(grid, cin, world, rank, barrier, dev, global_batch=64, steps=20, warmup=40):
+def sub_train(grid, cin, world, rank, barrier, dev, global_batch=64, steps=20, warmup=40, share_of=8):
     """BASELINE config 3: the same U-Net, training, GLOBAL batch 64 ('mse', Adam), data parallel over the ranks: each rank
     trains on its 64 / N rows, one all-reduce of the flat gradient buffer per step (RCCL through dlwp_allreduce_sum_f32).
     Strong scaling: the global batch is fixed."""
@@ -477,14 +561,33 @@ def sub_train(grid, cin, world, rank, barrier, dev, global_batch=64, steps=20, w
     flops = 3.0 * d.model.plan.conv_flops_per_sample() * global_batch * steps
     rec = {'value': global_batch * steps / dt, 'unit': 'samples/s', 'scaling': 'strong', 'global_batch': global_batch,
            'batch_per_gpu': hi - lo, 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
-           'algorithmic_tflops_per_gpu': flops / dt / 1e12 / world, 'loss': float(lv[0, 1].item()),
+           'algorithmic_tflops_per_gpu': flops / dt / 1e12 / world,
+           'algorithmic_frac': flops / dt / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+           'algorithmic_frac_definition': 'ALGORITHMIC FLOPs of the step (3 x the direct-convolution count of the forward: forward, data '
+                              'and weight gradients) / wall / 157.3 TFLOP/s; the Winograd forward and weight-gradient kernels '
+                              'execute fewer multiplies than that count',
+           'loss': float(lv[0, 1].item()),
            'all_reduce': ('none (single rank)' if world == 1 else
                           ('RCCL via dlwp_allreduce_sum_f32 (C ABI), %d floats incl. the loss table'
                            % tr._flat_exchange.numel() if tr.dp.uses_rccl_abi() else 'torch.distributed (%s)' % tr.dp.backend))}
+    if world == 1 and share_of:
+        # the share of one of `share_of` GPUs of the same global batch, on this one GPU (no exchange): the strong-scaling
+        # projection adds an assumed 40 us for the one 756 KB all-reduce over xGMI (never measured: no multi-GPU box)
+        nb = max(1, global_batch // share_of)
+        xs, ys = x[:nb].contiguous(), y[:nb].contiguous()
+        for _ in range(warmup):
+            tr.train_on_shard(xs, ys, nb, return_device=True)
+        dts = _sync_time(lambda: tr.train_on_shard(xs, ys, nb, return_device=True), steps)
+        ms8 = 1e3 * dts / steps
+        rec['share_of_%d_gpus' % share_of] = {
+            'batch': nb, 'ms_per_step': ms8, 'value': nb * steps / dts, 'unit': 'samples/s',
+            'algorithmic_frac': 3.0 * d.model.plan.conv_flops_per_sample() * nb * steps / dts / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            'assumed_all_reduce_ms': 0.04,
+            'projected_speedup_%d_gpus' % share_of: rec['ms_per_step'] / (ms8 + 0.04)}
     return rec
 
 
-def sub_cfg5(world, rank, barrier, dev, total_members=32, forwards=40):
+def sub_cfg5(world, rank, barrier, dev, total_members=32, forwards=40, share_of=8):
     """BASELINE config 5: 1-degree 180 x 360 x 12-channel U-Net, a 32-member perturbed-IC ensemble IN TOTAL, 40 forwards
     (80 six-hour steps) as one hipGraph per rank; members sharded over the ranks (4 per GPU at 8).  Strong scaling."""
     from dlwp_amd.parallel import shard_bounds
@@ -499,20 +602,83 @@ def sub_cfg5(world, rank, barrier, dev, total_members=32, forwards=40):
     _warm_until_steady(lambda: net.rollout_on_device(s0, forwards), batch=1, min_s=0.1)   # (per rank: no collective in a rollout)
     dt = _sync_time(lambda: net.rollout_on_device(s0, forwards), 3, barrier, world, dev)
     flops = net.plan.conv_flops_per_sample()
-    return {'value': total_members * forwards * 2 * 3 / dt, 'unit': '6-h forecast steps/s', 'scaling': 'strong',
-            'total_members': total_members, 'members_per_gpu': hi - lo, 'forwards': forwards,
-            'ms_per_rollout': 1e3 * dt / 3, 'finite': bool(torch.isfinite(ser[-1]).all().item()),
-            'algorithmic_tflops_per_gpu': total_members * forwards * 3 * flops / dt / 1e12 / world}
+    rec = {'value': total_members * forwards * 2 * 3 / dt, 'unit': '6-h forecast steps/s', 'scaling': 'strong',
+           'total_members': total_members, 'members_per_gpu': hi - lo, 'forwards': forwards,
+           'ms_per_rollout': 1e3 * dt / 3, 'finite': bool(torch.isfinite(ser[-1]).all().item()),
+           'algorithmic_tflops_per_gpu': total_members * forwards * 3 * flops / dt / 1e12 / world}
+    rec.update(operating_point(net, hi - lo, (hi - lo) * forwards * 3 / dt))
+    if world == 1 and share_of:
+        # the 8-GPU share of the same ensemble on this one GPU: what strong scaling over `share_of` GPUs can reach at best
+        m = max(1, total_members // share_of)
+        s1 = s0[:m].contiguous()
+        net.rollout_on_device(s1, forwards)
+        _warm_until_steady(lambda: net.rollout_on_device(s1, forwards), batch=1, min_s=0.1)
+        dts = _sync_time(lambda: net.rollout_on_device(s1, forwards), 3)
+        sh = {'members': m, 'value': m * forwards * 2 * 3 / dts, 'unit': '6-h forecast steps/s', 'ms_per_rollout': 1e3 * dts / 3}
+        sh.update(operating_point(net, m, m * forwards * 3 / dts))
+        sh['projected_speedup_%d_gpus' % share_of] = share_of * sh['value'] / rec['value']
+        rec['share_of_%d_gpus' % share_of] = sh
+    return rec
 
 
 # --------------------------------------------------------------------------------------------------------------------- #
+# self-launch: `python bench.py --gpus N` with no torchrun environment starts its own N ranks
+# --------------------------------------------------------------------------------------------------------------------- #
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, timeout_s):
+    """One process per GPU (reference: keras.utils.multi_gpu_model replicates inside one process,
+    DLWP/model/models.py:104-109).  The parent only starts the ranks with the torchrun environment (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT), forwards rank 0's stdout -- the ONE JSON line -- and returns the worst exit
+    code.  A rank that dies takes the others (its exact PIDs) with it so that nothing waits in a collective forever."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DLWP_BENCH_CHILD='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    t0 = time.time()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed or time.time() - t0 > timeout_s:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+            if not failed:
+                sys.stderr.write('bench.py: ranks did not finish within %.0f s\n' % timeout_s)
+                return 124
+            break
+        time.sleep(0.05)
+    return max(abs(c) for c in codes)
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--members', type=int, default=256, help='ensemble members / initial conditions PER GPU')
+    ap.add_argument('--members', type=int, default=256, help='ensemble members / initial conditions PER GPU (weak scaling) '
+                                                             'or IN TOTAL over the GPUs (--scaling strong)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: --members per GPU (the default headline); strong: --members in total, sharded over the ranks')
+    ap.add_argument('--launch-timeout', type=float, default=1500.0, help='self-launched ranks are stopped after this many seconds')
     ap.add_argument('--forwards', type=int, default=28, help='model applications per rollout (28 = 14 days)')
     ap.add_argument('--grid', default='88x180')
     ap.add_argument('--channels', type=int, default=4)
@@ -527,11 +693,15 @@ def main():
     a = ap.parse_args()
     grid = tuple(int(v) for v in a.grid.split('x'))
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (under torch.distributed.run the environment is there)
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:], a.launch_timeout))
+
     from dlwp_amd import parallel
     rank, world, local = parallel.init()
     if world != a.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' %
-                         (a.gpus, world, a.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or without a '
+                         'torchrun environment (bench.py then starts its own ranks)' % (a.gpus, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; there is no CPU fallback for the product path')
     dev = torch.device('cuda', local)
@@ -544,9 +714,16 @@ def main():
     weights_np = [(w, b) for w, b in zip(net.get_weights()[0::2], net.get_weights()[1::2])]
 
     # members: one base state + 0.01 * N(0,1) perturbations, different per rank
+    if a.scaling == 'strong':          # --members in total: this rank's contiguous shard (no collective in a rollout)
+        lo, hi = parallel.shard_bounds(a.members, rank, world)
+        m_local, m_total = hi - lo, a.members
+        if m_local == 0:
+            raise SystemExit('--scaling strong needs at least one member per rank (%d members, %d ranks)' % (a.members, world))
+    else:
+        m_local, m_total = a.members, a.members * world
     g = torch.Generator(device='cpu').manual_seed(1000 + rank)
     base = torch.randn((1, a.channels) + grid, generator=torch.Generator().manual_seed(0))
-    state0 = (base + 0.01 * torch.randn((a.members, a.channels) + grid, generator=g)).to(dev)
+    state0 = (base + 0.01 * torch.randn((m_local, a.channels) + grid, generator=g)).to(dev)
 
     def barrier():
         if world > 1:
@@ -572,19 +749,20 @@ def main():
         dt = float(t.item())
     finite = bool(torch.isfinite(series[-1]).all().item())
 
-    six_hour_steps = a.members * world * a.forwards * 2 * a.steps
+    six_hour_steps = m_total * a.forwards * 2 * a.steps
     value = six_hour_steps / dt
-    fwd_per_s = a.members * world * a.forwards * a.steps / dt
+    fwd_per_s = m_total * a.forwards * a.steps / dt
     out = {
         'metric': '6-h forecast steps/sec on 91x180x4-chan state (closed grid 88x180), predict_timeseries rollout',
         'value': value, 'unit': '6-h forecast steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-        'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
         'dtype': 'f32' if a.activation_dtype == 'float32' else 'f32 arithmetic, bf16 activation storage',
         'data': 'synthetic',
         'config': {'workload': 'cfg2: 2-deg %dx%d x%d-chan sequential PeriodicPadding2D U-Net (188996 params), fp32, '
-                               '%d-forward (14-day) predict_timeseries rollout as one hipGraph, %d members per GPU'
-                               % (grid[0], grid[1], a.channels, a.forwards, a.members),
-                   'members_per_gpu': a.members, 'forwards_per_rollout': a.forwards, 'time_dim': 2,
+                               '%d-forward (14-day) predict_timeseries rollout as one hipGraph, %d members per GPU%s'
+                               % (grid[0], grid[1], a.channels, a.forwards, m_local,
+                                  ' (%d in total, strong scaling)' % m_total if a.scaling == 'strong' else ''),
+                   'members_per_gpu': m_local, 'members_total': m_total, 'forwards_per_rollout': a.forwards, 'time_dim': 2,
                    'grid': list(grid), 'channels': a.channels, 'launches_per_forward': net.infer_plan.n_launches,
                    'parallelism': 'members sharded over %d GPU(s), no collective' % world,
                    'inference_plan': ('Winograd F(2x2,3x3) on the 3x3 layers; the decoder layers that read an up-sampled '
@@ -605,8 +783,8 @@ def main():
             state['printed'] = True
 
     if rank == 0:
-        rows = time_layers(net, a.members)
-        executed_fwd = sum(r['executed_flops'] for r in rows) / a.members          # per member per forward
+        rows = time_layers(net, m_local)
+        executed_fwd = sum(r['executed_flops'] for r in rows) / m_local            # per member per forward
         per_gpu_fwd_per_s = fwd_per_s / world
         out['forward'] = {
             'executed_tflops': per_gpu_fwd_per_s * executed_fwd / 1e12,
@@ -619,8 +797,8 @@ def main():
             'definition': 'executed = matrix-core FLOPs the kernels issue (MFMA x 2048, padding included); mfma_util_frac = '
                           'executed / wall / 157.3 TFLOP/s; algorithmic = direct-convolution FLOPs of the reference graph '
                           '(1597.7 MFLOP per forward per member)'}
-        out['roofline'] = roofline_of(rows, a.members)
-        cc = pmc_mfma_crosscheck(rows, a.members)
+        out['roofline'] = roofline_of(rows, m_local)
+        cc = pmc_mfma_crosscheck(rows, m_local)
         if cc:
             out['roofline']['pmc_crosscheck'] = cc
         out['layers'] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
@@ -630,12 +808,12 @@ def main():
         if rank == 0:
             try:
                 sub.update(sub_small_batches(net, grid, a.channels, a.forwards))
-                sub['host_visible'] = sub_host_visible(d, grid, a.channels, a.members, a.forwards)
+                sub['host_visible'] = sub_host_visible(d, grid, a.channels, m_local, a.forwards)
                 if grid == (88, 180) and a.channels == 4:
-                    sub['layer1_at_91x180'] = sub_layer1_nominal(net, a.members)
+                    sub['layer1_at_91x180'] = sub_layer1_nominal(net, m_local)
                 if world == 1:
                     sub['recurrent_cfg4_bf16'] = sub_cfg4()
-                    sub['row_connected_output_layer'] = sub_row_connected(grid, a.channels, a.members, a.forwards)
+                    sub['row_connected_output_layer'] = sub_row_connected(grid, a.channels, m_local, a.forwards)
             except Exception as e:  # noqa: BLE001  (a sub-record must never cost the headline line)
                 sub['error_local'] = repr(e)
         out['sub_records'] = sub

@@ -32,6 +32,7 @@ static int set_in(dlwp_options& o, int option, int value, int* previous, const c
     case DLWP_OPT_BF16_MFMA: slot = &o.bf16_mfma; value = value ? 1 : 0; break;
     case DLWP_OPT_FORCE_CONV_CONFIG: slot = &o.forced_cfg; break;
     case DLWP_OPT_FORCE_WGRAD_CONFIG: slot = &o.forced_wgrad; break;
+    case DLWP_OPT_WINO_PAIRS: slot = &o.wino_pairs; value = value ? 1 : 0; break;
     default: DLWP_FAIL(DLWP_EINVAL, "%s: unknown option %d", fn, option);
   }
   if (previous) *previous = *slot;

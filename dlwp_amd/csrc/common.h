@@ -10,7 +10,7 @@
 // two streams -- never see each other's settings.  dlwp_default_options(): what a fresh handle (and the handle-less host
 // logic) starts from: DLWP_WINOGRAD / DLWP_BF16_MFMA in the environment, read once.
 struct dlwp_options {
-  int winograd = 1, bf16_mfma = 1, forced_cfg = -1, forced_wgrad = -1;
+  int winograd = 1, bf16_mfma = 1, forced_cfg = -1, forced_wgrad = -1, wino_pairs = 1;
 };
 const dlwp_options& dlwp_default_options();
 

@@ -532,7 +532,7 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
   // ... or, better, two samples side by side (float32 out, plain source, dilation 1, an even batch): on a 22x45 map a sample
   // pair is a virtual row of 2 x 48 = 3 x 32 columns -- the gap of 3 holds the halos -- and everything runs on the wide
   // instance (the narrow launch's two-wave blocks reach 1.2 waves per SIMD: two 16 KB filter buffers per block).
-  static const bool pairs_enabled = !(getenv("DLWP_WINO_PAIRS") && atoi(getenv("DLWP_WINO_PAIRS")) == 0);   // (A/B switch)
+  const bool pairs_enabled = h->opt.wino_pairs != 0;      // (A/B switch: dlwp_set_option(h, DLWP_OPT_WINO_PAIRS, 0))
   const bool ragged = is_wino(e) && !e.split && e.tw == 32 && a.Wo > 32 && a.Wo % 32 != 0 && a.Wo % 32 <= 16 && a.Wo / 32 <= 3;
   const bool ragged_w = ragged && (long long)a.N * lp->tiles_h * (a.Wo / 32) * lp->cout_tiles >= 4ll * h->cu_count;
   // (pairs cost no second launch and run 3 column tiles per pair instead of 2 per sample: at every batch size)

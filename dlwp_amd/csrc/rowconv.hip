@@ -802,6 +802,7 @@ size_t plan_dgrad(RowArgs& a) {
   if (a.S > a.N) a.S = a.N > 0 ? a.N : 1;
   a.n_sg = dlwp_ceil_div(a.N, a.S);
   a.TW_in = a.FX * 16 + a.kw - 1;
+  if (a.TW_in > 128) return 0;              // the kernel stages two 64-lane column slots per tile row (goff[2])
   a.RS = a.TW_in;
   a.PS = round_mod32(a.kh * a.RS, 16);
   a.SS = a.CK * a.PS;
@@ -927,7 +928,8 @@ int dlwp_rowconv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void
   // column are reached by letting dz wrap while it is staged (the fold was a third of this pass: 0.062 of 0.205 ms)
   const dlwp_pad2d& hp = cd->halo;
   const bool circ = need && hp.mode_w == DLWP_PAD_WRAP && hp.left + hp.right == cd->kw - 1 && hp.left + hp.right > 0 &&
-                    (hp.mode_h == DLWP_PAD_ZERO || hp.top + hp.bottom == 0) && ys.w == xs.w;
+                    (hp.mode_h == DLWP_PAD_ZERO || hp.top + hp.bottom == 0) && ys.w == xs.w &&
+                    cd->kw - 1 <= xs.w;       // (dz wraps once while it is staged)
   if (circ) {
     a.circ = 1; a.OH = xs.h; a.OW = xs.w;
     a.y = (float*)dx;

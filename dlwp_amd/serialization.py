@@ -146,11 +146,23 @@ def _keras_layer_kwargs(cls, cfg):
                 kw[k] = L1L2(l2=float(c.get('l2', 0.0)))
             continue
         if k not in params and k not in ('name', 'trainable'):      # (the base Layer takes name / trainable / input_shape)
+            # a Keras option this layer does not implement: silent only at the value that changes nothing
+            if k != 'implementation' and _KERAS_NEUTRAL.get(k, _MISSING) != v:
+                import warnings
+                warnings.warn('checkpoint layer %r: Keras option %s=%r has no counterpart in %s and is ignored'
+                              % (cfg.get('name'), k, v, cls.__name__))
             continue
         if isinstance(v, list):
             v = tuple(tuple(e) if isinstance(e, list) else e for e in v)
         kw[k] = v
     return kw
+
+
+_MISSING = object()
+#: Keras 2.2 defaults of constructor arguments the layers here do not take: dropping them at these values changes nothing
+_KERAS_NEUTRAL = {'return_state': False, 'go_backwards': False, 'stateful': False, 'unroll': False, 'dropout': 0.0,
+                  'recurrent_dropout': 0.0, 'interpolation': 'nearest', 'strides': (1, 1), 'unit_forget_bias': True,
+                  'use_bias': True, 'data_format': 'channels_first', 'padding': 'valid', 'dilation_rate': (1, 1)}
 
 
 def import_keras_hdf5(path, custom_objects=None, device=None, compile=True):
@@ -255,10 +267,21 @@ def import_keras_hdf5(path, custom_objects=None, device=None, compile=True):
         oc = tc.get('optimizer_config', {})
         ocls = getattr(training, oc.get('class_name', 'Adam'), None)
         loss = tc.get('loss')
-        if ocls is not None and isinstance(loss, str) and loss in ('mse', 'mean_squared_error', 'mae', 'mean_absolute_error'):
+        import warnings
+        if isinstance(loss, str) and loss in (custom_objects or {}):
+            loss = custom_objects[loss]         # the reference's closures (`lat_loss`, `acc_loss`) arrive by name, custom.py:956-1088
+        known = isinstance(loss, C.LossSpec) or (isinstance(loss, str) and
+                                                  loss in ('mse', 'mean_squared_error', 'mae', 'mean_absolute_error'))
+        if ocls is not None and known:
             ocfg = {k: v for k, v in oc.get('config', {}).items() if isinstance(v, (int, float))}
             metrics = [m for m in (tc.get('metrics') or []) if m in ('mae', 'mse', 'mean_absolute_error', 'mean_squared_error')]
             model.compile(optimizer=ocls(**ocfg), loss=loss, metrics=metrics, loss_weights=tc.get('loss_weights'))
+            if 'optimizer_weights' in f:
+                warnings.warn('%s: the optimizer state of the checkpoint (iteration count and slot variables) is not imported; '
+                              'training resumes with fresh moments' % path)
+        else:
+            warnings.warn('%s: training_config with loss %r / optimizer %r is not recognised (pass the loss through '
+                          'custom_objects); the model is returned UNCOMPILED' % (path, loss, oc.get('class_name')))
     return model
 
 

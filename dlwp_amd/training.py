@@ -602,7 +602,12 @@ class Trainer(object):
     def _graph_step(self, x, ys, n_global, scale, dp):
         """Replays (capturing first, if needed) the step for this batch shape.  Returns the device loss table, or None when
         this shape has not been seen often enough yet (the caller then runs the step eagerly)."""
-        key = (int(x.shape[0]), int(n_global), 0 if dp is None else dp.world)
+        opt = self.model.optimizer
+        # the captured launches carry the optimizer's hyper-parameters as arguments: a changed rate (scheduler, callback,
+        # load_model) must not replay the old ones
+        hyper = tuple(float(getattr(opt, k)) for k in ('lr', 'decay', 'beta_1', 'beta_2', 'epsilon', 'momentum')
+                      if hasattr(opt, k))
+        key = (int(x.shape[0]), int(n_global), 0 if dp is None else dp.world, hyper)
         ent = self._graphs.get(key)
         if ent is None:
             seen = self._graph_seen.get(key, 0) + 1
@@ -612,7 +617,6 @@ class Trainer(object):
             if len(self._graphs) >= 4:
                 self._graphs.clear()
             ent = self._graphs[key] = self._capture_step(x, ys, n_global, scale, dp)
-        opt = self.model.optimizer
         ent['x'].copy_(x)
         for dst, src in zip(ent['ys'], ys):
             dst.copy_(src)
@@ -655,8 +659,9 @@ class Trainer(object):
             outs, loss_vals, dys = self._forward_loss(x, ys, True, scale)
             self._backward(x, outs, dys)
             self._add_regularizer_gradients()
-        else:                               # a rank without rows still takes part in the exchange
-            self._flat_exchange.zero_()
+        else:                               # a rank without rows still takes part in the exchange: no data gradient, but
+            self._flat_exchange.zero_()     # its share of the regularisers' (every rank adds it in full, the sum is / world)
+            self._add_regularizer_gradients()
             loss_vals = None
         reg = self._regularizer_loss()      # Keras reports the penalty at the weights the step started from
         if dp is not None:

@@ -109,6 +109,8 @@ int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, cha
                                         * in): multiply on the bf16 matrix cores with bf16-rounded weights (1, default)     */
 #define DLWP_OPT_FORCE_CONV_CONFIG  2  /* tuning sweeps / tests: run this forward tile configuration (-1 = heuristic)      */
 #define DLWP_OPT_FORCE_WGRAD_CONFIG 3  /* ... this weight-gradient configuration                                           */
+#define DLWP_OPT_WINO_PAIRS         4  /* Winograd on narrow maps (22x45): two samples side by side in one virtual row (1,
+                                        * default) or the wide + narrow launch pair (0); same bits either way              */
 int         dlwp_set_option(dlwp_handle_t h, int option, int value, int* previous);
 /* the defaults themselves: what handles created AFTERWARDS start from, and what the handle-less host logic (planner hints
  * called with a NULL handle, e.g. on a machine without a GPU) uses.  Existing handles are not touched.                 */

@@ -57,9 +57,9 @@ def _scenario(d, mode, n_global, shuffle_seed=77):
     ranks get another one and must still cut the same batches (index broadcast)."""
     from dlwp_amd.model import ArrayDataset, DataGenerator
     logs = []
-    if mode == 'batch':
+    if mode in ('batch', 'batch6'):
         x, y = _data(n_global)
-        for _ in range(3):
+        for _ in range(3 if mode == 'batch' else 6):
             logs.append(d.model.train_on_batch(x, y))
     elif mode == 'fit':
         x, y = _data(n_global)
@@ -75,10 +75,11 @@ def _scenario(d, mode, n_global, shuffle_seed=77):
     return logs
 
 
-def _worker(rank, world, port, mode, n_global, ret):
+def _worker(rank, world, port, mode, n_global, ret, extra_env=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), DLWP_SHARE_GPUS='1', DLWP_DIST_BACKEND='gloo')
+    os.environ.update(extra_env or {})
     from dlwp_amd import parallel
     from dlwp_amd.model import DLWPNeuralNet
     from dlwp_amd.training import Adam
@@ -100,17 +101,18 @@ def _worker(rank, world, port, mode, n_global, ret):
     logs = _scenario(d, mode, n_global, 77 if rank == 0 else 4242 + rank)
     torch.cuda.synchronize()
     ret[rank] = {'w0': w0, 'w1': d.model.get_weights(), 'logs': logs, 'iters': d.model.optimizer.iterations,
-                 'max_rows': max(uploaded) if uploaded else 0}
+                 'max_rows': max(uploaded) if uploaded else 0, 'graphs': len(tr._graphs), 'rccl_abi': tr.dp.uses_rccl_abi(),
+                 'device': torch.cuda.current_device()}
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def _run_group(mode, n_global, world=2):
+def _run_group(mode, n_global, world=2, extra_env=None):
     port = _free_port()
     ctx = mp.get_context('spawn')
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, mode, n_global, ret)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, mode, n_global, ret, extra_env)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -122,11 +124,9 @@ def _run_group(mode, n_global, world=2):
         return dict(ret)
 
 
-@pytest.mark.parametrize('mode,n_global', [('batch', 8), ('batch', 7), ('fit', 23), ('generator', 23)])
-def test_two_rank_product_training_equals_the_single_process_run(mode, n_global):
+def _check_against_single_process(res, mode, n_global):
     from dlwp_amd.model import DLWPNeuralNet
     from dlwp_amd.training import Adam
-    res = _run_group(mode, n_global)
     # replicas were aligned on rank 0's initial weights at compile, and stay identical
     for a, b in zip(res[0]['w0'], res[1]['w0']):
         assert np.array_equal(a, b)
@@ -148,6 +148,61 @@ def test_two_rank_product_training_equals_the_single_process_run(mode, n_global)
     for a, b in zip(res[0]['w1'], d.model.get_weights()):
         # identical mathematics, different summation split (two half-batch gradients vs one): fp32 round-off per step
         assert np.abs(a - b).max() <= 1e-6 * steps, np.abs(a - b).max()
+
+
+@pytest.mark.parametrize('mode,n_global', [('batch', 8), ('batch', 7), ('fit', 23), ('generator', 23)])
+def test_two_rank_product_training_equals_the_single_process_run(mode, n_global):
+    _check_against_single_process(_run_group(mode, n_global), mode, n_global)
+
+
+def test_two_rank_training_with_the_captured_step_equals_the_single_process_run():
+    """DLWP_TRAIN_GRAPH=1 under data parallelism: forward + loss + backward of a rank's shard replay as one hipGraph, the
+    all-reduce and the optimizer launch stay OUTSIDE the capture (Trainer._capture_step) on the same stream -- no collective is
+    ever captured -- and the result is still the single-process (eager) one."""
+    res = _run_group('batch6', 8, extra_env={'DLWP_TRAIN_GRAPH': '1'})
+    assert res[0]['graphs'] == 1 and res[1]['graphs'] == 1          # the step really was captured on both ranks
+    _check_against_single_process(res, 'batch6', 8)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank (this box has one)')
+@pytest.mark.parametrize('mode,n_global', [('batch', 8), ('batch', 7), ('fit', 23)])
+def test_two_gpu_rccl_training_equals_the_single_process_run(mode, n_global):
+    """The transport the product uses on a multi-GPU node: backend 'nccl', one GPU per rank, gradients summed by
+    dlwp_allreduce_sum_f32 and replicas aligned by dlwp_broadcast_f32 (csrc/comm.hip).  Skipped on the one-GPU test box."""
+    res = _run_group(mode, n_global, extra_env={'DLWP_SHARE_GPUS': '0', 'DLWP_DIST_BACKEND': 'nccl'})
+    assert res[0]['rccl_abi'] and res[1]['rccl_abi'] and res[0]['device'] != res[1]['device']
+    _check_against_single_process(res, mode, n_global)
+
+
+def test_bench_gpus_2_as_a_plain_script_prints_one_line_with_the_collective_sub_records():
+    """`python bench.py --gpus 2` the way the driver starts it (no torchrun environment): bench.py spawns its ranks, here two
+    on the one GPU over gloo, and rank 0 prints ONE JSON line whose sub-records include the data-parallel training step
+    (train_cfg3) and the sharded ensemble (ensemble_cfg5)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(DLWP_SHARE_GPUS='1', DLWP_DIST_BACKEND='gloo')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--members', '16', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['finite'] and rec['value'] > 0
+    assert rec['config']['members_total'] == 32 and rec['scaling'] == 'weak'
+    sub = rec['sub_records']
+    assert 'error_collective' not in sub and 'error_local' not in sub, sub
+    tr, ens = sub['train_cfg3'], sub['ensemble_cfg5']
+    assert tr['global_batch'] == 64 and tr['batch_per_gpu'] == 32 and tr['value'] > 0 and np.isfinite(tr['loss'])
+    assert ens['total_members'] == 32 and ens['members_per_gpu'] == 16 and ens['finite'] and 0 < ens['frac'] < 1
+    assert 0 < sub['members_1']['frac'] < sub['members_8']['frac'] < 1
+    # the same total under --scaling strong
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--members', '16', '--scaling', 'strong', '--no-cpu-baseline', '--no-extras'], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert rec['scaling'] == 'strong' and rec['config']['members_total'] == 16 and rec['config']['members_per_gpu'] == 8
 
 
 def test_rccl_communicator_of_the_c_abi_world_one():

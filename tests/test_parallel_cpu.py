@@ -215,3 +215,21 @@ def test_device_loader_list_targets_and_empty_shards():
             assert np.array_equal(np.concatenate(Xs), gen[i][0])
             for k in range(3):
                 assert np.array_equal(np.concatenate(ys[k]), gen[i][1][k])
+
+
+def test_bench_starts_its_own_ranks_when_launched_as_a_plain_script():
+    """`python bench.py --gpus 2` with no torchrun environment (how the driver starts the multi-GPU bench) must spawn its two
+    ranks itself.  Without a GPU every rank stops at 'needs an MI355X' -- AFTER the gloo process group of world size 2 came
+    up -- and the parent hands the failure on as its exit code instead of hanging or printing a line."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip('the GPU box runs the real thing (tests/test_gpu_parallel.py)')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['DLWP_DIST_BACKEND'] = 'gloo'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                        '--no-extras', '--no-cpu-baseline', '--launch-timeout', '240'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode not in (0, 124), (p.returncode, p.stderr[-400:])
+    assert p.stderr.count('needs an MI355X') == 2, p.stderr[-800:]
+    assert 'launch with torch.distributed.run' not in p.stderr
+    assert not any(l.startswith('{') for l in p.stdout.splitlines()), p.stdout[-400:]

@@ -17,6 +17,12 @@ export DLWP_ROLLOUT_GROUPS=1
 CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- $CMD > $OUT/${TAG}_stats_bench.json 2> $OUT/stats.err
 cp $OUT/stats/s_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv 2>/dev/null
+python - <<PY > $OUT/${TAG}_kernel_stats.meta.json
+import json, sys
+sys.path.insert(0, "$R")
+from dlwp_amd import _lib
+print(json.dumps({"source_sha": _lib.kernel_source_hash(), "members": 256, "command": "$CMD", "rollout_groups": 1}))
+PY
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $CMD > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $CMD > /dev/null 2> $OUT/pmc_write.err
 python $R/tools/parse_pmc.py $OUT/${TAG}_hbm_traffic_b256.json $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1
