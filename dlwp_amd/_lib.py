@@ -164,6 +164,13 @@ _sig('dlwp_adam_keras', [_vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 5 + 
 _sig('dlwp_adam_keras_dev', [_vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 5 + [_vp, _vp, ctypes.c_float, _vp])
 _sig('dlwp_sgd_keras', [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 3 + [ctypes.c_longlong, ctypes.c_float, _vp])
 _sig('dlwp_axpby', [_vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, _vp])
+_sig('dlwp_prepare_begin', [_vp])
+_sig('dlwp_prepare_flush', [_vp, _vp])
+_sig('dlwp_reductions_begin', [_vp])
+_sig('dlwp_reductions_flush', [_vp, _vp])
+_sig('dlwp_conv2d_bwd_data_prepared_bytes', [_vp, Shape4, _P(Conv2d), _i], _sz)
+_sig('dlwp_conv2d_bwd_data_prepare', [_vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
+_sig('dlwp_conv2d_bwd_data_prepared', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _i, _vp])
 _sig('dlwp_maxpool2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_maxpool2_bwd', [_vp, _vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_upsample2_fwd', [_vp, _vp, _vp, Shape4, _i, _vp])

@@ -73,6 +73,7 @@ int dlwp_create(dlwp_handle_t* out, int device) {
   strncpy(h->arch, prop.gcnArchName, sizeof(h->arch) - 1);
   h->wino_u = nullptr;
   h->wino_u_floats = 0;
+  h->prep_defer = h->n_prep = h->red_defer = h->n_red = 0;
   *out = h;
   return DLWP_OK;
 }

@@ -14,6 +14,29 @@ struct dlwp_options {
 };
 const dlwp_options& dlwp_default_options();
 
+// batch.hip: weight preparations / final sums recorded on the handle and run by ONE launch each
+enum { DLWP_PREP_WINO = 0, DLWP_PREP_PACKN = 1, DLWP_PREP_COPY = 2 };
+constexpr int DLWP_MAX_BATCH_JOBS = 24;
+struct dlwp_prep_job {
+  const float* w;       // the layer's stored HWIO kernel
+  float* dst;
+  int kind;             // DLWP_PREP_*
+  int cin, cout;        // of the convolution the prepared weights are FOR
+  int flip;             // 1: that convolution is the data gradient of the layer (taps flipped, channels swapped)
+  int taps;             // kh * kw
+  int ks, dil, S, ck, wch, n_chunks;   // packed-N geometry (conv_fwd.hip: packn_expand_weights_f32)
+  int blocks;
+};
+struct dlwp_red_job {
+  const float* src;
+  float* dst;
+  long long n, es, ss;  // dst[i] = scale * sum_{s < S} src[i * es + s * ss], i < n
+  int S, accumulate;
+  float scale;
+  int eb;               // elements per 256-thread block: 64 or 16
+  int vec4;             // contiguous elements summed as float4
+};
+
 struct dlwp_handle {
   dlwp_options opt;
   int device;
@@ -22,7 +45,17 @@ struct dlwp_handle {
   char arch[64];
   float* wino_u;        // transformed 3x3 filters of the Winograd path (conv_fwd.hip); fixed capacity, allocated once
   size_t wino_u_floats;
+  int prep_defer, n_prep;      // dlwp_prepare_begin / _flush
+  int red_defer, n_red;        // dlwp_reductions_begin / _flush
+  dlwp_prep_job prep[DLWP_MAX_BATCH_JOBS];
+  dlwp_red_job red[DLWP_MAX_BATCH_JOBS];
 };
+
+// record (batch mode) or run now
+int dlwp_prep_push(dlwp_handle_t h, dlwp_prep_job j, hipStream_t s);
+// 1: recorded for dlwp_reductions_flush; 0: the handle is not deferring (run your own final kernel); < 0: error
+int dlwp_reduce_defer(dlwp_handle_t h, const float* src, float* dst, long long n, int S, long long es, long long ss,
+                      float scale, int accumulate, hipStream_t s);
 
 // scratch for Cin x Cout transformed filters: NULL when it does not fit or cannot be allocated now (stream capture)
 float* dlwp_wino_scratch(dlwp_handle_t h, size_t floats, hipStream_t s);
@@ -109,3 +142,5 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
 size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
 int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype,
                      hipStream_t s);
+int dlwp_conv2d_prep_flipped(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 zs, const dlwp_conv2d* g,
+                             hipStream_t s);

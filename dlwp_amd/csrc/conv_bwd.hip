@@ -149,29 +149,23 @@ int dlwp_conv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d
   return DLWP_OK;
 }
 
-// dx = dL/d(input as the conv sees it BEFORE the halo and AFTER the src transform): (n, cin, hin, win).
-// dz: (n, out_c_total, ho, wo), channels [out_c_off, +cout).  For src_mode == DIRECT dx may be a channel window
-// [in_c_off, +cin) of a buffer with in_c_total channels (the stored tensor's gradient); otherwise it is dense and the
-// caller applies dlwp_upsample2_bwd / dlwp_maxpool2_bwd.
-// stored != 0: gradient w.r.t. the STORED tensor of a DLWP_SRC_UPSAMPLE2 layer (2x2 sum fused into the epilogue)
-static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
-                                const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream, int stored) {
-  DLWP_CHECK_ARG(h && dz && w && dx && cd && ws, "dlwp_conv2d_bwd_data: null handle or pointer");
-  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_conv2d_bwd_data: dtype %d not supported", dtype);
-  size_t need = 0;
-  int rc = dlwp_conv2d_bwd_workspace(h, xs, cd, 0, &need);
-  if (rc != DLWP_OK) return rc;
-  DLWP_CHECK_ARG(ws_bytes >= need, "dlwp_conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
-  dlwp_shape4 ys;
-  dlwp_conv2d_out_shape(xs, cd, &ys);
-  if (xs.n == 0) return DLWP_OK;
-  hipStream_t s = (hipStream_t)stream;
-  float* wt = (float*)ws;
-  rc = dlwp_launch_flip_transpose(h, (const float*)w, wt, cd->kh, cd->kw, xs.c, cd->cout, s);
-  if (rc != DLWP_OK) return rc;
-  const int hin = dlwp_src_dim(xs.h, cd->src_mode), win = dlwp_src_dim(xs.w, cd->src_mode);
-  const bool window = cd->src_mode == DLWP_SRC_DIRECT && cd->in_c_total > 0;
+// The data gradient is itself a fused convolution `g` of dz (shape zs) with the flipped / transposed kernel.
+// fast: symmetric 'same' halo with wrap / zero modes -- the adjoint is the same fused conv on the flipped kernel, writing the
+// gradient (window) directly; otherwise: full correlation into the padded gradient, then the halo is folded back.
+struct DgradPlan {
   dlwp_conv2d g;
+  dlwp_shape4 zs;
+  bool fast, window;
+  int hin, win;
+};
+
+static int plan_dgrad(dlwp_shape4 xs, const dlwp_conv2d* cd, int stored, DgradPlan* p) {
+  dlwp_shape4 ys;
+  if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return DLWP_EINVAL;
+  p->hin = dlwp_src_dim(xs.h, cd->src_mode);
+  p->win = dlwp_src_dim(xs.w, cd->src_mode);
+  p->window = cd->src_mode == DLWP_SRC_DIRECT && cd->in_c_total > 0;
+  dlwp_conv2d& g = p->g;
   memset(&g, 0, sizeof(g));
   g.cout = xs.c;
   g.kh = cd->kh;
@@ -182,28 +176,65 @@ static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, 
   g.in_c_off = cd->out_c_off;
   g.in_c_total = cd->out_c_total > 0 ? cd->out_c_total : cd->cout;
   g.src_mode = DLWP_SRC_DIRECT;
-  dlwp_shape4 zs = {xs.n, cd->cout, ys.h, ys.w};
-  if (stored && !(cd->src_mode == DLWP_SRC_UPSAMPLE2 && same_halo_fast_path(cd)))
+  p->zs = dlwp_shape4{xs.n, cd->cout, ys.h, ys.w};
+  p->fast = same_halo_fast_path(cd);
+  if (stored && !(cd->src_mode == DLWP_SRC_UPSAMPLE2 && p->fast))
     DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_bwd_data_stored: needs an up-sampled source and a symmetric wrap / zero halo");
-  if (same_halo_fast_path(cd)) {
-    // symmetric 'same' halo with wrap / zero modes: the adjoint is the same fused conv on the flipped kernel
+  if (p->fast) {
     g.halo = cd->halo;
     g.out_pool = stored ? 2 : 0;  // adjoint of the nearest up-sampling = 2x2 sum of the dense gradient
-    g.out_c_off = window ? cd->in_c_off : 0;
-    g.out_c_total = window ? cd->in_c_total : xs.c;
-    return dlwp_launch_conv2d(h, dz, wt, nullptr, dx, zs, &g, dtype, s);
+    g.out_c_off = p->window ? cd->in_c_off : 0;
+    g.out_c_total = p->window ? cd->in_c_total : xs.c;
+    return DLWP_OK;
   }
-  // general halo: full correlation into the padded gradient, then fold the halo back
-  DLWP_CHECK_ARG(!window || (cd->in_c_off == 0 && cd->in_c_total == xs.c),
+  DLWP_CHECK_ARG(!p->window || (cd->in_c_off == 0 && cd->in_c_total == xs.c),
                  "dlwp_conv2d_bwd_data: channel-window output needs the symmetric wrap/zero halo fast path");
   const int fh = cd->dil_h * (cd->kh - 1), fw = cd->dil_w * (cd->kw - 1);
   g.halo = dlwp_pad2d{fh, fh, fw, fw, DLWP_PAD_ZERO, DLWP_PAD_ZERO};
   g.out_c_off = 0;
   g.out_c_total = xs.c;
-  float* padded = (float*)((char*)ws + align256((size_t)cd->kh * cd->kw * xs.c * cd->cout * sizeof(float)));
-  rc = dlwp_launch_conv2d(h, dz, wt, nullptr, padded, zs, &g, dtype, s);
+  return DLWP_OK;
+}
+
+// dx = dL/d(input as the conv sees it BEFORE the halo and AFTER the src transform): (n, cin, hin, win).
+// dz: (n, out_c_total, ho, wo), channels [out_c_off, +cout).  For src_mode == DIRECT dx may be a channel window
+// [in_c_off, +cin) of a buffer with in_c_total channels (the stored tensor's gradient); otherwise it is dense and the
+// caller applies dlwp_upsample2_bwd / dlwp_maxpool2_bwd.
+// stored != 0: gradient w.r.t. the STORED tensor of a DLWP_SRC_UPSAMPLE2 layer (2x2 sum fused into the epilogue)
+// prepared != NULL: dlwp_conv2d_bwd_data_prepare built the flipped kernel (and its Winograd / packed-N form) there; w is unused
+static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
+                                const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream, int stored,
+                                const void* prepared = nullptr) {
+  DLWP_CHECK_ARG(h && dz && (w || prepared) && dx && cd && ws, "dlwp_conv2d_bwd_data: null handle or pointer");
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_conv2d_bwd_data: dtype %d not supported", dtype);
+  size_t need = 0;
+  int rc = dlwp_conv2d_bwd_workspace(h, xs, cd, 0, &need);
   if (rc != DLWP_OK) return rc;
-  return dlwp_pad2d_bwd(h, padded, dx, xs.n * xs.c, hin, win, 1, cd->halo, dtype, stream);
+  const size_t wbytes = align256((size_t)cd->kh * cd->kw * xs.c * cd->cout * sizeof(float));
+  if (prepared) need -= wbytes;          // the flipped kernel lives in `prepared`
+  DLWP_CHECK_ARG(ws_bytes >= need, "dlwp_conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
+  if (xs.n == 0) return DLWP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DgradPlan p;
+  rc = plan_dgrad(xs, cd, stored, &p);
+  if (rc != DLWP_OK) return rc;
+  const float* wt;
+  const float* u_pre = nullptr;
+  char* rest = (char*)ws;
+  if (prepared) {
+    wt = (const float*)prepared;
+    if (dlwp_conv2d_prep_floats(h, p.zs, &p.g, dtype) > 0) u_pre = (const float*)((const char*)prepared + wbytes);
+  } else {
+    rc = dlwp_launch_flip_transpose(h, (const float*)w, (float*)ws, cd->kh, cd->kw, xs.c, cd->cout, s);
+    if (rc != DLWP_OK) return rc;
+    wt = (const float*)ws;
+    rest += wbytes;
+  }
+  if (p.fast) return dlwp_launch_conv2d(h, dz, wt, nullptr, dx, p.zs, &p.g, dtype, s, u_pre);
+  float* padded = (float*)rest;
+  rc = dlwp_launch_conv2d(h, dz, wt, nullptr, padded, p.zs, &p.g, dtype, s, u_pre);
+  if (rc != DLWP_OK) return rc;
+  return dlwp_pad2d_bwd(h, padded, dx, xs.n * xs.c, p.hin, p.win, 1, cd->halo, dtype, stream);
 }
 
 int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
@@ -214,6 +245,45 @@ int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* d
 int dlwp_conv2d_bwd_data_stored(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
                                 const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream) {
   return conv2d_bwd_data_impl(h, dz, w, dx, xs, cd, dtype, ws, ws_bytes, stream, 1);
+}
+
+// Prepared operand of the data gradient: [flipped / transposed kernel | its Winograd or packed-N form, if the gradient's
+// convolution runs on such an instance].  It depends on the weights only: a training step builds it once, for all layers in
+// one launch (dlwp_prepare_begin / dlwp_prepare_flush), instead of two helper launches in front of every data gradient.
+size_t dlwp_conv2d_bwd_data_prepared_bytes(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int stored) {
+  DgradPlan p;
+  if (!h || !cd || xs.n <= 0 || plan_dgrad(xs, cd, stored, &p) != DLWP_OK) return 0;
+  if (stored && dlwp_conv2d_pick_config(h, p.zs, &p.g) < 0) return 0;   // no instance with the 2x2-sum epilogue for this layer
+  return align256((size_t)cd->kh * cd->kw * xs.c * cd->cout * sizeof(float)) +
+         dlwp_conv2d_prep_floats(h, p.zs, &p.g, DLWP_F32) * sizeof(float);
+}
+
+int dlwp_conv2d_bwd_data_prepare(dlwp_handle_t h, const void* w, void* prepared, dlwp_shape4 xs, const dlwp_conv2d* cd,
+                                 int stored, void* stream) {
+  DLWP_CHECK_ARG(h && w && prepared && cd && xs.n > 0, "dlwp_conv2d_bwd_data_prepare: null handle or pointer");
+  DgradPlan p;
+  int rc = plan_dgrad(xs, cd, stored, &p);
+  if (rc != DLWP_OK) return rc;
+  dlwp_prep_job j;
+  memset(&j, 0, sizeof(j));
+  j.w = (const float*)w;
+  j.dst = (float*)prepared;
+  j.kind = DLWP_PREP_COPY;
+  j.cin = cd->cout;            // the gradient's convolution reads dz (cout channels) and writes cin channels
+  j.cout = xs.c;
+  j.flip = 1;
+  j.taps = cd->kh * cd->kw;
+  rc = dlwp_prep_push(h, j, (hipStream_t)stream);
+  if (rc != DLWP_OK) return rc;
+  if (dlwp_conv2d_prep_floats(h, p.zs, &p.g, DLWP_F32) == 0) return DLWP_OK;
+  float* u = (float*)((char*)prepared + align256((size_t)cd->kh * cd->kw * xs.c * cd->cout * sizeof(float)));
+  return dlwp_conv2d_prep_flipped(h, w, u, p.zs, &p.g, (hipStream_t)stream);
+}
+
+int dlwp_conv2d_bwd_data_prepared(dlwp_handle_t h, const void* dz, const void* prepared, void* dx, dlwp_shape4 xs,
+                                  const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, int stored, void* stream) {
+  DLWP_CHECK_ARG(prepared != nullptr, "dlwp_conv2d_bwd_data_prepared: null prepared weights");
+  return conv2d_bwd_data_impl(h, dz, nullptr, dx, xs, cd, dtype, ws, ws_bytes, stream, stored, prepared);
 }
 
 // dw: (kh, kw, cin, cout) Keras HWIO.  accumulate != 0 adds to dw instead of overwriting (shared layers).
@@ -275,6 +345,9 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void*
   const int grid = c.ci_groups * c.co_tiles * c.splits;
   e.launch(a, grid, (hipStream_t)stream);
   DLWP_LAUNCH_CHECK("conv2d_wgrad_mfma_f32");
+  // between dlwp_reductions_begin / _flush the slab sum is recorded and done with the other layers' in one launch
+  const int rd = dlwp_reduce_defer(h, (const float*)ws, (float*)dw, wn, c.nslabs, 1, wn, 1.0f, accumulate, (hipStream_t)stream);
+  if (rd != 0) return rd < 0 ? rd : DLWP_OK;
   return dlwp_launch_reduce_slabs(h, (float*)ws, (float*)dw, wn, c.nslabs, accumulate, (hipStream_t)stream);
 }
 

@@ -445,7 +445,35 @@ static size_t prep_floats_of(const ConvKernelEntry& e, int cin, int cout) {
   return 0;
 }
 
-static int prep_with(const ConvKernelEntry& e, const void* w, float* dst, int cin, int cout, hipStream_t s, int lstm_f = 0) {
+// batch != 0 (dlwp_conv2d_prep, dlwp_conv2d_bwd_data_prepare): the work may be recorded on the handle and built by
+// dlwp_prepare_flush in one launch with the other layers' (batch.hip); flip: prepared weights of the layer's DATA GRADIENT
+// convolution from the layer's own HWIO kernel (taps flipped, channels swapped; cin / cout are that convolution's)
+static int prep_with(dlwp_handle_t h, const ConvKernelEntry& e, const void* w, float* dst, int cin, int cout, hipStream_t s,
+                     int lstm_f = 0, int batch = 0, int flip = 0) {
+  if (!is_bf16(e) && (flip || (batch && h->prep_defer)) && (is_wino(e) || e.pack > 0)) {
+    dlwp_prep_job j;
+    memset(&j, 0, sizeof(j));
+    j.w = (const float*)w;
+    j.dst = dst;
+    j.cin = cin;
+    j.cout = cout;
+    j.flip = flip;
+    j.taps = e.ks * e.ks;
+    if (is_wino(e)) {
+      j.kind = DLWP_PREP_WINO;
+    } else {
+      j.kind = DLWP_PREP_PACKN;
+      j.ks = e.ks;
+      j.dil = e.dil;
+      j.S = e.pack;
+      j.ck = e.ck;
+      j.wch = e.prep_chunk_floats;
+      j.n_chunks = dlwp_ceil_div(cin, e.ck);
+    }
+    return dlwp_prep_push(h, j, s);
+  }
+  if (flip && (is_bf16(e) || is_wino(e) || e.pack > 0))
+    DLWP_FAIL(DLWP_EUNSUPPORTED, "prepared data-gradient weights: kernel family not covered");
   if (is_bf16(e)) {
     const int n_chunks = dlwp_ceil_div(cin, e.ck), n_ct = dlwp_ceil_div(cout, 16 * e.bnf), wch = e.prep_chunk_floats / 4;
     const long long total = (long long)n_ct * n_chunks * wch;
@@ -473,7 +501,14 @@ size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2
 int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype,
                      hipStream_t s) {
   const ConvKernelEntry* e = entry_for(h, xs, cd, dtype);
-  return e ? prep_with(*e, w, dst, xs.c, cd->cout, s, cd->lstm_f) : DLWP_OK;
+  return e ? prep_with(h, *e, w, dst, xs.c, cd->cout, s, cd->lstm_f, 1, 0) : DLWP_OK;
+}
+
+// prepared weights of the data-gradient convolution `g` (input dz of shape zs) from the LAYER's HWIO kernel w
+int dlwp_conv2d_prep_flipped(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 zs, const dlwp_conv2d* g,
+                             hipStream_t s) {
+  const ConvKernelEntry* e = entry_for(h, zs, g, DLWP_F32);
+  return e ? prep_with(h, *e, w, dst, zs.c, g->cout, s, 0, 1, 1) : DLWP_OK;
 }
 
 namespace {
@@ -624,7 +659,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
     } else {
       float* u = dlwp_wino_scratch(h, prep_floats_of(e, a.Cin, a.Cout), s);
       if (!u) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: no scratch for the prepared weights");
-      const int rc2 = prep_with(e, a.w, u, a.Cin, a.Cout, s, cd->lstm_f);
+      const int rc2 = prep_with(h, e, a.w, u, a.Cin, a.Cout, s, cd->lstm_f);
       if (rc2 != DLWP_OK) return rc2;
       a.w = u;
     }

@@ -515,6 +515,15 @@ int dlwp_act_bwd(dlwp_handle_t h, const void* y, const void* dy, void* dz, size_
   return DLWP_OK;
 }
 
+// the final sum over the BIAS_SPLIT partials of every channel: recorded between dlwp_reductions_begin / _flush (batch.hip),
+// one 64-thread block per channel otherwise
+static inline int bias_final(dlwp_handle_t h, const float* ws, float* db, int c, hipStream_t s) {
+  const int rd = dlwp_reduce_defer(h, ws, db, c, BIAS_SPLIT, BIAS_SPLIT, 1, 1.0f, 0, s);
+  if (rd != 0) return rd < 0 ? rd : DLWP_OK;
+  bias_grad_final_kernel<<<c, 64, 0, s>>>(ws, db);
+  return DLWP_OK;
+}
+
 size_t dlwp_bias_grad_workspace(int c) { return (size_t)(c > 0 ? c : 0) * BIAS_SPLIT * sizeof(float); }
 
 int dlwp_bias_grad(dlwp_handle_t h, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, void* ws,
@@ -525,7 +534,8 @@ int dlwp_bias_grad(dlwp_handle_t h, const void* dz, void* db, int n, int c, int 
   DLWP_CHECK_ARG(ws_bytes >= dlwp_bias_grad_workspace(c), "dlwp_bias_grad: workspace too small");
   bias_grad_partial_kernel<<<dim3(c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>((const float*)dz, (float*)ws, n, c_off,
                                                                               c_total, hw);
-  bias_grad_final_kernel<<<c, 64, 0, (hipStream_t)stream>>>((const float*)ws, (float*)db);
+  const int rf = bias_final(h, (const float*)ws, (float*)db, c, (hipStream_t)stream);
+  if (rf != DLWP_OK) return rf;
   DLWP_LAUNCH_CHECK("bias_grad kernels");
   return DLWP_OK;
 }
@@ -543,7 +553,8 @@ int dlwp_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dy, void*
   else
     act_bwd_bias_partial_kernel<1><<<dim3(c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
         (const float*)y, (const float*)dy, (float*)dz, (float*)ws, n, c_off, c_total, hw, act);
-  bias_grad_final_kernel<<<c, 64, 0, (hipStream_t)stream>>>((const float*)ws, (float*)db);
+  const int rf = bias_final(h, (const float*)ws, (float*)db, c, (hipStream_t)stream);
+  if (rf != DLWP_OK) return rf;
   DLWP_LAUNCH_CHECK("act_bwd_bias_grad kernels");
   return DLWP_OK;
 }
@@ -563,7 +574,10 @@ int dlwp_pool_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dp, 
   else
     pool_act_bwd_bias_partial_kernel<false><<<dim3(ys.c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
         (const float*)y, (const float*)dp, (float*)dz, (float*)ws, ys.n, ys.c, ys.h, ys.w, act);
-  if (db) bias_grad_final_kernel<<<ys.c, 64, 0, (hipStream_t)stream>>>((const float*)ws, (float*)db);
+  if (db) {
+    const int rf = bias_final(h, (const float*)ws, (float*)db, ys.c, (hipStream_t)stream);
+    if (rf != DLWP_OK) return rf;
+  }
   DLWP_LAUNCH_CHECK("pool_act_bwd_bias_grad kernels");
   return DLWP_OK;
 }
@@ -580,7 +594,9 @@ int dlwp_mse_mae(dlwp_handle_t h, const void* y_pred, const void* y_true, size_t
   const float inv_n = 1.0f / (float)n;
   mse_mae_partial_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float*)y_pred, (const float*)y_true, (float*)dy,
                                                                (float*)ws, (long long)n, 2.0f * loss_weight * inv_n);
-  mse_mae_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>((const float*)ws, grid, inv_n, (float*)out2);
+  const int rd = dlwp_reduce_defer(h, (const float*)ws, (float*)out2, 2, grid, 1, 2, inv_n, 0, (hipStream_t)stream);
+  if (rd < 0) return rd;
+  if (rd == 0) mse_mae_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>((const float*)ws, grid, inv_n, (float*)out2);
   DLWP_LAUNCH_CHECK("mse_mae kernels");
   return DLWP_OK;
 }

@@ -101,8 +101,11 @@ class Executor(object):
         return out
 
     # -- eager forward ----------------------------------------------------------------------------------------------- #
-    def run(self, x, outs=None):
-        """x: device tensor (n, ...) matching the model input; returns the list of output tensors (stored layout)."""
+    def run(self, x, outs=None, prepared=None, skip_phasew=False):
+        """x: device tensor (n, ...) matching the model input; returns the list of output tensors (stored layout).
+        prepared: {op index: tensor of ops.conv2d_prepare} -- those convolutions do not transform their weights again;
+        skip_phasew: the derived kernels (plan.phase_params) are already up to date (the training step builds them, and every
+        prepared form, in front of the forward)."""
         from . import ops
         n = x.shape[0]
         x = x.reshape((n,) + self.plan._in_store)
@@ -115,7 +118,9 @@ class Executor(object):
             if i == P.STATE_IN:
                 return x
             return outs[-2 - i]
-        for op, d in zip(self.plan.ops, self._descriptors()):
+        for k, (op, d) in enumerate(zip(self.plan.ops, self._descriptors())):
+            if op.kind == 'phasew' and skip_phasew:
+                continue
             src, dst = res(op.src), res(op.dst)
             if op.kind == 'conv' and op.lstm_f:
                 kern, bias = self.conv_weights(op)
@@ -126,7 +131,8 @@ class Executor(object):
             elif op.kind == 'conv':
                 kern, bias = self.conv_weights(op)
                 ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0],
-                           compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16))
+                           compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16),
+                           prepared=prepared.get(k) if prepared else None)
             elif op.kind == 'rowconv':
                 ops.rowconv2d(src, op.layer.kernel, op.layer.bias, d, out=dst, x_channels=op.xs[0])
             elif op.kind == 'phasew':

@@ -111,9 +111,9 @@ def pad2d_bwd(dy, x_shape, pad, channels_last=False):
     return dx
 
 
-def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=False):
+def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=False, out=None):
     """Prepared weights for conv2d(x, ...) calls with exactly this input shape / storage (dlwp_conv2d_prepare), or None
-    when the layer's kernel reads the HWIO weights directly."""
+    when the layer's kernel reads the HWIO weights directly.  out: a buffer an earlier call returned (refilled in place)."""
     _check_f32(w_hwio)
     n, c_total, h, w = x.shape
     cin = int(x_channels) if x_channels is not None else c_total
@@ -125,7 +125,9 @@ def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=
     nbytes = _lib.lib.dlwp_conv2d_prepared_bytes(_lib.handle(_dev(x)), xs, ctypes.byref(cd), dt)
     if nbytes == 0:
         return None
-    u = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    u = out if out is not None else torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    if u.numel() * 4 < nbytes:
+        raise ValueError('conv2d_prepare: the buffer holds %d bytes, %d needed' % (u.numel() * 4, nbytes))
     _lib.check(_lib.lib.dlwp_conv2d_prepare(_lib.handle(_dev(x)), _ptr(w_hwio), _ptr(u), xs, ctypes.byref(cd), dt,
                                             _stream(x)))
     return u
@@ -415,9 +417,10 @@ def uses_bf16_weights(xs, cd, dtype):
 _workspaces = {}
 
 
-def workspace(device, nbytes):
-    """A growable per-device scratch allocation (bytes) for the *_bwd / loss kernels."""
-    key = (device.type, device.index)
+def workspace(device, nbytes, key=None):
+    """A growable per-device scratch allocation (bytes) for the *_bwd / loss kernels.  key: a scratch of its own for this
+    caller (a deferred final sum reads its partials at dlwp_reductions_flush: nothing else may write there meanwhile)."""
+    key = (device.type, device.index) if key is None else (device.type, device.index, key)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -428,9 +431,9 @@ def workspace(device, nbytes):
 _workspaces2 = {}
 
 
-def workspace2(device, nbytes):
+def workspace2(device, nbytes, key=None):
     """A second, small scratch allocation (reduction partials) that may be live next to `workspace`."""
-    key = (device.type, device.index)
+    key = (device.type, device.index) if key is None else (device.type, device.index, key)
     ws = _workspaces2.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
@@ -445,15 +448,70 @@ def conv_bwd_workspace_bytes(dev_index, xs, cd, which):
     return out.value
 
 
-def conv2d_bwd_data(dz, w_hwio, cd, xs, dx):
-    """dz: (n, out_c_total, ho, wo); dx: preallocated gradient buffer (see include/dlwp_hip.h for its layout)."""
-    _check_f32(dz, w_hwio, dx)
+def conv2d_bwd_data(dz, w_hwio, cd, xs, dx, prepared=None, stored=False):
+    """dz: (n, out_c_total, ho, wo); dx: preallocated gradient buffer (see include/dlwp_hip.h for its layout).
+    prepared: the tensor conv2d_bwd_data_prepare built for (w_hwio, xs, cd, stored) -- the gradient's convolution is then the
+    only launch; stored: gradient w.r.t. the STORED tensor of an up-sampled source (see conv2d_bwd_data_stored)."""
+    _check_f32(dz, w_hwio, dx, prepared)
     d = _dev(dz)
     need = conv_bwd_workspace_bytes(d, xs, cd, 0)
     ws = workspace(dz.device, need)
-    _lib.check(_lib.lib.dlwp_conv2d_bwd_data(_lib.handle(d), _ptr(dz), _ptr(w_hwio), _ptr(dx), xs, ctypes.byref(cd),
-                                             _lib.F32, _ptr(ws), ws.numel(), _stream(dz)))
+    if prepared is not None:
+        _lib.check(_lib.lib.dlwp_conv2d_bwd_data_prepared(_lib.handle(d), _ptr(dz), _ptr(prepared), _ptr(dx), xs,
+                                                          ctypes.byref(cd), _lib.F32, _ptr(ws), ws.numel(),
+                                                          1 if stored else 0, _stream(dz)))
+        return dx
+    fn = _lib.lib.dlwp_conv2d_bwd_data_stored if stored else _lib.lib.dlwp_conv2d_bwd_data
+    _lib.check(fn(_lib.handle(d), _ptr(dz), _ptr(w_hwio), _ptr(dx), xs, ctypes.byref(cd), _lib.F32, _ptr(ws), ws.numel(),
+                  _stream(dz)))
     return dx
+
+
+def conv2d_bwd_data_prepared_bytes(dev_index, xs, cd, stored=False):
+    """Bytes of the prepared operand of a data gradient (0: this gradient has no prepared form, e.g. `stored` on a layer
+    without the summing epilogue)."""
+    return int(_lib.lib.dlwp_conv2d_bwd_data_prepared_bytes(_lib.handle(dev_index), xs, ctypes.byref(cd), 1 if stored else 0))
+
+
+def conv2d_bwd_data_prepare(w_hwio, cd, xs, stored=False, out=None):
+    """The data gradient's operand from the layer's HWIO kernel (dlwp_conv2d_bwd_data_prepare); between prepare_begin /
+    prepare_flush the work is only recorded."""
+    _check_f32(w_hwio, out)
+    d = _dev(w_hwio)
+    nbytes = conv2d_bwd_data_prepared_bytes(d, xs, cd, stored)
+    if nbytes == 0:
+        return None
+    u = out if out is not None else torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=w_hwio.device)
+    if u.numel() * 4 < nbytes:
+        raise ValueError('conv2d_bwd_data_prepare: the buffer holds %d bytes, %d needed' % (u.numel() * 4, nbytes))
+    _lib.check(_lib.lib.dlwp_conv2d_bwd_data_prepare(_lib.handle(d), _ptr(w_hwio), _ptr(u), xs, ctypes.byref(cd),
+                                                     1 if stored else 0, _stream(w_hwio)))
+    return u
+
+
+def _dev_index(device):
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def prepare_begin(device):
+    """Weight preparations from now on are recorded and built by ONE launch at prepare_flush (csrc/batch.hip)."""
+    _lib.check(_lib.lib.dlwp_prepare_begin(_lib.handle(_dev_index(device))))
+
+
+def prepare_flush(device):
+    _lib.check(_lib.lib.dlwp_prepare_flush(_lib.handle(_dev_index(device)),
+                                           ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+
+
+def reductions_begin(device):
+    """The final sums of conv2d_bwd_weight / the bias gradients / mse_mae from now on are recorded and done by ONE launch at
+    reductions_flush; every such call needs a workspace of its own until then (ws_key)."""
+    _lib.check(_lib.lib.dlwp_reductions_begin(_lib.handle(_dev_index(device))))
+
+
+def reductions_flush(device):
+    _lib.check(_lib.lib.dlwp_reductions_flush(_lib.handle(_dev_index(device)),
+                                              ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
 
 
 # ---- RowConnected2D (reference DLWP/custom.py:695-896) ------------------------------------------------------------------ #
@@ -525,11 +583,11 @@ def conv2d_bwd_data_stored(dz, w_hwio, cd, xs, dx):
     return True
 
 
-def conv2d_bwd_weight(x, dz, dw, cd, xs, accumulate=False):
+def conv2d_bwd_weight(x, dz, dw, cd, xs, accumulate=False, ws_key=None):
     _check_f32(x, dz, dw)
     d = _dev(x)
     need = conv_bwd_workspace_bytes(d, xs, cd, 1)
-    ws = workspace(x.device, need)
+    ws = workspace(x.device, need, ws_key)
     _lib.check(_lib.lib.dlwp_conv2d_bwd_weight(_lib.handle(d), _ptr(x), _ptr(dz), _ptr(dw), xs, ctypes.byref(cd),
                                                int(bool(accumulate)), _lib.F32, _ptr(ws), ws.numel(), _stream(x)))
     return dw
@@ -543,48 +601,48 @@ def act_bwd(y, dy, act, out=None):
     return dz
 
 
-def bias_grad(dz, db, c, c_off=0):
+def bias_grad(dz, db, c, c_off=0, ws_key=None):
     _check_f32(dz, db)
     n, c_total, h, w = dz.shape
-    ws = workspace2(dz.device, _lib.lib.dlwp_bias_grad_workspace(int(c)))
+    ws = workspace2(dz.device, _lib.lib.dlwp_bias_grad_workspace(int(c)), ws_key)
     _lib.check(_lib.lib.dlwp_bias_grad(_lib.handle(_dev(dz)), _ptr(dz), _ptr(db), n, int(c), int(c_off), c_total, h * w,
                                        _ptr(ws), ws.numel(), _lib.F32, _stream(dz)))
     return db
 
 
-def act_bwd_bias_grad(y, dy, act, db, c, c_off=0, out=None):
+def act_bwd_bias_grad(y, dy, act, db, c, c_off=0, out=None, ws_key=None):
     """dz = dy * act'(y) on channels [c_off, c_off + c) and db = sum of dz over (n, h, w), in one pass (dz may be dy)."""
     _check_f32(y, dy, db)
     dz = out if out is not None else torch.empty_like(dy)
     n, c_total, h, w = dy.shape
-    ws = workspace2(dy.device, _lib.lib.dlwp_bias_grad_workspace(int(c)))
+    ws = workspace2(dy.device, _lib.lib.dlwp_bias_grad_workspace(int(c)), ws_key)
     _lib.check(_lib.lib.dlwp_act_bwd_bias_grad(_lib.handle(_dev(dy)), _ptr(y), _ptr(dy), _ptr(dz), _ptr(db), n, int(c),
                                                int(c_off), c_total, h * w, int(act), _ptr(ws), ws.numel(), _lib.F32,
                                                _stream(dy)))
     return dz
 
 
-def pool_act_bwd_bias_grad(y, dp, act, db=None):
+def pool_act_bwd_bias_grad(y, dp, act, db=None, ws_key=None):
     """Backward of MaxPooling2D(2) + activation (+ bias gradient) of the convolution that produced y, in one pass:
     returns dz (shape of y) from the pooled tensor's gradient dp."""
     _check_f32(y, dp, db)
     n, c, h, w = y.shape
     assert tuple(dp.shape) == (n, c, h // 2, w // 2) and y.is_contiguous() and dp.is_contiguous()
     dz = torch.empty_like(y)
-    ws = workspace2(y.device, _lib.lib.dlwp_bias_grad_workspace(int(c)))
+    ws = workspace2(y.device, _lib.lib.dlwp_bias_grad_workspace(int(c)), ws_key)
     _lib.check(_lib.lib.dlwp_pool_act_bwd_bias_grad(_lib.handle(_dev(y)), _ptr(y), _ptr(dp), _ptr(dz),
                                                     _ptr(db), _lib.Shape4(n, c, h, w), int(act),
                                                     _ptr(ws), ws.numel(), _lib.F32, _stream(y)))
     return dz
 
 
-def mse_mae(y_pred, y_true, out2, dy=None, loss_weight=1.0):
+def mse_mae(y_pred, y_true, out2, dy=None, loss_weight=1.0, ws_key=None):
     """out2 (device, 2 floats) <- [mse, mae]; dy <- loss_weight * 2 (y_pred - y_true) / numel."""
     _check_f32(y_pred, y_true, out2, dy)
     d = _dev(y_pred)
     h = _lib.handle(d)
     need = _lib.lib.dlwp_mse_mae_workspace(h)
-    ws = workspace(y_pred.device, need)
+    ws = workspace(y_pred.device, need, ws_key)
     _lib.check(_lib.lib.dlwp_mse_mae(h, _ptr(y_pred), _ptr(y_true), y_pred.numel(), _ptr(out2), _ptr(dy),
                                      float(loss_weight), _ptr(ws), ws.numel(), _lib.F32, _stream(y_pred)))
     return out2

@@ -155,6 +155,9 @@ class Trainer(object):
         self._graph_seen = {}
         self._iter_dev = None         # Adam's step number on the device (advanced inside the captured step)
         self._iter_shadow = None
+        self._fold = None             # see _fold_ok
+        self._prep_cache = {}         # batch size -> prepared weights of the step (see _prepare_step)
+        self._side = None             # second stream: the weight gradients run beside the data-gradient chain
         self.sync_parameters()
 
     # -- replicas ------------------------------------------------------------------------------------------------------ #
@@ -198,10 +201,79 @@ class Trainer(object):
         return out
 
     # -- forward + loss ------------------------------------------------------------------------------------------------ #
-    def _forward_loss(self, x, ys, want_grad, weight_scale=1.0):
+    # -- a step's weight-side helpers in one launch each (csrc/batch.hip) ------------------------------------------------ #
+    def _fold_ok(self):
+        """The folded step (default; DLWP_TRAIN_FOLD=0 keeps one launch per helper): every prepared form of the weights --
+        Winograd / packed-N forms for the forward and data-gradient convolutions, the flipped kernels -- is built by ONE
+        launch in front of the forward, every final sum (weight-gradient slabs, bias-gradient and loss partials) by ONE launch
+        behind the backward pass, and the weight gradients run on a second stream beside the data-gradient chain.  At 8
+        samples per GPU that is 64 -> ~36 launches.  Plans it covers: Conv2D layers used once each (no ConvLSTM2D /
+        RowConnected2D / shared layers)."""
+        if self._fold is None:
+            ok = self.device.type == 'cuda' and os.environ.get('DLWP_TRAIN_FOLD', '1') != '0'
+            seen = set()
+            for op in self.plan.ops:
+                if op.kind in ('lstm', 'rowconv') or (op.kind == 'conv' and (op.lstm_f or isinstance(op.layer, L._ConvPart))):
+                    ok = False
+                if op.kind == 'conv':
+                    ok = ok and id(op.layer) not in seen
+                    seen.add(id(op.layer))
+            # every deferred sum of a step in ONE flush (csrc/common.h: DLWP_MAX_BATCH_JOBS = 24; an early flush would run on
+            # whichever stream filled the table)
+            ok = ok and 2 * len(seen) + len(self.plan.output_store) <= 24 and 3 * len(seen) <= 24
+            self._fold = bool(ok)
+        return self._fold
+
+    def _prepare_step(self, x):
+        """Derived (phase-summed) kernels, then every prepared operand of this step's convolutions in one launch.  Returns
+        {'fwd': {op index: tensor}, 'bwd': {op index: (tensor, stored)}}; the buffers are cached per batch size."""
+        from . import _lib, ops
+        ex = self.model.train_executor
+        plan = self.plan
+        n = int(x.shape[0])
+        x = x.reshape((n,) + plan._in_store)
+        for op in plan.ops:
+            if op.kind == 'phasew':
+                w2, b2 = ex.phase_buffers()[op.wparam]
+                ops.phase_weights(op.layer.kernel, op.layer.bias, op.halo.top, op.halo.left, w2=w2, b2=b2)
+        cache = self._prep_cache.get(n)
+        if cache is None:
+            if len(self._prep_cache) > 4:
+                self._prep_cache.clear()
+            cache = self._prep_cache[n] = {'fwd': {}, 'bwd': {}}
+        bufs = ex.scratch(n)
+        dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        ops.prepare_begin(self.device)
+        try:
+            for k, (op, d) in enumerate(zip(plan.ops, ex._descriptors())):
+                if op.kind != 'conv':
+                    continue
+                kern = ex.conv_weights(op)[0]
+                src = x if op.src == P.STATE_IN else bufs[op.src]
+                dst_dtype = bufs[op.dst].dtype if op.dst >= 0 else torch.float32
+                u = ops.conv2d_prepare(src, kern, d, out_dtype=dst_dtype, x_channels=op.xs[0], out=cache['fwd'].get(k))
+                if u is not None:
+                    cache['fwd'][k] = u
+                if op.src == P.STATE_IN:
+                    continue
+                xs = _lib.Shape4(n, op.xs[0], op.xs[1], op.xs[2])
+                old = cache['bwd'].get(k)
+                stored = old[1] if old is not None else (op.src_mode == P.SRC_UPSAMPLE2 and
+                                                         ops.conv2d_bwd_data_prepared_bytes(dev, xs, d, True) > 0)
+                t = ops.conv2d_bwd_data_prepare(kern, d, xs, stored=stored, out=old[0] if old is not None else None)
+                if t is not None:
+                    cache['bwd'][k] = (t, stored)
+        finally:
+            ops.prepare_flush(self.device)
+        return cache
+
+    def _forward_loss(self, x, ys, want_grad, weight_scale=1.0, prep=None):
         """Returns (outs, loss table [n_out, 7] on device: col 0 custom-loss value, 1 mse, 2 mae, dys or None)."""
         from . import ops
-        outs = self.model.train_executor.run(x)
+        if prep is not None:
+            outs = self.model.train_executor.run(x, prepared=prep['fwd'], skip_phasew=True)
+        else:
+            outs = self.model.train_executor.run(x)
         n_out = len(outs)
         if self._loss_out is None or self._loss_out.shape[0] != n_out:
             self._loss_out = torch.zeros((n_out, 7), dtype=torch.float32, device=self.device)
@@ -215,7 +287,7 @@ class Trainer(object):
             dy = torch.empty_like(yp) if want_grad else None
             lw = self.loss_weights[o] * weight_scale
             if spec is None:
-                ops.mse_mae(yp, yt, self._loss_out[o, 1:3], dy, lw)
+                ops.mse_mae(yp, yt, self._loss_out[o, 1:3], dy, lw, ws_key=('mse', o) if prep is not None else None)
             else:
                 mean, roww = self._loss_consts
                 if yp.dim() != 4:
@@ -269,10 +341,46 @@ class Trainer(object):
         return ([total] + per_out + [float(v[o, col[k]]) for o in range(n_out) for k in self.metric_keys])
 
     # -- backward ------------------------------------------------------------------------------------------------------ #
-    def _backward(self, x, outs, dys):
+    def _backward(self, x, outs, dys, prep=None):
+        """prep (the folded step, _fold_ok): prepared data-gradient operands, a workspace per deferred final sum, the weight
+        gradients on the side stream; the caller brackets forward + backward with ops.reductions_begin / _flush and runs
+        the returned callables (work that needs the final sums) after the flush."""
         from . import _lib, ops
         plan = self.plan
         n = x.shape[0]
+        post = []
+        main = torch.cuda.current_stream(self.device) if prep is not None else None
+        if prep is not None and self._side is None:
+            self._side = [torch.cuda.Stream(self.device) for _ in range(3)]
+        sides = self._side if prep is not None else None
+        # Weight gradients leave the critical path (activation backward -> data gradient -> ...): they are queued and launched
+        # on side streams in TWO batches with one fork each -- a fork / join costs ~10 us inside a captured graph
+        # (profiles/r3_train_b8_timeline.txt): the first half, one after the other, beside the second half of the chain; the
+        # rest in parallel behind it.
+        wq, used = [], []
+        n_wgrad = sum(1 for op in plan.ops if op.kind == 'conv')
+        queued = [0]
+
+        def launch_queued(parallel):
+            started = set()
+            for i, fn in enumerate(wq):
+                st = sides[i % len(sides)] if parallel else sides[0]
+                if id(st) not in started:
+                    st.wait_stream(main)         # behind everything issued on the main stream so far
+                    started.add(id(st))
+                    if st not in used:
+                        used.append(st)
+                with torch.cuda.stream(st):
+                    fn()
+            del wq[:]
+
+        def on_side(fn):
+            if sides is None:
+                return fn()
+            wq.append(fn)
+            queued[0] += 1
+            if queued[0] == (n_wgrad + 1) // 2:
+                launch_queued(False)
         bufs = self.model.train_executor.scratch(n)
         x = x.reshape((n,) + plan._in_store)
 
@@ -339,7 +447,8 @@ class Trainer(object):
 
         touched_layers = set()
         descs = self.model.train_executor._descriptors()
-        for op, d in reversed(list(zip(plan.ops, descs))):
+        for k, (op, d) in reversed(list(enumerate(zip(plan.ops, descs)))):
+            key = (lambda what, k=k: (what, k)) if prep is not None else (lambda what: None)   # a scratch per deferred sum
             pooled_grad = None
             if op.dst in pending_pool:
                 lay = op.layer if op.kind == 'conv' else None
@@ -369,9 +478,10 @@ class Trainer(object):
                 if pooled_grad is not None:    # the layer's only reader is MaxPooling2D(2): its backward rides along
                     fused_bias = lay.bias is not None
                     gD = ops.pool_act_bwd_bias_grad(y, pooled_grad, op.act,
-                                                    self._grad_view(lay, 'bias') if fused_bias else None)
+                                                    self._grad_view(lay, 'bias') if fused_bias else None, ws_key=key('bias'))
                 elif fused_bias:       # dz in place of dy and the bias gradient from the same pass
-                    ops.act_bwd_bias_grad(y, gD, op.act, self._grad_view(lay, 'bias'), lay.filters, out=gD)
+                    ops.act_bwd_bias_grad(y, gD, op.act, self._grad_view(lay, 'bias'), lay.filters, out=gD,
+                                          ws_key=key('bias'))
                 elif lay.activation != 'linear':
                     ops.act_bwd(y, gD, op.act, out=gD)          # dz in place of dy
                 dz = gD
@@ -379,16 +489,25 @@ class Trainer(object):
                 if derived:                # gradients of the derived kernels, folded back onto the layer's own
                     pp = plan.phase_params[op.wparam]
                     dw2 = torch.empty(tuple(kern.shape), dtype=torch.float32, device=self.device)
-                    ops.conv2d_bwd_weight(src, dz, dw2, d, xs)
-                    db2 = None
-                    if lay.bias is not None:
-                        db2 = torch.empty(n_out, dtype=torch.float32, device=self.device)
-                        ops.bias_grad(dz, db2, n_out)
-                    ops.phase_weights_bwd(dw2, db2, self._grad_view(lay, 'kernel'),
-                                          self._grad_view(lay, 'bias') if lay.bias is not None else None,
-                                          pp['pad_top'], pp['pad_left'], accumulate=acc)
+                    db2 = torch.empty(n_out, dtype=torch.float32, device=self.device) if lay.bias is not None else None
+
+                    def derived_grads(src=src, dz=dz, dw2=dw2, db2=db2, d=d, xs=xs, n_out=n_out, key=key):
+                        ops.conv2d_bwd_weight(src, dz, dw2, d, xs, ws_key=key('wgrad'))
+                        if db2 is not None:
+                            ops.bias_grad(dz, db2, n_out, ws_key=key('bias'))
+                    on_side(derived_grads)
+
+                    def fold_back(dw2=dw2, db2=db2, lay=lay, pp=pp, acc=acc):
+                        ops.phase_weights_bwd(dw2, db2, self._grad_view(lay, 'kernel'),
+                                              self._grad_view(lay, 'bias') if lay.bias is not None else None,
+                                              pp['pad_top'], pp['pad_left'], accumulate=acc)
+                    if prep is not None:
+                        post.append(fold_back)          # dw2 / db2 are final only behind the deferred sums
+                    else:
+                        fold_back()
                 else:
-                    ops.conv2d_bwd_weight(src, dz, self._grad_view(lay, 'kernel'), d, xs, accumulate=acc)
+                    on_side(lambda src=src, dz=dz, lay=lay, d=d, xs=xs, acc=acc, key=key: ops.conv2d_bwd_weight(
+                        src, dz, self._grad_view(lay, 'kernel'), d, xs, accumulate=acc, ws_key=key('wgrad')))
                 if lay.bias is not None and not fused_bias and not derived:
                     gb = self._grad_view(lay, 'bias')
                     if acc:
@@ -396,7 +515,7 @@ class Trainer(object):
                         ops.bias_grad(dz, tmp, lay.filters)
                         ops.axpby(tmp, gb, 1.0, 1.0)
                     else:
-                        ops.bias_grad(dz, gb, lay.filters)
+                        on_side(lambda dz=dz, gb=gb, lay=lay, key=key: ops.bias_grad(dz, gb, lay.filters, ws_key=key('bias')))
                 touched_layers.add(id(lay))
                 if isinstance(lay, L._ConvPart):
                     touched_layers.add(id(lay.parent))
@@ -404,10 +523,12 @@ class Trainer(object):
                     continue                  # no gradient w.r.t. the model input is needed
                 cin = op.xs[0]
                 c_total = src.shape[1]
+                pb = prep['bwd'].get(k) if prep is not None else None     # (prepared operand, for the stored tensor?)
                 if op.src_mode == P.SRC_DIRECT:
                     g = grad_of(op.src)
                     if not overlaps(op.src, op.in_c_off, cin):
-                        ops.conv2d_bwd_data(dz, kern, d, xs, g)              # writes its channel window in place
+                        # writes its channel window in place
+                        ops.conv2d_bwd_data(dz, kern, d, xs, g, prepared=pb[0] if pb else None)
                         written.setdefault(op.src, []).append((op.in_c_off, cin))
                     else:
                         dd = ops.make_conv(d.cout, d.kh, d.kw, (d.dil_h, d.dil_w), d.halo, d.act, 0, 0, d.out_c_off,
@@ -420,13 +541,15 @@ class Trainer(object):
                     win = 2 * op.xs[2] if op.src_mode == P.SRC_UPSAMPLE2 else op.xs[2] // 2
                     if op.src_mode == P.SRC_UPSAMPLE2:    # 2x2 sum fused into the data-gradient kernel where it can be
                         dense = torch.empty((n, cin, op.xs[1], op.xs[2]), dtype=torch.float32, device=self.device)
-                        if not ops.conv2d_bwd_data_stored(dz, kern, d, xs, dense):
+                        if pb is not None and pb[1]:
+                            ops.conv2d_bwd_data(dz, kern, d, xs, dense, prepared=pb[0], stored=True)
+                        elif pb is not None or not ops.conv2d_bwd_data_stored(dz, kern, d, xs, dense):
                             tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
-                            ops.conv2d_bwd_data(dz, kern, d, xs, tmp)
+                            ops.conv2d_bwd_data(dz, kern, d, xs, tmp, prepared=pb[0] if pb else None)
                             dense = ops.upsample2_bwd(tmp)
                     else:
                         tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
-                        ops.conv2d_bwd_data(dz, kern, d, xs, tmp)
+                        ops.conv2d_bwd_data(dz, kern, d, xs, tmp, prepared=pb[0] if pb else None)
                         if op.in_c_off == 0 and cin == c_total:
                             xw = src
                         else:
@@ -512,6 +635,30 @@ class Trainer(object):
         for lay, nm, off, numel, shape in self.entries:
             if id(lay) not in touched_layers:
                 self.flat_grads[off:off + numel].zero_()
+        if sides is not None:
+            launch_queued(True)
+            for st in used:
+                main.wait_stream(st)     # the weight gradients join before anything reads them
+        return post
+
+    def _forward_backward(self, x, ys, scale):
+        """Forward + loss + backward of one step; gradients in flat_grads.  Returns (outs, loss table, dys)."""
+        from . import ops
+        if not self._fold_ok():
+            outs, loss_vals, dys = self._forward_loss(x, ys, True, scale)
+            self._backward(x, outs, dys)
+            return outs, loss_vals, dys
+        prep = self._prepare_step(x)
+        ops.reductions_begin(self.device)
+        post = []
+        try:
+            outs, loss_vals, dys = self._forward_loss(x, ys, True, scale, prep)
+            post = self._backward(x, outs, dys, prep)
+        finally:
+            ops.reductions_flush(self.device)      # (always: the handle must not stay in recording mode)
+        for fn in post:
+            fn()
+        return outs, loss_vals, dys
 
     # -- optimizer ----------------------------------------------------------------------------------------------------- #
     def _apply(self, grad_scale=1.0):
@@ -555,7 +702,10 @@ class Trainer(object):
     #: a batch shape seen this many times is captured (the first steps run eagerly: lazy allocations, scratch buffers)
     graph_after = 2
 
-    def _graph_ok(self):
+    #: DLWP_TRAIN_GRAPH unset: steps of at most this many samples x grid points replay as a captured graph
+    graph_below = 12 * 88 * 180
+
+    def _graph_ok(self, n_local=None):
         """Opt-in (DLWP_TRAIN_GRAPH=1): forward + loss + backward (+ optimizer) of one step are ~60 launches from Python; a
         step whose launch sequence does not depend on the data is captured once per batch shape (torch.cuda.CUDAGraph around
         our C-ABI launches: its private pool keeps the per-op gradient buffers at fixed addresses) and replayed with one
@@ -564,8 +714,16 @@ class Trainer(object):
         kernels, not by the host -- so the default stays eager.  Never captured: kernel regularisers (their penalty is read
         back to the host every step), SGD with decay (its rate is a launch argument), steps on the CPU device."""
         opt = self.model.optimizer
-        if self.device.type != 'cuda' or os.environ.get('DLWP_TRAIN_GRAPH', '0') != '1':
+        mode = os.environ.get('DLWP_TRAIN_GRAPH', 'auto')
+        if self.device.type != 'cuda' or mode == '0':
             return False
+        if mode != '1':
+            # auto (r3): the FOLDED step is launch-bound on the host below ~12 samples of the 88 x 180 grid (eager 0.68 ms vs
+            # 0.49 ms replayed at 8 samples) and GPU-bound above, where the replayed graph's fork / join gaps cost more than
+            # the host saves (1.68 ms eager vs 1.83 ms replayed at 64): capture small steps only
+            store = self.plan._in_store
+            if not self._fold_ok() or n_local is None or n_local * int(store[-1]) * int(store[-2]) > self.graph_below:
+                return False
         if any(True for _ in self._regularized()):
             return False
         return isinstance(opt, Adam) or (isinstance(opt, SGD) and opt.decay == 0.0)
@@ -584,8 +742,7 @@ class Trainer(object):
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with capture_lock, torch.cuda.graph(g, capture_error_mode='thread_local'):
-            outs, loss_vals, dys = self._forward_loss(gx, gys, True, scale)
-            self._backward(gx, outs, dys)
+            outs, loss_vals, dys = self._forward_backward(gx, gys, scale)
             if dp is not None:       # the exchange and the update stay outside: a collective in between
                 ops.axpby(loss_vals.view(-1), self._loss_tail.view(-1), scale, 0.0)
             elif isinstance(opt, Adam):
@@ -596,7 +753,8 @@ class Trainer(object):
                 ops.sgd_keras(self.flat_params, self.opt_state[0], self.flat_grads, 0, opt.lr, opt.momentum, 0.0, 1.0)
         # everything the captured launches point into must outlive the graph, whatever the caches do later
         keep = (outs, loss_vals, dys, dict(ops._workspaces), dict(ops._workspaces2),
-                self.model.train_executor.scratch(int(x.shape[0])), self.model.train_executor.phase_buffers())
+                self.model.train_executor.scratch(int(x.shape[0])), self.model.train_executor.phase_buffers(),
+                self._prep_cache.get(int(x.shape[0])), self._side)
         return {'graph': g, 'x': gx, 'ys': gys, 'loss': loss_vals, 'keep': keep}
 
     def _graph_step(self, x, ys, n_global, scale, dp):
@@ -639,7 +797,7 @@ class Trainer(object):
             raise ValueError('%d rows given for a batch of %d without data parallelism' % (n_local, n_global))
         if dp is not None and self._params_dirty:
             self.sync_parameters()
-        if n_local > 0 and self._graph_ok():
+        if n_local > 0 and self._graph_ok(n_local):
             scale_g = 1.0 if dp is None else n_local * dp.world / float(n_global)
             x = x.reshape((n_local,) + tuple(x.shape[1:]))
             loss_vals = self._graph_step(x, self._targets(y, n_local), n_global, scale_g, dp)
@@ -656,8 +814,7 @@ class Trainer(object):
         scale = 1.0 if dp is None else n_local * dp.world / float(n_global)
         if n_local > 0:
             ys = self._targets(y, n_local)
-            outs, loss_vals, dys = self._forward_loss(x, ys, True, scale)
-            self._backward(x, outs, dys)
+            outs, loss_vals, dys = self._forward_backward(x, ys, scale)
             self._add_regularizer_gradients()
         else:                               # a rank without rows still takes part in the exchange: no data gradient, but
             self._flat_exchange.zero_()     # its share of the regularisers' (every rank adds it in full, the sum is / world)

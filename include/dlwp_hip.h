@@ -285,6 +285,34 @@ int    dlwp_sgd_keras(dlwp_handle_t, void* p, void* vel, const void* g, size_t n
                       long long iteration, float grad_scale, void* stream);
 int    dlwp_axpby(dlwp_handle_t, const void* x, void* y, size_t n, float a, float b, void* stream);   /* y = a*x + b*y */
 
+/* ---- a training step's weight-side helpers in ONE launch each (csrc/batch.hip).  Keras / TF run one kernel per op
+ *      (the train step behind DLWP/model/models.py:188-228); at the 8 samples per GPU of an 8-way data-parallel config-3
+ *      step, 32 of 64 launches were sub-5-us helpers on weight-sized tensors.
+ *   dlwp_prepare_begin .. dlwp_prepare_flush: dlwp_conv2d_prepare and dlwp_conv2d_bwd_data_prepare in between only RECORD
+ *      their work (Winograd filter transforms, packed-N expansions, flipped / transposed kernels); flush builds all of it
+ *      with one kernel on `stream`.  (bf16 arrangements are not batched: they run at once.)
+ *   dlwp_reductions_begin .. dlwp_reductions_flush: the FINAL sums of dlwp_conv2d_bwd_weight (over its slabs),
+ *      dlwp_bias_grad / dlwp_act_bwd_bias_grad / dlwp_pool_act_bwd_bias_grad (over their partials) and dlwp_mse_mae in
+ *      between are recorded; their outputs (dw, db, out2) are undefined and their workspaces must stay untouched -- one
+ *      workspace per call -- until flush sums everything with one kernel (fixed order: deterministic).  Two recorded sums
+ *      into the same tensor (accumulate) flush in between.  At most 24 jobs per launch; more flush early.
+ *   The modes live on the handle: one thread per handle while they are on.                                              */
+int    dlwp_prepare_begin(dlwp_handle_t);
+int    dlwp_prepare_flush(dlwp_handle_t, void* stream);
+int    dlwp_reductions_begin(dlwp_handle_t);
+int    dlwp_reductions_flush(dlwp_handle_t, void* stream);
+/* The data gradient's operand -- the flipped / transposed kernel, followed by its Winograd / packed-N form when the
+ * gradient's convolution runs on such an instance -- depends on the weights only: build it once per step
+ * (dlwp_conv2d_bwd_data_prepare into `prepared`, dlwp_conv2d_bwd_data_prepared_bytes large; batched between
+ * dlwp_prepare_begin / _flush) and pass it to dlwp_conv2d_bwd_data_prepared, which then launches the gradient's convolution
+ * only.  stored: 0 = dlwp_conv2d_bwd_data semantics, 1 = dlwp_conv2d_bwd_data_stored.  The workspace may be smaller by the
+ * kernel's size (kh kw cin cout floats, rounded up to 256 bytes).                                                          */
+size_t dlwp_conv2d_bwd_data_prepared_bytes(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int stored);
+int    dlwp_conv2d_bwd_data_prepare(dlwp_handle_t, const void* w, void* prepared, dlwp_shape4 xs, const dlwp_conv2d* cd,
+                                    int stored, void* stream);
+int    dlwp_conv2d_bwd_data_prepared(dlwp_handle_t, const void* dz, const void* prepared, void* dx, dlwp_shape4 xs,
+                                     const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, int stored, void* stream);
+
 /* ---- keras MaxPooling2D(2) / UpSampling2D(2) standalone (examples/train.py:171,181,191,201) ------------------------ */
 int dlwp_maxpool2_fwd (dlwp_handle_t, const void* x, void* y, dlwp_shape4 xs, int dtype, void* stream);
 int dlwp_maxpool2_bwd (dlwp_handle_t, const void* x, const void* dy, void* dx, dlwp_shape4 xs, int dtype, void* stream);

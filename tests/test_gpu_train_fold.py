@@ -1,0 +1,202 @@
+"""The folded training step (csrc/batch.hip, Trainer._fold_ok): weight preparations recorded and built by one launch,
+final sums recorded and done by one launch, weight gradients on a second stream.  Same arithmetic as the one-launch-per-helper
+step -- the prepared operands are bit-identical, the final sums differ by their (fixed) order of summation only -- so the
+parity bar is the unfolded kernels' output, which the oracle tests of test_gpu_model.py pin (and which run folded by default).
+Reference: the Keras train step behind DLWP/model/models.py:188-228."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ref
+from tests.nets import unet_layers
+from tests.test_gpu_model import _build, _torch_step, _weights_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+#            cin cout  k dil   h    w  mode_w src_mode stored
+DGRAD_CASES = [(32, 64, 3, 1, 22, 45, 1, 0, False),      # Winograd data gradient (64 -> 32 channels)
+               (64, 32, 3, 2, 24, 40, 1, 0, False),      # dilation 2
+               (4, 32, 3, 2, 16, 24, 1, 0, False),       # direct family (4 output channels of the gradient: packed-N or direct)
+               (32, 4, 5, 1, 16, 24, 1, 0, False),       # 5x5 output layer
+               (64, 32, 3, 1, 11, 23, 1, 1, True),       # up-sampled source, 2x2 sum in the epilogue
+               (128, 64, 3, 1, 11, 23, 0, 1, True),
+               (16, 16, 3, 1, 10, 12, 1, 2, False),      # pooled source
+               (24, 40, 3, 1, 9, 20, 2, 0, False)]       # edge halo: the fold-back route
+
+
+def test_prepared_data_gradient_is_bit_identical_alone_and_batched():
+    """dlwp_conv2d_bwd_data_prepared(prepare(w)) == dlwp_conv2d_bwd_data(w) bit for bit, whether each operand is built by
+    its own call or all of them by ONE launch between prepare_begin / prepare_flush (together with forward operands)."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(41)
+    n = 4
+    built = []
+    for (cin, cout, k, dil, h, w, mw, sm, stored) in DGRAD_CASES:
+        p = dil * (k - 1) // 2
+        cd = ops.make_conv(cout, k, k, dil, ops.make_pad(p, p, p, p, 0, mw), ops.ACT_LINEAR, src_mode=sm)
+        xs = _lib.Shape4(n, cin, h, w)
+        ys = ops.conv_out_shape(xs, cd)
+        wt = dev(np_ref.glorot_uniform((k, k, cin, cout), rng))
+        dz = dev(rng.standard_normal((n, cout, ys.h, ys.w)).astype(np.float32))
+        hin, win = (2 * h, 2 * w) if sm == 1 else ((h // 2, w // 2) if sm == 2 else (h, w))
+        shape = (n, cin, h, w) if stored else (n, cin, hin, win)
+        want = torch.full(shape, float('nan'), device='cuda')
+        if stored:
+            assert ops.conv2d_bwd_data_stored(dz, wt, cd, xs, want)
+        else:
+            ops.conv2d_bwd_data(dz, wt, cd, xs, want)
+        prep = ops.conv2d_bwd_data_prepare(wt, cd, xs, stored=stored)
+        assert prep is not None
+        got = torch.full(shape, float('nan'), device='cuda')
+        ops.conv2d_bwd_data(dz, wt, cd, xs, got, prepared=prep, stored=stored)
+        assert torch.equal(got, want), (cin, cout, k, dil, sm)
+        built.append((cd, xs, wt, dz, want, prep, stored, shape))
+    # all operands again in one launch, into fresh buffers, next to two forward preparations
+    device = torch.device('cuda', torch.cuda.current_device())
+    xf = dev(rng.standard_normal((n, 32, 22, 45)).astype(np.float32))
+    wf = dev(np_ref.glorot_uniform((3, 3, 32, 64), rng))
+    cf = ops.make_conv(64, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
+    uf_alone = ops.conv2d_prepare(xf, wf, cf)
+    assert uf_alone is not None
+    ops.prepare_begin(device)
+    try:
+        batched = [ops.conv2d_bwd_data_prepare(wt, cd, xs, stored=stored) for cd, xs, wt, _, _, _, stored, _ in built]
+        uf = ops.conv2d_prepare(xf, wf, cf)
+    finally:
+        ops.prepare_flush(device)
+    assert torch.equal(uf, uf_alone)
+    for (cd, xs, wt, dz, want, prep, stored, shape), b in zip(built, batched):
+        assert torch.equal(b, prep)
+        got = torch.full(shape, float('nan'), device='cuda')
+        ops.conv2d_bwd_data(dz, wt, cd, xs, got, prepared=b, stored=stored)
+        assert torch.equal(got, want)
+
+
+def test_deferred_final_sums_equal_the_immediate_ones():
+    """Weight-gradient slab sums, bias-gradient and loss final sums recorded between reductions_begin / reductions_flush give
+    the immediate kernels' results up to the order of a float32 sum; nothing is written before the flush."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(43)
+    device = torch.device('cuda', torch.cuda.current_device())
+    n = 8
+    cases = []
+    for j, (cin, cout, k, dil, h, w) in enumerate([(32, 64, 3, 1, 22, 45), (4, 32, 3, 2, 24, 36), (32, 16, 3, 1, 24, 36),
+                                                    (32, 4, 5, 1, 16, 24), (128, 64, 3, 1, 22, 45)]):
+        p = dil * (k - 1) // 2
+        cd = ops.make_conv(cout, k, k, dil, ops.make_pad(p, p, p, p, 0, 1), ops.ACT_TANH)
+        xs = _lib.Shape4(n, cin, h, w)
+        x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+        y = dev(np.tanh(rng.standard_normal((n, cout, h, w))).astype(np.float32))
+        dy = dev(rng.standard_normal((n, cout, h, w)).astype(np.float32))
+        dw = torch.empty((k, k, cin, cout), device='cuda')
+        db = torch.empty(cout, device='cuda')
+        dz = ops.act_bwd_bias_grad(y, dy, ops.ACT_TANH, db, cout)
+        ops.conv2d_bwd_weight(x, dz, dw, cd, xs)
+        cases.append((j, cd, xs, x, y, dy, dw, db))
+    yp, yt = dev(rng.standard_normal((n, 4, 16, 24)).astype(np.float32)), dev(rng.standard_normal((n, 4, 16, 24)).astype(np.float32))
+    out_now = torch.zeros(2, device='cuda')
+    ops.mse_mae(yp, yt, out_now)
+    torch.cuda.synchronize()
+    outs = []
+    out_def = torch.full((2,), -7.0, device='cuda')
+    ops.reductions_begin(device)
+    try:
+        ops.mse_mae(yp, yt, out_def, ws_key=('t', 'mse'))
+        for j, cd, xs, x, y, dy, dw, db in cases:
+            dw2 = torch.full_like(dw, -7.0)
+            db2 = torch.full_like(db, -7.0)
+            dz = ops.act_bwd_bias_grad(y, dy, ops.ACT_TANH, db2, db.numel(), ws_key=('t', 'b', j))
+            ops.conv2d_bwd_weight(x, dz, dw2, cd, xs, ws_key=('t', 'w', j))
+            outs.append((dw2, db2))
+        torch.cuda.synchronize()
+        assert (out_def == -7.0).all() and all((a == -7.0).all() and (b == -7.0).all() for a, b in outs)   # not yet
+    finally:
+        ops.reductions_flush(device)
+    torch.cuda.synchronize()
+    assert torch.allclose(out_def, out_now, rtol=5e-6, atol=0)
+    for (j, cd, xs, x, y, dy, dw, db), (dw2, db2) in zip(cases, outs):
+        assert (dw2 - dw).abs().max().item() <= 2e-5 * dw.abs().max().item(), j
+        assert (db2 - db).abs().max().item() <= 2e-5 * max(db.abs().max().item(), 1.0), j
+    # accumulate: dw += second gradient, recorded after a first sum into the same tensor (flushes in between)
+    j, cd, xs, x, y, dy, dw, db = cases[0]
+    acc = torch.zeros_like(dw)
+    ops.reductions_begin(device)
+    try:
+        dz = ops.act_bwd(y, dy, ops.ACT_TANH)
+        ops.conv2d_bwd_weight(x, dz, acc, cd, xs, ws_key=('t', 'w', 'a'))
+        ops.conv2d_bwd_weight(x, dz, acc, cd, xs, accumulate=True, ws_key=('t', 'w', 'b'))
+    finally:
+        ops.reductions_flush(device)
+    assert (acc - 2 * dw).abs().max().item() <= 4e-5 * dw.abs().max().item()
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_folded_step_equals_the_unfolded_step_and_the_autograd_oracle(monkeypatch, graph):
+    """The whole step both ways from the same weights: gradients agree to float32 round-off of the final sums, and the folded
+    ones meet the autograd bar of test_train_step_gradients_loss_and_adam_match_autograd_oracle; also as a captured hipGraph
+    (the second stream forks and joins inside the capture)."""
+    monkeypatch.setenv('DLWP_TRAIN_GRAPH', '1' if graph else '0')
+    rng = np.random.default_rng(8)
+    cs = (4, 16, 24)
+    layers = unet_layers(cs)
+    x = rng.standard_normal((6,) + cs).astype(np.float32)
+    y = rng.standard_normal((6,) + cs).astype(np.float32)
+    res = {}
+    for fold in (True, False):
+        d = _build(layers, time_dim=2)
+        weights = _weights_of(d.model, np.random.default_rng(9))
+        tr = d.model._trainer
+        tr._fold = None if fold else False
+        assert tr._fold_ok() == fold
+        logs = [d.model.train_on_batch(x, y) for _ in range(5)]
+        torch.cuda.synchronize()
+        assert (len(tr._graphs) == 1) == graph
+        res[fold] = (logs, tr.flat_grads.cpu().numpy().copy(), d.model.get_weights(), weights)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-7), (a, b)
+    g1, g0 = res[True][1], res[False][1]
+    assert np.abs(g1 - g0).max() <= 5e-6 * np.abs(g0).max()
+    for a, b in zip(res[True][2], res[False][2]):
+        assert np.abs(a - b).max() <= 5e-6
+    # first step against the oracle
+    d = _build(layers, time_dim=2)
+    weights = _weights_of(d.model, np.random.default_rng(9))
+    loss_ref, mae_ref, grads_ref, _ = _torch_step(layers, weights, x, y)
+    vals = d.model.train_on_batch(x, y)
+    assert d.model._trainer._fold_ok()
+    assert vals[0] == pytest.approx(loss_ref, rel=2e-5) and vals[1] == pytest.approx(mae_ref, rel=2e-5)
+    off = 0
+    tr = d.model._trainer
+    for g_ref in grads_ref:
+        g = tr.flat_grads[off:off + g_ref.size].cpu().numpy().reshape(g_ref.shape)
+        off += g_ref.size
+        assert np.abs(g - g_ref).max() <= 2e-4 * max(np.abs(g_ref).max(), 1e-6), g_ref.shape
+
+
+def test_folded_step_launch_count():
+    """What the fold is for: count the kernel launches of one step with the profiler-free method -- the handle's job tables
+    are flushed once each, so the step's helpers shrink to two launches.  Checked through the recorded job counts."""
+    from dlwp_amd import ops
+    rng = np.random.default_rng(8)
+    cs = (4, 16, 24)
+    d = _build(unet_layers(cs), time_dim=2)
+    tr = d.model._trainer
+    assert tr._fold_ok()
+    x = rng.standard_normal((6,) + cs).astype(np.float32)
+    d.model.train_on_batch(x, x)
+    prep = tr._prep_cache[6]
+    n_conv = sum(1 for op in tr.plan.ops if op.kind == 'conv')
+    assert len(prep['bwd']) == n_conv - 1                  # every layer but the first has a data gradient
+    assert len(prep['fwd']) >= 4                           # the Winograd / packed-N layers of the forward
+    assert ('cuda', torch.cuda.current_device(), ('wgrad', max(k for k in prep['bwd']))) in ops._workspaces
