@@ -17,7 +17,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dlwp_hip.h')
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ERCCL = 0, -1, -2, -3, -4
 OPT_WINOGRAD, OPT_BF16_MFMA, OPT_FORCE_CONV_CONFIG, OPT_FORCE_WGRAD_CONFIG, OPT_WINO_PAIRS = 0, 1, 2, 3, 4
-F32, BF16 = 0, 1
+F32, BF16, BF16_O8 = 0, 1, 2
 PAD_ZERO, PAD_WRAP, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC = 0, 1, 2, 3, 4
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
@@ -135,6 +135,7 @@ _sig('dlwp_phase_weights_bwd', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
 _sig('dlwp_conv2d_uses_bf16_weights', [_vp, Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_prefers_unfused_pool', [_vp, _i, _i, _i, _i, _i, _i])
 _sig('dlwp_conv2d_supports_out_pool', [_vp, Shape4, _P(Conv2d)])
+_sig('dlwp_conv2d_supports_dtype', [_vp, Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_supports_out_d2s', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_launch_info', [_vp, Shape4, _P(Conv2d), _i, _P(LaunchInfo), _P(_i)])

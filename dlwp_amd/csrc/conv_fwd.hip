@@ -170,9 +170,20 @@ __global__ __launch_bounds__(256) void packn_expand_weights_f32(const float* __r
 int validate(const char* fn, dlwp_handle_t h, const void* x, const void* w, void* y, dlwp_shape4 xs,
              const dlwp_conv2d* cd, int dtype, dlwp_shape4* ys) {
   DLWP_CHECK_ARG(h && cd && (xs.n == 0 || (x && w && y)), "%s: null handle or pointer", fn);
-  DLWP_CHECK_ARG((unsigned)DLWP_DTYPE_IN(dtype & ~DLWP_COMPUTE_BF16) <= 1u &&
-                     (unsigned)DLWP_DTYPE_OUT(dtype & ~DLWP_COMPUTE_BF16) <= 1u && (dtype & ~0x3ffff) == 0,
+  DLWP_CHECK_ARG((unsigned)DLWP_DTYPE_IN(dtype & ~DLWP_COMPUTE_BF16) <= 2u &&
+                     (unsigned)DLWP_DTYPE_OUT(dtype & ~DLWP_COMPUTE_BF16) <= 2u && (dtype & ~0x3ffff) == 0,
                  "%s: dtype 0x%x not supported", fn, dtype);
+  // the octet layout: whole octets everywhere (channel counts and windows)
+  if (DLWP_DTYPE_IN(dtype & ~DLWP_COMPUTE_BF16) == DLWP_BF16_O8) {
+    const int tot = cd->in_c_total > 0 ? cd->in_c_total : xs.c;
+    DLWP_CHECK_ARG(xs.c % 8 == 0 && cd->in_c_off % 8 == 0 && tot % 8 == 0, "%s: DLWP_BF16_O8 input needs whole channel octets", fn);
+  }
+  if (DLWP_DTYPE_OUT(dtype & ~DLWP_COMPUTE_BF16) == DLWP_BF16_O8) {
+    const int fields = cd->lstm_f ? cd->lstm_f : cd->cout;
+    const int tot = cd->out_c_total > 0 ? cd->out_c_total : fields;
+    DLWP_CHECK_ARG(fields % 8 == 0 && cd->out_c_off % 8 == 0 && tot % 8 == 0 && !cd->out_d2s,
+                   "%s: DLWP_BF16_O8 output needs whole channel octets (and no phase-interleaved stores)", fn);
+  }
   DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, "%s: bad input shape (%d,%d,%d,%d)", fn, xs.n, xs.c,
                  xs.h, xs.w);
   if (dlwp_conv2d_out_shape(xs, cd, ys) != DLWP_OK) return DLWP_EINVAL;
@@ -184,8 +195,10 @@ ConvArgs make_args(const void* x, const void* w, const void* bias, void* y, dlwp
   ConvArgs a;
   a.compute_bf16 = (dtype & DLWP_COMPUTE_BF16) ? 1 : 0;
   dtype &= ~DLWP_COMPUTE_BF16;
-  a.in_bf16 = DLWP_DTYPE_IN(dtype) == DLWP_BF16;
-  a.out_bf16 = DLWP_DTYPE_OUT(dtype) == DLWP_BF16;
+  a.in_bf16 = DLWP_DTYPE_IN(dtype) == DLWP_BF16 || DLWP_DTYPE_IN(dtype) == DLWP_BF16_O8;
+  a.out_bf16 = DLWP_DTYPE_OUT(dtype) == DLWP_BF16 || DLWP_DTYPE_OUT(dtype) == DLWP_BF16_O8;
+  a.in_oct = DLWP_DTYPE_IN(dtype) == DLWP_BF16_O8;
+  a.out_oct = DLWP_DTYPE_OUT(dtype) == DLWP_BF16_O8;
   a.x = (const float*)x;
   a.w = (const float*)w;
   a.bias = (const float*)bias;
@@ -297,6 +310,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     if (cd->out_pool == 2 && !(is_wino(e) && e.dil == 1)) return -1;  // the 2x2 sum epilogue: dilation-1 Winograd instances
     if (cd->out_d2s && !(is_wino(e) && e.split)) return -1;           // interleaved phase stores: the 16-channel instances
     if ((cd->lstm_f != 0) != (is_bf16(e) && e.gates)) return -1;        // gates epilogue <-> the GATES instances
+    if ((e.in8 != 0) != (a.in_oct != 0) || (e.sw != 0) != (a.out_oct != 0)) return -1;   // octet layout <-> its instances
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? forced
                : -1;
@@ -309,9 +323,9 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     for (const ConvKernelEntry& e : r.entries)
       want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h && (!cd->out_pool || e.out_pool) &&
                                 (cd->lstm_f != 0) == (e.gates != 0) &&
-                                (e.in32 != 0) == !a.in_bf16 &&
+                                (e.in32 != 0) == !a.in_bf16 && (e.in8 != 0) == (a.in_oct != 0) && (e.sw != 0) == (a.out_oct != 0) &&
                                 bf16_prep_floats(e, a.Cin, a.Cout) <= WINO_SCRATCH_FLOATS);
-  if (cd->lstm_f && !want_bf16) return -1;
+  if ((cd->lstm_f || a.in_oct || a.out_oct) && !want_bf16) return -1;   // only the bf16 family has gates / octet instances
   bool want_wino = !want_bf16 && winograd_wanted(a, cd, o);
   if (want_wino) {  // fall back to the direct family when no Winograd instance matches (dilation / pooled loader)
     bool any = false;
@@ -342,6 +356,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
         (a.Cout % 32 != 0 || cd->out_d2s ||
          2ll * dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * (a.Cout / 32) * a.N >= (long long)cu_count)) continue;
     if (is_bf16(e) && ((e.in32 != 0) == (a.in_bf16 != 0) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) continue;
+    if (is_bf16(e) && ((e.in8 != 0) != (a.in_oct != 0) || (e.sw != 0) != (a.out_oct != 0))) continue;
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     if (cd->out_d2s && !(is_wino(e) && e.split)) continue;                 // interleaved phase stores: the 16-channel instances
     if ((cd->lstm_f != 0) != (is_bf16(e) && e.gates)) continue;            // gates epilogue <-> the GATES instances
@@ -627,6 +642,8 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   if (ci < 0) {
     if (h->opt.forced_cfg >= 0)
       DLWP_FAIL(DLWP_EINVAL, "dlwp_conv2d_fwd: forced configuration %d does not match the layer", h->opt.forced_cfg);
+    if (a.in_oct || a.out_oct)
+      DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no bf16 matrix-core instance covers this layer in the octet layout");
     if (cd->out_pool) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel with a pooling epilogue for this layer");
     if (cd->out_d2s) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no kernel stores this layer's phase channels interleaved");
     if (cd->lstm_f) DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_convlstm_conv_fwd: no bf16 matrix-core instance covers this layer");
@@ -814,7 +831,7 @@ int dlwp_conv2d_config_flags(int i) {
   Registry& r = registry();
   if (i < 0 || i >= (int)r.entries.size()) return 0;
   return ((is_wino(r.entries[i]) && r.entries[i].split) ? 1 : 0) | (r.entries[i].gates ? 2 : 0) |
-         ((is_wino(r.entries[i]) && r.entries[i].split == 2) ? 4 : 0);
+         ((is_wino(r.entries[i]) && r.entries[i].split == 2) ? 4 : 0) | (r.entries[i].in8 ? 8 : 0) | (r.entries[i].sw ? 16 : 0);
 }
 
 int dlwp_conv2d_prefers_unfused_pool(dlwp_handle_t h, int cin, int cout, int kh, int kw, int dil_h, int dil_w) {
@@ -834,6 +851,21 @@ int dlwp_conv2d_supports_out_pool(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_co
   if (dlwp_conv2d_out_shape(xs, &c2, &ys) != DLWP_OK) return 0;
   ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, &c2, ys);
   return choose_config(a, &c2, 256, h ? h->opt : dlwp_default_options()) >= 0 ? 1 : 0;
+}
+
+// Planner hint for the octet layout: is there a compiled instance for this layer with the storage codes of `dtype`
+// (DLWP_DTYPE_IO with DLWP_BF16_O8 on either side)?  Host logic only; cd->lstm_f descriptors are answered for
+// dlwp_convlstm_conv_fwd.
+int dlwp_conv2d_supports_dtype(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
+  if (!cd || xs.c <= 0 || xs.h <= 0 || xs.w <= 0) return 0;
+  if (xs.n <= 0) xs.n = 1;
+  dlwp_shape4 ys;
+  char dummy;
+  if (validate("dlwp_conv2d_supports_dtype", h ? h : (dlwp_handle_t)&dummy, &dummy, &dummy, &dummy, xs, cd, dtype, &ys) != DLWP_OK)
+    return 0;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys, dtype);
+  if (cd->lstm_f && a.Wo % 4 != 0) return 0;
+  return choose_config(a, cd, 256, h ? h->opt : dlwp_default_options()) >= 0 ? 1 : 0;
 }
 
 int dlwp_conv2d_supports_out_d2s(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd) {

@@ -29,6 +29,24 @@ static const ConvKernelEntry k_table[] = {
     // 4 x 64 tiles: 8-11 % faster than 8 x 32 on the dilation-1 layers whose width they tile well (a tile row of bf16
     // output is then a whole 128-byte line); slower with dilation 2 (measured, profiles/r1i_bf16_conv_layers_*)
     BF16_ENTRY(3, 1, 4, 64, 4, 4, 2, 32),
+    // r3 -- the octet layout (conv_fwd_bf16_kernel.h: IN8 / SW): the instances config 4 runs on, in O8 -> O8, O8 -> plain
+    // (a restated decoder layer's float32 phase channels) and float32 -> O8 (the ConvLSTM2D input convolutions) form
+    BF16_ENTRY_88(3, 1, 8, 32, 4, 4, 2, 32),
+    BF16_ENTRY_88(3, 1, 4, 64, 4, 4, 2, 32),
+    BF16_ENTRY_88(3, 2, 8, 32, 4, 4, 2, 32),
+    BF16_ENTRY_88(3, 2, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY_88(3, 1, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY_8P(3, 1, 8, 32, 4, 4, 2, 32),
+    BF16_ENTRY_8P(3, 1, 4, 64, 4, 4, 2, 32),
+    BF16_ENTRY_8P(3, 2, 8, 32, 4, 4, 2, 32),
+    BF16_ENTRY_8P(3, 2, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY_8P(3, 1, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY_IN32_8(3, 1, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY_IN32_8(3, 2, 8, 32, 4, 4, 2, 16),
+    BF16_ENTRY_GATES_IN32_8(3, 2, 4, 32, 4, 2, 16),
+    BF16_ENTRY_GATES_IN32_8(3, 1, 4, 32, 4, 2, 16),
+    BF16_ENTRY_GATES_88(3, 1, 4, 32, 4, 2, 32),
+    BF16_ENTRY_GATES_88(3, 1, 4, 32, 4, 2, 16),
     // (r2: 4 x 32 tiles with two fragments per wave -- 80-110 registers, more waves per SIMD -- were measured on every layer of
     //  config 4, tools/bench_bf16_conv.py: 3-20 % slower than these; only the cell-update instances above gain from them)
 };

@@ -22,10 +22,25 @@
 
 // IN32: the input is stored as float32 and rounded to bf16 while it is staged (the caller allowed it: DLWP_COMPUTE_BF16)
 // GATES: the instance of a ConvLSTM2D step -- 64-channel blocks = 4 gates x 16 hidden channels, cell update in the epilogue
-template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool IN32_ = false, bool GATES_ = false>
+//
+// r3 -- the OCTET layout DLWP_BF16_O8 = (N, C/8, H, W, 8) bf16: a pixel's 8 consecutive channels are 16 contiguous bytes,
+// which is what both LDS tiles (and the MFMA K slices) want.  With NCHW the loader needs 8 dword loads + 8 v_perm per octet
+// and column pair, and the epilogue stores 8 bytes per lane into 16 different channel planes (32-byte runs); r2's knock-out
+// profile put loads at 24 % and stores at 20 % of this kernel's time.
+// IN8: the input is stored in octets: one 16-byte load per (octet, pixel) straight into the LDS tile, no permutes.
+// SW : the output is stored in octets.  The MFMA operands swap roles (A = weights: output channels on the ROWS, B = pixels),
+//      so a lane ends with 4 consecutive output channels of ONE pixel = 8 bytes of that pixel's octet; the 16 lanes of a lane
+//      group hold 16 consecutive pixels and two lane groups the two halves of an octet: a wave's store instruction covers
+//      whole 256-byte runs.  No weight permutation: the arranged weights are those of the plain instances.
+//      SW + GATES: z_add is read in octets, the float32 cell state is kept as (N, F/8, H, W, 8) float32 as well.
+template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool IN32_ = false, bool GATES_ = false,
+          bool IN8_ = false, bool SW_ = false>
 struct BfCfg {
   static constexpr bool IN32 = IN32_;
   static constexpr bool GATES = GATES_;
+  static constexpr bool IN8 = IN8_;
+  static constexpr bool SW = SW_;
+  static_assert(!(IN32_ && IN8_), "octet input is bf16");
   static_assert(!GATES_ || BNF_ == 4, "gates epilogue: fragment column group g = gate g");
   static constexpr int KS = KS_, DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, FA = FA_, BNF = BNF_, CK = CK_;
   static constexpr int NT = WAVES * 64;
@@ -79,7 +94,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
   const int n = L / a.cout_tiles;
   const int i0 = th * C::TH, j0 = tw * C::TW, n0 = ct * C::BN;
   const bool ups = a.src_mode == DLWP_SRC_UPSAMPLE2;
-  constexpr unsigned ESZ_IN = C::IN32 ? 4u : 2u;
+  constexpr unsigned ESZ_IN = C::IN8 ? 16u : (C::IN32 ? 4u : 2u);   // IN8: bytes per (octet, pixel)
   const int e_al = a.pad_left & 1;   // the LDS tile starts one column early when the left halo is odd: even source columns
 
   // ---- loader bookkeeping: a thread owns COLUMN PAIRS (even source column + its neighbour: one dword of a bf16 plane; W
@@ -101,9 +116,11 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
   }
   const long long plane = (long long)a.Hs * a.Ws;
   const unsigned plane_bytes = (unsigned)plane * ESZ_IN;
-  const char* xn = (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * ESZ_IN;
-  const __amdgpu_buffer_rsrc_t x_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)a.Cin * plane_bytes, 0x00020000);
+  // IN8: planes are OCTET planes (channel window and Cin are whole octets: the host checks)
+  const char* xn = C::IN8 ? (const char*)a.x + ((long long)n * (a.in_c_total >> 3) + (a.in_c_off >> 3)) * plane * ESZ_IN
+                          : (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * ESZ_IN;
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)xn, 0, (unsigned)(C::IN8 ? ((a.Cin + 7) >> 3) : a.Cin) * plane_bytes, 0x00020000);
   const int n_chunks = (a.Cin + C::CK - 1) / C::CK;
   // a.w = bf16_arrange_weights output for THIS instance: [cout tile][chunk][WCH]
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -126,12 +143,22 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
 
   f32x4 acc[C::FA][C::BNF];
   float bias_v[C::BNF];   // loaded here: the latency hides under the main loop
+  f32x4 bias4[C::SW ? C::BNF : 1];   // SW: the lane's 4 consecutive output channels (MFMA rows 4 (lane >> 4) .. + 3) per fragment
 #pragma unroll
   for (int g = 0; g < C::BNF; ++g) {
     // gates epilogue (a.lstm_f): block ct = hidden channels 16 ct .. +15, fragment column group g = gate g
-    const int co = a.lstm_f ? g * a.lstm_f + ct * 16 + (lane & 15) : n0 + g * 16 + (lane & 15);
-    const bool cok = a.lstm_f ? ct * 16 + (lane & 15) < a.lstm_f : co < a.Cout;
-    bias_v[g] = (a.bias && cok) ? a.bias[co] : 0.f;
+    if constexpr (C::SW) {
+      const int c4 = 4 * (lane >> 4);
+      const int co = a.lstm_f ? g * a.lstm_f + ct * 16 + c4 : n0 + g * 16 + c4;
+      const bool cok = a.lstm_f ? ct * 16 + c4 < a.lstm_f : co < a.Cout;    // (channel counts are whole octets)
+      bias4[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (a.bias && cok) bias4[g] = (f32x4){a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
+      bias_v[g] = 0.f;
+    } else {
+      const int co = a.lstm_f ? g * a.lstm_f + ct * 16 + (lane & 15) : n0 + g * 16 + (lane & 15);
+      const bool cok = a.lstm_f ? ct * 16 + (lane & 15) < a.lstm_f : co < a.Cout;
+      bias_v[g] = (a.bias && cok) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < C::FA; ++i) acc[i][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -139,7 +166,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
   // ---- register-staged pipeline as in the fp32 kernel: loads of chunk c+1 in flight under the MFMAs of chunk c
   // raw column pairs in flight: one dword of a bf16 plane, or two floats of a float32 plane (IN32)
   typedef typename std::conditional<C::IN32, u32x2, unsigned>::type xraw_t;
-  xraw_t xr[C::CK][C::NPP];
+  xraw_t xr[C::IN8 ? 1 : C::CK][C::NPP];
+  u32x4 xr8[C::IN8 ? C::NO : 1][C::NPP][2];   // IN8: the pair's two pixels, 8 channels each
   u32x4 wr[C::NWV];
   int staged_live = C::NO;   // octets of the staged chunk that hold real channels (the others are zero)
   auto prefetch = [&](int c0) {
@@ -151,18 +179,28 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
 #pragma unroll
     for (int o = 0; o < C::NO; ++o) {
       if (o >= staged_live) continue;
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        const int c = o * 8 + cc;
-        const unsigned soff = (unsigned)(c0 + c) * plane_bytes;
+      if constexpr (C::IN8) {
+        const unsigned soff = (unsigned)((c0 >> 3) + o) * plane_bytes;
 #pragma unroll
         for (int q = 0; q < C::NPP; ++q) {
-          if (ups) {
-            if constexpr (C::IN32) xr[c][q] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0), 0u};
-            else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0);
-          } else {
-            if constexpr (C::IN32) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, goff[q], soff, 0);
-            else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0);
+          xr8[o][q][0] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[q], soff, 0);
+          // (up-sampled source: both columns of the pair are the same element; an out-of-range pair stays out of range)
+          if (!ups) xr8[o][q][1] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[q] + 16u, soff, 0);
+        }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int c = o * 8 + cc;
+          const unsigned soff = (unsigned)(c0 + c) * plane_bytes;
+#pragma unroll
+          for (int q = 0; q < C::NPP; ++q) {
+            if (ups) {
+              if constexpr (C::IN32) xr[c][q] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0), 0u};
+              else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0);
+            } else {
+              if constexpr (C::IN32) xr[c][q] = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, goff[q], soff, 0);
+              else xr[c][q] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0);
+            }
           }
         }
       }
@@ -194,24 +232,32 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
         }
         continue;
       }
+      if constexpr (C::IN8) {
 #pragma unroll
-      for (int q = 0; q < C::NPP; ++q) {
-        unsigned xd[8];
-        if (ups) {
-#pragma unroll
-          for (int cc = 0; cc < 8; ++cc) xd[cc] = pair_bits(xr[o * 8 + cc][q], std::true_type{});
-        } else {
-#pragma unroll
-          for (int cc = 0; cc < 8; ++cc) xd[cc] = pair_bits(xr[o * 8 + cc][q], std::false_type{});
+        for (int q = 0; q < C::NPP; ++q) {
+          xo[o * C::PSO + lpos[q]] = xr8[o][q][0];
+          xo[o * C::PSO + lpos[q] + 1] = ups ? xr8[o][q][0] : xr8[o][q][1];
         }
-        u32x4 lo, hi;   // column p / column p+1: channels 8o .. 8o+7
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          lo[j] = __builtin_amdgcn_perm(xd[2 * j + 1], xd[2 * j], 0x05040100u);
-          hi[j] = __builtin_amdgcn_perm(xd[2 * j + 1], xd[2 * j], 0x07060302u);
+        for (int q = 0; q < C::NPP; ++q) {
+          unsigned xd[8];
+          if (ups) {
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) xd[cc] = pair_bits(xr[o * 8 + cc][q], std::true_type{});
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) xd[cc] = pair_bits(xr[o * 8 + cc][q], std::false_type{});
+          }
+          u32x4 lo, hi;   // column p / column p+1: channels 8o .. 8o+7
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lo[j] = __builtin_amdgcn_perm(xd[2 * j + 1], xd[2 * j], 0x05040100u);
+            hi[j] = __builtin_amdgcn_perm(xd[2 * j + 1], xd[2 * j], 0x07060302u);
+          }
+          xo[o * C::PSO + lpos[q]] = lo;
+          xo[o * C::PSO + lpos[q] + 1] = hi;
         }
-        xo[o * C::PSO + lpos[q]] = lo;
-        xo[o * C::PSO + lpos[q] + 1] = hi;
       }
     }
 #pragma unroll
@@ -260,15 +306,139 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
       for (int i = 0; i < C::FA; ++i)
 #pragma unroll
         for (int g = 0; g < C::BNF; ++g) {
+          // SW: the weights are the A operand -> output channels on the accumulator's rows, pixels on its columns
+          const u32x4 ma = C::SW ? bf[cur][g] : af[cur][i], mb = C::SW ? af[cur][i] : bf[cur][g];
           if (k32)
-            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[cur][i]),
-                                                                __builtin_bit_cast(bf16x8, bf[cur][g]), acc[i][g], 0, 0, 0);
+            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ma), __builtin_bit_cast(bf16x8, mb),
+                                                                acc[i][g], 0, 0, 0);
           else
-            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(
-                __builtin_bit_cast(s16x4, (u32x2){af[cur][i][0], af[cur][i][1]}),
-                __builtin_bit_cast(s16x4, (u32x2){bf[cur][g][0], bf[cur][g][1]}), acc[i][g], 0, 0, 0);
+            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, (u32x2){ma[0], ma[1]}),
+                                                                  __builtin_bit_cast(s16x4, (u32x2){mb[0], mb[1]}), acc[i][g], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- SW: octet-layout output.  Accumulator rows = output channels: the lane holds channels 4 g4 .. 4 g4 + 3 of fragment
+  //      column group t for ONE pixel (column lane & 15 of pixel fragment i): 8 bytes of that pixel's octet per store.
+  if constexpr (C::SW) {
+    constexpr unsigned DROP = 0x7ffffff0u;
+    const int g4 = lane >> 4, pxl = lane & 15;
+    if constexpr (C::GATES) {
+      // cell update on the accumulators as below, for the lane's 4 hidden channels hb .. hb + 3 of one pixel; z_add comes in
+      // octets, the float32 cell state lives as (N, F/8, H, W, 8) float32: 16 bytes per lane, 512-byte runs per wave
+      const int F = a.lstm_f, hb = ct * 16 + 4 * g4;
+      const unsigned hw = (unsigned)(a.Ho * a.Wo);
+      const __amdgpu_buffer_rsrc_t z_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((const char*)a.zadd + (long long)n * 4 * F * hw * 2), 0, a.zadd ? (unsigned)(4 * F) * hw * 2u : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t cp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.c_prev + (long long)n * F * hw), 0, a.c_prev ? (unsigned)F * hw * 4u : 0u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t co_rsrc =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.c_out + (long long)n * F * hw), 0, (unsigned)F * hw * 4u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((char*)a.y + ((long long)n * (a.out_c_total >> 3) + (a.out_c_off >> 3)) * (long long)hw * 16), 0,
+          (unsigned)F * hw * 2u, 0x00020000);
+      u32x2 zpre[C::FA][4];
+      f32x4 cpre[C::FA];
+      unsigned pixv[C::FA];
+#pragma unroll
+      for (int i = 0; i < C::FA; ++i) {
+        const int p = (wave * C::FA + i) * 16 + pxl;
+        const int row = p / C::TW, col = p - row * C::TW;
+        const int oh = i0 + row, ow = j0 + col;
+        const bool ok = hb < F && p < C::P && oh < a.Ho && ow < a.Wo;
+        pixv[i] = ok ? (unsigned)(oh * a.Wo + ow) : 0xffffffffu;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const unsigned ch = (unsigned)(g * F + hb);
+          zpre[i][g] = __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, ok ? ((ch >> 3) * hw + pixv[i]) * 16u + (ch & 4u) * 2u : DROP, 0, 0);
+        }
+        cpre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                cp_rsrc, ok ? (((unsigned)hb >> 3) * hw + pixv[i]) * 32u + ((unsigned)hb & 4u) * 4u : DROP, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < C::FA; ++i) {
+        const bool ok = pixv[i] != 0xffffffffu;
+        float z[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x2 v = zpre[i][g];
+          const float za[4] = {bf16_bits_to_f32(v[0] & 0xffffu), bf16_bits_to_f32(v[0] >> 16), bf16_bits_to_f32(v[1] & 0xffffu),
+                               bf16_bits_to_f32(v[1] >> 16)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) z[g][r] = acc[i][g][r] + bias4[g][r] + za[r];
+        }
+        const f32x4 cp = cpre[i];
+        f32x4 cn, hn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float cv = dlwp_rec_apply(z[0][r], a.rec_act) * act_apply(z[2][r], a.act);
+          if (a.c_prev) cv = fmaf(dlwp_rec_apply(z[1][r], a.rec_act), cp[r], cv);
+          cn[r] = cv;
+          hn[r] = dlwp_rec_apply(z[3][r], a.rec_act) * act_apply(cv, a.act);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cn), co_rsrc,
+                                               ok ? (((unsigned)hb >> 3) * hw + pixv[i]) * 32u + ((unsigned)hb & 4u) * 4u : DROP, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3])}, h_rsrc,
+                                              ok ? (((unsigned)hb >> 3) * hw + pixv[i]) * 16u + ((unsigned)hb & 4u) * 2u : DROP, 0, 0);
+      }
+      return;
+    } else {
+      const unsigned oplane = (unsigned)(a.Hp * a.Wp);   // == Ho*Wo without the pooling epilogue
+      void* yn = (char*)a.y + ((long long)n * (a.out_c_total >> 3) + (a.out_c_off >> 3)) * (long long)oplane * 16;
+      const __amdgpu_buffer_rsrc_t y_rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(yn, 0, (unsigned)((a.Cout + 7) >> 3) * oplane * 16u, 0x00020000);
+      unsigned coff[C::BNF];   // byte offset of the lane's half octet in pixel 0 of its octet plane, or DROP
+#pragma unroll
+      for (int t = 0; t < C::BNF; ++t) {
+        const unsigned c4 = (unsigned)(n0 + 16 * t + 4 * g4);
+        coff[t] = (int)c4 < a.Cout ? (c4 >> 3) * oplane * 16u + (c4 & 4u) * 2u : DROP;
+      }
+      act_dispatch(a.act, [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        if constexpr (C::POOL_EPI) {
+          if (a.out_pool) {
+            // fragments i and i + FA/2 hold the same columns of tile rows 2 wave and 2 wave + 1; a window's horizontal
+            // neighbour sits in the neighbouring lane (pixel column ^ 1): one DPP move.  Even lanes store.
+            const int pr = (i0 >> 1) + wave;
+#pragma unroll
+            for (int i = 0; i < C::FA / 2; ++i) {
+              const int pc = (j0 >> 1) + i * 8 + (pxl >> 1);
+              const bool ok = (lane & 1) == 0 && pr < a.Hp && pc < a.Wp;
+              const unsigned poff = (unsigned)(pr * a.Wp + pc) * 16u;
+#pragma unroll
+              for (int t = 0; t < C::BNF; ++t) {
+                f32x4 m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float v = fmaxf(acc[i][t][r], acc[i + C::FA / 2][t][r]);
+                  const float w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+                  m[r] = fmaxf(v, w);
+                }
+                const f32x2 lo = act_apply2_c<ACT>(m.xy + bias4[t].xy), hi = act_apply2_c<ACT>(m.zw + bias4[t].zw);
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y)}, y_rsrc,
+                                                      (ok && coff[t] != DROP) ? coff[t] + poff : DROP, 0, 0);
+              }
+            }
+            return;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < C::FA; ++i) {
+          const int p = (wave * C::FA + i) * 16 + pxl;
+          const int row = p / C::TW, col = p - row * C::TW;
+          const int oh = i0 + row, ow = j0 + col;
+          const bool ok = p < C::P && oh < a.Ho && ow < a.Wo;
+          const unsigned poff = (unsigned)(oh * a.Wo + ow) * 16u;
+#pragma unroll
+          for (int t = 0; t < C::BNF; ++t) {
+            const f32x2 lo = act_apply2_c<ACT>(acc[i][t].xy + bias4[t].xy), hi = act_apply2_c<ACT>(acc[i][t].zw + bias4[t].zw);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y)}, y_rsrc,
+                                                  (ok && coff[t] != DROP) ? coff[t] + poff : DROP, 0, 0);
+          }
+        }
+      });
+      return;
     }
   }
 
@@ -459,15 +629,25 @@ static int bf16_prepare() {
 
 // registry entry: pack = -2 marks a bf16-MFMA instance (a.w = bf16_arrange_weights output); in32 = 1: float32-stored input,
 // rounded to bf16 in the loader; prep_chunk_floats = floats per (cout tile, channel chunk) of the arranged weights
-#define BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES)                                                     \
+// in8 / sw: the instance reads / writes the octet layout DLWP_BF16_O8 (and only that)
+#define BF16_ENTRY_X(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, IN8, SW)                                             \
   {                                                                                                                         \
-    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>::LDS_BYTES, 0, -2,         \
-        (!GATES && BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>::POOL_EPI) ? 1 : 0,                              \
-        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>::WCH * 4,                                                   \
-        &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>>,                                        \
-        &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES>>, IN32 ? 1 : 0, 0, GATES ? 1 : 0              \
+    KS, DIL, TH, TW, WAVES, FA, BNF, CK, BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, IN8, SW>::LDS_BYTES, 0,    \
+        -2, (!GATES && BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, IN8, SW>::POOL_EPI) ? 1 : 0,                 \
+        BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, IN8, SW>::WCH * 4,                                          \
+        &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, IN8, SW>>,                               \
+        &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, IN8, SW>>, IN32 ? 1 : 0, 0, GATES ? 1 : 0,    \
+        IN8 ? 1 : 0, SW ? 1 : 0                                                                                             \
   }
+#define BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES) \
+  BF16_ENTRY_X(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, false, false)
 #define BF16_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, false, false)
 #define BF16_ENTRY_IN32(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, true, false)
 #define BF16_ENTRY_GATES(KS, DIL, TH, TW, WAVES, FA, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, 4, CK, false, true)
 #define BF16_ENTRY_GATES_IN32(KS, DIL, TH, TW, WAVES, FA, CK) BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, 4, CK, true, true)
+// octet layout: O8 in and out; O8 in, plain (NCHW, float32 or bf16) out; float32 in, O8 out; and the gates instances
+#define BF16_ENTRY_88(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_X(KS, DIL, TH, TW, WAVES, FA, BNF, CK, false, false, true, true)
+#define BF16_ENTRY_8P(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_X(KS, DIL, TH, TW, WAVES, FA, BNF, CK, false, false, true, false)
+#define BF16_ENTRY_IN32_8(KS, DIL, TH, TW, WAVES, FA, BNF, CK) BF16_ENTRY_X(KS, DIL, TH, TW, WAVES, FA, BNF, CK, true, false, false, true)
+#define BF16_ENTRY_GATES_88(KS, DIL, TH, TW, WAVES, FA, CK) BF16_ENTRY_X(KS, DIL, TH, TW, WAVES, FA, 4, CK, false, true, true, true)
+#define BF16_ENTRY_GATES_IN32_8(KS, DIL, TH, TW, WAVES, FA, CK) BF16_ENTRY_X(KS, DIL, TH, TW, WAVES, FA, 4, CK, true, true, false, true)

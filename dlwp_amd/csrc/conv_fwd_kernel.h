@@ -46,6 +46,8 @@ struct ConvArgs {
   // Cout = 4 lstm_f gate pre-activations z = conv + bias (+ zadd) are never stored; y = the h buffer (channel window
   // out_c_off / out_c_total), c_prev / c_out the float32 cell state.  0: plain convolution.
   int lstm_f = 0, rec_act = 0;
+  int in_oct = 0, out_oct = 0;   // DLWP_BF16_O8 storage of x / y: (N, C/8, H, W, 8) bf16; out_oct with lstm_f: z_add is stored in
+                                 // octets too and the float32 cell state as (N, F/8, H, W, 8) float32
   const void* zadd = nullptr;
   const float* c_prev = nullptr;
   float* c_out = nullptr;
@@ -548,6 +550,7 @@ struct ConvKernelEntry {
   int split = 0; // Winograd: 1 = the 16-position case runs conv_fwd_wino2_kernel.h (positions split over two waves per
                  // tile fragment: 2 x waves x 64 threads); the 9-position variants are the same for both
   int gates = 0; // bf16-MFMA instances: 1 = ConvLSTM2D cell update in the epilogue (dlwp_conv2d.lstm_f), and only that
+  int in8 = 0, sw = 0;   // bf16-MFMA instances: the input / the output is stored in the octet layout DLWP_BF16_O8
 };
 
 template <class C>

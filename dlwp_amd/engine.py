@@ -35,6 +35,7 @@ class Executor(object):
         self._descs = None
         self._bf16 = set(plan.bf16_buffers()) if activation_dtype == 'bfloat16' else set()
         self._phase = None       # derived (phase-summed) kernels of plan.phase_params: [(w2, b2 | None)]
+        self._oct = self._octet_buffers() if self._bf16 and os.environ.get('DLWP_BF16_O8', '1') != '0' else set()
 
     # -- buffers ----------------------------------------------------------------------------------------------------- #
     def scratch(self, n):
@@ -81,13 +82,72 @@ class Executor(object):
             self._descs = descs
         return self._descs
 
-    def _conv_dtype(self, op):
+    def _conv_dtype(self, op, octets=None):
         """dtype code of a convolution launch: storage of its input / output buffers; in bfloat16 mode a float32-stored
-        input (the model state) feeding a bf16-stored output may be rounded to bf16 by the kernel (DLWP_COMPUTE_BF16)."""
+        input (the model state) feeding a bf16-stored output may be rounded to bf16 by the kernel (DLWP_COMPUTE_BF16).
+        Buffers of self._oct are stored in channel octets (DLWP_BF16_O8, include/dlwp_hip.h)."""
         from . import _lib
+        octets = self._oct if octets is None else octets
         in16, out16 = op.src in self._bf16, op.dst in self._bf16
-        return _lib.dtype_io(_lib.BF16 if in16 else _lib.F32, _lib.BF16 if out16 else _lib.F32,
-                             compute_bf16=(out16 and not in16))
+        code_in = _lib.BF16_O8 if op.src in octets else (_lib.BF16 if in16 else _lib.F32)
+        code_out = _lib.BF16_O8 if op.dst in octets else (_lib.BF16 if out16 else _lib.F32)
+        return _lib.dtype_io(code_in, code_out, compute_bf16=(out16 and not in16))
+
+    def _octet_buffers(self):
+        """The bfloat16 scratch buffers kept in channel OCTETS, (n, C/8, h, w, 8): a pixel's 8 consecutive channels are 16
+        contiguous bytes -- the unit the bf16 matrix-core kernels stage and multiply, so their loaders and epilogues move
+        16 / 8 bytes per lane in 256-byte runs instead of 2-byte elements of 8 channel planes (csrc/conv_fwd_bf16_kernel.h).
+        A buffer qualifies when its channels (and every channel window on it) are whole octets and EVERY op that touches it is
+        a convolution the library runs in that layout (dlwp_conv2d_supports_dtype); a ConvLSTM2D step with the cell update in
+        its convolution's epilogue then keeps its float32 cell state in octets too, which only those convolutions touch.
+        Model inputs / outputs stay NCHW.  DLWP_BF16_O8=0 switches the layout off."""
+        from . import _lib
+        plan = self.plan
+        descs = self._descriptors()
+        h = _lib.handle_or_none()
+        cand = {b for b in self._bf16 if plan.buffers[b][0] % 8 == 0}
+        fused = [op for op in plan.ops if op.kind == 'conv' and op.lstm_f]
+        cells = {b for op in fused for b in op.aux[1:] if b is not None}
+
+        def buffers_of(op):
+            extra = [b for b in (op.aux or ()) if isinstance(b, int)] if op.kind in ('conv', 'lstm') else []
+            return [op.src, op.dst] + extra
+        cells_private = all((op.kind == 'conv' and op.lstm_f) or not (set(buffers_of(op)) & cells) for op in plan.ops)
+
+        def settle():
+            changed = True
+            while changed and cand:
+                changed = False
+                for op, d in zip(plan.ops, descs):
+                    mine = [b for b in buffers_of(op) if b in cand]
+                    if not mine:
+                        continue
+                    ok = op.kind == 'conv'
+                    if ok and op.src in cand:
+                        tot = op.in_c_total if op.in_c_total else plan.buffers[op.src][0]
+                        ok = op.xs[0] % 8 == 0 and op.in_c_off % 8 == 0 and tot % 8 == 0
+                    if ok and op.dst in cand:
+                        tot = op.out_c_total if op.out_c_total else plan.buffers[op.dst][0]
+                        ok = not op.out_d2s and op.out_c_off % 8 == 0 and tot % 8 == 0
+                    if ok and op.lstm_f:       # z_add and h share the launch's output layout; the cell state follows it
+                        za = op.aux[0]
+                        ok = cells_private and op.lstm_f % 8 == 0 and (za is None or (za in cand) == (op.dst in cand))
+                    if ok:
+                        ok = bool(_lib.lib.dlwp_conv2d_supports_dtype(h, _lib.Shape4(1, *[int(v) for v in op.xs]),
+                                                                      ctypes.byref(d), int(self._conv_dtype(op, cand))))
+                    if not ok:
+                        for b in mine:
+                            cand.discard(b)
+                        changed = True
+        settle()
+        # the fused steps of a ConvLSTM2D share one cell state: all of them write octets, or none does
+        if fused and len({op.dst in cand for op in fused}) > 1:
+            for op in fused:
+                cand.discard(op.dst)
+                if op.aux[0] is not None:
+                    cand.discard(op.aux[0])
+            settle()
+        return cand
 
     def bf16_weight_layers(self, n=1):
         """The Conv2D layers this executor multiplies with bf16-rounded weights: the ones whose input buffer is stored as
@@ -127,12 +187,14 @@ class Executor(object):
                 za, cp, co = op.aux
                 ops.convlstm_conv(src, kern, bias, d, dst, res(co), z_add=res(za) if za is not None else None,
                                   c_prev=res(cp) if cp is not None else None, x_channels=op.xs[0],
-                                  compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16))
+                                  compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16),
+                                  in_o8=op.src in self._oct, out_o8=op.dst in self._oct)
             elif op.kind == 'conv':
                 kern, bias = self.conv_weights(op)
                 ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0],
                            compute_bf16=(op.dst in self._bf16 and op.src not in self._bf16),
-                           prepared=prepared.get(k) if prepared else None)
+                           prepared=prepared.get(k) if prepared else None,
+                           in_o8=op.src in self._oct, out_o8=op.dst in self._oct)
             elif op.kind == 'rowconv':
                 ops.rowconv2d(src, op.layer.kernel, op.layer.bias, d, out=dst, x_channels=op.xs[0])
             elif op.kind == 'phasew':

@@ -111,7 +111,11 @@ def pad2d_bwd(dy, x_shape, pad, channels_last=False):
     return dx
 
 
-def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=False, out=None):
+def _code(t, o8=False):
+    return _lib.BF16_O8 if o8 else storage_code(t)
+
+
+def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=False, out=None, in_o8=False, out_o8=False):
     """Prepared weights for conv2d(x, ...) calls with exactly this input shape / storage (dlwp_conv2d_prepare), or None
     when the layer's kernel reads the HWIO weights directly.  out: a buffer an earlier call returned (refilled in place)."""
     _check_f32(w_hwio)
@@ -121,7 +125,7 @@ def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=
         cd.in_c_total = c_total
     xs = Shape4(n, cin, h, w)
     out_code = storage_code(x) if out_dtype is None else {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}[out_dtype]
-    dt = _lib.dtype_io(storage_code(x), out_code, compute_bf16)
+    dt = _lib.dtype_io(_code(x, in_o8), _lib.BF16_O8 if out_o8 else out_code, compute_bf16)
     nbytes = _lib.lib.dlwp_conv2d_prepared_bytes(_lib.handle(_dev(x)), xs, ctypes.byref(cd), dt)
     if nbytes == 0:
         return None
@@ -133,11 +137,13 @@ def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=
     return u
 
 
-def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute_bf16=False, prepared=None):
+def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute_bf16=False, prepared=None, in_o8=False,
+           out_o8=False):
     """x: stored input (n, in_c_total, h, w); the conv reads `x_channels` (default: all) channels from cd.in_c_off.
     Returns (n, out_c_total, ho, wo); writes channels [out_c_off, out_c_off+cout).  compute_bf16: a float32 x may be
     rounded to bfloat16 so that the layer runs on the bf16 matrix cores (DLWP_COMPUTE_BF16).  prepared: the tensor
-    conv2d_prepare returned for this call (the weights are then not transformed again)."""
+    conv2d_prepare returned for this call (the weights are then not transformed again).  in_o8 / out_o8: the bfloat16
+    tensor x / out holds channel OCTETS, (n, C/8, h, w, 8) in the memory of an (n, C, h, w) tensor (DLWP_BF16_O8)."""
     _check_act(x, out)
     _check_f32(w_hwio, bias)
     n, c_total, h, w = x.shape
@@ -155,7 +161,9 @@ def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute
     elif tuple(out.shape) != (n, oc, ys.h, ys.w):
         raise ValueError('output buffer shape %s != %s' % (tuple(out.shape), (n, oc, ys.h, ys.w)))
     fn = _lib.lib.dlwp_conv2d_fwd_direct if direct else _lib.lib.dlwp_conv2d_fwd
-    dt = _lib.dtype_io(storage_code(x), storage_code(out), compute_bf16)      # storage of x / y
+    if (in_o8 and x.dtype != torch.bfloat16) or (out_o8 and out.dtype != torch.bfloat16):
+        raise ValueError('the octet layout is a bfloat16 storage')
+    dt = _lib.dtype_io(_code(x, in_o8), _code(out, out_o8), compute_bf16)      # storage of x / y
     if prepared is not None and not direct:
         _lib.check(_lib.lib.dlwp_conv2d_fwd_prepared(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(prepared),
                                                      _ptr(bias), _ptr(out), xs, ctypes.byref(cd), dt, _stream(x)))
@@ -174,7 +182,7 @@ def convlstm_conv_supported(xs_chw, cd, in_bf16, compute_bf16=False):
 
 
 def convlstm_conv(x, w_hwio, bias, cd, h_out, c_out, z_add=None, c_prev=None, x_channels=None, compute_bf16=False,
-                  prepared=None):
+                  prepared=None, in_o8=False, out_o8=False):
     """One of the two convolutions of a ConvLSTM2D step with the cell update in its epilogue (dlwp_convlstm_conv_fwd):
     z = conv(x) + bias (+ z_add) is not stored; writes c_out (float32 (n, F, ho, wo)) and channels [cd.out_c_off, +F) of
     h_out.  z_add: bfloat16 (n, 4F, ho, wo) or None; c_prev: float32 or None."""
@@ -195,7 +203,8 @@ def convlstm_conv(x, w_hwio, bias, cd, h_out, c_out, z_add=None, c_prev=None, x_
         raise ValueError('convlstm_conv: z_add must be bfloat16 (n, 4F, ho, wo)')
     if c_prev is not None and tuple(c_prev.shape) != tuple(c_out.shape):
         raise ValueError('convlstm_conv: c_prev shape')
-    dt = _lib.dtype_io(storage_code(x), storage_code(h_out), compute_bf16)
+    # out_o8: h_out AND z_add hold channel octets, c_prev / c_out float32 octets (n, F/8, h, w, 8)
+    dt = _lib.dtype_io(_code(x, in_o8), _code(h_out, out_o8), compute_bf16)
     _lib.check(_lib.lib.dlwp_convlstm_conv_fwd(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(prepared), _ptr(bias),
                                                _ptr(z_add), _ptr(c_prev), _ptr(c_out), _ptr(h_out), xs, ctypes.byref(cd), dt,
                                                _stream(x)))

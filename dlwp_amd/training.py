@@ -158,6 +158,7 @@ class Trainer(object):
         self._fold = None             # see _fold_ok
         self._prep_cache = {}         # batch size -> prepared weights of the step (see _prepare_step)
         self._side = None             # second stream: the weight gradients run beside the data-gradient chain
+        self._loader_threads = 0      # > 0 while fit_generator feeds through a DeviceLoader (see _graph_ok)
         self.sync_parameters()
 
     # -- replicas ------------------------------------------------------------------------------------------------------ #
@@ -721,8 +722,11 @@ class Trainer(object):
             # auto (r3): the FOLDED step is launch-bound on the host below ~12 samples of the 88 x 180 grid (eager 0.68 ms vs
             # 0.49 ms replayed at 8 samples) and GPU-bound above, where the replayed graph's fork / join gaps cost more than
             # the host saves (1.68 ms eager vs 1.83 ms replayed at 64): capture small steps only
+            # ... and never by default next to a DeviceLoader's staging thread (fit_generator): its pinned allocations and
+            # event waits race with a capture in the consumer thread (r3: one crash in hipGraphLaunch in 5 full test runs)
             store = self.plan._in_store
-            if not self._fold_ok() or n_local is None or n_local * int(store[-1]) * int(store[-2]) > self.graph_below:
+            if not self._fold_ok() or n_local is None or self._loader_threads or \
+                    n_local * int(store[-1]) * int(store[-2]) > self.graph_below:
                 return False
         if any(True for _ in self._regularized()):
             return False
@@ -999,7 +1003,11 @@ class Trainer(object):
                 vgen = validation_data
                 vsteps = int(validation_steps) if validation_steps is not None else len(vgen)
                 val = lambda: self.evaluate_generator(vgen, vsteps)  # noqa: E731
-        return self._run_epochs(epochs, initial_epoch, batches, None, val, callbacks, verbose, end)
+        self._loader_threads += 1
+        try:
+            return self._run_epochs(epochs, initial_epoch, batches, None, val, callbacks, verbose, end)
+        finally:
+            self._loader_threads -= 1
 
     def evaluate_generator(self, generator, steps=None):
         steps = int(steps) if steps is not None else len(generator)

@@ -40,6 +40,12 @@ extern "C" {
 
 #define DLWP_F32  0
 #define DLWP_BF16 1
+#define DLWP_BF16_O8 2   /* bfloat16 in channel OCTETS: (N, C/8, H, W, 8) -- a pixel's 8 consecutive channels are 16 contiguous
+                          * bytes, the unit the bf16 matrix-core kernels stage and multiply.  Only inside DLWP_DTYPE_IO(in, out)
+                          * of dlwp_conv2d_fwd / _prepared / dlwp_convlstm_conv_fwd, for layers dlwp_conv2d_supports_dtype
+                          * accepts; channel counts and channel windows must be whole octets.  With an O8 OUTPUT,
+                          * dlwp_convlstm_conv_fwd reads z_add in octets and keeps the float32 cell state (c_prev, c_out) as
+                          * (N, F/8, H, W, 8) float32.  NCHW stays the layout at the model boundary.                        */
 #define DLWP_DTYPE_IO(in, out) (0x10000 | (in) | ((out) << 8))   /* input / output storage of one launch */
 #define DLWP_DTYPE_IN(d)  (((d) & 0x10000) ? ((d) & 0xff) : (d))
 #define DLWP_DTYPE_OUT(d) (((d) & 0x10000) ? (((d) >> 8) & 0xff) : (d))
@@ -160,7 +166,9 @@ int dlwp_conv2d_config_flags(int i);        /* bit 0: Winograd instance whose 16
                                               * (dlwp_conv2d.lstm_f; takes only such layers);
                                               * bit 2: position-split instance evaluated in the 32-channel kernel's order of
                                               * operations (same bits as that kernel): for layers with whole 32-channel tiles on
-                                              * small grids, where the plain split instances (bit 0 alone) are not offered */
+                                              * small grids, where the plain split instances (bit 0 alone) are not offered;
+                                              * bit 3 / bit 4: bf16 instance whose input / output is stored in channel octets
+                                              * (DLWP_BF16_O8) -- it takes launches with exactly that storage            */
 /* Host logic (no device work; handle nullable = default options): 1 when dlwp_conv2d_fwd(xs, cd, dtype) multiplies with
  * bf16-rounded weights (the bf16-MFMA family), else 0: what a caller comparing against an fp32-weight computation needs to
  * know. */
@@ -172,6 +180,9 @@ int dlwp_conv2d_prefers_unfused_pool(dlwp_handle_t, int cin, int cout, int kh, i
 /* Planner hint (host logic, handle nullable): 1 when a compiled kernel can apply a following MaxPooling2D(2) in the epilogue
  * of this convolution (cd->out_pool = 1): the pre-pooling tensor is then never written. */
 int dlwp_conv2d_supports_out_pool(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
+/* 1 when a compiled matrix-core instance runs this layer with the storage codes of `dtype` (a DLWP_DTYPE_IO value; the question
+ * matters for DLWP_BF16_O8, which only the bf16 matrix-core family reads and writes).  Host logic; h may be NULL.            */
+int dlwp_conv2d_supports_dtype(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
 /* ... and 1 when a compiled kernel can store the 2x2 phase channels of this convolution interleaved (cd->out_d2s = 1). */
 int dlwp_conv2d_supports_out_d2s(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);
 int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);

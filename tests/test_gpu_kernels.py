@@ -449,7 +449,7 @@ def test_convlstm_cell_update_in_the_convolution_epilogue(ops, f, hw, first):
     tried = 0
     try:
         for i, c in enumerate(ops.conv_configs()):
-            if not (c[10] & 2 and c[1] == dil and (c[8] == 3) == first):
+            if not (c[10] & 2 and c[1] == dil and (c[8] == 3) == first) or c[10] & 24:     # (& 24: octet-layout instances)
                 continue
             ops.force_conv_config(i)
             h3, c3 = torch.zeros_like(h_out), torch.empty_like(c_out)
@@ -845,6 +845,8 @@ def test_conv2d_bf16_mfma_every_compiled_tile_configuration(ops):
     try:
         for i, (ks, dil, th, tw, waves, fa, bnf, ck, pool, lds, flags) in enumerate(cfgs):
             if pool < 2 or flags & 2:                         # (bit 1: cell-update instances, test_convlstm_cell_update_...)
+                continue
+            if flags & 24:                                    # (bits 3 / 4: octet-layout instances, test_gpu_bf16_octets.py)
                 continue
             seen += 1
             in32 = pool == 3                                  # float32-stored input, rounded by the loader

@@ -68,12 +68,13 @@ def main():
             kern, bias = ex.conv_weights(op)
             za, cp, co = op.aux
             fn = lambda: ops.convlstm_conv(src, kern, bias, desc, dst, res(co), z_add=res(za) if za is not None else None,  # noqa: E731
-                                           c_prev=res(cp) if cp is not None else None, x_channels=op.xs[0], compute_bf16=c16)
+                                           c_prev=res(cp) if cp is not None else None, x_channels=op.xs[0], compute_bf16=c16,
+                                           in_o8=op.src in ex._oct, out_o8=op.dst in ex._oct)
         elif op.kind == 'conv':
             c16 = op.dst in ex._bf16 and op.src not in ex._bf16      # as Executor.run: float32 state rounded by the loader
             kern, bias = ex.conv_weights(op)
             fn = lambda: ops.conv2d(src, kern, bias, desc, out=dst, x_channels=op.xs[0],  # noqa: E731
-                                    compute_bf16=c16)
+                                    compute_bf16=c16, in_o8=op.src in ex._oct, out_o8=op.dst in ex._oct)
         elif op.kind == 'lstm':
             zh, cp, co = op.aux
             fn = lambda: ops.convlstm_gates(src, res(zh) if zh is not None else None, res(cp) if cp is not None else None,  # noqa: E731
@@ -114,6 +115,8 @@ def main():
                 row['cell_update'] = 'in the epilogue (dlwp_convlstm_conv_fwd)'
                 co_ = 4 * op.lstm_f
                 fl = 2.0 * ho * wo * co_ * op.xs[0] * kh * kw * a.members
+            row['storage'] = '%s -> %s' % ('octets' if op.src in ex._oct else str(src.dtype).replace('torch.', ''),
+                                           'octets' if op.dst in ex._oct else str(dst.dtype).replace('torch.', ''))
             row.update(layer=op.layer.name, cin=op.xs[0], cout=co_, k=kh, algorithmic_tflops=round(fl / ms / 1e9, 1),
                        executed_tflops=round(ex_fl / ms / 1e9, 1), family='bf16 mfma' if on16 else 'fp32 mfma',
                        frac_of_matrix_peak=round(ex_fl / ms / 1e9 / peak, 3), matrix_peak_tflops=peak,
