@@ -12,7 +12,8 @@ import re
 import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdlwp_hip.so')
+# (DLWP_LIB_PATH: profiling builds of the same library, tools/knockout_bf16.sh -- never a different implementation)
+LIB_PATH = os.environ.get('DLWP_LIB_PATH') or os.path.join(_HERE, 'libdlwp_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dlwp_hip.h')
 
 OK, EINVAL, EUNSUPPORTED, EHIP, ERCCL = 0, -1, -2, -3, -4

@@ -10,6 +10,7 @@ const ConvKernelEntry* dlwp_conv_table_k3d1(int* n);
 const ConvKernelEntry* dlwp_conv_table_k3d2(int* n);
 const ConvKernelEntry* dlwp_conv_table_k5d1(int* n);
 const ConvKernelEntry* dlwp_conv_table_bf16(int* n);
+const ConvKernelEntry* dlwp_conv_table_bf16_o8(int* n);
 
 namespace {
 
@@ -25,6 +26,8 @@ struct Registry {
     t = dlwp_conv_table_k5d1(&n);
     entries.insert(entries.end(), t, t + n);
     t = dlwp_conv_table_bf16(&n);
+    entries.insert(entries.end(), t, t + n);
+    t = dlwp_conv_table_bf16_o8(&n);
     entries.insert(entries.end(), t, t + n);
     prepared.assign(entries.size(), 0);
   }
@@ -311,6 +314,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     if (cd->out_d2s && !(is_wino(e) && e.split)) return -1;           // interleaved phase stores: the 16-channel instances
     if ((cd->lstm_f != 0) != (is_bf16(e) && e.gates)) return -1;        // gates epilogue <-> the GATES instances
     if ((e.in8 != 0) != (a.in_oct != 0) || (e.sw != 0) != (a.out_oct != 0)) return -1;   // octet layout <-> its instances
+    if (is_bf16(e) && e.ck == 8 && a.Cin > 8) return -1;               // tap-packed instances: one octet of input channels
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
                ? forced
                : -1;
@@ -324,6 +328,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
       want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h && (!cd->out_pool || e.out_pool) &&
                                 (cd->lstm_f != 0) == (e.gates != 0) &&
                                 (e.in32 != 0) == !a.in_bf16 && (e.in8 != 0) == (a.in_oct != 0) && (e.sw != 0) == (a.out_oct != 0) &&
+                                !(e.ck == 8 && a.Cin > 8) &&
                                 bf16_prep_floats(e, a.Cin, a.Cout) <= WINO_SCRATCH_FLOATS);
   if ((cd->lstm_f || a.in_oct || a.out_oct) && !want_bf16) return -1;   // only the bf16 family has gates / octet instances
   bool want_wino = !want_bf16 && winograd_wanted(a, cd, o);
@@ -357,6 +362,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
          2ll * dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * (a.Cout / 32) * a.N >= (long long)cu_count)) continue;
     if (is_bf16(e) && ((e.in32 != 0) == (a.in_bf16 != 0) || bf16_prep_floats(e, a.Cin, a.Cout) > WINO_SCRATCH_FLOATS)) continue;
     if (is_bf16(e) && ((e.in8 != 0) != (a.in_oct != 0) || (e.sw != 0) != (a.out_oct != 0))) continue;
+    if (is_bf16(e) && e.ck == 8 && a.Cin > 8) continue;                   // tap-packed instances: one octet of input channels
     if (cd->out_pool && !e.out_pool) continue;                             // pooled epilogue: instances that have one
     if (cd->out_d2s && !(is_wino(e) && e.split)) continue;                 // interleaved phase stores: the 16-channel instances
     if ((cd->lstm_f != 0) != (is_bf16(e) && e.gates)) continue;            // gates epilogue <-> the GATES instances
@@ -364,7 +370,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     // cell-update instances: the epilogue's ~45 vector operations per hidden value want waves, not tile size -- the 4 x 32
     // tiles (two fragments per wave) with 16-channel chunks run 3-4 waves per SIMD (114-132 registers) against two for the
     // 8 x 32 / 32-channel ones (measured on config 4, tools/tune_lstm_conv.py: 0.100 vs 0.128 ms on the recurrent convolution)
-    if (e.gates) c *= (e.th == 4 ? 0.7 : 1.0) * (e.ck == 16 ? 0.7 : 1.0);
+    if (e.gates) c *= (e.th == 4 ? 0.7 : 1.0) * (e.ck <= 16 ? 0.7 : 1.0);   // (ck 8: the tap-packed instances, 0.057 vs 0.068 ms)
     // Winograd, grids of a few members: the two-wave instances (8 x 16, 4 x 32 tiles) lose to the four-wave ones although
     // they make more workgroups -- every workgroup fetches the whole 16 x cin x cout-tile block of transformed filters, with
     // half the threads to do it and twice the workgroups re-reading it from L2.  Measured (tools/tune_plan.py, r2z): 64 ->
@@ -552,7 +558,7 @@ double executed_matrix_flops(const ConvKernelEntry& e, const ConvArgs& a, long l
   } else if (is_bf16(e)) {
     rows = (double)e.th * e.tw;
     cols = 16.0 * e.bnf;
-    k = chunks * e.ck * e.ks * e.ks;
+    k = e.ck == 8 ? 8.0 * ((e.ks * e.ks + 3) & ~3) : chunks * e.ck * e.ks * e.ks;   // (ck 8: four taps per K = 32 step)
   } else if (e.pack > 0) {             // packed-N: cout x S column shifts fill the 16 columns, effective kernel ks x kwe
     rows = (double)e.waves * e.fa * 16.0;
     cols = 16.0;

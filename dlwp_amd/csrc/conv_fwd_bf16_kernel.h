@@ -19,6 +19,11 @@
 #pragma once
 #include "conv_fwd_kernel.h"
 #include <type_traits>
+// profiling builds only (tools/knockout_bf16.sh): -DDLWP_KNOCK=n removes one phase of the octet cell-update instances --
+// 1: the gate arithmetic, 2: the c / h stores, 3: the z_add / c_prev loads, 4: the matrix loop, 5: the input staging
+#ifndef DLWP_KNOCK
+#define DLWP_KNOCK 0
+#endif
 
 // IN32: the input is stored as float32 and rounded to bf16 while it is staged (the caller allowed it: DLWP_COMPUTE_BF16)
 // GATES: the instance of a ConvLSTM2D step -- 64-channel blocks = 4 gates x 16 hidden channels, cell update in the epilogue
@@ -54,8 +59,14 @@ struct BfCfg {
   static constexpr int N32 = CK / 32, N16 = (CK % 32) / 16;   // K=32 and K=16 MFMA steps per tap
   static constexpr int BN = 16 * BNF;
   static constexpr int TAPS = KS * KS;
+  // TAPK (CK == 8, layers with at most 8 input channels: the ConvLSTM2D input convolutions of config 4, 6 channels): the K = 32
+  // matrix instruction multiplies FOUR TAPS x one channel octet at a time -- lane group g supplies tap 4 s + g -- instead of one
+  // tap x 16 channels (10 of them zero) on the half-rate K = 16 instruction: 3 instead of 9 matrix steps per tile, which the
+  // knock-out profile (profiles/r3_cfg4_gates_knockout.txt) showed to be the largest part of those launches (30 of 73 us).
+  static constexpr bool TAPK = CK == 8;
+  static constexpr int TAPSLOTS = TAPK ? ((TAPS + 3) & ~3) : TAPS;
   static constexpr int X_U4 = NO * PSO;
-  static constexpr int W_U4 = TAPS * NO * BN;
+  static constexpr int W_U4 = TAPSLOTS * NO * BN;
   static constexpr int NWV = (W_U4 + NT - 1) / NT;            // 16-byte weight loads per thread and chunk
   static constexpr int WCH = NWV * NT;                         // padded chunk, 16-byte units
   static constexpr int LDS_BYTES = (X_U4 + WCH) * 16;
@@ -64,7 +75,7 @@ struct BfCfg {
   // a wave's FA fragments are exactly two tile rows -> the 2x2 pooling window of an output lives in ONE lane
   static constexpr bool POOL_EPI = (TW == 8 * FA) && (TH == 2 * WAVES) && (FA % 2 == 0);
   static_assert(MPAD >= P, "tile pixels must fit the wave/fragment decomposition");
-  static_assert(CK % 16 == 0, "channel chunk = whole 16-channel MFMA slices");
+  static_assert(CK % 16 == 0 || CK == 8, "channel chunk = whole 16-channel MFMA slices (or one octet: TAPK)");
   static_assert(LDS_BYTES <= 160 * 1024, "bad LDS geometry");
 };
 
@@ -139,6 +150,17 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
     if (C::N16) abase_h[i] = 2 * (r * C::LC + c + e_al + (4 * C::N32 + (lane >> 5)) * C::PSO) + ((lane >> 4) & 1);
   }
   const int bbase = (lane >> 4) * C::BN + (lane & 15);
+  // TAPK: lane group g multiplies tap 4 s + g in step s (slots past the last tap have zero weights: any address will do)
+  int toffg[C::TAPK ? C::TAPSLOTS / 4 : 1];
+  if constexpr (C::TAPK) {
+#pragma unroll
+    for (int st = 0; st < C::TAPSLOTS / 4; ++st) {
+      const int tap = 4 * st + (lane >> 4);
+      const int t = tap < C::TAPS ? tap : 0;
+      const int u = t / C::KS, vv = t - u * C::KS;
+      toffg[st] = u * C::DIL * C::LC + vv * C::DIL - (lane >> 4) * C::PSO;     // (abase carries + g PSO: taken back here)
+    }
+  }
   const int bbase_h = 2 * ((4 * C::N32 + (lane >> 5)) * C::BN + (lane & 15)) + ((lane >> 4) & 1);
 
   f32x4 acc[C::FA][C::BNF];
@@ -264,12 +286,40 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
     for (int k = 0; k < C::NWV; ++k) wo[tid + k * C::NT] = wr[k];
   };
 
-  prefetch(0);
+  constexpr bool KNOCK_STAGE = DLWP_KNOCK == 5 && C::GATES && C::SW, KNOCK_LOOP = DLWP_KNOCK == 4 && C::GATES && C::SW;
+  if (!KNOCK_STAGE) prefetch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += C::CK) {
     __syncthreads();
-    commit();
+    if (!KNOCK_STAGE) commit();
     __syncthreads();
-    if (c0 + C::CK < a.Cin) prefetch(c0 + C::CK);
+    if (!KNOCK_STAGE && c0 + C::CK < a.Cin) prefetch(c0 + C::CK);
+    if (KNOCK_LOOP) continue;
+    if constexpr (C::TAPK) {
+      constexpr int NST = C::TAPSLOTS / 4;
+      u32x4 af[2][C::FA], bf[2][C::BNF];
+      auto load_frags = [&](int step, int buf) {
+#pragma unroll
+        for (int i = 0; i < C::FA; ++i) af[buf][i] = xo[abase[i] + toffg[step]];
+#pragma unroll
+        for (int g = 0; g < C::BNF; ++g) bf[buf][g] = wo[bbase + 4 * step * C::BN + g * 16];
+      };
+      load_frags(0, 0);
+#pragma unroll
+      for (int step = 0; step < NST; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < NST) load_frags(step + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < C::FA; ++i)
+#pragma unroll
+          for (int g = 0; g < C::BNF; ++g) {
+            const u32x4 ma = C::SW ? bf[cur][g] : af[cur][i], mb = C::SW ? af[cur][i] : bf[cur][g];
+            acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ma), __builtin_bit_cast(bf16x8, mb),
+                                                                acc[i][g], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     constexpr int SPT = C::N32 + C::N16;   // steps per tap: N32 x (K=32), then N16 x (K=16)
     constexpr int NSTEPS = SPT * C::TAPS;
     u32x4 af[2][C::FA], bf[2][C::BNF];
@@ -317,6 +367,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }   // (!TAPK)
   }
 
   // ---- SW: octet-layout output.  Accumulator rows = output channels: the lane holds channels 4 g4 .. 4 g4 + 3 of fragment
@@ -351,10 +402,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const unsigned ch = (unsigned)(g * F + hb);
-          zpre[i][g] = __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, ok ? ((ch >> 3) * hw + pixv[i]) * 16u + (ch & 4u) * 2u : DROP, 0, 0);
+          zpre[i][g] = __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, (ok && DLWP_KNOCK != 3) ? ((ch >> 3) * hw + pixv[i]) * 16u + (ch & 4u) * 2u : DROP, 0, 0);
         }
         cpre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                cp_rsrc, ok ? (((unsigned)hb >> 3) * hw + pixv[i]) * 32u + ((unsigned)hb & 4u) * 4u : DROP, 0, 0));
+                                                cp_rsrc, (ok && DLWP_KNOCK != 3) ? (((unsigned)hb >> 3) * hw + pixv[i]) * 32u + ((unsigned)hb & 4u) * 4u : DROP, 0, 0));
       }
 #pragma unroll
       for (int i = 0; i < C::FA; ++i) {
@@ -372,15 +423,21 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
         f32x4 cn, hn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+#if DLWP_KNOCK == 1
+          cn[r] = z[0][r] + z[2][r] + z[1][r] * cp[r];
+          hn[r] = z[3][r] + cn[r];
+#else
           float cv = dlwp_rec_apply(z[0][r], a.rec_act) * act_apply(z[2][r], a.act);
           if (a.c_prev) cv = fmaf(dlwp_rec_apply(z[1][r], a.rec_act), cp[r], cv);
           cn[r] = cv;
           hn[r] = dlwp_rec_apply(z[3][r], a.rec_act) * act_apply(cv, a.act);
+#endif
         }
+        const bool st = ok && (DLWP_KNOCK != 2 || cn[0] == 12345.678f);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cn), co_rsrc,
-                                               ok ? (((unsigned)hb >> 3) * hw + pixv[i]) * 32u + ((unsigned)hb & 4u) * 4u : DROP, 0, 0);
+                                               st ? (((unsigned)hb >> 3) * hw + pixv[i]) * 32u + ((unsigned)hb & 4u) * 4u : DROP, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3])}, h_rsrc,
-                                              ok ? (((unsigned)hb >> 3) * hw + pixv[i]) * 16u + ((unsigned)hb & 4u) * 2u : DROP, 0, 0);
+                                              st ? (((unsigned)hb >> 3) * hw + pixv[i]) * 16u + ((unsigned)hb & 4u) * 2u : DROP, 0, 0);
       }
       return;
     } else {

@@ -180,7 +180,8 @@ def test_every_compiled_octet_instance_against_the_nchw_result():
             key = (ks, dil, in32)
             if key not in problems:
                 ops.force_conv_config(-1)                                     # (the reference: the heuristic's NCHW instance)
-                n, cin, h, w, cout = 2, (8 if in32 else 56), 19, 50, 40       # ragged tiles, ragged chunks for CK = 16 / 32
+                n, cin, h, w, cout = 2, (8 if in32 else 56), 19, 50, 40       # ragged tiles, ragged chunks for CK = 16 / 32;
+                #                                                               8 float32 channels: the tap-packed instances too
                 x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32)).cuda()
                 x = x if in32 else x.bfloat16()
                 wt = torch.from_numpy(np_ref.glorot_uniform((ks, ks, cin, cout), rng)).cuda()

@@ -850,9 +850,11 @@ def test_conv2d_bf16_mfma_every_compiled_tile_configuration(ops):
                 continue
             seen += 1
             in32 = pool == 3                                  # float32-stored input, rounded by the loader
-            key = (ks, dil, in32)
+            key = (ks, dil, in32, ck == 8)
             if key not in problems:
                 n, cin, h, w, cout = 2, 52, 19, 50, 36        # ragged tiles, ragged chunks for CK = 16 / 32 / 48
+                if ck == 8:                                   # tap-packed instances: at most one octet of input channels
+                    cin = 6
                 x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
                 xr = np_ref.round_bf16(x).astype(np.float32)
                 wt = np_ref.glorot_uniform((ks, ks, cin, cout), rng)
