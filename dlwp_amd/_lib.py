@@ -60,7 +60,8 @@ class Conv2d(ctypes.Structure):
 
 class Op(ctypes.Structure):
     _fields_ = [('kind', ctypes.c_int), ('src', ctypes.c_int), ('dst', ctypes.c_int), ('w', ctypes.c_int),
-                ('b', ctypes.c_int), ('xs', Shape4), ('conv', Conv2d), ('pad', Pad2d), ('aux', ctypes.c_int * 4)]
+                ('b', ctypes.c_int), ('xs', Shape4), ('conv', Conv2d), ('pad', Pad2d), ('aux', ctypes.c_int * 4),
+                ('src2', ctypes.c_int), ('w2', ctypes.c_int), ('xs2_c', ctypes.c_int), ('conv2', Conv2d)]
 
 
 class LaunchInfo(ctypes.Structure):
@@ -180,6 +181,10 @@ _sig('dlwp_upsample2_bwd', [_vp, _vp, _vp, Shape4, _i, _vp])
 _sig('dlwp_convlstm_gates', [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_convlstm_conv_fwd', [_vp] * 9 + [Shape4, _P(Conv2d), _i, _vp])
 _sig('dlwp_convlstm_conv_supported', [_vp, Shape4, _P(Conv2d), _i])
+_sig('dlwp_convlstm_step_supported', [_vp, Shape4, _P(Conv2d), Shape4, _P(Conv2d), _i])
+_sig('dlwp_convlstm_step_prepared_bytes', [_vp, Shape4, _P(Conv2d), Shape4, _P(Conv2d), _i], _sz)
+_sig('dlwp_convlstm_step_prepare', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), Shape4, _P(Conv2d), _i, _vp])
+_sig('dlwp_convlstm_step_fwd', [_vp] * 10 + [Shape4, _P(Conv2d), Shape4, _P(Conv2d), _i, _vp])
 _sig('dlwp_convlstm_gates_bwd', [_vp] * 9 + [_i] * 8 + [_vp])
 _sig('dlwp_copy_channels', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])

@@ -144,3 +144,11 @@ int dlwp_conv2d_prep(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 xs,
                      hipStream_t s);
 int dlwp_conv2d_prep_flipped(dlwp_handle_t h, const void* w, float* dst, dlwp_shape4 zs, const dlwp_conv2d* g,
                              hipStream_t s);
+// one ConvLSTM2D step per launch (conv_fwd.hip): arranged weights of both kernels, and the launch
+size_t dlwp_convlstm_step_prep_floats(dlwp_handle_t h, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h, dlwp_shape4 xs_x,
+                                      const dlwp_conv2d* cd_x, int dtype);
+int dlwp_convlstm_step_prep(dlwp_handle_t h, const void* w_h, const void* w_x, float* dst, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h,
+                            dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, hipStream_t s);
+int dlwp_launch_convlstm_step(dlwp_handle_t h, const void* h_in, const void* x_in, const void* w_h, const void* w_x, const void* bias,
+                              const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h,
+                              dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, hipStream_t s, const float* u_pre);

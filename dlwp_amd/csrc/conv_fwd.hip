@@ -118,6 +118,38 @@ __global__ __launch_bounds__(256) void bf16_arrange_weights(const float* __restr
   }
 }
 
+// Arranged weights of a dual-source cell-update instance (conv_fwd_bf16_kernel.h: DUAL): one chunk of 4 octets per tap --
+// octets 0..2 = hidden-state channels 8 oct .. + 7 of the RECURRENT kernel wh (zero past Ch), octet 3 = channels 0..7 of the
+// INPUT kernel wx (zero past Cx); columns as the gates instances: tile ct = hidden channels 16 ct .. + 15, gate col / 16.
+__global__ __launch_bounds__(256) void bf16_arrange_weights_dual(const float* __restrict__ wh, const float* __restrict__ wx,
+                                                                 unsigned* __restrict__ out, int Ch, int Cx, int Cout, int taps,
+                                                                 int bn, int wch, int n_ct, int lstm_f) {
+  const long long total = (long long)n_ct * wch;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int r = (int)(e % wch), ct = (int)(e / wch);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < taps * 4 * bn) {
+      const int col = r % bn, row = r / bn;
+      const int oct = row % 4, tap = row / 4;
+      const int hc = ct * 16 + (col & 15);
+      const int co = (col >> 4) * lstm_f + hc;
+      if (hc < lstm_f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (oct < 3) {
+            const int ci = oct * 8 + j;
+            if (ci < Ch) v[j] = wh[((long long)tap * Ch + ci) * Cout + co];
+          } else if (j < Cx) {
+            v[j] = wx[((long long)tap * Cx + j) * Cout + co];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[4 * e + j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+  }
+}
+
 // U = G g G^T for all (ci, co): u[((ci*4 + r)*Cout + co)*4 + c] = U[r][c]; HWIO weights in.
 __global__ __launch_bounds__(256) void wino_filter_transform_f32(const float* __restrict__ w, float* __restrict__ u,
                                                                   int Cin, int Cout) {
@@ -313,6 +345,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
     if (cd->out_pool == 2 && !(is_wino(e) && e.dil == 1)) return -1;  // the 2x2 sum epilogue: dilation-1 Winograd instances
     if (cd->out_d2s && !(is_wino(e) && e.split)) return -1;           // interleaved phase stores: the 16-channel instances
     if ((cd->lstm_f != 0) != (is_bf16(e) && e.gates)) return -1;        // gates epilogue <-> the GATES instances
+    if (e.dual) return -1;                                             // whole-step instances: dlwp_convlstm_step_fwd only
     if ((e.in8 != 0) != (a.in_oct != 0) || (e.sw != 0) != (a.out_oct != 0)) return -1;   // octet layout <-> its instances
     if (is_bf16(e) && e.ck == 8 && a.Cin > 8) return -1;               // tap-packed instances: one octet of input channels
     return (e.ks == cd->kh && e.ks == cd->kw && e.dil == cd->dil_h && e.dil == cd->dil_w && (e.pool != 0) == pool && pack_ok)
@@ -326,7 +359,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
   if (!sum_pool && bf16_wanted(a, cd, o))
     for (const ConvKernelEntry& e : r.entries)
       want_bf16 = want_bf16 || (is_bf16(e) && e.ks == cd->kh && e.dil == cd->dil_h && (!cd->out_pool || e.out_pool) &&
-                                (cd->lstm_f != 0) == (e.gates != 0) &&
+                                (cd->lstm_f != 0) == (e.gates != 0) && !e.dual &&
                                 (e.in32 != 0) == !a.in_bf16 && (e.in8 != 0) == (a.in_oct != 0) && (e.sw != 0) == (a.out_oct != 0) &&
                                 !(e.ck == 8 && a.Cin > 8) &&
                                 bf16_prep_floats(e, a.Cin, a.Cout) <= WINO_SCRATCH_FLOATS);
@@ -344,6 +377,7 @@ int choose_config(const ConvArgs& a, const dlwp_conv2d* cd, int cu_count, const 
   for (int i = 0; i < (int)r.entries.size(); ++i) {
     const ConvKernelEntry& e = r.entries[i];
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
+    if (e.dual) continue;                                                 // whole-step instances: dlwp_convlstm_step_fwd only
     if ((e.pool != 0) != (cd->src_mode == DLWP_SRC_MAXPOOL2)) continue;  // pooled loader <-> POOL instances only
     if (e.pack > 0 && cd->cout > 16 / e.pack) continue;                    // packed-N instances cover cout <= 16/S
     if (is_wino(e) != want_wino || is_bf16(e) != want_bf16) continue;      // kernel family fixed by the layer
@@ -795,6 +829,167 @@ int dlwp_convlstm_conv_fwd(dlwp_handle_t h, const void* x, const void* w, const 
   DLWP_CHECK_ARG(h && cd && cd->lstm_f > 0, "dlwp_convlstm_conv_fwd: null handle / descriptor, or lstm_f not set");
   const dlwp_lstm_io io{z_add, c_prev, c_out};
   return dlwp_launch_conv2d(h, x, w, bias, h_out, xs, cd, dtype, (hipStream_t)stream, (const float*)prepared, &io);
+}
+
+}  // extern "C"
+
+// ---- one ConvLSTM2D step t >= 1 in ONE launch (conv_fwd_bf16_kernel.h: DUAL) ------------------------------------------------
+// cd_h: the recurrent convolution ('same', zero halo 1, dilation 1, 3x3; its channel windows on the h sequence, lstm_f = F),
+// xs_h = (n, F, H, W); cd_x: the input convolution (3x3, dilation 2, halo 2 of any mode, its channel window on the float32
+// state), xs_x = (n, Cx <= 8, H, W).  Storage: h (in and out) in octets, float32 state, float32 cell state in octets.
+namespace {
+struct StepPlan {
+  int entry = -1;
+  ConvArgs a;
+  long long grid = 0;
+};
+
+int plan_step(dlwp_handle_t h, const dlwp_options& o, int cu_count, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h, dlwp_shape4 xs_x,
+              const dlwp_conv2d* cd_x, int dtype, StepPlan* p) {
+  (void)h;
+  if (!cd_h || !cd_x || !o.bf16_mfma) return DLWP_EUNSUPPORTED;
+  const int F = cd_h->lstm_f;
+  const dlwp_pad2d &ph = cd_h->halo, &px = cd_x->halo;
+  const bool geom = F > 0 && F % 8 == 0 && cd_h->cout == 4 * F && cd_x->cout == 4 * F && cd_h->kh == 3 && cd_h->kw == 3 &&
+                    cd_x->kh == 3 && cd_x->kw == 3 && cd_h->dil_h == 1 && cd_h->dil_w == 1 && cd_x->dil_h == 2 && cd_x->dil_w == 2 &&
+                    ph.top == 1 && ph.bottom == 1 && ph.left == 1 && ph.right == 1 && ph.mode_h == DLWP_PAD_ZERO &&
+                    ph.mode_w == DLWP_PAD_ZERO && px.top == 2 && px.bottom == 2 && px.left == 2 && px.right == 2 &&
+                    cd_h->src_mode == DLWP_SRC_DIRECT && cd_x->src_mode == DLWP_SRC_DIRECT && !cd_h->out_pool && !cd_h->out_d2s &&
+                    !cd_x->out_pool && !cd_x->out_d2s && !cd_x->lstm_f && cd_x->act == DLWP_ACT_LINEAR;
+  const int th = cd_h->in_c_total > 0 ? cd_h->in_c_total : xs_h.c, to = cd_h->out_c_total > 0 ? cd_h->out_c_total : F;
+  const bool shapes = xs_h.n > 0 && xs_h.n == xs_x.n && xs_h.h == xs_x.h && xs_h.w == xs_x.w && xs_h.c == F && F <= 24 &&
+                      xs_x.c >= 1 && xs_x.c <= 8 && (xs_h.w & 1) == 0 && cd_h->in_c_off % 8 == 0 && th % 8 == 0 &&
+                      cd_h->out_c_off % 8 == 0 && to % 8 == 0 &&
+                      (long long)xs_h.h * xs_h.w * th < (1ll << 28) && (long long)xs_h.h * xs_h.w * 4 * F < (1ll << 28);
+  if (!geom || !shapes || dtype != DLWP_DTYPE_IO(DLWP_BF16_O8, DLWP_BF16_O8)) return DLWP_EUNSUPPORTED;
+  dlwp_shape4 ys;
+  if (dlwp_conv2d_out_shape(xs_h, cd_h, &ys) != DLWP_OK || dlwp_conv2d_out_shape(xs_x, cd_x, &ys) != DLWP_OK) return DLWP_EINVAL;
+  Registry& r = registry();
+  int best = -1;
+  double best_cost = 0;
+  for (int i = 0; i < (int)r.entries.size(); ++i) {
+    const ConvKernelEntry& e = r.entries[i];
+    if (!e.dual) continue;
+    if (o.forced_cfg >= 0 && o.forced_cfg != i) continue;
+    // as the gates instances: the epilogue wants waves, not tile size (4 x 32 tiles, two fragments per wave)
+    const double c = (double)dlwp_ceil_div(ys.h, e.th) * e.th * dlwp_ceil_div(ys.w, e.tw) * e.tw * (e.th == 4 ? 0.85 : 1.0);
+    if (best < 0 || c < best_cost) {
+      best = i;
+      best_cost = c;
+    }
+  }
+  if (best < 0) return DLWP_EUNSUPPORTED;
+  const ConvKernelEntry& e = r.entries[best];
+  p->entry = best;
+  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs_h, cd_h, ys, dtype);
+  a.pad_top = a.pad_left = 2;            // both sources are staged on the tile of the larger halo
+  a.x2_cin = xs_x.c;
+  a.x2_c_off = cd_x->in_c_off;
+  a.x2_c_total = cd_x->in_c_total > 0 ? cd_x->in_c_total : xs_x.c;
+  a.x2_pad_top = px.top;
+  a.x2_pad_left = px.left;
+  a.x2_mode_h = px.mode_h;
+  a.x2_mode_w = px.mode_w;
+  a.tiles_h = dlwp_ceil_div(a.Ho, e.th);
+  a.tiles_w = dlwp_ceil_div(a.Wo, e.tw);
+  a.cout_tiles = dlwp_ceil_div(F, 16);
+  p->a = a;
+  p->grid = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
+  (void)cu_count;
+  return DLWP_OK;
+}
+
+int arrange_step(const ConvKernelEntry& e, const void* w_h, const void* w_x, float* dst, int ch, int cx, int F, hipStream_t s) {
+  const int n_ct = dlwp_ceil_div(F, 16), wch = e.prep_chunk_floats / 4;
+  const long long total = (long long)n_ct * wch;
+  bf16_arrange_weights_dual<<<dlwp_ceil_div(total, 256), 256, 0, s>>>((const float*)w_h, (const float*)w_x, (unsigned*)dst, ch, cx,
+                                                                      4 * F, 9, 16 * e.bnf, wch, n_ct, F);
+  DLWP_LAUNCH_CHECK("bf16_arrange_weights_dual");
+  return DLWP_OK;
+}
+}  // namespace
+
+size_t dlwp_convlstm_step_prep_floats(dlwp_handle_t h, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h, dlwp_shape4 xs_x,
+                                      const dlwp_conv2d* cd_x, int dtype) {
+  StepPlan p;
+  if (plan_step(h, h ? h->opt : dlwp_default_options(), h ? h->cu_count : 256, xs_h, cd_h, xs_x, cd_x, dtype, &p) != DLWP_OK) return 0;
+  return (size_t)dlwp_ceil_div(cd_h->lstm_f, 16) * registry().entries[p.entry].prep_chunk_floats;
+}
+
+int dlwp_convlstm_step_prep(dlwp_handle_t h, const void* w_h, const void* w_x, float* dst, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h,
+                            dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, hipStream_t s) {
+  StepPlan p;
+  const int rc = plan_step(h, h->opt, h->cu_count, xs_h, cd_h, xs_x, cd_x, dtype, &p);
+  if (rc != DLWP_OK) DLWP_FAIL(rc, "dlwp_convlstm_step_prepare: no dual-source instance covers this step");
+  return arrange_step(registry().entries[p.entry], w_h, w_x, dst, xs_h.c, xs_x.c, cd_h->lstm_f, s);
+}
+
+int dlwp_launch_convlstm_step(dlwp_handle_t h, const void* h_in, const void* x_in, const void* w_h, const void* w_x, const void* bias,
+                              const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h,
+                              dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, hipStream_t s, const float* u_pre) {
+  DLWP_CHECK_ARG(h && h_in && x_in && c_out && h_out && cd_h && cd_x && (u_pre || (w_h && w_x)),
+                 "dlwp_convlstm_step_fwd: null handle or pointer");
+  StepPlan p;
+  const int rc = plan_step(h, h->opt, h->cu_count, xs_h, cd_h, xs_x, cd_x, dtype, &p);
+  if (rc != DLWP_OK) DLWP_FAIL(rc, "dlwp_convlstm_step_fwd: no dual-source instance covers this step (dlwp_convlstm_step_supported)");
+  Registry& r = registry();
+  const ConvKernelEntry& e = r.entries[p.entry];
+  if (!r.prepared[p.entry]) {
+    std::lock_guard<std::mutex> lock(g_prepare_mutex);
+    if (!r.prepared[p.entry]) {
+      if (e.prepare() != 0) DLWP_FAIL(DLWP_EHIP, "dlwp_convlstm_step_fwd: hipFuncSetAttribute failed");
+      r.prepared[p.entry] = 1;
+    }
+  }
+  ConvArgs a = p.a;
+  a.x = (const float*)h_in;
+  a.x2 = x_in;
+  a.bias = (const float*)bias;
+  a.y = (float*)h_out;
+  a.c_prev = (const float*)c_prev;
+  a.c_out = (float*)c_out;
+  a.zadd = nullptr;
+  DLWP_CHECK_ARG(p.grid < (1ll << 31), "dlwp_convlstm_step_fwd: grid too large");
+  if (u_pre) {
+    a.w = u_pre;
+  } else {
+    const size_t fl = (size_t)dlwp_ceil_div(cd_h->lstm_f, 16) * e.prep_chunk_floats;
+    float* u = dlwp_wino_scratch(h, fl, s);
+    if (!u) DLWP_FAIL(DLWP_EHIP, "dlwp_convlstm_step_fwd: no scratch for the arranged weights");
+    const int rc2 = arrange_step(e, w_h, w_x, u, xs_h.c, xs_x.c, cd_h->lstm_f, s);
+    if (rc2 != DLWP_OK) return rc2;
+    a.w = u;
+  }
+  e.launch(a, (int)p.grid, s);
+  DLWP_LAUNCH_CHECK("conv2d_fwd_mfma_bf16 (dual-source cell update)");
+  return DLWP_OK;
+}
+
+extern "C" {
+
+int dlwp_convlstm_step_supported(dlwp_handle_t h, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h, dlwp_shape4 xs_x,
+                                 const dlwp_conv2d* cd_x, int dtype) {
+  if (xs_h.n <= 0) xs_h.n = xs_x.n = 1;
+  StepPlan p;
+  return plan_step(h, h ? h->opt : dlwp_default_options(), h ? h->cu_count : 256, xs_h, cd_h, xs_x, cd_x, dtype, &p) == DLWP_OK ? 1 : 0;
+}
+
+size_t dlwp_convlstm_step_prepared_bytes(dlwp_handle_t h, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h, dlwp_shape4 xs_x,
+                                         const dlwp_conv2d* cd_x, int dtype) {
+  return dlwp_convlstm_step_prep_floats(h, xs_h, cd_h, xs_x, cd_x, dtype) * sizeof(float);
+}
+
+int dlwp_convlstm_step_prepare(dlwp_handle_t h, const void* w_h, const void* w_x, void* prepared, dlwp_shape4 xs_h,
+                               const dlwp_conv2d* cd_h, dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, void* stream) {
+  DLWP_CHECK_ARG(h && w_h && w_x && prepared && cd_h && cd_x, "dlwp_convlstm_step_prepare: null handle or pointer");
+  return dlwp_convlstm_step_prep(h, w_h, w_x, (float*)prepared, xs_h, cd_h, xs_x, cd_x, dtype, (hipStream_t)stream);
+}
+
+int dlwp_convlstm_step_fwd(dlwp_handle_t h, const void* h_in, const void* x_in, const void* w_h, const void* w_x,
+                           const void* prepared, const void* bias, const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs_h,
+                           const dlwp_conv2d* cd_h, dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, void* stream) {
+  return dlwp_launch_convlstm_step(h, h_in, x_in, w_h, w_x, bias, c_prev, c_out, h_out, xs_h, cd_h, xs_x, cd_x, dtype,
+                                   (hipStream_t)stream, (const float*)prepared);
 }
 
 int dlwp_convlstm_conv_supported(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {

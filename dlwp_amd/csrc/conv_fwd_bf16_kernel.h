@@ -38,9 +38,18 @@
 //      group hold 16 consecutive pixels and two lane groups the two halves of an octet: a wave's store instruction covers
 //      whole 256-byte runs.  No weight permutation: the arranged weights are those of the plain instances.
 //      SW + GATES: z_add is read in octets, the float32 cell state is kept as (N, F/8, H, W, 8) float32 as well.
+// DUAL (r3): one ConvLSTM2D step >= 1 in ONE launch -- z = conv_h(h_{t-1}) + conv_x(x_t) + bias, cell update in the epilogue.
+//      The recurrent convolution of config 4 reads 24 hidden channels = 3 octets; the K = 32 matrix step has room for 4: the
+//      fourth lane group multiplies the INPUT convolution's taps on an octet of the float32 state (6 channels, rounded while it
+//      is staged), with its own tap offsets (dilation 2 where the hidden state has dilation 1) and its own weights in the same
+//      arranged block.  No extra matrix step, and the 4 F-channel pre-activations of the input convolution are neither written
+//      nor read back (config 4 at 8 members: a 0.034 ms launch and ~200 MB of traffic per forward).  The tile carries the halo of
+//      the larger dilation (DIL_ = the input convolution's); the hidden state's taps sit one pixel inside it.
 template <int KS_, int DIL_, int TH_, int TW_, int WAVES_, int FA_, int BNF_, int CK_, bool IN32_ = false, bool GATES_ = false,
-          bool IN8_ = false, bool SW_ = false>
+          bool IN8_ = false, bool SW_ = false, bool DUAL_ = false>
 struct BfCfg {
+  static constexpr bool DUAL = DUAL_;
+  static_assert(!DUAL_ || (GATES_ && SW_ && IN8_ && KS_ == 3 && DIL_ == 2 && CK_ == 32), "dual-source cell-update instance");
   static constexpr bool IN32 = IN32_;
   static constexpr bool GATES = GATES_;
   static constexpr bool IN8 = IN8_;
@@ -132,6 +141,24 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
                           : (const char*)a.x + ((long long)n * a.in_c_total + a.in_c_off) * plane * ESZ_IN;
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)xn, 0, (unsigned)(C::IN8 ? ((a.Cin + 7) >> 3) : a.Cin) * plane_bytes, 0x00020000);
+  // DUAL: the float32 state window the input convolution reads, same tile positions (the host set pad_top / pad_left of BOTH
+  // sources to the tile's halo), its own halo modes
+  unsigned goff2[C::DUAL ? C::NPP : 1];
+  __amdgpu_buffer_rsrc_t x2_rsrc = x_rsrc;
+  if constexpr (C::DUAL) {
+#pragma unroll
+    for (int q = 0; q < C::NPP; ++q) {
+      int s = tid + q * C::NT;
+      if (q == C::NPP - 1 && s >= C::NPAIR) s = 0;
+      const int lr = s / C::LCH, lc = 2 * (s - lr * C::LCH);
+      const int rs = dlwp_map_coord_tile(i0 + lr - a.x2_pad_top, a.H, a.x2_mode_h);
+      const int cs = dlwp_map_coord_tile(j0 + lc - a.x2_pad_left, a.W, a.x2_mode_w);
+      goff2[q] = (rs >= 0 && cs >= 0) ? (unsigned)(rs * a.Ws + cs) * 4u : 0x7ffffff0u;
+    }
+    x2_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)a.x2 + ((long long)n * a.x2_c_total + a.x2_c_off) * plane * 4), 0,
+        (unsigned)a.x2_cin * (unsigned)plane * 4u, 0x00020000);
+  }
   const int n_chunks = (a.Cin + C::CK - 1) / C::CK;
   // a.w = bf16_arrange_weights output for THIS instance: [cout tile][chunk][WCH]
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -150,6 +177,16 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
     if (C::N16) abase_h[i] = 2 * (r * C::LC + c + e_al + (4 * C::N32 + (lane >> 5)) * C::PSO) + ((lane >> 4) & 1);
   }
   const int bbase = (lane >> 4) * C::BN + (lane & 15);
+  // DUAL: lane groups 0..2 (hidden-state octets) read their taps at dilation 1, one pixel inside the tile; lane group 3 (the
+  // state octet) at the tile's own dilation
+  int toffd[C::DUAL ? C::TAPS : 1];
+  if constexpr (C::DUAL) {
+#pragma unroll
+    for (int tap = 0; tap < C::TAPS; ++tap) {
+      const int u = tap / C::KS, vv = tap - u * C::KS;
+      toffd[tap] = (lane >> 4) == 3 ? u * C::DIL * C::LC + vv * C::DIL : (u + C::DIL / 2) * C::LC + vv + C::DIL / 2;
+    }
+  }
   // TAPK: lane group g multiplies tap 4 s + g in step s (slots past the last tap have zero weights: any address will do)
   int toffg[C::TAPK ? C::TAPSLOTS / 4 : 1];
   if constexpr (C::TAPK) {
@@ -190,6 +227,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
   typedef typename std::conditional<C::IN32, u32x2, unsigned>::type xraw_t;
   xraw_t xr[C::IN8 ? 1 : C::CK][C::NPP];
   u32x4 xr8[C::IN8 ? C::NO : 1][C::NPP][2];   // IN8: the pair's two pixels, 8 channels each
+  u32x2 xr2[C::DUAL ? 8 : 1][C::NPP];          // DUAL: the state octet's column pairs, float32
   u32x4 wr[C::NWV];
   int staged_live = C::NO;   // octets of the staged chunk that hold real channels (the others are zero)
   auto prefetch = [&](int c0) {
@@ -197,7 +235,14 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
     // channel loop needs no clamp and no branch (a per-channel branch cost ~10 scalar instructions each: 40 % of this
     // kernel's instruction stream on the first version); whole OCTETS past Cin are skipped (one uniform branch each):
     // the 6-channel ConvLSTM2D input convolution fetches 8 planes, not 16
-    staged_live = min(C::NO, (a.Cin - c0 + 7) >> 3);
+    staged_live = min(C::DUAL ? C::NO - 1 : C::NO, (a.Cin - c0 + 7) >> 3);
+    if constexpr (C::DUAL) {   // plane NO - 1: 8 float32 channel planes of the state (past x2_cin: hardware zeros)
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+        for (int q = 0; q < C::NPP; ++q)
+          xr2[cc][q] = __builtin_amdgcn_raw_buffer_load_b64(x2_rsrc, goff2[q], (unsigned)cc * (unsigned)plane * 4u, 0);
+    }
 #pragma unroll
     for (int o = 0; o < C::NO; ++o) {
       if (o >= staged_live) continue;
@@ -246,6 +291,29 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
   auto commit = [&]() {
 #pragma unroll
     for (int o = 0; o < C::NO; ++o) {
+      if constexpr (C::DUAL) {
+        if (o == C::NO - 1) {   // the state octet: rounded to bfloat16 on the way, as the IN32 instances do
+#pragma unroll
+          for (int q = 0; q < C::NPP; ++q) {
+            unsigned xd[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+              typedef float f32x2_t __attribute__((ext_vector_type(2)));
+              const f32x2_t f = __builtin_bit_cast(f32x2_t, xr2[cc][q]);
+              xd[cc] = pack_bf16x2(f[0], f[1]);
+            }
+            u32x4 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              lo[j] = __builtin_amdgcn_perm(xd[2 * j + 1], xd[2 * j], 0x05040100u);
+              hi[j] = __builtin_amdgcn_perm(xd[2 * j + 1], xd[2 * j], 0x07060302u);
+            }
+            xo[o * C::PSO + lpos[q]] = lo;
+            xo[o * C::PSO + lpos[q] + 1] = hi;
+          }
+          continue;
+        }
+      }
       if (o >= staged_live) {   // no such channels: zeros
 #pragma unroll
         for (int q = 0; q < C::NPP; ++q) {
@@ -329,7 +397,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
       const int toff = u * C::DIL * C::LC + vv * C::DIL;
       if (sub < C::N32) {
 #pragma unroll
-        for (int i = 0; i < C::FA; ++i) af[buf][i] = xo[abase[i] + sub * 4 * C::PSO + toff];
+        for (int i = 0; i < C::FA; ++i) af[buf][i] = xo[abase[i] + sub * 4 * C::PSO + (C::DUAL ? toffd[C::DUAL ? tap : 0] : toff)];
 #pragma unroll
         for (int g = 0; g < C::BNF; ++g) bf[buf][g] = wo[bbase + (tap * C::NO + sub * 4) * C::BN + g * 16];
       } else {
@@ -695,6 +763,14 @@ static int bf16_prepare() {
         &bf16_launch_thunk<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, IN8, SW>>,                               \
         &bf16_prepare<BfCfg<KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, IN8, SW>>, IN32 ? 1 : 0, 0, GATES ? 1 : 0,    \
         IN8 ? 1 : 0, SW ? 1 : 0                                                                                             \
+  }
+// the dual-source cell-update instance (one ConvLSTM2D step per launch; takes only dlwp_convlstm_step_fwd launches)
+#define BF16_ENTRY_DUAL(TH, TW, WAVES, FA)                                                                                  \
+  {                                                                                                                         \
+    3, 2, TH, TW, WAVES, FA, 4, 32, BfCfg<3, 2, TH, TW, WAVES, FA, 4, 32, false, true, true, true, true>::LDS_BYTES, 0, -2, \
+        0, BfCfg<3, 2, TH, TW, WAVES, FA, 4, 32, false, true, true, true, true>::WCH * 4,                                   \
+        &bf16_launch_thunk<BfCfg<3, 2, TH, TW, WAVES, FA, 4, 32, false, true, true, true, true>>,                           \
+        &bf16_prepare<BfCfg<3, 2, TH, TW, WAVES, FA, 4, 32, false, true, true, true, true>>, 0, 0, 1, 1, 1, 1               \
   }
 #define BF16_ENTRY_T(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES) \
   BF16_ENTRY_X(KS, DIL, TH, TW, WAVES, FA, BNF, CK, IN32, GATES, false, false)

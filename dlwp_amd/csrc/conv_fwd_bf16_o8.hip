@@ -28,6 +28,9 @@ static const ConvKernelEntry k_table[] = {
     BF16_ENTRY_IN32(3, 2, 8, 32, 4, 4, 2, 8),
     BF16_ENTRY_GATES_IN32(3, 1, 4, 32, 4, 2, 8),
     BF16_ENTRY_IN32(3, 1, 8, 32, 4, 4, 2, 8),
+    // one ConvLSTM2D step per launch (conv_fwd_bf16_kernel.h: DUAL)
+    BF16_ENTRY_DUAL(4, 32, 4, 2),
+    BF16_ENTRY_DUAL(8, 32, 4, 4),
 };
 const ConvKernelEntry* dlwp_conv_table_bf16_o8(int* n) {
   *n = (int)(sizeof(k_table) / sizeof(k_table[0]));

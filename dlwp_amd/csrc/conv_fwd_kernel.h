@@ -48,6 +48,9 @@ struct ConvArgs {
   int lstm_f = 0, rec_act = 0;
   int in_oct = 0, out_oct = 0;   // DLWP_BF16_O8 storage of x / y: (N, C/8, H, W, 8) bf16; out_oct with lstm_f: z_add is stored in
                                  // octets too and the float32 cell state as (N, F/8, H, W, 8) float32
+  // dual-source cell-update instances (dlwp_convlstm_step_fwd): the float32 state window of the step's INPUT convolution
+  const void* x2 = nullptr;
+  int x2_cin = 0, x2_c_off = 0, x2_c_total = 0, x2_pad_top = 0, x2_pad_left = 0, x2_mode_h = 0, x2_mode_w = 0;
   const void* zadd = nullptr;
   const float* c_prev = nullptr;
   float* c_out = nullptr;
@@ -551,6 +554,7 @@ struct ConvKernelEntry {
                  // tile fragment: 2 x waves x 64 threads); the 9-position variants are the same for both
   int gates = 0; // bf16-MFMA instances: 1 = ConvLSTM2D cell update in the epilogue (dlwp_conv2d.lstm_f), and only that
   int in8 = 0, sw = 0;   // bf16-MFMA instances: the input / the output is stored in the octet layout DLWP_BF16_O8
+  int dual = 0;          // bf16-MFMA instances: a whole ConvLSTM2D step (recurrent + input convolution + cell update), and only that
 };
 
 template <class C>

@@ -18,8 +18,11 @@ struct dlwp_rollout {
 
 namespace {
 
+bool is_step(const dlwp_op& op) { return op.kind == DLWP_OP_CONV2D && op.conv.lstm_f > 0 && op.src2 != DLWP_BUF_NONE; }
+
 int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, const void* w, const void* b, int dtype,
-               hipStream_t s, void* const* aux = nullptr, const float* u_pre = nullptr) {
+               hipStream_t s, void* const* aux = nullptr, const float* u_pre = nullptr, const void* src2 = nullptr,
+               const void* w2 = nullptr) {
   switch (op.kind) {
     case DLWP_OP_LSTM_GATES:
       return dlwp_convlstm_gates(h, src, aux[0], aux[1], aux[2], dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w,
@@ -27,6 +30,11 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
                                  DLWP_DTYPE_IO((op.aux[3] & 512) ? DLWP_BF16 : DLWP_F32, (op.aux[3] & 256) ? DLWP_BF16 : DLWP_F32),
                                  (void*)s);
     case DLWP_OP_CONV2D:
+      if (is_step(op)) {          // a whole ConvLSTM2D step: recurrent + input convolution + cell update
+        const dlwp_shape4 xs2{op.xs.n, op.xs2_c, op.xs.h, op.xs.w};
+        return dlwp_launch_convlstm_step(h, src, src2, w, w2, b, aux[1], aux[2], dst, op.xs, &op.conv, xs2, &op.conv2, op.aux[0], s,
+                                         u_pre);
+      }
       if (op.conv.lstm_f > 0) {   // cell update in the epilogue: aux[1..3] = z_add | NONE, c_prev | NONE, c_out; dst = h buffer
         const dlwp_lstm_io io{aux[0], aux[1], aux[2]};
         return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre, &io);
@@ -68,7 +76,10 @@ static long long prepared_floats(dlwp_handle_t h, const dlwp_op* plan, int n_ops
     if (plan[i].kind != DLWP_OP_CONV2D) continue;
     dlwp_shape4 xs = plan[i].xs;
     xs.n = gn;
-    const long long need = (long long)dlwp_conv2d_prep_floats(h, xs, &plan[i].conv, plan[i].aux[0]);
+    const dlwp_shape4 xs2{gn, plan[i].xs2_c, xs.h, xs.w};
+    const long long need = is_step(plan[i])
+                               ? (long long)dlwp_convlstm_step_prep_floats(h, xs, &plan[i].conv, xs2, &plan[i].conv2, plan[i].aux[0])
+                               : (long long)dlwp_conv2d_prep_floats(h, xs, &plan[i].conv, plan[i].aux[0]);
     if (need > 0) {
       if (offsets) (*offsets)[i] = total;
       total += (need + 63) & ~63ll;   // 256-byte aligned
@@ -143,6 +154,9 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
       for (int k = 0; k < 3; ++k)
         DLWP_CHECK_ARG((k < 2 && op.aux[k] == DLWP_BUF_NONE) || (op.aux[k] >= 0 && op.aux[k] < n_buffers),
                        "rollout op %d: aux buffer %d out of range", i, op.aux[k]);
+    if (is_step(op))
+      DLWP_CHECK_ARG(op.src2 >= DLWP_BUF_OUT(n_outputs - 1) && op.src2 < n_buffers && op.w2 >= 0 && op.w2 < n_buffers,
+                     "rollout op %d: second source / kernel out of range", i);
     if (op.kind == DLWP_OP_CONV2D && op.conv.lstm_f > 0)
       for (int k = 1; k <= 3; ++k)
         DLWP_CHECK_ARG((k < 3 && op.aux[k] == DLWP_BUF_NONE) || (op.aux[k] >= 0 && op.aux[k] < n_buffers),
@@ -190,7 +204,12 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
     }
   if (wino_u)
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
-      if (u_off[i] >= 0) rc = dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, plan[i].aux[0], cap);
+      if (u_off[i] >= 0) {
+        const dlwp_shape4 xs2{plan[i].xs.n, plan[i].xs2_c, plan[i].xs.h, plan[i].xs.w};
+        rc = is_step(plan[i]) ? dlwp_convlstm_step_prep(h, buffers[plan[i].w], buffers[plan[i].w2], wino_u + u_off[i], plan[i].xs,
+                                                        &plan[i].conv, xs2, &plan[i].conv2, plan[i].aux[0], cap)
+                              : dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, plan[i].aux[0], cap);
+      }
   // one chain of `calls` forwards per member group; groups > 1: parallel branches forked after the weight preparation
   auto chain = [&](int g, hipStream_t s) {
     for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
@@ -206,7 +225,8 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
         if (op.kind == DLWP_OP_CONV2D && op.conv.lstm_f > 0)
           for (int k = 0; k < 3; ++k) aux[k] = op.aux[k + 1] == DLWP_BUF_NONE ? nullptr : resolve(op.aux[k + 1], t, g);
         rc = enqueue_op(h, op, resolve(op.src, t, g), resolve(op.dst, t, g), w, b, dtype, s, aux,
-                        (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr);
+                        (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr, is_step(op) ? resolve(op.src2, t, g) : nullptr,
+                        is_step(op) ? buffers[op.w2] : nullptr);
       }
     }
   };

@@ -82,6 +82,14 @@ class Executor(object):
             self._descs = descs
         return self._descs
 
+    def _descriptor2(self, op):
+        """descriptor of the INPUT convolution of a whole-step op (op.src2, plan.PlanOp)"""
+        from . import ops
+        s2 = op.src2
+        lay = s2['layer']
+        return ops.make_conv(4 * op.lstm_f, lay.kernel_size[0], lay.kernel_size[1], tuple(lay.dilation_rate),
+                             ops.make_pad(*s2['halo']), 0, s2['in_c_off'], s2['in_c_total'], 0, 4 * op.lstm_f)
+
     def _conv_dtype(self, op, octets=None):
         """dtype code of a convolution launch: storage of its input / output buffers; in bfloat16 mode a float32-stored
         input (the model state) feeding a bf16-stored output may be rounded to bf16 by the kernel (DLWP_COMPUTE_BF16).
@@ -132,7 +140,12 @@ class Executor(object):
                     if ok and op.lstm_f:       # z_add and h share the launch's output layout; the cell state follows it
                         za = op.aux[0]
                         ok = cells_private and op.lstm_f % 8 == 0 and (za is None or (za in cand) == (op.dst in cand))
-                    if ok:
+                    if ok and op.src2 is not None:     # a whole step per launch: h in octets on both sides, or not at all
+                        ok = op.src in cand and op.dst in cand and bool(_lib.lib.dlwp_convlstm_step_supported(
+                            h, _lib.Shape4(1, *[int(v) for v in op.xs]), ctypes.byref(d),
+                            _lib.Shape4(1, *[int(v) for v in op.src2['xs']]), ctypes.byref(self._descriptor2(op)),
+                            _lib.dtype_io(_lib.BF16_O8, _lib.BF16_O8)))
+                    elif ok:
                         ok = bool(_lib.lib.dlwp_conv2d_supports_dtype(h, _lib.Shape4(1, *[int(v) for v in op.xs]),
                                                                       ctypes.byref(d), int(self._conv_dtype(op, cand))))
                     if not ok:
@@ -158,6 +171,8 @@ class Executor(object):
         for op, d in zip(self.plan.ops, self._descriptors()):
             if op.kind == 'conv' and ops.uses_bf16_weights((n,) + tuple(op.xs), d, self._conv_dtype(op)):
                 out.append(op.layer)
+                if op.src2 is not None:          # a whole ConvLSTM2D step multiplies both kernels on the bf16 matrix cores
+                    out.append(op.src2['layer'])
         return out
 
     # -- eager forward ----------------------------------------------------------------------------------------------- #
@@ -182,7 +197,15 @@ class Executor(object):
             if op.kind == 'phasew' and skip_phasew:
                 continue
             src, dst = res(op.src), res(op.dst)
-            if op.kind == 'conv' and op.lstm_f:
+            if op.kind == 'conv' and op.src2 is not None:          # a whole ConvLSTM2D step (dlwp_convlstm_step_fwd)
+                if op.dst not in self._oct:
+                    raise RuntimeError('whole-step ConvLSTM2D launches need the h sequence in octets (Model.set_activation_dtype '
+                                       're-plans without them otherwise)')
+                kern, bias = self.conv_weights(op)
+                za, cp, co = op.aux
+                ops.convlstm_step(dst, res(op.src2['buf']), kern, op.src2['layer'].kernel, op.src2['layer'].bias, d,
+                                  self._descriptor2(op), res(cp), res(co), op.src2['xs'][0])
+            elif op.kind == 'conv' and op.lstm_f:
                 kern, bias = self.conv_weights(op)
                 za, cp, co = op.aux
                 ops.convlstm_conv(src, kern, bias, d, dst, res(co), z_add=res(za) if za is not None else None,
@@ -273,6 +296,7 @@ class Executor(object):
         for k, (op, d) in enumerate(zip(self.plan.ops, self._descriptors())):
             o = arr[k]
             o.kind, o.src, o.dst, o.w, o.b = kind[op.kind], op.src, op.dst, -1, -1
+            o.src2, o.w2 = _lib.BUF_NONE, -1
             o.xs = _lib.Shape4(n, *op.xs)
             if op.kind == 'conv':
                 o.w, o.b = pidx[op.wparam] if op.wparam is not None else widx[id(op.layer)]
@@ -283,6 +307,11 @@ class Executor(object):
                     o.aux[1] = za if za is not None else _lib.BUF_NONE
                     o.aux[2] = cp if cp is not None else _lib.BUF_NONE
                     o.aux[3] = co
+                if op.src2 is not None:                # a whole step: the input convolution rides along
+                    il = op.src2['layer']
+                    o.src2, o.w2, o.xs2_c = op.src2['buf'], widx[id(il)][0], op.src2['xs'][0]
+                    o.conv2 = self._descriptor2(op)
+                    o.b = widx[id(il)][1]                  # the layer's bias belongs to its input convolution
             elif op.kind == 'rowconv':                 # RowConnected2D: float32 buffers, per-row weights as stored
                 o.w, o.b = widx[id(op.layer)]
                 o.conv = d
@@ -419,6 +448,11 @@ class Model(object):
                           for op in self.infer_plan.ops):
                 self.infer_plan = P.build_plan(self.inputs, self.outputs, inference=True, fuse_d2s=False)
             self.executor = Executor(self.infer_plan, self.device, dtype)
+            if any(op.kind == 'conv' and op.src2 is not None and op.dst not in self.executor._oct for op in self.infer_plan.ops):
+                # whole-step ConvLSTM2D launches exist in the octet layout only: two launches per step otherwise
+                self.infer_plan = P.build_plan(self.inputs, self.outputs, inference=True, fuse_d2s=False, fuse_lstm=True,
+                                               fuse_lstm_step=False)
+                self.executor = Executor(self.infer_plan, self.device, dtype)
             self.__dict__.pop('_rollouts', None)
         return self
 

@@ -211,6 +211,54 @@ def convlstm_conv(x, w_hwio, bias, cd, h_out, c_out, z_add=None, c_prev=None, x_
     return h_out
 
 
+def _step_args(h_seq, x, cd_h, cd_x, x_channels):
+    n, _, hh, ww = h_seq.shape
+    f = int(cd_h.lstm_f)
+    if x.shape[0] != n or tuple(x.shape[2:]) != (hh, ww):
+        raise ValueError('convlstm_step: state %r does not match the h sequence %r' % (tuple(x.shape), tuple(h_seq.shape)))
+    if cd_h.in_c_total == 0 or cd_h.out_c_total == 0:
+        cd_h.in_c_total = cd_h.out_c_total = h_seq.shape[1]
+    if cd_x.in_c_total == 0:
+        cd_x.in_c_total = x.shape[1]
+    return Shape4(n, f, hh, ww), Shape4(n, int(x_channels), hh, ww), _lib.dtype_io(_lib.BF16_O8, _lib.BF16_O8)
+
+
+def convlstm_step_supported(xs_h_chw, cd_h, xs_x_chw, cd_x):
+    """Planner hint: can ONE launch run this ConvLSTM2D step (recurrent + input convolution + cell update,
+    dlwp_convlstm_step_fwd)?  Octet layout only."""
+    return bool(_lib.lib.dlwp_convlstm_step_supported(
+        _lib.handle_or_none(), Shape4(1, *[int(v) for v in xs_h_chw]), ctypes.byref(cd_h), Shape4(1, *[int(v) for v in xs_x_chw]),
+        ctypes.byref(cd_x), _lib.dtype_io(_lib.BF16_O8, _lib.BF16_O8)))
+
+
+def convlstm_step_prepare(h_seq, x, w_h, w_x, cd_h, cd_x, x_channels):
+    """Arranged weights of both kernels for convlstm_step calls of this geometry (dlwp_convlstm_step_prepare)."""
+    _check_f32(w_h, w_x)
+    xs_h, xs_x, dt = _step_args(h_seq, x, cd_h, cd_x, x_channels)
+    hd = _lib.handle(_dev(h_seq))
+    nbytes = _lib.lib.dlwp_convlstm_step_prepared_bytes(hd, xs_h, ctypes.byref(cd_h), xs_x, ctypes.byref(cd_x), dt)
+    if nbytes == 0:
+        raise _lib.DlwpError(_lib.EUNSUPPORTED, 'convlstm_step_prepare: this step has no dual-source instance')
+    u = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=h_seq.device)
+    _lib.check(_lib.lib.dlwp_convlstm_step_prepare(hd, _ptr(w_h), _ptr(w_x), _ptr(u), xs_h, ctypes.byref(cd_h), xs_x,
+                                                   ctypes.byref(cd_x), dt, _stream(h_seq)))
+    return u
+
+
+def convlstm_step(h_seq, x, w_h, w_x, bias, cd_h, cd_x, c_prev, c_out, x_channels, prepared=None):
+    """One ConvLSTM2D step t >= 1 in one launch (dlwp_convlstm_step_fwd): h_seq is the bfloat16 h sequence IN OCTETS -- cd_h's
+    input window holds h_{t-1}, its output window receives h_t; x the float32 state (cd_x's channel window = x_t); c_prev / c_out
+    the float32 cell state in octets."""
+    _check_f32(w_h, w_x, bias, c_prev, c_out, x)
+    if h_seq.dtype != torch.bfloat16 or not h_seq.is_contiguous():
+        raise ValueError('convlstm_step: the h sequence must be a contiguous bfloat16 tensor (octet layout)')
+    xs_h, xs_x, dt = _step_args(h_seq, x, cd_h, cd_x, x_channels)
+    _lib.check(_lib.lib.dlwp_convlstm_step_fwd(_lib.handle(_dev(h_seq)), _ptr(h_seq), _ptr(x), _ptr(w_h), _ptr(w_x), _ptr(prepared),
+                                               _ptr(bias), _ptr(c_prev), _ptr(c_out), _ptr(h_seq), xs_h, ctypes.byref(cd_h), xs_x,
+                                               ctypes.byref(cd_x), dt, _stream(h_seq)))
+    return h_seq
+
+
 def maxpool2(x, out=None):
     _check_act(x, out)
     n, c, h, w = x.shape

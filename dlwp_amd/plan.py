@@ -88,6 +88,9 @@ class PlanOp(object):
         # conv with the ConvLSTM2D cell update in its epilogue (bfloat16 inference plans): lstm_f = F hidden channels, dst = the h
         # buffer, aux = (z_add buffer | None, c_prev buffer | None, c_out buffer), act / rec_act = the cell's activations
         self.lstm_f = kw.pop('lstm_f', 0)
+        # ... and a WHOLE step in one launch (dlwp_convlstm_step_fwd; octet layout): this op is the recurrent convolution, src2
+        # describes the input convolution of the same step: {'buf', 'xs' (c, h, w), 'layer', 'halo', 'in_c_off', 'in_c_total'}
+        self.src2 = kw.pop('src2', None)
         # conv restated on a low-resolution source (inference plans; build_plan): geometry that overrides the layer's
         self.dil = kw.pop('dil', None)            # dilation (dh, dw)
         self.ksize = kw.pop('ksize', None)        # kernel size (kh, kw)
@@ -154,6 +157,9 @@ class Plan(object):
                 kh, kw = op.layer.kernel_size
                 co, ho, wo = getattr(op, 'conv_out_shape', None) or op.out_shape
                 tot += 2 * ho * wo * co * op.xs[0] * kh * kw
+                if op.src2 is not None:          # a whole ConvLSTM2D step: the input convolution's share
+                    k2 = op.src2['layer'].kernel_size
+                    tot += 2 * ho * wo * 4 * op.lstm_f * op.src2['xs'][0] * k2[0] * k2[1]
         return tot
 
     def algorithmic_bytes_per_sample(self, itemsize=4):
@@ -298,7 +304,22 @@ def _supports_lstm_conv(xs, part, halo, src_mode, act, rec_act, f, in_c_off, in_
         return False
 
 
-def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False):
+def _supports_lstm_step(lay, f, ho, wo, t_len, cin, v, halo, act, rec_act):
+    """can ONE launch run a step t >= 1 of this ConvLSTM2D (dlwp_convlstm_step_fwd)?"""
+    try:
+        from . import ops
+        ip, rp = lay.input_part, lay.recurrent_part
+        rk = ((rp.kernel_size[0] - 1) // 2, (rp.kernel_size[1] - 1) // 2)
+        cd_h = ops.make_conv(4 * f, rp.kernel_size[0], rp.kernel_size[1], 1, ops.make_pad(rk[0], rk[0], rk[1], rk[1], 0, 0), act,
+                             0, t_len * f, f, t_len * f, SRC_DIRECT, lstm_f=f, lstm_rec_act=rec_act)
+        cd_x = ops.make_conv(4 * f, ip.kernel_size[0], ip.kernel_size[1], tuple(ip.dilation_rate), ops.make_pad(*halo), 0,
+                             v.c_off + cin, v.c_total, 0, 4 * f, v.src_mode)
+        return v.h == ho and v.w == wo and ops.convlstm_step_supported((f, ho, wo), cd_h, (cin, v.h, v.w), cd_x)
+    except (ImportError, OSError, AttributeError):
+        return False
+
+
+def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False, fuse_lstm_step=True):
     """inputs: [KTensor] (exactly one), outputs: [KTensor].  Returns a Plan.  inference=True additionally moves a
     MaxPooling2D(2) that is the only consumer of a convolution into that convolution's epilogue (the pre-pooling tensor
     is never written; the training plan keeps it because the backward pass needs it)."""
@@ -475,7 +496,11 @@ def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False)
                                          v.c_off, v.c_total, 0, t_len * f, False) and
                      (t_len == 1 or _supports_lstm_conv((f, ho, wo), lay.recurrent_part, rhalo, SRC_DIRECT, ACT[lay.activation],
                                                         rec_code, f, 0, t_len * f, f, t_len * f, True)))
-            zxs = [None if (fused and step == 0) else plan.new_buffer(4 * f, ho, wo) for step in range(t_len)]
+            # ... and every later step as ONE launch where the library has the dual-source instance (octet layout; the executor
+            # falls back to the two launches when it cannot keep the h sequence in octets)
+            whole = (fused and fuse_lstm_step and t_len > 1 and os.environ.get('DLWP_LSTM_STEP', '1') != '0' and
+                     _supports_lstm_step(lay, f, ho, wo, t_len, cin, v, halo, ACT[lay.activation], rec_code))
+            zxs = [None if (fused and (step == 0 or whole)) else plan.new_buffer(4 * f, ho, wo) for step in range(t_len)]
             zhs = [None] + [None if fused else plan.new_buffer(4 * f, ho, wo) for _ in range(t_len - 1)]
             for step in range(t_len if fused else 0):
                 if step == 0:
@@ -483,6 +508,14 @@ def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False)
                                 act=ACT[lay.activation], rec_act=rec_code, lstm_f=f, aux=(None, None, cbufs[0]),
                                 in_c_off=v.c_off, in_c_total=v.c_total, out_c_off=0, out_c_total=t_len * f,
                                 out_shape=(f, ho, wo)))
+                    continue
+                if whole:
+                    emit(PlanOp('conv', hbuf, hbuf, (f, ho, wo), layer=lay.recurrent_part, halo=rhalo, src_mode=SRC_DIRECT,
+                                act=ACT[lay.activation], rec_act=rec_code, lstm_f=f, aux=(None, cbufs[step - 1], cbufs[step]),
+                                in_c_off=(step - 1) * f, in_c_total=t_len * f, out_c_off=step * f, out_c_total=t_len * f,
+                                out_shape=(f, ho, wo),
+                                src2={'buf': v.buf, 'xs': (cin, v.h, v.w), 'layer': lay.input_part, 'halo': halo,
+                                      'in_c_off': v.c_off + step * cin, 'in_c_total': v.c_total}))
                     continue
                 emit(PlanOp('conv', v.buf, zxs[step], (cin, v.h, v.w), layer=lay.input_part, halo=halo,
                             src_mode=v.src_mode, act=0, in_c_off=v.c_off + step * cin, in_c_total=v.c_total, out_c_off=0,

@@ -379,6 +379,23 @@ int dlwp_convlstm_conv_fwd(dlwp_handle_t, const void* x, const void* w, const vo
                            const void* z_add, const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int dtype, void* stream);
 int dlwp_convlstm_conv_supported(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
+/* One ConvLSTM2D step t >= 1 in ONE launch (r3; keras ConvLSTM2DCell.call, the recurrent front end of examples/train.py:144-157):
+ * z = conv_h(h_{t-1}) + conv_x(x_t) + bias, then the cell update -- the input convolution's 4 F pre-activations are neither
+ * stored nor read back.  cd_h: the recurrent convolution (3x3, 'same' zero halo 1, dilation 1, lstm_f = F <= 24, its channel
+ * windows on the h sequence: in = h_{t-1}, out = h_t), xs_h = (n, F, H, W); cd_x: the input convolution (3x3, dilation 2, halo 2
+ * of any mode, its channel window on the float32 state), xs_x = (n, Cx <= 8, H, W).  dtype = DLWP_DTYPE_IO(DLWP_BF16_O8,
+ * DLWP_BF16_O8): h in octets; c_prev / c_out float32 octets (N, F/8, H, W, 8).  w_h / w_x: the two HWIO kernels (ignored when
+ * `prepared` -- dlwp_convlstm_step_prepare's output, dlwp_convlstm_step_prepared_bytes large -- is given); bias: (4 F).       */
+int    dlwp_convlstm_step_supported(dlwp_handle_t, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h, dlwp_shape4 xs_x,
+                                    const dlwp_conv2d* cd_x, int dtype);
+size_t dlwp_convlstm_step_prepared_bytes(dlwp_handle_t, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h, dlwp_shape4 xs_x,
+                                         const dlwp_conv2d* cd_x, int dtype);
+int    dlwp_convlstm_step_prepare(dlwp_handle_t, const void* w_h, const void* w_x, void* prepared, dlwp_shape4 xs_h,
+                                  const dlwp_conv2d* cd_h, dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, void* stream);
+int    dlwp_convlstm_step_fwd(dlwp_handle_t, const void* h_in, const void* x_in, const void* w_h, const void* w_x,
+                              const void* prepared, const void* bias, const void* c_prev, void* c_out, void* h_out,
+                              dlwp_shape4 xs_h, const dlwp_conv2d* cd_h, dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype,
+                              void* stream);
 int dlwp_convlstm_gates(dlwp_handle_t, const void* zx, const void* zh, const void* c_prev, void* c_out, void* h_out,
                         int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act, int dtype, void* stream);
 /* backward of the cell update (one step of back-propagation through time behind DLWPNeuralNet.fit on the recurrent
@@ -421,6 +438,11 @@ typedef struct {
                              * DLWP_BF16 or DLWP_DTYPE_IO(in, out)); the rollout's own dtype describes state and series.
                              * DLWP_OP_CONV2D with conv.lstm_f > 0 (dlwp_convlstm_conv_fwd): dst = h buffer, aux[1..3] =
                              * {z_add | -1000, c_prev | -1000, c_out}                                                  */
+  /* DLWP_OP_CONV2D with conv.lstm_f > 0 and src2 != -1000: a whole ConvLSTM2D step (dlwp_convlstm_step_fwd) -- conv = the
+   * recurrent convolution, src = dst = the h buffer, w / b = recurrent kernel / the layer's bias; src2 = the float32 state the
+   * input convolution conv2 reads xs2_c channels of, w2 = its kernel.  Every other op: src2 = -1000.                       */
+  int src2, w2, xs2_c;
+  dlwp_conv2d conv2;
 } dlwp_op;
 #define DLWP_BUF_NONE (-1000)
 typedef struct dlwp_rollout* dlwp_rollout_t;

@@ -353,7 +353,8 @@ def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', 
     two convolutions ('kernel', 'recurrent') run on the bf16 matrix cores: their kernel and input are rounded to bf16;
     fused_cell_update -- the convolution that completes a step's pre-activations (the input convolution on the first step,
     the recurrent one afterwards) applies the cell update in its epilogue (dlwp_convlstm_conv_fwd): ITS pre-activations are
-    never stored, hence not rounded; the other convolution's (the input convolution's from the second step on) are."""
+    never stored, hence not rounded; the other convolution's (the input convolution's from the second step on) are;
+    fused_cell_update='step': a later step is one launch computing both convolutions -- nothing stored, nothing rounded."""
     x = np.asarray(x, dtype=np.float64)
     if 'kernel' in bf16_kernels:
         kernel, x = round_bf16(kernel), round_bf16(x)
@@ -373,7 +374,8 @@ def conv_lstm2d(x, kernel, recurrent_kernel, bias, dilation=1, padding='valid', 
             ph, pw = dilation * (kh - 1), dilation * (kw - 1)
             xt = np.pad(xt, ((0, 0), (0, 0), (ph // 2, ph - ph // 2), (pw // 2, pw - pw // 2)))
         z = conv2d(xt, kernel, bias, dilation, 'linear')
-        if not (fused_cell_update and h is None):
+        # 'step': every step of t >= 1 is ONE launch (dlwp_convlstm_step_fwd) -- no pre-activation is ever stored
+        if not ((fused_cell_update and h is None) or fused_cell_update == 'step'):
             z = rnd(z)
         if h is not None:
             hp = np.pad(h, ((0, 0), (0, 0), ((rkh - 1) // 2, rkh - 1 - (rkh - 1) // 2),

@@ -30,7 +30,8 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_lib.Shape4) == 16
     assert ctypes.sizeof(_lib.Pad2d) == 24
     assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 10 * 4     # ... src_mode, out_pool, out_d2s, lstm_f, lstm_rec_act
-    assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24 + 4 * 4   # + aux[4]
+    # + aux[4], then the second source of a whole-step op: src2, w2, xs2_c, conv2
+    assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24 + 4 * 4 + 3 * 4 + ctypes.sizeof(_lib.Conv2d)
 
 
 def test_conv_out_shape_and_validation_without_a_device():

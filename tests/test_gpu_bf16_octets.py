@@ -149,6 +149,8 @@ def test_recurrent_model_forecasts_identically_with_and_without_octets(monkeypat
     cs = (2, 6, 24, 40)
     x = rng.standard_normal((4,) + cs).astype(np.float32)
     outs = {}
+    # (the whole-step ConvLSTM2D launch exists in octets only and rounds one tensor less: compared on its own below)
+    monkeypatch.setenv('DLWP_LSTM_STEP', '0')
     for o8 in ('1', '0'):
         monkeypatch.setenv('DLWP_BF16_O8', o8)
         np.random.seed(3)
@@ -162,6 +164,18 @@ def test_recurrent_model_forecasts_identically_with_and_without_octets(monkeypat
         outs[o8] = (d.predict(x), d.predict_timeseries(x, 4))
     assert np.array_equal(outs['1'][0], outs['0'][0])
     assert np.array_equal(outs['1'][1], outs['0'][1])
+    # the default plan: later ConvLSTM2D steps as one launch -- the same forecast up to the rounding of the pre-activation tensor
+    # that is no longer stored
+    monkeypatch.setenv('DLWP_LSTM_STEP', '1')
+    monkeypatch.setenv('DLWP_BF16_O8', '1')
+    np.random.seed(3)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(lstm_unet_layers(cs), loss='mse', optimizer='adam')
+    d.model.set_activation_dtype('bfloat16')
+    assert any(op.kind == 'conv' and op.src2 is not None for op in d.model.infer_plan.ops)
+    one = d.predict(x)
+    assert np.abs(one - outs['1'][0]).max() < 2e-2 * max(1.0, np.abs(one).max())
+    assert np.array_equal(np.asarray(d.predict_timeseries(x, 2, keep_time_dim=True))[0].reshape(one.shape), one)   # graph == eager
 
 
 def test_every_compiled_octet_instance_against_the_nchw_result():
@@ -201,3 +215,51 @@ def test_every_compiled_octet_instance_against_the_nchw_result():
     finally:
         ops.force_conv_config(-1)
     assert seen >= 8
+
+
+@pytest.mark.parametrize('f,cx,h,w', [(24, 6, 20, 40), (16, 4, 18, 36), (16, 8, 9, 72)])
+def test_whole_convlstm_step_in_one_launch_equals_the_two_launch_step(f, cx, h, w):
+    """dlwp_convlstm_step_fwd (recurrent + input convolution + cell update in one launch) against the two launches it replaces
+    -- the input convolution into a stored bfloat16 z, then dlwp_convlstm_conv_fwd with z_add -- up to that tensor's rounding;
+    and against a float64 restatement of the cell (np_ref.conv_lstm2d arithmetic) with bf16-rounded inputs and kernels."""
+    from dlwp_amd import ops
+    rng = np.random.default_rng(100 + f)
+    n = 3
+    x = torch.from_numpy(rng.standard_normal((n, 2 * cx, h, w)).astype(np.float32)).cuda()
+    hseq = torch.from_numpy((0.5 * rng.standard_normal((n, 2 * f, h, w))).astype(np.float32)).cuda().bfloat16()
+    cp = torch.from_numpy(rng.standard_normal((n, f, h, w)).astype(np.float32)).cuda()
+    w_h = torch.from_numpy(np_ref.glorot_uniform((3, 3, f, 4 * f), rng)).cuda()
+    w_x = torch.from_numpy(np_ref.glorot_uniform((3, 3, cx, 4 * f), rng)).cuda()
+    b = torch.from_numpy((0.1 * rng.standard_normal(4 * f)).astype(np.float32)).cuda()
+    cd_h = ops.make_conv(4 * f, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 0), ops.ACT_TANH, in_c_off=0, in_c_total=2 * f, out_c_off=f,
+                         out_c_total=2 * f, lstm_f=f, lstm_rec_act=0)
+    cd_x = ops.make_conv(4 * f, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_LINEAR, in_c_off=cx, in_c_total=2 * cx)
+    assert ops.convlstm_step_supported((f, h, w), cd_h, (cx, h, w), cd_x)
+    # one launch
+    h1, c1 = to_o8(hseq), torch.empty((n, f, h, w), device='cuda')
+    ops.convlstm_step(h1, x, w_h, w_x, b, cd_h, cd_x, to_o8(cp), c1, cx)
+    h1, c1 = from_o8(h1), from_o8(c1)
+    # prepared weights: the same launch
+    prep = ops.convlstm_step_prepare(to_o8(hseq), x, w_h, w_x, cd_h, cd_x, cx)
+    h1p, c1p = to_o8(hseq), torch.empty((n, f, h, w), device='cuda')
+    ops.convlstm_step(h1p, x, w_h, w_x, b, cd_h, cd_x, to_o8(cp), c1p, cx, prepared=prep)
+    assert torch.equal(from_o8(h1p), h1) and torch.equal(from_o8(c1p), c1)
+    # two launches (NCHW instances), z stored as bfloat16
+    z = ops.conv2d(x, w_x, b, cd_x, out=torch.empty((n, 4 * f, h, w), device='cuda', dtype=torch.bfloat16), x_channels=cx,
+                   compute_bf16=True)
+    h2, c2 = hseq.clone(), torch.empty((n, f, h, w), device='cuda')
+    ops.convlstm_conv(hseq, w_h, None, cd_h, h2, c2, z_add=z, c_prev=cp, x_channels=f)
+    assert torch.equal(h1[:, :f], hseq[:, :f])                      # the step's window only
+    assert (c1 - c2).abs().max().item() < 2e-2 and (h1.float() - h2.float()).abs().max().item() < 2e-2
+    # float64 cell arithmetic on the rounded operands
+    r = np_ref.round_bf16
+    xt = np.pad(r(x[:, cx:].cpu().numpy()).astype(np.float64), ((0, 0), (0, 0), (2, 2), (0, 0)))
+    xt = np.concatenate([xt[..., -2:], xt, xt[..., :2]], axis=-1)
+    hp = np.pad(hseq[:, :f].float().cpu().numpy().astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1)))
+    zz = np_ref.conv2d(xt, r(w_x.cpu().numpy()), b.cpu().numpy(), 2, 'linear') + \
+        np_ref.conv2d(hp, r(w_h.cpu().numpy()), None, 1, 'linear')
+    zi, zf, zc, zo = zz[:, :f], zz[:, f:2 * f], zz[:, 2 * f:3 * f], zz[:, 3 * f:]
+    c_want = np_ref.hard_sigmoid(zf) * cp.cpu().numpy() + np_ref.hard_sigmoid(zi) * np.tanh(zc)
+    h_want = np_ref.hard_sigmoid(zo) * np.tanh(c_want)
+    assert np.abs(c1.cpu().numpy() - c_want).max() < 3e-5 * max(1.0, np.abs(c_want).max())
+    assert np.abs(h1[:, f:].float().cpu().numpy() - h_want).max() < 4.1e-3

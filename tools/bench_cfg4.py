@@ -63,7 +63,14 @@ def main():
     rows = []
     for op, desc in zip(plan.ops, ex._descriptors()):
         src, dst = res(op.src), res(op.dst)
-        if op.kind == 'conv' and op.lstm_f:                          # cell update in the convolution's epilogue
+        if op.kind == 'conv' and op.src2 is not None:                # a whole ConvLSTM2D step in one launch
+            kern, bias = ex.conv_weights(op)
+            za, cp, co = op.aux
+            il = op.src2['layer']
+            d2 = ex._descriptor2(op)
+            fn = lambda: ops.convlstm_step(dst, res(op.src2['buf']), kern, il.kernel, il.bias, desc, d2, res(cp), res(co),  # noqa: E731
+                                           op.src2['xs'][0])
+        elif op.kind == 'conv' and op.lstm_f:                        # cell update in the convolution's epilogue
             c16 = op.dst in ex._bf16 and op.src not in ex._bf16
             kern, bias = ex.conv_weights(op)
             za, cp, co = op.aux
@@ -112,7 +119,10 @@ def main():
                 za, cp, co = op.aux
                 hw_ = op.out_shape[1] * op.out_shape[2]
                 nb += a.members * hw_ * op.lstm_f * ((8.0 if za is not None else 0.0) + (4.0 if cp is not None else 0.0) + 4.0)
-                row['cell_update'] = 'in the epilogue (dlwp_convlstm_conv_fwd)'
+                row['cell_update'] = ('whole step in one launch (dlwp_convlstm_step_fwd)' if op.src2 is not None else
+                                      'in the epilogue (dlwp_convlstm_conv_fwd)')
+                if op.src2 is not None:      # + the float32 state channels the input convolution reads
+                    nb += 4.0 * a.members * op.src2['xs'][0] * hw_
                 co_ = 4 * op.lstm_f
                 fl = 2.0 * ho * wo * co_ * op.xs[0] * kh * kw * a.members
             row['storage'] = '%s -> %s' % ('octets' if op.src in ex._oct else str(src.dtype).replace('torch.', ''),

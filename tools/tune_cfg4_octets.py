@@ -53,6 +53,8 @@ def main():
         kern, bias = ex.conv_weights(op)
         c16 = op.dst in ex._bf16 and op.src not in ex._bf16
         in8, sw = op.src in ex._oct, op.dst in ex._oct
+        if op.src2 is not None:
+            continue                                  # whole-step launches: two instances only (forced through the same option)
         if op.lstm_f:
             za, cp, co = op.aux
             fn = lambda: ops.convlstm_conv(src, kern, bias, desc, dst, res(co), z_add=res(za) if za is not None else None,  # noqa: E731
