@@ -93,7 +93,9 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
   out->co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
   const long long total_tiles = (long long)N * out->tiles_h * out->tiles_w;
   // enough workgroups to fill the chip a few times over (16 waves per CU), every split walks >= 2 tiles
-  long long splits = ((long long)h->cu_count * 16 * 2) / ((long long)e.waves * out->ci_groups * out->co_tiles);
+  // (r3: half a complement of waves by default -- DLWP_OPT_WGRAD_FILL = 4 -- instead of two: at the 8 and 64 samples per GPU of config 3
+  //  the slabs were 200 MB per step for 0.75 MB of gradients, written by these kernels and read back by the final sums)
+  long long splits = ((long long)h->cu_count * 2 * h->opt.wgrad_fill) / ((long long)e.waves * out->ci_groups * out->co_tiles);
   if (splits > total_tiles / 2) splits = total_tiles / 2;
   if (splits < 1) splits = 1;
   // bound slab memory to 64 MiB

@@ -207,6 +207,11 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, bf2));
 }
 
+// profiling builds only (tools/knockout_l1.sh): -DDLWP_KNOCK_F32=n removes one phase of the direct kernel --
+// 1: the global stores, 2: the matrix loop, 3: the input / weight loads, 4: the activation
+#ifndef DLWP_KNOCK_F32
+#define DLWP_KNOCK_F32 0
+#endif
 template <class C>
 __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_f32(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -416,12 +421,13 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_f32(const ConvArgs a
 
   if (C::POOL != pool) return;  // the host pairs the pooled loader with POOL instances only (conv_fwd.hip)
 
-  prefetch(0);
+  if (DLWP_KNOCK_F32 != 3) prefetch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += C::CK) {
     __syncthreads();  // everyone is done reading the previous chunk
-    commit(c0);
+    if (DLWP_KNOCK_F32 != 3) commit(c0);
     __syncthreads();
-    if (c0 + C::CK < a.Cin) prefetch(c0 + C::CK);
+    if (DLWP_KNOCK_F32 != 3 && c0 + C::CK < a.Cin) prefetch(c0 + C::CK);
+    if (DLWP_KNOCK_F32 == 2) continue;
     // -- K loop over this chunk.  Order = (group of 4 channels, tap): the accumulation chain of every output element
     //    is then the same whatever CK / tile shape / batch size is in use, so results are bit-identical across tile
     //    configurations and across batch shardings.  Every LDS address = lane base + immediate.
@@ -473,9 +479,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_f32(const ConvArgs a
             for (int i = 0; i < C::FA / 2; ++i) {
               const int pc = (j0 >> 1) + i * 8 + (lane >> 4) * 2;
               const f32x4 u = acc[i][g], d = acc[i + C::FA / 2][g];
-              const f32x2 o01 = act_apply2_c<ACT>((f32x2){fmaxf(fmaxf(u[0], u[1]), fmaxf(d[0], d[1])),
-                                                           fmaxf(fmaxf(u[2], u[3]), fmaxf(d[2], d[3]))} + (f32x2){bv, bv});
+              const f32x2 o01 = act_apply2_c<(DLWP_KNOCK_F32 == 4 ? 0 : ACT)>(
+                  (f32x2){fmaxf(fmaxf(u[0], u[1]), fmaxf(d[0], d[1])), fmaxf(fmaxf(u[2], u[3]), fmaxf(d[2], d[3]))} + (f32x2){bv, bv});
               const float o0 = o01.x, o1 = o01.y;
+              if (DLWP_KNOCK_F32 == 1 && o0 != 12345.678f) continue;
               if (a.out_bf16) {
                 bf16_t* yp = (bf16_t*)a.y + yo + pc;
                 if (pc + 1 < a.Wp && (a.Wp & 1) == 0) *(unsigned*)yp = pack_bf16x2(o0, o1);
@@ -514,9 +521,11 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_f32(const ConvArgs a
         f32x4 o;
         {
           const f32x2 bb = (f32x2){bv, bv};
-          const f32x2 lo = act_apply2_c<ACT>(acc[i][g].xy + bb), hi = act_apply2_c<ACT>(acc[i][g].zw + bb);
+          const f32x2 lo = act_apply2_c<(DLWP_KNOCK_F32 == 4 ? 0 : ACT)>(acc[i][g].xy + bb),
+                      hi = act_apply2_c<(DLWP_KNOCK_F32 == 4 ? 0 : ACT)>(acc[i][g].zw + bb);
           o = (f32x4){lo.x, lo.y, hi.x, hi.y};
         }
+        if (DLWP_KNOCK_F32 == 1 && o[0] != 12345.678f) continue;
         if (vec_store) {
           const int row = p / C::TW, col = p - row * C::TW;
           const int oh = i0 + row, ow = j0 + col;

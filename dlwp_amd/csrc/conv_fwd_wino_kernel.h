@@ -453,10 +453,18 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         const f32x2 y0 = act_apply2_c<ACT>(y_even(s, aa) + bv);
         const f32x2 y1 = act_apply2_c<ACT>(y_odd(s, aa) + bv);
         float* q = op + aa * C::DIL * C::TW;
-        q[0] = y0.x;                  // tile t:     columns 0, DIL
-        q[2 * C::DIL] = y0.y;         // tile t + 1: columns 2 DIL, 3 DIL
-        q[C::DIL] = y1.x;
-        q[3 * C::DIL] = y1.y;
+        if constexpr (C::DIL == 1) {
+          // the pair's four outputs of this row are adjacent: ONE 16-byte write (r3).  Four 4-byte writes put all 64 lanes of
+          // an instruction on the 8 banks = 0 (mod 4) -- the plane stride OPS = 4 (mod 32) spreads the 16 channels of a lane
+          // group over multiples of 4 only: the 17 % bank-conflict cycles of profiles/r2z_stalls.json; a 16-byte write covers
+          // banks b .. b + 3 and the same stride makes 8 lanes tile all 32
+          *(f32x4*)q = (f32x4){y0.x, y1.x, y0.y, y1.y};
+        } else {
+          q[0] = y0.x;                  // tile t:     columns 0, DIL
+          q[2 * C::DIL] = y0.y;         // tile t + 1: columns 2 DIL, 3 DIL
+          q[C::DIL] = y1.x;
+          q[3 * C::DIL] = y1.y;
+        }
       }
     });
   });

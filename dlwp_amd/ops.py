@@ -14,7 +14,15 @@ from ._lib import (ACT_LINEAR, ACT_RELU, ACT_TANH, PAD_EDGE, PAD_REFLECT, PAD_SY
 ACTIVATIONS = {None: ACT_LINEAR, 'linear': ACT_LINEAR, 'tanh': ACT_TANH, 'relu': ACT_RELU}
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(t):
+    """the current HIP stream of t's device (torch.cuda.current_stream builds a Stream object per call: ~5 us, 50 times per
+    training step; the raw handle is what the C ABI wants anyway)"""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return ctypes.c_void_p(_raw_stream(idx if idx is not None else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -555,9 +563,14 @@ def prepare_begin(device):
     _lib.check(_lib.lib.dlwp_prepare_begin(_lib.handle(_dev_index(device))))
 
 
+def _device_stream(device):
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(_dev_index(device)))
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
 def prepare_flush(device):
-    _lib.check(_lib.lib.dlwp_prepare_flush(_lib.handle(_dev_index(device)),
-                                           ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+    _lib.check(_lib.lib.dlwp_prepare_flush(_lib.handle(_dev_index(device)), _device_stream(device)))
 
 
 def reductions_begin(device):
@@ -567,8 +580,7 @@ def reductions_begin(device):
 
 
 def reductions_flush(device):
-    _lib.check(_lib.lib.dlwp_reductions_flush(_lib.handle(_dev_index(device)),
-                                              ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)))
+    _lib.check(_lib.lib.dlwp_reductions_flush(_lib.handle(_dev_index(device)), _device_stream(device)))
 
 
 # ---- RowConnected2D (reference DLWP/custom.py:695-896) ------------------------------------------------------------------ #

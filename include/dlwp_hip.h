@@ -117,6 +117,11 @@ int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, cha
 #define DLWP_OPT_FORCE_WGRAD_CONFIG 3  /* ... this weight-gradient configuration                                           */
 #define DLWP_OPT_WINO_PAIRS         4  /* Winograd on narrow maps (22x45): two samples side by side in one virtual row (1,
                                         * default) or the wide + narrow launch pair (0); same bits either way              */
+#define DLWP_OPT_WGRAD_FILL         5  /* weight gradient: how many waves per CU the number of partial-sum splits aims at, in
+                                        * eighths of the CU's 16 wave slots (default 4 = half a complement; r2 used 16: measured on
+                                        * the six weight gradients of the config-2 U-Net, 8 / 64 samples: 0.306 / 1.291 ms at 16,
+                                        * 0.251 / 1.172 ms at 4, 0.263 / 1.820 ms at 2, tools/bench_reduce_jobs.py).  Every
+                                        * split writes a slab the size of the weight tensor: fewer splits = less slab traffic    */
 int         dlwp_set_option(dlwp_handle_t h, int option, int value, int* previous);
 /* the defaults themselves: what handles created AFTERWARDS start from, and what the handle-less host logic (planner hints
  * called with a NULL handle, e.g. on a machine without a GPU) uses.  Existing handles are not touched.                 */

@@ -46,6 +46,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         lv, _ = tr.train_on_batch(x, y, return_device=True)
+    t_host = time.perf_counter() - t0          # the host's share: launches issued, nothing waited for
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -58,7 +59,8 @@ def main():
     if rank == 0:
         print(json.dumps({'metric': 'training samples/s (cfg3: 88x180x4 U-Net, fp32, Adam, mse)', 'value': n_global * a.steps / dt,
                           'unit': 'samples/s', 'n_gpus': world, 'batch_per_gpu': a.batch, 'steps': a.steps,
-                          'ms_per_step': 1e3 * dt / a.steps, 'approx_tflops_per_gpu': flops / dt / 1e12 / world,
+                          'ms_per_step': 1e3 * dt / a.steps, 'host_ms_per_step': 1e3 * t_host / a.steps,
+                          'captured_graph': bool(tr._graphs), 'approx_tflops_per_gpu': flops / dt / 1e12 / world,
                           'loss': [float(v) for v in lv.detach().cpu().numpy().ravel()]}))
 
 
