@@ -547,8 +547,13 @@ int dlwp_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dy, void*
                  "dlwp_act_bwd_bias_grad: bad arguments");
   DLWP_CHECK_ARG(ws_bytes >= dlwp_bias_grad_workspace(c), "dlwp_act_bwd_bias_grad: workspace too small");
   const bool v4 = hw % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dz | (uintptr_t)y) & 15) == 0;
+  // (r3) planes of an even but not 4-divisible size -- the 22 x 45 maps of the U-Net: 990 floats -- still start 8-byte aligned
+  const bool v2 = hw % 2 == 0 && (((uintptr_t)dy | (uintptr_t)dz | (uintptr_t)y) & 7) == 0;
   if (v4)
     act_bwd_bias_partial_kernel<4><<<dim3(c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
+        (const float*)y, (const float*)dy, (float*)dz, (float*)ws, n, c_off, c_total, hw, act);
+  else if (v2)
+    act_bwd_bias_partial_kernel<2><<<dim3(c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
         (const float*)y, (const float*)dy, (float*)dz, (float*)ws, n, c_off, c_total, hw, act);
   else
     act_bwd_bias_partial_kernel<1><<<dim3(c, BIAS_SPLIT), 256, 0, (hipStream_t)stream>>>(
