@@ -354,6 +354,11 @@ class Trainer(object):
         if prep is not None and self._side is None:
             self._side = [torch.cuda.Stream(self.device) for _ in range(3)]
         sides = self._side if prep is not None else None
+        if sides is not None and torch.cuda.is_current_stream_capturing():
+            # inside a captured step everything stays on ONE stream: replaying graphs with forked branches crashed inside
+            # hipGraphLaunch now and then (r3: 2 of 3 full test runs), and the forks bought little there (0.49 vs ~0.47 ms at 8
+            # samples: a fork / join costs ~10 us in a graph).  The eager step keeps the side streams (batch 64: 1.78 -> 1.68 ms).
+            sides = None
         # Weight gradients leave the critical path (activation backward -> data gradient -> ...): they are queued and launched
         # on side streams in TWO batches with one fork each -- a fork / join costs ~10 us inside a captured graph
         # (profiles/r3_train_b8_timeline.txt): the first half, one after the other, beside the second half of the chain; the
@@ -742,9 +747,26 @@ class Trainer(object):
             self._lr_t = torch.zeros(1, dtype=torch.float32, device=self.device)
         if self.opt_state is None:
             raise RuntimeError('the optimizer slots must exist before the step is captured')
+        import gc
         from ._lib import capture_lock
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
+        # No garbage collection while the stream is capturing: a collection cycle that finalises an old model's graphs, streams,
+        # events or device memory (hipGraphExecDestroy, hipStreamDestroy, hipFree ...) in the middle of a capture aborts the
+        # process or leaves a graph that crashes at launch (r3: seen as 'Fatal Python error: Aborted ... Garbage-collecting' inside
+        # _capture_step and as segmentation faults in replay, 3 of 7 full test runs, once small steps were captured by default).
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._capture_locked(g, gx, gys, n_global, scale, dp, opt, capture_lock)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _capture_locked(self, g, gx, gys, n_global, scale, dp, opt, capture_lock):
+        from . import ops
+        x = gx
         with capture_lock, torch.cuda.graph(g, capture_error_mode='thread_local'):
             outs, loss_vals, dys = self._forward_backward(gx, gys, scale)
             if dp is not None:       # the exchange and the update stay outside: a collective in between
