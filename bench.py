@@ -477,8 +477,9 @@ def sub_host_visible(d, grid, cin, members, forwards):
         times.append(time.perf_counter() - t0)
     return {'value': members * forwards * 2 / min(times), 'unit': '6-h forecast steps/s', 'members': members,
             'series_bytes': int(out.nbytes), 's_per_call': min(times),
-            'note': 'DLWPNeuralNet.predict_timeseries(numpy) -> numpy; the series returns in member chunks into a pinned '
-                    'host array on a copy stream under the next chunk\'s hipGraph launch'}
+            'note': 'DLWPNeuralNet.predict_timeseries(numpy) -> numpy; the series returns in member chunks into a recycled '
+                    'pinned host array, one strided DMA per chunk on a copy stream under the next chunk\'s hipGraph launch; '
+                    'the next chunk\'s input is staged and uploaded meanwhile'}
 
 
 def sub_layer1_nominal(net, members):
