@@ -871,8 +871,9 @@ int plan_step(dlwp_handle_t h, const dlwp_options& o, int cu_count, dlwp_shape4 
     const ConvKernelEntry& e = r.entries[i];
     if (!e.dual) continue;
     if (o.forced_cfg >= 0 && o.forced_cfg != i) continue;
-    // as the gates instances: the epilogue wants waves, not tile size (4 x 32 tiles, two fragments per wave)
-    const double c = (double)dlwp_ceil_div(ys.h, e.th) * e.th * dlwp_ceil_div(ys.w, e.tw) * e.tw * (e.th == 4 ? 0.85 : 1.0);
+    // padded pixels; between equals the 8 x 32 tiles (four fragments per wave: each weight fragment read from LDS feeds four
+    // MFMAs instead of two -- the matrix loop is LDS-bandwidth bound): 0.104 vs 0.111 ms at 8 members of config 4, 0.408 vs 0.424 at 32
+    const double c = (double)dlwp_ceil_div(ys.h, e.th) * e.th * dlwp_ceil_div(ys.w, e.tw) * e.tw * (e.th == 8 ? 0.9 : 1.0);
     if (best < 0 || c < best_cost) {
       best = i;
       best_cost = c;

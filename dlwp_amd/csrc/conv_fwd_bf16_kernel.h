@@ -470,7 +470,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const unsigned ch = (unsigned)(g * F + hb);
-          zpre[i][g] = __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, (ok && DLWP_KNOCK != 3) ? ((ch >> 3) * hw + pixv[i]) * 16u + (ch & 4u) * 2u : DROP, 0, 0);
+          if constexpr (C::DUAL) zpre[i][g] = (u32x2){0u, 0u};      // both convolutions of the step are in the accumulators
+          else zpre[i][g] = __builtin_amdgcn_raw_buffer_load_b64(z_rsrc, (ok && DLWP_KNOCK != 3) ? ((ch >> 3) * hw + pixv[i]) * 16u + (ch & 4u) * 2u : DROP, 0, 0);
         }
         cpre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                 cp_rsrc, (ok && DLWP_KNOCK != 3) ? (((unsigned)hb >> 3) * hw + pixv[i]) * 32u + ((unsigned)hb & 4u) * 4u : DROP, 0, 0));
