@@ -1,7 +1,7 @@
 // conv_bwd.hip -- Conv2D backward: data gradient (re-using the forward implicit-GEMM kernel on flipped / transposed
 // weights) and weight gradient (conv_wgrad_kernel.h).  These are the backward halves of the Keras train step that
 // DLWPNeuralNet.fit / fit_generator drive (DLWP/model/models.py:188-228; layers of examples/train.py:159-219).
-#include "conv_wgrad_kernel.h"
+#include "conv_wgrad_cb_kernel.h"
 #include <mutex>
 #include <vector>
 
@@ -38,6 +38,13 @@ const WgradKernelEntry k_wgrad[] = {
     // Winograd F(2x2,3x3) weight gradient (conv_wgrad_kernel.h)
     WGRAD_ENTRY_W(1, 8, 32, 2, 4), WGRAD_ENTRY_W(1, 4, 32, 2, 4), WGRAD_ENTRY_W(1, 4, 48, 2, 4), WGRAD_ENTRY_W(1, 4, 16, 2, 4),
     WGRAD_ENTRY_W(2, 8, 32, 2, 4), WGRAD_ENTRY_W(2, 4, 32, 2, 4), WGRAD_ENTRY_W(2, 4, 48, 2, 4), WGRAD_ENTRY_W(2, 4, 36, 2, 3),
+    // r3 -- channel-block Winograd weight gradient (conv_wgrad_cb_kernel.h): TH TW, 16-channel input groups x cout groups per
+    // workgroup, cout fragments per wave
+    WGRAD_ENTRY_CB(4, 32, 4, 2, 2), WGRAD_ENTRY_CB(8, 16, 4, 2, 2),   // 64 x 64 channels, 8 waves
+    WGRAD_ENTRY_CB(4, 32, 2, 2, 2), WGRAD_ENTRY_CB(8, 16, 2, 2, 2),   // 32 x 64, 4 waves
+    WGRAD_ENTRY_CB(4, 32, 4, 2, 1), WGRAD_ENTRY_CB(8, 16, 4, 2, 1),   // 64 x 32, 8 waves
+    WGRAD_ENTRY_CB(4, 32, 2, 2, 1),                                   // 32 x 32, 4 waves
+    WGRAD_ENTRY_CB(4, 32, 2, 4, 1), WGRAD_ENTRY_CB(8, 16, 2, 4, 1),   // 32 x 64, 8 waves
 };
 constexpr int N_WGRAD = (int)(sizeof(k_wgrad) / sizeof(k_wgrad[0]));
 char g_wg_prepared[N_WGRAD] = {0};
@@ -78,7 +85,18 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
     if (e.wino && e.th >= 8) pen *= 1.3;         // measured: the 8-row Winograd tiles spill registers at 2 waves per SIMD
     if (e.pack && e.cib > 8) pen *= 1.2;         // measured: the 8-channel packed instance is 1.25x the 16-channel one
     if (e.nt == 4 && e.tw == 32) pen *= 1.15;    // measured: 59 % matrix-pipe use where the 48-wide tiles reach 70 %
-    const double c = tiles * co_tiles * ci_groups * (t_mfma + 0.6 * 22.0 * loads + 1500.0 / resident) * pen;
+    double c = tiles * co_tiles * ci_groups * (t_mfma + 0.6 * 22.0 * loads + 1500.0 / resident) * pen;
+    if (e.wino == 3) {
+      // channel-block form: every wave issues 8 quads x 16 (9 on an up-sampled source) positions x (cout fragments per wave)
+      // MFMAs per tile, two waves per SIMD; measured against the instances above on the config-3 layers at 8 and 64 samples
+      // (tools/tune_wgrad.py, profiles/r3_wgrad_cb_sweep_*.txt): 0.85 x their time where the channel block is full, and the
+      // two-fragment waves without the up-sampled source's 9 positions pay for 256 registers (staged values spilled)
+      if (Cin < 16 || Cout < 16) continue;
+      const double frw = (double)e.nt * (e.cib / 16) / e.waves;   // cout fragments per wave
+      const bool ups9 = cd->src_mode == DLWP_SRC_UPSAMPLE2 && (cd->halo.top & 1) && (cd->halo.left & 1);
+      c = tiles * co_tiles * ci_groups * e.waves * (8.0 * (ups9 ? 9.0 : 16.0) * frw * 32.0 / 4.0) * 1.25;
+      if (frw > 1 && !ups9) c *= 1.12;
+    }
     if (best < 0 || c < best_cost) {
       best = i;
       best_cost = c;

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/wg
+timeout 1500 python -m pytest tests -q -x -m gpu > gpurun_out/wg/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/wg/pytest.log
+for b in 64 8; do python tools/bench_train.py --batch $b --steps 40 --warmup 20 2>/dev/null | tail -1 | cut -c1-330; done
+python tools/bench_reduce_jobs.py --batch 64 2>&1 | tail -4

@@ -28,6 +28,9 @@ def unet_layers(cin, h, w):
         # ... and as the inference plan runs them: MaxPooling2D(2) in the epilogue (name ends with 'o')
         ('L1o', cin, 32, 3, 2, 0, h, w),
         ('L2o', 32, 64, 3, 1, 0, h // 2, w // 2),
+        # the decoder layers as both plans restate them on their low-resolution source
+        ('L5r', 64, 32, 3, 1, 0, h // 2, w // 2),
+        ('L6r', 32, 4 * cin, 3, 1, 0, h // 2, w // 2),
     ]
 
 
