@@ -19,6 +19,14 @@
 #pragma once
 #include "conv_wgrad_kernel.h"
 
+// (p, q) -> (p + q, p - q) in one packed add (op_sel broadcasts p into both halves of the first operand and q into both of
+// the second, neg_hi flips the second one's high half)
+__device__ __forceinline__ f32x2 pk_sum_diff(f32x2 pq) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(pq));
+  return r;
+}
+
 template <int TH_, int TW_, int CIG_, int COG_, int NT_, bool WUPS_ = false>
 struct WgCbCfg {
   static constexpr int TH = TH_, TW = TW_, CIG = CIG_, COG = COG_, NT = NT_;
@@ -223,11 +231,12 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
     //      its true value, s = (1, 1, 1, -1) -- no negations in the loop, the same bits (products and sums are sign-symmetric)
 #pragma unroll
     for (int q = 0; q < C::NQW; ++q) {
-      if (more) {
+      if (more) {   // all loads are out after quad LQ - 1: the last ones have the remaining quads to land
+        constexpr int LQ = C::NQW - 2;
 #pragma unroll
-        for (int ci = q * C::XPT / C::NQW; ci < (q + 1) * C::XPT / C::NQW; ++ci) load_x(ci);
+        for (int ci = (q * C::XPT + LQ - 1) / LQ; ci < ((q + 1) * C::XPT + LQ - 1) / LQ && ci < C::XPT; ++ci) load_x(ci);
 #pragma unroll
-        for (int k = q * C::NZ4 / C::NQW; k < (q + 1) * C::NZ4 / C::NQW; ++k) load_z(k);
+        for (int k = (q * C::NZ4 + LQ - 1) / LQ; k < ((q + 1) * C::NZ4 + LQ - 1) / LQ && k < C::NZ4; ++k) load_z(k);
       }
       __builtin_amdgcn_sched_barrier(0);
       // (the lane's LDS offsets are re-derived from an opaque copy of the lane id in every quad: four instructions, against
@@ -238,52 +247,56 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
       const int tx0 = (4 * q) % C::TXN, ty0 = (4 * q) / C::TXN;   // (a quad never straddles a tile row: TXN % 4 == 0)
       const int r0 = 2 * ty0, c0 = 2 * (tx0 + (ln >> 4));
       const float* xa = xs + (cg * 16 + (ln & 15)) * C::PSX + r0 * C::LC + c0 + e_al;
-      float d[4][4], tc[4][4], V[4][4];
+      // V = B^T d B on column pairs in packed fp32 (conv_fwd_kernel.h: 16 v_pk_add_f32 instead of 32 adds), |A dY A^T| in 6
+      f32x2 d2[4][2], t2[4][2], v2[4][2];   // rows as (columns 0 1 | columns 2 3)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[i][j] = xa[i * C::LC + j];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {   // B^T d
-        tc[0][j] = d[0][j] - d[2][j];
-        tc[1][j] = d[1][j] + d[2][j];
-        tc[2][j] = d[2][j] - d[1][j];
-        tc[3][j] = d[1][j] - d[3][j];
+      for (int i = 0; i < 4; ++i) {
+        d2[i][0] = (f32x2){xa[i * C::LC + 0], xa[i * C::LC + 1]};
+        d2[i][1] = (f32x2){xa[i * C::LC + 2], xa[i * C::LC + 3]};
+        t2[i][0] = pk_wino_t01(d2[i][0], d2[i][1]);   // d B, one patch row: (d0 - d2, d1 + d2 | d2 - d1, d1 - d3)
+        t2[i][1] = pk_wino_t23(d2[i][0], d2[i][1]);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {   // (B^T d) B
-        V[i][0] = tc[i][0] - tc[i][2];
-        V[i][1] = tc[i][1] + tc[i][2];
-        V[i][2] = tc[i][2] - tc[i][1];
-        V[i][3] = tc[i][1] - tc[i][3];
+      for (int h = 0; h < 2; ++h) {                   // B^T (d B)
+        v2[0][h] = pk_sub(t2[0][h], t2[2][h]);
+        v2[1][h] = pk_add(t2[1][h], t2[2][h]);
+        v2[2][h] = pk_sub(t2[2][h], t2[1][h]);
+        v2[3][h] = pk_sub(t2[1][h], t2[3][h]);
       }
+      f32x2 rw[C::NT][4], sd[C::NT][4];
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) {
         const float* zb = zs + ((og * C::NT + nt) * 16 + (ln & 15)) * C::PSZ + r0 * C::TW + c0;
-        const float y00 = zb[0], y01 = zb[1], y10 = zb[C::TW], y11 = zb[C::TW + 1];
-        // |A dY|: rows (y0), (y0 + y1), (y0 - y1), (y1); then each row (p, q) -> (p, p + q, p - q, q)
-        const float rp[4] = {y00, y00 + y10, y00 - y10, y10}, rq[4] = {y01, y01 + y11, y01 - y11, y11};
+        // |A dY|: rows (y0), (y0 + y1), (y0 - y1), (y1) as pairs (left, right); then each row (p, q) -> (p, p + q, p - q, q)
+        rw[nt][0] = (f32x2){zb[0], zb[1]};
+        rw[nt][3] = (f32x2){zb[C::TW], zb[C::TW + 1]};
+        rw[nt][1] = pk_add(rw[nt][0], rw[nt][3]);
+        rw[nt][2] = pk_sub(rw[nt][0], rw[nt][3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sd[nt][i] = pk_sum_diff(rw[nt][i]);
+      }
+      // every transform of the quad is done before its first MFMA: the packed adds are inline asm, which the compiler's
+      // hazard recogniser does not count as vector writes -- an MFMA reading such a result in the next slot got the old
+      // register contents (measured: errors of the data's own magnitude) -- so the wait states are set here
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 1");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float m4[4] = {rp[i], rp[i] + rq[i], rp[i] - rq[i], rq[i]};
+          const float m4[4] = {rw[nt][i][0], sd[nt][i][0], sd[nt][i][1], rw[nt][i][1]};
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (!(C::WUPS && (i == 2 || j == 2)))
               acc[(i * 4 + j) * C::NT + nt] =
-                  __builtin_amdgcn_mfma_f32_16x16x4f32(V[i][j], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(v2[i][j >> 1][j & 1], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
         }
-      }
       __builtin_amdgcn_sched_barrier(0);
     }
     DLWP_WG_T(5);
   }
 
-#ifdef DLWP_PHASE_TIMING
-  if (a.dbg && threadIdx.x == 0) {
-    for (int k = 0; k < 7; ++k) a.dbg[(long long)blockIdx.x * 8 + k] = wg_ph[k];
-    a.dbg[(long long)blockIdx.x * 8 + 7] = t_end - t_begin;
-  }
-#endif
   // ---- one partial slab per split: dg = G^T dU G per (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
   float* slab = a.slabs + (long long)split * 9 * a.Cin * a.Cout;
 #pragma unroll
@@ -313,6 +326,14 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
       }
     }
   }
+#ifdef DLWP_PHASE_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  DLWP_WG_T(7);   // slab transform + stores issued
+  if (a.dbg && threadIdx.x == 0) {
+    for (int k = 0; k < 8; ++k) a.dbg[(long long)blockIdx.x * 16 + k] = wg_ph[k];
+    a.dbg[(long long)blockIdx.x * 16 + 8] = t_end - t_begin;
+  }
+#endif
 }
 
 // 256 registers per wave: two waves per SIMD (8-wave workgroups: one per CU; 4-wave workgroups: two)

@@ -35,8 +35,8 @@ static void run(const char* what, int N, int Cin, int Cout, int H, int W, int ta
   a.pad_top = 1; a.pad_left = 1; a.mode_h = DLWP_PAD_ZERO; a.mode_w = DLWP_PAD_WRAP; a.src_mode = DLWP_SRC_DIRECT;
   a.splits = splits; a.ci_groups = ci_groups; a.co_tiles = co_tiles;
   long long* dbg;
-  hipMalloc(&dbg, sizeof(long long) * 8 * grid);
-  hipMemset(dbg, 0, sizeof(long long) * 8 * grid);
+  hipMalloc(&dbg, sizeof(long long) * 16 * grid);
+  hipMemset(dbg, 0, sizeof(long long) * 16 * grid);
   if (C::LDS_BYTES > 64 * 1024)
     hipFuncSetAttribute((const void*)conv2d_wgrad_wino_cb_f32<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
   a.dbg = nullptr;
@@ -51,19 +51,20 @@ static void run(const char* what, int N, int Cin, int Cout, int H, int W, int ta
   a.dbg = dbg;
   hipLaunchKernelGGL((conv2d_wgrad_wino_cb_f32<C>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, 0, a);
   hipDeviceSynchronize();
-  std::vector<long long> h(8 * (size_t)grid);
+  std::vector<long long> h(16 * (size_t)grid);
   hipMemcpy(h.data(), dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-  double ph[7] = {0, 0, 0, 0, 0, 0, 0}, tiles = 0;
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tiles = 0;
   for (int b = 0; b < grid; ++b) {
-    for (int k = 0; k < 7; ++k) ph[k] += (double)h[b * 8 + k];
-    tiles += (double)h[b * 8 + 7];
+    for (int k = 0; k < 8; ++k) ph[k] += (double)h[b * 16 + k];
+    tiles += (double)h[b * 16 + 8];
   }
   printf("%s: grid %d x %d threads (LDS %d), %.1f tiles per block, %.4f ms per launch (untimed run)\n", what, grid, C::NTHREADS,
          C::LDS_BYTES, tiles / grid, ms);
   printf("   per tile: barrier(consumed) %.0f | staging incl. load wait %.0f | barrier(staged) %.0f | x loads issued %.0f | dz loads "
          "issued %.0f | quads %.0f   (MFMA floor per wave and tile: %d cycles)\n",
          ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, ph[6] / tiles, ph[5] / tiles, C::NQW * 16 * C::NT * 32);
-  printf("   first prefetch + prologue per block: %.0f\n", ph[0] / grid);
+  printf("   first prefetch + prologue per block: %.0f | slab epilogue per block: %.0f | launch = %.0f cycles at 2.4 GHz\n", ph[0] / grid,
+         ph[7] / grid, ms * 2.4e6);
   hipFree(x); hipFree(dz); hipFree(slabs); hipFree(dbg);
 }
 
