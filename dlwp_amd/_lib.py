@@ -161,6 +161,8 @@ _sig('dlwp_act_bwd_bias_grad', [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
 _sig('dlwp_pool_act_bwd_bias_grad', [_vp, _vp, _vp, _vp, _vp, Shape4, _i, _vp, _sz, _i, _vp])
 _sig('dlwp_mse_mae_workspace', [_vp], _sz)
 _sig('dlwp_mse_mae', [_vp, _vp, _vp, _sz, _vp, _vp, ctypes.c_float, _vp, _sz, _i, _vp])
+_sig('dlwp_mse_mae_phase_workspace', [_i], _sz)
+_sig('dlwp_mse_mae_phase', [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _sz, _i, _vp])
 _sig('dlwp_loss_workspace', [_vp, _i, _i], _sz)
 _sig('dlwp_loss_custom', [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, ctypes.c_float, _vp, _sz, _i, _vp])
 _sig('dlwp_adam_keras', [_vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 5 + [ctypes.c_longlong, ctypes.c_float, _vp])

@@ -176,11 +176,12 @@ class Executor(object):
         return out
 
     # -- eager forward ----------------------------------------------------------------------------------------------- #
-    def run(self, x, outs=None, prepared=None, skip_phasew=False):
+    def run(self, x, outs=None, prepared=None, skip_phasew=False, skip_ops=()):
         """x: device tensor (n, ...) matching the model input; returns the list of output tensors (stored layout).
         prepared: {op index: tensor of ops.conv2d_prepare} -- those convolutions do not transform their weights again;
         skip_phasew: the derived kernels (plan.phase_params) are already up to date (the training step builds them, and every
-        prepared form, in front of the forward)."""
+        prepared form, in front of the forward); skip_ops: op indices left out (the training step takes its loss on the phase
+        channels of a restated output layer: no depth-to-space pass, the output tensor stays unwritten)."""
         from . import ops
         n = x.shape[0]
         x = x.reshape((n,) + self.plan._in_store)
@@ -194,7 +195,7 @@ class Executor(object):
                 return x
             return outs[-2 - i]
         for k, (op, d) in enumerate(zip(self.plan.ops, self._descriptors())):
-            if op.kind == 'phasew' and skip_phasew:
+            if (op.kind == 'phasew' and skip_phasew) or k in skip_ops:
                 continue
             src, dst = res(op.src), res(op.dst)
             if op.kind == 'conv' and op.src2 is not None:          # a whole ConvLSTM2D step (dlwp_convlstm_step_fwd)

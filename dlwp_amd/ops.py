@@ -717,6 +717,21 @@ def mse_mae(y_pred, y_true, out2, dy=None, loss_weight=1.0, ws_key=None):
     return out2
 
 
+def mse_mae_phase(y_phase, y_true, out2, dz=None, db=None, loss_weight=1.0, ws_key=None):
+    """dlwp_mse_mae on the phase channels (n, 4f, h, w) of a restated output layer against the target (n, f, 2h, 2w); dz
+    (phase layout) and db (4f: the sums of dz) are optional outputs."""
+    _check_f32(y_phase, y_true, out2, dz, db)
+    n, f4, hh, ww = y_phase.shape
+    f = f4 // 4
+    if f4 != 4 * f or tuple(y_true.shape) != (n, f, 2 * hh, 2 * ww):
+        raise ValueError('mse_mae_phase: phase tensor %r does not match the target %r' % (tuple(y_phase.shape), tuple(y_true.shape)))
+    h = _lib.handle(_dev(y_phase))
+    ws = workspace(y_phase.device, _lib.lib.dlwp_mse_mae_phase_workspace(f), ws_key)
+    _lib.check(_lib.lib.dlwp_mse_mae_phase(h, _ptr(y_phase), _ptr(y_true), n, f, hh, ww, _ptr(out2), _ptr(dz), _ptr(db),
+                                           float(loss_weight), _ptr(ws), ws.numel(), _lib.F32, _stream(y_phase)))
+    return out2
+
+
 def loss_custom(y_pred, y_true, stats7, dy=None, loss_weight=1.0, mean=None, row_weights=None, kind=0, regularize=0):
     """The reference's custom losses (include/dlwp_hip.h: dlwp_loss_custom).  y: (n, c, h, w) device tensors."""
     _check_f32(y_pred, y_true, stats7, dy, mean, row_weights)

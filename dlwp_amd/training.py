@@ -112,6 +112,14 @@ def flatten_parameters(model):
 # trainer
 # ------------------------------------------------------------------------------------------------------------------ #
 
+class _PhaseGrad(object):
+    """The loss gradient of an output the plan produces as phase channels + depth-to-space, in phase layout: the gradient of
+    plan buffer `buf` (written by convolution op `conv_k`); db: the bias gradient of the phase channels, or None."""
+
+    def __init__(self, buf, conv_k, dz, db):
+        self.buf, self.conv_k, self.dz, self.db = buf, conv_k, dz, db
+
+
 class Trainer(object):
     def __init__(self, model):
         self.model = model
@@ -149,6 +157,7 @@ class Trainer(object):
         self.dp = getattr(model, '_dp', None)
         self._grad_bufs = {}
         self._loss_out = None
+        self._phase_out = None        # _phase_outputs(): outputs whose loss is taken on the phase channels
         self._loss_consts = None      # device copies of a custom loss's climatology / latitude weights
         self._params_dirty = False    # set by Model.set_weights / load: replicas re-align at the next collective step
         self._graphs = {}             # (n_local, n_global) -> captured training step (see _graph_step)
@@ -271,10 +280,12 @@ class Trainer(object):
     def _forward_loss(self, x, ys, want_grad, weight_scale=1.0, prep=None):
         """Returns (outs, loss table [n_out, 7] on device: col 0 custom-loss value, 1 mse, 2 mae, dys or None)."""
         from . import ops
+        phase = self._phase_outputs()
+        skip = tuple(k for k, _, _ in phase.values())
         if prep is not None:
-            outs = self.model.train_executor.run(x, prepared=prep['fwd'], skip_phasew=True)
+            outs = self.model.train_executor.run(x, prepared=prep['fwd'], skip_phasew=True, skip_ops=skip)
         else:
-            outs = self.model.train_executor.run(x)
+            outs = self.model.train_executor.run(x, skip_ops=skip)
         n_out = len(outs)
         if self._loss_out is None or self._loss_out.shape[0] != n_out:
             self._loss_out = torch.zeros((n_out, 7), dtype=torch.float32, device=self.device)
@@ -285,8 +296,20 @@ class Trainer(object):
             self._loss_consts = (mean, roww)
         dys = []
         for o, (yp, yt) in enumerate(zip(outs, ys)):
-            dy = torch.empty_like(yp) if want_grad else None
             lw = self.loss_weights[o] * weight_scale
+            if o in phase:       # 'mse' on the phase channels of a restated output layer: no depth-to-space / space-to-depth pass
+                _, d2s, conv_k = phase[o]
+                lay = self.plan.ops[conv_k].layer
+                yph = self.model.train_executor.scratch(x.shape[0])[d2s.src]
+                dz = torch.empty_like(yph) if want_grad else None
+                db = None
+                if want_grad and lay.bias is not None and lay.activation == 'linear':     # db = the sums of dz: same pass
+                    db = torch.empty(yph.shape[1], dtype=torch.float32, device=self.device)
+                ops.mse_mae_phase(yph, yt.reshape((yph.shape[0], yph.shape[1] // 4, 2 * yph.shape[2], 2 * yph.shape[3])),
+                                  self._loss_out[o, 1:3], dz, db, lw, ws_key=('mse', o) if prep is not None else None)
+                dys.append(_PhaseGrad(d2s.src, conv_k, dz, db) if want_grad else None)
+                continue
+            dy = torch.empty_like(yp) if want_grad else None
             if spec is None:
                 ops.mse_mae(yp, yt, self._loss_out[o, 1:3], dy, lw, ws_key=('mse', o) if prep is not None else None)
             else:
@@ -301,6 +324,28 @@ class Trainer(object):
                 ops.loss_custom(yp, yt, self._loss_out[o], dy, lw * spec.scale, mean, roww, spec.kind, spec.regularize)
             dys.append(dy)
         return outs, self._loss_out, dys
+
+    def _phase_outputs(self):
+        """{output index: (index of its 'd2s' op, that op, index of the convolution in front)} for outputs the plan restates as
+        phase channels + depth-to-space (plan.py) and whose loss is the plain 'mse': the step then takes loss,
+        gradient and bias gradient on the phase channels (ops.mse_mae_phase).  DLWP_PHASE_LOSS=0 keeps the separate passes."""
+        if self._phase_out is None:
+            found = {}
+            if self.loss_kind != 'custom' and os.environ.get('DLWP_PHASE_LOSS', '1') != '0':
+                ops_ = self.plan.ops
+                for k, op in enumerate(ops_):
+                    if op.kind != 'd2s' or op.dst >= 0 or op.dst == P.STATE_IN or op.out_c_off != 0:
+                        continue
+                    o = -2 - op.dst
+                    writers = [j for j, w in enumerate(ops_) if w.dst == op.src]
+                    readers = [j for j, r in enumerate(ops_) if r.src == op.src and j != k]
+                    store = self.plan.output_store[o] if 0 <= o < len(self.plan.output_store) else None
+                    if (len(writers) == 1 and not readers and ops_[writers[0]].kind == 'conv' and
+                            ops_[writers[0]].wparam is not None and store is not None and store[0] == op.xs[0] and
+                            sum(1 for w in ops_ if w.dst == op.dst) == 1):
+                        found[o] = (k, op, writers[0])
+            self._phase_out = found
+        return self._phase_out
 
     # -- kernel regularisers (keras.regularizers.l2 on the ConvLSTM2D kernel, examples/train.py:154) --------------------- #
     def _regularized(self):
@@ -418,7 +463,14 @@ class Trainer(object):
                 grads[buf] = g
             return g
 
+        phase_db = {}        # convolution op index -> bias gradient of its phase channels, already summed with the loss
         for o, dy in enumerate(dys):
+            if isinstance(dy, _PhaseGrad):     # the gradient arrives on the phase channels: the 'd2s' op has no adjoint to run
+                grads[dy.buf] = dy.dz
+                written[dy.buf] = [(0, dy.dz.shape[1])]
+                if dy.db is not None:
+                    phase_db[dy.conv_k] = dy.db
+                continue
             grads[P.OUT(o)] = dy
             written[P.OUT(o)] = [(0, dy.shape[1])]
 
@@ -495,11 +547,13 @@ class Trainer(object):
                 if derived:                # gradients of the derived kernels, folded back onto the layer's own
                     pp = plan.phase_params[op.wparam]
                     dw2 = torch.empty(tuple(kern.shape), dtype=torch.float32, device=self.device)
-                    db2 = torch.empty(n_out, dtype=torch.float32, device=self.device) if lay.bias is not None else None
+                    have_db = k in phase_db
+                    db2 = phase_db[k] if have_db else (
+                        torch.empty(n_out, dtype=torch.float32, device=self.device) if lay.bias is not None else None)
 
-                    def derived_grads(src=src, dz=dz, dw2=dw2, db2=db2, d=d, xs=xs, n_out=n_out, key=key):
+                    def derived_grads(src=src, dz=dz, dw2=dw2, db2=db2, d=d, xs=xs, n_out=n_out, key=key, have_db=have_db):
                         ops.conv2d_bwd_weight(src, dz, dw2, d, xs, ws_key=key('wgrad'))
-                        if db2 is not None:
+                        if db2 is not None and not have_db:
                             ops.bias_grad(dz, db2, n_out, ws_key=key('bias'))
                     on_side(derived_grads)
 

@@ -277,6 +277,14 @@ int    dlwp_pool_act_bwd_bias_grad(dlwp_handle_t, const void* y, const void* dp,
 size_t dlwp_mse_mae_workspace(dlwp_handle_t);
 int    dlwp_mse_mae(dlwp_handle_t, const void* y_pred, const void* y_true, size_t n, void* out2, void* dy,
                     float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* dlwp_mse_mae taken on the PHASE channels of a restated output layer (dlwp_phase_weights: y_phase (n, 4f, h, w), output
+ * pixel (2i+a, 2j+b) of field co in channel (2a+b) f + co) against the target y_true (n, f, 2h, 2w): out2 as above;
+ * dz_phase (nullable, (n, 4f, h, w)) = what dlwp_space_to_depth2 makes of dy; db4f (nullable, 4f floats) = its sums over
+ * (n, h, w), the bias gradient of a linear layer.  One pass instead of dlwp_depth_to_space2 + dlwp_mse_mae +
+ * dlwp_space_to_depth2 + dlwp_bias_grad (the train step of examples/train.py's 5x5 output layer, DLWP/model/models.py:188-228). */
+size_t dlwp_mse_mae_phase_workspace(int f);
+int    dlwp_mse_mae_phase(dlwp_handle_t, const void* y_phase, const void* y_true, int n, int f, int h, int w, void* out2,
+                          void* dz_phase, void* db4f, float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream);
 /* the reference's custom losses, on the device (values + gradient, no host round trip):
  *   kind 0: mean((w (yp-yt))^2)                           -- latitude_weighted_loss(mse) (DLWP/custom.py:956-991)
  *   kind 1: regularizer - ACC,  ACC = mean(PT)/sqrt(mean(P^2) mean(T^2)), P = w*yp - mean, T = w*yt - mean

@@ -200,3 +200,60 @@ def test_folded_step_launch_count():
     assert len(prep['bwd']) == n_conv - 1                  # every layer but the first has a data gradient
     assert len(prep['fwd']) >= 4                           # the Winograd / packed-N layers of the forward
     assert ('cuda', torch.cuda.current_device(), ('wgrad', max(k for k in prep['bwd']))) in ops._workspaces
+
+
+@pytest.mark.parametrize('n,f,h,w', [(3, 4, 8, 12), (5, 1, 7, 9), (8, 4, 44, 90)])
+def test_loss_on_phase_channels_equals_the_separate_passes(n, f, h, w):
+    """dlwp_mse_mae_phase == dlwp_depth_to_space2 -> dlwp_mse_mae -> dlwp_space_to_depth2 -> dlwp_bias_grad on the same data
+    (sums in a different fixed order: float32 round-off), with and without the optional outputs."""
+    from dlwp_amd import ops
+    rng = np.random.default_rng(n * 100 + f)
+    yph = dev(rng.standard_normal((n, 4 * f, h, w)).astype(np.float32))
+    yt = dev(rng.standard_normal((n, f, 2 * h, 2 * w)).astype(np.float32))
+    full = ops.depth_to_space2(yph, f)
+    out_ref, dy = torch.zeros(2, device='cuda'), torch.empty_like(full)
+    ops.mse_mae(full, yt, out_ref, dy, 0.7)
+    dz_ref = ops.space_to_depth2(dy, f)
+    db_ref = torch.empty(4 * f, device='cuda')
+    ops.bias_grad(dz_ref, db_ref, 4 * f)
+    out, dz, db = torch.zeros(2, device='cuda'), torch.full_like(yph, float('nan')), torch.empty(4 * f, device='cuda')
+    ops.mse_mae_phase(yph, yt, out, dz, db, 0.7)
+    assert torch.allclose(out, out_ref, rtol=2e-6, atol=0)
+    assert torch.allclose(dz, dz_ref, rtol=1e-6, atol=0)
+    assert torch.allclose(db, db_ref, rtol=1e-4, atol=1e-7)
+    want = float(((full.double() - yt.double()) ** 2).mean())
+    assert float(out[0]) == pytest.approx(want, rel=2e-6)
+    out2 = torch.zeros(2, device='cuda')
+    ops.mse_mae_phase(yph, yt, out2)                       # value only (test_on_batch)
+    assert torch.equal(out2, out)
+
+
+def test_step_with_the_loss_on_phase_channels_equals_the_step_with_separate_passes(monkeypatch):
+    """The U-Net's restated 5x5 output layer: loss, gradient and bias gradient taken on its phase channels (default) against
+    DLWP_PHASE_LOSS=0 (depth-to-space, loss, space-to-depth, bias gradient as four launches) -- the same numbers to float32
+    round-off, eager and as a captured graph; evaluate() takes the same route."""
+    rng = np.random.default_rng(18)
+    cs = (4, 16, 24)
+    layers = unet_layers(cs)
+    x = rng.standard_normal((6,) + cs).astype(np.float32)
+    y = rng.standard_normal((6,) + cs).astype(np.float32)
+    res = {}
+    for graph in ('0', '1'):
+        for phase in ('1', '0'):
+            monkeypatch.setenv('DLWP_TRAIN_GRAPH', graph)
+            monkeypatch.setenv('DLWP_PHASE_LOSS', phase)
+            d = _build(layers, time_dim=2)
+            _weights_of(d.model, np.random.default_rng(9))
+            tr = d.model._trainer
+            logs = [d.model.train_on_batch(x, y) for _ in range(4)]
+            logs.append(d.model.test_on_batch(x, y))
+            torch.cuda.synchronize()
+            assert bool(tr._phase_outputs()) == (phase == '1')
+            res[(graph, phase)] = (logs, tr.flat_grads.cpu().numpy().copy(), d.model.get_weights())
+    for graph in ('0', '1'):
+        a, b = res[(graph, '1')], res[(graph, '0')]
+        for la, lb in zip(a[0], b[0]):
+            assert np.allclose(la, lb, rtol=2e-5, atol=1e-7), (la, lb)
+        assert np.abs(a[1] - b[1]).max() <= 5e-6 * np.abs(b[1]).max()
+        for wa, wb in zip(a[2], b[2]):
+            assert np.abs(wa - wb).max() <= 5e-6

@@ -1,8 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/wg
-python tools/_wg_chk.py 2>&1 | grep -v amdgpu.ids | cut -c1-60
-timeout 120 tools/microbench/wgrad_cb_phase_timing.bin > gpurun_out/wg/phase.txt 2>&1; cat gpurun_out/wg/phase.txt
-timeout 900 python -m pytest tests/test_gpu_model.py -q -x -k "weight_gradient or backward_kernels" > gpurun_out/wg/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/wg/pytest.log
-for b in 64 8; do timeout 600 python tools/tune_wgrad.py --batch $b --layers L2p,L3p,L4,L5r,L6r > gpurun_out/wg/sweep_b$b.txt 2>&1; done
-grep -A4 "^L" gpurun_out/wg/sweep_b64.txt
+timeout 1500 python -m pytest tests -q -x -m gpu > gpurun_out/wg/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/wg/pytest.log | cut -c1-300
 for b in 64 8; do python tools/bench_train.py --batch $b --steps 40 --warmup 20 2>/dev/null | tail -1 | cut -c1-330; done
+for b in 64 8; do DLWP_PHASE_LOSS=0 python tools/bench_train.py --batch $b --steps 40 --warmup 20 2>/dev/null | tail -1 | cut -c1-330; done

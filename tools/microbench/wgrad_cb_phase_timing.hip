@@ -11,9 +11,10 @@
 void dlwp_set_error(const char*, ...) {}
 
 template <class C>
-static void run(const char* what, int N, int Cin, int Cout, int H, int W, int target_blocks) {
+static void run(const char* what, int N, int Cin, int Cout, int H, int W, int target_blocks, bool ups = false) {
   WgradArgs a{};
-  size_t xe = (size_t)N * Cin * H * W, ze = (size_t)N * Cout * H * W;
+  const int Hs = ups ? H / 2 : H, Ws = ups ? W / 2 : W;   // ups: the source is stored at half resolution (UpSampling2D fused)
+  size_t xe = (size_t)N * Cin * Hs * Ws, ze = (size_t)N * Cout * H * W;
   float *x, *dz, *slabs;
   const int ci_groups = (Cin + C::CIX - 1) / C::CIX, co_tiles = (Cout + C::ZC - 1) / C::ZC;
   a.tiles_h = (H + C::TH - 1) / C::TH; a.tiles_w = (W + C::TW - 1) / C::TW;
@@ -30,9 +31,9 @@ static void run(const char* what, int N, int Cin, int Cout, int H, int W, int ta
   hipMemcpy(x, hx.data(), xe * 4, hipMemcpyHostToDevice);
   hipMemcpy(dz, hz.data(), ze * 4, hipMemcpyHostToDevice);
   a.x = x; a.dz = dz; a.slabs = slabs;
-  a.N = N; a.Cin = Cin; a.Hs = H; a.Ws = W; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cout = Cout;
+  a.N = N; a.Cin = Cin; a.Hs = Hs; a.Ws = Ws; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cout = Cout;
   a.in_c_off = 0; a.in_c_total = Cin; a.dz_c_off = 0; a.dz_c_total = Cout;
-  a.pad_top = 1; a.pad_left = 1; a.mode_h = DLWP_PAD_ZERO; a.mode_w = DLWP_PAD_WRAP; a.src_mode = DLWP_SRC_DIRECT;
+  a.pad_top = 1; a.pad_left = 1; a.mode_h = DLWP_PAD_ZERO; a.mode_w = DLWP_PAD_WRAP; a.src_mode = ups ? DLWP_SRC_UPSAMPLE2 : DLWP_SRC_DIRECT;
   a.splits = splits; a.ci_groups = ci_groups; a.co_tiles = co_tiles;
   long long* dbg;
   hipMalloc(&dbg, sizeof(long long) * 16 * grid);
@@ -62,7 +63,7 @@ static void run(const char* what, int N, int Cin, int Cout, int H, int W, int ta
          C::LDS_BYTES, tiles / grid, ms);
   printf("   per tile: barrier(consumed) %.0f | staging incl. load wait %.0f | barrier(staged) %.0f | x loads issued %.0f | dz loads "
          "issued %.0f | quads %.0f   (MFMA floor per wave and tile: %d cycles)\n",
-         ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, ph[6] / tiles, ph[5] / tiles, C::NQW * 16 * C::NT * 32);
+         ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, ph[6] / tiles, ph[5] / tiles, C::NQW * (C::WUPS ? 9 : 16) * C::NT * 32);
   printf("   first prefetch + prologue per block: %.0f | slab epilogue per block: %.0f | launch = %.0f cycles at 2.4 GHz\n", ph[0] / grid,
          ph[7] / grid, ms * 2.4e6);
   hipFree(x); hipFree(dz); hipFree(slabs); hipFree(dbg);
@@ -74,6 +75,8 @@ int main() {
   run<WgCbCfg<4, 32, 2, 4, 1>>("layer 2, 32x64 block, 8 waves", 64, 32, 64, 44, 90, 256);
   run<WgCbCfg<8, 16, 4, 2, 2>>("layer 3 weight gradient 64->128 @22x45, batch 64, 64x64 block", 64, 64, 128, 22, 45, 256);
   run<WgCbCfg<4, 32, 4, 2, 2>>("layer 4-like 128->64 @44x90 (plain source), 64x64 block", 64, 128, 64, 44, 90, 256);
+  run<WgCbCfg<4, 32, 4, 2, 2, true>>("layer 4 weight gradient 128->64 @44x90 on the up-sampled 22x45 source (9 positions), 64x64 block", 64, 128, 64, 44, 90, 256, true);
+  run<WgCbCfg<4, 32, 2, 4, 1, true>>("layer 4, 32x64 block, 8 waves", 64, 128, 64, 44, 90, 256, true);
   run<WgCbCfg<4, 32, 4, 2, 2>>("64->64 @44x88 (aligned rows: pixel-quad dz loads), 64x64 block", 64, 64, 64, 44, 88, 256);
   return 0;
 }
