@@ -425,9 +425,23 @@ class Trainer(object):
                     fn()
             del wq[:]
 
+        # (r3, eager steps: every weight gradient forks as soon as its operands exist -- the two-batch rule above was made for
+        #  forks inside a captured graph, which is single-stream now; batch 64: the last layers' weight gradients no longer pile
+        #  up behind the end of the chain.  DLWP_WGRAD_FORKS=batch keeps the two batches)
+        each = os.environ.get('DLWP_WGRAD_FORKS', 'each') != 'batch'
+
         def on_side(fn):
             if sides is None:
                 return fn()
+            if each:
+                st = sides[queued[0] % len(sides)]
+                queued[0] += 1
+                st.wait_stream(main)
+                if st not in used:
+                    used.append(st)
+                with torch.cuda.stream(st):
+                    fn()
+                return None
             wq.append(fn)
             queued[0] += 1
             if queued[0] == (n_wgrad + 1) // 2:

@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/wg
-timeout 1500 python -m pytest tests -q -x -m gpu > gpurun_out/wg/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/wg/pytest.log | cut -c1-300
-for b in 64 8; do python tools/bench_train.py --batch $b --steps 40 --warmup 20 2>/dev/null | tail -1 | cut -c1-330; done
-for b in 64 8; do DLWP_PHASE_LOSS=0 python tools/bench_train.py --batch $b --steps 40 --warmup 20 2>/dev/null | tail -1 | cut -c1-330; done
+timeout 900 python -m pytest tests/test_gpu_train_fold.py tests/test_gpu_parallel.py tests/test_gpu_model.py -q -x -m gpu > gpurun_out/wg/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/wg/pytest.log | cut -c1-200
