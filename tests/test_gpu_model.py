@@ -698,6 +698,47 @@ def test_conv_weight_gradient_full_size_properties():
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), float(y.double().abs().sum()) * 1e-3)       # adjoint of the forward conv
 
 
+@pytest.mark.parametrize('cin,cout,h,w,src,n', [(64, 128, 22, 45, 0, 8), (128, 64, 22, 45, 1, 4), (32, 64, 44, 90, 0, 4),
+                                                (64, 32, 44, 90, 0, 3)])
+def test_channel_block_weight_gradient_full_size_properties(cin, cout, h, w, src, n):
+    """The config-3 U-Net's Winograd weight gradients at their full grids (csrc/conv_wgrad_cb_kernel.h: odd widths -> element
+    loads, 90-wide rows -> ragged last pixel quad, the up-sampled source's 9-position form): additivity over the batch (other
+    splits, other tile walks), linearity in dz, the adjoint identity against the forward kernel, and a float64 oracle on a
+    corner of the kernel tensor (two input x three output channels: cheap at this size)."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(cin + cout + src)
+    x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32)).cuda()
+    ho, wo = (2 * h, 2 * w) if src == 1 else (h, w)
+    dz1 = torch.from_numpy(rng.standard_normal((n, cout, ho, wo)).astype(np.float32)).cuda()
+    dz2 = torch.from_numpy(rng.standard_normal((n, cout, ho, wo)).astype(np.float32)).cuda()
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_LINEAR, src_mode=src)
+
+    def dw_of(xx, dz):
+        out = torch.empty((3, 3, cin, cout), dtype=torch.float32, device='cuda')
+        ops.conv2d_bwd_weight(xx, dz, out, cd, _lib.Shape4(xx.shape[0], cin, h, w))
+        return out
+    a, b = dw_of(x, dz1), dw_of(x, dz2)
+    scale = float(a.abs().max())
+    assert float((dw_of(x, dz1 + dz2) - (a + b)).abs().max()) <= 2e-5 * scale * 2
+    assert float((dw_of(x, 2 * dz1) - 2 * a).abs().max()) == 0.0
+    k = n // 2
+    halves = dw_of(x[:k].contiguous(), dz1[:k].contiguous()) + dw_of(x[k:].contiguous(), dz1[k:].contiguous())
+    assert float((halves - a).abs().max()) <= 2e-5 * scale
+    wt = torch.from_numpy(np_ref.glorot_uniform((3, 3, cin, cout), rng)).cuda()
+    y = ops.conv2d(x, wt, None, cd)
+    lhs = float((y.double() * dz1.double()).sum())
+    rhs = float((wt.double() * a.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), float(y.double().abs().sum()) * 1e-3)
+    # float64 oracle on channels (0, cin - 1) x (0, 17, cout - 1)
+    ci_s, co_s = [0, cin - 1], [0, 17, cout - 1]
+    xs64 = x[:, ci_s].double().cpu().numpy()
+    xt = np_ref.upsample2(xs64) if src == 1 else xs64
+    xp = np_ref.pad2d_modes(xt, (1, 1, 1, 1), 0, 1)
+    _, dw_ref, _ = np_ref.conv2d_grads(xp, np.zeros((3, 3, 2, 3)), dz1[:, co_s].double().cpu().numpy(), 1)
+    got = a.cpu().numpy()[:, :, ci_s][:, :, :, co_s]
+    assert np.abs(got - dw_ref).max() <= 3e-5 * max(1., np.abs(dw_ref).max())
+
+
 def test_fused_activation_backward_and_bias_gradient_equal_the_two_separate_kernels():
     """dlwp_act_bwd_bias_grad == dlwp_act_bwd followed by dlwp_bias_grad: dz bit for bit, db to float32 rounding (fixed
     but differently ordered partial sums), on a channel window, with vector (hw % 4 == 0) and scalar planes, in place."""

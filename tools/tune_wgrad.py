@@ -56,7 +56,7 @@ def main():
         rows.sort(key=lambda r: r[0])
         print('%s wgrad %d->%d k%d d%d src%d out %dx%d batch %d  (%.1f GFLOP)' % (name, cin, cout, k, dil, src, ys.h, ys.w,
                                                                              a.batch, flops / 1e9))
-        for ms, i, c in rows[:8]:
+        for ms, i, c in rows[:14]:
             tag = ('heuristic -> cfg %d' % _lib.lib.dlwp_conv2d_wgrad_pick_config(_lib.handle(0), xs, cd)) if c is None else 'th=%d tw=%d nt=%d waves=%d lds=%d' % (c[2], c[3], c[4], c[5], c[6])
             print('   cfg %3d %-40s : %7.3f ms  %6.1f TF' % (i, tag, ms, flops / ms / 1e9))
 
