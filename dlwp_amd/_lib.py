@@ -166,6 +166,7 @@ _sig('dlwp_mse_mae_phase', [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, ctypes
 _sig('dlwp_loss_workspace', [_vp, _i, _i], _sz)
 _sig('dlwp_loss_custom', [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, ctypes.c_float, _vp, _sz, _i, _vp])
 _sig('dlwp_adam_keras', [_vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 5 + [ctypes.c_longlong, ctypes.c_float, _vp])
+_sig('dlwp_copy_many', [_vp, _vp, _vp, _vp, _i, _vp])
 _sig('dlwp_adam_keras_dev', [_vp, _vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 5 + [_vp, _vp, ctypes.c_float, _vp])
 _sig('dlwp_sgd_keras', [_vp, _vp, _vp, _vp, _sz] + [ctypes.c_float] * 3 + [ctypes.c_longlong, ctypes.c_float, _vp])
 _sig('dlwp_axpby', [_vp, _vp, _vp, _sz, ctypes.c_float, ctypes.c_float, _vp])

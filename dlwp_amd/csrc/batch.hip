@@ -223,7 +223,50 @@ int dlwp_reduce_defer(dlwp_handle_t h, const float* src, float* dst, long long n
   return 1;
 }
 
+namespace {
+struct CopyTable {
+  const float* src[8];
+  float* dst[8];
+  long long n[8];
+  int vec4[8];
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(const CopyTable t) {
+  const int j = blockIdx.y;
+  const long long n = t.n[j];
+  if (t.vec4[j]) {
+    const float4* s = (const float4*)t.src[j];
+    float4* d = (float4*)t.dst[j];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (long long)gridDim.x * 256) d[i] = s[i];
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) t.dst[j][i] = t.src[j][i];
+  }
+}
+}  // namespace
+
 extern "C" {
+
+int dlwp_copy_many(dlwp_handle_t h, const void* const* srcs, void* const* dsts, const size_t* floats, int count, void* stream) {
+  DLWP_CHECK_ARG(h && srcs && dsts && floats && count >= 0 && count <= 8, "dlwp_copy_many: null pointer or more than 8 copies");
+  if (count == 0) return DLWP_OK;
+  CopyTable t;
+  long long most = 0;
+  for (int i = 0; i < count; ++i) {
+    DLWP_CHECK_ARG(floats[i] == 0 || (srcs[i] && dsts[i]), "dlwp_copy_many: null source or destination");
+    t.src[i] = (const float*)srcs[i];
+    t.dst[i] = (float*)dsts[i];
+    t.n[i] = (long long)floats[i];
+    t.vec4[i] = floats[i] % 4 == 0 && (((uintptr_t)srcs[i] | (uintptr_t)dsts[i]) & 15) == 0;
+    const long long items = t.vec4[i] ? t.n[i] / 4 : t.n[i];
+    if (items > most) most = items;
+  }
+  long long blocks = (most + 255) / 256;
+  const long long cap = (long long)h->cu_count * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  copy_many_kernel<<<dim3((unsigned)blocks, (unsigned)count), 256, 0, (hipStream_t)stream>>>(t);
+  DLWP_LAUNCH_CHECK("copy_many_kernel");
+  return DLWP_OK;
+}
 
 int dlwp_prepare_begin(dlwp_handle_t h) {
   DLWP_CHECK_ARG(h != nullptr, "dlwp_prepare_begin: null handle");

@@ -769,6 +769,23 @@ def sgd_keras(p, vel, g, iteration, lr=0.01, momentum=0.0, decay=0.0, grad_scale
                                        int(iteration), grad_scale, _stream(p)))
 
 
+def copy_many(pairs):
+    """[(src, dst), ...] (at most 8 contiguous float32 tensors of equal element counts per pair) copied by ONE launch."""
+    pairs = list(pairs)
+    if not pairs:
+        return
+    for s, d in pairs:
+        _check_f32(s, d)
+        if s.numel() != d.numel() or not s.is_contiguous() or not d.is_contiguous():
+            raise ValueError('copy_many: contiguous tensors of equal size, please')
+    k = len(pairs)
+    srcs = (ctypes.c_void_p * k)(*[s.data_ptr() for s, _ in pairs])
+    dsts = (ctypes.c_void_p * k)(*[d.data_ptr() for _, d in pairs])
+    cnt = (ctypes.c_size_t * k)(*[s.numel() for s, _ in pairs])
+    dst0 = pairs[0][1]
+    _lib.check(_lib.lib.dlwp_copy_many(_lib.handle(_dev(dst0)), srcs, dsts, cnt, k, _stream(dst0)))
+
+
 def axpby(x, y, a=1.0, b=1.0):
     """y <- a*x + b*y"""
     _check_f32(x, y)

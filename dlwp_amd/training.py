@@ -854,6 +854,7 @@ class Trainer(object):
     def _graph_step(self, x, ys, n_global, scale, dp):
         """Replays (capturing first, if needed) the step for this batch shape.  Returns the device loss table, or None when
         this shape has not been seen often enough yet (the caller then runs the step eagerly)."""
+        from . import ops
         opt = self.model.optimizer
         # the captured launches carry the optimizer's hyper-parameters as arguments: a changed rate (scheduler, callback,
         # load_model) must not replay the old ones
@@ -869,9 +870,12 @@ class Trainer(object):
             if len(self._graphs) >= 4:
                 self._graphs.clear()
             ent = self._graphs[key] = self._capture_step(x, ys, n_global, scale, dp)
-        ent['x'].copy_(x)
-        for dst, src in zip(ent['ys'], ys):
-            dst.copy_(src)
+        pairs = [(x, ent['x'])] + list(zip(ys, ent['ys']))
+        if len(pairs) <= 8 and all(s.is_contiguous() and s.dtype == torch.float32 and s.numel() == d.numel() for s, d in pairs):
+            ops.copy_many(pairs)            # the batch and its targets into the graph's buffers: one launch
+        else:
+            for s, d in pairs:
+                d.copy_(s.reshape(d.shape))
         if dp is None and isinstance(opt, Adam) and self._iter_shadow != opt.iterations:
             self._iter_dev.fill_(int(opt.iterations))          # (after load_model / a manual change / eager steps)
         ent['graph'].replay()

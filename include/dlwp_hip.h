@@ -308,6 +308,9 @@ int    dlwp_adam_keras_dev(dlwp_handle_t, void* p, void* m, void* v, const void*
 int    dlwp_sgd_keras(dlwp_handle_t, void* p, void* vel, const void* g, size_t n, float lr, float momentum, float decay,
                       long long iteration, float grad_scale, void* stream);
 int    dlwp_axpby(dlwp_handle_t, const void* x, void* y, size_t n, float a, float b, void* stream);   /* y = a*x + b*y */
+/* count <= 8 contiguous float32 copies dsts[i] <- srcs[i] (floats[i] elements each) in ONE launch: the batch and its targets
+ * on their way into the fixed buffers a captured training step reads (a device-to-device memcpy each before: ~5 us apiece). */
+int    dlwp_copy_many(dlwp_handle_t, const void* const* srcs, void* const* dsts, const size_t* floats, int count, void* stream);
 
 /* ---- a training step's weight-side helpers in ONE launch each (csrc/batch.hip).  Keras / TF run one kernel per op
  *      (the train step behind DLWP/model/models.py:188-228); at the 8 samples per GPU of an 8-way data-parallel config-3

@@ -257,3 +257,28 @@ def test_step_with_the_loss_on_phase_channels_equals_the_step_with_separate_pass
         assert np.abs(a[1] - b[1]).max() <= 5e-6 * np.abs(b[1]).max()
         for wa, wb in zip(a[2], b[2]):
             assert np.abs(wa - wb).max() <= 5e-6
+
+
+def test_copy_many_and_the_device_step_adam():
+    """dlwp_copy_many: several tensors (16-byte aligned or not, multiples of 4 or not) in one launch; dlwp_adam_keras_dev: the
+    update with the step number in device memory equals dlwp_adam_keras step for step, and advances the number itself."""
+    from dlwp_amd import ops
+    rng = np.random.default_rng(77)
+    srcs = [dev(rng.standard_normal(s).astype(np.float32)) for s in [(8, 4, 10, 12), (1001,), (3, 5)]]
+    srcs.append(dev(rng.standard_normal(260).astype(np.float32))[1:257])            # misaligned view
+    dsts = [torch.full_like(s, float('nan')) for s in srcs]
+    ops.copy_many(list(zip(srcs, dsts)))
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)
+    n = 70001
+    p0 = rng.standard_normal(n).astype(np.float32)
+    pa, ma, va = dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    pb, mb, vb = dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    it_dev, ticket = torch.full((1,), 3, dtype=torch.int64, device='cuda'), torch.zeros(1, device='cuda')
+    for step in range(3, 8):
+        g = dev(rng.standard_normal(n).astype(np.float32))
+        ops.adam_keras(pa, ma, va, g, step, lr=2e-3, decay=1e-3, grad_scale=0.5)
+        ops.adam_keras_dev(pb, mb, vb, g, it_dev, ticket, lr=2e-3, decay=1e-3, grad_scale=0.5)
+        assert int(it_dev) == step + 1
+        assert torch.equal(ma, mb) and torch.equal(va, vb)
+        assert torch.allclose(pa, pb, rtol=0, atol=1e-9)
