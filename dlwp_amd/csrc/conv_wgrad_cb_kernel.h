@@ -49,7 +49,7 @@ struct WgCbCfg {
   static constexpr int PSZ = P + (((2 - P % 32) % 32) + 32) % 32;
   static constexpr int NQW = P / 16;               // quads of 2x2-output tiles
   static constexpr int TYN = TH_ / 2, TXN = TW_ / 2;
-  static constexpr int X_FLOATS = CIX * PSX, Z_FLOATS = ZC * PSZ;
+  static constexpr int X_FLOATS = CIX * PSX + 2, Z_FLOATS = ZC * PSZ;   // + 2: the x planes start one column pair in (below)
   static constexpr int LDS_BYTES = (X_FLOATS + Z_FLOATS) * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
@@ -57,7 +57,13 @@ struct WgCbCfg {
 template <class C>
 __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;
+  // The x tile's GLOBAL column pairs start on an even source column (8-byte loads), which with an odd left halo is one column
+  // left of the first patch column.  In LDS the planes are shifted by that column instead, so that every 4 x 4 patch starts on
+  // an EVEN offset and is read as 8-byte pairs: lanes (ci, tile) = (l & 15, l >> 4) with plane stride 2 (mod 32) and tiles two
+  // floats apart then cover all 32 banks four times per ds_read_b64 -- the ideal; the 4-byte reads of an odd patch origin put
+  // all 64 lanes on 16 banks of one parity (4-way conflicts on all 16 reads of a quad: 6 k cycles of the CU's LDS pipe per
+  // tile, profiles/r3_wgrad_cb_phase_timing.txt).  The staging writes pay: two 4-byte halves where the shift is odd.
+  float* xs = lds + 2;
   float* zs = lds + C::X_FLOATS;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -92,7 +98,7 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
   const int xsub = __builtin_amdgcn_readfirstlane(tid / C::PG);
   const int xs_ = min(tid - xsub * C::PG, C::NPAIR - 1);   // surplus threads of a subgroup repeat its last pair
   const int x_lr = xs_ / C::LCH, x_lc = 2 * (xs_ - x_lr * C::LCH);
-  float* const x_dst = xs + xsub * C::XPT * C::PSX + x_lr * C::LC + x_lc;
+  float* const x_dst = xs + xsub * C::XPT * C::PSX + x_lr * C::LC + x_lc - e_al;
   //                     dz -- this thread's pixel quad and first channel; further items ZSTEP channels apart
   const int zq = tid % C::PZQ, zc0 = tid / C::PZQ;
   const int z_r = (zq * 4) / C::TW, z_c = zq * 4 - z_r * C::TW;
@@ -211,8 +217,10 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
     __syncthreads();   // previous tile consumed
     DLWP_WG_T(1);
 #pragma unroll
-    for (int ci = 0; ci < C::XPT; ++ci)
-      *(u32x2*)(x_dst + ci * C::PSX) = (u32x2){__builtin_bit_cast(unsigned, xv[ci][0]), __builtin_bit_cast(unsigned, xv[ci][1])};
+    for (int ci = 0; ci < C::XPT; ++ci) {
+      x_dst[ci * C::PSX] = xv[ci][0];
+      x_dst[ci * C::PSX + 1] = xv[ci][1];
+    }
 #pragma unroll
     for (int k = 0; k < C::NZ4; ++k) {
       float* d = z_dst + k * C::ZSTEP * C::PSZ;
@@ -246,13 +254,13 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
       asm volatile("" : "+v"(ln));
       const int tx0 = (4 * q) % C::TXN, ty0 = (4 * q) / C::TXN;   // (a quad never straddles a tile row: TXN % 4 == 0)
       const int r0 = 2 * ty0, c0 = 2 * (tx0 + (ln >> 4));
-      const float* xa = xs + (cg * 16 + (ln & 15)) * C::PSX + r0 * C::LC + c0 + e_al;
+      const float* xa = xs + (cg * 16 + (ln & 15)) * C::PSX + r0 * C::LC + c0;
       // V = B^T d B on column pairs in packed fp32 (conv_fwd_kernel.h: 16 v_pk_add_f32 instead of 32 adds), |A dY A^T| in 6
       f32x2 d2[4][2], t2[4][2], v2[4][2];   // rows as (columns 0 1 | columns 2 3)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        d2[i][0] = (f32x2){xa[i * C::LC + 0], xa[i * C::LC + 1]};
-        d2[i][1] = (f32x2){xa[i * C::LC + 2], xa[i * C::LC + 3]};
+        d2[i][0] = *(const f32x2*)(xa + i * C::LC);
+        d2[i][1] = *(const f32x2*)(xa + i * C::LC + 2);
         t2[i][0] = pk_wino_t01(d2[i][0], d2[i][1]);   // d B, one patch row: (d0 - d2, d1 + d2 | d2 - d1, d1 - d3)
         t2[i][1] = pk_wino_t23(d2[i][0], d2[i][1]);
       }
