@@ -190,46 +190,40 @@ __global__ __launch_bounds__(256) void mse_mae_partial_kernel(const float* __res
 // the same loss on a restated output layer's PHASE channels: yp (N, 4F, h, w) holds output pixel (2i + a, 2j + b)
 // of field co in channel (2a + b) F + co; yt is the target (N, F, 2h, 2w).  Sums as mse_mae_partial_kernel would take them on
 // the interleaved output; the gradient is written in phase layout (what dlwp_space_to_depth2 makes of dy), and the per-channel
-// sums of that gradient -- the bias gradient of a linear layer -- leave with it.  Block (co, s) owns slice s of the N h w source
-// pixels of field co: loss partials [(co * BIAS_SPLIT + s) * 2], bias partials [((2a + b) F + co) * BIAS_SPLIT + s].
+// sums of that gradient -- the bias gradient of a linear layer -- leave with it.  Block (c4, s) owns slice s of the N h w pixels
+// of phase channel c4 = (2a + b) F + co (one block per FIELD and slice was 256 blocks for the 4-field output: all memory latency,
+// 31 us at 64 samples): loss partials [(c4 * BIAS_SPLIT + s) * 2], bias partials [c4 * BIAS_SPLIT + s].
 __global__ __launch_bounds__(256) void mse_mae_phase_partial_kernel(const float* __restrict__ yp, const float* __restrict__ yt,
                                                                     float* __restrict__ dz, float* __restrict__ partial,
                                                                     float* __restrict__ bias_partial, int N, int F, int h, int w,
                                                                     float grad_scale) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  const int co = blockIdx.x, sidx = blockIdx.y;
-  const long long hw = (long long)h * w, per = (long long)N * hw;
-  const long long chunk = (per + BIAS_SPLIT - 1) / BIAS_SPLIT;
-  const long long lo = sidx * chunk, hi = lo + chunk < per ? lo + chunk : per;
-  float s2 = 0.f, s1 = 0.f, sb[4] = {0.f, 0.f, 0.f, 0.f};
-  for (long long e = lo + threadIdx.x; e < hi; e += 256) {
-    const int j = (int)(e % w);
-    const long long q = e / w;
-    const int i = (int)(q % h);
-    const long long n = q / h;
-    const long long pb = (n * 4 * F + co) * hw + (long long)i * w + j;
-    const float* t = yt + ((n * F + co) * 2 * h + 2 * i) * (2ll * w) + 2 * j;
-    const f2 t0 = *(const f2*)t, t1 = *(const f2*)(t + 2 * w);
-    const float tv[4] = {t0[0], t0[1], t1[0], t1[1]};
-#pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-      const float d = yp[pb + (long long)ph * F * hw] - tv[ph];
-      s2 += d * d;
-      s1 += fabsf(d);
-      const float g = grad_scale * d;
-      if (dz) dz[pb + (long long)ph * F * hw] = g;
-      sb[ph] += g;
-    }
+  const int c4 = blockIdx.x, sidx = blockIdx.y;
+  const int ph = c4 / F, co = c4 - ph * F, pa = ph >> 1, pb = ph & 1;
+  const long long hw = (long long)h * w;
+  const unsigned per = (unsigned)N * (unsigned)hw;      // (< 2^31: checked by the host -- 32-bit index arithmetic, no 64-bit divisions)
+  const unsigned chunk = (per + BIAS_SPLIT - 1) / BIAS_SPLIT;
+  const unsigned lo = sidx * chunk, hi = lo + chunk < per ? lo + chunk : per;
+  float s2 = 0.f, s1 = 0.f, sb = 0.f, dummy = 0.f;
+#pragma unroll 4
+  for (unsigned e = lo + threadIdx.x; e < hi; e += 256) {
+    const unsigned q = e / (unsigned)w;
+    const int j = (int)(e - q * (unsigned)w);
+    const long long n = q / (unsigned)h;
+    const int i = (int)(q - (unsigned)n * (unsigned)h);
+    const long long pi = (n * 4 * F + c4) * hw + (long long)i * w + j;
+    const float d = yp[pi] - yt[((n * F + co) * 2 * h + 2 * i + pa) * (2ll * w) + 2 * j + pb];
+    s2 += d * d;
+    s1 += fabsf(d);
+    const float g = grad_scale * d;
+    if (dz) dz[pi] = g;
+    sb += g;
   }
   block_sum2(s2, s1);
-  block_sum2(sb[0], sb[1]);
-  block_sum2(sb[2], sb[3]);
+  block_sum2(sb, dummy);
   if (threadIdx.x == 0) {
-    partial[(co * BIAS_SPLIT + sidx) * 2] = s2;
-    partial[(co * BIAS_SPLIT + sidx) * 2 + 1] = s1;
-    if (bias_partial)
-#pragma unroll
-      for (int ph = 0; ph < 4; ++ph) bias_partial[(ph * F + co) * BIAS_SPLIT + sidx] = sb[ph];
+    partial[(c4 * BIAS_SPLIT + sidx) * 2] = s2;
+    partial[(c4 * BIAS_SPLIT + sidx) * 2 + 1] = s1;
+    if (bias_partial) bias_partial[c4 * BIAS_SPLIT + sidx] = sb;
   }
 }
 
@@ -655,24 +649,24 @@ int dlwp_mse_mae(dlwp_handle_t h, const void* y_pred, const void* y_true, size_t
   return DLWP_OK;
 }
 
-size_t dlwp_mse_mae_phase_workspace(int f) { return (size_t)(f > 0 ? f : 0) * BIAS_SPLIT * (2 + 4) * sizeof(float); }
+size_t dlwp_mse_mae_phase_workspace(int f) { return (size_t)(f > 0 ? f : 0) * 4 * BIAS_SPLIT * (2 + 1) * sizeof(float); }
 
 int dlwp_mse_mae_phase(dlwp_handle_t h, const void* y_phase, const void* y_true, int n, int f, int hh, int ww, void* out2,
                        void* dz_phase, void* db4f, float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream) {
   DLWP_CHECK_ARG(h && y_phase && y_true && out2 && ws, "dlwp_mse_mae_phase: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n > 0 && f > 0 && hh > 0 && ww > 0, "dlwp_mse_mae_phase: bad dtype / shape");
-  DLWP_CHECK_ARG(((uintptr_t)y_true & 7) == 0, "dlwp_mse_mae_phase: the target must be 8-byte aligned");
+  DLWP_CHECK_ARG((long long)n * hh * ww < (1ll << 31), "dlwp_mse_mae_phase: more than 2^31 source pixels per channel");
   DLWP_CHECK_ARG(ws_bytes >= dlwp_mse_mae_phase_workspace(f), "dlwp_mse_mae_phase: workspace too small (%zu < %zu)", ws_bytes,
                  dlwp_mse_mae_phase_workspace(f));
   const double count = 4.0 * n * f * hh * ww;
   const float inv_n = (float)(1.0 / count);
   float* lp = (float*)ws;
-  float* bp = lp + (size_t)f * BIAS_SPLIT * 2;
+  float* bp = lp + (size_t)f * 4 * BIAS_SPLIT * 2;
   hipStream_t s = (hipStream_t)stream;
-  mse_mae_phase_partial_kernel<<<dim3(f, BIAS_SPLIT), 256, 0, s>>>((const float*)y_phase, (const float*)y_true, (float*)dz_phase,
+  mse_mae_phase_partial_kernel<<<dim3(4 * f, BIAS_SPLIT), 256, 0, s>>>((const float*)y_phase, (const float*)y_true, (float*)dz_phase,
                                                                     lp, db4f ? bp : nullptr, n, f, hh, ww,
                                                                     2.0f * loss_weight * inv_n);
-  const int blocks = f * BIAS_SPLIT;
+  const int blocks = 4 * f * BIAS_SPLIT;
   const int rd = dlwp_reduce_defer(h, lp, (float*)out2, 2, blocks, 1, 2, inv_n, 0, s);
   if (rd < 0) return rd;
   if (rd == 0) mse_mae_final_kernel<<<1, 256, 0, s>>>(lp, blocks, inv_n, (float*)out2);
