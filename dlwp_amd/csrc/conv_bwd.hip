@@ -2,6 +2,7 @@
 // weights) and weight gradient (conv_wgrad_kernel.h).  These are the backward halves of the Keras train step that
 // DLWPNeuralNet.fit / fit_generator drive (DLWP/model/models.py:188-228; layers of examples/train.py:159-219).
 #include "conv_wgrad_cb_kernel.h"
+#include "conv_wgrad_c4_kernel.h"
 #include <mutex>
 #include <vector>
 
@@ -45,6 +46,8 @@ const WgradKernelEntry k_wgrad[] = {
     WGRAD_ENTRY_CB(4, 32, 4, 2, 1), WGRAD_ENTRY_CB(8, 16, 4, 2, 1),   // 64 x 32, 8 waves
     WGRAD_ENTRY_CB(4, 32, 2, 2, 1),                                   // 32 x 32, 4 waves
     WGRAD_ENTRY_CB(4, 32, 2, 4, 1), WGRAD_ENTRY_CB(8, 16, 2, 4, 1),   // 32 x 64, 8 waves
+    // r3 -- at most 4 input channels: dz straight from memory into the B operand (conv_wgrad_c4_kernel.h)
+    WGRAD_ENTRY_C4(2, 8, 32), WGRAD_ENTRY_C4(1, 8, 32), WGRAD_ENTRY_C4(2, 4, 32), WGRAD_ENTRY_C4(1, 4, 32),
 };
 constexpr int N_WGRAD = (int)(sizeof(k_wgrad) / sizeof(k_wgrad[0]));
 char g_wg_prepared[N_WGRAD] = {0};
@@ -86,6 +89,10 @@ bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const
     if (e.pack && e.cib > 8) pen *= 1.2;         // measured: the 8-channel packed instance is 1.25x the 16-channel one
     if (e.nt == 4 && e.tw == 32) pen *= 1.15;    // measured: 59 % matrix-pipe use where the 48-wide tiles reach 70 %
     double c = tiles * co_tiles * ci_groups * (t_mfma + 0.6 * 22.0 * loads + 1500.0 / resident) * pen;
+    if (e.wino == 4) {   // the 4-channel streaming form: only what it was made for, and then always (tools/tune_wgrad.py)
+      if (Cin > 4) continue;
+      c *= 0.5;
+    }
     if (e.wino == 3) {
       // channel-block form: every wave issues 8 quads x 16 (9 on an up-sampled source) positions x (cout fragments per wave)
       // MFMAs per tile, two waves per SIMD; measured against the instances above on the config-3 layers at 8 and 64 samples
@@ -380,6 +387,13 @@ int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes) {
   const int v[6] = {e.ks, e.dil, e.th, e.tw, e.pack ? -e.pack : e.nt, e.waves};
   for (int k = 0; k < 6; ++k) info6[k] = v[k];
   if (lds_bytes) *lds_bytes = e.lds_bytes;
+  return DLWP_OK;
+}
+
+int dlwp_conv2d_wgrad_config_form(int i, int* cin_block, int* form) {
+  DLWP_CHECK_ARG(i >= 0 && i < N_WGRAD && cin_block && form, "dlwp_conv2d_wgrad_config_form: index out of range");
+  *cin_block = k_wgrad[i].cib;
+  *form = k_wgrad[i].wino;
   return DLWP_OK;
 }
 

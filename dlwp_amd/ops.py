@@ -804,5 +804,16 @@ def wgrad_configs():
     return out
 
 
+def wgrad_config_forms():
+    """[(input channels per workgroup, form)] per compiled weight-gradient instance; form 0 direct, 1 Winograd, 3 channel-block
+    Winograd, 4 the streaming form for at most 4 input channels."""
+    out = []
+    cib, form = ctypes.c_int(), ctypes.c_int()
+    for i in range(_lib.lib.dlwp_conv2d_wgrad_num_configs()):
+        _lib.check(_lib.lib.dlwp_conv2d_wgrad_config_form(i, ctypes.byref(cib), ctypes.byref(form)))
+        out.append((cib.value, form.value))
+    return out
+
+
 def force_wgrad_config(i):
     _lib.set_option(_lib.OPT_FORCE_WGRAD_CONFIG, int(i))

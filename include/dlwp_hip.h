@@ -225,6 +225,9 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* d
 int dlwp_conv2d_wgrad_num_configs(void);                                   /* tuning hooks, as for the forward */
 int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes);      /* {ks, dil, th, tw, cout_frags (< 0: packed-N
                                                                              * instance for cout <= -cout_frags), waves} */
+int dlwp_conv2d_wgrad_config_form(int i, int* cin_block, int* form);      /* input channels per workgroup; form 0 direct, 1
+                                                                             * Winograd, 3 channel-block Winograd, 4 the
+                                                                             * streaming form for <= 4 input channels */
 int dlwp_conv2d_wgrad_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd);   /* the heuristic's choice, -1: none */
 
 /* ---- DLWP.custom.RowConnected2D.call / row_conv2d (DLWP/custom.py:825-837, 840-896): a Conv2D whose filters are shared

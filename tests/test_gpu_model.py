@@ -789,14 +789,18 @@ def test_conv_weight_gradient_every_compiled_tile_configuration():
     from dlwp_amd import _lib, ops
     rng = np.random.default_rng(17)
     cfgs = ops.wgrad_configs()
+    forms = ops.wgrad_config_forms()
     geoms = [(3, 19, 50, 0), (2, 11, 21, 0), (2, 18, 44, 2), (2, 7, 13, 1)]      # (n, h, w stored, src_mode)
     cache = {}
     try:
         for i, (ks, dil, th, tw, nt, waves, lds) in enumerate(cfgs):
+            c4 = forms[i][1] == 4                                   # the streaming form: at most 4 input channels
             for gi, (n, h, w, src) in enumerate(geoms):
-                key = (ks, dil, gi, nt < 0)
+                key = (ks, dil, gi, nt < 0, c4)
                 if key not in cache:
                     cin, cout = (20, 36) if nt > 0 else (20, 3)     # packed-N instances: at most 4 output channels
+                    if c4:
+                        cin, cout = 3 + gi % 2, 36                  # 3 or 4 channels, a ragged second cout tile
                     x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
                     xs64 = np.asarray(x, np.float64)
                     xt = {0: xs64, 1: np_ref.upsample2(xs64), 2: np_ref.maxpool2(xs64)}[src]
