@@ -57,13 +57,15 @@ struct WgChoice {
   int idx, splits, nslabs, tiles_h, tiles_w, ci_groups, co_tiles;
 };
 
-bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const dlwp_conv2d* cd, WgChoice* out) {
+bool pick_wgrad(dlwp_handle_t h, int N, int Cin, int Cout, int Ho, int Wo, const dlwp_conv2d* cd, WgChoice* out,
+                int only_form = -1) {
   int best = -1;
   double best_cost = 0;
   for (int i = 0; i < N_WGRAD; ++i) {
     const WgradKernelEntry& e = k_wgrad[i];
     if (e.ks != cd->kh || e.ks != cd->kw || e.dil != cd->dil_h || e.dil != cd->dil_w) continue;
     if (h->opt.forced_wgrad >= 0 && i != h->opt.forced_wgrad) continue;
+    if (only_form >= 0 && e.wino != only_form) continue;
     if (e.pack && Cout > e.pack) continue;   // packed-N instances: at most 4 output channels
     const double tiles = (double)dlwp_ceil_div(Ho, e.th) * dlwp_ceil_div(Wo + (e.pack ? e.pack - 1 : 0), e.tw);
     const double co_tiles = dlwp_ceil_div(Cout, 16 * e.nt);
@@ -167,12 +169,13 @@ int dlwp_conv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d
     *bytes = b;
     return DLWP_OK;
   }
-  DLWP_CHECK_ARG(pass == 1, "dlwp_conv2d_bwd_workspace: pass must be 0 or 1");
+  DLWP_CHECK_ARG(pass == 1 || pass == 2, "dlwp_conv2d_bwd_workspace: pass must be 0, 1 or 2");
   WgChoice c;
-  if (!pick_wgrad(h, xs.n, xs.c, cd->cout, ys.h, ys.w, cd, &c))
+  if (!pick_wgrad(h, xs.n, xs.c, cd->cout, ys.h, ys.w, cd, &c, pass == 2 ? 4 : -1))
     DLWP_FAIL(DLWP_EUNSUPPORTED, "conv2d_bwd_weight: no kernel for %dx%d dilation %dx%d", cd->kh, cd->kw, cd->dil_h,
               cd->dil_w);
-  *bytes = align256((size_t)c.nslabs * wbytes);
+  // pass 2 (dlwp_conv2d_bwd_weight_pooled): the bias gradient's partials behind the slabs
+  *bytes = align256((size_t)c.nslabs * wbytes) + (pass == 2 ? align256((size_t)c.nslabs * cd->cout * sizeof(float)) : 0);
   return DLWP_OK;
 }
 
@@ -314,20 +317,22 @@ int dlwp_conv2d_bwd_data_prepared(dlwp_handle_t h, const void* dz, const void* p
 }
 
 // dw: (kh, kw, cin, cout) Keras HWIO.  accumulate != 0 adds to dw instead of overwriting (shared layers).
-int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
-                           const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+static int conv2d_bwd_weight_impl(dlwp_handle_t h, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
+                                  const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream,
+                                  const void* dpool, void* db, int act) {
   DLWP_CHECK_ARG(h && x && dz && dw && cd && ws, "dlwp_conv2d_bwd_weight: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_conv2d_bwd_weight: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(!cd->out_pool && !cd->out_d2s && !cd->lstm_f, "dlwp_conv2d_bwd_weight: out_pool / out_d2s / lstm_f descriptors are forward-only");
   dlwp_shape4 ys;
   if (dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return DLWP_EINVAL;
   WgChoice c;
-  if (!pick_wgrad(h, xs.n, xs.c, cd->cout, ys.h, ys.w, cd, &c))
-    DLWP_FAIL(DLWP_EUNSUPPORTED, "conv2d_bwd_weight: no kernel for %dx%d dilation %dx%d", cd->kh, cd->kw, cd->dil_h,
-              cd->dil_w);
+  if (!pick_wgrad(h, xs.n, xs.c, cd->cout, ys.h, ys.w, cd, &c, dpool ? 4 : -1))
+    DLWP_FAIL(DLWP_EUNSUPPORTED, "conv2d_bwd_weight: no kernel for %dx%d dilation %dx%d%s", cd->kh, cd->kw, cd->dil_h,
+              cd->dil_w, dpool ? " with the pooling backward in its loader" : "");
   const long long wn = (long long)cd->kh * cd->kw * xs.c * cd->cout;
-  DLWP_CHECK_ARG(ws_bytes >= (size_t)c.nslabs * wn * sizeof(float), "dlwp_conv2d_bwd_weight: workspace %zu < %zu", ws_bytes,
-                 (size_t)c.nslabs * wn * sizeof(float));
+  const size_t need = dpool ? align256((size_t)c.nslabs * wn * sizeof(float)) + (size_t)c.nslabs * cd->cout * sizeof(float)
+                            : (size_t)c.nslabs * wn * sizeof(float);
+  DLWP_CHECK_ARG(ws_bytes >= need, "dlwp_conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
   DLWP_CHECK_ARG(xs.n > 0, "dlwp_conv2d_bwd_weight: empty batch");
   // the kernel addresses a sample's channel window with 32-bit byte offsets
   DLWP_CHECK_ARG((long long)xs.c * xs.h * xs.w < (1ll << 29) && (long long)cd->cout * ys.h * ys.w < (1ll << 29),
@@ -369,13 +374,46 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void*
   a.splits = c.splits;
   a.ci_groups = c.ci_groups;
   a.co_tiles = c.co_tiles;
+  float* bias_part = nullptr;
+  if (dpool) {          // dz = the layer's OUTPUT here; the loader forms the gradient (conv_wgrad_c4_kernel.h, FUSE)
+    bias_part = (float*)((char*)ws + align256((size_t)c.nslabs * wn * sizeof(float)));
+    a.y = (const float*)dz;
+    a.dpool = (const float*)dpool;
+    a.bias_part = bias_part;
+    a.act = act;
+  }
   const int grid = c.ci_groups * c.co_tiles * c.splits;
   e.launch(a, grid, (hipStream_t)stream);
   DLWP_LAUNCH_CHECK("conv2d_wgrad_mfma_f32");
   // between dlwp_reductions_begin / _flush the slab sum is recorded and done with the other layers' in one launch
+  if (db) {
+    const int rb = dlwp_reduce_defer(h, bias_part, (float*)db, cd->cout, c.nslabs, 1, cd->cout, 1.0f, accumulate, (hipStream_t)stream);
+    if (rb < 0) return rb;
+    if (rb == 0) {
+      const int e2 = dlwp_launch_reduce_slabs(h, bias_part, (float*)db, cd->cout, c.nslabs, accumulate, (hipStream_t)stream);
+      if (e2 != DLWP_OK) return e2;
+    }
+  }
   const int rd = dlwp_reduce_defer(h, (const float*)ws, (float*)dw, wn, c.nslabs, 1, wn, 1.0f, accumulate, (hipStream_t)stream);
   if (rd != 0) return rd < 0 ? rd : DLWP_OK;
   return dlwp_launch_reduce_slabs(h, (float*)ws, (float*)dw, wn, c.nslabs, accumulate, (hipStream_t)stream);
+}
+
+int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
+                           const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  return conv2d_bwd_weight_impl(h, x, dz, dw, xs, cd, accumulate, dtype, ws, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+// The weight AND bias gradient of a layer whose only reader is MaxPooling2D(2) and whose data gradient nobody needs (the first
+// layer), from the layer's output y and the pooled tensor's gradient: dlwp_pool_act_bwd_bias_grad + dlwp_conv2d_bwd_weight without
+// the dz tensor in between.  DLWP_EUNSUPPORTED where no streaming instance fits (more than 4 input channels, not 3x3).
+int dlwp_conv2d_bwd_weight_pooled(dlwp_handle_t h, const void* x, const void* y, const void* dpool, void* dw, void* db,
+                                  dlwp_shape4 xs, const dlwp_conv2d* cd, int act, int accumulate, int dtype, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  DLWP_CHECK_ARG(dpool != nullptr, "dlwp_conv2d_bwd_weight_pooled: null pooled gradient");
+  DLWP_CHECK_ARG(act == DLWP_ACT_LINEAR || act == DLWP_ACT_TANH || act == DLWP_ACT_RELU,
+                 "dlwp_conv2d_bwd_weight_pooled: activation %d has no backward here", act);
+  return conv2d_bwd_weight_impl(h, x, y, dw, xs, cd, accumulate, dtype, ws, ws_bytes, stream, dpool, db, act);
 }
 
 int dlwp_conv2d_wgrad_num_configs(void) { return N_WGRAD; }

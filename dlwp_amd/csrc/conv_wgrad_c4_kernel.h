@@ -17,9 +17,14 @@
 #pragma once
 #include "conv_wgrad_kernel.h"
 
-template <int DIL_, int TH_, int TW_>
+template <int DIL_, int TH_, int TW_, bool FUSE_ = false>
 struct WgC4Cfg {
   static constexpr int DIL = DIL_, TH = TH_, TW = TW_;
+  // FUSE: the layer's only reader is MaxPooling2D(2) and nothing needs its data gradient (the first layer): dz is formed in the
+  // loader from the layer's output y and the pooled tensor's gradient -- dlwp_pool_act_bwd_bias_grad's arithmetic, ties
+  // included -- and never stored; the bias gradient's partial sums leave with the slabs
+  static constexpr bool FUSE = FUSE_;
+  static_assert(!FUSE_ || (TH_ % 2 == 0 && (TH_ * TW_ / 16 / 4) % 2 == 0), "pooling windows inside the tile, vertical group pairs per wave");
   static constexpr int CI = 4, NT = 2, MF = 3, WAVES = 4, NTHREADS = 256;
   static constexpr int LR = TH_ + 2 * DIL_, LC = TW_ + 2 * DIL_ + 2, LCH = LC / 2, NPAIR = LR * LCH;
   static_assert(NPAIR <= NTHREADS, "one column pair per thread");
@@ -89,6 +94,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
   const bool quad_z = (a.Wo & 3) == 0;
 
   float xv[C::CI][2];
+  float bsum[C::NT] = {0.f, 0.f};     // FUSE: this lane's share of the bias gradient
   int tw_i, th_i, n_i;
   {
     int q = t_begin;
@@ -135,6 +141,15 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
       }
     }
   };
+  // group k of this wave -> (row, first column) inside the tile.  FUSE: vertical pairs (k even = top row, k + 1 = the row below)
+  auto group_row = [&](int k) -> int {
+    if constexpr (C::FUSE) return 2 * ((wave * (C::GPW / 2) + k / 2) / C::GPR) + (k & 1);
+    else return (wave * C::GPW + k) / C::GPR;
+  };
+  auto group_col = [&](int k) -> int {
+    if constexpr (C::FUSE) return ((wave * (C::GPW / 2) + k / 2) % C::GPR) * 16;
+    else return ((wave * C::GPW + k) % C::GPR) * 16;
+  };
   if (t_begin < t_end) load_x_tile(n_i, th_i, tw_i);
   int buf = 0;
   for (int tile = t_begin; tile < t_end; ++tile, buf ^= 1) {
@@ -142,23 +157,68 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
     // ---- dz of this wave's groups, straight into registers: 16 bytes per lane, cout fragment and group.  (Requesting the
     //      NEXT tile's dz before this tile's MFMAs -- twice the registers -- was measured: 0.060 vs 0.056 ms at 64 samples; the
     //      four resident workgroups of a CU already cover the latency.)
-    const float* zp = a.dz + ((long long)n_cur * a.dz_c_total + a.dz_c_off + co0) * oplane;
+    const float* zp = (C::FUSE ? a.y : a.dz) + ((long long)n_cur * a.dz_c_total + a.dz_c_off + co0) * oplane;
     const __amdgpu_buffer_rsrc_t z_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)zp, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
+    const float* pp = C::FUSE ? a.dpool + ((long long)n_cur * a.Cout + co0) * ((a.Ho >> 1) * (a.Wo >> 1)) : a.dz;
+    const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)pp, 0, C::FUSE ? (unsigned)z_chans * (unsigned)((a.Ho >> 1) * (a.Wo >> 1)) * 4u : 0u, 0x00020000);
     f32x4 zv[C::GPW][C::NT];
+    if constexpr (!C::FUSE) {
 #pragma unroll
-    for (int k = 0; k < C::GPW; ++k) {
-      const int gi = wave * C::GPW + k;
-      const int prow = gi / C::GPR, pcol = (gi - prow * C::GPR) * 16 + 4 * (lane >> 4);
-      const int row = i0 + prow, col = j0 + pcol;
-      const int rem = a.Wo - col;                           // valid elements of the quad from here on
-      const bool ok = row < a.Ho && rem > 0;
+      for (int k = 0; k < C::GPW; ++k) {
+        const int prow = group_row(k), pcol = group_col(k) + 4 * (lane >> 4);
+        const int row = i0 + prow, col = j0 + pcol;
+        const int rem = a.Wo - col;                           // valid elements of the quad from here on
+        const bool ok = row < a.Ho && rem > 0;
 #pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt) {
-        const unsigned voff = ok ? (unsigned)(((nt * 16 + (lane & 15)) * (int)oplane + row * a.Wo + col)) * 4u : DROP;
-        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, voff, 0, 0));
+        for (int nt = 0; nt < C::NT; ++nt) {
+          const unsigned voff = ok ? (unsigned)(((nt * 16 + (lane & 15)) * (int)oplane + row * a.Wo + col)) * 4u : DROP;
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, voff, 0, 0));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zv[k][nt][r] = (quad_z || r < rem) ? v[r] : 0.f;
+          for (int r = 0; r < 4; ++r) zv[k][nt][r] = (quad_z || r < rem) ? v[r] : 0.f;
+        }
+      }
+    } else {
+      // groups come in vertical pairs (rows 2p, 2p + 1 of the same 16 columns): a lane holds both rows of its two pooling windows
+      // -- every element of y is loaded once -- and forms the gradient of all 8 pixels: the window's FIRST maximum in row-major
+      // order takes dpool x act'(y) (maxpool2_bwd_kernel), everything else, an odd last row / column included, is zero
+      const int H2 = a.Ho >> 1, W2 = a.Wo >> 1;
+#pragma unroll
+      for (int k = 0; k < C::GPW; k += 2) {
+        const int prow = group_row(k), pcol = group_col(k) + 4 * (lane >> 4);
+        const int row = i0 + prow, col = j0 + pcol;             // row even (tiles start on even rows, pairs on even rows)
+        const bool okw = (row >> 1) < H2 && col < 2 * W2;
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) {
+          const unsigned voff = okw ? (unsigned)(((nt * 16 + (lane & 15)) * (int)oplane + row * a.Wo + col)) * 4u : DROP;
+          const f32x4 top = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, voff, 0, 0));
+          const f32x4 bot = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, okw ? voff + (unsigned)a.Wo * 4u : DROP, 0, 0));
+          const unsigned doff = okw ? (unsigned)(((nt * 16 + (lane & 15)) * (H2 * W2) + (row >> 1) * W2 + (col >> 1))) * 4u : DROP;
+          const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p_rsrc, doff, 0, 0));
+          const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p_rsrc, okw ? doff + 4u : DROP, 0, 0));
+#pragma unroll
+          for (int wdw = 0; wdw < 2; ++wdw) {
+            const float v[4] = {top[2 * wdw], top[2 * wdw + 1], bot[2 * wdw], bot[2 * wdw + 1]};
+            int arg = 0;
+            float m = v[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+              if (v[q] > m) {
+                m = v[q];
+                arg = q;
+              }
+            float g = wdw ? g1 : g0;
+            if (a.act == DLWP_ACT_TANH) g *= 1.f - m * m;
+            else if (a.act == DLWP_ACT_RELU) g = m > 0.f ? g : 0.f;
+            if (!(okw && (col >> 1) + wdw < W2)) g = 0.f;       // (no such window)
+            bsum[nt] += g;
+            zv[k][nt][2 * wdw] = arg == 0 ? g : 0.f;
+            zv[k][nt][2 * wdw + 1] = arg == 1 ? g : 0.f;
+            zv[k + 1][nt][2 * wdw] = arg == 2 ? g : 0.f;
+            zv[k + 1][nt][2 * wdw + 1] = arg == 3 ? g : 0.f;
+          }
+        }
       }
     }
     // ---- x tile -> LDS (the other buffer may still be read by a wave that is behind: one barrier per tile)
@@ -178,8 +238,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
     // ---- 16-pixel groups: 6 LDS reads (4 consecutive floats each) + 24 MFMAs
 #pragma unroll
     for (int k = 0; k < C::GPW; ++k) {
-      const int gi = wave * C::GPW + k;
-      const int prow = gi / C::GPR, pcol = (gi - prow * C::GPR) * 16;
+      const int prow = group_row(k), pcol = group_col(k);
       const float* xb = xs + prow * C::LC + pcol;
       float av[C::MF][4];
 #pragma unroll
@@ -196,6 +255,16 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
     }
   }
 
+  if constexpr (C::FUSE) {   // the four pixel-quad lanes of a channel -> one partial per (split, wave, channel)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) {
+      float v = bsum[nt];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int co = co0 + nt * 16 + (lane & 15);
+      if (lane < 16 && co < a.Cout) a.bias_part[(long long)(split * C::WAVES + wave) * a.Cout + co] = v;
+    }
+  }
   // ---- one partial slab per (split, wave)
   float* slab = a.slabs + (long long)(split * C::WAVES + wave) * 9 * a.Cin * a.Cout;
 #pragma unroll
@@ -214,6 +283,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
 
 template <class C>
 static void wgrad_c4_launch_thunk(const WgradArgs& a, int grid, hipStream_t s) {
+  if (a.dpool) {
+    typedef WgC4Cfg<C::DIL, C::TH, C::TW, true> CF;
+    hipLaunchKernelGGL((conv2d_wgrad_c4_f32<CF>), dim3(grid), dim3(CF::NTHREADS), CF::LDS_BYTES, s, a);
+    return;
+  }
   hipLaunchKernelGGL((conv2d_wgrad_c4_f32<C>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, s, a);
 }
 static int wgrad_c4_prepare() { return 0; }

@@ -28,6 +28,13 @@ struct WgradArgs {
   int in_c_off, in_c_total, dz_c_off, dz_c_total;
   int pad_top, pad_left, mode_h, mode_w, src_mode;
   int tiles_h, tiles_w, total_tiles, splits, ci_groups, co_tiles;
+  // conv_wgrad_c4_kernel.h, FUSE instances: dz is not stored -- it is MaxPooling2D(2)'s and the activation's backward of the
+  // pooled tensor's gradient, formed in the loader from y (this layer's output, laid out like dz) and dpool (N, Cout, Ho/2, Wo/2);
+  // its per-channel sums (the bias gradient) leave as [nslabs][Cout] partials
+  const float* y = nullptr;
+  const float* dpool = nullptr;
+  float* bias_part = nullptr;
+  int act = 0;
 #ifdef DLWP_PHASE_TIMING  // tools/microbench/wgrad_phase_timing.hip only: per-block sums of s_memtime differences, 8 per block
   long long* dbg = nullptr;
 #endif

@@ -662,6 +662,31 @@ def conv2d_bwd_weight(x, dz, dw, cd, xs, accumulate=False, ws_key=None):
     return dw
 
 
+def conv2d_bwd_weight_pooled_supported(xs, cd, dev_index=None):
+    """Can dlwp_conv2d_bwd_weight_pooled take this layer (3x3, at most 4 input channels)?"""
+    out = ctypes.c_size_t()
+    d = torch.cuda.current_device() if dev_index is None else dev_index
+    return _lib.lib.dlwp_conv2d_bwd_workspace(_lib.handle(d), xs, ctypes.byref(cd), 2, ctypes.byref(out)) == _lib.OK
+
+
+def conv2d_bwd_weight_pooled(x, y, dpool, dw, db, cd, xs, act, accumulate=False, ws_key=None):
+    """dw (and db, unless None) of a layer whose only reader is MaxPooling2D(2) and whose data gradient nobody needs, from its
+    output y and the pooled tensor's gradient dpool (n, cout, ho/2, wo/2): the gradient tensor in between is never stored
+    (include/dlwp_hip.h: dlwp_conv2d_bwd_weight_pooled)."""
+    _check_f32(x, y, dpool, dw, db)
+    n, cout, hp, wp = dpool.shape
+    if cout != cd.cout or not dpool.is_contiguous() or (hp, wp) != (y.shape[2] // 2, y.shape[3] // 2):
+        raise ValueError('conv2d_bwd_weight_pooled: pooled gradient %r does not match the layer output %r' %
+                         (tuple(dpool.shape), tuple(y.shape)))
+    d = _dev(x)
+    need = conv_bwd_workspace_bytes(d, xs, cd, 2)
+    ws = workspace(x.device, need, ws_key)
+    _lib.check(_lib.lib.dlwp_conv2d_bwd_weight_pooled(_lib.handle(d), _ptr(x), _ptr(y), _ptr(dpool), _ptr(dw), _ptr(db), xs,
+                                                     ctypes.byref(cd), int(act), int(bool(accumulate)), _lib.F32, _ptr(ws),
+                                                     ws.numel(), _stream(x)))
+    return dw
+
+
 def act_bwd(y, dy, act, out=None):
     _check_f32(y, dy)
     dz = out if out is not None else torch.empty_like(dy)

@@ -547,6 +547,20 @@ class Trainer(object):
                 n_out = op.conv_geometry[0]
                 fused_bias = (pooled_grad is None and lay.activation != 'linear' and lay.bias is not None and not acc and
                               not derived and gD.shape[1] == lay.filters and tuple(y.shape) == tuple(gD.shape))
+                if (pooled_grad is not None and op.src == P.STATE_IN and not acc and pooled_grad.is_contiguous() and
+                        os.environ.get('DLWP_WGRAD_POOLED', '1') != '0' and
+                        ops.conv2d_bwd_weight_pooled_supported(_lib.Shape4(n, op.xs[0], op.xs[1], op.xs[2]), d)):
+                    # the first layer under MaxPooling2D(2): nobody needs its data gradient, so the pooling + activation
+                    # backward is formed inside the weight gradient's loader and the gradient tensor is never stored
+                    gb = self._grad_view(lay, 'bias') if lay.bias is not None else None
+                    on_side(lambda src=src, y=y, pg=pooled_grad, lay=lay, gb=gb, d=d, act=op.act, key=key,
+                            xs=_lib.Shape4(n, op.xs[0], op.xs[1], op.xs[2]):
+                            ops.conv2d_bwd_weight_pooled(src, y, pg, self._grad_view(lay, 'kernel'), gb, d, xs, act,
+                                                         ws_key=key('wgrad')))
+                    touched_layers.add(id(lay))
+                    if isinstance(lay, L._ConvPart):
+                        touched_layers.add(id(lay.parent))
+                    continue
                 if pooled_grad is not None:    # the layer's only reader is MaxPooling2D(2): its backward rides along
                     fused_bias = lay.bias is not None
                     gD = ops.pool_act_bwd_bias_grad(y, pooled_grad, op.act,

@@ -222,6 +222,15 @@ int dlwp_conv2d_bwd_data_stored(dlwp_handle_t, const void* dz, const void* w, vo
                                 const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream);
 int dlwp_conv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* The weight AND bias gradient of a layer whose only reader is MaxPooling2D(2) and whose data gradient nobody needs (the first
+ * layer of the reference's networks, examples/train.py:159-170), from the layer's output y (laid out like dz above) and the
+ * POOLED tensor's gradient dpool (n, cout, Ho/2, Wo/2): what dlwp_pool_act_bwd_bias_grad + dlwp_conv2d_bwd_weight compute, without
+ * the gradient tensor in between (it is formed in the weight-gradient kernel's loader; ties as dlwp_maxpool2_bwd).  act:
+ * DLWP_ACT_LINEAR / TANH / RELU; db nullable.  Workspace: dlwp_conv2d_bwd_workspace(pass = 2).  DLWP_EUNSUPPORTED where no
+ * streaming instance fits (3x3, at most 4 input channels): the caller keeps the two calls.                                   */
+int dlwp_conv2d_bwd_weight_pooled(dlwp_handle_t, const void* x, const void* y, const void* dpool, void* dw, void* db,
+                                  dlwp_shape4 xs, const dlwp_conv2d* cd, int act, int accumulate, int dtype, void* ws,
+                                  size_t ws_bytes, void* stream);
 int dlwp_conv2d_wgrad_num_configs(void);                                   /* tuning hooks, as for the forward */
 int dlwp_conv2d_wgrad_config_info(int i, int* info6, int* lds_bytes);      /* {ks, dil, th, tw, cout_frags (< 0: packed-N
                                                                              * instance for cout <= -cout_frags), waves} */

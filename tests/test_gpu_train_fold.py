@@ -282,3 +282,62 @@ def test_copy_many_and_the_device_step_adam():
         assert int(it_dev) == step + 1
         assert torch.equal(ma, mb) and torch.equal(va, vb)
         assert torch.allclose(pa, pb, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,dil', [(3, 4, 32, 16, 24, 2), (2, 3, 36, 11, 21, 1), (4, 4, 32, 88, 180, 2), (2, 4, 16, 10, 36, 1)])
+def test_weight_gradient_with_the_pooling_backward_in_its_loader(n, cin, cout, h, w, dil):
+    """dlwp_conv2d_bwd_weight_pooled == dlwp_pool_act_bwd_bias_grad then dlwp_conv2d_bwd_weight (+ its bias gradient): the first
+    layer under MaxPooling2D(2) without the gradient tensor in between.  Ties inside windows (the first maximum takes the
+    gradient), odd rows / columns (no window: zero), ragged second cout tile, every activation."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(n * 7 + cout)
+    x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+    cd = ops.make_conv(cout, 3, 3, dil, ops.make_pad(dil, dil, dil, dil, 0, 1), ops.ACT_TANH)
+    xs = _lib.Shape4(n, cin, h, w)
+    assert ops.conv2d_bwd_weight_pooled_supported(xs, cd)
+    big = ops.make_conv(cout, 3, 3, dil, ops.make_pad(dil, dil, dil, dil, 0, 1), ops.ACT_TANH)
+    assert not ops.conv2d_bwd_weight_pooled_supported(_lib.Shape4(n, 8, h, w), big)          # more than 4 input channels
+    for act in (ops.ACT_TANH, ops.ACT_RELU, ops.ACT_LINEAR):
+        yv = np.tanh(rng.standard_normal((n, cout, h, w))).astype(np.float32)
+        yv[rng.random(yv.shape) < 0.3] = 0.25                      # plenty of ties inside windows
+        y = dev(yv)
+        dp = dev(rng.standard_normal((n, cout, h // 2, w // 2)).astype(np.float32))
+        db_ref = torch.empty(cout, device='cuda')
+        dz = ops.pool_act_bwd_bias_grad(y, dp, act, db_ref)
+        dw_ref = torch.empty((3, 3, cin, cout), device='cuda')
+        ops.conv2d_bwd_weight(x, dz, dw_ref, cd, xs)
+        dw, db = torch.full_like(dw_ref, float('nan')), torch.full_like(db_ref, float('nan'))
+        ops.conv2d_bwd_weight_pooled(x, y, dp, dw, db, cd, xs, act)
+        scale = max(1.0, float(dw_ref.abs().max()))
+        assert float((dw - dw_ref).abs().max()) <= 2e-5 * scale, (act, float((dw - dw_ref).abs().max()))
+        assert torch.allclose(db, db_ref, rtol=1e-4, atol=1e-4 * max(1.0, float(db_ref.abs().max())))
+        dw2 = torch.full_like(dw_ref, float('nan'))
+        ops.conv2d_bwd_weight_pooled(x, y, dp, dw2, None, cd, xs, act)          # without a bias
+        assert torch.equal(dw2, dw)
+
+
+def test_step_with_the_first_layers_pooling_backward_in_its_weight_gradient(monkeypatch):
+    """The U-Net's first layer (4 fields in, MaxPooling2D(2) behind it): DLWP_WGRAD_POOLED=0 keeps the separate
+    dlwp_pool_act_bwd_bias_grad launch -- the same step to float32 round-off, eager and captured."""
+    rng = np.random.default_rng(19)
+    cs = (4, 16, 24)
+    layers = unet_layers(cs)
+    x = rng.standard_normal((6,) + cs).astype(np.float32)
+    y = rng.standard_normal((6,) + cs).astype(np.float32)
+    res = {}
+    for graph in ('0', '1'):
+        for fused in ('1', '0'):
+            monkeypatch.setenv('DLWP_TRAIN_GRAPH', graph)
+            monkeypatch.setenv('DLWP_WGRAD_POOLED', fused)
+            d = _build(layers, time_dim=2)
+            _weights_of(d.model, np.random.default_rng(9))
+            logs = [d.model.train_on_batch(x, y) for _ in range(4)]
+            torch.cuda.synchronize()
+            res[(graph, fused)] = (logs, d.model._trainer.flat_grads.cpu().numpy().copy(), d.model.get_weights())
+    for graph in ('0', '1'):
+        a, b = res[(graph, '1')], res[(graph, '0')]
+        for la, lb in zip(a[0], b[0]):
+            assert np.allclose(la, lb, rtol=2e-5, atol=1e-7), (la, lb)
+        assert np.abs(a[1] - b[1]).max() <= 5e-6 * np.abs(b[1]).max()
+        for wa, wb in zip(a[2], b[2]):
+            assert np.abs(wa - wb).max() <= 5e-6
