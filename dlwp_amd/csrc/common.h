@@ -137,7 +137,7 @@ struct dlwp_lstm_io {
 };
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre = nullptr,
-                       const dlwp_lstm_io* lstm = nullptr);
+                       const dlwp_lstm_io* lstm = nullptr, void* y_pool = nullptr);
 // prepared weights of the Winograd / packed-N / bf16-MFMA families: floats needed for this layer (0 = the kernel reads HWIO), and
 // the kernel that builds them
 size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);

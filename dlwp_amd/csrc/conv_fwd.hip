@@ -660,7 +660,20 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
 }  // namespace (second part)
 
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
-                       const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre, const dlwp_lstm_io* lstm) {
+                       const dlwp_conv2d* cd_in, int dtype, hipStream_t s, const float* u_pre, const dlwp_lstm_io* lstm,
+                       void* y_pool) {
+  // y_pool (dlwp_conv2d_fwd_pool2): the instance is chosen as for the pooling epilogue -- same tiles, same cost -- and then stores
+  // BOTH tensors; only the direct family has that epilogue
+  dlwp_conv2d cd_pool;
+  const dlwp_conv2d* cd = cd_in;
+  if (y_pool) {
+    DLWP_CHECK_ARG(cd_in && !cd_in->out_pool && !cd_in->out_d2s && !cd_in->lstm_f && !(dtype & DLWP_COMPUTE_BF16) &&
+                       DLWP_DTYPE_IN(dtype) == DLWP_F32 && DLWP_DTYPE_OUT(dtype) == DLWP_F32,
+                   "dlwp_conv2d_fwd_pool2: float32, no other epilogue option");
+    cd_pool = *cd_in;
+    cd_pool.out_pool = 1;
+    cd = &cd_pool;
+  }
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;
@@ -691,6 +704,12 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   }
   Registry& r = registry();
   const ConvKernelEntry& e = r.entries[ci];
+  if (y_pool) {
+    if (is_wino(e) || is_bf16(e) || e.pack != 0 || !e.out_pool || lp.narrow >= 0)
+      DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd_pool2: this layer's kernel cannot store both tensors");
+    a.out_pool = 0;                 // (a.Hp / a.Wp stay: the pooled tensor's shape)
+    a.y2 = (float*)y_pool;
+  }
   auto ensure_prepared = [&](int idx) -> int {
     if (!r.prepared[idx]) {
       std::lock_guard<std::mutex> lock(g_prepare_mutex);
@@ -802,6 +821,14 @@ int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys
 int dlwp_conv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                     const dlwp_conv2d* cd, int dtype, void* stream) {
   return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream);
+}
+
+// y (n, out_c_total, ho, wo) AND its MaxPooling2D(2) image y_pool (n, out_c_total, ho/2, wo/2) from one launch: the training
+// forward of a layer under a pooling layer (the backward pass needs y).  DLWP_EUNSUPPORTED: keep dlwp_conv2d_fwd + dlwp_maxpool2_fwd.
+int dlwp_conv2d_fwd_pool2(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, void* y_pool, dlwp_shape4 xs,
+                          const dlwp_conv2d* cd, int dtype, void* stream) {
+  DLWP_CHECK_ARG(y_pool != nullptr, "dlwp_conv2d_fwd_pool2: null pooled output");
+  return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream, nullptr, nullptr, y_pool);
 }
 
 size_t dlwp_conv2d_prepared_bytes(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {

@@ -54,6 +54,9 @@ struct ConvArgs {
   const void* zadd = nullptr;
   const float* c_prev = nullptr;
   float* c_out = nullptr;
+  // dlwp_conv2d_fwd_pool2 (training forward of a layer under MaxPooling2D(2): the backward pass needs y, the next layer its
+  // pooled image): y_pool (N, out_c_total, Hp, Wp) written BESIDE y by the direct instances with a pooling epilogue
+  float* y2 = nullptr;
 #ifdef DLWP_PHASE_TIMING  // tools/microbench/wino_phase_timing.hip only: s_memtime stamps of wave 0, 8 per block
   long long* dbg = nullptr;
 #endif
@@ -462,10 +465,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_f32(const ConvArgs a
   // ---- epilogue: bias + activation, 4 consecutive pixels of one channel per lane
   act_dispatch(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
-    if (a.out_pool) {
-      // MaxPooling2D(2) in the epilogue (instances where a wave owns two whole tile rows): fragment i and i + FA/2 hold
-      // the same columns of rows 2w and 2w+1, registers (0,1) and (2,3) are horizontal neighbours.  bias and the
-      // (monotonic) activation are applied after the maximum: 4x fewer tanh.
+    // MaxPooling2D(2) in the epilogue (instances where a wave owns two whole tile rows): fragment i and i + FA/2 hold
+    // the same columns of rows 2w and 2w+1, registers (0,1) and (2,3) are horizontal neighbours.  bias and the
+    // (monotonic) activation are applied after the maximum: 4x fewer tanh.  dst = y (out_pool) or y2 (both tensors stored)
+    auto pooled_stores = [&](float* dst) {
       if constexpr (C::POOL_EPI) {
         const int pr = (i0 >> 1) + wave;
         if (pr < a.Hp) {
@@ -484,14 +487,14 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_f32(const ConvArgs a
               const float o0 = o01.x, o1 = o01.y;
               if (DLWP_KNOCK_F32 == 1 && o0 != 12345.678f) continue;
               if (a.out_bf16) {
-                bf16_t* yp = (bf16_t*)a.y + yo + pc;
+                bf16_t* yp = (bf16_t*)dst + yo + pc;
                 if (pc + 1 < a.Wp && (a.Wp & 1) == 0) *(unsigned*)yp = pack_bf16x2(o0, o1);
                 else {
                   if (pc < a.Wp) yp[0] = f32_to_bf16(o0);
                   if (pc + 1 < a.Wp) yp[1] = f32_to_bf16(o1);
                 }
               } else {
-                float* yp = a.y + yo + pc;
+                float* yp = dst + yo + pc;
                 if (pc + 1 < a.Wp && (a.Wp & 1) == 0) *(u32x2*)yp = (u32x2){__builtin_bit_cast(unsigned, o0), __builtin_bit_cast(unsigned, o1)};
                 else {
                   if (pc < a.Wp) yp[0] = o0;
@@ -502,8 +505,12 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_f32(const ConvArgs a
           }
         }
       }
+    };
+    if (a.out_pool) {
+      pooled_stores(a.y);
       return;
     }
+    if (a.y2) pooled_stores(a.y2);
     const bool vec_store = (C::TW % 4 == 0) && ((a.Wo & 3) == 0);
     float* yn = a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;
     bf16_t* yn16 = (bf16_t*)a.y + ((long long)n * a.out_c_total + a.out_c_off) * a.Ho * a.Wo;  // if a.out_bf16

@@ -33,6 +33,7 @@ class Executor(object):
         self.plan, self.device = plan, device
         self._bufs = {}
         self._descs = None
+        self._pool2 = None      # _pooled_too(): convolutions of a training forward that store their pooled image as well
         self._bf16 = set(plan.bf16_buffers()) if activation_dtype == 'bfloat16' else set()
         self._phase = None       # derived (phase-summed) kernels of plan.phase_params: [(w2, b2 | None)]
         self._oct = self._octet_buffers() if self._bf16 and os.environ.get('DLWP_BF16_O8', '1') != '0' else set()
@@ -176,6 +177,26 @@ class Executor(object):
         return out
 
     # -- eager forward ----------------------------------------------------------------------------------------------- #
+    def _pooled_too(self):
+        """{conv op index: index of the 'maxpool' op that reads its whole float32 output} -- candidates for dlwp_conv2d_fwd_pool2 in
+        the training forward (the executor of a training step passes `prepared` / `skip_ops`; plain run() calls keep the two
+        launches).  DLWP_CONV_POOL2=0 switches it off."""
+        if self._pool2 is None:
+            found = {}
+            if os.environ.get('DLWP_CONV_POOL2', '1') != '0' and not self._bf16:
+                ops_ = self.plan.ops
+                for k, op in enumerate(ops_):
+                    if op.kind != 'conv' or op.lstm_f or op.out_pool or op.out_d2s or op.src2 is not None or op.dst < 0:
+                        continue
+                    readers = [j for j, r in enumerate(ops_) if r.src == op.dst]
+                    writers = [j for j, w in enumerate(ops_) if w.dst == op.dst]
+                    pools = [j for j in readers if ops_[j].kind == 'maxpool' and j > k]
+                    if len(writers) == 1 and len(pools) == 1 and op.out_c_off == 0 and ops_[pools[0]].dst >= 0 and \
+                            op.conv_geometry[0] == self.plan.buffers[op.dst][0]:
+                        found[k] = pools[0]
+            self._pool2 = found
+        return self._pool2
+
     def run(self, x, outs=None, prepared=None, skip_phasew=False, skip_ops=()):
         """x: device tensor (n, ...) matching the model input; returns the list of output tensors (stored layout).
         prepared: {op index: tensor of ops.conv2d_prepare} -- those convolutions do not transform their weights again;
@@ -194,10 +215,19 @@ class Executor(object):
             if i == P.STATE_IN:
                 return x
             return outs[-2 - i]
+        pooled_too = self._pooled_too() if prepared is not None or skip_ops else {}
+        done = set()
         for k, (op, d) in enumerate(zip(self.plan.ops, self._descriptors())):
-            if (op.kind == 'phasew' and skip_phasew) or k in skip_ops:
+            if (op.kind == 'phasew' and skip_phasew) or k in skip_ops or k in done:
                 continue
             src, dst = res(op.src), res(op.dst)
+            if k in pooled_too and (not prepared or prepared.get(k) is None):
+                # training forward: the layer's output AND its MaxPooling2D(2) image from one launch (the pooling op is skipped)
+                kp = pooled_too[k]
+                kern, bias = self.conv_weights(op)
+                if ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], out_pool2=res(self.plan.ops[kp].dst)) is not None:
+                    done.add(kp)
+                    continue
             if op.kind == 'conv' and op.src2 is not None:          # a whole ConvLSTM2D step (dlwp_convlstm_step_fwd)
                 if op.dst not in self._oct:
                     raise RuntimeError('whole-step ConvLSTM2D launches need the h sequence in octets (Model.set_activation_dtype '

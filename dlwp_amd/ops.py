@@ -146,12 +146,14 @@ def conv2d_prepare(x, w_hwio, cd, out_dtype=None, x_channels=None, compute_bf16=
 
 
 def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute_bf16=False, prepared=None, in_o8=False,
-           out_o8=False):
+           out_o8=False, out_pool2=None):
     """x: stored input (n, in_c_total, h, w); the conv reads `x_channels` (default: all) channels from cd.in_c_off.
     Returns (n, out_c_total, ho, wo); writes channels [out_c_off, out_c_off+cout).  compute_bf16: a float32 x may be
     rounded to bfloat16 so that the layer runs on the bf16 matrix cores (DLWP_COMPUTE_BF16).  prepared: the tensor
     conv2d_prepare returned for this call (the weights are then not transformed again).  in_o8 / out_o8: the bfloat16
-    tensor x / out holds channel OCTETS, (n, C/8, h, w, 8) in the memory of an (n, C, h, w) tensor (DLWP_BF16_O8)."""
+    tensor x / out holds channel OCTETS, (n, C/8, h, w, 8) in the memory of an (n, C, h, w) tensor (DLWP_BF16_O8).
+    out_pool2: a float32 (n, out_c_total, ho/2, wo/2) tensor that receives MaxPooling2D(2) of the output from the same launch
+    (dlwp_conv2d_fwd_pool2); returns None -- nothing written -- where the layer's kernel cannot store both."""
     _check_act(x, out)
     _check_f32(w_hwio, bias)
     n, c_total, h, w = x.shape
@@ -172,6 +174,16 @@ def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute
     if (in_o8 and x.dtype != torch.bfloat16) or (out_o8 and out.dtype != torch.bfloat16):
         raise ValueError('the octet layout is a bfloat16 storage')
     dt = _lib.dtype_io(_code(x, in_o8), _code(out, out_o8), compute_bf16)      # storage of x / y
+    if out_pool2 is not None:
+        _check_f32(x, out, out_pool2)
+        if tuple(out_pool2.shape) != (n, oc, ys.h // 2, ys.w // 2) or not out_pool2.is_contiguous():
+            raise ValueError('pooled output buffer shape %s != %s' % (tuple(out_pool2.shape), (n, oc, ys.h // 2, ys.w // 2)))
+        rc = _lib.lib.dlwp_conv2d_fwd_pool2(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(bias), _ptr(out), _ptr(out_pool2),
+                                            xs, ctypes.byref(cd), dt, _stream(x))
+        if rc == _lib.EUNSUPPORTED:
+            return None
+        _lib.check(rc)
+        return out
     if prepared is not None and not direct:
         _lib.check(_lib.lib.dlwp_conv2d_fwd_prepared(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(prepared),
                                                      _ptr(bias), _ptr(out), xs, ctypes.byref(cd), dt, _stream(x)))

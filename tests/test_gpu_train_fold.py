@@ -341,3 +341,30 @@ def test_step_with_the_first_layers_pooling_backward_in_its_weight_gradient(monk
         assert np.abs(a[1] - b[1]).max() <= 5e-6 * np.abs(b[1]).max()
         for wa, wb in zip(a[2], b[2]):
             assert np.abs(wa - wb).max() <= 5e-6
+
+
+def test_convolution_that_stores_its_pooled_image_as_well():
+    """dlwp_conv2d_fwd_pool2 == dlwp_conv2d_fwd followed by dlwp_maxpool2_fwd, both tensors bit for bit (the activations are
+    monotonic: the maximum of the activated values is the activated maximum); a layer whose kernel has no such epilogue (Winograd)
+    reports unsupported and writes nothing."""
+    from dlwp_amd import ops
+    rng = np.random.default_rng(31)
+    for (n, cin, cout, h, w, dil, act) in [(3, 4, 32, 16, 24, 2, ops.ACT_TANH), (2, 4, 32, 88, 180, 2, ops.ACT_TANH),
+                                           (2, 3, 20, 11, 21, 1, ops.ACT_RELU), (2, 4, 32, 10, 36, 2, ops.ACT_LINEAR)]:
+        x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+        wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+        b = dev((0.1 * rng.standard_normal(cout)).astype(np.float32))
+        cd = ops.make_conv(cout, 3, 3, dil, ops.make_pad(dil, dil, dil, dil, 0, 1), act)
+        y_ref = ops.conv2d(x, wt, b, cd)
+        p_ref = ops.maxpool2(y_ref)
+        y = torch.full_like(y_ref, float('nan'))
+        p = torch.full_like(p_ref, float('nan'))
+        assert ops.conv2d(x, wt, b, cd, out=y, out_pool2=p) is not None, (cin, cout, h, w)
+        assert torch.equal(y, y_ref) and torch.equal(p, p_ref), (cin, cout, h, w)
+    x = dev(rng.standard_normal((2, 32, 16, 24)).astype(np.float32))
+    wt = dev(np_ref.glorot_uniform((3, 3, 32, 64), rng))
+    cd = ops.make_conv(64, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
+    y = torch.full((2, 64, 16, 24), float('nan'), device='cuda')
+    p = torch.full((2, 64, 8, 12), float('nan'), device='cuda')
+    assert ops.conv2d(x, wt, None, cd, out=y, out_pool2=p) is None
+    assert torch.isnan(y).all() and torch.isnan(p).all()
