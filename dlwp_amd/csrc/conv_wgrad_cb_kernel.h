@@ -19,6 +19,12 @@
 #pragma once
 #include "conv_wgrad_kernel.h"
 
+// profiling builds only (tools/microbench/wgrad_cb_phase_timing.hip -DDLWP_WG_KNOCK=k; results wrong by construction):
+// 1 = no loads of the next tile inside the quad loop, 2 = no MFMAs, 3 = no LDS reads in the transforms
+#ifndef DLWP_WG_KNOCK
+#define DLWP_WG_KNOCK 0
+#endif
+
 // (p, q) -> (p + q, p - q) in one packed add (op_sel broadcasts p into both halves of the first operand and q into both of
 // the second, neg_hi flips the second one's high half)
 __device__ __forceinline__ f32x2 pk_sum_diff(f32x2 pq) {
@@ -239,7 +245,7 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
     //      its true value, s = (1, 1, 1, -1) -- no negations in the loop, the same bits (products and sums are sign-symmetric)
 #pragma unroll
     for (int q = 0; q < C::NQW; ++q) {
-      if (more) {   // all loads are out after quad LQ - 1: the last ones have the remaining quads to land
+      if (more && DLWP_WG_KNOCK != 1) {   // all loads are out after quad LQ - 1: the last ones have the remaining quads to land
         constexpr int LQ = C::NQW - 2;
 #pragma unroll
         for (int ci = (q * C::XPT + LQ - 1) / LQ; ci < ((q + 1) * C::XPT + LQ - 1) / LQ && ci < C::XPT; ++ci) load_x(ci);
@@ -259,8 +265,13 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
       f32x2 d2[4][2], t2[4][2], v2[4][2];   // rows as (columns 0 1 | columns 2 3)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        d2[i][0] = *(const f32x2*)(xa + i * C::LC);
-        d2[i][1] = *(const f32x2*)(xa + i * C::LC + 2);
+        if (DLWP_WG_KNOCK == 3) {
+          d2[i][0] = (f32x2){(float)ln, 1.f};
+          d2[i][1] = (f32x2){2.f, (float)q};
+        } else {
+          d2[i][0] = *(const f32x2*)(xa + i * C::LC);
+          d2[i][1] = *(const f32x2*)(xa + i * C::LC + 2);
+        }
         t2[i][0] = pk_wino_t01(d2[i][0], d2[i][1]);   // d B, one patch row: (d0 - d2, d1 + d2 | d2 - d1, d1 - d3)
         t2[i][1] = pk_wino_t23(d2[i][0], d2[i][1]);
       }
@@ -276,8 +287,13 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
       for (int nt = 0; nt < C::NT; ++nt) {
         const float* zb = zs + ((og * C::NT + nt) * 16 + (ln & 15)) * C::PSZ + r0 * C::TW + c0;
         // |A dY|: rows (y0), (y0 + y1), (y0 - y1), (y1) as pairs (left, right); then each row (p, q) -> (p, p + q, p - q, q)
-        rw[nt][0] = (f32x2){zb[0], zb[1]};
-        rw[nt][3] = (f32x2){zb[C::TW], zb[C::TW + 1]};
+        if (DLWP_WG_KNOCK == 3) {
+          rw[nt][0] = (f32x2){(float)ln, 1.f};
+          rw[nt][3] = (f32x2){2.f, (float)q};
+        } else {
+          rw[nt][0] = (f32x2){zb[0], zb[1]};
+          rw[nt][3] = (f32x2){zb[C::TW], zb[C::TW + 1]};
+        }
         rw[nt][1] = pk_add(rw[nt][0], rw[nt][3]);
         rw[nt][2] = pk_sub(rw[nt][0], rw[nt][3]);
 #pragma unroll
@@ -296,9 +312,12 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
           const float m4[4] = {rw[nt][i][0], sd[nt][i][0], sd[nt][i][1], rw[nt][i][1]};
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (!(C::WUPS && (i == 2 || j == 2)))
-              acc[(i * 4 + j) * C::NT + nt] =
-                  __builtin_amdgcn_mfma_f32_16x16x4f32(v2[i][j >> 1][j & 1], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
+            if (!(C::WUPS && (i == 2 || j == 2))) {
+              if (DLWP_WG_KNOCK == 2) acc[(i * 4 + j) * C::NT + nt][0] += v2[i][j >> 1][j & 1] * m4[j];
+              else
+                acc[(i * 4 + j) * C::NT + nt] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(v2[i][j >> 1][j & 1], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
+            }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
