@@ -146,6 +146,7 @@ _sig('dlwp_conv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _i, _P(_sz)])
 _sig('dlwp_conv2d_bwd_data', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])
 _sig('dlwp_conv2d_bwd_data_stored', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])
 _sig('dlwp_conv2d_bwd_weight', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _i, _vp, _sz, _vp])
+_sig('dlwp_conv2d_bwd_data_act', [_vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _vp, _i, _vp, _i, _vp, _sz, _vp])
 _sig('dlwp_conv2d_bwd_weight_pooled', [_vp, _vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _i, _i, _vp, _sz, _vp])
 _sig('dlwp_conv2d_wgrad_num_configs', [])
 _sig('dlwp_conv2d_wgrad_config_info', [_i, _P(_i), _P(_i)])

@@ -135,9 +135,16 @@ struct dlwp_lstm_io {
   const void* c_prev;    // float32 (n, F, ho, wo) or NULL
   void* c_out;           // float32 (n, F, ho, wo)
 };
+// dlwp_conv2d_bwd_data_act: the store phase multiplies by act'(yact) (yact laid out like y: same channel window) and leaves the
+// per-channel sums of the product as bpart[(sample, 8 x 32 tile)][cout] partials
+struct dlwp_act_epi {
+  const void* yact;
+  int act;
+  float* bpart;
+};
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre = nullptr,
-                       const dlwp_lstm_io* lstm = nullptr, void* y_pool = nullptr);
+                       const dlwp_lstm_io* lstm = nullptr, void* y_pool = nullptr, const dlwp_act_epi* act_epi = nullptr);
 // prepared weights of the Winograd / packed-N / bf16-MFMA families: floats needed for this layer (0 = the kernel reads HWIO), and
 // the kernel that builds them
 size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);

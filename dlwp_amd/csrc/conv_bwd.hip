@@ -146,6 +146,12 @@ bool same_halo_fast_path(const dlwp_conv2d* cd) {
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// bias partials of dlwp_conv2d_bwd_data_act: one per (sample, 8 x 32 tile of the layer's input map) and input channel
+size_t act_partials(dlwp_shape4 xs, const dlwp_conv2d* cd) {
+  const int hin = dlwp_src_dim(xs.h, cd->src_mode), win = dlwp_src_dim(xs.w, cd->src_mode);
+  return (size_t)xs.n * dlwp_ceil_div(hin, 8) * dlwp_ceil_div(win, 32);
+}
+
 }  // namespace
 
 extern "C" {
@@ -169,7 +175,14 @@ int dlwp_conv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d
     *bytes = b;
     return DLWP_OK;
   }
-  DLWP_CHECK_ARG(pass == 1 || pass == 2, "dlwp_conv2d_bwd_workspace: pass must be 0, 1 or 2");
+  if (pass == 3) {   // dlwp_conv2d_bwd_data_act: pass 0 + the bias partials
+    size_t b0 = 0;
+    const int rc0 = dlwp_conv2d_bwd_workspace(h, xs, cd, 0, &b0);
+    if (rc0 != DLWP_OK) return rc0;
+    *bytes = b0 + align256(act_partials(xs, cd) * xs.c * sizeof(float));
+    return DLWP_OK;
+  }
+  DLWP_CHECK_ARG(pass == 1 || pass == 2, "dlwp_conv2d_bwd_workspace: pass must be 0 ... 3");
   WgChoice c;
   if (!pick_wgrad(h, xs.n, xs.c, cd->cout, ys.h, ys.w, cd, &c, pass == 2 ? 4 : -1))
     DLWP_FAIL(DLWP_EUNSUPPORTED, "conv2d_bwd_weight: no kernel for %dx%d dilation %dx%d", cd->kh, cd->kw, cd->dil_h,
@@ -234,7 +247,8 @@ static int plan_dgrad(dlwp_shape4 xs, const dlwp_conv2d* cd, int stored, DgradPl
 // prepared != NULL: dlwp_conv2d_bwd_data_prepare built the flipped kernel (and its Winograd / packed-N form) there; w is unused
 static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
                                 const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream, int stored,
-                                const void* prepared = nullptr) {
+                                const void* prepared = nullptr, const void* x_act = nullptr, int act_in = 0,
+                                void* db_in = nullptr) {
   DLWP_CHECK_ARG(h && dz && (w || prepared) && dx && cd && ws, "dlwp_conv2d_bwd_data: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_conv2d_bwd_data: dtype %d not supported", dtype);
   size_t need = 0;
@@ -242,6 +256,8 @@ static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, 
   if (rc != DLWP_OK) return rc;
   const size_t wbytes = align256((size_t)cd->kh * cd->kw * xs.c * cd->cout * sizeof(float));
   if (prepared) need -= wbytes;          // the flipped kernel lives in `prepared`
+  const size_t act_off = need;
+  if (x_act) need += align256(act_partials(xs, cd) * xs.c * sizeof(float));
   DLWP_CHECK_ARG(ws_bytes >= need, "dlwp_conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
   if (xs.n == 0) return DLWP_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -260,6 +276,21 @@ static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, 
     wt = (const float*)ws;
     rest += wbytes;
   }
+  if (x_act) {   // dx <- dx * act'(x) in the store phase, the bias gradient of the layer that PRODUCED x from the same pass
+    if (!p.fast || stored || cd->src_mode != DLWP_SRC_DIRECT)
+      DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_bwd_data_act: only the in-place data gradient of a plain source");
+    dlwp_act_epi ae;
+    ae.yact = x_act;
+    ae.act = act_in;
+    ae.bpart = (float*)((char*)ws + act_off);
+    rc = dlwp_launch_conv2d(h, dz, wt, nullptr, dx, p.zs, &p.g, dtype, s, u_pre, nullptr, nullptr, &ae);
+    if (rc != DLWP_OK || !db_in) return rc;
+    const int S = (int)act_partials(xs, cd);
+    const int rb = dlwp_reduce_defer(h, ae.bpart, (float*)db_in, xs.c, S, 1, xs.c, 1.0f, 0, s);
+    if (rb < 0) return rb;
+    if (rb == 0) return dlwp_launch_reduce_slabs(h, ae.bpart, (float*)db_in, xs.c, S, 0, s);
+    return DLWP_OK;
+  }
   if (p.fast) return dlwp_launch_conv2d(h, dz, wt, nullptr, dx, p.zs, &p.g, dtype, s, u_pre);
   float* padded = (float*)rest;
   rc = dlwp_launch_conv2d(h, dz, wt, nullptr, padded, p.zs, &p.g, dtype, s, u_pre);
@@ -275,6 +306,19 @@ int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* d
 int dlwp_conv2d_bwd_data_stored(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
                                 const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream) {
   return conv2d_bwd_data_impl(h, dz, w, dx, xs, cd, dtype, ws, ws_bytes, stream, 1);
+}
+
+// dx <- (data gradient) * act'(x), where x -- the layer's input -- is the activation OUTPUT of the layer in front, and db_in
+// (xs.c floats, nullable) <- the per-channel sums of that product: that layer's dlwp_act_bwd_bias_grad without a launch (the
+// Winograd kernel's store phase multiplies and sums).  prepared as dlwp_conv2d_bwd_data_prepared (nullable: then w).  Workspace:
+// dlwp_conv2d_bwd_workspace(pass = 3).  DLWP_EUNSUPPORTED where the gradient does not run on that instance: the caller keeps
+// dlwp_conv2d_bwd_data + dlwp_act_bwd_bias_grad.
+int dlwp_conv2d_bwd_data_act(dlwp_handle_t h, const void* dz, const void* w, const void* prepared, void* dx, dlwp_shape4 xs,
+                             const dlwp_conv2d* cd, const void* x, int act_in, void* db_in, int dtype, void* ws, size_t ws_bytes,
+                             void* stream) {
+  DLWP_CHECK_ARG(x != nullptr, "dlwp_conv2d_bwd_data_act: null layer input");
+  DLWP_CHECK_ARG(act_in == DLWP_ACT_TANH || act_in == DLWP_ACT_RELU, "dlwp_conv2d_bwd_data_act: activation %d (tanh / relu)", act_in);
+  return conv2d_bwd_data_impl(h, dz, w, dx, xs, cd, dtype, ws, ws_bytes, stream, 0, prepared, x, act_in, db_in);
 }
 
 // Prepared operand of the data gradient: [flipped / transposed kernel | its Winograd or packed-N form, if the gradient's

@@ -661,7 +661,7 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
 
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd_in, int dtype, hipStream_t s, const float* u_pre, const dlwp_lstm_io* lstm,
-                       void* y_pool) {
+                       void* y_pool, const dlwp_act_epi* act_epi) {
   // y_pool (dlwp_conv2d_fwd_pool2): the instance is chosen as for the pooling epilogue -- same tiles, same cost -- and then stores
   // BOTH tensors; only the direct family has that epilogue
   dlwp_conv2d cd_pool;
@@ -704,6 +704,16 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   }
   Registry& r = registry();
   const ConvKernelEntry& e = r.entries[ci];
+  if (act_epi) {   // only the 8 x 32 / 32-channel Winograd instance has that store phase (conv_fwd_wino_kernel.h: DACT)
+    if (!is_wino(e) || e.split || e.dil != 1 || e.th != 8 || e.tw != 32 || e.waves != 4 || e.bnf != 2 || wino_skips_row2(a) ||
+        a.in_bf16 || a.out_bf16 || cd->out_pool || cd->out_d2s || lp.pair_vw != 0 || lp.narrow >= 0 || a.Cout % 32 != 0)
+      DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_bwd_data_act: this data gradient does not run on the instance with the fused store phase");
+    a.yact = (const float*)act_epi->yact;
+    a.yact_c_off = a.out_c_off;
+    a.yact_c_total = a.out_c_total;
+    a.dact = act_epi->act;
+    a.bpart = act_epi->bpart;
+  }
   if (y_pool) {
     if (is_wino(e) || is_bf16(e) || e.pack != 0 || !e.out_pool || lp.narrow >= 0)
       DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd_pool2: this layer's kernel cannot store both tensors");

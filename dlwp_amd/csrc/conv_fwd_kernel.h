@@ -57,6 +57,13 @@ struct ConvArgs {
   // dlwp_conv2d_fwd_pool2 (training forward of a layer under MaxPooling2D(2): the backward pass needs y, the next layer its
   // pooled image): y_pool (N, out_c_total, Hp, Wp) written BESIDE y by the direct instances with a pooling epilogue
   float* y2 = nullptr;
+  // dlwp_conv2d_bwd_data_act (the data gradient of a layer whose input is ANOTHER layer's activation output, training): the
+  // Winograd kernel's store phase multiplies its result by act'(yact) -- yact (N, yact_c_total, Ho, Wo), window from yact_c_off:
+  // the producing layer's output -- and leaves the per-channel sums of the product (that layer's bias gradient) as
+  // bpart[(sample, tile)][Cout] partials: dlwp_act_bwd_bias_grad without a launch (conv_fwd_wino_kernel.h, WinoCfg::DACT)
+  const float* yact = nullptr;
+  int yact_c_off = 0, yact_c_total = 0, dact = 0;
+  float* bpart = nullptr;
 #ifdef DLWP_PHASE_TIMING  // tools/microbench/wino_phase_timing.hip only: s_memtime stamps of wave 0, 8 per block
   long long* dbg = nullptr;
 #endif

@@ -41,10 +41,13 @@
 // column), so row 2 of B^T d -- d2 - d1 -- and column 2 of (B^T d) B are exactly zero: 7 of the 16 Winograd positions
 // contribute nothing and their MFMAs (and U fragment loads) are left out -- 9 multiplies per 2x2 output tile and channel
 // pair instead of 16 (direct: 36), bit-identical results.
-template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false, bool UPS_ = false>
+template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false, bool UPS_ = false, bool DACT_ = false>
 struct WinoCfg {
   static constexpr bool IN16 = IN16_;  // input stored as bfloat16 (the loop stays branch-free: one instance per input type)
   static constexpr bool UPS = UPS_;
+  // DACT (r3, training): the float32 store phase multiplies by act'(yact) and leaves the bias-gradient partials of the product
+  // (ConvArgs::yact / bpart) -- an instance of its own, so that the inference instances keep their code
+  static constexpr bool DACT = DACT_;
   static_assert(!UPS_ || DIL_ == 1, "the up-sampled-source variant is the dilation-1 case");
   static constexpr int DIL = DIL_, TH = TH_, TW = TW_, WAVES = WAVES_, BNF = BNF_, CK = CK_;
   static constexpr int NT = WAVES * 64;
@@ -580,6 +583,51 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     const bool rok = oh < a.Ho;
     const unsigned voff_q = (rok && ow + 3 < a.Wo) ? pix : DROP;
     const float* lp = lds + cb * C::OPS + rem;
+    if constexpr (C::DACT) {
+      // every pass: the same pixel quad of channel cb + k CS -- a wave (64 threads x 4 pixels = the 8 x 32 tile) owns ONE channel
+      // per pass, so the bias partial of (this tile, that channel) is a wave sum.  Out-of-map pixels carry whatever the padded
+      // tile computed: they are neither stored nor summed.
+      static_assert(PL == 256 && C::NT == 256, "one wave per channel and pass");
+      const float* ab = a.yact + ((long long)n_s * a.yact_c_total + a.yact_c_off + n0) * a.Ho * a.Wo;
+      const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (unsigned)C::BN * plane_b, 0x00020000);
+      const unsigned apix = (unsigned)(oh * a.Wo + ow) * 4u + (unsigned)cb * plane_b;
+      const bool inq = rok && ow + 3 < a.Wo;
+      const bool edge = rok && ow < a.Wo && ow + 3 >= a.Wo;     // a quad the map's right edge cuts: element-wise
+      float* bp = a.bpart + ((long long)(n_s * a.tiles_h + th) * a.tiles_w + tw) * a.Cout + n0 + cb;
+#pragma unroll
+      for (int k = 0; k < NOUT; ++k) {
+        f32x4 o = *(const f32x4*)(lp + k * CS * C::OPS);
+        const unsigned so = (unsigned)(k * CS) * plane_b;
+        float bs = 0.f;
+        if (!edge) {
+          const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, inq ? apix : DROP, so, 0));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = a.dact == DLWP_ACT_TANH ? o[r] * (1.f - yv[r] * yv[r]) : (yv[r] > 0.f ? o[r] : 0.f);
+          if (inq) bs = (o[0] + o[1]) + (o[2] + o[3]);
+          // the 16-byte store's data registers must outlive it by a few cycles: hipcc put `v_add_f32 v0, v0, v1` (the sum above)
+          // directly behind `buffer_store_dwordx4 v[0:3]` -- no hazard by its rules when the store has an SGPR soffset -- and under
+          // load the stored element 0 of lanes 12-15 (mod 16) came out as the SUM.  So: sum first, store last, pad behind it.
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), y_rsrc, voff_q, so, 0);
+          asm volatile("s_nop 3" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool okr = ow + r < a.Wo;
+            const float yv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, okr ? apix + 4u * r : DROP, so, 0));
+            const float v = a.dact == DLWP_ACT_TANH ? o[r] * (1.f - yv * yv) : (yv > 0.f ? o[r] : 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rsrc, okr ? pix + 4u * r : DROP, so, 0);
+            if (okr) bs += v;
+          }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) bs += __shfl_xor(bs, m);
+        if (lane == 0 && n0 + cb + k * CS < a.Cout) bp[k * CS] = bs;
+      }
+      DLWP_STAMP(6);
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NOUT; ++k)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)(lp + k * CS * C::OPS)), y_rsrc, voff_q,
@@ -648,6 +696,12 @@ static void wino_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
       return;
     }
   }
+  if constexpr (DIL == 1 && TH == 8 && TW == 32 && WAVES == 4 && BNF == 2) {
+    if (a.yact) {   // (the host sends only float32, plain-source, unpooled launches here: conv_bwd.hip)
+      wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true>>(a, grid, s);
+      return;
+    }
+  }
   if (a.in_bf16) wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>(a, grid, s);
   else wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false>>(a, grid, s);
 }
@@ -659,6 +713,9 @@ static int wino_prepare_both() {
   if constexpr (DIL == 1) {
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, true>>();
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true, true>>();
+  }
+  if constexpr (DIL == 1 && TH == 8 && TW == 32 && WAVES == 4 && BNF == 2) {
+    if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true>>();
   }
   return e;
 }

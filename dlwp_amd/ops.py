@@ -544,6 +544,22 @@ def conv2d_bwd_data(dz, w_hwio, cd, xs, dx, prepared=None, stored=False):
     return dx
 
 
+def conv2d_bwd_data_act(dz, w_hwio, cd, xs, dx, x, act_in, db_in=None, prepared=None, ws_key=None):
+    """conv2d_bwd_data whose result is multiplied by act'(x) in the store phase -- x: the layer's input = the activation output of
+    the layer in front -- with that layer's bias gradient db_in (xs.c floats) from the same pass (dlwp_conv2d_bwd_data_act).
+    Returns False, nothing written, where the gradient does not run on the instance with that store phase."""
+    _check_f32(dz, w_hwio, dx, x, db_in, prepared)
+    d = _dev(dz)
+    need = conv_bwd_workspace_bytes(d, xs, cd, 3)
+    ws = workspace(dz.device, need, ws_key)
+    rc = _lib.lib.dlwp_conv2d_bwd_data_act(_lib.handle(d), _ptr(dz), _ptr(w_hwio), _ptr(prepared), _ptr(dx), xs, ctypes.byref(cd),
+                                           _ptr(x), int(act_in), _ptr(db_in), _lib.F32, _ptr(ws), ws.numel(), _stream(dz))
+    if rc == _lib.EUNSUPPORTED:
+        return False
+    _lib.check(rc)
+    return True
+
+
 def conv2d_bwd_data_prepared_bytes(dev_index, xs, cd, stored=False):
     """Bytes of the prepared operand of a data gradient (0: this gradient has no prepared form, e.g. `stored` on a layer
     without the summing epilogue)."""

@@ -227,6 +227,15 @@ int dlwp_conv2d_bwd_data_stored(dlwp_handle_t, const void* dz, const void* w, vo
                                 const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream);
 int dlwp_conv2d_bwd_weight(dlwp_handle_t, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* dlwp_conv2d_bwd_data where the layer's input x is the ACTIVATION OUTPUT of the layer in front (Conv2D -> Conv2D, the decoder of
+ * examples/train.py:191-219): dx <- (data gradient) * act'(x) and db_in (xs.c floats, nullable) <- the per-channel sums of that
+ * product -- the front layer's dlwp_act_bwd_bias_grad -- from the data gradient's own store phase.  prepared: as
+ * dlwp_conv2d_bwd_data_prepared, or NULL (then w is flipped here).  act_in: DLWP_ACT_TANH / RELU.  Workspace:
+ * dlwp_conv2d_bwd_workspace(pass = 3).  DLWP_EUNSUPPORTED where the gradient's convolution does not run on the instance with that
+ * store phase (8 x 32 Winograd tiles, whole 32-channel tiles of xs.c, plain source, 'same' halo): keep the two calls.            */
+int dlwp_conv2d_bwd_data_act(dlwp_handle_t, const void* dz, const void* w, const void* prepared, void* dx, dlwp_shape4 xs,
+                             const dlwp_conv2d* cd, const void* x, int act_in, void* db_in, int dtype, void* ws, size_t ws_bytes,
+                             void* stream);
 /* The weight AND bias gradient of a layer whose only reader is MaxPooling2D(2) and whose data gradient nobody needs (the first
  * layer of the reference's networks, examples/train.py:159-170), from the layer's output y (laid out like dz above) and the
  * POOLED tensor's gradient dpool (n, cout, Ho/2, Wo/2): what dlwp_pool_act_bwd_bias_grad + dlwp_conv2d_bwd_weight compute, without

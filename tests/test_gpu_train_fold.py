@@ -368,3 +368,52 @@ def test_convolution_that_stores_its_pooled_image_as_well():
     p = torch.full((2, 64, 8, 12), float('nan'), device='cuda')
     assert ops.conv2d(x, wt, None, cd, out=y, out_pool2=p) is None
     assert torch.isnan(y).all() and torch.isnan(p).all()
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,act', [(4, 64, 32, 44, 90, 'tanh'), (8, 32, 16, 44, 90, 'tanh'), (64, 32, 16, 44, 90, 'tanh'),
+                                               (4, 64, 64, 16, 40, 'relu'), (4, 96, 32, 11, 37, 'tanh')])
+def test_data_gradient_with_the_activation_backward_in_its_store_phase(n, cin, cout, h, w, act):
+    """dlwp_conv2d_bwd_data_act == dlwp_conv2d_bwd_data followed by dlwp_act_bwd_bias_grad on the layer's input (the activation
+    output of the layer in front): the gradient bit for bit (the same products in the same order, one multiply later), the bias
+    gradient to float32 round-off; prepared operand or not; ragged right edge (90, 37 columns)."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(cin + cout + h)
+    a = ops.ACT_TANH if act == 'tanh' else ops.ACT_RELU
+    xv = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    x = dev(np.tanh(xv) if act == 'tanh' else np.maximum(xv, 0.0))
+    dz = dev(rng.standard_normal((n, cout, h, w)).astype(np.float32))
+    wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_LINEAR)
+    xs = _lib.Shape4(n, cin, h, w)
+    dx_ref = torch.empty((n, cin, h, w), device='cuda')
+    ops.conv2d_bwd_data(dz, wt, cd, xs, dx_ref)
+    db_ref = torch.empty(cin, device='cuda')
+    ops.act_bwd_bias_grad(x, dx_ref, a, db_ref, cin, out=dx_ref)
+    dx = torch.full_like(dx_ref, float('nan'))
+    db = torch.full_like(db_ref, float('nan'))
+    if not ops.conv2d_bwd_data_act(dz, wt, cd, xs, dx, x, a, db):
+        assert (n, cin, h) != (4, 64, 44), 'the config-3 decoder shape must run fused'
+        assert torch.isnan(dx).all()
+        pytest.skip('the heuristic put this gradient on another instance: the caller keeps the two launches')
+    assert torch.equal(dx, dx_ref)
+    assert torch.allclose(db, db_ref, rtol=1e-4, atol=1e-4 * max(1.0, float(db_ref.abs().max())))
+    prep = ops.conv2d_bwd_data_prepare(wt, cd, xs)
+    dx2 = torch.full_like(dx_ref, float('nan'))
+    assert ops.conv2d_bwd_data_act(dz, wt, cd, xs, dx2, x, a, None, prepared=prep)
+    assert torch.equal(dx2, dx_ref)
+
+
+def test_data_gradient_with_activation_backward_reports_unsupported_layers():
+    """5x5 kernels, few channels and dilation 2 do not run on the Winograd instance with the fused store phase: False, nothing
+    written."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(3)
+    for (cin, cout, k, dil) in [(4, 32, 3, 2), (32, 4, 5, 1), (20, 32, 3, 1)]:
+        p = dil * (k - 1) // 2
+        x = dev(np.tanh(rng.standard_normal((2, cin, 16, 40))).astype(np.float32))
+        dz = dev(rng.standard_normal((2, cout, 16, 40)).astype(np.float32))
+        wt = dev(np_ref.glorot_uniform((k, k, cin, cout), rng))
+        cd = ops.make_conv(cout, k, k, dil, ops.make_pad(p, p, p, p, 0, 1), ops.ACT_LINEAR)
+        dx = torch.full((2, cin, 16, 40), float('nan'), device='cuda')
+        assert not ops.conv2d_bwd_data_act(dz, wt, cd, _lib.Shape4(2, cin, 16, 40), dx, x, ops.ACT_TANH, None)
+        assert torch.isnan(dx).all()
