@@ -219,6 +219,9 @@ int dlwp_reduce_defer(dlwp_handle_t h, const float* src, float* dst, long long n
   j.vec4 = es == 1 && n % 4 == 0 && ss % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
   // few elements and many partials: narrow blocks, more partial groups per element
   j.eb = ((j.vec4 ? n / 4 : n) < 64 * 256 && S >= 64) ? 16 : 64;
+  // a handful of elements over a thousand partials (the bias partials of dlwp_conv2d_bwd_data_act / _bwd_weight_pooled: one per
+  // tile or slab): 64 partial groups per element, or the job's few blocks walk their partials for longer than every other job
+  if ((j.vec4 ? n / 4 : n) <= 1024 && S >= 512) j.eb = 4;
   h->red[h->n_red++] = j;
   return 1;
 }

@@ -379,6 +379,26 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   DLWP_STAMP(2);
   __syncthreads();  // every wave is out of the loop: LDS becomes the output staging area
   DLWP_STAMP(3);
+  // DACT: the activation-output tile this block's results are multiplied with is requested NOW -- its latency runs under the
+  // output transform and the staging (requested in the store phase, every block ended on an exposed memory latency and the fused
+  // data gradients were no faster than the two launches)
+  constexpr int NOUT_A = C::BN * C::TH * C::TW / 4 / C::NT;
+  f32x4 yq[C::DACT ? NOUT_A : 1];
+  if constexpr (C::DACT) {
+    constexpr int PL_A = C::TH * C::TW, CS_A = 4 * C::NT / PL_A;
+    const int e0 = tid * 4, cb = e0 / PL_A, rem = e0 - cb * PL_A;
+    const int row = rem / C::TW, colx = rem - row * C::TW;
+    const int oh = i0 + row, ow = j0 + colx;
+    const unsigned plane_b = (unsigned)(a.Ho * a.Wo) * 4u;
+    const float* ab = a.yact + ((long long)n * a.yact_c_total + a.yact_c_off + n0) * a.Ho * a.Wo;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (unsigned)C::BN * plane_b, 0x00020000);
+    const unsigned apix = (unsigned)(oh * a.Wo + ow) * 4u + (unsigned)cb * plane_b;
+    const bool inq = oh < a.Ho && ow + 3 < a.Wo;
+#pragma unroll
+    for (int k = 0; k < NOUT_A; ++k)
+      yq[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, inq ? apix : 0x7ffffff0u,
+                                                                               (unsigned)(k * CS_A) * plane_b, 0));
+  }
 
   // ---- output transform Y = A^T M A in registers, bias + activation, then [co][row][col] through LDS.  One straight-line
   //      path per (activation, pooling kind): the runtime switches are taken ONCE, outside the loops over the lane's 4 x BNF
@@ -600,7 +620,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         const unsigned so = (unsigned)(k * CS) * plane_b;
         float bs = 0.f;
         if (!edge) {
-          const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, inq ? apix : DROP, so, 0));
+          const f32x4 yv = yq[k];
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = a.dact == DLWP_ACT_TANH ? o[r] * (1.f - yv[r] * yv[r]) : (yv[r] > 0.f ? o[r] : 0.f);
           if (inq) bs = (o[0] + o[1]) + (o[2] + o[3]);

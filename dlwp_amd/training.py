@@ -158,6 +158,7 @@ class Trainer(object):
         self._grad_bufs = {}
         self._loss_out = None
         self._phase_out = None        # _phase_outputs(): outputs whose loss is taken on the phase channels
+        self._dact_ops = None         # _dgrad_act_ops(): data gradients that carry the producer's activation backward
         self._loss_consts = None      # device copies of a custom loss's climatology / latitude weights
         self._params_dirty = False    # set by Model.set_weights / load: replicas re-align at the next collective step
         self._graphs = {}             # (n_local, n_global) -> captured training step (see _graph_step)
@@ -325,6 +326,40 @@ class Trainer(object):
             dys.append(dy)
         return outs, self._loss_out, dys
 
+    def _dgrad_act_ops(self):
+        """{convolution op k: op index of the Conv2D whose activation output k alone reads} -- candidates for
+        dlwp_conv2d_bwd_data_act: k's data gradient then multiplies by act'(that output) and sums that layer's bias gradient in its
+        store phase, and the producer's dlwp_act_bwd_bias_grad launch disappears.  OFF unless DLWP_DGRAD_ACT=1: measured equal to
+        the two launches on config 3 (batch 64: 1.385-1.391 vs 1.382-1.399 ms, batch 8: 0.410 vs 0.409 ms, same box) -- the store
+        phase's extra read costs the data gradient what the separate pass cost."""
+        if self._dact_ops is None:
+            found = {}
+            if os.environ.get('DLWP_DGRAD_ACT', '0') == '1':
+                ops_ = self.plan.ops
+                uses = {}
+                for w in ops_:
+                    if w.kind == 'conv' and w.layer is not None:
+                        uses[id(w.layer)] = uses.get(id(w.layer), 0) + 1
+                for k, op in enumerate(ops_):
+                    if op.kind != 'conv' or op.src < 0 or op.src_mode != P.SRC_DIRECT or op.lstm_f or op.src2 is not None:
+                        continue
+                    chans = self.plan.buffers[op.src][0]
+                    if op.in_c_off != 0 or op.xs[0] != chans:
+                        continue
+                    readers = [j for j, r in enumerate(ops_) if r.src == op.src or (r.src2 is not None and r.src2.get('buf') == op.src)
+                               or (r.aux is not None and op.src in [a for a in r.aux if a is not None])]
+                    writers = [j for j, w in enumerate(ops_) if w.dst == op.src]
+                    if readers != [k] or len(writers) != 1:
+                        continue
+                    pw = ops_[writers[0]]
+                    if (pw.kind == 'conv' and not pw.lstm_f and pw.wparam is None and not pw.out_pool and not pw.out_d2s and
+                            pw.out_c_off == 0 and pw.conv_geometry[0] == chans and pw.layer is not None and
+                            pw.layer.bias is not None and pw.layer.activation in ('tanh', 'relu') and
+                            uses.get(id(pw.layer), 0) == 1 and writers[0] < k):
+                        found[k] = writers[0]
+            self._dact_ops = found
+        return self._dact_ops
+
     def _phase_outputs(self):
         """{output index: (index of its 'd2s' op, that op, index of the convolution in front)} for outputs the plan restates as
         phase channels + depth-to-space (plan.py) and whose loss is the plain 'mse': the step then takes loss,
@@ -477,6 +512,7 @@ class Trainer(object):
                 grads[buf] = g
             return g
 
+        preact = set()       # buffers whose gradient is already a PRE-activation gradient (dlwp_conv2d_bwd_data_act)
         phase_db = {}        # convolution op index -> bias gradient of its phase channels, already summed with the loss
         for o, dy in enumerate(dys):
             if isinstance(dy, _PhaseGrad):     # the gradient arrives on the phase channels: the 'd2s' op has no adjoint to run
@@ -561,7 +597,9 @@ class Trainer(object):
                     if isinstance(lay, L._ConvPart):
                         touched_layers.add(id(lay.parent))
                     continue
-                if pooled_grad is not None:    # the layer's only reader is MaxPooling2D(2): its backward rides along
+                if op.dst in preact:           # the reader's data gradient left dz and this layer's bias gradient already
+                    fused_bias = True
+                elif pooled_grad is not None:  # the layer's only reader is MaxPooling2D(2): its backward rides along
                     fused_bias = lay.bias is not None
                     gD = ops.pool_act_bwd_bias_grad(y, pooled_grad, op.act,
                                                     self._grad_view(lay, 'bias') if fused_bias else None, ws_key=key('bias'))
@@ -615,8 +653,18 @@ class Trainer(object):
                 if op.src_mode == P.SRC_DIRECT:
                     g = grad_of(op.src)
                     if not overlaps(op.src, op.in_c_off, cin):
-                        # writes its channel window in place
-                        ops.conv2d_bwd_data(dz, kern, d, xs, g, prepared=pb[0] if pb else None)
+                        # writes its channel window in place -- where this layer is the only reader of another Conv2D's
+                        # activation output, already times act'(that output), with that layer's bias gradient from the same pass
+                        done = False
+                        kp = self._dgrad_act_ops().get(k)
+                        if kp is not None:
+                            pop = plan.ops[kp]
+                            done = ops.conv2d_bwd_data_act(dz, kern, d, xs, g, src, pop.act, self._grad_view(pop.layer, 'bias'),
+                                                           prepared=pb[0] if pb else None, ws_key=key('dact'))
+                            if done:
+                                preact.add(op.src)
+                        if not done:
+                            ops.conv2d_bwd_data(dz, kern, d, xs, g, prepared=pb[0] if pb else None)
                         written.setdefault(op.src, []).append((op.in_c_off, cin))
                     else:
                         dd = ops.make_conv(d.cout, d.kh, d.kw, (d.dil_h, d.dil_w), d.halo, d.act, 0, 0, d.out_c_off,

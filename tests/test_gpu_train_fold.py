@@ -417,3 +417,34 @@ def test_data_gradient_with_activation_backward_reports_unsupported_layers():
         dx = torch.full((2, cin, 16, 40), float('nan'), device='cuda')
         assert not ops.conv2d_bwd_data_act(dz, wt, cd, _lib.Shape4(2, cin, 16, 40), dx, x, ops.ACT_TANH, None)
         assert torch.isnan(dx).all()
+
+
+def test_step_with_the_activation_backward_in_the_data_gradients_equals_the_step_without(monkeypatch):
+    """Config 3 at its full grid (the fused store phase exists on the 8 x 32 Winograd instance only, which small maps do not
+    take): DLWP_DGRAD_ACT=0 keeps dlwp_conv2d_bwd_data + dlwp_act_bwd_bias_grad -- the same step to float32 round-off, eager and
+    captured; and the planner found the two decoder layers."""
+    from tests.nets import unet_layers as ul
+    rng = np.random.default_rng(23)
+    cs = (4, 88, 180)
+    layers = ul(cs)
+    x = rng.standard_normal((8,) + cs).astype(np.float32)
+    y = rng.standard_normal((8,) + cs).astype(np.float32)
+    res = {}
+    for graph in ('0', '1'):
+        for fused in ('1', '0'):
+            monkeypatch.setenv('DLWP_TRAIN_GRAPH', graph)
+            monkeypatch.setenv('DLWP_DGRAD_ACT', fused)
+            d = _build(layers, time_dim=2)
+            _weights_of(d.model, np.random.default_rng(9))
+            tr = d.model._trainer
+            logs = [d.model.train_on_batch(x, y) for _ in range(3)]
+            torch.cuda.synchronize()
+            assert (len(tr._dgrad_act_ops()) >= 2) == (fused == '1')
+            res[(graph, fused)] = (logs, tr.flat_grads.cpu().numpy().copy(), d.model.get_weights())
+    for graph in ('0', '1'):
+        a, b = res[(graph, '1')], res[(graph, '0')]
+        for la, lb in zip(a[0], b[0]):
+            assert np.allclose(la, lb, rtol=2e-5, atol=1e-7), (la, lb)
+        assert np.abs(a[1] - b[1]).max() <= 5e-6 * np.abs(b[1]).max()
+        for wa, wb in zip(a[2], b[2]):
+            assert np.abs(wa - wb).max() <= 5e-6
