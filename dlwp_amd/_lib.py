@@ -122,7 +122,7 @@ _sig('dlwp_pad2d_fwd', [_vp, _vp, _vp, _i, _i, _i, _i, Pad2d, _i, _vp])
 _sig('dlwp_pad2d_bwd', [_vp, _vp, _vp, _i, _i, _i, _i, Pad2d, _i, _vp])
 _sig('dlwp_conv2d_out_shape', [Shape4, _P(Conv2d), _P(Shape4)])
 _sig('dlwp_conv2d_fwd', [_vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
-_sig('dlwp_conv2d_fwd_pool2', [_vp, _vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
+_sig('dlwp_conv2d_fwd_pool2', [_vp, _vp, _vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
 _sig('dlwp_conv2d_fwd_direct', [_vp, _vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
 _sig('dlwp_conv2d_prepared_bytes', [_vp, Shape4, _P(Conv2d), _i], _sz)
 _sig('dlwp_conv2d_prepare', [_vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])

@@ -715,7 +715,10 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
     a.bpart = act_epi->bpart;
   }
   if (y_pool) {
-    if (is_wino(e) || is_bf16(e) || e.pack != 0 || !e.out_pool || lp.narrow >= 0)
+    const bool direct_ok = !is_wino(e) && !is_bf16(e) && e.pack == 0 && e.out_pool;
+    const bool wino_ok = is_wino(e) && !e.split && e.dil == 1 && e.th == 8 && e.tw == 32 && e.waves == 4 && e.bnf == 2 &&
+                         !wino_skips_row2(a) && !a.in_bf16 && lp.pair_vw == 0;      // conv_fwd_wino_kernel.h: POOL2
+    if (!(direct_ok || wino_ok) || lp.narrow >= 0)
       DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd_pool2: this layer's kernel cannot store both tensors");
     a.out_pool = 0;                 // (a.Hp / a.Wp stay: the pooled tensor's shape)
     a.y2 = (float*)y_pool;
@@ -835,10 +838,10 @@ int dlwp_conv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void* b
 
 // y (n, out_c_total, ho, wo) AND its MaxPooling2D(2) image y_pool (n, out_c_total, ho/2, wo/2) from one launch: the training
 // forward of a layer under a pooling layer (the backward pass needs y).  DLWP_EUNSUPPORTED: keep dlwp_conv2d_fwd + dlwp_maxpool2_fwd.
-int dlwp_conv2d_fwd_pool2(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, void* y_pool, dlwp_shape4 xs,
-                          const dlwp_conv2d* cd, int dtype, void* stream) {
+int dlwp_conv2d_fwd_pool2(dlwp_handle_t h, const void* x, const void* w, const void* prepared, const void* bias, void* y,
+                          void* y_pool, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, void* stream) {
   DLWP_CHECK_ARG(y_pool != nullptr, "dlwp_conv2d_fwd_pool2: null pooled output");
-  return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream, nullptr, nullptr, y_pool);
+  return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream, (const float*)prepared, nullptr, y_pool);
 }
 
 size_t dlwp_conv2d_prepared_bytes(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {

@@ -41,8 +41,14 @@
 // column), so row 2 of B^T d -- d2 - d1 -- and column 2 of (B^T d) B are exactly zero: 7 of the 16 Winograd positions
 // contribute nothing and their MFMAs (and U fragment loads) are left out -- 9 multiplies per 2x2 output tile and channel
 // pair instead of 16 (direct: 36), bit-identical results.
-template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false, bool UPS_ = false, bool DACT_ = false>
+template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false, bool UPS_ = false, bool DACT_ = false,
+          bool POOL2_ = false>
 struct WinoCfg {
+  // POOL2 (r3, training forward): the block stores its output AND the MaxPooling2D(2) image of it (ConvArgs::y2) -- a second
+  // staging area behind the first; an instance of its own (dilation 1: a lane's 2 x 2 output tile is one pooling window)
+  static constexpr bool POOL2 = POOL2_;
+  static_assert(!POOL2_ || (DIL_ == 1 && !DACT_), "pooled image beside the output: dilation 1");
+  static constexpr int PPS = (TH_ / 2) * (TW_ / 2) + 4;   // POOL2: plane stride of the pooled staging area
   static constexpr bool IN16 = IN16_;  // input stored as bfloat16 (the loop stays branch-free: one instance per input type)
   static constexpr bool UPS = UPS_;
   // DACT (r3, training): the float32 store phase multiplies by act'(yact) and leaves the bias-gradient partials of the product
@@ -68,7 +74,8 @@ struct WinoCfg {
   static constexpr int U_FLOATS = UQ * 4 * CK * BN;
   static constexpr int OPS = TH * TW + 4;          // output staging: plane stride of one channel
   static constexpr int O_FLOATS = BN * OPS;
-  static constexpr int L_FLOATS = (2 * X_FLOATS + 2 * U_FLOATS) > O_FLOATS ? (2 * X_FLOATS + 2 * U_FLOATS) : O_FLOATS;
+  static constexpr int O2_FLOATS = O_FLOATS + (POOL2_ ? BN * PPS : 0);
+  static constexpr int L_FLOATS = (2 * X_FLOATS + 2 * U_FLOATS) > O2_FLOATS ? (2 * X_FLOATS + 2 * U_FLOATS) : O2_FLOATS;
   static constexpr int LDS_BYTES = L_FLOATS * 4;
   static constexpr int NPOS = (LR * LC + NT - 1) / NT;
   static constexpr int NXI = CK * NPOS;            // input elements per thread and chunk
@@ -471,10 +478,15 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     }
     for_tiles([&](const f32x2 (&s)[2][4], int col, f32x2 bv, int ti, int tj, int pi, int pj) {
       float* op = lds + col * C::OPS + (ti * 2 * C::DIL + pi) * C::TW + tj * 2 * C::DIL + pj;
+      f32x2 pmax = (f32x2){0.f, 0.f};
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa) {
         const f32x2 y0 = act_apply2_c<ACT>(y_even(s, aa) + bv);
         const f32x2 y1 = act_apply2_c<ACT>(y_odd(s, aa) + bv);
+        if constexpr (C::POOL2) {   // the maximum of the ACTIVATED window = the activated maximum (monotonic activations)
+          const f32x2 m = (f32x2){fmaxf(y0.x, y1.x), fmaxf(y0.y, y1.y)};
+          pmax = aa == 0 ? m : (f32x2){fmaxf(pmax.x, m.x), fmaxf(pmax.y, m.y)};
+        }
         float* q = op + aa * C::DIL * C::TW;
         if constexpr (C::DIL == 1) {
           // the pair's four outputs of this row are adjacent: ONE 16-byte write (r3).  Four 4-byte writes put all 64 lanes of
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
           q[3 * C::DIL] = y1.y;
         }
       }
+      if constexpr (C::POOL2) *(f32x2*)(lds + C::O_FLOATS + col * C::PPS + ti * (C::TW / 2) + tj) = pmax;
     });
   });
   DLWP_STAMP(4);
@@ -665,6 +678,31 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         }
       }
     }
+    if constexpr (C::POOL2) {   // the pooled image: [co][TH/2][TW/2] from the second staging area, as the out_pool store phase
+      constexpr int PW2 = C::TW / 2, PP2 = (C::TH / 2) * PW2, NP2 = C::BN * PP2 / 4 / C::NT, CS2 = 4 * C::NT / PP2;
+      static_assert((C::BN * PP2 / 4) % C::NT == 0 && PW2 % 4 == 0 && (4 * C::NT) % PP2 == 0, "pooled staging: whole float4 per thread");
+      const int f0 = tid * 4, cb2 = f0 / PP2, rem2 = f0 - cb2 * PP2;
+      const int prow = rem2 / PW2, pcol = rem2 - prow * PW2;
+      const int ph = (i0 >> 1) + prow, pw = (j0 >> 1) + pcol;
+      const unsigned pplane_b = (unsigned)(a.Hp * a.Wp) * 4u;
+      float* pb = a.y2 + ((long long)n_s * a.out_c_total + a.out_c_off + n0) * a.Hp * a.Wp;
+      const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pb, 0, (unsigned)C::BN * pplane_b, 0x00020000);
+      const unsigned ppix = (unsigned)(ph * a.Wp + pw) * 4u + (unsigned)cb2 * pplane_b;
+      const bool prok = ph < a.Hp;
+      const float* lp2 = lds + C::O_FLOATS + cb2 * C::PPS + rem2;
+#pragma unroll
+      for (int k = 0; k < NP2; ++k) {
+        const f32x4 o = *(const f32x4*)(lp2 + k * CS2 * C::PPS);
+        if (pw + 3 < a.Wp) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, prok ? ppix : DROP, (unsigned)(k * CS2) * pplane_b, 0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[r]), p_rsrc,
+                                                  (prok && pw + r < a.Wp) ? ppix + 4u * r : DROP, (unsigned)(k * CS2) * pplane_b, 0);
+        }
+      }
+    }
     DLWP_STAMP(6);
     return;
   }
@@ -721,6 +759,10 @@ static void wino_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
       wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true>>(a, grid, s);
       return;
     }
+    if (a.y2) {     // dlwp_conv2d_fwd_pool2 (conv_fwd.hip: float32, plain source)
+      wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true>>(a, grid, s);
+      return;
+    }
   }
   if (a.in_bf16) wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true>>(a, grid, s);
   else wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false>>(a, grid, s);
@@ -736,6 +778,7 @@ static int wino_prepare_both() {
   }
   if constexpr (DIL == 1 && TH == 8 && TW == 32 && WAVES == 4 && BNF == 2) {
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true>>();
+    if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true>>();
   }
   return e;
 }

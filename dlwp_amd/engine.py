@@ -221,11 +221,12 @@ class Executor(object):
             if (op.kind == 'phasew' and skip_phasew) or k in skip_ops or k in done:
                 continue
             src, dst = res(op.src), res(op.dst)
-            if k in pooled_too and (not prepared or prepared.get(k) is None):
+            if k in pooled_too:
                 # training forward: the layer's output AND its MaxPooling2D(2) image from one launch (the pooling op is skipped)
                 kp = pooled_too[k]
                 kern, bias = self.conv_weights(op)
-                if ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], out_pool2=res(self.plan.ops[kp].dst)) is not None:
+                if ops.conv2d(src, kern, bias, d, out=dst, x_channels=op.xs[0], prepared=prepared.get(k) if prepared else None,
+                              out_pool2=res(self.plan.ops[kp].dst)) is not None:
                     done.add(kp)
                     continue
             if op.kind == 'conv' and op.src2 is not None:          # a whole ConvLSTM2D step (dlwp_convlstm_step_fwd)

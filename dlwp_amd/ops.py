@@ -178,8 +178,8 @@ def conv2d(x, w_hwio, bias, cd, out=None, direct=False, x_channels=None, compute
         _check_f32(x, out, out_pool2)
         if tuple(out_pool2.shape) != (n, oc, ys.h // 2, ys.w // 2) or not out_pool2.is_contiguous():
             raise ValueError('pooled output buffer shape %s != %s' % (tuple(out_pool2.shape), (n, oc, ys.h // 2, ys.w // 2)))
-        rc = _lib.lib.dlwp_conv2d_fwd_pool2(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(bias), _ptr(out), _ptr(out_pool2),
-                                            xs, ctypes.byref(cd), dt, _stream(x))
+        rc = _lib.lib.dlwp_conv2d_fwd_pool2(_lib.handle(_dev(x)), _ptr(x), _ptr(w_hwio), _ptr(prepared), _ptr(bias), _ptr(out),
+                                            _ptr(out_pool2), xs, ctypes.byref(cd), dt, _stream(x))
         if rc == _lib.EUNSUPPORTED:
             return None
         _lib.check(rc)

@@ -145,10 +145,12 @@ int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys
 int dlwp_conv2d_fwd(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                     const dlwp_conv2d* cd, int dtype, void* stream);
 /* y AND its MaxPooling2D(2) image y_pool (n, out_c_total, ho/2, wo/2) from one launch: the training forward of a Conv2D under a
- * pooling layer (examples/train.py:164-171: the backward pass needs y, the next layer the pooled tensor).  float32, no other
- * epilogue option in cd.  DLWP_EUNSUPPORTED where the layer's kernel has no such epilogue: dlwp_conv2d_fwd + dlwp_maxpool2_fwd. */
-int dlwp_conv2d_fwd_pool2(dlwp_handle_t, const void* x, const void* w, const void* bias, void* y, void* y_pool, dlwp_shape4 xs,
-                          const dlwp_conv2d* cd, int dtype, void* stream);
+ * pooling layer (examples/train.py:164-181: the backward pass needs y, the next layer the pooled tensor).  float32, no other
+ * epilogue option in cd; prepared: as dlwp_conv2d_fwd_prepared (built for the same xs / cd with out_pool = 1 -- the instance is
+ * chosen as for the pooling epilogue), or NULL.  DLWP_EUNSUPPORTED where the layer's kernel has no such epilogue:
+ * dlwp_conv2d_fwd + dlwp_maxpool2_fwd.                                                                                       */
+int dlwp_conv2d_fwd_pool2(dlwp_handle_t, const void* x, const void* w, const void* prepared, const void* bias, void* y,
+                          void* y_pool, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, void* stream);
 /* Weight-stationary use (model.predict over many batches, the rollout of DLWP/model/models.py:263-310): some kernel
  * families read the weights in a prepared layout (Winograd G g G^T, packed-N expansion, bf16 arrangement), which
  * dlwp_conv2d_fwd builds in the handle's scratch before every launch (~5 us).  dlwp_conv2d_prepare builds it once into

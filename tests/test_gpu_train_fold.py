@@ -361,13 +361,33 @@ def test_convolution_that_stores_its_pooled_image_as_well():
         p = torch.full_like(p_ref, float('nan'))
         assert ops.conv2d(x, wt, b, cd, out=y, out_pool2=p) is not None, (cin, cout, h, w)
         assert torch.equal(y, y_ref) and torch.equal(p, p_ref), (cin, cout, h, w)
+    # Winograd layers: the 8 x 32 / 32-channel instance has the second staging area (config 3's second layer at its grid, ragged
+    # right edge: 90 = 2 x 32 + 26 columns), with prepared filters or not; where the heuristic takes another instance: None
+    for (n, cin, cout, h, w) in [(8, 32, 64, 44, 90), (64, 32, 64, 44, 90), (4, 64, 32, 22, 46)]:
+        x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+        wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+        b = dev((0.1 * rng.standard_normal(cout)).astype(np.float32))
+        cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
+        y_ref = ops.conv2d(x, wt, b, cd)
+        p_ref = ops.maxpool2(y_ref)
+        for prep in (None, ops.conv2d_prepare(x, wt, cd)):
+            y = torch.full_like(y_ref, float('nan'))
+            p = torch.full_like(p_ref, float('nan'))
+            if ops.conv2d(x, wt, b, cd, out=y, prepared=prep, out_pool2=p) is None:
+                assert (n, h) != (64, 44), 'config 3, layer 2 at 64 samples must store both'
+                assert torch.isnan(y).all() and torch.isnan(p).all()
+                continue
+            assert torch.equal(y, y_ref) and torch.equal(p, p_ref), (n, cin, cout, h, w, prep is not None)
     x = dev(rng.standard_normal((2, 32, 16, 24)).astype(np.float32))
-    wt = dev(np_ref.glorot_uniform((3, 3, 32, 64), rng))
-    cd = ops.make_conv(64, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
-    y = torch.full((2, 64, 16, 24), float('nan'), device='cuda')
-    p = torch.full((2, 64, 8, 12), float('nan'), device='cuda')
-    assert ops.conv2d(x, wt, None, cd, out=y, out_pool2=p) is None
-    assert torch.isnan(y).all() and torch.isnan(p).all()
+    wt = dev(np_ref.glorot_uniform((5, 5, 32, 8), rng))
+    cd = ops.make_conv(8, 5, 5, 1, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH)
+    y = torch.full((2, 8, 16, 24), float('nan'), device='cuda')
+    p = torch.full((2, 8, 8, 12), float('nan'), device='cuda')
+    if ops.conv2d(x, wt, None, cd, out=y, out_pool2=p) is None:               # (a layer without such an epilogue writes nothing)
+        assert torch.isnan(y).all() and torch.isnan(p).all()
+    else:
+        y_ref = ops.conv2d(x, wt, None, cd)
+        assert torch.equal(y, y_ref) and torch.equal(p, ops.maxpool2(y_ref))
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,act', [(4, 64, 32, 44, 90, 'tanh'), (8, 32, 16, 44, 90, 'tanh'), (64, 32, 16, 44, 90, 'tanh'),
