@@ -75,9 +75,11 @@ def config_symbol(cfg, ups=False):
     if fa == 0:
         split = len(cfg) > 10 and cfg[10] and not ups
         if split:          # the 16-position case of these entries: positions split over two waves per tile fragment
-            return 'conv2d_fwd_wino2_f32<WinoSplitCfg<%d, %d, %d, %d, %d, %d, false> >' % (dil, th, tw, waves, bnf, ck)
-        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s> >' % (dil, th, tw, waves, bnf, ck,
-                                                                                  'true' if ups else 'false')
+            return 'conv2d_fwd_wino2_f32<WinoSplitCfg<%d, %d, %d, %d, %d, %d, false, false> >' % (dil, th, tw, waves, bnf,
+                                                                                                 ck)
+        # <..., IN16, UPS, DACT, POOL2>: the inference plan uses neither the training epilogue nor the second output
+        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s, false, false> >' % (
+            dil, th, tw, waves, bnf, ck, 'true' if ups else 'false')
     if bnf < 0:
         return 'conv2d_fwd_packn_f32<PackCfg<%d, %d, %d, %d, %d, %d, %d, %d> >' % (ks, dil, th, tw, waves, fa, ck, -bnf)
     if pool >= 2:

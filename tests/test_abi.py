@@ -72,3 +72,48 @@ def test_compiled_tile_configurations_cover_the_unet_layers():
         if fa == 0:                                                 # Winograd instance: 2x2 tiles, one fragment / wave
             pixels, fa = th * tw // 4, 1
         assert pixels <= 16 * fa * waves and lds <= 160 * 1024 and ck % 4 == 0
+
+
+def test_bench_kernel_symbols_match_the_committed_profiles():
+    """bench.py quotes rocprofv3's average duration and the PMC traffic of the dominant kernel from profiles/ by kernel
+    symbol.  The symbol it composes from a tile configuration has to be the one the library really emits (template
+    arguments included), or the lookup silently falls back to an older summary: every forward kernel of the newest
+    same-source kernel-stats summary must be found by the name bench.py would compose for it."""
+    import csv, glob, json, os, re, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.kernel_source_hash()
+    found = 0
+    for meta_file in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*kernel_stats.meta.json')), reverse=True):
+        meta = json.load(open(meta_file))
+        if meta.get('source_sha') != sha:
+            continue
+        names = [r['Name'] for r in csv.DictReader(open(meta_file[:-len('.meta.json')] + '.csv'))]
+        for n in names:
+            m = re.search(r'conv2d_fwd_wino_f32<WinoCfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), false, (true|false)', n)
+            if m:
+                dil, th, tw, waves, bnf, ck = map(int, m.groups()[:6])
+                sym = bench.config_symbol((3, dil, th, tw, waves, 0, bnf, ck, 0, 0, 0), ups=m.group(7) == 'true')
+                assert sym in n, (sym, n)
+                found += 1
+            m = re.search(r'conv2d_fwd_wino2_f32<WinoSplitCfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), false', n)
+            if m:
+                dil, th, tw, waves, bnf, ck = map(int, m.groups())
+                sym = bench.config_symbol((3, dil, th, tw, waves, 0, bnf, ck, 0, 0, 1))
+                assert sym in n, (sym, n)
+                found += 1
+            m = re.search(r'conv2d_fwd_mfma_f32<ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)', n)
+            if m:
+                v = list(map(int, m.groups()[:8]))
+                sym = bench.config_symbol(tuple(v) + (1 if m.group(9) == 'true' else 0,))
+                assert sym in n, (sym, n)
+                found += 1
+        break
+    else:
+        pytest.skip('no kernel-stats summary of the current kernel source in profiles/')
+    assert found >= 3
+    ent = bench.rocprof_launch_ms('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false> >', 256)
+    assert ent and ent['same_source']
+    traffic, src = bench.measured_traffic('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false> >', 256)
+    assert traffic and 2.0e8 < traffic < 4.0e8, (traffic, src)
