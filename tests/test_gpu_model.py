@@ -155,6 +155,29 @@ def test_predict_timeseries_pipelined_host_copy_is_bit_identical():
         d.host_chunk_members = 64
 
 
+@pytest.mark.parametrize('n', [1031, 2101])
+def test_full_size_ensemble_beyond_a_thousand_members(n):
+    """1031 / 2101 members (odd: one unpaired member after the sample pairs, a ragged last host chunk) of the full 88 x 180
+    grid in one rollout: activations of 2.1 / 4.3 GB per layer (past 32-bit byte offsets), per-sample buffer descriptors
+    on 64-bit sample bases.  The first, a middle
+    and the last members equal the same members run as a small ensemble (other tile configurations are chosen there: equal
+    to rounding, not to the bit), device-resident and through the chunked host return."""
+    import torch
+    rng = np.random.default_rng(77)
+    cs = (4, 88, 180)
+    d = _build(unet_layers(cs), time_dim=2)
+    _weights_of(d.model, rng)
+    x = torch.from_numpy(rng.standard_normal((8,) + cs).astype(np.float32)).cuda()
+    x = (x.repeat((n + 7) // 8, 1, 1, 1)[:n] * torch.linspace(0.5, 1.5, n, device='cuda')[:, None, None, None]).contiguous()
+    dev = d.predict_timeseries(x, 4, return_device=True)
+    assert tuple(dev.shape) == (4, n) + (2,) + cs[1:] and bool(torch.isfinite(dev).all())
+    for lo, hi in ((0, 5), (511, 518), (n - 7, n)):
+        small = d.predict_timeseries(x[lo:hi].contiguous(), 4, return_device=True)
+        assert _rel(dev[:, lo:hi].cpu().numpy(), small.cpu().numpy()) < 2e-5, (lo, hi)
+    host = d.predict_timeseries(x, 4)                                 # chunks of 64 members and a ragged last one
+    assert isinstance(host, np.ndarray) and np.array_equal(host, dev.cpu().numpy())
+
+
 def test_member_sharding_is_bit_identical():
     """Ensemble members are independent: a rollout of a shard equals the same rows of the full rollout (what lets the
     8-GPU run be compared member by member with the 1-GPU run)."""
