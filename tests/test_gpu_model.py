@@ -472,6 +472,26 @@ def test_train_step_gradients_loss_and_adam_match_autograd_oracle():
     assert ev[0] == pytest.approx(np_ref.mse(y, out1), rel=1e-3) and ev[1] == pytest.approx(np_ref.mae(y, out1), rel=1e-3)
 
 
+def test_full_size_training_batch_of_520_equals_its_eight_distinct_samples():
+    """A batch of 520 at 88 x 180 (65 copies of 8 samples; 1 GB per activation, 4 160 weight-gradient tiles per layer-2
+    channel block, the partial-sum workspaces at their large-batch sizes) has the loss and the mean gradient of the 8
+    samples: a size-independent check of the whole training step far above the batches the benchmarks use."""
+    rng = np.random.default_rng(21)
+    cs = (4, 88, 180)
+    x8 = rng.standard_normal((8,) + cs).astype(np.float32)
+    y8 = rng.standard_normal((8,) + cs).astype(np.float32)
+    got = []
+    for reps in (1, 65):
+        d = _build(unet_layers(cs), time_dim=2, seed=5)
+        vals = d.model.train_on_batch(np.tile(x8, (reps, 1, 1, 1)), np.tile(y8, (reps, 1, 1, 1)))
+        torch.cuda.synchronize()
+        got.append((vals, d.model._trainer.flat_grads.cpu().numpy().copy()))
+    (v8, g8), (v520, g520) = got
+    assert v520[0] == pytest.approx(v8[0], rel=2e-5) and v520[1] == pytest.approx(v8[1], rel=2e-5)
+    assert np.isfinite(g520).all() and np.abs(g8).max() > 0
+    assert np.abs(g520 - g8).max() <= 2e-4 * np.abs(g8).max()
+
+
 def test_captured_training_step_equals_the_eager_step(monkeypatch):
     """A batch shape seen more than twice runs as one captured hipGraph (Trainer._graph_step: forward, loss, backward and the
     Adam update with the step number in device memory).  Same kernels, same order: weights, reported loss and the step
