@@ -241,7 +241,13 @@ def time_layers(model, members, iters=5):
                op.halo.left % 2 == 1)
         info = ops.conv_launch_info((members, op.xs[0], op.xs[1], op.xs[2]), d, ex._conv_dtype(op),
                                     model.device.index or 0)
-        launch_flops = [(config_symbol(cfgs[i[0]], ups) if i[0] >= 0 else 'conv2d_fwd_direct_f32', i[3]) for i in info]
+        def symbol_of(i):
+            if i[0] >= 0:
+                return config_symbol(cfgs[i[0]], ups)
+            if i[0] == -2:      # dlwp_conv2d_launch_info: the few-channel streaming kernel (csrc/conv_fwd_few.hip), <DIL, ACT, QUAD>
+                return 'conv2d_fwd_few_f32<%d, ' % dil_run[0]
+            return 'conv2d_fwd_direct_f32'
+        launch_flops = [(symbol_of(i), i[3]) for i in info]
         cfg = cfgs[info[0][0]] if info and info[0][0] >= 0 else None
         rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': dil_run[0], 'tile_cfg': cfg,
                      'kernel': launch_flops[0][0], 'launches': len(info), 'out': [ho, wo], 'ms_isolated': ms,

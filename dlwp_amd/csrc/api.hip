@@ -19,6 +19,8 @@ static dlwp_options& default_options_rw() {
     o.winograd = (e && e[0] == '0') ? 0 : 1;
     e = getenv("DLWP_BF16_MFMA");
     o.bf16_mfma = (e && e[0] == '0') ? 0 : 1;
+    e = getenv("DLWP_FEW_STREAM");        // (A/B runs of DLWP_OPT_FEW_STREAM)
+    if (e && e[0] >= '0' && e[0] <= '2') o.few_stream = e[0] - '0';
     e = getenv("DLWP_WGRAD_FILL");        // (A/B runs of DLWP_OPT_WGRAD_FILL)
     if (e && atoi(e) >= 1 && atoi(e) <= 64) o.wgrad_fill = atoi(e);
     return o;
@@ -35,6 +37,7 @@ static int set_in(dlwp_options& o, int option, int value, int* previous, const c
     case DLWP_OPT_FORCE_CONV_CONFIG: slot = &o.forced_cfg; break;
     case DLWP_OPT_FORCE_WGRAD_CONFIG: slot = &o.forced_wgrad; break;
     case DLWP_OPT_WINO_PAIRS: slot = &o.wino_pairs; value = value ? 1 : 0; break;
+    case DLWP_OPT_FEW_STREAM: slot = &o.few_stream; value = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case DLWP_OPT_WGRAD_FILL: slot = &o.wgrad_fill; value = value < 1 ? 1 : (value > 64 ? 64 : value); break;
     default: DLWP_FAIL(DLWP_EINVAL, "%s: unknown option %d", fn, option);
   }

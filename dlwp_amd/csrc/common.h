@@ -11,6 +11,7 @@
 // logic) starts from: DLWP_WINOGRAD / DLWP_BF16_MFMA in the environment, read once.
 struct dlwp_options {
   int winograd = 1, bf16_mfma = 1, forced_cfg = -1, forced_wgrad = -1, wino_pairs = 1;
+  int few_stream = 1;   // conv_fwd_few.hip: 0 off, 1 when the batch is large enough, 2 whenever the layer qualifies (DLWP_OPT_FEW_STREAM)
   int wgrad_fill = 4;   // weight gradient: workgroups per CU the split count aims at, in eighths of 16 waves (DLWP_OPT_WGRAD_FILL)
 };
 const dlwp_options& dlwp_default_options();

@@ -657,6 +657,23 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
   return DLWP_OK;
 }
 
+// conv_fwd_few.hip instead of the chosen direct-family instance?  Returns the grid (0: no).  The streaming kernel amortises a tile
+// position's bookkeeping over the samples a workgroup walks.  Grid = 3 workgroups per CU: that is how many the hardware keeps
+// resident (measured with s_memrealtime stamps, tools/microbench/few_phase_timing.hip: of 4 per CU a quarter starts when the
+// first ones end; layer 1 at 256 members: 0.119 / 0.114 / 0.125 / 0.129 ms with 2 / 3 / 4 / 5 per CU).  Used from 2.5 items per
+// workgroup on (measured against the general kernel on the 88 x 180 grid: 16 members 14.7 vs 13.6 us, 24: 18.8 vs 18.5,
+// 32: 19.9 vs 22.5, 64: 33.8 vs 39.8, 128: 59.3 vs 77.2, 256: 114 vs 144).
+int few_stream_grid(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, const LaunchPlan& lp) {
+  if (h->opt.few_stream == 0 || h->opt.forced_cfg >= 0 || lp.primary < 0 || cd->kh != cd->kw) return 0;
+  const ConvKernelEntry& e = registry().entries[lp.primary];
+  if (is_wino(e) || is_bf16(e) || e.pack != 0 || lp.narrow >= 0 || lp.pair_vw != 0) return 0;
+  if (!dlwp_conv_few_covers(a, cd->kh, cd->dil_h, cd->dil_w)) return 0;
+  const long long items = (long long)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 32) * a.N;
+  const long long slots = 3ll * h->cu_count;
+  if (h->opt.few_stream == 1 && 2 * items < 5 * slots) return 0;
+  return (int)(items < slots ? items : slots);
+}
+
 }  // namespace (second part)
 
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
@@ -722,6 +739,17 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
       DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd_pool2: this layer's kernel cannot store both tensors");
     a.out_pool = 0;                 // (a.Hp / a.Wp stay: the pooled tensor's shape)
     a.y2 = (float*)y_pool;
+  }
+  if (!lstm && !act_epi && !y_pool) {
+    const int fg = few_stream_grid(h, a, cd, lp);
+    if (fg > 0) {
+      a.tiles_h = dlwp_ceil_div(a.Ho, 8);
+      a.tiles_w = dlwp_ceil_div(a.Wo, 32);
+      a.cout_tiles = dlwp_ceil_div(a.Cout, 32);
+      dlwp_conv_few_launch(a, cd->dil_h, fg, s);
+      DLWP_LAUNCH_CHECK("conv2d_fwd_few_f32");
+      return DLWP_OK;
+    }
   }
   auto ensure_prepared = [&](int idx) -> int {
     if (!r.prepared[idx]) {
@@ -1145,6 +1173,12 @@ int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
     const long long total = (long long)a.N * a.Cout * a.Ho * a.Wo;
     const long long want = (total + 255) / 256, cap = (long long)h->cu_count * 16;
     out2[0] = dlwp_launch_info{-1, (int)(want < cap ? want : cap), 256, 0.0, 0};
+    *n_launches = 1;
+    return DLWP_OK;
+  }
+  if (const int fg = few_stream_grid(h, a, cd, lp)) {   // config -2: conv_fwd_few.hip -- 72 MFMAs per wave and 8 x 32 / 32-channel item
+    const double items = (double)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 32) * a.N;
+    out2[0] = dlwp_launch_info{-2, fg, 256, 2.0 * 256.0 * 32.0 * 36.0 * items, 0};
     *n_launches = 1;
     return DLWP_OK;
   }

@@ -603,3 +603,10 @@ static int conv_prepare() {
   }
 #define CONV_ENTRY(KS, DIL, TH, TW, WAVES, FA, BNF, CK) CONV_ENTRY_P(KS, DIL, TH, TW, WAVES, FA, BNF, CK, false)
 #define CONV_ENTRY_POOL(KS, DIL, TH, TW, WAVES, FA, BNF, CK) CONV_ENTRY_P(KS, DIL, TH, TW, WAVES, FA, BNF, CK, true)
+
+// conv_fwd_few.hip: the streaming kernel for 3x3 layers of at most four input channels under a pooling epilogue (the first
+// layer of a large ensemble).  Not a registry entry: dlwp_launch_conv2d substitutes it for the direct family's 8 x 32 instance
+// -- same tiles, same bits -- when the batch gives every workgroup several samples to walk over (DLWP_OPT_FEW_STREAM).
+bool dlwp_conv_few_covers(const ConvArgs& a, int ks, int dil_h, int dil_w);
+void dlwp_conv_few_launch(const ConvArgs& a, int dil, int grid, hipStream_t s);
+

@@ -406,6 +406,12 @@ def force_conv_config(i):
     _lib.set_option(_lib.OPT_FORCE_CONV_CONFIG, int(i))
 
 
+def set_few_stream(mode):
+    """DLWP_OPT_FEW_STREAM: the streaming kernel for pooled 3x3 layers of at most four input channels (csrc/conv_fwd_few.hip):
+    0 never, 1 from 8 tiles per workgroup on (default), 2 whenever the layer qualifies.  Returns the previous setting."""
+    return int(_lib.set_option(_lib.OPT_FEW_STREAM, int(mode)))
+
+
 def prefers_unfused_pool(cin, cout, kh, kw, dil_h, dil_w):
     """Planner hint: materialise a MaxPooling2D in front of this convolution instead of fusing it into the loader?"""
     return bool(_lib.lib.dlwp_conv2d_prefers_unfused_pool(_lib.handle_or_none(), cin, cout, kh, kw, dil_h, dil_w))

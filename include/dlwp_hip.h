@@ -122,6 +122,10 @@ int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, cha
                                         * the six weight gradients of the config-2 U-Net, 8 / 64 samples: 0.306 / 1.291 ms at 16,
                                         * 0.251 / 1.172 ms at 4, 0.263 / 1.820 ms at 2, tools/bench_reduce_jobs.py).  Every
                                         * split writes a slab the size of the weight tensor: fewer splits = less slab traffic    */
+#define DLWP_OPT_FEW_STREAM         6  /* 3x3 layers of at most 4 input channels under a pooling epilogue (the first layer):
+                                        * the streaming kernel that keeps the weights in registers and walks over the samples
+                                        * (csrc/conv_fwd_few.hip) -- 1 (default): from 8 tiles per workgroup on, 0: never,
+                                        * 2: whenever the layer qualifies.  Same bits as the direct family's instance         */
 int         dlwp_set_option(dlwp_handle_t h, int option, int value, int* previous);
 /* the defaults themselves: what handles created AFTERWARDS start from, and what the handle-less host logic (planner hints
  * called with a NULL handle, e.g. on a machine without a GPU) uses.  Existing handles are not touched.                 */
@@ -203,7 +207,8 @@ int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd
  * padded GEMM volume its MFMA instructions multiply, 2 FLOP per multiply-add, tile / channel padding included and with
  * Winograd's 16 (9) multiplies per 2x2 outputs instead of the direct 36.  For the fp32 families this is exactly
  * SQ_INSTS_MFMA x 2048 (v_mfma_f32_16x16x4_f32) of a rocprofv3 --pmc pass.  config: index for dlwp_conv2d_config_info
- * (-1: the one-thread-per-output vector kernel, no matrix work).  out2 must hold 2 entries.                              */
+ * (-1: the one-thread-per-output vector kernel, no matrix work; -2: the streaming kernel of DLWP_OPT_FEW_STREAM, whose grid
+ * is a number of persistent workgroups, not of tiles).  out2 must hold 2 entries.                                         */
 typedef struct {
   int config, grid, block_threads;
   double matrix_flops;

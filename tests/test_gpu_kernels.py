@@ -234,6 +234,66 @@ def test_conv2d_every_compiled_tile_configuration(ops):
         ops.force_conv_config(-1)
 
 
+@pytest.mark.parametrize('dil', [1, 2])
+def test_few_channel_streaming_kernel_equals_the_general_instance(ops, dil):
+    """csrc/conv_fwd_few.hip (pooled 3x3 layers of at most four input channels; weights in registers, a workgroup walks over the
+    samples of one tile position): the bits of the direct family's instance it stands in for, and the float64 oracle -- ragged
+    tiles in both directions, 1 / 3 / 4 input channels, 16 / 32 / 40 output channels, every activation, wrap / zero / edge halos,
+    channel windows on both sides, a batch that leaves workgroups with one item and with several (position changes inside a
+    workgroup's share)."""
+    rng = np.random.default_rng(400 + dil)
+    p = dil
+    cases = [  # n, cin, h, w, cout, mode_h, mode_w, act
+        (5, 4, 20, 52, 32, 0, 1, 'tanh'),
+        (3, 3, 18, 76, 40, 2, 1, 'relu'),
+        (70, 1, 10, 36, 16, 1, 0, 'linear'),
+        (300, 4, 12, 68, 32, 0, 1, 'tanh'),
+        (4, 2, 16, 44, 32, 0, 2, 'tanh'),       # edge columns: the dword loader (no aligned 16-byte quads across the halo)
+        (3, 4, 24, 72, 32, 0, 1, 'relu'),       # pooled width 36: 16-byte stores
+    ]
+    for n, cin, h, w, cout, mh, mw, act in cases:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+        b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        cd = ops.make_conv(cout, 3, 3, dil, ops.make_pad(p, p, p, p, mh, mw), ops.ACTIVATIONS[act], out_pool=True)
+        xd, wd, bd = dev(x), dev(wt), dev(b)
+        prev = ops.set_few_stream(0)
+        try:
+            base = ops.conv2d(xd, wd, bd, cd)
+            assert ops.conv_launch_info(x.shape, cd)[0][0] >= 0
+            ops.set_few_stream(2)
+            info = ops.conv_launch_info(x.shape, cd)
+            assert info[0][0] == -2 and info[0][2] == 256, info
+            got = ops.conv2d(xd, wd, bd, cd)
+        finally:
+            ops.set_few_stream(prev)
+        assert torch.equal(got, base), (n, cin, h, w, cout, float((got - base).abs().max()))
+        if n <= 5:
+            want = np_ref.maxpool2(_conv_ref(x, wt, b, dil, (p, p, p, p), mh, mw, act, 0))
+            _check_conv(ops, host(got), want, 'few-channel stream %r' % ((n, cin, h, w, cout),))
+    # channel windows: 3 of 6 stored input channels from channel 2, the 32 outputs into channels 8.. of a 48-channel tensor
+    n, h, w = 9, 16, 40
+    x6 = rng.standard_normal((n, 6, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, 3, 32), rng)
+    b = (0.1 * rng.standard_normal(32)).astype(np.float32)
+    cd = ops.make_conv(32, 3, 3, dil, ops.make_pad(p, p, p, p, 0, 1), ops.ACT_TANH, in_c_off=2, in_c_total=6, out_c_off=8,
+                       out_c_total=48, out_pool=True)
+    outs = []
+    prev = ops.set_few_stream(0)
+    try:
+        for mode in (0, 2):
+            ops.set_few_stream(mode)
+            y = torch.full((n, 48, h // 2, w // 2), 7.0, device='cuda')
+            ops.conv2d(dev(x6), dev(wt), dev(b), cd, out=y, x_channels=3)
+            outs.append(y)
+    finally:
+        ops.set_few_stream(prev)
+    assert torch.equal(outs[0], outs[1])
+    want = np_ref.maxpool2(_conv_ref(x6[:, 2:5], wt, b, dil, (p, p, p, p), 0, 1, 'tanh', 0))
+    _check_conv(ops, host(outs[1][:, 8:40]), want, 'few-channel stream, channel windows')
+    assert float(outs[1][:, :8].min()) == 7.0 and float(outs[1][:, 40:].max()) == 7.0
+
+
 def test_winograd_nine_position_variants_of_every_instance(ops):
     """The WinoCfg::UPS variants (up-sampled source with an odd halo; 2x2 summing epilogue) of every dilation-1 Winograd
     instance, forced in turn, against the float64 oracle -- and bit-identical across instances."""
