@@ -47,8 +47,7 @@ struct FewCfg {
   static constexpr int EPL = QUAD ? 4 : 1;            // floats per staged element
   static constexpr int NQ = (PS_RAW / EPL + 63) / 64;  // elements a lane stages (a wave = one channel plane)
   static constexpr int X_FLOATS = 4 * PS;
-  static constexpr int TRASH = 2 * X_FLOATS;          // 64 elements nobody reads: the last element group's lanes past the tile
-  static constexpr int LDS_BYTES = (2 * X_FLOATS + 64 * EPL) * 4;
+  static constexpr int LDS_BYTES = 2 * X_FLOATS * 4;
 };
 
 // Items = (8 x 32 tile position incl. the 32-channel tile, sample).  Order: groups of `group` samples outermost, then the
@@ -155,9 +154,9 @@ __global__ __launch_bounds__(256, 4) void conv2d_fwd_few_f32(const ConvArgs a, c
   // 8 (m >> 2) + 4 (i & 1) + (m & 3), channel lane >> 4: the D registers of the four fragments then hold the 2x2 windows of FOUR
   // CONSECUTIVE pooled pixels of one channel -- one 16-byte store, 64-byte runs per channel and store instruction
   const int abase = (lane >> 4) * C::PS + (2 * wave) * C::LC + 8 * ((lane & 15) >> 2) + (lane & 3) + (C::QUAD ? 4 - a.pad_left : 0);
-  // LDS slots of the staged elements: channel plane `wave`, element lane + 64 q (the last group's lanes past the tile: trash)
+  // LDS slots of the staged elements: channel plane `wave`, element lane + 64 q (the last group's lanes past the tile: not written)
   const int sbase = wave * C::PS + lane * C::EPL;
-  const int slast = ((lane + 64 * (C::NQ - 1)) * C::EPL < C::PS_RAW) ? sbase + 64 * (C::NQ - 1) * C::EPL : C::TRASH + lane * C::EPL;
+  const bool last_ok = (lane + 64 * (C::NQ - 1)) * C::EPL < C::PS_RAW;
 
   using elem_t = std::conditional_t<C::QUAD, f32x4, float>;
   elem_t xr[C::NQ];
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_fwd_few_f32(const ConvArgs a, c
   auto stage = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < C::NQ - 1; ++q) *(elem_t*)(lds + buf * C::X_FLOATS + sbase + 64 * q * C::EPL) = xr[q];
-    *(elem_t*)(lds + (slast >= C::TRASH ? 0 : buf * C::X_FLOATS) + slast) = xr[C::NQ - 1];
+    if (last_ok) *(elem_t*)(lds + buf * C::X_FLOATS + sbase + 64 * (C::NQ - 1) * C::EPL) = xr[C::NQ - 1];
   };
 
   // ---- the pipeline.  vmcnt counts loads AND stores in issue order on gfx9, so a wait for loads also waits for every store
@@ -310,13 +309,22 @@ __global__ __launch_bounds__(256, 4) void conv2d_fwd_few_f32(const ConvArgs a, c
   }
 }
 
+#ifdef DLWP_PHASE_TIMING
+int g_few_group_override = 0;
+#endif
+
 template <int DIL, bool QUAD>
 void launch_few(const ConvArgs& a, int grid, hipStream_t s) {
   using C = FewCfg<DIL, QUAD>;
-  // samples per group ~ the length of a workgroup's share (4 .. 64)
+  // samples per group = the length of a workgroup's share: workgroup j then walks (about) one position over one sample group
+  // and its neighbours the positions next to it over the SAME samples.  (A cap of 64 on the group put the neighbours of a
+  // 1024-member launch 24 samples apart: 0.758 ms against the general kernel's 0.531, profiles/r3_few_stream.txt.)
   const long long items = (long long)a.tiles_h * a.tiles_w * a.cout_tiles * a.N;
   int group = (int)((items + grid / 2) / grid);
-  group = group < 4 ? 4 : (group > 64 ? 64 : group);
+  group = group < 4 ? 4 : (group > a.N ? a.N : group);
+#ifdef DLWP_PHASE_TIMING
+  if (g_few_group_override > 0) group = g_few_group_override;   // (tools/microbench/few_phase_timing.hip sweeps it)
+#endif
   if (a.act == DLWP_ACT_TANH)
     hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_TANH, QUAD>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
   else if (a.act == DLWP_ACT_RELU)

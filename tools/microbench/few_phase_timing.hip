@@ -13,7 +13,8 @@
 void dlwp_set_error(const char*, ...) {}
 
 int main(int argc, char** argv) {
-  const int N = argc > 1 ? atoi(argv[1]) : 256, grid = argc > 2 ? atoi(argv[2]) : 1024;
+  const int N = argc > 1 ? atoi(argv[1]) : 256, grid = argc > 2 ? atoi(argv[2]) : 768;
+  g_few_group_override = argc > 3 ? atoi(argv[3]) : 0;   // samples per group (0: the launcher's rule)
   ConvArgs a{};
   const int H = 88, W = 180, Cin = 4, Cout = 32;
   float *x, *w, *b, *y;
@@ -35,6 +36,8 @@ int main(int argc, char** argv) {
   long long* dbg;
   hipMalloc(&dbg, sizeof(long long) * 8 * grid);
   hipMemset(dbg, 0, sizeof(long long) * 8 * grid);
+  if (argc > 4)   // experiment: opt in to a larger dynamic-LDS carve-out (bytes)
+    printf("hipFuncSetAttribute -> %d\n", (int)hipFuncSetAttribute((const void*)conv2d_fwd_few_f32<2, DLWP_ACT_TANH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, atoi(argv[4])));
   a.dbg = nullptr;
   for (int i = 0; i < 3; ++i) dlwp_conv_few_launch(a, 2, grid, 0);
   hipEvent_t e0, e1;
@@ -54,8 +57,8 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 5; ++k) ph[k] += (double)h[g * 8 + k];
     items += (double)h[g * 8 + 5];
   }
-  printf("layer 1 (4 -> 32 @88x180, pooled), %d members: grid %d x 256 threads, %.1f items per workgroup, %.4f ms per launch (untimed runs, stamps compiled in)\n",
-         N, grid, items / grid, ms);
+  printf("layer 1 (4 -> 32 @88x180, pooled), %d members, group %d: grid %d x 256 threads, %.1f items per workgroup, %.4f ms per launch (untimed runs, stamps compiled in)\n",
+         N, g_few_group_override, grid, items / grid, ms);
   printf("   s_memtime ticks per item: MFMAs %.0f | next tile -> LDS incl. load wait %.0f | epilogue + stores %.0f | loads issued %.0f | barrier %.0f  (sum %.0f)\n",
          ph[0] / items, ph[1] / items, ph[2] / items, ph[3] / items, ph[4] / items, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) / items);
   // s_memrealtime (100 MHz, device-wide) at the start of a workgroup's pipeline and at its end

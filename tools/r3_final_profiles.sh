@@ -16,5 +16,8 @@ done
 cd $R
 for b in 64 8; do python tools/bench_train.py --batch $b --steps 40 --warmup 20 > $O/r3_train_b${b}_noprof.json 2>/dev/null; tail -1 $O/r3_train_b${b}_noprof.json | cut -c1-300; done
 bash tools/profile_wgrad.sh r3 > $O/r3_profile_wgrad.log 2>&1
+bash tools/profile_few.sh r3 > $O/r3_profile_few.log 2>&1
+# the bench line quotes the rocprofv3 / PMC summaries of THIS kernel source from profiles/: put the fresh ones there first
+for f in r3_kernel_stats.csv r3_kernel_stats.meta.json r3_hbm_traffic_b256.json r3_mfma_busy.json; do cp $O/$f $R/profiles/$f; done
 timeout 600 python bench.py > $O/r3_bench.json 2> $O/r3_bench.err; echo "bench rc=$?"
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/cfg4_stats $O/cfg4_fetch $O/cfg4_write
