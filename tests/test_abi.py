@@ -109,6 +109,10 @@ def test_bench_kernel_symbols_match_the_committed_profiles():
                 sym = bench.config_symbol(tuple(v) + (1 if m.group(9) == 'true' else 0,))
                 assert sym in n, (sym, n)
                 found += 1
+            m = re.search(r'conv2d_fwd_few_f32<(\d+), ', n)
+            if m:         # the streaming layer-1 kernel: bench.py's time_layers composes this prefix for launch-info config -2
+                assert "'conv2d_fwd_few_f32<%d, ' % dil_run[0]" in open(os.path.join(ROOT, 'bench.py')).read()
+                found += 1
         break
     else:
         pytest.skip('no kernel-stats summary of the current kernel source in profiles/')

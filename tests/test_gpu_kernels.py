@@ -294,6 +294,28 @@ def test_few_channel_streaming_kernel_equals_the_general_instance(ops, dil):
     assert float(outs[1][:, :8].min()) == 7.0 and float(outs[1][:, 40:].max()) == 7.0
 
 
+def test_few_channel_streaming_kernel_is_chosen_by_batch_size(ops):
+    """DLWP_OPT_FEW_STREAM = 1 (default): layer 1 of the 88 x 180 U-Net goes to the streaming kernel from 2.5 tiles per resident
+    workgroup on (3 per CU), the general instance below; never for an unpooled launch, more than four input channels or 5x5."""
+    cd = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH, out_pool=True)
+    assert ops.conv_launch_info((256, 4, 88, 180), cd)[0][0] == -2
+    g = ops.conv_launch_info((256, 4, 88, 180), cd)[0]
+    assert g[2] == 256 and g[1] % 3 == 0 and g[3] == 2.0 * 256 * 32 * 36 * 11 * 6 * 256      # 3 workgroups per CU; 72 MFMAs per wave and tile
+    assert ops.conv_launch_info((64, 4, 88, 180), cd)[0][0] == -2
+    assert ops.conv_launch_info((16, 4, 88, 180), cd)[0][0] >= 0
+    assert ops.conv_launch_info((1, 4, 88, 180), cd)[0][0] >= 0
+    assert ops.conv_launch_info((256, 5, 88, 180), cd)[0][0] >= 0
+    plain = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH)
+    assert ops.conv_launch_info((256, 4, 88, 180), plain)[0][0] >= 0
+    five = ops.make_conv(32, 5, 5, 1, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH, out_pool=True)
+    assert ops.conv_launch_info((256, 4, 88, 180), five)[0][0] != -2
+    prev = ops.set_few_stream(0)
+    try:
+        assert ops.conv_launch_info((256, 4, 88, 180), cd)[0][0] >= 0
+    finally:
+        ops.set_few_stream(prev)
+
+
 def test_winograd_nine_position_variants_of_every_instance(ops):
     """The WinoCfg::UPS variants (up-sampled source with an odd halo; 2x2 summing epilogue) of every dilation-1 Winograd
     instance, forced in turn, against the float64 oracle -- and bit-identical across instances."""
