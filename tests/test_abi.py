@@ -121,3 +121,43 @@ def test_bench_kernel_symbols_match_the_committed_profiles():
     assert ent and ent['same_source']
     traffic, src = bench.measured_traffic('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false> >', 256)
     assert traffic and 2.0e8 < traffic < 4.0e8, (traffic, src)
+
+
+def test_streaming_kernel_item_order_visits_every_tile_of_every_sample_once():
+    """csrc/conv_fwd_few.hip hands (tile position, sample) items to its persistent workgroups by integer arithmetic alone: sample
+    groups as long as a share, positions inside a group, samples inside a position; block b -> logical index (XCD b % 8, slot);
+    share = [T L / grid, T (L + 1) / grid); a ragged last group.  The same arithmetic restated here must visit every item exactly
+    once for any batch, tiling and grid (the GPU tests compare the kernel's results at a handful of sizes; this covers the corners:
+    one member, more workgroups than items, groups longer than the batch, 2101 members)."""
+    def visit(n, npos, grid):
+        total = npos * n
+        group = (total + grid // 2) // grid
+        group = 4 if group < 4 else (n if group > n else group)
+        seen = set()
+        for b in range(grid):
+            xcd, idx, q, r = b & 7, b >> 3, grid >> 3, grid & 7
+            lidx = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+            it = total * lidx // grid
+            left = total * (lidx + 1) // grid - it
+            if left <= 0:
+                continue
+            per = npos * group
+            sg, rem = divmod(it, per)
+            g0 = sg * group
+            gs = min(group, n - g0)
+            pos, sn = divmod(rem, gs)
+            for _ in range(left):
+                assert 0 <= pos < npos and 0 <= g0 + sn < n and gs > 0
+                assert (pos, g0 + sn) not in seen
+                seen.add((pos, g0 + sn))
+                sn += 1
+                if sn == gs:
+                    sn, pos = 0, pos + 1
+                    if pos == npos:
+                        pos, g0 = 0, g0 + gs
+                        gs = min(group, n - g0)
+        assert len(seen) == total, (n, npos, grid)
+    for n in list(range(1, 20)) + [63, 64, 65, 200, 256, 257, 1031, 2101]:
+        for npos in (1, 6, 66):
+            for grid in (1, 7, 30, 768, 1024):
+                visit(n, npos, min(grid, npos * n))
