@@ -727,7 +727,13 @@ def build_plan(inputs, outputs, inference=False, fuse_d2s=True, fuse_lstm=False,
                 w0 = writers[0] if len(writers) == 1 else None
                 if (w0 is not None and w0.kind in ('conv', 'd2s', 'rowconv') and not w0.lstm_f and not w0.out_pool and
                         w0.out_c_off == 0 and w0.out_c_total in (0, lc[0]) and not any(reads(op) for op in plan.ops)):
+                    # every view of the abandoned scratch buffer follows the launch into the output slot (the convolution's own
+                    # tensor in front of the Reshape, slices of it): a consumer lowered LATER -- another branch of a
+                    # multi-output model -- must not read a buffer nothing writes any more
+                    old = v.buf
                     w0.dst = OUT(o)
+                    for uid in [u for u, vv in views.items() if vv.buf == old]:
+                        views[uid] = views[uid].copy(buf=OUT(o))
                     views[t.uid] = View(OUT(o), 0, lc[0], lc[0], lc[1], lc[2], shape=v.shape)
                     continue
             materialize(v, dst=OUT(o), dst_c_off=0, dst_c_total=lc[0])

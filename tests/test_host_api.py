@@ -544,3 +544,17 @@ def test_tf_padding3d_lowers_to_a_mirror_halo_of_the_recurrent_front_end():
         custom.TFPadding3D((0, 1, 1), mode='WRAP', **CF)
     with pytest.raises(NotImplementedError):
         Model(inputs=x0, outputs=custom.TFPadding3D((1, 0, 0), **CF)(x0))       # padding of the first (channel) axis
+
+
+def test_output_written_in_place_behind_a_reshape_is_what_a_later_branch_reads():
+    """a convolution behind a Reshape writes the model's output slot itself; a second branch lowered AFTER that
+    redirect must read the slot, not the abandoned scratch buffer."""
+    x0 = L.Input(shape=(2, 8, 12))
+    a = L.Conv2D(3, 3, padding='same', activation='tanh', **CF)(x0)
+    out0 = L.Reshape((1, 3, 8, 12))(a)
+    out1 = L.Conv2D(2, 3, padding='same', **CF)(a)
+    m = Model(inputs=x0, outputs=[out0, out1])
+    for plan in (m.plan, m.infer_plan):
+        convs = [op for op in plan.ops if op.kind == 'conv']
+        assert [op.kind for op in plan.ops] == ['conv', 'conv']
+        assert convs[0].dst == P.OUT(0) and convs[1].src == P.OUT(0) and convs[1].dst == P.OUT(1)
