@@ -19,6 +19,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'dlwp_hip.h')
 OK, EINVAL, EUNSUPPORTED, EHIP, ERCCL = 0, -1, -2, -3, -4
 OPT_WINOGRAD, OPT_BF16_MFMA, OPT_FORCE_CONV_CONFIG, OPT_FORCE_WGRAD_CONFIG, OPT_WINO_PAIRS, OPT_WGRAD_FILL = 0, 1, 2, 3, 4, 5
 OPT_FEW_STREAM = 6
+OPT_SPLITK = 7
 F32, BF16, BF16_O8 = 0, 1, 2
 PAD_ZERO, PAD_WRAP, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC = 0, 1, 2, 3, 4
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
@@ -26,6 +27,7 @@ SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
 OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES, OP_PHASE_WEIGHTS, OP_DEPTH2SPACE = 0, 1, 2, 3, 4, 5, 6, 7
 OP_ROWCONV2D = 8
 BUF_NONE = -1000
+STEP_LANES, STEP_GRAPH, STEP_GRAPH_BRANCHES = 0, 1, 2
 
 
 COMPUTE_BF16 = 0x20000
@@ -143,6 +145,7 @@ _sig('dlwp_conv2d_supports_dtype', [_vp, Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_supports_out_d2s', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_pick_config', [_vp, Shape4, _P(Conv2d)])
 _sig('dlwp_conv2d_launch_info', [_vp, Shape4, _P(Conv2d), _i, _P(LaunchInfo), _P(_i)])
+_sig('dlwp_conv2d_split_count', [_vp, Shape4, _P(Conv2d), _i])
 _sig('dlwp_conv2d_bwd_workspace', [_vp, Shape4, _P(Conv2d), _i, _P(_sz)])
 _sig('dlwp_conv2d_bwd_data', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])
 _sig('dlwp_conv2d_bwd_data_stored', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _vp])
@@ -201,6 +204,13 @@ _sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i
 _sig('dlwp_rollout_create_grouped', [_vp, _P(Op), _i, _P(_vp), _i, _P(_sz), _i, _vp, _vp, _sz, _i, _i, _i, _vp, _sz, _P(_vp)])
 _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
+_sig('dlwp_train_step_record_begin', [_vp, _vp])
+_sig('dlwp_train_step_record_abort', [_vp])
+_sig('dlwp_stream_wait', [_vp, _vp, _vp])
+_sig('dlwp_train_step_create', [_vp, _i, _P(_vp), _P(_sz), _P(_vp)])
+_sig('dlwp_train_step_info', [_vp, _P(_i), _P(_i), _P(_i)])
+_sig('dlwp_train_step_launch', [_vp, _P(_vp), _i, _vp])
+_sig('dlwp_train_step_destroy', [_vp])
 _sig('dlwp_comm_unique_id', [_vp, _P(_sz)])
 _sig('dlwp_comm_init_rank', [_P(_vp), _i, _i, _i, _vp, _sz])
 _sig('dlwp_comm_info', [_vp, _P(_i), _P(_i), _P(_i)])

@@ -23,6 +23,8 @@ static dlwp_options& default_options_rw() {
     if (e && e[0] >= '0' && e[0] <= '2') o.few_stream = e[0] - '0';
     e = getenv("DLWP_WGRAD_FILL");        // (A/B runs of DLWP_OPT_WGRAD_FILL)
     if (e && atoi(e) >= 1 && atoi(e) <= 64) o.wgrad_fill = atoi(e);
+    e = getenv("DLWP_SPLITK");            // (A/B runs of DLWP_OPT_SPLITK)
+    if (e && atoi(e) >= 0 && atoi(e) <= 64) o.splitk = atoi(e);
     return o;
   }();
   return d;
@@ -39,6 +41,7 @@ static int set_in(dlwp_options& o, int option, int value, int* previous, const c
     case DLWP_OPT_WINO_PAIRS: slot = &o.wino_pairs; value = value ? 1 : 0; break;
     case DLWP_OPT_FEW_STREAM: slot = &o.few_stream; value = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case DLWP_OPT_WGRAD_FILL: slot = &o.wgrad_fill; value = value < 1 ? 1 : (value > 64 ? 64 : value); break;
+    case DLWP_OPT_SPLITK: slot = &o.splitk; value = value < 0 ? 0 : (value > 64 ? 64 : value); break;
     default: DLWP_FAIL(DLWP_EINVAL, "%s: unknown option %d", fn, option);
   }
   if (previous) *previous = *slot;
@@ -80,12 +83,16 @@ int dlwp_create(dlwp_handle_t* out, int device) {
   h->wino_u = nullptr;
   h->wino_u_floats = 0;
   h->prep_defer = h->n_prep = h->red_defer = h->n_red = 0;
+  h->ksplit_mem = nullptr;
+  h->ksplit_used = 0;
+  for (int i = 0; i < DLWP_SPLITK_REGIONS; ++i) h->ksplit_stream[i] = nullptr;
   *out = h;
   return DLWP_OK;
 }
 
 int dlwp_destroy(dlwp_handle_t h) {
   if (h && h->wino_u) (void)hipFree(h->wino_u);
+  if (h && h->ksplit_mem) (void)hipFree(h->ksplit_mem);
   delete h;
   return DLWP_OK;
 }

@@ -11,6 +11,7 @@
 // Reference: the Keras train step behind DLWPNeuralNet.fit / fit_generator (DLWP/model/models.py:188-228); Keras / TF
 // launch one kernel per op and have no counterpart of this file.
 #include "common.h"
+#include "tape.h"
 
 namespace {
 
@@ -250,6 +251,12 @@ extern "C" {
 
 int dlwp_copy_many(dlwp_handle_t h, const void* const* srcs, void* const* dsts, const size_t* floats, int count, void* stream) {
   DLWP_CHECK_ARG(h && srcs && dsts && floats && count >= 0 && count <= 8, "dlwp_copy_many: null pointer or more than 8 copies");
+  dlwp_tape_scope tape_scope_;
+  if (tape_scope_.outer && dlwp_tape_recording(h)) {        // (the pointer tables are the caller's: copied)
+    struct Tables { const void* s[8]; void* d[8]; size_t f[8]; } t;
+    for (int i = 0; i < count; ++i) t.s[i] = srcs[i], t.d[i] = dsts[i], t.f[i] = floats[i];
+    dlwp_tape_push(h, stream, [=](void* s_) -> int { return dlwp_copy_many(h, t.s, t.d, t.f, count, s_); }, "dlwp_copy_many");
+  }
   if (count == 0) return DLWP_OK;
   CopyTable t;
   long long most = 0;
@@ -272,6 +279,7 @@ int dlwp_copy_many(dlwp_handle_t h, const void* const* srcs, void* const* dsts, 
 }
 
 int dlwp_prepare_begin(dlwp_handle_t h) {
+  DLWP_TAPE_HOST(h, dlwp_prepare_begin, h);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_prepare_begin: null handle");
   h->prep_defer = 1;
   h->n_prep = 0;
@@ -279,12 +287,14 @@ int dlwp_prepare_begin(dlwp_handle_t h) {
 }
 
 int dlwp_prepare_flush(dlwp_handle_t h, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_prepare_flush, h);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_prepare_flush: null handle");
   h->prep_defer = 0;
   return launch_prep(h, (hipStream_t)stream);
 }
 
 int dlwp_reductions_begin(dlwp_handle_t h) {
+  DLWP_TAPE_HOST(h, dlwp_reductions_begin, h);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_reductions_begin: null handle");
   h->red_defer = 1;
   h->n_red = 0;
@@ -292,6 +302,7 @@ int dlwp_reductions_begin(dlwp_handle_t h) {
 }
 
 int dlwp_reductions_flush(dlwp_handle_t h, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_reductions_flush, h);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_reductions_flush: null handle");
   h->red_defer = 0;
   return launch_red(h, (hipStream_t)stream);

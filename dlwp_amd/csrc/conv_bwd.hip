@@ -3,6 +3,7 @@
 // DLWPNeuralNet.fit / fit_generator drive (DLWP/model/models.py:188-228; layers of examples/train.py:159-219).
 #include "conv_wgrad_cb_kernel.h"
 #include "conv_wgrad_c4_kernel.h"
+#include "tape.h"
 #include <mutex>
 #include <vector>
 
@@ -300,11 +301,13 @@ static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, 
 
 int dlwp_conv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
                          const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_bwd_data, dlwp_conv2d_bwd_data(h, dz, w, dx, xs, cdp, dtype, ws, ws_bytes, s_));
   return conv2d_bwd_data_impl(h, dz, w, dx, xs, cd, dtype, ws, ws_bytes, stream, 0);
 }
 
 int dlwp_conv2d_bwd_data_stored(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs,
                                 const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_bwd_data_stored, dlwp_conv2d_bwd_data_stored(h, dz, w, dx, xs, cdp, dtype, ws, ws_bytes, s_));
   return conv2d_bwd_data_impl(h, dz, w, dx, xs, cd, dtype, ws, ws_bytes, stream, 1);
 }
 
@@ -316,6 +319,7 @@ int dlwp_conv2d_bwd_data_stored(dlwp_handle_t h, const void* dz, const void* w, 
 int dlwp_conv2d_bwd_data_act(dlwp_handle_t h, const void* dz, const void* w, const void* prepared, void* dx, dlwp_shape4 xs,
                              const dlwp_conv2d* cd, const void* x, int act_in, void* db_in, int dtype, void* ws, size_t ws_bytes,
                              void* stream) {
+  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_bwd_data_act, dlwp_conv2d_bwd_data_act(h, dz, w, prepared, dx, xs, cdp, x, act_in, db_in, dtype, ws, ws_bytes, s_));
   DLWP_CHECK_ARG(x != nullptr, "dlwp_conv2d_bwd_data_act: null layer input");
   DLWP_CHECK_ARG(act_in == DLWP_ACT_TANH || act_in == DLWP_ACT_RELU, "dlwp_conv2d_bwd_data_act: activation %d (tanh / relu)", act_in);
   return conv2d_bwd_data_impl(h, dz, w, dx, xs, cd, dtype, ws, ws_bytes, stream, 0, prepared, x, act_in, db_in);
@@ -334,6 +338,7 @@ size_t dlwp_conv2d_bwd_data_prepared_bytes(dlwp_handle_t h, dlwp_shape4 xs, cons
 
 int dlwp_conv2d_bwd_data_prepare(dlwp_handle_t h, const void* w, void* prepared, dlwp_shape4 xs, const dlwp_conv2d* cd,
                                  int stored, void* stream) {
+  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_bwd_data_prepare, dlwp_conv2d_bwd_data_prepare(h, w, prepared, xs, cdp, stored, s_));
   DLWP_CHECK_ARG(h && w && prepared && cd && xs.n > 0, "dlwp_conv2d_bwd_data_prepare: null handle or pointer");
   DgradPlan p;
   int rc = plan_dgrad(xs, cd, stored, &p);
@@ -356,6 +361,7 @@ int dlwp_conv2d_bwd_data_prepare(dlwp_handle_t h, const void* w, void* prepared,
 
 int dlwp_conv2d_bwd_data_prepared(dlwp_handle_t h, const void* dz, const void* prepared, void* dx, dlwp_shape4 xs,
                                   const dlwp_conv2d* cd, int dtype, void* ws, size_t ws_bytes, int stored, void* stream) {
+  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_bwd_data_prepared, dlwp_conv2d_bwd_data_prepared(h, dz, prepared, dx, xs, cdp, dtype, ws, ws_bytes, stored, s_));
   DLWP_CHECK_ARG(prepared != nullptr, "dlwp_conv2d_bwd_data_prepared: null prepared weights");
   return conv2d_bwd_data_impl(h, dz, nullptr, dx, xs, cd, dtype, ws, ws_bytes, stream, stored, prepared);
 }
@@ -445,6 +451,7 @@ static int conv2d_bwd_weight_impl(dlwp_handle_t h, const void* x, const void* dz
 
 int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void* dw, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int accumulate, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_bwd_weight, dlwp_conv2d_bwd_weight(h, x, dz, dw, xs, cdp, accumulate, dtype, ws, ws_bytes, s_));
   return conv2d_bwd_weight_impl(h, x, dz, dw, xs, cd, accumulate, dtype, ws, ws_bytes, stream, nullptr, nullptr, 0);
 }
 
@@ -454,6 +461,7 @@ int dlwp_conv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void*
 int dlwp_conv2d_bwd_weight_pooled(dlwp_handle_t h, const void* x, const void* y, const void* dpool, void* dw, void* db,
                                   dlwp_shape4 xs, const dlwp_conv2d* cd, int act, int accumulate, int dtype, void* ws,
                                   size_t ws_bytes, void* stream) {
+  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_bwd_weight_pooled, dlwp_conv2d_bwd_weight_pooled(h, x, y, dpool, dw, db, xs, cdp, act, accumulate, dtype, ws, ws_bytes, s_));
   DLWP_CHECK_ARG(dpool != nullptr, "dlwp_conv2d_bwd_weight_pooled: null pooled gradient");
   DLWP_CHECK_ARG(act == DLWP_ACT_LINEAR || act == DLWP_ACT_TANH || act == DLWP_ACT_RELU,
                  "dlwp_conv2d_bwd_weight_pooled: activation %d has no backward here", act);

@@ -64,6 +64,12 @@ struct ConvArgs {
   const float* yact = nullptr;
   int yact_c_off = 0, yact_c_total = 0, dact = 0;
   float* bpart = nullptr;
+  // split-K launches of the Winograd kernel on small grids (conv_fwd_wino_kernel.h, WinoCfg::SPLITK): ksplit workgroups per output
+  // tile multiply kchunks channel chunks each; kslab = one private slab per (tile, split), kcount = one arrival counter per tile
+  // (zero between launches: the finishing workgroup clears it)
+  int ksplit = 0, kchunks = 0;
+  float* kslab = nullptr;
+  unsigned* kcount = nullptr;
 #ifdef DLWP_PHASE_TIMING  // tools/microbench/wino_phase_timing.hip only: s_memtime stamps of wave 0, 8 per block
   long long* dbg = nullptr;
 #endif
@@ -578,6 +584,7 @@ struct ConvKernelEntry {
   int gates = 0; // bf16-MFMA instances: 1 = ConvLSTM2D cell update in the epilogue (dlwp_conv2d.lstm_f), and only that
   int in8 = 0, sw = 0;   // bf16-MFMA instances: the input / the output is stored in the octet layout DLWP_BF16_O8
   int dual = 0;          // bf16-MFMA instances: a whole ConvLSTM2D step (recurrent + input convolution + cell update), and only that
+  int splitk = 0;        // Winograd instances: 1 = a split-K variant is compiled (ConvArgs::ksplit > 1 launches it)
 };
 
 template <class C>

@@ -42,8 +42,14 @@
 // contribute nothing and their MFMAs (and U fragment loads) are left out -- 9 multiplies per 2x2 output tile and channel
 // pair instead of 16 (direct: 36), bit-identical results.
 template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false, bool UPS_ = false, bool DACT_ = false,
-          bool POOL2_ = false>
+          bool POOL2_ = false, bool SPLITK_ = false>
 struct WinoCfg {
+  // SPLITK (r4, small grids): the input channels are divided over ConvArgs::ksplit workgroups per output tile, each of which
+  // multiplies kchunks chunks and leaves its transformed 2x2 outputs (no bias, no activation) in a slab of its own; the workgroup
+  // that arrives LAST at the tile's counter sums the slabs in index order -- a fixed order: deterministic -- adds the bias,
+  // activates (pools) and stores.  Instances of their own, so that the unsplit ones keep their code.
+  static constexpr bool SPLITK = SPLITK_;
+  static_assert(!SPLITK_ || (!DACT_ && !POOL2_ && !IN16_), "split-K: float32 source, plain / pooled / 2x2-sum epilogues");
   // POOL2 (r3, training forward): the block stores its output AND the MaxPooling2D(2) image of it (ConvArgs::y2) -- a second
   // staging area behind the first; an instance of its own (dilation 1: a lane's 2 x 2 output tile is one pooling window)
   static constexpr bool POOL2 = POOL2_;
@@ -110,6 +116,15 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     const int xcd = b & 7, idx = b >> 3, q = nb >> 3, r = nb & 7;
     L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // SPLITK: the splits of one output tile are neighbours in the XCD-contiguous order (their slabs meet in that XCD's L2)
+  int ks = 0;
+  if constexpr (C::SPLITK) {
+    ks = L % a.ksplit;
+    L /= a.ksplit;
+  }
+  const int tile_lin = L;
+  const int c_base = C::SPLITK ? ks * a.kchunks * C::CK : 0;                                    // first input channel of this block
+  const int cin_l = C::SPLITK ? min(a.Cin - c_base, a.kchunks * C::CK) : a.Cin;                 // ... and how many it multiplies
   const int tw = L % a.tiles_w;
   L /= a.tiles_w;
   const int th = L % a.tiles_h;
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   const long long plane = (long long)a.Hs * a.Ws;
   constexpr int ESZ = C::IN16 ? 2 : 4;
   const int n_s = a.pair_vw ? 2 * n : n;          // first (only) sample of this block
-  const char* xn = (const char*)a.x + ((long long)n_s * a.in_c_total + a.in_c_off) * plane * ESZ;
+  const char* xn = (const char*)a.x + ((long long)n_s * a.in_c_total + a.in_c_off + c_base) * plane * ESZ;
   const unsigned plane_bytes = (unsigned)plane * ESZ;
 
   // ---- this lane's tile (= its MFMA A-operand row) and the LDS offset of the tile's 4x4 patch origin, channel l>>4
@@ -177,9 +192,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     u_dst[k] = (ci * C::BN + co) * 4;
   }
   const __amdgpu_buffer_rsrc_t u_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cin * a.Cout * 64, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long long)c_base * a.Cout * 16), 0, cin_l * a.Cout * 64, 0x00020000);
   const int b_lane = ((lane >> 4) * C::BN + (lane & 15)) * 4;
-  const int last_c0 = ((a.Cin + C::CK - 1) / C::CK - 1) * C::CK;   // (Cin may be ragged: the planes past it read 0)
+  const int last_c0 = ((cin_l + C::CK - 1) / C::CK - 1) * C::CK;   // (Cin may be ragged: the planes past it read 0)
 
   // (Measured, r2e: starting the accumulation from a literal-zero C operand in a peeled first chunk instead of clearing the
   // accumulators -- 128 v_mov per lane -- costs 23 registers and a third copy of the loop body and gained nothing.)
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   // check includes the scalar offset.
   // (a sample pair: the window reaches over the second sample's channels; Cin is then a whole number of chunks -- host)
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)xn, 0, (unsigned)a.Cin * plane_bytes + (a.pair_vw ? (unsigned)a.in_c_total * plane_bytes : 0u), 0x00020000);
+      (void*)xn, 0, (unsigned)cin_l * plane_bytes + (a.pair_vw ? (unsigned)a.in_c_total * plane_bytes : 0u), 0x00020000);
   // (Measured, r2p: the loads the last two chunks issue have no chunk of this tile left to fetch; aiming them at chunks 0 / 1
   // of the tile that the NEXT workgroup of this XCD slot will start with -- an L2 prefetch at no instruction cost -- changed
   // nothing, 401.9 vs 403.1 k steps/s: the prologue does not wait for memory.  They stay clamped re-reads.)
@@ -377,11 +392,11 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   DLWP_STAMP(1);
   {
     int c0 = 0;
-    for (; c0 + C::CK < a.Cin; c0 += 2 * C::CK) {
+    for (; c0 + C::CK < cin_l; c0 += 2 * C::CK) {
       chunk(std::integral_constant<int, 0>{}, c0);
       chunk(std::integral_constant<int, 1>{}, c0 + C::CK);
     }
-    if (c0 < a.Cin) chunk(std::integral_constant<int, 0>{}, c0);
+    if (c0 < cin_l) chunk(std::integral_constant<int, 0>{}, c0);
   }
   DLWP_STAMP(2);
   __syncthreads();  // every wave is out of the loop: LDS becomes the output staging area
@@ -413,13 +428,19 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   //      The lane's four tiles are handled as two PAIRS (registers r, r+1 of every accumulator = tiles t, t+1 = horizontal
   //      neighbours of one tile row) in packed fp32: half the vector instructions.
   static_assert(C::RTW % 2 == 0 && C::T % 2 == 0, "tile pairs: neighbours in one tile row");
-  act_dispatch(a.act, [&](auto act_c) {
+  // SPLITK: what a block stages first is its PARTIAL result -- linear, no bias; the full tile unless the epilogue is the 2x2 sum
+  // (linear too: the partial sums are staged pooled).  The bias, the activation and the max-pooling belong to the block that
+  // finishes the tile (below).
+  const int act_stage = C::SPLITK ? DLWP_ACT_LINEAR : a.act;
+  const float* const bias_stage = C::SPLITK ? nullptr : a.bias;
+  const int pool_stage = C::SPLITK ? (a.out_pool == 2 ? 2 : 0) : a.out_pool;
+  act_dispatch(act_stage, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
     auto for_tiles = [&](auto&& body) {
 #pragma unroll
       for (int g = 0; g < C::BNF; ++g) {
         const int col = g * 16 + (lane & 15);
-        const float bv1 = a.bias ? a.bias[n0 + col] : 0.f;
+        const float bv1 = bias_stage ? bias_stage[n0 + col] : 0.f;
         const f32x2 bv = (f32x2){bv1, bv1};
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
@@ -458,7 +479,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
       return C::UPS ? pk_sub(s[aa][1], s[aa][3]) : pk_sub(pk_sub(s[aa][1], s[aa][2]), s[aa][3]);
     };
     if constexpr (C::DIL == 1) {
-      if (a.out_pool == 2) {  // 2x2 sum: 1^T A^T M A 1 with A 1 = (1, 2, 0, -1) -- row / column 2 of M drop out
+      if (pool_stage == 2) {  // 2x2 sum: 1^T A^T M A 1 with A 1 = (1, 2, 0, -1) -- row / column 2 of M drop out
         for_tiles([&](const f32x2 (&s)[2][4], int col, f32x2, int ti, int tj, int, int) {
           const f32x2 t0 = pk_add(s[0][0], s[1][0]), t1 = pk_add(s[0][1], s[1][1]), t3 = pk_add(s[0][3], s[1][3]);
           const f32x2 o = pk_sub(__builtin_elementwise_fma((f32x2){2.f, 2.f}, t1, t0), t3);
@@ -466,7 +487,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         });
         return;
       }
-      if (a.out_pool) {  // MaxPooling2D(2): a lane's 2x2 output tile IS one pooling window; activation after the max
+      if (pool_stage) {  // MaxPooling2D(2): a lane's 2x2 output tile IS one pooling window; activation after the max
         for_tiles([&](const f32x2 (&s)[2][4], int col, f32x2 bv, int ti, int tj, int, int) {
           const f32x2 y00 = y_even(s, 0), y01 = y_odd(s, 0), y10 = y_even(s, 1), y11 = y_odd(s, 1);
           const f32x2 mx = (f32x2){fmaxf(fmaxf(y00.x, y01.x), fmaxf(y10.x, y11.x)),
@@ -507,6 +528,79 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   DLWP_STAMP(4);
   __syncthreads();
   DLWP_STAMP(5);
+  if constexpr (C::SPLITK) {
+    // ---- the partial tile leaves as staged, [co][TH x TW] contiguous: slab (tile, split) of BN x TH x TW floats -- private memory,
+    //      no bounds, 16-byte stores a wave writes as 1 KB runs.  Then the tile's arrival counter: one atomic per block; the LAST
+    //      arrival sums the ksplit slabs in index order, adds the bias, activates and re-stages the tile for the ordinary store
+    //      phase, and clears the counter for the next launch.  (The order of the sum does not depend on who arrives last:
+    //      bit-reproducible.)
+    //      Coherence: the eight XCDs have an L2 each, and an agent-scope fence on gfx950 is `buffer_wbl2 sc1` + `buffer_inv sc1`
+    //      -- a write-back and an invalidation of the XCD's WHOLE L2, by every workgroup: measured 45 us on top of a 16 us launch
+    //      (r4, gpurun_out/s1).  So no fence: slabs and counters live in UNCACHED device memory (hipDeviceMallocUncached: never
+    //      in an L2), every slab access carries sc0 sc1 (past the CU's L1 as well), and the order is store -> s_waitcnt vmcnt(0)
+    //      (the writes are acknowledged by memory) -> barrier -> atomic add; the last arrival's loads go to memory again.
+    constexpr int PL_S = C::TH * C::TW, NOUT_S = C::BN * PL_S / 4 / C::NT, CS_S = 4 * C::NT / PL_S;
+    static_assert((4 * C::NT) % PL_S == 0, "a pass advances every thread by whole channels");
+    constexpr int SYS = 17;                                    // cache policy sc0 | sc1: system scope
+    constexpr unsigned SLAB_B = (unsigned)C::BN * PL_S * 4u;   // bytes of one slab
+    __shared__ unsigned s_arrival;
+    const int e0 = tid * 4, cb = e0 / PL_S, rem = e0 - cb * PL_S;
+    float* const lp = lds + cb * C::OPS + rem;
+    // one descriptor over the ksplit slabs of this tile; lane offset = the thread's first float4, scalar offset = slab + pass
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.kslab + (long long)tile_lin * a.ksplit * (C::BN * PL_S)), 0, (unsigned)a.ksplit * SLAB_B, 0x00020000);
+    const unsigned kv = (unsigned)e0 * 4u;
+#pragma unroll
+    for (int k = 0; k < NOUT_S; ++k)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)(lp + k * CS_S * C::OPS)), k_rsrc, kv,
+                                             (unsigned)ks * SLAB_B + (unsigned)(k * C::NT * 16), SYS);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slab writes are acknowledged by memory
+    __syncthreads();
+    if (tid == 0)
+      s_arrival = __hip_atomic_fetch_add(a.kcount + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_arrival != (unsigned)(a.ksplit - 1)) return;     // (uniform)
+    if (tid == 0) __hip_atomic_store(a.kcount + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool lin = a.out_pool == 2;                       // the 2x2-sum epilogue has neither bias nor activation
+    // slabs 0, 1, 2 ... added in THAT order whatever the arrival order; the loads of G slabs are in flight together (one memory
+    // round trip per group, not per slab: the accumulators are dead, the registers are there)
+    constexpr int G = NOUT_S <= 8 ? 4 : 2;
+    auto slab_at = [&](int s2, int k) -> f32x4 {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, kv, (unsigned)s2 * SLAB_B + (unsigned)(k * C::NT * 16), SYS));
+    };
+    f32x4 v[NOUT_S];
+#pragma unroll
+    for (int k = 0; k < NOUT_S; ++k) v[k] = slab_at(0, k);
+    int s2 = 1;
+    for (; s2 + G <= a.ksplit; s2 += G) {
+      f32x4 t[G][NOUT_S];
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int k = 0; k < NOUT_S; ++k) t[j][k] = slab_at(s2 + j, k);
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int k = 0; k < NOUT_S; ++k) v[k] += t[j][k];
+    }
+    for (; s2 < a.ksplit; ++s2) {
+      f32x4 t[NOUT_S];
+#pragma unroll
+      for (int k = 0; k < NOUT_S; ++k) t[k] = slab_at(s2, k);
+#pragma unroll
+      for (int k = 0; k < NOUT_S; ++k) v[k] += t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NOUT_S; ++k) {
+      if (!lin) {
+        const float bv = a.bias ? a.bias[n0 + cb + k * CS_S] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[k][r] = act_apply(v[k][r] + bv, a.act);
+      }
+      *(f32x4*)(lp + k * CS_S * C::OPS) = v[k];
+    }
+    __syncthreads();
+  }
   // ---- stores: 16-byte row segments of the (pooled) output.  The float32 paths go through a buffer descriptor over this
   //      block's BN output planes: a thread's staging slot and its output pixel do not depend on the pass k (only the
   //      channel does: + CS planes per pass, a SCALAR offset), so a pass is one ds_read_b128 and one buffer_store_dwordx4
@@ -521,7 +615,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     constexpr int PW = C::TW / 2, PP = (C::TH / 2) * PW;
     static_assert((C::BN * PP / 4) % C::NT == 0 && PW % 4 == 0, "pooled output staging: whole float4 per thread");
     constexpr int NPASS = C::BN * PP / 4 / C::NT;
-    if (C::DIL == 1 && !a.out_bf16) {
+    // (SPLITK with MaxPooling2D(2): the finishing block staged the full activated tile, as the dilation-2 instances do)
+    const bool staged_pooled = C::DIL == 1 && !(C::SPLITK && a.out_pool == 1);
+    if (staged_pooled && !a.out_bf16) {
       static_assert((4 * C::NT) % PP == 0, "a pass advances every thread by whole channels");
       constexpr int CS = 4 * C::NT / PP;
       const int e0 = tid * 4, cb = e0 / PP, rem = e0 - cb * PP;
@@ -561,7 +657,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
         const int oh = (i0 >> 1) + row, ow = (j0 >> 1) + colx;
         if (oh >= a.Hp || ow >= a.Wp) continue;
         f32x4 o;
-        if constexpr (C::DIL == 1) {
+        if (staged_pooled) {
           o = *(const f32x4*)(lds + co * C::OPS + rem);
         } else {
           const float* p0 = lds + co * C::OPS + (2 * row) * C::TW + 2 * colx;
@@ -728,6 +824,25 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
   DLWP_STAMP(6);
 }
 
+// Split-K variants (WinoCfg::SPLITK) are compiled in a translation unit of their own (conv_fwd_k3d1s.hip) for the geometries the
+// small-grid rule of conv_fwd.hip may pick; WinoSplitK<...>::value tells the registry which.
+template <int DIL, int TH, int TW, int WAVES, int BNF>
+struct WinoSplitK {
+  static constexpr bool value = false;
+};
+#define DLWP_WINO_SPLITK_DECL(DIL, TH, TW, WAVES, BNF)                \
+  template <>                                                         \
+  struct WinoSplitK<DIL, TH, TW, WAVES, BNF> {                        \
+    static constexpr bool value = true;                               \
+    static void launch(const ConvArgs& a, int grid, hipStream_t s);   \
+    static int prepare();                                             \
+  };
+DLWP_WINO_SPLITK_DECL(1, 8, 32, 4, 2)
+DLWP_WINO_SPLITK_DECL(1, 8, 32, 4, 4)
+DLWP_WINO_SPLITK_DECL(1, 4, 64, 4, 2)
+DLWP_WINO_SPLITK_DECL(1, 8, 16, 2, 2)
+DLWP_WINO_SPLITK_DECL(1, 4, 32, 2, 2)
+
 template <class C>
 static void wino_launch_thunk(const ConvArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((conv2d_fwd_wino_f32<C>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
@@ -745,6 +860,12 @@ static int wino_prepare() {
 // left halos takes the variant that leaves out the 7 identically-zero Winograd positions (WinoCfg::UPS)
 template <int DIL, int TH, int TW, int WAVES, int BNF, int CK>
 static void wino_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
+  if constexpr (WinoSplitK<DIL, TH, TW, WAVES, BNF>::value) {
+    if (a.ksplit > 1) {
+      WinoSplitK<DIL, TH, TW, WAVES, BNF>::launch(a, grid, s);
+      return;
+    }
+  }
   if constexpr (DIL == 1) {
     // positions with a row / column index 2 are never needed: the source makes them zero (up-sampled, odd halo) or the
     // 2x2 sum epilogue does not read them
@@ -780,6 +901,9 @@ static int wino_prepare_both() {
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true>>();
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true>>();
   }
+  if constexpr (WinoSplitK<DIL, TH, TW, WAVES, BNF>::value) {
+    if (e == 0) e = WinoSplitK<DIL, TH, TW, WAVES, BNF>::prepare();
+  }
   return e;
 }
 
@@ -787,5 +911,6 @@ static int wino_prepare_both() {
 #define WINO_ENTRY(DIL, TH, TW, WAVES, BNF, CK)                                                                         \
   {                                                                                                                      \
     3, DIL, TH, TW, WAVES, 0, BNF, CK, WinoCfg<DIL, TH, TW, WAVES, BNF, CK>::LDS_BYTES, false, -1, 1, 0,                  \
-        &wino_launch_either<DIL, TH, TW, WAVES, BNF, CK>, &wino_prepare_both<DIL, TH, TW, WAVES, BNF, CK>                \
+        &wino_launch_either<DIL, TH, TW, WAVES, BNF, CK>, &wino_prepare_both<DIL, TH, TW, WAVES, BNF, CK>, 0, 0, 0, 0, 0, \
+        0, WinoSplitK<DIL, TH, TW, WAVES, BNF>::value ? 1 : 0                                                            \
   }

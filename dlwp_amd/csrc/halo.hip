@@ -9,6 +9,7 @@
 //
 // All of these move each byte once: algorithmic bytes = bytes(in) + bytes(out); roofline = HBM.
 #include "common.h"
+#include "tape.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -428,6 +429,7 @@ extern "C" {
 
 int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, int W, int inner, dlwp_pad2d p, int dtype,
                    void* stream) {
+  DLWP_TAPE(h, stream, dlwp_pad2d_fwd, h, x, y, outer, H, W, inner, p, dtype);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_pad2d_fwd: null handle");
   if (outer == 0) return DLWP_OK;  // empty batch: torch hands out null data pointers for empty tensors
   DLWP_CHECK_ARG(x && y, "dlwp_pad2d_fwd: null pointer");
@@ -475,6 +477,7 @@ int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, in
 
 int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, int W, int inner, dlwp_pad2d p,
                    int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_pad2d_bwd, h, dy, dx, outer, H, W, inner, p, dtype);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_pad2d_bwd: null handle");
   if (outer == 0) return DLWP_OK;
   DLWP_CHECK_ARG(dy && dx, "dlwp_pad2d_bwd: null pointer");
@@ -534,6 +537,7 @@ int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, 
   DLWP_CHECK_ARG(xs.n >= 0 && xs.c > 0 && xs.h > 0 && xs.w > 0, name ": bad shape")
 
 int dlwp_maxpool2_fwd(dlwp_handle_t h, const void* x, void* y, dlwp_shape4 xs, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_maxpool2_fwd, h, x, y, xs, dtype);
   const bool x_ok = x && y;
   const bool bf16 = dtype == DLWP_BF16;
   if (bf16) dtype = DLWP_F32;  // the shared argument check knows fp32 only; this entry point also stores bf16
@@ -555,6 +559,7 @@ int dlwp_maxpool2_fwd(dlwp_handle_t h, const void* x, void* y, dlwp_shape4 xs, i
 
 int dlwp_maxpool2_bwd(dlwp_handle_t h, const void* x, const void* dy, void* dx, dlwp_shape4 xs, int dtype,
                       void* stream) {
+  DLWP_TAPE(h, stream, dlwp_maxpool2_bwd, h, x, dy, dx, xs, dtype);
   const bool x_ok = x && dy && dx;
   POOL_ARGS_OK("dlwp_maxpool2_bwd");
   const long long planes = (long long)xs.n * xs.c;
@@ -567,6 +572,7 @@ int dlwp_maxpool2_bwd(dlwp_handle_t h, const void* x, const void* dy, void* dx, 
 }
 
 int dlwp_upsample2_fwd(dlwp_handle_t h, const void* x, void* y, dlwp_shape4 xs, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_upsample2_fwd, h, x, y, xs, dtype);
   const bool x_ok = x && y;
   POOL_ARGS_OK("dlwp_upsample2_fwd");
   const long long planes = (long long)xs.n * xs.c;
@@ -585,6 +591,7 @@ int dlwp_upsample2_fwd(dlwp_handle_t h, const void* x, void* y, dlwp_shape4 xs, 
 
 // xs = shape of dx (the low-resolution tensor); dy is (n, c, 2h, 2w)
 int dlwp_upsample2_bwd(dlwp_handle_t h, const void* dy, void* dx, dlwp_shape4 xs, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_upsample2_bwd, h, dy, dx, xs, dtype);
   const bool x_ok = dy && dx;
   POOL_ARGS_OK("dlwp_upsample2_bwd");
   const long long planes = (long long)xs.n * xs.c;
@@ -603,6 +610,7 @@ int dlwp_upsample2_bwd(dlwp_handle_t h, const void* dy, void* dx, dlwp_shape4 xs
 
 int dlwp_copy_channels(dlwp_handle_t h, const void* src, void* dst, int n, int c, int hw, int src_c_off, int src_c_total,
                        int dst_c_off, int dst_c_total, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_copy_channels, h, src, dst, n, c, hw, src_c_off, src_c_total, dst_c_off, dst_c_total, dtype);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_copy_channels: null handle");
   if (n == 0) return DLWP_OK;
   DLWP_CHECK_ARG(src && dst, "dlwp_copy_channels: null pointer");

@@ -12,6 +12,7 @@
 // The halo modes carry over unchanged (the up-sampled halo of an even / odd width 2p maps to floor(r/2) on the source
 // axis: periodic, zero and edge alike).  Sums of weights are taken in a fixed order: deterministic.
 #include "common.h"
+#include "tape.h"
 
 namespace {
 
@@ -133,6 +134,7 @@ int dlwp_phase_geometry(int k, int pad, int* k2, int* lo, int* hi) {
 
 int dlwp_phase_weights(dlwp_handle_t h, const void* w, const void* bias, void* w2, void* b2, int kh, int kw, int cin,
                        int cout, int pad_top, int pad_left, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_phase_weights, h, w, bias, w2, b2, kh, kw, cin, cout, pad_top, pad_left, dtype);
   DLWP_CHECK_ARG(h && w && w2, "dlwp_phase_weights: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && kh > 0 && kw > 0 && cin > 0 && cout > 0 && pad_top >= 0 && pad_left >= 0,
                  "dlwp_phase_weights: bad arguments");
@@ -151,6 +153,7 @@ int dlwp_phase_weights(dlwp_handle_t h, const void* w, const void* bias, void* w
 
 int dlwp_phase_weights_bwd(dlwp_handle_t h, const void* dw2, const void* db2, void* dw, void* db, int kh, int kw, int cin,
                            int cout, int pad_top, int pad_left, int accumulate, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_phase_weights_bwd, h, dw2, db2, dw, db, kh, kw, cin, cout, pad_top, pad_left, accumulate, dtype);
   DLWP_CHECK_ARG(h && dw2 && dw, "dlwp_phase_weights_bwd: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && kh > 0 && kw > 0 && cin > 0 && cout > 0 && pad_top >= 0 && pad_left >= 0,
                  "dlwp_phase_weights_bwd: bad arguments");
@@ -169,6 +172,7 @@ int dlwp_phase_weights_bwd(dlwp_handle_t h, const void* dw2, const void* db2, vo
 
 int dlwp_space_to_depth2(dlwp_handle_t h, const void* src, void* dst, int n, int f, int hh, int ww, int c_off, int c_total,
                          int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_space_to_depth2, h, src, dst, n, f, hh, ww, c_off, c_total, dtype);
   DLWP_CHECK_ARG(h && (n == 0 || (src && dst)), "dlwp_space_to_depth2: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n >= 0 && f > 0 && hh > 0 && ww > 0 && c_off >= 0 && c_off + f <= c_total,
                  "dlwp_space_to_depth2: bad arguments");
@@ -184,6 +188,7 @@ int dlwp_space_to_depth2(dlwp_handle_t h, const void* src, void* dst, int n, int
 
 int dlwp_depth_to_space2(dlwp_handle_t h, const void* src, void* dst, int n, int f, int hh, int ww, int c_off, int c_total,
                          int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_depth_to_space2, h, src, dst, n, f, hh, ww, c_off, c_total, dtype);
   DLWP_CHECK_ARG(h && (n == 0 || (src && dst)), "dlwp_depth_to_space2: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n >= 0 && f > 0 && hh > 0 && ww > 0 && c_off >= 0 && c_off + f <= c_total,
                  "dlwp_depth_to_space2: bad arguments");

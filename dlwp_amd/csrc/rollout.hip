@@ -14,6 +14,7 @@ struct dlwp_rollout {
   hipGraphExec_t exec;
   int calls, n_ops;
   float* wino_u;  // caller's workspace: prepared weights (Winograd / packed-N / bf16), written once at the head of every launch
+  char* ksplit;   // uncached split-K regions of the member chains (NULL: no launch of this rollout splits)
 };
 
 namespace {
@@ -22,7 +23,7 @@ bool is_step(const dlwp_op& op) { return op.kind == DLWP_OP_CONV2D && op.conv.ls
 
 int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, const void* w, const void* b, int dtype,
                hipStream_t s, void* const* aux = nullptr, const float* u_pre = nullptr, const void* src2 = nullptr,
-               const void* w2 = nullptr) {
+               const void* w2 = nullptr, const dlwp_splitk_ws* kws = nullptr) {
   switch (op.kind) {
     case DLWP_OP_LSTM_GATES:
       return dlwp_convlstm_gates(h, src, aux[0], aux[1], aux[2], dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w,
@@ -39,7 +40,7 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
         const dlwp_lstm_io io{aux[0], aux[1], aux[2]};
         return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre, &io);
       }
-      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre);  // aux[0]: per-op storage
+      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre, nullptr, nullptr, nullptr, kws);  // aux[0]: per-op storage
     case DLWP_OP_ROWCONV2D:     // RowConnected2D: float32 buffers, weights read as stored (nothing to prepare)
       return dlwp_rowconv2d_fwd(h, src, w, b, dst, op.xs, &op.conv, DLWP_F32, (void*)s);
     case DLWP_OP_PAD2D:
@@ -86,6 +87,19 @@ static long long prepared_floats(dlwp_handle_t h, const dlwp_op* plan, int n_ops
     }
   }
   return total;
+}
+
+// split-K memory (counters + slabs, conv_fwd.hip) of ONE member chain: its launches are ordered, so the largest layer's decides
+static size_t splitk_region_bytes(dlwp_handle_t h, const dlwp_op* plan, int n_ops, int gn) {
+  size_t most = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    if (plan[i].kind != DLWP_OP_CONV2D || plan[i].conv.lstm_f > 0) continue;
+    dlwp_shape4 xs = plan[i].xs;
+    xs.n = gn;
+    const size_t b = dlwp_conv2d_splitk_bytes(h, xs, &plan[i].conv, plan[i].aux[0]);
+    if (b > most) most = b;
+  }
+  return (most + 255) & ~(size_t)255;
 }
 
 size_t dlwp_rollout_workspace_bytes(dlwp_handle_t h, const dlwp_op* plan, int n_ops, int groups) {
@@ -185,6 +199,19 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
                  "dlwp_rollout_create: workspace of %zu bytes, %lld needed (dlwp_rollout_workspace_bytes)", workspace_bytes,
                  u_floats * (long long)sizeof(float));
   float* wino_u = u_floats > 0 ? (float*)workspace : nullptr;
+  // split-K launches on small grids (conv_fwd.hip: plan_splitk): one region of counters + slabs per member chain -- a chain's
+  // launch site owns its counters.  UNCACHED device memory (the exchange crosses XCDs), so the library allocates it itself: the
+  // one allocation of a rollout, small grids only (<= 32 MB per chain), freed by dlwp_rollout_destroy.
+  const size_t k_region = splitk_region_bytes(h, plan, n_ops, gn);
+  char* k_base = nullptr;
+  if (k_region > 0) {
+    if (hipExtMallocWithFlags((void**)&k_base, (size_t)groups * k_region, hipDeviceMallocUncached) != hipSuccess ||
+        hipMemset(k_base, 0, (size_t)groups * k_region) != hipSuccess) {
+      (void)hipGetLastError();
+      if (k_base) (void)hipFree(k_base);
+      DLWP_FAIL(DLWP_EHIP, "dlwp_rollout_create: no uncached memory for the split-K regions (%zu bytes)", (size_t)groups * k_region);
+    }
+  }
 
   hipStream_t cap;
   DLWP_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
@@ -192,6 +219,7 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
   hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) {
     (void)hipStreamDestroy(cap);
+    if (k_base) (void)hipFree(k_base);
     DLWP_FAIL(DLWP_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
   }
   int rc = DLWP_OK;
@@ -212,6 +240,8 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
       }
   // one chain of `calls` forwards per member group; groups > 1: parallel branches forked after the weight preparation
   auto chain = [&](int g, hipStream_t s) {
+    // (no region: the chain's convolutions must not fall back on the handle's -- a chain's launch site owns its counters)
+    const dlwp_splitk_ws kws{k_base ? k_base + (size_t)g * k_region : nullptr, k_base ? k_region : 0};
     for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
       for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
         const dlwp_op& op = plan[i];
@@ -226,7 +256,7 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
           for (int k = 0; k < 3; ++k) aux[k] = op.aux[k + 1] == DLWP_BUF_NONE ? nullptr : resolve(op.aux[k + 1], t, g);
         rc = enqueue_op(h, op, resolve(op.src, t, g), resolve(op.dst, t, g), w, b, dtype, s, aux,
                         (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr, is_step(op) ? resolve(op.src2, t, g) : nullptr,
-                        is_step(op) ? buffers[op.w2] : nullptr);
+                        is_step(op) ? buffers[op.w2] : nullptr, &kws);
       }
     }
   };
@@ -261,15 +291,18 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
   (void)hipStreamDestroy(cap);
   if (rc != DLWP_OK) {
     if (graph) (void)hipGraphDestroy(graph);
+    if (k_base) (void)hipFree(k_base);
     return rc;  // error string already set by the failing op
   }
   if (e != hipSuccess) {
+    if (k_base) (void)hipFree(k_base);
     DLWP_FAIL(DLWP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
   }
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {
     (void)hipGraphDestroy(graph);
+    if (k_base) (void)hipFree(k_base);
     DLWP_FAIL(DLWP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
   }
   dlwp_rollout* r = new dlwp_rollout();
@@ -279,6 +312,7 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
   r->calls = calls;
   r->n_ops = n_ops;
   r->wino_u = wino_u;
+  r->ksplit = k_base;
   *out = r;
   return DLWP_OK;
 }
@@ -293,6 +327,7 @@ int dlwp_rollout_destroy(dlwp_rollout_t r) {
   if (!r) return DLWP_OK;
   if (r->exec) (void)hipGraphExecDestroy(r->exec);
   if (r->graph) (void)hipGraphDestroy(r->graph);
+  if (r->ksplit) (void)hipFree(r->ksplit);
   delete r;
   return DLWP_OK;
 }

@@ -7,6 +7,7 @@
 // All reductions are two-stage with a fixed summation tree: results are bit-reproducible run to run, and a
 // data-parallel step can be compared with the single-GPU step on the concatenated batch.
 #include "common.h"
+#include "tape.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -549,6 +550,7 @@ int dlwp_launch_reduce_slabs(dlwp_handle_t h, float* slabs, float* out, long lon
 extern "C" {
 
 int dlwp_act_bwd(dlwp_handle_t h, const void* y, const void* dy, void* dz, size_t n, int act, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_act_bwd, h, y, dy, dz, n, act, dtype);
   DLWP_CHECK_ARG(h && dy && dz && (y || act == DLWP_ACT_LINEAR), "dlwp_act_bwd: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && (unsigned)act <= 2u, "dlwp_act_bwd: bad dtype/activation");
   if (n == 0) return DLWP_OK;
@@ -571,6 +573,7 @@ size_t dlwp_bias_grad_workspace(int c) { return (size_t)(c > 0 ? c : 0) * BIAS_S
 
 int dlwp_bias_grad(dlwp_handle_t h, const void* dz, void* db, int n, int c, int c_off, int c_total, int hw, void* ws,
                    size_t ws_bytes, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_bias_grad, h, dz, db, n, c, c_off, c_total, hw, ws, ws_bytes, dtype);
   DLWP_CHECK_ARG(h && dz && db && ws, "dlwp_bias_grad: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n >= 0 && c > 0 && hw > 0 && c_off >= 0 && c_off + c <= c_total,
                  "dlwp_bias_grad: bad arguments");
@@ -585,6 +588,7 @@ int dlwp_bias_grad(dlwp_handle_t h, const void* dz, void* db, int n, int c, int 
 
 int dlwp_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dy, void* dz, void* db, int n, int c, int c_off,
                            int c_total, int hw, int act, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_act_bwd_bias_grad, h, y, dy, dz, db, n, c, c_off, c_total, hw, act, ws, ws_bytes, dtype);
   DLWP_CHECK_ARG(h && dy && dz && db && ws && (y || act == DLWP_ACT_LINEAR), "dlwp_act_bwd_bias_grad: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && (unsigned)act <= 2u && n >= 0 && c > 0 && hw > 0 && c_off >= 0 && c_off + c <= c_total,
                  "dlwp_act_bwd_bias_grad: bad arguments");
@@ -609,6 +613,7 @@ int dlwp_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dy, void*
 
 int dlwp_pool_act_bwd_bias_grad(dlwp_handle_t h, const void* y, const void* dp, void* dz, void* db, dlwp_shape4 ys, int act,
                                 void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_pool_act_bwd_bias_grad, h, y, dp, dz, db, ys, act, ws, ws_bytes, dtype);
   DLWP_CHECK_ARG(h && y && dp && dz && ws, "dlwp_pool_act_bwd_bias_grad: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && (unsigned)act <= 2u && ys.n >= 0 && ys.c > 0 && ys.h >= 2 && ys.w >= 2,
                  "dlwp_pool_act_bwd_bias_grad: bad arguments");
@@ -634,6 +639,7 @@ size_t dlwp_mse_mae_workspace(dlwp_handle_t h) { return h ? (size_t)h->cu_count 
 
 int dlwp_mse_mae(dlwp_handle_t h, const void* y_pred, const void* y_true, size_t n, void* out2, void* dy,
                  float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_mse_mae, h, y_pred, y_true, n, out2, dy, loss_weight, ws, ws_bytes, dtype);
   DLWP_CHECK_ARG(h && y_pred && y_true && out2 && ws, "dlwp_mse_mae: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n > 0, "dlwp_mse_mae: bad dtype / empty input");
   const int grid = grid_for((long long)n, h->cu_count);
@@ -653,6 +659,7 @@ size_t dlwp_mse_mae_phase_workspace(int f) { return (size_t)(f > 0 ? f : 0) * 4 
 
 int dlwp_mse_mae_phase(dlwp_handle_t h, const void* y_phase, const void* y_true, int n, int f, int hh, int ww, void* out2,
                        void* dz_phase, void* db4f, float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_mse_mae_phase, h, y_phase, y_true, n, f, hh, ww, out2, dz_phase, db4f, loss_weight, ws, ws_bytes, dtype);
   DLWP_CHECK_ARG(h && y_phase && y_true && out2 && ws, "dlwp_mse_mae_phase: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n > 0 && f > 0 && hh > 0 && ww > 0, "dlwp_mse_mae_phase: bad dtype / shape");
   DLWP_CHECK_ARG((long long)n * hh * ww < (1ll << 31), "dlwp_mse_mae_phase: more than 2^31 source pixels per channel");
@@ -686,6 +693,7 @@ size_t dlwp_loss_workspace(dlwp_handle_t h, int n, int c) {
 int dlwp_loss_custom(dlwp_handle_t h, const void* y_pred, const void* y_true, int n, int c, int hh, int ww,
                      const void* mean, const void* row_weights, int kind, int regularize, void* stats7, void* dy,
                      float loss_weight, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_loss_custom, h, y_pred, y_true, n, c, hh, ww, mean, row_weights, kind, regularize, stats7, dy, loss_weight, ws, ws_bytes, dtype);
   DLWP_CHECK_ARG(h && y_pred && y_true && stats7 && ws, "dlwp_loss_custom: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32 && n > 0 && c > 0 && hh > 0 && ww > 0, "dlwp_loss_custom: bad dtype / shape");
   DLWP_CHECK_ARG((kind == 0 || kind == 1) && regularize >= 0 && regularize <= 4, "dlwp_loss_custom: bad kind / regularizer");
@@ -736,6 +744,7 @@ int dlwp_adam_keras(dlwp_handle_t h, void* p, void* m, void* v, const void* g, s
 int dlwp_adam_keras_dev(dlwp_handle_t h, void* p, void* m, void* v, const void* g, size_t n, float lr, float beta_1,
                         float beta_2, float epsilon, float decay, long long* iteration_dev, float* lr_t_scratch,
                         float grad_scale, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_adam_keras_dev, h, p, m, v, g, n, lr, beta_1, beta_2, epsilon, decay, iteration_dev, lr_t_scratch, grad_scale);
   DLWP_CHECK_ARG(h && p && m && v && g && iteration_dev && lr_t_scratch, "dlwp_adam_keras_dev: null handle or pointer");
   if (n == 0) return DLWP_OK;
   adam_step_kernel<<<1, 1, 0, (hipStream_t)stream>>>(iteration_dev, lr_t_scratch, lr, beta_1, beta_2, decay);
@@ -747,6 +756,7 @@ int dlwp_adam_keras_dev(dlwp_handle_t h, void* p, void* m, void* v, const void* 
 
 int dlwp_sgd_keras(dlwp_handle_t h, void* p, void* vel, const void* g, size_t n, float lr, float momentum, float decay,
                    long long iteration, float grad_scale, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_sgd_keras, h, p, vel, g, n, lr, momentum, decay, iteration, grad_scale);
   DLWP_CHECK_ARG(h && p && vel && g, "dlwp_sgd_keras: null handle or pointer");
   if (n == 0) return DLWP_OK;
   const float lr_ = (float)((double)lr / (1.0 + (double)decay * (double)iteration));
@@ -757,6 +767,7 @@ int dlwp_sgd_keras(dlwp_handle_t h, void* p, void* vel, const void* g, size_t n,
 }
 
 int dlwp_axpby(dlwp_handle_t h, const void* x, void* y, size_t n, float a, float b, void* stream) {
+  DLWP_TAPE(h, stream, dlwp_axpby, h, x, y, n, a, b);
   DLWP_CHECK_ARG(h && x && y, "dlwp_axpby: null handle or pointer");
   if (n == 0) return DLWP_OK;
   axpby_kernel<<<grid_for((long long)n, h->cu_count), 256, 0, (hipStream_t)stream>>>((const float*)x, (float*)y,

@@ -412,6 +412,20 @@ def set_few_stream(mode):
     return int(_lib.set_option(_lib.OPT_FEW_STREAM, int(mode)))
 
 
+def set_splitk(mode):
+    """DLWP_OPT_SPLITK: Winograd launches on small grids divide the input channels over several workgroups per output tile, the
+    last arrival sums the partial tiles in index order (csrc/conv_fwd_k3d1s.hip): 0 never, 1 by the library's rule (default),
+    k >= 2 that many wherever the layer is eligible.  Returns the previous setting."""
+    return int(_lib.set_option(_lib.OPT_SPLITK, int(mode)))
+
+
+def conv_split_count(x_shape, cd, dtype=None, device_index=0):
+    """The split regime of conv2d on a stored input of shape (n, cin, h, w): workgroups per output tile, 1 = unsplit
+    (dlwp_conv2d_split_count).  Equal counts -> equal bits for a sample; across counts float32 round-off."""
+    return int(_lib.lib.dlwp_conv2d_split_count(_lib.handle(device_index), Shape4(*[int(v) for v in x_shape]), ctypes.byref(cd),
+                                                _lib.F32 if dtype is None else int(dtype)))
+
+
 def prefers_unfused_pool(cin, cout, kh, kw, dil_h, dil_w):
     """Planner hint: materialise a MaxPooling2D in front of this convolution instead of fusing it into the loader?"""
     return bool(_lib.lib.dlwp_conv2d_prefers_unfused_pool(_lib.handle_or_none(), cin, cout, kh, kw, dil_h, dil_w))

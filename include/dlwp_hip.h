@@ -126,6 +126,15 @@ int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, cha
                                         * the streaming kernel that keeps the weights in registers and walks over the samples
                                         * (csrc/conv_fwd_few.hip) -- 1 (default): from 8 tiles per workgroup on, 0: never,
                                         * 2: whenever the layer qualifies.  Same bits as the direct family's instance         */
+#define DLWP_OPT_SPLITK             7  /* Winograd layers on SMALL grids (a launch under one round of resident workgroups: an
+                                        * ensemble share of 1 ... 8 members, 8 training samples per rank): the input channels are
+                                        * divided over several workgroups per output tile; the last one to arrive sums the partial
+                                        * tiles in index order (deterministic), adds the bias, activates, pools and stores
+                                        * (csrc/conv_fwd_k3d1s.hip).  1 (default): by the rule of dlwp_conv2d_split_count;
+                                        * 0: never -- then a sample's bits do not depend on its batch size at all; k >= 2: k
+                                        * workgroups per tile wherever the layer is eligible (tuning sweeps, tests).  A split
+                                        * launch differs from the unsplit one by float32 round-off (another association of the
+                                        * same sum); two launches with the SAME split count give the same bits               */
 int         dlwp_set_option(dlwp_handle_t h, int option, int value, int* previous);
 /* the defaults themselves: what handles created AFTERWARDS start from, and what the handle-less host logic (planner hints
  * called with a NULL handle, e.g. on a machine without a GPU) uses.  Existing handles are not touched.                 */
@@ -184,7 +193,8 @@ int dlwp_conv2d_config_flags(int i);        /* bit 0: Winograd instance whose 16
                                               * operations (same bits as that kernel): for layers with whole 32-channel tiles on
                                               * small grids, where the plain split instances (bit 0 alone) are not offered;
                                               * bit 3 / bit 4: bf16 instance whose input / output is stored in channel octets
-                                              * (DLWP_BF16_O8) -- it takes launches with exactly that storage            */
+                                              * (DLWP_BF16_O8) -- it takes launches with exactly that storage;
+                                              * bit 5: Winograd instance with a compiled split-K variant (DLWP_OPT_SPLITK)   */
 /* Host logic (no device work; handle nullable = default options): 1 when dlwp_conv2d_fwd(xs, cd, dtype) multiplies with
  * bf16-rounded weights (the bf16-MFMA family), else 0: what a caller comparing against an fp32-weight computation needs to
  * know. */
@@ -216,6 +226,11 @@ typedef struct {
 } dlwp_launch_info;
 int dlwp_conv2d_launch_info(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, dlwp_launch_info* out2,
                             int* n_launches);
+/* The split regime of dlwp_conv2d_fwd(xs, cd, dtype) on this handle (DLWP_OPT_SPLITK): how many workgroups share the input
+ * channels of one output tile -- 1: unsplit.  Two launches of a layer give the same bits for a sample exactly when their split
+ * counts are equal (the count follows from the layer and xs.n: every batch size from the chip's first full round of workgroups
+ * on is unsplit); across counts the results differ by float32 round-off.                                                     */
+int dlwp_conv2d_split_count(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
 
 /* ---- backward of the fused Conv2D: the two halves of the Keras train step behind DLWPNeuralNet.fit / fit_generator
  *      (DLWP/model/models.py:188-228).  dz = dL/d(pre-activation), (n, out_c_total, ho, wo) window [out_c_off,+cout).
@@ -512,6 +527,30 @@ int dlwp_rollout_create_grouped(dlwp_handle_t, const dlwp_op* plan, int n_ops, v
                                 size_t workspace_bytes, dlwp_rollout_t* out);
 int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
 int dlwp_rollout_destroy(dlwp_rollout_t);
+
+/* ---- the training step as a library object: replaces the per-step Python launch loop behind keras Model.train_on_batch as
+ *      DLWPNeuralNet.fit / fit_generator drive it (DLWP/model/models.py:188-228; examples/train.py:262-263).
+ *      A model's step is ~30 launches through this ABI.  Between dlwp_train_step_record_begin and dlwp_train_step_create every
+ *      launch-type entry point the RECORDING THREAD calls on the handle is executed as usual and appended to a tape: a closure over
+ *      its arguments (descriptors copied; device pointers as given -- the caller keeps that memory alive and in place).  Streams are
+ *      recorded as lanes (lane 0 = main_stream), fork / join edges between them go through dlwp_stream_wait.  The step object
+ *      replays the tape with ONE C call: DLWP_STEP_LANES issues the launches one by one (lane 0 on the given stream, the others on
+ *      the step's own side streams), DLWP_STEP_GRAPH replays one hipGraph captured from that sequence on a single stream (built at
+ *      the first launch in that mode), DLWP_STEP_GRAPH_BRANCHES one with the lanes as graph branches.  What varies from step to
+ *      step must live in device memory (the Adam step number: dlwp_adam_keras_dev); collectives stay outside.
+ *      in_dst / in_floats: the (at most 8) device buffers the recorded launches read the batch and its targets from;
+ *      dlwp_train_step_launch(srcs != NULL) copies srcs[i] there first, in one launch.                                        */
+#define DLWP_STEP_LANES          0
+#define DLWP_STEP_GRAPH          1
+#define DLWP_STEP_GRAPH_BRANCHES 2
+typedef struct dlwp_train_step* dlwp_train_step_t;
+int dlwp_train_step_record_begin(dlwp_handle_t, void* main_stream);
+int dlwp_train_step_record_abort(dlwp_handle_t);
+int dlwp_stream_wait(dlwp_handle_t, void* waiter_stream, void* signaler_stream);   /* waiter waits for what signaler holds now */
+int dlwp_train_step_create(dlwp_handle_t, int n_in, void* const* in_dst, const size_t* in_floats, dlwp_train_step_t* out);
+int dlwp_train_step_info(dlwp_train_step_t, int* n_launches, int* n_lanes, int* n_waits);
+int dlwp_train_step_launch(dlwp_train_step_t, const void* const* srcs, int mode, void* stream);
+int dlwp_train_step_destroy(dlwp_train_step_t);
 
 /* ---- data parallel training: replaces keras.utils.multi_gpu_model (DLWP/model/models.py:104-109, 365-372; batch =
  *      n_gpu x batch, Azure/train_tf.py:163-164).  One process per GPU; every rank holds the whole (< 1 MB) weight set and
