@@ -2,6 +2,8 @@
 #include "common.h"
 #include <cstdlib>
 #include <string>
+#include <thread>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -94,6 +96,33 @@ int dlwp_destroy(dlwp_handle_t h) {
   if (h && h->wino_u) (void)hipFree(h->wino_u);
   if (h && h->ksplit_mem) (void)hipFree(h->ksplit_mem);
   delete h;
+  return DLWP_OK;
+}
+
+// Host side of the DataGenerator feed (DLWP/model/generators.py:103-159: keras.utils.Sequence batches assembled by worker
+// processes): dst[i] = src[rows[i]] for rows of row_bytes bytes, memcpy per row on `threads` host threads -- straight into the
+// pinned staging buffer the H2D copy reads (dlwp_amd/model/generators.py: DeviceLoader).  No device work.
+int dlwp_host_gather_rows(void* dst, const void* src, const long long* rows, long long n_rows, size_t row_bytes, long long src_rows,
+                          int threads) {
+  DLWP_CHECK_ARG((dst && src && rows) || n_rows == 0, "dlwp_host_gather_rows: null pointer");
+  DLWP_CHECK_ARG(n_rows >= 0 && threads >= 1 && threads <= 256, "dlwp_host_gather_rows: bad row / thread count");
+  for (long long i = 0; i < n_rows; ++i)
+    DLWP_CHECK_ARG(rows[i] >= 0 && rows[i] < src_rows, "dlwp_host_gather_rows: row %lld out of range (%lld rows)", rows[i], src_rows);
+  auto part = [=](long long lo, long long hi) {
+    for (long long i = lo; i < hi; ++i)
+      memcpy((char*)dst + (size_t)i * row_bytes, (const char*)src + (size_t)rows[i] * row_bytes, row_bytes);
+  };
+  long long nt = threads;
+  if ((size_t)n_rows * row_bytes < ((size_t)1 << 20)) nt = 1;     // (a thread costs more than a small copy)
+  if (nt > n_rows) nt = n_rows > 0 ? n_rows : 1;
+  if (nt <= 1) {
+    part(0, n_rows);
+    return DLWP_OK;
+  }
+  std::vector<std::thread> pool;
+  for (long long t = 1; t < nt; ++t) pool.emplace_back(part, n_rows * t / nt, n_rows * (t + 1) / nt);
+  part(0, n_rows / nt);
+  for (std::thread& th : pool) th.join();
   return DLWP_OK;
 }
 

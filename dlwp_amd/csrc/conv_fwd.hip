@@ -661,10 +661,15 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
 
 // ---- split-K on small grids (conv_fwd_wino_kernel.h: WinoCfg::SPLITK; instances in conv_fwd_k3d1s.hip) ------------------------ //
 // A Winograd launch under one round of resident workgroups is bound by the LIFE of a workgroup -- prologue, one pipeline stage per
-// chunk of 8 input channels, epilogue -- not by the matrix cores: 64 -> 128 channels at 22 x 45 on 8 members is 144 workgroups
-// of 8 chunks each on 256 CUs (15.5 us per launch, profiles/r3_cfg2_m8_kernel_stats.csv).  Dividing the chunks over S workgroups
-// per tile shortens that life; the last arrival sums the S partial tiles in index order.
-//   rule (DLWP_OPT_SPLITK = 1): S = as many as still fit ONE round of resident workgroups, at least `min_chunks` chunks each;
+// chunk of 8 input channels, epilogue -- not by the matrix cores.  Dividing the chunks over S workgroups per tile shortens that
+// life; the last arrival sums the S partial tiles in index order.  What it costs (r4, gpurun_out/s2 -> profiles/r4_splitk_sweep.txt):
+// the exchange is three dependent trips to memory -- slab writes acknowledged, the arrival atomic, the last arrival's slab reads;
+// uncached memory, because an agent-scope fence on gfx950 writes back and invalidates the XCD's whole L2 (45 us on a 16 us launch)
+// -- about 5 us, against ~1.2 us per chunk taken off the chain.  So it pays only where the chain is long and the grid tiny:
+//   128 -> 64 channels on the up-sampled 22 x 45 map (16 chunks): 1 member 17.8 -> 13.4 us (S = 3), 2 members 19.1 -> 15.3,
+//   4 members 19.7 -> 20.4 (no); 64-channel layers (8 chunks): 8 members 15.6 -> 18.8 (S = 3), 1 member 14.7 -> 12.7 but the
+//   position-split COMPAT instance the tile choice takes there runs 11.0 unsplit.
+//   rule (DLWP_OPT_SPLITK = 1): at least 12 chunks and at most a third of a workgroup per CU -> S = 3.
 //   eligible: 32 / 64-channel Winograd instances with a compiled split variant, float32 in and out, no narrow second launch,
 //   no phase-interleaved stores, no fused training epilogues (act', pooled image).
 // The choice depends on the batch size: launches with different S differ by float32 round-off (another association of the sum
@@ -685,11 +690,7 @@ void plan_splitk(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Laun
   if (h->opt.splitk >= 2) {
     S = h->opt.splitk;
   } else {
-    // resident workgroups per CU: registers allow two four-wave workgroups (three of the 9-position, 32-channel ones), LDS three
-    // two-wave ones
-    const int per_cu = e.waves < 4 ? 3 : (wino_skips_row2(a) && e.bnf == 2 ? 3 : 2);
-    const long long slots = (long long)h->cu_count * per_cu;
-    S = (int)(slots / lp->grid);
+    S = (chunks >= 12 && 3 * lp->grid <= (long long)h->cu_count) ? 3 : 1;
   }
   if (S > chunks) S = chunks;
   while (S >= 2 && splitk_bytes(e, lp->grid, S) > avail) --S;

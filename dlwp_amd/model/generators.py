@@ -13,6 +13,8 @@ Batch feed for fit_generator.
                   i+1 into a pinned host buffer and a copy stream moves it to HBM while batch i trains
                   (pinned-host -> HBM double buffering).
 """
+import ctypes
+import os
 import threading
 
 import numpy as np
@@ -137,6 +139,32 @@ class DataGenerator(object):
             p = p.reshape((n,) + self.dense_shape)
             t = t.reshape((n,) + self.dense_shape)
         return p, t
+
+    def batch_sources(self):
+        """DeviceLoader's fast path: [(array, per-sample shape)] for predictors and targets when generate(samples) is nothing but
+        a row gather -- float32 C-contiguous arrays without NaN samples to drop, no imputer or scaler in the model -- so that the
+        rows can be copied straight into pinned memory by the library's host threads (dlwp_host_gather_rows); None otherwise.
+        Same values as generate(): every step of it is then a copy or a reshape."""
+        fast = self.__dict__.get('_fast_sources', False)
+        if fast is False:
+            fast = None
+            p, t = getattr(self.ds.predictors, 'values', None), getattr(self.ds.targets, 'values', None)
+            ok = (isinstance(p, np.ndarray) and isinstance(t, np.ndarray) and p.dtype == np.float32 and t.dtype == np.float32 and
+                  p.flags['C_CONTIGUOUS'] and t.flags['C_CONTIGUOUS'] and p.shape[0] == t.shape[0] and p.shape[0] > 0 and
+                  not self._impute_missing and getattr(self.model, 'scaler_type', None) is None)
+            if ok and self._remove_nan:           # (one pass over the arrays, once: a set without NaNs drops nothing)
+                ok = not (np.isnan(p).any() or np.isnan(t).any())
+            if ok:
+                if self._is_convolutional:
+                    shp = tuple(self.convolution_shape)
+                elif self._keep_time_axis:
+                    shp = tuple(self.dense_shape)
+                else:
+                    shp = (self.n_features,)
+                if int(np.prod(shp)) == p[0].size == t[0].size:
+                    fast = [(p.reshape(p.shape[0], -1), shp), (t.reshape(t.shape[0], -1), shp)]
+            self._fast_sources = fast
+        return fast
 
     def __len__(self):
         return int(np.ceil(self._n_sample / self._batch_size))
@@ -459,11 +487,16 @@ class DeviceLoader(object):
         for X, y in DeviceLoader(gen, device):   # X, y are device tensors, valid until the next iteration
             ...
 
-    A worker thread runs gen[i+1] (numpy gather on the host) and stages it into one of two pinned buffers while the
-    consumer works on batch i; the H2D copies are issued on a private copy stream and the consumer's stream waits on
-    their event, so compute and transfer overlap.  y may be one array or a list of arrays (SeriesDataGenerator with
-    `sequence`, the multi-output DLWPFunctional models): every target gets its own staging buffers and comes out as a
-    list of device tensors.
+    Division of labour (r4): a worker thread assembles batch k + 1, k + 2 ... in PINNED host buffers -- host work only, no
+    device call ever leaves that thread -- while the consumer thread, the only one that talks to the device, issues the H2D copy
+    of batch k + 1 on a private copy stream before it hands out batch k (its own stream waits on the copy's event): transfer,
+    host gather and the training step overlap, and nothing races a stream capture or a graph launch in the consumer.  (r3's
+    loader copied from its worker thread; the captured training step therefore never ran next to it.)
+    Generators with the DataGenerator protocol whose batches are plain row gathers of float32 arrays (`batch_sources`) are
+    gathered straight into the pinned buffers by the library's host threads (dlwp_host_gather_rows: the reference's
+    use_multiprocessing=True workers, examples/train.py:262-263); everything else goes through `gen[i]` / `generate` and one
+    copy.  y may be one array or a list of arrays (SeriesDataGenerator with `sequence`, the multi-output DLWPFunctional
+    models): every target gets its own staging buffers and comes out as a list of device tensors.
 
     `order` optionally restricts / permutes the batch indices.  `shard=(rank, world)` is the data-parallel feed: batch i is
     still the GLOBAL batch i of the generator (same index list on every rank -- the trainer broadcasts rank 0's), but this
@@ -473,7 +506,10 @@ class DeviceLoader(object):
     Sequence is asked for the whole batch and sliced on the host before the upload.  iter_batches() yields
     (X, y, n_global) so the training step can weight ragged shards exactly."""
 
-    def __init__(self, generator, device, order=None, depth=2, shard=None):
+    #: host threads of a native row gather (dlwp_host_gather_rows)
+    gather_threads = max(1, min(8, (os.cpu_count() or 2) // 2))
+
+    def __init__(self, generator, device, order=None, depth=3, shard=None):
         import torch
         self.gen, self.device, self.depth = generator, device, max(2, int(depth))
         self.order = list(range(len(generator))) if order is None else list(order)
@@ -486,6 +522,22 @@ class DeviceLoader(object):
         return len(self.order)
 
     # -- host side: this rank's rows of global batch `idx` -------------------------------------------------------------- #
+    def _samples(self, idx):
+        """(sample indices of this rank's rows, n_global) for a generator with the DataGenerator protocol, else None"""
+        from ..parallel import shard_bounds
+        gen = self.gen
+        if not all(hasattr(gen, a) for a in ('_indices', '_batch_size', 'generate')):
+            return None
+        bs = int(gen._batch_size)
+        if int(idx) < 0:
+            idx = len(gen) + int(idx)
+        samples = gen._indices[idx * bs:(idx + 1) * bs]
+        n_global = len(samples)
+        if self.shard is not None:
+            lo, hi = shard_bounds(n_global, *self.shard)
+            samples = samples[lo:hi]
+        return samples, n_global
+
     def _fetch(self, idx):
         """(X, [targets], was_list, n_global) as float32 numpy arrays"""
         from ..parallel import shard_bounds
@@ -493,17 +545,12 @@ class DeviceLoader(object):
         if self.shard is None:
             X, y = gen[idx]
             n_global = int(np.asarray(X).shape[0])
-        elif all(hasattr(gen, a) for a in ('_indices', '_batch_size', 'generate')):
-            bs = int(gen._batch_size)
-            if int(idx) < 0:
-                idx = len(gen) + int(idx)
-            samples = gen._indices[idx * bs:(idx + 1) * bs]
-            n_global = len(samples)
-            lo, hi = shard_bounds(n_global, *self.shard)
-            if hi > lo:
-                X, y = gen.generate(samples[lo:hi])
+        elif self._samples(idx) is not None:
+            samples, n_global = self._samples(idx)
+            if len(samples) > 0:
+                X, y = gen.generate(samples)
             else:                               # no rows for this rank: right trailing shape, zero rows
-                X, y = gen.generate(samples[:1])      # (generate([]) would mean "every sample")
+                X, y = gen.generate(gen._indices[:1])      # (generate([]) would mean "every sample")
                 X = X[:0]
                 y = [t[:0] for t in y] if isinstance(y, (list, tuple)) else y[:0]
         else:
@@ -516,87 +563,146 @@ class DeviceLoader(object):
         ys = [np.ascontiguousarray(t, dtype=np.float32) for t in (y if was_list else [y])]
         return np.ascontiguousarray(X, dtype=np.float32), ys, was_list, n_global
 
+    def _native_plan(self, idx):
+        """[(source 2-D float32 array, per-sample shape)] + rows + n_global when batch idx is a plain row gather the library's host
+        threads can do (the generator's `batch_sources`), else None"""
+        if not hasattr(self.gen, 'batch_sources'):
+            return None
+        sm = self._samples(idx)
+        if sm is None or len(sm[0]) == 0:
+            return None
+        src = self.gen.batch_sources()
+        if src is None:
+            return None
+        return src, np.ascontiguousarray(sm[0], dtype=np.int64), sm[1]
+
     # -- staging ---------------------------------------------------------------------------------------------------------- #
-    def _stage(self, slot, arrays):
-        """arrays: [X, y0, y1, ...] -> device tensors of the same shapes, through this slot's pinned buffers"""
+    def _alloc_slot(self, sizes):
+        """(consumer thread) pinned host + device buffers for arrays of `sizes` elements"""
         torch = self._torch
-        bufs = self._slots[slot]
-        sizes = [max(1, a.size) for a in arrays]
-        if bufs is None or len(bufs['cap']) != len(sizes) or any(c < s for c, s in zip(bufs['cap'], sizes)):
-            pin = self.device.type == 'cuda'
-            bufs = {'cap': sizes,
-                    'host': [torch.empty(s, dtype=torch.float32, pin_memory=pin) for s in sizes],
-                    'dev': [torch.empty(s, dtype=torch.float32, device=self.device) for s in sizes],
-                    'ev': torch.cuda.Event() if pin else None, 'free': None}
-            self._slots[slot] = bufs
-        if bufs['ev'] is not None and bufs.get('recorded'):
-            bufs['ev'].synchronize()        # the previous H2D copy out of this pinned slot must have drained
-        hs, ds = [], []
-        for a, hbuf, dbuf in zip(arrays, bufs['host'], bufs['dev']):
-            h = hbuf[:a.size].view(a.shape)
-            h.numpy()[...] = a
-            hs.append(h)
-            ds.append(dbuf[:a.size].view(a.shape))
-        if self._copy_stream is not None:
-            from .._lib import capture_lock
-            with capture_lock:          # never while the consumer thread is capturing its training step as a graph
-                if bufs['free'] is not None:
-                    self._copy_stream.wait_event(bufs['free'])      # the consumer is done with this slot's device buffers
-                with torch.cuda.stream(self._copy_stream):
-                    for d, h in zip(ds, hs):
-                        d.copy_(h, non_blocking=True)
-                    bufs['ev'].record(self._copy_stream)
-                    bufs['recorded'] = True
-        else:
-            for d, h in zip(ds, hs):
-                d.copy_(h)
-        return ds, bufs
+        pin = self.device.type == 'cuda'
+        return {'cap': list(sizes),
+                'host': [torch.empty(max(1, s), dtype=torch.float32, pin_memory=pin) for s in sizes],
+                'dev': [torch.empty(max(1, s), dtype=torch.float32, device=self.device) for s in sizes],
+                'ev': torch.cuda.Event() if pin else None, 'done': None}
+
+    def _fill(self, slot, idx):
+        """(worker thread: host work only) batch idx into the pinned buffers of `slot`; returns (shapes, was_list, n_global), or
+        the fetched arrays themselves when they do not fit the slot (the consumer re-allocates and copies)"""
+        from .. import _lib
+        plan = self._native_plan(idx)
+        if plan is not None:
+            srcs, rows, n_global = plan
+            shapes = [(len(rows),) + tuple(shp) for _, shp in srcs]
+            sizes = [int(np.prod(sh)) for sh in shapes]
+            if slot is not None and len(slot['cap']) == len(sizes) and all(c >= z for c, z in zip(slot['cap'], sizes)):
+                for (arr, shp), hbuf in zip(srcs, slot['host']):
+                    row_bytes = int(np.prod(shp)) * 4
+                    _lib.check(_lib.lib.dlwp_host_gather_rows(ctypes.c_void_p(hbuf.data_ptr()), ctypes.c_void_p(arr.ctypes.data),
+                                                              rows.ctypes.data_as(ctypes.c_void_p), len(rows), row_bytes,
+                                                              arr.shape[0], int(self.gather_threads)))
+                return {'shapes': shapes, 'was_list': False, 'n_global': n_global, 'arrays': None}
+        X, ys, was_list, n_global = self._fetch(idx)
+        arrays = [X] + ys
+        shapes = [a.shape for a in arrays]
+        if slot is not None and len(slot['cap']) == len(arrays) and all(c >= a.size for c, a in zip(slot['cap'], arrays)):
+            for a, hbuf in zip(arrays, slot['host']):
+                hbuf[:a.size].view(a.shape).numpy()[...] = a
+            arrays = None
+        return {'shapes': shapes, 'was_list': was_list, 'n_global': n_global, 'arrays': arrays}
 
     def iter_batches(self):
         """yields (X, y, n_global): device tensors of this rank's rows (y a list when the generator gives a list) and
         the size of the global batch they belong to"""
         torch = self._torch
-        results = {}
-        lock = threading.Condition()
         n = len(self.order)
+        lock = threading.Condition()
+        state = {'filled': {}, 'free': set(range(self.depth)), 'error': None, 'stop': False}
 
         def worker():
             try:
                 for k, idx in enumerate(self.order):
+                    s = k % self.depth
                     with lock:
-                        while k - state['consumed'] >= self.depth:
+                        while s not in state['free'] and not state['stop']:
                             lock.wait()
-                    X, ys, was_list, n_global = self._fetch(idx)
-                    ds, bufs = self._stage(k % self.depth, [X] + ys)
+                        if state['stop']:
+                            return
+                        state['free'].discard(s)
+                    res = self._fill(self._slots[s], idx)
                     with lock:
-                        results[k] = (ds, bufs, was_list, n_global)
+                        state['filled'][k] = res
                         lock.notify_all()
             except BaseException as e:  # noqa: BLE001
                 with lock:
-                    results['error'] = e
+                    state['error'] = e
                     lock.notify_all()
 
-        state = {'consumed': 0}
         th = threading.Thread(target=worker, daemon=True)
         th.start()
-        for k in range(n):
+        cuda = self._copy_stream is not None
+
+        def issue(k):
+            """(consumer thread) wait for the host copy of batch k, start its upload; returns the device views"""
+            s = k % self.depth
             with lock:
-                while k not in results and 'error' not in results:
+                while k not in state['filled'] and state['error'] is None:
                     lock.wait()
-                if 'error' in results:
-                    raise results['error']
-                ds, bufs, was_list, n_global = results.pop(k)
-            if bufs['ev'] is not None:
-                torch.cuda.current_stream(self.device).wait_event(bufs['ev'])
-            yield ds[0], (ds[1:] if was_list else ds[1]), n_global
-            if bufs['ev'] is not None:
-                done = torch.cuda.Event()
-                done.record(torch.cuda.current_stream(self.device))
-                bufs['free'] = done
+                if state['error'] is not None:
+                    raise state['error']
+                res = state['filled'].pop(k)
+            slot = self._slots[s]
+            if res['arrays'] is not None:            # first use of the slot, or a batch larger than it: (re)allocate, copy here
+                sizes = [a.size for a in res['arrays']]
+                if slot is None or len(slot['cap']) != len(sizes) or any(c < z for c, z in zip(slot['cap'], sizes)):
+                    if slot is not None and slot['ev'] is not None and slot.get('recorded'):
+                        slot['ev'].synchronize()
+                    slot = self._slots[s] = self._alloc_slot(sizes)
+                for a, hbuf in zip(res['arrays'], slot['host']):
+                    hbuf[:a.size].view(a.shape).numpy()[...] = a
+            hs = [hbuf[:int(np.prod(sh))].view(tuple(sh)) for sh, hbuf in zip(res['shapes'], slot['host'])]
+            ds = [dbuf[:int(np.prod(sh))].view(tuple(sh)) for sh, dbuf in zip(res['shapes'], slot['dev'])]
+            if cuda:
+                if slot['done'] is not None:
+                    self._copy_stream.wait_event(slot['done'])      # the consumer is through with this slot's device buffers
+                with torch.cuda.stream(self._copy_stream):
+                    for d, h in zip(ds, hs):
+                        d.copy_(h, non_blocking=True)
+                    slot['ev'].record(self._copy_stream)
+                    slot['recorded'] = True
+            else:
+                for d, h in zip(ds, hs):
+                    d.copy_(h)
+            return ds, slot, res['was_list'], res['n_global']
+
+        def release(k):
+            """(consumer thread) batch k's pinned buffers may be refilled once its upload has drained"""
+            slot = self._slots[k % self.depth]
+            if slot is not None and slot['ev'] is not None and slot.get('recorded'):
+                slot['ev'].synchronize()
             with lock:
-                state['consumed'] = k + 1
+                state['free'].add(k % self.depth)
                 lock.notify_all()
-        th.join()
+
+        try:
+            nxt = issue(0) if n else None
+            for k in range(n):
+                cur = nxt
+                nxt = issue(k + 1) if k + 1 < n else None        # batch k + 1 uploads under batch k's step
+                ds, slot, was_list, n_global = cur
+                if slot['ev'] is not None:
+                    torch.cuda.current_stream(self.device).wait_event(slot['ev'])
+                yield ds[0], (ds[1:] if was_list else ds[1]), n_global
+                if slot['ev'] is not None:
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(self.device))
+                    slot['done'] = done
+                release(k)
+        finally:
+            with lock:
+                state['stop'] = True
+                lock.notify_all()
+            th.join()
 
     def __iter__(self):
         for X, y, _ in self.iter_batches():

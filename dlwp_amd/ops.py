@@ -606,6 +606,13 @@ def _dev_index(device):
     return device.index if device.index is not None else torch.cuda.current_device()
 
 
+def stream_wait(waiter, signaler):
+    """`waiter` (a torch.cuda.Stream) waits for everything issued on `signaler` so far -- torch's Stream.wait_stream through the
+    library (dlwp_stream_wait), so that a step being recorded (Trainer._record_step) keeps its fork / join edges."""
+    dev = waiter.device.index if waiter.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.lib.dlwp_stream_wait(_lib.handle(dev), ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(signaler.cuda_stream)))
+
+
 def prepare_begin(device):
     """Weight preparations from now on are recorded and built by ONE launch at prepare_flush (csrc/batch.hip)."""
     _lib.check(_lib.lib.dlwp_prepare_begin(_lib.handle(_dev_index(device))))

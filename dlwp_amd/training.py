@@ -7,6 +7,7 @@ all-reduce of ONE flat gradient buffer per step (RCCL over xGMI on the GPU box, 
 Reference: keras Model.fit / fit_generator / evaluate as driven by DLWP/model/models.py:188-228, 303-316 and
 examples/train.py:240,258-263,274; loss / metric / optimizer strings of examples/train.py:240.
 """
+import ctypes
 import os
 import time
 
@@ -112,6 +113,22 @@ def flatten_parameters(model):
 # trainer
 # ------------------------------------------------------------------------------------------------------------------ #
 
+class _StepHandle(object):
+    """Owner of a dlwp_train_step_t (csrc/tape.hip)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            from . import _lib
+            if self.h is not None:
+                _lib.lib.dlwp_train_step_destroy(self.h)
+                self.h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class _PhaseGrad(object):
     """The loss gradient of an output the plan produces as phase channels + depth-to-space, in phase layout: the gradient of
     plan buffer `buf` (written by convolution op `conv_k`); db: the bias gradient of the phase channels, or None."""
@@ -169,6 +186,8 @@ class Trainer(object):
         self._prep_cache = {}         # batch size -> prepared weights of the step (see _prepare_step)
         self._side = None             # second stream: the weight gradients run beside the data-gradient chain
         self._loader_threads = 0      # > 0 while fit_generator feeds through a DeviceLoader (see _graph_ok)
+        self._foreign = False         # set where a step launches through torch instead of the library (see _record_step)
+        self._no_tape = set()         # step shapes whose recording was refused
         self.sync_parameters()
 
     # -- replicas ------------------------------------------------------------------------------------------------------ #
@@ -452,7 +471,7 @@ class Trainer(object):
             for i, fn in enumerate(wq):
                 st = sides[i % len(sides)] if parallel else sides[0]
                 if id(st) not in started:
-                    st.wait_stream(main)         # behind everything issued on the main stream so far
+                    ops.stream_wait(st, main)    # behind everything issued on the main stream so far
                     started.add(id(st))
                     if st not in used:
                         used.append(st)
@@ -471,7 +490,7 @@ class Trainer(object):
             if each:
                 st = sides[queued[0] % len(sides)]
                 queued[0] += 1
-                st.wait_stream(main)
+                ops.stream_wait(st, main)
                 if st not in used:
                     used.append(st)
                 with torch.cuda.stream(st):
@@ -537,6 +556,7 @@ class Trainer(object):
             if not overlaps(buf, c_off, c):
                 if full:
                     if dense.data_ptr() != g.data_ptr():
+                        self._foreign = True
                         g.view(-1).copy_(dense.reshape(-1))
                 else:
                     ops.copy_channels(dense.reshape((n, c) + tuple(g.shape[2:])), g, c, 0, c_off)
@@ -770,11 +790,12 @@ class Trainer(object):
         # layers that received no gradient this step (unused by any output) must not keep a stale one
         for lay, nm, off, numel, shape in self.entries:
             if id(lay) not in touched_layers:
+                self._foreign = True          # (torch's own launch: a recorded step would miss it)
                 self.flat_grads[off:off + numel].zero_()
         if sides is not None:
             launch_queued(True)
             for st in used:
-                main.wait_stream(st)     # the weight gradients join before anything reads them
+                ops.stream_wait(main, st)     # the weight gradients join before anything reads them
         return post
 
     def _forward_backward(self, x, ys, scale):
@@ -842,30 +863,85 @@ class Trainer(object):
     graph_below = 12 * 88 * 180
 
     def _graph_ok(self, n_local=None):
-        """Opt-in (DLWP_TRAIN_GRAPH=1): forward + loss + backward (+ optimizer) of one step are ~60 launches from Python; a
-        step whose launch sequence does not depend on the data is captured once per batch shape (torch.cuda.CUDAGraph around
-        our C-ABI launches: its private pool keeps the per-op gradient buffers at fixed addresses) and replayed with one
-        hipGraphLaunch.  Measured on one MI355X (profiles/r2k_train_graph_ab.txt): 1.86 vs 1.84 ms / step at 64 samples and
-        0.569 vs 0.557 ms at 8 -- the asynchronous launches already run ahead of the GPU, the step is bound by its ~60 short
-        kernels, not by the host -- so the default stays eager.  Never captured: kernel regularisers (their penalty is read
-        back to the host every step), SGD with decay (its rate is a launch argument), steps on the CPU device."""
+        """How a step of n_local samples runs: False -- launch by launch from Python (the eager step) -- or the form in which it is
+        REPLAYED once its shape has been seen graph_after times:
+          'graph' / 'lanes' / 'branches'  the library's step object (csrc/tape.hip, dlwp_train_step_*): the launch sequence is
+                    recorded once, while an eager step runs, and replayed with ONE C call -- as one hipGraph on a single stream
+                    ('graph'), launch by launch with the weight gradients on the step's side streams ('lanes'), or as one hipGraph
+                    with those lanes as branches ('branches').  Plans the folded step covers (_fold_ok).  r4: this replaces both the
+                    ~0.6 ms of Python per eager step and the torch.cuda.CUDAGraph capture, which raced a DeviceLoader's thread.
+          'torch'   torch.cuda.CUDAGraph around the Python step (r2/r3): plans outside the folded step, DLWP_TRAIN_GRAPH=1 only.
+        DLWP_TRAIN_GRAPH: '0' never replay; '1' always; unset: folded plans replay -- small steps (at most graph_below samples x
+        grid points) as 'graph', larger ones as 'lanes' (their weight gradients gain from the side streams: batch 64 1.78 ->
+        1.68 ms in r3).  DLWP_TRAIN_STEP=graph|lanes|branches|torch picks the form.  Never replayed: kernel regularisers (their
+        penalty is read back to the host every step), SGD with decay (its rate is a launch argument), steps on the CPU device."""
         opt = self.model.optimizer
         mode = os.environ.get('DLWP_TRAIN_GRAPH', 'auto')
-        if self.device.type != 'cuda' or mode == '0':
+        if self.device.type != 'cuda' or mode == '0' or n_local is None:
             return False
-        if mode != '1':
-            # auto (r3): the FOLDED step is launch-bound on the host below ~12 samples of the 88 x 180 grid (eager 0.68 ms vs
-            # 0.49 ms replayed at 8 samples) and GPU-bound above, where the replayed graph's fork / join gaps cost more than
-            # the host saves (1.68 ms eager vs 1.83 ms replayed at 64): capture small steps only
-            # ... and never by default next to a DeviceLoader's staging thread (fit_generator): its pinned allocations and
-            # event waits race with a capture in the consumer thread (r3: one crash in hipGraphLaunch in 5 full test runs)
-            store = self.plan._in_store
-            if not self._fold_ok() or n_local is None or self._loader_threads or \
-                    n_local * int(store[-1]) * int(store[-2]) > self.graph_below:
-                return False
         if any(True for _ in self._regularized()):
             return False
-        return isinstance(opt, Adam) or (isinstance(opt, SGD) and opt.decay == 0.0)
+        if not (isinstance(opt, Adam) or (isinstance(opt, SGD) and opt.decay == 0.0)):
+            return False
+        form = os.environ.get('DLWP_TRAIN_STEP')
+        if form not in (None, '', 'graph', 'lanes', 'branches', 'torch'):
+            raise ValueError('DLWP_TRAIN_STEP=%r (graph, lanes, branches, torch)' % form)
+        if not self._fold_ok():
+            return 'torch' if (mode == '1' or form == 'torch') else False
+        if form:
+            return form
+        store = self.plan._in_store
+        return 'graph' if (mode == '1' or n_local * int(store[-1]) * int(store[-2]) <= self.graph_below) else 'lanes'
+
+    # -- the step as a library object (dlwp_train_step_*) ------------------------------------------------------------------ #
+    def _record_step(self, x, ys, n_global, scale, dp):
+        """Runs ONE real step on (x, ys) while the library records its launches; returns the step entry, or None when the step
+        contained device work that did not go through the library (it then stays eager).  Memory: every tensor the step allocates
+        while recording comes from a private torch.cuda.MemPool that is kept with the entry, so the addresses the tape holds
+        stay valid and nobody else is handed them."""
+        from . import _lib, ops
+        opt = self.model.optimizer
+        gx = x.clone()
+        gys = [t.clone() for t in ys]
+        if self._iter_dev is None:
+            self._iter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._lr_t = torch.zeros(1, dtype=torch.float32, device=self.device)
+        if self.opt_state is None:
+            raise RuntimeError('the optimizer slots must exist before the step is recorded')
+        if dp is None and isinstance(opt, Adam):
+            self._iter_dev.fill_(int(opt.iterations))
+        dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        h = _lib.handle(dev)
+        main = torch.cuda.current_stream(self.device)
+        pool = torch.cuda.MemPool()
+        self._foreign = False
+        with torch.cuda.use_mem_pool(pool, device=self.device):
+            _lib.check(_lib.lib.dlwp_train_step_record_begin(h, ctypes.c_void_p(main.cuda_stream)))
+            try:
+                outs, loss_vals, dys = self._forward_backward(gx, gys, scale)
+                if dp is not None:       # the exchange and the update stay outside: a collective in between
+                    ops.axpby(loss_vals.view(-1), self._loss_tail.view(-1), scale, 0.0)
+                elif isinstance(opt, Adam):
+                    m, v = self.opt_state
+                    ops.adam_keras_dev(self.flat_params, m, v, self.flat_grads, self._iter_dev, self._lr_t, opt.lr, opt.beta_1,
+                                       opt.beta_2, opt.epsilon, opt.decay, 1.0)
+                else:
+                    ops.sgd_keras(self.flat_params, self.opt_state[0], self.flat_grads, 0, opt.lr, opt.momentum, 0.0, 1.0)
+            except BaseException:
+                _lib.lib.dlwp_train_step_record_abort(h)
+                raise
+            ins = [gx] + gys
+            if self._foreign or len(ins) > 8:
+                _lib.lib.dlwp_train_step_record_abort(h)
+                return {'refused': True, 'loss': loss_vals}
+            step = ctypes.c_void_p()
+            dst = (ctypes.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
+            floats = (ctypes.c_size_t * len(ins))(*[t.numel() for t in ins])
+            _lib.check(_lib.lib.dlwp_train_step_create(h, len(ins), dst, floats, ctypes.byref(step)))
+        keep = (outs, loss_vals, dys, dict(ops._workspaces), dict(ops._workspaces2),
+                self.model.train_executor.scratch(int(x.shape[0])), self.model.train_executor.phase_buffers(),
+                self._prep_cache.get(int(x.shape[0])), self._side, pool)
+        return {'step': _StepHandle(step), 'x': gx, 'ys': gys, 'loss': loss_vals, 'keep': keep}
 
     def _capture_step(self, x, ys, n_global, scale, dp):
         from . import ops
@@ -922,7 +998,10 @@ class Trainer(object):
         # load_model) must not replay the old ones
         hyper = tuple(float(getattr(opt, k)) for k in ('lr', 'decay', 'beta_1', 'beta_2', 'epsilon', 'momentum')
                       if hasattr(opt, k))
-        key = (int(x.shape[0]), int(n_global), 0 if dp is None else dp.world, hyper)
+        form = self._graph_ok(int(x.shape[0]))
+        key = (int(x.shape[0]), int(n_global), 0 if dp is None else dp.world, hyper, 'torch' if form == 'torch' else 'tape')
+        if key in self._no_tape:
+            return None
         ent = self._graphs.get(key)
         if ent is None:
             seen = self._graph_seen.get(key, 0) + 1
@@ -931,7 +1010,34 @@ class Trainer(object):
                 return None
             if len(self._graphs) >= 4:
                 self._graphs.clear()
-            ent = self._graphs[key] = self._capture_step(x, ys, n_global, scale, dp)
+            if form == 'torch':
+                ent = self._graphs[key] = self._capture_step(x, ys, n_global, scale, dp)
+            else:
+                ent = self._record_step(x, ys, n_global, scale, dp)     # (this IS a step: on x, ys)
+                if ent.get('refused'):
+                    self._no_tape.add(key)
+                else:
+                    self._graphs[key] = ent
+                if dp is None:
+                    opt.iterations += 1
+                    self._iter_shadow = opt.iterations
+                return ent['loss']
+        if 'step' in ent:
+            from . import _lib
+            if dp is None and isinstance(opt, Adam) and self._iter_shadow != opt.iterations:
+                self._iter_dev.fill_(int(opt.iterations))          # (after load_model / a manual change / eager steps)
+            srcs = [x] + list(ys)
+            if not all(s_.is_contiguous() and s_.dtype == torch.float32 and s_.numel() == d_.numel()
+                       for s_, d_ in zip(srcs, [ent['x']] + ent['ys'])):
+                srcs = [s_.to(torch.float32).contiguous() for s_ in srcs]
+            ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+            mode = {'lanes': _lib.STEP_LANES, 'graph': _lib.STEP_GRAPH, 'branches': _lib.STEP_GRAPH_BRANCHES}[form]
+            _lib.check(_lib.lib.dlwp_train_step_launch(ent['step'].h, ptrs, mode,
+                                                       ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            if dp is None:
+                opt.iterations += 1
+                self._iter_shadow = opt.iterations
+            return ent['loss']
         pairs = [(x, ent['x'])] + list(zip(ys, ent['ys']))
         if len(pairs) <= 8 and all(s.is_contiguous() and s.dtype == torch.float32 and s.numel() == d.numel() for s, d in pairs):
             ops.copy_many(pairs)            # the batch and its targets into the graph's buffers: one launch

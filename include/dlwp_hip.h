@@ -528,6 +528,13 @@ int dlwp_rollout_create_grouped(dlwp_handle_t, const dlwp_op* plan, int n_ops, v
 int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
 int dlwp_rollout_destroy(dlwp_rollout_t);
 
+/* ---- host side of the DataGenerator feed (keras.utils.Sequence batches assembled by worker processes under
+ *      fit_generator(use_multiprocessing=True), DLWP/model/models.py:216-228, generators.py:137-159): dst[i] = src[rows[i]],
+ *      rows of row_bytes bytes, on `threads` host threads -- straight into the pinned staging buffer of the H2D copy.
+ *      Host memory only; no device work, no handle.                                                                          */
+int dlwp_host_gather_rows(void* dst, const void* src, const long long* rows, long long n_rows, size_t row_bytes,
+                          long long src_rows, int threads);
+
 /* ---- the training step as a library object: replaces the per-step Python launch loop behind keras Model.train_on_batch as
  *      DLWPNeuralNet.fit / fit_generator drive it (DLWP/model/models.py:188-228; examples/train.py:262-263).
  *      A model's step is ~30 launches through this ABI.  Between dlwp_train_step_record_begin and dlwp_train_step_create every

@@ -52,7 +52,7 @@ CASES = [
     (3, 32, 44, 90, 64, 0, 1, 'tanh', 0, True),        # layer 2 with MaxPooling2D(2) in the epilogue (the finishing block pools)
     (2, 128, 22, 45, 64, 0, 1, 'relu', 1, False),      # layer 4: up-sampled source, 9 live Winograd positions
     (2, 64, 44, 90, 32, 0, 1, 'tanh', 0, False),       # layer 5 restated on the 44 x 90 tensor
-    (2, 20, 19, 50, 64, 2, 1, 'linear', 0, False),     # ragged input channels (3 chunks, the last one half empty), edge rows
+    (2, 22, 19, 50, 64, 2, 1, 'linear', 0, False),     # ragged input channels (3 chunks, the last one with 6 of 8), edge rows
     (2, 40, 17, 33, 32, 1, 1, 'tanh', 0, True),        # odd map under a pooling epilogue, periodic in both axes
 ]
 
@@ -93,6 +93,8 @@ def test_split_counts_match_the_oracle_and_the_unsplit_launch(ops, case):
             for s in (2, 3, 4, 8, 16):
                 ops.set_splitk(s)
                 eff = ops.conv_split_count(x.shape, cd)
+                if eff == 1 and ops.conv_configs()[cfg][6] == 4:
+                    break                      # 64-channel blocks split only in their 9-position form (as they are registered)
                 assert 2 <= eff <= min(s, chunks), (cfg, s, eff, chunks)
                 outs = [ops.conv2d(xd, wd, bd, cd).clone() for _ in range(3)]      # back to back: the counters reset themselves
                 assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), ('not reproducible', cfg, s)
@@ -157,19 +159,24 @@ def test_split_data_gradients(ops):
         _close(res[1], res[0], 'data gradient, src_mode %d' % src)
 
 
-def test_rule_splits_small_grids_only(ops):
-    """DLWP_OPT_SPLITK = 1: launches under one round of resident workgroups split, full grids never do -- from the chip's first
-    full round on a sample's bits do not depend on the batch size"""
-    cd3 = ops.make_conv(128, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)
-    assert ops.conv_split_count((1, 64, 22, 45), cd3) >= 2
-    assert ops.conv_split_count((8, 64, 22, 45), cd3) >= 2
-    for n in (64, 256, 1024):
+def test_rule_splits_long_chains_on_tiny_grids_only(ops):
+    """DLWP_OPT_SPLITK = 1: the exchange between the workgroups of a tile costs ~5 us, a chunk of 8 input channels ~1.2 us of a
+    workgroup's life -- the rule splits (S = 3) launches of at least 12 chunks on at most a third of a workgroup per CU, nothing
+    else: from 4 members of the 88 x 180 grid on, and for every layer of at most 88 input channels, a sample's bits do not depend on
+    its batch size at all"""
+    cd4 = ops.make_conv(64, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, src_mode=1)       # layer 4: 128 -> 64, up-sampled
+    assert ops.conv_split_count((1, 128, 22, 45), cd4) == 3
+    assert ops.conv_split_count((2, 128, 22, 45), cd4) == 3
+    for n in (4, 8, 64, 256, 1024):
+        assert ops.conv_split_count((n, 128, 22, 45), cd4) == 1
+    cd3 = ops.make_conv(128, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)                    # layer 3: 8 chunks
+    for n in (1, 2, 8, 256):
         assert ops.conv_split_count((n, 64, 22, 45), cd3) == 1
     cd1 = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH, out_pool=True)     # 4 input channels: one chunk
     assert ops.conv_split_count((1, 4, 88, 180), cd1) == 1
     prev = ops.set_splitk(0)
     try:
-        assert ops.conv_split_count((1, 64, 22, 45), cd3) == 1
+        assert ops.conv_split_count((1, 128, 22, 45), cd4) == 1
     finally:
         ops.set_splitk(prev)
 
