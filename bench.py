@@ -73,12 +73,13 @@ def config_symbol(cfg, ups=False):
     """kernel symbol of a tile configuration tuple (dlwp_conv2d_config_info), as rocprofv3 prints it"""
     ks, dil, th, tw, waves, fa, bnf, ck, pool = cfg[:9]
     if fa == 0:
-        split = len(cfg) > 10 and cfg[10] and not ups
+        split = len(cfg) > 10 and (cfg[10] & 1) and not ups
         if split:          # the 16-position case of these entries: positions split over two waves per tile fragment
             return 'conv2d_fwd_wino2_f32<WinoSplitCfg<%d, %d, %d, %d, %d, %d, false, false> >' % (dil, th, tw, waves, bnf,
                                                                                                  ck)
-        # <..., IN16, UPS, DACT, POOL2>: the inference plan uses neither the training epilogue nor the second output
-        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s, false, false> >' % (
+        # <..., IN16, UPS, DACT, POOL2, SPLITK>: the inference plan uses neither the training epilogue nor the second output, and
+        # launches that fill the chip are never split
+        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s, false, false, false> >' % (
             dil, th, tw, waves, bnf, ck, 'true' if ups else 'false')
     if bnf < 0:
         return 'conv2d_fwd_packn_f32<PackCfg<%d, %d, %d, %d, %d, %d, %d, %d> >' % (ks, dil, th, tw, waves, fa, ck, -bnf)
@@ -552,48 +553,153 @@ def sub_row_connected(grid, cin, members, forwards):
             'finite': bool(torch.isfinite(ser[-1]).all().item())}
 
 
-def sub_train(grid, cin, world, rank, barrier, dev, global_batch=64, steps=20, warmup=40, share_of=8):
-    """BASELINE config 3: the same U-Net, training, GLOBAL batch 64 ('mse', Adam), data parallel over the ranks: each rank
-    trains on its 64 / N rows, one all-reduce of the flat gradient buffer per step (RCCL through dlwp_allreduce_sum_f32).
-    Strong scaling: the global batch is fixed."""
+def _train_exec_frac(batch):
+    """Executed matrix-core FLOPs of one training step of `batch` samples per GPU, from the committed rocprofv3 --pmc SQ_INSTS_MFMA
+    pass of tools/bench_train.py (profiles/r4_train_mfma_b<batch>.json) -- quoted only when it was taken on THIS kernel source."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r4_train_mfma_b%d.json' % batch)
+    try:
+        d = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None
+    if d.get('_meta', {}).get('source_sha') != kernel_source_hash():
+        return None
+    return d.get('mfma_per_step')
+
+
+def _time_all_reduce(tr, world, barrier, dev, reps=50):
+    """ms per all-reduce of the step's flat exchange buffer (gradients + loss table), alone on the stream"""
+    if world <= 1:
+        return None
+    for _ in range(5):
+        tr.dp.all_reduce_sum_(tr._flat_exchange)
+    dt = _sync_time(lambda: tr.dp.all_reduce_sum_(tr._flat_exchange), reps, barrier, world, dev)
+    tr._flat_exchange.zero_()
+    return 1e3 * dt / reps
+
+
+def sub_train(grid, cin, world, rank, barrier, dev, per_gpu_batch=64, steps=20, warmup=40, share_of=8):
+    """BASELINE config 3: the same U-Net, training ('mse', Adam), data parallel over the ranks -- each rank trains on its rows of
+    the global batch, one all-reduce of the flat gradient buffer per step (RCCL through dlwp_allreduce_sum_f32).  Both conventions
+    at N > 1: 'strong' -- the global batch stays 64, every rank takes 64 / N rows -- and 'weak' -- the reference's: the batch grows
+    with the GPU count, 64 per GPU (Azure/train_tf.py:163-164: batch_size = n_gpu * batch_size)."""
     from dlwp_amd.parallel import shard_bounds
     d = build_model(grid, cin, gpus=world, lr=1e-4)
     tr = d.model._trainer
-    lo, hi = shard_bounds(global_batch, rank, world)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn((global_batch, cin) + grid, generator=g)[lo:hi].to(dev)
-    y = torch.randn((global_batch, cin) + grid, generator=g)[lo:hi].to(dev)
-    for _ in range(warmup):
-        tr.train_on_shard(x, y, global_batch, return_device=True)
-    dt = _sync_time(lambda: tr.train_on_shard(x, y, global_batch, return_device=True), steps, barrier, world, dev)
-    lv, _ = tr.train_on_shard(x, y, global_batch, return_device=True)
-    flops = 3.0 * d.model.plan.conv_flops_per_sample() * global_batch * steps
-    rec = {'value': global_batch * steps / dt, 'unit': 'samples/s', 'scaling': 'strong', 'global_batch': global_batch,
-           'batch_per_gpu': hi - lo, 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
-           'algorithmic_tflops_per_gpu': flops / dt / 1e12 / world,
-           'algorithmic_frac': flops / dt / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
-           'algorithmic_frac_definition': 'ALGORITHMIC FLOPs of the step (3 x the direct-convolution count of the forward: forward, data '
-                              'and weight gradients) / wall / 157.3 TFLOP/s; the Winograd forward and weight-gradient kernels '
-                              'execute fewer multiplies than that count',
-           'loss': float(lv[0, 1].item()),
-           'all_reduce': ('none (single rank)' if world == 1 else
-                          ('RCCL via dlwp_allreduce_sum_f32 (C ABI), %d floats incl. the loss table'
-                           % tr._flat_exchange.numel() if tr.dp.uses_rccl_abi() else 'torch.distributed (%s)' % tr.dp.backend))}
+    flops_s = 3.0 * d.model.plan.conv_flops_per_sample()
+
+    def run(global_batch, label):
+        lo, hi = shard_bounds(global_batch, rank, world)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn((global_batch, cin) + grid, generator=g)[lo:hi].to(dev)
+        y = torch.randn((global_batch, cin) + grid, generator=g)[lo:hi].to(dev)
+        for _ in range(warmup):
+            tr.train_on_shard(x, y, global_batch, return_device=True)
+        dt = _sync_time(lambda: tr.train_on_shard(x, y, global_batch, return_device=True), steps, barrier, world, dev)
+        lv, _ = tr.train_on_shard(x, y, global_batch, return_device=True)
+        flops = flops_s * global_batch * steps
+        rec = {'value': global_batch * steps / dt, 'unit': 'samples/s', 'scaling': label, 'global_batch': global_batch,
+               'batch_per_gpu': hi - lo, 'ms_per_step': 1e3 * dt / steps, 'steps': steps,
+               'step_form': tr._graph_ok(hi - lo) or 'python',
+               'algorithmic_tflops_per_gpu': flops / dt / 1e12 / world,
+               'algorithmic_frac': flops / dt / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 'loss': float(lv[0, 1].item())}
+        mf = _train_exec_frac(hi - lo)
+        if mf:
+            rec['executed_frac'] = mf * 2048.0 * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS
+            rec['executed_mfma_per_step'] = mf
+        return rec, x, y
+
+    rec, x, y = run(per_gpu_batch, 'strong')
+    rec['frac_definition'] = ('algorithmic_frac: ALGORITHMIC FLOPs of the step (3 x the direct-convolution count of the forward: '
+                              'forward, data and weight gradients) / wall / 157.3 TFLOP/s -- the Winograd forward and weight-gradient '
+                              'kernels execute fewer multiplies than that count; executed_frac: SQ_INSTS_MFMA x 2048 of the step '
+                              '(rocprofv3 --pmc pass of tools/bench_train.py on this kernel source, profiles/r4_train_mfma_b*.json) '
+                              '/ wall / 157.3 TFLOP/s')
+    rec['step_forms'] = ("'graph' / 'lanes' / 'branches': the step replayed by the library (dlwp_train_step_launch: one hipGraph / "
+                         "launch by launch over the recorded lanes / one hipGraph with the lanes as branches); 'python': launch by "
+                         "launch from the interpreter")
+    rec['all_reduce'] = ('none (single rank)' if world == 1 else
+                         ('RCCL via dlwp_allreduce_sum_f32 (C ABI), %d floats incl. the loss table'
+                          % tr._flat_exchange.numel() if tr.dp.uses_rccl_abi() else 'torch.distributed (%s)' % tr.dp.backend))
+    ar_ms = _time_all_reduce(tr, world, barrier, dev)
+    if ar_ms is not None:
+        rec['all_reduce_ms_measured'] = ar_ms
+        rec['all_reduce_bytes'] = int(tr._flat_exchange.numel()) * 4
+    if world > 1:
+        weak, _, _ = run(per_gpu_batch * world, 'weak')
+        weak['convention'] = 'reference: batch_size = n_gpu * batch_size (Azure/train_tf.py:163-164)'
+        rec['weak'] = weak
     if world == 1 and share_of:
         # the share of one of `share_of` GPUs of the same global batch, on this one GPU (no exchange): the strong-scaling
-        # projection adds an assumed 40 us for the one 756 KB all-reduce over xGMI (never measured: no multi-GPU box)
-        nb = max(1, global_batch // share_of)
+        # projection adds an ASSUMED 40 us for the one 756 KB all-reduce over xGMI (no multi-GPU box to measure it on; the N > 1
+        # runs of this record print all_reduce_ms_measured)
+        nb = max(1, per_gpu_batch // share_of)
         xs, ys = x[:nb].contiguous(), y[:nb].contiguous()
         for _ in range(warmup):
             tr.train_on_shard(xs, ys, nb, return_device=True)
         dts = _sync_time(lambda: tr.train_on_shard(xs, ys, nb, return_device=True), steps)
         ms8 = 1e3 * dts / steps
-        rec['share_of_%d_gpus' % share_of] = {
-            'batch': nb, 'ms_per_step': ms8, 'value': nb * steps / dts, 'unit': 'samples/s',
-            'algorithmic_frac': 3.0 * d.model.plan.conv_flops_per_sample() * nb * steps / dts / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            'assumed_all_reduce_ms': 0.04,
-            'projected_speedup_%d_gpus' % share_of: rec['ms_per_step'] / (ms8 + 0.04)}
+        sh = {'batch': nb, 'ms_per_step': ms8, 'value': nb * steps / dts, 'unit': 'samples/s',
+              'step_form': tr._graph_ok(nb) or 'python', 'input': 'device-resident tensors (no loader)',
+              'algorithmic_frac': flops_s * nb * steps / dts / 1e12 / PEAK_F32_MFMA_TFLOPS,
+              'assumed_all_reduce_ms': 0.04, 'all_reduce': 'ASSUMED, not measured (single GPU)',
+              'projected_speedup_%d_gpus' % share_of: rec['ms_per_step'] / (ms8 + 0.04)}
+        mf = _train_exec_frac(nb)
+        if mf:
+            sh['executed_frac'] = mf * 2048.0 * steps / dts / 1e12 / PEAK_F32_MFMA_TFLOPS
+        rec['share_of_%d_gpus' % share_of] = sh
     return rec
+
+
+def sub_train_loader_fed(grid, cin, dev, batches=(64, 8), samples_per_batch=40, epochs=3):
+    """BASELINE config 3 the way the reference drives it: fit_generator(DataGenerator(batch, shuffle=True), ...)
+    (examples/train.py:262-263, DLWP/model/models.py:216-228) over a host-resident float32 training set -- every step's rows cross
+    the link (H2D included), against the same step on device-resident tensors.  Single rank."""
+    from dlwp_amd.model import ArrayDataset, DataGenerator
+    out = {}
+    for b in batches:
+        d = build_model(grid, cin, lr=1e-4)
+        tr = d.model._trainer
+        rng = np.random.default_rng(0)
+        n = b * samples_per_batch
+        P = rng.standard_normal((n, 2, cin // 2) + tuple(grid), dtype=np.float32)
+        T = rng.standard_normal((n, 2, cin // 2) + tuple(grid), dtype=np.float32)
+        gen = DataGenerator(d, ArrayDataset(P, T), batch_size=b, shuffle=True)
+        steps = len(gen)
+        d.fit_generator(gen, epochs=1, verbose=0)                   # warm-up: buffers, page-locking, the recorded step
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d.fit_generator(gen, epochs=epochs, verbose=0)
+        torch.cuda.synchronize()
+        fed = (time.perf_counter() - t0) / (epochs * steps)
+        x = torch.from_numpy(P[:b].reshape((b, cin) + tuple(grid))).to(dev)
+        y = torch.from_numpy(T[:b].reshape((b, cin) + tuple(grid))).to(dev)
+        for _ in range(10):
+            tr.train_on_shard(x, y, b, return_device=True)
+        torch.cuda.synchronize()
+        k = 60
+        t0 = time.perf_counter()
+        for _ in range(k):
+            tr.train_on_shard(x, y, b, return_device=True)
+        host = (time.perf_counter() - t0) / k                       # launches issued, nothing waited for
+        torch.cuda.synchronize()
+        res = (time.perf_counter() - t0) / k
+        from dlwp_amd.model.generators import DeviceLoader
+        ld = DeviceLoader(gen, dev)
+        ld._setup_pull()
+        out['batch_%d' % b] = {
+            'loader_fed_ms_per_step': 1e3 * fed, 'device_resident_ms_per_step': 1e3 * res, 'loader_over_resident': fed / res,
+            'host_ms_per_step': 1e3 * host, 'step_form': tr._graph_ok(b) or 'python', 'samples_per_s': b / fed,
+            'h2d_mb_per_step': 2 * b * cin * grid[0] * grid[1] * 4 / 1e6,
+            'feed': ('rows pulled over the link by a gather kernel from the page-locked training set (dlwp_gather_rows_h2d)'
+                     if ld._pull else ('host gather into pinned buffers (dlwp_host_gather_rows) + H2D copy'
+                                       if gen.batch_sources() is not None else 'generator batches + H2D copy')),
+            'steps_timed': epochs * steps}
+        del d, tr, gen, P, T
+        torch.cuda.empty_cache()
+    out['definition'] = ('fit_generator over DataGenerator(shuffle=True) on a host-resident float32 set, wall / step over whole epochs '
+                         '(callbacks, the epoch-end loss read-back included); device_resident: train_on_shard on tensors already in '
+                         'HBM; host_ms_per_step: time to ISSUE a device-resident step')
+    return out
 
 
 def sub_cfg5(world, rank, barrier, dev, total_members=32, forwards=40, share_of=8):
@@ -839,6 +945,8 @@ def main():
             net.__dict__.pop('_rollouts', None)
             torch.cuda.empty_cache()
             sub['train_cfg3'] = sub_train(grid if grid == (88, 180) else (88, 180), 4, world, rank, barrier, dev)
+            if world == 1:
+                sub['train_cfg3_loader_fed'] = sub_train_loader_fed((88, 180), 4, dev)
             sub['ensemble_cfg5'] = sub_cfg5(world, rank, barrier, dev)
         except Exception as e:  # noqa: BLE001
             sub['error_collective'] = repr(e)

@@ -205,6 +205,9 @@ _sig('dlwp_rollout_create_grouped', [_vp, _P(Op), _i, _P(_vp), _i, _P(_sz), _i, 
 _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
 _sig('dlwp_host_gather_rows', [_vp, _vp, _vp, ctypes.c_longlong, _sz, ctypes.c_longlong, _i])
+_sig('dlwp_host_register', [_vp, _sz, _P(_vp)])
+_sig('dlwp_host_unregister', [_vp])
+_sig('dlwp_gather_rows_h2d', [_vp, _vp, _vp, _vp, ctypes.c_longlong, _sz, ctypes.c_longlong, _vp])
 _sig('dlwp_train_step_record_begin', [_vp, _vp])
 _sig('dlwp_train_step_record_abort', [_vp])
 _sig('dlwp_stream_wait', [_vp, _vp, _vp])

@@ -33,16 +33,26 @@ int lane_of(Tape* t, void* stream) {
 
 }  // namespace
 
-dlwp_tape_scope::dlwp_tape_scope() { outer = (t_depth++ == 0); }
-dlwp_tape_scope::~dlwp_tape_scope() { --t_depth; }
+dlwp_tape_scope::dlwp_tape_scope() {
+  outer = (t_depth++ == 0);
+  errors_at_entry = dlwp_error_count();
+  pushed = -1;
+}
+dlwp_tape_scope::~dlwp_tape_scope() {
+  --t_depth;
+  // the call failed: its record (the last one: nothing else is pushed while an outermost scope is open) leaves the tape
+  if (pushed >= 0 && t_tape && dlwp_error_count() != errors_at_entry && (long long)t_tape->recs.size() == pushed + 1)
+    t_tape->recs.pop_back();
+}
 
 bool dlwp_tape_recording(dlwp_handle_t h) { return t_tape != nullptr && t_tape->h == h; }
 
-void dlwp_tape_push(dlwp_handle_t, void* stream, std::function<int(void*)> fn, const char* name) {
+long long dlwp_tape_push(dlwp_handle_t, void* stream, std::function<int(void*)> fn, const char* name) {
   Tape* t = t_tape;
   // (host-only calls -- a null stream -- ride on lane 0: they only touch the handle's state, in issue order)
   const int lane = stream ? lane_of(t, stream) : 0;
   t->recs.push_back(Rec{lane, -1, std::move(fn), name});
+  return (long long)t->recs.size() - 1;
 }
 
 struct dlwp_train_step {
@@ -74,7 +84,12 @@ int replay(dlwp_train_step* st, const std::vector<hipStream_t>& lanes, bool sing
       continue;
     }
     const int rc = r.fn((void*)lanes[single ? 0 : r.lane]);
-    if (rc != DLWP_OK) return rc;     // (the error string names the entry point)
+    if (rc != DLWP_OK) {              // (the error string names the entry point)
+      // a step that stops half way must not leave the handle recording weight preparations / final sums
+      st->h->prep_defer = st->h->red_defer = 0;
+      st->h->n_prep = st->h->n_red = 0;
+      return rc;
+    }
   }
   return DLWP_OK;
 }

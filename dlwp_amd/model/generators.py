@@ -577,14 +577,46 @@ class DeviceLoader(object):
         return src, np.ascontiguousarray(sm[0], dtype=np.int64), sm[1]
 
     # -- staging ---------------------------------------------------------------------------------------------------------- #
-    def _alloc_slot(self, sizes):
-        """(consumer thread) pinned host + device buffers for arrays of `sizes` elements"""
+    def _alloc_slot(self, sizes, host=True):
+        """(consumer thread) pinned host + device buffers for arrays of `sizes` elements (host=False: the pull path stages
+        nothing on the host)"""
         torch = self._torch
         pin = self.device.type == 'cuda'
         return {'cap': list(sizes),
-                'host': [torch.empty(max(1, s), dtype=torch.float32, pin_memory=pin) for s in sizes],
+                'host': [torch.empty(max(1, s), dtype=torch.float32, pin_memory=pin) for s in sizes] if host else None,
                 'dev': [torch.empty(max(1, s), dtype=torch.float32, device=self.device) for s in sizes],
                 'ev': torch.cuda.Event() if pin else None, 'done': None}
+
+    def _setup_pull(self):
+        """(consumer thread, before the worker starts) The PULL path: the generator's source arrays page-locked and mapped for the
+        device once (dlwp_host_register), every batch then fetched over the link by a gather kernel on the copy stream
+        (dlwp_gather_rows_h2d) -- no host copy at all.  Taken when the batches are plain row gathers (`batch_sources`) of rows
+        that are whole 16-byte units; the registration lives as long as the generator.  DLWP_LOADER_PULL=0 keeps the host gather."""
+        import weakref
+        from .. import _lib
+        self._pull = None
+        if self._copy_stream is None or os.environ.get('DLWP_LOADER_PULL', '1') == '0' or not hasattr(self.gen, 'batch_sources'):
+            return
+        srcs = self.gen.batch_sources()
+        if srcs is None or any((int(np.prod(shp)) * 4) % 16 or arr.ctypes.data % 16 for arr, shp in srcs):
+            return
+        mapped = self.gen.__dict__.get('_dlwp_mapped')
+        if mapped is None:
+            mapped, done = [], []
+            for arr, _ in srcs:
+                dptr = ctypes.c_void_p()
+                if _lib.lib.dlwp_host_register(ctypes.c_void_p(arr.ctypes.data), arr.nbytes, ctypes.byref(dptr)) != _lib.OK:
+                    for a in done:
+                        _lib.lib.dlwp_host_unregister(ctypes.c_void_p(a))
+                    mapped = False
+                    break
+                done.append(arr.ctypes.data)
+                mapped.append(int(dptr.value))
+            self.gen._dlwp_mapped = mapped
+            if mapped:
+                weakref.finalize(self.gen, lambda ptrs=tuple(done): [_lib.lib.dlwp_host_unregister(ctypes.c_void_p(p)) for p in ptrs])
+        if mapped:
+            self._pull = list(zip(mapped, srcs))
 
     def _fill(self, slot, idx):
         """(worker thread: host work only) batch idx into the pinned buffers of `slot`; returns (shapes, was_list, n_global), or
@@ -595,6 +627,8 @@ class DeviceLoader(object):
             srcs, rows, n_global = plan
             shapes = [(len(rows),) + tuple(shp) for _, shp in srcs]
             sizes = [int(np.prod(sh)) for sh in shapes]
+            if self.__dict__.get('_pull'):          # nothing to do on the host: the consumer launches the gather kernels
+                return {'shapes': shapes, 'was_list': False, 'n_global': n_global, 'arrays': None, 'pull': rows}
             if slot is not None and len(slot['cap']) == len(sizes) and all(c >= z for c, z in zip(slot['cap'], sizes)):
                 for (arr, shp), hbuf in zip(srcs, slot['host']):
                     row_bytes = int(np.prod(shp)) * 4
@@ -638,6 +672,7 @@ class DeviceLoader(object):
                     state['error'] = e
                     lock.notify_all()
 
+        self._setup_pull()
         th = threading.Thread(target=worker, daemon=True)
         th.start()
         cuda = self._copy_stream is not None
@@ -652,6 +687,26 @@ class DeviceLoader(object):
                     raise state['error']
                 res = state['filled'].pop(k)
             slot = self._slots[s]
+            if res.get('pull') is not None:          # the batch is pulled over the link by kernels on the copy stream
+                from .. import _lib
+                sizes = [int(np.prod(sh)) for sh in res['shapes']]
+                if slot is None or len(slot['cap']) != len(sizes) or any(c < z for c, z in zip(slot['cap'], sizes)):
+                    slot = self._slots[s] = self._alloc_slot([max(z, int(np.prod(shp)) * int(getattr(self.gen, '_batch_size', 0)))
+                                                              for z, (_, (_, shp)) in zip(sizes, self._pull)], host=False)
+                ds = [dbuf[:z].view(tuple(sh)) for z, sh, dbuf in zip(sizes, res['shapes'], slot['dev'])]
+                rows = res['pull']
+                if slot['done'] is not None:
+                    self._copy_stream.wait_event(slot['done'])
+                dev_i = self.device.index if self.device.index is not None else torch.cuda.current_device()
+                for d, (dptr, (arr, shp)) in zip(ds, self._pull):
+                    _lib.check(_lib.lib.dlwp_gather_rows_h2d(_lib.handle(dev_i), ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(dptr),
+                                                             rows.ctypes.data_as(ctypes.c_void_p), len(rows), int(np.prod(shp)) * 4,
+                                                             arr.shape[0], ctypes.c_void_p(self._copy_stream.cuda_stream)))
+                slot['ev'].record(self._copy_stream)
+                slot['recorded'] = True
+                return ds, slot, res['was_list'], res['n_global']
+            if slot is not None and slot['host'] is None:
+                slot = None                          # (a pull slot: no host buffers)
             if res['arrays'] is not None:            # first use of the slot, or a batch larger than it: (re)allocate, copy here
                 sizes = [a.size for a in res['arrays']]
                 if slot is None or len(slot['cap']) != len(sizes) or any(c < z for c, z in zip(slot['cap'], sizes)):

@@ -27,3 +27,19 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """the measured forward / rollout errors of this session (tests/test_gpu_model.py: MEASURED) next to the test log"""
+    mod = sys.modules.get('tests.test_gpu_model')
+    measured = getattr(mod, 'MEASURED', None)
+    if not measured:
+        return
+    import json
+    out = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'forward_errors.json'), 'w') as f:
+            json.dump({k: [float('%.3e' % v) for v in vs] for k, vs in sorted(measured.items())}, f, indent=1)
+    except OSError:
+        pass

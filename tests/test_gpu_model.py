@@ -41,8 +41,17 @@ def _weights_of(model, rng=None, bias_scale=0.1):
     return pairs
 
 
+#: every relative error the forward / rollout parity tests measured in this session: {test id: [values]} -- written to
+#: gpurun_out/forward_errors.json when the session ends (tests/conftest.py), so that the tolerance can be read against what the
+#: kernels actually deliver
+MEASURED = {}
+
+
 def _rel(a, b):
-    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    v = float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    import os
+    MEASURED.setdefault(os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0], []).append(v)
+    return v
 
 
 def _bf16_weight_indices(model, n):
@@ -92,9 +101,22 @@ def test_predict_does_not_depend_on_batch_chunking_or_batch_mates():
     d = _build(unet_layers(cs))
     _weights_of(d.model, rng)
     x = rng.standard_normal((300,) + cs).astype(np.float32)
+    from dlwp_amd import ops
     full = d.predict(x)
     assert np.array_equal(full, d.predict(x, batch_size=256))      # chunked (256 + 44) == one pass, bit for bit
-    assert np.array_equal(full[7:8], d.predict(x[7:8]))              # a member alone == the member inside a batch
+    # r4: launches of a handful of samples may divide a long input-channel sum over several workgroups (DLWP_OPT_SPLITK: the
+    # 128-channel decoder layer here): the same sum in another association.  Within one split regime a member's bits do not depend
+    # on its batch mates; across regimes they agree to float32 round-off; with the option off they never differ.
+    alone, pair = d.predict(x[7:8]), d.predict(x[7:9])
+    assert np.array_equal(alone, pair[:1])                           # 1 and 2 members: the same regime
+    assert _rel(alone, full[7:8]) < 2e-6
+    prev = ops.set_splitk(0)
+    try:
+        full0 = d.predict(x)
+        assert np.array_equal(full0, d.predict(x, batch_size=256))
+        assert np.array_equal(full0[7:8], d.predict(x[7:8]))         # a member alone == the member inside a batch
+    finally:
+        ops.set_splitk(prev)
 
 
 def test_predict_timeseries_graph_equals_host_loop_and_tracks_the_oracle():
