@@ -221,6 +221,12 @@ _sig('dlwp_comm_info', [_vp, _P(_i), _P(_i), _P(_i)])
 _sig('dlwp_allreduce_sum_f32', [_vp, _vp, _sz, _vp])
 _sig('dlwp_broadcast_f32', [_vp, _vp, _sz, _i, _vp])
 _sig('dlwp_comm_destroy', [_vp])
+_sig('dlwp_xchg_create', [_vp, _i, _i, _sz, _vp, _P(_vp)])
+_sig('dlwp_xchg_connect', [_vp, _vp])
+_sig('dlwp_xchg_allreduce_sum_f32', [_vp, _vp, _sz, _vp])
+_sig('dlwp_xchg_allreduce_adam', [_vp, _vp, _sz, _sz, _vp, _vp, _vp] + [ctypes.c_float] * 5 + [ctypes.c_longlong, ctypes.c_float, _vp])
+_sig('dlwp_xchg_status', [_vp, _P(_i)])
+_sig('dlwp_xchg_destroy', [_vp])
 
 
 def check(rc):

@@ -1,0 +1,246 @@
+// xchg.hip -- a one-shot all-reduce of our own for the data-parallel training step, fused with the Keras-form Adam update.
+//
+// Reference: keras.utils.multi_gpu_model (DLWP/model/models.py:104-109, 365-372) gathers the replicas' gradients on the host every
+// step.  Here the exchange is one flat float32 buffer of 189 k floats (756 KB: every gradient of the config-2 U-Net + the loss
+// table) per step -- latency-bound: a ring collective pays 2 (W - 1) hops for it, a one-shot exchange ONE: every rank publishes
+// its buffer in memory its peers have mapped (hipIpcMemHandle over xGMI; on the test box two processes of one GPU), raises a flag in
+// every peer's memory, waits for the peers' flags, reads all W buffers and sums them IN RANK ORDER -- the same order on every rank,
+// so the replicas stay bit-identical -- and applies the Adam update to its own parameters in the same kernel.
+//
+//   region of a rank (device memory, mapped by every peer):  header { flags[64], arrive, error }  +  2 payload buffers (step parity)
+//   one launch: (A) blocks copy their slice of `flat` into payload[step & 1]; the LAST block to finish stores `step` into flag
+//   [my rank] of every peer's header.  (B) every block waits until all flags of its OWN header read `step`, then sums its slice over
+//   the ranks 0 .. W - 1 and updates p, m, v (or writes the sum back to flat).
+//   Two payload buffers suffice: a rank overwrites buffer s & 1 at step s + 2, after its step s + 1 completed, which needed every
+//   peer's flag s + 1, which a peer raises only after its own step s -- the last reader of that buffer -- returned.
+// Coherence: no fences (an agent-scope fence on gfx950 writes back and invalidates the XCD's whole L2, see conv_fwd_wino_kernel.h):
+// every payload / flag access carries sc0 sc1 (system scope: past the L1s and L2s on both sides), stores are waited for
+// (s_waitcnt vmcnt(0)) before the flag goes up.  A wait is BOUNDED (2 s of s_memrealtime): a peer that never arrives makes the kernel
+// set header.error and return; dlwp_xchg_status reports it -- never a hung GPU.
+#include "common.h"
+
+namespace {
+
+constexpr int XCHG_MAX_WORLD = 16;
+constexpr size_t XCHG_HEADER_BYTES = 1024;
+constexpr int SYS = 17;    // cache policy sc0 | sc1
+
+struct Header {
+  unsigned flag[64];       // flag[q] = the last step rank q published (written by rank q, remotely)
+  unsigned arrive;         // blocks of the local launch that finished their copy
+  unsigned error;          // 1: a wait timed out
+};
+
+struct Peers {
+  char* region[XCHG_MAX_WORLD];    // every rank's region as mapped HERE; [rank] = the own one
+};
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned load_sys(const unsigned* p) {
+  return __builtin_nontemporal_load(p);   // (replaced below by the buffer form; kept for clarity of intent)
+}
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void xchg_allreduce_kernel(Peers peers, int world, int rank, unsigned step, long long n4,
+                                                             long long n_params, float* __restrict__ flat, float* __restrict__ p,
+                                                             float* __restrict__ m, float* __restrict__ v, float lr_t, float b1,
+                                                             float b2, float eps, float grad_scale) {
+  const int tid = threadIdx.x;
+  const long long i = (long long)blockIdx.x * 256 + tid;          // this thread's float4
+  const size_t pay_off = XCHG_HEADER_BYTES + (size_t)(step & 1u) * (size_t)n4 * 16;
+  Header* const mine = (Header*)peers.region[rank];
+  // ---- (A) publish
+  {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(peers.region[rank] + pay_off), 0, (unsigned)(n4 * 16), 0x00020000);
+    if (i < n4) {
+      const f32x4_t g = *(const f32x4_t*)(flat + 4 * i);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, g), r, (unsigned)(i * 16), 0, SYS);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned s_last;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&mine->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_last == gridDim.x - 1) {          // every block's slice is in memory: raise the flag in every rank's header
+      if (tid == 0) __hip_atomic_store(&mine->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid < world) {
+        const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)peers.region[tid], 0, (unsigned)XCHG_HEADER_BYTES, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(step, fr, (unsigned)(rank * 4), 0, SYS);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  // ---- (B) wait for every rank's flag in the OWN header
+  {
+    __shared__ unsigned s_ok;
+    if (tid == 0) s_ok = 1u;
+    __syncthreads();
+    if (tid < world) {
+      const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, (unsigned)XCHG_HEADER_BYTES, 0x00020000);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+      for (;;) {
+        const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(fr, (unsigned)(tid * 4), 0, SYS);
+        if ((int)(f - step) >= 0) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {        // 2 s: the peer is not coming
+          __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_ok = 0u;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+  }
+  if (i >= n4) return;
+  // ---- sum over the ranks in rank order (identical on every rank), then the update
+  f32x4_t g = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < world; ++q) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(peers.region[q] + pay_off), 0, (unsigned)(n4 * 16), 0x00020000);
+    const f32x4_t t = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(i * 16), 0, SYS));
+    g = q == 0 ? t : g + t;
+  }
+  if (ADAM) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long long e = 4 * i + k;
+      if (e < n_params) {
+        const float gi = g[k] * grad_scale;
+        const float mi = b1 * m[e] + (1.f - b1) * gi;
+        const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
+        m[e] = mi;
+        v[e] = vi;
+        p[e] = p[e] - lr_t * mi / (sqrtf(vi) + eps);
+      }
+    }
+  }
+  *(f32x4_t*)(flat + 4 * i) = g;          // the summed buffer (gradients and the loss table in its tail)
+}
+
+}  // namespace
+
+struct dlwp_xchg {
+  dlwp_handle_t h;
+  int world, rank;
+  size_t n_floats, n4;
+  char* region;                      // own
+  size_t region_bytes;
+  Peers peers;
+  bool mapped[XCHG_MAX_WORLD];
+  unsigned step;
+  bool connected;
+};
+
+extern "C" {
+
+// n_floats: capacity of one exchange (rounded up to whole float4).  ipc_handle_out: 64 bytes (hipIpcMemHandle_t) to hand to the peers.
+int dlwp_xchg_create(dlwp_handle_t h, int world, int rank, size_t n_floats, void* ipc_handle_out, dlwp_xchg_t* out) {
+  DLWP_CHECK_ARG(h && out && ipc_handle_out, "dlwp_xchg_create: null handle or pointer");
+  DLWP_CHECK_ARG(world >= 1 && world <= XCHG_MAX_WORLD && rank >= 0 && rank < world && n_floats > 0 && n_floats < (1ull << 28),
+                 "dlwp_xchg_create: world %d (at most %d), rank %d, %zu floats", world, XCHG_MAX_WORLD, rank, n_floats);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  dlwp_xchg* x = new dlwp_xchg();
+  x->h = h;
+  x->world = world;
+  x->rank = rank;
+  x->n4 = (n_floats + 3) / 4;
+  x->n_floats = x->n4 * 4;
+  x->region_bytes = XCHG_HEADER_BYTES + 2 * x->n4 * 16;
+  x->step = 0;
+  x->connected = false;
+  for (int i = 0; i < XCHG_MAX_WORLD; ++i) x->peers.region[i] = nullptr, x->mapped[i] = false;
+  hipError_t e = hipMalloc((void**)&x->region, x->region_bytes);
+  if (e == hipSuccess) e = hipMemset(x->region, 0, x->region_bytes);
+  hipIpcMemHandle_t hd;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&hd, x->region);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (x->region) (void)hipFree(x->region);
+    delete x;
+    DLWP_FAIL(DLWP_EHIP, "dlwp_xchg_create: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
+  }
+  memcpy(ipc_handle_out, &hd, 64);
+  x->peers.region[rank] = x->region;
+  *out = x;
+  return DLWP_OK;
+}
+
+// handles: world x 64 bytes in rank order (the own entry is ignored)
+int dlwp_xchg_connect(dlwp_xchg_t x, const void* handles) {
+  DLWP_CHECK_ARG(x && handles, "dlwp_xchg_connect: null pointer");
+  for (int q = 0; q < x->world; ++q) {
+    if (q == x->rank || x->mapped[q]) continue;
+    hipIpcMemHandle_t hd;
+    memcpy(&hd, (const char*)handles + 64 * q, 64);
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      DLWP_FAIL(DLWP_EHIP, "dlwp_xchg_connect: hipIpcOpenMemHandle of rank %d's region failed: %s", q, hipGetErrorString(e));
+    }
+    x->peers.region[q] = (char*)p;
+    x->mapped[q] = true;
+  }
+  x->connected = true;
+  return DLWP_OK;
+}
+
+static int xchg_launch(dlwp_xchg_t x, float* flat, size_t n, bool adam, size_t n_params, float* p, float* m, float* v, float lr_t,
+                       float b1, float b2, float eps, float grad_scale, hipStream_t s) {
+  DLWP_CHECK_ARG(x && x->connected, "dlwp_xchg: not connected (dlwp_xchg_connect)");
+  DLWP_CHECK_ARG(flat && n > 0 && n <= x->n_floats && n % 4 == 0 && ((uintptr_t)flat & 15) == 0,
+                 "dlwp_xchg: %zu floats (whole aligned float4, at most %zu)", n, x->n_floats);
+  const long long n4 = (long long)(n / 4);
+  // (the payload stride of a parity is fixed by the region, not by this call's n)
+  DLWP_CHECK_ARG((size_t)n4 == x->n4, "dlwp_xchg: every exchange moves the %zu floats the region was made for", x->n_floats);
+  ++x->step;
+  const int grid = (int)((n4 + 255) / 256);
+  if (adam)
+    xchg_allreduce_kernel<true><<<grid, 256, 0, s>>>(x->peers, x->world, x->rank, x->step, n4, (long long)n_params, flat, p, m, v, lr_t,
+                                                     b1, b2, eps, grad_scale);
+  else
+    xchg_allreduce_kernel<false><<<grid, 256, 0, s>>>(x->peers, x->world, x->rank, x->step, n4, 0, flat, nullptr, nullptr, nullptr, 0.f,
+                                                      0.f, 0.f, 0.f, 1.f);
+  DLWP_LAUNCH_CHECK("xchg_allreduce_kernel");
+  return DLWP_OK;
+}
+
+// flat <- sum over the ranks of flat (n floats, n = the region's size), in rank order.  Collective: every rank calls it.
+int dlwp_xchg_allreduce_sum_f32(dlwp_xchg_t x, void* flat, size_t n, void* stream) {
+  return xchg_launch(x, (float*)flat, n, false, 0, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, (hipStream_t)stream);
+}
+
+// ... and the Keras-form Adam update of the first n_params elements in the same kernel: g = grad_scale * sum; flat receives the sums
+// (the loss table behind the gradients travels along).  `iteration`: the optimizer's step number BEFORE this update, as dlwp_adam_keras.
+int dlwp_xchg_allreduce_adam(dlwp_xchg_t x, void* flat, size_t n_params, size_t n, void* p, void* m, void* v, float lr, float beta_1,
+                             float beta_2, float epsilon, float decay, long long iteration, float grad_scale, void* stream) {
+  DLWP_CHECK_ARG(p && m && v && n_params <= n, "dlwp_xchg_allreduce_adam: null pointer or n_params > n");
+  const double t = (double)iteration + 1.0;
+  const double lr_ = (double)lr / (1.0 + (double)decay * (double)iteration);
+  const double lr_t = lr_ * sqrt(1.0 - pow((double)beta_2, t)) / (1.0 - pow((double)beta_1, t));
+  return xchg_launch(x, (float*)flat, n, true, n_params, (float*)p, (float*)m, (float*)v, (float)lr_t, beta_1, beta_2, epsilon, grad_scale,
+                     (hipStream_t)stream);
+}
+
+// 0: fine; 1: a wait for a peer's flag timed out in some launch (the result of that launch is invalid).  Synchronises the device.
+int dlwp_xchg_status(dlwp_xchg_t x, int* timed_out) {
+  DLWP_CHECK_ARG(x && timed_out, "dlwp_xchg_status: null pointer");
+  Header hd;
+  DLWP_HIP(hipMemcpy(&hd, x->region, sizeof(Header), hipMemcpyDeviceToHost));
+  *timed_out = hd.error ? 1 : 0;
+  return DLWP_OK;
+}
+
+int dlwp_xchg_destroy(dlwp_xchg_t x) {
+  if (!x) return DLWP_OK;
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < x->world; ++q)
+    if (x->mapped[q]) (void)hipIpcCloseMemHandle(x->peers.region[q]);
+  if (x->region) (void)hipFree(x->region);
+  delete x;
+  return DLWP_OK;
+}
+
+}  // extern "C"

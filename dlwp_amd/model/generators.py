@@ -595,7 +595,12 @@ class DeviceLoader(object):
         import weakref
         from .. import _lib
         self._pull = None
-        if self._copy_stream is None or os.environ.get('DLWP_LOADER_PULL', '1') == '0' or not hasattr(self.gen, 'batch_sources'):
+        # OFF by default (r4, profiles/r4_loader_timeline.txt): while the gather kernel runs on the copy stream's queue, every
+        # kernel boundary of the training step waits for it -- a 11 us launch of the step ends when the 310 us gather ends -- so the
+        # transfer ADDS to the step instead of hiding under it (2.08 ms per step at 64 samples against 1.48 ms with DMA copies,
+        # 1.44 ms with no feed at all).  Copy-engine transfers do not have that effect; the host gather in front of them runs at
+        # 45 (1 thread) - 150 GB/s (8 threads) on the GPU box, the link at 55 GB/s.
+        if self._copy_stream is None or os.environ.get('DLWP_LOADER_PULL', '0') != '1' or not hasattr(self.gen, 'batch_sources'):
             return
         srcs = self.gen.batch_sources()
         if srcs is None or any((int(np.prod(shp)) * 4) % 16 or arr.ctypes.data % 16 for arr, shp in srcs):
@@ -645,10 +650,13 @@ class DeviceLoader(object):
             arrays = None
         return {'shapes': shapes, 'was_list': was_list, 'n_global': n_global, 'arrays': arrays}
 
-    def iter_batches(self):
+    def iter_batches(self, order=None):
         """yields (X, y, n_global): device tensors of this rank's rows (y a list when the generator gives a list) and
-        the size of the global batch they belong to"""
+        the size of the global batch they belong to.  order: this pass's batch indices (default: the loader's); the staging
+        buffers stay with the loader, so one loader serves every epoch of a fit_generator call."""
         torch = self._torch
+        if order is not None:
+            self.order = list(order)
         n = len(self.order)
         lock = threading.Condition()
         state = {'filled': {}, 'free': set(range(self.depth)), 'error': None, 'stop': False}
@@ -673,6 +681,16 @@ class DeviceLoader(object):
                     lock.notify_all()
 
         self._setup_pull()
+        if not self._pull and hasattr(self.gen, 'batch_sources') and self.gen.batch_sources() is not None:
+            # plain row gathers: the batch shapes are known without fetching one -- staging buffers for whole batches up front, so
+            # that the worker gathers into pinned memory from the first batch on
+            bs = int(getattr(self.gen, '_batch_size', 0))
+            sizes = [bs * int(np.prod(shp)) for _, shp in self.gen.batch_sources()]
+            for i in range(self.depth):
+                sl = self._slots[i]
+                if bs > 0 and (sl is None or sl['host'] is None or len(sl['cap']) != len(sizes) or
+                               any(c < z for c, z in zip(sl['cap'], sizes))):
+                    self._slots[i] = self._alloc_slot(sizes)
         th = threading.Thread(target=worker, daemon=True)
         th.start()
         cuda = self._copy_stream is not None

@@ -77,6 +77,59 @@ class DataParallel(object):
             from . import _lib
             _lib.lib.dlwp_comm_destroy(self._comm)
             self._comm = None
+        if getattr(self, '_xchg', None):
+            from . import _lib
+            _lib.lib.dlwp_xchg_destroy(self._xchg[0])
+            self._xchg = None
+
+    # -- the library's own one-shot exchange (csrc/xchg.hip), DLWP_ALLREDUCE=oneshot ------------------------------------- #
+    def wants_oneshot(self, flat):
+        """the step's exchange through dlwp_xchg_* (every rank publishes its buffer in peer-mapped memory, reads all of them, sums
+        in rank order and updates its parameters in the same kernel) instead of RCCL / torch.distributed.  Opt-in
+        (DLWP_ALLREDUCE=oneshot): RCCL stays the default until a multi-GPU run has been through it."""
+        return os.environ.get('DLWP_ALLREDUCE', '') == 'oneshot' and flat.is_cuda and flat.numel() % 4 == 0 and self.world <= 16
+
+    def xchg(self, flat):
+        """dlwp_xchg_t for buffers of flat.numel() floats; created collectively at the first call (the 64-byte IPC handles travel
+        through torch.distributed's host channel, like RCCL's unique id)"""
+        ent = getattr(self, '_xchg', None)
+        if ent is None or ent[1] != flat.numel():
+            from . import _lib
+            if ent is not None:
+                _lib.lib.dlwp_xchg_destroy(ent[0])
+            idx = flat.device.index if flat.device.index is not None else torch.cuda.current_device()
+            hd = (ctypes.c_char * 64)()
+            out = ctypes.c_void_p()
+            _lib.check(_lib.lib.dlwp_xchg_create(_lib.handle(idx), self.world, self.rank, flat.numel(), hd, ctypes.byref(out)))
+            handles = [None] * self.world
+            self.dist.all_gather_object(handles, bytes(hd), group=self.group)
+            blob = (ctypes.c_char * (64 * self.world)).from_buffer_copy(b''.join(handles))
+            _lib.check(_lib.lib.dlwp_xchg_connect(out, blob))
+            self.dist.barrier(group=self.group)          # every region is mapped everywhere before the first flag is written
+            ent = self._xchg = (out, flat.numel())
+        return ent[0]
+
+    def oneshot_all_reduce_(self, flat):
+        from . import _lib
+        _lib.check(_lib.lib.dlwp_xchg_allreduce_sum_f32(self.xchg(flat), ctypes.c_void_p(flat.data_ptr()), flat.numel(), self._stream(flat)))
+        return flat
+
+    def oneshot_adam_(self, flat, n_params, p, m, v, lr, beta_1, beta_2, epsilon, decay, iteration, grad_scale):
+        """flat <- the sums over the ranks (in rank order); p, m, v <- the Keras-form Adam step on grad_scale * flat[:n_params]"""
+        from . import _lib
+        _lib.check(_lib.lib.dlwp_xchg_allreduce_adam(self.xchg(flat), ctypes.c_void_p(flat.data_ptr()), int(n_params), flat.numel(),
+                                                     ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(m.data_ptr()),
+                                                     ctypes.c_void_p(v.data_ptr()), float(lr), float(beta_1), float(beta_2),
+                                                     float(epsilon), float(decay), int(iteration), float(grad_scale), self._stream(flat)))
+
+    def oneshot_timed_out(self):
+        from . import _lib
+        ent = getattr(self, '_xchg', None)
+        if ent is None:
+            return False
+        t = ctypes.c_int(0)
+        _lib.check(_lib.lib.dlwp_xchg_status(ent[0], ctypes.byref(t)))
+        return bool(t.value)
 
     # -- collectives on flat float32 device buffers ---------------------------------------------------------------------- #
     @staticmethod

@@ -167,9 +167,10 @@ class Trainer(object):
         self.flat_params, self.entries = flatten_parameters(model)
         # gradients + (behind them) the [n_out, 7] loss table of a data-parallel step: ONE buffer, ONE all-reduce
         n_par = self.flat_params.numel()
-        self._flat_exchange = torch.zeros(n_par + 7 * n_out, dtype=torch.float32, device=self.device)
+        n_x = -(-(n_par + 7 * n_out) // 4) * 4        # (whole float4: the library's own exchange moves 16-byte units)
+        self._flat_exchange = torch.zeros(n_x, dtype=torch.float32, device=self.device)
         self.flat_grads = self._flat_exchange[:n_par]
-        self._loss_tail = self._flat_exchange[n_par:].view(n_out, 7)
+        self._loss_tail = self._flat_exchange[n_par:n_par + 7 * n_out].view(n_out, 7)
         self.opt_state = None
         self.dp = getattr(model, '_dp', None)
         self._grad_bufs = {}
@@ -818,14 +819,36 @@ class Trainer(object):
         return outs, loss_vals, dys
 
     # -- optimizer ----------------------------------------------------------------------------------------------------- #
-    def _apply(self, grad_scale=1.0):
-        from . import ops
+    def _ensure_opt_state(self):
         opt = self.model.optimizer
         if self.opt_state is None:
             if isinstance(opt, Adam):
                 self.opt_state = (torch.zeros_like(self.flat_params), torch.zeros_like(self.flat_params))
             else:
                 self.opt_state = (torch.zeros_like(self.flat_params),)
+
+    def _exchange_and_apply(self, dp):
+        """The data-parallel half of a step: the flat gradient buffer (loss table in its tail) summed over the ranks, then the
+        optimizer with grad_scale 1 / world.  RCCL (or torch.distributed) + the update as two launches; with DLWP_ALLREDUCE=oneshot
+        and Adam ONE launch of the library's own exchange does both (csrc/xchg.hip)."""
+        opt = self.model.optimizer
+        if dp.wants_oneshot(self._flat_exchange):
+            self._ensure_opt_state()
+            if isinstance(opt, Adam):
+                m, v = self.opt_state
+                dp.oneshot_adam_(self._flat_exchange, self.flat_params.numel(), self.flat_params, m, v, opt.lr, opt.beta_1,
+                                 opt.beta_2, opt.epsilon, opt.decay, opt.iterations, 1.0 / dp.world)
+                opt.iterations += 1
+                return
+            dp.oneshot_all_reduce_(self._flat_exchange)
+        else:
+            dp.all_reduce_sum_(self._flat_exchange)        # gradients and loss table: one collective
+        self._apply(1.0 / dp.world)
+
+    def _apply(self, grad_scale=1.0):
+        from . import ops
+        opt = self.model.optimizer
+        self._ensure_opt_state()
         if isinstance(opt, Adam):
             m, v = self.opt_state
             ops.adam_keras(self.flat_params, m, v, self.flat_grads, opt.iterations, opt.lr, opt.beta_1, opt.beta_2,
@@ -1069,8 +1092,7 @@ class Trainer(object):
             loss_vals = self._graph_step(x, self._targets(y, n_local), n_global, scale_g, dp)
             if loss_vals is not None:
                 if dp is not None:
-                    dp.all_reduce_sum_(self._flat_exchange)
-                    self._apply(1.0 / dp.world)
+                    self._exchange_and_apply(dp)
                     loss_vals = self._loss_tail
                     ops.axpby(loss_vals.view(-1), loss_vals.view(-1), 0.0, 1.0 / dp.world)
                 if return_device:
@@ -1090,8 +1112,7 @@ class Trainer(object):
         if dp is not None:
             if loss_vals is not None:
                 ops.axpby(loss_vals.view(-1), self._loss_tail.view(-1), scale, 0.0)
-            dp.all_reduce_sum_(self._flat_exchange)        # gradients and loss table: one collective
-            self._apply(1.0 / dp.world)
+            self._exchange_and_apply(dp)
             loss_vals = self._loss_tail
             ops.axpby(loss_vals.view(-1), loss_vals.view(-1), 0.0, 1.0 / dp.world)
         else:
@@ -1238,6 +1259,8 @@ class Trainer(object):
         dp = self.dp if (self.dp is not None and self.dp.world > 1) else None
         shard = None if dp is None else (dp.rank, dp.world)
 
+        loader = [None]          # one loader for the whole call: its pinned / device staging buffers serve every epoch
+
         def batches(epoch):
             order = list(range(steps))
             if dp is not None and hasattr(generator, '_indices'):
@@ -1245,7 +1268,9 @@ class Trainer(object):
                 # replicas must cut THE SAME batch i, so every rank takes rank 0's index list for this epoch
                 generator._indices = dp.broadcast_indices(generator._indices)
             if self.device.type == 'cuda' or shard is not None:
-                for X, y, n_glob in DeviceLoader(generator, self.device, order=order, shard=shard).iter_batches():
+                if loader[0] is None:
+                    loader[0] = DeviceLoader(generator, self.device, order=order, shard=shard)
+                for X, y, n_glob in loader[0].iter_batches(order):
                     yield X, y, n_glob
             else:
                 for i in order:

@@ -586,6 +586,24 @@ int dlwp_allreduce_sum_f32(dlwp_comm_t, void* flat, size_t n, void* stream);
 int dlwp_broadcast_f32(dlwp_comm_t, void* flat, size_t n, int root, void* stream);   /* replicas start identical */
 int dlwp_comm_destroy(dlwp_comm_t);
 
+/* ---- a one-shot all-reduce of our own for the same exchange, fused with the Keras-form Adam update (csrc/xchg.hip; SURVEY 5 /
+ *      8e: the step's 756 KB buffer is latency-bound -- a ring pays 2 (W - 1) hops, this ONE).  Every rank owns a region of device
+ *      memory (header with one flag per rank + two payload buffers, step parity) that its peers map through hipIpcMemHandle (xGMI
+ *      peers of one node; on a one-GPU test box two processes of the same device).  One launch per step and rank: publish the
+ *      flat buffer, raise the flag in every peer's header, wait for the peers' flags (bounded: 2 s, then dlwp_xchg_status reports
+ *      a time-out instead of a hung GPU), read all W buffers, sum them IN RANK ORDER -- identical bits on every rank -- and update
+ *      the rank's own parameters.  n (floats, a multiple of 4) is fixed at creation.  RCCL (dlwp_comm_*) stays the default
+ *      transport; dlwp_amd/parallel.py takes this one with DLWP_ALLREDUCE=oneshot.
+ *      create (every rank) -> exchange the 64-byte handles through any host channel -> connect (world x 64 bytes, rank order).   */
+typedef struct dlwp_xchg* dlwp_xchg_t;
+int dlwp_xchg_create(dlwp_handle_t, int world, int rank, size_t n_floats, void* ipc_handle_out_64_bytes, dlwp_xchg_t* out);
+int dlwp_xchg_connect(dlwp_xchg_t, const void* handles);
+int dlwp_xchg_allreduce_sum_f32(dlwp_xchg_t, void* flat, size_t n, void* stream);
+int dlwp_xchg_allreduce_adam(dlwp_xchg_t, void* flat, size_t n_params, size_t n, void* p, void* m, void* v, float lr, float beta_1,
+                             float beta_2, float epsilon, float decay, long long iteration, float grad_scale, void* stream);
+int dlwp_xchg_status(dlwp_xchg_t, int* timed_out);
+int dlwp_xchg_destroy(dlwp_xchg_t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,7 +102,8 @@ def _worker(rank, world, port, mode, n_global, ret, extra_env=None):
     torch.cuda.synchronize()
     ret[rank] = {'w0': w0, 'w1': d.model.get_weights(), 'logs': logs, 'iters': d.model.optimizer.iterations,
                  'max_rows': max(uploaded) if uploaded else 0, 'graphs': len(tr._graphs), 'rccl_abi': tr.dp.uses_rccl_abi(),
-                 'device': torch.cuda.current_device()}
+                 'device': torch.cuda.current_device(), 'oneshot': bool(getattr(tr.dp, '_xchg', None)),
+                 'oneshot_timed_out': tr.dp.oneshot_timed_out()}
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -234,3 +235,62 @@ def test_rccl_communicator_of_the_c_abi_world_one():
         assert lib.dlwp_broadcast_f32(comm, ctypes.c_void_p(g.data_ptr()), g.numel(), 3, None) == _lib.EINVAL
     finally:
         _lib.check(lib.dlwp_comm_destroy(comm))
+
+
+@pytest.mark.parametrize('mode,n_global', [('batch6', 8), ('batch', 7), ('generator', 23)])
+def test_two_rank_training_through_the_one_shot_exchange_equals_the_single_process_run(mode, n_global):
+    """DLWP_ALLREDUCE=oneshot (csrc/xchg.hip): the step's exchange through the library's own one-shot
+    all-reduce -- each rank publishes its flat gradient buffer in memory the peer has mapped through hipIpcMemHandle (here: two
+    processes of the one GPU), raises a flag, reads both buffers, sums them in rank order and applies the Keras-form Adam update in
+    the same kernel.  The replicas stay bit-identical (same order of the sum on every rank) and follow the single-process run to
+    float32 round-off; ragged shards (7 = 4 + 3, batches of 23) included; no wait timed out."""
+    res = _run_group(mode, n_global, extra_env={'DLWP_ALLREDUCE': 'oneshot'})
+    assert res[0]['oneshot'] and res[1]['oneshot'], 'the one-shot exchange was not taken'
+    assert not res[0]['oneshot_timed_out'] and not res[1]['oneshot_timed_out']
+    _check_against_single_process(res, mode, n_global)
+
+
+def _xchg_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DLWP_SHARE_GPUS='1', DLWP_DIST_BACKEND='gloo', DLWP_ALLREDUCE='oneshot')
+    from dlwp_amd import parallel
+    parallel.init()
+    dp = parallel.DataParallel()
+    n = 189024                                            # the config-2 U-Net's exchange: 188 996 parameters + 7 loss values, padded
+    outs = []
+    for step in range(5):                                  # both payload parities, flags that keep counting
+        g = torch.Generator().manual_seed(100 * step + rank)
+        flat = torch.randn(n, generator=g).cuda()
+        dp.oneshot_all_reduce_(flat)
+        outs.append(flat.cpu().numpy())
+    torch.cuda.synchronize()
+    ret[rank] = {'outs': outs, 'timed_out': dp.oneshot_timed_out()}
+    torch.distributed.barrier()
+    dp.close()
+    torch.distributed.destroy_process_group()
+
+
+def test_one_shot_all_reduce_sums_in_rank_order_on_every_rank():
+    """dlwp_xchg_allreduce_sum_f32 alone, five exchanges of the config-2 buffer between two processes: every rank ends with
+    rank 0's values + rank 1's, the same bits on both"""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_xchg_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            if p.is_alive():
+                p.kill()
+                pytest.fail('one-shot exchange worker timed out')
+            assert p.exitcode == 0
+        res = dict(ret)
+    assert not res[0]['timed_out'] and not res[1]['timed_out']
+    for step in range(5):
+        want = (torch.randn(189024, generator=torch.Generator().manual_seed(100 * step)) +
+                torch.randn(189024, generator=torch.Generator().manual_seed(100 * step + 1))).numpy()
+        assert np.array_equal(res[0]['outs'][step], res[1]['outs'][step])
+        assert np.array_equal(res[0]['outs'][step], want)

@@ -165,7 +165,9 @@ def test_device_loader_rank_shards_partition_every_global_batch():
                     for X, y, n in DeviceLoader(gen, torch.device('cpu'), shard=(rank, world)).iter_batches()]
             gen.generate = orig
             parts.append(rows)
-        assert max(gathered) <= -(-8 // world)          # no rank ever gathered more than its share of a batch
+        # no rank ever gathered more than its share of a batch (float32 row gathers go to the library's host threads and never
+        # call generate(): the rows they copied are checked below)
+        assert all(g <= -(-8 // world) for g in gathered)
         del gathered[:]
         for i in range(len(gen)):
             Xf, yf = gen[i]

@@ -9,20 +9,25 @@ DLWP_LOADER_PULL=$pull DLWP_TRAIN_STEP=graph rocprofv3 --kernel-trace --memory-c
 python - <<PY > $O/$TAG.timeline.txt
 import csv, glob
 rows=list(csv.DictReader(open('$O/$TAG/s_kernel_trace.csv')))
+print('kernel trace columns', list(rows[0].keys()) if rows else None, len(rows))
 cp=[]
 for f in glob.glob('$O/$TAG/*memory_copy_trace.csv'):
     cp+=list(csv.DictReader(open(f)))
-ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),'q'+r.get('Queue_Id','?'),r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','')[:60]) for r in rows]
-ev+=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),'copy',r.get('Direction','')+' '+r.get('Bytes','')) for r in cp]
+print('copy trace columns', list(cp[0].keys()) if cp else None, len(cp))
+def ts(r,k):
+    return int(r[k])
+ev=[(ts(r,'Start_Timestamp'),ts(r,'End_Timestamp'),'q'+str(r.get('Queue_Id','?')),r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ','')[:60]) for r in rows]
+ev+=[(ts(r,'Start_Timestamp'),ts(r,'End_Timestamp'),'copy',str(r.get('Direction',''))+' '+str(r.get('Bytes',r.get('Size','')))) for r in cp]
 ev.sort()
-# window: the middle of the SECOND fit_generator (timed) -- take events from 55% to 55%+8ms of the span
-t0=ev[0][0]; t1=ev[-1][1]
-w0=t0+int(0.55*(t1-t0)); w1=w0+6000000
-print('$TAG window of 6 ms')
-for s,e,q,n in ev:
-    if s>=w0 and s<=w1:
+# the timed fit_generator: find the gather / copy_many kernels and print 3 consecutive steps around the 70th percentile
+marks=[i for i,e in enumerate(ev) if 'copy_many' in e[3]]
+print('events', len(ev), 'copy_many marks', len(marks))
+if len(marks) > 12:
+    a=marks[int(0.3*len(marks))]; b=marks[int(0.3*len(marks))+3]
+    w0=ev[a][0]
+    for s,e,q,n in ev[a:b+1]:
         print('%9.1f %9.1f %7.1f  %-5s %s'%((s-w0)/1e3,(e-w0)/1e3,(e-s)/1e3,q,n))
 PY
-head -150 $O/$TAG.timeline.txt
+head -200 $O/$TAG.timeline.txt | cut -c1-120
 rm -rf $O/$TAG
 done
