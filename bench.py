@@ -650,7 +650,7 @@ def sub_train(grid, cin, world, rank, barrier, dev, per_gpu_batch=64, steps=20, 
     return rec
 
 
-def sub_train_loader_fed(grid, cin, dev, batches=(64, 8), samples_per_batch=40, epochs=3):
+def sub_train_loader_fed(grid, cin, dev, batches=(64, 8), samples=2560, epochs=3):
     """BASELINE config 3 the way the reference drives it: fit_generator(DataGenerator(batch, shuffle=True), ...)
     (examples/train.py:262-263, DLWP/model/models.py:216-228) over a host-resident float32 training set -- every step's rows cross
     the link (H2D included), against the same step on device-resident tensors.  Single rank."""
@@ -660,7 +660,7 @@ def sub_train_loader_fed(grid, cin, dev, batches=(64, 8), samples_per_batch=40, 
         d = build_model(grid, cin, lr=1e-4)
         tr = d.model._trainer
         rng = np.random.default_rng(0)
-        n = b * samples_per_batch
+        n = samples - samples % b          # the same training set for every batch size: 40 steps per epoch at 64, 320 at 8
         P = rng.standard_normal((n, 2, cin // 2) + tuple(grid), dtype=np.float32)
         T = rng.standard_normal((n, 2, cin // 2) + tuple(grid), dtype=np.float32)
         gen = DataGenerator(d, ArrayDataset(P, T), batch_size=b, shuffle=True)

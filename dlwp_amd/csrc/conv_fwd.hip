@@ -805,10 +805,15 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
                          !wino_skips_row2(a) && !a.in_bf16 && lp.pair_vw == 0;      // conv_fwd_wino_kernel.h: POOL2
     if (!(direct_ok || wino_ok) || lp.narrow >= 0)
       DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd_pool2: this layer's kernel cannot store both tensors");
+    if (u_pre) {   // prepared for the layer's PLAIN descriptor (dlwp_conv2d_prepare): must be the form this instance reads
+      const ConvKernelEntry* ep = entry_for(h, xs, cd_in, dtype);
+      if (!ep || is_wino(*ep) != is_wino(e) || is_bf16(*ep) != is_bf16(e) || (ep->pack > 0 ? ep->pack : 0) != (e.pack > 0 ? e.pack : 0))
+        DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd_pool2: the prepared weights were built for another kernel family");
+    }
     a.out_pool = 0;                 // (a.Hp / a.Wp stay: the pooled tensor's shape)
     a.y2 = (float*)y_pool;
   }
-  if (!lstm && !act_epi && !y_pool) {
+  if (!lstm && !act_epi) {      // (r4: the streaming kernel also stores the unpooled tensor, alone or beside the pooled one)
     const int fg = few_stream_grid(h, a, cd, lp);
     if (fg > 0) {
       a.tiles_h = dlwp_ceil_div(a.Ho, 8);

@@ -55,8 +55,13 @@ struct FewCfg {
 // of one XCD are contiguous.  With `group` ~ a share's length a workgroup walks about one position over one sample group, and
 // the workgroups next to it walk the neighbouring positions over the SAME samples at the same pace: the halo re-reads and the
 // two 64-byte halves of an output line meet in that XCD's L2.
-template <int DIL, int ACT, bool QUAD>
-__global__ __launch_bounds__(256, 4) void conv2d_fwd_few_f32(const ConvArgs a, const int group) {
+// OUT (r4): 0 = the MaxPooling2D(2) image only (the inference plan's first layer); 1 = the layer's own output, unpooled (a first
+// layer without pooling behind it: the 91 x 180 sub-record); 2 = both -- the training forward's dlwp_conv2d_fwd_pool2: the activated
+// tensor for the backward pass AND its pooled image for the next layer.  The unpooled values leave as they sit in the accumulators:
+// fragment i of channel tile g = 4 consecutive pixels of one row and channel -> one 16-byte store, its row / quad offset a SCALAR;
+// the stores of item k go out behind its matrix loop and drain under item k + 1's (a general-instance workgroup ends on them).
+template <int DIL, int ACT, bool QUAD, int OUT>
+__global__ __launch_bounds__(256, OUT == 0 ? 4 : 3) void conv2d_fwd_few_f32(const ConvArgs a, const int group) {
   using C = FewCfg<DIL, QUAD>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -100,11 +105,16 @@ __global__ __launch_bounds__(256, 4) void conv2d_fwd_few_f32(const ConvArgs a, c
   const long long x_sample = (long long)a.in_c_total * plane_bytes;
   const long long y_sample = (long long)a.out_c_total * oplane_bytes;
   const char* x0 = (const char*)a.x + (long long)a.in_c_off * plane_bytes;
-  char* y0 = (char*)a.y + (long long)a.out_c_off * oplane_bytes;
+  char* y0 = (char*)(OUT == 2 ? a.y2 : a.y) + (long long)a.out_c_off * oplane_bytes;             // the pooled tensor
+  const unsigned uplane_bytes = (unsigned)(a.Ho * a.Wo) * 4u;
+  const long long u_sample = (long long)a.out_c_total * uplane_bytes;
+  char* u0 = (char*)a.y + (long long)a.out_c_off * uplane_bytes;                                  // the unpooled tensor (OUT != 0)
 
   // ---- per-position state
   unsigned goff[C::NQ];          // byte offset of this lane's tile positions in a channel plane (0x7ffffff0: reads 0.0)
   unsigned voff[2];              // byte offset of this lane's FOUR pooled pixels, channel tile g (0x7ffffff0: dropped)
+  unsigned uoff[2][2];           // OUT != 0: byte offset of fragment 0's pixel quad in tile row 2 wave + r, channel tile g
+  bool q1_ok = true;             // ... and is the quad 4 columns to its right (the odd fragments') inside the map?
   bool wide = true;              // (uniform) the tile's 16 pooled columns are all inside the map: one 16-byte store per lane and g
   int pc0 = 0;                   // this lane's first pooled column
   float bw[9][2];                // B operands: w[tap][ci = lane >> 4][co = n0 + 16 g + (lane & 15)]
@@ -146,6 +156,15 @@ __global__ __launch_bounds__(256, 4) void conv2d_fwd_few_f32(const ConvArgs a, c
         bv[g] = (a.bias && c_ok) ? a.bias[cc] : 0.f;
       }
       voff[g] = (c_ok && pr < a.Hp && pc0 < a.Wp) ? (unsigned)((co * a.Hp + pr) * a.Wp + pc0) * 4u : 0x7ffffff0u;
+      if constexpr (OUT != 0) {
+        const int uc = tw * C::TW + 8 * (lane >> 4);           // (+ 4 for the odd fragments: a scalar offset at the store)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int ur = th * C::TH + 2 * wave + r;
+          uoff[g][r] = (c_ok && ur < a.Ho && uc < a.Wo) ? (unsigned)((co * a.Ho + ur) * a.Wo + uc) * 4u : 0x7ffffff0u;
+        }
+        q1_ok = uc + 4 < a.Wo;                                  // (Wo is a multiple of 4: quads are in or out as a whole)
+      }
     }
     ct_loaded = ct;
   };
@@ -253,7 +272,23 @@ __global__ __launch_bounds__(256, 4) void conv2d_fwd_few_f32(const ConvArgs a, c
 
       // ---- epilogue: fragments i and i + 2 hold the same columns of tile rows 2 wave and 2 wave + 1, registers (0, 1) and
       //      (2, 3) are horizontal neighbours: the 2x2 windows live in this lane.  Bias and activation after the maximum.
-      {
+      if constexpr (OUT != 0) {   // the layer's own output: act(raw + bias), 4 consecutive pixels of a row per fragment
+        const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(u0 + (long long)(g0 + sn) * u_sample), 0, (unsigned)a.Cout * uplane_bytes, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const f32x2 bb = (f32x2){bv[g], bv[g]};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x2 lo = act_apply2_c<((DLWP_KNOCK_FEW & 2) ? 0 : ACT)>(acc[i][g].xy + bb);
+            const f32x2 hi = act_apply2_c<((DLWP_KNOCK_FEW & 2) ? 0 : ACT)>(acc[i][g].zw + bb);
+            // (odd fragments: the quad 4 columns to the right -- a map narrower than that quad's end drops it through the offset)
+            const unsigned vo = (i & 1) ? ((uoff[g][i >> 1] != 0x7ffffff0u && q1_ok) ? uoff[g][i >> 1] + 16u : 0x7ffffff0u) : uoff[g][i >> 1];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3)), u_rsrc, vo, 0, 0);
+          }
+        }
+      }
+      if constexpr (OUT != 1) {
         const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(y0 + (long long)(g0 + sn) * y_sample), 0, (unsigned)a.Cout * oplane_bytes, 0x00020000);
 #pragma unroll
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_fwd_few_f32(const ConvArgs a, c
 int g_few_group_override = 0;
 #endif
 
-template <int DIL, bool QUAD>
+template <int DIL, bool QUAD, int OUT>
 void launch_few(const ConvArgs& a, int grid, hipStream_t s) {
   using C = FewCfg<DIL, QUAD>;
   // samples per group = the length of a workgroup's share: workgroup j then walks (about) one position over one sample group
@@ -326,20 +361,25 @@ void launch_few(const ConvArgs& a, int grid, hipStream_t s) {
   if (g_few_group_override > 0) group = g_few_group_override;   // (tools/microbench/few_phase_timing.hip sweeps it)
 #endif
   if (a.act == DLWP_ACT_TANH)
-    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_TANH, QUAD>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
+    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_TANH, QUAD, OUT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
   else if (a.act == DLWP_ACT_RELU)
-    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_RELU, QUAD>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
+    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_RELU, QUAD, OUT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
   else
-    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_LINEAR, QUAD>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
+    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_LINEAR, QUAD, OUT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
 }
 
 }  // namespace
 
 // Host logic only: does the streaming kernel cover this launch?  (a.tiles_* need not be set.)
+// Output modes: the pooling epilogue (a.out_pool == 1), the layer's own output (a.out_pool == 0: whole pixel quads, i.e. a width
+// that is a multiple of 4), or both (a.y2 = the pooled tensor beside a.y: dlwp_conv2d_fwd_pool2).
 bool dlwp_conv_few_covers(const ConvArgs& a, int ks, int dil_h, int dil_w) {
+  const bool pooled = a.out_pool == 1 || a.y2 != nullptr;           // a pooled tensor is written
+  const bool plain = a.out_pool == 0;                               // the unpooled tensor is written
   return ks == 3 && dil_h == dil_w && (dil_h == 1 || dil_h == 2) && a.Cin >= 1 && a.Cin <= 4 && a.src_mode == DLWP_SRC_DIRECT &&
-         !a.in_bf16 && !a.out_bf16 && !a.compute_bf16 && a.out_pool == 1 && !a.out_d2s && !a.lstm_f && !a.y2 && !a.yact &&
-         a.Wp % 2 == 0 && a.Hp * 2 <= a.Ho && a.Wp * 2 <= a.Wo &&
+         !a.in_bf16 && !a.out_bf16 && !a.compute_bf16 && (a.out_pool == 0 || a.out_pool == 1) && !a.out_d2s && !a.lstm_f && !a.yact &&
+         (!pooled || (a.Wp % 2 == 0 && a.Hp * 2 <= a.Ho && a.Wp * 2 <= a.Wo)) && (!plain || a.Wo % 4 == 0) &&
+         (long long)a.Ho * a.Wo * a.Cout < (1ll << 28) &&
          // byte offsets inside a sample stay 32-bit, the item count an int
          (long long)a.Hs * a.Ws * a.Cin < (1ll << 28) && (long long)a.Hp * a.Wp * a.Cout < (1ll << 28) &&
          (long long)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 32) * a.N < (1ll << 30);
@@ -351,6 +391,14 @@ void dlwp_conv_few_launch(const ConvArgs& a, int dil, int grid, hipStream_t s) {
   const bool quad = a.W % 4 == 0 && a.Ws == a.W && ((long long)a.Hs * a.Ws) % 4 == 0 && ((long long)a.in_c_off * a.Hs * a.Ws) % 4 == 0 &&
                     ((size_t)a.x & 15) == 0 && a.pad_left >= 0 && a.pad_left <= 4 &&
                     (a.mode_w == DLWP_PAD_ZERO || a.mode_w == DLWP_PAD_WRAP);
-  if (dil == 1) quad ? launch_few<1, true>(a, grid, s) : launch_few<1, false>(a, grid, s);
-  else quad ? launch_few<2, true>(a, grid, s) : launch_few<2, false>(a, grid, s);
+  const int out = a.out_pool == 1 ? 0 : (a.y2 ? 2 : 1);
+  auto go = [&](auto dil_c, auto quad_c) {
+    constexpr int D = decltype(dil_c)::value;
+    constexpr bool Q = decltype(quad_c)::value;
+    if (out == 0) launch_few<D, Q, 0>(a, grid, s);
+    else if (out == 1) launch_few<D, Q, 1>(a, grid, s);
+    else launch_few<D, Q, 2>(a, grid, s);
+  };
+  if (dil == 1) quad ? go(std::integral_constant<int, 1>{}, std::true_type{}) : go(std::integral_constant<int, 1>{}, std::false_type{});
+  else quad ? go(std::integral_constant<int, 2>{}, std::true_type{}) : go(std::integral_constant<int, 2>{}, std::false_type{});
 }

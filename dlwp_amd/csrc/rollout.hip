@@ -202,7 +202,10 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
   // split-K launches on small grids (conv_fwd.hip: plan_splitk): one region of counters + slabs per member chain -- a chain's
   // launch site owns its counters.  UNCACHED device memory (the exchange crosses XCDs), so the library allocates it itself: the
   // one allocation of a rollout, small grids only (<= 32 MB per chain), freed by dlwp_rollout_destroy.
-  const size_t k_region = splitk_region_bytes(h, plan, n_ops, gn);
+  // ONE chain only: graphs with forked member chains never hold split launches.  (r4: the full GPU suite died in hipGraphLaunch of
+  // the grouped-rollout test in 3 of 11 runs with split kernels inside the branches, in 0 of 6 without -- a host-side fault inside
+  // the runtime; member chains are for grids that fill the chip anyway, where nothing splits.)
+  const size_t k_region = groups == 1 ? splitk_region_bytes(h, plan, n_ops, gn) : 0;
   char* k_base = nullptr;
   if (k_region > 0) {
     if (hipExtMallocWithFlags((void**)&k_base, (size_t)groups * k_region, hipDeviceMallocUncached) != hipSuccess ||

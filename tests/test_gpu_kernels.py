@@ -294,9 +294,51 @@ def test_few_channel_streaming_kernel_equals_the_general_instance(ops, dil):
     assert float(outs[1][:, :8].min()) == 7.0 and float(outs[1][:, 40:].max()) == 7.0
 
 
+@pytest.mark.parametrize('dil', [1, 2])
+def test_few_channel_streaming_kernel_unpooled_and_both_outputs(ops, dil):
+    """r4: the streaming kernel also stores the layer's own output -- alone (a first layer without pooling: the
+    91 x 180 sub-record) or beside its MaxPooling2D(2) image (the training forward, dlwp_conv2d_fwd_pool2).  The bits of the
+    general instance in both modes; odd heights (91 rows), ragged channel tiles, every activation, widths that cut the last tile."""
+    rng = np.random.default_rng(500 + dil)
+    p = dil
+    cases = [  # n, cin, h, w, cout, mode_h, mode_w, act
+        (40, 4, 91, 180, 32, 0, 1, 'tanh'),
+        (70, 3, 18, 76, 40, 2, 1, 'relu'),
+        (300, 1, 10, 36, 16, 1, 0, 'linear'),
+        (90, 4, 24, 72, 32, 0, 1, 'tanh'),
+    ]
+    for n, cin, h, w, cout, mh, mw, act in cases:
+        x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+        wt = dev(np_ref.glorot_uniform((3, 3, cin, cout), rng))
+        b = dev((0.1 * rng.standard_normal(cout)).astype(np.float32))
+        cd = ops.make_conv(cout, 3, 3, dil, ops.make_pad(p, p, p, p, mh, mw), ops.ACTIVATIONS[act])
+        res = {}
+        prev = ops.set_few_stream(0)
+        try:
+            for mode in (0, 2):
+                ops.set_few_stream(mode)
+                info = ops.conv_launch_info(tuple(x.shape), cd)
+                assert (info[0][0] == -2) == (mode == 2), (mode, info)
+                y = ops.conv2d(x, wt, b, cd).clone()
+                y2 = torch.full((n, cout, h, w), 7.0, device='cuda')
+                pl = torch.full((n, cout, h // 2, w // 2), 7.0, device='cuda')
+                both = ops.conv2d(x, wt, b, cd, out=y2, out_pool2=pl)
+                res[mode] = (y, y2, pl, both is not None)
+        finally:
+            ops.set_few_stream(prev)
+        assert torch.equal(res[0][0], res[2][0]), ('unpooled', n, cin, h, w, cout)
+        assert res[0][3] and res[2][3]
+        assert torch.equal(res[0][1], res[2][1]) and torch.equal(res[0][2], res[2][2]), ('both outputs', n, cin, h, w, cout)
+        assert torch.equal(res[2][1], res[2][0]) and torch.equal(res[2][2], ops.maxpool2(res[2][0]))
+        if n <= 40:
+            want = _conv_ref(host(x)[:2], host(wt), host(b), dil, (p, p, p, p), mh, mw, act, 0)
+            _check_conv(ops, host(res[2][0])[:2], want, 'streaming kernel, unpooled')
+
+
 def test_few_channel_streaming_kernel_is_chosen_by_batch_size(ops):
     """DLWP_OPT_FEW_STREAM = 1 (default): layer 1 of the 88 x 180 U-Net goes to the streaming kernel from 2.5 tiles per resident
-    workgroup on (3 per CU), the general instance below; never for an unpooled launch, more than four input channels or 5x5."""
+    workgroup on (3 per CU), the general instance below -- with the pooling epilogue and (r4) for the unpooled output of a width that
+    is a multiple of 4; never for more than four input channels, 5x5, or an unpooled width that cuts a pixel quad."""
     cd = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH, out_pool=True)
     assert ops.conv_launch_info((256, 4, 88, 180), cd)[0][0] == -2
     g = ops.conv_launch_info((256, 4, 88, 180), cd)[0]
@@ -306,7 +348,10 @@ def test_few_channel_streaming_kernel_is_chosen_by_batch_size(ops):
     assert ops.conv_launch_info((1, 4, 88, 180), cd)[0][0] >= 0
     assert ops.conv_launch_info((256, 5, 88, 180), cd)[0][0] >= 0
     plain = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH)
-    assert ops.conv_launch_info((256, 4, 88, 180), plain)[0][0] >= 0
+    assert ops.conv_launch_info((256, 4, 88, 180), plain)[0][0] == -2
+    assert ops.conv_launch_info((256, 4, 91, 180), plain)[0][0] == -2
+    assert ops.conv_launch_info((256, 4, 88, 178), plain)[0][0] >= 0          # 178 columns: the last quad is cut
+    assert ops.conv_launch_info((8, 4, 88, 180), plain)[0][0] >= 0
     five = ops.make_conv(32, 5, 5, 1, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH, out_pool=True)
     assert ops.conv_launch_info((256, 4, 88, 180), five)[0][0] != -2
     prev = ops.set_few_stream(0)
