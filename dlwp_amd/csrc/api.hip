@@ -91,6 +91,7 @@ int dlwp_create(dlwp_handle_t* out, int device) {
   h->wino_u = nullptr;
   h->wino_u_floats = 0;
   h->prep_defer = h->n_prep = h->red_defer = h->n_red = 0;
+  h->prep_owner = h->red_owner = 0;
   h->ksplit_mem = nullptr;
   h->ksplit_used = 0;
   for (int i = 0; i < DLWP_SPLITK_REGIONS; ++i) h->ksplit_stream[i] = nullptr;

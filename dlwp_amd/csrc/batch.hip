@@ -11,6 +11,7 @@
 // Reference: the Keras train step behind DLWPNeuralNet.fit / fit_generator (DLWP/model/models.py:188-228); Keras / TF
 // launch one kernel per op and have no counterpart of this file.
 #include "common.h"
+#include <atomic>
 #include "tape.h"
 
 namespace {
@@ -174,6 +175,15 @@ int launch_red(dlwp_handle_t h, hipStream_t s) {
 
 }  // namespace
 
+// The deferring modes belong to the THREAD that opened them: ctypes releases the GIL during a call, so another
+// thread working on the same handle must neither see its own final sums swallowed by the trainer's table nor race on the counts.
+// A thread that is not the owner runs its work at once, through a table of its own.
+static int this_thread_id() {
+  static std::atomic<int> next{1};
+  static thread_local int id = next.fetch_add(1);
+  return id;
+}
+
 // Record (batch mode) or run now: one preparation of weights.  blocks is set here.
 int dlwp_prep_push(dlwp_handle_t h, dlwp_prep_job j, hipStream_t s) {
   long long items;
@@ -184,30 +194,35 @@ int dlwp_prep_push(dlwp_handle_t h, dlwp_prep_job j, hipStream_t s) {
   if (blocks < 1) blocks = 1;
   if (blocks > 512) blocks = 512;
   j.blocks = (int)blocks;
-  if (h->n_prep == DLWP_MAX_BATCH_JOBS) {
-    const int rc = launch_prep(h, s);
-    if (rc != DLWP_OK) return rc;
+  if (!(h->prep_defer && h->prep_owner == this_thread_id())) {      // not deferring (for this thread): one job, now
+    PrepTable T;
+    T.n = 1;
+    T.j[0] = j;
+    T.first[0] = 0;
+    T.first[1] = j.blocks;
+    prep_jobs_kernel<<<j.blocks, 256, 0, s>>>(T);
+    DLWP_LAUNCH_CHECK("prep_jobs_kernel");
+    return DLWP_OK;
   }
+  if (h->n_prep == DLWP_MAX_BATCH_JOBS)
+    DLWP_FAIL(DLWP_EINVAL, "more than %d weight preparations between dlwp_prepare_begin and _flush", DLWP_MAX_BATCH_JOBS);
   h->prep[h->n_prep++] = j;
-  return h->prep_defer ? DLWP_OK : launch_prep(h, s);
+  return DLWP_OK;
 }
 
 // Record (between dlwp_reductions_begin / _flush) the final sum of partial results.  Returns 1 when recorded, 0 when the
 // handle is not deferring (the caller then runs its own final kernel), < 0 on error.
 int dlwp_reduce_defer(dlwp_handle_t h, const float* src, float* dst, long long n, int S, long long es, long long ss,
                       float scale, int accumulate, hipStream_t s) {
-  if (!h->red_defer) return 0;
-  // one target per flush: an accumulating job must not run beside the job that first writes the same tensor
+  if (!h->red_defer || h->red_owner != this_thread_id()) return 0;
+  // one target per flush (an accumulating job must not run beside the job that first writes the same tensor) and at most
+  // DLWP_MAX_BATCH_JOBS sums: an early flush would run on whichever stream is calling -- possibly a side stream -- without joining
+  // the others, so both are errors; the trainer folds only plans inside these bounds (Trainer._fold_ok)
   for (int k = 0; k < h->n_red; ++k)
-    if (h->red[k].dst == dst) {
-      const int rc = launch_red(h, s);
-      if (rc != DLWP_OK) return rc;
-      break;
-    }
-  if (h->n_red == DLWP_MAX_BATCH_JOBS) {
-    const int rc = launch_red(h, s);
-    if (rc != DLWP_OK) return rc;
-  }
+    if (h->red[k].dst == dst)
+      DLWP_FAIL(DLWP_EINVAL, "two deferred sums into one tensor between dlwp_reductions_begin and _flush");
+  if (h->n_red == DLWP_MAX_BATCH_JOBS)
+    DLWP_FAIL(DLWP_EINVAL, "more than %d deferred sums between dlwp_reductions_begin and _flush", DLWP_MAX_BATCH_JOBS);
   dlwp_red_job j;
   j.src = src;
   j.dst = dst;
@@ -282,6 +297,7 @@ int dlwp_prepare_begin(dlwp_handle_t h) {
   DLWP_TAPE_HOST(h, dlwp_prepare_begin, h);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_prepare_begin: null handle");
   h->prep_defer = 1;
+  h->prep_owner = this_thread_id();
   h->n_prep = 0;
   return DLWP_OK;
 }
@@ -297,6 +313,7 @@ int dlwp_reductions_begin(dlwp_handle_t h) {
   DLWP_TAPE_HOST(h, dlwp_reductions_begin, h);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_reductions_begin: null handle");
   h->red_defer = 1;
+  h->red_owner = this_thread_id();
   h->n_red = 0;
   return DLWP_OK;
 }

@@ -59,6 +59,7 @@ struct dlwp_handle {
   size_t wino_u_floats;
   int prep_defer, n_prep;      // dlwp_prepare_begin / _flush
   int red_defer, n_red;        // dlwp_reductions_begin / _flush
+  int prep_owner, red_owner;   // the thread that opened the mode (batch.hip): other threads never defer
   dlwp_prep_job prep[DLWP_MAX_BATCH_JOBS];
   dlwp_red_job red[DLWP_MAX_BATCH_JOBS];
   // split-K workspaces of eager launches (conv_fwd.hip: dlwp_splitk_region): one region per stream that has launched a split

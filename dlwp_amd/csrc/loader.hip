@@ -59,6 +59,17 @@ int dlwp_host_unregister(void* ptr) {
   return DLWP_OK;
 }
 
+// rows x width bytes, device -> page-locked host, as ONE strided DMA: dst row r at dst + r * dst_pitch (the member chunk of a
+// (T, N, ...) series in a pinned result array), src contiguous (pitch = width).  hipMemcpy2DAsync on the runtime this library is
+// linked against -- the one torch loaded (never a second copy of libamdhip64 found by bare name).
+int dlwp_copy2d_d2h_async(void* dst, size_t dst_pitch, const void* src, size_t width, size_t rows, void* stream) {
+  DLWP_CHECK_ARG((dst && src) || rows == 0, "dlwp_copy2d_d2h_async: null pointer");
+  DLWP_CHECK_ARG(dst_pitch >= width, "dlwp_copy2d_d2h_async: rows of %zu bytes at a pitch of %zu", width, dst_pitch);
+  if (rows == 0 || width == 0) return DLWP_OK;
+  DLWP_HIP(hipMemcpy2DAsync(dst, dst_pitch, src, width, width, rows, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return DLWP_OK;
+}
+
 // dst[i] = src[rows[i]], rows of row_bytes bytes (a multiple of 16): dst in HBM, src the DEVICE address of registered host memory
 // (or any device-readable memory), rows on the host (they travel as kernel arguments, 255 per launch)
 int dlwp_gather_rows_h2d(dlwp_handle_t h, void* dst, const void* src, const long long* rows, long long n_rows, size_t row_bytes,

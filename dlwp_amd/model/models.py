@@ -107,32 +107,34 @@ class _Wrapper(object):
                 ev.record(up_stream)
             stage_ev[k % 2] = ev
             return t, ev
-        nxt = upload(0) if on_host else None
-        for k, (lo, hi) in enumerate(bounds):
-            if on_host:
-                xc, ev = nxt
-                torch.cuda.current_stream(net.device).wait_event(ev)
-                xc.record_stream(torch.cuda.current_stream(net.device))
-            else:
-                xc = predictors[lo:hi]
-            out = self._rollout_chunk(xc, calls, keep_time_dim, fresh=True)
-            if on_host and k + 1 < len(bounds):
-                nxt = upload(k + 1)                         # host copy + DMA under this chunk's kernels
-            if host is None:         # page-locked, recycled once the caller lets the previous result go (util._PinnedPool)
-                host = util.pinned_results.take((out.shape[0], n) + tuple(out.shape[2:]))
-            done = torch.cuda.Event()
-            done.record()
-            copy_stream.wait_event(done)
-            with torch.cuda.stream(copy_stream):
-                # the chunk's (T, members, ...) block -> rows lo:hi of every time slot: one strided DMA (row-by-row otherwise)
-                if not (host.is_pinned() and util.copy2d_d2h_async(host[:, lo:hi], out, copy_stream)):
-                    for t in range(out.shape[0]):
-                        host[t, lo:hi].copy_(out[t], non_blocking=True)
-            out.record_stream(copy_stream)
-        copy_stream.synchronize()
-        if stage is not None:
-            for buf in stage:
-                util.pinned_results._give_back(buf.view(-1))
+        try:
+          nxt = upload(0) if on_host else None
+          for k, (lo, hi) in enumerate(bounds):
+              if on_host:
+                  xc, ev = nxt
+                  torch.cuda.current_stream(net.device).wait_event(ev)
+                  xc.record_stream(torch.cuda.current_stream(net.device))
+              else:
+                  xc = predictors[lo:hi]
+              out = self._rollout_chunk(xc, calls, keep_time_dim, fresh=True)
+              if on_host and k + 1 < len(bounds):
+                  nxt = upload(k + 1)                         # host copy + DMA under this chunk's kernels
+              if host is None:         # page-locked, recycled once the caller lets the previous result go (util._PinnedPool)
+                  host = util.pinned_results.take((out.shape[0], n) + tuple(out.shape[2:]))
+              done = torch.cuda.Event()
+              done.record()
+              copy_stream.wait_event(done)
+              with torch.cuda.stream(copy_stream):
+                  # the chunk's (T, members, ...) block -> rows lo:hi of every time slot: one strided DMA (row-by-row otherwise)
+                  if not (host.is_pinned() and util.copy2d_d2h_async(host[:, lo:hi], out, copy_stream)):
+                      for t in range(out.shape[0]):
+                          host[t, lo:hi].copy_(out[t], non_blocking=True)
+              out.record_stream(copy_stream)
+          copy_stream.synchronize()
+        finally:
+            if stage is not None:          # (also when a chunk fails: the staging buffers go back to the pool)
+                for buf in stage:
+                    util.pinned_results._give_back(buf.view(-1))
         return util.pinned_results.lend(host)
 
 

@@ -143,7 +143,8 @@ class _PinnedPool(object):
     costs about as much as a quarter of the rollout.  The array handed out is a numpy view of a pinned torch tensor through a
     ctypes buffer object that every view of it keeps alive; when the LAST view dies the tensor returns to the pool (a weakref
     finaliser), so a buffer is never reused while the caller can still see it."""
-    limit_bytes = 8 << 30
+    #: page-locked bytes the pool keeps at most (DLWP_PINNED_POOL_MB; trim() releases them): two 256-member 14-day series
+    limit_bytes = int(__import__('os').environ.get('DLWP_PINNED_POOL_MB', '4096')) << 20
     per_size = 2
 
     def __init__(self):
@@ -164,8 +165,16 @@ class _PinnedPool(object):
         except RuntimeError:
             return torch.empty(shape, dtype=torch.float32)
 
+    def trim(self):
+        """release every pooled buffer (their page-locked memory returns to the system)"""
+        with self._lock:
+            self._free.clear()
+            self._bytes = 0
+
     def _give_back(self, flat):
         n = flat.numel()
+        if not flat.is_pinned():          # (take() fell back to pageable memory: nothing worth keeping, and never to be handed
+            return                        #  out as a pinned buffer later -- ADVICE r3)
         with self._lock:
             lst = self._free.setdefault(n, [])
             if len(lst) < self.per_size and self._bytes + 4 * n <= self.limit_bytes:
@@ -186,37 +195,22 @@ class _PinnedPool(object):
 
 pinned_results = _PinnedPool()
 
-_hip_rt = [None]
-
-
 def copy2d_d2h_async(dst_host, src_dev, stream):
-    """dst_host[t, ...] <- src_dev[t, ...] for every leading index t as ONE strided device-to-host DMA (hipMemcpy2DAsync on the HIP
-    runtime torch already loaded): dst_host is a slice of a pinned array whose rows are further apart than they are long -- a
-    member chunk of a (T, N, ...) series -- src_dev is contiguous.  One descriptor list for the copy engine instead of T separate
-    copies (56 x 8 MB per chunk of a 14-day rollout: 37 GB/s effective; one strided copy runs at the link rate).  Returns False
-    when the runtime entry point is not available (the caller then copies row by row)."""
+    """dst_host[t, ...] <- src_dev[t, ...] for every leading index t as ONE strided device-to-host DMA (dlwp_copy2d_d2h_async:
+    hipMemcpy2DAsync on the runtime the library -- and torch -- are linked against): dst_host is a slice of a pinned array whose
+    rows are further apart than they are long -- a member chunk of a (T, N, ...) series -- src_dev is contiguous.  One descriptor
+    list for the copy engine instead of T separate copies (56 x 8 MB per chunk of a 14-day rollout: 37 GB/s effective; one strided
+    copy runs at the link rate).  Returns False when the shapes do not fit (the caller then copies row by row)."""
     import ctypes
-    if _hip_rt[0] is None:
-        try:
-            lib = ctypes.CDLL('libamdhip64.so')
-            fn = lib.hipMemcpy2DAsync
-            fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
-                           ctypes.c_int, ctypes.c_void_p]
-            fn.restype = ctypes.c_int
-            _hip_rt[0] = fn
-        except (OSError, AttributeError):
-            _hip_rt[0] = False
-    fn = _hip_rt[0]
-    if not fn:
-        return False
+    from . import _lib
     t = int(src_dev.shape[0])
     row_elems = int(src_dev[0].numel())
     if not (src_dev.is_contiguous() and dst_host[0].is_contiguous() and dst_host.shape == src_dev.shape and t > 0):
         return False
     width = row_elems * src_dev.element_size()
     dpitch = int(dst_host.stride(0)) * dst_host.element_size()
-    rc = fn(ctypes.c_void_p(dst_host.data_ptr()), dpitch, ctypes.c_void_p(src_dev.data_ptr()), width, width, t,
-            2, ctypes.c_void_p(stream.cuda_stream))            # 2 = hipMemcpyDeviceToHost
+    rc = _lib.lib.dlwp_copy2d_d2h_async(ctypes.c_void_p(dst_host.data_ptr()), dpitch, ctypes.c_void_p(src_dev.data_ptr()), width, t,
+                                        ctypes.c_void_p(stream.cuda_stream))
     return rc == 0
 
 

@@ -539,6 +539,8 @@ int dlwp_host_gather_rows(void* dst, const void* src, const long long* rows, lon
  * into the device buffer the training step reads -- dst[i] = src[rows[i]], one launch per array and batch (rows travel as kernel
  * arguments).  row_bytes: a multiple of 16.  Measured on the GPU box (r4): host memcpy ~15 GB/s whatever the thread count, so a
  * 64-sample batch (32 MB) takes 2.2 ms to assemble on the host against a 1.4 ms training step.                              */
+int dlwp_copy2d_d2h_async(void* dst_pinned_host, size_t dst_pitch, const void* src_device, size_t width, size_t rows,
+                          void* stream);   /* one strided DMA: the member chunk of a predict_timeseries series going home */
 int dlwp_host_register(void* ptr, size_t bytes, void** device_ptr);
 int dlwp_host_unregister(void* ptr);
 int dlwp_gather_rows_h2d(dlwp_handle_t, void* dst, const void* src_device_address, const long long* rows, long long n_rows,
