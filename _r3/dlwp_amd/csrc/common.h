@@ -13,7 +13,6 @@ struct dlwp_options {
   int winograd = 1, bf16_mfma = 1, forced_cfg = -1, forced_wgrad = -1, wino_pairs = 1;
   int few_stream = 1;   // conv_fwd_few.hip: 0 off, 1 when the batch is large enough, 2 whenever the layer qualifies (DLWP_OPT_FEW_STREAM)
   int wgrad_fill = 4;   // weight gradient: workgroups per CU the split count aims at, in eighths of 16 waves (DLWP_OPT_WGRAD_FILL)
-  int splitk = 1;       // Winograd forward on small grids: 0 never, 1 by rule, k >= 2 forced split count (DLWP_OPT_SPLITK)
 };
 const dlwp_options& dlwp_default_options();
 
@@ -40,15 +39,6 @@ struct dlwp_red_job {
   int vec4;             // contiguous elements summed as float4
 };
 
-// a split-K launch's memory: counters (zero between launches) in front, slabs behind
-constexpr int DLWP_SPLITK_REGIONS = 8;
-constexpr size_t DLWP_SPLITK_COUNTER_BYTES = 64u << 10;            // 16 K output tiles
-constexpr size_t DLWP_SPLITK_REGION_BYTES = (32u << 20) + DLWP_SPLITK_COUNTER_BYTES;
-struct dlwp_splitk_ws {
-  void* p;
-  size_t bytes;
-};
-
 struct dlwp_handle {
   dlwp_options opt;
   int device;
@@ -59,30 +49,15 @@ struct dlwp_handle {
   size_t wino_u_floats;
   int prep_defer, n_prep;      // dlwp_prepare_begin / _flush
   int red_defer, n_red;        // dlwp_reductions_begin / _flush
-  int prep_owner, red_owner;   // the thread that opened the mode (batch.hip): other threads never defer
   dlwp_prep_job prep[DLWP_MAX_BATCH_JOBS];
   dlwp_red_job red[DLWP_MAX_BATCH_JOBS];
-  // split-K workspaces of eager launches (conv_fwd.hip: dlwp_splitk_region): one region per stream that has launched a split
-  // convolution -- launches of one stream are ordered, two streams never share slabs or counters.  Allocated together, once.
-  char* ksplit_mem;
-  void* ksplit_stream[DLWP_SPLITK_REGIONS];
-  int ksplit_used;
-  struct dlwp_uncached_pool* uncached;      // rollout graphs' split-K regions (conv_fwd.hip: dlwp_uncached_take)
 };
-
 
 // record (batch mode) or run now
 int dlwp_prep_push(dlwp_handle_t h, dlwp_prep_job j, hipStream_t s);
 // 1: recorded for dlwp_reductions_flush; 0: the handle is not deferring (run your own final kernel); < 0: error
 int dlwp_reduce_defer(dlwp_handle_t h, const float* src, float* dst, long long n, int S, long long es, long long ss,
                       float scale, int accumulate, hipStream_t s);
-
-// Uncached device memory for the split-K regions of rollout graphs (conv_fwd.hip): blocks are taken from / given back to a free
-// list of the handle and NEVER returned to the runtime while the process lives.  (r4: with a hipExtMallocWithFlags /
-// hipFree pair per rollout the full GPU suite died inside hipGraphLaunch of a LATER, unrelated graph in 4 of 17 runs; never without
-// those calls.)  Zeroed when handed out (counters start at zero; a finished launch leaves them there).
-char* dlwp_uncached_take(dlwp_handle_t h, size_t bytes);
-void dlwp_uncached_give(dlwp_handle_t h, char* p);
 
 // scratch for Cin x Cout transformed filters: NULL when it does not fit or cannot be allocated now (stream capture)
 float* dlwp_wino_scratch(dlwp_handle_t h, size_t floats, hipStream_t s);
@@ -168,13 +143,9 @@ struct dlwp_act_epi {
   int act;
   float* bpart;
 };
-// kws: the split-K memory of this launch site (the rollout graph's workspace); NULL = the handle's region of stream s
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd, int dtype, hipStream_t s, const float* u_pre = nullptr,
-                       const dlwp_lstm_io* lstm = nullptr, void* y_pool = nullptr, const dlwp_act_epi* act_epi = nullptr,
-                       const dlwp_splitk_ws* kws = nullptr);
-// bytes of split-K memory (counters + slabs) the launch of this layer would use on n = xs.n samples; 0: the launch is not split
-size_t dlwp_conv2d_splitk_bytes(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);
+                       const dlwp_lstm_io* lstm = nullptr, void* y_pool = nullptr, const dlwp_act_epi* act_epi = nullptr);
 // prepared weights of the Winograd / packed-N / bf16-MFMA families: floats needed for this layer (0 = the kernel reads HWIO), and
 // the kernel that builds them
 size_t dlwp_conv2d_prep_floats(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype);

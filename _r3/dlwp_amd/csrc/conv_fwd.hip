@@ -3,7 +3,6 @@
 // Reference call sites: examples/train.py:164-169 ... 214-219, Azure/train_tf.py:213-268.
 #include <cstdlib>
 #include "conv_fwd_kernel.h"
-#include "tape.h"
 #include <mutex>
 #include <vector>
 
@@ -578,7 +577,6 @@ struct LaunchPlan {
   int n_tiles_h = 0, n_cout_tiles = 0, col0 = 0;   // the narrow launch
   long long n_grid = 0;
   int pair_vw = 0;                                   // > 0: sample pairs side by side, virtual sample width (no narrow launch)
-  int ksplit = 1, kchunks = 0;                       // split-K: workgroups per output tile (1: unsplit), channel chunks of each
 };
 
 // Matrix-core work of `grid` workgroups of instance e on layer a: the padded GEMM volume the MFMA instructions actually
@@ -659,72 +657,6 @@ int plan_launch(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Launc
   return DLWP_OK;
 }
 
-// ---- split-K on small grids (conv_fwd_wino_kernel.h: WinoCfg::SPLITK; instances in conv_fwd_k3d1s.hip) ------------------------ //
-// A Winograd launch under one round of resident workgroups is bound by the LIFE of a workgroup -- prologue, one pipeline stage per
-// chunk of 8 input channels, epilogue -- not by the matrix cores.  Dividing the chunks over S workgroups per tile shortens that
-// life; the last arrival sums the S partial tiles in index order.  What it costs (r4, gpurun_out/s2 -> profiles/r4_splitk_sweep.txt):
-// the exchange is three dependent trips to memory -- slab writes acknowledged, the arrival atomic, the last arrival's slab reads;
-// uncached memory, because an agent-scope fence on gfx950 writes back and invalidates the XCD's whole L2 (45 us on a 16 us launch)
-// -- about 5 us, against ~1.2 us per chunk taken off the chain.  So it pays only where the chain is long and the grid tiny:
-//   128 -> 64 channels on the up-sampled 22 x 45 map (16 chunks): 1 member 17.8 -> 13.4 us (S = 3), 2 members 19.1 -> 15.3,
-//   4 members 19.7 -> 20.4 (no); 64-channel layers (8 chunks): 8 members 15.6 -> 18.8 (S = 3), 1 member 14.7 -> 12.7 but the
-//   position-split COMPAT instance the tile choice takes there runs 11.0 unsplit.
-//   rule (DLWP_OPT_SPLITK = 1): at least 12 chunks and at most a third of a workgroup per CU -> S = 3.
-//   eligible: 32 / 64-channel Winograd instances with a compiled split variant, float32 in and out, no narrow second launch,
-//   no phase-interleaved stores, no fused training epilogues (act', pooled image).
-// The choice depends on the batch size: launches with different S differ by float32 round-off (another association of the sum
-// over input channels); equal S -> equal bits.  dlwp_conv2d_split_count tells a caller which regime a launch is in.
-size_t splitk_bytes(const ConvKernelEntry& e, long long tiles, int S) {
-  return DLWP_SPLITK_COUNTER_BYTES + (size_t)tiles * S * (16 * e.bnf) * e.th * e.tw * sizeof(float);
-}
-void plan_splitk(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, LaunchPlan* lp, bool fused_epilogue, size_t avail) {
-  lp->ksplit = 1;
-  lp->kchunks = 0;
-  if (lp->primary < 0 || h->opt.splitk == 0 || fused_epilogue) return;
-  const ConvKernelEntry& e = registry().entries[lp->primary];
-  if (!is_wino(e) || e.split || !e.splitk || lp->narrow >= 0 || a.in_bf16 || a.out_bf16 || cd->out_d2s || cd->lstm_f) return;
-  if (e.bnf == 4 && !wino_skips_row2(a)) return;
-  const int chunks = dlwp_ceil_div(a.Cin, e.ck);
-  if (chunks < 2 || lp->grid <= 0 || lp->grid * 4 > (long long)DLWP_SPLITK_COUNTER_BYTES) return;
-  int S;
-  if (h->opt.splitk >= 2) {
-    S = h->opt.splitk;
-  } else {
-    S = (chunks >= 12 && 3 * lp->grid <= (long long)h->cu_count) ? 3 : 1;
-  }
-  if (S > chunks) S = chunks;
-  while (S >= 2 && splitk_bytes(e, lp->grid, S) > avail) --S;
-  if (S < 2) return;
-  lp->kchunks = dlwp_ceil_div(chunks, S);
-  lp->ksplit = dlwp_ceil_div(chunks, lp->kchunks);     // no empty split
-  if (lp->ksplit < 2) lp->ksplit = 1;
-}
-
-// the handle's split-K memory for launches on stream s (NULL: none -- the launch then runs unsplit)
-char* dlwp_splitk_region(dlwp_handle_t h, hipStream_t s) {
-  static std::mutex m;
-  std::lock_guard<std::mutex> lock(m);
-  for (int i = 0; i < h->ksplit_used; ++i)
-    if (h->ksplit_stream[i] == (void*)s) return h->ksplit_mem + (size_t)i * DLWP_SPLITK_REGION_BYTES;
-  if (!h->ksplit_mem) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return nullptr;
-    // UNCACHED device memory: slabs and counters are exchanged between workgroups of different XCDs inside one launch, and an
-    // XCD's L2 is neither coherent with the others' nor cheap to write back (conv_fwd_wino_kernel.h)
-    char* p = nullptr;
-    if (hipExtMallocWithFlags((void**)&p, DLWP_SPLITK_REGIONS * DLWP_SPLITK_REGION_BYTES, hipDeviceMallocUncached) != hipSuccess ||
-        hipMemset(p, 0, DLWP_SPLITK_REGIONS * DLWP_SPLITK_REGION_BYTES) != hipSuccess) {
-      (void)hipGetLastError();
-      if (p) (void)hipFree(p);
-      return nullptr;
-    }
-    h->ksplit_mem = p;
-  }
-  if (h->ksplit_used >= DLWP_SPLITK_REGIONS) return nullptr;
-  h->ksplit_stream[h->ksplit_used] = (void*)s;
-  return h->ksplit_mem + (size_t)(h->ksplit_used++) * DLWP_SPLITK_REGION_BYTES;
-}
-
 // conv_fwd_few.hip instead of the chosen direct-family instance?  Returns the grid (0: no).  The streaming kernel amortises a tile
 // position's bookkeeping over the samples a workgroup walks.  Grid = 3 workgroups per CU: that is how many the hardware keeps
 // resident (measured with s_memrealtime stamps, tools/microbench/few_phase_timing.hip: of 4 per CU a quarter starts when the
@@ -746,7 +678,7 @@ int few_stream_grid(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, c
 
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd_in, int dtype, hipStream_t s, const float* u_pre, const dlwp_lstm_io* lstm,
-                       void* y_pool, const dlwp_act_epi* act_epi, const dlwp_splitk_ws* kws) {
+                       void* y_pool, const dlwp_act_epi* act_epi) {
   // y_pool (dlwp_conv2d_fwd_pool2): the instance is chosen as for the pooling epilogue -- same tiles, same cost -- and then stores
   // BOTH tensors; only the direct family has that epilogue
   dlwp_conv2d cd_pool;
@@ -805,15 +737,10 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
                          !wino_skips_row2(a) && !a.in_bf16 && lp.pair_vw == 0;      // conv_fwd_wino_kernel.h: POOL2
     if (!(direct_ok || wino_ok) || lp.narrow >= 0)
       DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd_pool2: this layer's kernel cannot store both tensors");
-    if (u_pre) {   // prepared for the layer's PLAIN descriptor (dlwp_conv2d_prepare): must be the form this instance reads
-      const ConvKernelEntry* ep = entry_for(h, xs, cd_in, dtype);
-      if (!ep || is_wino(*ep) != is_wino(e) || is_bf16(*ep) != is_bf16(e) || (ep->pack > 0 ? ep->pack : 0) != (e.pack > 0 ? e.pack : 0))
-        DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd_pool2: the prepared weights were built for another kernel family");
-    }
     a.out_pool = 0;                 // (a.Hp / a.Wp stay: the pooled tensor's shape)
     a.y2 = (float*)y_pool;
   }
-  if (!lstm && !act_epi) {      // (r4: the streaming kernel also stores the unpooled tensor, alone or beside the pooled one)
+  if (!lstm && !act_epi && !y_pool) {
     const int fg = few_stream_grid(h, a, cd, lp);
     if (fg > 0) {
       a.tiles_h = dlwp_ceil_div(a.Ho, 8);
@@ -854,20 +781,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
       a.w = u;
     }
   }
-  long long grid = lp.grid;
-  plan_splitk(h, a, cd, &lp, lstm || act_epi || y_pool, kws ? kws->bytes : DLWP_SPLITK_REGION_BYTES);
-  if (lp.ksplit > 1) {
-    char* ws = kws ? (char*)kws->p : dlwp_splitk_region(h, s);
-    if (ws) {
-      a.ksplit = lp.ksplit;
-      a.kchunks = lp.kchunks;
-      a.kcount = (unsigned*)ws;
-      a.kslab = (float*)(ws + DLWP_SPLITK_COUNTER_BYTES);
-      grid *= lp.ksplit;
-      DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
-    }
-  }
-  e.launch(a, (int)grid, s);
+  e.launch(a, (int)lp.grid, s);
   if (lp.narrow >= 0) {
     const ConvKernelEntry& p = r.entries[lp.narrow];
     a.col0 = lp.col0;
@@ -878,87 +792,6 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   }
   DLWP_LAUNCH_CHECK("conv2d_fwd_mfma_f32");
   return DLWP_OK;
-}
-
-struct dlwp_uncached_pool {
-  struct Block {
-    char* p;
-    size_t bytes;
-    bool free;
-  };
-  std::mutex m;
-  std::vector<Block> blocks;
-};
-
-char* dlwp_uncached_take(dlwp_handle_t h, size_t bytes) {
-  static std::mutex create;
-  {
-    std::lock_guard<std::mutex> lock(create);
-    if (!h->uncached) h->uncached = new dlwp_uncached_pool();
-  }
-  dlwp_uncached_pool& pool = *h->uncached;
-  std::lock_guard<std::mutex> lock(pool.m);
-  dlwp_uncached_pool::Block* best = nullptr;
-  for (auto& b : pool.blocks)
-    if (b.free && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
-  if (!best) {
-    char* p = nullptr;
-    const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    if (hipExtMallocWithFlags((void**)&p, cap, hipDeviceMallocUncached) != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    pool.blocks.push_back({p, cap, true});
-    best = &pool.blocks.back();
-  }
-  // counters from zero (the device is idle with respect to this block: its last graph was destroyed behind a synchronisation)
-  if (hipMemset(best->p, 0, bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  best->free = false;
-  return best->p;
-}
-
-void dlwp_uncached_give(dlwp_handle_t h, char* p) {
-  if (!h || !h->uncached || !p) return;
-  (void)hipDeviceSynchronize();          // the graph that used the block may still be in flight
-  std::lock_guard<std::mutex> lock(h->uncached->m);
-  static const bool release = getenv("DLWP_UNCACHED_FREE") != nullptr;     // (A/B of the fault described in common.h)
-  for (size_t i = 0; i < h->uncached->blocks.size(); ++i) {
-    auto& b = h->uncached->blocks[i];
-    if (b.p != p) continue;
-    if (release) {
-      (void)hipFree(p);
-      h->uncached->blocks.erase(h->uncached->blocks.begin() + i);
-    } else {
-      b.free = true;
-    }
-    break;
-  }
-}
-
-static int split_count_of(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, size_t* bytes) {
-  dlwp_shape4 ys;
-  if (bytes) *bytes = 0;
-  if (!h || !cd || xs.n <= 0 || dlwp_conv2d_out_shape(xs, cd, &ys) != DLWP_OK) return 1;
-  ConvArgs a = make_args(nullptr, nullptr, nullptr, nullptr, xs, cd, ys, dtype);
-  LaunchPlan lp;
-  plan_launch(h, a, cd, &lp);
-  if (lp.primary < 0 || few_stream_grid(h, a, cd, lp) > 0) return 1;
-  plan_splitk(h, a, cd, &lp, false, DLWP_SPLITK_REGION_BYTES);
-  if (lp.ksplit > 1 && bytes) *bytes = splitk_bytes(registry().entries[lp.primary], lp.grid, lp.ksplit);
-  return lp.ksplit;
-}
-
-size_t dlwp_conv2d_splitk_bytes(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
-  size_t b = 0;
-  split_count_of(h, xs, cd, dtype, &b);
-  return b;
-}
-
-extern "C" int dlwp_conv2d_split_count(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype) {
-  return split_count_of(h, xs, cd, dtype, nullptr);
 }
 
 float* dlwp_wino_scratch(dlwp_handle_t h, size_t floats, hipStream_t s) {
@@ -1028,7 +861,6 @@ int dlwp_conv2d_out_shape(dlwp_shape4 xs, const dlwp_conv2d* cd, dlwp_shape4* ys
 
 int dlwp_conv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                     const dlwp_conv2d* cd, int dtype, void* stream) {
-  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_fwd, dlwp_conv2d_fwd(h, x, w, bias, y, xs, cdp, dtype, s_));
   return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream);
 }
 
@@ -1036,7 +868,6 @@ int dlwp_conv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void* b
 // forward of a layer under a pooling layer (the backward pass needs y).  DLWP_EUNSUPPORTED: keep dlwp_conv2d_fwd + dlwp_maxpool2_fwd.
 int dlwp_conv2d_fwd_pool2(dlwp_handle_t h, const void* x, const void* w, const void* prepared, const void* bias, void* y,
                           void* y_pool, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, void* stream) {
-  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_fwd_pool2, dlwp_conv2d_fwd_pool2(h, x, w, prepared, bias, y, y_pool, xs, cdp, dtype, s_));
   DLWP_CHECK_ARG(y_pool != nullptr, "dlwp_conv2d_fwd_pool2: null pooled output");
   return dlwp_launch_conv2d(h, x, w, bias, y, xs, cd, dtype, (hipStream_t)stream, (const float*)prepared, nullptr, y_pool);
 }
@@ -1048,14 +879,12 @@ size_t dlwp_conv2d_prepared_bytes(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_co
 
 int dlwp_conv2d_prepare(dlwp_handle_t h, const void* w, void* prepared, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype,
                         void* stream) {
-  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_prepare, dlwp_conv2d_prepare(h, w, prepared, xs, cdp, dtype, s_));
   DLWP_CHECK_ARG(h && w && prepared && cd, "dlwp_conv2d_prepare: null handle or pointer");
   return dlwp_conv2d_prep(h, w, (float*)prepared, xs, cd, dtype, (hipStream_t)stream);
 }
 
 int dlwp_conv2d_fwd_prepared(dlwp_handle_t h, const void* x, const void* w, const void* prepared, const void* bias, void* y,
                              dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, void* stream) {
-  DLWP_TAPE_CD(h, stream, cd, dlwp_conv2d_fwd_prepared, dlwp_conv2d_fwd_prepared(h, x, w, prepared, bias, y, xs, cdp, dtype, s_));
   DLWP_CHECK_ARG(h && cd, "dlwp_conv2d_fwd_prepared: null handle or descriptor");
   DLWP_CHECK_ARG(prepared || dlwp_conv2d_prep_floats(h, xs, cd, dtype) == 0,
                  "dlwp_conv2d_fwd_prepared: this layer runs on prepared weights (dlwp_conv2d_prepare)");
@@ -1272,8 +1101,7 @@ int dlwp_conv2d_config_flags(int i) {
   Registry& r = registry();
   if (i < 0 || i >= (int)r.entries.size()) return 0;
   return ((is_wino(r.entries[i]) && r.entries[i].split) ? 1 : 0) | (r.entries[i].gates ? 2 : 0) |
-         ((is_wino(r.entries[i]) && r.entries[i].split == 2) ? 4 : 0) | (r.entries[i].in8 ? 8 : 0) | (r.entries[i].sw ? 16 : 0) |
-         (r.entries[i].splitk ? 32 : 0);
+         ((is_wino(r.entries[i]) && r.entries[i].split == 2) ? 4 : 0) | (r.entries[i].in8 ? 8 : 0) | (r.entries[i].sw ? 16 : 0);
 }
 
 int dlwp_conv2d_prefers_unfused_pool(dlwp_handle_t h, int cin, int cout, int kh, int kw, int dil_h, int dil_w) {
@@ -1359,8 +1187,7 @@ int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
   auto threads = [&](const ConvKernelEntry& k) {   // the position-split Winograd kernel runs two waves per fragment
     return 64 * k.waves * ((is_wino(k) && k.split && !wino_skips_row2(a)) ? 2 : 1);
   };
-  plan_splitk(h, a, cd, &lp, false, DLWP_SPLITK_REGION_BYTES);     // (grid = workgroups launched: tiles x splits; same matrix work)
-  out2[0] = dlwp_launch_info{lp.primary, (int)(lp.grid * lp.ksplit), threads(e), executed_matrix_flops(e, a, lp.grid),
+  out2[0] = dlwp_launch_info{lp.primary, (int)lp.grid, threads(e), executed_matrix_flops(e, a, lp.grid),
                              is_bf16(e) ? 1 : 0};
   *n_launches = 1;
   if (lp.narrow >= 0) {

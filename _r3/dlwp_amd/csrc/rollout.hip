@@ -6,7 +6,6 @@
 // [t*n_outputs, (t+1)*n_outputs) of the device-resident series buffer and call t+1 reads its input from the last of
 // those slots.  All `calls` forwards are stream-captured once and replayed with a single hipGraphLaunch.
 #include "common.h"
-#include <cstdlib>
 #include <vector>
 
 struct dlwp_rollout {
@@ -15,9 +14,6 @@ struct dlwp_rollout {
   hipGraphExec_t exec;
   int calls, n_ops;
   float* wino_u;  // caller's workspace: prepared weights (Winograd / packed-N / bf16), written once at the head of every launch
-  char* ksplit;   // uncached split-K regions of the member chains (NULL: no launch of this rollout splits)
-  hipStream_t run;   // forked graphs (DLWP_ROLLOUT_OWN_STREAM=1): the stream they are launched on
-  hipEvent_t ev, ev2;
 };
 
 namespace {
@@ -26,7 +22,7 @@ bool is_step(const dlwp_op& op) { return op.kind == DLWP_OP_CONV2D && op.conv.ls
 
 int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, const void* w, const void* b, int dtype,
                hipStream_t s, void* const* aux = nullptr, const float* u_pre = nullptr, const void* src2 = nullptr,
-               const void* w2 = nullptr, const dlwp_splitk_ws* kws = nullptr) {
+               const void* w2 = nullptr) {
   switch (op.kind) {
     case DLWP_OP_LSTM_GATES:
       return dlwp_convlstm_gates(h, src, aux[0], aux[1], aux[2], dst, op.xs.n, op.xs.c, op.xs.h * op.xs.w,
@@ -43,7 +39,7 @@ int enqueue_op(dlwp_handle_t h, const dlwp_op& op, const void* src, void* dst, c
         const dlwp_lstm_io io{aux[0], aux[1], aux[2]};
         return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre, &io);
       }
-      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre, nullptr, nullptr, nullptr, kws);  // aux[0]: per-op storage
+      return dlwp_launch_conv2d(h, src, w, b, dst, op.xs, &op.conv, op.aux[0], s, u_pre);  // aux[0]: per-op storage
     case DLWP_OP_ROWCONV2D:     // RowConnected2D: float32 buffers, weights read as stored (nothing to prepare)
       return dlwp_rowconv2d_fwd(h, src, w, b, dst, op.xs, &op.conv, DLWP_F32, (void*)s);
     case DLWP_OP_PAD2D:
@@ -90,19 +86,6 @@ static long long prepared_floats(dlwp_handle_t h, const dlwp_op* plan, int n_ops
     }
   }
   return total;
-}
-
-// split-K memory (counters + slabs, conv_fwd.hip) of ONE member chain: its launches are ordered, so the largest layer's decides
-static size_t splitk_region_bytes(dlwp_handle_t h, const dlwp_op* plan, int n_ops, int gn) {
-  size_t most = 0;
-  for (int i = 0; i < n_ops; ++i) {
-    if (plan[i].kind != DLWP_OP_CONV2D || plan[i].conv.lstm_f > 0) continue;
-    dlwp_shape4 xs = plan[i].xs;
-    xs.n = gn;
-    const size_t b = dlwp_conv2d_splitk_bytes(h, xs, &plan[i].conv, plan[i].aux[0]);
-    if (b > most) most = b;
-  }
-  return (most + 255) & ~(size_t)255;
 }
 
 size_t dlwp_rollout_workspace_bytes(dlwp_handle_t h, const dlwp_op* plan, int n_ops, int groups) {
@@ -202,46 +185,34 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
                  "dlwp_rollout_create: workspace of %zu bytes, %lld needed (dlwp_rollout_workspace_bytes)", workspace_bytes,
                  u_floats * (long long)sizeof(float));
   float* wino_u = u_floats > 0 ? (float*)workspace : nullptr;
-  // split-K launches on small grids (conv_fwd.hip: plan_splitk): one region of counters + slabs per member chain -- a chain's
-  // launch site owns its counters.  UNCACHED device memory (the exchange crosses XCDs), so the library allocates it itself: the
-  // one allocation of a rollout, small grids only (<= 32 MB per chain), freed by dlwp_rollout_destroy.
-  // ONE chain only: graphs with forked member chains never hold split launches.  (r4: the full GPU suite died in hipGraphLaunch of
-  // the grouped-rollout test in 3 of 11 runs with split kernels inside the branches, in 0 of 6 without -- a host-side fault inside
-  // the runtime; member chains are for grids that fill the chip anyway, where nothing splits.)
-  const size_t k_region = groups == 1 ? splitk_region_bytes(h, plan, n_ops, gn) : 0;
-  char* k_base = nullptr;
-  if (k_region > 0) {
-    k_base = dlwp_uncached_take(h, (size_t)groups * k_region);
-    if (!k_base)
-      DLWP_FAIL(DLWP_EHIP, "dlwp_rollout_create: no uncached memory for the split-K regions (%zu bytes)", (size_t)groups * k_region);
-  }
 
   hipStream_t cap;
   DLWP_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
   hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(cap);
+    DLWP_FAIL(DLWP_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+  }
   int rc = DLWP_OK;
-  // derived (phase-summed) kernels first: the convolutions reading them may be prepared right behind
-  auto prepare = [&](hipStream_t s) {
+  // derived (phase-summed) kernels first: the convolutions reading them may be prepared right below
+  for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
+    if (plan[i].kind == DLWP_OP_PHASE_WEIGHTS) {
+      const dlwp_op& op = plan[i];
+      void* aux1[3] = {op.aux[0] == DLWP_BUF_NONE ? nullptr : buffers[op.aux[0]], nullptr, nullptr};
+      rc = enqueue_op(h, op, buffers[op.src], buffers[op.dst], nullptr, op.b >= 0 ? buffers[op.b] : nullptr, dtype, cap, aux1);
+    }
+  if (wino_u)
     for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
-      if (plan[i].kind == DLWP_OP_PHASE_WEIGHTS) {
-        const dlwp_op& op = plan[i];
-        void* aux1[3] = {op.aux[0] == DLWP_BUF_NONE ? nullptr : buffers[op.aux[0]], nullptr, nullptr};
-        rc = enqueue_op(h, op, buffers[op.src], buffers[op.dst], nullptr, op.b >= 0 ? buffers[op.b] : nullptr, dtype, s, aux1);
+      if (u_off[i] >= 0) {
+        const dlwp_shape4 xs2{plan[i].xs.n, plan[i].xs2_c, plan[i].xs.h, plan[i].xs.w};
+        rc = is_step(plan[i]) ? dlwp_convlstm_step_prep(h, buffers[plan[i].w], buffers[plan[i].w2], wino_u + u_off[i], plan[i].xs,
+                                                        &plan[i].conv, xs2, &plan[i].conv2, plan[i].aux[0], cap)
+                              : dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, plan[i].aux[0], cap);
       }
-    if (wino_u)
-      for (int i = 0; i < n_ops && rc == DLWP_OK; ++i)
-        if (u_off[i] >= 0) {
-          const dlwp_shape4 xs2{plan[i].xs.n, plan[i].xs2_c, plan[i].xs.h, plan[i].xs.w};
-          rc = is_step(plan[i]) ? dlwp_convlstm_step_prep(h, buffers[plan[i].w], buffers[plan[i].w2], wino_u + u_off[i], plan[i].xs,
-                                                          &plan[i].conv, xs2, &plan[i].conv2, plan[i].aux[0], s)
-                                : dlwp_conv2d_prep(h, buffers[plan[i].w], wino_u + u_off[i], plan[i].xs, &plan[i].conv, plan[i].aux[0], s);
-        }
-  };
-  // one chain of `ncalls` forwards per member group; groups > 1: parallel branches forked after the weight preparation
-  auto chain = [&](int g, hipStream_t s, int ncalls) {
-    // (no region: the chain's convolutions must not fall back on the handle's -- a chain's launch site owns its counters)
-    const dlwp_splitk_ws kws{k_base ? k_base + (size_t)g * k_region : nullptr, k_base ? k_region : 0};
-    for (int t = 0; t < ncalls && rc == DLWP_OK; ++t) {
+  // one chain of `calls` forwards per member group; groups > 1: parallel branches forked after the weight preparation
+  auto chain = [&](int g, hipStream_t s) {
+    for (int t = 0; t < calls && rc == DLWP_OK; ++t) {
       for (int i = 0; i < n_ops && rc == DLWP_OK; ++i) {
         const dlwp_op& op = plan[i];
         if (op.kind == DLWP_OP_PHASE_WEIGHTS) continue;   // done once, at the head of the graph
@@ -255,21 +226,14 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
           for (int k = 0; k < 3; ++k) aux[k] = op.aux[k + 1] == DLWP_BUF_NONE ? nullptr : resolve(op.aux[k + 1], t, g);
         rc = enqueue_op(h, op, resolve(op.src, t, g), resolve(op.dst, t, g), w, b, dtype, s, aux,
                         (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr, is_step(op) ? resolve(op.src2, t, g) : nullptr,
-                        is_step(op) ? buffers[op.w2] : nullptr, &kws);
+                        is_step(op) ? buffers[op.w2] : nullptr);
       }
     }
   };
-  hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) {
-    (void)hipStreamDestroy(cap);
-    if (k_base) dlwp_uncached_give(h, k_base);
-    DLWP_FAIL(DLWP_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
-  }
-  prepare(cap);
   std::vector<hipStream_t> branch;
   std::vector<hipEvent_t> events;
   if (groups == 1) {
-    chain(0, cap, calls);
+    chain(0, cap);
   } else {
     hipEvent_t fork = nullptr;
     if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventRecord(fork, cap) != hipSuccess) rc = DLWP_EHIP;
@@ -281,7 +245,7 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
         branch.push_back(s);
         if (hipStreamWaitEvent(s, fork, 0) != hipSuccess) { rc = DLWP_EHIP; break; }   // joins the capture
       }
-      chain(g, s, calls);
+      chain(g, s);
       if (g > 0 && rc == DLWP_OK) {
         hipEvent_t done = nullptr;
         if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess || hipEventRecord(done, s) != hipSuccess ||
@@ -297,18 +261,15 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
   (void)hipStreamDestroy(cap);
   if (rc != DLWP_OK) {
     if (graph) (void)hipGraphDestroy(graph);
-    if (k_base) dlwp_uncached_give(h, k_base);
     return rc;  // error string already set by the failing op
   }
   if (e != hipSuccess) {
-    if (k_base) dlwp_uncached_give(h, k_base);
     DLWP_FAIL(DLWP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
   }
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {
     (void)hipGraphDestroy(graph);
-    if (k_base) dlwp_uncached_give(h, k_base);
     DLWP_FAIL(DLWP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
   }
   dlwp_rollout* r = new dlwp_rollout();
@@ -318,46 +279,20 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
   r->calls = calls;
   r->n_ops = n_ops;
   r->wino_u = wino_u;
-  r->ksplit = k_base;
-  r->run = nullptr;
-  r->ev = r->ev2 = nullptr;
-  if (groups > 1) {
-    (void)hipStreamCreateWithFlags(&r->run, hipStreamNonBlocking);
-    (void)hipEventCreateWithFlags(&r->ev, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&r->ev2, hipEventDisableTiming);
-  }
   *out = r;
   return DLWP_OK;
 }
 
 int dlwp_rollout_launch(dlwp_rollout_t r, void* stream) {
   DLWP_CHECK_ARG(r && r->exec, "dlwp_rollout_launch: null rollout");
-  // A FORKED graph (member chains) is launched on a stream of the rollout's own, ordered behind and in front of the caller's by two
-  // events -- never on the caller's stream itself, which under torch is the legacy null stream: r4, the first full GPU test run on a
-  // fresh box faulted inside hipGraphLaunch (null object in the runtime, profiles/r4_forked_graph_fault.txt) at the first forked
-  // graph launched there, 8 of 8 fresh boxes; with the stream of its own 0 of 2.  DLWP_ROLLOUT_OWN_STREAM=0: the caller's stream.
-  static const bool own = !(getenv("DLWP_ROLLOUT_OWN_STREAM") && getenv("DLWP_ROLLOUT_OWN_STREAM")[0] == '0');
-  if (own && r->run) {
-    DLWP_HIP(hipEventRecord(r->ev, (hipStream_t)stream));
-    DLWP_HIP(hipStreamWaitEvent(r->run, r->ev, 0));
-    DLWP_HIP(hipGraphLaunch(r->exec, r->run));
-    DLWP_HIP(hipEventRecord(r->ev2, r->run));
-    DLWP_HIP(hipStreamWaitEvent((hipStream_t)stream, r->ev2, 0));
-    return DLWP_OK;
-  }
   DLWP_HIP(hipGraphLaunch(r->exec, (hipStream_t)stream));
   return DLWP_OK;
 }
 
 int dlwp_rollout_destroy(dlwp_rollout_t r) {
   if (!r) return DLWP_OK;
-  (void)hipDeviceSynchronize();     // a launch of this graph may still be running (see dlwp_train_step_destroy)
   if (r->exec) (void)hipGraphExecDestroy(r->exec);
   if (r->graph) (void)hipGraphDestroy(r->graph);
-  if (r->ksplit) dlwp_uncached_give(r->h, r->ksplit);
-  if (r->run) (void)hipStreamDestroy(r->run);
-  if (r->ev) (void)hipEventDestroy(r->ev);
-  if (r->ev2) (void)hipEventDestroy(r->ev2);
   delete r;
   return DLWP_OK;
 }

@@ -1,0 +1,189 @@
+"""
+TimeSeriesEstimator: the rollout entry point examples/validate.py:197-205 uses (reference DLWP/model/extensions.py:21-303).
+
+It steps a model forward over EVERY sample of a generator, feeding predictions back in as inputs, for models whose
+inputs and outputs need not coincide (variable / level selection, fewer output than input time steps, an insolation
+input channel that is known analytically).  The reference expresses the feedback with xarray label arithmetic
+(`reindex`, `.loc[...] = ...`); xarray is absent from this image, so the same bookkeeping is restated on plain index
+arithmetic.  Pinned by tests/golden/estimator.npz: the reference's own predict() run by oracle/make_golden.py under a
+numpy-backed stub of the xarray calls it makes (13 cases: same / fewer / more output steps, variable selections,
+insolation, interval, impute, keep_time_dim, varlev datasets).  What it reduces to, with
+k = es + interval - 1 series steps covered per model call:
+
+    p_{s+1}[i] = p_s[i + k]              rows re-indexed to the later start time; the last k rows run out of data (NaN,
+                                         or the sample-mean input when impute=True, for the last `es` rows as the
+                                         reference does)
+    insolation channel of the last es rows: recomputed from the (known) times
+    channels the model predicts (outputs_in_inputs): overwritten with the prediction --
+        output_time_steps <= input_time_steps: the last `es` input time steps take all output time steps
+        otherwise: the first (prefer_first_times) or last `input_time_steps` output time steps
+
+When inputs == outputs (same channels, same time steps, no insolation) every channel is overwritten and the loop is
+exactly DLWPNeuralNet.predict_timeseries: that case is dispatched to the device-resident hipGraph rollout; all other
+cases run model.predict (one fused device forward) per step with the re-indexing on the host, as the reference does.
+The result carries the reference's coordinates (f_hour, time, [time_step,] varlev | variable, level, lat, lon) in a
+LabeledArray.
+"""
+import warnings
+
+import numpy as np
+
+from ..util import insolation
+from .generators import DataGenerator, LabeledArray, SeriesDataGenerator
+from .models import DLWPFunctional, DLWPNeuralNet
+
+
+def _labels(sel, da, dim):
+    if dim in sel:
+        return np.atleast_1d(np.asarray(sel[dim]))
+    return np.asarray(da.coords[dim])
+
+
+class TimeSeriesEstimator(object):
+    def __init__(self, model, generator):
+        if not isinstance(model, (DLWPNeuralNet, DLWPFunctional)):
+            raise TypeError("'model' must be a valid instance of a DLWP model class")
+        if not isinstance(generator, (DataGenerator, SeriesDataGenerator)):
+            raise TypeError("'generator' must be a valid instance of a DLWP generator class")
+        if isinstance(model, DLWPFunctional):
+            warnings.warn('DLWPFunctional models are only partially supported by TimeSeriesEstimator. The '
+                          'inputs/outputs to the model must be the same if the model predicts a sequence.')
+        self.model = model
+        self.generator = generator
+        self._add_insolation = bool(getattr(generator, '_add_insolation', False))
+        self._is_series = isinstance(generator, SeriesDataGenerator)
+        da = generator.ds.predictors
+        if not isinstance(da, LabeledArray):
+            raise TypeError('TimeSeriesEstimator needs a dataset with coordinates (SeriesDataset / LabeledArray)')
+        self._da = da
+        self._uses_varlev = 'varlev' in da.dims
+        samples = np.asarray(da.coords['sample'])
+        self._dt = samples[1] - samples[0]
+        self._interval = getattr(generator, '_interval', 1)
+        in_sel = getattr(generator, '_input_sel', None) or {}
+        out_sel = getattr(generator, '_output_sel', None) or {}
+        if self._uses_varlev:
+            self._input_sel = {'varlev': _labels(in_sel, da, 'varlev')}
+            self._output_sel = {'varlev': _labels(out_sel, da, 'varlev')}
+        else:
+            self._input_sel = {'variable': _labels(in_sel, da, 'variable'), 'level': _labels(in_sel, da, 'level')}
+            self._output_sel = {'variable': _labels(out_sel, da, 'variable'), 'level': _labels(out_sel, da, 'level')}
+            for sel in (self._input_sel, self._output_sel):   # flattened 'variable/level' labels, variable-major
+                sel['varlev'] = np.array(['/'.join([str(v), str(l)]) for v in sel['variable'] for l in sel['level']])
+        self._outputs_in_inputs = {
+            k: np.array([v for v in self._output_sel[k] if v in self._input_sel[k]]) for k in self._output_sel}
+        if self._add_insolation:
+            self._input_sel['varlev'] = np.concatenate([self._input_sel['varlev'], np.array(['SOL'])])
+        self._input_time_steps = generator._input_time_steps if self._is_series else model.time_dim
+        self._output_time_steps = generator._output_time_steps if self._is_series else model.time_dim
+
+    # -- the forecast ------------------------------------------------------------------------------------------------ #
+    def predict(self, steps, impute=False, keep_time_dim=False, prefer_first_times=True, **kwargs):
+        """Step the model forward `steps` series steps for every sample of the generator.  Returns a LabeledArray with
+        dims (f_hour, time, varlev | variable, level, lat, lon) -- or (f_hour, time, time_step, ...) with keep_time_dim
+        -- float32, NaN where a forecast needed inputs beyond the end of the data."""
+        if int(steps) < 1:
+            raise ValueError('must use positive integer for steps')
+        steps = int(steps)
+        t_in, t_out = self._input_time_steps, self._output_time_steps
+        if t_out <= t_in:
+            keep_inputs, es = True, t_out
+            in_times = np.arange(t_in) - (t_in - t_out)
+        else:
+            keep_inputs = False
+            es = t_in if prefer_first_times else t_out
+            in_times = np.arange(t_in) + (0 if prefer_first_times else (t_out - t_in))
+        effective_steps = int(np.ceil(steps / float(es)))
+        k = es + self._interval - 1                                # series steps the window advances per model call
+
+        gen = self.generator
+        p, t = gen.generate([], scale_and_impute=False)
+        p_shape = tuple(p.shape)
+        n = p_shape[0]
+        hw = tuple(gen.convolution_shape[-2:])
+        p = np.array(p, dtype=np.float32).reshape((n, t_in, -1) + hw)
+        t_shape = tuple((t[0] if isinstance(t, (list, tuple)) else t).shape)
+        sample_coord = np.asarray(self._da.coords['sample'])[:gen._n_sample]
+        if not self._is_series:
+            sample_coord = sample_coord - self._dt * (t_in - 1)
+        lat, lon = self._da.coords.get('lat'), self._da.coords.get('lon')
+        in_labels = list(self._input_sel['varlev'])
+        out_labels = list(self._output_sel['varlev'])
+        shared = list(self._outputs_in_inputs['varlev'])
+        idx_in = [in_labels.index(v) for v in shared]
+        idx_out = [out_labels.index(v) for v in shared]
+        p_mean = p.mean(axis=0) if impute else None
+        result = np.full((effective_steps,) + t_shape, np.nan, dtype=np.float32)
+
+        same_io = (keep_inputs and t_in == t_out and not self._add_insolation and self._interval == 1 and
+                   in_labels == out_labels and isinstance(self.model, DLWPNeuralNet))
+        if isinstance(self.model, DLWPFunctional) and self.model._n_steps > 1:
+            result[:] = self.model.predict_timeseries(p.reshape(p_shape), steps, keep_time_dim=True,
+                                                      **kwargs).reshape((-1,) + t_shape)[:effective_steps]
+        elif same_io and not impute:
+            # every input channel and time step is replaced by the prediction: the plain autoregressive rollout, which
+            # DLWPNeuralNet.predict_timeseries keeps on the device (one hipGraph).  The reference's re-indexing blanks the
+            # rows past the end of the data and then overwrites ALL of them with the forecast (extensions.py:214-240), so
+            # every row stays finite at every lead -- pinned by tests/golden/estimator.npz ('same', 'varlev_same').
+            series = self.model.predict_timeseries(p.reshape(p_shape), effective_steps * self.model.time_dim,
+                                                   keep_time_dim=True, **kwargs)
+            result[:] = np.asarray(series).reshape((effective_steps,) + t_shape)
+        else:
+            sample_now = sample_coord.copy()
+            for s in range(effective_steps):
+                if kwargs.get('verbose', 0) > 0:
+                    print('Time step %d/%d' % (s + 1, effective_steps))
+                result[s] = self.model.predict(p.reshape(p_shape), **kwargs)
+                r = result[s].reshape((n, t_out, -1) + hw)
+                # re-index the inputs to the start times of the next step: row i takes the data of row i + k
+                p_next = np.full_like(p, np.nan)
+                if k < n:
+                    p_next[:n - k] = p[k:]
+                p = p_next
+                sample_now = sample_now + k * self._dt
+                if impute:
+                    p[-es:] = p_mean[np.newaxis]
+                if self._add_insolation:
+                    sol_idx = in_labels.index('SOL')
+                    tail = sample_now[-es:]
+                    p[-es:, :, sol_idx] = np.stack([insolation(tail + m * self._dt, lat, lon) for m in range(t_in)], axis=1)
+                # feed the predicted channels back in; the others stay what the data (or the imputation) provided
+                if keep_inputs:
+                    p[:, t_in - es:, idx_in] = r[:, :, idx_out]
+                elif prefer_first_times:
+                    p[:, :, idx_in] = r[:, :t_in][:, :, idx_out]
+                else:
+                    p[:, :, idx_in] = r[:, -t_in:][:, :, idx_out]
+
+        # -- coordinates --------------------------------------------------------------------------------------------- #
+        result = result.reshape((effective_steps, n, t_out, -1) + hw)
+        time_coord = sample_coord + (t_in - 1) * self._dt
+        if keep_time_dim:
+            f_hour = np.array([self._dt * (1 + e * k) for e in range(effective_steps)])
+            dims = ['f_hour', 'time', 'time_step', 'varlev', 'lat', 'lon']
+            coords = {'f_hour': f_hour, 'time': time_coord, 'time_step': np.arange(t_out)}
+        else:
+            if not keep_inputs and prefer_first_times:
+                result = result[:, :, :es]
+            kept = result.shape[2]
+            result = result.transpose((0, 2, 1, 3, 4, 5)).reshape((-1, n, result.shape[3]) + hw)
+            f_hour = np.array([self._dt * (m + self._interval + e * (es - 1 + self._interval))
+                               for e in range(effective_steps) for m in range(kept)])
+            result, f_hour = result[:steps], f_hour[:steps]
+            dims = ['f_hour', 'time', 'varlev', 'lat', 'lon']
+            coords = {'f_hour': f_hour, 'time': time_coord}
+        coords.update({'varlev': np.asarray(out_labels)})
+        if lat is not None:
+            coords['lat'], coords['lon'] = lat, lon
+        if not self._uses_varlev:
+            # the reference unstacks a pandas MultiIndex.from_product((variable, level)) (extensions.py:298-302): the new
+            # coordinates are the index LEVELS, i.e. the labels in sorted order, not in selection order
+            var, lev = np.asarray(self._output_sel['variable']), np.asarray(self._output_sel['level'])
+            ax = dims.index('varlev')
+            result = result.reshape(result.shape[:ax] + (len(var), len(lev)) + result.shape[ax + 1:])
+            vo, lo = np.argsort(var, kind='stable'), np.argsort(lev, kind='stable')
+            result = np.take(np.take(result, vo, axis=ax), lo, axis=ax + 1)
+            dims = dims[:ax] + ['variable', 'level'] + dims[ax + 1:]
+            coords.pop('varlev')
+            coords.update({'variable': var[vo], 'level': lev[lo]})
+        return LabeledArray(result, coords, tuple(dims))

@@ -1,0 +1,172 @@
+"""
+Data parallelism: one process per GPU.  Replaces keras.utils.multi_gpu_model (reference DLWP/model/models.py:104-109,
+365-372), which replicates the graph inside one process, keeps the weights on the CPU and moves them over PCIe every step.
+
+  training : every rank holds the full (tiny, <1 MB) weight set and trains on ITS ROWS of the global batch -- contiguous
+             row shards, exactly how multi_gpu_model's get_slice cuts a batch; the global batch is n_gpu x the per-GPU
+             batch (reference Azure/train_tf.py:163-164).  The ONE flat fp32 gradient buffer (with the loss table riding
+             in its tail) is summed with a single all-reduce per step: ~756 KB for the config-2 U-Net, latency-bound, so
+             one collective and no bucketing.  On the GPU box that all-reduce is the library's own RCCL communicator
+             (include/dlwp_hip.h: dlwp_comm_*, dlwp_allreduce_sum_f32) enqueued on the training stream right behind the
+             last weight-gradient kernel; torch.distributed only carries the rendezvous (the 128-byte unique id) and the
+             host-side index broadcasts.  With the 'gloo' backend (CPU tests, two ranks sharing one GPU) the same calls go
+             through torch.distributed.
+  feeding  : every rank gathers and uploads only its own rows (DeviceLoader(shard=...), Trainer.fit): the batch
+             index list is rank 0's, broadcast once per epoch, so shuffles agree without relying on seeds.
+  inference: ensemble members / samples are independent (reference models.py:277-293 is elementwise over the sample
+             axis): shard_bounds() gives each rank its members and NO collective is issued during the rollout.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous row shard [lo, hi) of n rows for `rank` of `world` (remainder spread over the first ranks)."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DataParallel(object):
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised; call dlwp_amd.parallel.init() first')
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+        self._comm = None           # dlwp_comm_t (RCCL through the C ABI) once a device buffer asked for it
+        self._comm_device = None
+
+    def shard(self, n):
+        return shard_bounds(n, self.rank, self.world)
+
+    # -- the library's RCCL communicator ------------------------------------------------------------------------------ #
+    def uses_rccl_abi(self, t=None):
+        """True when device collectives go through dlwp_comm_* (backend 'nccl' on a GPU; DLWP_RCCL_ABI=0 keeps them in
+        torch.distributed)."""
+        if self.backend != 'nccl' or os.environ.get('DLWP_RCCL_ABI', '1') == '0':
+            return False
+        return t is None or t.is_cuda
+
+    def comm(self, device):
+        """dlwp_comm_t of this rank on `device`; created collectively at the first call (every rank must make it)."""
+        if self._comm is None:
+            from . import _lib
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            nbytes = ctypes.c_size_t(0)
+            _lib.check(_lib.lib.dlwp_comm_unique_id(None, ctypes.byref(nbytes)))
+            uid = (ctypes.c_char * nbytes.value)()
+            if self.rank == 0:
+                _lib.check(_lib.lib.dlwp_comm_unique_id(uid, ctypes.byref(nbytes)))
+            box = [bytes(uid)]
+            self.dist.broadcast_object_list(box, src=0, group=self.group)       # rendezvous only: 128 bytes
+            raw = (ctypes.c_char * nbytes.value).from_buffer_copy(box[0])
+            out = ctypes.c_void_p()
+            _lib.check(_lib.lib.dlwp_comm_init_rank(ctypes.byref(out), int(idx), self.world, self.rank, raw, nbytes.value))
+            self._comm, self._comm_device = out, idx
+        return self._comm
+
+    def close(self):
+        if self._comm is not None:
+            from . import _lib
+            _lib.lib.dlwp_comm_destroy(self._comm)
+            self._comm = None
+
+    # -- collectives on flat float32 device buffers ---------------------------------------------------------------------- #
+    @staticmethod
+    def _stream(t):
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def all_reduce_sum_(self, flat):
+        if self.uses_rccl_abi(flat):
+            from . import _lib
+            if flat.dtype != torch.float32 or not flat.is_contiguous():
+                raise ValueError('the RCCL all-reduce takes a contiguous float32 buffer')
+            _lib.check(_lib.lib.dlwp_allreduce_sum_f32(self.comm(flat.device), ctypes.c_void_p(flat.data_ptr()),
+                                                       flat.numel(), self._stream(flat)))
+        else:
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def broadcast_(self, flat, src=0):
+        if self.uses_rccl_abi(flat) and flat.dtype == torch.float32 and flat.is_contiguous():
+            from . import _lib
+            _lib.check(_lib.lib.dlwp_broadcast_f32(self.comm(flat.device), ctypes.c_void_p(flat.data_ptr()), flat.numel(),
+                                                   int(src), self._stream(flat)))
+        else:
+            self.dist.broadcast(flat, src=src, group=self.group)
+        return flat
+
+    def mean_loss(self, vals):
+        vals = vals.clone()
+        self.all_reduce_sum_(vals)
+        return vals / self.world
+
+    # -- host-side agreement (index lists, flags) ------------------------------------------------------------------------ #
+    def broadcast_indices(self, idx, src=0):
+        """Rank `src`'s integer index array on every rank (one small object broadcast; the shuffle of an epoch)."""
+        box = [np.ascontiguousarray(idx, dtype=np.int64) if self.rank == src else None]
+        self.dist.broadcast_object_list(box, src=src, group=self.group)
+        return box[0]
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and
+    bind this process to its GPU.  Returns (rank, world, local_rank).  No-op when already initialised."""
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        if local >= ndev and os.environ.get('DLWP_SHARE_GPUS') == '1':
+            local %= ndev          # testing only: several ranks on one GPU (needs DLWP_DIST_BACKEND=gloo, RCCL refuses)
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        backend = backend or os.environ.get('DLWP_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        kwargs = {}
+        if backend == 'nccl':
+            kwargs['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, local
+
+
+def attach(model, gpus):
+    """build_model(gpus=n): make `model` data parallel over the current process group.  If the script was not launched
+    with one process per GPU (no process group, WORLD_SIZE unset) this raises instead of silently training on one GPU."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            init()
+        else:
+            raise RuntimeError('gpus=%d requested but this is a single process: launch one process per GPU, e.g. '
+                               '`python -m torch.distributed.run --nproc-per-node %d script.py`' % (gpus, gpus))
+    dp = DataParallel()
+    if dp.world != gpus:
+        raise RuntimeError('gpus=%d but the process group has %d ranks' % (gpus, dp.world))
+    model._dp = dp
+    tr = getattr(model, '_trainer', None)
+    if tr is not None:              # attached after compile: the trainer picks the group up and aligns the replicas
+        tr.dp = dp
+        tr.sync_parameters()
+    return dp
+
+
+def sync_parameters(model):
+    """Broadcast rank 0's flat parameter buffer (and optimizer state) so every replica is identical.  Model.compile and
+    the first training step after set_weights / load do this themselves; kept for scripts that edit weights in place."""
+    tr = getattr(model, '_trainer', None)
+    if tr is not None:
+        tr.sync_parameters()

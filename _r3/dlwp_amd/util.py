@@ -1,0 +1,230 @@
+"""
+Utilities with the reference's names (DLWP/util.py): the class registry used by build_model, NaN-sample deletion,
+train/test index splitting, and model save / load.
+"""
+import pickle
+import random
+from copy import copy
+from importlib import import_module
+
+import numpy as np
+
+
+def get_from_class(module_name, class_name):
+    """`from module_name import class_name` as an object (reference DLWP/util.py:82-93).  The Keras module names the
+    reference passes are mapped onto this package's registries, so reference-style call sites keep working."""
+    module_name = {'keras.layers': 'dlwp_amd.layers', 'DLWP.custom': 'dlwp_amd.custom',
+                   'keras.callbacks': 'dlwp_amd.custom'}.get(module_name, module_name)
+    module = import_module(module_name)
+    return getattr(module, class_name)
+
+
+def get_classes(module_name):
+    module = import_module(module_name)
+    return {k: getattr(module, k) for k in dir(module) if isinstance(getattr(module, k), type)}
+
+
+def get_methods(module_name):
+    module = import_module(module_name)
+    return {k: getattr(module, k) for k in dir(module) if callable(getattr(module, k))}
+
+
+def delete_nan_samples(predictors, targets, large_fill_value=False, threshold=None):
+    """Drop every sample that has a NaN in its predictors or targets (or a NaN fraction >= `threshold`).
+    Same contract as reference DLWP/util.py:238-268; returns new arrays with the original trailing shapes."""
+    if threshold is not None and not (0 <= threshold <= 1):
+        raise ValueError("'threshold' must be between 0 and 1")
+    if large_fill_value:
+        predictors[(predictors >= 1.e20) | (predictors <= -1.e20)] = np.nan
+        targets[(targets >= 1.e20) | (targets <= -1.e20)] = np.nan
+    nan_p = np.isnan(predictors.reshape((predictors.shape[0], -1)))
+    nan_t = np.isnan(targets.reshape((targets.shape[0], -1)))
+    if threshold is None:
+        bad = nan_p.any(axis=1) | nan_t.any(axis=1)
+    else:
+        bad = (nan_p.mean(axis=1) >= threshold) | (nan_t.mean(axis=1) >= threshold)
+    if not bad.any():
+        return predictors, targets
+    keep = np.flatnonzero(~bad)
+    return predictors[keep], targets[keep]
+
+
+def train_test_split_ind(n_sample, test_size, method='random'):
+    """Index lists (train, test) -- reference DLWP/util.py:271-297."""
+    if method == 'first':
+        return list(range(test_size, n_sample)), list(range(test_size))
+    if method == 'last':
+        return list(range(n_sample - test_size)), list(range(n_sample - test_size, n_sample))
+    if method == 'random':
+        train = list(range(n_sample))
+        test = []
+        for _ in range(test_size):
+            i = random.choice(train)
+            test.append(i)
+            train.remove(i)
+        return train, sorted(test)
+    raise ValueError("'method' must be 'first', 'last', or 'random'")
+
+
+def save_model(model, file_name, history=None):
+    """Write `<file_name>.keras` (architecture + weights in Keras layout, see dlwp_amd.serialization), `<file_name>.pkl`
+    (the wrapper object without its model) and optionally `<file_name>.history` -- the reference's three files
+    (DLWP/util.py:126-153)."""
+    from . import serialization
+    net = model.base_model if getattr(model, 'base_model', None) is not None else model.model
+    serialization.save_model_file(net, '%s.keras' % file_name)
+    shell = copy(model)
+    shell.model = None
+    if hasattr(model, 'base_model'):
+        shell.base_model = None
+    with open('%s.pkl' % file_name, 'wb') as f:
+        pickle.dump(shell, f, protocol=pickle.HIGHEST_PROTOCOL)
+    if history is not None:
+        with open('%s.history' % file_name, 'wb') as f:
+            pickle.dump(history.history, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+
+def load_model(file_name, history=False, custom_objects=None, gpus=1):
+    """Inverse of save_model (reference DLWP/util.py:156-192).  `gpus` > 1 marks the wrapper for data-parallel use
+    (one process per GPU under torch.distributed; see dlwp_amd.parallel)."""
+    from . import serialization
+    with open('%s.pkl' % file_name, 'rb') as f:
+        model = pickle.load(f)
+    net = serialization.load_model_file('%s.keras' % file_name, custom_objects=custom_objects)
+    model.base_model = net
+    model.model = net
+    model.gpus = gpus
+    if history:
+        with open('%s.history' % file_name, 'rb') as f:
+            return model, pickle.load(f)
+    return model
+
+
+def day_of_year(date):
+    """Fractional day of the year of a timestamp, 0.0 at 1 Jan 00:00 (reference DLWP/util.py:300-302)."""
+    import pandas as pd
+    date = pd.Timestamp(date)
+    return (date - pd.Timestamp(date.year, 1, 1)).total_seconds() / 86400.
+
+
+def insolation(dates, lat, lon, S=1.):
+    """Approximate top-of-atmosphere insolation (date, lat, lon), float32 -- reference DLWP/util.py:305-352: fixed 1995
+    orbital constants, first-order longitude of the earth on its orbit, declination, hour angle from day fraction +
+    longitude, inverse-square distance factor; negative (night-side) values clipped to 0.  lat / lon: both 1-D (a
+    regular grid) or both 2-D of one shape, degrees.  Unlike the reference, 2-D `lat` is not modified in place."""
+    lat, lon = np.asarray(lat, dtype=np.float64), np.asarray(lon, dtype=np.float64)
+    if lat.ndim != lon.ndim:
+        raise ValueError("'lat' and 'lon' must either both be 1d or both be 2d'")
+    if lat.ndim == 2 and lat.shape != lon.shape:
+        raise ValueError('shape mismatch between lat (%s) and lon (%s)' % (lat.shape, lon.shape))
+    if lat.ndim == 1:
+        lon, lat = np.meshgrid(lon, lat)
+    eps = 23.4441 * np.pi / 180.        # obliquity
+    ecc = 0.016715                      # eccentricity
+    om = 282.7 * np.pi / 180.           # longitude of perihelion
+    beta = np.sqrt(1 - ecc ** 2.)
+    days = np.array([day_of_year(d) for d in np.asarray(dates).ravel()], dtype=np.float64)
+    lambda_m0 = ecc * (1. + beta) * np.sin(om)
+    lambda_m = lambda_m0 + 2. * np.pi * (days - 80.5) / 365.
+    lambda_ = lambda_m + 2. * ecc * np.sin(lambda_m - om)
+    dec = np.arcsin(np.sin(eps) * np.sin(lambda_))
+    h = 2 * np.pi * (days[:, None, None] + lon / 360.)
+    rho = (1. - ecc ** 2.) / (1. + ecc * np.cos(lambda_ - om))
+    latr = lat * (np.pi / 180.)
+    sol = S * (np.sin(latr[None, ...]) * np.sin(dec[:, None, None]) -
+               np.cos(latr[None, ...]) * np.cos(dec[:, None, None]) * np.cos(h)) * rho[:, None, None] ** -2.
+    sol[sol < 0.] = 0.
+    return sol.astype(np.float32)
+
+
+class _PinnedPool(object):
+    """Page-locked result arrays, recycled.  predict_timeseries hands its series back as a numpy array (the reference's contract,
+    DLWP/model/models.py:230-301); for a 256-member 14-day rollout that is 1.8 GB, and page-locking 1.8 GB anew on every call
+    costs about as much as a quarter of the rollout.  The array handed out is a numpy view of a pinned torch tensor through a
+    ctypes buffer object that every view of it keeps alive; when the LAST view dies the tensor returns to the pool (a weakref
+    finaliser), so a buffer is never reused while the caller can still see it."""
+    limit_bytes = 8 << 30
+    per_size = 2
+
+    def __init__(self):
+        import threading
+        self._free, self._bytes, self._lock = {}, 0, threading.Lock()
+
+    def take(self, shape):
+        import torch
+        shape = tuple(int(v) for v in shape)
+        n = int(np.prod(shape)) if shape else 1
+        with self._lock:
+            lst = self._free.get(n)
+            if lst:
+                self._bytes -= 4 * n
+                return lst.pop().view(shape)
+        try:
+            return torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        except RuntimeError:
+            return torch.empty(shape, dtype=torch.float32)
+
+    def _give_back(self, flat):
+        n = flat.numel()
+        with self._lock:
+            lst = self._free.setdefault(n, [])
+            if len(lst) < self.per_size and self._bytes + 4 * n <= self.limit_bytes:
+                lst.append(flat)
+                self._bytes += 4 * n
+
+    def lend(self, tensor):
+        """numpy array over `tensor`'s memory; the tensor goes back to the pool when the array and all its views are gone"""
+        import ctypes
+        import weakref
+        if not (tensor.is_pinned() and tensor.is_contiguous() and tensor.numel() > 0):
+            return tensor.numpy()
+        flat = tensor.view(-1)
+        buf = (ctypes.c_float * flat.numel()).from_address(flat.data_ptr())
+        weakref.finalize(buf, self._give_back, flat)
+        return np.frombuffer(buf, dtype=np.float32).reshape(tuple(tensor.shape))
+
+
+pinned_results = _PinnedPool()
+
+_hip_rt = [None]
+
+
+def copy2d_d2h_async(dst_host, src_dev, stream):
+    """dst_host[t, ...] <- src_dev[t, ...] for every leading index t as ONE strided device-to-host DMA (hipMemcpy2DAsync on the HIP
+    runtime torch already loaded): dst_host is a slice of a pinned array whose rows are further apart than they are long -- a
+    member chunk of a (T, N, ...) series -- src_dev is contiguous.  One descriptor list for the copy engine instead of T separate
+    copies (56 x 8 MB per chunk of a 14-day rollout: 37 GB/s effective; one strided copy runs at the link rate).  Returns False
+    when the runtime entry point is not available (the caller then copies row by row)."""
+    import ctypes
+    if _hip_rt[0] is None:
+        try:
+            lib = ctypes.CDLL('libamdhip64.so')
+            fn = lib.hipMemcpy2DAsync
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                           ctypes.c_int, ctypes.c_void_p]
+            fn.restype = ctypes.c_int
+            _hip_rt[0] = fn
+        except (OSError, AttributeError):
+            _hip_rt[0] = False
+    fn = _hip_rt[0]
+    if not fn:
+        return False
+    t = int(src_dev.shape[0])
+    row_elems = int(src_dev[0].numel())
+    if not (src_dev.is_contiguous() and dst_host[0].is_contiguous() and dst_host.shape == src_dev.shape and t > 0):
+        return False
+    width = row_elems * src_dev.element_size()
+    dpitch = int(dst_host.stride(0)) * dst_host.element_size()
+    rc = fn(ctypes.c_void_p(dst_host.data_ptr()), dpitch, ctypes.c_void_p(src_dev.data_ptr()), width, width, t,
+            2, ctypes.c_void_p(stream.cuda_stream))            # 2 = hipMemcpyDeviceToHost
+    return rc == 0
+
+
+def host_result_buffer(shape):
+    """float32 host tensor for results copied back from the device: page-locked (asynchronous DMA on a copy stream) when
+    the host allows it, pageable otherwise (the copies then simply run synchronously)."""
+    import torch
+    try:
+        return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32, pin_memory=True)
+    except RuntimeError:
+        return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32)

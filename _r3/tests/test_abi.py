@@ -1,0 +1,163 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every symbol that
+include/dlwp_hip.h declares; argument validation that needs no device."""
+import ctypes
+
+import pytest
+
+from dlwp_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    names = _lib.declared_symbols()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(_lib.lib, n)]
+    assert not missing, missing
+
+
+def test_every_declared_symbol_is_bound_with_a_signature():
+    for n in _lib.declared_symbols():
+        fn = getattr(_lib.lib, n)
+        assert fn.argtypes is not None, '%s has no ctypes signature in dlwp_amd/_lib.py' % n
+
+
+def test_version_and_error_string():
+    assert _lib.lib.dlwp_version() >= 100
+    assert isinstance(_lib.lib.dlwp_last_error(), bytes)
+
+
+def test_struct_layouts_match_the_header():
+    # sizes implied by include/dlwp_hip.h (all-int structs, no padding)
+    assert ctypes.sizeof(_lib.Shape4) == 16
+    assert ctypes.sizeof(_lib.Pad2d) == 24
+    assert ctypes.sizeof(_lib.Conv2d) == 5 * 4 + 24 + 10 * 4     # ... src_mode, out_pool, out_d2s, lstm_f, lstm_rec_act
+    # + aux[4], then the second source of a whole-step op: src2, w2, xs2_c, conv2
+    assert ctypes.sizeof(_lib.Op) == 5 * 4 + 16 + ctypes.sizeof(_lib.Conv2d) + 24 + 4 * 4 + 3 * 4 + ctypes.sizeof(_lib.Conv2d)
+
+
+def test_conv_out_shape_and_validation_without_a_device():
+    from dlwp_amd import ops
+    cd = ops.make_conv(32, 3, 3, dil=2, halo=ops.make_pad(2, 2, 2, 2, ops.PAD_ZERO, ops.PAD_WRAP), act=ops.ACT_TANH)
+    ys = ops.conv_out_shape(_lib.Shape4(3, 4, 88, 180), cd)
+    assert (ys.n, ys.c, ys.h, ys.w) == (3, 32, 88, 180)
+    cd.src_mode = ops.SRC_MAXPOOL2
+    ys = ops.conv_out_shape(_lib.Shape4(3, 4, 88, 180), cd)
+    assert (ys.h, ys.w) == (44, 90)
+    cd.src_mode = ops.SRC_UPSAMPLE2
+    ys = ops.conv_out_shape(_lib.Shape4(3, 4, 22, 45), cd)
+    assert (ys.h, ys.w) == (44, 90)
+    # the reference's periodic slices do not tile: halo > axis is an error (custom.py:197-200)
+    bad = ops.make_conv(4, 3, 3, halo=ops.make_pad(0, 0, 7, 7, ops.PAD_ZERO, ops.PAD_WRAP))
+    with pytest.raises(_lib.DlwpError, match='column halo'):
+        ops.conv_out_shape(_lib.Shape4(1, 1, 5, 6), bad)
+    with pytest.raises(_lib.DlwpError, match='larger than the padded input'):
+        ops.conv_out_shape(_lib.Shape4(1, 1, 3, 3), ops.make_conv(4, 5, 5))
+    with pytest.raises(_lib.DlwpError, match='output channel window'):
+        ops.conv_out_shape(_lib.Shape4(1, 1, 8, 8), ops.make_conv(4, 3, 3, out_c_off=2, out_c_total=4))
+    # interleaved phase stores: 4 F channels -> F fields at twice the resolution, window counted in fields
+    ys = ops.conv_out_shape(_lib.Shape4(2, 8, 10, 12), ops.make_conv(16, 3, 3, halo=ops.make_pad(1, 1, 1, 1), out_c_off=1,
+                                                                   out_c_total=5, out_d2s=True))
+    assert (ys.n, ys.c, ys.h, ys.w) == (2, 4, 20, 24)
+    with pytest.raises(_lib.DlwpError, match='out_d2s'):
+        ops.conv_out_shape(_lib.Shape4(1, 1, 8, 8), ops.make_conv(6, 3, 3, out_d2s=True))
+
+
+def test_compiled_tile_configurations_cover_the_unet_layers():
+    from dlwp_amd import ops
+    cfgs = ops.conv_configs()
+    kinds = {(c[0], c[1]) for c in cfgs}
+    assert {(3, 1), (3, 2), (5, 1)} <= kinds
+    for c in cfgs:
+        ks, dil, th, tw, waves, fa, bnf, ck, pool, lds, flags = c
+        pixels = th * tw if bnf > 0 else th * tw // (-bnf)          # packed-N instances tile super-pixels
+        if fa == 0:                                                 # Winograd instance: 2x2 tiles, one fragment / wave
+            pixels, fa = th * tw // 4, 1
+        assert pixels <= 16 * fa * waves and lds <= 160 * 1024 and ck % 4 == 0
+
+
+def test_bench_kernel_symbols_match_the_committed_profiles():
+    """bench.py quotes rocprofv3's average duration and the PMC traffic of the dominant kernel from profiles/ by kernel
+    symbol.  The symbol it composes from a tile configuration has to be the one the library really emits (template
+    arguments included), or the lookup silently falls back to an older summary: every forward kernel of the newest
+    same-source kernel-stats summary must be found by the name bench.py would compose for it."""
+    import csv, glob, json, os, re, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    sha = bench.kernel_source_hash()
+    found = 0
+    for meta_file in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*kernel_stats.meta.json')), reverse=True):
+        meta = json.load(open(meta_file))
+        if meta.get('source_sha') != sha:
+            continue
+        names = [r['Name'] for r in csv.DictReader(open(meta_file[:-len('.meta.json')] + '.csv'))]
+        for n in names:
+            m = re.search(r'conv2d_fwd_wino_f32<WinoCfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), false, (true|false)', n)
+            if m:
+                dil, th, tw, waves, bnf, ck = map(int, m.groups()[:6])
+                sym = bench.config_symbol((3, dil, th, tw, waves, 0, bnf, ck, 0, 0, 0), ups=m.group(7) == 'true')
+                assert sym in n, (sym, n)
+                found += 1
+            m = re.search(r'conv2d_fwd_wino2_f32<WinoSplitCfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), false', n)
+            if m:
+                dil, th, tw, waves, bnf, ck = map(int, m.groups())
+                sym = bench.config_symbol((3, dil, th, tw, waves, 0, bnf, ck, 0, 0, 1))
+                assert sym in n, (sym, n)
+                found += 1
+            m = re.search(r'conv2d_fwd_mfma_f32<ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false)', n)
+            if m:
+                v = list(map(int, m.groups()[:8]))
+                sym = bench.config_symbol(tuple(v) + (1 if m.group(9) == 'true' else 0,))
+                assert sym in n, (sym, n)
+                found += 1
+            m = re.search(r'conv2d_fwd_few_f32<(\d+), ', n)
+            if m:         # the streaming layer-1 kernel: bench.py's time_layers composes this prefix for launch-info config -2
+                assert "'conv2d_fwd_few_f32<%d, ' % dil_run[0]" in open(os.path.join(ROOT, 'bench.py')).read()
+                found += 1
+        break
+    else:
+        pytest.skip('no kernel-stats summary of the current kernel source in profiles/')
+    assert found >= 3
+    ent = bench.rocprof_launch_ms('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false> >', 256)
+    assert ent and ent['same_source']
+    traffic, src = bench.measured_traffic('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false> >', 256)
+    assert traffic and 2.0e8 < traffic < 4.0e8, (traffic, src)
+
+
+def test_streaming_kernel_item_order_visits_every_tile_of_every_sample_once():
+    """csrc/conv_fwd_few.hip hands (tile position, sample) items to its persistent workgroups by integer arithmetic alone: sample
+    groups as long as a share, positions inside a group, samples inside a position; block b -> logical index (XCD b % 8, slot);
+    share = [T L / grid, T (L + 1) / grid); a ragged last group.  The same arithmetic restated here must visit every item exactly
+    once for any batch, tiling and grid (the GPU tests compare the kernel's results at a handful of sizes; this covers the corners:
+    one member, more workgroups than items, groups longer than the batch, 2101 members)."""
+    def visit(n, npos, grid):
+        total = npos * n
+        group = (total + grid // 2) // grid
+        group = 4 if group < 4 else (n if group > n else group)
+        seen = set()
+        for b in range(grid):
+            xcd, idx, q, r = b & 7, b >> 3, grid >> 3, grid & 7
+            lidx = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+            it = total * lidx // grid
+            left = total * (lidx + 1) // grid - it
+            if left <= 0:
+                continue
+            per = npos * group
+            sg, rem = divmod(it, per)
+            g0 = sg * group
+            gs = min(group, n - g0)
+            pos, sn = divmod(rem, gs)
+            for _ in range(left):
+                assert 0 <= pos < npos and 0 <= g0 + sn < n and gs > 0
+                assert (pos, g0 + sn) not in seen
+                seen.add((pos, g0 + sn))
+                sn += 1
+                if sn == gs:
+                    sn, pos = 0, pos + 1
+                    if pos == npos:
+                        pos, g0 = 0, g0 + gs
+                        gs = min(group, n - g0)
+        assert len(seen) == total, (n, npos, grid)
+    for n in list(range(1, 20)) + [63, 64, 65, 200, 256, 257, 1031, 2101]:
+        for npos in (1, 6, 66):
+            for grid in (1, 7, 30, 768, 1024):
+                visit(n, npos, min(grid, npos * n))

@@ -20,6 +20,51 @@ void dlwp_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Debug aid (DLWP_SEGV_TRACE=1 in the environment, read at the first dlwp_create): a SIGSEGV prints the NATIVE backtrace (module +
+// offset per frame, glibc backtrace_symbols_fd) before the handler that was installed before runs -- Python's faulthandler shows
+// the interpreter's frames only, and a fault inside the HIP runtime (r4: hipGraphLaunch of a forked graph) has none of ours.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static struct sigaction g_prev_segv;
+static void segv_trace(int sig, siginfo_t* info, void* ctx) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "\n[dlwp] SIGSEGV -- native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  {
+    char b[96];
+    const int k = snprintf(b, sizeof(b), "[dlwp] fault address %p\n", info ? info->si_addr : nullptr);
+    (void)!write(2, b, k);
+  }
+  backtrace_symbols_fd(frames, n, 2);
+  if (g_prev_segv.sa_flags & SA_SIGINFO) {
+    if (g_prev_segv.sa_sigaction) g_prev_segv.sa_sigaction(sig, info, ctx);
+  } else if (g_prev_segv.sa_handler && g_prev_segv.sa_handler != SIG_DFL && g_prev_segv.sa_handler != SIG_IGN) {
+    g_prev_segv.sa_handler(sig);
+  }
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+static void install_segv_trace() {
+  static bool done = false;
+  if (done || !getenv("DLWP_SEGV_TRACE")) return;
+  done = true;
+  // an alternate signal stack for this (the calling) thread: a fault that is a stack overflow leaves no room for a handler
+  static char alt[1 << 16];
+  stack_t ss;
+  ss.ss_sp = alt;
+  ss.ss_size = sizeof(alt);
+  ss.ss_flags = 0;
+  (void)sigaltstack(&ss, nullptr);
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = segv_trace;
+  sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+  sigemptyset(&sa.sa_mask);
+  sigaction(SIGSEGV, &sa, &g_prev_segv);
+}
+
 static dlwp_options& default_options_rw() {
   static dlwp_options d = [] {
     dlwp_options o;
@@ -74,6 +119,7 @@ const char* dlwp_last_error(void) { return g_err; }
 
 int dlwp_create(dlwp_handle_t* out, int device) {
   DLWP_CHECK_ARG(out != nullptr, "dlwp_create: null output pointer");
+  install_segv_trace();
   int count = 0;
   DLWP_HIP(hipGetDeviceCount(&count));
   DLWP_CHECK_ARG(device >= 0 && device < count, "dlwp_create: device %d out of range (%d visible)", device, count);
@@ -93,6 +139,7 @@ int dlwp_create(dlwp_handle_t* out, int device) {
   h->prep_defer = h->n_prep = h->red_defer = h->n_red = 0;
   h->prep_owner = h->red_owner = 0;
   h->ksplit_mem = nullptr;
+  h->uncached = nullptr;
   h->ksplit_used = 0;
   for (int i = 0; i < DLWP_SPLITK_REGIONS; ++i) h->ksplit_stream[i] = nullptr;
   *out = h;

@@ -61,7 +61,8 @@ struct dlwp_train_step {
   int n_lanes, n_launches, n_waits;
   std::vector<hipStream_t> side;        // lanes 1 .. n_lanes - 1 (library-owned)
   std::vector<hipEvent_t> events;       // one per wait record
-  hipStream_t cap;                      // capture stream of the graph forms
+  hipStream_t cap;                      // capture stream of the graph forms (and the launch stream of the branched one)
+  hipEvent_t order[2];                  // ... its ordering against the caller's stream
   hipGraph_t graph[2];
   hipGraphExec_t exec[2];               // [0]: every lane on one stream, [1]: lanes as graph branches
   // fixed input buffers the recorded launches read; dlwp_train_step_launch copies the batch there first
@@ -182,7 +183,10 @@ int dlwp_train_step_create(dlwp_handle_t h, int n_in, void* const* in_dst, const
     st->in_floats[i] = in_floats[i];
   }
   for (const Rec& r : st->recs) (r.wait_on >= 0 ? st->n_waits : st->n_launches)++;
+  st->order[0] = st->order[1] = nullptr;
   bool ok = hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&st->order[0], hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&st->order[1], hipEventDisableTiming) == hipSuccess;
   for (int i = 1; i < st->n_lanes && ok; ++i) {
     hipStream_t s = nullptr;
     ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
@@ -232,17 +236,30 @@ int dlwp_train_step_launch(dlwp_train_step_t st, const void* const* srcs, int mo
     const int rc = build_graph(st, b);
     if (rc != DLWP_OK) return rc;
   }
+  if (b) {     // a graph with branches: on the step's own stream, ordered against the caller's (rollout.hip: dlwp_rollout_launch)
+    DLWP_HIP(hipEventRecord(st->order[0], (hipStream_t)stream));
+    DLWP_HIP(hipStreamWaitEvent(st->cap, st->order[0], 0));
+    DLWP_HIP(hipGraphLaunch(st->exec[b], st->cap));
+    DLWP_HIP(hipEventRecord(st->order[1], st->cap));
+    DLWP_HIP(hipStreamWaitEvent((hipStream_t)stream, st->order[1], 0));
+    return DLWP_OK;
+  }
   DLWP_HIP(hipGraphLaunch(st->exec[b], (hipStream_t)stream));
   return DLWP_OK;
 }
 
 int dlwp_train_step_destroy(dlwp_train_step_t st) {
   if (!st) return DLWP_OK;
+  // nothing of the step may still be in flight when its graphs, streams and events go (finalisers run at arbitrary points: r4 saw
+  // hipGraphLaunch of a LATER graph fault in the first full-suite run on a fresh box, 5 of 6 boxes)
+  (void)hipDeviceSynchronize();
   for (int b = 0; b < 2; ++b) {
     if (st->exec[b]) (void)hipGraphExecDestroy(st->exec[b]);
     if (st->graph[b]) (void)hipGraphDestroy(st->graph[b]);
   }
   for (hipEvent_t e : st->events) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i)
+    if (st->order[i]) (void)hipEventDestroy(st->order[i]);
   for (hipStream_t s : st->side) (void)hipStreamDestroy(s);
   if (st->cap) (void)hipStreamDestroy(st->cap);
   delete st;
