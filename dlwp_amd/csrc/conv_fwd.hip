@@ -739,6 +739,12 @@ int few_stream_grid(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, c
   const long long items = (long long)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 32) * a.N;
   const long long slots = 3ll * h->cu_count;
   if (h->opt.few_stream == 1 && 2 * items < 5 * slots) return 0;
+  // r4: the kernel can also store the layer's own output -- alone or beside the pooled image (FewCfg OUT 1 / 2:
+  // same bits as the general instance, tests/test_gpu_kernels.py) -- but that is no faster: 91 x 180 x 256 members unpooled 0.2486 ms
+  // against the general instance's 0.2426 (gpurun_out/s11), the batch-64 training step 1.4287 against 1.4299 ms.  The launch
+  // writes 537 MB behind ~113 us of matrix + vector work; what bounds it is the write stream itself (2.2 TB/s of 16-byte pieces in
+  // 64 cache lines per store instruction either way), not the workgroups' lifetime.  Taken only when asked for (few_stream = 2).
+  if (h->opt.few_stream == 1 && (a.out_pool != 1 || a.y2)) return 0;
   return (int)(items < slots ? items : slots);
 }
 
