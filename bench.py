@@ -247,6 +247,8 @@ def time_layers(model, members, iters=5):
                 return config_symbol(cfgs[i[0]], ups)
             if i[0] == -2:      # dlwp_conv2d_launch_info: the few-channel streaming kernel (csrc/conv_fwd_few.hip), <DIL, ACT, QUAD>
                 return 'conv2d_fwd_few_f32<%d, ' % dil_run[0]
+            if i[0] == -3:      # ... the streaming position-split Winograd kernel (csrc/conv_fwd_wino2s.hip), <chunks, depth-to-space>
+                return 'conv2d_fwd_wino2s_f32<%d, ' % ((op.xs[0] + 7) // 8)
             return 'conv2d_fwd_direct_f32'
         launch_flops = [(symbol_of(i), i[3]) for i in info]
         cfg = cfgs[info[0][0]] if info and info[0][0] >= 0 else None

@@ -748,6 +748,21 @@ int few_stream_grid(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, c
   return (int)(items < slots ? items : slots);
 }
 
+// conv_fwd_wino2s.hip instead of the chosen position-split Winograd instance (16-channel blocks: the restated output layer)?
+// Returns the grid (0: no).  Same bits as every non-COMPAT instance of conv_fwd_wino2_kernel.h, so the choice may depend on the
+// batch.  Grid = 2 workgroups of 512 threads per CU (73 KB of LDS each); taken from 2.5 items per workgroup on, as the other
+// streaming kernel, and under the same option (DLWP_OPT_FEW_STREAM: 0 never, 2 whenever the layer qualifies).
+int wino2s_grid(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, const LaunchPlan& lp) {
+  if (h->opt.few_stream == 0 || h->opt.forced_cfg >= 0 || lp.primary < 0 || lp.narrow >= 0 || lp.pair_vw != 0 || lp.ksplit > 1) return 0;
+  const ConvKernelEntry& e = registry().entries[lp.primary];
+  if (!is_wino(e) || e.split != 1 || e.bnf != 1 || e.dil != 1 || e.pool != 0 || cd->dil_h != 1 || cd->dil_w != 1) return 0;
+  if (!dlwp_conv_wino2s_covers(a)) return 0;
+  const long long items = (long long)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 16) * a.N;
+  const long long slots = 2ll * h->cu_count;
+  if (h->opt.few_stream == 1 && 2 * items < 5 * slots) return 0;
+  return (int)(items < slots ? items : slots);
+}
+
 }  // namespace (second part)
 
 int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
@@ -871,6 +886,16 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
       a.kslab = (float*)(ws + DLWP_SPLITK_COUNTER_BYTES);
       grid *= lp.ksplit;
       DLWP_CHECK_ARG(grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
+    }
+  }
+  if (!lstm && !act_epi && !y_pool) {
+    if (const int sg = wino2s_grid(h, a, cd, lp)) {   // the streaming form of the 16-channel-block instance (same bits)
+      a.tiles_h = dlwp_ceil_div(a.Ho, 8);
+      a.tiles_w = dlwp_ceil_div(a.Wo, 32);
+      a.cout_tiles = dlwp_ceil_div(a.Cout, 16);
+      if (dlwp_conv_wino2s_launch(a, sg, s) != 0) DLWP_FAIL(DLWP_EHIP, "dlwp_conv2d_fwd: hipFuncSetAttribute failed");
+      DLWP_LAUNCH_CHECK("conv2d_fwd_wino2s_f32");
+      return DLWP_OK;
     }
   }
   e.launch(a, (int)grid, s);
@@ -1366,6 +1391,12 @@ int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
     return 64 * k.waves * ((is_wino(k) && k.split && !wino_skips_row2(a)) ? 2 : 1);
   };
   plan_splitk(h, a, cd, &lp, false, DLWP_SPLITK_REGION_BYTES);     // (grid = workgroups launched: tiles x splits; same matrix work)
+  if (const int sg = wino2s_grid(h, a, cd, lp)) {   // config -3: conv_fwd_wino2s.hip -- the instance's matrix work, 2 workgroups per CU
+    const long long g832 = (long long)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 16) * a.N;
+    out2[0] = dlwp_launch_info{-3, sg, 512, 2.0 * 64.0 * 16.0 * 16.0 * 8.0 * ((a.Cin + 7) / 8) * (double)g832, 0};
+    *n_launches = 1;
+    return DLWP_OK;
+  }
   out2[0] = dlwp_launch_info{lp.primary, (int)(lp.grid * lp.ksplit), threads(e), executed_matrix_flops(e, a, lp.grid),
                              is_bf16(e) ? 1 : 0};
   *n_launches = 1;

@@ -616,4 +616,7 @@ static int conv_prepare() {
 // -- same tiles, same bits -- when the batch gives every workgroup several samples to walk over (DLWP_OPT_FEW_STREAM).
 bool dlwp_conv_few_covers(const ConvArgs& a, int ks, int dil_h, int dil_w);
 void dlwp_conv_few_launch(const ConvArgs& a, int dil, int grid, hipStream_t s);
+// conv_fwd_wino2s.hip: the streaming form of the position-split Winograd kernel for 16-output-channel blocks
+bool dlwp_conv_wino2s_covers(const ConvArgs& a);
+int dlwp_conv_wino2s_launch(const ConvArgs& a, int grid, hipStream_t s);
 

@@ -125,7 +125,10 @@ int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, cha
 #define DLWP_OPT_FEW_STREAM         6  /* 3x3 layers of at most 4 input channels under a pooling epilogue (the first layer):
                                         * the streaming kernel that keeps the weights in registers and walks over the samples
                                         * (csrc/conv_fwd_few.hip) -- 1 (default): from 8 tiles per workgroup on, 0: never,
-                                        * 2: whenever the layer qualifies.  Same bits as the direct family's instance         */
+                                        * 2: whenever the layer qualifies.  Same bits as the direct family's instance.  r4: the
+                                        * same switch selects the streaming form of the 16-output-channel Winograd blocks
+                                        * (csrc/conv_fwd_wino2s.hip: at most 32 input channels, filters resident in LDS; the
+                                        * restated output layer) -- the bits of the position-split instance it stands in for   */
 #define DLWP_OPT_SPLITK             7  /* Winograd layers on SMALL grids (a launch under one round of resident workgroups: an
                                         * ensemble share of 1 ... 8 members, 8 training samples per rank): the input channels are
                                         * divided over several workgroups per output tile; the last one to arrive sums the partial
@@ -217,8 +220,9 @@ int dlwp_conv2d_pick_config(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd
  * padded GEMM volume its MFMA instructions multiply, 2 FLOP per multiply-add, tile / channel padding included and with
  * Winograd's 16 (9) multiplies per 2x2 outputs instead of the direct 36.  For the fp32 families this is exactly
  * SQ_INSTS_MFMA x 2048 (v_mfma_f32_16x16x4_f32) of a rocprofv3 --pmc pass.  config: index for dlwp_conv2d_config_info
- * (-1: the one-thread-per-output vector kernel, no matrix work; -2: the streaming kernel of DLWP_OPT_FEW_STREAM, whose grid
- * is a number of persistent workgroups, not of tiles).  out2 must hold 2 entries.                                         */
+ * (-1: the one-thread-per-output vector kernel, no matrix work; -2 / -3: the streaming kernels of DLWP_OPT_FEW_STREAM -- few
+ * input channels under a pooling epilogue / 16-output-channel Winograd blocks --, whose grid is a number of persistent
+ * workgroups, not of tiles).  out2 must hold 2 entries.                                                                   */
 typedef struct {
   int config, grid, block_threads;
   double matrix_flops;

@@ -491,6 +491,88 @@ def test_winograd_compat_split_instances_give_the_bits_of_the_32_channel_kernel(
     assert torch.equal(ops.conv2d(x, wt, b, cd), seen)
 
 
+def test_position_split_streaming_kernel_equals_the_general_instance(ops):
+    """csrc/conv_fwd_wino2s.hip (16-output-channel Winograd blocks with the transformed filters resident in LDS, a workgroup walks
+    over the samples of one tile position -- the restated output layer at large batches): the bits of the position-split instance
+    it stands in for, and the float64 oracle.  The depth-to-space store and the plain one, 2 and 4 channel chunks with ragged
+    channel counts, ragged tiles in both directions, 16 / 48 output channels (a workgroup's share crosses filter blocks), every
+    activation, channel windows on both sides, batches that leave a workgroup one item and several (position changes)."""
+    rng = np.random.default_rng(4242)
+    cases = [  # n, cin, h, w, cout, mode_h, mode_w, act, d2s
+        (24, 32, 44, 90, 16, 0, 1, 'linear', True),      # the U-Net's restated output layer
+        (5, 16, 19, 44, 48, 0, 1, 'tanh', False),
+        (7, 30, 20, 70, 16, 2, 1, 'relu', True),
+        (130, 14, 10, 36, 16, 1, 0, 'tanh', False),
+        (3, 32, 16, 64, 48, 0, 2, 'linear', False),
+        (1, 29, 9, 34, 16, 0, 1, 'tanh', True),
+    ]
+    for n, cin, h, w, cout, mh, mw, act, d2s in cases:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+        b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+        cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, mh, mw), ops.ACTIVATIONS[act], out_d2s=d2s)
+        xd, wd, bd = dev(x), dev(wt), dev(b)
+        prev = ops.set_few_stream(0)
+        try:
+            base = ops.conv2d(xd, wd, bd, cd)
+            assert ops.conv_launch_info(x.shape, cd)[0][0] >= 0
+            ops.set_few_stream(2)
+            info = ops.conv_launch_info(x.shape, cd)
+            assert info[0][0] == -3 and info[0][2] == 512, info
+            got = ops.conv2d(xd, wd, bd, cd)
+        finally:
+            ops.set_few_stream(prev)
+        assert torch.equal(got, base), (n, cin, h, w, cout, float((got - base).abs().max()))
+        if n <= 7:
+            want = _conv_ref(x, wt, b, 1, (1, 1, 1, 1), mh, mw, act, 0)
+            if d2s:
+                want = np_ref.depth_to_space2(want, cout // 4)
+            _check_conv(ops, host(got), want, 'position-split stream %r' % ((n, cin, h, w, cout),))
+    # channel windows: 24 of 40 stored input channels from channel 8; 4 fields into channels 2.. of a 7-field tensor
+    n, h, w = 9, 20, 70
+    x40 = rng.standard_normal((n, 40, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, 24, 16), rng)
+    b = (0.1 * rng.standard_normal(16)).astype(np.float32)
+    cd = ops.make_conv(16, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, in_c_off=8, in_c_total=40, out_c_off=2,
+                       out_c_total=7, out_d2s=True)
+    outs = []
+    prev = ops.set_few_stream(0)
+    try:
+        for mode in (0, 2):
+            ops.set_few_stream(mode)
+            y = torch.full((n, 7, 2 * h, 2 * w), 7.0, device='cuda')
+            ops.conv2d(dev(x40), dev(wt), dev(b), cd, out=y, x_channels=24)
+            outs.append(y)
+    finally:
+        ops.set_few_stream(prev)
+    assert torch.equal(outs[0], outs[1])
+    want = np_ref.depth_to_space2(_conv_ref(x40[:, 8:32], wt, b, 1, (1, 1, 1, 1), 0, 1, 'tanh', 0), 4)
+    _check_conv(ops, host(outs[1][:, 2:6]), want, 'position-split stream, channel windows')
+    assert float(outs[1][:, :2].min()) == 7.0 and float(outs[1][:, 6:].max()) == 7.0
+
+
+def test_position_split_streaming_kernel_is_chosen_by_batch_size(ops):
+    """DLWP_OPT_FEW_STREAM = 1 (default): the restated output layer of the 88 x 180 U-Net (32 -> 16 phase channels at 44 x 90,
+    stored depth-to-space) goes to the streaming kernel from 2.5 tiles per resident workgroup on (2 per CU), the general instance
+    below; never with more than 32 input channels, a pooling epilogue, 32-channel blocks, or bfloat16 storage."""
+    cd = ops.make_conv(16, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_LINEAR, out_d2s=True)
+    g = ops.conv_launch_info((256, 32, 44, 90), cd)[0]
+    assert g[0] == -3 and g[2] == 512 and g[1] % 2 == 0, g
+    assert g[3] == 2.0 * 1024 * 16 * 32 * 6 * 3 * 256       # 64 tiles x 16 positions x 16 channels x 32 inputs per item
+    assert ops.conv_launch_info((128, 32, 44, 90), cd)[0][0] == -3
+    assert ops.conv_launch_info((32, 32, 44, 90), cd)[0][0] >= 0
+    assert ops.conv_launch_info((1, 32, 44, 90), cd)[0][0] >= 0
+    assert ops.conv_launch_info((256, 40, 44, 90), cd)[0][0] >= 0
+    assert ops.conv_launch_info((256, 32, 44, 90), ops.make_conv(32, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH))[0][0] >= 0
+    assert ops.conv_launch_info((256, 32, 44, 90), ops.make_conv(16, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH,
+                                                                   out_pool=True))[0][0] >= 0
+    prev = ops.set_few_stream(0)
+    try:
+        assert ops.conv_launch_info((256, 32, 44, 90), cd)[0][0] >= 0
+    finally:
+        ops.set_few_stream(prev)
+
+
 @pytest.mark.parametrize('fields,hw', [(4, (20, 70)), (12, (19, 45)), (4, (44, 90))])
 def test_winograd_phase_channels_stored_interleaved(ops, fields, hw):
     """dlwp_conv2d.out_d2s: the 4 F output channels are the 2x2 phases of F fields (phase-major) and the 16-channel Winograd

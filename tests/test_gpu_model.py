@@ -208,6 +208,34 @@ def test_full_size_ensemble_beyond_a_thousand_members(n):
     assert isinstance(host, np.ndarray) and np.array_equal(host, dev.cpu().numpy())
 
 
+def test_headline_ensemble_of_256_members_against_the_oracle_directly():
+    """the bench's operating point -- 256 members of the full 88 x 180 grid in one rollout graph, i.e. the
+    streaming layer-1 kernel, sample pairs, the 256-member tile choices, the streaming output layer -- checked against the
+    float64 oracle DIRECTLY (not through a small-ensemble run): members 0, 131 and 255 after the first forward to the parity
+    bar, member 0 after the second forward (its own output fed back) to twice that."""
+    import torch
+    rng = np.random.default_rng(256)
+    cs = (4, 88, 180)
+    layers = unet_layers(cs)
+    d = _build(layers, time_dim=2)
+    weights = _weights_of(d.model, rng)
+    x = rng.standard_normal((256,) + cs).astype(np.float32)
+    dev = d.predict_timeseries(torch.from_numpy(x).cuda(), 4, keep_time_dim=True, return_device=True)   # 2 forwards
+    got = dev.cpu().numpy().reshape((2, 256) + cs)
+    worst = 0.0
+    for m in (0, 131, 255):
+        want = np_ref.run_layers(layers, x[m:m + 1].astype(np.float64), weights)
+        err = _rel(got[0, m:m + 1], want)
+        worst = max(worst, err)
+        assert err < FWD_TOL, (m, err)
+        if m == 0:
+            want2 = np_ref.run_layers(layers, want, weights)
+            err2 = _rel(got[1, :1], want2)
+            assert err2 < 2 * FWD_TOL, err2
+            MEASURED['headline_256_members_second_forward_member_0'] = err2
+    MEASURED['headline_256_members_first_forward_members_0_131_255'] = worst
+
+
 def test_member_sharding_is_bit_identical():
     """Ensemble members are independent: a rollout of a shard equals the same rows of the full rollout (what lets the
     8-GPU run be compared member by member with the 1-GPU run)."""

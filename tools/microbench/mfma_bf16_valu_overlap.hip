@@ -1,7 +1,7 @@
-// mfma_valu_overlap.hip -- does the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, which runs at the fp32 VECTOR rate on
-// gfx950) overlap with vector-ALU work (a) of the same wave, (b) of another wave on the same SIMD?  The Winograd kernels'
-// design hinges on the answer (conv_fwd_wino_kernel.h / conv_fwd_wino2_kernel.h).
-// Build: hipcc -O3 --offload-arch=gfx950 -o mfma_valu_overlap.bin mfma_valu_overlap.hip ; run on an MI355X.
+// mfma_bf16_valu_overlap.hip -- the same question as mfma_valu_overlap.hip for the BF16 matrix instruction
+// (v_mfma_f32_16x16x32_bf16, 16x the fp32 instruction's rate): does it overlap with vector-ALU work (a) of the same wave, (b) of
+// another wave on the same SIMD?  (r4: what a split-bf16 -- 3 limbs, 6 products -- Winograd kernel could hope for)
+// Build: hipcc -O3 --offload-arch=gfx950 -o mfma_bf16_valu_overlap.bin mfma_bf16_valu_overlap.hip ; run on an MI355X.
 // Each kernel: 1 block per CU x `rounds` over all CUs, waves per block = 4 * WPS (WPS waves per SIMD); a loop of ITERS
 // iterations, each iteration = NM MFMAs on NM independent accumulators + NV independent VALU FMAs (+ NT transcendentals)
 // issued by the waves selected with `role`:
@@ -17,6 +17,8 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NM, int NV, int NT, int ROLE>
 __global__ __launch_bounds__(1024) void probe(float* out, long long* cyc, int iters, float seed) {
@@ -31,6 +33,8 @@ __global__ __launch_bounds__(1024) void probe(float* out, long long* cyc, int it
 #pragma unroll
   for (int i = 0; i < (NT > 0 ? NT : 1); ++i) t[i] = seed * 0.001f + i;
   const float a = seed * 0.5f, b = seed * 0.25f;
+  const unsigned ub = __builtin_bit_cast(unsigned, a) >> 16 | (__builtin_bit_cast(unsigned, b) & 0xffff0000u);
+  const bf16x8 a8 = __builtin_bit_cast(bf16x8, (u32x4){ub, ub + threadIdx.x, ub, ub}), b8 = __builtin_bit_cast(bf16x8, (u32x4){ub, ub, ub + 1u, ub});
   const bool do_m = ROLE == 0 || (ROLE == 1 ? (wave & 1) == 0 : ((wave >> 2) & 1) == 0);
   const bool do_v = ROLE == 0 || (ROLE == 1 ? (wave & 1) == 1 : ((wave >> 2) & 1) == 1);
   __syncthreads();
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(1024) void probe(float* out, long long* cyc, int it
   for (int it = 0; it < iters; ++it) {
     if (do_m) {
 #pragma unroll
-      for (int i = 0; i < NM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < NM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[i], 0, 0, 0);
     }
     if (do_v) {
 #pragma unroll

@@ -1,0 +1,35 @@
+#!/bin/bash
+# round-4 final measurements on ONE box: the GPU suite (first run on the box), rocprofv3 kernel stats + PMC passes of the bench command,
+# config 4, config 5 at 4 members, 8 members of config 2, the training step (kernel stats + executed MFMA instructions), the bench line.
+# Everything lands in gpurun_out/prof (copy what should be judged into profiles/).
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof; mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+if [ "$1" != "--no-tests" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q > $O/r4_pytest.log 2>&1; echo "pytest rc=$? $(grep -E 'passed|failed' $O/r4_pytest.log | tail -1)"
+  cp gpurun_out/forward_errors.json $O/r4_forward_errors.json 2>/dev/null
+fi
+bash tools/profile_bench.sh r4 > $O/r4_profile_bench.log 2>&1; tail -30 $O/r4_profile_bench.log | cut -c1-200
+bash tools/profile_cfg4.sh r4 8 > $O/r4_profile_cfg4.log 2>&1; tail -12 $O/r4_profile_cfg4.log | cut -c1-200
+cd /tmp
+for b in 64 8; do
+  rocprofv3 --kernel-trace --stats -d $O/tr$b -o s --output-format csv -- python $R/tools/bench_train.py --batch $b --steps 40 --warmup 10 > $O/r4_train_b$b.json 2> $O/tr$b.err
+  cp $(find $O/tr$b -name '*kernel_stats.csv' | head -1) $O/r4_train_b${b}_kernel_stats.csv
+  rm -rf $O/tr$b
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA -d $O/trm$b -o p --output-format csv -- python $R/tools/bench_train.py --batch $b --steps 20 --warmup 10 > /dev/null 2> $O/trm$b.err
+  python $R/tools/parse_train_mfma.py $O/r4_train_mfma_b$b.json $O/trm$b --batch $b
+  rm -rf $O/trm$b
+done
+# config 5 (1-degree grid, 12 channels) at 4 members = one GPU's share of 32 members on 8; config 2 at 8 members
+rocprofv3 --kernel-trace --stats -d $O/c5 -o s --output-format csv -- python $R/bench.py --grid 180x360 --channels 12 --members 4 --forwards 40 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/r4_bench_cfg5_m4.json 2> $O/c5.err
+cp $(find $O/c5 -name '*kernel_stats.csv' | head -1) $O/r4_cfg5_m4_kernel_stats.csv; rm -rf $O/c5
+rocprofv3 --kernel-trace --stats -d $O/c2 -o s --output-format csv -- python $R/bench.py --members 8 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/r4_bench_cfg2_m8.json 2> $O/c2.err
+cp $(find $O/c2 -name '*kernel_stats.csv' | head -1) $O/r4_cfg2_m8_kernel_stats.csv; rm -rf $O/c2
+cd $R
+for b in 64 8; do python tools/bench_train.py --batch $b --steps 40 --warmup 20 > $O/r4_train_b${b}_noprof.json 2>/dev/null; tail -1 $O/r4_train_b${b}_noprof.json | cut -c1-300; done
+python tools/bench_layer6.py > $O/r4_layer6.json 2>/dev/null; cat $O/r4_layer6.json
+# the bench line quotes the rocprofv3 / PMC summaries of THIS kernel source from profiles/: put the fresh ones there first
+for f in r4_kernel_stats.csv r4_kernel_stats.meta.json r4_hbm_traffic_b256.json r4_mfma_busy.json r4_train_mfma_b64.json r4_train_mfma_b8.json; do cp $O/$f $R/profiles/$f; done
+timeout 900 python bench.py > $O/r4_bench.json 2> $O/r4_bench.err; echo "bench rc=$?"; tail -1 $O/r4_bench.json | cut -c1-400
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/cfg4_stats $O/cfg4_fetch $O/cfg4_write
