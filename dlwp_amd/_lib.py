@@ -182,6 +182,9 @@ _sig('dlwp_prepare_begin', [_vp])
 _sig('dlwp_prepare_flush', [_vp, _vp])
 _sig('dlwp_reductions_begin', [_vp])
 _sig('dlwp_reductions_flush', [_vp, _vp])
+_sig('dlwp_pair_begin', [_vp])
+_sig('dlwp_pair_end', [_vp, _vp])
+_sig('dlwp_pair_fused_count', [_vp], ctypes.c_longlong)
 _sig('dlwp_conv2d_bwd_data_prepared_bytes', [_vp, Shape4, _P(Conv2d), _i], _sz)
 _sig('dlwp_conv2d_bwd_data_prepare', [_vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp])
 _sig('dlwp_conv2d_bwd_data_prepared', [_vp, _vp, _vp, _vp, Shape4, _P(Conv2d), _i, _vp, _sz, _i, _vp])

@@ -1,5 +1,6 @@
 // api.hip -- handle lifetime, error string, version.
 #include "common.h"
+#include "conv_pair.h"
 #include <cstdlib>
 #include <string>
 #include <condition_variable>
@@ -140,6 +141,7 @@ int dlwp_create(dlwp_handle_t* out, int device) {
   h->prep_owner = h->red_owner = 0;
   h->ksplit_mem = nullptr;
   h->uncached = nullptr;
+  h->pair = nullptr;
   h->ksplit_used = 0;
   for (int i = 0; i < DLWP_SPLITK_REGIONS; ++i) h->ksplit_stream[i] = nullptr;
   *out = h;
@@ -149,6 +151,7 @@ int dlwp_create(dlwp_handle_t* out, int device) {
 int dlwp_destroy(dlwp_handle_t h) {
   if (h && h->wino_u) (void)hipFree(h->wino_u);
   if (h && h->ksplit_mem) (void)hipFree(h->ksplit_mem);
+  dlwp_pair_free(h);
   delete h;
   return DLWP_OK;
 }

@@ -68,6 +68,7 @@ struct dlwp_handle {
   void* ksplit_stream[DLWP_SPLITK_REGIONS];
   int ksplit_used;
   struct dlwp_uncached_pool* uncached;      // rollout graphs' split-K regions (conv_fwd.hip: dlwp_uncached_take)
+  struct dlwp_pair_state* pair;             // dlwp_pair_begin / _end (conv_pair.hip)
 };
 
 

@@ -2,6 +2,7 @@
 // weights) and weight gradient (conv_wgrad_kernel.h).  These are the backward halves of the Keras train step that
 // DLWPNeuralNet.fit / fit_generator drive (DLWP/model/models.py:188-228; layers of examples/train.py:159-219).
 #include "conv_wgrad_cb_kernel.h"
+#include "conv_pair.h"
 #include "conv_wgrad_c4_kernel.h"
 #include "tape.h"
 #include <mutex>
@@ -292,7 +293,12 @@ static int conv2d_bwd_data_impl(dlwp_handle_t h, const void* dz, const void* w, 
     if (rb == 0) return dlwp_launch_reduce_slabs(h, ae.bpart, (float*)db_in, xs.c, S, 0, s);
     return DLWP_OK;
   }
-  if (p.fast) return dlwp_launch_conv2d(h, dz, wt, nullptr, dx, p.zs, &p.g, dtype, s, u_pre);
+  if (p.fast) {      // (inside dlwp_pair_begin / _end this launch may leave with the layer's weight gradient: conv_pair.h)
+    if (h->pair) dlwp_pair_allow_fwd(h, 1);
+    rc = dlwp_launch_conv2d(h, dz, wt, nullptr, dx, p.zs, &p.g, dtype, s, u_pre);
+    if (h->pair) dlwp_pair_allow_fwd(h, 0);
+    return rc;
+  }
   float* padded = (float*)rest;
   rc = dlwp_launch_conv2d(h, dz, wt, nullptr, padded, p.zs, &p.g, dtype, s, u_pre);
   if (rc != DLWP_OK) return rc;
@@ -433,8 +439,14 @@ static int conv2d_bwd_weight_impl(dlwp_handle_t h, const void* x, const void* dz
     a.act = act;
   }
   const int grid = c.ci_groups * c.co_tiles * c.splits;
-  e.launch(a, grid, (hipStream_t)stream);
-  DLWP_LAUNCH_CHECK("conv2d_wgrad_mfma_f32");
+  // between dlwp_pair_begin / _end a channel-block Winograd launch is handed over: it may leave in one grid with the layer's data
+  // gradient (conv_pair.h); the slab sums below are recorded / issued behind it as usual (dlwp_pair_end comes first on the stream)
+  const bool handed_over = h->pair && e.wino == 3 && !dpool &&
+                           dlwp_pair_stash_wgrad(h, a, e.th, e.tw, e.waves, e.nt, e.cib, grid, e.launch, (hipStream_t)stream);
+  if (!handed_over) {
+    e.launch(a, grid, (hipStream_t)stream);
+    DLWP_LAUNCH_CHECK("conv2d_wgrad_mfma_f32");
+  }
   // between dlwp_reductions_begin / _flush the slab sum is recorded and done with the other layers' in one launch
   if (db) {
     const int rb = dlwp_reduce_defer(h, bias_part, (float*)db, cd->cout, c.nslabs, 1, cd->cout, 1.0f, accumulate, (hipStream_t)stream);
@@ -446,6 +458,11 @@ static int conv2d_bwd_weight_impl(dlwp_handle_t h, const void* x, const void* dz
   }
   const int rd = dlwp_reduce_defer(h, (const float*)ws, (float*)dw, wn, c.nslabs, 1, wn, 1.0f, accumulate, (hipStream_t)stream);
   if (rd != 0) return rd < 0 ? rd : DLWP_OK;
+  if (handed_over) {      // the slab sum goes out behind the launch, from dlwp_pair_end
+    const int nslabs = c.nslabs;
+    dlwp_pair_after_wgrad(h, [=]() { return dlwp_launch_reduce_slabs(h, (float*)ws, (float*)dw, wn, nslabs, accumulate, (hipStream_t)stream); });
+    return DLWP_OK;
+  }
   return dlwp_launch_reduce_slabs(h, (float*)ws, (float*)dw, wn, c.nslabs, accumulate, (hipStream_t)stream);
 }
 

@@ -3,6 +3,7 @@
 // Reference call sites: examples/train.py:164-169 ... 214-219, Azure/train_tf.py:213-268.
 #include <cstdlib>
 #include "conv_fwd_kernel.h"
+#include "conv_pair.h"
 #include "tape.h"
 #include <mutex>
 #include <vector>
@@ -898,6 +899,11 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
       return DLWP_OK;
     }
   }
+  // between dlwp_pair_begin / _end the launch is handed over: it may leave in one grid with a weight gradient (conv_pair.h)
+  if (h->pair && is_wino(e) && !e.split && e.dil == 1 && e.th == 8 && e.tw == 32 && e.waves == 4 && e.bnf == 2 && lp.narrow < 0 &&
+      a.ksplit <= 1 && !a.in_bf16 && !a.yact && !a.y2 && !lstm &&
+      dlwp_pair_stash_fwd(h, a, wino_skips_row2(a) ? 1 : 0, (int)grid, e.launch, s))
+    return DLWP_OK;
   e.launch(a, (int)grid, s);
   if (lp.narrow >= 0) {
     const ConvKernelEntry& p = r.entries[lp.narrow];

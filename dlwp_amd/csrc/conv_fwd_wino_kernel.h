@@ -100,9 +100,10 @@ struct WinoCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
 
+// The kernel's body: workgroup `blk` of `nblk` (r4: a function of its own so that conv_pair.hip can run it beside a weight-gradient
+// body in ONE launch; conv2d_fwd_wino_f32 below is this body on blockIdx.x / gridDim.x -- the same code after inlining).
 template <class C>
-// __launch_bounds__(threads, waves per SIMD)
-__global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(const ConvArgs a) {
+__device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const int blk, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int US0 = 2 * C::X_FLOATS;
   const int tid = threadIdx.x;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
 
   int L;
   {
-    const int b = blockIdx.x, nb = gridDim.x;
+    const int b = blk, nb = nblk;
     const int xcd = b & 7, idx = b >> 3, q = nb >> 3, r = nb & 7;
     L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -822,6 +823,12 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(
     }
   }
   DLWP_STAMP(6);
+}
+
+template <class C>
+// __launch_bounds__(threads, waves per SIMD)
+__global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void conv2d_fwd_wino_f32(const ConvArgs a) {
+  conv2d_fwd_wino_body<C>(a, blockIdx.x, gridDim.x);
 }
 
 // Split-K variants (WinoCfg::SPLITK) are compiled in a translation unit of their own (conv_fwd_k3d1s.hip) for the geometries the

@@ -61,7 +61,7 @@ struct WgCbCfg {
 };
 
 template <class C>
-__device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
+__device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const int blk, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // The x tile's GLOBAL column pairs start on an even source column (8-byte loads), which with an odd left halo is one column
   // left of the first patch column.  In LDS the planes are shifted by that column instead, so that every 4 x 4 patch starts on
@@ -78,7 +78,7 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
 
   int b;   // XCD-aware block order (conv_wgrad_kernel.h)
   {
-    const int bi = blockIdx.x, nb = gridDim.x;
+    const int bi = blk, nb = nblk;
     const int xcd = bi & 7, idx = bi >> 3, q = nb >> 3, r = nb & 7;
     b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -366,7 +366,7 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a) {
 // 256 registers per wave: two waves per SIMD (8-wave workgroups: one per CU; 4-wave workgroups: two)
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, 512 / C::NTHREADS) void conv2d_wgrad_wino_cb_f32(const WgradArgs a) {
-  conv2d_wgrad_cb_body<C>(a);
+  conv2d_wgrad_cb_body<C>(a, blockIdx.x, gridDim.x);
 }
 
 template <class C>

@@ -638,6 +638,21 @@ def reductions_flush(device):
     _lib.check(_lib.lib.dlwp_reductions_flush(_lib.handle(_dev_index(device)), _device_stream(device)))
 
 
+def pair_begin(device):
+    """From now until pair_end ONE conv2d_bwd_weight and ONE conv2d_bwd_data of INDEPENDENT tensors hand their launch over; pair_end
+    issues both -- as one grid where a fused instance exists (dlwp_pair_begin / dlwp_pair_end, csrc/conv_pair.hip)."""
+    _lib.check(_lib.lib.dlwp_pair_begin(_lib.handle(_dev_index(device))))
+
+
+def pair_end(device):
+    _lib.check(_lib.lib.dlwp_pair_end(_lib.handle(_dev_index(device)), _device_stream(device)))
+
+
+def pair_fused_count(device):
+    """pairs the device's handle has issued as ONE launch so far"""
+    return int(_lib.lib.dlwp_pair_fused_count(_lib.handle(_dev_index(device))))
+
+
 # ---- RowConnected2D (reference DLWP/custom.py:695-896) ------------------------------------------------------------------ #
 def rowconv2d(x, kernel, bias, cd, out=None, direct=False, x_channels=None):
     """RowConnected2D.call / row_conv2d, channels_first: x stored (n, in_c_total, h, w); kernel (ho, kh, kw, cin, cout) --

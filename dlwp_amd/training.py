@@ -501,6 +501,22 @@ class Trainer(object):
             queued[0] += 1
             if queued[0] == (n_wgrad + 1) // 2:
                 launch_queued(False)
+        # r4: where the step replays as ONE hipGraph on one stream (small batches: every launch under a round of workgroups), a
+        # layer's weight gradient and its data gradient -- both read dz, neither the other's output -- leave in one launch
+        # (ops.pair_begin / pair_end, csrc/conv_pair.hip).  The pair opens in front of the weight gradient and closes behind the data
+        # gradient's convolution; what is issued in between (bias gradient) depends on neither.
+        can_pair = (prep is not None and os.environ.get('DLWP_TRAIN_PAIR', '1') != '0' and self._graph_ok(int(n)) == 'graph')
+        pair_open = [False]
+
+        def pair_begin():
+            if can_pair and not pair_open[0]:
+                ops.pair_begin(self.device)
+                pair_open[0] = True
+
+        def pair_end():
+            if pair_open[0]:
+                pair_open[0] = False
+                ops.pair_end(self.device)
         bufs = self.model.train_executor.scratch(n)
         x = x.reshape((n,) + plan._in_store)
 
@@ -631,6 +647,8 @@ class Trainer(object):
                     ops.act_bwd(y, gD, op.act, out=gD)          # dz in place of dy
                 dz = gD
                 xs = _lib.Shape4(n, op.xs[0], op.xs[1], op.xs[2])
+                if op.src != P.STATE_IN:
+                    pair_begin()           # (closed behind the data gradient's convolution, below)
                 if derived:                # gradients of the derived kernels, folded back onto the layer's own
                     pp = plan.phase_params[op.wparam]
                     dw2 = torch.empty(tuple(kern.shape), dtype=torch.float32, device=self.device)
@@ -686,12 +704,14 @@ class Trainer(object):
                                 preact.add(op.src)
                         if not done:
                             ops.conv2d_bwd_data(dz, kern, d, xs, g, prepared=pb[0] if pb else None)
+                        pair_end()
                         written.setdefault(op.src, []).append((op.in_c_off, cin))
                     else:
                         dd = ops.make_conv(d.cout, d.kh, d.kw, (d.dil_h, d.dil_w), d.halo, d.act, 0, 0, d.out_c_off,
                                            d.out_c_total, d.src_mode)
                         tmp = torch.empty((n, cin) + tuple(src.shape[2:]), dtype=torch.float32, device=self.device)
                         ops.conv2d_bwd_data(dz, kern, dd, xs, tmp)
+                        pair_end()
                         deposit(op.src, op.in_c_off, cin, tmp)
                 else:
                     hin = 2 * op.xs[1] if op.src_mode == P.SRC_UPSAMPLE2 else op.xs[1] // 2
@@ -700,13 +720,17 @@ class Trainer(object):
                         dense = torch.empty((n, cin, op.xs[1], op.xs[2]), dtype=torch.float32, device=self.device)
                         if pb is not None and pb[1]:
                             ops.conv2d_bwd_data(dz, kern, d, xs, dense, prepared=pb[0], stored=True)
+                            pair_end()
                         elif pb is not None or not ops.conv2d_bwd_data_stored(dz, kern, d, xs, dense):
                             tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
                             ops.conv2d_bwd_data(dz, kern, d, xs, tmp, prepared=pb[0] if pb else None)
+                            pair_end()
                             dense = ops.upsample2_bwd(tmp)
+                        pair_end()
                     else:
                         tmp = torch.empty((n, cin, hin, win), dtype=torch.float32, device=self.device)
                         ops.conv2d_bwd_data(dz, kern, d, xs, tmp, prepared=pb[0] if pb else None)
+                        pair_end()
                         if op.in_c_off == 0 and cin == c_total:
                             xw = src
                         else:
@@ -788,6 +812,7 @@ class Trainer(object):
                 deposit(op.src, 0, src.shape[1], ops.upsample2_bwd(gD))
             else:
                 raise RuntimeError(op.kind)
+        pair_end()          # (a layer whose data gradient took no convolution)
         # layers that received no gradient this step (unused by any output) must not keep a stale one
         for lay, nm, off, numel, shape in self.entries:
             if id(lay) not in touched_layers:

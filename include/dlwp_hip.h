@@ -380,6 +380,21 @@ int    dlwp_prepare_begin(dlwp_handle_t);
 int    dlwp_prepare_flush(dlwp_handle_t, void* stream);
 int    dlwp_reductions_begin(dlwp_handle_t);
 int    dlwp_reductions_flush(dlwp_handle_t, void* stream);
+
+/* ---- two INDEPENDENT launches of a training step as ONE kernel launch (r4; csrc/conv_pair.hip).  On grids under one round of
+ *      workgroups (8 samples per GPU: every launch of a step) a layer's weight gradient and its data gradient -- both read the
+ *      layer's pre-activation gradient, neither reads the other's output -- each leave most CUs idle; issued back to back they cost
+ *      the sum of their lifetimes, on two queues more.  Between dlwp_pair_begin and dlwp_pair_end ONE
+ *      dlwp_conv2d_bwd_weight and ONE dlwp_conv2d_bwd_data[_stored / _prepared] (in either order) hand their launch over instead of
+ *      issuing it; dlwp_pair_end(stream) issues both on `stream` -- as one grid whose first blocks run the weight-gradient
+ *      body and whose other blocks run the data-gradient body when a fused instance is compiled for the two kernel
+ *      instances (the channel-block Winograd weight gradient on 4 x 32 tiles beside the 8 x 32 Winograd forward instance, 16- or
+ *      9-position), one after the other otherwise.  Same bodies, same bits.  The CALLER states the independence; calls the
+ *      mode does not cover (another family, a padded-gradient data gradient, a second call of the same kind) run at once.
+ *      dlwp_pair_fused_count: pairs this handle has issued as one launch so far (introspection for tests and tools).       */
+int    dlwp_pair_begin(dlwp_handle_t);
+int    dlwp_pair_end(dlwp_handle_t, void* stream);
+long long dlwp_pair_fused_count(dlwp_handle_t);
 /* The data gradient's operand -- the flipped / transposed kernel, followed by its Winograd / packed-N form when the
  * gradient's convolution runs on such an instance -- depends on the weights only: build it once per step
  * (dlwp_conv2d_bwd_data_prepare into `prepared`, dlwp_conv2d_bwd_data_prepared_bytes large; batched between

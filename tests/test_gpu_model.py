@@ -232,8 +232,8 @@ def test_headline_ensemble_of_256_members_against_the_oracle_directly():
             want2 = np_ref.run_layers(layers, want, weights)
             err2 = _rel(got[1, :1], want2)
             assert err2 < 2 * FWD_TOL, err2
-            MEASURED['headline_256_members_second_forward_member_0'] = err2
-    MEASURED['headline_256_members_first_forward_members_0_131_255'] = worst
+            MEASURED['headline_256_members_second_forward_member_0'] = [err2]
+    MEASURED['headline_256_members_first_forward_members_0_131_255'] = [worst]
 
 
 def test_member_sharding_is_bit_identical():

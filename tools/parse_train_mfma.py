@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Executed matrix-core instructions of ONE training step from a `rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA` pass of
-tools/bench_train.py: the counter summed over every dispatch of the run / the number of steps the run made (= the dispatches of
-the loss-gradient kernel, launched once per step).  Writes {'_meta': {source_sha, batch}, 'mfma_per_step': N, 'per_kernel': {...}}
+tools/bench_train.py: the counter summed over every dispatch of the run / the number of steps the run made (--steps: warm-up + timed
+train_on_batch calls; every matrix kernel must have been launched a whole number of times per step).  Writes {'_meta': {source_sha, batch}, 'mfma_per_step': N, 'per_kernel': {...}}
 -- what bench.py's train_cfg3.executed_frac reads (profiles/r4_train_mfma_b<batch>.json; quoted only on the same kernel source).
-Usage: parse_train_mfma.py out.json pmc_dir --batch B"""
+Usage: parse_train_mfma.py out.json pmc_dir --batch B --steps S"""
 import collections
 import csv
 import glob
@@ -23,13 +23,10 @@ def main():
                 continue
             total[r['Kernel_Name']] += float(r['Counter_Value'])
             calls[r['Kernel_Name']] += 1
-    steps = 0
-    for key in ('loss_grad_kernel', 'adam_dev_kernel', 'adam_kernel('):
-        steps = sum(c for k, c in calls.items() if key in k)
-        if steps:
-            break
-    if not steps:
-        sys.exit('no once-per-step kernel in %s' % d)
+    steps = int(sys.argv[sys.argv.index('--steps') + 1])     # train_on_batch calls of the profiled run: warm-up + timed
+    odd = {k: c for k, c in calls.items() if total[k] > 0 and c % steps}
+    if odd:
+        sys.exit('kernels not launched a whole number of times per step (%d steps?): %r' % (steps, odd))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from dlwp_amd import _lib
     res = {'_meta': {'source_sha': _lib.kernel_source_hash(), 'batch': batch, 'steps_in_run': steps,

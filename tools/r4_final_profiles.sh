@@ -18,7 +18,7 @@ for b in 64 8; do
   cp $(find $O/tr$b -name '*kernel_stats.csv' | head -1) $O/r4_train_b${b}_kernel_stats.csv
   rm -rf $O/tr$b
   rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA -d $O/trm$b -o p --output-format csv -- python $R/tools/bench_train.py --batch $b --steps 20 --warmup 10 > /dev/null 2> $O/trm$b.err
-  python $R/tools/parse_train_mfma.py $O/r4_train_mfma_b$b.json $O/trm$b --batch $b
+  python $R/tools/parse_train_mfma.py $O/r4_train_mfma_b$b.json $O/trm$b --batch $b --steps 30
   rm -rf $O/trm$b
 done
 # config 5 (1-degree grid, 12 channels) at 4 members = one GPU's share of 32 members on 8; config 2 at 8 members
