@@ -109,6 +109,10 @@ def test_bench_kernel_symbols_match_the_committed_profiles():
                 sym = bench.config_symbol(tuple(v) + (1 if m.group(9) == 'true' else 0,))
                 assert sym in n, (sym, n)
                 found += 1
+            m = re.search(r'conv2d_fwd_wino2s_f32<(\d+), ', n)
+            if m:         # the streaming position-split kernel (launch-info config -3)
+                assert "'conv2d_fwd_wino2s_f32<%d, ' % ((op.xs[0] + 7) // 8)" in open(os.path.join(ROOT, 'bench.py')).read()
+                found += 1
             m = re.search(r'conv2d_fwd_few_f32<(\d+), ', n)
             if m:         # the streaming layer-1 kernel: bench.py's time_layers composes this prefix for launch-info config -2
                 assert "'conv2d_fwd_few_f32<%d, ' % dil_run[0]" in open(os.path.join(ROOT, 'bench.py')).read()
@@ -117,9 +121,9 @@ def test_bench_kernel_symbols_match_the_committed_profiles():
     else:
         pytest.skip('no kernel-stats summary of the current kernel source in profiles/')
     assert found >= 3
-    ent = bench.rocprof_launch_ms('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false> >', 256)
+    ent = bench.rocprof_launch_ms('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false, false> >', 256)
     assert ent and ent['same_source']
-    traffic, src = bench.measured_traffic('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false> >', 256)
+    traffic, src = bench.measured_traffic('conv2d_fwd_wino_f32<WinoCfg<1, 8, 32, 4, 2, 8, false, false, false, false, false> >', 256)
     assert traffic and 2.0e8 < traffic < 4.0e8, (traffic, src)
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Executed matrix-core instructions of ONE training step from a `rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA` pass of
 tools/bench_train.py: the counter summed over every dispatch of the run / the number of steps the run made (--steps: warm-up + timed
-train_on_batch calls; every matrix kernel must have been launched a whole number of times per step).  Writes {'_meta': {source_sha, batch}, 'mfma_per_step': N, 'per_kernel': {...}}
+train_on_batch calls; the run's total must be a whole multiple of it).  Writes {'_meta': {source_sha, batch}, 'mfma_per_step': N, 'per_kernel': {...}}
 -- what bench.py's train_cfg3.executed_frac reads (profiles/r4_train_mfma_b<batch>.json; quoted only on the same kernel source).
 Usage: parse_train_mfma.py out.json pmc_dir --batch B --steps S"""
 import collections
@@ -24,9 +24,10 @@ def main():
             total[r['Kernel_Name']] += float(r['Counter_Value'])
             calls[r['Kernel_Name']] += 1
     steps = int(sys.argv[sys.argv.index('--steps') + 1])     # train_on_batch calls of the profiled run: warm-up + timed
-    odd = {k: c for k, c in calls.items() if total[k] > 0 and c % steps}
-    if odd:
-        sys.exit('kernels not launched a whole number of times per step (%d steps?): %r' % (steps, odd))
+    # every step executes the same matrix instructions (its first steps run launch by launch, the later ones replay the recorded
+    # step, where a weight gradient and a data gradient may share a launch: other kernel NAMES, the same bodies)
+    if sum(total.values()) % steps:
+        sys.exit('SQ_INSTS_MFMA of the run is not a whole multiple of %d steps: %r' % (steps, dict(calls)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from dlwp_amd import _lib
     res = {'_meta': {'source_sha': _lib.kernel_source_hash(), 'batch': batch, 'steps_in_run': steps,
