@@ -908,7 +908,9 @@ class Trainer(object):
     graph_after = 2
 
     #: DLWP_TRAIN_GRAPH unset: steps of at most this many samples x grid points replay as a captured graph
-    graph_below = 12 * 88 * 180
+    # (r4, gpurun s18, ms per step graph / lanes: 12 samples 0.446 / 0.469, 16: 0.564 / 0.563, 24: 0.690 / 0.704, 32: 0.872 / 0.844 --
+    #  and the graph form needs 0.04 ms of host time per step where the lanes need 0.18)
+    graph_below = 24 * 88 * 180
 
     def _graph_ok(self, n_local=None):
         """How a step of n_local samples runs: False -- launch by launch from Python (the eager step) -- or the form in which it is
