@@ -139,12 +139,39 @@ void dlwp_pair_free(dlwp_handle_t h) {
 
 extern "C" {
 
+// what a pair holds goes out, each launch on the stream it was recorded for (`fused_stream` != nullptr: as one grid there when both
+// launches belong to it and a fused instance exists)
+static int issue_pair(dlwp_handle_t h, dlwp_pair_state* p, bool may_fuse, hipStream_t fused_stream) {
+  int fused = 0;
+  if (may_fuse && p->f_set && p->w_set && p->f_stream == fused_stream && p->w_stream == fused_stream) {
+    fused = try_fused(*p, h->cu_count, fused_stream);
+    if (fused < 0) fused = 0;        // (the attribute call failed: the two launches still go out)
+    p->n_fused += fused;
+  }
+  if (!fused) {
+    if (p->w_set) p->w_launch(p->wa, p->w_grid, p->w_stream);
+    if (p->f_set) p->f_launch(p->fa, p->f_grid, p->f_stream);
+  }
+  const int launched = p->f_set || p->w_set;
+  std::function<int()> post;
+  post.swap(p->w_post);
+  p->f_set = p->w_set = p->f_allow = 0;
+  if (launched) DLWP_LAUNCH_CHECK("conv2d_pair_wgrad_dgrad_f32");
+  return post ? post() : DLWP_OK;
+}
+
 int dlwp_pair_begin(dlwp_handle_t h) {
   DLWP_TAPE_HOST(h, dlwp_pair_begin, h);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_pair_begin: null handle");
   dlwp_pair_state* p = state_of(h);
   if (!p) DLWP_FAIL(DLWP_EHIP, "dlwp_pair_begin: out of memory");
-  DLWP_CHECK_ARG(!p->open, "dlwp_pair_begin: a pair is already open on this handle");
+  if (p->open) {
+    // a pair left open (the caller's step raised between begin and end): its launches go out one by one before the new pair
+    // opens -- a handle must not stay wedged behind an exception in somebody's training loop
+    DLWP_CHECK_ARG(p->owner == this_thread_id(), "dlwp_pair_begin: another thread has a pair open on this handle");
+    const int rc = issue_pair(h, p, false, nullptr);
+    if (rc != DLWP_OK) return rc;
+  }
   p->open = 1;
   p->owner = this_thread_id();
   p->f_set = p->w_set = p->f_allow = 0;
@@ -157,24 +184,8 @@ int dlwp_pair_end(dlwp_handle_t h, void* stream) {
   dlwp_pair_state* p = h->pair;
   DLWP_CHECK_ARG(p->owner == this_thread_id(), "dlwp_pair_end: the pair was opened by another thread");
   p->open = 0;
-  hipStream_t s = (hipStream_t)stream;
-  int fused = 0;
   // (a launch recorded for another stream than the pair's keeps its own: no fusion across streams)
-  if (p->f_set && p->w_set && p->f_stream == s && p->w_stream == s) {
-    fused = try_fused(*p, h->cu_count, s);
-    if (fused < 0) DLWP_FAIL(DLWP_EHIP, "dlwp_pair_end: hipFuncSetAttribute failed");
-    p->n_fused += fused;
-  }
-  if (!fused) {
-    if (p->w_set) p->w_launch(p->wa, p->w_grid, p->w_stream);
-    if (p->f_set) p->f_launch(p->fa, p->f_grid, p->f_stream);
-  }
-  const int launched = p->f_set || p->w_set;
-  std::function<int()> post;
-  post.swap(p->w_post);
-  p->f_set = p->w_set = 0;
-  if (launched) DLWP_LAUNCH_CHECK("conv2d_pair_wgrad_dgrad_f32");
-  return post ? post() : DLWP_OK;
+  return issue_pair(h, p, true, (hipStream_t)stream);
 }
 
 // pairs this handle has issued as ONE launch so far (tests, tools: did the fused instance run?)

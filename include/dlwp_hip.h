@@ -391,7 +391,8 @@ int    dlwp_reductions_flush(dlwp_handle_t, void* stream);
  *      instances (the channel-block Winograd weight gradient on 4 x 32 tiles beside the 8 x 32 Winograd forward instance, 16- or
  *      9-position), one after the other otherwise.  Same bodies, same bits.  The CALLER states the independence; calls the
  *      mode does not cover (another family, a padded-gradient data gradient, a second call of the same kind) run at once.
- *      dlwp_pair_fused_count: pairs this handle has issued as one launch so far (introspection for tests and tools).       */
+ *      dlwp_pair_begin on a pair that was never ended (the caller's step raised) issues what that pair holds, launch by launch,
+ *      and opens the new one.  dlwp_pair_fused_count: pairs this handle has issued as one launch so far (tests and tools).  */
 int    dlwp_pair_begin(dlwp_handle_t);
 int    dlwp_pair_end(dlwp_handle_t, void* stream);
 long long dlwp_pair_fused_count(dlwp_handle_t);
