@@ -1186,10 +1186,23 @@ class Trainer(object):
             sums = None
             seen = 0
             pending = []
+            # The epoch's logs are batch-size-weighted means of the per-batch values, and for the per-element losses those are
+            # LINEAR in the step's loss table: the tables are summed on the device, weighted, by one small launch per step (r4: a
+            # clone per step was a device-to-device memcpy between two graph launches -- 4 us and ~15 us of queue bubbles around it,
+            # profiles/r4_loader_timeline.txt) and read once per epoch.  Whole-batch statistics (custom losses) keep their tables.
+            acc, reg_sum = None, 0.0
             for bi, (X, y, n_glob) in enumerate(batches_fn(epoch)):      # X, y: this rank's rows of a batch of n_glob
                 self._call(cbs, 'on_batch_begin', bi, {'batch': bi, 'size': n_glob})
                 lv, reg = self.train_on_shard(X, y, n_glob, return_device=True)
-                pending.append((lv.clone(), n_glob, reg))
+                if self.loss_kind != 'custom' and lv.is_cuda and lv.dtype == torch.float32 and lv.is_contiguous():
+                    from . import ops
+                    if acc is None:
+                        acc = torch.zeros_like(lv)
+                    ops.axpby(lv.view(-1), acc.view(-1), float(n_glob), 1.0)
+                    reg_sum += float(n_glob) * float(reg)
+                    seen += n_glob
+                else:
+                    pending.append((lv.clone(), n_glob, reg))
                 # convert lazily: one host sync per epoch unless a callback wants per-batch logs
                 if any(getattr(type(c), 'on_batch_end', Callback.on_batch_end) is not Callback.on_batch_end
                        for c in cbs if isinstance(c, Callback)) or any(not isinstance(c, Callback) for c in cbs):
@@ -1203,6 +1216,10 @@ class Trainer(object):
                     vals = np.asarray(self._report_from(tab, reg), dtype=np.float64)
                     sums = vals * bs if sums is None else sums + vals * bs
                     seen += bs
+            if acc is not None:          # sum over the batches of size x table -> size-weighted sums of the reported values
+                vals = np.asarray(self._report_from(acc.cpu().numpy().astype(np.float64), 0.0), dtype=np.float64)
+                vals[0] += reg_sum
+                sums = vals if sums is None else sums + vals
             logs = dict(zip(self.metrics_names, (sums / max(seen, 1)).tolist())) if sums is not None else {}
             if validate_fn is not None:
                 vvals = validate_fn()

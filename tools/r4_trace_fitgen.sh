@@ -3,9 +3,9 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/s6; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for pull in 1 0; do
-TAG=fitgen_b64_pull$pull
-DLWP_LOADER_PULL=$pull DLWP_TRAIN_STEP=graph rocprofv3 --kernel-trace --memory-copy-trace -d $O/$TAG -o s --output-format csv -- python $R/tools/bench_fit_generator.py --batch 64 --samples 1280 --epochs 1 > $O/$TAG.json 2> $O/$TAG.err
+for pull in ${PULLS:-1 0}; do
+B=${BATCH:-64}; TAG=fitgen_b${B}_pull$pull
+DLWP_LOADER_PULL=$pull DLWP_TRAIN_STEP=graph rocprofv3 --kernel-trace --memory-copy-trace -d $O/$TAG -o s --output-format csv -- python $R/tools/bench_fit_generator.py --batch $B --samples ${SAMPLES:-1280} --epochs 1 > $O/$TAG.json 2> $O/$TAG.err
 python - <<PY > $O/$TAG.timeline.txt
 import csv, glob
 rows=list(csv.DictReader(open('$O/$TAG/s_kernel_trace.csv')))
