@@ -27,7 +27,7 @@ SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
 OP_CONV2D, OP_PAD2D, OP_MAXPOOL2, OP_UPSAMPLE2, OP_COPYCH, OP_LSTM_GATES, OP_PHASE_WEIGHTS, OP_DEPTH2SPACE = 0, 1, 2, 3, 4, 5, 6, 7
 OP_ROWCONV2D = 8
 BUF_NONE = -1000
-STEP_LANES, STEP_GRAPH, STEP_GRAPH_BRANCHES = 0, 1, 2
+STEP_LANES, STEP_GRAPH, STEP_GRAPH_BRANCHES, STEP_LANES_RECORDED = 0, 1, 2, 3
 
 
 COMPUTE_BF16 = 0x20000

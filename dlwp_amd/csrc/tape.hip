@@ -60,6 +60,7 @@ struct dlwp_train_step {
   std::vector<Rec> recs;
   int n_lanes, n_launches, n_waits;
   std::vector<hipStream_t> side;        // lanes 1 .. n_lanes - 1 (library-owned)
+  std::vector<void*> recorded;          // the streams the lanes were recorded on ([0]: the main stream of the recording)
   std::vector<hipEvent_t> events;       // one per wait record
   hipStream_t cap;                      // capture stream of the graph forms (and the launch stream of the branched one)
   hipEvent_t order[2];                  // ... its ordering against the caller's stream
@@ -172,6 +173,7 @@ int dlwp_train_step_create(dlwp_handle_t h, int n_in, void* const* in_dst, const
   st->h = h;
   st->recs = std::move(t->recs);
   st->n_lanes = (int)t->lanes.size();
+  st->recorded = t->lanes;
   delete t;
   st->n_launches = st->n_waits = 0;
   st->cap = nullptr;
@@ -214,19 +216,25 @@ int dlwp_train_step_info(dlwp_train_step_t st, int* n_launches, int* n_lanes, in
 }
 
 // srcs (nullable): n_in device pointers copied into the step's input buffers first (one launch).  mode DLWP_STEP_LANES: the
-// recorded launches one by one, lane 0 on `stream`, the others on the step's side streams; DLWP_STEP_GRAPH: one hipGraph with
+// recorded launches one by one, lane 0 on `stream`, the others on the step's side streams (DLWP_STEP_LANES_RECORDED: on the streams
+// they were recorded on, which the caller keeps alive); DLWP_STEP_GRAPH: one hipGraph with
 // every launch on one stream; DLWP_STEP_GRAPH_BRANCHES: one hipGraph whose branches are the lanes.
 int dlwp_train_step_launch(dlwp_train_step_t st, const void* const* srcs, int mode, void* stream) {
   DLWP_CHECK_ARG(st != nullptr, "dlwp_train_step_launch: null step");
-  DLWP_CHECK_ARG(mode >= DLWP_STEP_LANES && mode <= DLWP_STEP_GRAPH_BRANCHES, "dlwp_train_step_launch: mode %d", mode);
+  DLWP_CHECK_ARG(mode >= DLWP_STEP_LANES && mode <= DLWP_STEP_LANES_RECORDED, "dlwp_train_step_launch: mode %d", mode);
   DLWP_CHECK_ARG(t_tape == nullptr, "dlwp_train_step_launch: this thread is recording");
   if (srcs && st->n_in > 0) {
     const int rc = dlwp_copy_many(st->h, srcs, st->in_dst, st->in_floats, st->n_in, stream);
     if (rc != DLWP_OK) return rc;
   }
-  if (mode == DLWP_STEP_LANES) {
+  if (mode == DLWP_STEP_LANES || mode == DLWP_STEP_LANES_RECORDED) {
+    // DLWP_STEP_LANES_RECORDED: the side lanes are the very streams the step was recorded on.  The runtime multiplexes streams
+    // onto a few hardware queues (4 by default); streams the library creates LATER may share a queue with the caller's main stream
+    // -- a side lane's 0.2 ms weight gradient then sits in front of the data-gradient chain (config-3 step at 64 samples: 1.409 ms
+    // on own streams, 1.373 with GPU_MAX_HW_QUEUES=8, 1.363 launched from Python on the recorded streams; gpurun_out/s21).
     std::vector<hipStream_t> lanes(st->n_lanes, (hipStream_t)stream);
-    for (int i = 1; i < st->n_lanes; ++i) lanes[i] = st->side[i - 1];
+    for (int i = 1; i < st->n_lanes; ++i)
+      lanes[i] = mode == DLWP_STEP_LANES_RECORDED ? (hipStream_t)st->recorded[i] : st->side[i - 1];
     return replay(st, lanes, false);
   }
   const int b = mode == DLWP_STEP_GRAPH_BRANCHES ? 1 : 0;

@@ -908,9 +908,10 @@ class Trainer(object):
     graph_after = 2
 
     #: DLWP_TRAIN_GRAPH unset: steps of at most this many samples x grid points replay as a captured graph
-    # (r4, gpurun s18, ms per step graph / lanes: 12 samples 0.446 / 0.469, 16: 0.564 / 0.563, 24: 0.690 / 0.704, 32: 0.872 / 0.844 --
-    #  and the graph form needs 0.04 ms of host time per step where the lanes need 0.18)
-    graph_below = 24 * 88 * 180
+    # (r4, gpurun s22, ms per step graph / lanes -- the lanes on the streams the step was recorded on, DLWP_STEP_LANES_RECORDED --:
+    #  8 samples 0.382 / 0.394, 12: 0.450 / 0.434, 16: 0.560 / 0.536, 24: 0.692 / 0.667, 64: 1.431 / 1.381; the graph form needs 0.04 ms
+    #  of host time per step, the lanes 0.18)
+    graph_below = 10 * 88 * 180
 
     def _graph_ok(self, n_local=None):
         """How a step of n_local samples runs: False -- launch by launch from Python (the eager step) -- or the form in which it is
@@ -1081,7 +1082,10 @@ class Trainer(object):
                        for s_, d_ in zip(srcs, [ent['x']] + ent['ys'])):
                 srcs = [s_.to(torch.float32).contiguous() for s_ in srcs]
             ptrs = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
-            mode = {'lanes': _lib.STEP_LANES, 'graph': _lib.STEP_GRAPH, 'branches': _lib.STEP_GRAPH_BRANCHES}[form]
+            # ('lanes': on the trainer's own side streams, the ones the step was recorded on -- they are kept in ent['keep'] --: streams
+            #  the library creates later may share a hardware queue with the main stream; DLWP_TRAIN_LANES=own picks those)
+            lanes_mode = _lib.STEP_LANES if os.environ.get('DLWP_TRAIN_LANES') == 'own' else _lib.STEP_LANES_RECORDED
+            mode = {'lanes': lanes_mode, 'graph': _lib.STEP_GRAPH, 'branches': _lib.STEP_GRAPH_BRANCHES}[form]
             _lib.check(_lib.lib.dlwp_train_step_launch(ent['step'].h, ptrs, mode,
                                                        ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
             if dp is None:

@@ -581,6 +581,8 @@ int dlwp_gather_rows_h2d(dlwp_handle_t, void* dst, const void* src_device_addres
 #define DLWP_STEP_LANES          0
 #define DLWP_STEP_GRAPH          1
 #define DLWP_STEP_GRAPH_BRANCHES 2
+#define DLWP_STEP_LANES_RECORDED 3  /* as DLWP_STEP_LANES, the side lanes on the streams the step was RECORDED on (the caller keeps them
+                                     * alive): streams created later may share a hardware queue with the main stream            */
 typedef struct dlwp_train_step* dlwp_train_step_t;
 int dlwp_train_step_record_begin(dlwp_handle_t, void* main_stream);
 int dlwp_train_step_record_abort(dlwp_handle_t);
