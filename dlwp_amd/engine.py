@@ -287,7 +287,8 @@ class Executor(object):
         r2q): two chains +7 % at 64 members (361.8 -> 387.4 k steps/s), +4 % at 32 members of config 5, +1.3 % at 256
         (400.6 -> 405.7 k); four or eight chains lose again (389 k at 256: the launches get too small); within noise or
         worse below 32 members of the 88 x 180 grid.  Default: TWO chains from members x grid points >= 0.5 M on (32 members of
-        that grid, 8 of the 1-degree grid), one below; DLWP_ROLLOUT_GROUPS=g asks for g."""
+        that grid, 8 of the 1-degree grid), one below; DLWP_ROLLOUT_GROUPS=g asks for g.  r4: between 0.2 M and 0.5 M points
+        make_rollout measures one chain against two (whether two help there depends on how the member count fills rounds of workgroups)."""
         # what decides is the work per launch, members x grid points: 32 members of the 88 x 180 grid = 0.5 M points; the 1-degree
         # recurrent stack (config 4, 180 x 360) gains from 8 members on (r2y: 44.2 -> 45.8 k steps/s at 8, 48.2 -> 50.5 k at 16,
         # four chains 44.4 k), 4 members of config 5 (0.26 M points) do not
@@ -298,8 +299,59 @@ class Executor(object):
             g -= 1
         return g
 
+    #: work per launch (members x grid points) between which make_rollout MEASURES one chain against two (below: launches of a
+    #: few tiles, two chains only add launches; above: the rule of member_groups)
+    tune_groups_between = (200000, 500000)
+
     def make_rollout(self, state0, series, calls, groups=None):
-        """Capture `calls` model applications.  state0: (n,)+input store; series: (calls*n_out, n)+store, contiguous."""
+        """Capture `calls` model applications.  state0: (n,)+input store; series: (calls*n_out, n)+store, contiguous.
+        groups=None: member_groups' rule -- and, in the range where the better choice follows from how the member count happens
+        to fill rounds of workgroups (r4, gpurun s23: config 5 at 4 members 49.7 k steps/s as one chain, 54.5 k as two; at 3 members
+        49.9 / 49.9, at 6 members 61.9 / 64.5; 16 members of the 88 x 180 grid 235.8 / 238.8 k), by MEASUREMENT: both graphs are
+        captured, each is launched four times on the (zeroed) state, the faster one is kept.  Only where one chain and two run every
+        convolution in the same split regime (ops.conv_split_count): the choice never changes a bit of the result."""
+        if groups is None and os.environ.get('DLWP_ROLLOUT_GROUPS') is None and os.environ.get('DLWP_ROLLOUT_TUNE', '1') != '0':
+            n = int(state0.shape[0])
+            work = n * int(self.plan._in_store[1]) * int(self.plan._in_store[2])
+            if n >= 2 and n % 2 == 0 and self.tune_groups_between[0] <= work < self.tune_groups_between[1] and \
+                    self.device.type == 'cuda' and self._same_split_regime(n, n // 2):
+                best = None
+                state0.zero_()
+                for g in (1, 2):
+                    cand = self._make_rollout(state0, series, calls, g)
+                    cand.launch()
+                    torch.cuda.synchronize(self.device)
+                    ts = []
+                    for _ in range(3):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        cand.launch()
+                        e1.record()
+                        e1.synchronize()
+                        ts.append(e0.elapsed_time(e1))
+                    t = min(ts)
+                    if best is None or t < 0.98 * best[0]:      # (two chains must win by 2 %: they cost a second set of buffers)
+                        if best is not None:
+                            best[1].close()
+                        best = (t, cand, g)
+                    else:
+                        cand.close()
+                best[1].groups = best[2]
+                return best[1]
+        return self._make_rollout(state0, series, calls, groups)
+
+    def _same_split_regime(self, n_a, n_b):
+        """Do the plan's convolutions run in the same split-K regime (equal bits) at n_a and at n_b members per launch?"""
+        from . import ops
+        dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        for op, d in zip(self.plan.ops, self._descriptors()):
+            if op.kind == 'conv' and not op.lstm_f and op.src2 is None:
+                dt = self._conv_dtype(op)
+                if ops.conv_split_count((n_a,) + tuple(op.xs), d, dt, dev) != ops.conv_split_count((n_b,) + tuple(op.xs), d, dt, dev):
+                    return False
+        return True
+
+    def _make_rollout(self, state0, series, calls, groups=None):
         from . import _lib, ops
         n = state0.shape[0]
         n_out = len(self.plan.output_store)
@@ -392,7 +444,9 @@ class Executor(object):
                                                         ctypes.c_void_p(series.data_ptr()), slot, int(calls), n_out,
                                                         _lib.F32, ctypes.c_void_p(ws.data_ptr()), ws_bytes,
                                                         ctypes.byref(out)))
-        return RolloutGraph(out, keep=(table, state0, series, arr, ptrs, ws), device=self.device)
+        rg = RolloutGraph(out, keep=(table, state0, series, arr, ptrs, ws), device=self.device)
+        rg.groups = int(groups)
+        return rg
 
 
 class RolloutGraph(object):

@@ -285,6 +285,40 @@ def test_rollout_captured_as_parallel_member_chains_is_bit_identical():
         net.executor.make_rollout(torch.empty_like(x), torch.empty_like(want), 5, groups=4)
 
 
+def test_member_chains_chosen_by_measurement_never_change_a_bit():
+    """Executor.make_rollout(groups=None) in the range where one chain is MEASURED against two (members x grid points in
+    Executor.tune_groups_between: 16 members of the 88 x 180 grid): whichever it keeps gives the bits of the single chain; outside the
+    range, with an odd member count, or with DLWP_ROLLOUT_GROUPS set nothing is measured (groups as member_groups' rule says)."""
+    import torch
+    from dlwp_amd.engine import Executor
+    rng = np.random.default_rng(11)
+    cs = (4, 88, 180)
+    d = _build(unet_layers(cs), time_dim=2)
+    _weights_of(d.model, rng)
+    net = d.model
+    lo, hi = Executor.tune_groups_between
+    n = 16
+    assert lo <= n * 88 * 180 < hi
+    x = torch.from_numpy(rng.standard_normal((n,) + cs).astype(np.float32)).to(net.device)
+    outs = {}
+    for groups in (1, None):
+        s0 = torch.empty_like(x)
+        ser = torch.empty((3, n) + cs, device=net.device)
+        g = net.executor.make_rollout(s0, ser, 3, groups=groups)
+        assert g.groups in (1, 2) if groups is None else g.groups == 1
+        s0.copy_(x)
+        g.launch()
+        torch.cuda.synchronize()
+        outs[groups] = ser.clone()
+        g.close()
+    assert torch.equal(outs[1], outs[None])
+    for m in (4, 15):                      # below the range / odd: the rule, no measurement
+        s0 = torch.empty((m,) + cs, device=net.device)
+        g = net.executor.make_rollout(s0, torch.empty((3, m) + cs, device=net.device), 3)
+        assert g.groups == Executor.member_groups(m, 88 * 180)
+        g.close()
+
+
 def test_functional_skip_unet_and_chained_outputs():
     from dlwp_amd import custom, layers as L
     from dlwp_amd.engine import Model
