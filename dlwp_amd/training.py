@@ -441,6 +441,19 @@ class Trainer(object):
             return [total] + [float(v[0, col[k]]) for k in self.metric_keys]
         return ([total] + per_out + [float(v[o, col[k]]) for o in range(n_out) for k in self.metric_keys])
 
+    #: side streams of the weight gradients (DLWP_SIDE_STREAMS).  With the loader's copy stream and the main stream that is four -- the
+    #: hardware queues a process has by default
+    side_streams = 2
+
+    def _ensure_side_streams(self):
+        """The streams the weight gradients run on beside the data-gradient chain: probed to sit on hardware queues of their own
+        (util.distinct_streams).  fit_generator calls this BEFORE it builds its DeviceLoader, whose copy stream then avoids them."""
+        if self._side is None and self.device.type == 'cuda':
+            from .util import distinct_streams
+            k = max(1, int(os.environ.get('DLWP_SIDE_STREAMS', self.side_streams)))
+            self._side = distinct_streams(self.device, k, [torch.cuda.current_stream(self.device)])
+        return self._side or []
+
     # -- backward ------------------------------------------------------------------------------------------------------ #
     def _backward(self, x, outs, dys, prep=None):
         """prep (the folded step, _fold_ok): prepared data-gradient operands, a workspace per deferred final sum, the weight
@@ -452,7 +465,7 @@ class Trainer(object):
         post = []
         main = torch.cuda.current_stream(self.device) if prep is not None else None
         if prep is not None and self._side is None:
-            self._side = [torch.cuda.Stream(self.device) for _ in range(3)]
+            self._ensure_side_streams()
         sides = self._side if prep is not None else None
         if sides is not None and torch.cuda.is_current_stream_capturing():
             # inside a captured step everything stays on ONE stream: replaying graphs with forked branches crashed inside
@@ -1317,7 +1330,10 @@ class Trainer(object):
                 generator._indices = dp.broadcast_indices(generator._indices)
             if self.device.type == 'cuda' or shard is not None:
                 if loader[0] is None:
-                    loader[0] = DeviceLoader(generator, self.device, order=order, shard=shard)
+                    # (its copy stream on a hardware queue of its own: not the main stream's, not a weight-gradient stream's)
+                    avoid = [torch.cuda.current_stream(self.device)] + list(self._ensure_side_streams() if self._fold_ok() else [])
+                    loader[0] = DeviceLoader(generator, self.device, order=order, shard=shard,
+                                             avoid_streams=avoid if self.device.type == 'cuda' else None)
                 for X, y, n_glob in loader[0].iter_batches(order):
                     yield X, y, n_glob
             else:

@@ -222,3 +222,58 @@ def host_result_buffer(shape):
         return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32, pin_memory=True)
     except RuntimeError:
         return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32)
+
+
+def distinct_streams(device, k, avoid):
+    """k new streams that really run BESIDE the streams in `avoid` (and each other).  The HIP runtime multiplexes streams onto a
+    few hardware queues (four per process by default) in an order that depends on every stream the process has created, so a fresh
+    stream may share the queue of the stream it is meant to overlap with -- its launches then queue up in front of that stream's
+    instead of running beside them (r4, config-3 step at 64 samples: 1.38 ms with the weight-gradient streams on queues of their
+    own, 1.42-1.43 where one shared the main stream's queue; an upload stream behind a weight-gradient stream: 2.03 ms).  Candidates
+    are PROBED: a one-thread spin kernel on a stream of `avoid` and one on the candidate take the time of one where the queues
+    differ, of two where they are the same.  Candidates that serialise with a stream to avoid are passed over (and returned last,
+    if nothing better turns up: the result always has k streams).  DLWP_PROBE_STREAMS=0: no probing."""
+    import os
+    import torch
+    fresh = lambda: torch.cuda.Stream(device)  # noqa: E731
+    if os.environ.get('DLWP_PROBE_STREAMS', '1') == '0' or not hasattr(torch.cuda, '_sleep') or device.type != 'cuda':
+        return [fresh() for _ in range(k)]
+
+    def pair_ms(a, b, cycles):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b.wait_stream(a)
+        e0.record(a)
+        b.wait_event(e0)
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+        with torch.cuda.stream(b):
+            torch.cuda._sleep(cycles)
+        a.wait_stream(b)
+        e1.record(a)
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+    try:
+        with torch.cuda.device(device):
+            base = avoid[0] if avoid else torch.cuda.current_stream(device)
+            cycles = 200000
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(base):
+                torch.cuda._sleep(cycles)           # (first launch of the spin kernel)
+                e0.record(base)
+                torch.cuda._sleep(cycles)
+                e1.record(base)
+            e1.synchronize()
+            one = e0.elapsed_time(e1)
+            taken, spare = [], []
+            for _ in range(4 * k + 4):
+                c = fresh()
+                if all(pair_ms(o, c, cycles) < 1.5 * one for o in list(avoid) + taken):
+                    taken.append(c)
+                    if len(taken) == k:
+                        break
+                else:
+                    spare.append(c)
+            return (taken + spare + [fresh() for _ in range(k)])[:k]
+    except Exception:  # noqa: BLE001  (a probe must never take its caller down)
+        return [fresh() for _ in range(k)]
+
