@@ -617,7 +617,9 @@ class Model(object):
         results = None
         if n > chunk and self.device.type == 'cuda':
             # several chunks: results go into pinned host arrays on a copy stream, under the next chunk's kernels
-            copy_stream = torch.cuda.Stream(device=self.device)
+            from .util import io_streams
+            copy_stream = io_streams(self.device)[0]          # (a hardware queue of its own: util.distinct_streams)
+            copy_stream.wait_stream(torch.cuda.current_stream(self.device))
             pinned = None
             for lo in range(0, n, chunk):
                 xd = torch.from_numpy(x[lo:lo + chunk]).to(self.device, non_blocking=False)

@@ -86,11 +86,12 @@ class _Wrapper(object):
         parts = -(-n // chunk)
         chunk = -(-n // parts)                       # even chunks: one graph shape (plus at most one remainder shape)
         xh = np.ascontiguousarray(predictors, dtype=np.float32) if on_host else None
-        copy_stream = torch.cuda.Stream(device=net.device)
+        copy_stream, up_probed = util.io_streams(net.device)      # (hardware queues of their own: util.distinct_streams)
+        copy_stream.wait_stream(torch.cuda.current_stream(net.device))
         host = None
         # host inputs: chunk k + 1 is staged into page-locked memory and uploaded on its own stream while chunk k rolls out (a
         # synchronous upload from pageable memory in front of every chunk left the GPU idle for ~1.5 ms each)
-        up_stream = torch.cuda.Stream(device=net.device) if on_host else None
+        up_stream = up_probed if on_host else None
         stage = [util.pinned_results.take((chunk,) + tuple(predictors.shape[1:])) for _ in range(2)] if on_host else None
         stage_ev = [None, None]
         bounds = [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]

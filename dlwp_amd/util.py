@@ -277,3 +277,17 @@ def distinct_streams(device, k, avoid):
     except Exception:  # noqa: BLE001  (a probe must never take its caller down)
         return [fresh() for _ in range(k)]
 
+
+_io_streams = {}
+
+
+def io_streams(device):
+    """(download stream, upload stream) of a device for results / inputs that cross the link under compute: probed once per process
+    and device to sit on hardware queues other than the current stream's and each other's (distinct_streams)."""
+    import torch
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _io_streams.get(key)
+    if st is None:
+        st = _io_streams[key] = tuple(distinct_streams(device, 2, [torch.cuda.current_stream(device)]))
+    return st
+
