@@ -307,9 +307,12 @@ class Executor(object):
         """Capture `calls` model applications.  state0: (n,)+input store; series: (calls*n_out, n)+store, contiguous.
         groups=None: member_groups' rule -- and, in the range where the better choice follows from how the member count happens
         to fill rounds of workgroups (r4, gpurun s23: config 5 at 4 members 49.7 k steps/s as one chain, 54.5 k as two; at 3 members
-        49.9 / 49.9, at 6 members 61.9 / 64.5; 16 members of the 88 x 180 grid 235.8 / 238.8 k), by MEASUREMENT: both graphs are
-        captured, each is launched four times on the (zeroed) state, the faster one is kept.  Only where one chain and two run every
+        49.9 / 49.9, at 6 members 61.9 / 64.5; 16 members of the 88 x 180 grid 235.8 / 238.8 k), by MEASUREMENT: one chain, two single-chain graphs on two
+        probed streams (SplitRollout) and the forked graph are captured in turn, each is launched four times on the (zeroed) state; the
+        first form that beats one chain by 2 % is kept.  Only where one chain and two run every
         convolution in the same split regime (ops.conv_split_count): the choice never changes a bit of the result."""
+        if groups == 'split':
+            return self._make_split_rollout(state0, series, calls)
         if groups is None and os.environ.get('DLWP_ROLLOUT_GROUPS') is None and os.environ.get('DLWP_ROLLOUT_TUNE', '1') != '0':
             n = int(state0.shape[0])
             work = n * int(self.plan._in_store[1]) * int(self.plan._in_store[2])
@@ -320,10 +323,11 @@ class Executor(object):
                 # (two chains are built up to three times: a graph's branches run on streams the runtime creates when the graph is
                 #  instantiated, and whether those land on different HARDWARE QUEUES depends on every stream the process has created
                 #  before -- branches on one queue run one after the other.  A new instantiation draws new streams.)
-                for g in (1, 2, 2, 2):
-                    if best is not None and best[2] == 2:
+                for g in (1, 'split', 2, 2):
+                    if best is not None and best[2] != 1:
                         break
-                    cand = self._make_rollout(state0, series, calls, g)
+                    cand = self._make_split_rollout(state0, series, calls) if g == 'split' else \
+                        self._make_rollout(state0, series, calls, g)
                     cand.launch()
                     torch.cuda.synchronize(self.device)
                     ts = []
@@ -345,6 +349,13 @@ class Executor(object):
                 return best[1]
         return self._make_rollout(state0, series, calls, groups)
 
+    def _make_split_rollout(self, state0, series, calls):
+        from .util import distinct_streams
+        st = self.__dict__.get('_chain_streams')
+        if st is None:
+            st = self._chain_streams = distinct_streams(self.device, 2, [torch.cuda.current_stream(self.device)])
+        return SplitRollout([self._make_rollout(state0, series, calls, 1, chain=(c, 2)) for c in range(2)], st, self.device)
+
     def _same_split_regime(self, n_a, n_b):
         """Do the plan's convolutions run in the same split-K regime (equal bits) at n_a and at n_b members per launch?"""
         from . import ops
@@ -356,15 +367,21 @@ class Executor(object):
                     return False
         return True
 
-    def _make_rollout(self, state0, series, calls, groups=None):
+    def _make_rollout(self, state0, series, calls, groups=None, chain=None):
+        """chain = (index, count): a single-chain graph over members [index * n / count, (index + 1) * n / count) of state0 / series,
+        with activation buffers of its own (the halves of a SplitRollout)."""
         from . import _lib, ops
-        n = state0.shape[0]
+        n_total = int(state0.shape[0])
+        n = n_total if chain is None else n_total // int(chain[1])
+        first = 0 if chain is None else int(chain[0]) * n
         n_out = len(self.plan.output_store)
         for s in self.plan.output_store:
             if tuple(s) != tuple(self.plan._in_store):
                 raise ValueError('rollout needs every model output to have the input state shape %r, got %r' %
                                  (self.plan._in_store, s))
-        bufs = self.scratch(n)
+        bufs = self.scratch(n) if chain is None else \
+            [torch.empty((n,) + s_, dtype=torch.bfloat16 if i in self._bf16 else torch.float32, device=self.device)
+             for i, s_ in enumerate(self.plan.buffers)]
         table = [b for b in bufs]
         widx = {}
         for lay in self.plan.conv_layers:
@@ -434,7 +451,8 @@ class Executor(object):
                 o.conv.act = op.act
                 o.conv.out_c_off, o.conv.out_c_total = op.out_c_off, op.out_c_total
         ptrs = (ctypes.c_void_p * max(1, len(table)))(*[t.data_ptr() for t in table])
-        slot = int(np.prod(self.plan._in_store)) * n
+        member = int(np.prod(self.plan._in_store))
+        slot = member * n_total                    # elements between two time slots of the series (all members of the rollout)
         out = ctypes.c_void_p()
         dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
         groups = self.member_groups(n, self.plan._in_store[1] * self.plan._in_store[2]) if groups is None else int(groups)
@@ -445,8 +463,8 @@ class Executor(object):
         ws_bytes = int(_lib.lib.dlwp_rollout_workspace_bytes(_lib.handle(dev), arr, len(self.plan.ops), groups))
         ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=self.device)
         _lib.check(_lib.lib.dlwp_rollout_create_grouped(_lib.handle(dev), arr, len(self.plan.ops), ptrs, len(table),
-                                                        sample_bytes, groups, ctypes.c_void_p(state0.data_ptr()),
-                                                        ctypes.c_void_p(series.data_ptr()), slot, int(calls), n_out,
+                                                        sample_bytes, groups, ctypes.c_void_p(state0.data_ptr() + 4 * first * member),
+                                                        ctypes.c_void_p(series.data_ptr() + 4 * first * member), slot, int(calls), n_out,
                                                         _lib.F32, ctypes.c_void_p(ws.data_ptr()), ws_bytes,
                                                         ctypes.byref(out)))
         rg = RolloutGraph(out, keep=(table, state0, series, arr, ptrs, ws), device=self.device)
@@ -469,6 +487,36 @@ class RolloutGraph(object):
             from . import _lib
             _lib.lib.dlwp_rollout_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class SplitRollout(object):
+    """The members of a rollout as TWO single-chain graphs (Executor._make_rollout(chain=...)) launched side by side on two streams
+    that were probed to sit on hardware queues of their own (util.distinct_streams) -- what a forked graph's branches do only when
+    the streams the runtime draws for them happen to land on different queues.  Same kernels, same bits."""
+
+    def __init__(self, graphs, streams, device):
+        self._graphs, self._streams, self.device = list(graphs), list(streams), device
+        self.groups = 'split'
+
+    def launch(self):
+        main = torch.cuda.current_stream(self.device)
+        for g, s in zip(self._graphs, self._streams):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                g.launch()
+        for s in self._streams:
+            main.wait_stream(s)
+
+    def close(self):
+        for g in self._graphs:
+            g.close()
+        self._graphs = []
 
     def __del__(self):
         try:

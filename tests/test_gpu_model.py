@@ -301,17 +301,17 @@ def test_member_chains_chosen_by_measurement_never_change_a_bit():
     assert lo <= n * 88 * 180 < hi
     x = torch.from_numpy(rng.standard_normal((n,) + cs).astype(np.float32)).to(net.device)
     outs = {}
-    for groups in (1, None):
+    for groups in (1, None, 'split'):         # 'split': two single-chain graphs of 8 members on two probed streams
         s0 = torch.empty_like(x)
         ser = torch.empty((3, n) + cs, device=net.device)
         g = net.executor.make_rollout(s0, ser, 3, groups=groups)
-        assert g.groups in (1, 2) if groups is None else g.groups == 1
+        assert g.groups in (1, 2, 'split') if groups is None else g.groups == groups
         s0.copy_(x)
         g.launch()
         torch.cuda.synchronize()
         outs[groups] = ser.clone()
         g.close()
-    assert torch.equal(outs[1], outs[None])
+    assert torch.equal(outs[1], outs[None]) and torch.equal(outs[1], outs['split'])
     for m in (4, 15):                      # below the range / odd: the rule, no measurement
         s0 = torch.empty((m,) + cs, device=net.device)
         g = net.executor.make_rollout(s0, torch.empty((3, m) + cs, device=net.device), 3)
