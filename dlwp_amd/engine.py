@@ -293,7 +293,7 @@ class Executor(object):
         # recurrent stack (config 4, 180 x 360) gains from 8 members on (r2y: 44.2 -> 45.8 k steps/s at 8, 48.2 -> 50.5 k at 16,
         # four chains 44.4 k), 4 members of config 5 (0.26 M points) do not
         env = os.environ.get('DLWP_ROLLOUT_GROUPS')
-        g = int(env) if env else (2 if n * int(pixels) >= 500000 else 1)
+        g = int(env) if env and env != 'split' else (2 if n * int(pixels) >= 500000 else 1)
         g = max(1, min(g, max(n, 1)))
         while n % g:
             g -= 1
@@ -311,6 +311,8 @@ class Executor(object):
         probed streams (SplitRollout) and the forked graph are captured in turn, each is launched four times on the (zeroed) state; the
         first form that beats one chain by 2 % is kept.  Only where one chain and two run every
         convolution in the same split regime (ops.conv_split_count): the choice never changes a bit of the result."""
+        if groups is None and os.environ.get('DLWP_ROLLOUT_GROUPS') == 'split' and int(state0.shape[0]) % 2 == 0:
+            groups = 'split'
         if groups == 'split':
             return self._make_split_rollout(state0, series, calls)
         if groups is None and os.environ.get('DLWP_ROLLOUT_GROUPS') is None and os.environ.get('DLWP_ROLLOUT_TUNE', '1') != '0':
