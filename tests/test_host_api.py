@@ -558,3 +558,20 @@ def test_output_written_in_place_behind_a_reshape_is_what_a_later_branch_reads()
         convs = [op for op in plan.ops if op.kind == 'conv']
         assert [op.kind for op in plan.ops] == ['conv', 'conv']
         assert convs[0].dst == P.OUT(0) and convs[1].src == P.OUT(0) and convs[1].dst == P.OUT(1)
+
+
+def test_member_chain_rule_and_its_overrides(monkeypatch):
+    """Executor.member_groups: one chain below 0.5 M grid points per launch, two from there on, always a divisor of the member
+    count; DLWP_ROLLOUT_GROUPS=<g> asks for g chains, 'split' (two graphs on two probed streams, Executor.make_rollout) leaves the
+    rule alone.  The range in which make_rollout measures instead lies below the rule's threshold."""
+    from dlwp_amd.engine import Executor
+    monkeypatch.delenv('DLWP_ROLLOUT_GROUPS', raising=False)
+    assert Executor.member_groups(8, 88 * 180) == 1 and Executor.member_groups(32, 88 * 180) == 2
+    assert Executor.member_groups(4, 180 * 360) == 1 and Executor.member_groups(8, 180 * 360) == 2
+    assert Executor.member_groups(33, 88 * 180) == 1            # odd: no two equal chains
+    monkeypatch.setenv('DLWP_ROLLOUT_GROUPS', '4')
+    assert Executor.member_groups(8, 88 * 180) == 4 and Executor.member_groups(6, 88 * 180) == 3
+    monkeypatch.setenv('DLWP_ROLLOUT_GROUPS', 'split')
+    assert Executor.member_groups(8, 88 * 180) == 1 and Executor.member_groups(32, 88 * 180) == 2
+    lo, hi = Executor.tune_groups_between
+    assert 0 < lo < hi <= 500000
