@@ -1331,9 +1331,10 @@ class Trainer(object):
             if self.device.type == 'cuda' or shard is not None:
                 if loader[0] is None:
                     # (its copy stream on a hardware queue of its own: not the main stream's, not a weight-gradient stream's)
-                    avoid = [torch.cuda.current_stream(self.device)] + list(self._ensure_side_streams() if self._fold_ok() else [])
-                    loader[0] = DeviceLoader(generator, self.device, order=order, shard=shard,
-                                             avoid_streams=avoid if self.device.type == 'cuda' else None)
+                    avoid = None
+                    if self.device.type == 'cuda':
+                        avoid = [torch.cuda.current_stream(self.device)] + list(self._ensure_side_streams() if self._fold_ok() else [])
+                    loader[0] = DeviceLoader(generator, self.device, order=order, shard=shard, avoid_streams=avoid)
                 for X, y, n_glob in loader[0].iter_batches(order):
                     yield X, y, n_glob
             else:
