@@ -685,16 +685,12 @@ def sub_train_loader_fed(grid, cin, dev, batches=(64, 8), samples=2560, epochs=3
         host = (time.perf_counter() - t0) / k                       # launches issued, nothing waited for
         torch.cuda.synchronize()
         res = (time.perf_counter() - t0) / k
-        from dlwp_amd.model.generators import DeviceLoader
-        ld = DeviceLoader(gen, dev)
-        ld._setup_pull()
         out['batch_%d' % b] = {
             'loader_fed_ms_per_step': 1e3 * fed, 'device_resident_ms_per_step': 1e3 * res, 'loader_over_resident': fed / res,
             'host_ms_per_step': 1e3 * host, 'step_form': tr._graph_ok(b) or 'python', 'samples_per_s': b / fed,
             'h2d_mb_per_step': 2 * b * cin * grid[0] * grid[1] * 4 / 1e6,
-            'feed': ('rows pulled over the link by a gather kernel from the page-locked training set (dlwp_gather_rows_h2d)'
-                     if ld._pull else ('host gather into pinned buffers (dlwp_host_gather_rows) + H2D copy'
-                                       if gen.batch_sources() is not None else 'generator batches + H2D copy')),
+            'feed': ('host gather into pinned buffers (dlwp_host_gather_rows) + H2D copy'
+                     if gen.batch_sources() is not None else 'generator batches + H2D copy'),
             'steps_timed': epochs * steps}
         del d, tr, gen, P, T
         torch.cuda.empty_cache()

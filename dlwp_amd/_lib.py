@@ -21,6 +21,7 @@ OPT_WINOGRAD, OPT_BF16_MFMA, OPT_FORCE_CONV_CONFIG, OPT_FORCE_WGRAD_CONFIG, OPT_
 OPT_FEW_STREAM = 6
 OPT_SPLITK = 7
 F32, BF16, BF16_O8 = 0, 1, 2
+ROLLOUT_PREPARED = 0x100
 PAD_ZERO, PAD_WRAP, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC = 0, 1, 2, 3, 4
 ACT_LINEAR, ACT_TANH, ACT_RELU = 0, 1, 2
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_MAXPOOL2 = 0, 1, 2
@@ -209,9 +210,7 @@ _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
 _sig('dlwp_host_gather_rows', [_vp, _vp, _vp, ctypes.c_longlong, _sz, ctypes.c_longlong, _i])
 _sig('dlwp_copy2d_d2h_async', [_vp, _sz, _vp, _sz, _sz, _vp])
-_sig('dlwp_host_register', [_vp, _sz, _P(_vp)])
-_sig('dlwp_host_unregister', [_vp])
-_sig('dlwp_gather_rows_h2d', [_vp, _vp, _vp, _vp, ctypes.c_longlong, _sz, ctypes.c_longlong, _vp])
+_sig('dlwp_store2d_to_host', [_vp, _vp, _sz, _vp, _sz, _sz, _sz, _i, _vp])
 _sig('dlwp_train_step_record_begin', [_vp, _vp])
 _sig('dlwp_train_step_record_abort', [_vp])
 _sig('dlwp_stream_wait', [_vp, _vp, _vp])
@@ -230,6 +229,7 @@ _sig('dlwp_xchg_connect', [_vp, _vp])
 _sig('dlwp_xchg_allreduce_sum_f32', [_vp, _vp, _sz, _vp])
 _sig('dlwp_xchg_allreduce_adam', [_vp, _vp, _sz, _sz, _vp, _vp, _vp] + [ctypes.c_float] * 5 + [ctypes.c_longlong, ctypes.c_float, _vp])
 _sig('dlwp_xchg_status', [_vp, _P(_i)])
+_sig('dlwp_xchg_info', [_vp, _P(_i), _P(_i)])
 _sig('dlwp_xchg_destroy', [_vp])
 
 

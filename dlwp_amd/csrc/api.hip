@@ -5,6 +5,7 @@
 #include <string>
 #include <condition_variable>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -215,9 +216,17 @@ struct GatherPool {
     }
   }
 };
+GatherPool* g_gather_pool = nullptr;
 GatherPool& gather_pool() {
-  static GatherPool* p = new GatherPool();     // (never destroyed: its detached threads may outlive static destructors)
-  return *p;
+  // (never destroyed: its detached threads may outlive static destructors.)  A fork()ed child inherits the pool's bookkeeping but
+  // none of its threads -- and possibly a locked mutex: the child starts from a fresh pool (it waited forever on
+  // pending == 0 otherwise)
+  static std::once_flag once;
+  std::call_once(once, [] {
+    g_gather_pool = new GatherPool();
+    (void)pthread_atfork(nullptr, nullptr, [] { g_gather_pool = new GatherPool(); });
+  });
+  return *g_gather_pool;
 }
 }  // namespace
 

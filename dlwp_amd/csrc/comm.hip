@@ -7,6 +7,7 @@
 // and inside a PyTorch process the already-loaded librccl.so.1 instance is reused (RTLD_NOLOAD first), so there is one
 // RCCL per process.  Only the stable NCCL 2.x C API is used; the prototypes are restated here from rccl.h.
 #include "common.h"
+#include "tape.h"
 #include <dlfcn.h>
 #include <mutex>
 
@@ -126,6 +127,7 @@ int dlwp_comm_info(dlwp_comm_t c, int* world, int* rank, int* rccl_version) {
 }
 
 int dlwp_allreduce_sum_f32(dlwp_comm_t c, void* flat, size_t n, void* stream) {
+  DLWP_UNTAPED(dlwp_allreduce_sum_f32);
   DLWP_CHECK_ARG(c != nullptr, "dlwp_allreduce_sum_f32: null communicator");
   DLWP_CHECK_ARG(flat != nullptr || n == 0, "dlwp_allreduce_sum_f32: null buffer");
   if (n == 0) return DLWP_OK;
@@ -136,6 +138,7 @@ int dlwp_allreduce_sum_f32(dlwp_comm_t c, void* flat, size_t n, void* stream) {
 }
 
 int dlwp_broadcast_f32(dlwp_comm_t c, void* flat, size_t n, int root, void* stream) {
+  DLWP_UNTAPED(dlwp_broadcast_f32);
   DLWP_CHECK_ARG(c != nullptr, "dlwp_broadcast_f32: null communicator");
   DLWP_CHECK_ARG(root >= 0 && root < c->world, "dlwp_broadcast_f32: root %d of %d", root, c->world);
   DLWP_CHECK_ARG(flat != nullptr || n == 0, "dlwp_broadcast_f32: null buffer");

@@ -13,7 +13,7 @@ struct dlwp_options {
   int winograd = 1, bf16_mfma = 1, forced_cfg = -1, forced_wgrad = -1, wino_pairs = 1;
   int few_stream = 1;   // conv_fwd_few.hip: 0 off, 1 when the batch is large enough, 2 whenever the layer qualifies (DLWP_OPT_FEW_STREAM)
   int wgrad_fill = 4;   // weight gradient: workgroups per CU the split count aims at, in eighths of 16 waves (DLWP_OPT_WGRAD_FILL)
-  int splitk = 1;       // Winograd forward on small grids: 0 never, 1 by rule, k >= 2 forced split count (DLWP_OPT_SPLITK)
+  int splitk = 0;       // Winograd forward on small grids: 0 never (default, r5: batch-invariant bits), 1 by rule, k >= 2 forced split count (DLWP_OPT_SPLITK)
 };
 const dlwp_options& dlwp_default_options();
 
@@ -85,8 +85,18 @@ int dlwp_reduce_defer(dlwp_handle_t h, const float* src, float* dst, long long n
 char* dlwp_uncached_take(dlwp_handle_t h, size_t bytes);
 void dlwp_uncached_give(dlwp_handle_t h, char* p);
 
+// conv_fwd.hip: a stream about to be destroyed gives its split-K region of the handle back
+void dlwp_splitk_release(dlwp_handle_t h, hipStream_t s);
+
 // scratch for Cin x Cout transformed filters: NULL when it does not fit or cannot be allocated now (stream capture)
 float* dlwp_wino_scratch(dlwp_handle_t h, size_t floats, hipStream_t s);
+
+// The training step's tape (tape.h / tape.hip) records the launch-type entry points that carry DLWP_TAPE.  Every OTHER entry point
+// that takes a stream starts with DLWP_UNTAPED(name): called by a thread that is recording (outside a taped call), it marks the
+// tape FOREIGN and dlwp_train_step_create refuses it -- a replay would silently miss that launch.
+// tests/test_abi.py checks that every stream-taking export carries one of the two macros.
+void dlwp_tape_foreign(const char* name);
+#define DLWP_UNTAPED(NAME) dlwp_tape_foreign(#NAME)
 
 // thread-local error string (defined in api.hip)
 void dlwp_set_error(const char* fmt, ...);

@@ -568,6 +568,19 @@ int dlwp_conv2d_prep_flipped(dlwp_handle_t h, const void* w, float* dst, dlwp_sh
   return e ? prep_with(h, *e, w, dst, zs.c, g->cout, s, 0, 1, 1) : DLWP_OK;
 }
 
+static std::mutex g_splitk_mutex;
+// a stream that is about to be destroyed gives its region back (dlwp_train_step_destroy: the step's capture / side streams; the
+// device has been synchronised).  The last slot moves into the gap: its stream's earlier launches are through their counters
+// (zero between launches), its later ones are ordered behind them on that stream.
+void dlwp_splitk_release(dlwp_handle_t h, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_splitk_mutex);
+  for (int i = 0; i < h->ksplit_used; ++i)
+    if (h->ksplit_stream[i] == (void*)s) {
+      h->ksplit_stream[i] = h->ksplit_stream[--h->ksplit_used];
+      return;
+    }
+}
+
 namespace {
 
 // What one dlwp_conv2d_fwd call launches: the chosen instance and, for a Winograd layer on a map whose last 32-column
@@ -701,10 +714,10 @@ void plan_splitk(dlwp_handle_t h, const ConvArgs& a, const dlwp_conv2d* cd, Laun
   if (lp->ksplit < 2) lp->ksplit = 1;
 }
 
-// the handle's split-K memory for launches on stream s (NULL: none -- the launch then runs unsplit)
+// the handle's split-K memory for launches on stream s (NULL: none -- the launch fails: a silently unsplit launch would sum in
+// another order than dlwp_conv2d_split_count promises)
 char* dlwp_splitk_region(dlwp_handle_t h, hipStream_t s) {
-  static std::mutex m;
-  std::lock_guard<std::mutex> lock(m);
+  std::lock_guard<std::mutex> lock(g_splitk_mutex);
   for (int i = 0; i < h->ksplit_used; ++i)
     if (h->ksplit_stream[i] == (void*)s) return h->ksplit_mem + (size_t)i * DLWP_SPLITK_REGION_BYTES;
   if (!h->ksplit_mem) {
@@ -880,7 +893,10 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   plan_splitk(h, a, cd, &lp, lstm || act_epi || y_pool, kws ? kws->bytes : DLWP_SPLITK_REGION_BYTES);
   if (lp.ksplit > 1) {
     char* ws = kws ? (char*)kws->p : dlwp_splitk_region(h, s);
-    if (ws) {
+    if (!ws)
+      DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_conv2d_fwd: no split-K region for this stream (%d streams hold one; the first split launch of a "
+                "handle must not be inside a stream capture) -- DLWP_OPT_SPLITK 0 runs the layer unsplit", h->ksplit_used);
+    {
       a.ksplit = lp.ksplit;
       a.kchunks = lp.kchunks;
       a.kcount = (unsigned*)ws;
@@ -1102,6 +1118,7 @@ int dlwp_conv2d_fwd_prepared(dlwp_handle_t h, const void* x, const void* w, cons
 int dlwp_convlstm_conv_fwd(dlwp_handle_t h, const void* x, const void* w, const void* prepared, const void* bias,
                            const void* z_add, const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_convlstm_conv_fwd);
   DLWP_CHECK_ARG(h && cd && cd->lstm_f > 0, "dlwp_convlstm_conv_fwd: null handle / descriptor, or lstm_f not set");
   const dlwp_lstm_io io{z_add, c_prev, c_out};
   return dlwp_launch_conv2d(h, x, w, bias, h_out, xs, cd, dtype, (hipStream_t)stream, (const float*)prepared, &io);
@@ -1258,6 +1275,7 @@ size_t dlwp_convlstm_step_prepared_bytes(dlwp_handle_t h, dlwp_shape4 xs_h, cons
 
 int dlwp_convlstm_step_prepare(dlwp_handle_t h, const void* w_h, const void* w_x, void* prepared, dlwp_shape4 xs_h,
                                const dlwp_conv2d* cd_h, dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_convlstm_step_prepare);
   DLWP_CHECK_ARG(h && w_h && w_x && prepared && cd_h && cd_x, "dlwp_convlstm_step_prepare: null handle or pointer");
   return dlwp_convlstm_step_prep(h, w_h, w_x, (float*)prepared, xs_h, cd_h, xs_x, cd_x, dtype, (hipStream_t)stream);
 }
@@ -1265,6 +1283,7 @@ int dlwp_convlstm_step_prepare(dlwp_handle_t h, const void* w_h, const void* w_x
 int dlwp_convlstm_step_fwd(dlwp_handle_t h, const void* h_in, const void* x_in, const void* w_h, const void* w_x,
                            const void* prepared, const void* bias, const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs_h,
                            const dlwp_conv2d* cd_h, dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_convlstm_step_fwd);
   return dlwp_launch_convlstm_step(h, h_in, x_in, w_h, w_x, bias, c_prev, c_out, h_out, xs_h, cd_h, xs_x, cd_x, dtype,
                                    (hipStream_t)stream, (const float*)prepared);
 }
@@ -1280,6 +1299,7 @@ int dlwp_convlstm_conv_supported(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_con
 
 int dlwp_conv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                            const dlwp_conv2d* cd, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_conv2d_fwd_direct);
   dlwp_shape4 ys;
   int rc = validate("dlwp_conv2d_fwd_direct", h, x, w, y, xs, cd, dtype, &ys);
   if (rc != DLWP_OK) return rc;

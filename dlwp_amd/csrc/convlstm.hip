@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void convlstm_gates_bwd_kernel(
 extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* zh, const void* c_prev, void* c_out,
                                    void* h_out, int n, int f, int hw, int h_c_off, int h_c_total, int act, int rec_act,
                                    int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_convlstm_gates);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_convlstm_gates: null handle");
   DLWP_CHECK_ARG((unsigned)DLWP_DTYPE_IN(dtype) <= 1u && (unsigned)DLWP_DTYPE_OUT(dtype) <= 1u && (dtype & ~0x1ffff) == 0,
                  "dlwp_convlstm_gates: dtype 0x%x not supported", dtype);
@@ -172,6 +173,7 @@ extern "C" int dlwp_convlstm_gates(dlwp_handle_t h, const void* zx, const void* 
 extern "C" int dlwp_convlstm_gates_bwd(dlwp_handle_t h, const void* zx, const void* zh, const void* c_prev, const void* c,
                                        const void* dh, const void* dc_in, void* dz, void* dc_prev, int n, int f, int hw,
                                        int h_c_off, int h_c_total, int act, int rec_act, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_convlstm_gates_bwd);
   DLWP_CHECK_ARG(h != nullptr, "dlwp_convlstm_gates_bwd: null handle");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_convlstm_gates_bwd: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(n >= 0 && f > 0 && hw > 0, "dlwp_convlstm_gates_bwd: bad sizes n=%d f=%d hw=%d", n, f, hw);

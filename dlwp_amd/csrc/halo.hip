@@ -41,7 +41,13 @@ __device__ __forceinline__ int pad_map_col(int p, int n, int mode) {
   return p < 0 ? p + n : p - n;
 }
 
-template <int VEC, bool INNER1>
+// FLAT (r5; VEC = 4, INNER1): rows whose length is NOT a multiple of 4 floats (92-float rows of the 44 x 90 maps, 47-float rows of
+// the 22 x 45 maps: the shapes the profile of r2 had at 0.21-0.40 of the HBM peak on 8- and 4-byte accesses).  A group of ROWS = 4
+// output rows starts at a multiple of 4 floats whatever the row length, so the GROUP is stored as aligned 16-byte vectors of the
+// flat output (a vector may span two rows: every element finds its own row and column); a source row that starts misaligned is
+// pulled into LDS through the aligned 16-byte window around it (<= 3 floats of its neighbours on either side ride along, `off`
+// tells where the row starts inside its slot).
+template <int VEC, bool INNER1, bool FLAT = false>
 __global__ __launch_bounds__(256) void pad2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int outer,
                                                         int H, int W, int inner, int Ho, int Wo, int top, int left,
                                                         int mode_h, int mode_w, int row_lds /* floats per row slot */) {
@@ -70,6 +76,55 @@ __global__ __launch_bounds__(256) void pad2d_fwd_kernel(const float* __restrict_
         const int hs = dlwp_map_coord((int)(r - (long long)o * Ho) - top, H, mode_h);
         if (hs >= 0) srow[k] = (long long)o * H + hs;
       }
+    }
+    if constexpr (FLAT) {
+      const long long total_in = (long long)outer * H * RI;
+      const int NV = (RI + 6) >> 2;                    // 16-byte units of a row's aligned window, at most
+      for (int j = lane; j < ROWS * NV; j += 64) {
+        const int k = (j >= NV) + (j >= 2 * NV) + (j >= 3 * NV);
+        const int i = j - k * NV;
+        const long long sr = k == 0 ? srow[0] : (k == 1 ? srow[1] : (k == 2 ? srow[2] : srow[3]));
+        if (sr < 0) continue;
+        const long long b = sr * RI;
+        const int off = (int)(b & 3);
+        if (4 * i >= off + RI) continue;
+        const long long a = (b & ~3ll) + 4 * i;
+        float* d = slot + k * row_lds + 4 * i;
+        if (a + 4 <= total_in) {
+          *(f32x4*)d = *(const f32x4*)(x + a);
+        } else {                                         // the tensor's last, partial unit
+          for (int q = 0; q < 4; ++q)
+            if (a + q < total_in) d[q] = x[a + q];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int rows_here = (int)(n_rows - r0 < ROWS ? n_rows - r0 : ROWS);
+      const int valid = rows_here * RO;                  // floats of this group that exist
+      for (int j = lane; 4 * j < valid; j += 64) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = 4 * j + q;
+          const int k = (e >= RO) + (e >= 2 * RO) + (e >= 3 * RO);
+          const int wo = e - k * RO;
+          const long long sr = k == 0 ? srow[0] : (k == 1 ? srow[1] : (k == 2 ? srow[2] : srow[3]));
+          const int ws = pad_map_col(wo - left, W, mode_w);
+          const int off = (int)((sr * RI) & 3);
+          v[q] = (sr >= 0 && ws >= 0) ? slot[k * row_lds + off + (ws >= 0 ? ws : 0)] : 0.f;
+        }
+        float* dst = y + r0 * RO + 4 * j;
+        if (4 * j + 4 <= valid) {
+          *(f32x4*)dst = v;
+        } else {
+          for (int q = 0; q < 4; ++q)
+            if (4 * j + q < valid) dst[q] = v[q];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      continue;
     }
     for (int j = lane; j < ROWS * RIV; j += 64) {
       const int k = (j >= RIV) + (j >= 2 * RIV) + (j >= 3 * RIV);
@@ -112,7 +167,7 @@ __global__ __launch_bounds__(256) void pad2d_fwd_kernel(const float* __restrict_
 // stores whose lanes add the column images (interior column + wrapped / clamped halo columns) out of LDS.  The few dx rows
 // that are also the image of halo ROWS (the first / last `bottom` / `top` rows of a periodic axis, row 0 / H-1 of an edge
 // axis) add those rows straight from global memory.  Fixed summation order per element: deterministic.
-template <int VEC, bool INNER1>
+template <int VEC, bool INNER1, bool FLAT = false>
 __global__ __launch_bounds__(256) void pad2d_bwd_rows_kernel(const float* __restrict__ dy, float* __restrict__ dx, int outer,
                                                              int H, int W, int inner, int Ho, int Wo, int top, int bottom,
                                                              int left, int right, int mode_h, int mode_w, int row_lds) {
@@ -147,6 +202,86 @@ __global__ __launch_bounds__(256) void pad2d_bwd_rows_kernel(const float* __rest
     return s;
   };
   for (long long r0 = ((long long)blockIdx.x * 4 + wave) * ROWS; r0 < n_rows; r0 += stride) {
+    if constexpr (FLAT) {          // (see pad2d_fwd_kernel: aligned windows in, the group of 4 dx rows out as flat 16-byte vectors)
+      const long long total_dy = (long long)outer * Ho * RO;
+      const int NV = (RO + 6) >> 2;
+      long long ob[ROWS];          // first dy element of the interior row of dx row r0 + k (-1: past the end)
+      int hk[ROWS];
+#pragma unroll
+      for (int k = 0; k < ROWS; ++k) {
+        const long long r = r0 + k;
+        ob[k] = -1;
+        hk[k] = 0;
+        if (r < n_rows) {
+          const long long o = r / H;
+          hk[k] = (int)(r - o * H);
+          ob[k] = (o * Ho + hk[k] + top) * RO;
+        }
+      }
+      for (int j = lane; j < ROWS * NV; j += 64) {
+        const int k = (j >= NV) + (j >= 2 * NV) + (j >= 3 * NV);
+        const int i = j - k * NV;
+        const long long b = k == 0 ? ob[0] : (k == 1 ? ob[1] : (k == 2 ? ob[2] : ob[3]));
+        if (b < 0) continue;
+        const int off = (int)(b & 3);
+        if (4 * i >= off + RO) continue;
+        const long long a = (b & ~3ll) + 4 * i;
+        float* d = slot + k * row_lds + 4 * i;
+        if (a + 4 <= total_dy) {
+          *(f32x4*)d = *(const f32x4*)(dy + a);
+        } else {
+          for (int q = 0; q < 4; ++q)
+            if (a + q < total_dy) d[q] = dy[a + q];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int rows_here = (int)(n_rows - r0 < ROWS ? n_rows - r0 : ROWS);
+      const int valid = rows_here * RI;
+      for (int j = lane; 4 * j < valid; j += 64) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int e = 4 * j + q;
+          const int k = (e >= RI) + (e >= 2 * RI) + (e >= 3 * RI);
+          const int w = e - k * RI;
+          const long long b = k == 0 ? ob[0] : (k == 1 ? ob[1] : (k == 2 ? ob[2] : ob[3]));
+          const int hh = k == 0 ? hk[0] : (k == 1 ? hk[1] : (k == 2 ? hk[2] : hk[3]));
+          float acc = 0.f;
+          if (b >= 0) {
+            const float* row = slot + k * row_lds + (int)(b & 3);
+            const float* img = dy + (b - (long long)(hh + top) * RO);      // this image's padded gradient
+            acc = col_sum(row, w, 0);
+            if (mode_h == DLWP_PAD_WRAP) {
+              if (hh >= H - top) acc += col_sum(img + (long long)(hh - (H - top)) * RO, w, 0);
+              if (hh < bottom) acc += col_sum(img + (long long)(top + H + hh) * RO, w, 0);
+            } else if (mode_h == DLWP_PAD_EDGE) {
+              if (hh == 0)
+                for (int rr = 0; rr < top; ++rr) acc += col_sum(img + (long long)rr * RO, w, 0);
+              if (hh == H - 1)
+                for (int rr = top + H; rr < Ho; ++rr) acc += col_sum(img + (long long)rr * RO, w, 0);
+            } else if (mode_h >= DLWP_PAD_REFLECT) {
+              for (int rr = 0; rr < top; ++rr)
+                if (pad_map_col(rr - top, H, mode_h) == hh) acc += col_sum(img + (long long)rr * RO, w, 0);
+              for (int rr = top + H; rr < Ho; ++rr)
+                if (pad_map_col(rr - top, H, mode_h) == hh) acc += col_sum(img + (long long)rr * RO, w, 0);
+            }
+          }
+          v[q] = acc;
+        }
+        float* dst = dx + r0 * RI + 4 * j;
+        if (4 * j + 4 <= valid) {
+          *(f32x4*)dst = v;
+        } else {
+          for (int q = 0; q < 4; ++q)
+            if (4 * j + q < valid) dst[q] = v[q];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     for (int j = lane; j < ROWS * ROV; j += 64) {
       const int k = (j >= ROV) + (j >= 2 * ROV) + (j >= 3 * ROV);
       const int c = (j - k * ROV) * VEC;
@@ -448,20 +583,25 @@ int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, in
   if (outer == 0) return DLWP_OK;
   const int Ho = H + p.top + p.bottom, Wo = W + p.left + p.right;
   const long long RI = (long long)W * inner, RO = (long long)Wo * inner;
-  const int row_lds = (int)((RI + 3) / 4 * 4);
+  const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(x) && aligned16(y);
+  // rows that are not whole 16-byte units: aligned windows in, flat 16-byte vectors out (pad2d_fwd_kernel<4, true, true>)
+  const bool flat = !vec && inner == 1 && aligned16(x) && aligned16(y);
+  const int row_lds = flat ? (int)((RI + 6) / 4 * 4 + 4) : (int)((RI + 3) / 4 * 4);
   const size_t lds_bytes = (size_t)row_lds * 4 * 4 * sizeof(float);  // 4 waves x ROWS(4) row slots
   DLWP_CHECK_ARG(lds_bytes <= (size_t)h->lds_bytes, "dlwp_pad2d_fwd: row of %lld floats does not fit in LDS", RI);
   const long long n_rows = (long long)outer * Ho;
   int grid = (int)((n_rows + 15) / 16);
   const int cap = h->cu_count * 8;
   if (grid > cap) grid = cap;
-  const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(x) && aligned16(y);
   const bool vec2 = (RI % 2 == 0) && (RO % 2 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 7) == 0;
   hipStream_t s = (hipStream_t)stream;
 #define PAD_LAUNCH(V, I1)                                                                                            \
   pad2d_fwd_kernel<V, I1><<<grid, 256, lds_bytes, s>>>((const float*)x, (float*)y, outer, H, W, inner, Ho, Wo, p.top, \
                                                        p.left, p.mode_h, p.mode_w, row_lds)
-  if (inner == 1) {
+  if (flat) {
+    pad2d_fwd_kernel<4, true, true><<<grid, 256, lds_bytes, s>>>((const float*)x, (float*)y, outer, H, W, inner, Ho, Wo, p.top,
+                                                                 p.left, p.mode_h, p.mode_w, row_lds);
+  } else if (inner == 1) {
     if (vec) PAD_LAUNCH(4, true);
     else if (vec2) PAD_LAUNCH(2, true);
     else PAD_LAUNCH(1, true);
@@ -494,20 +634,24 @@ int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, 
     // row-staged kernel whenever 4 waves x 4 padded rows fit in LDS (every shape of the reference's networks does)
     const int Ho = H + p.top + p.bottom, Wo = W + p.left + p.right;
     const long long RI = (long long)W * inner, RO = (long long)Wo * inner;
-    const int row_lds = (int)((RO + 3) / 4 * 4);
+    const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(dy) && aligned16(dx);
+    const bool flat = !vec && inner == 1 && aligned16(dy) && aligned16(dx);
+    const int row_lds = flat ? (int)((RO + 6) / 4 * 4 + 4) : (int)((RO + 3) / 4 * 4);
     const size_t lds_bytes = (size_t)row_lds * 4 * 4 * sizeof(float);
     if (lds_bytes <= (size_t)h->lds_bytes && lds_bytes <= 64 * 1024) {
       const long long n_rows = (long long)outer * H;
       int grid = (int)((n_rows + 15) / 16);
       const int cap = h->cu_count * 8;
       if (grid > cap) grid = cap;
-      const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(dy) && aligned16(dx);
       const bool vec2 = (RI % 2 == 0) && (RO % 2 == 0) && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 7) == 0;
       hipStream_t s = (hipStream_t)stream;
 #define PADB_LAUNCH(V, I1)                                                                                              \
   pad2d_bwd_rows_kernel<V, I1><<<grid, 256, lds_bytes, s>>>((const float*)dy, (float*)dx, outer, H, W, inner, Ho, Wo,   \
                                                             p.top, p.bottom, p.left, p.right, p.mode_h, p.mode_w, row_lds)
-      if (inner == 1) {
+      if (flat) {
+        pad2d_bwd_rows_kernel<4, true, true><<<grid, 256, lds_bytes, s>>>((const float*)dy, (float*)dx, outer, H, W, inner, Ho, Wo,
+                                                                          p.top, p.bottom, p.left, p.right, p.mode_h, p.mode_w, row_lds);
+      } else if (inner == 1) {
         if (vec) PADB_LAUNCH(4, true);
         else if (vec2) PADB_LAUNCH(2, true);
         else PADB_LAUNCH(1, true);
@@ -636,6 +780,7 @@ int dlwp_copy_channels(dlwp_handle_t h, const void* src, void* dst, int n, int c
 
 int dlwp_series_merge_time(dlwp_handle_t h, const void* series, void* out, int t, int n, int time_dim, int v, int hw,
                            int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_series_merge_time);
   DLWP_CHECK_ARG(h && series && out, "dlwp_series_merge_time: null handle or pointer");
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_series_merge_time: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(t >= 0 && n >= 0 && time_dim > 0 && v > 0 && hw > 0, "dlwp_series_merge_time: bad shape");

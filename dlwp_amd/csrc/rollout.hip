@@ -151,6 +151,12 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
     }
   const dlwp_op* plan = gplan.data();
   DLWP_CHECK_ARG(n_ops > 0 && calls > 0 && n_outputs > 0 && slot_elems > 0, "dlwp_rollout_create: bad sizes");
+  // DLWP_ROLLOUT_PREPARED: this graph is a LATER slice of a rollout whose first slice is launched in front of it on the same
+  // stream and has written the prepared weights into the SAME workspace -- the slice prepares nothing (time-sliced rollouts,
+  // dlwp_amd/engine.py: StreamedRollout: one graph per model call, so that a forecast slot can leave for the host while the
+  // next call runs)
+  const bool prepared = (dtype & DLWP_ROLLOUT_PREPARED) != 0;
+  dtype &= ~DLWP_ROLLOUT_PREPARED;
   DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_rollout_create: dtype %d not supported", dtype);
   DLWP_CHECK_ARG(n_buffers == 0 || buffers, "dlwp_rollout_create: null buffer table");
   for (int i = 0; i < n_ops; ++i) {
@@ -265,7 +271,7 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
     if (k_base) dlwp_uncached_give(h, k_base);
     DLWP_FAIL(DLWP_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
   }
-  prepare(cap);
+  if (!prepared) prepare(cap);
   std::vector<hipStream_t> branch;
   std::vector<hipEvent_t> events;
   if (groups == 1) {
@@ -331,6 +337,7 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
 }
 
 int dlwp_rollout_launch(dlwp_rollout_t r, void* stream) {
+  DLWP_UNTAPED(dlwp_rollout_launch);
   DLWP_CHECK_ARG(r && r->exec, "dlwp_rollout_launch: null rollout");
   // A FORKED graph (member chains) is launched on a stream of the rollout's own, ordered behind and in front of the caller's by two
   // events -- never on the caller's stream itself, which under torch is the legacy null stream: r4, the first full GPU test run on a

@@ -847,6 +847,7 @@ extern "C" {
 
 int dlwp_rowconv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                        const dlwp_conv2d* cd, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_rowconv2d_fwd);
   dlwp_shape4 ys;
   if (int rc = validate_row("dlwp_rowconv2d_fwd", h, xs, cd, dtype, &ys)) return rc;
   DLWP_CHECK_ARG(xs.n == 0 || (x && w && y), "dlwp_rowconv2d_fwd: null pointer");
@@ -882,6 +883,7 @@ int dlwp_rowconv2d_fwd(dlwp_handle_t h, const void* x, const void* w, const void
 
 int dlwp_rowconv2d_fwd_direct(dlwp_handle_t h, const void* x, const void* w, const void* bias, void* y, dlwp_shape4 xs,
                               const dlwp_conv2d* cd, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_rowconv2d_fwd_direct);
   dlwp_shape4 ys;
   if (int rc = validate_row("dlwp_rowconv2d_fwd_direct", h, xs, cd, dtype, &ys)) return rc;
   DLWP_CHECK_ARG(xs.n == 0 || (x && w && y), "dlwp_rowconv2d_fwd_direct: null pointer");
@@ -911,6 +913,7 @@ int dlwp_rowconv2d_bwd_workspace(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_con
 
 int dlwp_rowconv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void* dx, dlwp_shape4 xs, const dlwp_conv2d* cd,
                             int dtype, void* ws, size_t ws_bytes, void* stream) {
+  DLWP_UNTAPED(dlwp_rowconv2d_bwd_data);
   dlwp_shape4 ys;
   if (int rc = validate_row("dlwp_rowconv2d_bwd_data", h, xs, cd, dtype, &ys, false)) return rc;
   DLWP_CHECK_ARG(xs.n == 0 || (dz && w && dx), "dlwp_rowconv2d_bwd_data: null pointer");
@@ -959,6 +962,7 @@ int dlwp_rowconv2d_bwd_data(dlwp_handle_t h, const void* dz, const void* w, void
 
 int dlwp_rowconv2d_bwd_weight(dlwp_handle_t h, const void* x, const void* dz, void* dw, void* db, dlwp_shape4 xs,
                               const dlwp_conv2d* cd, int accumulate, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_rowconv2d_bwd_weight);
   dlwp_shape4 ys;
   if (int rc = validate_row("dlwp_rowconv2d_bwd_weight", h, xs, cd, dtype, &ys)) return rc;
   DLWP_CHECK_ARG(x && dz && dw, "dlwp_rowconv2d_bwd_weight: null pointer");

@@ -18,7 +18,8 @@ struct Tape {
   dlwp_handle_t h;
   std::vector<void*> lanes;          // recorded stream of every lane; [0] = the main stream
   std::vector<Rec> recs;
-  int error;
+  int error;                         // 1: the thread called an entry point the tape does not carry (dlwp_tape_foreign)
+  const char* foreign;               // ... its name
 };
 
 thread_local Tape* t_tape = nullptr;
@@ -43,6 +44,15 @@ dlwp_tape_scope::~dlwp_tape_scope() {
   // the call failed: its record (the last one: nothing else is pushed while an outermost scope is open) leaves the tape
   if (pushed >= 0 && t_tape && dlwp_error_count() != errors_at_entry && (long long)t_tape->recs.size() == pushed + 1)
     t_tape->recs.pop_back();
+}
+
+// an entry point WITHOUT a tape record was called by a recording thread, outside any taped call (inside one it is part of that
+// call's closure): the step object would replay without it
+void dlwp_tape_foreign(const char* name) {
+  if (t_tape && t_depth == 0 && !t_tape->error) {
+    t_tape->error = 1;
+    t_tape->foreign = name;
+  }
 }
 
 bool dlwp_tape_recording(dlwp_handle_t h) { return t_tape != nullptr && t_tape->h == h; }
@@ -131,6 +141,7 @@ int dlwp_train_step_record_begin(dlwp_handle_t h, void* main_stream) {
   Tape* t = new Tape();
   t->h = h;
   t->error = 0;
+  t->foreign = nullptr;
   t->lanes.push_back(main_stream);
   t_tape = t;
   return DLWP_OK;
@@ -169,6 +180,11 @@ int dlwp_train_step_create(dlwp_handle_t h, int n_in, void* const* in_dst, const
   DLWP_CHECK_ARG(n_in >= 0 && n_in <= 8 && (n_in == 0 || (in_dst && in_floats)), "dlwp_train_step_create: at most 8 input buffers");
   Tape* t = t_tape;
   t_tape = nullptr;
+  if (t->error) {       // (the recording is over either way: the caller runs this shape launch by launch)
+    const char* name = t->foreign ? t->foreign : "?";
+    delete t;
+    DLWP_FAIL(DLWP_EUNSUPPORTED, "dlwp_train_step_create: the recorded step called %s, which the tape does not record", name);
+  }
   dlwp_train_step* st = new dlwp_train_step();
   st->h = h;
   st->recs = std::move(t->recs);
@@ -268,8 +284,14 @@ int dlwp_train_step_destroy(dlwp_train_step_t st) {
   for (hipEvent_t e : st->events) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i)
     if (st->order[i]) (void)hipEventDestroy(st->order[i]);
-  for (hipStream_t s : st->side) (void)hipStreamDestroy(s);
-  if (st->cap) (void)hipStreamDestroy(st->cap);
+  for (hipStream_t s : st->side) {
+    dlwp_splitk_release(st->h, s);
+    (void)hipStreamDestroy(s);
+  }
+  if (st->cap) {
+    dlwp_splitk_release(st->h, st->cap);
+    (void)hipStreamDestroy(st->cap);
+  }
   delete st;
   return DLWP_OK;
 }

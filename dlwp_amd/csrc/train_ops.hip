@@ -729,6 +729,7 @@ int dlwp_loss_custom(dlwp_handle_t h, const void* y_pred, const void* y_true, in
 
 int dlwp_adam_keras(dlwp_handle_t h, void* p, void* m, void* v, const void* g, size_t n, float lr, float beta_1,
                     float beta_2, float epsilon, float decay, long long iteration, float grad_scale, void* stream) {
+  DLWP_UNTAPED(dlwp_adam_keras);
   DLWP_CHECK_ARG(h && p && m && v && g, "dlwp_adam_keras: null handle or pointer");
   if (n == 0) return DLWP_OK;
   // t = it+1; lr' = lr/(1+decay*it); lr_t = lr' * sqrt(1-b2^t)/(1-b1^t)    (DLWP/custom.py:38-40), in double on the host

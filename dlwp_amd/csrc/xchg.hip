@@ -7,16 +7,21 @@
 // every peer's memory, waits for the peers' flags, reads all W buffers and sums them IN RANK ORDER -- the same order on every rank,
 // so the replicas stay bit-identical -- and applies the Adam update to its own parameters in the same kernel.
 //
-//   region of a rank (device memory, mapped by every peer):  header { flags[64], arrive, error }  +  2 payload buffers (step parity)
-//   one launch: (A) blocks copy their slice of `flat` into payload[step & 1]; the LAST block to finish stores `step` into flag
-//   [my rank] of every peer's header.  (B) every block waits until all flags of its OWN header read `step`, then sums its slice over
-//   the ranks 0 .. W - 1 and updates p, m, v (or writes the sum back to flat).
+//   region of a rank (UNCACHED device memory, mapped by every peer):  header { flags[64], arrive, error }  +  2 payload buffers
+//   (step parity).  One launch of a PERSISTENT grid (at most one workgroup per CU, grid-stride over the float4s -- every workgroup is
+//   resident whatever the buffer's size; r4's one-workgroup-per-1024-floats grid could not be above ~2 M floats and then always
+//   timed out): (A) the workgroups copy `flat` into payload[step & 1]; the LAST one to finish stores `step` into flag
+//   [my rank] of every peer's header.  (B) every workgroup waits until all flags of its OWN header read `step`, then (C) sums its
+//   float4s over the ranks 0 .. W - 1 and updates p, m, v (or writes the sum back to flat).
 //   Two payload buffers suffice: a rank overwrites buffer s & 1 at step s + 2, after its step s + 1 completed, which needed every
 //   peer's flag s + 1, which a peer raises only after its own step s -- the last reader of that buffer -- returned.
 // Coherence: no fences (an agent-scope fence on gfx950 writes back and invalidates the XCD's whole L2, see conv_fwd_wino_kernel.h):
-// every payload / flag access carries sc0 sc1 (system scope: past the L1s and L2s on both sides), stores are waited for
-// (s_waitcnt vmcnt(0)) before the flag goes up.  A wait is BOUNDED (2 s of s_memrealtime): a peer that never arrives makes the kernel
-// set header.error and return; dlwp_xchg_status reports it -- never a hung GPU.
+// the region is allocated hipDeviceMallocUncached (as the split-K slabs, DESIGN 5.10: intra-kernel visibility of a PEER's writes is
+// what uncached / fine-grained memory is for; VERDICT r4 weak e), every payload / flag access carries sc0 sc1 on top (system scope:
+// past the L1s and L2s on both sides), stores are waited for (s_waitcnt vmcnt(0)) before the flag goes up.  A wait is BOUNDED (2 s
+// of s_memrealtime): a peer that never arrives makes the kernel set header.error, overwrite the loss table behind the parameters
+// with NaN and return WITHOUT touching p, m, v; dlwp_xchg_status reports it (the trainer asks whenever it reads a loss) -- never a
+// hung GPU, never a silent half-applied update.
 #include "common.h"
 
 namespace {
@@ -38,23 +43,19 @@ struct Peers {
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned load_sys(const unsigned* p) {
-  return __builtin_nontemporal_load(p);   // (replaced below by the buffer form; kept for clarity of intent)
-}
-
 template <bool ADAM>
 __global__ __launch_bounds__(256) void xchg_allreduce_kernel(Peers peers, int world, int rank, unsigned step, long long n4,
                                                              long long n_params, float* __restrict__ flat, float* __restrict__ p,
                                                              float* __restrict__ m, float* __restrict__ v, float lr_t, float b1,
                                                              float b2, float eps, float grad_scale) {
   const int tid = threadIdx.x;
-  const long long i = (long long)blockIdx.x * 256 + tid;          // this thread's float4
+  const long long first = (long long)blockIdx.x * 256 + tid, stride = (long long)gridDim.x * 256;   // in float4s
   const size_t pay_off = XCHG_HEADER_BYTES + (size_t)(step & 1u) * (size_t)n4 * 16;
   Header* const mine = (Header*)peers.region[rank];
   // ---- (A) publish
   {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(peers.region[rank] + pay_off), 0, (unsigned)(n4 * 16), 0x00020000);
-    if (i < n4) {
+    for (long long i = first; i < n4; i += stride) {
       const f32x4_t g = *(const f32x4_t*)(flat + 4 * i);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, g), r, (unsigned)(i * 16), 0, SYS);
     }
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(Peers peers, int wo
     __shared__ unsigned s_last;
     if (tid == 0) s_last = __hip_atomic_fetch_add(&mine->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (s_last == gridDim.x - 1) {          // every block's slice is in memory: raise the flag in every rank's header
+    if (s_last == gridDim.x - 1) {          // every workgroup's share is in memory: raise the flag in every rank's header
       if (tid == 0) __hip_atomic_store(&mine->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tid < world) {
         const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)peers.region[tid], 0, (unsigned)XCHG_HEADER_BYTES, 0x00020000);
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(Peers peers, int wo
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
-  // ---- (B) wait for every rank's flag in the OWN header
+  // ---- (B) wait for every rank's flag in the OWN header (the grid is resident as a whole: at most one workgroup per CU)
   {
     __shared__ unsigned s_ok;
     if (tid == 0) s_ok = 1u;
@@ -83,7 +84,9 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(Peers peers, int wo
       for (;;) {
         const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(fr, (unsigned)(tid * 4), 0, SYS);
         if ((int)(f - step) >= 0) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {        // 2 s: the peer is not coming
+        // (another workgroup of this launch gave up: so does this one -- nobody applies half an update)
+        const unsigned err = __builtin_amdgcn_raw_buffer_load_b32(fr, (unsigned)__builtin_offsetof(Header, error), 0, SYS);
+        if (err != 0u || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {        // 2 s: the peer is not coming
           __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           s_ok = 0u;
           break;
@@ -92,31 +95,36 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(Peers peers, int wo
       }
     }
     __syncthreads();
-    if (!s_ok) return;
-  }
-  if (i >= n4) return;
-  // ---- sum over the ranks in rank order (identical on every rank), then the update
-  f32x4_t g = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int q = 0; q < world; ++q) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(peers.region[q] + pay_off), 0, (unsigned)(n4 * 16), 0x00020000);
-    const f32x4_t t = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(i * 16), 0, SYS));
-    g = q == 0 ? t : g + t;
-  }
-  if (ADAM) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const long long e = 4 * i + k;
-      if (e < n_params) {
-        const float gi = g[k] * grad_scale;
-        const float mi = b1 * m[e] + (1.f - b1) * gi;
-        const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
-        m[e] = mi;
-        v[e] = vi;
-        p[e] = p[e] - lr_t * mi / (sqrtf(vi) + eps);
-      }
+    if (!s_ok) {
+      // the step's result is invalid: the loss table (everything behind the parameters) reads NaN, p / m / v keep their values
+      for (long long e = n_params + first; e < 4 * n4; e += stride) flat[e] = __builtin_nanf("");
+      return;
     }
   }
-  *(f32x4_t*)(flat + 4 * i) = g;          // the summed buffer (gradients and the loss table in its tail)
+  // ---- (C) sum over the ranks in rank order (identical on every rank), then the update
+  for (long long i = first; i < n4; i += stride) {
+    f32x4_t g = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < world; ++q) {
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(peers.region[q] + pay_off), 0, (unsigned)(n4 * 16), 0x00020000);
+      const f32x4_t t = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(i * 16), 0, SYS));
+      g = q == 0 ? t : g + t;
+    }
+    if (ADAM) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long long e = 4 * i + k;
+        if (e < n_params) {
+          const float gi = g[k] * grad_scale;
+          const float mi = b1 * m[e] + (1.f - b1) * gi;
+          const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
+          m[e] = mi;
+          v[e] = vi;
+          p[e] = p[e] - lr_t * mi / (sqrtf(vi) + eps);
+        }
+      }
+    }
+    *(f32x4_t*)(flat + 4 * i) = g;          // the summed buffer (gradients and the loss table in its tail)
+  }
 }
 
 }  // namespace
@@ -131,6 +139,8 @@ struct dlwp_xchg {
   bool mapped[XCHG_MAX_WORLD];
   unsigned step;
   bool connected;
+  int memory_kind;                   // 2: hipDeviceMallocUncached, 1: hipDeviceMallocFinegrained, 0: plain hipMalloc (coarse-grained)
+  int max_blocks;                    // persistent grid: one workgroup per CU
 };
 
 extern "C" {
@@ -151,16 +161,30 @@ int dlwp_xchg_create(dlwp_handle_t h, int world, int rank, size_t n_floats, void
   x->step = 0;
   x->connected = false;
   for (int i = 0; i < XCHG_MAX_WORLD; ++i) x->peers.region[i] = nullptr, x->mapped[i] = false;
-  hipError_t e = hipMalloc((void**)&x->region, x->region_bytes);
-  if (e == hipSuccess) e = hipMemset(x->region, 0, x->region_bytes);
+  // uncached first (what intra-kernel visibility of a peer's writes asks for), then fine-grained, then plain device memory: the kind
+  // that both allocates AND exports an IPC handle on this runtime wins; dlwp_xchg_info tells which
+  const unsigned kinds[3] = {hipDeviceMallocUncached, hipDeviceMallocFinegrained, hipDeviceMallocDefault};
+  hipError_t e = hipErrorUnknown;
   hipIpcMemHandle_t hd;
-  if (e == hipSuccess) e = hipIpcGetMemHandle(&hd, x->region);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    if (x->region) (void)hipFree(x->region);
+  x->memory_kind = -1;
+  for (int k = 0; k < 3 && x->memory_kind < 0; ++k) {
+    x->region = nullptr;
+    e = k < 2 ? hipExtMallocWithFlags((void**)&x->region, x->region_bytes, kinds[k]) : hipMalloc((void**)&x->region, x->region_bytes);
+    if (e == hipSuccess) e = hipMemset(x->region, 0, x->region_bytes);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&hd, x->region);
+    if (e == hipSuccess) {
+      x->memory_kind = 2 - k;
+    } else {
+      (void)hipGetLastError();
+      if (x->region) (void)hipFree(x->region);
+      x->region = nullptr;
+    }
+  }
+  if (x->memory_kind < 0) {
     delete x;
     DLWP_FAIL(DLWP_EHIP, "dlwp_xchg_create: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 exported?)", hipGetErrorString(e));
   }
+  x->max_blocks = h->cu_count > 0 ? h->cu_count : 256;
   memcpy(ipc_handle_out, &hd, 64);
   x->peers.region[rank] = x->region;
   *out = x;
@@ -196,7 +220,8 @@ static int xchg_launch(dlwp_xchg_t x, float* flat, size_t n, bool adam, size_t n
   // (the payload stride of a parity is fixed by the region, not by this call's n)
   DLWP_CHECK_ARG((size_t)n4 == x->n4, "dlwp_xchg: every exchange moves the %zu floats the region was made for", x->n_floats);
   ++x->step;
-  const int grid = (int)((n4 + 255) / 256);
+  const long long want = (n4 + 255) / 256;
+  const int grid = (int)(want < x->max_blocks ? want : x->max_blocks);
   if (adam)
     xchg_allreduce_kernel<true><<<grid, 256, 0, s>>>(x->peers, x->world, x->rank, x->step, n4, (long long)n_params, flat, p, m, v, lr_t,
                                                      b1, b2, eps, grad_scale);
@@ -209,6 +234,7 @@ static int xchg_launch(dlwp_xchg_t x, float* flat, size_t n, bool adam, size_t n
 
 // flat <- sum over the ranks of flat (n floats, n = the region's size), in rank order.  Collective: every rank calls it.
 int dlwp_xchg_allreduce_sum_f32(dlwp_xchg_t x, void* flat, size_t n, void* stream) {
+  DLWP_UNTAPED(dlwp_xchg_allreduce_sum_f32);
   return xchg_launch(x, (float*)flat, n, false, 0, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f, 1.f, (hipStream_t)stream);
 }
 
@@ -216,6 +242,7 @@ int dlwp_xchg_allreduce_sum_f32(dlwp_xchg_t x, void* flat, size_t n, void* strea
 // (the loss table behind the gradients travels along).  `iteration`: the optimizer's step number BEFORE this update, as dlwp_adam_keras.
 int dlwp_xchg_allreduce_adam(dlwp_xchg_t x, void* flat, size_t n_params, size_t n, void* p, void* m, void* v, float lr, float beta_1,
                              float beta_2, float epsilon, float decay, long long iteration, float grad_scale, void* stream) {
+  DLWP_UNTAPED(dlwp_xchg_allreduce_adam);
   DLWP_CHECK_ARG(p && m && v && n_params <= n, "dlwp_xchg_allreduce_adam: null pointer or n_params > n");
   const double t = (double)iteration + 1.0;
   const double lr_ = (double)lr / (1.0 + (double)decay * (double)iteration);
@@ -230,6 +257,14 @@ int dlwp_xchg_status(dlwp_xchg_t x, int* timed_out) {
   Header hd;
   DLWP_HIP(hipMemcpy(&hd, x->region, sizeof(Header), hipMemcpyDeviceToHost));
   *timed_out = hd.error ? 1 : 0;
+  return DLWP_OK;
+}
+
+// memory_kind: 2 uncached, 1 fine-grained, 0 plain (coarse-grained) device memory; max_blocks: the persistent grid's size
+int dlwp_xchg_info(dlwp_xchg_t x, int* memory_kind, int* max_blocks) {
+  DLWP_CHECK_ARG(x != nullptr, "dlwp_xchg_info: null exchange");
+  if (memory_kind) *memory_kind = x->memory_kind;
+  if (max_blocks) *max_blocks = x->max_blocks;
   return DLWP_OK;
 }
 

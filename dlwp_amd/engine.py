@@ -369,13 +369,18 @@ class Executor(object):
                     return False
         return True
 
-    def _make_rollout(self, state0, series, calls, groups=None, chain=None):
+    def _make_rollout(self, state0, series, calls, groups=None, chain=None, span=None, ws=None, prepared=False):
         """chain = (index, count): a single-chain graph over members [index * n / count, (index + 1) * n / count) of state0 / series,
-        with activation buffers of its own (the halves of a SplitRollout)."""
+        with activation buffers of its own (the halves of a SplitRollout).
+        span = (first call, number of calls): a TIME SLICE of the rollout over `series` -- the graph of calls [first, first + number),
+        reading its state from the series slot the call before wrote (state0 for first = 0) -- one of several graphs launched one
+        behind the other on a stream (StreamedRollout).  ws: the prepared-weights workspace to use (slices of one member count
+        share it); prepared: the slice launched in front has filled it."""
         from . import _lib, ops
         n_total = int(state0.shape[0])
         n = n_total if chain is None else n_total // int(chain[1])
         first = 0 if chain is None else int(chain[0]) * n
+        call0, calls = (0, int(calls)) if span is None else (int(span[0]), int(span[1]))
         n_out = len(self.plan.output_store)
         for s in self.plan.output_store:
             if tuple(s) != tuple(self.plan._in_store):
@@ -463,15 +468,47 @@ class Executor(object):
             *[(t[0].numel() * t.element_size() if (i < nbuf and n > 0) else 0) for i, t in enumerate(table)])
         # prepared weights (Winograd / packed-N / bf16 layouts) live in memory WE own: the library allocates nothing
         ws_bytes = int(_lib.lib.dlwp_rollout_workspace_bytes(_lib.handle(dev), arr, len(self.plan.ops), groups))
-        ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=self.device)
+        if ws is None:
+            ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=self.device)
+        elif ws.numel() * 4 < ws_bytes:
+            raise ValueError('rollout workspace of %d bytes, %d needed' % (ws.numel() * 4, ws_bytes))
+        # (a time slice: the state comes from the slot in front of its first one, its series starts at its own first slot)
+        state_ptr = state0.data_ptr() if call0 == 0 else series.data_ptr() + 4 * (call0 * n_out - 1) * slot
+        series_ptr = series.data_ptr() + 4 * call0 * n_out * slot
         _lib.check(_lib.lib.dlwp_rollout_create_grouped(_lib.handle(dev), arr, len(self.plan.ops), ptrs, len(table),
-                                                        sample_bytes, groups, ctypes.c_void_p(state0.data_ptr() + 4 * first * member),
-                                                        ctypes.c_void_p(series.data_ptr() + 4 * first * member), slot, int(calls), n_out,
-                                                        _lib.F32, ctypes.c_void_p(ws.data_ptr()), ws_bytes,
-                                                        ctypes.byref(out)))
+                                                        sample_bytes, groups, ctypes.c_void_p(state_ptr + 4 * first * member),
+                                                        ctypes.c_void_p(series_ptr + 4 * first * member), slot, int(calls), n_out,
+                                                        _lib.F32 | (_lib.ROLLOUT_PREPARED if prepared else 0),
+                                                        ctypes.c_void_p(ws.data_ptr()), ws_bytes, ctypes.byref(out)))
         rg = RolloutGraph(out, keep=(table, state0, series, arr, ptrs, ws), device=self.device)
         rg.groups = int(groups)
+        rg.ws = ws
         return rg
+
+    def make_streamed_rollout(self, n, calls, head_chunks=1):
+        """The rollout as TIME SLICES (StreamedRollout): one graph per model call, launched one behind the other, so that the
+        caller can hand a finished forecast slot to the copy engine while the next call runs.  The first call is cut into
+        `head_chunks` member chunks (graphs with activation buffers of their own) so that it can start on the first chunk of an
+        input that is still being uploaded.  Same kernels on the same data as the one-graph rollout: the same bits."""
+        n, calls, head_chunks = int(n), int(calls), max(1, int(head_chunks))
+        while n % head_chunks:
+            head_chunks -= 1
+        n_out = len(self.plan.output_store)
+        s0 = torch.empty((n,) + self.plan._in_store, dtype=torch.float32, device=self.device)
+        series = torch.empty((calls * n_out, n) + self.plan._in_store, dtype=torch.float32, device=self.device)
+        # one member chain per call (DLWP_STREAMED_GROUPS): a forked graph is launched on a stream of its own between two events
+        # (csrc/rollout.hip) -- per CALL here, not per rollout
+        g = int(os.environ.get('DLWP_STREAMED_GROUPS', '1'))
+        while n % g:
+            g -= 1
+        if head_chunks == 1:
+            head = [self._make_rollout(s0, series, calls, g, span=(0, 1))]
+        else:
+            head = [self._make_rollout(s0, series, calls, 1, chain=(c, head_chunks), span=(0, 1)) for c in range(head_chunks)]
+        tail = []
+        for j in range(1, calls):
+            tail.append(self._make_rollout(s0, series, calls, g, span=(j, 1), ws=tail[0].ws if tail else None, prepared=bool(tail)))
+        return StreamedRollout(s0, series, head, tail, n_out, self.device)
 
 
 class RolloutGraph(object):
@@ -489,6 +526,36 @@ class RolloutGraph(object):
             from . import _lib
             _lib.lib.dlwp_rollout_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class StreamedRollout(object):
+    """A rollout captured as one graph per model call (Executor.make_streamed_rollout): head[c] = call 0 on member chunk c,
+    tail[j - 1] = call j on all members.  The owner launches them in order on ONE stream and records an event behind each: slot(s)
+    [j * n_outputs, (j + 1) * n_outputs) of `series` are final when call j's event has passed -- that is when their copies to the
+    host may start, under call j + 1.  Replaces the host loop of DLWP/model/models.py:277-293, whose every step ends with a
+    device-to-host copy the next step waits for."""
+
+    def __init__(self, s0, series, head, tail, n_out, device):
+        self.s0, self.series, self.head, self.tail, self.n_out, self.device = s0, series, list(head), list(tail), n_out, device
+
+    @property
+    def calls(self):
+        return 1 + len(self.tail)
+
+    def chunk_bounds(self):
+        n, k = int(self.s0.shape[0]), len(self.head)
+        return [(c * (n // k), (c + 1) * (n // k)) for c in range(k)]
+
+    def close(self):
+        for g in self.head + self.tail:
+            g.close()
+        self.head, self.tail = [], []
 
     def __del__(self):
         try:
@@ -595,6 +662,7 @@ class Model(object):
                                                fuse_lstm_step=False)
                 self.executor = Executor(self.infer_plan, self.device, dtype)
             self.__dict__.pop('_rollouts', None)
+            self.__dict__.pop('_rollouts_streamed', None)
         return self
 
     @property
@@ -732,10 +800,25 @@ class Model(object):
             return series
         return out
 
+    def streamed_rollout(self, n, calls, head_chunks=4):
+        """The time-sliced rollout of n members x `calls` model applications (Executor.make_streamed_rollout), cached like the
+        one-graph rollouts of rollout_on_device."""
+        key = (int(n), int(calls), int(head_chunks))
+        cache = self.__dict__.setdefault('_rollouts_streamed', {})
+        ent = cache.get(key)
+        if ent is None:
+            if cache:
+                for old in cache.values():
+                    old.close()
+                cache.clear()
+            ent = cache[key] = self.executor.make_streamed_rollout(n, calls, head_chunks)
+        return ent
+
     # -- training (dlwp_amd.training) ---------------------------------------------------------------------------------- #
     def compile(self, optimizer='adam', loss=None, metrics=None, loss_weights=None, **kwargs):
         from . import training
         self.__dict__.pop('_rollouts', None)     # compile re-homes the weights into one flat buffer: drop captured graphs
+        self.__dict__.pop('_rollouts_streamed', None)
         self.optimizer = training.get_optimizer(optimizer)
         self.loss = loss
         self.loss_weights = loss_weights

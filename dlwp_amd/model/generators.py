@@ -54,6 +54,15 @@ class ArrayDataset(object):
         pass
 
 
+def _has_nan(a, chunk=1 << 24):
+    """np.isnan(a).any() without a full-size boolean temporary: 16 M elements at a time, stops at the first hit"""
+    flat = a.reshape(-1)
+    for lo in range(0, flat.size, chunk):
+        if np.isnan(flat[lo:lo + chunk]).any():
+            return True
+    return False
+
+
 class DataGenerator(object):
     """Generates (predictors, targets) batches on the fly from a dataset with `predictors` and `targets` variables."""
 
@@ -144,26 +153,36 @@ class DataGenerator(object):
         """DeviceLoader's fast path: [(array, per-sample shape)] for predictors and targets when generate(samples) is nothing but
         a row gather -- float32 C-contiguous arrays without NaN samples to drop, no imputer or scaler in the model -- so that the
         rows can be copied straight into pinned memory by the library's host threads (dlwp_host_gather_rows); None otherwise.
-        Same values as generate(): every step of it is then a copy or a reshape."""
-        fast = self.__dict__.get('_fast_sources', False)
-        if fast is False:
-            fast = None
-            p, t = getattr(self.ds.predictors, 'values', None), getattr(self.ds.targets, 'values', None)
-            ok = (isinstance(p, np.ndarray) and isinstance(t, np.ndarray) and p.dtype == np.float32 and t.dtype == np.float32 and
-                  p.flags['C_CONTIGUOUS'] and t.flags['C_CONTIGUOUS'] and p.shape[0] == t.shape[0] and p.shape[0] > 0 and
-                  not self._impute_missing and getattr(self.model, 'scaler_type', None) is None)
-            if ok and self._remove_nan:           # (one pass over the arrays, once: a set without NaNs drops nothing)
-                ok = not (np.isnan(p).any() or np.isnan(t).any())
-            if ok:
-                if self._is_convolutional:
-                    shp = tuple(self.convolution_shape)
-                elif self._keep_time_axis:
-                    shp = tuple(self.dense_shape)
-                else:
-                    shp = (self.n_features,)
-                if int(np.prod(shp)) == p[0].size == t[0].size:
-                    fast = [(p.reshape(p.shape[0], -1), shp), (t.reshape(t.shape[0], -1), shp)]
-            self._fast_sources = fast
+        Same values as generate(): every step of it is then a copy or a reshape.  The decision is cached against what it was
+        made FROM -- the two arrays' identity and address, the model's scaler / imputer switches -- and re-taken when any of
+        them changes; a subclass that overrides generate() or __getitem__ (augmentation) never takes the fast path.  The NaN
+        scan happens once per array; writing NaNs into a set afterwards is not seen (as little as by a cached dataset)."""
+        if type(self).generate is not DataGenerator.generate or type(self).__getitem__ is not DataGenerator.__getitem__:
+            return None
+        p, t = getattr(self.ds.predictors, 'values', None), getattr(self.ds.targets, 'values', None)
+        if not (isinstance(p, np.ndarray) and isinstance(t, np.ndarray)):
+            return None
+        key = (id(p), p.ctypes.data, p.shape, id(t), t.ctypes.data, t.shape, bool(self._impute_missing),
+               getattr(self.model, 'scaler_type', None), bool(self._remove_nan))
+        cached = self.__dict__.get('_fast_sources')
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        fast = None
+        ok = (p.dtype == np.float32 and t.dtype == np.float32 and
+              p.flags['C_CONTIGUOUS'] and t.flags['C_CONTIGUOUS'] and p.shape[0] == t.shape[0] and p.shape[0] > 0 and
+              not self._impute_missing and getattr(self.model, 'scaler_type', None) is None)
+        if ok and self._remove_nan:           # (one pass over the arrays, once: a set without NaNs drops nothing)
+            ok = not (_has_nan(p) or _has_nan(t))
+        if ok:
+            if self._is_convolutional:
+                shp = tuple(self.convolution_shape)
+            elif self._keep_time_axis:
+                shp = tuple(self.dense_shape)
+            else:
+                shp = (self.n_features,)
+            if int(np.prod(shp)) == p[0].size == t[0].size:
+                fast = [(p.reshape(p.shape[0], -1), shp), (t.reshape(t.shape[0], -1), shp)]
+        self._fast_sources = (key, fast)
         return fast
 
     def __len__(self):
@@ -585,51 +604,14 @@ class DeviceLoader(object):
         return src, np.ascontiguousarray(sm[0], dtype=np.int64), sm[1]
 
     # -- staging ---------------------------------------------------------------------------------------------------------- #
-    def _alloc_slot(self, sizes, host=True):
-        """(consumer thread) pinned host + device buffers for arrays of `sizes` elements (host=False: the pull path stages
-        nothing on the host)"""
+    def _alloc_slot(self, sizes):
+        """(consumer thread) pinned host + device buffers for arrays of `sizes` elements"""
         torch = self._torch
         pin = self.device.type == 'cuda'
         return {'cap': list(sizes),
-                'host': [torch.empty(max(1, s), dtype=torch.float32, pin_memory=pin) for s in sizes] if host else None,
+                'host': [torch.empty(max(1, s), dtype=torch.float32, pin_memory=pin) for s in sizes],
                 'dev': [torch.empty(max(1, s), dtype=torch.float32, device=self.device) for s in sizes],
                 'ev': torch.cuda.Event() if pin else None, 'done': None}
-
-    def _setup_pull(self):
-        """(consumer thread, before the worker starts) The PULL path: the generator's source arrays page-locked and mapped for the
-        device once (dlwp_host_register), every batch then fetched over the link by a gather kernel on the copy stream
-        (dlwp_gather_rows_h2d) -- no host copy at all.  Taken when the batches are plain row gathers (`batch_sources`) of rows
-        that are whole 16-byte units; the registration lives as long as the generator.  DLWP_LOADER_PULL=0 keeps the host gather."""
-        import weakref
-        from .. import _lib
-        self._pull = None
-        # OFF by default (r4, profiles/r4_loader_timeline.txt): while the gather kernel runs on the copy stream's queue, every
-        # kernel boundary of the training step waits for it -- a 11 us launch of the step ends when the 310 us gather ends -- so the
-        # transfer ADDS to the step instead of hiding under it (2.08 ms per step at 64 samples against 1.48 ms with DMA copies,
-        # 1.44 ms with no feed at all).  Copy-engine transfers do not have that effect; the host gather in front of them runs at
-        # 45 (1 thread) - 150 GB/s (8 threads) on the GPU box, the link at 55 GB/s.
-        if self._copy_stream is None or os.environ.get('DLWP_LOADER_PULL', '0') != '1' or not hasattr(self.gen, 'batch_sources'):
-            return
-        srcs = self.gen.batch_sources()
-        if srcs is None or any((int(np.prod(shp)) * 4) % 16 or arr.ctypes.data % 16 for arr, shp in srcs):
-            return
-        mapped = self.gen.__dict__.get('_dlwp_mapped')
-        if mapped is None:
-            mapped, done = [], []
-            for arr, _ in srcs:
-                dptr = ctypes.c_void_p()
-                if _lib.lib.dlwp_host_register(ctypes.c_void_p(arr.ctypes.data), arr.nbytes, ctypes.byref(dptr)) != _lib.OK:
-                    for a in done:
-                        _lib.lib.dlwp_host_unregister(ctypes.c_void_p(a))
-                    mapped = False
-                    break
-                done.append(arr.ctypes.data)
-                mapped.append(int(dptr.value))
-            self.gen._dlwp_mapped = mapped
-            if mapped:
-                weakref.finalize(self.gen, lambda ptrs=tuple(done): [_lib.lib.dlwp_host_unregister(ctypes.c_void_p(p)) for p in ptrs])
-        if mapped:
-            self._pull = list(zip(mapped, srcs))
 
     def _fill(self, slot, idx):
         """(worker thread: host work only) batch idx into the pinned buffers of `slot`; returns (shapes, was_list, n_global), or
@@ -640,8 +622,6 @@ class DeviceLoader(object):
             srcs, rows, n_global = plan
             shapes = [(len(rows),) + tuple(shp) for _, shp in srcs]
             sizes = [int(np.prod(sh)) for sh in shapes]
-            if self.__dict__.get('_pull'):          # nothing to do on the host: the consumer launches the gather kernels
-                return {'shapes': shapes, 'was_list': False, 'n_global': n_global, 'arrays': None, 'pull': rows}
             if slot is not None and len(slot['cap']) == len(sizes) and all(c >= z for c, z in zip(slot['cap'], sizes)):
                 for (arr, shp), hbuf in zip(srcs, slot['host']):
                     row_bytes = int(np.prod(shp)) * 4
@@ -688,15 +668,14 @@ class DeviceLoader(object):
                     state['error'] = e
                     lock.notify_all()
 
-        self._setup_pull()
-        if not self._pull and hasattr(self.gen, 'batch_sources') and self.gen.batch_sources() is not None:
+        if hasattr(self.gen, 'batch_sources') and self.gen.batch_sources() is not None:
             # plain row gathers: the batch shapes are known without fetching one -- staging buffers for whole batches up front, so
             # that the worker gathers into pinned memory from the first batch on
             bs = int(getattr(self.gen, '_batch_size', 0))
             sizes = [bs * int(np.prod(shp)) for _, shp in self.gen.batch_sources()]
             for i in range(self.depth):
                 sl = self._slots[i]
-                if bs > 0 and (sl is None or sl['host'] is None or len(sl['cap']) != len(sizes) or
+                if bs > 0 and (sl is None or len(sl['cap']) != len(sizes) or
                                any(c < z for c, z in zip(sl['cap'], sizes))):
                     self._slots[i] = self._alloc_slot(sizes)
         th = threading.Thread(target=worker, daemon=True)
@@ -713,26 +692,6 @@ class DeviceLoader(object):
                     raise state['error']
                 res = state['filled'].pop(k)
             slot = self._slots[s]
-            if res.get('pull') is not None:          # the batch is pulled over the link by kernels on the copy stream
-                from .. import _lib
-                sizes = [int(np.prod(sh)) for sh in res['shapes']]
-                if slot is None or len(slot['cap']) != len(sizes) or any(c < z for c, z in zip(slot['cap'], sizes)):
-                    slot = self._slots[s] = self._alloc_slot([max(z, int(np.prod(shp)) * int(getattr(self.gen, '_batch_size', 0)))
-                                                              for z, (_, (_, shp)) in zip(sizes, self._pull)], host=False)
-                ds = [dbuf[:z].view(tuple(sh)) for z, sh, dbuf in zip(sizes, res['shapes'], slot['dev'])]
-                rows = res['pull']
-                if slot['done'] is not None:
-                    self._copy_stream.wait_event(slot['done'])
-                dev_i = self.device.index if self.device.index is not None else torch.cuda.current_device()
-                for d, (dptr, (arr, shp)) in zip(ds, self._pull):
-                    _lib.check(_lib.lib.dlwp_gather_rows_h2d(_lib.handle(dev_i), ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(dptr),
-                                                             rows.ctypes.data_as(ctypes.c_void_p), len(rows), int(np.prod(shp)) * 4,
-                                                             arr.shape[0], ctypes.c_void_p(self._copy_stream.cuda_stream)))
-                slot['ev'].record(self._copy_stream)
-                slot['recorded'] = True
-                return ds, slot, res['was_list'], res['n_global']
-            if slot is not None and slot['host'] is None:
-                slot = None                          # (a pull slot: no host buffers)
             if res['arrays'] is not None:            # first use of the slot, or a batch larger than it: (re)allocate, copy here
                 sizes = [a.size for a in res['arrays']]
                 if slot is None or len(slot['cap']) != len(sizes) or any(c < z for c, z in zip(slot['cap'], sizes)):
@@ -784,6 +743,11 @@ class DeviceLoader(object):
                 state['stop'] = True
                 lock.notify_all()
             th.join()
+            # a consumer that leaves early (break, exception) has the upload of batch k + 1 in flight: the next pass's worker must
+            # not refill that pinned slot under the copy engine
+            for sl in self._slots:
+                if sl is not None and sl['ev'] is not None and sl.get('recorded'):
+                    sl['ev'].synchronize()
 
     def __iter__(self):
         for X, y, _ in self.iter_batches():

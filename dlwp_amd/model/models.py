@@ -66,76 +66,160 @@ class _Wrapper(object):
         out = ops.series_merge_time(flat.contiguous(), self.time_dim)
         return out.reshape((n_slots * self.time_dim, n_sample, -1) + fs[1:])
 
-    #: members per hipGraph launch when the series goes back to the host: the device-to-host copy of one chunk runs
-    #: on its own stream under the rollout of the next (results do not depend on the chunking: tests/test_gpu_model.py)
-    host_chunk_members = 64
+    #: a series of at least this many bytes goes back to the host SLOT BY SLOT while the rollout runs (_rollout_streamed); smaller
+    #: ones after it, in one copy
+    host_stream_bytes = 64 << 20
+    #: member chunks the first model call of a streamed rollout is cut into when the predictors come from the host: the call
+    #: starts on the first chunk while the others are still being uploaded
+    host_head_chunks = 4
 
     def _rollout_device(self, predictors, calls, keep_time_dim, return_device=False):
         import torch
         net = self.model
         on_host = not isinstance(predictors, torch.Tensor)
         n = int(predictors.shape[0])
-        chunk = int(self.host_chunk_members)
-        if return_device or n < 2 * chunk:
+        member = int(np.prod(predictors.shape[1:]))
+        n_out = len(net.outputs)
+        run = member // int(self.time_dim)
+        streamed = (not return_device and calls >= 2 and 4 * n * member * calls * n_out >= int(self.host_stream_bytes)
+                    and net.device.type == 'cuda' and (keep_time_dim or run % 4 == 0) and member % 4 == 0)
+        if not streamed:
             x = predictors if not on_host else \
                 torch.from_numpy(np.ascontiguousarray(predictors, dtype=np.float32)).to(net.device)
             out = self._rollout_chunk(x, calls, keep_time_dim)
             return out if return_device else out.cpu().numpy()
-        # large ensembles: pipelined over member chunks into ONE pinned host array (time first, as the reference returns
-        # it); slot t of a chunk is a contiguous block of it, so every copy is a plain asynchronous DMA
-        parts = -(-n // chunk)
-        chunk = -(-n // parts)                       # even chunks: one graph shape (plus at most one remainder shape)
-        xh = np.ascontiguousarray(predictors, dtype=np.float32) if on_host else None
-        copy_stream, up_probed = util.io_streams(net.device)      # (hardware queues of their own: util.distinct_streams)
-        copy_stream.wait_stream(torch.cuda.current_stream(net.device))
-        host = None
-        # host inputs: chunk k + 1 is staged into page-locked memory and uploaded on its own stream while chunk k rolls out (a
-        # synchronous upload from pageable memory in front of every chunk left the GPU idle for ~1.5 ms each)
-        up_stream = up_probed if on_host else None
-        stage = [util.pinned_results.take((chunk,) + tuple(predictors.shape[1:])) for _ in range(2)] if on_host else None
-        stage_ev = [None, None]
-        bounds = [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]
+        return self._rollout_streamed(predictors, calls, keep_time_dim)
 
-        def upload(k):
-            lo, hi = bounds[k]
-            buf = stage[k % 2]
-            if stage_ev[k % 2] is not None:
-                stage_ev[k % 2].synchronize()             # the upload that last read this staging buffer has drained
-            buf[:hi - lo].numpy()[...] = xh[lo:hi]
-            with torch.cuda.stream(up_stream):
-                t = buf[:hi - lo].to(net.device, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(up_stream)
-            stage_ev[k % 2] = ev
-            return t, ev
+    def _rollout_streamed(self, predictors, calls, keep_time_dim):
+        """The rollout with its series going home WHILE it runs (the metric's own API -- numpy in, numpy out,
+        DLWP/model/models.py:265-301, call site examples/plot_forecasts.py:234-239 -- at the device-resident speed).
+        The rollout is one hipGraph PER MODEL CALL (engine.StreamedRollout), all members in each, launched back to back on the
+        main stream; behind call j an event, and on a copy stream (two, alternating; hardware queues of their own) the slots call j
+        wrote leave for ONE page-locked result array laid out as the reference returns it (time first) under call j + 1:
+          DLWP_D2H=dma (default)  keep_time_dim: one 1-D copy-engine transfer straight from the series slot; otherwise the
+                                  sample <-> time transposition of the slot into a staging buffer (dlwp_series_merge_time, ~25 us)
+                                  and ONE contiguous transfer of both time steps;
+          DLWP_D2H=kernel         dlwp_store2d_to_host: a few workgroups store the slot straight into the mapped result array, the
+                                  transposition folded into the addressing (no staging pass, no copy engine).
+        The pipeline's fill is one model call and its drain one slot's transfer (r4's member chunks: a quarter of the rollout
+        each).  Host predictors: call 0 is cut into member chunks, chunk c + 1 is gathered into page-locked staging by the
+        library's host threads and uploaded while chunk c computes.  Same kernels on the same data as the one-graph rollout:
+        bit-identical (tests/test_gpu_model.py)."""
+        import ctypes
+        import os
+        import torch
+        from .. import _lib
+        net = self.model
+        dev = net.device
+        on_host = not isinstance(predictors, torch.Tensor)
+        n = int(predictors.shape[0])
+        td = int(self.time_dim)
+        sr = net.streamed_rollout(n, calls, int(self.host_head_chunks) if on_host else 1)
+        n_out = sr.n_out
+        member = int(sr.s0[0].numel())
+        run = member // td
+        feat = tuple(predictors.shape[1:])
+        fs = feat[1:] if self.is_recurrent else feat
+        slots = calls * n_out
+        if keep_time_dim:
+            out_shape = (slots, n, td, member // td // int(np.prod(fs[1:]))) + tuple(fs[1:])
+        else:
+            out_shape = (slots * td, n, run // int(np.prod(fs[1:]))) + tuple(fs[1:])
+        host = util.pinned_results.take(out_shape)
+        mode = os.environ.get('DLWP_D2H', 'dma')
+        if mode == 'kernel' and not host.is_pinned():
+            mode = 'dma'
+        blocks = int(os.environ.get('DLWP_D2H_BLOCKS', '16'))
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        h = _lib.handle(idx)
+        main = torch.cuda.current_stream(dev)
+        down, up = util.d2h_streams(dev), util.io_streams(dev)[1]
+        for s_ in down:
+            s_.wait_stream(main)
+        stage = None
+        if mode == 'dma' and not keep_time_dim:          # one transposed call per copy stream in flight
+            stage = [sr.__dict__.setdefault('_stage%d' % k, torch.empty(n_out * td * n * run, dtype=torch.float32, device=dev))
+                     for k in range(len(down))]
+        host_ptr, series_ptr = host.data_ptr(), sr.series.data_ptr()
+        slot_bytes = 4 * n * member
+
+        def send(call, k):
+            """(copy stream k) the slots of `call` -> their place in the result array"""
+            st = down[k]
+            sp = ctypes.c_void_p(st.cuda_stream)
+            src = series_ptr + call * n_out * slot_bytes
+            dst = host_ptr + call * n_out * slot_bytes
+            if mode == 'kernel':
+                if keep_time_dim:
+                    _lib.check(_lib.lib.dlwp_store2d_to_host(h, ctypes.c_void_p(dst), 4 * member, ctypes.c_void_p(src), 4 * member,
+                                                             4 * member, n * n_out, blocks, sp))
+                else:
+                    for o in range(n_out):
+                        for j in range(td):
+                            _lib.check(_lib.lib.dlwp_store2d_to_host(
+                                h, ctypes.c_void_p(dst + (o * td + j) * 4 * n * run), 4 * run,
+                                ctypes.c_void_p(src + o * slot_bytes + 4 * j * run), 4 * member, 4 * run, n, blocks, sp))
+                return
+            with torch.cuda.stream(st):
+                if keep_time_dim:
+                    host.view(-1)[call * n_out * n * member:(call + 1) * n_out * n * member].copy_(
+                        sr.series.view(-1)[call * n_out * n * member:(call + 1) * n_out * n * member], non_blocking=True)
+                else:
+                    _lib.check(_lib.lib.dlwp_series_merge_time(h, ctypes.c_void_p(src), ctypes.c_void_p(stage[k].data_ptr()), n_out, n,
+                                                               td, 1, run, _lib.F32, sp))
+                    host.view(-1)[call * n_out * n * member:(call + 1) * n_out * n * member].copy_(stage[k], non_blocking=True)
+
+        pins = []
         try:
-          nxt = upload(0) if on_host else None
-          for k, (lo, hi) in enumerate(bounds):
-              if on_host:
-                  xc, ev = nxt
-                  torch.cuda.current_stream(net.device).wait_event(ev)
-                  xc.record_stream(torch.cuda.current_stream(net.device))
-              else:
-                  xc = predictors[lo:hi]
-              out = self._rollout_chunk(xc, calls, keep_time_dim, fresh=True)
-              if on_host and k + 1 < len(bounds):
-                  nxt = upload(k + 1)                         # host copy + DMA under this chunk's kernels
-              if host is None:         # page-locked, recycled once the caller lets the previous result go (util._PinnedPool)
-                  host = util.pinned_results.take((out.shape[0], n) + tuple(out.shape[2:]))
-              done = torch.cuda.Event()
-              done.record()
-              copy_stream.wait_event(done)
-              with torch.cuda.stream(copy_stream):
-                  # the chunk's (T, members, ...) block -> rows lo:hi of every time slot: one strided DMA (row-by-row otherwise)
-                  if not (host.is_pinned() and util.copy2d_d2h_async(host[:, lo:hi], out, copy_stream)):
-                      for t in range(out.shape[0]):
-                          host[t, lo:hi].copy_(out[t], non_blocking=True)
-              out.record_stream(copy_stream)
-          copy_stream.synchronize()
+            # ---- call 0: in member chunks, each behind its own upload
+            if on_host:
+                xh = np.ascontiguousarray(predictors, dtype=np.float32).reshape(n, member)
+                bounds = sr.chunk_bounds()
+                pins = [util.pinned_results.take((hi - lo, member)) for lo, hi in bounds[:2]]
+                pin_ev = [None, None]
+                up.wait_stream(main)
+                threads = max(1, min(8, (os.cpu_count() or 2) // 2))
+                for c, (lo, hi) in enumerate(bounds):
+                    buf = pins[c % 2]
+                    if pin_ev[c % 2] is not None:
+                        pin_ev[c % 2].synchronize()           # the upload that last read this staging buffer has drained
+                    rows = np.arange(lo, hi, dtype=np.int64)
+                    if buf.is_pinned():
+                        _lib.check(_lib.lib.dlwp_host_gather_rows(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(xh.ctypes.data),
+                                                                  rows.ctypes.data_as(ctypes.c_void_p), hi - lo, 4 * member, n, threads))
+                    else:
+                        buf.numpy()[...] = xh[lo:hi]
+                    with torch.cuda.stream(up):
+                        sr.s0.view(n, member)[lo:hi].copy_(buf, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(up)
+                    pin_ev[c % 2] = ev
+                    main.wait_event(ev)
+                    sr.head[c].launch()
+            else:
+                sr.s0.copy_(predictors.reshape(sr.s0.shape))
+                for g in sr.head:
+                    g.launch()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            down[0].wait_event(ev)
+            send(0, 0)
+            # ---- calls 1 ...: all members, slot j leaves under call j + 1
+            for j, g in enumerate(sr.tail, start=1):
+                g.launch()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                k = j % len(down)
+                down[k].wait_event(ev)
+                send(j, k)
+            for s_ in down:
+                s_.synchronize()
+            # (the cached series / staging buffers are rewritten by the next call on the main stream: order it behind the copies)
+            for s_ in down:
+                main.wait_stream(s_)
         finally:
-            if stage is not None:          # (also when a chunk fails: the staging buffers go back to the pool)
-                for buf in stage:
-                    util.pinned_results._give_back(buf.view(-1))
+            for buf in pins:               # (also when a call fails: the staging buffers go back to the pool)
+                util.pinned_results._give_back(buf.view(-1))
         return util.pinned_results.lend(host)
 
 

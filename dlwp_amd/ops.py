@@ -414,7 +414,7 @@ def set_few_stream(mode):
 
 def set_splitk(mode):
     """DLWP_OPT_SPLITK: Winograd launches on small grids divide the input channels over several workgroups per output tile, the
-    last arrival sums the partial tiles in index order (csrc/conv_fwd_k3d1s.hip): 0 never, 1 by the library's rule (default),
+    last arrival sums the partial tiles in index order (csrc/conv_fwd_k3d1s.hip): 0 never (default since r5), 1 by the library's rule,
     k >= 2 that many wherever the layer is eligible.  Returns the previous setting."""
     return int(_lib.set_option(_lib.OPT_SPLITK, int(mode)))
 

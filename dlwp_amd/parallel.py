@@ -131,6 +131,25 @@ class DataParallel(object):
         _lib.check(_lib.lib.dlwp_xchg_status(ent[0], ctypes.byref(t)))
         return bool(t.value)
 
+    def oneshot_check(self):
+        """Raises when a launch of the one-shot exchange gave up waiting for a peer (2 s): that launch left the parameters alone
+        and wrote NaN over the loss table, and the exchange is dead from then on -- training must not continue on it.
+        Synchronises the device: the trainer calls it wherever it reads a loss back anyway (every train_on_batch, once per epoch
+        of fit / fit_generator)."""
+        if getattr(self, '_xchg', None) is not None and self.oneshot_timed_out():
+            raise RuntimeError('dlwp_xchg: rank %d waited 2 s for a peer of the one-shot all-reduce (DLWP_ALLREDUCE=oneshot); the step '
+                               'was NOT applied.  A rank died, or the ranks do not call the step collectively.' % self.rank)
+
+    def oneshot_info(self):
+        """{'memory': 'uncached' | 'fine-grained' | 'plain', 'blocks': persistent grid size} of the exchange, or None"""
+        from . import _lib
+        ent = getattr(self, '_xchg', None)
+        if ent is None:
+            return None
+        k, b = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib.dlwp_xchg_info(ent[0], ctypes.byref(k), ctypes.byref(b)))
+        return {'memory': {2: 'uncached', 1: 'fine-grained', 0: 'plain'}.get(k.value, '?'), 'blocks': b.value}
+
     # -- collectives on flat float32 device buffers ---------------------------------------------------------------------- #
     @staticmethod
     def _stream(t):

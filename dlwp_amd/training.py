@@ -427,6 +427,8 @@ class Trainer(object):
         """[loss, (per-output losses), metrics...] as python floats from the device loss table; reg: the kernel
         regularisers' penalty that belongs to it (None: at the current weights)."""
         v = loss_vals.detach().cpu().numpy().astype(np.float64)
+        if self.dp is not None and getattr(self.dp, '_xchg', None) is not None:
+            self.dp.oneshot_check()       # (a timed-out one-shot exchange: raise here, where the host looks at the step)
         return self._report_from(v, reg)
 
     def _report_from(self, v, reg=None):
@@ -958,11 +960,17 @@ class Trainer(object):
         return 'graph' if (mode == '1' or n_local * int(store[-1]) * int(store[-2]) <= self.graph_below) else 'lanes'
 
     # -- the step as a library object (dlwp_train_step_*) ------------------------------------------------------------------ #
-    def _record_step(self, x, ys, n_global, scale, dp):
-        """Runs ONE real step on (x, ys) while the library records its launches; returns the step entry, or None when the step
-        contained device work that did not go through the library (it then stays eager).  Memory: every tensor the step allocates
+    def _record_step(self, x, ys, n_global, scale, dp, form='graph'):
+        """Runs ONE real step on (x, ys) while the library records its launches; returns the step entry, or {'refused': True} when
+        the step contained device work the tape does not carry (it then stays eager).  Memory: every tensor the step allocates
         while recording comes from a private torch.cuda.MemPool that is kept with the entry, so the addresses the tape holds
-        stay valid and nobody else is handed them."""
+        stay valid and nobody else is handed them.
+        Two guards against a replay that silently misses a launch.  Structural: every stream-taking entry point of the
+        library WITHOUT a tape record marks the tape foreign (DLWP_UNTAPED, csrc/common.h) and dlwp_train_step_create refuses it;
+        torch-side launches set self._foreign.  By result (DLWP_TAPE_VALIDATE, default on): before the entry is cached the step
+        is REPLAYED once in the form it will run in (`form`), from the state the recorded step started from, with the gradient
+        buffer, the loss table and the step's outputs overwritten by NaN first -- parameters, optimizer slots, gradients and the
+        loss table must come out as the recorded (eager) step left them.  One extra step per recorded shape."""
         from . import _lib, ops
         opt = self.model.optimizer
         gx = x.clone()
@@ -979,6 +987,8 @@ class Trainer(object):
         main = torch.cuda.current_stream(self.device)
         pool = torch.cuda.MemPool()
         self._foreign = False
+        validate = os.environ.get('DLWP_TAPE_VALIDATE', '1') != '0'
+        state0 = [t.clone() for t in [self.flat_params] + list(self.opt_state) + [self._iter_dev]] if validate else None
         with torch.cuda.use_mem_pool(pool, device=self.device):
             _lib.check(_lib.lib.dlwp_train_step_record_begin(h, ctypes.c_void_p(main.cuda_stream)))
             try:
@@ -1001,11 +1011,64 @@ class Trainer(object):
             step = ctypes.c_void_p()
             dst = (ctypes.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
             floats = (ctypes.c_size_t * len(ins))(*[t.numel() for t in ins])
-            _lib.check(_lib.lib.dlwp_train_step_create(h, len(ins), dst, floats, ctypes.byref(step)))
+            rc = _lib.lib.dlwp_train_step_create(h, len(ins), dst, floats, ctypes.byref(step))
+            if rc == _lib.EUNSUPPORTED:          # an entry point without a tape record ran inside the step: the shape stays eager
+                return {'refused': True, 'loss': loss_vals, 'why': _lib.lib.dlwp_last_error().decode('utf-8', 'replace')}
+            _lib.check(rc)
         keep = (outs, loss_vals, dys, dict(ops._workspaces), dict(ops._workspaces2),
                 self.model.train_executor.scratch(int(x.shape[0])), self.model.train_executor.phase_buffers(),
                 self._prep_cache.get(int(x.shape[0])), self._side, pool)
-        return {'step': _StepHandle(step), 'x': gx, 'ys': gys, 'loss': loss_vals, 'keep': keep}
+        ent = {'step': _StepHandle(step), 'x': gx, 'ys': gys, 'loss': loss_vals, 'keep': keep}
+        if validate:
+            why = self._validate_step(ent, state0, outs, dys, form, dp is not None)
+            if why is not None:
+                import warnings
+                warnings.warn('dlwp_amd: the recorded training step did not reproduce the eager step (%s); batches of %d samples '
+                              'keep running launch by launch' % (why, int(x.shape[0])), RuntimeWarning)
+                ent['step'] = None                   # (its finaliser destroys the step object)
+                return {'refused': True, 'loss': loss_vals, 'why': why}
+        return ent
+
+    def _validate_step(self, ent, state0, outs, dys, form, data_parallel=False):
+        """Replays the freshly recorded step from the state it started from and compares every result with the eager run's; returns
+        None when they agree, else what differed.  On disagreement the eager results are put back."""
+        from . import _lib
+        live = [self.flat_params] + list(self.opt_state) + [self._iter_dev]
+        # (the loss table rides behind the gradients only in a data-parallel step: the recorded launches write it there)
+        gbuf = self._flat_exchange if data_parallel else self.flat_grads
+        want = [t.clone() for t in live] + [gbuf.clone(), ent['loss'].clone()]
+        for t, t0 in zip(live, state0):
+            t.copy_(t0)
+        nan = float('nan')
+        gbuf.fill_(nan)
+        ent['loss'].fill_(nan)
+        for t in list(outs) + [d for d in dys if isinstance(d, torch.Tensor)]:
+            if isinstance(t, torch.Tensor) and t.is_floating_point():
+                t.fill_(nan)
+        lanes_mode = _lib.STEP_LANES if os.environ.get('DLWP_TRAIN_LANES') == 'own' else _lib.STEP_LANES_RECORDED
+        mode = {'lanes': lanes_mode, 'graph': _lib.STEP_GRAPH, 'branches': _lib.STEP_GRAPH_BRANCHES}.get(form, _lib.STEP_GRAPH)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = _lib.lib.dlwp_train_step_launch(ent['step'].h, None, mode, stream)      # (the inputs are in the step's buffers already)
+        why = None
+        if rc != _lib.OK:
+            why = 'replay failed: ' + _lib.lib.dlwp_last_error().decode('utf-8', 'replace')
+        else:
+            torch.cuda.synchronize(self.device)
+            names = ['parameters'] + ['optimizer slot %d' % i for i in range(len(self.opt_state))] + ['step counter', 'gradients', 'loss table']
+            for name, got, ref in zip(names, live + [gbuf, ent['loss']], want):
+                if got.dtype.is_floating_point:
+                    bad = not bool(torch.isfinite(got).all()) if bool(torch.isfinite(ref).all()) else False
+                    tol = 1e-5 * float(ref.abs().max()) + 1e-30
+                    if bad or float((got - ref).abs().max()) > tol:
+                        why = '%s differ' % name
+                        break
+                elif not torch.equal(got, ref):
+                    why = '%s differ' % name
+                    break
+        if why is not None:
+            for t, w in zip(live + [gbuf, ent['loss']], want):
+                t.copy_(w)
+        return why
 
     def _capture_step(self, x, ys, n_global, scale, dp):
         from . import ops
@@ -1077,7 +1140,7 @@ class Trainer(object):
             if form == 'torch':
                 ent = self._graphs[key] = self._capture_step(x, ys, n_global, scale, dp)
             else:
-                ent = self._record_step(x, ys, n_global, scale, dp)     # (this IS a step: on x, ys)
+                ent = self._record_step(x, ys, n_global, scale, dp, form)     # (this IS a step: on x, ys)
                 if ent.get('refused'):
                     self._no_tape.add(key)
                 else:
@@ -1238,6 +1301,8 @@ class Trainer(object):
                 vals[0] += reg_sum
                 sums = vals if sums is None else sums + vals
             logs = dict(zip(self.metrics_names, (sums / max(seen, 1)).tolist())) if sums is not None else {}
+            if self.dp is not None and getattr(self.dp, '_xchg', None) is not None:
+                self.dp.oneshot_check()         # (the epoch's tables are on the host: the device has been synchronised anyway)
             if validate_fn is not None:
                 vvals = validate_fn()
                 logs.update({'val_' + k: v for k, v in zip(self.metrics_names, vvals)})

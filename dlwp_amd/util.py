@@ -291,3 +291,20 @@ def io_streams(device):
         st = _io_streams[key] = tuple(distinct_streams(device, 2, [torch.cuda.current_stream(device)]))
     return st
 
+
+
+_d2h_streams = {}
+
+
+def d2h_streams(device):
+    """TWO download streams for results that leave the device while a rollout runs (model/models.py: _rollout_streamed), probed
+    once per process and device onto hardware queues other than the current stream's, the upload stream's and each other's where
+    the process still has that many (four queues: the fourth candidate may have to share -- distinct_streams then returns it last)."""
+    import torch
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _d2h_streams.get(key)
+    if st is None:
+        first, up = io_streams(device)
+        second = distinct_streams(device, 1, [torch.cuda.current_stream(device), first, up])[0]
+        st = _d2h_streams[key] = (first, second)
+    return st

@@ -133,8 +133,11 @@ int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, cha
                                         * ensemble share of 1 ... 8 members, 8 training samples per rank): the input channels are
                                         * divided over several workgroups per output tile; the last one to arrive sums the partial
                                         * tiles in index order (deterministic), adds the bias, activates, pools and stores
-                                        * (csrc/conv_fwd_k3d1s.hip).  1 (default): by the rule of dlwp_conv2d_split_count;
-                                        * 0: never -- then a sample's bits do not depend on its batch size at all; k >= 2: k
+                                        * (csrc/conv_fwd_k3d1s.hip).  0 (default since r5): never -- a sample's bits do not depend on
+                                        * its batch size at all (a member rolls out to the same bits alone, in a
+                                        * batch, on 1 GPU or as a shard of 8); the one operating point that gains is 1 ... 2
+                                        * members of the 88 x 180 grid (+6 %).  1 (DLWP_SPLITK=1 in the environment):
+                                        * by the rule of dlwp_conv2d_split_count; k >= 2: k
                                         * workgroups per tile wherever the layer is eligible (tuning sweeps, tests).  A split
                                         * launch differs from the unsplit one by float32 round-off (another association of the
                                         * same sum); two launches with the SAME split count give the same bits               */
@@ -545,6 +548,10 @@ int dlwp_rollout_create_grouped(dlwp_handle_t, const dlwp_op* plan, int n_ops, v
                                 const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
                                 size_t slot_elems, int calls, int n_outputs, int dtype, void* workspace,
                                 size_t workspace_bytes, dlwp_rollout_t* out);
+/* `dtype` of the two create calls may carry DLWP_ROLLOUT_PREPARED: the graph is a later TIME SLICE of a rollout (state0 = the
+ * previous slice's last series slot) that shares `workspace` with the first slice and is always launched behind it on the same
+ * stream -- it does not prepare the weights again.                                                                          */
+#define DLWP_ROLLOUT_PREPARED 0x100
 int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
 int dlwp_rollout_destroy(dlwp_rollout_t);
 
@@ -554,17 +561,16 @@ int dlwp_rollout_destroy(dlwp_rollout_t);
  *      Host memory only; no device work, no handle.                                                                          */
 int dlwp_host_gather_rows(void* dst, const void* src, const long long* rows, long long n_rows, size_t row_bytes,
                           long long src_rows, int threads);
-/* ... and the path that needs no host copy at all: the training set's arrays are page-locked and mapped once
- * (dlwp_host_register: hipHostRegister), and a kernel on the loader's copy stream PULLS the rows of a batch over the link straight
- * into the device buffer the training step reads -- dst[i] = src[rows[i]], one launch per array and batch (rows travel as kernel
- * arguments).  row_bytes: a multiple of 16.  Measured on the GPU box (r4): host memcpy ~15 GB/s whatever the thread count, so a
- * 64-sample batch (32 MB) takes 2.2 ms to assemble on the host against a 1.4 ms training step.                              */
+/* ---- a predict_timeseries series going home (DLWP/model/models.py:270, 294-301 return a host ndarray, time first): rows x width
+ *      bytes from device memory into the page-locked result array, destination rows dst_pitch bytes apart.
+ *      dlwp_copy2d_d2h_async: ONE strided copy-engine transfer, source contiguous.  dlwp_store2d_to_host: the same (and the
+ *      strided-source form: the sample <-> time transposition of a merged series) as a KERNEL of `blocks` workgroups (0: 16)
+ *      storing 16-byte units straight into the device-mapped pinned array -- few workgroups, link-bound, runs beside the next
+ *      model call of the rollout.  width, pitches and addresses: multiples of 16 bytes.                                        */
 int dlwp_copy2d_d2h_async(void* dst_pinned_host, size_t dst_pitch, const void* src_device, size_t width, size_t rows,
-                          void* stream);   /* one strided DMA: the member chunk of a predict_timeseries series going home */
-int dlwp_host_register(void* ptr, size_t bytes, void** device_ptr);
-int dlwp_host_unregister(void* ptr);
-int dlwp_gather_rows_h2d(dlwp_handle_t, void* dst, const void* src_device_address, const long long* rows, long long n_rows,
-                         size_t row_bytes, long long src_rows, void* stream);
+                          void* stream);
+int dlwp_store2d_to_host(dlwp_handle_t, void* dst_pinned_host, size_t dst_pitch, const void* src_device, size_t src_pitch,
+                         size_t width, size_t rows, int blocks, void* stream);
 
 /* ---- the training step as a library object: replaces the per-step Python launch loop behind keras Model.train_on_batch as
  *      DLWPNeuralNet.fit / fit_generator drive it (DLWP/model/models.py:188-228; examples/train.py:262-263).
@@ -613,10 +619,13 @@ int dlwp_comm_destroy(dlwp_comm_t);
 /* ---- a one-shot all-reduce of our own for the same exchange, fused with the Keras-form Adam update (csrc/xchg.hip; SURVEY 5 /
  *      8e: the step's 756 KB buffer is latency-bound -- a ring pays 2 (W - 1) hops, this ONE).  Every rank owns a region of device
  *      memory (header with one flag per rank + two payload buffers, step parity) that its peers map through hipIpcMemHandle (xGMI
- *      peers of one node; on a one-GPU test box two processes of the same device).  One launch per step and rank: publish the
- *      flat buffer, raise the flag in every peer's header, wait for the peers' flags (bounded: 2 s, then dlwp_xchg_status reports
- *      a time-out instead of a hung GPU), read all W buffers, sum them IN RANK ORDER -- identical bits on every rank -- and update
- *      the rank's own parameters.  n (floats, a multiple of 4) is fixed at creation.  RCCL (dlwp_comm_*) stays the default
+ *      peers of one node; on a one-GPU test box two processes of the same device); the region is UNCACHED device memory where the
+ *      runtime exports an IPC handle for it (dlwp_xchg_info: memory_kind 2; 1 fine-grained, 0 plain).  One launch per step and
+ *      rank, a persistent grid of at most one workgroup per CU whatever n: publish the flat buffer, raise the flag in every peer's
+ *      header, wait for the peers' flags (bounded: 2 s; then the launch leaves p / m / v alone, writes NaN over flat[n_params:]
+ *      -- the loss table -- and dlwp_xchg_status reports the time-out, for good: the exchange is dead afterwards), read all W
+ *      buffers, sum them IN RANK ORDER -- identical bits on every rank -- and update the rank's own parameters.
+ *      n (floats, a multiple of 4) is fixed at creation.  RCCL (dlwp_comm_*) stays the default
  *      transport; dlwp_amd/parallel.py takes this one with DLWP_ALLREDUCE=oneshot.
  *      create (every rank) -> exchange the 64-byte handles through any host channel -> connect (world x 64 bytes, rank order).   */
 typedef struct dlwp_xchg* dlwp_xchg_t;
@@ -626,6 +635,7 @@ int dlwp_xchg_allreduce_sum_f32(dlwp_xchg_t, void* flat, size_t n, void* stream)
 int dlwp_xchg_allreduce_adam(dlwp_xchg_t, void* flat, size_t n_params, size_t n, void* p, void* m, void* v, float lr, float beta_1,
                              float beta_2, float epsilon, float decay, long long iteration, float grad_scale, void* stream);
 int dlwp_xchg_status(dlwp_xchg_t, int* timed_out);
+int dlwp_xchg_info(dlwp_xchg_t, int* memory_kind, int* max_blocks);
 int dlwp_xchg_destroy(dlwp_xchg_t);
 
 #ifdef __cplusplus

@@ -165,3 +165,27 @@ def test_streaming_kernel_item_order_visits_every_tile_of_every_sample_once():
         for npos in (1, 6, 66):
             for grid in (1, 7, 30, 768, 1024):
                 visit(n, npos, min(grid, npos * n))
+
+
+def test_every_stream_taking_export_is_taped_or_marks_the_tape_foreign():
+    """The training step's tape (csrc/tape.hip) replays the entry points that carry DLWP_TAPE; any OTHER launch a recording thread
+    issues would silently be missing from the replay.  Structural guard: every exported function that takes a stream
+    starts with DLWP_TAPE* (recorded) or DLWP_UNTAPED (marks the tape foreign: dlwp_train_step_create then refuses the step).  A new
+    entry point has to pick one."""
+    import glob, os, re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set(_lib.declared_symbols())
+    allowed = {'dlwp_train_step_launch'}            # refuses outright while the thread records (tape.hip)
+    seen, bare = set(), []
+    for f in sorted(glob.glob(os.path.join(ROOT, 'dlwp_amd', 'csrc', '*.hip'))):
+        s = open(f).read()
+        for m in re.finditer(r'^(?:extern "C" )?int (dlwp_\w+)\(([^)]*)\)\s*\{', s, re.M | re.S):
+            name, args = m.group(1), m.group(2)
+            if name not in declared or 'void* stream' not in args:
+                continue
+            seen.add(name)
+            body = s[m.end():s.index('\n}\n', m.end())]
+            if 'DLWP_TAPE' not in body and 'DLWP_UNTAPED(%s)' % name not in body and name not in allowed:
+                bare.append(name)
+    assert len(seen) >= 50, len(seen)
+    assert not bare, bare

@@ -66,13 +66,18 @@ def test_pad2d_rejects_periodic_pad_larger_than_axis(ops):
         ops.pad2d(x, ops.make_pad(0, 0, 5, 5, ops.PAD_ZERO, ops.PAD_WRAP))
 
 
-@pytest.mark.parametrize('shape', [(3, 5, 7, 9), (2, 4, 88, 180), (1, 3, 73, 144), (2, 2, 16, 20)])
+@pytest.mark.parametrize('shape', [(3, 5, 7, 9), (2, 4, 88, 180), (1, 3, 73, 144), (2, 2, 16, 20),
+                                   # r5: rows that are not whole 16-byte units -- the flat-vector instances of pad2d_fwd / pad2d_bwd
+                                   # (aligned windows in, groups of 4 rows out; csrc/halo.hip) -- on the U-Net's inner maps
+                                   (2, 3, 22, 45), (2, 2, 44, 90), (5, 1, 3, 5), (1, 1, 1, 7)])
 def test_pad2d_all_modes_fwd_bwd(ops, shape):
     rng = np.random.default_rng(sum(shape))
     x = rng.standard_normal(shape).astype(np.float32)
     for mh in (0, 1, 2, 3, 4):           # zero, periodic, edge, tf.pad REFLECT, tf.pad SYMMETRIC
         for mw in (0, 1, 2, 3, 4):
             pads = (2, 1, 3, 2) if shape[-1] % 4 else (2, 2, 2, 2)
+            if shape[-2] < 3:
+                pads = (1, 0, 3, 2) if mh in (1, 2, 4) else (0, 0, 3, 2)      # (a 1-row axis: what each mode admits)
             p = ops.make_pad(*pads, mh, mw)
             want = np_ref.pad2d_modes(x, pads, mh, mw)
             got = host(ops.pad2d(dev(x), p))
@@ -81,6 +86,21 @@ def test_pad2d_all_modes_fwd_bwd(ops, shape):
             dx = host(ops.pad2d_bwd(dev(dy), shape, p))
             dx_ref = np_ref.pad2d_modes_grad(dy, shape, pads, mh, mw)
             assert np.abs(dx - dx_ref).max() <= 1e-5 * max(1., np.abs(dx_ref).max())
+
+
+@pytest.mark.parametrize('c,h,w,k', [(32, 44, 90, 1), (64, 22, 45, 1), (128, 44, 90, 1)])
+def test_pad2d_composite_halos_of_the_unets_inner_maps(ops, c, h, w, k):
+    """Periodic(0, k) + Zero(k, 0) on the 44 x 90 and 22 x 45 maps (92- / 47-float rows: the flat-vector instances), 7 samples so
+    that the last group of four rows is partial: bit-exact forward, adjoint backward."""
+    rng = np.random.default_rng(c + w)
+    x = rng.standard_normal((7, c, h, w)).astype(np.float32)
+    p = ops.make_pad(k, k, k, k, ops.PAD_ZERO, ops.PAD_WRAP)
+    want = np_ref.pad2d_modes(x, (k, k, k, k), 0, 1)
+    assert np.array_equal(host(ops.pad2d(dev(x), p)), want)
+    dy = rng.standard_normal(want.shape).astype(np.float32)
+    dx = host(ops.pad2d_bwd(dev(dy), x.shape, p))
+    dx_ref = np_ref.pad2d_modes_grad(dy, x.shape, (k, k, k, k), 0, 1)
+    assert np.abs(dx - dx_ref).max() <= 1e-5 * max(1., np.abs(dx_ref).max())
 
 
 def test_pad2d_empty_and_single(ops):

@@ -112,17 +112,19 @@ def test_predict_does_not_depend_on_batch_chunking_or_batch_mates():
     from dlwp_amd import ops
     full = d.predict(x)
     assert np.array_equal(full, d.predict(x, batch_size=256))      # chunked (256 + 44) == one pass, bit for bit
-    # r4: launches of a handful of samples may divide a long input-channel sum over several workgroups (DLWP_OPT_SPLITK: the
-    # 128-channel decoder layer here): the same sum in another association.  Within one split regime a member's bits do not depend
-    # on its batch mates; across regimes they agree to float32 round-off; with the option off they never differ.
-    alone, pair = d.predict(x[7:8]), d.predict(x[7:9])
-    assert np.array_equal(alone, pair[:1])                           # 1 and 2 members: the same regime
-    assert _rel(alone, full[7:8]) < 2e-6
-    prev = ops.set_splitk(0)
+    # a member alone == the member inside a batch, BIT FOR BIT, at every batch size -- the default since r5 (split-K,
+    # which divides a long input-channel sum over several workgroups on launches of a handful of samples, is opt-in again:
+    # VERDICT r4 weak c)
+    assert ops.set_splitk(0) == 0                                    # (the default IS off)
+    for lo, hi in ((7, 8), (7, 9), (5, 9), (0, 16)):
+        assert np.array_equal(d.predict(x[lo:hi]), full[lo:hi]), (lo, hi)
+    # opted in (DLWP_OPT_SPLITK = 1): within one split regime a member's bits do not depend on its batch mates; across regimes
+    # they agree to float32 round-off
+    prev = ops.set_splitk(1)
     try:
-        full0 = d.predict(x)
-        assert np.array_equal(full0, d.predict(x, batch_size=256))
-        assert np.array_equal(full0[7:8], d.predict(x[7:8]))         # a member alone == the member inside a batch
+        alone, pair = d.predict(x[7:8]), d.predict(x[7:9])
+        assert np.array_equal(alone, pair[:1])                       # 1 and 2 members: the same regime
+        assert _rel(alone, full[7:8]) < 2e-6
     finally:
         ops.set_splitk(prev)
 
@@ -152,7 +154,7 @@ def test_predict_timeseries_graph_equals_host_loop_and_tracks_the_oracle():
     # (2) against the float64 oracle rollout: tight on the first forward, bounded growth afterwards
     want = np_ref.predict_timeseries_nn(lambda p: np_ref.run_layers(layers, p, weights), x.astype(np.float64), steps, 2)
     assert _rel(got[:2], want[:2]) < FWD_TOL
-    assert _rel(got, want) < 50 * FWD_TOL
+    assert _rel(got, want) < FWD_TOL
     # replay: same graph, new initial state
     x2 = rng.standard_normal((5,) + cs).astype(np.float32)
     got2 = d.predict_timeseries(x2, steps)
@@ -163,26 +165,36 @@ def test_predict_timeseries_graph_equals_host_loop_and_tracks_the_oracle():
     assert np.array_equal(seq[0], d.predict(x).reshape(5, 2, 2, 16, 24)[:, 0])
 
 
-def test_predict_timeseries_pipelined_host_copy_is_bit_identical():
-    """Large ensembles go back to the host chunk by chunk (pinned array, copy stream under the next chunk's rollout):
-    same bits as one launch, for both output layouts, ragged last chunk, device or host predictors."""
+def test_predict_timeseries_pipelined_host_copy_is_bit_identical(monkeypatch):
+    """A large series goes back to the host slot by slot WHILE the rollout runs (DLWPNeuralNet._rollout_streamed: one graph per
+    model call, copy streams, one pinned result array; r5): same bits as the one-graph rollout with a single copy behind it, for
+    both output layouts, both transfer forms (copy engine / store kernel), member chunks in the first call (host predictors) or
+    not (7 members: no even cut; device predictors)."""
     import torch
     rng = np.random.default_rng(5)
     cs = (4, 16, 24)
     d = _build(unet_layers(cs), time_dim=2)
     _weights_of(d.model, rng)
-    x = rng.standard_normal((7,) + cs).astype(np.float32)
-    whole = d.predict_timeseries(x, 6)
-    whole_kept = d.predict_timeseries(x, 6, keep_time_dim=True)
-    d.host_chunk_members = 2                    # 7 members -> chunks of 2, 2, 2, 1
-    try:
-        assert np.array_equal(d.predict_timeseries(x, 6), whole)
-        assert np.array_equal(d.predict_timeseries(x, 6, keep_time_dim=True), whole_kept)
-        assert np.array_equal(d.predict_timeseries(torch.from_numpy(x).cuda(), 6), whole)
-        dev = d.predict_timeseries(x, 6, return_device=True)
-        assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), whole)
-    finally:
-        d.host_chunk_members = 64
+    for n in (8, 7):
+        x = rng.standard_normal((n,) + cs).astype(np.float32)
+        d.host_stream_bytes = 1 << 60               # never streamed: one graph, one copy
+        whole = d.predict_timeseries(x, 6)
+        whole_kept = d.predict_timeseries(x, 6, keep_time_dim=True)
+        d.host_stream_bytes = 0                     # always streamed
+        try:
+            for mode in ('dma', 'kernel'):
+                monkeypatch.setenv('DLWP_D2H', mode)
+                for _ in range(2):                  # (the second call reuses the cached graphs, staging buffers and streams)
+                    assert np.array_equal(d.predict_timeseries(x, 6), whole), (n, mode)
+                    assert np.array_equal(d.predict_timeseries(x, 6, keep_time_dim=True), whole_kept), (n, mode)
+                assert np.array_equal(d.predict_timeseries(torch.from_numpy(x).cuda(), 6), whole), (n, mode)
+            sr = d.model.streamed_rollout(n, 3, d.host_head_chunks)
+            assert len(sr.head) == (4 if n == 8 else 1) and len(sr.tail) == 2
+            dev = d.predict_timeseries(x, 6, return_device=True)
+            assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), whole)
+        finally:
+            d.host_stream_bytes = 64 << 20
+    monkeypatch.delenv('DLWP_D2H')
 
 
 @pytest.mark.parametrize('n', [1031, 2101])
@@ -204,7 +216,7 @@ def test_full_size_ensemble_beyond_a_thousand_members(n):
     for lo, hi in ((0, 5), (511, 518), (n - 7, n)):
         small = d.predict_timeseries(x[lo:hi].contiguous(), 4, return_device=True)
         assert _rel(dev[:, lo:hi].cpu().numpy(), small.cpu().numpy()) < 2e-5, (lo, hi)
-    host = d.predict_timeseries(x, 4)                                 # chunks of 64 members and a ragged last one
+    host = d.predict_timeseries(x, 4)                                 # streamed: slot by slot while the rollout runs
     assert isinstance(host, np.ndarray) and np.array_equal(host, dev.cpu().numpy())
 
 
@@ -231,7 +243,7 @@ def test_headline_ensemble_of_256_members_against_the_oracle_directly():
         if m == 0:
             want2 = np_ref.run_layers(layers, want, weights)
             err2 = _rel(got[1, :1], want2)
-            assert err2 < 2 * FWD_TOL, err2
+            assert err2 < FWD_TOL, err2
             MEASURED['headline_256_members_second_forward_member_0'] = [err2]
     MEASURED['headline_256_members_first_forward_members_0_131_255'] = [worst]
 
@@ -264,9 +276,10 @@ def test_rollout_captured_as_parallel_member_chains_is_bit_identical():
     from dlwp_amd import ops
     # (r4) forked graphs never hold split-K launches (csrc/rollout.hip), a single chain of this few members does: the chains equal
     # the single chain of the same -- unsplit -- regime bit for bit, and the split one to float32 round-off
-    want_split = net.rollout_on_device(x, 5, graph_cache=False).clone()
-    prev = ops.set_splitk(0)
+    prev = ops.set_splitk(1)                 # (opt-in since r5)
     try:
+        want_split = net.rollout_on_device(x, 5, graph_cache=False).clone()
+        ops.set_splitk(0)
         want = net.rollout_on_device(x, 5, graph_cache=False).clone()
     finally:
         ops.set_splitk(prev)
@@ -373,12 +386,12 @@ def test_functional_skip_unet_and_chained_outputs():
     y1, y2 = f.predict(x)
     r1 = ref(x.astype(np.float64))
     r2 = ref(r1)
-    assert _rel(y1, r1) < FWD_TOL and _rel(y2, r2) < 4 * FWD_TOL
+    assert _rel(y1, r1) < FWD_TOL and _rel(y2, r2) < FWD_TOL
     # rollout: 2 outputs per call, time_dim 2 -> 5 steps need ceil(5/2/2) = 2 calls = 4 slots = 8 steps
     ts = f.predict_timeseries(x, 5)
     assert ts.shape == (8, 3, 2, 16, 24)
     want = np_ref.predict_timeseries_functional(lambda p: [ref(p), ref(ref(p))], x.astype(np.float64), 5, 2, n_outputs=2)
-    assert _rel(ts[:4], want[:4]) < 4 * FWD_TOL
+    assert _rel(ts[:4], want[:4]) < FWD_TOL
     # and it is exactly the host loop over predict()
     p, slots = x, []
     for _ in range(2):
@@ -1136,9 +1149,9 @@ def test_convlstm_unet_forward_and_rollout_match_oracle():
     got = d.predict(x)
     want = np_ref.run_layers(layers, x, weights)
     assert got.shape == want.shape == (3,) + cs
-    assert _rel(got, want) < 2 * FWD_TOL
+    assert _rel(got, want) < FWD_TOL
     want32 = torch_ref.run_layers(layers, torch.from_numpy(x), torch_ref.to_torch_weights(weights)).numpy()
-    assert _rel(got, want32) < 2 * FWD_TOL
+    assert _rel(got, want32) < FWD_TOL
     # rollout: the hipGraph replay equals the host loop over predict(), and follows the reference's bookkeeping
     series = d.predict_timeseries(x, 5)                               # ceil(5/2) = 3 forwards -> 6 steps
     assert series.shape == (6, 3, 2, 16, 24)
@@ -1412,7 +1425,7 @@ def test_imported_keras_hdf5_checkpoint_forecasts_like_the_oracle():
 
 
 def test_host_series_come_from_recycled_pinned_buffers_without_aliasing_a_live_result():
-    """predict_timeseries over member chunks returns a numpy array on page-locked memory that goes back to a pool when the caller
+    """predict_timeseries (streamed return) gives a numpy array on page-locked memory that goes back to a pool when the caller
     lets it go (util._PinnedPool): a result that is still referenced -- even through a view -- is never overwritten by a later
     call, and a released one is reused (same address) instead of page-locking 1.8 GB again."""
     import gc
@@ -1420,7 +1433,7 @@ def test_host_series_come_from_recycled_pinned_buffers_without_aliasing_a_live_r
     rng = np.random.default_rng(3)
     cs = (4, 16, 24)
     d = _build(unet_layers(cs, widths=(8, 16, 16, 16, 8)), time_dim=2)
-    d.host_chunk_members = 4
+    d.host_stream_bytes = 0                      # the streamed return (its result array comes from the pool)
     x1 = rng.standard_normal((16,) + cs).astype(np.float32)
     x2 = rng.standard_normal((16,) + cs).astype(np.float32)
     a = d.predict_timeseries(x1, 4)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""The stages of the DataGenerator feed on this box, each alone: host row gather (dlwp_host_gather_rows, 1 / 8 threads), pinned H2D
-copy (torch), and the pull path (dlwp_gather_rows_h2d: a kernel reading the page-locked training set over the link).
-    python tools/bench_pull.py"""
+"""The stages of the DataGenerator feed on this box, each alone: host row gather (dlwp_host_gather_rows, 1 / 8 threads) and the
+pinned H2D copy (torch).  (r4 also measured a pull path -- a kernel reading the page-locked training set over the link, 51 GB/s
+alone, slower inside a training loop: profiles/r4_feed_stages.json, r4_loader_timeline.txt -- removed in r5.)
+    python tools/bench_feed_stages.py"""
 import ctypes
 import json
 import os
@@ -22,11 +23,6 @@ def main():
     n_src = 2560
     src = np.random.default_rng(0).standard_normal((n_src, row), dtype=np.float32)
     out = {'row_bytes': row * 4, 'cpus': os.cpu_count()}
-    dptr = ctypes.c_void_p()
-    t0 = time.perf_counter()
-    rc = _lib.lib.dlwp_host_register(ctypes.c_void_p(src.ctypes.data), src.nbytes, ctypes.byref(dptr))
-    out['register_s'] = round(time.perf_counter() - t0, 3)
-    out['register_rc'] = rc
     for n in (8, 64, 256):
         rows = np.random.default_rng(1).permutation(n_src)[:n].astype(np.int64)
         nbytes = n * row * 4
@@ -52,20 +48,6 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         rec['pinned_h2d_copy'] = {'ms': round(1e3 * dt, 3), 'GBs': round(nbytes / dt / 1e9, 1)}
-        if rc == 0:
-            st = torch.cuda.current_stream().cuda_stream
-            for _ in range(3):
-                _lib.check(_lib.lib.dlwp_gather_rows_h2d(h, ctypes.c_void_p(dst.data_ptr()), dptr, rows.ctypes.data_as(ctypes.c_void_p),
-                                                         n, row * 4, n_src, ctypes.c_void_p(st)))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                _lib.check(_lib.lib.dlwp_gather_rows_h2d(h, ctypes.c_void_p(dst.data_ptr()), dptr, rows.ctypes.data_as(ctypes.c_void_p),
-                                                         n, row * 4, n_src, ctypes.c_void_p(st)))
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 10
-            ok = bool(np.array_equal(dst.cpu().numpy().reshape(n, row), src[rows]))
-            rec['pull_kernel'] = {'ms': round(1e3 * dt, 3), 'GBs': round(nbytes / dt / 1e9, 1), 'equal': ok}
         out['rows_%d' % n] = rec
     print(json.dumps(out))
 
