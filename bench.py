@@ -522,12 +522,22 @@ def sub_cfg4(members=8, forwards=4):
     net = d.model
     net.set_activation_dtype('bfloat16')
     x = torch.randn((members,) + net.infer_plan._in_store, device=net.device)
-    ser = net.rollout_on_device(x, forwards)
-    _warm_until_steady(lambda: net.rollout_on_device(x, forwards), batch=10)   # the model was built on the host, the GPU sat idle
-    reps = 30
-    dt = _sync_time(lambda: net.rollout_on_device(x, forwards), reps)
+    # On a stream of the caller's own: the rollout's two member chains are a FORKED graph, which the library launches directly on a
+    # real stream and through a stream of its own (two cross-queue hops, ~40 us of this 1 ms rollout) on torch's null stream
+    # (csrc/rollout.hip: dlwp_rollout_launch; profiles/r5_cfg4_stream_ab.txt).  `null_stream` = the same loop on the null stream.
+    side = torch.cuda.Stream(net.device)
+    side.wait_stream(torch.cuda.current_stream(net.device))
+    with torch.cuda.stream(side):
+        ser = net.rollout_on_device(x, forwards)
+        _warm_until_steady(lambda: net.rollout_on_device(x, forwards), batch=10)   # the model was built on the host, the GPU sat idle
+        reps = 30
+        dt = _sync_time(lambda: net.rollout_on_device(x, forwards), reps)
+    torch.cuda.current_stream(net.device).wait_stream(side)
+    dt0 = _sync_time(lambda: net.rollout_on_device(x, forwards), reps)
     rec = {'value': members * forwards * 2 * reps / dt, 'unit': '6-h forecast steps/s', 'members': members, 'forwards': forwards,
            'ms_per_forward': 1e3 * dt / reps / forwards, 'dtype': 'bf16 storage and matrix cores, f32 accumulation and cell state',
+           'launch_stream': "the caller's own (torch.cuda.Stream)", 'null_stream': {'value': members * forwards * 2 * reps / dt0,
+                                                                                      'ms_per_forward': 1e3 * dt0 / reps / forwards},
            'launches_per_forward': net.infer_plan.n_launches, 'finite': bool(torch.isfinite(ser[-1]).all().item())}
     rec.update(operating_point(net, members, members * forwards * reps / dt))
     return rec

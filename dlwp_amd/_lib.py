@@ -209,8 +209,6 @@ _sig('dlwp_rollout_create_grouped', [_vp, _P(Op), _i, _P(_vp), _i, _P(_sz), _i, 
 _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
 _sig('dlwp_host_gather_rows', [_vp, _vp, _vp, ctypes.c_longlong, _sz, ctypes.c_longlong, _i])
-_sig('dlwp_copy2d_d2h_async', [_vp, _sz, _vp, _sz, _sz, _vp])
-_sig('dlwp_store2d_to_host', [_vp, _vp, _sz, _vp, _sz, _sz, _sz, _i, _vp])
 _sig('dlwp_train_step_record_begin', [_vp, _vp])
 _sig('dlwp_train_step_record_abort', [_vp])
 _sig('dlwp_stream_wait', [_vp, _vp, _vp])

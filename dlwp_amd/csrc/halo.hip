@@ -41,13 +41,7 @@ __device__ __forceinline__ int pad_map_col(int p, int n, int mode) {
   return p < 0 ? p + n : p - n;
 }
 
-// FLAT (r5; VEC = 4, INNER1): rows whose length is NOT a multiple of 4 floats (92-float rows of the 44 x 90 maps, 47-float rows of
-// the 22 x 45 maps: the shapes the profile of r2 had at 0.21-0.40 of the HBM peak on 8- and 4-byte accesses).  A group of ROWS = 4
-// output rows starts at a multiple of 4 floats whatever the row length, so the GROUP is stored as aligned 16-byte vectors of the
-// flat output (a vector may span two rows: every element finds its own row and column); a source row that starts misaligned is
-// pulled into LDS through the aligned 16-byte window around it (<= 3 floats of its neighbours on either side ride along, `off`
-// tells where the row starts inside its slot).
-template <int VEC, bool INNER1, bool FLAT = false>
+template <int VEC, bool INNER1>
 __global__ __launch_bounds__(256) void pad2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int outer,
                                                         int H, int W, int inner, int Ho, int Wo, int top, int left,
                                                         int mode_h, int mode_w, int row_lds /* floats per row slot */) {
@@ -76,55 +70,6 @@ __global__ __launch_bounds__(256) void pad2d_fwd_kernel(const float* __restrict_
         const int hs = dlwp_map_coord((int)(r - (long long)o * Ho) - top, H, mode_h);
         if (hs >= 0) srow[k] = (long long)o * H + hs;
       }
-    }
-    if constexpr (FLAT) {
-      const long long total_in = (long long)outer * H * RI;
-      const int NV = (RI + 6) >> 2;                    // 16-byte units of a row's aligned window, at most
-      for (int j = lane; j < ROWS * NV; j += 64) {
-        const int k = (j >= NV) + (j >= 2 * NV) + (j >= 3 * NV);
-        const int i = j - k * NV;
-        const long long sr = k == 0 ? srow[0] : (k == 1 ? srow[1] : (k == 2 ? srow[2] : srow[3]));
-        if (sr < 0) continue;
-        const long long b = sr * RI;
-        const int off = (int)(b & 3);
-        if (4 * i >= off + RI) continue;
-        const long long a = (b & ~3ll) + 4 * i;
-        float* d = slot + k * row_lds + 4 * i;
-        if (a + 4 <= total_in) {
-          *(f32x4*)d = *(const f32x4*)(x + a);
-        } else {                                         // the tensor's last, partial unit
-          for (int q = 0; q < 4; ++q)
-            if (a + q < total_in) d[q] = x[a + q];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int rows_here = (int)(n_rows - r0 < ROWS ? n_rows - r0 : ROWS);
-      const int valid = rows_here * RO;                  // floats of this group that exist
-      for (int j = lane; 4 * j < valid; j += 64) {
-        f32x4 v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = 4 * j + q;
-          const int k = (e >= RO) + (e >= 2 * RO) + (e >= 3 * RO);
-          const int wo = e - k * RO;
-          const long long sr = k == 0 ? srow[0] : (k == 1 ? srow[1] : (k == 2 ? srow[2] : srow[3]));
-          const int ws = pad_map_col(wo - left, W, mode_w);
-          const int off = (int)((sr * RI) & 3);
-          v[q] = (sr >= 0 && ws >= 0) ? slot[k * row_lds + off + (ws >= 0 ? ws : 0)] : 0.f;
-        }
-        float* dst = y + r0 * RO + 4 * j;
-        if (4 * j + 4 <= valid) {
-          *(f32x4*)dst = v;
-        } else {
-          for (int q = 0; q < 4; ++q)
-            if (4 * j + q < valid) dst[q] = v[q];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      continue;
     }
     for (int j = lane; j < ROWS * RIV; j += 64) {
       const int k = (j >= RIV) + (j >= 2 * RIV) + (j >= 3 * RIV);
@@ -167,7 +112,7 @@ __global__ __launch_bounds__(256) void pad2d_fwd_kernel(const float* __restrict_
 // stores whose lanes add the column images (interior column + wrapped / clamped halo columns) out of LDS.  The few dx rows
 // that are also the image of halo ROWS (the first / last `bottom` / `top` rows of a periodic axis, row 0 / H-1 of an edge
 // axis) add those rows straight from global memory.  Fixed summation order per element: deterministic.
-template <int VEC, bool INNER1, bool FLAT = false>
+template <int VEC, bool INNER1>
 __global__ __launch_bounds__(256) void pad2d_bwd_rows_kernel(const float* __restrict__ dy, float* __restrict__ dx, int outer,
                                                              int H, int W, int inner, int Ho, int Wo, int top, int bottom,
                                                              int left, int right, int mode_h, int mode_w, int row_lds) {
@@ -202,86 +147,6 @@ __global__ __launch_bounds__(256) void pad2d_bwd_rows_kernel(const float* __rest
     return s;
   };
   for (long long r0 = ((long long)blockIdx.x * 4 + wave) * ROWS; r0 < n_rows; r0 += stride) {
-    if constexpr (FLAT) {          // (see pad2d_fwd_kernel: aligned windows in, the group of 4 dx rows out as flat 16-byte vectors)
-      const long long total_dy = (long long)outer * Ho * RO;
-      const int NV = (RO + 6) >> 2;
-      long long ob[ROWS];          // first dy element of the interior row of dx row r0 + k (-1: past the end)
-      int hk[ROWS];
-#pragma unroll
-      for (int k = 0; k < ROWS; ++k) {
-        const long long r = r0 + k;
-        ob[k] = -1;
-        hk[k] = 0;
-        if (r < n_rows) {
-          const long long o = r / H;
-          hk[k] = (int)(r - o * H);
-          ob[k] = (o * Ho + hk[k] + top) * RO;
-        }
-      }
-      for (int j = lane; j < ROWS * NV; j += 64) {
-        const int k = (j >= NV) + (j >= 2 * NV) + (j >= 3 * NV);
-        const int i = j - k * NV;
-        const long long b = k == 0 ? ob[0] : (k == 1 ? ob[1] : (k == 2 ? ob[2] : ob[3]));
-        if (b < 0) continue;
-        const int off = (int)(b & 3);
-        if (4 * i >= off + RO) continue;
-        const long long a = (b & ~3ll) + 4 * i;
-        float* d = slot + k * row_lds + 4 * i;
-        if (a + 4 <= total_dy) {
-          *(f32x4*)d = *(const f32x4*)(dy + a);
-        } else {
-          for (int q = 0; q < 4; ++q)
-            if (a + q < total_dy) d[q] = dy[a + q];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int rows_here = (int)(n_rows - r0 < ROWS ? n_rows - r0 : ROWS);
-      const int valid = rows_here * RI;
-      for (int j = lane; 4 * j < valid; j += 64) {
-        f32x4 v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int e = 4 * j + q;
-          const int k = (e >= RI) + (e >= 2 * RI) + (e >= 3 * RI);
-          const int w = e - k * RI;
-          const long long b = k == 0 ? ob[0] : (k == 1 ? ob[1] : (k == 2 ? ob[2] : ob[3]));
-          const int hh = k == 0 ? hk[0] : (k == 1 ? hk[1] : (k == 2 ? hk[2] : hk[3]));
-          float acc = 0.f;
-          if (b >= 0) {
-            const float* row = slot + k * row_lds + (int)(b & 3);
-            const float* img = dy + (b - (long long)(hh + top) * RO);      // this image's padded gradient
-            acc = col_sum(row, w, 0);
-            if (mode_h == DLWP_PAD_WRAP) {
-              if (hh >= H - top) acc += col_sum(img + (long long)(hh - (H - top)) * RO, w, 0);
-              if (hh < bottom) acc += col_sum(img + (long long)(top + H + hh) * RO, w, 0);
-            } else if (mode_h == DLWP_PAD_EDGE) {
-              if (hh == 0)
-                for (int rr = 0; rr < top; ++rr) acc += col_sum(img + (long long)rr * RO, w, 0);
-              if (hh == H - 1)
-                for (int rr = top + H; rr < Ho; ++rr) acc += col_sum(img + (long long)rr * RO, w, 0);
-            } else if (mode_h >= DLWP_PAD_REFLECT) {
-              for (int rr = 0; rr < top; ++rr)
-                if (pad_map_col(rr - top, H, mode_h) == hh) acc += col_sum(img + (long long)rr * RO, w, 0);
-              for (int rr = top + H; rr < Ho; ++rr)
-                if (pad_map_col(rr - top, H, mode_h) == hh) acc += col_sum(img + (long long)rr * RO, w, 0);
-            }
-          }
-          v[q] = acc;
-        }
-        float* dst = dx + r0 * RI + 4 * j;
-        if (4 * j + 4 <= valid) {
-          *(f32x4*)dst = v;
-        } else {
-          for (int q = 0; q < 4; ++q)
-            if (4 * j + q < valid) dst[q] = v[q];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      continue;
-    }
     for (int j = lane; j < ROWS * ROV; j += 64) {
       const int k = (j >= ROV) + (j >= 2 * ROV) + (j >= 3 * ROV);
       const int c = (j - k * ROV) * VEC;
@@ -331,6 +196,236 @@ __global__ __launch_bounds__(256) void pad2d_bwd_rows_kernel(const float* __rest
         v[q] = acc;
       }
       *(vec_t*)(dx + r * RI + c) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ //
+// r5: the FLAT row-group kernels -- NCHW (inner = 1), 16-byte aligned tensors, ANY row length.
+// r4's row-staged kernels moved rows as 16-, 8- or 4-byte units according to the row length, four rows per wave: 92-float rows
+// (44 x 90 maps) went as 8-byte units at 0.40 of the HBM peak, 47-float rows (22 x 45) as single floats at 0.21, and even
+// whole-unit rows had only ~2.9 KB (180 floats) or ~0.75 KB (47 floats) of loads in flight per wave.  Here a wave owns a GROUP
+// of ROWS consecutive output rows, ROWS in {4, 8, 16} chosen so that a group is >= ~2.5 KB: a multiple of 4 rows starts at a
+// multiple of 4 floats whatever the row length, so the group is STORED as aligned 16-byte vectors of the flat output (a vector
+// may span two rows: every element finds its own row and column through a multiply-high division); a source row that starts
+// misaligned is pulled into LDS through the aligned 16-byte window around it (<= 3 floats of its neighbours ride along, the
+// low two bits of its base say where it starts inside its slot).  Per-row bases live in a small LDS table of the wave.
+// ------------------------------------------------------------------------------------------------------------------ //
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned magic) {   // n / d for n * d < 2^32; magic 0: d = 1
+  return magic ? __umulhi(n, magic) : n;
+}
+
+template <int ROWS, int MH = -1, int MW = -1>
+__global__ __launch_bounds__(256) void pad2d_fwd_flat_kernel(const float* __restrict__ x, float* __restrict__ y, int outer, int H,
+                                                             int W, int Ho, int Wo, int top, int left, int mode_h_rt, int mode_w_rt,
+                                                             int row_lds, unsigned magic_nv, unsigned magic_ro) {
+  const int mode_h = MH >= 0 ? MH : mode_h_rt, mode_w = MW >= 0 ? MW : mode_w_rt;   // (see pad2d_bwd_flat_kernel)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* slot = lds + wave * ROWS * row_lds;
+  long long* tbl = (long long*)(lds + 4 * ROWS * row_lds) + wave * ROWS;      // first source element of each row, -1: zero row
+  const int RI = W, RO = Wo;
+  const int NV = (RI + 6) >> 2;                        // 16-byte units of a row's aligned window, at most
+  const long long n_rows = (long long)outer * Ho;
+  const long long total_in = (long long)outer * H * RI;
+  const long long stride = (long long)gridDim.x * 4 * ROWS;
+  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * ROWS; r0 < n_rows; r0 += stride) {
+    if (lane < ROWS) {
+      const long long r = r0 + lane;
+      long long b = -1;
+      if (r < n_rows) {
+        const long long o = r / Ho;
+        const int hs = dlwp_map_coord((int)(r - o * Ho) - top, H, mode_h);
+        if (hs >= 0) b = (o * H + hs) * RI;
+      }
+      tbl[lane] = b;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = lane; j < ROWS * NV; j += 64) {
+      const int k = (int)udiv_magic((unsigned)j, magic_nv);
+      const int i = j - k * NV;
+      const long long b = tbl[k];
+      if (b < 0) continue;
+      const int off = (int)(b & 3);
+      if (4 * i >= off + RI) continue;
+      const long long a = (b & ~3ll) + 4 * i;
+      float* d = slot + k * row_lds + 4 * i;
+      if (a + 4 <= total_in) {
+        *(f32x4*)d = __builtin_nontemporal_load((const f32x4*)(x + a));
+      } else {                                           // the tensor's last, partial unit
+        for (int q = 0; q < 4; ++q)
+          if (a + q < total_in) d[q] = x[a + q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int rows_here = (int)(n_rows - r0 < ROWS ? n_rows - r0 : ROWS);
+    const int valid = rows_here * RO;                    // floats of this group that exist
+    for (int j = lane; 4 * j < valid; j += 64) {
+      const int k0 = (int)udiv_magic((unsigned)(4 * j), magic_ro);
+      const long long b0 = tbl[k0], b1 = tbl[k0 + 1 < ROWS ? k0 + 1 : k0];
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = 4 * j + q;
+        int k = k0;
+        long long b = b0;
+        if (e >= (k0 + 1) * RO) {                          // (RO < 4: a vector may span several rows -- walk on)
+          k = k0 + 1;
+          b = b1;
+          while (e >= (k + 1) * RO) {
+            ++k;
+            b = k < ROWS ? tbl[k] : -1;
+          }
+        }
+        const int wo = e - k * RO;
+        const int ws = pad_map_col(wo - left, W, mode_w);
+        v[q] = (b >= 0 && ws >= 0 && e < valid) ? slot[k * row_lds + (int)(b & 3) + (ws >= 0 ? ws : 0)] : 0.f;
+      }
+      float* dst = y + r0 * RO + 4 * j;
+      if (4 * j + 4 <= valid) {
+        __builtin_nontemporal_store(v, (f32x4*)dst);
+      } else {
+        for (int q = 0; q < 4; ++q)
+          if (4 * j + q < valid) dst[q] = v[q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// backward: a wave owns ROWS dx rows, stages their INTERIOR dy rows, adds the column images out of LDS and the halo-row images
+// straight from global memory (as pad2d_bwd_rows_kernel), stores the group as flat 16-byte vectors.  Deterministic.
+// MH / MW >= 0: the halo modes as compile-time constants -- the composite halo of every network here (zero rows, periodic
+// columns) gets an instance of a few hundred instructions; with run-time modes the four elements of a vector each carry the whole
+// mode switch (10 k lines of code: the r2-r4 kernel ran at 0.3-0.48 of the HBM peak out of the instruction cache).
+template <int ROWS, int MH = -1, int MW = -1>
+__global__ __launch_bounds__(256) void pad2d_bwd_flat_kernel(const float* __restrict__ dy, float* __restrict__ dx, int outer, int H,
+                                                             int W, int Ho, int Wo, int top, int bottom, int left, int right,
+                                                             int mode_h_rt, int mode_w_rt, int row_lds, unsigned magic_nv,
+                                                             unsigned magic_ri) {
+  const int mode_h = MH >= 0 ? MH : mode_h_rt, mode_w = MW >= 0 ? MW : mode_w_rt;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* slot = lds + wave * ROWS * row_lds;
+  long long* tbl = (long long*)(lds + 4 * ROWS * row_lds) + wave * ROWS;      // first dy element of each dx row's interior row
+  int* hht = (int*)((long long*)(lds + 4 * ROWS * row_lds) + 4 * ROWS) + wave * ROWS;   // ... and the row's index in its image
+  const int RI = W, RO = Wo;
+  const int NV = (RO + 6) >> 2;
+  const long long n_rows = (long long)outer * H;
+  const long long total_dy = (long long)outer * Ho * RO;
+  const long long stride = (long long)gridDim.x * 4 * ROWS;
+  auto col_sum = [&](const float* rp, int w) {
+    float s = rp[w + left];
+    if (mode_w == DLWP_PAD_WRAP) {
+      if (w >= W - left) s += rp[w - (W - left)];
+      if (w < right) s += rp[left + W + w];
+    } else if (mode_w == DLWP_PAD_EDGE) {
+      if (w == 0)
+        for (int c = 0; c < left; ++c) s += rp[c];
+      if (w == W - 1)
+        for (int c = left + W; c < Wo; ++c) s += rp[c];
+    } else if (mode_w >= DLWP_PAD_REFLECT) {   // mirror halos: every halo column is the image of exactly one column
+      for (int c = 0; c < left; ++c)
+        if (pad_map_col(c - left, W, mode_w) == w) s += rp[c];
+      for (int c = left + W; c < Wo; ++c)
+        if (pad_map_col(c - left, W, mode_w) == w) s += rp[c];
+    }
+    return s;
+  };
+  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * ROWS; r0 < n_rows; r0 += stride) {
+    if (lane < ROWS) {
+      const long long r = r0 + lane;
+      long long b = -1;
+      int hh = 0;
+      if (r < n_rows) {
+        const long long o = r / H;
+        hh = (int)(r - o * H);
+        b = (o * Ho + hh + top) * RO;
+      }
+      tbl[lane] = b;
+      hht[lane] = hh;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int j = lane; j < ROWS * NV; j += 64) {
+      const int k = (int)udiv_magic((unsigned)j, magic_nv);
+      const int i = j - k * NV;
+      const long long b = tbl[k];
+      if (b < 0) continue;
+      const int off = (int)(b & 3);
+      if (4 * i >= off + RO) continue;
+      const long long a = (b & ~3ll) + 4 * i;
+      float* d = slot + k * row_lds + 4 * i;
+      if (a + 4 <= total_dy) {
+        *(f32x4*)d = __builtin_nontemporal_load((const f32x4*)(dy + a));
+      } else {
+        for (int q = 0; q < 4; ++q)
+          if (a + q < total_dy) d[q] = dy[a + q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int rows_here = (int)(n_rows - r0 < ROWS ? n_rows - r0 : ROWS);
+    const int valid = rows_here * RI;
+    for (int j = lane; 4 * j < valid; j += 64) {
+      const int k0 = (int)udiv_magic((unsigned)(4 * j), magic_ri);
+      const long long b0 = tbl[k0], b1 = tbl[k0 + 1 < ROWS ? k0 + 1 : k0];
+      f32x4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = 4 * j + q;
+        int k = k0;
+        long long b = b0;
+        if (e >= (k0 + 1) * RI) {                          // (RI < 4: a vector may span several rows -- walk on)
+          k = k0 + 1;
+          b = b1;
+          while (e >= (k + 1) * RI) {
+            ++k;
+            b = k < ROWS ? tbl[k] : -1;
+          }
+        }
+        const int w = e - k * RI;
+        float acc = 0.f;
+        if (b >= 0 && e < valid) {
+          const int hh = hht[k];
+          const float* row = slot + k * row_lds + (int)(b & 3);
+          const float* img = dy + (b - (long long)(hh + top) * RO);      // this image's padded gradient
+          acc = col_sum(row, w);
+          if (mode_h == DLWP_PAD_WRAP) {
+            if (hh >= H - top) acc += col_sum(img + (long long)(hh - (H - top)) * RO, w);
+            if (hh < bottom) acc += col_sum(img + (long long)(top + H + hh) * RO, w);
+          } else if (mode_h == DLWP_PAD_EDGE) {
+            if (hh == 0)
+              for (int rr = 0; rr < top; ++rr) acc += col_sum(img + (long long)rr * RO, w);
+            if (hh == H - 1)
+              for (int rr = top + H; rr < Ho; ++rr) acc += col_sum(img + (long long)rr * RO, w);
+          } else if (mode_h >= DLWP_PAD_REFLECT) {
+            for (int rr = 0; rr < top; ++rr)
+              if (pad_map_col(rr - top, H, mode_h) == hh) acc += col_sum(img + (long long)rr * RO, w);
+            for (int rr = top + H; rr < Ho; ++rr)
+              if (pad_map_col(rr - top, H, mode_h) == hh) acc += col_sum(img + (long long)rr * RO, w);
+          }
+        }
+        v[q] = acc;
+      }
+      float* dst = dx + r0 * RI + 4 * j;
+      if (4 * j + 4 <= valid) {
+        __builtin_nontemporal_store(v, (f32x4*)dst);
+      } else {
+        for (int q = 0; q < 4; ++q)
+          if (4 * j + q < valid) dst[q] = v[q];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -562,6 +657,11 @@ __global__ __launch_bounds__(256) void copy_runs_kernel(const float* __restrict_
 
 extern "C" {
 
+// the flat row-group kernels: rows per wave so that a group is >= ~2.5 KB (loads in flight per wave), and the multiply-high
+// constant of a division by d (exact for n * d < 2^32: n < 16 rows x 4096 floats)
+static inline int pad_flat_rows(int row_floats) { return row_floats <= 80 ? 16 : (row_floats <= 160 ? 8 : 4); }
+static inline unsigned pad_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+
 int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, int W, int inner, dlwp_pad2d p, int dtype,
                    void* stream) {
   DLWP_TAPE(h, stream, dlwp_pad2d_fwd, h, x, y, outer, H, W, inner, p, dtype);
@@ -583,25 +683,47 @@ int dlwp_pad2d_fwd(dlwp_handle_t h, const void* x, void* y, int outer, int H, in
   if (outer == 0) return DLWP_OK;
   const int Ho = H + p.top + p.bottom, Wo = W + p.left + p.right;
   const long long RI = (long long)W * inner, RO = (long long)Wo * inner;
-  const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(x) && aligned16(y);
-  // rows that are not whole 16-byte units: aligned windows in, flat 16-byte vectors out (pad2d_fwd_kernel<4, true, true>)
-  const bool flat = !vec && inner == 1 && aligned16(x) && aligned16(y);
-  const int row_lds = flat ? (int)((RI + 6) / 4 * 4 + 4) : (int)((RI + 3) / 4 * 4);
+  if (inner == 1 && aligned16(x) && aligned16(y) && Wo <= 4096) {      // r5: the flat row-group kernel (any row length)
+    const int rows = pad_flat_rows(W < Wo ? W : Wo);
+    const int flat_lds = (int)((RI + 6) / 4 * 4 + 4);
+    const size_t bytes = (size_t)flat_lds * 4 * rows * sizeof(float) + (size_t)4 * rows * sizeof(long long);
+    if (bytes <= 64 * 1024 && bytes <= (size_t)h->lds_bytes) {
+      const long long groups = ((long long)outer * Ho + rows - 1) / rows;
+      int grid = (int)((groups + 3) / 4);
+      const int cap = h->cu_count * 8;
+      if (grid > cap) grid = cap;
+      const unsigned m_nv = pad_magic((unsigned)((RI + 6) >> 2)), m_ro = pad_magic((unsigned)RO);
+#define PADF_LAUNCH(R, MH, MW)                                                                                              \
+  pad2d_fwd_flat_kernel<R, MH, MW><<<grid, 256, bytes, (hipStream_t)stream>>>((const float*)x, (float*)y, outer, H, W, Ho, Wo,   \
+                                                                              p.top, p.left, p.mode_h, p.mode_w, flat_lds, m_nv, m_ro)
+      if (p.mode_h == DLWP_PAD_ZERO && p.mode_w == DLWP_PAD_WRAP) {        // PeriodicPadding2D((0, k)) + ZeroPadding2D((k, 0))
+        if (rows == 16) PADF_LAUNCH(16, DLWP_PAD_ZERO, DLWP_PAD_WRAP);
+        else if (rows == 8) PADF_LAUNCH(8, DLWP_PAD_ZERO, DLWP_PAD_WRAP);
+        else PADF_LAUNCH(4, DLWP_PAD_ZERO, DLWP_PAD_WRAP);
+      } else {
+        if (rows == 16) PADF_LAUNCH(16, -1, -1);
+        else if (rows == 8) PADF_LAUNCH(8, -1, -1);
+        else PADF_LAUNCH(4, -1, -1);
+      }
+#undef PADF_LAUNCH
+      DLWP_LAUNCH_CHECK("pad2d_fwd_flat_kernel");
+      return DLWP_OK;
+    }
+  }
+  const int row_lds = (int)((RI + 3) / 4 * 4);
   const size_t lds_bytes = (size_t)row_lds * 4 * 4 * sizeof(float);  // 4 waves x ROWS(4) row slots
   DLWP_CHECK_ARG(lds_bytes <= (size_t)h->lds_bytes, "dlwp_pad2d_fwd: row of %lld floats does not fit in LDS", RI);
   const long long n_rows = (long long)outer * Ho;
   int grid = (int)((n_rows + 15) / 16);
   const int cap = h->cu_count * 8;
   if (grid > cap) grid = cap;
+  const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(x) && aligned16(y);
   const bool vec2 = (RI % 2 == 0) && (RO % 2 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 7) == 0;
   hipStream_t s = (hipStream_t)stream;
 #define PAD_LAUNCH(V, I1)                                                                                            \
   pad2d_fwd_kernel<V, I1><<<grid, 256, lds_bytes, s>>>((const float*)x, (float*)y, outer, H, W, inner, Ho, Wo, p.top, \
                                                        p.left, p.mode_h, p.mode_w, row_lds)
-  if (flat) {
-    pad2d_fwd_kernel<4, true, true><<<grid, 256, lds_bytes, s>>>((const float*)x, (float*)y, outer, H, W, inner, Ho, Wo, p.top,
-                                                                 p.left, p.mode_h, p.mode_w, row_lds);
-  } else if (inner == 1) {
+  if (inner == 1) {
     if (vec) PAD_LAUNCH(4, true);
     else if (vec2) PAD_LAUNCH(2, true);
     else PAD_LAUNCH(1, true);
@@ -630,28 +752,53 @@ int dlwp_pad2d_bwd(dlwp_handle_t h, const void* dy, void* dx, int outer, int H, 
   DLWP_CHECK_ARG(dlwp_pad_fits(p.top, p.bottom, H, p.mode_h) && dlwp_pad_fits(p.left, p.right, W, p.mode_w),
                  "dlwp_pad2d_bwd: mirror padding exceeds the axis");
   if (outer == 0) return DLWP_OK;
+  if (inner == 1 && aligned16(dy) && aligned16(dx) && W + p.left + p.right <= 4096) {      // r5: the flat row-group kernel
+    const int Ho = H + p.top + p.bottom, Wo = W + p.left + p.right;
+    const int rows = pad_flat_rows(W);
+    const int flat_lds = (int)((Wo + 6) / 4 * 4 + 4);
+    const size_t bytes = (size_t)flat_lds * 4 * rows * sizeof(float) + (size_t)4 * rows * (sizeof(long long) + sizeof(int));
+    if (bytes <= 64 * 1024 && bytes <= (size_t)h->lds_bytes) {
+      const long long groups = ((long long)outer * H + rows - 1) / rows;
+      int grid = (int)((groups + 3) / 4);
+      const int cap = h->cu_count * 8;
+      if (grid > cap) grid = cap;
+      const unsigned m_nv = pad_magic((unsigned)((Wo + 6) >> 2)), m_ri = pad_magic((unsigned)W);
+#define PADBF_LAUNCH(R, MH, MW)                                                                                              \
+  pad2d_bwd_flat_kernel<R, MH, MW><<<grid, 256, bytes, (hipStream_t)stream>>>((const float*)dy, (float*)dx, outer, H, W, Ho, Wo,  \
+                                                                              p.top, p.bottom, p.left, p.right, p.mode_h, p.mode_w, \
+                                                                              flat_lds, m_nv, m_ri)
+      if (p.mode_h == DLWP_PAD_ZERO && p.mode_w == DLWP_PAD_WRAP) {        // PeriodicPadding2D((0, k)) + ZeroPadding2D((k, 0))
+        if (rows == 16) PADBF_LAUNCH(16, DLWP_PAD_ZERO, DLWP_PAD_WRAP);
+        else if (rows == 8) PADBF_LAUNCH(8, DLWP_PAD_ZERO, DLWP_PAD_WRAP);
+        else PADBF_LAUNCH(4, DLWP_PAD_ZERO, DLWP_PAD_WRAP);
+      } else {
+        if (rows == 16) PADBF_LAUNCH(16, -1, -1);
+        else if (rows == 8) PADBF_LAUNCH(8, -1, -1);
+        else PADBF_LAUNCH(4, -1, -1);
+      }
+#undef PADBF_LAUNCH
+      DLWP_LAUNCH_CHECK("pad2d_bwd_flat_kernel");
+      return DLWP_OK;
+    }
+  }
   {
     // row-staged kernel whenever 4 waves x 4 padded rows fit in LDS (every shape of the reference's networks does)
     const int Ho = H + p.top + p.bottom, Wo = W + p.left + p.right;
     const long long RI = (long long)W * inner, RO = (long long)Wo * inner;
-    const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(dy) && aligned16(dx);
-    const bool flat = !vec && inner == 1 && aligned16(dy) && aligned16(dx);
-    const int row_lds = flat ? (int)((RO + 6) / 4 * 4 + 4) : (int)((RO + 3) / 4 * 4);
+    const int row_lds = (int)((RO + 3) / 4 * 4);
     const size_t lds_bytes = (size_t)row_lds * 4 * 4 * sizeof(float);
     if (lds_bytes <= (size_t)h->lds_bytes && lds_bytes <= 64 * 1024) {
       const long long n_rows = (long long)outer * H;
       int grid = (int)((n_rows + 15) / 16);
       const int cap = h->cu_count * 8;
       if (grid > cap) grid = cap;
+      const bool vec = (RI % 4 == 0) && (RO % 4 == 0) && aligned16(dy) && aligned16(dx);
       const bool vec2 = (RI % 2 == 0) && (RO % 2 == 0) && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 7) == 0;
       hipStream_t s = (hipStream_t)stream;
 #define PADB_LAUNCH(V, I1)                                                                                              \
   pad2d_bwd_rows_kernel<V, I1><<<grid, 256, lds_bytes, s>>>((const float*)dy, (float*)dx, outer, H, W, inner, Ho, Wo,   \
                                                             p.top, p.bottom, p.left, p.right, p.mode_h, p.mode_w, row_lds)
-      if (flat) {
-        pad2d_bwd_rows_kernel<4, true, true><<<grid, 256, lds_bytes, s>>>((const float*)dy, (float*)dx, outer, H, W, inner, Ho, Wo,
-                                                                          p.top, p.bottom, p.left, p.right, p.mode_h, p.mode_w, row_lds);
-      } else if (inner == 1) {
+      if (inner == 1) {
         if (vec) PADB_LAUNCH(4, true);
         else if (vec2) PADB_LAUNCH(2, true);
         else PADB_LAUNCH(1, true);

@@ -339,11 +339,15 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
 int dlwp_rollout_launch(dlwp_rollout_t r, void* stream) {
   DLWP_UNTAPED(dlwp_rollout_launch);
   DLWP_CHECK_ARG(r && r->exec, "dlwp_rollout_launch: null rollout");
-  // A FORKED graph (member chains) is launched on a stream of the rollout's own, ordered behind and in front of the caller's by two
-  // events -- never on the caller's stream itself, which under torch is the legacy null stream: r4, the first full GPU test run on a
-  // fresh box faulted inside hipGraphLaunch (null object in the runtime, profiles/r4_forked_graph_fault.txt) at the first forked
-  // graph launched there, 8 of 8 fresh boxes; with the stream of its own 0 of 2.  DLWP_ROLLOUT_OWN_STREAM=0: the caller's stream.
-  static const bool own = !(getenv("DLWP_ROLLOUT_OWN_STREAM") && getenv("DLWP_ROLLOUT_OWN_STREAM")[0] == '0');
+  // A FORKED graph (member chains) launched on torch's legacy NULL stream goes to a stream of the rollout's own, ordered behind and
+  // in front of the caller's by two events: r4, the first full GPU test run on a fresh box faulted inside hipGraphLaunch (null object
+  // in the runtime, profiles/r4_forked_graph_fault.txt) at the first forked graph launched on the null stream, 8 of 8 fresh boxes;
+  // with the stream of its own 0 of 2.  The hop costs two cross-queue dependencies per launch (~40 us: config 4 at 8 members, a
+  // 1 ms rollout, 61.2-62.1 k steps/s against 63.6-65.0 k launched directly, profiles/r5_cfg4_stream_ab.txt -- the whole of r4's
+  // "regression" of that record), so a caller that runs on a REAL stream of its own gets the direct launch (r5).
+  // DLWP_ROLLOUT_OWN_STREAM=0: always direct; =2: always the own stream.
+  static const int own_mode = getenv("DLWP_ROLLOUT_OWN_STREAM") ? atoi(getenv("DLWP_ROLLOUT_OWN_STREAM")) : 1;
+  const bool own = own_mode == 2 || (own_mode == 1 && stream == nullptr);
   if (own && r->run) {
     DLWP_HIP(hipEventRecord(r->ev, (hipStream_t)stream));
     DLWP_HIP(hipStreamWaitEvent(r->run, r->ev, 0));

@@ -96,11 +96,11 @@ class _Wrapper(object):
         The rollout is one hipGraph PER MODEL CALL (engine.StreamedRollout), all members in each, launched back to back on the
         main stream; behind call j an event, and on a copy stream (two, alternating; hardware queues of their own) the slots call j
         wrote leave for ONE page-locked result array laid out as the reference returns it (time first) under call j + 1:
-          DLWP_D2H=dma (default)  keep_time_dim: one 1-D copy-engine transfer straight from the series slot; otherwise the
-                                  sample <-> time transposition of the slot into a staging buffer (dlwp_series_merge_time, ~25 us)
-                                  and ONE contiguous transfer of both time steps;
-          DLWP_D2H=kernel         dlwp_store2d_to_host: a few workgroups store the slot straight into the mapped result array, the
-                                  transposition folded into the addressing (no staging pass, no copy engine).
+        keep_time_dim: one 1-D copy-engine transfer straight from the series slot; otherwise the sample <-> time transposition of
+        the slot into a staging buffer (dlwp_series_merge_time, ~25 us) and ONE contiguous transfer of both time steps.
+        (r5 also built the transfer as a store kernel writing the mapped result array, transposition folded in: 55-58 GB/s alone,
+        like the copy engine's 56.7 -- but beside the rollout it took the 34.6 ms rollout to 50.9-53.4 ms, at 8, 16 or 32
+        workgroups, where copy-engine transfers leave it at 34.6: profiles/r5_d2h_forms.json.  Removed.)
         The pipeline's fill is one model call and its drain one slot's transfer (r4's member chunks: a quarter of the rollout
         each).  Host predictors: call 0 is cut into member chunks, chunk c + 1 is gathered into page-locked staging by the
         library's host threads and uploaded while chunk c computes.  Same kernels on the same data as the one-graph rollout:
@@ -126,10 +126,6 @@ class _Wrapper(object):
         else:
             out_shape = (slots * td, n, run // int(np.prod(fs[1:]))) + tuple(fs[1:])
         host = util.pinned_results.take(out_shape)
-        mode = os.environ.get('DLWP_D2H', 'dma')
-        if mode == 'kernel' and not host.is_pinned():
-            mode = 'dma'
-        blocks = int(os.environ.get('DLWP_D2H_BLOCKS', '16'))
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         h = _lib.handle(idx)
         main = torch.cuda.current_stream(dev)
@@ -137,10 +133,10 @@ class _Wrapper(object):
         for s_ in down:
             s_.wait_stream(main)
         stage = None
-        if mode == 'dma' and not keep_time_dim:          # one transposed call per copy stream in flight
+        if not keep_time_dim:          # one transposed call per copy stream in flight
             stage = [sr.__dict__.setdefault('_stage%d' % k, torch.empty(n_out * td * n * run, dtype=torch.float32, device=dev))
                      for k in range(len(down))]
-        host_ptr, series_ptr = host.data_ptr(), sr.series.data_ptr()
+        series_ptr = sr.series.data_ptr()
         slot_bytes = 4 * n * member
 
         def send(call, k):
@@ -148,18 +144,6 @@ class _Wrapper(object):
             st = down[k]
             sp = ctypes.c_void_p(st.cuda_stream)
             src = series_ptr + call * n_out * slot_bytes
-            dst = host_ptr + call * n_out * slot_bytes
-            if mode == 'kernel':
-                if keep_time_dim:
-                    _lib.check(_lib.lib.dlwp_store2d_to_host(h, ctypes.c_void_p(dst), 4 * member, ctypes.c_void_p(src), 4 * member,
-                                                             4 * member, n * n_out, blocks, sp))
-                else:
-                    for o in range(n_out):
-                        for j in range(td):
-                            _lib.check(_lib.lib.dlwp_store2d_to_host(
-                                h, ctypes.c_void_p(dst + (o * td + j) * 4 * n * run), 4 * run,
-                                ctypes.c_void_p(src + o * slot_bytes + 4 * j * run), 4 * member, 4 * run, n, blocks, sp))
-                return
             with torch.cuda.stream(st):
                 if keep_time_dim:
                     host.view(-1)[call * n_out * n * member:(call + 1) * n_out * n * member].copy_(

@@ -968,9 +968,10 @@ class Trainer(object):
         Two guards against a replay that silently misses a launch.  Structural: every stream-taking entry point of the
         library WITHOUT a tape record marks the tape foreign (DLWP_UNTAPED, csrc/common.h) and dlwp_train_step_create refuses it;
         torch-side launches set self._foreign.  By result (DLWP_TAPE_VALIDATE, default on): before the entry is cached the step
-        is REPLAYED once in the form it will run in (`form`), from the state the recorded step started from, with the gradient
-        buffer, the loss table and the step's outputs overwritten by NaN first -- parameters, optimizer slots, gradients and the
-        loss table must come out as the recorded (eager) step left them.  One extra step per recorded shape."""
+        runs twice more on a DIFFERENT batch from DIFFERENT weights (both derived from the recorded ones: nothing a missing
+        launch leaves behind from the recorded step can pass for its result -- not even a weight preparation's) -- once launch by
+        launch, once as the replay in the form it will run in (`form`) -- and parameters, optimizer slots, gradients and the loss
+        table of the two must agree; the state the recorded step left is put back afterwards.  Two extra steps per recorded shape."""
         from . import _lib, ops
         opt = self.model.optimizer
         gx = x.clone()
@@ -989,18 +990,21 @@ class Trainer(object):
         self._foreign = False
         validate = os.environ.get('DLWP_TAPE_VALIDATE', '1') != '0'
         state0 = [t.clone() for t in [self.flat_params] + list(self.opt_state) + [self._iter_dev]] if validate else None
+        def body(bx, bys):
+            outs_, loss_, dys_ = self._forward_backward(bx, bys, scale)
+            if dp is not None:       # the exchange and the update stay outside: a collective in between
+                ops.axpby(loss_.view(-1), self._loss_tail.view(-1), scale, 0.0)
+            elif isinstance(opt, Adam):
+                m, v = self.opt_state
+                ops.adam_keras_dev(self.flat_params, m, v, self.flat_grads, self._iter_dev, self._lr_t, opt.lr, opt.beta_1,
+                                   opt.beta_2, opt.epsilon, opt.decay, 1.0)
+            else:
+                ops.sgd_keras(self.flat_params, self.opt_state[0], self.flat_grads, 0, opt.lr, opt.momentum, 0.0, 1.0)
+            return outs_, loss_, dys_
         with torch.cuda.use_mem_pool(pool, device=self.device):
             _lib.check(_lib.lib.dlwp_train_step_record_begin(h, ctypes.c_void_p(main.cuda_stream)))
             try:
-                outs, loss_vals, dys = self._forward_backward(gx, gys, scale)
-                if dp is not None:       # the exchange and the update stay outside: a collective in between
-                    ops.axpby(loss_vals.view(-1), self._loss_tail.view(-1), scale, 0.0)
-                elif isinstance(opt, Adam):
-                    m, v = self.opt_state
-                    ops.adam_keras_dev(self.flat_params, m, v, self.flat_grads, self._iter_dev, self._lr_t, opt.lr, opt.beta_1,
-                                       opt.beta_2, opt.epsilon, opt.decay, 1.0)
-                else:
-                    ops.sgd_keras(self.flat_params, self.opt_state[0], self.flat_grads, 0, opt.lr, opt.momentum, 0.0, 1.0)
+                outs, loss_vals, dys = body(gx, gys)
             except BaseException:
                 _lib.lib.dlwp_train_step_record_abort(h)
                 raise
@@ -1020,7 +1024,7 @@ class Trainer(object):
                 self._prep_cache.get(int(x.shape[0])), self._side, pool)
         ent = {'step': _StepHandle(step), 'x': gx, 'ys': gys, 'loss': loss_vals, 'keep': keep}
         if validate:
-            why = self._validate_step(ent, state0, outs, dys, form, dp is not None)
+            why = self._validate_step(ent, state0, body, form, dp is not None)
             if why is not None:
                 import warnings
                 warnings.warn('dlwp_amd: the recorded training step did not reproduce the eager step (%s); batches of %d samples '
@@ -1029,44 +1033,53 @@ class Trainer(object):
                 return {'refused': True, 'loss': loss_vals, 'why': why}
         return ent
 
-    def _validate_step(self, ent, state0, outs, dys, form, data_parallel=False):
-        """Replays the freshly recorded step from the state it started from and compares every result with the eager run's; returns
-        None when they agree, else what differed.  On disagreement the eager results are put back."""
+    def _validate_step(self, ent, state0, body, form, data_parallel=False):
+        """The freshly recorded step against the launch-by-launch step on a batch and weights neither has seen (see _record_step);
+        returns None when they agree, else what differed.  Leaves the state the recorded step left."""
         from . import _lib
         live = [self.flat_params] + list(self.opt_state) + [self._iter_dev]
         # (the loss table rides behind the gradients only in a data-parallel step: the recorded launches write it there)
         gbuf = self._flat_exchange if data_parallel else self.flat_grads
-        want = [t.clone() for t in live] + [gbuf.clone(), ent['loss'].clone()]
-        for t, t0 in zip(live, state0):
-            t.copy_(t0)
-        nan = float('nan')
-        gbuf.fill_(nan)
-        ent['loss'].fill_(nan)
-        for t in list(outs) + [d for d in dys if isinstance(d, torch.Tensor)]:
-            if isinstance(t, torch.Tensor) and t.is_floating_point():
-                t.fill_(nan)
-        lanes_mode = _lib.STEP_LANES if os.environ.get('DLWP_TRAIN_LANES') == 'own' else _lib.STEP_LANES_RECORDED
-        mode = {'lanes': lanes_mode, 'graph': _lib.STEP_GRAPH, 'branches': _lib.STEP_GRAPH_BRANCHES}.get(form, _lib.STEP_GRAPH)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = _lib.lib.dlwp_train_step_launch(ent['step'].h, None, mode, stream)      # (the inputs are in the step's buffers already)
+        after = [t.clone() for t in live] + [gbuf.clone(), ent['loss'].clone()]
+        xv = ent['x'] * 0.75 + 0.125
+        yvs = [t * 1.25 - 0.0625 for t in ent['ys']]
+
+        def start():
+            for t, t0 in zip(live, state0):
+                t.copy_(t0)
+            self.flat_params.mul_(1.0 + 2.0 ** -9)          # other weights: every prepared operand changes with them
         why = None
-        if rc != _lib.OK:
-            why = 'replay failed: ' + _lib.lib.dlwp_last_error().decode('utf-8', 'replace')
-        else:
-            torch.cuda.synchronize(self.device)
-            names = ['parameters'] + ['optimizer slot %d' % i for i in range(len(self.opt_state))] + ['step counter', 'gradients', 'loss table']
-            for name, got, ref in zip(names, live + [gbuf, ent['loss']], want):
-                if got.dtype.is_floating_point:
-                    bad = not bool(torch.isfinite(got).all()) if bool(torch.isfinite(ref).all()) else False
-                    tol = 1e-5 * float(ref.abs().max()) + 1e-30
-                    if bad or float((got - ref).abs().max()) > tol:
+        try:
+            start()
+            _, loss_e, _ = body(xv, yvs)
+            want = [t.clone() for t in live] + [gbuf.clone(), loss_e.clone()]
+            start()
+            ent['x'].copy_(xv)
+            for d_, s_ in zip(ent['ys'], yvs):
+                d_.copy_(s_)
+            lanes_mode = _lib.STEP_LANES if os.environ.get('DLWP_TRAIN_LANES') == 'own' else _lib.STEP_LANES_RECORDED
+            mode = {'lanes': lanes_mode, 'graph': _lib.STEP_GRAPH, 'branches': _lib.STEP_GRAPH_BRANCHES}.get(form, _lib.STEP_GRAPH)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            rc = _lib.lib.dlwp_train_step_launch(ent['step'].h, None, mode, stream)      # (the inputs are in the step's buffers)
+            if rc != _lib.OK:
+                why = 'replay failed: ' + _lib.lib.dlwp_last_error().decode('utf-8', 'replace')
+            else:
+                torch.cuda.synchronize(self.device)
+                names = ['parameters'] + ['optimizer slot %d' % i for i in range(len(self.opt_state))] + \
+                    ['step counter', 'gradients', 'loss table']
+                for name, got, ref in zip(names, live + [gbuf, ent['loss']], want):
+                    if got.dtype.is_floating_point:
+                        if not bool(torch.isfinite(got).all()) and bool(torch.isfinite(ref).all()):
+                            why = '%s are not finite' % name
+                            break
+                        if float((got - ref).abs().max()) > 1e-5 * float(ref.abs().max()) + 1e-30:
+                            why = '%s differ by %.3g of %.3g' % (name, float((got - ref).abs().max()), float(ref.abs().max()))
+                            break
+                    elif not torch.equal(got, ref):
                         why = '%s differ' % name
                         break
-                elif not torch.equal(got, ref):
-                    why = '%s differ' % name
-                    break
-        if why is not None:
-            for t, w in zip(live + [gbuf, ent['loss']], want):
+        finally:
+            for t, w in zip(live + [gbuf, ent['loss']], after):
                 t.copy_(w)
         return why
 

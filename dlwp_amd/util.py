@@ -195,25 +195,6 @@ class _PinnedPool(object):
 
 pinned_results = _PinnedPool()
 
-def copy2d_d2h_async(dst_host, src_dev, stream):
-    """dst_host[t, ...] <- src_dev[t, ...] for every leading index t as ONE strided device-to-host DMA (dlwp_copy2d_d2h_async:
-    hipMemcpy2DAsync on the runtime the library -- and torch -- are linked against): dst_host is a slice of a pinned array whose
-    rows are further apart than they are long -- a member chunk of a (T, N, ...) series -- src_dev is contiguous.  One descriptor
-    list for the copy engine instead of T separate copies (56 x 8 MB per chunk of a 14-day rollout: 37 GB/s effective; one strided
-    copy runs at the link rate).  Returns False when the shapes do not fit (the caller then copies row by row)."""
-    import ctypes
-    from . import _lib
-    t = int(src_dev.shape[0])
-    row_elems = int(src_dev[0].numel())
-    if not (src_dev.is_contiguous() and dst_host[0].is_contiguous() and dst_host.shape == src_dev.shape and t > 0):
-        return False
-    width = row_elems * src_dev.element_size()
-    dpitch = int(dst_host.stride(0)) * dst_host.element_size()
-    rc = _lib.lib.dlwp_copy2d_d2h_async(ctypes.c_void_p(dst_host.data_ptr()), dpitch, ctypes.c_void_p(src_dev.data_ptr()), width, t,
-                                        ctypes.c_void_p(stream.cuda_stream))
-    return rc == 0
-
-
 def host_result_buffer(shape):
     """float32 host tensor for results copied back from the device: page-locked (asynchronous DMA on a copy stream) when
     the host allows it, pageable otherwise (the copies then simply run synchronously)."""

@@ -561,17 +561,6 @@ int dlwp_rollout_destroy(dlwp_rollout_t);
  *      Host memory only; no device work, no handle.                                                                          */
 int dlwp_host_gather_rows(void* dst, const void* src, const long long* rows, long long n_rows, size_t row_bytes,
                           long long src_rows, int threads);
-/* ---- a predict_timeseries series going home (DLWP/model/models.py:270, 294-301 return a host ndarray, time first): rows x width
- *      bytes from device memory into the page-locked result array, destination rows dst_pitch bytes apart.
- *      dlwp_copy2d_d2h_async: ONE strided copy-engine transfer, source contiguous.  dlwp_store2d_to_host: the same (and the
- *      strided-source form: the sample <-> time transposition of a merged series) as a KERNEL of `blocks` workgroups (0: 16)
- *      storing 16-byte units straight into the device-mapped pinned array -- few workgroups, link-bound, runs beside the next
- *      model call of the rollout.  width, pitches and addresses: multiples of 16 bytes.                                        */
-int dlwp_copy2d_d2h_async(void* dst_pinned_host, size_t dst_pitch, const void* src_device, size_t width, size_t rows,
-                          void* stream);
-int dlwp_store2d_to_host(dlwp_handle_t, void* dst_pinned_host, size_t dst_pitch, const void* src_device, size_t src_pitch,
-                         size_t width, size_t rows, int blocks, void* stream);
-
 /* ---- the training step as a library object: replaces the per-step Python launch loop behind keras Model.train_on_batch as
  *      DLWPNeuralNet.fit / fit_generator drive it (DLWP/model/models.py:188-228; examples/train.py:262-263).
  *      A model's step is ~30 launches through this ABI.  Between dlwp_train_step_record_begin and dlwp_train_step_create every

@@ -165,11 +165,10 @@ def test_predict_timeseries_graph_equals_host_loop_and_tracks_the_oracle():
     assert np.array_equal(seq[0], d.predict(x).reshape(5, 2, 2, 16, 24)[:, 0])
 
 
-def test_predict_timeseries_pipelined_host_copy_is_bit_identical(monkeypatch):
+def test_predict_timeseries_pipelined_host_copy_is_bit_identical():
     """A large series goes back to the host slot by slot WHILE the rollout runs (DLWPNeuralNet._rollout_streamed: one graph per
     model call, copy streams, one pinned result array; r5): same bits as the one-graph rollout with a single copy behind it, for
-    both output layouts, both transfer forms (copy engine / store kernel), member chunks in the first call (host predictors) or
-    not (7 members: no even cut; device predictors)."""
+    both output layouts, member chunks in the first call (host predictors) or not (7 members: no even cut; device predictors)."""
     import torch
     rng = np.random.default_rng(5)
     cs = (4, 16, 24)
@@ -182,19 +181,16 @@ def test_predict_timeseries_pipelined_host_copy_is_bit_identical(monkeypatch):
         whole_kept = d.predict_timeseries(x, 6, keep_time_dim=True)
         d.host_stream_bytes = 0                     # always streamed
         try:
-            for mode in ('dma', 'kernel'):
-                monkeypatch.setenv('DLWP_D2H', mode)
-                for _ in range(2):                  # (the second call reuses the cached graphs, staging buffers and streams)
-                    assert np.array_equal(d.predict_timeseries(x, 6), whole), (n, mode)
-                    assert np.array_equal(d.predict_timeseries(x, 6, keep_time_dim=True), whole_kept), (n, mode)
-                assert np.array_equal(d.predict_timeseries(torch.from_numpy(x).cuda(), 6), whole), (n, mode)
+            for _ in range(2):                  # (the second call reuses the cached graphs, staging buffers and streams)
+                assert np.array_equal(d.predict_timeseries(x, 6), whole), n
+                assert np.array_equal(d.predict_timeseries(x, 6, keep_time_dim=True), whole_kept), n
+            assert np.array_equal(d.predict_timeseries(torch.from_numpy(x).cuda(), 6), whole), n
             sr = d.model.streamed_rollout(n, 3, d.host_head_chunks)
             assert len(sr.head) == (4 if n == 8 else 1) and len(sr.tail) == 2
             dev = d.predict_timeseries(x, 6, return_device=True)
             assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), whole)
         finally:
             d.host_stream_bytes = 64 << 20
-    monkeypatch.delenv('DLWP_D2H')
 
 
 @pytest.mark.parametrize('n', [1031, 2101])

@@ -165,18 +165,19 @@ def test_rule_splits_long_chains_on_tiny_grids_only(ops):
     else: from 4 members of the 88 x 180 grid on, and for every layer of at most 88 input channels, a sample's bits do not depend on
     its batch size at all"""
     cd4 = ops.make_conv(64, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH, src_mode=1)       # layer 4: 128 -> 64, up-sampled
-    assert ops.conv_split_count((1, 128, 22, 45), cd4) == 3
-    assert ops.conv_split_count((2, 128, 22, 45), cd4) == 3
-    for n in (4, 8, 64, 256, 1024):
-        assert ops.conv_split_count((n, 128, 22, 45), cd4) == 1
-    cd3 = ops.make_conv(128, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)                    # layer 3: 8 chunks
-    for n in (1, 2, 8, 256):
-        assert ops.conv_split_count((n, 64, 22, 45), cd3) == 1
-    cd1 = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH, out_pool=True)     # 4 input channels: one chunk
-    assert ops.conv_split_count((1, 4, 88, 180), cd1) == 1
-    prev = ops.set_splitk(0)
+    assert ops.conv_split_count((1, 128, 22, 45), cd4) == 1          # r5: OFF unless asked for (batch-invariant bits by default)
+    prev = ops.set_splitk(1)
+    assert prev == 0
     try:
-        assert ops.conv_split_count((1, 128, 22, 45), cd4) == 1
+        assert ops.conv_split_count((1, 128, 22, 45), cd4) == 3
+        assert ops.conv_split_count((2, 128, 22, 45), cd4) == 3
+        for n in (4, 8, 64, 256, 1024):
+            assert ops.conv_split_count((n, 128, 22, 45), cd4) == 1
+        cd3 = ops.make_conv(128, 3, 3, 1, ops.make_pad(1, 1, 1, 1, 0, 1), ops.ACT_TANH)                    # layer 3: 8 chunks
+        for n in (1, 2, 8, 256):
+            assert ops.conv_split_count((n, 64, 22, 45), cd3) == 1
+        cd1 = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH, out_pool=True)     # 4 input channels: one chunk
+        assert ops.conv_split_count((1, 4, 88, 180), cd1) == 1
     finally:
         ops.set_splitk(prev)
 
