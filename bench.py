@@ -589,6 +589,83 @@ def _time_all_reduce(tr, world, barrier, dev, reps=50):
     return 1e3 * dt / reps
 
 
+def sub_pad_hbm(members):
+    """north_star: 'rocprof HBM GB/s reported for the padding kernels'.  The standalone PeriodicPadding2D + ZeroPadding2D kernel
+    (dlwp_pad2d_fwd / _bwd, csrc/halo.hip; DLWP/custom.py:197-204 + keras ZeroPadding2D) on the six composite halos of one
+    config-2 forward at this member count: ALGORITHMIC bytes (in + out) / HIP-event time, as a fraction of the 8 TB/s HBM peak.
+    (The product's forward never launches these -- every halo is fused into a convolution's loader; they serve layer stacks
+    nothing fuses and the TFPadding2D / FillPadding2D modes.)  `counters`: HBM bytes from the rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of tools/profile_pads.sh on THIS kernel source (profiles/r5_pad_pool_hbm.json), when there is one."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+    import bench_pad
+    rows = bench_pad.measure(members, 10, pads_only=True)
+    out = {'rows': [{'kernel': r['kernel'], 'shape': r['shape'], 'halo': r['halo'], 'ms': round(r['ms'], 4), 'gbs': round(r['gbs'], 1),
+                     'hbm_frac': round(r['gbs'] / PEAK_HBM_GBS, 3)} for r in rows],
+           'unit': 'GB/s, algorithmic bytes (in + out) / HIP-event time', 'peak_gbs': PEAK_HBM_GBS}
+    out['min_hbm_frac'] = min(r['hbm_frac'] for r in out['rows'])
+    try:
+        prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r5_pad_pool_hbm.json')))
+        if prof.get('_meta', {}).get('source_sha') == kernel_source_hash():
+            out['counters'] = [{'kernel': r['kernel'], 'shape': r['shape'], 'traffic_over_algorithmic': round(r['traffic_over_algorithmic'], 3),
+                                'hbm_gbs_from_counters': round(r['hbm_gbs_from_counters'], 1)}
+                               for r in prof['rows'] if r['kernel'].startswith('pad2d') and 'traffic_over_algorithmic' in r]
+        else:
+            out['counters'] = 'profiles/r5_pad_pool_hbm.json was taken on another kernel source'
+    except Exception:  # noqa: BLE001
+        out['counters'] = None
+    return out
+
+
+def _compare_exchanges(tr, world, rank, barrier, dev, reps=50):
+    """Both transports of the step's exchange on the SAME buffer, once for the sums and `reps` times for the latency: RCCL (the
+    default) and the library's own one-shot all-reduce (csrc/xchg.hip, DLWP_ALLREDUCE=oneshot: peer-mapped uncached regions,
+    rank-order sum).  The first multi-GPU run of this script thereby yields the comparison -- equal sums, both latencies -- instead
+    of a hang or a silently wrong sum: a one-shot launch that waits 2 s for a peer gives up, dlwp_xchg_status reports it, and the
+    record says so (the training records above always ran on RCCL).  Collective: every rank calls it."""
+    out = {}
+    try:
+        n = int(tr._flat_exchange.numel())
+        # small integers: every partial sum is exact in float32, whatever the order a transport adds in
+        base = (torch.arange(n, device=dev, dtype=torch.float32) % 251.0) + float(rank + 1)
+        a = base.clone()
+        tr.dp.all_reduce_sum_(a)
+        torch.cuda.synchronize()
+        want = ((torch.arange(n, device=dev, dtype=torch.float32) % 251.0) * world + world * (world + 1) / 2.0)
+        out['rccl_sum_exact'] = bool(torch.equal(a, want))
+        prev = os.environ.get('DLWP_ALLREDUCE')
+        os.environ['DLWP_ALLREDUCE'] = 'oneshot'
+        try:
+            if not tr.dp.wants_oneshot(base):
+                out['oneshot'] = 'not available for this buffer / world size'
+                return out
+            b = base.clone()
+            tr.dp.oneshot_all_reduce_(b)
+            torch.cuda.synchronize()
+            if tr.dp.oneshot_timed_out():
+                out['oneshot'] = 'TIMED OUT waiting for a peer (dlwp_xchg_status): RCCL stays the transport'
+                return out
+            out['oneshot_sum_exact'] = bool(torch.equal(b, want))
+            out['equal_sums'] = bool(torch.equal(a, b))
+            out['oneshot_region'] = tr.dp.oneshot_info()
+            for _ in range(5):
+                tr.dp.oneshot_all_reduce_(b)
+            dt = _sync_time(lambda: tr.dp.oneshot_all_reduce_(b), reps, barrier, world, dev)
+            out['oneshot_ms'] = 1e3 * dt / reps
+            out['oneshot_timed_out'] = bool(tr.dp.oneshot_timed_out())
+            for _ in range(5):
+                tr.dp.all_reduce_sum_(a)
+            dt = _sync_time(lambda: tr.dp.all_reduce_sum_(a), reps, barrier, world, dev)
+            out['rccl_ms'] = 1e3 * dt / reps
+        finally:
+            if prev is None:
+                os.environ.pop('DLWP_ALLREDUCE', None)
+            else:
+                os.environ['DLWP_ALLREDUCE'] = prev
+    except Exception as e:  # noqa: BLE001  (the comparison must never take the bench line down)
+        out['error'] = repr(e)[:300]
+    return out
+
+
 def sub_train(grid, cin, world, rank, barrier, dev, per_gpu_batch=64, steps=20, warmup=40, share_of=8):
     """BASELINE config 3: the same U-Net, training ('mse', Adam), data parallel over the ranks -- each rank trains on its rows of
     the global batch, one all-reduce of the flat gradient buffer per step (RCCL through dlwp_allreduce_sum_f32).  Both conventions
@@ -636,6 +713,7 @@ def sub_train(grid, cin, world, rank, barrier, dev, per_gpu_batch=64, steps=20, 
     if ar_ms is not None:
         rec['all_reduce_ms_measured'] = ar_ms
         rec['all_reduce_bytes'] = int(tr._flat_exchange.numel()) * 4
+        rec['exchange_check'] = _compare_exchanges(tr, world, rank, barrier, dev)
     if world > 1:
         weak, _, _ = run(per_gpu_batch * world, 'weak')
         weak['convention'] = 'reference: batch_size = n_gpu * batch_size (Azure/train_tf.py:163-164)'
@@ -935,6 +1013,7 @@ def main():
                 if grid == (88, 180) and a.channels == 4:
                     sub['layer1_at_91x180'] = sub_layer1_nominal(net, m_local)
                 if world == 1:
+                    sub['pad_hbm'] = sub_pad_hbm(m_local)
                     sub['recurrent_cfg4_bf16'] = sub_cfg4()
                     sub['row_connected_output_layer'] = sub_row_connected(grid, a.channels, m_local, a.forwards)
             except Exception as e:  # noqa: BLE001  (a sub-record must never cost the headline line)
@@ -960,6 +1039,18 @@ def main():
             sub['error_collective'] = repr(e)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(grid, a.channels, a.forwards, weights_np)
+    # what the stream probes of every rank found (util.distinct_streams: side streams of the training step, the loader's and the
+    # rollout's copy streams): candidates passed over because they shared a hardware queue, streams that had to share one anyway
+    from dlwp_amd import util as _util
+    probes = list(_util.probe_log)
+    if world > 1 and 'error_collective' not in out.get('sub_records', {}):
+        try:
+            box = [None] * world
+            torch.distributed.all_gather_object(box, probes)
+            probes = box
+        except Exception as e:  # noqa: BLE001
+            probes = {'error': repr(e)[:200], 'rank0': probes}
+    out['stream_probes'] = probes
     emit()
     if world > 1 and 'error_collective' in out.get('sub_records', {}):
         os._exit(0)                  # a rank may be gone: no barrier to wait in

@@ -197,6 +197,17 @@ def test_bench_gpus_2_as_a_plain_script_prints_one_line_with_the_collective_sub_
     assert tr['global_batch'] == 64 and tr['batch_per_gpu'] == 32 and tr['value'] > 0 and np.isfinite(tr['loss'])
     assert ens['total_members'] == 32 and ens['members_per_gpu'] == 16 and ens['finite'] and 0 < ens['frac'] < 1
     assert 0 < sub['members_1']['frac'] < sub['members_8']['frac'] < 1
+    # r5: both transports of the step's exchange were run on the same buffer -- torch.distributed / RCCL and the
+    # library's one-shot all-reduce (two processes on the one GPU here) --, the sums are exact and equal, both latencies are there,
+    # the one-shot region sits in uncached (or fine-grained) memory, no launch timed out; and every rank reports its stream probes
+    ex = tr['exchange_check']
+    assert 'error' not in ex, ex
+    assert ex['rccl_sum_exact'] and ex['oneshot_sum_exact'] and ex['equal_sums'] and not ex['oneshot_timed_out'], ex
+    assert ex['oneshot_ms'] > 0 and ex['rccl_ms'] > 0 and ex['oneshot_region']['memory'] in ('uncached', 'fine-grained', 'plain')
+    assert ex['oneshot_region']['blocks'] >= 1
+    probes = rec['stream_probes']
+    assert isinstance(probes, list) and len(probes) == 2 and all(isinstance(p_, list) for p_ in probes), probes
+    assert any('rejected' in e for p_ in probes for e in p_), probes
     # the same total under --scaling strong
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
                         '--members', '16', '--scaling', 'strong', '--no-cpu-baseline', '--no-extras'], env=env,
@@ -265,7 +276,19 @@ def _xchg_worker(rank, world, port, ret):
         dp.oneshot_all_reduce_(flat)
         outs.append(flat.cpu().numpy())
     torch.cuda.synchronize()
-    ret[rank] = {'outs': outs, 'timed_out': dp.oneshot_timed_out()}
+    info = dp.oneshot_info()
+    timed_out = dp.oneshot_timed_out()
+    # r5: a buffer far above what r4's one-workgroup-per-1024-floats grid could keep resident (~2 M floats: every launch
+    # timed out beyond that) -- the persistent grid walks it; a new size means a new region (created collectively)
+    big_n = 6 * 1024 * 1024
+    big_ok = []
+    for step in range(3):
+        flat = (torch.arange(big_n, dtype=torch.float32) % 509.0 + float(10 * step + rank)).cuda()
+        dp.oneshot_all_reduce_(flat)
+        want = (torch.arange(big_n, dtype=torch.float32) % 509.0) * 2 + float(20 * step + 1)
+        big_ok.append(bool(torch.equal(flat.cpu(), want)))
+    ret[rank] = {'outs': outs, 'timed_out': timed_out, 'info': info, 'big_ok': big_ok, 'big_timed_out': dp.oneshot_timed_out(),
+                 'big_info': dp.oneshot_info()}
     torch.distributed.barrier()
     dp.close()
     torch.distributed.destroy_process_group()
@@ -289,8 +312,67 @@ def test_one_shot_all_reduce_sums_in_rank_order_on_every_rank():
             assert p.exitcode == 0
         res = dict(ret)
     assert not res[0]['timed_out'] and not res[1]['timed_out']
+    for r in range(2):
+        assert res[r]['info']['memory'] in ('uncached', 'fine-grained', 'plain') and 1 <= res[r]['info']['blocks'] <= 256, res[r]['info']
+        assert res[r]['big_ok'] == [True, True, True] and not res[r]['big_timed_out'], (res[r]['big_ok'], res[r]['big_timed_out'])
+        assert res[r]['big_info']['blocks'] >= 128          # one workgroup per CU, whatever the size
+    print('one-shot exchange region memory:', res[0]['info'], res[0]['big_info'])
     for step in range(5):
         want = (torch.randn(189024, generator=torch.Generator().manual_seed(100 * step)) +
                 torch.randn(189024, generator=torch.Generator().manual_seed(100 * step + 1))).numpy()
         assert np.array_equal(res[0]['outs'][step], res[1]['outs'][step])
         assert np.array_equal(res[0]['outs'][step], want)
+
+
+def _xchg_timeout_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DLWP_SHARE_GPUS='1', DLWP_DIST_BACKEND='gloo', DLWP_ALLREDUCE='oneshot')
+    import time
+    from dlwp_amd import parallel
+    parallel.init()
+    dp = parallel.DataParallel()
+    n, n_par = 4096, 4000
+    flat = torch.ones(n).cuda()
+    dp.xchg(flat)                                  # (collective: both ranks create and connect their regions)
+    if rank == 0:                                  # ... and then only rank 0 shows up for the step
+        p, m, v = torch.full((n_par,), 3.0).cuda(), torch.zeros(n_par).cuda(), torch.zeros(n_par).cuda()
+        t0 = time.time()
+        dp.oneshot_adam_(flat, n_par, p, m, v, 1e-3, 0.9, 0.999, 1e-7, 0.0, 0, 0.5)
+        torch.cuda.synchronize()
+        took = time.time() - t0
+        raised = False
+        try:
+            dp.oneshot_check()
+        except RuntimeError:
+            raised = True
+        ret[0] = {'took': took, 'timed_out': dp.oneshot_timed_out(), 'raised': raised,
+                  'p_untouched': bool((p == 3.0).all()), 'm_untouched': bool((m == 0).all()),
+                  'tail_nan': bool(torch.isnan(flat[n_par:]).all()), 'grads_kept': bool((flat[:n_par] == 1.0).all())}
+    else:
+        time.sleep(0.5)
+    torch.distributed.barrier()
+    dp.close()
+    torch.distributed.destroy_process_group()
+
+
+def test_one_shot_exchange_that_waits_in_vain_gives_up_leaves_the_parameters_alone_and_is_reported():
+    """a peer that never arrives.  The launch waits 2 s (bounded: never a hung GPU), then leaves p / m / v untouched,
+    writes NaN over the loss table behind the parameters, and dlwp_xchg_status / DataParallel.oneshot_check report it -- the
+    trainer calls oneshot_check wherever it reads a loss, so training never continues on a half-applied step."""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_xchg_timeout_worker, args=(r, 2, port, ret)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            if p.is_alive():
+                p.kill()
+                pytest.fail('worker hung')
+            assert p.exitcode == 0
+        res = dict(ret)[0]
+    assert 1.5 < res['took'] < 10.0, res
+    assert res['timed_out'] and res['raised'] and res['p_untouched'] and res['m_untouched'] and res['tail_nan'] and res['grads_kept'], res
