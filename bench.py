@@ -567,15 +567,17 @@ def sub_row_connected(grid, cin, members, forwards):
 
 def _train_exec_frac(batch):
     """Executed matrix-core FLOPs of one training step of `batch` samples per GPU, from the committed rocprofv3 --pmc SQ_INSTS_MFMA
-    pass of tools/bench_train.py (profiles/r4_train_mfma_b<batch>.json) -- quoted only when it was taken on THIS kernel source."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r4_train_mfma_b%d.json' % batch)
-    try:
-        d = json.load(open(path))
-    except Exception:  # noqa: BLE001
-        return None
-    if d.get('_meta', {}).get('source_sha') != kernel_source_hash():
-        return None
-    return d.get('mfma_per_step')
+    pass of tools/bench_train.py (profiles/r*_train_mfma_b<batch>.json) -- quoted only when it was taken on THIS kernel source."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, 'profiles', 'r*_train_mfma_b%d.json' % batch)), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get('_meta', {}).get('source_sha') == kernel_source_hash():
+            return d.get('mfma_per_step')
+    return None
 
 
 def _time_all_reduce(tr, world, barrier, dev, reps=50):
@@ -701,7 +703,7 @@ def sub_train(grid, cin, world, rank, barrier, dev, per_gpu_batch=64, steps=20, 
     rec['frac_definition'] = ('algorithmic_frac: ALGORITHMIC FLOPs of the step (3 x the direct-convolution count of the forward: '
                               'forward, data and weight gradients) / wall / 157.3 TFLOP/s -- the Winograd forward and weight-gradient '
                               'kernels execute fewer multiplies than that count; executed_frac: SQ_INSTS_MFMA x 2048 of the step '
-                              '(rocprofv3 --pmc pass of tools/bench_train.py on this kernel source, profiles/r4_train_mfma_b*.json) '
+                              '(rocprofv3 --pmc pass of tools/bench_train.py on this kernel source, profiles/r*_train_mfma_b*.json) '
                               '/ wall / 157.3 TFLOP/s')
     rec['step_forms'] = ("'graph' / 'lanes' / 'branches': the step replayed by the library (dlwp_train_step_launch: one hipGraph / "
                          "launch by launch over the recorded lanes / one hipGraph with the lanes as branches); 'python': launch by "

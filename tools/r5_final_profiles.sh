@@ -1,0 +1,61 @@
+#!/bin/bash
+# round-5 final measurements on ONE box: the GPU suite (first run on the box), rocprofv3 kernel stats + PMC passes of the bench command,
+# config 4, config 5 at 4 members, 8 members of config 2, the training step (kernel stats + executed MFMA instructions), the bench line.
+# Everything lands in gpurun_out/prof (copy what should be judged into profiles/).
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof; mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+if [ "$1" != "--no-tests" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q > $O/r5_pytest.log 2>&1; echo "pytest rc=$? $(grep -E 'passed|failed' $O/r5_pytest.log | tail -1)"
+  cp gpurun_out/forward_errors.json $O/r5_forward_errors.json 2>/dev/null
+fi
+bash tools/profile_bench.sh r5 > $O/r5_profile_bench.log 2>&1; tail -30 $O/r5_profile_bench.log | cut -c1-200
+bash tools/profile_cfg4.sh r5 8 > $O/r5_profile_cfg4.log 2>&1; tail -12 $O/r5_profile_cfg4.log | cut -c1-200
+cd /tmp
+for b in 64 8; do
+  rocprofv3 --kernel-trace --stats -d $O/tr$b -o s --output-format csv -- python $R/tools/bench_train.py --batch $b --steps 40 --warmup 10 > $O/r5_train_b$b.json 2> $O/tr$b.err
+  cp $(find $O/tr$b -name '*kernel_stats.csv' | head -1) $O/r5_train_b${b}_kernel_stats.csv
+  rm -rf $O/tr$b
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA -d $O/trm$b -o p --output-format csv -- python $R/tools/bench_train.py --batch $b --steps 20 --warmup 10 > /dev/null 2> $O/trm$b.err
+  python $R/tools/parse_train_mfma.py $O/r5_train_mfma_b$b.json $O/trm$b --batch $b --steps 30
+  rm -rf $O/trm$b
+done
+# config 5 (1-degree grid, 12 channels) at 4 members = one GPU's share of 32 members on 8; config 2 at 8 members
+rocprofv3 --kernel-trace --stats -d $O/c5 -o s --output-format csv -- python $R/bench.py --grid 180x360 --channels 12 --members 4 --forwards 40 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/r5_bench_cfg5_m4.json 2> $O/c5.err
+cp $(find $O/c5 -name '*kernel_stats.csv' | head -1) $O/r5_cfg5_m4_kernel_stats.csv; rm -rf $O/c5
+rocprofv3 --kernel-trace --stats -d $O/c2 -o s --output-format csv -- python $R/bench.py --members 8 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/r5_bench_cfg2_m8.json 2> $O/c2.err
+cp $(find $O/c2 -name '*kernel_stats.csv' | head -1) $O/r5_cfg2_m8_kernel_stats.csv; rm -rf $O/c2
+cd $R
+for b in 64 8; do python tools/bench_train.py --batch $b --steps 40 --warmup 20 > $O/r5_train_b${b}_noprof.json 2>/dev/null; tail -1 $O/r5_train_b${b}_noprof.json | cut -c1-300; done
+python tools/bench_layer6.py > $O/r5_layer6.json 2>/dev/null; cat $O/r5_layer6.json
+# the bench line quotes the rocprofv3 / PMC summaries of THIS kernel source from profiles/: put the fresh ones there first
+for f in r5_kernel_stats.csv r5_kernel_stats.meta.json r5_hbm_traffic_b256.json r5_mfma_busy.json r5_train_mfma_b64.json r5_train_mfma_b8.json; do cp $O/$f $R/profiles/$f; done
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/cfg4_stats $O/cfg4_fetch $O/cfg4_write
+# the padding kernels: HIP-event rates + rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (north_star: HBM GB/s of the padding kernels)
+cd $R
+bash tools/profile_pads.sh r5 > $O/r5_profile_pads.log 2>&1; tail -3 $O/r5_profile_pads.log | cut -c1-200
+for f in r5_pad_pool_hbm.json r5_pad_pool_kernel_stats.csv; do cp $O/$f $R/profiles/$f 2>/dev/null; done
+# the host-visible rollout with a memory-copy trace: the series leaves through the copy engines (SDMA), not through blit kernels
+cd /tmp
+rocprofv3 --kernel-trace --memory-copy-trace --stats -d $O/hv -o s --output-format csv -- python $R/tools/bench_host_rollout.py --reps 2 > $O/r5_host_visible.json 2> $O/hv.err
+python - <<PY > $O/r5_host_visible_copies.txt
+import csv, glob, collections
+f = glob.glob("$O/hv/**/*memory_copy_trace.csv", recursive=True)
+rows = list(csv.DictReader(open(f[0]))) if f else []
+by = collections.Counter()
+byt = collections.Counter()
+for r in rows:
+    k = r.get('Direction') or r.get('Kind') or '?'
+    by[k] += 1
+    byt[k] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+print('memory copies by direction (count, total ms):', {k: (by[k], round(byt[k] / 1e6, 2)) for k in by})
+big = [r for r in rows if int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 500000]
+print('copies over 0.5 ms:', len(big), 'of', len(rows))
+ks = glob.glob("$O/hv/**/*kernel_stats.csv", recursive=True)
+if ks:
+    names = [r['Name'] for r in csv.DictReader(open(ks[0]))]
+    print('blit / copy kernels in the kernel trace:', [n for n in names if 'copyBuffer' in n or 'blit' in n.lower()][:6])
+PY
+cat $O/r5_host_visible_copies.txt; rm -rf $O/hv
+timeout 900 python bench.py > $O/r5_bench.json 2> $O/r5_bench.err; echo "bench (with pad counters) rc=$?"; tail -1 $O/r5_bench.json | cut -c1-300
