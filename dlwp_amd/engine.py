@@ -487,7 +487,7 @@ class Executor(object):
 
     def make_streamed_rollout(self, n, calls, head_chunks=1):
         """The rollout as TIME SLICES (StreamedRollout): one graph per model call, launched one behind the other, so that the
-        caller can hand a finished forecast slot to the copy engine while the next call runs.  The first call is cut into
+        caller can start a finished forecast slot's copy to the host while the next call runs.  The first call is cut into
         `head_chunks` member chunks (graphs with activation buffers of their own) so that it can start on the first chunk of an
         input that is still being uploaded.  Same kernels on the same data as the one-graph rollout: the same bits."""
         n, calls, head_chunks = int(n), int(calls), max(1, int(head_chunks))

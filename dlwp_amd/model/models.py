@@ -96,11 +96,16 @@ class _Wrapper(object):
         The rollout is one hipGraph PER MODEL CALL (engine.StreamedRollout), all members in each, launched back to back on the
         main stream; behind call j an event, and on a copy stream (two, alternating; hardware queues of their own) the slots call j
         wrote leave for ONE page-locked result array laid out as the reference returns it (time first) under call j + 1:
-        keep_time_dim: one 1-D copy-engine transfer straight from the series slot; otherwise the sample <-> time transposition of
-        the slot into a staging buffer (dlwp_series_merge_time, ~25 us) and ONE contiguous transfer of both time steps.
-        (r5 also built the transfer as a store kernel writing the mapped result array, transposition folded in: 55-58 GB/s alone,
-        like the copy engine's 56.7 -- but beside the rollout it took the 34.6 ms rollout to 50.9-53.4 ms, at 8, 16 or 32
-        workgroups, where copy-engine transfers leave it at 34.6: profiles/r5_d2h_forms.json.  Removed.)
+        keep_time_dim: one contiguous asynchronous copy (hipMemcpyAsync) straight from the series slot; otherwise the sample <->
+        time transposition of the slot into a staging buffer (dlwp_series_merge_time, ~25 us) and ONE contiguous copy of both
+        time steps.  What the runtime does with such a copy on this ROCm (rocprofv3 --memory-copy-trace,
+        profiles/r5_host_visible_copies.txt): NOT a copy-engine (SDMA) transfer -- uploads are, downloads into page-locked memory
+        run as the runtime's blit kernel, `__amd_rocclr_copyBuffer`, 1.0 ms per 65 MB slot = 56 GB/s, and no switch of the
+        runtime moves them (GPU_FORCE_BLIT_COPY_SIZE=0, DEBUG_CLR_LIMIT_BLIT_WG: same trace, same rate).  It shares the chip
+        gracefully: the 34.6 ms rollout stays 34.6 ms beside 1 GB of such copies, where r5's own store kernel (a few workgroups
+        writing the mapped result array, transposition folded in; 55-58 GB/s alone) took it to 50.9-53.4 ms at 8, 16 or 32
+        workgroups (profiles/r5_d2h_forms.json) -- removed.  The rollout is now LINK-bound: 1.82 GB leave in ~34.5 ms = 52.7 GB/s
+        of the 56.7 GB/s a lone copy reaches on this box.
         The pipeline's fill is one model call and its drain one slot's transfer (r4's member chunks: a quarter of the rollout
         each).  Host predictors: call 0 is cut into member chunks, chunk c + 1 is gathered into page-locked staging by the
         library's host threads and uploaded while chunk c computes.  Same kernels on the same data as the one-graph rollout:

@@ -17,7 +17,7 @@ for b in 64 8; do
   rocprofv3 --kernel-trace --stats -d $O/tr$b -o s --output-format csv -- python $R/tools/bench_train.py --batch $b --steps 40 --warmup 10 > $O/r5_train_b$b.json 2> $O/tr$b.err
   cp $(find $O/tr$b -name '*kernel_stats.csv' | head -1) $O/r5_train_b${b}_kernel_stats.csv
   rm -rf $O/tr$b
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA -d $O/trm$b -o p --output-format csv -- python $R/tools/bench_train.py --batch $b --steps 20 --warmup 10 > /dev/null 2> $O/trm$b.err
+  DLWP_TAPE_VALIDATE=0 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA -d $O/trm$b -o p --output-format csv -- python $R/tools/bench_train.py --batch $b --steps 20 --warmup 10 > /dev/null 2> $O/trm$b.err
   python $R/tools/parse_train_mfma.py $O/r5_train_mfma_b$b.json $O/trm$b --batch $b --steps 30
   rm -rf $O/trm$b
 done
@@ -39,23 +39,7 @@ for f in r5_pad_pool_hbm.json r5_pad_pool_kernel_stats.csv; do cp $O/$f $R/profi
 # the host-visible rollout with a memory-copy trace: the series leaves through the copy engines (SDMA), not through blit kernels
 cd /tmp
 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $O/hv -o s --output-format csv -- python $R/tools/bench_host_rollout.py --reps 2 > $O/r5_host_visible.json 2> $O/hv.err
-python - <<PY > $O/r5_host_visible_copies.txt
-import csv, glob, collections
-f = glob.glob("$O/hv/**/*memory_copy_trace.csv", recursive=True)
-rows = list(csv.DictReader(open(f[0]))) if f else []
-by = collections.Counter()
-byt = collections.Counter()
-for r in rows:
-    k = r.get('Direction') or r.get('Kind') or '?'
-    by[k] += 1
-    byt[k] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
-print('memory copies by direction (count, total ms):', {k: (by[k], round(byt[k] / 1e6, 2)) for k in by})
-big = [r for r in rows if int(r['End_Timestamp']) - int(r['Start_Timestamp']) > 500000]
-print('copies over 0.5 ms:', len(big), 'of', len(rows))
-ks = glob.glob("$O/hv/**/*kernel_stats.csv", recursive=True)
-if ks:
-    names = [r['Name'] for r in csv.DictReader(open(ks[0]))]
-    print('blit / copy kernels in the kernel trace:', [n for n in names if 'copyBuffer' in n or 'blit' in n.lower()][:6])
-PY
+python $R/tools/trace_copies.py $O/hv > $O/r5_host_visible_copies.txt 2>&1
 cat $O/r5_host_visible_copies.txt; rm -rf $O/hv
+cd $R
 timeout 900 python bench.py > $O/r5_bench.json 2> $O/r5_bench.err; echo "bench (with pad counters) rc=$?"; tail -1 $O/r5_bench.json | cut -c1-300
