@@ -1017,6 +1017,7 @@ def main():
                 if world == 1:
                     sub['pad_hbm'] = sub_pad_hbm(m_local)
                     sub['recurrent_cfg4_bf16'] = sub_cfg4()
+                    sub['recurrent_cfg4_bf16_m32'] = sub_cfg4(members=32)     # a member count that fills the chip (config 5's)
                     sub['row_connected_output_layer'] = sub_row_connected(grid, a.channels, m_local, a.forwards)
             except Exception as e:  # noqa: BLE001  (a sub-record must never cost the headline line)
                 sub['error_local'] = repr(e)

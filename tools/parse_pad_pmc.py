@@ -13,7 +13,7 @@ import json
 import os
 import sys
 
-SYMBOL = {'pad2d_fwd': 'pad2d_fwd_kernel', 'pad2d_bwd': 'pad2d_bwd', 'maxpool2_fwd': 'maxpool2_fwd_kernel',
+SYMBOL = {'pad2d_fwd': 'pad2d_fwd_', 'pad2d_bwd': 'pad2d_bwd', 'maxpool2_fwd': 'maxpool2_fwd_kernel',
           'upsample2_fwd': 'upsample2_fwd', 'series_merge_time': 'copy_runs_kernel'}
 
 
