@@ -321,6 +321,44 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
     // ---- tile quads: lane (ci | co = lane & 15, tile k = lane >> 4 of the quad) transforms its own patches.  The signs of
     //      A dY A^T (row 3 and column 3 are negated) are left to the slab epilogue: position (i, j) accumulates s_i s_j times
     //      its true value, s = (1, 1, 1, -1) -- no negations in the loop, the same bits (products and sums are sign-symmetric)
+    // r5: the quad loop is software-pipelined over its LDS reads -- the raw 4 x 4 input patch and the two dz rows of quad q + 1 are
+    // requested between the transforms of quad q and its MFMAs and land under them (16 NT MFMAs = 512 NT cycles against an LDS
+    // latency of ~130).  Before, every quad began with its own reads and the two waves of a SIMD could not cover them: the quad
+    // phase ran at 38 % matrix occupancy (2.7 k cycles per quad for 2 x 512 of MFMA, profiles/r3_wgrad_cb_phase_timing.txt).  The
+    // patch registers are dead once the transforms are through, so the next quad's reads cost the dz pairs only (4 NT registers).
+    f32x2 dq[2][4][2], zq[2][C::NT][2];
+    auto read_quad = [&](int q, f32x2 (&dd)[4][2], f32x2 (&zz)[C::NT][2]) {
+      // (the lane's LDS offsets are re-derived from an opaque copy of the lane id in every quad: four instructions, against
+      //  two address registers alive through the whole tile -- at 256 registers those were spilled, and a scratch reload
+      //  waits on vmcnt, i.e. for the prefetch loads in flight)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int tx0 = (4 * q) % C::TXN, ty0 = (4 * q) / C::TXN;   // (a quad never straddles a tile row: TXN % 4 == 0)
+      const int r0 = 2 * ty0, c0 = 2 * (tx0 + (ln >> 4));
+      const float* xa = xs + (cg * 16 + (ln & 15)) * C::PSX + r0 * C::LC + c0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (DLWP_WG_KNOCK == 3) {
+          dd[i][0] = (f32x2){(float)ln, 1.f};
+          dd[i][1] = (f32x2){2.f, (float)q};
+        } else {
+          dd[i][0] = *(const f32x2*)(xa + i * C::LC);
+          dd[i][1] = *(const f32x2*)(xa + i * C::LC + 2);
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) {
+        const float* zb = zs + ((og * C::NT + nt) * 16 + (ln & 15)) * C::PSZ + r0 * C::TW + c0;
+        if (DLWP_WG_KNOCK == 3) {
+          zz[nt][0] = (f32x2){(float)ln, 1.f};
+          zz[nt][1] = (f32x2){2.f, (float)q};
+        } else {
+          zz[nt][0] = (f32x2){zb[0], zb[1]};
+          zz[nt][1] = (f32x2){zb[C::TW], zb[C::TW + 1]};
+        }
+      }
+    };
+    read_quad(0, dq[0], zq[0]);
 #pragma unroll
     for (int q = 0; q < C::NQW; ++q) {
       if (more && DLWP_WG_KNOCK != 1) {   // all loads are out after quad LQ - 1: the last ones have the remaining quads to land
@@ -335,25 +373,11 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
         for (int k = (q * C::NZ4 + LQ - 1) / LQ; k < ((q + 1) * C::NZ4 + LQ - 1) / LQ && k < C::NZ4; ++k) load_z(k);
       }
       __builtin_amdgcn_sched_barrier(0);
-      // (the lane's LDS offsets are re-derived from an opaque copy of the lane id in every quad: four instructions, against
-      //  two address registers alive through the whole tile -- at 256 registers those were spilled, and a scratch reload
-      //  waits on vmcnt, i.e. for the prefetch loads in flight)
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int tx0 = (4 * q) % C::TXN, ty0 = (4 * q) / C::TXN;   // (a quad never straddles a tile row: TXN % 4 == 0)
-      const int r0 = 2 * ty0, c0 = 2 * (tx0 + (ln >> 4));
-      const float* xa = xs + (cg * 16 + (ln & 15)) * C::PSX + r0 * C::LC + c0;
       // V = B^T d B on column pairs in packed fp32 (conv_fwd_kernel.h: 16 v_pk_add_f32 instead of 32 adds), |A dY A^T| in 6
-      f32x2 d2[4][2], t2[4][2], v2[4][2];   // rows as (columns 0 1 | columns 2 3)
+      f32x2 t2[4][2], v2[4][2];   // rows as (columns 0 1 | columns 2 3)
+      f32x2 (&d2)[4][2] = dq[q & 1];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (DLWP_WG_KNOCK == 3) {
-          d2[i][0] = (f32x2){(float)ln, 1.f};
-          d2[i][1] = (f32x2){2.f, (float)q};
-        } else {
-          d2[i][0] = *(const f32x2*)(xa + i * C::LC);
-          d2[i][1] = *(const f32x2*)(xa + i * C::LC + 2);
-        }
         t2[i][0] = pk_wino_t01(d2[i][0], d2[i][1]);   // d B, one patch row: (d0 - d2, d1 + d2 | d2 - d1, d1 - d3)
         t2[i][1] = pk_wino_t23(d2[i][0], d2[i][1]);
       }
@@ -367,15 +391,9 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
       f32x2 rw[C::NT][4], sd[C::NT][4];
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) {
-        const float* zb = zs + ((og * C::NT + nt) * 16 + (ln & 15)) * C::PSZ + r0 * C::TW + c0;
         // |A dY|: rows (y0), (y0 + y1), (y0 - y1), (y1) as pairs (left, right); then each row (p, q) -> (p, p + q, p - q, q)
-        if (DLWP_WG_KNOCK == 3) {
-          rw[nt][0] = (f32x2){(float)ln, 1.f};
-          rw[nt][3] = (f32x2){2.f, (float)q};
-        } else {
-          rw[nt][0] = (f32x2){zb[0], zb[1]};
-          rw[nt][3] = (f32x2){zb[C::TW], zb[C::TW + 1]};
-        }
+        rw[nt][0] = zq[q & 1][nt][0];
+        rw[nt][3] = zq[q & 1][nt][1];
         rw[nt][1] = pk_add(rw[nt][0], rw[nt][3]);
         rw[nt][2] = pk_sub(rw[nt][0], rw[nt][3]);
 #pragma unroll
@@ -383,7 +401,10 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
       }
       // every transform of the quad is done before its first MFMA: the packed adds are inline asm, which the compiler's
       // hazard recogniser does not count as vector writes -- an MFMA reading such a result in the next slot got the old
-      // register contents (measured: errors of the data's own magnitude) -- so the wait states are set here
+      // register contents (measured: errors of the data's own magnitude) -- so the wait states are set here; the next quad's LDS
+      // reads sit in between
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < C::NQW) read_quad(q + 1, dq[(q + 1) & 1], zq[(q + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_nop 1");
       __builtin_amdgcn_sched_barrier(0);
