@@ -618,7 +618,7 @@ def sub_pad_hbm(members):
     return out
 
 
-def _compare_exchanges(tr, world, rank, barrier, dev, reps=50):
+def _compare_exchanges(tr, world, rank, barrier, dev, reps=50, crash_line=None, rec=None):
     """Both transports of the step's exchange on the SAME buffer, once for the sums and `reps` times for the latency: RCCL (the
     default) and the library's own one-shot all-reduce (csrc/xchg.hip, DLWP_ALLREDUCE=oneshot: peer-mapped uncached regions,
     rank-order sum).  The first multi-GPU run of this script thereby yields the comparison -- equal sums, both latencies -- instead
@@ -636,6 +636,11 @@ def _compare_exchanges(tr, world, rank, barrier, dev, reps=50):
         out['rccl_sum_exact'] = bool(torch.equal(a, want))
         prev = os.environ.get('DLWP_ALLREDUCE')
         os.environ['DLWP_ALLREDUCE'] = 'oneshot'
+        # the one-shot exchange has never run between two DEVICES: should a GPU memory fault abort this process, the line as it
+        # stands (this record marked) still reaches stdout (dlwp_set_crash_message)
+        if crash_line is not None and rec is not None:
+            rec['exchange_check'] = dict(out, oneshot='the process died inside the one-shot exchange (line written by the crash handler)')
+            crash_line(True, rec)
         try:
             if not tr.dp.wants_oneshot(base):
                 out['oneshot'] = 'not available for this buffer / world size'
@@ -659,6 +664,8 @@ def _compare_exchanges(tr, world, rank, barrier, dev, reps=50):
             dt = _sync_time(lambda: tr.dp.all_reduce_sum_(a), reps, barrier, world, dev)
             out['rccl_ms'] = 1e3 * dt / reps
         finally:
+            if crash_line is not None:
+                crash_line(False)
             if prev is None:
                 os.environ.pop('DLWP_ALLREDUCE', None)
             else:
@@ -668,7 +675,7 @@ def _compare_exchanges(tr, world, rank, barrier, dev, reps=50):
     return out
 
 
-def sub_train(grid, cin, world, rank, barrier, dev, per_gpu_batch=64, steps=20, warmup=40, share_of=8):
+def sub_train(grid, cin, world, rank, barrier, dev, per_gpu_batch=64, steps=20, warmup=40, share_of=8, crash_line=None):
     """BASELINE config 3: the same U-Net, training ('mse', Adam), data parallel over the ranks -- each rank trains on its rows of
     the global batch, one all-reduce of the flat gradient buffer per step (RCCL through dlwp_allreduce_sum_f32).  Both conventions
     at N > 1: 'strong' -- the global batch stays 64, every rank takes 64 / N rows -- and 'weak' -- the reference's: the batch grows
@@ -715,7 +722,7 @@ def sub_train(grid, cin, world, rank, barrier, dev, per_gpu_batch=64, steps=20, 
     if ar_ms is not None:
         rec['all_reduce_ms_measured'] = ar_ms
         rec['all_reduce_bytes'] = int(tr._flat_exchange.numel()) * 4
-        rec['exchange_check'] = _compare_exchanges(tr, world, rank, barrier, dev)
+        rec['exchange_check'] = _compare_exchanges(tr, world, rank, barrier, dev, crash_line=crash_line, rec=rec)
     if world > 1:
         weak, _, _ = run(per_gpu_batch * world, 'weak')
         weak['convention'] = 'reference: batch_size = n_gpu * batch_size (Azure/train_tf.py:163-164)'
@@ -1034,7 +1041,17 @@ def main():
             del series
             net.__dict__.pop('_rollouts', None)
             torch.cuda.empty_cache()
-            sub['train_cfg3'] = sub_train(grid if grid == (88, 180) else (88, 180), 4, world, rank, barrier, dev)
+            def crash_line(on, rec=None):
+                """(rank 0) park / clear the line as it stands -- with the training record measured so far -- for the library's
+                crash handler (dlwp_set_crash_message)"""
+                if rank != 0:
+                    return
+                from dlwp_amd import _lib
+                if on:
+                    _lib.lib.dlwp_set_crash_message(json.dumps(dict(out, sub_records=dict(sub, train_cfg3=rec))).encode('utf-8'))
+                else:
+                    _lib.lib.dlwp_set_crash_message(None)
+            sub['train_cfg3'] = sub_train(grid if grid == (88, 180) else (88, 180), 4, world, rank, barrier, dev, crash_line=crash_line)
             if world == 1:
                 sub['train_cfg3_loader_fed'] = sub_train_loader_fed((88, 180), 4, dev)
             sub['ensemble_cfg5'] = sub_cfg5(world, rank, barrier, dev)

@@ -103,6 +103,10 @@ typedef struct {
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 int         dlwp_version(void);
 const char* dlwp_last_error(void);
+/* Diagnostics: `text` (NULL: nothing) is written to stdout, followed by a newline, if the process dies of SIGABRT / SIGSEGV / SIGBUS -- the
+ * HSA runtime abort()s a process on a GPU memory fault.  bench.py parks its result line here before it runs the one-shot exchange
+ * between real GPUs for the first time, and clears it afterwards.  At most 512 KB; earlier handlers are chained.                 */
+int         dlwp_set_crash_message(const char* text);
 int         dlwp_create(dlwp_handle_t* h, int device);   /* one handle per device; thread-compatible */
 int         dlwp_destroy(dlwp_handle_t h);
 int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, char* arch, size_t arch_len);

@@ -189,3 +189,19 @@ def test_every_stream_taking_export_is_taped_or_marks_the_tape_foreign():
                 bare.append(name)
     assert len(seen) >= 50, len(seen)
     assert not bare, bare
+
+
+def test_crash_message_reaches_stdout_when_the_process_aborts():
+    """dlwp_set_crash_message: bench.py parks its line there before the first one-shot exchange between real GPUs (a GPU memory fault
+    makes the HSA runtime abort() the process); a parked text is written to stdout by the signal handler, a cleared one is not."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys\nsys.path.insert(0, %r)\nfrom dlwp_amd import _lib\n"
+            "_lib.lib.dlwp_set_crash_message(b'{\"parked\": 1}')\n%sos.abort()\n")
+    p = subprocess.run([sys.executable, '-c', code % (root, '')], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and p.stdout.strip().endswith('{"parked": 1}')
+    p = subprocess.run([sys.executable, '-c', code % (root, '_lib.lib.dlwp_set_crash_message(None)\n')], capture_output=True, text=True,
+                       timeout=120)
+    assert p.returncode != 0 and 'parked' not in p.stdout
