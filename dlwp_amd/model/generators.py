@@ -162,11 +162,18 @@ class DataGenerator(object):
         p, t = getattr(self.ds.predictors, 'values', None), getattr(self.ds.targets, 'values', None)
         if not (isinstance(p, np.ndarray) and isinstance(t, np.ndarray)):
             return None
-        key = (id(p), p.ctypes.data, p.shape, id(t), t.ctypes.data, t.shape, bool(self._impute_missing),
+        key = (p.ctypes.data, p.shape, t.ctypes.data, t.shape, bool(self._impute_missing),
                getattr(self.model, 'scaler_type', None), bool(self._remove_nan))
         cached = self.__dict__.get('_fast_sources')
-        if cached is not None and cached[0] == key:
+        if cached is not None and (cached[0] == key or cached[0] == 'off'):
             return cached[1]
+        # a dataset whose `.values` hands out a fresh array every time (a lazy file-backed variable) changes the key on every call:
+        # the decision -- a full NaN scan -- must not be re-taken per batch.  Three different keys: generate() it is.
+        misses = self.__dict__.get('_fast_misses', 0) + (1 if cached is not None else 0)
+        self._fast_misses = misses
+        if misses >= 3:
+            self._fast_sources = ('off', None)
+            return None
         fast = None
         ok = (p.dtype == np.float32 and t.dtype == np.float32 and
               p.flags['C_CONTIGUOUS'] and t.flags['C_CONTIGUOUS'] and p.shape[0] == t.shape[0] and p.shape[0] > 0 and
