@@ -1054,6 +1054,15 @@ def main():
             sub['train_cfg3'] = sub_train(grid if grid == (88, 180) else (88, 180), 4, world, rank, barrier, dev, crash_line=crash_line)
             if world == 1:
                 sub['train_cfg3_loader_fed'] = sub_train_loader_fed((88, 180), 4, dev)
+                # the strong-scaling projection the way the reference drives training (fit_generator: H2D included), beside the
+                # device-resident one
+                lf, sh = sub['train_cfg3_loader_fed'], sub['train_cfg3'].get('share_of_8_gpus')
+                if sh and 'batch_64' in lf and 'batch_8' in lf:
+                    sh['loader_fed'] = {'ms_per_step_64': lf['batch_64']['loader_fed_ms_per_step'],
+                                        'ms_per_step_8': lf['batch_8']['loader_fed_ms_per_step'],
+                                        'projected_speedup_8_gpus': lf['batch_64']['loader_fed_ms_per_step'] /
+                                        (lf['batch_8']['loader_fed_ms_per_step'] + sh['assumed_all_reduce_ms']),
+                                        'all_reduce': 'ASSUMED %.2f ms, not measured (single GPU)' % sh['assumed_all_reduce_ms']}
             sub['ensemble_cfg5'] = sub_cfg5(world, rank, barrier, dev)
         except Exception as e:  # noqa: BLE001
             sub['error_collective'] = repr(e)

@@ -207,7 +207,9 @@ class _Wrapper(object):
             for s_ in down:
                 main.wait_stream(s_)
         finally:
-            for buf in pins:               # (also when a call fails: the staging buffers go back to the pool)
+            if pins:                       # (also when a call fails: no upload may still be reading a staging buffer that goes
+                up.synchronize()           #  back to the pool)
+            for buf in pins:
                 util.pinned_results._give_back(buf.view(-1))
         return util.pinned_results.lend(host)
 
