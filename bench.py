@@ -648,8 +648,12 @@ def _compare_exchanges(tr, world, rank, barrier, dev, reps=50, crash_line=None, 
             b = base.clone()
             tr.dp.oneshot_all_reduce_(b)
             torch.cuda.synchronize()
-            if tr.dp.oneshot_timed_out():
-                out['oneshot'] = 'TIMED OUT waiting for a peer (dlwp_xchg_status): RCCL stays the transport'
+            # (the ranks agree on the outcome before anyone goes on: a rank that timed out must not leave the others launching
+            #  exchanges it no longer takes part in)
+            flag = torch.tensor([1.0 if tr.dp.oneshot_timed_out() else 0.0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if float(flag.item()) > 0.0:
+                out['oneshot'] = 'TIMED OUT waiting for a peer (dlwp_xchg_status) on at least one rank: RCCL stays the transport'
                 return out
             out['oneshot_sum_exact'] = bool(torch.equal(b, want))
             out['equal_sums'] = bool(torch.equal(a, b))

@@ -91,21 +91,36 @@ class DataParallel(object):
 
     def xchg(self, flat):
         """dlwp_xchg_t for buffers of flat.numel() floats; created collectively at the first call (the 64-byte IPC handles travel
-        through torch.distributed's host channel, like RCCL's unique id)"""
+        through torch.distributed's host channel, like RCCL's unique id).  Failure is collective too: a rank whose region cannot be
+        created, exported or mapped still takes part in every host-side exchange of this call, and ALL ranks raise together -- no
+        rank is left waiting in a collective for one that gave up (r5: the first run between real GPUs must not hang)."""
         ent = getattr(self, '_xchg', None)
         if ent is None or ent[1] != flat.numel():
             from . import _lib
             if ent is not None:
                 _lib.lib.dlwp_xchg_destroy(ent[0])
+                self._xchg = None
             idx = flat.device.index if flat.device.index is not None else torch.cuda.current_device()
             hd = (ctypes.c_char * 64)()
             out = ctypes.c_void_p()
-            _lib.check(_lib.lib.dlwp_xchg_create(_lib.handle(idx), self.world, self.rank, flat.numel(), hd, ctypes.byref(out)))
-            handles = [None] * self.world
-            self.dist.all_gather_object(handles, bytes(hd), group=self.group)
-            blob = (ctypes.c_char * (64 * self.world)).from_buffer_copy(b''.join(handles))
-            _lib.check(_lib.lib.dlwp_xchg_connect(out, blob))
-            self.dist.barrier(group=self.group)          # every region is mapped everywhere before the first flag is written
+            err = None
+            if _lib.lib.dlwp_xchg_create(_lib.handle(idx), self.world, self.rank, flat.numel(), hd, ctypes.byref(out)) != _lib.OK:
+                err = _lib.lib.dlwp_last_error().decode('utf-8', 'replace')
+                out = ctypes.c_void_p()
+            got = [None] * self.world
+            self.dist.all_gather_object(got, (err, bytes(hd)), group=self.group)
+            if err is None and all(g[0] is None for g in got):
+                blob = (ctypes.c_char * (64 * self.world)).from_buffer_copy(b''.join(g[1] for g in got))
+                if _lib.lib.dlwp_xchg_connect(out, blob) != _lib.OK:
+                    err = _lib.lib.dlwp_last_error().decode('utf-8', 'replace')
+            errs = [None] * self.world
+            self.dist.all_gather_object(errs, err if err is not None else next((g[0] for g in got if g[0] is not None), None),
+                                        group=self.group)          # (also the barrier: every region is mapped everywhere
+            bad = [(r, e) for r, e in enumerate(errs) if e is not None]          #  before the first flag is written)
+            if bad:
+                if out:
+                    _lib.lib.dlwp_xchg_destroy(out)
+                raise RuntimeError('dlwp_xchg: the one-shot exchange could not be set up (rank %d: %s)' % bad[0])
             ent = self._xchg = (out, flat.numel())
         return ent[0]
 
