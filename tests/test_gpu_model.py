@@ -395,6 +395,15 @@ def test_functional_skip_unet_and_chained_outputs():
         slots += [o1, o2]
         p = o2
     assert np.array_equal(ts, np_ref._merge_time(np.stack(slots), 4, 3, 2, cs, False))
+    # r5: the streamed return (one graph per model call, BOTH output slots of a call leaving under the next call) gives the same array
+    kept = f.predict_timeseries(x, 5, keep_time_dim=True)
+    f.host_stream_bytes = 0
+    try:
+        assert np.array_equal(f.predict_timeseries(x, 5), ts)
+        assert np.array_equal(f.predict_timeseries(x, 5, keep_time_dim=True), kept)
+        assert m.streamed_rollout(3, 2, 1).n_out == 2
+    finally:
+        f.host_stream_bytes = 64 << 20
 
 
 def test_fit_generator_with_sequence_targets_of_a_multi_output_model():
@@ -1157,6 +1166,15 @@ def test_convlstm_unet_forward_and_rollout_match_oracle():
         ser.append(p)
     ser = np.stack(ser)
     assert np.array_equal(series, np_ref._merge_time(ser, 3, 3, 2, cs[1:], False).reshape(series.shape))
+    # r5: the streamed return on a RECURRENT state (time_step, variable, lat, lon): the same arrays, both layouts
+    kept = d.predict_timeseries(x, 5, keep_time_dim=True)
+    d.host_stream_bytes = 0
+    try:
+        assert np.array_equal(d.predict_timeseries(x, 5), series)
+        got_kept = d.predict_timeseries(x, 5, keep_time_dim=True)
+        assert got_kept.shape == kept.shape and np.array_equal(got_kept, kept)
+    finally:
+        d.host_stream_bytes = 64 << 20
 
 
 def test_convlstm_train_step_matches_autograd_oracle_with_l2():
