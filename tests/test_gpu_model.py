@@ -289,6 +289,24 @@ def test_rollout_captured_as_parallel_member_chains_is_bit_identical():
         torch.cuda.synchronize()
         assert torch.equal(ser, want), groups
         g.close()
+    # r5: a forked graph goes through a stream of the rollout's own only when the caller sits on the null stream (the runtime fault of
+    # r4); on a caller's REAL stream it is launched directly (csrc/rollout.hip) -- the same bits either way
+    s0 = torch.empty_like(x)
+    ser = torch.empty_like(want)
+    g = net.executor.make_rollout(s0, ser, 5, groups=2)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s0.copy_(x)
+        g.launch()
+    side.synchronize()
+    assert torch.equal(ser, want)
+    ser.zero_()
+    s0.copy_(x)
+    g.launch()                          # ... and from the null stream
+    torch.cuda.synchronize()
+    assert torch.equal(ser, want)
+    g.close()
     from dlwp_amd._lib import DlwpError
     with pytest.raises(DlwpError, match='equal groups'):
         net.executor.make_rollout(torch.empty_like(x), torch.empty_like(want), 5, groups=4)
