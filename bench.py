@@ -620,7 +620,7 @@ def sub_pad_hbm(members):
 
 def _compare_exchanges(tr, world, rank, barrier, dev, reps=50, crash_line=None, rec=None):
     """Both transports of the step's exchange on the SAME buffer, once for the sums and `reps` times for the latency: RCCL (the
-    default) and the library's own one-shot all-reduce (csrc/xchg.hip, DLWP_ALLREDUCE=oneshot: peer-mapped uncached regions,
+    default; torch.distributed where the group is not on RCCL) and the library's own one-shot all-reduce (csrc/xchg.hip, DLWP_ALLREDUCE=oneshot: peer-mapped uncached regions,
     rank-order sum).  The first multi-GPU run of this script thereby yields the comparison -- equal sums, both latencies -- instead
     of a hang or a silently wrong sum: a one-shot launch that waits 2 s for a peer gives up, dlwp_xchg_status reports it, and the
     record says so (the training records above always ran on RCCL).  Collective: every rank calls it."""
@@ -633,7 +633,9 @@ def _compare_exchanges(tr, world, rank, barrier, dev, reps=50, crash_line=None, 
         tr.dp.all_reduce_sum_(a)
         torch.cuda.synchronize()
         want = ((torch.arange(n, device=dev, dtype=torch.float32) % 251.0) * world + world * (world + 1) / 2.0)
-        out['rccl_sum_exact'] = bool(torch.equal(a, want))
+        out['default_transport'] = ('RCCL via dlwp_allreduce_sum_f32 (C ABI)' if tr.dp.uses_rccl_abi() else
+                                    'torch.distributed (%s)' % tr.dp.backend)
+        out['default_sum_exact'] = bool(torch.equal(a, want))
         prev = os.environ.get('DLWP_ALLREDUCE')
         os.environ['DLWP_ALLREDUCE'] = 'oneshot'
         # the one-shot exchange has never run between two DEVICES: should a GPU memory fault abort this process, the line as it
@@ -666,7 +668,7 @@ def _compare_exchanges(tr, world, rank, barrier, dev, reps=50, crash_line=None, 
             for _ in range(5):
                 tr.dp.all_reduce_sum_(a)
             dt = _sync_time(lambda: tr.dp.all_reduce_sum_(a), reps, barrier, world, dev)
-            out['rccl_ms'] = 1e3 * dt / reps
+            out['default_ms'] = 1e3 * dt / reps
         finally:
             if crash_line is not None:
                 crash_line(False)

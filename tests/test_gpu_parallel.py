@@ -202,8 +202,8 @@ def test_bench_gpus_2_as_a_plain_script_prints_one_line_with_the_collective_sub_
     # the one-shot region sits in uncached (or fine-grained) memory, no launch timed out; and every rank reports its stream probes
     ex = tr['exchange_check']
     assert 'error' not in ex, ex
-    assert ex['rccl_sum_exact'] and ex['oneshot_sum_exact'] and ex['equal_sums'] and not ex['oneshot_timed_out'], ex
-    assert ex['oneshot_ms'] > 0 and ex['rccl_ms'] > 0 and ex['oneshot_region']['memory'] in ('uncached', 'fine-grained', 'plain')
+    assert ex['default_sum_exact'] and ex['oneshot_sum_exact'] and ex['equal_sums'] and not ex['oneshot_timed_out'], ex
+    assert ex['oneshot_ms'] > 0 and ex['default_ms'] > 0 and 'gloo' in ex['default_transport'] and ex['oneshot_region']['memory'] in ('uncached', 'fine-grained', 'plain')
     assert ex['oneshot_region']['blocks'] >= 1
     probes = rec['stream_probes']
     assert isinstance(probes, list) and len(probes) == 2 and all(isinstance(p_, list) for p_ in probes), probes
