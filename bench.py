@@ -488,9 +488,11 @@ def sub_host_visible(d, grid, cin, members, forwards):
         times.append(time.perf_counter() - t0)
     return {'value': members * forwards * 2 / min(times), 'unit': '6-h forecast steps/s', 'members': members,
             'series_bytes': int(out.nbytes), 's_per_call': min(times),
-            'note': 'DLWPNeuralNet.predict_timeseries(numpy) -> numpy; the series returns in member chunks into a recycled '
-                    'pinned host array, one strided DMA per chunk on a copy stream under the next chunk\'s hipGraph launch; '
-                    'the next chunk\'s input is staged and uploaded meanwhile'}
+            'note': 'DLWPNeuralNet.predict_timeseries(numpy) -> numpy: one hipGraph per model call, every finished forecast slot '
+                    'leaves for ONE recycled pinned result array (time first, as the reference returns it) on a copy stream while the '
+                    'next call runs; the first call in member chunks under the upload (DESIGN.md 5.15).  Link-bound: the series / '
+                    's_per_call is the rate the PCIe link delivers beside the rollout',
+            'series_gbs': out.nbytes / min(times) / 1e9}
 
 
 def sub_layer1_nominal(net, members):
@@ -834,6 +836,20 @@ def sub_cfg5(world, rank, barrier, dev, total_members=32, forwards=40, share_of=
         sh.update(operating_point(net, m, m * forwards * 3 / dts))
         sh['projected_speedup_%d_gpus' % share_of] = share_of * sh['value'] / rec['value']
         rec['share_of_%d_gpus' % share_of] = sh
+    if world == 1:
+        # the same ensemble through the API (numpy in, numpy out): 4 GB of series for 31 ms of rollout -- the link decides
+        x = s0.cpu().numpy()
+        d.predict_timeseries(x, 2 * forwards)
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            out = d.predict_timeseries(x, 2 * forwards)
+            times.append(time.perf_counter() - t0)
+        rec['host_visible'] = {'value': total_members * forwards * 2 / min(times), 'unit': '6-h forecast steps/s',
+                               'series_bytes': int(out.nbytes), 's_per_call': min(times), 'series_gbs': out.nbytes / min(times) / 1e9,
+                               'note': 'predict_timeseries(numpy) -> numpy, streamed return (DESIGN.md 5.15); r4 returned this series '
+                                       'through one pageable copy after the rollout'}
+        del out
     return rec
 
 
