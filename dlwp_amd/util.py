@@ -216,24 +216,28 @@ def distinct_streams(device, k, avoid):
     stream may share the queue of the stream it is meant to overlap with -- its launches then queue up in front of that stream's
     instead of running beside them (r4, config-3 step at 64 samples: 1.38 ms with the weight-gradient streams on queues of their
     own, 1.42-1.43 where one shared the main stream's queue; an upload stream behind a weight-gradient stream: 2.03 ms).  Candidates
-    are PROBED: a one-thread spin kernel on a stream of `avoid` and one on the candidate take the time of one where the queues
+    are PROBED: a one-wave spin kernel (dlwp_spin, 100 us) on a stream of `avoid` and one on the candidate take the time of one where the queues
     differ, of two where they are the same.  Candidates that serialise with a stream to avoid are passed over (and returned last,
     if nothing better turns up: the result always has k streams).  DLWP_PROBE_STREAMS=0: no probing."""
+    import ctypes
     import os
     import torch
     fresh = lambda: torch.cuda.Stream(device)  # noqa: E731
-    if os.environ.get('DLWP_PROBE_STREAMS', '1') == '0' or not hasattr(torch.cuda, '_sleep') or device.type != 'cuda':
+    if os.environ.get('DLWP_PROBE_STREAMS', '1') == '0' or device.type != 'cuda':
         return [fresh() for _ in range(k)]
+    from . import _lib
+    h = _lib.handle(device.index if device.index is not None else torch.cuda.current_device())
+
+    def spin(stream, us):         # (r5: the library's own spin kernel, dlwp_spin -- r4 leaned on the private torch.cuda._sleep)
+        _lib.check(_lib.lib.dlwp_spin(h, int(us), ctypes.c_void_p(stream.cuda_stream)))
 
     def pair_ms(a, b, cycles):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         b.wait_stream(a)
         e0.record(a)
         b.wait_event(e0)
-        with torch.cuda.stream(a):
-            torch.cuda._sleep(cycles)
-        with torch.cuda.stream(b):
-            torch.cuda._sleep(cycles)
+        spin(a, cycles)
+        spin(b, cycles)
         a.wait_stream(b)
         e1.record(a)
         e1.synchronize()
@@ -241,13 +245,12 @@ def distinct_streams(device, k, avoid):
     try:
         with torch.cuda.device(device):
             base = avoid[0] if avoid else torch.cuda.current_stream(device)
-            cycles = 200000
+            cycles = 100                            # microseconds per spin
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(base):
-                torch.cuda._sleep(cycles)           # (first launch of the spin kernel)
-                e0.record(base)
-                torch.cuda._sleep(cycles)
-                e1.record(base)
+            spin(base, cycles)                      # (first launch of the spin kernel)
+            e0.record(base)
+            spin(base, cycles)
+            e1.record(base)
             e1.synchronize()
             one = e0.elapsed_time(e1)
             taken, spare = [], []

@@ -107,6 +107,9 @@ const char* dlwp_last_error(void);
  * HSA runtime abort()s a process on a GPU memory fault.  bench.py parks its result line here before it runs the one-shot exchange
  * between real GPUs for the first time, and clears it afterwards.  At most 512 KB; earlier handlers are chained.                 */
 int         dlwp_set_crash_message(const char* text);
+/* One idle wave that occupies `stream`'s hardware queue for `microseconds` (at most 100 000): the probe with which the host layer
+ * finds out whether two streams really run beside each other (the runtime multiplexes streams onto a few hardware queues).       */
+int         dlwp_spin(dlwp_handle_t h, int microseconds, void* stream);
 int         dlwp_create(dlwp_handle_t* h, int device);   /* one handle per device; thread-compatible */
 int         dlwp_destroy(dlwp_handle_t h);
 int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, char* arch, size_t arch_len);
