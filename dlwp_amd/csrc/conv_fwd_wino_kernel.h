@@ -328,13 +328,22 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
     for (int s = 0; s < HL; ++s) {
       if (s % GS == 0 && !(C::UPS && ((s / GS + 1) & 3) == 2))   // (UPS: transformed-filter row 2 is never multiplied)
         load_frags(ucur, s / GS == 3 ? 1 : 0, (s / GS + 1) & 3, (s / GS + 1) & 1);
-      if (s < 8) vt_read(xcur, 1, s);
+      if (s < 8) vt_read(xcur, 1, s);   // (one 8-byte read per step: two per step merge into ds_read2_b64, whose 8-bit offsets need a
+                                        //  v_add_u32 for the base -- a vector instruction, i.e. a pipe switch, per step)
       if (s >= 8 && s < 24) {  // registers (chunk k+1) -> xs[nxt]
 #pragma unroll
         for (int i = (s - 8) * C::NXI / 16; i < (s - 7) * C::NXI / 16; ++i) stage_x(xnxt, i);
       }
-      if (s >= 4 && s < 12 && (s & 1) == 0) vt_rows((s - 4) >> 1);
-      if (s >= 12 && s < 16) vt_cols(1, s - 12);
+      // r5: the fp32 matrix pipe and the vector ALU exclude each other AND a switch between them costs ~11 cycles on top of the issue
+      // slots (tools/microbench/mfma_bf16_interleave.hip: the first vector instruction behind an MFMA 15.4 cycles, every further
+      // one 4).  The 16 packed adds of a transform used to sit behind eight different MFMAs (rows at s = 4, 6, 8, 10, columns at
+      // s = 12 ... 15): eight switches per 32 MFMAs; now two (the rows three MFMAs behind the last patch read).
+      if (s == 11) {
+#pragma unroll
+        for (int r_ = 0; r_ < 4; ++r_) vt_rows(r_);
+#pragma unroll
+        for (int r_ = 0; r_ < 4; ++r_) vt_cols(1, r_);
+      }
       if (s >= 6 && s < 6 + 2 * C::NUI) stage_u(unxt, (s - 6) >> 1, (s - 6) & 1);            // xy quads 0,1 of chunk k+1
       if (s >= 8 + 2 * C::NUI && s < 8 + 4 * C::NUI) {                                        // load quads 2,3 of chunk k+1
         const int h = s - 8 - 2 * C::NUI;
@@ -370,8 +379,12 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
         const int h = s - 18 - 2 * C::NUI;
         load_u(c0 + 2 * C::CK, h >> 1, h & 1);
       }
-      if (s >= 4 && s < 12 && (s & 1) == 0) vt_rows((s - 4) >> 1);
-      if (s >= 12 && s < 16) vt_cols(0, s - 12);
+      if (s == 11) {
+#pragma unroll
+        for (int r_ = 0; r_ < 4; ++r_) vt_rows(r_);
+#pragma unroll
+        for (int r_ = 0; r_ < 4; ++r_) vt_cols(0, r_);
+      }
       if (s < 16) {  // chunk k+2 -> registers (the rest of the input, then the filters)
 #pragma unroll
         for (int i = (s + 8) * C::NXI / 24; i < (s + 9) * C::NXI / 24; ++i) load_x(c0 + 2 * C::CK, i);
