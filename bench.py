@@ -33,6 +33,7 @@ import ctypes
 import glob
 import json
 import os
+import re
 import sys
 import threading
 import time
@@ -69,7 +70,7 @@ def kernel_source_hash():
     return _lib.kernel_source_hash()
 
 
-def config_symbol(cfg, ups=False):
+def config_symbol(cfg, ups=False, x_loader=0):
     """kernel symbol of a tile configuration tuple (dlwp_conv2d_config_info), as rocprofv3 prints it"""
     ks, dil, th, tw, waves, fa, bnf, ck, pool = cfg[:9]
     if fa == 0:
@@ -77,16 +78,25 @@ def config_symbol(cfg, ups=False):
         if split:          # the 16-position case of these entries: positions split over two waves per tile fragment
             return 'conv2d_fwd_wino2_f32<WinoSplitCfg<%d, %d, %d, %d, %d, %d, false, false> >' % (dil, th, tw, waves, bnf,
                                                                                                  ck)
-        # <..., IN16, UPS, DACT, POOL2, SPLITK>: the inference plan uses neither the training epilogue nor the second output, and
-        # launches that fill the chip are never split
-        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s, false, false, false> >' % (
-            dil, th, tw, waves, bnf, ck, 'true' if ups else 'false')
+        # <..., IN16, UPS, DACT, POOL2, SPLITK, PAIRX, UPSQ>: the inference plan uses neither the training epilogue nor the second
+        # output, and launches that fill the chip are never split; the last two = the input loader (dlwp_launch_info.x_loader)
+        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s, false, false, false, %s, %s> >' % (
+            dil, th, tw, waves, bnf, ck, 'true' if ups else 'false', 'true' if x_loader == 1 else 'false',
+            'true' if x_loader == 2 else 'false')
     if bnf < 0:
         return 'conv2d_fwd_packn_f32<PackCfg<%d, %d, %d, %d, %d, %d, %d, %d> >' % (ks, dil, th, tw, waves, fa, ck, -bnf)
     if pool >= 2:
         return 'conv2d_fwd_mfma_bf16<...%dx%d, %d waves>' % (th, tw, waves)
     return 'conv2d_fwd_mfma_f32<ConvCfg<%d, %d, %d, %d, %d, %d, %d, %d, %s> >' % (ks, dil, th, tw, waves, fa, bnf, ck,
                                                                                'true' if pool else 'false')
+
+
+def kernel_family(symbol):
+    """A Winograd instance's symbol without its last two template arguments (the input loader, r5: WinoCfg::PAIRX / UPSQ): the
+    loader variants of one tile configuration run the same loop on the same bits and count as ONE kernel in the roofline -- a
+    prefix of every variant's full name, so the lookups below find (and average over) all of them."""
+    m = re.match(r'^(conv2d_fwd_wino_f32<WinoCfg<(?:[^,<>]+, ){10}[^,<>]+), (?:true|false), (?:true|false)> >$', symbol)
+    return m.group(1) if m else symbol
 
 
 def measured_traffic(symbol, members):
@@ -101,13 +111,16 @@ def measured_traffic(symbol, members):
         except (OSError, ValueError):
             continue
         meta = d.get('_meta', {})
-        for name, e in d.items():
-            if name != '_meta' and symbol in name and 'hbm_read_bytes' in e and 'hbm_write_bytes' in e:
-                if meta.get('source_sha') != sha:
-                    stale = stale or os.path.basename(f)
-                    continue
-                scale = members / float(meta.get('members', 256))
-                return (e['hbm_read_bytes'] + e['hbm_write_bytes']) * scale, os.path.basename(f)
+        hits = [e for name, e in d.items() if name != '_meta' and symbol in name and 'hbm_read_bytes' in e and 'hbm_write_bytes' in e]
+        if not hits:
+            continue
+        if meta.get('source_sha') != sha:
+            stale = stale or os.path.basename(f)
+            continue
+        scale = members / float(meta.get('members', 256))
+        n = sum(float(e.get('launches', 1)) for e in hits)        # (several instances of one family: mean over all their launches)
+        return sum((e['hbm_read_bytes'] + e['hbm_write_bytes']) * float(e.get('launches', 1)) for e in hits) / n * scale, \
+            os.path.basename(f)
     return None, ('stale: %s was measured on other kernel source' % stale) if stale else 'no PMC summary for this kernel'
 
 
@@ -136,13 +149,16 @@ def rocprof_launch_ms(symbol, members):
             continue
         same = meta.get('source_sha') == sha
         try:
-            for r in csv.DictReader(open(f)):
-                if symbol in r['Name']:
-                    ent = {'file': base, 'avg_ms': float(r['AverageNs']) / 1e6, 'calls': int(r['Calls']), 'same_source': same}
-                    if same:
-                        return ent
-                    best = best or ent
-                    break
+            hits = [r for r in csv.DictReader(open(f)) if symbol in r['Name']]
+            if hits:                         # (several instances of one family: mean over all their calls)
+                calls = sum(int(r['Calls']) for r in hits)
+                ent = {'file': base, 'avg_ms': sum(float(r['TotalDurationNs']) for r in hits) / calls / 1e6, 'calls': calls,
+                       'same_source': same}
+                if len(hits) > 1:
+                    ent['instances'] = {r['Name']: {'avg_ms': float(r['AverageNs']) / 1e6, 'calls': int(r['Calls'])} for r in hits}
+                if same:
+                    return ent
+                best = best or ent
         except (OSError, KeyError, ValueError):
             continue
     return best
@@ -244,7 +260,7 @@ def time_layers(model, members, iters=5):
                                     model.device.index or 0)
         def symbol_of(i):
             if i[0] >= 0:
-                return config_symbol(cfgs[i[0]], ups)
+                return config_symbol(cfgs[i[0]], ups, i[5] if len(i) > 5 else 0)
             if i[0] == -2:      # dlwp_conv2d_launch_info: the few-channel streaming kernel (csrc/conv_fwd_few.hip), <DIL, ACT, QUAD>
                 return 'conv2d_fwd_few_f32<%d, ' % dil_run[0]
             if i[0] == -3:      # ... the streaming position-split Winograd kernel (csrc/conv_fwd_wino2s.hip), <chunks, depth-to-space>
@@ -324,8 +340,9 @@ def roofline_of(rows, members):
     for r in rows:
         if r.get('kind') == 'hbm':
             continue
-        groups.setdefault(r['kernel'], []).append(r)
+        groups.setdefault(kernel_family(r['kernel']), []).append(r)
     sym, rs = max(groups.items(), key=lambda kv: sum(r['ms'] for r in kv[1]))
+    variants = sorted({r['kernel'] for r in rs})
     ms = sum(r['ms'] for r in rs)
     n_launch = len(rs)
     executed = sum(r['executed_flops'] for r in rs)
@@ -347,6 +364,14 @@ def roofline_of(rows, members):
            'executed_flops_per_launch': executed / n_launch, 'algorithmic_flops_per_launch': algorithmic / n_launch,
            'algorithmic_bytes_per_launch': sum(r['bytes'] for r in rs) / n_launch,
            'share_of_forward_time': ms / tot, 'traffic_unit': 'bytes per launch'}
+    if len(variants) == 1:
+        out['kernel'] = variants[0]
+    else:
+        out['kernel'] = sym + ', *, *> >'
+        out['instances'] = {v: [r['layer'] for r in rs if r['kernel'] == v] for v in variants}
+        out['instances_note'] = ('one tile configuration, one loop, the same bits; the last two template arguments pick the input '
+                                 'loader (DLWP_OPT_WINO_XLOADER: image-aligned column pairs on even widths, element by element '
+                                 'otherwise); `rocprof` and `traffic` are means over all their launches')
     if any(r['launches'] > 1 for r in rs):
         out['note'] = ('layers on a 45-column map hand their ragged last column tile to a 16-wide instance in a second '
                        'launch; its time and FLOPs are inside these figures')

@@ -20,6 +20,7 @@ OK, EINVAL, EUNSUPPORTED, EHIP, ERCCL = 0, -1, -2, -3, -4
 OPT_WINOGRAD, OPT_BF16_MFMA, OPT_FORCE_CONV_CONFIG, OPT_FORCE_WGRAD_CONFIG, OPT_WINO_PAIRS, OPT_WGRAD_FILL = 0, 1, 2, 3, 4, 5
 OPT_FEW_STREAM = 6
 OPT_SPLITK = 7
+OPT_WINO_XLOADER = 8
 F32, BF16, BF16_O8 = 0, 1, 2
 ROLLOUT_PREPARED = 0x100
 PAD_ZERO, PAD_WRAP, PAD_EDGE, PAD_REFLECT, PAD_SYMMETRIC = 0, 1, 2, 3, 4
@@ -70,7 +71,7 @@ class Op(ctypes.Structure):
 
 class LaunchInfo(ctypes.Structure):
     _fields_ = [('config', ctypes.c_int), ('grid', ctypes.c_int), ('block_threads', ctypes.c_int),
-                ('matrix_flops', ctypes.c_double), ('bf16_matrix', ctypes.c_int)]
+                ('matrix_flops', ctypes.c_double), ('bf16_matrix', ctypes.c_int), ('x_loader', ctypes.c_int)]
 
 
 class DlwpError(RuntimeError):

@@ -121,6 +121,8 @@ static dlwp_options& default_options_rw() {
     if (e && e[0] >= '0' && e[0] <= '2') o.few_stream = e[0] - '0';
     e = getenv("DLWP_WGRAD_FILL");        // (A/B runs of DLWP_OPT_WGRAD_FILL)
     if (e && atoi(e) >= 1 && atoi(e) <= 64) o.wgrad_fill = atoi(e);
+    e = getenv("DLWP_WINO_XLOADER");      // (A/B runs of DLWP_OPT_WINO_XLOADER)
+    if (e && e[0] >= '0' && e[0] <= '3') o.wino_xld = e[0] - '0';
     e = getenv("DLWP_SPLITK");            // (A/B runs of DLWP_OPT_SPLITK)
     if (e && atoi(e) >= 0 && atoi(e) <= 64) o.splitk = atoi(e);
     return o;
@@ -139,6 +141,7 @@ static int set_in(dlwp_options& o, int option, int value, int* previous, const c
     case DLWP_OPT_WINO_PAIRS: slot = &o.wino_pairs; value = value ? 1 : 0; break;
     case DLWP_OPT_FEW_STREAM: slot = &o.few_stream; value = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case DLWP_OPT_WGRAD_FILL: slot = &o.wgrad_fill; value = value < 1 ? 1 : (value > 64 ? 64 : value); break;
+    case DLWP_OPT_WINO_XLOADER: slot = &o.wino_xld; value &= 3; break;
     case DLWP_OPT_SPLITK: slot = &o.splitk; value = value < 0 ? 0 : (value > 64 ? 64 : value); break;
     default: DLWP_FAIL(DLWP_EINVAL, "%s: unknown option %d", fn, option);
   }

@@ -877,6 +877,7 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
   a.cout_tiles = lp.cout_tiles;
   a.col0 = 0;
   a.pair_vw = lp.pair_vw;
+  a.xld = h->opt.wino_xld;
   DLWP_CHECK_ARG(lp.grid < (1ll << 31), "dlwp_conv2d_fwd: grid too large");
   if (e.pack != 0) {  // Winograd / packed-N: prepared weights (into the handle's scratch unless the caller built them)
     if (u_pre) {
@@ -1401,13 +1402,13 @@ int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
   if (lp.primary < 0) {               // one thread per output on the vector ALU: no matrix-core work
     const long long total = (long long)a.N * a.Cout * a.Ho * a.Wo;
     const long long want = (total + 255) / 256, cap = (long long)h->cu_count * 16;
-    out2[0] = dlwp_launch_info{-1, (int)(want < cap ? want : cap), 256, 0.0, 0};
+    out2[0] = dlwp_launch_info{-1, (int)(want < cap ? want : cap), 256, 0.0, 0, 0};
     *n_launches = 1;
     return DLWP_OK;
   }
   if (const int fg = few_stream_grid(h, a, cd, lp)) {   // config -2: conv_fwd_few.hip -- 72 MFMAs per wave and 8 x 32 / 32-channel item
     const double items = (double)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 32) * a.N;
-    out2[0] = dlwp_launch_info{-2, fg, 256, 2.0 * 256.0 * 32.0 * 36.0 * items, 0};
+    out2[0] = dlwp_launch_info{-2, fg, 256, 2.0 * 256.0 * 32.0 * 36.0 * items, 0, 0};
     *n_launches = 1;
     return DLWP_OK;
   }
@@ -1419,16 +1420,23 @@ int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
   plan_splitk(h, a, cd, &lp, false, DLWP_SPLITK_REGION_BYTES);     // (grid = workgroups launched: tiles x splits; same matrix work)
   if (const int sg = wino2s_grid(h, a, cd, lp)) {   // config -3: conv_fwd_wino2s.hip -- the instance's matrix work, 2 workgroups per CU
     const long long g832 = (long long)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 16) * a.N;
-    out2[0] = dlwp_launch_info{-3, sg, 512, 2.0 * 64.0 * 16.0 * 16.0 * 8.0 * ((a.Cin + 7) / 8) * (double)g832, 0};
+    out2[0] = dlwp_launch_info{-3, sg, 512, 2.0 * 64.0 * 16.0 * 16.0 * 8.0 * ((a.Cin + 7) / 8) * (double)g832, 0, 0};
     *n_launches = 1;
     return DLWP_OK;
   }
   out2[0] = dlwp_launch_info{lp.primary, (int)(lp.grid * lp.ksplit), threads(e), executed_matrix_flops(e, a, lp.grid),
-                             is_bf16(e) ? 1 : 0};
+                             is_bf16(e) ? 1 : 0, 0};
+  if (is_wino(e) && !e.split) {     // (what wino_launch_either will do with this launch)
+    a.pair_vw = lp.pair_vw;
+    a.ksplit = lp.ksplit;
+    a.xld = h->opt.wino_xld;
+    a.col0 = 0;
+    out2[0].x_loader = wino_x_loader(a, e.dil, e.th, e.tw, e.waves, e.bnf);
+  }
   *n_launches = 1;
   if (lp.narrow >= 0) {
     const ConvKernelEntry& p = r.entries[lp.narrow];
-    out2[1] = dlwp_launch_info{lp.narrow, (int)lp.n_grid, threads(p), executed_matrix_flops(p, a, lp.n_grid), 0};
+    out2[1] = dlwp_launch_info{lp.narrow, (int)lp.n_grid, threads(p), executed_matrix_flops(p, a, lp.n_grid), 0, 0};
     *n_launches = 2;
   }
   return DLWP_OK;

@@ -40,6 +40,8 @@ struct ConvArgs {
   int compute_bf16;       // DLWP_COMPUTE_BF16: a float32-stored input may be rounded to bf16 for the bf16 matrix cores
   int col0 = 0;           // Winograd: first output column of this launch (a wide-tile launch + a narrow one for the rest)
   int out_d2s = 0;        // the 4 F output channels are 2x2 phases: stored interleaved, y = (N, out_c_total, 2 Ho, 2 Wo)
+  int xld = 3;            // Winograd input loaders the launch may take (DLWP_OPT_WINO_XLOADER): bit 0 column pairs (WinoCfg::PAIRX),
+                          // bit 1 source-resolution fetch of an up-sampled source (WinoCfg::UPSQ); same bits either way
   int pair_vw = 0;        // Winograd, narrow maps: two samples side by side in a VIRTUAL row of 2 pair_vw columns (sample k at
                           // [k pair_vw, k pair_vw + W)); the grid then counts sample PAIRS (conv_fwd_wino_kernel.h)
   // ConvLSTM2D cell update in the epilogue (bf16 matrix-core instances with 64-channel blocks, conv_fwd_bf16_kernel.h):
@@ -586,6 +588,23 @@ struct ConvKernelEntry {
   int dual = 0;          // bf16-MFMA instances: a whole ConvLSTM2D step (recurrent + input convolution + cell update), and only that
   int splitk = 0;        // Winograd instances: 1 = a split-K variant is compiled (ConvArgs::ksplit > 1 launches it)
 };
+
+// Which input loader a launch of the (DIL, TH, TW, WAVES, BNF) geometry takes (ConvArgs::xld = DLWP_OPT_WINO_XLOADER): 0 element
+// by element, 1 image-aligned column pairs (WinoCfg::PAIRX), 2 an up-sampled source at source resolution (WinoCfg::UPSQ).  One
+// predicate for wino_launch_either (conv_fwd_wino_kernel.h) and dlwp_conv2d_launch_info (what the tests assert ran).
+static inline int wino_x_loader(const ConvArgs& a, int dil, int th, int tw, int waves, int bnf) {
+  if (dil != 1 || th != 8 || tw != 32 || waves != 4 || a.in_bf16 || a.pair_vw || a.ksplit > 1) return 0;
+  if ((a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1)) || a.out_pool == 2) {   // the 9-position variants
+    // halo modes that commute with the 2 x 2 replication, even tile origins
+    const auto commutes = [](int m) { return m == DLWP_PAD_ZERO || m == DLWP_PAD_WRAP || m == DLWP_PAD_EDGE; };
+    return ((a.xld & 2) && a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1) && (a.col0 & 1) == 0 &&
+            a.H == 2 * a.Hs && a.W == 2 * a.Ws && commutes(a.mode_h) && commutes(a.mode_w)) ? 2 : 0;
+  }
+  if (bnf != 2) return 0;
+  // pairs on even image columns: whole inside a row of even length whatever the (zero / periodic) halo does
+  return ((a.xld & 1) && a.src_mode == DLWP_SRC_DIRECT && (a.W & 1) == 0 && a.W >= 2 && a.Ws == a.W &&
+          (a.mode_w == DLWP_PAD_ZERO || a.mode_w == DLWP_PAD_WRAP) && ((a.col0 - a.pad_left - 1) & 1) == 0) ? 1 : 0;
+}
 
 template <class C>
 static void conv_launch_thunk(const ConvArgs& a, int grid, hipStream_t s) {

@@ -42,8 +42,28 @@
 // contribute nothing and their MFMAs (and U fragment loads) are left out -- 9 multiplies per 2x2 output tile and channel
 // pair instead of 16 (direct: 36), bit-identical results.
 template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false, bool UPS_ = false, bool DACT_ = false,
-          bool POOL2_ = false, bool SPLITK_ = false>
+          bool POOL2_ = false, bool SPLITK_ = false, bool PAIRX_ = false, bool UPSQ_ = false>
 struct WinoCfg {
+  // UPSQ (r5): the tile of an UP-SAMPLED source is fetched at SOURCE resolution -- one 4-byte load per source element, written to
+  // the (up to) 2 x 2 tile slots it replicates into: a chunk needs (LR/2 + 1)(LC/2 + 1) = 108 loads per channel instead of 340
+  // (4 per thread and chunk instead of 16; a knock-out of three loads in four bounded the gain at 3.4 % of the 256-member rollout,
+  // DESIGN 5.18).  Tile rows 2 r - 1, 2 r and columns 2 c - 1, 2 c are source element (r, c) (odd halos, even tile origin: host);
+  // rows -1 / LR and columns -1 / LC do not exist: the plane has a dummy row on top (the bottom one is the next plane's top row)
+  // and dummy columns left and right (pitch LC + 2, tile column 0 in slot 2: patch reads stay 8-byte aligned), never read.  The
+  // halo is applied at source resolution: zero / periodic / edge commute with the 2 x 2 replication (host: those modes only).
+  // Same values in the same patch positions as the element-wise UPS instance: the same bits.
+  static constexpr bool UPSQ = UPSQ_;
+  static_assert(!UPSQ_ || (UPS_ && !IN16_ && !SPLITK_ && !PAIRX_), "source-resolution fetch: the float32 up-sampled-source variant");
+  // PAIRX (r5): the input tile is fetched as image-aligned COLUMN PAIRS -- one 8-byte buffer load per two elements, half the loads
+  // of a chunk (the first memory instruction behind an fp32 MFMA costs ~24 cycles of the wave's issue time; a
+  // knock-out of every second load bounded the gain at 3.6 % of the 256-member rollout).  Pairs start on EVEN image columns, so on
+  // an even row length no pair straddles the periodic seam or the zero border: the host takes the instance for float32, plain
+  // sources, even W, zero / periodic column halos and an even first pair column only (wino_launch_either).  The tile is one pair
+  // wider on the left (columns j0 - 2 ...) and sits in LDS at pitch LC + 2 with tile column 0 in slot 2: the patch reads stay
+  // 8-byte aligned, lane t's pair lands in floats 2 t + 1, 2 t + 2 (conflict-free), the plane stride does not grow.  Same
+  // values in the same patch positions: the same bits as the element-wise instance.
+  static constexpr bool PAIRX = PAIRX_;
+  static_assert(!PAIRX_ || (DIL_ == 1 && !IN16_ && !UPS_ && !SPLITK_), "column pairs: dilation 1, float32, plain source");
   // SPLITK (r4, small grids): the input channels are divided over ConvArgs::ksplit workgroups per output tile, each of which
   // multiplies kchunks chunks and leaves its transformed 2x2 outputs (no bias, no activation) in a slab of its own; the workgroup
   // that arrives LAST at the tile's counter sums the slabs in index order -- a fixed order: deterministic -- adds the bias,
@@ -66,14 +86,19 @@ struct WinoCfg {
   static constexpr int LR = TH + 2 * DIL, LC = TW + 2 * DIL;
   // LDS layout of one channel: the DIL*DIL parity sub-lattices de-interleaved, [pi][pj][LR/DIL][LC/DIL] -- the elements of
   // a tile's 4x4 patch (DIL pixels apart in the image) are adjacent in LDS, whatever the dilation
-  static constexpr int LRP = LR / DIL, LCP = LC / DIL;
-  static constexpr int PS_RAW = LR * LC;
+  static constexpr int LRP = LR / DIL, LCP = (PAIRX_ || UPSQ_) ? LC + 2 : LC / DIL;
+  static constexpr int XCOL0 = (PAIRX_ || UPSQ_) ? 2 : 0;   // LDS slot of tile column 0 within a row
+  static constexpr int XROW0 = UPSQ_ ? 1 : 0;                 // ... and LDS row of tile row 0
+  static constexpr int NSR = LR / 2 + 1, NSC = LC / 2 + 1;    // UPSQ: source rows / columns under a tile
+  static constexpr int NQ = UPSQ_ ? (CK_ * NSR * NSC + WAVES_ * 64 - 1) / (WAVES_ * 64) : 0;   // UPSQ: source elements per thread and chunk
+  static constexpr int NPAIR = LC / 2 + 1;             // PAIRX: pairs per tile row (columns -1 ... LC)
+  static constexpr int PS_RAW = UPSQ_ ? (LR + 1) * (LC + 2) : PAIRX_ ? LR * (LC + 2) + 1 : LR * LC;
   static constexpr int PS = PS_RAW + (((16 - PS_RAW % 32) % 32) + 32) % 32;
   static constexpr int RTH = TH / (2 * DIL), RTW = TW / (2 * DIL);  // tiles per parity class
   static constexpr int T = DIL * DIL * RTH * RTW;                      // = TH*TW/4
   static constexpr int TPAD = 16 * WAVES;
   static constexpr int BN = 16 * BNF;
-  static constexpr int X_FLOATS = CK * PS;
+  static constexpr int X_FLOATS = CK * PS + (UPSQ_ ? LC + 6 : 0);   // (UPSQ: the last plane's dummy bottom row)
   // us[xy/4][ci][co][xy%4]; the UPS variants never multiply transformed-filter row 2 (xy/4 == 2): they keep rows 0, 1, 3
   // only, which brings a BNF = 2 block under a third of the CU's LDS (3 blocks per CU at its 143 registers)
   static constexpr int UQ = UPS_ ? 3 : 4;
@@ -83,7 +108,8 @@ struct WinoCfg {
   static constexpr int O2_FLOATS = O_FLOATS + (POOL2_ ? BN * PPS : 0);
   static constexpr int L_FLOATS = (2 * X_FLOATS + 2 * U_FLOATS) > O2_FLOATS ? (2 * X_FLOATS + 2 * U_FLOATS) : O2_FLOATS;
   static constexpr int LDS_BYTES = L_FLOATS * 4;
-  static constexpr int NPOS = (LR * LC + NT - 1) / NT;
+  static constexpr int NPOS = PAIRX_ ? (LR * NPAIR + NT - 1) / NT : (LR * LC + NT - 1) / NT;   // items (elements / pairs) per thread
+  static constexpr int XRW = PAIRX_ ? 2 * NPOS : NPOS;                                          // ... and their registers
   static constexpr int NXI = CK * NPOS;            // input elements per thread and chunk
   static constexpr int NUI = (CK * BN) / NT;       // (ci, co) filter items per thread
   static constexpr int NWI = 4 * NUI;              // float4 filter loads per thread and chunk
@@ -138,9 +164,45 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
   //      slot; the lanes past the tile of the last pass repeat element 0 (same value written twice: harmless)
   unsigned goff[C::NPOS];
   int loff[C::NPOS];
+  int loff1[C::NPOS];     // PAIRX: the pair's second float, in a register of its own (below)
+  // UPSQ: source element k of this thread (channel ci of the chunk, source row r, column c of the tile): byte offset from the
+  // chunk's first plane (channel included: the chunk is selected by the scalar offset) and the LDS slot of tile (2 r - 1, 2 c - 1)
+  unsigned qoff[C::UPSQ ? C::NQ : 1];
+  int qdst[C::UPSQ ? C::NQ : 1], qdst1[C::UPSQ ? C::NQ : 1];
+  if constexpr (C::UPSQ) {
+    const unsigned plane_b = (unsigned)(a.Hs * a.Ws) * 4u;
+    const int vr0 = (i0 - a.pad_top - 1) >> 1, vc0 = (j0 - a.pad_left - 1) >> 1;   // (both differences are even: host)
+#pragma unroll
+    for (int k = 0; k < C::NQ; ++k) {
+      int e = tid + k * C::NT;
+      if (e >= C::CK * C::NSR * C::NSC) e = 0;       // (idle slots repeat element 0: the same value into the same slots)
+      const int ci = e / (C::NSR * C::NSC), rem = e - ci * (C::NSR * C::NSC);
+      const int r = rem / C::NSC, c = rem - r * C::NSC;
+      const int sr = dlwp_map_coord_tile(vr0 + r, a.Hs, a.mode_h), sc = dlwp_map_coord_tile(vc0 + c, a.Ws, a.mode_w);
+      qoff[k] = (sr >= 0 && sc >= 0) ? (unsigned)(sr * a.Ws + sc) * 4u + (unsigned)ci * plane_b : 0x7ffffff0u;
+      qdst[k] = ci * C::PS + 2 * r * C::LCP + 2 * c + 1;
+      qdst1[k] = qdst[k] + 1;                        // (opaque, as loff1 below: no ds_write2_b32 + v_add_u32)
+      asm volatile("" : "+v"(qdst1[k]));
+    }
+  }
 #pragma unroll
   for (int q = 0; q < C::NPOS; ++q) {
     int s = tid + q * C::NT;
+    if constexpr (C::PAIRX) {
+      if (q == C::NPOS - 1 && s >= C::LR * C::NPAIR) s = 0;
+      const int lr = s / C::NPAIR, pp = s - lr * C::NPAIR;
+      const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
+      const int vc = j0 - a.pad_left - 1 + 2 * pp;     // even (host): vc + 1 is its neighbour in memory wherever vc maps to
+      const int cs = (vc < -a.W) ? -1 : dlwp_map_coord_tile(vc, a.W, a.mode_w);
+      goff[q] = (rs >= 0 && cs >= 0) ? (unsigned)(rs * a.Ws + cs) * 4u : 0x7ffffff0u;
+      loff[q] = lr * C::LCP + 2 * pp + 1;
+      // opaque to the compiler: it would merge the two stores of a pair into ds_write2_b32, whose 8-bit offsets cannot reach a
+      // channel plane -- one v_add_u32 per store for the base, i.e. eight more switches between the matrix pipe and the vector ALU
+      // per chunk; two ds_write_b32 carry the plane offset in their 16-bit immediates
+      loff1[q] = loff[q] + 1;
+      asm volatile("" : "+v"(loff1[q]));
+      continue;
+    }
     if (q == C::NPOS - 1 && s >= C::LR * C::LC) s = 0;
     const int lr = s / C::LC, lc = s - lr * C::LC;
     const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
@@ -180,7 +242,7 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
     const int pc = tt / (C::RTH * C::RTW), rem = tt - pc * (C::RTH * C::RTW);
     const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
     const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
-    v_src = (lane >> 4) * C::PS + ((pi * C::DIL + pj) * C::LRP + ti * 2) * C::LCP + tj * 2;
+    v_src = (lane >> 4) * C::PS + ((pi * C::DIL + pj) * C::LRP + ti * 2 + C::XROW0) * C::LCP + tj * 2 + C::XCOL0;
   }
   // ---- filter items -> (ci, co): byte offset in the transformed filter (chunk 0, xy quad 0) and LDS slot
   unsigned u_off[C::NUI];
@@ -206,7 +268,8 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
     for (int g = 0; g < C::BNF; ++g)
       if (!(C::UPS && (xy / 4 == 2 || xy % 4 == 2))) acc[xy][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float xr[C::CK][C::NPOS];
+  float xr[C::CK][C::XRW];
+  float xq[C::UPSQ ? C::NQ : 1];
   f32x4 ur[C::NUI][2];  // two xy quads at a time: (0,1) loaded a chunk ahead, (2,3) half a chunk ahead
   // element i of the chunk starting at channel c0 (uniform; clamped to the last chunk).  ONE buffer descriptor for the
   // sample's channel window (num_records = Cin planes); the channel is selected by the SCALAR offset, so a load costs one
@@ -223,7 +286,11 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
   auto load_x = [&](int c0, int i) {
     const int ci = i / C::NPOS, q = i - ci * C::NPOS;
     const unsigned soff = (unsigned)(min(c0, last_c0) + ci) * plane_bytes;
-    if constexpr (C::IN16)  // 16 raw bits (0 out of range), widened when they are written to LDS
+    if constexpr (C::PAIRX) {
+      const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, goff[q], soff, 0));
+      xr[ci][2 * q] = v.x;
+      xr[ci][2 * q + 1] = v.y;
+    } else if constexpr (C::IN16)  // 16 raw bits (0 out of range), widened when they are written to LDS
       xr[ci][q] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(x_rsrc, goff[q], soff, 0));
     else
       xr[ci][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], soff, 0));
@@ -235,7 +302,18 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
   };
   auto stage_x = [&](int xdst, int i) {
     const int ci = i / C::NPOS, q = i - ci * C::NPOS;
-    lds[xdst + ci * C::PS + loff[q]] = C::IN16 ? bf16_bits_to_f32(__builtin_bit_cast(unsigned, xr[ci][q])) : xr[ci][q];
+    if constexpr (C::PAIRX) {   // (two 4-byte writes: the pair starts on an odd float)
+      lds[xdst + ci * C::PS + loff[q]] = xr[ci][2 * q];
+      lds[xdst + ci * C::PS + loff1[q]] = xr[ci][2 * q + 1];
+    } else
+      lds[xdst + ci * C::PS + loff[q]] = C::IN16 ? bf16_bits_to_f32(__builtin_bit_cast(unsigned, xr[ci][q])) : xr[ci][q];
+  };
+  auto load_q = [&](int c0, int k) {      // UPSQ: source element k of the chunk starting at channel c0
+    xq[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, qoff[k], (unsigned)min(c0, last_c0) * plane_bytes, 0));
+  };
+  auto stage_q = [&](int xdst, int j) {   // ... into slot j & 3 of element j >> 2: (row, column) = (j >> 1 & 1, j & 1)
+    const int k = j >> 2;
+    lds[xdst + ((j & 1) ? qdst1[k] : qdst[k]) + ((j >> 1) & 1) * C::LCP] = xq[k];
   };
   auto stage_u = [&](int udst, int k, int r) {
     if (C::UPS && r == 2) return;
@@ -285,8 +363,13 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
   //      Every global load of chunk 0 -- the input tile AND all four filter quads -- is in flight before the first wait
   //      (the loop's two filter staging slots would serialise three memory latencies here; the prologue has the registers
   //      for all four quads, nothing else is live yet).
+  if constexpr (C::UPSQ) {
 #pragma unroll
-  for (int i = 0; i < C::NXI; ++i) load_x(0, i);
+    for (int k = 0; k < C::NQ; ++k) load_q(0, k);
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::NXI; ++i) load_x(0, i);
+  }
   {
     f32x4 up[C::NUI][4];
 #pragma unroll
@@ -295,8 +378,13 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
       for (int r = 0; r < 4; ++r)
         if (!(C::UPS && r == 2))
           up[k][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_off[k], r * a.Cout * 16, 0));
+    if constexpr (C::UPSQ) {
 #pragma unroll
-    for (int i = 0; i < C::NXI; ++i) stage_x(0, i);
+      for (int j = 0; j < 4 * C::NQ; ++j) stage_q(0, j);
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NXI; ++i) stage_x(0, i);
+    }
 #pragma unroll
     for (int k = 0; k < C::NUI; ++k)
 #pragma unroll
@@ -305,8 +393,13 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
           *(f32x4*)(lds + US0 + u_dst[k] + (C::UPS && r == 3 ? 2 : r) * C::CK * C::BN * 4) = up[k][r];
   }
   __syncthreads();
+  if constexpr (C::UPSQ) {
 #pragma unroll
-  for (int i = 0; i < C::NXI; ++i) load_x(C::CK, i);
+    for (int k = 0; k < C::NQ; ++k) load_q(C::CK, k);
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::NXI; ++i) load_x(C::CK, i);
+  }
 #pragma unroll
   for (int h = 0; h < 2 * C::NUI; ++h) load_u(C::CK, h >> 1, h & 1);
 #pragma unroll
@@ -331,8 +424,13 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
       if (s < 8) vt_read(xcur, 1, s);   // (one 8-byte read per step: two per step merge into ds_read2_b64, whose 8-bit offsets need a
                                         //  v_add_u32 for the base -- a vector instruction, i.e. a pipe switch, per step)
       if (s >= 8 && s < 24) {  // registers (chunk k+1) -> xs[nxt]
+        if constexpr (C::UPSQ) {
 #pragma unroll
-        for (int i = (s - 8) * C::NXI / 16; i < (s - 7) * C::NXI / 16; ++i) stage_x(xnxt, i);
+          for (int j = (s - 8) * (4 * C::NQ) / 16; j < (s - 7) * (4 * C::NQ) / 16; ++j) stage_q(xnxt, j);
+        } else {
+#pragma unroll
+          for (int i = (s - 8) * C::NXI / 16; i < (s - 7) * C::NXI / 16; ++i) stage_x(xnxt, i);
+        }
       }
       // r5: the fp32 matrix pipe and the vector ALU exclude each other AND a switch between them costs ~11 cycles on top of the issue
       // slots (tools/microbench/mfma_bf16_interleave.hip: the first vector instruction behind an MFMA 15.4 cycles, every further
@@ -349,7 +447,9 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
         const int h = s - 8 - 2 * C::NUI;
         load_u(c0 + C::CK, h >> 1, 2 + (h & 1));
       }
-      if (s >= 24) {  // chunk k+2 -> registers (first third)
+      if constexpr (C::UPSQ) {  // chunk k+2 -> registers: the NQ loads, one every second step (their registers are free from s = 24)
+        if (s >= 24 && s < 24 + 2 * C::NQ && (s & 1) == 0) load_q(c0 + 2 * C::CK, (s - 24) >> 1);
+      } else if (s >= 24) {  // chunk k+2 -> registers (first third)
 #pragma unroll
         for (int i = (s - 24) * C::NXI / 24; i < (s - 23) * C::NXI / 24; ++i) load_x(c0 + 2 * C::CK, i);
       }
@@ -385,7 +485,7 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
 #pragma unroll
         for (int r_ = 0; r_ < 4; ++r_) vt_cols(0, r_);
       }
-      if (s < 16) {  // chunk k+2 -> registers (the rest of the input, then the filters)
+      if (!C::UPSQ && s < 16) {  // chunk k+2 -> registers (the rest of the input, then the filters)
 #pragma unroll
         for (int i = (s + 8) * C::NXI / 24; i < (s + 9) * C::NXI / 24; ++i) load_x(c0 + 2 * C::CK, i);
       }
@@ -890,18 +990,33 @@ static void wino_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
     // positions with a row / column index 2 are never needed: the source makes them zero (up-sampled, odd halo) or the
     // 2x2 sum epilogue does not read them
     if ((a.src_mode == DLWP_SRC_UPSAMPLE2 && (a.pad_top & 1) && (a.pad_left & 1)) || a.out_pool == 2) {
+      if constexpr (TH == 8 && TW == 32 && WAVES == 4) {
+        if (wino_x_loader(a, DIL, TH, TW, WAVES, BNF) == 2) {   // source-resolution fetch (WinoCfg::UPSQ)
+          wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, true, false, false, false, false, true>>(a, grid, s);
+          return;
+        }
+      }
       if (a.in_bf16) wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true, true>>(a, grid, s);
       else wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, true>>(a, grid, s);
       return;
     }
   }
   if constexpr (DIL == 1 && TH == 8 && TW == 32 && WAVES == 4 && BNF == 2) {
+    const bool pairs = wino_x_loader(a, DIL, TH, TW, WAVES, BNF) == 1;   // column pairs (WinoCfg::PAIRX)
     if (a.yact) {   // (the host sends only float32, plain-source, unpooled launches here: conv_bwd.hip)
-      wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true>>(a, grid, s);
+      if (pairs) wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true, false, false, true>>(a, grid, s);
+      else wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true>>(a, grid, s);
       return;
     }
     if (a.y2) {     // dlwp_conv2d_fwd_pool2 (conv_fwd.hip: float32, plain source)
-      wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true>>(a, grid, s);
+      if (pairs) wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true, false, true>>(a, grid, s);
+      else wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true>>(a, grid, s);
+      return;
+    }
+  }
+  if constexpr (DIL == 1 && TH == 8 && TW == 32 && WAVES == 4 && BNF == 2) {
+    if (wino_x_loader(a, DIL, TH, TW, WAVES, BNF) == 1) {   // column pairs (WinoCfg::PAIRX)
+      wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, false, false, true>>(a, grid, s);
       return;
     }
   }
@@ -916,10 +1031,16 @@ static int wino_prepare_both() {
   if constexpr (DIL == 1) {
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, true>>();
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, true, true>>();
+    if constexpr (TH == 8 && TW == 32 && WAVES == 4) {
+      if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, true, false, false, false, false, true>>();
+    }
   }
   if constexpr (DIL == 1 && TH == 8 && TW == 32 && WAVES == 4 && BNF == 2) {
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true>>();
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true>>();
+    if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, false, false, true>>();
+    if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true, false, false, true>>();
+    if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true, false, true>>();
   }
   if constexpr (WinoSplitK<DIL, TH, TW, WAVES, BNF>::value) {
     if (e == 0) e = WinoSplitK<DIL, TH, TW, WAVES, BNF>::prepare();

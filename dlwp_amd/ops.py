@@ -393,13 +393,14 @@ def conv_configs():
 
 def conv_launch_info(x_shape, cd, dtype=None, device_index=0):
     """What conv2d on a stored input of shape (n, cin, h, w) launches: [(config index, grid, block threads, executed
-    matrix-core FLOPs, on the bf16 matrix cores?)], one entry per kernel launch (dlwp_conv2d_launch_info)."""
+    matrix-core FLOPs, on the bf16 matrix cores?, input loader of a Winograd 8 x 32 launch: 0 elements / 1 column pairs / 2 source
+    resolution)], one entry per kernel launch (dlwp_conv2d_launch_info)."""
     out = (_lib.LaunchInfo * 2)()
     n = ctypes.c_int(0)
     _lib.check(_lib.lib.dlwp_conv2d_launch_info(_lib.handle(device_index), Shape4(*[int(v) for v in x_shape]),
                                                 ctypes.byref(cd), _lib.F32 if dtype is None else int(dtype), out,
                                                 ctypes.byref(n)))
-    return [(o.config, o.grid, o.block_threads, o.matrix_flops, bool(o.bf16_matrix)) for o in out[:n.value]]
+    return [(o.config, o.grid, o.block_threads, o.matrix_flops, bool(o.bf16_matrix), int(o.x_loader)) for o in out[:n.value]]
 
 
 def force_conv_config(i):
@@ -410,6 +411,13 @@ def set_few_stream(mode):
     """DLWP_OPT_FEW_STREAM: the streaming kernel for pooled 3x3 layers of at most four input channels (csrc/conv_fwd_few.hip):
     0 never, 1 from 8 tiles per workgroup on (default), 2 whenever the layer qualifies.  Returns the previous setting."""
     return int(_lib.set_option(_lib.OPT_FEW_STREAM, int(mode)))
+
+
+def set_wino_xloader(mask):
+    """DLWP_OPT_WINO_XLOADER: which input loaders the Winograd 8 x 32 instances may take -- bit 0 image-aligned column pairs, bit 1 an
+    up-sampled source at source resolution; 3 = both (default), 0 = element by element.  The same bits whatever the setting.  Returns
+    the previous setting."""
+    return int(_lib.set_option(_lib.OPT_WINO_XLOADER, int(mask)))
 
 
 def set_splitk(mode):

@@ -1326,3 +1326,62 @@ def test_phase_weights_adjoint_and_space_to_depth(ops, k, pt, pl):
     y = rng.standard_normal((2, 4 * cout, 5, 7)).astype(np.float32)
     hi = ops.depth_to_space2(dev(y), cout)
     assert np.array_equal(host(ops.space_to_depth2(hi, cout)), y)
+
+
+XLD_CASES = [
+    # (n, cin, h, w of the STORED input, cout, mode_h, mode_w, src_mode, loader the launch must take)
+    (3, 16, 11, 23, 64, 0, 1, 1, 2),    # up-sampled 11 x 23 -> 22 x 46: ragged tiles both ways, zero rows / periodic columns
+    (2, 24, 22, 45, 32, 1, 1, 1, 2),    # the U-Net's layer-4 source size, periodic both ways, three chunks
+    (2, 8, 9, 20, 64, 2, 0, 1, 2),      # edge rows, zero columns
+    (2, 16, 5, 16, 32, 0, 2, 1, 2),     # edge columns, one tile row
+    (2, 8, 6, 10, 32, 4, 4, 1, 0),      # SYMMETRIC halo: does not commute with the replication -> element by element
+    (3, 16, 13, 46, 32, 0, 1, 0, 1),    # plain source, even width: column pairs, ragged last column tile
+    (2, 32, 44, 90, 64, 0, 1, 0, 1),    # the dominant layer's geometry (two 32-channel tiles)
+    (2, 8, 10, 34, 32, 2, 0, 0, 1),     # zero columns, edge rows
+    (2, 8, 12, 64, 32, 1, 1, 0, 1),     # whole tiles, periodic both ways
+    (2, 8, 12, 45, 32, 0, 1, 0, 0),     # odd width: a pair would straddle the seam -> element by element
+    (2, 8, 12, 20, 32, 0, 3, 0, 0),     # REFLECT columns -> element by element
+]
+
+
+@pytest.mark.parametrize('case', XLD_CASES)
+def test_winograd_input_loaders_give_the_bits_of_the_element_wise_loader(ops, case):
+    """DLWP_OPT_WINO_XLOADER (r5): the 8 x 32 Winograd instances fetch a plain source of even width as image-aligned column pairs
+    (WinoCfg::PAIRX) and an up-sampled source at source resolution (WinoCfg::UPSQ).  Same values in the same patch positions: the
+    launch must give the BITS of the element-wise loader -- on ragged tiles, every halo mode the loaders accept, several chunks --,
+    dlwp_conv2d_launch_info must name the loader that ran, and the result is the float64 oracle's."""
+    n, cin, h, w, cout, mh, mw, src, want_loader = case
+    rng = np.random.default_rng(7000 + XLD_CASES.index(case))
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, mh, mw), ops.ACT_TANH, src_mode=src)
+    cfgs = ops.conv_configs()
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    ran = 0
+    try:
+        for bnf in (2, 4):
+            idx = [i for i, c in enumerate(cfgs) if c[:8] == (3, 1, 8, 32, 4, 0, bnf, 8) and not (c[10] & 1)]
+            if not idx or cout % (16 * bnf):
+                continue
+            if bnf == 4 and src != 1:
+                continue                               # (64-channel blocks exist for the 9-position variants only)
+            ops.force_conv_config(idx[0])
+            prev = ops.set_wino_xloader(0)
+            try:
+                info0 = ops.conv_launch_info(x.shape, cd)
+                base = ops.conv2d(xd, wd, bd, cd)
+                ops.set_wino_xloader(3)
+                info = ops.conv_launch_info(x.shape, cd)
+                got = ops.conv2d(xd, wd, bd, cd)
+            finally:
+                ops.set_wino_xloader(prev)
+            assert info0[0][0] == idx[0] and info0[0][5] == 0, info0
+            assert info[0][0] == idx[0] and info[0][5] == want_loader, (info, want_loader)
+            assert torch.equal(got, base), (case, bnf, float((got - base).abs().max()))
+            ran += 1
+    finally:
+        ops.force_conv_config(-1)
+    assert ran >= 1
+    want = _conv_ref(x, wt, b, 1, (1, 1, 1, 1), mh, mw, 'tanh', src)
+    _check_conv(ops, host(got), want, 'winograd loader %d' % want_loader)
