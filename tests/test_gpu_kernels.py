@@ -1341,6 +1341,10 @@ XLD_CASES = [
     (2, 8, 12, 64, 32, 1, 1, 0, 1),     # whole tiles, periodic both ways
     (2, 8, 12, 45, 32, 0, 1, 0, 0),     # odd width: a pair would straddle the seam -> element by element
     (2, 8, 12, 20, 32, 0, 3, 0, 0),     # REFLECT columns -> element by element
+    (2, 8, 7, 12, 32, 1, 1, 1, 2, (3, 1, 1, 3)),   # up-sampled, halos of 3 (top) and 3 (right): the window starts two source rows out
+    (2, 8, 7, 12, 32, 2, 0, 1, 2, (1, 3, 3, 1)),   # ... 3 on the left under a zero halo, edge rows
+    (2, 8, 10, 36, 32, 0, 1, 0, 1, (1, 1, 3, 3)),  # plain source, column halo of 3: pairs start three columns out
+    (2, 8, 10, 36, 32, 0, 1, 0, 0, (1, 1, 2, 2)),  # even column halo: the first pair would start on an odd column -> element by element
 ]
 
 
@@ -1350,12 +1354,13 @@ def test_winograd_input_loaders_give_the_bits_of_the_element_wise_loader(ops, ca
     (WinoCfg::PAIRX) and an up-sampled source at source resolution (WinoCfg::UPSQ).  Same values in the same patch positions: the
     launch must give the BITS of the element-wise loader -- on ragged tiles, every halo mode the loaders accept, several chunks --,
     dlwp_conv2d_launch_info must name the loader that ran, and the result is the float64 oracle's."""
-    n, cin, h, w, cout, mh, mw, src, want_loader = case
+    n, cin, h, w, cout, mh, mw, src, want_loader = case[:9]
+    pads = case[9] if len(case) > 9 else (1, 1, 1, 1)
     rng = np.random.default_rng(7000 + XLD_CASES.index(case))
     x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
     wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
     b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
-    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, mh, mw), ops.ACT_TANH, src_mode=src)
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(*pads, mh, mw), ops.ACT_TANH, src_mode=src)
     cfgs = ops.conv_configs()
     xd, wd, bd = dev(x), dev(wt), dev(b)
     ran = 0
@@ -1383,5 +1388,5 @@ def test_winograd_input_loaders_give_the_bits_of_the_element_wise_loader(ops, ca
     finally:
         ops.force_conv_config(-1)
     assert ran >= 1
-    want = _conv_ref(x, wt, b, 1, (1, 1, 1, 1), mh, mw, 'tanh', src)
+    want = _conv_ref(x, wt, b, 1, pads, mh, mw, 'tanh', src)
     _check_conv(ops, host(got), want, 'winograd loader %d' % want_loader)
