@@ -70,13 +70,11 @@ static void run(const char* what, int N, int Cin, int Cout, int H, int W, int ta
 }
 
 int main() {
-  run<WgCbCfg<4, 32, 2, 2, 2>>("layer 2 weight gradient 32->64 @44x90, batch 64, 32x64 block", 64, 32, 64, 44, 90, 512);
-  run<WgCbCfg<4, 32, 2, 2, 1>>("layer 2, 32x32 block", 64, 32, 64, 44, 90, 512);
-  run<WgCbCfg<4, 32, 2, 4, 1>>("layer 2, 32x64 block, 8 waves", 64, 32, 64, 44, 90, 256);
-  run<WgCbCfg<8, 16, 4, 2, 2>>("layer 3 weight gradient 64->128 @22x45, batch 64, 64x64 block", 64, 64, 128, 22, 45, 256);
-  run<WgCbCfg<4, 32, 4, 2, 2>>("layer 4-like 128->64 @44x90 (plain source), 64x64 block", 64, 128, 64, 44, 90, 256);
+  // the instances the batch-64 step of config 3 runs (profiles/r5_train_b64_single_stream_kernel_stats.csv)
+  run<WgCbCfg<4, 32, 2, 2, 1>>("layer 2 weight gradient 32->64 @44x90, batch 64, 32x32 block, 4 waves", 64, 32, 64, 44, 90, 512);
+  run<WgCbCfg<8, 16, 4, 2, 1>>("layer 3 weight gradient 64->128 @22x45, 64x32 block, 8 waves", 64, 64, 128, 22, 45, 256);
+  run<WgCbCfg<4, 32, 4, 2, 1>>("layer 5 weight gradient 64->32 @88x180 (plain source), 64x32 block, 8 waves", 64, 64, 32, 88, 180, 256);
   run<WgCbCfg<4, 32, 4, 2, 2, true>>("layer 4 weight gradient 128->64 @44x90 on the up-sampled 22x45 source (9 positions), 64x64 block", 64, 128, 64, 44, 90, 256, true);
-  run<WgCbCfg<4, 32, 2, 4, 1, true>>("layer 4, 32x64 block, 8 waves", 64, 128, 64, 44, 90, 256, true);
-  run<WgCbCfg<4, 32, 4, 2, 2>>("64->64 @44x88 (aligned rows: pixel-quad dz loads), 64x64 block", 64, 64, 64, 44, 88, 256);
+  run<WgCbCfg<4, 32, 4, 2, 2>>("layer 4-like 128->64 @44x90 (plain source), 64x64 block", 64, 128, 64, 44, 90, 256);
   return 0;
 }
