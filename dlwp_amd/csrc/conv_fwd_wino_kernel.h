@@ -54,6 +54,10 @@ struct WinoCfg {
   // Same values in the same patch positions as the element-wise UPS instance: the same bits.
   static constexpr bool UPSQ = UPSQ_;
   static_assert(!UPSQ_ || (UPS_ && !IN16_ && !SPLITK_ && !PAIRX_), "source-resolution fetch: the float32 up-sampled-source variant");
+  // (the loop issues the NQ loads of a chunk in steps 24, 26 ... of a channel group's 16 BNF steps; the host offers the instance for
+  //  the 8 x 32 tile only -- on the smaller tile shapes it measured no faster)
+  static_assert(!UPSQ_ || (24 + 2 * ((CK_ * ((TH_ + 2) / 2 + 1) * ((TW_ + 2) / 2 + 1) + WAVES_ * 64 - 1) / (WAVES_ * 64)) <= 16 * BNF_),
+                "source-resolution fetch: at most (16 BNF - 24) / 2 source elements per thread and chunk");
   // PAIRX (r5): the input tile is fetched as image-aligned COLUMN PAIRS -- one 8-byte buffer load per two elements, half the loads
   // of a chunk (the first memory instruction behind an fp32 MFMA costs ~24 cycles of the wave's issue time; a
   // knock-out of every second load bounded the gain at 3.6 % of the 256-member rollout).  Pairs start on EVEN image columns, so on
