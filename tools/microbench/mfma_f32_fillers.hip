@@ -42,6 +42,8 @@ __global__ __launch_bounds__(256) void probe(float* out, const float* in, int it
         if (FILL == 2) asm volatile("ds_write_b64 %0, %1 offset:2048" ::"v"(la), "v"(d[(i * K + f) & 7]));
         if (FILL == 3) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
         if (FILL == 4) asm volatile("global_load_dword %0, %1, off" : "=v"(g[(i * K + f) & 7]) : "v"(gp));
+        if (FILL == 5) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(i * K + f) & 7]));
+        if (FILL == 6) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[(i * K + f) & 7]));
       }
     }
     if (FILL == 1 || FILL == 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -51,6 +53,38 @@ __global__ __launch_bounds__(256) void probe(float* out, const float* in, int it
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3] + v[i] + d[i][0] + d[i][1] + g[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s + lds[(threadIdx.x * 7) & 4095];
+}
+
+// two waves per SIMD: waves 0-3 of the workgroup run ROLE_A, waves 4-7 ROLE_B (0 nothing, 1 MFMAs, 2 v_exp_f32, 3 v_fma_f32)
+template <int ROLE_A, int ROLE_B>
+__global__ __launch_bounds__(512) void probe2(float* out, int iters, float seed) {
+  f32x4 acc[8];
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = (f32x4){seed, seed, seed, seed};
+    v[i] = seed * 0.001f + i * 0.01f;
+  }
+  const float a = seed * 0.5f, b = seed * 0.25f;
+  const int role = (threadIdx.x >> 8) ? ROLE_B : ROLE_A;     // (wave-uniform)
+  if (role == 1) {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+  } else if (role == 2) {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i & 7]));
+  } else if (role == 3) {
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 64; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i & 7]) : "v"(a), "v"(b));
+  }
+  asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3] + v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
 static double g_ghz = 2.4;
@@ -90,6 +124,40 @@ static void sweep(const char* what) {
   run<FILL, 4>(what);
 }
 
+template <int A, int B>
+static float run2(const char* what) {
+  float* out;
+  hipMalloc(&out, sizeof(float) * 256 * 512);
+  const int iters = 4000;
+  probe2<A, B><<<256, 512>>>(out, iters, 1.0f);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float best = 1e9f;
+  for (int r = 0; r < 3; ++r) {
+    hipEventRecord(e0);
+    probe2<A, B><<<256, 512>>>(out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  printf("two waves per SIMD | %-58s | wall %.3f ms\n", what, best);
+  hipFree(out);
+  return best;
+}
+// per iteration: the MFMA wave issues 8 MFMAs (256 cycles), the other wave 16 v_exp_f32 (256 cycles at a quarter rate) or 64 v_fma_f32
+static void cross() {
+  run2<1, 0>("wave A: 8 MFMA per iteration, wave B idle");
+  run2<0, 2>("wave A idle, wave B: 16 v_exp_f32 per iteration");
+  run2<1, 2>("wave A: MFMAs, wave B: v_exp_f32 (sum = exclusive, max = overlap)");
+  run2<0, 3>("wave A idle, wave B: 64 v_fma_f32 per iteration");
+  run2<1, 3>("wave A: MFMAs, wave B: v_fma_f32");
+  run2<2, 2>("both waves: v_exp_f32");
+}
+
 int main() {
   hipDeviceProp_t p;
   hipGetDeviceProperties(&p, 0);
@@ -100,5 +168,8 @@ int main() {
   sweep<2>("ds_write_b64");
   sweep<3>("s_add_u32");
   sweep<4>("global_load_dword");
+  sweep<5>("v_exp_f32");
+  sweep<6>("v_rcp_f32");
+  cross();
   return 0;
 }
