@@ -367,7 +367,9 @@ def roofline_of(rows, members):
     if len(variants) == 1:
         out['kernel'] = variants[0]
     else:
-        out['kernel'] = sym + ', *, *> >'
+        # `kernel` stays a symbol rocprofv3 prints (the variant with the largest share); the figures are the family's
+        out['kernel'] = max(variants, key=lambda v: sum(r['ms'] for r in rs if r['kernel'] == v))
+        out['kernel_family'] = sym + ', *, *> >'
         out['instances'] = {v: [r['layer'] for r in rs if r['kernel'] == v] for v in variants}
         out['instances_note'] = ('one tile configuration, one loop, the same bits; the last two template arguments pick the input '
                                  'loader (DLWP_OPT_WINO_XLOADER: image-aligned column pairs on even widths, element by element '
