@@ -411,9 +411,12 @@ def cpu_baseline(grid, cin, forwards, weights, budget_s=12.0):
     for nt in sorted({min(ncpu, v) for v in (8, 16, 32, 64, 128, ncpu)}):
         torch.set_num_threads(nt)
         torch_ref.rollout_host_loop(layers, tw, x, 1)
-        ts = time.time()
-        torch_ref.rollout_host_loop(layers, tw, x, 1)
-        per = time.time() - ts
+        per = None                                       # best of three: one noisy call used to pick 64 threads on a busy node
+        for _ in range(3):                               # and then measure 130 steps/s where 16 threads give 300-440
+            ts = time.time()
+            torch_ref.rollout_host_loop(layers, tw, x, 1)
+            dt_ = time.time() - ts
+            per = dt_ if per is None else min(per, dt_)
         if best is None or per < best[0]:
             best = (per, nt)
         if time.time() - t1 > 0.6 * budget_s:
