@@ -269,6 +269,31 @@ def set_option(option, value, device_index=None):
     return prev.value
 
 
+# Destruction of library objects that own hipGraphs / streams / events (dlwp_train_step_t, dlwp_rollout_t) is never done from a
+# finaliser: the garbage collector runs finalisers at arbitrary points -- in the middle of a step that is being recorded, between two
+# launches of another graph, under a DeviceLoader worker's copies -- and dlwp_*_destroy synchronises the device and tears down graphs,
+# streams and events there (r4: a fault in hipGraphLaunch of a LATER graph; r5: one abort() inside a collection during _record_step in
+# ~15 runs of the GPU suite).  A finaliser BURIES the handle; the owner of the next safe point -- the start of a training step, of a
+# rollout capture, an explicit close() -- drains the graveyard.
+_graveyard = []
+
+
+def bury(kind, h):
+    """from a finaliser: remember `h` ('step' | 'rollout') for destruction at the next safe point"""
+    if h is not None:
+        _graveyard.append((kind, h))
+
+
+def drain_graveyard():
+    """at a safe point (nothing of ours is being recorded or captured on this thread): destroy what finalisers buried"""
+    while _graveyard:
+        kind, h = _graveyard.pop()
+        try:
+            (lib.dlwp_train_step_destroy if kind == 'step' else lib.dlwp_rollout_destroy)(h)
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def handle(device_index=0):
     """One library handle per device, created on first use.  Raises DlwpError when there is no gfx950 GPU."""
     h = _handles.get(device_index)

@@ -377,6 +377,7 @@ class Executor(object):
         behind the other on a stream (StreamedRollout).  ws: the prepared-weights workspace to use (slices of one member count
         share it); prepared: the slice launched in front has filled it."""
         from . import _lib, ops
+        _lib.drain_graveyard()          # a safe point: nothing is being captured yet
         n_total = int(state0.shape[0])
         n = n_total if chain is None else n_total // int(chain[1])
         first = 0 if chain is None else int(chain[0]) * n
@@ -527,9 +528,11 @@ class RolloutGraph(object):
             _lib.lib.dlwp_rollout_destroy(self._h)
             self._h = None
 
-    def __del__(self):
+    def __del__(self):      # (never destroys here: _lib.bury -- the next rollout capture or training step drains the graveyard)
         try:
-            self.close()
+            from . import _lib
+            _lib.bury('rollout', self._h)
+            self._h = None
         except Exception:  # noqa: BLE001
             pass
 
@@ -556,12 +559,7 @@ class StreamedRollout(object):
         for g in self.head + self.tail:
             g.close()
         self.head, self.tail = [], []
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:  # noqa: BLE001
-            pass
+    # (no finaliser: the graphs bury themselves, RolloutGraph.__del__)
 
 
 class SplitRollout(object):
@@ -586,12 +584,7 @@ class SplitRollout(object):
         for g in self._graphs:
             g.close()
         self._graphs = []
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:  # noqa: BLE001
-            pass
+    # (no finaliser: the graphs bury themselves, RolloutGraph.__del__)
 
 
 class Model(object):

@@ -119,12 +119,17 @@ class _StepHandle(object):
     def __init__(self, h):
         self.h = h
 
-    def __del__(self):
+    def close(self):
+        from . import _lib
+        if self.h is not None:
+            _lib.lib.dlwp_train_step_destroy(self.h)
+            self.h = None
+
+    def __del__(self):      # (never destroys here: _lib.bury)
         try:
             from . import _lib
-            if self.h is not None:
-                _lib.lib.dlwp_train_step_destroy(self.h)
-                self.h = None
+            _lib.bury('step', self.h)
+            self.h = None
         except Exception:  # noqa: BLE001
             pass
 
@@ -1132,6 +1137,8 @@ class Trainer(object):
     def _graph_step(self, x, ys, n_global, scale, dp):
         """Replays (capturing first, if needed) the step for this batch shape.  Returns the device loss table, or None when
         this shape has not been seen often enough yet (the caller then runs the step eagerly)."""
+        from . import _lib
+        _lib.drain_graveyard()          # a safe point: nothing is being recorded or replayed yet
         from . import ops
         opt = self.model.optimizer
         # the captured launches carry the optimizer's hyper-parameters as arguments: a changed rate (scheduler, callback,
