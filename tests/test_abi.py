@@ -208,3 +208,40 @@ def test_crash_message_reaches_stdout_when_the_process_aborts():
     p = subprocess.run([sys.executable, '-c', code % (root, '_lib.lib.dlwp_set_crash_message(None)\n')], capture_output=True, text=True,
                        timeout=120)
     assert p.returncode != 0 and 'parked' not in p.stdout
+
+
+def test_finalisers_bury_and_safe_points_drain():
+    """dlwp_amd/_lib.py: objects that own hipGraphs are never destroyed from a finaliser -- __del__ buries the handle, the next safe
+    point drains the graveyard.  (Host logic: a null handle is what dlwp_*_destroy accepts without a GPU.)"""
+    import ctypes
+    from dlwp_amd import _lib
+    from dlwp_amd.training import _StepHandle
+    from dlwp_amd.engine import RolloutGraph
+    _lib.drain_graveyard()
+    assert _lib._graveyard == []
+    _lib.bury('step', None)                                   # nothing to bury
+    assert _lib._graveyard == []
+    s, g = _StepHandle(ctypes.c_void_p(0)), RolloutGraph(ctypes.c_void_p(0), None, None)
+    del s, g                                                  # the finalisers run here: nothing is destroyed, two handles wait
+    assert sorted(k for k, _ in _lib._graveyard) == ['rollout', 'step']
+    _lib.drain_graveyard()
+    assert _lib._graveyard == []
+    g = RolloutGraph(ctypes.c_void_p(0), None, None)
+    g.close()                                                 # an explicit close destroys at once and leaves nothing behind
+    del g
+    assert _lib._graveyard == []
+
+
+def test_bench_counts_the_loader_variants_of_one_tile_configuration_as_one_kernel():
+    """bench.py's roofline groups the input-loader variants of a Winograd tile configuration (same loop, same bits): the family
+    name is a prefix of every variant's symbol, other kernels are their own family."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cfg = (3, 1, 8, 32, 4, 0, 2, 8, 0, 0, 0)
+    syms = [bench.config_symbol(cfg, x_loader=k) for k in (0, 1)]
+    fam = {bench.kernel_family(s) for s in syms}
+    assert len(fam) == 1 and all(s.startswith(next(iter(fam))) for s in syms) and syms[0] != syms[1]
+    ups = bench.config_symbol((3, 1, 8, 32, 4, 0, 4, 8, 0, 0, 0), ups=True, x_loader=2)
+    assert bench.kernel_family(ups) not in fam and ups.startswith(bench.kernel_family(ups))
+    assert bench.kernel_family('conv2d_fwd_few_f32<2, ') == 'conv2d_fwd_few_f32<2, '
