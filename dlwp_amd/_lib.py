@@ -69,6 +69,16 @@ class Op(ctypes.Structure):
                 ('src2', ctypes.c_int), ('w2', ctypes.c_int), ('xs2_c', ctypes.c_int), ('conv2', Conv2d)]
 
 
+FB_MAX_CHANNELS = 128
+
+
+class Feedback(ctypes.Structure):
+    """dlwp_feedback (include/dlwp_hip.h): the state update between two model calls of a fed rollout"""
+    _fields_ = [('rows', ctypes.c_int), ('state_c', ctypes.c_int), ('out_c', ctypes.c_int), ('hw', ctypes.c_int),
+                ('shift', ctypes.c_int), ('tail', ctypes.c_int), ('sol_planes', ctypes.c_int),
+                ('src', ctypes.c_int * FB_MAX_CHANNELS), ('sol', ctypes.c_int * FB_MAX_CHANNELS)]
+
+
 class LaunchInfo(ctypes.Structure):
     _fields_ = [('config', ctypes.c_int), ('grid', ctypes.c_int), ('block_threads', ctypes.c_int),
                 ('matrix_flops', ctypes.c_double), ('bf16_matrix', ctypes.c_int), ('x_loader', ctypes.c_int)]
@@ -207,6 +217,8 @@ _sig('dlwp_series_merge_time', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp])
 _sig('dlwp_rollout_workspace_bytes', [_vp, _P(Op), _i, _i], _sz)
 _sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _vp, _sz, _P(_vp)])
 _sig('dlwp_rollout_create_grouped', [_vp, _P(Op), _i, _P(_vp), _i, _P(_sz), _i, _vp, _vp, _sz, _i, _i, _i, _vp, _sz, _P(_vp)])
+_sig('dlwp_state_feedback', [_vp, _vp, _vp, _vp, _vp, _vp, _P(Feedback), _i, _vp])
+_sig('dlwp_rollout_create_fed', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _vp, _sz, _i, _P(Feedback), _vp, _vp, _i, _vp, _sz, _P(_vp)])
 _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
 _sig('dlwp_host_gather_rows', [_vp, _vp, _vp, ctypes.c_longlong, _sz, ctypes.c_longlong, _i])

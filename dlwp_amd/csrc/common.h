@@ -202,3 +202,7 @@ int dlwp_convlstm_step_prep(dlwp_handle_t h, const void* w_h, const void* w_x, f
 int dlwp_launch_convlstm_step(dlwp_handle_t h, const void* h_in, const void* x_in, const void* w_h, const void* w_x, const void* bias,
                               const void* c_prev, void* c_out, void* h_out, dlwp_shape4 xs_h, const dlwp_conv2d* cd_h,
                               dlwp_shape4 xs_x, const dlwp_conv2d* cd_x, int dtype, hipStream_t s, const float* u_pre);
+// feedback.hip: the state update between two model calls of a fed rollout (rollout.hip: dlwp_rollout_create_fed)
+int dlwp_feedback_check(const dlwp_feedback* fb, const char* who);
+int dlwp_launch_state_feedback(dlwp_handle_t h, const void* old_state, const void* out, void* new_state, const void* sol,
+                               const void* mean, const dlwp_feedback* fb, hipStream_t s);

@@ -126,11 +126,20 @@ int dlwp_rollout_create(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* c
 // workgroups; at small batches (config 5: 4 members per GPU) a single chain leaves every launch with a partly filled last
 // round of workgroups and a drained GPU at every kernel boundary -- branches at different layers fill those gaps with
 // each other's work.  Same kernels, same per-member arithmetic (the kernel family never depends on the batch size).
-int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_ops, void* const* buffers, int n_buffers,
-                                const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
-                                size_t slot_elems, int calls, int n_outputs, int dtype, void* workspace,
-                                size_t workspace_bytes, dlwp_rollout_t* out) {
+// fed: the state update between two calls (dlwp_rollout_create_fed); NULL = the last output of a call is the next input
+struct FedArgs {
+  const dlwp_feedback* fb;
+  void* state_b;
+  const void* sol;
+  const void* mean;
+};
+static int create_impl(dlwp_handle_t h, const dlwp_op* plan_in, int n_ops, void* const* buffers, int n_buffers,
+                       const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
+                       size_t slot_elems, int calls, int n_outputs, int dtype, void* workspace,
+                       size_t workspace_bytes, dlwp_rollout_t* out, const FedArgs* fed) {
   DLWP_CHECK_ARG(h && plan_in && out && state0 && series, "dlwp_rollout_create: null handle or pointer");
+  DLWP_CHECK_ARG(!fed || (groups == 1 && n_outputs == 1 && fed->state_b && fed->state_b != state0),
+                 "dlwp_rollout_create_fed: one member chain, one output per call and two distinct state buffers");
   DLWP_CHECK_ARG(groups >= 1 && groups <= 64, "dlwp_rollout_create: %d member groups", groups);
   DLWP_CHECK_ARG(groups == 1 || buffer_sample_bytes, "dlwp_rollout_create: member groups need the per-member buffer sizes");
   int members = 0;
@@ -193,6 +202,7 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
     const size_t lo = (size_t)g * gn;
     if (idx >= 0) return (char*)buffers[idx] + (buffer_sample_bytes ? lo * buffer_sample_bytes[idx] : 0);
     if (idx == DLWP_BUF_STATE_IN) {
+      if (fed) return (call & 1) ? fed->state_b : const_cast<void*>(state0);     // (one chain: lo == 0)
       if (call == 0) return (char*)const_cast<void*>(state0) + lo * member_elems * esz;
       return (char*)series + (((size_t)call * n_outputs - 1) * slot_elems + lo * member_elems) * esz;
     }
@@ -262,6 +272,13 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
         rc = enqueue_op(h, op, resolve(op.src, t, g), resolve(op.dst, t, g), w, b, dtype, s, aux,
                         (wino_u && u_off[i] >= 0) ? wino_u + u_off[i] : nullptr, is_step(op) ? resolve(op.src2, t, g) : nullptr,
                         is_step(op) ? buffers[op.w2] : nullptr, &kws);
+      }
+      // the next call's input from this call's output, the old state and the known inputs (feedback.hip)
+      if (fed && t + 1 < ncalls && rc == DLWP_OK) {
+        const dlwp_feedback& F = *fed->fb;
+        const float* sol_t = fed->sol ? (const float*)fed->sol + (size_t)t * F.tail * F.sol_planes * F.hw : nullptr;
+        rc = dlwp_launch_state_feedback(h, resolve(DLWP_BUF_STATE_IN, t, g), resolve(DLWP_BUF_OUT(0), t, g),
+                                        resolve(DLWP_BUF_STATE_IN, t + 1, g), sol_t, fed->mean, &F, s);
       }
     }
   };
@@ -334,6 +351,26 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan_in, int n_o
   }
   *out = r;
   return DLWP_OK;
+}
+
+int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
+                                const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
+                                size_t slot_elems, int calls, int n_outputs, int dtype, void* workspace,
+                                size_t workspace_bytes, dlwp_rollout_t* out) {
+  return create_impl(h, plan, n_ops, buffers, n_buffers, buffer_sample_bytes, groups, state0, series, slot_elems, calls, n_outputs,
+                     dtype, workspace, workspace_bytes, out, nullptr);
+}
+
+int dlwp_rollout_create_fed(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers, void* state_a,
+                            void* state_b, void* series, size_t slot_elems, int calls, const dlwp_feedback* fb, const void* sol,
+                            const void* mean, int dtype, void* workspace, size_t workspace_bytes, dlwp_rollout_t* out) {
+  const int rc = dlwp_feedback_check(fb, "dlwp_rollout_create_fed");
+  if (rc != DLWP_OK) return rc;
+  DLWP_CHECK_ARG(slot_elems == (size_t)fb->rows * fb->out_c * fb->hw, "dlwp_rollout_create_fed: series slots of %zu elements, %d rows of %d x %d",
+                 slot_elems, fb->rows, fb->out_c, fb->hw);
+  const FedArgs fed{fb, state_b, sol, mean};
+  return create_impl(h, plan, n_ops, buffers, n_buffers, nullptr, 1, state_a, series, slot_elems, calls, 1, dtype, workspace,
+                     workspace_bytes, out, &fed);
 }
 
 int dlwp_rollout_launch(dlwp_rollout_t r, void* stream) {

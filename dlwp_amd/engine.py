@@ -369,8 +369,10 @@ class Executor(object):
                     return False
         return True
 
-    def _make_rollout(self, state0, series, calls, groups=None, chain=None, span=None, ws=None, prepared=False):
-        """chain = (index, count): a single-chain graph over members [index * n / count, (index + 1) * n / count) of state0 / series,
+    def _make_rollout(self, state0, series, calls, groups=None, chain=None, span=None, ws=None, prepared=False, fed=None):
+        """fed = (dlwp_feedback, state_b, sol | None, mean | None): the outputs are not the next inputs -- a feedback launch between
+        the calls builds the next state (dlwp_rollout_create_fed; one chain, one output); series: (calls, n) + output store.
+        chain = (index, count): a single-chain graph over members [index * n / count, (index + 1) * n / count) of state0 / series,
         with activation buffers of its own (the halves of a SplitRollout).
         span = (first call, number of calls): a TIME SLICE of the rollout over `series` -- the graph of calls [first, first + number),
         reading its state from the series slot the call before wrote (state0 for first = 0) -- one of several graphs launched one
@@ -383,10 +385,14 @@ class Executor(object):
         first = 0 if chain is None else int(chain[0]) * n
         call0, calls = (0, int(calls)) if span is None else (int(span[0]), int(span[1]))
         n_out = len(self.plan.output_store)
-        for s in self.plan.output_store:
-            if tuple(s) != tuple(self.plan._in_store):
-                raise ValueError('rollout needs every model output to have the input state shape %r, got %r' %
-                                 (self.plan._in_store, s))
+        if fed is not None:
+            if n_out != 1 or chain is not None or span is not None:
+                raise ValueError('a fed rollout is one graph of a model with one output')
+        else:
+            for s in self.plan.output_store:
+                if tuple(s) != tuple(self.plan._in_store):
+                    raise ValueError('rollout needs every model output to have the input state shape %r, got %r' %
+                                     (self.plan._in_store, s))
         bufs = self.scratch(n) if chain is None else \
             [torch.empty((n,) + s_, dtype=torch.bfloat16 if i in self._bf16 else torch.float32, device=self.device)
              for i, s_ in enumerate(self.plan.buffers)]
@@ -463,6 +469,8 @@ class Executor(object):
         slot = member * n_total                    # elements between two time slots of the series (all members of the rollout)
         out = ctypes.c_void_p()
         dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if fed is not None:
+            groups = 1                             # rows exchange data between the calls: one chain
         groups = self.member_groups(n, self.plan._in_store[1] * self.plan._in_store[2]) if groups is None else int(groups)
         nbuf = len(bufs)
         sample_bytes = (ctypes.c_size_t * max(1, len(table)))(
@@ -473,6 +481,17 @@ class Executor(object):
             ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=self.device)
         elif ws.numel() * 4 < ws_bytes:
             raise ValueError('rollout workspace of %d bytes, %d needed' % (ws.numel() * 4, ws_bytes))
+        if fed is not None:
+            fb, state_b, sol, mean = fed
+            _lib.check(_lib.lib.dlwp_rollout_create_fed(
+                _lib.handle(dev), arr, len(self.plan.ops), ptrs, len(table), ctypes.c_void_p(state0.data_ptr()),
+                ctypes.c_void_p(state_b.data_ptr()), ctypes.c_void_p(series.data_ptr()), int(np.prod(self.plan.output_store[0])) * n,
+                int(calls), ctypes.byref(fb), ctypes.c_void_p(sol.data_ptr() if sol is not None else 0),
+                ctypes.c_void_p(mean.data_ptr() if mean is not None else 0), _lib.F32, ctypes.c_void_p(ws.data_ptr()), ws_bytes,
+                ctypes.byref(out)))
+            rg = RolloutGraph(out, keep=(table, state0, series, arr, ptrs, ws, fed), device=self.device)
+            rg.groups, rg.ws = 1, ws
+            return rg
         # (a time slice: the state comes from the slot in front of its first one, its series starts at its own first slot)
         state_ptr = state0.data_ptr() if call0 == 0 else series.data_ptr() + 4 * (call0 * n_out - 1) * slot
         series_ptr = series.data_ptr() + 4 * call0 * n_out * slot
@@ -792,6 +811,49 @@ class Model(object):
             series.copy_(out)
             return series
         return out
+
+    def fed_rollout_on_device(self, state0, calls, src, shift=0, tail=0, sol=None, sol_map=None, mean=None):
+        """A rollout whose outputs are NOT its next inputs, entirely in HBM (dlwp_rollout_create_fed): between two model calls ONE
+        launch builds the next state from the old one (rows shifted by `shift`), the call's output (src[c] = -1 - j), the insolation
+        block of the call (sol: (calls - 1, tail, planes) + grid, channel c takes plane sol_map[c]) and the mean state -- the
+        bookkeeping TimeSeriesEstimator.predict does on the host with xarray between two model.predict round trips
+        (DLWP/model/extensions.py:206-240) and the step_sequence shift of DLWP/model/models.py:280-290.
+        state0: (n,) + input shape, device or host.  Returns the device series (calls, n) + output shape; cached per configuration."""
+        n, calls = int(state0.shape[0]), int(calls)
+        if len(self.plan.output_store) != 1:
+            raise ValueError('a fed rollout needs a model with one output')
+        c_in, h, w = self.plan._in_store
+        c_out = int(self.plan.output_store[0][0])
+        if tuple(self.plan.output_store[0][1:]) != (h, w):
+            raise ValueError('a fed rollout needs outputs on the input grid: %r -> %r' % (self.plan._in_store, self.plan.output_store[0]))
+        src = tuple(int(v) for v in src)
+        sol_map = tuple(int(v) for v in sol_map) if sol is not None else None
+        planes = int(sol.shape[2]) if sol is not None else 0
+        key = (n, calls, src, int(shift), int(tail), sol_map, planes, mean is not None)
+        cache = self.__dict__.setdefault('_rollouts_fed', {})
+        ent = cache.get(key)
+        if ent is None:
+            from . import ops
+            for old in cache.values():
+                old[0].close()
+            cache.clear()
+            f32 = dict(dtype=torch.float32, device=self.device)
+            sa, sb = torch.empty((n, c_in, h, w), **f32), torch.empty((n, c_in, h, w), **f32)
+            ser = torch.empty((calls, n) + tuple(self.plan.output_store[0]), **f32)
+            fb = ops.make_feedback(n, c_in, c_out, h * w, src, shift=shift, tail=tail, sol=sol_map, sol_planes=planes)
+            sol_d = torch.empty((max(calls - 1, 1), fb.tail, planes, h, w), **f32) if sol is not None else None
+            mean_d = torch.empty((c_in, h, w), **f32) if mean is not None else None
+            g = self.executor._make_rollout(sa, ser, calls, fed=(fb, sb, sol_d, mean_d))
+            ent = cache[key] = (g, sa, sb, ser, sol_d, mean_d)
+        g, sa, sb, ser, sol_d, mean_d = ent
+        as_dev = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))  # noqa: E731
+        sa.copy_(as_dev(state0).reshape(sa.shape), non_blocking=True)
+        if sol_d is not None and calls > 1:
+            sol_d.copy_(as_dev(sol).reshape(sol_d.shape), non_blocking=True)
+        if mean_d is not None:
+            mean_d.copy_(as_dev(mean).reshape(mean_d.shape), non_blocking=True)
+        g.launch()
+        return ser.reshape((calls, n) + tuple(self.plan.output_shapes[0]))
 
     def streamed_rollout(self, n, calls, head_chunks=4):
         """The time-sliced rollout of n members x `calls` model applications (Executor.make_streamed_rollout), cached like the

@@ -19,8 +19,14 @@ k = es + interval - 1 series steps covered per model call:
         otherwise: the first (prefer_first_times) or last `input_time_steps` output time steps
 
 When inputs == outputs (same channels, same time steps, no insolation) every channel is overwritten and the loop is
-exactly DLWPNeuralNet.predict_timeseries: that case is dispatched to the device-resident hipGraph rollout; all other
-cases run model.predict (one fused device forward) per step with the re-indexing on the host, as the reference does.
+exactly DLWPNeuralNet.predict_timeseries: that case is dispatched to the device-resident hipGraph rollout.  Every other
+case -- the one examples/validate.py:191-205 runs: insolation inputs, variable selections, interval > 1, fewer or more
+output than input steps, impute -- is a FED rollout (engine.Model.fed_rollout_on_device, csrc/feedback.hip): the state
+stays in HBM, one launch between two model calls does the row shift, the NaN / mean fill, the insolation of the rows
+past the data (a table computed once for all lead times before the rollout: util.insolation depends on the times
+only) and the scatter of the predicted channels, all calls in ONE hipGraph.  The reference's form of the same loop --
+model.predict (H2D + D2H of the full state) and three host copies of the state per step -- remains for foreign model
+objects, scalers and DLWP_ESTIMATOR_HOST=1 (the parity tests run both and compare bit for bit).
 The result carries the reference's coordinates (f_hour, time, [time_step,] varlev | variable, level, lat, lon) in a
 LabeledArray.
 """
@@ -77,6 +83,27 @@ class TimeSeriesEstimator(object):
         self._input_time_steps = generator._input_time_steps if self._is_series else model.time_dim
         self._output_time_steps = generator._output_time_steps if self._is_series else model.time_dim
 
+    def _fed_rollout_ok(self, p_shape, t_shape, n):
+        """Can the whole loop run on the device?  A dlwp_amd network behind a DLWPNeuralNet / single-output DLWPFunctional with
+        identity scaling, stored as (channels, lat, lon) with at most 128 state channels, and room in HBM for the two states, the
+        series and the activations of all samples at once (the row shift couples the samples: they are not chunked)."""
+        import os
+        wrapper, net = self.model, getattr(self.model, 'model', None)
+        if os.environ.get('DLWP_ESTIMATOR_HOST', '0') == '1' or not hasattr(net, 'fed_rollout_on_device'):
+            return False
+        if getattr(wrapper, 'impute', False) or getattr(wrapper, 'scaler_type', None) is not None:
+            return False
+        if len(net.outputs) != 1 or tuple(p_shape[1:]) != tuple(net.inputs[0].shape) or \
+                tuple(t_shape[1:]) != tuple(net.outputs[0].shape) or net.device.type != 'cuda':
+            return False
+        state_c = int(np.prod(p_shape[1:-2]))
+        if state_c > 128:
+            return False
+        import torch
+        free = torch.cuda.mem_get_info(net.device)[0]
+        need = 4 * n * sum(int(np.prod(b)) for b in net.infer_plan.buffers) + 8 * int(np.prod(p_shape))
+        return need < 0.8 * free
+
     # -- the forecast ------------------------------------------------------------------------------------------------ #
     def predict(self, steps, impute=False, keep_time_dim=False, prefer_first_times=True, **kwargs):
         """Step the model forward `steps` series steps for every sample of the generator.  Returns a LabeledArray with
@@ -85,6 +112,7 @@ class TimeSeriesEstimator(object):
         if int(steps) < 1:
             raise ValueError('must use positive integer for steps')
         steps = int(steps)
+        return_device = bool(kwargs.pop('return_device', False))     # (bench.py: the device series of the fed rollout, no D2H)
         t_in, t_out = self._input_time_steps, self._output_time_steps
         if t_out <= t_in:
             keep_inputs, es = True, t_out
@@ -128,6 +156,39 @@ class TimeSeriesEstimator(object):
             series = self.model.predict_timeseries(p.reshape(p_shape), effective_steps * self.model.time_dim,
                                                    keep_time_dim=True, **kwargs)
             result[:] = np.asarray(series).reshape((effective_steps,) + t_shape)
+        elif self._fed_rollout_ok(p_shape, t_shape, n):
+            # ---- the whole loop on the device: ONE hipGraph, the feedback launch between the calls (csrc/feedback.hip)
+            c_in, c_out = len(in_labels), len(out_labels)
+            src = list(range(t_in * c_in))                      # default: the same channel of row i + k
+            for j_in, j_out in zip(idx_in, idx_out):
+                if keep_inputs:
+                    for m in range(es):
+                        src[(t_in - es + m) * c_in + j_in] = -1 - (m * c_out + j_out)
+                else:
+                    first = 0 if prefer_first_times else t_out - t_in
+                    for ts in range(t_in):
+                        src[ts * c_in + j_in] = -1 - ((first + ts) * c_out + j_out)
+            tail = min(es, n)
+            sol, sol_map = None, None
+            if self._add_insolation:
+                sol_idx = in_labels.index('SOL')
+                sol_map = [-1] * (t_in * c_in)
+                for ts in range(t_in):
+                    sol_map[ts * c_in + sol_idx] = ts
+                # the times of the rows past the data at every lead: known before the rollout starts
+                sol = np.empty((max(effective_steps - 1, 1), tail, t_in) + hw, dtype=np.float32)
+                for s in range(effective_steps - 1):
+                    late = (sample_coord + (s + 1) * k * self._dt)[-es:]
+                    sol[s] = np.stack([insolation(late + m * self._dt, lat, lon) for m in range(t_in)], axis=1)
+            if kwargs.get('verbose', 0) > 0:
+                for s in range(effective_steps):
+                    print('Time step %d/%d' % (s + 1, effective_steps))
+            series = self.model.model.fed_rollout_on_device(p.reshape((n, t_in * c_in) + hw), effective_steps, src, shift=k,
+                                                            tail=tail, sol=sol, sol_map=sol_map,
+                                                            mean=p_mean.reshape((t_in * c_in,) + hw) if impute else None)
+            if return_device:
+                return series
+            result[:] = series.cpu().numpy().reshape((effective_steps,) + t_shape)
         else:
             sample_now = sample_coord.copy()
             for s in range(effective_steps):

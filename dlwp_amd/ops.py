@@ -379,6 +379,42 @@ def series_merge_time(series, time_dim):
     return out
 
 
+def make_feedback(rows, state_c, out_c, hw, src, shift=0, tail=0, sol=None, sol_planes=0):
+    """dlwp_feedback (include/dlwp_hip.h): src[c] >= 0 -> channel of the old state (row i + shift); -1 - j -> channel j of the
+    model output of row i; sol[c] >= 0 -> plane of the tail rows' insolation block."""
+    if state_c > _lib.FB_MAX_CHANNELS:
+        raise ValueError('a fed rollout carries at most %d state channels, got %d' % (_lib.FB_MAX_CHANNELS, state_c))
+    fb = _lib.Feedback()
+    fb.rows, fb.state_c, fb.out_c, fb.hw = int(rows), int(state_c), int(out_c), int(hw)
+    fb.shift, fb.tail, fb.sol_planes = int(shift), int(min(tail, rows)), int(sol_planes)
+    for c in range(state_c):
+        fb.src[c] = int(src[c])
+        fb.sol[c] = int(sol[c]) if sol is not None else -1
+    return fb
+
+
+def state_feedback(old_state, out, fb, sol=None, mean=None, new_state=None):
+    """The next input state of a forecast whose inputs and outputs differ (TimeSeriesEstimator.predict,
+    DLWP/model/extensions.py:206-240; models.py:280-290): one launch, planes copied bit for bit.  old_state (rows, state_c, h, w),
+    out (rows, out_c, h, w), sol (tail, sol_planes, h, w) | None, mean (state_c, h, w) | None."""
+    _check_f32(old_state, out, sol, mean)
+    if new_state is None:
+        new_state = torch.empty_like(old_state)
+    _check_f32(new_state)
+    if old_state.numel() != fb.rows * fb.state_c * fb.hw or out.numel() != fb.rows * fb.out_c * fb.hw or \
+            new_state.numel() != old_state.numel():
+        raise ValueError('state_feedback: tensors of %d / %d elements for %d rows of %d -> %d channels x %d' %
+                         (old_state.numel(), out.numel(), fb.rows, fb.state_c, fb.out_c, fb.hw))
+    if sol is not None and sol.numel() != fb.tail * fb.sol_planes * fb.hw:
+        raise ValueError('state_feedback: insolation block of %d elements, %d x %d x %d expected' %
+                         (sol.numel(), fb.tail, fb.sol_planes, fb.hw))
+    if mean is not None and mean.numel() != fb.state_c * fb.hw:
+        raise ValueError('state_feedback: mean state of %d elements, %d x %d expected' % (mean.numel(), fb.state_c, fb.hw))
+    _lib.check(_lib.lib.dlwp_state_feedback(_lib.handle(_dev(old_state)), _ptr(old_state), _ptr(out), _ptr(new_state), _ptr(sol),
+                                            _ptr(mean), ctypes.byref(fb), _lib.F32, _stream(old_state)))
+    return new_state
+
+
 def conv_configs():
     """[(ks, dil, th, tw, waves, frags_per_wave, cout_frags, channel_chunk, pooled_loader, lds_bytes, flags)] of the
     compiled MFMA tiles (flags bit 0: position-split Winograd instance, dlwp_conv2d_config_flags)."""

@@ -567,6 +567,38 @@ int dlwp_rollout_create_grouped(dlwp_handle_t, const dlwp_op* plan, int n_ops, v
  * previous slice's last series slot) that shares `workspace` with the first slice and is always launched behind it on the same
  * stream -- it does not prepare the weights again.                                                                          */
 #define DLWP_ROLLOUT_PREPARED 0x100
+/* ---- a rollout whose model outputs are NOT its next inputs: TimeSeriesEstimator.predict (DLWP/model/extensions.py:206-240, the
+ *      forecast examples/validate.py:191-205 runs: inputs = 2 time steps x (variables + insolation), outputs = 2 x variables) and
+ *      the step_sequence branch of DLWPNeuralNet.predict_timeseries (DLWP/model/models.py:280-290).  Between two model calls the
+ *      reference rebuilds the input on the host (reindex of the sample axis by k, impute, insolation of the rows past the data,
+ *      .loc assignment of the predicted channels); dlwp_state_feedback is that update as ONE launch on device-resident tensors:
+ *      for every row i < rows and state channel c, in the reference's order of precedence
+ *          src[c] = -1 - j              -> out[i, j]                                   (the model predicts this channel)
+ *          i >= rows - tail, sol[c] >= 0 -> sol[i - (rows - tail), sol[c]]              (insolation, known for any time)
+ *          i >= rows - tail, mean        -> mean[c]                                     (impute=True)
+ *          i + shift < rows              -> old_state[i + shift, src[c]]                (the data of the later start time)
+ *          otherwise                     -> NaN                                         (ran out of data)
+ *      old_state / new_state (rows, state_c, hw), out (rows, out_c, hw), sol (tail, sol_planes, hw) | NULL, mean (state_c, hw) |
+ *      NULL; float32, planes are copied bit for bit.  new_state must not alias old_state.                                      */
+#define DLWP_FB_MAX_CHANNELS 128
+typedef struct {
+  int rows, state_c, out_c, hw;
+  int shift;                        /* k = es + interval - 1: series steps the window advances per model call (0: none)      */
+  int tail;                         /* min(es, rows): trailing rows that receive the insolation / the mean state             */
+  int sol_planes;                   /* planes per tail row of the insolation block (the input time steps)                    */
+  int src[DLWP_FB_MAX_CHANNELS];    /* per state channel: >= 0 channel of the old state; -1 - j: channel j of the output     */
+  int sol[DLWP_FB_MAX_CHANNELS];    /* per state channel: plane of the tail row's insolation block, or -1                    */
+} dlwp_feedback;
+int dlwp_state_feedback(dlwp_handle_t, const void* old_state, const void* out, void* new_state, const void* sol,
+                        const void* mean, const dlwp_feedback* fb, int dtype, void* stream);
+/* The rollout graph with that update between its calls: call t reads state[t & 1] (state_a = the initial state, written by the
+ * caller before every launch; state_b = scratch of the same size), writes series slot t (slot_elems = rows * out_c * hw), and
+ * the feedback launch behind it builds state[(t + 1) & 1] with the insolation block sol + t * tail * sol_planes * hw
+ * (sol: (calls - 1, tail, sol_planes, hw) | NULL).  One output per call, one member chain (rows exchange data).               */
+int dlwp_rollout_create_fed(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
+                            void* state_a, void* state_b, void* series, size_t slot_elems, int calls, const dlwp_feedback* fb,
+                            const void* sol, const void* mean, int dtype, void* workspace, size_t workspace_bytes,
+                            dlwp_rollout_t* out);
 int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
 int dlwp_rollout_destroy(dlwp_rollout_t);
 

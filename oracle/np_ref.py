@@ -626,6 +626,34 @@ def predict_timeseries_functional(predict, predictors, time_steps, time_dim, n_o
     return _merge_time(series, n_slots, n_sample, time_dim, feature_shape, keep_time_dim)
 
 
+def estimator_next_state(p, r, k, es, idx_in, idx_out, keep_inputs=True, prefer_first_times=True, mean=None, sol=None,
+                         sol_idx=None):
+    """The input of the NEXT model call of TimeSeriesEstimator.predict, DLWP/model/extensions.py:214-240, on plain index
+    arithmetic (the reference writes it with xarray labels; PINNED end to end by tests/golden/estimator.npz through
+    dlwp_amd.model.extensions' host loop, which is this function inlined).
+      p (n, t_in, C_in, H, W): the inputs of this call;  r (n, t_out, C_out, H, W): its prediction
+      :215  p.reindex(sample = sample + k dt): row i takes row i + k, rows past the data are NaN
+      :219-221  impute: the last es rows = the mean input (mean: (t_in, C_in, H, W))
+      :224-228  insolation: channel sol_idx of the last es rows = sol (min(es, n), t_in, H, W)
+      :232-240  the predicted channels idx_in <- idx_out: the last es input steps (keep_inputs), else the first / last t_in
+                predicted steps."""
+    n, t_in = p.shape[:2]
+    nxt = np.full_like(p, np.nan)
+    if k < n:
+        nxt[:n - k] = p[k:]
+    if mean is not None:
+        nxt[-es:] = mean[np.newaxis]
+    if sol is not None:
+        nxt[-es:, :, sol_idx] = sol
+    if keep_inputs:
+        nxt[:, t_in - es:, idx_in] = r[:, :, idx_out]
+    elif prefer_first_times:
+        nxt[:, :, idx_in] = r[:, :t_in][:, :, idx_out]
+    else:
+        nxt[:, :, idx_in] = r[:, -t_in:][:, :, idx_out]
+    return nxt
+
+
 # ------------------------------------------------------------------------------------------------------------------ #
 # data feed  (PINNED by tests/golden/generator.npz)
 # ------------------------------------------------------------------------------------------------------------------ #
