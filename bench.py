@@ -525,6 +525,62 @@ def sub_host_visible(d, grid, cin, members, forwards):
             'series_gbs': out.nbytes / min(times) / 1e9}
 
 
+def sub_timeseries_estimator(grid, members, forwards, plain_steps_per_s):
+    """The rollout examples/validate.py:191-205 runs: SeriesDataGenerator(add_insolation=True) ->
+    TimeSeriesEstimator.predict -- inputs 2 time steps x (2 variables + insolation) = 6 channels, outputs 2 x 2 = 4 channels, so
+    the forecast is NOT the next input: between two model calls the rows shift to the later start time, the insolation of the rows
+    past the data is refreshed and the predicted channels are scattered into the state (csrc/feedback.hip), all `forwards` calls
+    in ONE hipGraph.  value = the device-resident loop (as the headline); api = TimeSeriesEstimator.predict -> LabeledArray
+    (host generator, insolation table, upload, D2H of the series); host_loop = the reference's form of the same loop (one
+    model.predict round trip + numpy re-indexing per step, DLWP/model/extensions.py:206-240) around the same device forward."""
+    from dlwp_amd.model import DLWPNeuralNet, SeriesDataGenerator, SeriesDataset, TimeSeriesEstimator
+    from dlwp_amd.presets import unet_layers
+    rng = np.random.default_rng(3)
+    n_t = members + 3                                   # samples = n_t - input steps - output steps + 1
+    dates = (np.datetime64('2010-01-01T00') + np.arange(n_t) * np.timedelta64(6, 'h')).astype('datetime64[s]')
+    series = rng.standard_normal((n_t, 2, 1) + grid).astype(np.float32)
+    ds = SeriesDataset(series, {'sample': dates, 'variable': np.array(['z', 'tau']), 'level': np.array([500]),
+                                'lat': np.linspace(88., -88., grid[0]), 'lon': np.arange(0., 360., 360. / grid[1])},
+                       ('sample', 'variable', 'level', 'lat', 'lon'))
+    np.random.seed(1234)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(unet_layers((6,) + grid, cout=4), loss='mse', optimizer='adam', metrics=['mae'])
+    gen = SeriesDataGenerator(d, ds, input_time_steps=2, output_time_steps=2, add_insolation=True, batch_size=64)
+    est = TimeSeriesEstimator(d, gen)
+    steps = 2 * forwards
+    est.predict(steps, return_device=True)                        # (capture)
+    graph = next(iter(d.model._rollouts_fed.values()))[0][0]
+    _warm_until_steady(graph.launch)
+    reps = 5
+    dt = _sync_time(graph.launch, reps)
+    value = members * steps * reps / dt
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = est.predict(steps)
+        times.append(time.perf_counter() - t0)
+    rec = {'value': value, 'unit': '6-h forecast steps/s', 'samples': members, 'model_calls': forwards,
+           'ms_per_rollout': 1e3 * dt / reps, 'vs_plain_rollout': value / plain_steps_per_s,
+           'channels': '6 in (2 steps x (z500, tau300-700, insolation)) -> 4 out', 'finite': bool(np.isfinite(out.values).all()),
+           'api': {'value': members * steps / min(times), 's_per_call': min(times), 'series_bytes': int(out.values.nbytes),
+                   'note': 'TimeSeriesEstimator.predict(steps) -> LabeledArray: generator gather + insolation table on the host, '
+                           'upload, the graph, D2H of the series'}}
+    os.environ['DLWP_ESTIMATOR_HOST'] = '1'
+    try:
+        t0 = time.perf_counter()
+        host = est.predict(steps)
+        rec['host_loop'] = {'value': members * steps / (time.perf_counter() - t0),
+                            'note': 'the reference-form loop: model.predict round trip + numpy re-indexing per step',
+                            'bit_identical': bool(np.array_equal(host.values, out.values, equal_nan=True))}
+    finally:
+        del os.environ['DLWP_ESTIMATOR_HOST']
+    for old in d.model._rollouts_fed.values():
+        for g_ in old[0]:
+            g_.close()
+    d.model._rollouts_fed.clear()
+    return rec
+
+
 def sub_layer1_nominal(net, members):
     """layer 1 (4 -> 32, 3x3 dilation 2, periodic + zero halo, tanh) alone at the NOMINAL 91 x 180 grid"""
     from dlwp_amd import _lib, ops
@@ -1073,6 +1129,8 @@ def main():
                 sub['host_visible'] = sub_host_visible(d, grid, a.channels, m_local, a.forwards)
                 if grid == (88, 180) and a.channels == 4:
                     sub['layer1_at_91x180'] = sub_layer1_nominal(net, m_local)
+                if world == 1:
+                    sub['timeseries_estimator'] = sub_timeseries_estimator(grid, m_local, a.forwards, value)
                 if world == 1:
                     sub['pad_hbm'] = sub_pad_hbm(m_local)
                     sub['recurrent_cfg4_bf16'] = sub_cfg4()

@@ -218,7 +218,8 @@ _sig('dlwp_rollout_workspace_bytes', [_vp, _P(Op), _i, _i], _sz)
 _sig('dlwp_rollout_create', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _sz, _i, _i, _i, _vp, _sz, _P(_vp)])
 _sig('dlwp_rollout_create_grouped', [_vp, _P(Op), _i, _P(_vp), _i, _P(_sz), _i, _vp, _vp, _sz, _i, _i, _i, _vp, _sz, _P(_vp)])
 _sig('dlwp_state_feedback', [_vp, _vp, _vp, _vp, _vp, _vp, _P(Feedback), _i, _vp])
-_sig('dlwp_rollout_create_fed', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _vp, _sz, _i, _P(Feedback), _vp, _vp, _i, _vp, _sz, _P(_vp)])
+_sig('dlwp_rollout_create_fed', [_vp, _P(Op), _i, _P(_vp), _i, _vp, _vp, _vp, _sz, _i, _i, _i, _P(Feedback), _vp, _vp, _i, _vp, _sz, _P(_vp)])
+_sig('dlwp_series_arrange', [_vp, _vp, _vp, _i, _i, _i, _i, _i, _P(_i), _i, _i, _vp])
 _sig('dlwp_rollout_launch', [_vp, _vp])
 _sig('dlwp_rollout_destroy', [_vp])
 _sig('dlwp_host_gather_rows', [_vp, _vp, _vp, ctypes.c_longlong, _sz, ctypes.c_longlong, _i])

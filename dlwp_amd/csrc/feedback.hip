@@ -59,6 +59,32 @@ __global__ __launch_bounds__(256) void state_feedback_kernel(const float* __rest
   }
 }
 
+struct ArrangeTable {
+  int n, t, c, hw, kept, time_major;
+  int perm[DLWP_FB_MAX_CHANNELS];
+};
+
+// one model call's output (n, t, c, hw) -> its block of the returned series: (kept, n, c, hw) time first, or (n, kept, c, hw);
+// destination channel j <- source channel perm[j].  One destination plane per blockIdx.x.
+template <bool VEC>
+__global__ __launch_bounds__(256) void series_arrange_kernel(const float* __restrict__ src, float* __restrict__ dst, const ArrangeTable A) {
+  const long long plane = blockIdx.x;
+  const int j = (int)(plane % A.c);
+  const long long q = plane / A.c;
+  int i, m;
+  if (A.time_major) { i = (int)(q % A.n); m = (int)(q / A.n); }
+  else { m = (int)(q % A.kept); i = (int)(q / A.kept); }
+  const float* s = src + (((long long)i * A.t + m) * A.c + A.perm[j]) * A.hw;
+  float* d = dst + plane * A.hw;
+  if (VEC) {
+    const int n4 = A.hw >> 2;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < n4; e += gridDim.y * 256)
+      __builtin_nontemporal_store(__builtin_nontemporal_load((const f32x4*)s + e), (f32x4*)d + e);
+  } else {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < A.hw; e += gridDim.y * 256) d[e] = s[e];
+  }
+}
+
 }  // namespace
 
 int dlwp_feedback_check(const dlwp_feedback* fb, const char* who) {
@@ -106,6 +132,32 @@ int dlwp_state_feedback(dlwp_handle_t h, const void* old_state, const void* out,
   const int rc = dlwp_feedback_check(fb, "dlwp_state_feedback");
   if (rc != DLWP_OK) return rc;
   return dlwp_launch_state_feedback(h, old_state, out, new_state, sol, mean, fb, (hipStream_t)stream);
+}
+
+int dlwp_series_arrange(dlwp_handle_t h, const void* src, void* dst, int n, int t, int c, int hw, int kept, const int* perm,
+                        int time_major, int dtype, void* stream) {
+  DLWP_UNTAPED(dlwp_series_arrange);
+  DLWP_CHECK_ARG(h && src && dst && src != dst, "dlwp_series_arrange: null handle or pointer, or dst aliases src");
+  DLWP_CHECK_ARG(dtype == DLWP_F32, "dlwp_series_arrange: dtype %d not supported", dtype);
+  DLWP_CHECK_ARG(n > 0 && t > 0 && c > 0 && c <= DLWP_FB_MAX_CHANNELS && hw > 0 && kept > 0 && kept <= t,
+                 "dlwp_series_arrange: %d samples x %d steps x %d channels (at most %d) x %d, %d steps kept", n, t, c,
+                 DLWP_FB_MAX_CHANNELS, hw, kept);
+  ArrangeTable A;
+  A.n = n, A.t = t, A.c = c, A.hw = hw, A.kept = kept, A.time_major = time_major != 0;
+  for (int j = 0; j < c; ++j) {
+    A.perm[j] = perm ? perm[j] : j;
+    DLWP_CHECK_ARG(A.perm[j] >= 0 && A.perm[j] < c, "dlwp_series_arrange: channel %d takes source channel %d of %d", j, A.perm[j], c);
+  }
+  const long long planes = (long long)kept * n * c;
+  DLWP_CHECK_ARG(planes < (1ll << 31), "dlwp_series_arrange: %lld planes", planes);
+  const bool vec = hw % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  int pieces = dlwp_ceil_div(vec ? hw / 4 : hw, 1024);
+  if (pieces > 64) pieces = 64;
+  const dim3 grid((unsigned)planes, (unsigned)pieces);
+  if (vec) series_arrange_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, (float*)dst, A);
+  else series_arrange_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)src, (float*)dst, A);
+  DLWP_LAUNCH_CHECK("series_arrange_kernel");
+  return DLWP_OK;
 }
 
 }  // extern "C"

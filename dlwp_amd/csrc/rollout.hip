@@ -132,6 +132,8 @@ struct FedArgs {
   void* state_b;
   const void* sol;
   const void* mean;
+  int first_call;   // this graph holds calls [first_call, first_call + calls) of the rollout (a time slice)
+  int feed_last;    // a later slice follows: the feedback behind the graph's last call belongs to this graph
 };
 static int create_impl(dlwp_handle_t h, const dlwp_op* plan_in, int n_ops, void* const* buffers, int n_buffers,
                        const size_t* buffer_sample_bytes, int groups, const void* state0, void* series,
@@ -202,7 +204,7 @@ static int create_impl(dlwp_handle_t h, const dlwp_op* plan_in, int n_ops, void*
     const size_t lo = (size_t)g * gn;
     if (idx >= 0) return (char*)buffers[idx] + (buffer_sample_bytes ? lo * buffer_sample_bytes[idx] : 0);
     if (idx == DLWP_BUF_STATE_IN) {
-      if (fed) return (call & 1) ? fed->state_b : const_cast<void*>(state0);     // (one chain: lo == 0)
+      if (fed) return ((fed->first_call + call) & 1) ? fed->state_b : const_cast<void*>(state0);     // (one chain: lo == 0)
       if (call == 0) return (char*)const_cast<void*>(state0) + lo * member_elems * esz;
       return (char*)series + (((size_t)call * n_outputs - 1) * slot_elems + lo * member_elems) * esz;
     }
@@ -274,9 +276,9 @@ static int create_impl(dlwp_handle_t h, const dlwp_op* plan_in, int n_ops, void*
                         is_step(op) ? buffers[op.w2] : nullptr, &kws);
       }
       // the next call's input from this call's output, the old state and the known inputs (feedback.hip)
-      if (fed && t + 1 < ncalls && rc == DLWP_OK) {
+      if (fed && (t + 1 < ncalls || fed->feed_last) && rc == DLWP_OK) {
         const dlwp_feedback& F = *fed->fb;
-        const float* sol_t = fed->sol ? (const float*)fed->sol + (size_t)t * F.tail * F.sol_planes * F.hw : nullptr;
+        const float* sol_t = fed->sol ? (const float*)fed->sol + (size_t)(fed->first_call + t) * F.tail * F.sol_planes * F.hw : nullptr;
         rc = dlwp_launch_state_feedback(h, resolve(DLWP_BUF_STATE_IN, t, g), resolve(DLWP_BUF_OUT(0), t, g),
                                         resolve(DLWP_BUF_STATE_IN, t + 1, g), sol_t, fed->mean, &F, s);
       }
@@ -362,13 +364,15 @@ int dlwp_rollout_create_grouped(dlwp_handle_t h, const dlwp_op* plan, int n_ops,
 }
 
 int dlwp_rollout_create_fed(dlwp_handle_t h, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers, void* state_a,
-                            void* state_b, void* series, size_t slot_elems, int calls, const dlwp_feedback* fb, const void* sol,
-                            const void* mean, int dtype, void* workspace, size_t workspace_bytes, dlwp_rollout_t* out) {
+                            void* state_b, void* series, size_t slot_elems, int calls, int first_call, int feed_last,
+                            const dlwp_feedback* fb, const void* sol, const void* mean, int dtype, void* workspace,
+                            size_t workspace_bytes, dlwp_rollout_t* out) {
   const int rc = dlwp_feedback_check(fb, "dlwp_rollout_create_fed");
   if (rc != DLWP_OK) return rc;
   DLWP_CHECK_ARG(slot_elems == (size_t)fb->rows * fb->out_c * fb->hw, "dlwp_rollout_create_fed: series slots of %zu elements, %d rows of %d x %d",
                  slot_elems, fb->rows, fb->out_c, fb->hw);
-  const FedArgs fed{fb, state_b, sol, mean};
+  DLWP_CHECK_ARG(first_call >= 0, "dlwp_rollout_create_fed: first call %d", first_call);
+  const FedArgs fed{fb, state_b, sol, mean, first_call, feed_last != 0};
   return create_impl(h, plan, n_ops, buffers, n_buffers, nullptr, 1, state_a, series, slot_elems, calls, 1, dtype, workspace,
                      workspace_bytes, out, &fed);
 }

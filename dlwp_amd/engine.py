@@ -370,8 +370,9 @@ class Executor(object):
         return True
 
     def _make_rollout(self, state0, series, calls, groups=None, chain=None, span=None, ws=None, prepared=False, fed=None):
-        """fed = (dlwp_feedback, state_b, sol | None, mean | None): the outputs are not the next inputs -- a feedback launch between
-        the calls builds the next state (dlwp_rollout_create_fed; one chain, one output); series: (calls, n) + output store.
+        """fed = (dlwp_feedback, state_b, sol | None, mean | None, calls of the whole rollout): the outputs are not the next inputs --
+        a feedback launch between the calls builds the next state (dlwp_rollout_create_fed; one chain, one output); series:
+        (calls, n) + output store; with span a time slice of it.
         chain = (index, count): a single-chain graph over members [index * n / count, (index + 1) * n / count) of state0 / series,
         with activation buffers of its own (the halves of a SplitRollout).
         span = (first call, number of calls): a TIME SLICE of the rollout over `series` -- the graph of calls [first, first + number),
@@ -386,8 +387,8 @@ class Executor(object):
         call0, calls = (0, int(calls)) if span is None else (int(span[0]), int(span[1]))
         n_out = len(self.plan.output_store)
         if fed is not None:
-            if n_out != 1 or chain is not None or span is not None:
-                raise ValueError('a fed rollout is one graph of a model with one output')
+            if n_out != 1 or chain is not None:
+                raise ValueError('a fed rollout is one member chain of a model with one output')
         else:
             for s in self.plan.output_store:
                 if tuple(s) != tuple(self.plan._in_store):
@@ -482,13 +483,15 @@ class Executor(object):
         elif ws.numel() * 4 < ws_bytes:
             raise ValueError('rollout workspace of %d bytes, %d needed' % (ws.numel() * 4, ws_bytes))
         if fed is not None:
-            fb, state_b, sol, mean = fed
+            fb, state_b, sol, mean, total_calls = fed
+            slot_out = int(np.prod(self.plan.output_store[0])) * n
             _lib.check(_lib.lib.dlwp_rollout_create_fed(
                 _lib.handle(dev), arr, len(self.plan.ops), ptrs, len(table), ctypes.c_void_p(state0.data_ptr()),
-                ctypes.c_void_p(state_b.data_ptr()), ctypes.c_void_p(series.data_ptr()), int(np.prod(self.plan.output_store[0])) * n,
-                int(calls), ctypes.byref(fb), ctypes.c_void_p(sol.data_ptr() if sol is not None else 0),
-                ctypes.c_void_p(mean.data_ptr() if mean is not None else 0), _lib.F32, ctypes.c_void_p(ws.data_ptr()), ws_bytes,
-                ctypes.byref(out)))
+                ctypes.c_void_p(state_b.data_ptr()), ctypes.c_void_p(series.data_ptr() + 4 * call0 * slot_out), slot_out,
+                int(calls), call0, int(call0 + calls < int(total_calls)), ctypes.byref(fb),
+                ctypes.c_void_p(sol.data_ptr() if sol is not None else 0),
+                ctypes.c_void_p(mean.data_ptr() if mean is not None else 0), _lib.F32 | (_lib.ROLLOUT_PREPARED if prepared else 0),
+                ctypes.c_void_p(ws.data_ptr()), ws_bytes, ctypes.byref(out)))
             rg = RolloutGraph(out, keep=(table, state0, series, arr, ptrs, ws, fed), device=self.device)
             rg.groups, rg.ws = 1, ws
             return rg
@@ -812,14 +815,8 @@ class Model(object):
             return series
         return out
 
-    def fed_rollout_on_device(self, state0, calls, src, shift=0, tail=0, sol=None, sol_map=None, mean=None):
-        """A rollout whose outputs are NOT its next inputs, entirely in HBM (dlwp_rollout_create_fed): between two model calls ONE
-        launch builds the next state from the old one (rows shifted by `shift`), the call's output (src[c] = -1 - j), the insolation
-        block of the call (sol: (calls - 1, tail, planes) + grid, channel c takes plane sol_map[c]) and the mean state -- the
-        bookkeeping TimeSeriesEstimator.predict does on the host with xarray between two model.predict round trips
-        (DLWP/model/extensions.py:206-240) and the step_sequence shift of DLWP/model/models.py:280-290.
-        state0: (n,) + input shape, device or host.  Returns the device series (calls, n) + output shape; cached per configuration."""
-        n, calls = int(state0.shape[0]), int(calls)
+    def _fed_entry(self, n, calls, src, shift, tail, sol, sol_map, mean, sliced):
+        """the cached graphs + buffers of a fed rollout: one graph of all calls, or (sliced) one graph per call"""
         if len(self.plan.output_store) != 1:
             raise ValueError('a fed rollout needs a model with one output')
         c_in, h, w = self.plan._in_store
@@ -829,13 +826,14 @@ class Model(object):
         src = tuple(int(v) for v in src)
         sol_map = tuple(int(v) for v in sol_map) if sol is not None else None
         planes = int(sol.shape[2]) if sol is not None else 0
-        key = (n, calls, src, int(shift), int(tail), sol_map, planes, mean is not None)
+        key = (n, calls, src, int(shift), int(tail), sol_map, planes, mean is not None, bool(sliced))
         cache = self.__dict__.setdefault('_rollouts_fed', {})
         ent = cache.get(key)
         if ent is None:
             from . import ops
             for old in cache.values():
-                old[0].close()
+                for g in old[0]:
+                    g.close()
             cache.clear()
             f32 = dict(dtype=torch.float32, device=self.device)
             sa, sb = torch.empty((n, c_in, h, w), **f32), torch.empty((n, c_in, h, w), **f32)
@@ -843,17 +841,95 @@ class Model(object):
             fb = ops.make_feedback(n, c_in, c_out, h * w, src, shift=shift, tail=tail, sol=sol_map, sol_planes=planes)
             sol_d = torch.empty((max(calls - 1, 1), fb.tail, planes, h, w), **f32) if sol is not None else None
             mean_d = torch.empty((c_in, h, w), **f32) if mean is not None else None
-            g = self.executor._make_rollout(sa, ser, calls, fed=(fb, sb, sol_d, mean_d))
-            ent = cache[key] = (g, sa, sb, ser, sol_d, mean_d)
-        g, sa, sb, ser, sol_d, mean_d = ent
+            fed = (fb, sb, sol_d, mean_d, calls)
+            if not sliced:
+                graphs = [self.executor._make_rollout(sa, ser, calls, fed=fed)]
+            else:
+                graphs = []
+                for j in range(calls):
+                    graphs.append(self.executor._make_rollout(sa, ser, calls, fed=fed, span=(j, 1),
+                                                              ws=graphs[0].ws if graphs else None, prepared=bool(graphs)))
+            ent = cache[key] = (graphs, sa, sb, ser, sol_d, mean_d)
+        return ent
+
+    @staticmethod
+    def _fed_inputs(ent, calls, state0, sol, mean):
+        _, sa, _, _, sol_d, mean_d = ent
         as_dev = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))  # noqa: E731
         sa.copy_(as_dev(state0).reshape(sa.shape), non_blocking=True)
         if sol_d is not None and calls > 1:
             sol_d.copy_(as_dev(sol).reshape(sol_d.shape), non_blocking=True)
         if mean_d is not None:
             mean_d.copy_(as_dev(mean).reshape(mean_d.shape), non_blocking=True)
-        g.launch()
-        return ser.reshape((calls, n) + tuple(self.plan.output_shapes[0]))
+
+    def fed_rollout_on_device(self, state0, calls, src, shift=0, tail=0, sol=None, sol_map=None, mean=None):
+        """A rollout whose outputs are NOT its next inputs, entirely in HBM (dlwp_rollout_create_fed): between two model calls ONE
+        launch builds the next state from the old one (rows shifted by `shift`), the call's output (src[c] = -1 - j), the insolation
+        block of the call (sol: (calls - 1, tail, planes) + grid, channel c takes plane sol_map[c]) and the mean state -- the
+        bookkeeping TimeSeriesEstimator.predict does on the host with xarray between two model.predict round trips
+        (DLWP/model/extensions.py:206-240) and the step_sequence shift of DLWP/model/models.py:280-290.
+        state0: (n,) + input shape, device or host.  Returns the device series (calls, n) + output shape; cached per configuration."""
+        n, calls = int(state0.shape[0]), int(calls)
+        ent = self._fed_entry(n, calls, src, shift, tail, sol, sol_map, mean, sliced=False)
+        self._fed_inputs(ent, calls, state0, sol, mean)
+        ent[0][0].launch()
+        return ent[3].reshape((calls, n) + tuple(self.plan.output_shapes[0]))
+
+    def fed_rollout_to_host(self, state0, calls, src, shift=0, tail=0, sol=None, sol_map=None, mean=None, t_out=1, kept=None,
+                            perm=None, time_major=True, blocks=None):
+        """The same forecast with its series going home WHILE it runs, in the layout the reference returns
+        (DLWP/model/extensions.py:243-302): one hipGraph per model call (call + feedback), launched back to back; behind call j, on
+        a copy stream, its output (n, t_out, C) is arranged into its block of the result -- time first (kept, n, C) or, time_major
+        False, (n, t_out, C); channels permuted by `perm` -- and leaves for ONE page-locked array under call j + 1.  blocks: how
+        many (time-major: time steps; else calls) of the result to keep in all (the [:steps] cut).  Returns a numpy array
+        (blocks | calls * kept, n, C, h, w) or (calls, n, t_out, C, h, w) lent from the pinned pool."""
+        import ctypes as ct
+        from . import _lib, util
+        n, calls = int(state0.shape[0]), int(calls)
+        ent = self._fed_entry(n, calls, src, shift, tail, sol, sol_map, mean, sliced=True)
+        graphs, _, _, ser, _, _ = ent
+        c_tot, h, w = self.plan.output_store[0]
+        t_out = int(t_out)
+        c = int(c_tot) // t_out
+        kept = t_out if (kept is None or not time_major) else int(kept)
+        total = calls * kept if time_major else calls
+        blocks = total if blocks is None else min(int(blocks), total)
+        host = util.pinned_results.take(((blocks, n, c, h, w) if time_major else (blocks, n, t_out, c, h, w)))
+        per_block = n * c * h * w if time_major else n * t_out * c * h * w
+        dev = self.device
+        hnd = _lib.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+        main = torch.cuda.current_stream(dev)
+        down = util.d2h_streams(dev)
+        stage = self.__dict__.setdefault('_fed_stage', {})
+        for k in range(len(down)):
+            if k not in stage or stage[k].numel() < kept * n * c * h * w or stage[k].device != dev:
+                stage[k] = torch.empty(kept * n * c * h * w, dtype=torch.float32, device=dev)
+        perm_arr = (ct.c_int * c)(*[int(v) for v in (perm if perm is not None else range(c))])
+        self._fed_inputs(ent, calls, state0, sol, mean)
+        for s_ in down:
+            s_.wait_stream(main)
+        try:
+            for j, g in enumerate(graphs):
+                g.launch()
+                first = j * kept if time_major else j
+                take = min(kept if time_major else 1, blocks - first)
+                if take <= 0:
+                    continue
+                ev = torch.cuda.Event()
+                ev.record(main)
+                k = j % len(down)
+                down[k].wait_event(ev)
+                with torch.cuda.stream(down[k]):
+                    _lib.check(_lib.lib.dlwp_series_arrange(hnd, ct.c_void_p(ser[j].data_ptr()), ct.c_void_p(stage[k].data_ptr()), n,
+                                                            t_out, c, h * w, kept, perm_arr, 1 if time_major else 0, _lib.F32,
+                                                            ct.c_void_p(down[k].cuda_stream)))
+                    host.view(-1)[first * per_block:(first + take) * per_block].copy_(stage[k][:take * per_block], non_blocking=True)
+        finally:
+            for s_ in down:
+                s_.synchronize()
+            for s_ in down:                    # (the cached series / staging buffers are rewritten by the next rollout on the main stream)
+                main.wait_stream(s_)
+        return util.pinned_results.lend(host)
 
     def streamed_rollout(self, n, calls, head_chunks=4):
         """The time-sliced rollout of n members x `calls` model applications (Executor.make_streamed_rollout), cached like the

@@ -125,12 +125,16 @@ class TimeSeriesEstimator(object):
         k = es + self._interval - 1                                # series steps the window advances per model call
 
         gen = self.generator
-        p, t = gen.generate([], scale_and_impute=False)
+        made = gen.generate_inputs() if hasattr(gen, 'generate_inputs') else None
+        if made is not None:                                    # (the targets are never read here: only their shape)
+            p, t_shape = made
+        else:
+            p, t = gen.generate([], scale_and_impute=False)
+            t_shape = tuple((t[0] if isinstance(t, (list, tuple)) else t).shape)
         p_shape = tuple(p.shape)
         n = p_shape[0]
         hw = tuple(gen.convolution_shape[-2:])
-        p = np.array(p, dtype=np.float32).reshape((n, t_in, -1) + hw)
-        t_shape = tuple((t[0] if isinstance(t, (list, tuple)) else t).shape)
+        p = np.asarray(p, dtype=np.float32).reshape((n, t_in, -1) + hw)
         sample_coord = np.asarray(self._da.coords['sample'])[:gen._n_sample]
         if not self._is_series:
             sample_coord = sample_coord - self._dt * (t_in - 1)
@@ -141,11 +145,13 @@ class TimeSeriesEstimator(object):
         idx_in = [in_labels.index(v) for v in shared]
         idx_out = [out_labels.index(v) for v in shared]
         p_mean = p.mean(axis=0) if impute else None
-        result = np.full((effective_steps,) + t_shape, np.nan, dtype=np.float32)
+        arranged = None       # the device path hands the series back already in the returned layout
+        alloc = lambda: np.full((effective_steps,) + t_shape, np.nan, dtype=np.float32)  # noqa: E731
 
         same_io = (keep_inputs and t_in == t_out and not self._add_insolation and self._interval == 1 and
                    in_labels == out_labels and isinstance(self.model, DLWPNeuralNet))
         if isinstance(self.model, DLWPFunctional) and self.model._n_steps > 1:
+            result = alloc()
             result[:] = self.model.predict_timeseries(p.reshape(p_shape), steps, keep_time_dim=True,
                                                       **kwargs).reshape((-1,) + t_shape)[:effective_steps]
         elif same_io and not impute:
@@ -155,7 +161,7 @@ class TimeSeriesEstimator(object):
             # every row stays finite at every lead -- pinned by tests/golden/estimator.npz ('same', 'varlev_same').
             series = self.model.predict_timeseries(p.reshape(p_shape), effective_steps * self.model.time_dim,
                                                    keep_time_dim=True, **kwargs)
-            result[:] = np.asarray(series).reshape((effective_steps,) + t_shape)
+            result = np.asarray(series).reshape((effective_steps,) + t_shape)
         elif self._fed_rollout_ok(p_shape, t_shape, n):
             # ---- the whole loop on the device: ONE hipGraph, the feedback launch between the calls (csrc/feedback.hip)
             c_in, c_out = len(in_labels), len(out_labels)
@@ -176,20 +182,32 @@ class TimeSeriesEstimator(object):
                 for ts in range(t_in):
                     sol_map[ts * c_in + sol_idx] = ts
                 # the times of the rows past the data at every lead: known before the rollout starts
+                # (util.insolation is element-wise in the dates: ONE call over the distinct times, then a gather)
                 sol = np.empty((max(effective_steps - 1, 1), tail, t_in) + hw, dtype=np.float32)
-                for s in range(effective_steps - 1):
-                    late = (sample_coord + (s + 1) * k * self._dt)[-es:]
-                    sol[s] = np.stack([insolation(late + m * self._dt, lat, lon) for m in range(t_in)], axis=1)
+                if effective_steps > 1:
+                    offs = np.array([[(s + 1) * k + m for m in range(t_in)] for s in range(effective_steps - 1)])
+                    when = sample_coord[-es:][np.newaxis, :, np.newaxis] + offs[:, np.newaxis, :] * self._dt
+                    uniq, inv = np.unique(when.ravel(), return_inverse=True)
+                    sol[:] = insolation(uniq, lat, lon)[inv.ravel()].reshape(sol.shape)
             if kwargs.get('verbose', 0) > 0:
                 for s in range(effective_steps):
                     print('Time step %d/%d' % (s + 1, effective_steps))
-            series = self.model.model.fed_rollout_on_device(p.reshape((n, t_in * c_in) + hw), effective_steps, src, shift=k,
-                                                            tail=tail, sol=sol, sol_map=sol_map,
-                                                            mean=p_mean.reshape((t_in * c_in,) + hw) if impute else None)
+            fed = dict(shift=k, tail=tail, sol=sol, sol_map=sol_map, mean=p_mean.reshape((t_in * c_in,) + hw) if impute else None)
             if return_device:
-                return series
-            result[:] = series.cpu().numpy().reshape((effective_steps,) + t_shape)
+                return self.model.model.fed_rollout_on_device(p.reshape((n, t_in * c_in) + hw), effective_steps, src, **fed)
+            # the series leaves for the host while the rollout runs, each call's block already in the returned layout: time first,
+            # the [:, :, :es] cut, the [:steps] cut, (variable, level) in sorted label order (the tail of this method, on the device)
+            perm = None
+            if not self._uses_varlev:
+                var, lev = np.asarray(self._output_sel['variable']), np.asarray(self._output_sel['level'])
+                vo, lo = np.argsort(var, kind='stable'), np.argsort(lev, kind='stable')
+                perm = [int(a) * len(lev) + int(b) for a in vo for b in lo]
+            arranged = self.model.model.fed_rollout_to_host(
+                p.reshape((n, t_in * c_in) + hw), effective_steps, src, t_out=t_out,
+                kept=es if (not keep_inputs and prefer_first_times) else t_out, perm=perm, time_major=not keep_time_dim,
+                blocks=effective_steps if keep_time_dim else steps, **fed)
         else:
+            result = alloc()
             sample_now = sample_coord.copy()
             for s in range(effective_steps):
                 if kwargs.get('verbose', 0) > 0:
@@ -217,20 +235,20 @@ class TimeSeriesEstimator(object):
                     p[:, :, idx_in] = r[:, -t_in:][:, :, idx_out]
 
         # -- coordinates --------------------------------------------------------------------------------------------- #
-        result = result.reshape((effective_steps, n, t_out, -1) + hw)
         time_coord = sample_coord + (t_in - 1) * self._dt
+        if arranged is None:
+            result = result.reshape((effective_steps, n, t_out, -1) + hw)
         if keep_time_dim:
             f_hour = np.array([self._dt * (1 + e * k) for e in range(effective_steps)])
             dims = ['f_hour', 'time', 'time_step', 'varlev', 'lat', 'lon']
             coords = {'f_hour': f_hour, 'time': time_coord, 'time_step': np.arange(t_out)}
         else:
-            if not keep_inputs and prefer_first_times:
-                result = result[:, :, :es]
-            kept = result.shape[2]
-            result = result.transpose((0, 2, 1, 3, 4, 5)).reshape((-1, n, result.shape[3]) + hw)
+            kept = es if (not keep_inputs and prefer_first_times) else t_out
+            if arranged is None:
+                result = result[:, :, :kept]
+                result = result.transpose((0, 2, 1, 3, 4, 5)).reshape((-1, n, result.shape[3]) + hw)[:steps]
             f_hour = np.array([self._dt * (m + self._interval + e * (es - 1 + self._interval))
-                               for e in range(effective_steps) for m in range(kept)])
-            result, f_hour = result[:steps], f_hour[:steps]
+                               for e in range(effective_steps) for m in range(kept)])[:steps]
             dims = ['f_hour', 'time', 'varlev', 'lat', 'lon']
             coords = {'f_hour': f_hour, 'time': time_coord}
         coords.update({'varlev': np.asarray(out_labels)})
@@ -241,10 +259,15 @@ class TimeSeriesEstimator(object):
             # coordinates are the index LEVELS, i.e. the labels in sorted order, not in selection order
             var, lev = np.asarray(self._output_sel['variable']), np.asarray(self._output_sel['level'])
             ax = dims.index('varlev')
-            result = result.reshape(result.shape[:ax] + (len(var), len(lev)) + result.shape[ax + 1:])
             vo, lo = np.argsort(var, kind='stable'), np.argsort(lev, kind='stable')
-            result = np.take(np.take(result, vo, axis=ax), lo, axis=ax + 1)
+            if arranged is None:
+                result = result.reshape(result.shape[:ax] + (len(var), len(lev)) + result.shape[ax + 1:])
+                result = np.take(np.take(result, vo, axis=ax), lo, axis=ax + 1)
+            else:
+                result = arranged.reshape(arranged.shape[:ax] + (len(var), len(lev)) + arranged.shape[ax + 1:])
             dims = dims[:ax] + ['variable', 'level'] + dims[ax + 1:]
             coords.pop('varlev')
             coords.update({'variable': var[vo], 'level': lev[lo]})
+        elif arranged is not None:
+            result = arranged
         return LabeledArray(result, coords, tuple(dims))

@@ -492,6 +492,38 @@ class SeriesDataGenerator(object):
         p = p_out
         return p, targets
 
+    def generate_inputs(self):
+        """(predictors of EVERY sample unscaled, shape of the targets) -- what TimeSeriesEstimator.predict takes from
+        generate([], scale_and_impute=False) (DLWP/model/extensions.py:171-172) without assembling the targets it never reads.
+        Only when no sample can be dropped for NaNs (checked once per dataset array); otherwise None: call generate()."""
+        if self._sequence is not None:
+            return None
+        if self._remove_nan:
+            arrays = [self.input_da.values, self.output_da.values] + ([self.insolation_da.values] if self._add_insolation else [])
+            key = tuple(id(a) for a in arrays)
+            if self.__dict__.get('_nan_free_key') != key:
+                self._nan_free, self._nan_free_key = not any(np.isnan(a).any() for a in arrays), key
+            if not self._nan_free:
+                return None
+        n = self._n_sample
+        samples = np.arange(n, dtype=int)
+        v = self.input_da.values
+        t_in = self._input_time_steps
+        if self._add_insolation:
+            s = self._conv_shape(True, 0)                      # (t_in, channels, y, x) without the insolation
+            p = np.empty((n, t_in, s[1] + 1) + tuple(s[2:]), dtype=v.dtype)
+            sol = self.insolation_da.values
+            for m in range(t_in):
+                p[:, m, :s[1]] = v[m:m + n].reshape((n, s[1]) + tuple(s[2:]))
+                p[:, m, s[1]] = sol[m:m + n]
+        else:
+            p = np.stack([v[samples + m] for m in range(t_in)], axis=1)
+        p = p.reshape((n,) + self.convolution_shape) if self._is_convolutional else \
+            p.reshape((n,) + (self.dense_shape if self._keep_time_axis else (-1,)))
+        t_shape = (n,) + (self.output_convolution_shape if self._is_convolutional else
+                          (self.output_dense_shape if self._keep_time_axis else (self.output_n_features,)))
+        return p, t_shape
+
     def __len__(self):
         return int(np.ceil(self._n_sample / self._batch_size))
 

@@ -592,13 +592,22 @@ typedef struct {
 int dlwp_state_feedback(dlwp_handle_t, const void* old_state, const void* out, void* new_state, const void* sol,
                         const void* mean, const dlwp_feedback* fb, int dtype, void* stream);
 /* The rollout graph with that update between its calls: call t reads state[t & 1] (state_a = the initial state, written by the
- * caller before every launch; state_b = scratch of the same size), writes series slot t (slot_elems = rows * out_c * hw), and
+ * caller before every launch; state_b = scratch of the same size), writes its series slot (slot_elems = rows * out_c * hw), and
  * the feedback launch behind it builds state[(t + 1) & 1] with the insolation block sol + t * tail * sol_planes * hw
- * (sol: (calls - 1, tail, sol_planes, hw) | NULL).  One output per call, one member chain (rows exchange data).               */
+ * (sol: (calls of the whole rollout - 1, tail, sol_planes, hw) | NULL).  One output per call, one member chain (rows exchange
+ * data).  A TIME SLICE of a rollout (one graph per model call, so that a finished slot can leave for the host under the next
+ * call): the graph holds calls [first_call, first_call + calls), `series` points at the slot of first_call, feed_last != 0
+ * puts the feedback behind its last call into the graph too (every slice but the last); DLWP_ROLLOUT_PREPARED as above.        */
 int dlwp_rollout_create_fed(dlwp_handle_t, const dlwp_op* plan, int n_ops, void* const* buffers, int n_buffers,
-                            void* state_a, void* state_b, void* series, size_t slot_elems, int calls, const dlwp_feedback* fb,
-                            const void* sol, const void* mean, int dtype, void* workspace, size_t workspace_bytes,
-                            dlwp_rollout_t* out);
+                            void* state_a, void* state_b, void* series, size_t slot_elems, int calls, int first_call,
+                            int feed_last, const dlwp_feedback* fb, const void* sol, const void* mean, int dtype,
+                            void* workspace, size_t workspace_bytes, dlwp_rollout_t* out);
+/* ---- the returned series of such a forecast (DLWP/model/extensions.py:243-302): one model call's output (n, t, c, hw) -> its
+ *      block of the result, time first (kept, n, c, hw) -- the transpose + reshape of :262-263 and the [:, :, :es] cut of :260 --
+ *      or (n, kept, c, hw) with keep_time_dim; destination channel j <- source channel perm[j] (NULL: identity): the sorted
+ *      (variable, level) order xarray's unstack returns (:298-302).                                                          */
+int dlwp_series_arrange(dlwp_handle_t, const void* src, void* dst, int n, int t, int c, int hw, int kept, const int* perm,
+                        int time_major, int dtype, void* stream);
 int dlwp_rollout_launch(dlwp_rollout_t, void* stream);
 int dlwp_rollout_destroy(dlwp_rollout_t);
 

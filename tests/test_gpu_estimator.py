@@ -92,6 +92,27 @@ def test_state_feedback_rejects_what_it_cannot_do():
         ops.make_feedback(4, 200, 2, 16, list(range(200)))
 
 
+@pytest.mark.parametrize('n,t,c,hw,kept,time_major', [(5, 2, 4, (6, 8), 2, True), (5, 2, 4, (6, 8), 1, True), (3, 3, 2, (5, 7), 3, False),
+                                                      (64, 2, 2, (88, 180), 2, True)])
+def test_series_arrange_is_the_returned_layout(n, t, c, hw, kept, time_major):
+    """DLWP/model/extensions.py:260-263, 298-302: the [:, :, :es] cut, time first, (variable, level) in sorted order -- per call"""
+    import ctypes
+    from dlwp_amd import _lib
+    rng = np.random.default_rng(n + t)
+    x = rng.standard_normal((n, t, c) + hw).astype(np.float32)
+    perm = [int(v) for v in rng.permutation(c)]
+    want = x[:, :kept][:, :, perm]
+    if time_major:
+        want = want.transpose(1, 0, 2, 3, 4)
+    src = torch.from_numpy(x).cuda()
+    dst = torch.empty(want.shape, dtype=torch.float32, device='cuda')
+    _lib.check(_lib.lib.dlwp_series_arrange(_lib.handle(0), ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), n, t, c,
+                                            hw[0] * hw[1], kept, (ctypes.c_int * c)(*perm), int(time_major), _lib.F32,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(dst.cpu().numpy()), _bits(np.ascontiguousarray(want)))
+
+
 def _mixing_network(c_in, c_out, hw):
     """oracle.estimator_cases.mixing_model as a REAL network: out[:, j] = tanh(sum_i A[j, i] p[:, i] + b[j]) is a 1 x 1 Conv2D
     with tanh -- the goldens of the reference's predict() then pin the device loop end to end."""
@@ -120,8 +141,8 @@ def test_device_loop_equals_the_reference_estimator(golden, tag, case, varlev, m
     gen = SeriesDataGenerator(d, _golden_dataset(golden('series'), varlev), **kw)
     est = TimeSeriesEstimator(d, gen)
     calls = []
-    real = d.model.fed_rollout_on_device
-    monkeypatch.setattr(d.model, 'fed_rollout_on_device', lambda *a, **k: calls.append(1) or real(*a, **k))
+    real = d.model._fed_entry
+    monkeypatch.setattr(d.model, '_fed_entry', lambda *a, **k: calls.append(1) or real(*a, **k))
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         out = est.predict(**case['predict'])
@@ -172,8 +193,8 @@ def test_validate_script_rollout_with_insolation_runs_on_the_device(monkeypatch,
     gen = SeriesDataGenerator(d, ds, input_time_steps=2, output_time_steps=2, add_insolation=True, interval=interval, batch_size=4)
     est = TimeSeriesEstimator(d, gen)
     calls = []
-    real = d.model.fed_rollout_on_device
-    monkeypatch.setattr(d.model, 'fed_rollout_on_device', lambda *a, **k: calls.append(1) or real(*a, **k))
+    real = d.model._fed_entry
+    monkeypatch.setattr(d.model, '_fed_entry', lambda *a, **k: calls.append(1) or real(*a, **k))
     out = est.predict(7, impute=impute)
     assert calls and out.shape[0] == 7
     monkeypatch.setenv('DLWP_ESTIMATOR_HOST', '1')
@@ -189,10 +210,15 @@ def test_validate_script_rollout_with_insolation_runs_on_the_device(monkeypatch,
     want = np_ref.run_layers(unet_layers((6, h, w), widths=(8, 16, 16, 16, 8), cout=4), X, weights).reshape(n, 2, 2, h, w)
     got0 = out.values[:2, :, ::-1, 0].transpose(1, 0, 2, 3, 4)          # variables come back sorted ('t', 'z')
     assert np.abs(got0 - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
-    # a second call replays the cached graph
+    # a second call replays the cached graphs
     monkeypatch.delenv('DLWP_ESTIMATOR_HOST')
     again = est.predict(7, impute=impute)
     assert len(calls) == 2
+    # the device-resident form (all calls in ONE graph, bench.py's timed region): the same series, un-arranged
+    dev = est.predict(7, impute=impute, return_device=True)
+    assert isinstance(dev, torch.Tensor) and tuple(dev.shape) == (4, n, 4, h, w)
+    ser = dev.cpu().numpy().reshape(4, n, 2, 2, h, w).transpose(0, 2, 1, 3, 4, 5).reshape(8, n, 2, h, w)[:7, :, ::-1]
+    assert np.array_equal(_bits(ser), _bits(host.values[:, :, :, 0]))
     assert np.array_equal(_bits(again.values), _bits(host.values))
 
 
@@ -206,8 +232,8 @@ def test_step_sequence_rollout_runs_on_the_device(monkeypatch):
     _weights_of(d.model, rng)
     x = rng.standard_normal((5,) + cs).astype(np.float32)
     calls = []
-    real = d.model.fed_rollout_on_device
-    monkeypatch.setattr(d.model, 'fed_rollout_on_device', lambda *a, **k: calls.append(1) or real(*a, **k))
+    real = d.model._fed_entry
+    monkeypatch.setattr(d.model, '_fed_entry', lambda *a, **k: calls.append(1) or real(*a, **k))
     for keep in (False, True):
         got = d.predict_timeseries(x, 4, step_sequence=True, keep_time_dim=keep)
         want = np_ref.predict_timeseries_nn(d.predict, x, 4, 3, step_sequence=True, keep_time_dim=keep)

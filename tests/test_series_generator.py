@@ -111,3 +111,20 @@ def test_labeled_array_selection_errors():
         da.sel(height=[2])
     with pytest.raises(ValueError, match="'predictors'"):
         SeriesDataGenerator(DLWPNeuralNet(scaler_type=None), object())
+
+
+@pytest.mark.parametrize('tag', sorted(CASES))
+def test_generate_inputs_is_generate_without_the_targets(tag):
+    """TimeSeriesEstimator.predict reads the predictors of generate([], scale_and_impute=False) and only the SHAPE of the
+    targets (DLWP/model/extensions.py:171-172, 199-203): generate_inputs builds just that, bit for bit."""
+    g = _gen(tag)
+    made = g.generate_inputs()
+    p, t = g.generate([], scale_and_impute=False)
+    if CASES[tag]['kw'].get('sequence'):
+        assert made is None                                # a list of target blocks: the estimator goes through generate()
+        return
+    assert made is not None and np.array_equal(made[0], p) and made[0].dtype == p.dtype and tuple(made[1]) == tuple(t.shape)
+    # a NaN anywhere in the series: samples may be dropped, so the full generate() decides
+    s = G['S'].copy()
+    s[5, 0, 0, 1, 1] = np.nan
+    assert _gen(tag, _ds(s)).generate_inputs() is None

@@ -1,0 +1,25 @@
+"""Where the time of TimeSeriesEstimator.predict -> LabeledArray goes (bench.py: timeseries_estimator.api)."""
+import cProfile
+import pstats
+import sys
+import os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from dlwp_amd.model import DLWPNeuralNet, SeriesDataGenerator, SeriesDataset, TimeSeriesEstimator
+from dlwp_amd.presets import unet_layers
+grid, members, forwards = (88, 180), 256, 28
+rng = np.random.default_rng(3)
+n_t = members + 3
+dates = (np.datetime64('2010-01-01T00') + np.arange(n_t) * np.timedelta64(6, 'h')).astype('datetime64[s]')
+series = rng.standard_normal((n_t, 2, 1) + grid).astype(np.float32)
+ds = SeriesDataset(series, {'sample': dates, 'variable': np.array(['z', 'tau']), 'level': np.array([500]),
+                            'lat': np.linspace(88., -88., grid[0]), 'lon': np.arange(0., 360., 360. / grid[1])},
+                   ('sample', 'variable', 'level', 'lat', 'lon'))
+d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
+d.build_model(unet_layers((6,) + grid, cout=4), loss='mse', optimizer='adam', metrics=['mae'])
+gen = SeriesDataGenerator(d, ds, input_time_steps=2, output_time_steps=2, add_insolation=True, batch_size=64)
+est = TimeSeriesEstimator(d, gen)
+for _ in range(3):
+    est.predict(2 * forwards)
+cProfile.run('est.predict(2 * forwards)', '/tmp/est.prof')
+pstats.Stats('/tmp/est.prof').sort_stats('cumulative').print_stats(25)
