@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void copy_many_kernel(const CopyTable t) {
 extern "C" {
 
 int dlwp_copy_many(dlwp_handle_t h, const void* const* srcs, void* const* dsts, const size_t* floats, int count, void* stream) {
-  DLWP_UNTAPED(dlwp_copy_many);
+  // (recorded by hand below -- the pointer tables are the caller's and must be copied -- so neither DLWP_TAPE nor DLWP_UNTAPED: the
+  //  latter would mark every recorded step that copies foreign and send it to the eager path; tests/test_abi.py knows this name)
   DLWP_CHECK_ARG(h && srcs && dsts && floats && count >= 0 && count <= 8, "dlwp_copy_many: null pointer or more than 8 copies");
   dlwp_tape_scope tape_scope_;
   if (tape_scope_.outer && dlwp_tape_recording(h)) {        // (the pointer tables are the caller's: copied)

@@ -570,13 +570,15 @@ int dlwp_conv2d_prep_flipped(dlwp_handle_t h, const void* w, float* dst, dlwp_sh
 
 static std::mutex g_splitk_mutex;
 // a stream that is about to be destroyed gives its region back (dlwp_train_step_destroy: the step's capture / side streams; the
-// device has been synchronised).  The last slot moves into the gap: its stream's earlier launches are through their counters
-// (zero between launches), its later ones are ordered behind them on that stream.
+// device has been synchronised).  The slot is marked EMPTY and handed to the next new stream; nothing moves: a stream keeps ITS
+// region for its whole lifetime, so step graphs built earlier (the region pointer is baked into their kernel arguments) never end up
+// sharing counters with a later stream's launches (the earlier compaction moved the last slot's stream into the gap).
+static void* const kSplitkEmpty = (void*)(intptr_t)-1;       // (NULL is a stream: the legacy default stream)
 void dlwp_splitk_release(dlwp_handle_t h, hipStream_t s) {
   std::lock_guard<std::mutex> lock(g_splitk_mutex);
   for (int i = 0; i < h->ksplit_used; ++i)
     if (h->ksplit_stream[i] == (void*)s) {
-      h->ksplit_stream[i] = h->ksplit_stream[--h->ksplit_used];
+      h->ksplit_stream[i] = kSplitkEmpty;
       return;
     }
 }
@@ -734,6 +736,11 @@ char* dlwp_splitk_region(dlwp_handle_t h, hipStream_t s) {
     }
     h->ksplit_mem = p;
   }
+  for (int i = 0; i < h->ksplit_used; ++i)              // a released slot first
+    if (h->ksplit_stream[i] == kSplitkEmpty) {
+      h->ksplit_stream[i] = (void*)s;
+      return h->ksplit_mem + (size_t)i * DLWP_SPLITK_REGION_BYTES;
+    }
   if (h->ksplit_used >= DLWP_SPLITK_REGIONS) return nullptr;
   h->ksplit_stream[h->ksplit_used] = (void*)s;
   return h->ksplit_mem + (size_t)(h->ksplit_used++) * DLWP_SPLITK_REGION_BYTES;

@@ -7,11 +7,12 @@
 // every peer's memory, waits for the peers' flags, reads all W buffers and sums them IN RANK ORDER -- the same order on every rank,
 // so the replicas stay bit-identical -- and applies the Adam update to its own parameters in the same kernel.
 //
-//   region of a rank (UNCACHED device memory, mapped by every peer):  header { flags[64], arrive, error }  +  2 payload buffers
+//   region of a rank (UNCACHED device memory, mapped by every peer):  header { flags[64], arrive, error, verdict }  +  2 payload buffers
 //   (step parity).  One launch of a PERSISTENT grid (at most one workgroup per CU, grid-stride over the float4s -- every workgroup is
 //   resident whatever the buffer's size; r4's one-workgroup-per-1024-floats grid could not be above ~2 M floats and then always
 //   timed out): (A) the workgroups copy `flat` into payload[step & 1]; the LAST one to finish stores `step` into flag
-//   [my rank] of every peer's header.  (B) every workgroup waits until all flags of its OWN header read `step`, then (C) sums its
+//   [my rank] of every peer's header.  (B) workgroup 0 waits until all flags of its OWN header read `step` and publishes ONE verdict for
+//   the launch, every workgroup waits for that verdict, then (C) sums its
 //   float4s over the ranks 0 .. W - 1 and updates p, m, v (or writes the sum back to flat).
 //   Two payload buffers suffice: a rank overwrites buffer s & 1 at step s + 2, after its step s + 1 completed, which needed every
 //   peer's flag s + 1, which a peer raises only after its own step s -- the last reader of that buffer -- returned.
@@ -34,6 +35,7 @@ struct Header {
   unsigned flag[64];       // flag[q] = the last step rank q published (written by rank q, remotely)
   unsigned arrive;         // blocks of the local launch that finished their copy
   unsigned error;          // 1: a wait timed out
+  unsigned verdict;        // 2 * step + 1: workgroup 0 of the local launch of `step` saw every flag (go); 2 * step: it gave up (no-go)
 };
 
 struct Peers {
@@ -73,25 +75,50 @@ __global__ __launch_bounds__(256) void xchg_allreduce_kernel(Peers peers, int wo
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
-  // ---- (B) wait for every rank's flag in the OWN header (the grid is resident as a whole: at most one workgroup per CU)
+  // ---- (B) ONE go / no-go decision per launch (with a timer per workgroup a flag arriving near the 2 s mark let some
+  //      workgroups apply their share of the update while others gave up).  Workgroup 0 waits for every rank's flag in the OWN
+  //      header and publishes the verdict; every other workgroup waits for the verdict of THIS step (the grid is resident as a
+  //      whole -- at most one workgroup per CU -- so workgroup 0 is running; its wait is bounded, theirs follows from it).
   {
     __shared__ unsigned s_ok;
     if (tid == 0) s_ok = 1u;
     __syncthreads();
-    if (tid < world) {
-      const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, (unsigned)XCHG_HEADER_BYTES, 0x00020000);
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
-      for (;;) {
-        const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(fr, (unsigned)(tid * 4), 0, SYS);
-        if ((int)(f - step) >= 0) break;
-        // (another workgroup of this launch gave up: so does this one -- nobody applies half an update)
-        const unsigned err = __builtin_amdgcn_raw_buffer_load_b32(fr, (unsigned)__builtin_offsetof(Header, error), 0, SYS);
-        if (err != 0u || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {        // 2 s: the peer is not coming
-          __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          s_ok = 0u;
-          break;
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, (unsigned)XCHG_HEADER_BYTES, 0x00020000);
+    if (blockIdx.x == 0) {
+      if (tid < world) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+        for (;;) {
+          const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(fr, (unsigned)(tid * 4), 0, SYS);
+          if ((int)(f - step) >= 0) break;
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {        // 2 s: the peer is not coming
+            s_ok = 0u;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
         }
-        __builtin_amdgcn_s_sleep(8);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        if (!s_ok) __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_raw_buffer_store_b32(2u * step + (s_ok ? 1u : 0u), fr, (unsigned)__builtin_offsetof(Header, verdict), 0, SYS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {
+      if (tid == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+          const unsigned vd = __builtin_amdgcn_raw_buffer_load_b32(fr, (unsigned)__builtin_offsetof(Header, verdict), 0, SYS);
+          if ((vd >> 1) == (step & 0x7fffffffu)) {
+            s_ok = vd & 1u;
+            break;
+          }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 600000000ull) {        // 6 s: workgroup 0 itself is gone (never expected)
+            __hip_atomic_store(&mine->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ok = 0u;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
       }
     }
     __syncthreads();

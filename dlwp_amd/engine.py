@@ -527,7 +527,12 @@ class Executor(object):
         if head_chunks == 1:
             head = [self._make_rollout(s0, series, calls, g, span=(0, 1))]
         else:
-            head = [self._make_rollout(s0, series, calls, 1, chain=(c, head_chunks), span=(0, 1)) for c in range(head_chunks)]
+            # (the chunks have one member count, i.e. one layout of prepared weights: chunk 0 prepares, the others -- launched behind
+            #  it on the same stream -- read its workspace)
+            head = []
+            for c in range(head_chunks):
+                head.append(self._make_rollout(s0, series, calls, 1, chain=(c, head_chunks), span=(0, 1),
+                                               ws=head[0].ws if head else None, prepared=bool(head)))
         tail = []
         for j in range(1, calls):
             tail.append(self._make_rollout(s0, series, calls, g, span=(j, 1), ws=tail[0].ws if tail else None, prepared=bool(tail)))

@@ -166,6 +166,8 @@ class DataGenerator(object):
                getattr(self.model, 'scaler_type', None), bool(self._remove_nan))
         cached = self.__dict__.get('_fast_sources')
         if cached is not None and (cached[0] == key or cached[0] == 'off'):
+            if cached[0] == key:
+                self._fast_misses = 0          #  a key that repeats: only CONSECUTIVE changes count against the fast path
             return cached[1]
         # a dataset whose `.values` hands out a fresh array every time (a lazy file-backed variable) changes the key on every call:
         # the decision -- a full NaN scan -- must not be re-taken per batch.  Three different keys: generate() it is.

@@ -206,6 +206,16 @@ class _Wrapper(object):
             # (the cached series / staging buffers are rewritten by the next call on the main stream: order it behind the copies)
             for s_ in down:
                 main.wait_stream(s_)
+        except BaseException:
+            #  a failed call: copies on the download streams may still be writing into the result array -- let them
+            # drain, then the array goes back to the pool instead of leaking its page-locked memory
+            for s_ in down:
+                try:
+                    s_.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+            util.pinned_results._give_back(host.view(-1))
+            raise
         finally:
             if pins:                       # (also when a call fails: no upload may still be reading a staging buffer that goes
                 up.synchronize()           #  back to the pool)
