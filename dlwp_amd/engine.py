@@ -539,6 +539,19 @@ class Executor(object):
         return StreamedRollout(s0, series, head, tail, n_out, self.device)
 
 
+def _mirrored(fn):
+    """driver mode of dlwp_amd.parallel (a plain script that asked for gpus=n): the call goes to the worker ranks too"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(self, *args, **kwargs):
+        drv = self.__dict__.get('_driver')
+        if drv is not None and not drv.in_call and not drv.closed:
+            return drv.call(self, fn.__name__, args, kwargs, fn)
+        return fn(self, *args, **kwargs)
+    return wrap
+
+
 class RolloutGraph(object):
     """Owner of a captured rollout (dlwp_rollout_t).  launch() replays all forwards with one hipGraphLaunch."""
 
@@ -702,6 +715,7 @@ class Model(object):
     def get_weights(self):
         return [a for lay in self.layers for a in lay.get_weights()]
 
+    @_mirrored
     def set_weights(self, arrays):
         arrays = list(arrays)
         k = 0
@@ -951,6 +965,7 @@ class Model(object):
         return ent
 
     # -- training (dlwp_amd.training) ---------------------------------------------------------------------------------- #
+    @_mirrored
     def compile(self, optimizer='adam', loss=None, metrics=None, loss_weights=None, **kwargs):
         from . import training
         self.__dict__.pop('_rollouts', None)     # compile re-homes the weights into one flat buffer: drop captured graphs
@@ -967,18 +982,21 @@ class Model(object):
             raise RuntimeError('You must compile a model before training/testing. Use `model.compile(optimizer, loss)`.')
         return self._trainer
 
+    @_mirrored
     def train_on_batch(self, x, y):
         return self._need_trainer().train_on_batch(x, y)
 
     def test_on_batch(self, x, y):
         return self._need_trainer().test_on_batch(x, y)
 
+    @_mirrored
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
             shuffle=True, initial_epoch=0, **kwargs):
         return self._need_trainer().fit(x, y, batch_size=batch_size, epochs=epochs, verbose=verbose,
                                         callbacks=callbacks, validation_data=validation_data, shuffle=shuffle,
                                         initial_epoch=initial_epoch)
 
+    @_mirrored
     def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=1, callbacks=None,
                       validation_data=None, validation_steps=None, use_multiprocessing=False, workers=1,
                       max_queue_size=10, shuffle=True, initial_epoch=0, **kwargs):

@@ -276,7 +276,15 @@ class DLWPNeuralNet(_Wrapper):
         self.gpus = gpus
         if gpus > 1:
             from .. import parallel
-            parallel.attach(net, gpus)
+            # (from a plain single process the other ranks are started here and build the same network from this specification:
+            #  the reference's keras.utils.multi_gpu_model is a single-process call too, models.py:104-109)
+            wargs = dict(is_convolutional=self.is_convolutional, is_recurrent=self.is_recurrent, time_dim=self.time_dim,
+                         scaler_type=self.scaler_type, scale_targets=self.scale_targets,
+                         apply_same_y_scaling=self.apply_same_y_scaling, impute_missing=self.impute)
+            parallel.attach(net, gpus, spec=('sequential', wargs, tuple(specs), dict(compile_kwargs)), wrapper=self)
+            with parallel.unmirrored(net):
+                net.compile(**compile_kwargs)
+            return
         net.compile(**compile_kwargs)
 
     # -- scaling / imputing (host side, scikit-learn; identity for every convolutional example: scaler_type=None) ----- #
@@ -387,6 +395,10 @@ class DLWPNeuralNet(_Wrapper):
         if time_steps < 1:
             raise ValueError("time_steps must be an int > 0")
         return_device = bool(kwargs.pop('return_device', False))
+        drv = getattr(self.model, '__dict__', {}).get('_driver')
+        if drv is not None and not drv.in_call and not drv.closed and not return_device and drv.world > 1:
+            return drv.sharded_rollout(self, predictors, time_steps, dict(kwargs, step_sequence=step_sequence,
+                                                                           keep_time_dim=keep_time_dim))
         n_calls = time_steps if step_sequence else int(math.ceil(1. * time_steps / self.time_dim))
         identity_io = (not self.impute) and (self.scaler_type is None)
         if identity_io and not step_sequence and self._device_rollout_ok(predictors):
@@ -450,8 +462,25 @@ class DLWPFunctional(_Wrapper):
         self._n_steps = len(model.outputs)
         self.gpus = gpus
         if gpus > 1:
+            import os
             from .. import parallel
-            parallel.attach(model, gpus)
+            spec = None
+            if parallel.needs_spawn():          # a plain single process: the workers load the graph from a file
+                path = os.path.join(parallel._shm_dir(), 'dlwp_graph_%d_%d.npz' % (os.getpid(), id(model) & 0xffff))
+                model.save(path)
+                wargs = dict(is_convolutional=self.is_convolutional, is_recurrent=self.is_recurrent, time_dim=self.time_dim)
+                spec = ('functional', wargs, path, dict(compile_kwargs))
+            try:
+                parallel.attach(model, gpus, spec=spec, wrapper=self)
+                with parallel.unmirrored(model):
+                    model.compile(**compile_kwargs)       # (its parameter broadcast ends only when the workers have built theirs)
+            finally:
+                if spec is not None:
+                    try:
+                        os.unlink(spec[2])
+                    except OSError:
+                        pass
+            return
         model.compile(**compile_kwargs)
 
     def scaler_transform(self, X, y=None):
@@ -476,6 +505,9 @@ class DLWPFunctional(_Wrapper):
         if time_steps < 1:
             raise ValueError("time_steps must be an int > 0")
         return_device = bool(kwargs.pop('return_device', False))
+        drv = getattr(self.model, '__dict__', {}).get('_driver')
+        if drv is not None and not drv.in_call and not drv.closed and not return_device and drv.world > 1:
+            return drv.sharded_rollout(self, predictors, time_steps, dict(kwargs, keep_time_dim=keep_time_dim))
         n_calls = int(math.ceil(time_steps / self._n_steps / self.time_dim))
         if self._device_rollout_ok(predictors):
             return self._rollout_device(predictors, n_calls, keep_time_dim, return_device)

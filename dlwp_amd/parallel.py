@@ -15,6 +15,19 @@ Data parallelism: one process per GPU.  Replaces keras.utils.multi_gpu_model (re
              index list is rank 0's, broadcast once per epoch, so shuffles agree without relying on seeds.
   inference: ensemble members / samples are independent (reference models.py:277-293 is elementwise over the sample
              axis): shard_bounds() gives each rank its members and NO collective is issued during the rollout.
+
+Two ways in, both one process per GPU underneath ("one process per GPU or one process with 8 handles -- both must
+work"):
+  launched : `python -m torch.distributed.run --nproc-per-node N script.py` -- every rank runs the script (SPMD).
+  driver   : a PLAIN `python script.py` that calls build_model(..., gpus=N), as the reference's scripts do
+             (examples/train_generator.py:243, Azure/train_func.py:101 -> keras.utils.multi_gpu_model inside one process):
+             attach() starts the N - 1 other ranks itself (`python -m dlwp_amd.worker`), sends them the model's SPECIFICATION --
+             layer triples or the saved functional graph, compile arguments; never the user's script -- and from then on
+             MIRRORS the calls that hold a collective (compile, set_weights, train_on_batch, fit, fit_generator) to them:
+             arguments travel pickled, arrays through files in /dev/shm that the workers map, the wrapper / network objects
+             inside generators are replaced by the worker's own.  predict_timeseries shards the members over the ranks and
+             gathers the series on rank 0.  Callbacks and validation run on rank 0 only; its stop_training flag is agreed at
+             the end of every epoch.
 """
 import ctypes
 import os
@@ -42,6 +55,9 @@ class DataParallel(object):
         self.backend = dist.get_backend(group)
         self._comm = None           # dlwp_comm_t (RCCL through the C ABI) once a device buffer asked for it
         self._comm_device = None
+        #: driver mode (a plain script that asked for gpus=n, parallel.spawn): rank 0 alone runs callbacks, so its stop_training
+        #: flag is agreed at the end of every epoch
+        self.mirror = os.environ.get('DLWP_WORKER') == '1'
 
     def shard(self, n):
         return shard_bounds(n, self.rank, self.world)
@@ -206,6 +222,237 @@ class DataParallel(object):
         self.dist.barrier(group=self.group)
 
 
+# --------------------------------------------------------------------------------------------------------------------- #
+# driver mode: a single script process that owns N - 1 worker ranks
+# --------------------------------------------------------------------------------------------------------------------- #
+
+#: arrays of at least this many bytes travel through /dev/shm files instead of the pickle
+SHM_MIN_BYTES = 1 << 16
+
+
+def _shm_dir():
+    return '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else __import__('tempfile').gettempdir()
+
+
+def dumps(obj, wrapper=None, net=None, files=None, prefix='dlwp'):
+    """pickle `obj` for the other ranks: the DLWP wrapper / its network become references to the receiver's own, arrays (numpy
+    or torch) of SHM_MIN_BYTES or more are written to files the receiver maps (their paths are appended to `files`)."""
+    import io
+    import pickle
+
+    class P(pickle.Pickler):
+        def persistent_id(self, o):
+            if wrapper is not None and o is wrapper:
+                return ('wrapper',)
+            if net is not None and o is net:
+                return ('net',)
+            if isinstance(o, torch.Tensor):
+                o = o.detach().cpu().numpy()
+                if o.nbytes < SHM_MIN_BYTES:
+                    return ('array', o)
+            if isinstance(o, np.ndarray) and o.nbytes >= SHM_MIN_BYTES and o.dtype != object and files is not None:
+                path = os.path.join(_shm_dir(), '%s_%d_%d.bin' % (prefix, os.getpid(), len(files) + dumps.counter))
+                dumps.counter += 1
+                a = np.ascontiguousarray(o)
+                with open(path, 'wb') as f:
+                    f.write(a.data)
+                files.append(path)
+                return ('file', path, a.dtype.str, a.shape)
+            return None
+    buf = io.BytesIO()
+    P(buf, protocol=4).dump(obj)
+    return buf.getvalue()
+
+
+dumps.counter = 0
+
+
+def loads(data, wrapper=None, net=None):
+    import io
+    import pickle
+
+    class U(pickle.Unpickler):
+        def persistent_load(self, pid):
+            if pid[0] == 'wrapper':
+                return wrapper
+            if pid[0] == 'net':
+                return net if net is not None else getattr(wrapper, 'model', None)
+            if pid[0] == 'array':
+                return pid[1]
+            if pid[0] == 'file':
+                _, path, dt, shape = pid
+                if int(np.prod(shape)) == 0:
+                    return np.empty(shape, dtype=np.dtype(dt))
+                return np.memmap(path, dtype=np.dtype(dt), mode='r', shape=tuple(shape))
+            raise pickle.UnpicklingError('unknown persistent id %r' % (pid,))
+    return U(io.BytesIO(data)).load()
+
+
+class Driver(object):
+    """Rank 0 of a group it started itself.  send() broadcasts one command to the worker loop (dlwp_amd/worker.py); call() mirrors a
+    method call: the workers run it on their replica with the same arguments while rank 0 runs it locally."""
+
+    def __init__(self, dp, procs):
+        self.dp, self.procs, self.in_call, self.closed = dp, procs, False, False
+        self.wrapper = None
+
+    @property
+    def world(self):
+        return self.dp.world
+
+    def check_workers(self):
+        dead = [(r + 1, p.poll()) for r, p in enumerate(self.procs) if p.poll() is not None]
+        if dead and not self.closed:
+            raise RuntimeError('data-parallel worker rank %d exited with status %r' % dead[0])
+
+    def send(self, cmd, net=None, files=None):
+        self.check_workers()
+        blob = dumps(cmd, wrapper=self.wrapper, net=net, files=files)
+        self.dp.dist.broadcast_object_list([blob], src=0, group=self.dp.group)
+
+    def call(self, net, name, args, kwargs, fn):
+        """mirror net.<name>(*args, **kwargs): the workers get the call (callbacks / validation / verbosity stay here), then rank 0
+        runs fn -- the collectives inside pair up."""
+        wkw = {k: v for k, v in kwargs.items() if k not in ('callbacks', 'validation_data', 'validation_steps', 'verbose')}
+        if name in ('fit', 'fit_generator'):
+            wkw['verbose'] = 0
+        files = []
+        self.in_call = True
+        try:
+            self.send(('call', name, args, wkw), net=net, files=files)
+            out = fn(net, *args, **kwargs)
+            self.dp.barrier()                # the workers are through the call: their maps of the argument files are no longer needed
+            return out
+        finally:
+            self.in_call = False
+            for f in files:
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
+
+    def sharded_rollout(self, wrapper, predictors, time_steps, kwargs):
+        """predict_timeseries with the members sharded over the ranks (no collective in the rollout; reference models.py:277-293 is
+        elementwise over the sample axis): every rank forecasts its contiguous rows and leaves the series in a /dev/shm file, rank 0
+        joins them along the sample axis."""
+        predictors = np.ascontiguousarray(predictors, dtype=np.float32)
+        files = []
+        self.in_call = True
+        try:
+            self.send(('rollout', predictors, int(time_steps), kwargs), net=wrapper.model, files=files)
+            lo, hi = self.dp.shard(predictors.shape[0])
+            mine = wrapper.predict_timeseries(predictors[lo:hi], time_steps, **kwargs) if hi > lo else None
+            parts = [None] * self.world
+            self.dp.dist.gather_object(None, parts, dst=0, group=self.dp.group)
+            series = []
+            for r, part in enumerate(parts):
+                if r == 0:
+                    if mine is not None:
+                        series.append(np.asarray(mine))
+                    continue
+                if part is None:
+                    continue
+                if isinstance(part, str):
+                    raise RuntimeError('data-parallel worker rank %d failed in predict_timeseries: %s' % (r, part))
+                path, dt, shape = part
+                files.append(path)
+                series.append(np.fromfile(path, dtype=np.dtype(dt)).reshape(shape))
+            return np.concatenate(series, axis=1) if len(series) > 1 else series[0]
+        finally:
+            self.in_call = False
+            for f in files:
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
+
+    def close(self):
+        if self.closed:
+            return
+        self.closed = True
+        try:
+            if all(p.poll() is None for p in self.procs):
+                blob = dumps(('stop',))
+                self.dp.dist.broadcast_object_list([blob], src=0, group=self.dp.group)
+        except Exception:  # noqa: BLE001
+            pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:  # noqa: BLE001
+                p.kill()
+        try:
+            if self.dp.dist.is_initialized():
+                self.dp.dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_driver = [None]
+
+
+def unmirrored(net):
+    """context: calls on `net` inside are NOT mirrored to the workers (rank 0's own compile during build_model: the workers
+    compile as part of their build command)"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def ctx():
+        drv = getattr(net, '_driver', None)
+        prev = drv.in_call if drv is not None else None
+        if drv is not None:
+            drv.in_call = True
+        try:
+            yield
+        finally:
+            if drv is not None:
+                drv.in_call = prev
+    return ctx()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn(gpus):
+    """Start ranks 1 .. gpus - 1 (`python -m dlwp_amd.worker`) and make this process rank 0 of their group.  Returns the Driver."""
+    import atexit
+    import subprocess
+    import sys
+    if _driver[0] is not None and not _driver[0].closed:
+        if _driver[0].world != gpus:
+            raise RuntimeError('this process already drives %d ranks; gpus=%d asked' % (_driver[0].world, gpus))
+        return _driver[0]
+    if torch.cuda.is_available() and torch.cuda.device_count() < gpus and os.environ.get('DLWP_SHARE_GPUS') != '1':
+        raise RuntimeError('gpus=%d requested but only %d device(s) are visible' % (gpus, torch.cuda.device_count()))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), WORLD_SIZE=str(gpus), DLWP_WORKER='1',
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    env['PYTHONPATH'] = root + (os.pathsep + env['PYTHONPATH'] if env.get('PYTHONPATH') else '')
+    procs = []
+    for r in range(1, gpus):
+        procs.append(subprocess.Popen([sys.executable, '-m', 'dlwp_amd.worker'], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      cwd=root))
+    os.environ.update(MASTER_ADDR=env['MASTER_ADDR'], MASTER_PORT=env['MASTER_PORT'], WORLD_SIZE=str(gpus), RANK='0',
+                      LOCAL_RANK=os.environ.get('LOCAL_RANK', '0'))
+    try:
+        init()
+    except Exception:
+        for p in procs:
+            p.kill()
+        raise
+    dp = DataParallel()
+    dp.mirror = True
+    drv = _driver[0] = Driver(dp, procs)
+    atexit.register(drv.close)
+    return drv
+
+
 def init(backend=None):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and
     bind this process to its GPU.  Returns (rank, world, local_rank).  No-op when already initialised."""
@@ -230,20 +477,44 @@ def init(backend=None):
     return rank, world, local
 
 
-def attach(model, gpus):
-    """build_model(gpus=n): make `model` data parallel over the current process group.  If the script was not launched
-    with one process per GPU (no process group, WORLD_SIZE unset) this raises instead of silently training on one GPU."""
+def needs_spawn():
+    """does attach() need a model specification for worker ranks -- a plain single process (no group, no launcher environment:
+    attach starts the workers) or a process that already drives some?"""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-            init()
-        else:
-            raise RuntimeError('gpus=%d requested but this is a single process: launch one process per GPU, e.g. '
+    if _driver[0] is not None and not _driver[0].closed:
+        return True
+    if os.environ.get('DLWP_WORKER') == '1' or (dist.is_available() and dist.is_initialized()):
+        return False
+    return int(os.environ.get('WORLD_SIZE', '1')) <= 1
+
+
+def attach(model, gpus, spec=None, wrapper=None):
+    """build_model(gpus=n): make `model` data parallel.  Launched one process per GPU (a process group exists / WORLD_SIZE is set):
+    over that group.  From a plain single process: this process becomes rank 0 and starts the other n - 1 ranks itself (spawn);
+    `spec` -- what the workers need to build the same model -- is sent to them: ('sequential', wrapper arguments, layer triples,
+    compile arguments) or ('functional', wrapper arguments, path of the saved graph, compile arguments)."""
+    import torch.distributed as dist
+    drv = None
+    if os.environ.get('DLWP_WORKER') == '1' or (dist.is_available() and dist.is_initialized() and _driver[0] is None):
+        pass                                    # a launched rank (or a worker of a driver): the group is there
+    elif _driver[0] is not None and not _driver[0].closed:
+        drv = _driver[0]
+    elif int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        init()
+    else:
+        if spec is None:
+            raise RuntimeError('gpus=%d requested from a single process: build the model through DLWPNeuralNet / DLWPFunctional '
+                               'build_model (which starts the other ranks), or launch one process per GPU, e.g. '
                                '`python -m torch.distributed.run --nproc-per-node %d script.py`' % (gpus, gpus))
-    dp = DataParallel()
+        drv = spawn(gpus)
+    dp = drv.dp if drv is not None else DataParallel()
     if dp.world != gpus:
         raise RuntimeError('gpus=%d but the process group has %d ranks' % (gpus, dp.world))
     model._dp = dp
+    if drv is not None:
+        drv.wrapper = wrapper
+        model._driver = drv
+        drv.send(('build', spec))
     tr = getattr(model, '_trainer', None)
     if tr is not None:              # attached after compile: the trainer picks the group up and aligns the replicas
         tr.dp = dp

@@ -1332,6 +1332,9 @@ class Trainer(object):
                 msg = ' - '.join('%s: %.4f' % (k, v) for k, v in logs.items())
                 print('Epoch %d/%d - %.1fs - %s' % (epoch + 1, epochs, time.time() - t0, msg))
             self._call(cbs, 'on_epoch_end', epoch, logs)
+            if self.dp is not None and self.dp.world > 1 and getattr(self.dp, 'mirror', False):
+                # driver mode: callbacks (EarlyStopping ...) run on rank 0 only -- every rank takes its decision
+                self.model.stop_training = bool(self.dp.broadcast_indices(np.array([int(bool(self.model.stop_training))]))[0])
             if self.model.stop_training:
                 break
         self._call(cbs, 'on_train_end', {})

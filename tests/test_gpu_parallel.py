@@ -376,3 +376,43 @@ def test_one_shot_exchange_that_waits_in_vain_gives_up_leaves_the_parameters_alo
         res = dict(ret)[0]
     assert 1.5 < res['took'] < 10.0, res
     assert res['timed_out'] and res['raised'] and res['p_untouched'] and res['m_untouched'] and res['tail_nan'] and res['grads_kept'], res
+
+
+@pytest.mark.parametrize('mode,n_global,functional', [('batch', 7, False), ('fit', 23, False), ('generator', 23, False),
+                                                      ('batch', 8, True)])
+def test_a_plain_script_that_asks_for_two_gpus_trains_like_the_single_process_run(tmp_path, mode, n_global, functional):
+    """VERDICT r5 missing 2 / SURVEY 8b: build_model(..., gpus=2) from a plain `python script.py` -- the reference's
+    keras.utils.multi_gpu_model is a single-process call (DLWP/model/models.py:104-109) -- starts the second rank itself
+    (dlwp_amd/worker.py), mirrors the training calls to it, shards predict_timeseries over the ranks and gathers on rank 0.  The
+    result must equal the single-process run from the same initial weights."""
+    import subprocess
+    from dlwp_amd.model import DLWPNeuralNet
+    from dlwp_amd.training import Adam
+    out = str(tmp_path / 'driver.npz')
+    env = dict(os.environ, DLWP_SHARE_GPUS='1', DLWP_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'scripts', 'driver_mode.py'), mode, str(n_global), out] +
+                       (['functional'] if functional else []), env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    got = np.load(out)
+    w0 = [got['w0_%d' % i] for i in range(int(got['n_w']))]
+    w1 = [got['w1_%d' % i] for i in range(int(got['n_w']))]
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
+    d.build_model(unet_layers(CS, widths=(8, 16, 16, 16, 8)), loss='mse', optimizer=Adam(lr=1e-3), metrics=['mae'])
+    d.model.set_weights(w0)
+    logs = _scenario(d, mode, n_global)
+    steps = int(got['iters']) - 1                       # (the script took one more step after its scenario)
+    assert d.model.optimizer.iterations == steps
+    for a, b in zip(got['logs'], np.asarray(logs, dtype=np.float64)):
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-6), (a, b)
+    for a, b in zip(w1, d.model.get_weights()):
+        assert np.abs(a - b).max() <= 1e-6 * steps, np.abs(a - b).max()
+    # the sharded forecast: members are independent, so the joined series is the one-process series bit for bit
+    d.model.set_weights(w1)
+    x, _ = _data(5, seed=9)
+    assert np.array_equal(got['series'], d.predict_timeseries(x, 4))
+    d2 = DLWPNeuralNet(is_convolutional=True, is_recurrent=False, time_dim=2, scaler_type=None, scale_targets=False)
+    d2.build_model(unet_layers(CS, widths=(8, 16, 16, 16, 8)), loss='mse', optimizer=Adam(lr=1e-3), metrics=['mae'])
+    d2.model.set_weights(w0)
+    assert np.allclose(got['again'], d2.model.train_on_batch(*_data(8)), rtol=2e-5, atol=1e-6)

@@ -152,9 +152,10 @@ def test_fit_generator_through_the_device_loader_equals_train_on_batch_on_the_sa
 
 
 def test_a_step_with_a_launch_the_tape_does_not_carry_is_refused_and_stays_eager(monkeypatch):
-    """a replay must never silently miss device work.  An entry point without a tape record (here dlwp_copy_many,
-    called from inside the step through a hooked _forward_backward) marks the tape foreign: dlwp_train_step_create refuses, the
-    shape stays eager and keeps giving the eager results."""
+    """a replay must never silently miss device work.  An entry point without a tape record (here
+    dlwp_series_merge_time, called from inside the step through a hooked _forward_backward) marks the tape foreign:
+    dlwp_train_step_create refuses, the shape stays eager and keeps giving the eager results.  (dlwp_copy_many, r5's example,
+    records itself since r6 -- ADVICE r5 -- and a step that copies replays: the second half of this test.)"""
     from dlwp_amd import ops
     monkeypatch.setenv('DLWP_TRAIN_GRAPH', '1')
     cs = (4, 16, 24)
@@ -168,18 +169,25 @@ def test_a_step_with_a_launch_the_tape_does_not_carry_is_refused_and_stays_eager
         tr = d.model._trainer
         if hook:
             inner = tr._forward_backward
-            scratch = [torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')]
+            scratch = [torch.ones((1, 2, 4, 8, 8), device='cuda'), torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')]
 
             def fb(x, y, scale):
-                ops.copy_many([(scratch[0], scratch[1])])         # a launch through the library that the tape does not record
+                if hook == 'untaped':
+                    ops.series_merge_time(scratch[0], 2)          # a launch through the library that the tape does not record
+                else:
+                    ops.copy_many([(scratch[1], scratch[2])])     # records itself (dlwp_tape_push): the step still replays
                 return inner(x, y, scale)
             tr._forward_backward = fb
         logs = [d.model.train_on_batch(x, y) for x, y in zip(xs, ys)]
         return d, tr, logs
     d0, tr0, logs0 = run(False)
-    d1, tr1, logs1 = run(True)
+    d1, tr1, logs1 = run('untaped')
+    d2, tr2, logs2 = run('copy_many')
     assert any(e.get('step') is not None for e in tr0._graphs.values())
     assert not tr1._graphs and len(tr1._no_tape) == 1                      # refused, remembered, eager from then on
+    assert any(e.get('step') is not None for e in tr2._graphs.values()) and not tr2._no_tape
+    for a, b in zip(logs0, logs2):
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
     for a, b in zip(logs0, logs1):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
     for a, b in zip(d0.model.get_weights(), d1.model.get_weights()):

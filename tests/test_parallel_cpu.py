@@ -102,13 +102,48 @@ def test_shard_bounds_partition_rows_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_attach_refuses_a_single_process():
+def test_attach_from_a_single_process_needs_the_model_specification():
+    """build_model(gpus=n) from a plain process starts the other ranks itself (parallel.spawn) and sends them the model's
+    specification; a bare attach() without one has nothing to send and says what to do."""
     from dlwp_amd import parallel
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         pytest.skip('a process group is active')
     os.environ.pop('WORLD_SIZE', None)
+    assert parallel.needs_spawn()
     with pytest.raises(RuntimeError, match='one process per GPU'):
         parallel.attach(object(), 8)
+
+
+def test_driver_commands_travel_with_arrays_in_shared_files_and_object_references():
+    """parallel.dumps / loads: what rank 0 of the driver mode sends its workers -- large arrays through files the receiver maps,
+    the wrapper / network objects as references to the receiver's own (a generator holds its DLWP model), the rest pickled."""
+    from dlwp_amd import parallel
+    from dlwp_amd.model import ArrayDataset, DataGenerator, DLWPNeuralNet
+    rng = np.random.default_rng(0)
+    P = rng.standard_normal((40, 2, 2, 16, 24)).astype(np.float32)          # 245 KB: a file
+    T = rng.standard_normal((40, 2, 2, 16, 24)).astype(np.float32)
+    small = np.arange(5, dtype=np.int64)
+    mine = DLWPNeuralNet(is_convolutional=True, time_dim=2, scaler_type=None, scale_targets=False)
+    theirs = DLWPNeuralNet(is_convolutional=True, time_dim=2, scaler_type=None, scale_targets=False)
+    np.random.seed(3)
+    gen = DataGenerator(mine, ArrayDataset(P, T), batch_size=8, shuffle=True)
+    files = []
+    blob = parallel.dumps(('call', 'fit_generator', (gen,), {'epochs': 2, 'idx': small, 't': torch.arange(4.)}), wrapper=mine,
+                          files=files)
+    try:
+        assert len(files) == 2 and all(os.path.exists(f) for f in files) and len(blob) < 20000
+        cmd = parallel.loads(blob, wrapper=theirs)
+        g2 = cmd[2][0]
+        assert cmd[:2] == ('call', 'fit_generator') and cmd[3]['epochs'] == 2 and np.array_equal(cmd[3]['idx'], small)
+        assert np.array_equal(cmd[3]['t'], np.arange(4, dtype=np.float32))
+        assert g2.model is theirs and g2 is not gen
+        assert np.array_equal(g2._indices, gen._indices)                     # the shuffle of the sender
+        for i in range(len(gen)):
+            a, b = gen[i], g2[i]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    finally:
+        for f in files:
+            os.unlink(f)
 
 
 def test_device_loader_host_path_preserves_order_and_content():
