@@ -78,11 +78,12 @@ def config_symbol(cfg, ups=False, x_loader=0):
         if split:          # the 16-position case of these entries: positions split over two waves per tile fragment
             return 'conv2d_fwd_wino2_f32<WinoSplitCfg<%d, %d, %d, %d, %d, %d, false, false> >' % (dil, th, tw, waves, bnf,
                                                                                                  ck)
-        # <..., IN16, UPS, DACT, POOL2, SPLITK, PAIRX, UPSQ>: the inference plan uses neither the training epilogue nor the second
-        # output, and launches that fill the chip are never split; the last two = the input loader (dlwp_launch_info.x_loader)
-        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s, false, false, false, %s, %s> >' % (
-            dil, th, tw, waves, bnf, ck, 'true' if ups else 'false', 'true' if x_loader == 1 else 'false',
-            'true' if x_loader == 2 else 'false')
+        # <..., IN16, UPS, DACT, POOL2, SPLITK, PAIRX, UPSQ, EP>: the inference plan uses neither the training epilogue nor the second
+        # output, and launches that fill the chip are never split; the last three = the input loader and the edge pairs
+        # (dlwp_launch_info.x_loader: 1 / 2, + 4)
+        return 'conv2d_fwd_wino_f32<WinoCfg<%d, %d, %d, %d, %d, %d, false, %s, false, false, false, %s, %s, %s> >' % (
+            dil, th, tw, waves, bnf, ck, 'true' if ups else 'false', 'true' if (x_loader & 3) == 1 else 'false',
+            'true' if (x_loader & 3) == 2 else 'false', 'true' if x_loader & 4 else 'false')
     if bnf < 0:
         return 'conv2d_fwd_packn_f32<PackCfg<%d, %d, %d, %d, %d, %d, %d, %d> >' % (ks, dil, th, tw, waves, fa, ck, -bnf)
     if pool >= 2:
@@ -92,10 +93,10 @@ def config_symbol(cfg, ups=False, x_loader=0):
 
 
 def kernel_family(symbol):
-    """A Winograd instance's symbol without its last two template arguments (the input loader, r5: WinoCfg::PAIRX / UPSQ): the
-    loader variants of one tile configuration run the same loop on the same bits and count as ONE kernel in the roofline -- a
-    prefix of every variant's full name, so the lookups below find (and average over) all of them."""
-    m = re.match(r'^(conv2d_fwd_wino_f32<WinoCfg<(?:[^,<>]+, ){10}[^,<>]+), (?:true|false), (?:true|false)> >$', symbol)
+    """A Winograd instance's symbol without its last three template arguments (the input loader and the edge pairs, r5:
+    WinoCfg::PAIRX / UPSQ / EP): those variants of one tile configuration run the same loop on the same bits and count as ONE
+    kernel in the roofline -- a prefix of every variant's full name, so the lookups below find (and average over) all of them."""
+    m = re.match(r'^(conv2d_fwd_wino_f32<WinoCfg<(?:[^,<>]+, ){10}[^,<>]+), (?:true|false), (?:true|false), (?:true|false)> >$', symbol)
     return m.group(1) if m else symbol
 
 
@@ -268,10 +269,18 @@ def time_layers(model, members, iters=5):
             return 'conv2d_fwd_direct_f32'
         launch_flops = [(symbol_of(i), i[3]) for i in info]
         cfg = cfgs[info[0][0]] if info and info[0][0] >= 0 else None
+        # USEFUL matrix work: what the instance's GEMMs would multiply without tile / channel padding -- for a Winograd instance
+        # 16 (9 on an up-sampled source with odd halos) GEMMs of (2x2 output tiles) x cout x cin; otherwise the direct sum
+        cco, cho, cwo = getattr(op, 'conv_out_shape', None) or op.out_shape
+        if cfg is not None and cfg[0] == 3 and cfg[5] == 0:
+            useful = 2.0 * (9 if ups else 16) * ((cho + 1) // 2) * ((cwo + 1) // 2) * cco * op.xs[0] * members
+        else:
+            useful = 2.0 * cho * cwo * cco * op.xs[0] * kh * kw * members
         rows.append({'layer': lay.name, 'cin': op.xs[0], 'cout': co, 'k': kh, 'dil': dil_run[0], 'tile_cfg': cfg,
                      'kernel': launch_flops[0][0], 'launches': len(info), 'out': [ho, wo], 'ms_isolated': ms,
                      'flops': flops, 'bytes': nbytes,
-                     'executed_flops': sum(i[3] for i in info), 'launch_flops': launch_flops,
+                     'executed_flops': sum(i[3] for i in info), 'useful_flops': min(useful, sum(i[3] for i in info)),
+                     'launch_flops': launch_flops,
                      'bf16_matrix': bool(info and info[0][4])})
         if op.alg_flops is not None:
             rows[-1]['restated'] = 'on the low-resolution source of the UpSampling2D in front (DESIGN.md 5.7)'
@@ -354,6 +363,11 @@ def roofline_of(rows, members):
            'layers': ['%s (%d->%d, %dx%d dil %d, out %dx%d)' % (r['layer'], r['cin'], r['cout'], r['k'], r['k'], r['dil'],
                                                                  r['out'][0], r['out'][1]) for r in rs],
            'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+           #  executed minus multiplied padding: a change that removes padded work lowers `frac` and raises this
+           'useful_frac': sum(r.get('useful_flops', r['executed_flops']) for r in rs) / ms / 1e9 / peak,
+           'useful_definition': 'the same launches priced on the matrix work WITHOUT tile / channel padding (Winograd: positions x '
+                                '2x2 output tiles x cout x cin); frac - useful_frac is multiplied padding.  Judge kernel changes by '
+                                'steps/s and useful_frac, not by frac',
            'definition': 'matrix-core FLOPs the kernel executes (MFMA instructions x 2048, tile and channel padding '
                          'included) / HIP-event time of its launches inside a forward / dense fp32 MFMA peak; `traffic` and '
                          '`rocprof` are LOOKUPS in the committed rocprofv3 summaries under profiles/ (counters cannot be read '
@@ -369,11 +383,12 @@ def roofline_of(rows, members):
     else:
         # `kernel` stays a symbol rocprofv3 prints (the variant with the largest share); the figures are the family's
         out['kernel'] = max(variants, key=lambda v: sum(r['ms'] for r in rs if r['kernel'] == v))
-        out['kernel_family'] = sym + ', *, *> >'
+        out['kernel_family'] = sym + ', *, *, *> >'
         out['instances'] = {v: [r['layer'] for r in rs if r['kernel'] == v] for v in variants}
-        out['instances_note'] = ('one tile configuration, one loop, the same bits; the last two template arguments pick the input '
-                                 'loader (DLWP_OPT_WINO_XLOADER: image-aligned column pairs on even widths, element by element '
-                                 'otherwise); `rocprof` and `traffic` are means over all their launches')
+        out['instances_note'] = ('one tile configuration, one loop, the same bits; the last three template arguments pick the input '
+                                 'loader and the edge pairs (DLWP_OPT_WINO_XLOADER: image-aligned column pairs on even widths, '
+                                 'element by element otherwise; the half-used last tile row of a 44-row map paired up); `rocprof` '
+                                 'and `traffic` are means over all their launches')
     if any(r['launches'] > 1 for r in rs):
         out['note'] = ('layers on a 45-column map hand their ragged last column tile to a 16-wide instance in a second '
                        'launch; its time and FLOPs are inside these figures')
@@ -1118,7 +1133,7 @@ def main():
         if cc:
             out['roofline']['pmc_crosscheck'] = cc
         out['layers'] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
-                          if k not in ('flops', 'bytes', 'executed_flops', 'launch_flops', 'bf16_matrix')} for r in rows]
+                          if k not in ('flops', 'bytes', 'executed_flops', 'useful_flops', 'launch_flops', 'bf16_matrix')} for r in rows]
     if not a.no_extras:
         sub = {}
         if rank == 0:

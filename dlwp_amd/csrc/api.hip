@@ -22,28 +22,30 @@ void dlwp_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// Debug aid (DLWP_SEGV_TRACE=1 in the environment, read at the first dlwp_create): a SIGSEGV prints the NATIVE backtrace (module +
+// Debug aid (DLWP_SEGV_TRACE=1 in the environment, read at the first dlwp_create): a SIGSEGV / SIGABRT prints the NATIVE backtrace (module +
 // offset per frame, glibc backtrace_symbols_fd) before the handler that was installed before runs -- Python's faulthandler shows
 // the interpreter's frames only, and a fault inside the HIP runtime (r4: hipGraphLaunch of a forked graph) has none of ours.
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
-static struct sigaction g_prev_segv;
+static struct sigaction g_prev_segv, g_prev_abrt;
 static void segv_trace(int sig, siginfo_t* info, void* ctx) {
   void* frames[64];
   const int n = backtrace(frames, 64);
-  const char msg[] = "\n[dlwp] SIGSEGV -- native backtrace:\n";
-  (void)!write(2, msg, sizeof(msg) - 1);
+  const char msg[] = "\n[dlwp] SIGSEGV -- native backtrace:\n", msga[] = "\n[dlwp] SIGABRT -- native backtrace:\n";
+  if (sig == SIGABRT) (void)!write(2, msga, sizeof(msga) - 1);
+  else (void)!write(2, msg, sizeof(msg) - 1);
   {
     char b[96];
     const int k = snprintf(b, sizeof(b), "[dlwp] fault address %p\n", info ? info->si_addr : nullptr);
     (void)!write(2, b, k);
   }
   backtrace_symbols_fd(frames, n, 2);
-  if (g_prev_segv.sa_flags & SA_SIGINFO) {
-    if (g_prev_segv.sa_sigaction) g_prev_segv.sa_sigaction(sig, info, ctx);
-  } else if (g_prev_segv.sa_handler && g_prev_segv.sa_handler != SIG_DFL && g_prev_segv.sa_handler != SIG_IGN) {
-    g_prev_segv.sa_handler(sig);
+  const struct sigaction& prev = sig == SIGABRT ? g_prev_abrt : g_prev_segv;
+  if (prev.sa_flags & SA_SIGINFO) {
+    if (prev.sa_sigaction) prev.sa_sigaction(sig, info, ctx);
+  } else if (prev.sa_handler && prev.sa_handler != SIG_DFL && prev.sa_handler != SIG_IGN) {
+    prev.sa_handler(sig);
   }
   signal(sig, SIG_DFL);
   raise(sig);
@@ -65,6 +67,7 @@ static void install_segv_trace() {
   sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
   sigemptyset(&sa.sa_mask);
   sigaction(SIGSEGV, &sa, &g_prev_segv);
+  sigaction(SIGABRT, &sa, &g_prev_abrt);     // (r5: an abort() inside the HIP runtime or glibc -- seen once in a finaliser -- as well)
 }
 
 // dlwp_set_crash_message: a text the process leaves on stdout if it dies of SIGABRT / SIGSEGV / SIGBUS (the HSA runtime abort()s the
@@ -122,7 +125,7 @@ static dlwp_options& default_options_rw() {
     e = getenv("DLWP_WGRAD_FILL");        // (A/B runs of DLWP_OPT_WGRAD_FILL)
     if (e && atoi(e) >= 1 && atoi(e) <= 64) o.wgrad_fill = atoi(e);
     e = getenv("DLWP_WINO_XLOADER");      // (A/B runs of DLWP_OPT_WINO_XLOADER)
-    if (e && e[0] >= '0' && e[0] <= '3') o.wino_xld = e[0] - '0';
+    if (e && e[0] >= '0' && e[0] <= '7') o.wino_xld = e[0] - '0';
     e = getenv("DLWP_SPLITK");            // (A/B runs of DLWP_OPT_SPLITK)
     if (e && atoi(e) >= 0 && atoi(e) <= 64) o.splitk = atoi(e);
     return o;
@@ -141,7 +144,7 @@ static int set_in(dlwp_options& o, int option, int value, int* previous, const c
     case DLWP_OPT_WINO_PAIRS: slot = &o.wino_pairs; value = value ? 1 : 0; break;
     case DLWP_OPT_FEW_STREAM: slot = &o.few_stream; value = value < 0 ? 0 : (value > 2 ? 2 : value); break;
     case DLWP_OPT_WGRAD_FILL: slot = &o.wgrad_fill; value = value < 1 ? 1 : (value > 64 ? 64 : value); break;
-    case DLWP_OPT_WINO_XLOADER: slot = &o.wino_xld; value &= 3; break;
+    case DLWP_OPT_WINO_XLOADER: slot = &o.wino_xld; value &= 7; break;
     case DLWP_OPT_SPLITK: slot = &o.splitk; value = value < 0 ? 0 : (value > 64 ? 64 : value); break;
     default: DLWP_FAIL(DLWP_EINVAL, "%s: unknown option %d", fn, option);
   }

@@ -13,7 +13,7 @@ struct dlwp_options {
   int winograd = 1, bf16_mfma = 1, forced_cfg = -1, forced_wgrad = -1, wino_pairs = 1;
   int few_stream = 1;   // conv_fwd_few.hip: 0 off, 1 when the batch is large enough, 2 whenever the layer qualifies (DLWP_OPT_FEW_STREAM)
   int wgrad_fill = 4;   // weight gradient: workgroups per CU the split count aims at, in eighths of 16 waves (DLWP_OPT_WGRAD_FILL)
-  int wino_xld = 3;     // Winograd input loaders: bit 0 column pairs, bit 1 source-resolution fetch of an up-sampled source (DLWP_OPT_WINO_XLOADER)
+  int wino_xld = 7;     // Winograd input loaders: bit 0 column pairs, bit 1 source-resolution fetch of an up-sampled source, bit 2 edge pairs (DLWP_OPT_WINO_XLOADER)
   int splitk = 0;       // Winograd forward on small grids: 0 never (default, r5: batch-invariant bits), 1 by rule, k >= 2 forced split count (DLWP_OPT_SPLITK)
 };
 const dlwp_options& dlwp_default_options();

@@ -928,6 +928,11 @@ int dlwp_launch_conv2d(dlwp_handle_t h, const void* x, const void* w, const void
       a.ksplit <= 1 && !a.in_bf16 && !a.yact && !a.y2 && !lstm &&
       dlwp_pair_stash_fwd(h, a, wino_skips_row2(a) ? 1 : 0, (int)grid, e.launch, s))
     return DLWP_OK;
+  if (is_wino(e) && !e.split && lp.narrow < 0 && !lstm && wino_edge_pairs(a, e.dil, e.th, e.tw, e.waves, e.bnf)) {
+    a.edge_pairs = 1;     // the last tile row's blocks take two column tiles each (WinoCfg::EP); a launch that was handed over to a
+                          // pair (above) keeps the plain grid: the fused kernel runs the plain body
+    grid = (long long)(grid / ((long long)a.tiles_h * a.tiles_w)) * ((long long)a.tiles_w * (a.tiles_h - 1) + (a.tiles_w + 1) / 2);
+  }
   e.launch(a, (int)grid, s);
   if (lp.narrow >= 0) {
     const ConvKernelEntry& p = r.entries[lp.narrow];
@@ -1438,7 +1443,15 @@ int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
     a.ksplit = lp.ksplit;
     a.xld = h->opt.wino_xld;
     a.col0 = 0;
-    out2[0].x_loader = wino_x_loader(a, e.dil, e.th, e.tw, e.waves, e.bnf);
+    a.tiles_h = lp.tiles_h;
+    a.tiles_w = lp.tiles_w;
+    if (lp.narrow < 0 && wino_edge_pairs(a, e.dil, e.th, e.tw, e.waves, e.bnf)) {   // the paired edge blocks: fewer workgroups, less padding multiplied
+      a.edge_pairs = 1;
+      const long long g = lp.grid / ((long long)a.tiles_h * a.tiles_w) * ((long long)a.tiles_w * (a.tiles_h - 1) + (a.tiles_w + 1) / 2);
+      out2[0].grid = (int)g;
+      out2[0].matrix_flops = executed_matrix_flops(e, a, g);
+    }
+    out2[0].x_loader = wino_x_loader(a, e.dil, e.th, e.tw, e.waves, e.bnf) | (a.edge_pairs ? 4 : 0);
   }
   *n_launches = 1;
   if (lp.narrow >= 0) {

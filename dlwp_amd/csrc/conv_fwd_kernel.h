@@ -40,8 +40,10 @@ struct ConvArgs {
   int compute_bf16;       // DLWP_COMPUTE_BF16: a float32-stored input may be rounded to bf16 for the bf16 matrix cores
   int col0 = 0;           // Winograd: first output column of this launch (a wide-tile launch + a narrow one for the rest)
   int out_d2s = 0;        // the 4 F output channels are 2x2 phases: stored interleaved, y = (N, out_c_total, 2 Ho, 2 Wo)
-  int xld = 3;            // Winograd input loaders the launch may take (DLWP_OPT_WINO_XLOADER): bit 0 column pairs (WinoCfg::PAIRX),
-                          // bit 1 source-resolution fetch of an up-sampled source (WinoCfg::UPSQ); same bits either way
+  int xld = 7;            // Winograd input loaders the launch may take (DLWP_OPT_WINO_XLOADER): bit 0 column pairs (WinoCfg::PAIRX),
+                          // bit 1 source-resolution fetch of an up-sampled source (WinoCfg::UPSQ), bit 2 edge pairs (WinoCfg::EP);
+                          // same bits either way
+  int edge_pairs = 0;     // the launch is an EP launch: the last tile row's blocks take two column tiles each (wino_edge_pairs)
   int pair_vw = 0;        // Winograd, narrow maps: two samples side by side in a VIRTUAL row of 2 pair_vw columns (sample k at
                           // [k pair_vw, k pair_vw + W)); the grid then counts sample PAIRS (conv_fwd_wino_kernel.h)
   // ConvLSTM2D cell update in the epilogue (bf16 matrix-core instances with 64-channel blocks, conv_fwd_bf16_kernel.h):
@@ -604,6 +606,22 @@ static inline int wino_x_loader(const ConvArgs& a, int dil, int th, int tw, int 
   // pairs on even image columns: whole inside a row of even length whatever the (zero / periodic) halo does
   return ((a.xld & 1) && a.src_mode == DLWP_SRC_DIRECT && (a.W & 1) == 0 && a.W >= 2 && a.Ws == a.W &&
           (a.mode_w == DLWP_PAD_ZERO || a.mode_w == DLWP_PAD_WRAP) && ((a.col0 - a.pad_left - 1) & 1) == 0) ? 1 : 0;
+}
+
+// Edge pairs (WinoCfg::EP): the last 8-row tile of the map is at most half used, so its blocks take the four valid rows of two column
+// tiles each.  1 when a launch of the (dil, th, tw, waves, bnf) geometry does that (the grid then counts
+// tiles_w (tiles_h - 1) + ceil(tiles_w / 2) blocks per image and channel tile).  Compiled for the float32 plain / pooled epilogues of
+// the 8 x 32 x 32-channel instance on the column-pair loader.  (The 9-position instances of an up-sampled source: measured on the
+// element-wise loader -- their source-resolution fetch has neither the LDS nor the registers for a second half -- and no faster than
+// that fetch without the pairs, DESIGN 5.20: not compiled.)
+static inline int wino_edge_pairs(const ConvArgs& a, int dil, int th, int tw, int waves, int bnf) {
+  if (!(a.xld & 4) || dil != 1 || th != 8 || tw != 32 || waves != 4) return 0;
+  if (a.in_bf16 || a.out_bf16 || a.pair_vw || a.ksplit > 1 || a.yact || a.y2 || a.col0 != 0 || a.out_pool == 2) return 0;
+  const int left = a.Ho & 7;
+  if (left < 1 || left > 4 || a.tiles_w < 2 || a.tiles_h != (a.Ho + 7) / 8) return 0;
+  if (a.src_mode != DLWP_SRC_DIRECT || bnf != 2) return 0;
+  return ((a.xld & 1) && (a.W & 1) == 0 && a.W >= 2 && a.Ws == a.W && (a.mode_w == DLWP_PAD_ZERO || a.mode_w == DLWP_PAD_WRAP) &&
+          ((a.pad_left + 1) & 1) == 0) ? 1 : 0;
 }
 
 template <class C>

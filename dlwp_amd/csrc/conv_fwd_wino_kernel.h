@@ -42,8 +42,19 @@
 // contribute nothing and their MFMAs (and U fragment loads) are left out -- 9 multiplies per 2x2 output tile and channel
 // pair instead of 16 (direct: 36), bit-identical results.
 template <int DIL_, int TH_, int TW_, int WAVES_, int BNF_, int CK_, bool IN16_ = false, bool UPS_ = false, bool DACT_ = false,
-          bool POOL2_ = false, bool SPLITK_ = false, bool PAIRX_ = false, bool UPSQ_ = false>
+          bool POOL2_ = false, bool SPLITK_ = false, bool PAIRX_ = false, bool UPSQ_ = false, bool EP_ = false>
 struct WinoCfg {
+  // EP (r5, "edge pairs"): a map whose height leaves the last 8-row tile at most half used (44 rows: 5.5 tiles) spends one block
+  // in six on four rows of padding -- a knock-out with 17 of every 18 blocks launched ran the 256-member rollout 3.9 % faster.
+  // In an EP launch the blocks of the last tile row take the four valid rows of TWO neighbouring column tiles each: waves 0-1 the
+  // rows of tile tw, waves 2-3 those of tile tw + 1.  The loop is untouched; what changes are per-lane offsets -- the loader
+  // fetches two 6-row halves (LDS rows 0-5 and 6-11 of a 12-row plane), the patch origin of wave w is LDS row 6 (w >> 1) + 2 (w & 1),
+  // and the store phase sends staged rows 4-7 to rows 0-3 of the second tile.  Same arithmetic on the same operands: the same bits.
+  // The grid counts tiles_w (tiles_h - 1) + ceil(tiles_w / 2) blocks per image and channel tile (host: wino_edge_pairs).
+  static constexpr bool EP = EP_;
+  static_assert(!EP_ || (DIL_ == 1 && TH_ == 8 && TW_ == 32 && WAVES_ == 4 && !IN16_ && !DACT_ && !POOL2_ && !SPLITK_ && !UPSQ_),
+                "edge pairs: the 8 x 32 four-wave float32 instances, plain / pooled epilogues, element-wise or column-pair loader");
+  static constexpr int LRE = EP_ ? 2 * (TH_ / 2 + 2 * DIL_) : TH_ + 2 * DIL_;   // LDS rows of a channel's input tile
   // UPSQ (r5): the tile of an UP-SAMPLED source is fetched at SOURCE resolution -- one 4-byte load per source element, written to
   // the (up to) 2 x 2 tile slots it replicates into: a chunk needs (LR/2 + 1)(LC/2 + 1) = 108 loads per channel instead of 340
   // (4 per thread and chunk instead of 16; a knock-out of three loads in four bounded the gain at 3.4 % of the 256-member rollout,
@@ -96,7 +107,7 @@ struct WinoCfg {
   static constexpr int NSR = LR / 2 + 1, NSC = LC / 2 + 1;    // UPSQ: source rows / columns under a tile
   static constexpr int NQ = UPSQ_ ? (CK_ * NSR * NSC + WAVES_ * 64 - 1) / (WAVES_ * 64) : 0;   // UPSQ: source elements per thread and chunk
   static constexpr int NPAIR = LC / 2 + 1;             // PAIRX: pairs per tile row (columns -1 ... LC)
-  static constexpr int PS_RAW = UPSQ_ ? (LR + 1) * (LC + 2) : PAIRX_ ? LR * (LC + 2) + 1 : LR * LC;
+  static constexpr int PS_RAW = UPSQ_ ? (LR + 1) * (LC + 2) : PAIRX_ ? LRE * (LC + 2) + 1 : LRE * LC;
   static constexpr int PS = PS_RAW + (((16 - PS_RAW % 32) % 32) + 32) % 32;
   static constexpr int RTH = TH / (2 * DIL), RTW = TW / (2 * DIL);  // tiles per parity class
   static constexpr int T = DIL * DIL * RTH * RTW;                      // = TH*TW/4
@@ -112,7 +123,7 @@ struct WinoCfg {
   static constexpr int O2_FLOATS = O_FLOATS + (POOL2_ ? BN * PPS : 0);
   static constexpr int L_FLOATS = (2 * X_FLOATS + 2 * U_FLOATS) > O2_FLOATS ? (2 * X_FLOATS + 2 * U_FLOATS) : O2_FLOATS;
   static constexpr int LDS_BYTES = L_FLOATS * 4;
-  static constexpr int NPOS = PAIRX_ ? (LR * NPAIR + NT - 1) / NT : (LR * LC + NT - 1) / NT;   // items (elements / pairs) per thread
+  static constexpr int NPOS = PAIRX_ ? (LRE * NPAIR + NT - 1) / NT : (LRE * LC + NT - 1) / NT;   // items (elements / pairs) per thread
   static constexpr int XRW = PAIRX_ ? 2 * NPOS : NPOS;                                          // ... and their registers
   static constexpr int NXI = CK * NPOS;            // input elements per thread and chunk
   static constexpr int NUI = (CK * BN) / NT;       // (ci, co) filter items per thread
@@ -156,10 +167,22 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
   const int tile_lin = L;
   const int c_base = C::SPLITK ? ks * a.kchunks * C::CK : 0;                                    // first input channel of this block
   const int cin_l = C::SPLITK ? min(a.Cin - c_base, a.kchunks * C::CK) : a.Cin;                 // ... and how many it multiplies
-  const int tw = L % a.tiles_w;
-  L /= a.tiles_w;
-  const int th = L % a.tiles_h;
-  L /= a.tiles_h;
+  int tw, th;
+  bool ep = false;      // (uniform) this block is an edge pair: the valid half of column tiles tw and tw + 1 of the last tile row
+  if constexpr (C::EP) {
+    const int full = a.tiles_w * (a.tiles_h - 1), per = full + ((a.tiles_w + 1) >> 1);
+    const int t = L % per;
+    L /= per;
+    ep = t >= full;
+    th = ep ? a.tiles_h - 1 : t / a.tiles_w;
+    tw = ep ? 2 * (t - full) : t - th * a.tiles_w;
+  } else {
+    tw = L % a.tiles_w;
+    L /= a.tiles_w;
+    th = L % a.tiles_h;
+    L /= a.tiles_h;
+  }
+  constexpr int HR = C::TH / 2 + 2 * C::DIL;    // EP: input rows of one half (4 output rows + halo)
   const int ct = L % a.cout_tiles;
   const int n = L / a.cout_tiles;
   const int i0 = th * C::TH, j0 = a.col0 + tw * C::TW, n0 = ct * C::BN;
@@ -193,13 +216,17 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
   for (int q = 0; q < C::NPOS; ++q) {
     int s = tid + q * C::NT;
     if constexpr (C::PAIRX) {
-      if (q == C::NPOS - 1 && s >= C::LR * C::NPAIR) s = 0;
-      const int lr = s / C::NPAIR, pp = s - lr * C::NPAIR;
+      if (q == C::NPOS - 1 && s >= (ep ? C::LRE : C::LR) * C::NPAIR) s = 0;
+      int lr = s / C::NPAIR;
+      const int pp = s - lr * C::NPAIR;
+      const int lrl = lr;                              // the LDS row; EP: the second half's rows sit behind the first's
+      const int hx = (ep && lr >= HR) ? 1 : 0;
+      lr -= hx * HR;
       const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
-      const int vc = j0 - a.pad_left - 1 + 2 * pp;     // even (host): vc + 1 is its neighbour in memory wherever vc maps to
+      const int vc = j0 + hx * C::TW - a.pad_left - 1 + 2 * pp;   // even (host): vc + 1 is its neighbour in memory wherever vc maps to
       const int cs = (vc < -a.W) ? -1 : dlwp_map_coord_tile(vc, a.W, a.mode_w);
       goff[q] = (rs >= 0 && cs >= 0) ? (unsigned)(rs * a.Ws + cs) * 4u : 0x7ffffff0u;
-      loff[q] = lr * C::LCP + 2 * pp + 1;
+      loff[q] = lrl * C::LCP + 2 * pp + 1;
       // opaque to the compiler: it would merge the two stores of a pair into ds_write2_b32, whose 8-bit offsets cannot reach a
       // channel plane -- one v_add_u32 per store for the base, i.e. eight more switches between the matrix pipe and the vector ALU
       // per chunk; two ds_write_b32 carry the plane offset in their 16-bit immediates
@@ -207,10 +234,14 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
       asm volatile("" : "+v"(loff1[q]));
       continue;
     }
-    if (q == C::NPOS - 1 && s >= C::LR * C::LC) s = 0;
-    const int lr = s / C::LC, lc = s - lr * C::LC;
+    if (q == C::NPOS - 1 && s >= (ep ? C::LRE : C::LR) * C::LC) s = 0;
+    int lr = s / C::LC;
+    const int lc = s - lr * C::LC;
+    const int lrl = lr;                                // the LDS row (EP: as above)
+    const int hx = (ep && lr >= HR) ? 1 : 0;
+    lr -= hx * HR;
     const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
-    int vc = j0 + lc - a.pad_left, img = 0;
+    int vc = j0 + hx * C::TW + lc - a.pad_left, img = 0;
     if (a.pair_vw) {
       // Two samples side by side (a.pair_vw): virtual column vc -> sample k = floor(vc / VW), column c = vc - k VW.  The gap
       // VW - W between the samples holds sample k's right halo (c = W ...: through the halo map, like any column past the
@@ -230,7 +261,7 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
     const int g = (a.src_mode == DLWP_SRC_UPSAMPLE2) ? (rs >> 1) * a.Ws + (cs >> 1) : rs * a.Ws + cs;
     goff[q] = ok ? (unsigned)g * (C::IN16 ? 2u : 4u) + (unsigned)img * ((unsigned)a.in_c_total * (unsigned)(a.Hs * a.Ws) * (C::IN16 ? 2u : 4u))
                  : 0x7ffffff0u;
-    loff[q] = (((lr % C::DIL) * C::DIL + lc % C::DIL) * C::LRP + lr / C::DIL) * C::LCP + lc / C::DIL;
+    loff[q] = (((lrl % C::DIL) * C::DIL + lc % C::DIL) * C::LRP + lrl / C::DIL) * C::LCP + lc / C::DIL;
   }
   const long long plane = (long long)a.Hs * a.Ws;
   constexpr int ESZ = C::IN16 ? 2 : 4;
@@ -246,7 +277,9 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
     const int pc = tt / (C::RTH * C::RTW), rem = tt - pc * (C::RTH * C::RTW);
     const int ti = rem / C::RTW, tj = rem - ti * C::RTW;
     const int pi = pc / C::DIL, pj = pc - pi * C::DIL;
-    v_src = (lane >> 4) * C::PS + ((pi * C::DIL + pj) * C::LRP + ti * 2 + C::XROW0) * C::LCP + tj * 2 + C::XCOL0;
+    // (EP, edge pair: tile row ti = wave w holds rows 2 (w & 1), + 1 of half w >> 1, whose input rows start at LDS row HR (w >> 1))
+    const int trow = (C::EP && ep) ? HR * (ti >> 1) + 2 * (ti & 1) : ti * 2;
+    v_src = (lane >> 4) * C::PS + ((pi * C::DIL + pj) * C::LRP + trow + C::XROW0) * C::LCP + tj * 2 + C::XCOL0;
   }
   // ---- filter items -> (ci, co): byte offset in the transformed filter (chunk 0, xy quad 0) and LDS slot
   unsigned u_off[C::NUI];
@@ -740,7 +773,8 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
       constexpr int CS = 4 * C::NT / PP;
       const int e0 = tid * 4, cb = e0 / PP, rem = e0 - cb * PP;
       const int row = rem / PW, colx = rem - row * PW;
-      const int oh = (i0 >> 1) + row, ow = (j0 >> 1) + colx;
+      // (EP, edge pair: staged pooled rows 2, 3 are rows 0, 1 of the second column tile)
+      const int oh = (i0 >> 1) + ((C::EP && ep) ? (row & 1) : row), ow = (j0 >> 1) + colx + ((C::EP && ep && row >= 2) ? PW : 0);
       const unsigned plane_b = (unsigned)(a.Hp * a.Wp) * 4u;
       float* yb = a.y + ((long long)n * a.out_c_total + a.out_c_off + n0) * a.Hp * a.Wp;
       const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)C::BN * plane_b, 0x00020000);
@@ -752,7 +786,7 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
       for (int k = 0; k < NPASS; ++k)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)(lp + k * CS * C::OPS)), y_rsrc, voff_q,
                                                (unsigned)(k * CS) * plane_b, 0);
-      if (((j0 >> 1) + PW > a.Wp) && (a.Wp & 3)) {   // (uniform) the map's right edge cuts a quad: element stores there
+      if (((j0 >> 1) + ((C::EP && ep) ? 2 : 1) * PW > a.Wp) && (a.Wp & 3)) {   // (uniform) the map's right edge cuts a quad: element stores there
         const bool edge = rok && ow < a.Wp && ow + 3 >= a.Wp;
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) {
@@ -816,8 +850,9 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
     constexpr int CS = 4 * C::NT / PL;
     const int e0 = tid * 4, cb = e0 / PL, rem = e0 - cb * PL;
     const int row = rem / C::TW, colx = rem - row * C::TW;
-    const int oh = i0 + row;
-    int ow = j0 + colx, img = 0;
+    // (EP, edge pair: staged rows 4 ... 7 are rows 0 ... 3 of the second column tile)
+    const int oh = i0 + ((C::EP && ep) ? (row & 3) : row);
+    int ow = j0 + colx + ((C::EP && ep && row >= 4) ? C::TW : 0), img = 0;
     if (a.pair_vw) {            // virtual column -> (sample of the pair, column); a quad never straddles two samples
       img = ow >= a.pair_vw ? 1 : 0;
       ow -= img * a.pair_vw;
@@ -879,7 +914,7 @@ __device__ __forceinline__ void conv2d_fwd_wino_body(const ConvArgs& a, const in
     for (int k = 0; k < NOUT; ++k)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, *(const f32x4*)(lp + k * CS * C::OPS)), y_rsrc, voff_q,
                                              (unsigned)(k * CS) * plane_b, 0);
-    if ((a.pair_vw || j0 + C::TW > a.Wo) && (a.Wo & 3)) {   // (uniform) a map's right edge cuts a quad: element stores there
+    if ((a.pair_vw || j0 + ((C::EP && ep) ? 2 : 1) * C::TW > a.Wo) && (a.Wo & 3)) {   // (uniform) a map's right edge cuts a quad: element stores there
       const bool edge = rok && ow < a.Wo && ow + 3 >= a.Wo;
 #pragma unroll
       for (int k = 0; k < NOUT; ++k) {
@@ -990,6 +1025,12 @@ static void wino_launch_either(const ConvArgs& a, int grid, hipStream_t s) {
       return;
     }
   }
+  if constexpr (DIL == 1 && TH == 8 && TW == 32 && WAVES == 4 && BNF == 2) {
+    if (a.edge_pairs) {      // WinoCfg::EP (host: wino_edge_pairs; the grid already counts the paired edge blocks)
+      wino_launch_thunk<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, false, false, true, false, true>>(a, grid, s);
+      return;
+    }
+  }
   if constexpr (DIL == 1) {
     // positions with a row / column index 2 are never needed: the source makes them zero (up-sampled, odd halo) or the
     // 2x2 sum epilogue does not read them
@@ -1044,6 +1085,7 @@ static int wino_prepare_both() {
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true>>();
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, false, false, true>>();
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, true, false, false, true>>();
+    if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, false, false, true, false, true>>();
     if (e == 0) e = wino_prepare<WinoCfg<DIL, TH, TW, WAVES, BNF, CK, false, false, false, true, false, true>>();
   }
   if constexpr (WinoSplitK<DIL, TH, TW, WAVES, BNF>::value) {

@@ -451,7 +451,8 @@ def set_few_stream(mode):
 
 def set_wino_xloader(mask):
     """DLWP_OPT_WINO_XLOADER: which input loaders the Winograd 8 x 32 instances may take -- bit 0 image-aligned column pairs, bit 1 an
-    up-sampled source at source resolution; 3 = both (default), 0 = element by element.  The same bits whatever the setting.  Returns
+    up-sampled source at source resolution, bit 2 edge pairs (the half-used last tile row's blocks take two column tiles each);
+    7 = all (default), 0 = as before r5.  The same bits whatever the setting.  Returns
     the previous setting."""
     return int(_lib.set_option(_lib.OPT_WINO_XLOADER, int(mask)))
 

@@ -152,9 +152,11 @@ int         dlwp_device_info(dlwp_handle_t h, int* cu_count, int* lds_bytes, cha
                                         * image-aligned column PAIRS (one 8-byte load per two elements) on float32 plain sources of
                                         * even width under zero / periodic column halos; bit 1: an UP-SAMPLED float32 source at
                                         * source resolution (one load per source element, written to the 2 x 2 tile slots it
-                                        * replicates into; zero / periodic / edge halos).  3 (default): both; 0: element by
-                                        * element, as before r5 (DLWP_WINO_XLOADER in the environment).  The same values reach the
-                                        * same patch positions: identical bits whatever the setting                           */
+                                        * replicates into; zero / periodic / edge halos); bit 2: EDGE PAIRS -- on a map whose
+                                        * last 8-row tile is at most half used (44 rows) the blocks of that tile row take the
+                                        * valid rows of two neighbouring column tiles each: one block in eighteen less.  7
+                                        * (default): all; 0: as before r5 (DLWP_WINO_XLOADER in the environment).  The same
+                                        * values reach the same patch positions: identical bits whatever the setting            */
 int         dlwp_set_option(dlwp_handle_t h, int option, int value, int* previous);
 /* the defaults themselves: what handles created AFTERWARDS start from, and what the handle-less host logic (planner hints
  * called with a NULL handle, e.g. on a machine without a GPU) uses.  Existing handles are not touched.                 */
@@ -244,7 +246,8 @@ typedef struct {
   int config, grid, block_threads;
   double matrix_flops;
   int bf16_matrix;            /* 1: v_mfma_f32_16x16x32_bf16 (peak 2.5 PFLOP/s), 0: fp32 matrix cores (157.3 TFLOP/s) */
-  int x_loader;               /* Winograd 8 x 32 instances (DLWP_OPT_WINO_XLOADER): 0 element by element, 1 column pairs, 2 source resolution */
+  int x_loader;               /* Winograd 8 x 32 instances (DLWP_OPT_WINO_XLOADER): 0 element by element, 1 column pairs, 2 source resolution;
+                               * + 4: an edge-pair launch (the last tile row's blocks take two column tiles each)                       */
 } dlwp_launch_info;
 int dlwp_conv2d_launch_info(dlwp_handle_t, dlwp_shape4 xs, const dlwp_conv2d* cd, int dtype, dlwp_launch_info* out2,
                             int* n_launches);

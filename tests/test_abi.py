@@ -92,11 +92,12 @@ def test_bench_kernel_symbols_match_the_committed_profiles():
         names = [r['Name'] for r in csv.DictReader(open(meta_file[:-len('.meta.json')] + '.csv'))]
         for n in names:
             m = re.search(r'conv2d_fwd_wino_f32<WinoCfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), false, (true|false), false, false, '
-                          r'false, (true|false), (true|false)', n)
+                          r'false, (true|false), (true|false), (true|false)', n)
             if m:
                 dil, th, tw, waves, bnf, ck = map(int, m.groups()[:6])
                 sym = bench.config_symbol((3, dil, th, tw, waves, 0, bnf, ck, 0, 0, 0), ups=m.group(7) == 'true',
-                                          x_loader=1 if m.group(8) == 'true' else (2 if m.group(9) == 'true' else 0))
+                                          x_loader=(1 if m.group(8) == 'true' else (2 if m.group(9) == 'true' else 0)) +
+                                          (4 if m.group(10) == 'true' else 0))
                 assert sym in n, (sym, n)
                 found += 1
             m = re.search(r'conv2d_fwd_wino2_f32<WinoSplitCfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), false', n)
@@ -123,7 +124,7 @@ def test_bench_kernel_symbols_match_the_committed_profiles():
     else:
         pytest.skip('no kernel-stats summary of the current kernel source in profiles/')
     assert found >= 3
-    dominant = bench.config_symbol((3, 1, 8, 32, 4, 0, 2, 8, 0, 0, 0), x_loader=1)      # the column-pair instance: layers 2 and 5
+    dominant = bench.config_symbol((3, 1, 8, 32, 4, 0, 2, 8, 0, 0, 0), x_loader=5)      # column pairs + edge pairs: layers 2 and 5
     ent = bench.rocprof_launch_ms(dominant, 256)
     assert ent and ent['same_source']
     traffic, src = bench.measured_traffic(dominant, 256)

@@ -1390,3 +1390,58 @@ def test_winograd_input_loaders_give_the_bits_of_the_element_wise_loader(ops, ca
     assert ran >= 1
     want = _conv_ref(x, wt, b, 1, pads, mh, mw, 'tanh', src)
     _check_conv(ops, host(got), want, 'winograd loader %d' % want_loader)
+
+
+EP_CASES = [
+    # (n, cin, h, w of the STORED input, cout, mode_h, mode_w, src_mode, pooled epilogue, launch-info loader code at mask 7)
+    (3, 16, 44, 90, 64, 0, 1, 0, False, 5),    # the U-Net's 44 x 90 layers: 5.5 tile rows, three column tiles (one pair + a single)
+    (2, 32, 12, 64, 32, 1, 1, 0, True, 5),     # MaxPooling2D(2) in the epilogue, two column tiles, periodic rows
+    (2, 8, 20, 70, 32, 0, 1, 0, False, 5),     # the map's right edge cuts the second tile's last pixel quad
+    (2, 8, 11, 66, 32, 0, 0, 0, False, 5),     # three valid rows in the last tile, zero columns
+    (2, 8, 12, 70, 32, 0, 1, 0, True, 5),      # pooled, pooled width 35: element stores at the edge
+    (2, 16, 6, 33, 64, 0, 1, 1, False, 2),     # up-sampled source: stays on its source-resolution fetch (no pairs compiled)
+    (2, 8, 12, 66, 32, 0, 2, 0, False, 0),     # edge columns: no column pairs, hence no edge pairs
+    (2, 8, 44, 32, 32, 0, 1, 0, False, 1),     # one column tile: nothing to pair
+    (2, 8, 48, 64, 32, 0, 1, 0, False, 1),     # whole tile rows
+    (2, 8, 14, 64, 32, 0, 1, 0, False, 1),     # six valid rows in the last tile: more than half
+]
+
+
+@pytest.mark.parametrize('case', EP_CASES)
+def test_winograd_edge_pairs_give_the_bits_of_the_plain_launch(ops, case):
+    """DLWP_OPT_WINO_XLOADER bit 2 (WinoCfg::EP, r5): on a map whose last 8-row tile is at most half used the blocks of that tile
+    row take the valid rows of two neighbouring column tiles each.  Per-lane offsets of the loader, the patch origin and the store
+    phase change, the arithmetic does not: the launch must give the BITS of the launch without it (and the oracle's values), with
+    fewer workgroups -- tiles_w (tiles_h - 1) + ceil(tiles_w / 2) per image and channel tile -- and only where it applies."""
+    n, cin, h, w, cout, mh, mw, src, pool, code = case
+    rng = np.random.default_rng(7300 + EP_CASES.index(case))
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = np_ref.glorot_uniform((3, 3, cin, cout), rng)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, mh, mw), ops.ACT_TANH, src_mode=src, out_pool=pool)
+    cfgs = ops.conv_configs()
+    bnf = 4 if (src == 1 and cout % 64 == 0) else 2
+    idx = [i for i, c in enumerate(cfgs) if c[:8] == (3, 1, 8, 32, 4, 0, bnf, 8) and not (c[10] & 1)][0]
+    xd, wd, bd = dev(x), dev(wt), dev(b)
+    ho, wo = (2 * h, 2 * w) if src == 1 else (h, w)
+    th, tw = -(-ho // 8), -(-wo // 32)
+    try:
+        ops.force_conv_config(idx)
+        prev = ops.set_wino_xloader(0)
+        try:
+            info0 = ops.conv_launch_info(x.shape, cd)
+            base = ops.conv2d(xd, wd, bd, cd)
+            ops.set_wino_xloader(7)
+            info = ops.conv_launch_info(x.shape, cd)
+            got = ops.conv2d(xd, wd, bd, cd)
+        finally:
+            ops.set_wino_xloader(prev)
+    finally:
+        ops.force_conv_config(-1)
+    per_image = n * (cout // (16 * bnf))
+    assert info0[0][0] == idx and info0[0][5] == 0 and info0[0][1] == per_image * th * tw, info0
+    assert info[0][0] == idx and info[0][5] == code, (info, code)
+    assert info[0][1] == per_image * ((tw * (th - 1) + (tw + 1) // 2) if code & 4 else th * tw), info
+    assert torch.equal(got, base), (case, float((got - base).abs().max()))
+    want = _conv_ref(x, wt, b, 1, (1, 1, 1, 1), mh, mw, 'tanh', src)
+    _check_conv(ops, host(got), np_ref.maxpool2(want) if pool else want, 'edge pairs %d' % code)
