@@ -20,7 +20,8 @@
 #include "conv_wgrad_kernel.h"
 
 // profiling builds only (tools/microbench/wgrad_cb_phase_timing.hip -DDLWP_WG_KNOCK=k; results wrong by construction):
-// 1 = no loads of the next tile inside the quad loop, 2 = no MFMAs, 3 = no LDS reads in the transforms
+// 1 = no loads of the next tile inside the quad loop, 2 = no MFMAs, 3 = no LDS reads in the transforms, 4 = no transforms (the raw
+// patch values are multiplied: what a kernel that transforms every patch ONCE per workgroup instead of once per wave could save at most)
 #ifndef DLWP_WG_KNOCK
 #define DLWP_WG_KNOCK 0
 #endif
@@ -378,11 +379,21 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
       f32x2 (&d2)[4][2] = dq[q & 1];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if (DLWP_WG_KNOCK == 4) {
+          t2[i][0] = d2[i][0];
+          t2[i][1] = d2[i][1];
+          continue;
+        }
         t2[i][0] = pk_wino_t01(d2[i][0], d2[i][1]);   // d B, one patch row: (d0 - d2, d1 + d2 | d2 - d1, d1 - d3)
         t2[i][1] = pk_wino_t23(d2[i][0], d2[i][1]);
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {                   // B^T (d B)
+        if (DLWP_WG_KNOCK == 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v2[i][h] = t2[i][h];
+          continue;
+        }
         v2[0][h] = pk_sub(t2[0][h], t2[2][h]);
         v2[1][h] = pk_add(t2[1][h], t2[2][h]);
         v2[2][h] = pk_sub(t2[2][h], t2[1][h]);
@@ -394,6 +405,13 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
         // |A dY|: rows (y0), (y0 + y1), (y0 - y1), (y1) as pairs (left, right); then each row (p, q) -> (p, p + q, p - q, q)
         rw[nt][0] = zq[q & 1][nt][0];
         rw[nt][3] = zq[q & 1][nt][1];
+        if (DLWP_WG_KNOCK == 4) {
+          rw[nt][1] = rw[nt][0];
+          rw[nt][2] = rw[nt][3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sd[nt][i] = rw[nt][i];
+          continue;
+        }
         rw[nt][1] = pk_add(rw[nt][0], rw[nt][3]);
         rw[nt][2] = pk_sub(rw[nt][0], rw[nt][3]);
 #pragma unroll
