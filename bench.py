@@ -725,7 +725,7 @@ def sub_pad_hbm(members):
     config-2 forward at this member count: ALGORITHMIC bytes (in + out) / HIP-event time, as a fraction of the 8 TB/s HBM peak.
     (The product's forward never launches these -- every halo is fused into a convolution's loader; they serve layer stacks
     nothing fuses and the TFPadding2D / FillPadding2D modes.)  `counters`: HBM bytes from the rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes of tools/profile_pads.sh on THIS kernel source (profiles/r5_pad_pool_hbm.json), when there is one."""
+    WRITE_SIZE passes of tools/profile_pads.sh on THIS kernel source (profiles/r*_pad_pool_hbm.json), when there is one."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
     import bench_pad
     rows = bench_pad.measure(members, 10, pads_only=True)
@@ -734,13 +734,16 @@ def sub_pad_hbm(members):
            'unit': 'GB/s, algorithmic bytes (in + out) / HIP-event time', 'peak_gbs': PEAK_HBM_GBS}
     out['min_hbm_frac'] = min(r['hbm_frac'] for r in out['rows'])
     try:
-        prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r5_pad_pool_hbm.json')))
+        import glob
+        cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pad_pool_hbm.json')), reverse=True)
+        profs = [json.load(open(f)) for f in cands]
+        prof = next((q for q in profs if q.get('_meta', {}).get('source_sha') == kernel_source_hash()), profs[0] if profs else {})
         if prof.get('_meta', {}).get('source_sha') == kernel_source_hash():
             out['counters'] = [{'kernel': r['kernel'], 'shape': r['shape'], 'traffic_over_algorithmic': round(r['traffic_over_algorithmic'], 3),
                                 'hbm_gbs_from_counters': round(r['hbm_gbs_from_counters'], 1)}
                                for r in prof['rows'] if r['kernel'].startswith('pad2d') and 'traffic_over_algorithmic' in r]
         else:
-            out['counters'] = 'profiles/r5_pad_pool_hbm.json was taken on another kernel source'
+            out['counters'] = 'no profiles/r*_pad_pool_hbm.json of this kernel source'
     except Exception:  # noqa: BLE001
         out['counters'] = None
     return out
