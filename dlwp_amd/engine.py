@@ -1009,9 +1009,10 @@ class Model(object):
         return self._need_trainer().evaluate(x, y, batch_size=batch_size, verbose=verbose)
 
     # -- persistence ---------------------------------------------------------------------------------------------------- #
-    def save(self, path):
+    def save(self, path, format=None):
+        """Keras HDF5 by default (what the reference's model.save writes, DLWP/util.py:141-144); format='npz': this package's archive"""
         from . import serialization
-        serialization.save_model_file(self, path)
+        serialization.save_model_file(self, path, format=format)
 
 
 class Sequential(Model):

@@ -1456,6 +1456,44 @@ def test_imported_keras_hdf5_checkpoint_forecasts_like_the_oracle():
     assert _rel(mf.predict(xf), out) <= FWD_TOL
 
 
+def test_keras_hdf5_checkpoint_written_here_resumes_training_where_it_stopped(tmp_path):
+    """The reference's save_model / load_model pair (DLWP/util.py:126-192) through the Keras HDF5 files THIS package writes (r6):
+    architecture, weights, training_config, iteration count and Adam moments (group optimizer_weights, Keras' order) -- a run that
+    is saved after 3 steps, loaded and continued equals the uninterrupted run; the custom loss with its arrays survives too."""
+    from dlwp_amd import custom, hdf5_lite, util
+    from dlwp_amd.training import Adam
+    rng = np.random.default_rng(8)
+    cs = (4, 16, 24)
+    x = [rng.standard_normal((6,) + cs).astype(np.float32) for _ in range(6)]
+    climo = rng.standard_normal((1,) + cs).astype(np.float32)
+    loss = custom.anomaly_correlation_loss(climo, regularize_mean='mse')
+    d = _build(unet_layers(cs, widths=(8, 16, 16, 16, 8)), time_dim=2, seed=4, loss=loss, optimizer=Adam(lr=2e-3))
+    _weights_of(d.model, rng)
+    w_start = d.model.get_weights()
+    for k in range(3):
+        d.model.train_on_batch(x[k], x[k])
+    base = str(tmp_path / 'ckpt')
+    util.save_model(d, base)
+    assert hdf5_lite.is_hdf5(base + '.keras')
+    f = hdf5_lite.File(base + '.keras')
+    names = [n.decode() for n in np.asarray(f['optimizer_weights'].attrs['weight_names']).reshape(-1)]
+    n_par = len(d.model._trainer.entries)
+    assert names[0] == 'Adam/iterations:0' and len(names) == 1 + 3 * n_par
+    assert int(np.asarray(f['optimizer_weights'][names[0]][...]).reshape(-1)[0]) == 3
+    d2 = util.load_model(base)
+    assert isinstance(d2.model.loss, custom.LossSpec) and np.array_equal(d2.model.loss.mean, climo[0])
+    assert d2.model.optimizer.iterations == 3 and d2.model.optimizer.lr == pytest.approx(2e-3)
+    assert all(np.array_equal(a, b) for a, b in zip(d.model.get_weights(), d2.model.get_weights()))
+    for a, b in zip(d.model._trainer.opt_state, d2.model._trainer.opt_state):
+        assert torch.equal(a, b)
+    for k in range(3, 6):
+        la, lb = d.model.train_on_batch(x[k], x[k]), d2.model.train_on_batch(x[k], x[k])
+        assert np.allclose(la, lb, rtol=1e-6, atol=1e-7)
+    for a, b in zip(d.model.get_weights(), d2.model.get_weights()):
+        assert np.abs(a - b).max() <= 1e-7
+    assert not all(np.array_equal(a, b) for a, b in zip(w_start, d2.model.get_weights()))
+
+
 def test_host_series_come_from_recycled_pinned_buffers_without_aliasing_a_live_result():
     """predict_timeseries (streamed return) gives a numpy array on page-locked memory that goes back to a pool when the caller
     lets it go (util._PinnedPool): a result that is still referenced -- even through a view -- is never overwritten by a later
