@@ -56,7 +56,17 @@ bool wino_channels_ok(int cin, int cout, int dil) {
   const int pad8 = dlwp_ceil_div(cin, 8) * 8, pad4 = dlwp_ceil_div(cin, 4) * 4;
   return (cout % 32 == 0 || (cout % 16 == 0 && dil == 1)) && cin >= 5 && pad8 * 16 * 2 <= pad4 * 36;
 }
+// r6: a first layer of 5-8 input channels (2 time steps x (2 variables + insolation), examples/validate.py) that the streaming kernel
+// of conv_fwd_few.hip covers stays in the DIRECT family at every batch size: that kernel is the direct instances' bits, large batches
+// take it (at 256 members of the 88 x 180 grid the 6 -> 32 dilation-2 layer: Winograd 0.231 ms, streaming kernel see DESIGN 5.20) and
+// a member's bits must not depend on its batch.  Geometry and storage only, never the batch size.
+bool few_family(const ConvArgs& a, const dlwp_conv2d* cd, const dlwp_options& o) {
+  return a.Cin >= 5 && a.Cin <= 8 && cd->kh == 3 && cd->kw == 3 && cd->dil_h == cd->dil_w &&
+         (cd->dil_h == 1 || cd->dil_h == 2) && cd->src_mode == DLWP_SRC_DIRECT && !a.in_bf16 && !a.out_bf16 && !a.compute_bf16 &&
+         (cd->out_pool == 0 || cd->out_pool == 1) && !cd->out_d2s && !cd->lstm_f && a.Cout % 32 == 0;
+}
 bool winograd_wanted(const ConvArgs& a, const dlwp_conv2d* cd, const dlwp_options& o) {
+  if (few_family(a, cd, o)) return false;
   return o.winograd && cd->kh == 3 && cd->kw == 3 && cd->dil_h == cd->dil_w && wino_channels_ok(a.Cin, a.Cout, cd->dil_h) &&
          cd->src_mode != DLWP_SRC_MAXPOOL2 &&
          (long long)a.Hs * a.Ws * a.in_c_total < (1ll << 29) &&   // channel offsets inside a sample: 32-bit byte offsets
@@ -1420,7 +1430,7 @@ int dlwp_conv2d_launch_info(dlwp_handle_t h, dlwp_shape4 xs, const dlwp_conv2d* 
   }
   if (const int fg = few_stream_grid(h, a, cd, lp)) {   // config -2: conv_fwd_few.hip -- 72 MFMAs per wave and 8 x 32 / 32-channel item
     const double items = (double)dlwp_ceil_div(a.Ho, 8) * dlwp_ceil_div(a.Wo, 32) * dlwp_ceil_div(a.Cout, 32) * a.N;
-    out2[0] = dlwp_launch_info{-2, fg, 256, 2.0 * 256.0 * 32.0 * 36.0 * items, 0, 0};
+    out2[0] = dlwp_launch_info{-2, fg, 256, 2.0 * 256.0 * 32.0 * 36.0 * (a.Cin > 4 ? 2.0 : 1.0) * items, 0, 0};   // (r6: 5-8 channels = two groups of four)
     *n_launches = 1;
     return DLWP_OK;
   }

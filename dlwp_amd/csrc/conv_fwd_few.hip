@@ -1,5 +1,8 @@
-// conv_fwd_few.hip -- the first layer of a large ensemble: 3x3 convolution of AT MOST FOUR input channels with the
-// MaxPooling2D(2) epilogue, fp32 matrix cores (gfx950), as a STREAMING kernel.
+// conv_fwd_few.hip -- the first layer of a large ensemble: 3x3 convolution of AT MOST FOUR (CG = 2, r6: EIGHT) input channels with
+// the MaxPooling2D(2) epilogue, fp32 matrix cores (gfx950), as a STREAMING kernel.
+// r6: CG = 2 covers 5-8 input channels -- the first layer of the network examples/validate.py runs: 2 time steps x (z500,
+// tau300-700, insolation) = 6 channels (DLWP/model/generators.py:537-551) -- as two groups of four: a wave stages two planes, the
+// weight block is 36 registers, the K loop 18 matrix steps in the direct family's order (channel group, tap).
 //
 // Why a kernel of its own (profiles/r3_layer1_knockout.txt): with four input channels a tile's whole K loop is 9
 // matrix steps -- 72 v_mfma_f32_16x16x4_f32 per wave in the general kernel (conv_fwd_kernel.h) -- behind ~300 vector
@@ -35,9 +38,9 @@ namespace {
 // width and plane size are multiples of 4, zero / periodic columns, a left halo of at most 4): TWO buffer_load_dwordx4 per lane
 // and item instead of SEVEN buffer_load_dword.  What bounds this kernel is the number of vector-memory INSTRUCTIONS in flight per
 // CU, not their bytes (tools/microbench/few_phase_timing.hip: ~200 cycles of issue stall per load instruction).
-template <int DIL_, bool QUAD_>
+template <int DIL_, bool QUAD_, int CG_ = 1>
 struct FewCfg {
-  static constexpr int DIL = DIL_, TH = 8, TW = 32, WAVES = 4, NT = 256;
+  static constexpr int DIL = DIL_, TH = 8, TW = 32, WAVES = 4, NT = 256, CG = CG_;
   static constexpr bool QUAD = QUAD_;
   static constexpr int LR = TH + 2 * DIL, LC = QUAD ? 40 : TW + 2 * DIL;
   static constexpr int PS_RAW = LR * LC;
@@ -46,7 +49,7 @@ struct FewCfg {
   static constexpr int PS = PS_RAW + ((4 - PS_RAW % 8) + 8) % 8;
   static constexpr int EPL = QUAD ? 4 : 1;            // floats per staged element
   static constexpr int NQ = (PS_RAW / EPL + 63) / 64;  // elements a lane stages (a wave = one channel plane)
-  static constexpr int X_FLOATS = 4 * PS;
+  static constexpr int X_FLOATS = 4 * CG * PS;
   static constexpr int LDS_BYTES = 2 * X_FLOATS * 4;
 };
 
@@ -60,9 +63,9 @@ struct FewCfg {
 // tensor for the backward pass AND its pooled image for the next layer.  The unpooled values leave as they sit in the accumulators:
 // fragment i of channel tile g = 4 consecutive pixels of one row and channel -> one 16-byte store, its row / quad offset a SCALAR;
 // the stores of item k go out behind its matrix loop and drain under item k + 1's (a general-instance workgroup ends on them).
-template <int DIL, int ACT, bool QUAD, int OUT>
-__global__ __launch_bounds__(256, OUT == 0 ? 4 : 3) void conv2d_fwd_few_f32(const ConvArgs a, const int group) {
-  using C = FewCfg<DIL, QUAD>;
+template <int DIL, int ACT, bool QUAD, int OUT, int CG = 1>
+__global__ __launch_bounds__(256, (OUT == 0 && CG == 1) ? 4 : 3) void conv2d_fwd_few_f32(const ConvArgs a, const int group) {
+  using C = FewCfg<DIL, QUAD, CG>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, OUT == 0 ? 4 : 3) void conv2d_fwd_few_f32(cons
   bool q1_ok = true;             // ... and is the quad 4 columns to its right (the odd fragments') inside the map?
   bool wide = true;              // (uniform) the tile's 16 pooled columns are all inside the map: one 16-byte store per lane and g
   int pc0 = 0;                   // this lane's first pooled column
-  float bw[9][2];                // B operands: w[tap][ci = lane >> 4][co = n0 + 16 g + (lane & 15)]
+  float bw[CG][9][2];            // B operands: w[tap][ci = 4 cg + (lane >> 4)][co = n0 + 16 g + (lane & 15)]
   float bv[2];
   int ct_loaded = -1;
   auto setup_loads = [&](int p) {
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(256, OUT == 0 ? 4 : 3) void conv2d_fwd_few_f32(cons
       const int lr = s / C::LC, lc = s - lr * C::LC;
       const int rs = dlwp_map_coord_tile(i0 + lr - a.pad_top, a.H, a.mode_h);
       const int cs = dlwp_map_coord_tile(j0 + lc - (C::QUAD ? 4 : a.pad_left), a.W, a.mode_w);
-      // (a channel plane past Cin: the lane offset is what the range check is sure to see -- the scalar channel offset may not be)
+      // (a channel plane past Cin: the lane offset is what the range check is sure to see -- the scalar channel offset may not be;
+      //  the planes of the second channel group are checked where they are loaded)
       const bool ok = (q < C::NQ - 1 || s < C::PS_RAW) && rs >= 0 && cs >= 0 && wave < a.Cin;
       goff[q] = ok ? (unsigned)(rs * a.Ws + cs) * 4u : 0x7ffffff0u;
     }
@@ -149,10 +153,13 @@ __global__ __launch_bounds__(256, OUT == 0 ? 4 : 3) void conv2d_fwd_few_f32(cons
       const bool c_ok = co < a.Cout;
       const int cc = c_ok ? co : 0;
       if (ct != ct_loaded) {   // (uniform; the weights are the same for every position of a channel tile)
-        const int ci = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-          bw[t][g] = (c_ok && ci < a.Cin) ? a.w[((long long)t * a.Cin + ci) * a.Cout + cc] : 0.f;
+        for (int cg = 0; cg < CG; ++cg) {
+          const int ci = 4 * cg + (lane >> 4);
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+            bw[cg][t][g] = (c_ok && ci < a.Cin) ? a.w[((long long)t * a.Cin + ci) * a.Cout + cc] : 0.f;
+        }
         bv[g] = (a.bias && c_ok) ? a.bias[cc] : 0.f;
       }
       voff[g] = (c_ok && pr < a.Hp && pc0 < a.Wp) ? (unsigned)((co * a.Hp + pr) * a.Wp + pc0) * 4u : 0x7ffffff0u;
@@ -178,22 +185,30 @@ __global__ __launch_bounds__(256, OUT == 0 ? 4 : 3) void conv2d_fwd_few_f32(cons
   const bool last_ok = (lane + 64 * (C::NQ - 1)) * C::EPL < C::PS_RAW;
 
   using elem_t = std::conditional_t<C::QUAD, f32x4, float>;
-  elem_t xr[C::NQ];
+  elem_t xr[CG][C::NQ];
+  const bool second_ok = wave + 4 < a.Cin;          // (uniform) this wave's plane of the second channel group exists
   auto load_item = [&](int nn) {
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(x0 + (long long)nn * x_sample), 0, (unsigned)a.Cin * plane_bytes, 0x00020000);
 #pragma unroll
-    for (int q = 0; q < C::NQ; ++q) {
-      if constexpr (C::QUAD)
-        xr[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, goff[q], wave * plane_bytes, 0));
-      else
-        xr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, goff[q], wave * plane_bytes, 0));
-    }
+    for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+      for (int q = 0; q < C::NQ; ++q) {
+        const unsigned off = (cg == 0 || second_ok) ? goff[q] : 0x7ffffff0u;
+        if constexpr (C::QUAD)
+          xr[cg][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, (wave + 4 * cg) * plane_bytes, 0));
+        else
+          xr[cg][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, off, (wave + 4 * cg) * plane_bytes, 0));
+      }
   };
   auto stage = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < C::NQ - 1; ++q) *(elem_t*)(lds + buf * C::X_FLOATS + sbase + 64 * q * C::EPL) = xr[q];
-    if (last_ok) *(elem_t*)(lds + buf * C::X_FLOATS + sbase + 64 * (C::NQ - 1) * C::EPL) = xr[C::NQ - 1];
+    for (int cg = 0; cg < CG; ++cg) {
+      float* pl = lds + buf * C::X_FLOATS + 4 * cg * C::PS + sbase;
+#pragma unroll
+      for (int q = 0; q < C::NQ - 1; ++q) *(elem_t*)(pl + 64 * q * C::EPL) = xr[cg][q];
+      if (last_ok) *(elem_t*)(pl + 64 * (C::NQ - 1) * C::EPL) = xr[cg][C::NQ - 1];
+    }
   };
 
   // ---- the pipeline.  vmcnt counts loads AND stores in issue order on gfx9, so a wait for loads also waits for every store
@@ -240,28 +255,29 @@ __global__ __launch_bounds__(256, OUT == 0 ? 4 : 3) void conv2d_fwd_few_f32(cons
 #pragma unroll
     for (int buf = 0; buf < 2; ++buf) {
       const float* xs = lds + buf * C::X_FLOATS;
-      // ---- 9 matrix steps (taps in order; one 4-channel group): fragments double-buffered in registers
+      // ---- 9 CG matrix steps in the direct family's order (4-channel group, tap: conv_fwd_kernel.h); fragments double-buffered
       f32x4 acc[4][2];
       float af[2][4];
-      auto load_frags = [&](int tap, int b) {
+      auto load_frags = [&](int step, int b) {
+        const int cg = step / 9, tap = step - 9 * cg;
         const int u = tap / 3, v = tap - 3 * u;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          af[b][i] = xs[abase + (i >> 1) * C::LC + (i & 1) * 4 + u * C::DIL * C::LC + v * C::DIL];
+          af[b][i] = xs[abase + 4 * cg * C::PS + (i >> 1) * C::LC + (i & 1) * 4 + u * C::DIL * C::LC + v * C::DIL];
       };
       load_frags(0, 0);
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int cur = tap & 1;
-        if (tap + 1 < 9) load_frags(tap + 1, cur ^ 1);
+      for (int step = 0; step < 9 * CG; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < 9 * CG) load_frags(step + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int g = 0; g < 2; ++g)
-            if (!(DLWP_KNOCK_FEW & 8) || tap == 0)
-              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bw[tap][g],
-                                                               tap == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][g], 0, 0, 0);
+            if (!(DLWP_KNOCK_FEW & 8) || step == 0)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bw[step / 9][step % 9][g],
+                                                               step == 0 ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][g], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
 
@@ -348,9 +364,9 @@ __global__ __launch_bounds__(256, OUT == 0 ? 4 : 3) void conv2d_fwd_few_f32(cons
 int g_few_group_override = 0;
 #endif
 
-template <int DIL, bool QUAD, int OUT>
+template <int DIL, bool QUAD, int OUT, int CG = 1>
 void launch_few(const ConvArgs& a, int grid, hipStream_t s) {
-  using C = FewCfg<DIL, QUAD>;
+  using C = FewCfg<DIL, QUAD, CG>;
   // samples per group = the length of a workgroup's share: workgroup j then walks (about) one position over one sample group
   // and its neighbours the positions next to it over the SAME samples.  (A cap of 64 on the group put the neighbours of a
   // 1024-member launch 24 samples apart: 0.758 ms against the general kernel's 0.531, profiles/r3_few_stream.txt.)
@@ -361,11 +377,11 @@ void launch_few(const ConvArgs& a, int grid, hipStream_t s) {
   if (g_few_group_override > 0) group = g_few_group_override;   // (tools/microbench/few_phase_timing.hip sweeps it)
 #endif
   if (a.act == DLWP_ACT_TANH)
-    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_TANH, QUAD, OUT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
+    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_TANH, QUAD, OUT, CG>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
   else if (a.act == DLWP_ACT_RELU)
-    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_RELU, QUAD, OUT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
+    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_RELU, QUAD, OUT, CG>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
   else
-    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_LINEAR, QUAD, OUT>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
+    hipLaunchKernelGGL((conv2d_fwd_few_f32<DIL, DLWP_ACT_LINEAR, QUAD, OUT, CG>), dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a, group);
 }
 
 }  // namespace
@@ -376,7 +392,7 @@ void launch_few(const ConvArgs& a, int grid, hipStream_t s) {
 bool dlwp_conv_few_covers(const ConvArgs& a, int ks, int dil_h, int dil_w) {
   const bool pooled = a.out_pool == 1 || a.y2 != nullptr;           // a pooled tensor is written
   const bool plain = a.out_pool == 0;                               // the unpooled tensor is written
-  return ks == 3 && dil_h == dil_w && (dil_h == 1 || dil_h == 2) && a.Cin >= 1 && a.Cin <= 4 && a.src_mode == DLWP_SRC_DIRECT &&
+  return ks == 3 && dil_h == dil_w && (dil_h == 1 || dil_h == 2) && a.Cin >= 1 && a.Cin <= 8 && a.src_mode == DLWP_SRC_DIRECT &&
          !a.in_bf16 && !a.out_bf16 && !a.compute_bf16 && (a.out_pool == 0 || a.out_pool == 1) && !a.out_d2s && !a.lstm_f && !a.yact &&
          (!pooled || (a.Wp % 2 == 0 && a.Hp * 2 <= a.Ho && a.Wp * 2 <= a.Wo)) && (!plain || a.Wo % 4 == 0) &&
          (long long)a.Ho * a.Wo * a.Cout < (1ll << 28) &&
@@ -395,6 +411,12 @@ void dlwp_conv_few_launch(const ConvArgs& a, int dil, int grid, hipStream_t s) {
   auto go = [&](auto dil_c, auto quad_c) {
     constexpr int D = decltype(dil_c)::value;
     constexpr bool Q = decltype(quad_c)::value;
+    if (a.Cin > 4) {          // two groups of four input channels (r6)
+      if (out == 0) launch_few<D, Q, 0, 2>(a, grid, s);
+      else if (out == 1) launch_few<D, Q, 1, 2>(a, grid, s);
+      else launch_few<D, Q, 2, 2>(a, grid, s);
+      return;
+    }
     if (out == 0) launch_few<D, Q, 0>(a, grid, s);
     else if (out == 1) launch_few<D, Q, 1>(a, grid, s);
     else launch_few<D, Q, 2>(a, grid, s);

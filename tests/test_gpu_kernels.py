@@ -270,6 +270,12 @@ def test_few_channel_streaming_kernel_equals_the_general_instance(ops, dil):
         (300, 4, 12, 68, 32, 0, 1, 'tanh'),
         (4, 2, 16, 44, 32, 0, 2, 'tanh'),       # edge columns: the dword loader (no aligned 16-byte quads across the halo)
         (3, 4, 24, 72, 32, 0, 1, 'relu'),       # pooled width 36: 16-byte stores
+        # r6: 5-8 input channels = two groups of four (the 6-channel first layer of examples/validate.py's network)
+        (5, 6, 20, 52, 32, 0, 1, 'tanh'),
+        (300, 6, 12, 68, 32, 0, 1, 'tanh'),
+        (70, 5, 18, 76, 64, 2, 1, 'relu'),
+        (4, 8, 16, 44, 32, 0, 2, 'linear'),
+        (40, 7, 24, 72, 32, 1, 0, 'tanh'),
     ]
     for n, cin, h, w, cout, mh, mw, act in cases:
         x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
@@ -326,6 +332,8 @@ def test_few_channel_streaming_kernel_unpooled_and_both_outputs(ops, dil):
         (70, 3, 18, 76, 40, 2, 1, 'relu'),
         (300, 1, 10, 36, 16, 1, 0, 'linear'),
         (90, 4, 24, 72, 32, 0, 1, 'tanh'),
+        (40, 6, 91, 180, 32, 0, 1, 'tanh'),      # r6: two channel groups
+        (90, 8, 24, 72, 32, 0, 1, 'relu'),
     ]
     for n, cin, h, w, cout, mh, mw, act in cases:
         x = dev(rng.standard_normal((n, cin, h, w)).astype(np.float32))
@@ -358,7 +366,9 @@ def test_few_channel_streaming_kernel_unpooled_and_both_outputs(ops, dil):
 def test_few_channel_streaming_kernel_is_chosen_by_batch_size(ops):
     """DLWP_OPT_FEW_STREAM = 1 (default): layer 1 of the 88 x 180 U-Net goes to the streaming kernel from 2.5 tiles per resident
     workgroup on (3 per CU), the general instance below -- with the pooling epilogue; the unpooled output (r4: a width that is a
-    multiple of 4) only with DLWP_OPT_FEW_STREAM = 2; never for more than four input channels, 5x5, or a width that cuts a quad."""
+    multiple of 4) only with DLWP_OPT_FEW_STREAM = 2; never for more than eight input channels (r6: 5-8 run as two groups of four,
+    and such a layer belongs to the direct family at EVERY batch size -- a member's bits do not depend on its batch), 5x5, or a
+    width that cuts a quad."""
     cd = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH, out_pool=True)
     assert ops.conv_launch_info((256, 4, 88, 180), cd)[0][0] == -2
     g = ops.conv_launch_info((256, 4, 88, 180), cd)[0]
@@ -366,7 +376,12 @@ def test_few_channel_streaming_kernel_is_chosen_by_batch_size(ops):
     assert ops.conv_launch_info((64, 4, 88, 180), cd)[0][0] == -2
     assert ops.conv_launch_info((16, 4, 88, 180), cd)[0][0] >= 0
     assert ops.conv_launch_info((1, 4, 88, 180), cd)[0][0] >= 0
-    assert ops.conv_launch_info((256, 5, 88, 180), cd)[0][0] >= 0
+    g6 = ops.conv_launch_info((256, 6, 88, 180), cd)[0]
+    assert g6[0] == -2 and g6[3] == 2 * g[3]                                   # 144 MFMAs per wave and tile
+    cfgs = ops.conv_configs()
+    small = ops.conv_launch_info((8, 6, 88, 180), cd)[0]
+    assert small[0] >= 0 and cfgs[small[0]][5] > 0                             # the general DIRECT instance (not Winograd: fa > 0)
+    assert ops.conv_launch_info((256, 9, 88, 180), cd)[0][0] >= 0
     plain = ops.make_conv(32, 3, 3, 2, ops.make_pad(2, 2, 2, 2, 0, 1), ops.ACT_TANH)
     assert ops.conv_launch_info((256, 4, 88, 180), plain)[0][0] >= 0          # (measured no faster unpooled: only when asked for)
     prev = ops.set_few_stream(2)
