@@ -764,7 +764,7 @@ def test_winograd_wide_plus_narrow_launch_is_bit_identical(ops):
 def test_winograd_with_ragged_input_channels(ops, cin, dil, src):
     """Input-channel counts that are not multiples of 8 run zero-padded to whole chunks (the ConvLSTM2D input convolution of
     config 4 has 6): out-of-range planes and filter rows read as 0.  9 or 12 input channels stay on the direct family,
-    whose chunks of 4 waste less."""
+    whose chunks of 4 waste less; r6: so do 5-8 channels of a plain source (the first layer of a network with an insolation input)."""
     import ctypes
     from dlwp_amd import _lib
     rng = np.random.default_rng(100 + cin)
@@ -775,7 +775,12 @@ def test_winograd_with_ragged_input_channels(ops, cin, dil, src):
     pads = (dil, dil, dil, dil)
     cd = ops.make_conv(cout, 3, 3, dil, ops.make_pad(*pads, 0, 1), ops.ACT_TANH, src_mode=src)
     pick = _lib.lib.dlwp_conv2d_pick_config(_lib.handle(0), ops.Shape4(n, cin, h, w), ctypes.byref(cd))
-    assert pick >= 0 and ops.conv_configs()[pick][5] == 0, 'expected a Winograd instance'
+    if cin <= 8 and src == 0:
+        # r6: a plain-source layer of 5-8 input channels belongs to the DIRECT family (the streaming first-layer kernel stands in
+        # for its instances at large batches with the same bits: csrc/conv_fwd.hip few_family)
+        assert pick >= 0 and ops.conv_configs()[pick][5] != 0, 'expected a direct-family instance'
+    else:
+        assert pick >= 0 and ops.conv_configs()[pick][5] == 0, 'expected a Winograd instance'
     # the planes behind the window must not leak in: poison what follows the last channel
     xd = torch.full((n, cin + 3, h, w), 1e6, dtype=torch.float32, device='cuda')
     xd[:, :cin] = dev(x)
@@ -1345,6 +1350,7 @@ def test_phase_weights_adjoint_and_space_to_depth(ops, k, pt, pl):
 
 XLD_CASES = [
     # (n, cin, h, w of the STORED input, cout, mode_h, mode_w, src_mode, loader the launch must take)
+    # (plain sources carry 16 channels: 5-8 channels of a plain source are direct-family layers since r6)
     (3, 16, 11, 23, 64, 0, 1, 1, 2),    # up-sampled 11 x 23 -> 22 x 46: ragged tiles both ways, zero rows / periodic columns
     (2, 24, 22, 45, 32, 1, 1, 1, 2),    # the U-Net's layer-4 source size, periodic both ways, three chunks
     (2, 8, 9, 20, 64, 2, 0, 1, 2),      # edge rows, zero columns
@@ -1352,14 +1358,14 @@ XLD_CASES = [
     (2, 8, 6, 10, 32, 4, 4, 1, 0),      # SYMMETRIC halo: does not commute with the replication -> element by element
     (3, 16, 13, 46, 32, 0, 1, 0, 1),    # plain source, even width: column pairs, ragged last column tile
     (2, 32, 44, 90, 64, 0, 1, 0, 1),    # the dominant layer's geometry (two 32-channel tiles)
-    (2, 8, 10, 34, 32, 2, 0, 0, 1),     # zero columns, edge rows
-    (2, 8, 12, 64, 32, 1, 1, 0, 1),     # whole tiles, periodic both ways
-    (2, 8, 12, 45, 32, 0, 1, 0, 0),     # odd width: a pair would straddle the seam -> element by element
-    (2, 8, 12, 20, 32, 0, 3, 0, 0),     # REFLECT columns -> element by element
+    (2, 16, 10, 34, 32, 2, 0, 0, 1),     # zero columns, edge rows
+    (2, 16, 12, 64, 32, 1, 1, 0, 1),     # whole tiles, periodic both ways
+    (2, 16, 12, 45, 32, 0, 1, 0, 0),     # odd width: a pair would straddle the seam -> element by element
+    (2, 16, 12, 20, 32, 0, 3, 0, 0),     # REFLECT columns -> element by element
     (2, 8, 7, 12, 32, 1, 1, 1, 2, (3, 1, 1, 3)),   # up-sampled, halos of 3 (top) and 3 (right): the window starts two source rows out
     (2, 8, 7, 12, 32, 2, 0, 1, 2, (1, 3, 3, 1)),   # ... 3 on the left under a zero halo, edge rows
-    (2, 8, 10, 36, 32, 0, 1, 0, 1, (1, 1, 3, 3)),  # plain source, column halo of 3: pairs start three columns out
-    (2, 8, 10, 36, 32, 0, 1, 0, 0, (1, 1, 2, 2)),  # even column halo: the first pair would start on an odd column -> element by element
+    (2, 16, 10, 36, 32, 0, 1, 0, 1, (1, 1, 3, 3)),  # plain source, column halo of 3: pairs start three columns out
+    (2, 16, 10, 36, 32, 0, 1, 0, 0, (1, 1, 2, 2)),  # even column halo: the first pair would start on an odd column -> element by element
 ]
 
 
@@ -1409,16 +1415,17 @@ def test_winograd_input_loaders_give_the_bits_of_the_element_wise_loader(ops, ca
 
 EP_CASES = [
     # (n, cin, h, w of the STORED input, cout, mode_h, mode_w, src_mode, pooled epilogue, launch-info loader code at mask 7)
+    # (16 channels and more: 5-8 channels of a plain source are direct-family layers since r6)
     (3, 16, 44, 90, 64, 0, 1, 0, False, 5),    # the U-Net's 44 x 90 layers: 5.5 tile rows, three column tiles (one pair + a single)
     (2, 32, 12, 64, 32, 1, 1, 0, True, 5),     # MaxPooling2D(2) in the epilogue, two column tiles, periodic rows
-    (2, 8, 20, 70, 32, 0, 1, 0, False, 5),     # the map's right edge cuts the second tile's last pixel quad
-    (2, 8, 11, 66, 32, 0, 0, 0, False, 5),     # three valid rows in the last tile, zero columns
-    (2, 8, 12, 70, 32, 0, 1, 0, True, 5),      # pooled, pooled width 35: element stores at the edge
+    (2, 16, 20, 70, 32, 0, 1, 0, False, 5),     # the map's right edge cuts the second tile's last pixel quad
+    (2, 16, 11, 66, 32, 0, 0, 0, False, 5),     # three valid rows in the last tile, zero columns
+    (2, 16, 12, 70, 32, 0, 1, 0, True, 5),      # pooled, pooled width 35: element stores at the edge
     (2, 16, 6, 33, 64, 0, 1, 1, False, 2),     # up-sampled source: stays on its source-resolution fetch (no pairs compiled)
-    (2, 8, 12, 66, 32, 0, 2, 0, False, 0),     # edge columns: no column pairs, hence no edge pairs
-    (2, 8, 44, 32, 32, 0, 1, 0, False, 1),     # one column tile: nothing to pair
-    (2, 8, 48, 64, 32, 0, 1, 0, False, 1),     # whole tile rows
-    (2, 8, 14, 64, 32, 0, 1, 0, False, 1),     # six valid rows in the last tile: more than half
+    (2, 16, 12, 66, 32, 0, 2, 0, False, 0),     # edge columns: no column pairs, hence no edge pairs
+    (2, 16, 44, 32, 32, 0, 1, 0, False, 1),     # one column tile: nothing to pair
+    (2, 16, 48, 64, 32, 0, 1, 0, False, 1),     # whole tile rows
+    (2, 16, 14, 64, 32, 0, 1, 0, False, 1),     # six valid rows in the last tile: more than half
 ]
 
 
