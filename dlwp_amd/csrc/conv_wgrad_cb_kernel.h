@@ -21,7 +21,9 @@
 
 // profiling builds only (tools/microbench/wgrad_cb_phase_timing.hip -DDLWP_WG_KNOCK=k; results wrong by construction):
 // 1 = no loads of the next tile inside the quad loop, 2 = no MFMAs, 3 = no LDS reads in the transforms, 4 = no transforms (the raw
-// patch values are multiplied: what a kernel that transforms every patch ONCE per workgroup instead of once per wave could save at most)
+// patch values are multiplied: what a kernel that transforms every patch ONCE per workgroup instead of once per wave could save at most),
+// 5 = every tile's loads go to the FIRST tile of the FIRST sample (the same instructions, the data from the caches: separates the
+// cost of issuing the loads from the cost of the memory traffic behind them)
 #ifndef DLWP_WG_KNOCK
 #define DLWP_WG_KNOCK 0
 #endif
@@ -166,8 +168,9 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
     return (unsigned)(rs * a.Ws + cs) * 4u;
   };
   auto tile_setup = [&]() {
-    const int i0 = th_i * C::TH, j0 = tw_i * C::TW;
-    const float* xn = a.x + ((long long)n_i * a.in_c_total + a.in_c_off + ci0) * plane;
+    const int i0 = DLWP_WG_KNOCK == 5 ? 0 : th_i * C::TH, j0 = DLWP_WG_KNOCK == 5 ? 0 : tw_i * C::TW;
+    const int n_src = DLWP_WG_KNOCK == 5 ? 0 : n_i;
+    const float* xn = a.x + ((long long)n_src * a.in_c_total + a.in_c_off + ci0) * plane;
     x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)x_chans * plane_bytes, 0x00020000);
     if constexpr (C::WUPS) {
       // source row / columns of this lane's quad; halo modes at source resolution (zero / periodic / edge commute with the 2 x 2
@@ -194,7 +197,7 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
       gx0 = src_off(rs, map_axis(c0, a.W, a.mode_w, fast_w));
       if (x_mode == 3) gx1 = src_off(rs, map_axis(c0 + 1, a.W, a.mode_w, fast_w));
     }
-    const float* zn = a.dz + ((long long)n_i * a.dz_c_total + a.dz_c_off + co0) * oplane;
+    const float* zn = a.dz + ((long long)n_src * a.dz_c_total + a.dz_c_off + co0) * oplane;
     z_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)zn, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
     z_tile_off = (unsigned)(i0 * a.Wo + j0) * 4u;
     z_rem = a.Wo - (j0 + z_c);
