@@ -131,6 +131,28 @@ def test_bench_kernel_symbols_match_the_committed_profiles():
     assert traffic and 2.0e8 < traffic < 4.0e8, (traffic, src)
 
 
+def test_kernel_stats_listed_for_the_current_source_carry_its_hash():
+    """profiles/README.md lists, per round, the summaries 'taken on the FINAL kernel source <hash>'.  For the
+    section of the CURRENT source every *_kernel_stats.csv named there must exist with a .meta.json whose source_sha is that hash --
+    a CSV from an earlier state of the kernels cannot sit under the heading unnoticed."""
+    import glob, json, os, re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = _lib.kernel_source_hash()
+    text = open(os.path.join(ROOT, 'profiles', 'README.md')).read()
+    sections = re.split(r'^## ', text, flags=re.M)
+    mine = [sec for sec in sections if sha in sec.split('\n', 1)[0]]
+    if not mine:
+        pytest.skip('profiles/README.md has no section for kernel source %s (profiles are re-taken at the end of a round)' % sha)
+    names = set(re.findall(r'`(r\d+[a-z]?_[A-Za-z0-9_]*kernel_stats\.csv)`', mine[0]))
+    assert names, 'the section of the current source lists no kernel-stats summary'
+    for n in sorted(names):
+        path = os.path.join(ROOT, 'profiles', n)
+        assert os.path.exists(path), n
+        meta = path[:-4] + '.meta.json'
+        assert os.path.exists(meta), 'no %s' % os.path.basename(meta)
+        assert json.load(open(meta)).get('source_sha') == sha, n
+
+
 def test_streaming_kernel_item_order_visits_every_tile_of_every_sample_once():
     """csrc/conv_fwd_few.hip hands (tile position, sample) items to its persistent workgroups by integer arithmetic alone: sample
     groups as long as a share, positions inside a group, samples inside a position; block b -> logical index (XCD b % 8, slot);
