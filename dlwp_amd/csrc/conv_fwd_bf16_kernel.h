@@ -19,6 +19,57 @@
 #pragma once
 #include "conv_fwd_kernel.h"
 #include <type_traits>
+// ---- the ConvLSTM2D cell update of four values (keras ConvLSTM2DCell.call: c = f c_prev + i act(z_c); h = o act(c)) with the
+//      activation kinds known at COMPILE time and the full-rate arithmetic packed (r6).  Before, both epilogues below branched on
+//      a.act / a.rec_act / a.c_prev per ELEMENT: 2 400 instructions behind the last MFMA of the whole-step instance, a fifth of them
+//      scalar compares and branches, both recurrent activations compiled in (the sigmoid with its IEEE division) -- the knock-out
+//      build without the gate arithmetic ran the two ConvLSTM2D launches of config 4 24 % faster (profiles/r6_cfg4_knockout.txt).
+//      The same operations on the same operands in the same order as the per-element form: the same bits (hard_sigmoid =
+//      min(max(fma(0.2, z, 0.5), 0), 1); tanh = act_apply2_c's form of dlwp_tanh).
+template <int REC>
+__device__ __forceinline__ f32x2 lstm_rec2(f32x2 z) {
+  if constexpr (REC == 0) {
+    // ONE packed instruction per pair: the fma with the VOP3P clamp modifier (result clamped to [0, 1], NaN -> 0 under the kernel's
+    // DX10_CLAMP mode -- what min(max(., 0), 1) gives: fmaxf(NaN, 0) = 0)
+    f32x2 r;
+    const f32x2 k = (f32x2){0.2f, 0.2f}, h = (f32x2){0.5f, 0.5f};
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(z), "v"(k), "v"(h));
+    return r;
+  } else {
+    return (f32x2){1.f / (1.f + __expf(-z.x)), 1.f / (1.f + __expf(-z.y))};
+  }
+}
+template <int ACT, int REC, bool CP>
+__device__ __forceinline__ void lstm_cell4(const float (&z)[4][4], const f32x4 cp, f32x4& cn, f32x4& hn) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const f32x2 gi = lstm_rec2<REC>((f32x2){z[0][2 * p], z[0][2 * p + 1]});
+    const f32x2 gc = act_apply2_c<ACT>((f32x2){z[2][2 * p], z[2][2 * p + 1]});
+    f32x2 cv = gi * gc;
+    if constexpr (CP)
+      cv = __builtin_elementwise_fma(lstm_rec2<REC>((f32x2){z[1][2 * p], z[1][2 * p + 1]}), (f32x2){cp[2 * p], cp[2 * p + 1]}, cv);
+    const f32x2 hv = lstm_rec2<REC>((f32x2){z[3][2 * p], z[3][2 * p + 1]}) * act_apply2_c<ACT>(cv);
+    cn[2 * p] = cv.x, cn[2 * p + 1] = cv.y;
+    hn[2 * p] = hv.x, hn[2 * p + 1] = hv.y;
+  }
+}
+// one dispatch per workgroup (uniform) instead of three branches per element
+__device__ __forceinline__ void lstm_cell4_any(const float (&z)[4][4], const f32x4 cp, f32x4& cn, f32x4& hn, int act, int rec_act,
+                                               bool has_cp) {
+  if (act == DLWP_ACT_TANH && rec_act == 0) {
+    if (has_cp) lstm_cell4<DLWP_ACT_TANH, 0, true>(z, cp, cn, hn);
+    else lstm_cell4<DLWP_ACT_TANH, 0, false>(z, cp, cn, hn);
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {       // every other combination: the per-element form
+    float cv = dlwp_rec_apply(z[0][r], rec_act) * act_apply(z[2][r], act);
+    if (has_cp) cv = fmaf(dlwp_rec_apply(z[1][r], rec_act), cp[r], cv);
+    cn[r] = cv;
+    hn[r] = dlwp_rec_apply(z[3][r], rec_act) * act_apply(cv, act);
+  }
+}
+
 // profiling builds only (tools/knockout_bf16.sh): -DDLWP_KNOCK=n removes one phase of the octet cell-update instances --
 // 1: the gate arithmetic, 2: the c / h stores, 3: the z_add / c_prev loads, 4: the matrix loop, 5: the input staging
 #ifndef DLWP_KNOCK
@@ -490,18 +541,15 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
         }
         const f32x4 cp = cpre[i];
         f32x4 cn, hn;
+#if DLWP_KNOCK == 1
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#if DLWP_KNOCK == 1
           cn[r] = z[0][r] + z[2][r] + z[1][r] * cp[r];
           hn[r] = z[3][r] + cn[r];
-#else
-          float cv = dlwp_rec_apply(z[0][r], a.rec_act) * act_apply(z[2][r], a.act);
-          if (a.c_prev) cv = fmaf(dlwp_rec_apply(z[1][r], a.rec_act), cp[r], cv);
-          cn[r] = cv;
-          hn[r] = dlwp_rec_apply(z[3][r], a.rec_act) * act_apply(cv, a.act);
-#endif
         }
+#else
+        lstm_cell4_any(z, cp, cn, hn, a.act, a.rec_act, a.c_prev != nullptr);
+#endif
         const bool st = ok && (DLWP_KNOCK != 2 || cn[0] == 12345.678f);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cn), co_rsrc,
                                                st ? (((unsigned)hb >> 3) * hw + pixv[i]) * 32u + ((unsigned)hb & 4u) * 4u : DROP, 0, 0);
@@ -628,13 +676,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
         }
         const f32x4 cp = cpre[i];
         f32x4 cn, hn;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float cv = dlwp_rec_apply(z[0][r], a.rec_act) * act_apply(z[2][r], a.act);
-          if (a.c_prev) cv = fmaf(dlwp_rec_apply(z[1][r], a.rec_act), cp[r], cv);
-          cn[r] = cv;
-          hn[r] = dlwp_rec_apply(z[3][r], a.rec_act) * act_apply(cv, a.act);
-        }
+        lstm_cell4_any(z, cp, cn, hn, a.act, a.rec_act, a.c_prev != nullptr);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cn), co_rsrc, ok ? ((unsigned)ch * hw + pix) * 4u : DROP, 0, 0);
         if (a.out_bf16)
           __builtin_amdgcn_raw_buffer_store_b64((u32x2){pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3])}, h_rsrc,
