@@ -160,7 +160,11 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
   int z_rem = 0;                          // dz columns left in the row from this thread's quad on (< 4: ragged last quad)
   const unsigned xc_off = (unsigned)(xsub * C::XPT) * plane_bytes;
   // 0: column pair, plain source | 1: pair of an up-sampled source (one element) | 2: pair of a pooled source | 3: element-wise
+#ifdef DLWP_WG_XMODE     // profiling builds: the loader's source kind as a compile-time constant (what would a per-kind instance save?)
+  constexpr int x_mode = DLWP_WG_XMODE;
+#else
   const int x_mode = !pair_x ? 3 : a.src_mode == DLWP_SRC_DIRECT ? 0 : a.src_mode == DLWP_SRC_UPSAMPLE2 ? 1 : 2;
+#endif
   auto src_off = [&](int rs, int cs) -> unsigned {
     if (rs < 0 || cs < 0) return DROP;
     if (a.src_mode == DLWP_SRC_UPSAMPLE2) return (unsigned)((rs >> 1) * a.Ws + (cs >> 1)) * 4u;
