@@ -85,7 +85,9 @@ def test_bench_kernel_symbols_match_the_committed_profiles():
     import bench
     sha = bench.kernel_source_hash()
     found = 0
-    for meta_file in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*kernel_stats.meta.json')), reverse=True):
+    # (the summary of the BENCH command: r<N>_kernel_stats -- since r6 the training / config-4 / estimator summaries carry meta files too)
+    for meta_file in sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', '*kernel_stats.meta.json'))
+                            if re.match(r'^r\d+[a-z]?_kernel_stats\.meta\.json$', os.path.basename(f))), reverse=True):
         meta = json.load(open(meta_file))
         if meta.get('source_sha') != sha:
             continue

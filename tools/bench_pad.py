@@ -13,17 +13,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dlwp_amd import ops  # noqa: E402
 
 
-def timeit(fn, iters):
+def timeit(fn, iters, repeats=3):
+    """ms per call: the best of `repeats` event-bracketed runs of `iters` calls (r6: one run of 10 calls read 0.32 ms on a 0.20 ms
+    kernel once -- a first touch of freshly allocated memory or a clock ramp inside the only window; the counters of the same
+    launch said 5.5 TB/s)"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    best = None
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        best = ms if best is None else min(best, ms)
+    return best
 
 
 def measure(n=256, iters=20, pads_only=False):
