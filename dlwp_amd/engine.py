@@ -943,6 +943,14 @@ class Model(object):
                                                             t_out, c, h * w, kept, perm_arr, 1 if time_major else 0, _lib.F32,
                                                             ct.c_void_p(down[k].cuda_stream)))
                     host.view(-1)[first * per_block:(first + take) * per_block].copy_(stage[k][:take * per_block], non_blocking=True)
+        except BaseException:
+            for s_ in down:                    # (copies in flight may still write into the result array: drain, then recycle it)
+                try:
+                    s_.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+            util.pinned_results._give_back(host.view(-1))
+            raise
         finally:
             for s_ in down:
                 s_.synchronize()

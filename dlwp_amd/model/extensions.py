@@ -83,7 +83,7 @@ class TimeSeriesEstimator(object):
         self._input_time_steps = generator._input_time_steps if self._is_series else model.time_dim
         self._output_time_steps = generator._output_time_steps if self._is_series else model.time_dim
 
-    def _fed_rollout_ok(self, p_shape, t_shape, n):
+    def _fed_rollout_ok(self, p_shape, t_shape, n, calls=1):
         """Can the whole loop run on the device?  A dlwp_amd network behind a DLWPNeuralNet / single-output DLWPFunctional with
         identity scaling, stored as (channels, lat, lon) with at most 128 state channels, and room in HBM for the two states, the
         series and the activations of all samples at once (the row shift couples the samples: they are not chunked)."""
@@ -101,7 +101,8 @@ class TimeSeriesEstimator(object):
             return False
         import torch
         free = torch.cuda.mem_get_info(net.device)[0]
-        need = 4 * n * sum(int(np.prod(b)) for b in net.infer_plan.buffers) + 8 * int(np.prod(p_shape))
+        need = 4 * n * sum(int(np.prod(b)) for b in net.infer_plan.buffers) + 8 * int(np.prod(p_shape)) + \
+            4 * int(calls) * int(np.prod(t_shape)) + 8 * int(np.prod(t_shape))         # activations, two states, the series, staging
         return need < 0.8 * free
 
     # -- the forecast ------------------------------------------------------------------------------------------------ #
@@ -162,7 +163,7 @@ class TimeSeriesEstimator(object):
             series = self.model.predict_timeseries(p.reshape(p_shape), effective_steps * self.model.time_dim,
                                                    keep_time_dim=True, **kwargs)
             result = np.asarray(series).reshape((effective_steps,) + t_shape)
-        elif self._fed_rollout_ok(p_shape, t_shape, n):
+        elif self._fed_rollout_ok(p_shape, t_shape, n, effective_steps):
             # ---- the whole loop on the device: ONE hipGraph, the feedback launch between the calls (csrc/feedback.hip)
             c_in, c_out = len(in_labels), len(out_labels)
             src = list(range(t_in * c_in))                      # default: the same channel of row i + k

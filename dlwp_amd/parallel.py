@@ -439,7 +439,7 @@ def spawn(gpus):
         procs.append(subprocess.Popen([sys.executable, '-m', 'dlwp_amd.worker'], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                                       cwd=root))
     os.environ.update(MASTER_ADDR=env['MASTER_ADDR'], MASTER_PORT=env['MASTER_PORT'], WORLD_SIZE=str(gpus), RANK='0',
-                      LOCAL_RANK=os.environ.get('LOCAL_RANK', '0'))
+                      LOCAL_RANK=os.environ.get('LOCAL_RANK', '0'), DLWP_DRIVER='1')
     try:
         init()
     except Exception:
@@ -473,6 +473,10 @@ def init(backend=None):
         kwargs = {}
         if backend == 'nccl':
             kwargs['device_id'] = torch.device('cuda', local)
+        if os.environ.get('DLWP_DP_TIMEOUT') or os.environ.get('DLWP_WORKER') == '1' or os.environ.get('DLWP_DRIVER') == '1':
+            # driver mode: a collective whose peer died must not hold the script for the backend's default (10-30 minutes)
+            import datetime
+            kwargs['timeout'] = datetime.timedelta(seconds=int(os.environ.get('DLWP_DP_TIMEOUT', '600')))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, world, local
 
