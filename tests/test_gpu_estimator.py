@@ -241,3 +241,36 @@ def test_step_sequence_rollout_runs_on_the_device(monkeypatch):
     assert len(calls) == 2
     dev = d.predict_timeseries(x, 4, step_sequence=True, return_device=True)
     assert isinstance(dev, torch.Tensor) and np.array_equal(dev.cpu().numpy(), got[:, :, 0] if got.ndim == 6 else got)
+
+
+def test_recurrent_model_with_insolation_rolls_out_on_the_device(monkeypatch):
+    """The reference's DEFAULT flow (examples/train.py with model_is_recurrent = True, then examples/validate.py): a ConvLSTM2D front
+    end on (time, variables + insolation, lat, lon) inputs, outputs (time, variables, lat, lon).  The state's channel axis is the
+    flattened (time step, variable) pair either way, so the same feedback launch serves: device loop == reference-form host loop."""
+    from dlwp_amd.model import DLWPNeuralNet, SeriesDataGenerator, TimeSeriesEstimator
+    rng = np.random.default_rng(17)
+    h, w = 16, 24
+    ds = _series_dataset(rng, 18, h, w)
+    d = DLWPNeuralNet(is_convolutional=True, is_recurrent=True, time_dim=2, scaler_type=None, scale_targets=False)
+    gen = SeriesDataGenerator(d, ds, input_time_steps=2, output_time_steps=2, add_insolation=True, batch_size=4)
+    cs, cso = gen.convolution_shape, gen.output_convolution_shape        # (2, 3, h, w) -> (2, 2, h, w)
+    cf = {'data_format': 'channels_first'}
+
+    def block(k, filters, size, dilation, activation):
+        return (('PeriodicPadding2D', ((0, k),), dict(cf)), ('ZeroPadding2D', ((k, 0),), dict(cf)),
+                ('Conv2D', (filters, size), dict(cf, dilation_rate=dilation, padding='valid', activation=activation)))
+    layers = (('PeriodicPadding3D', ((0, 0, 2),), dict(cf, input_shape=cs)), ('ZeroPadding3D', ((0, 2, 0),), dict(cf)),
+              ('ConvLSTM2D', (4 * cs[1], 3), dict(cf, dilation_rate=2, padding='valid', activation='tanh', return_sequences=True)),
+              ('Reshape', ((4 * cs[0] * cs[1], cs[2], cs[3]),), None)) + block(1, 16, 3, 1, 'tanh') + \
+        block(2, cso[0] * cso[1], 5, 1, 'linear') + (('Reshape', (cso,), None),)
+    np.random.seed(5)
+    d.build_model(layers, loss='mse', optimizer='adam')
+    est = TimeSeriesEstimator(d, gen)
+    calls = []
+    real = d.model._fed_entry
+    monkeypatch.setattr(d.model, '_fed_entry', lambda *a, **k: calls.append(1) or real(*a, **k))
+    out = est.predict(5)
+    assert calls and out.shape == (5, gen._n_sample, 2, 1, h, w) and np.isfinite(out.values).all()
+    monkeypatch.setenv('DLWP_ESTIMATOR_HOST', '1')
+    host = est.predict(5)
+    assert len(calls) == 1 and np.array_equal(_bits(out.values), _bits(host.values))
