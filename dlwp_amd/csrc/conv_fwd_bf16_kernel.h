@@ -70,7 +70,8 @@ __device__ __forceinline__ void lstm_cell4_any(const float (&z)[4][4], const f32
   }
 }
 
-// profiling builds only (tools/knockout_bf16.sh): -DDLWP_KNOCK=n removes one phase of the octet cell-update instances --
+// profiling builds only (tools/knockout_bf16.sh): -DDLWP_KNOCK=n removes one phase of the octet cell-update instances (6: the weight
+// loads and their staging) --
 // 1: the gate arithmetic, 2: the c / h stores, 3: the z_add / c_prev loads, 4: the matrix loop, 5: the input staging
 #ifndef DLWP_KNOCK
 #define DLWP_KNOCK 0
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
       }
     }
     const unsigned wsoff = w_tile_off + (unsigned)(c0 / C::CK) * (C::WCH * 16u);
+    if (DLWP_KNOCK == 6 && C::GATES && C::SW) return;     // (profiling: no weight loads -- the ceiling of a weight-stationary loop)
 #pragma unroll
     for (int k = 0; k < C::NWV; ++k)
       wr[k] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (unsigned)(tid + k * C::NT) * 16u, wsoff, 0);
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv2d_fwd_mfma_bf16(const ConvArgs 
         }
       }
     }
+    if (DLWP_KNOCK == 6 && C::GATES && C::SW) return;     // (... and no weight staging)
 #pragma unroll
     for (int k = 0; k < C::NWV; ++k) wo[tid + k * C::NT] = wr[k];
   };

@@ -1,4 +1,4 @@
-for k in base 1 2 3 4 5; do
+for k in ${KNOCKS:-base 1 2 3 4 5}; do
   if [ $k = base ]; then unset DLWP_LIB_PATH; else export DLWP_LIB_PATH=$GRAFT_REPO_ROOT/dlwp_amd/knock/libdlwp_hip_k$k.so; fi
   python tools/bench_cfg4.py --members 8 2>/dev/null | tail -1 | python -c "
 import sys, json
