@@ -126,6 +126,29 @@ class TimeSeriesEstimator(object):
         k = es + self._interval - 1                                # series steps the window advances per model call
 
         gen = self.generator
+        # the insolation of the rows past the data at every lead depends on the sample times only: its table (one vectorised call of
+        # util.insolation, ~9 ms at 28 calls of the 88 x 180 grid) is computed on a thread of its own WHILE the predictors are
+        # gathered and uploaded below (numpy releases the interpreter lock inside its kernels); joined where the device loop needs it
+        sol_job = None
+        if self._add_insolation and effective_steps > 1 and hasattr(getattr(self.model, 'model', None), 'fed_rollout_on_device'):
+            import threading
+            hw0 = tuple(gen.convolution_shape[-2:])
+            coord0 = np.asarray(self._da.coords['sample'])[:gen._n_sample]
+            if not self._is_series:
+                coord0 = coord0 - self._dt * (t_in - 1)
+            box = {}
+
+            def work():
+                try:
+                    offs = np.array([[(s + 1) * k + m for m in range(t_in)] for s in range(effective_steps - 1)])
+                    when = coord0[-es:][np.newaxis, :, np.newaxis] + offs[:, np.newaxis, :] * self._dt
+                    uniq, inv = np.unique(when.ravel(), return_inverse=True)
+                    box['sol'] = insolation(uniq, self._da.coords.get('lat'), self._da.coords.get('lon'))[inv.ravel()].reshape(
+                        (effective_steps - 1, when.shape[1], t_in) + hw0)
+                except BaseException as e:  # noqa: BLE001  (raised where the table is asked for)
+                    box['error'] = e
+            sol_job = (threading.Thread(target=work, daemon=True), box)
+            sol_job[0].start()
         made = gen.generate_inputs() if hasattr(gen, 'generate_inputs') else None
         if made is not None:                                    # (the targets are never read here: only their shape)
             p, t_shape = made
@@ -183,13 +206,14 @@ class TimeSeriesEstimator(object):
                 for ts in range(t_in):
                     sol_map[ts * c_in + sol_idx] = ts
                 # the times of the rows past the data at every lead: known before the rollout starts
-                # (util.insolation is element-wise in the dates: ONE call over the distinct times, then a gather)
+                # (util.insolation is element-wise in the dates: ONE call over the distinct times, then a gather -- started on its own
+                #  thread at the top of this method)
                 sol = np.empty((max(effective_steps - 1, 1), tail, t_in) + hw, dtype=np.float32)
                 if effective_steps > 1:
-                    offs = np.array([[(s + 1) * k + m for m in range(t_in)] for s in range(effective_steps - 1)])
-                    when = sample_coord[-es:][np.newaxis, :, np.newaxis] + offs[:, np.newaxis, :] * self._dt
-                    uniq, inv = np.unique(when.ravel(), return_inverse=True)
-                    sol[:] = insolation(uniq, lat, lon)[inv.ravel()].reshape(sol.shape)
+                    sol_job[0].join()
+                    if 'error' in sol_job[1]:
+                        raise sol_job[1]['error']
+                    sol[:] = sol_job[1]['sol']
             if kwargs.get('verbose', 0) > 0:
                 for s in range(effective_steps):
                     print('Time step %d/%d' % (s + 1, effective_steps))
