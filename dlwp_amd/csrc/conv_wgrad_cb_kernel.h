@@ -138,11 +138,14 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
   constexpr int NSR = C::LR / 2 + 1, NSC = C::LC / 2, NSQ = (NSC + 3) / 4, UIT = NSR * NSQ;
   constexpr int UCPP = C::NTHREADS / 32, XPQ = C::CIX / UCPP;
   static_assert(!C::WUPS || (UIT <= 32 && C::CIX % UCPP == 0 && XPQ <= C::NQW - 2), "source-resolution loader geometry");
-  f32x4 xq[C::WUPS ? XPQ : 1];
+  f32x4 xq[C::WUPS ? XPQ : 1], xe[C::WUPS ? XPQ : 1];   // (xe: the boundary quads' elements, loaded only by tiles that have some)
+#pragma unroll
+  for (int p_ = 0; p_ < (C::WUPS ? XPQ : 1); ++p_) xe[p_] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int u_it = tid & 31, u_cg = tid >> 5;
   const int u_sr = u_it / NSQ, u_sq = u_it - u_sr * NSQ;          // (u_it >= UIT: idle lanes)
   unsigned uq_off = DROP, ue_off[4] = {DROP, DROP, DROP, DROP};
   bool uq_quad = true;                    // the quad is 4 consecutive source elements (one 16-byte load)
+  bool uq_edges = false;                  // some lane of this wave has a boundary quad (wave-uniform)
   int tw_i, th_i, n_i;
   {
     int q = t_begin;
@@ -187,13 +190,18 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
       if ((unsigned)rs >= (unsigned)Hs) rs = -1;
       const int c0 = ((j0 - a.pad_left - e_al) >> 1) + 4 * u_sq;
       uq_quad = c0 >= 0 && c0 + 3 < Ws;
-      uq_off = (rs >= 0 && u_it < UIT && uq_quad) ? (unsigned)(rs * Ws + c0) * 4u : DROP;
+      uq_edges = __builtin_amdgcn_ballot_w64(!uq_quad && u_it < UIT) != 0;
+      // (r6: the lane's channel goes into the VECTOR offset.  u_cg = tid >> 5 differs between the halves of a wave, and as the scalar
+      //  offset of the load it made every load a waterfall loop -- readfirstlane, compare, load under the matching half, repeat --
+      //  with s_waitcnt vmcnt(0) behind it: tools/isa_waits.py.  DROP + a channel offset stays out of range, no wrap.)
+      const unsigned ch_off = (unsigned)u_cg * plane_bytes;
+      uq_off = (rs >= 0 && u_it < UIT && uq_quad) ? (unsigned)(rs * Ws + c0) * 4u + ch_off : DROP;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         int c = c0 + k;
         if (a.mode_w == DLWP_PAD_ZERO) c = (unsigned)c < (unsigned)Ws ? c : -1;
         else c = c < 0 ? c + Ws : (c >= Ws ? c - Ws : c);
-        ue_off[k] = (rs >= 0 && u_it < UIT && !uq_quad && (unsigned)c < (unsigned)Ws) ? (unsigned)(rs * Ws + c) * 4u : DROP;
+        ue_off[k] = (rs >= 0 && u_it < UIT && !uq_quad && (unsigned)c < (unsigned)Ws) ? (unsigned)(rs * Ws + c) * 4u + ch_off : DROP;
       }
     } else {
       const int rs = map_axis(i0 + x_lr - a.pad_top, a.H, a.mode_h, fast_h);
@@ -244,21 +252,27 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
     }
   };
   auto load_xq = [&](int p) {            // WUPS: the quad of channel u_cg + p UCPP (boundary quads element by element)
-    const unsigned so = (unsigned)(u_cg + p * UCPP) * plane_bytes;
-    if (uq_quad) {
-      xq[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, uq_off, so, 0));
-    } else {
+    const unsigned so = (unsigned)(p * UCPP) * plane_bytes;      // (wave-uniform; the lane's own channel is in uq_off / ue_off)
+    // (r6: two register sets, merged where the quad is staged.  As one set written under `if (uq_quad) ... else ...` the two
+    //  definitions did not always land in the same registers, and the copy that joins them sat behind the load with
+    //  s_waitcnt vmcnt(0) -- every load in flight awaited once per tile.  Lanes of the other kind have DROP as their offset.)
+    xq[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, uq_off, so, 0));
+    if (uq_edges) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) xq[p][k] = ld1(ue_off[k], so);
+      for (int k = 0; k < 4; ++k) xe[p][k] = ld1(ue_off[k], so);
     }
   };
   // one 16-byte load per pixel quad (dword-aligned; rows whose length is no multiple of 4 keep the last quad's surplus
   // elements -- they belong to the next row -- out with selects)
+  // (r6: the ragged last quad is masked where the quad is STAGED, not here.  With the selects behind the load the compiler put
+  //  s_waitcnt vmcnt(0) + 4 v_cndmask right behind every dz load of the quad loop -- a full memory latency exposed per load, and a
+  //  wait for every x load issued before it: the "cost of issuing the loads" of profiles/r6_wgrad_cb_knockout.txt.  z_rem is set by
+  //  the tile_setup() that issues a tile's loads and still holds that tile's value when the tile is staged.)
   auto load_z = [&](int k) {
     const unsigned voff = gz + (unsigned)(k * C::ZSTEP) * oplane_bytes;   // (DROP + channels: still out of range, no wrap)
     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, voff, z_tile_off, 0));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zv[k][r] = (quad_z || r < z_rem) ? v[r] : 0.f;
+    for (int r = 0; r < 4; ++r) zv[k][r] = v[r];
   };
 
   if (t_begin < t_end) {
@@ -284,7 +298,7 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
       if (u_it < UIT) {
 #pragma unroll
         for (int p_ = 0; p_ < XPQ; ++p_) {
-          const f32x4 e = xq[p_];
+          const f32x4 e = uq_quad ? xq[p_] : xe[p_];      // (uq_quad: still the staged tile's -- tile_setup() runs after this)
           float* pl = xs + (u_cg + p_ * UCPP) * C::PSX + 8 * u_sq - 1;
           const bool v1 = 4 * u_sq + 1 < NSC, v2 = 4 * u_sq + 2 < NSC, v3 = 4 * u_sq + 3 < NSC;   // (v0: always)
 #pragma unroll
@@ -316,8 +330,11 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
 #pragma unroll
     for (int k = 0; k < C::NZ4; ++k) {
       float* d = z_dst + k * C::ZSTEP * C::PSZ;
-      *(u32x2*)d = (u32x2){__builtin_bit_cast(unsigned, zv[k][0]), __builtin_bit_cast(unsigned, zv[k][1])};
-      *(u32x2*)(d + 2) = (u32x2){__builtin_bit_cast(unsigned, zv[k][2]), __builtin_bit_cast(unsigned, zv[k][3])};
+      float zm[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zm[r] = (quad_z || r < z_rem) ? zv[k][r] : 0.f;      // (the surplus elements of a ragged last quad)
+      *(u32x2*)d = (u32x2){__builtin_bit_cast(unsigned, zm[0]), __builtin_bit_cast(unsigned, zm[1])};
+      *(u32x2*)(d + 2) = (u32x2){__builtin_bit_cast(unsigned, zm[2]), __builtin_bit_cast(unsigned, zm[3])};
     }
     DLWP_WG_T(2);   // staging written (includes the wait for the prefetched loads)
     __syncthreads();

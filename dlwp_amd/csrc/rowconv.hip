@@ -547,10 +547,12 @@ __global__ __launch_bounds__(256, 2) void rowconv2d_wgrad_mfma(const RowArgs a) 
     for (int q = 0; q < 4; ++q) {
       const int co = wave + 4 * q;
       const bool ok = co0 + co < a.Cout;
+      // (scalar offsets pinned to an SGPR: left to the compiler they came out of a select in a VGPR and every load became a
+      //  waterfall loop -- readfirstlane, compare, load, branch; tools/isa_waits.py)
+      const unsigned so = (unsigned)uniform((int)((ok ? (unsigned)co * zplane_b : 0u) + zrow_b));
 #pragma unroll
       for (int j = 0; j < NSLOT; ++j)
-        zv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? zoff[j] : DROP,
-                                                                                  (ok ? (unsigned)co * zplane_b : 0u) + zrow_b, 0));
+        zv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rsrc, ok ? zoff[j] : DROP, so, 0));
     }
   };
   auto issue_x = [&](int n, int c0) {      // rows c0 + 4 q
@@ -558,10 +560,10 @@ __global__ __launch_bounds__(256, 2) void rowconv2d_wgrad_mfma(const RowArgs a) 
 #pragma unroll
     for (int q = 0; q < XRR; ++q) {
       const int c = c0 + 4 * q;
+      const unsigned so = (unsigned)uniform((int)((unsigned)min(c, a.Cin - 1) * xplane_b + xrow_b));
 #pragma unroll
       for (int j = 0; j < NSLOT; ++j)
-        xv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, c < a.Cin ? xoff[j] : DROP,
-                                                                                  (unsigned)min(c, a.Cin - 1) * xplane_b + xrow_b, 0));
+        xv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, c < a.Cin ? xoff[j] : DROP, so, 0));
     }
   };
   auto store_x = [&](int c0) {
