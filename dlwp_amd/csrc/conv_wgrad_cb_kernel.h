@@ -36,6 +36,8 @@ __device__ __forceinline__ f32x2 pk_sum_diff(f32x2 pq) {
   return r;
 }
 
+#include "conv_wgrad_cbu_kernel.h"   // WUPS instances: the body for an up-sampled source (r6)
+
 template <int TH_, int TW_, int CIG_, int COG_, int NT_, bool WUPS_ = false>
 struct WgCbCfg {
   static constexpr int TH = TH_, TW = TW_, CIG = CIG_, COG = COG_, NT = NT_;
@@ -59,12 +61,14 @@ struct WgCbCfg {
   static constexpr int NQW = P / 16;               // quads of 2x2-output tiles
   static constexpr int TYN = TH_ / 2, TXN = TW_ / 2;
   static constexpr int X_FLOATS = CIX * PSX + 2, Z_FLOATS = ZC * PSZ;   // + 2: the x planes start one column pair in (below)
-  static constexpr int LDS_BYTES = (X_FLOATS + Z_FLOATS) * 4;
+  typedef WgCbuCfg<TH_, TW_, CIG_, COG_, NT_> U;       // WUPS: geometry and LDS of conv_wgrad_cbu_kernel.h
+  static constexpr int LDS_BYTES = WUPS_ ? U::LDS_BYTES : (X_FLOATS + Z_FLOATS) * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS tile too large");
 };
 
 template <class C>
 __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const int blk, const int nblk) {
+  static_assert(!C::WUPS, "an up-sampled source has a body of its own (conv_wgrad_cbu_kernel.h)");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // The x tile's GLOBAL column pairs start on an even source column (8-byte loads), which with an odd left halo is one column
   // left of the first patch column.  In LDS the planes are shifted by that column instead, so that every 4 x 4 patch starts on
@@ -129,23 +133,7 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
 #ifdef DLWP_PHASE_TIMING
   long long wg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wg_t = __builtin_amdgcn_s_memtime();
 #endif
-  float xv[C::WUPS ? 1 : C::XPT][2], zv[C::NZ4][4];
-  // ---- WUPS instances (r5): an up-sampled source is fetched at SOURCE resolution.  The (TH + 2) x (TW + 4) window of the
-  //      up-sampled image is NSR x NSC source elements (odd halos: the window starts on the second row / column of a 2 x 2
-  //      replica), fetched as 16-byte column quads -- lane group of 32 = (source row, column quad) x one channel, XPQ loads per
-  //      thread and tile where the element-wise loader issued XPT = 16 four-byte ones (r3 knock-out: those 16 loads cost 8.1 k of
-  //      the quad phase's 19.5 k cycles on layer 4) -- and replicated 2 x 2 into the same LDS planes when they are staged.
-  constexpr int NSR = C::LR / 2 + 1, NSC = C::LC / 2, NSQ = (NSC + 3) / 4, UIT = NSR * NSQ;
-  constexpr int UCPP = C::NTHREADS / 32, XPQ = C::CIX / UCPP;
-  static_assert(!C::WUPS || (UIT <= 32 && C::CIX % UCPP == 0 && XPQ <= C::NQW - 2), "source-resolution loader geometry");
-  f32x4 xq[C::WUPS ? XPQ : 1], xe[C::WUPS ? XPQ : 1];   // (xe: the boundary quads' elements, loaded only by tiles that have some)
-#pragma unroll
-  for (int p_ = 0; p_ < (C::WUPS ? XPQ : 1); ++p_) xe[p_] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int u_it = tid & 31, u_cg = tid >> 5;
-  const int u_sr = u_it / NSQ, u_sq = u_it - u_sr * NSQ;          // (u_it >= UIT: idle lanes)
-  unsigned uq_off = DROP, ue_off[4] = {DROP, DROP, DROP, DROP};
-  bool uq_quad = true;                    // the quad is 4 consecutive source elements (one 16-byte load)
-  bool uq_edges = false;                  // some lane of this wave has a boundary quad (wave-uniform)
+  float xv[C::XPT][2], zv[C::NZ4][4];
   int tw_i, th_i, n_i;
   {
     int q = t_begin;
@@ -179,36 +167,10 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
     const int n_src = DLWP_WG_KNOCK == 5 ? 0 : n_i;
     const float* xn = a.x + ((long long)n_src * a.in_c_total + a.in_c_off + ci0) * plane;
     x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)x_chans * plane_bytes, 0x00020000);
-    if constexpr (C::WUPS) {
-      // source row / columns of this lane's quad; halo modes at source resolution (zero / periodic / edge commute with the 2 x 2
-      // replication on an even axis; the mirror modes do not: the host keeps them on the 16-position instance)
-      const int Hs = a.Hs, Ws = a.Ws;
-      int rs = ((i0 - a.pad_top) >> 1) + u_sr;
-      if (a.mode_h == DLWP_PAD_ZERO) rs = (unsigned)rs < (unsigned)Hs ? rs : -1;
-      else if (a.mode_h == DLWP_PAD_EDGE) rs = min(max(rs, 0), Hs - 1);
-      else rs = rs < 0 ? rs + Hs : (rs >= Hs ? rs - Hs : rs);
-      if ((unsigned)rs >= (unsigned)Hs) rs = -1;
-      const int c0 = ((j0 - a.pad_left - e_al) >> 1) + 4 * u_sq;
-      uq_quad = c0 >= 0 && c0 + 3 < Ws;
-      uq_edges = __builtin_amdgcn_ballot_w64(!uq_quad && u_it < UIT) != 0;
-      // (r6: the lane's channel goes into the VECTOR offset.  u_cg = tid >> 5 differs between the halves of a wave, and as the scalar
-      //  offset of the load it made every load a waterfall loop -- readfirstlane, compare, load under the matching half, repeat --
-      //  with s_waitcnt vmcnt(0) behind it: tools/isa_waits.py.  DROP + a channel offset stays out of range, no wrap.)
-      const unsigned ch_off = (unsigned)u_cg * plane_bytes;
-      uq_off = (rs >= 0 && u_it < UIT && uq_quad) ? (unsigned)(rs * Ws + c0) * 4u + ch_off : DROP;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        int c = c0 + k;
-        if (a.mode_w == DLWP_PAD_ZERO) c = (unsigned)c < (unsigned)Ws ? c : -1;
-        else c = c < 0 ? c + Ws : (c >= Ws ? c - Ws : c);
-        ue_off[k] = (rs >= 0 && u_it < UIT && !uq_quad && (unsigned)c < (unsigned)Ws) ? (unsigned)(rs * Ws + c) * 4u + ch_off : DROP;
-      }
-    } else {
-      const int rs = map_axis(i0 + x_lr - a.pad_top, a.H, a.mode_h, fast_h);
-      const int c0 = j0 + x_lc - a.pad_left - e_al;
-      gx0 = src_off(rs, map_axis(c0, a.W, a.mode_w, fast_w));
-      if (x_mode == 3) gx1 = src_off(rs, map_axis(c0 + 1, a.W, a.mode_w, fast_w));
-    }
+    const int rs = map_axis(i0 + x_lr - a.pad_top, a.H, a.mode_h, fast_h);
+    const int c0 = j0 + x_lc - a.pad_left - e_al;
+    gx0 = src_off(rs, map_axis(c0, a.W, a.mode_w, fast_w));
+    if (x_mode == 3) gx1 = src_off(rs, map_axis(c0 + 1, a.W, a.mode_w, fast_w));
     const float* zn = a.dz + ((long long)n_src * a.dz_c_total + a.dz_c_off + co0) * oplane;
     z_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)zn, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
     z_tile_off = (unsigned)(i0 * a.Wo + j0) * 4u;
@@ -251,17 +213,6 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
       xv[ci][1] = ld1(gx1, so);
     }
   };
-  auto load_xq = [&](int p) {            // WUPS: the quad of channel u_cg + p UCPP (boundary quads element by element)
-    const unsigned so = (unsigned)(p * UCPP) * plane_bytes;      // (wave-uniform; the lane's own channel is in uq_off / ue_off)
-    // (r6: two register sets, merged where the quad is staged.  As one set written under `if (uq_quad) ... else ...` the two
-    //  definitions did not always land in the same registers, and the copy that joins them sat behind the load with
-    //  s_waitcnt vmcnt(0) -- every load in flight awaited once per tile.  Lanes of the other kind have DROP as their offset.)
-    xq[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, uq_off, so, 0));
-    if (uq_edges) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xe[p][k] = ld1(ue_off[k], so);
-    }
-  };
   // one 16-byte load per pixel quad (dword-aligned; rows whose length is no multiple of 4 keep the last quad's surplus
   // elements -- they belong to the next row -- out with selects)
   // (r6: the ragged last quad is masked where the quad is STAGED, not here.  With the selects behind the load the compiler put
@@ -277,13 +228,8 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
 
   if (t_begin < t_end) {
     tile_setup();
-    if constexpr (C::WUPS) {
 #pragma unroll
-      for (int p_ = 0; p_ < XPQ; ++p_) load_xq(p_);
-    } else {
-#pragma unroll
-      for (int ci = 0; ci < C::XPT; ++ci) load_x(ci);
-    }
+    for (int ci = 0; ci < C::XPT; ++ci) load_x(ci);
     DLWP_WG_T(4);
 #pragma unroll
     for (int k = 0; k < C::NZ4; ++k) load_z(k);
@@ -292,40 +238,10 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
   for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();   // previous tile consumed
     DLWP_WG_T(1);
-    if constexpr (C::WUPS) {
-      // a source element -> its 2 x 2 replica inside the window: source row u_sr is window rows 2 u_sr - 1 and 2 u_sr, source
-      // column 4 u_sq + k window columns 8 u_sq + 2 k, + 1 (planes shifted left by e_al = 1: the pairs straddle even offsets)
-      if (u_it < UIT) {
 #pragma unroll
-        for (int p_ = 0; p_ < XPQ; ++p_) {
-          const f32x4 e = uq_quad ? xq[p_] : xe[p_];      // (uq_quad: still the staged tile's -- tile_setup() runs after this)
-          float* pl = xs + (u_cg + p_ * UCPP) * C::PSX + 8 * u_sq - 1;
-          const bool v1 = 4 * u_sq + 1 < NSC, v2 = 4 * u_sq + 2 < NSC, v3 = 4 * u_sq + 3 < NSC;   // (v0: always)
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const int lr = 2 * u_sr - 1 + half;
-            if (lr < 0 || lr >= C::LR) continue;
-            float* d = pl + lr * C::LC;
-            d[0] = e[0];
-            if (v1) *(f32x2*)(d + 1) = (f32x2){e[0], e[1]};
-            else d[1] = e[0];
-            if (v2) *(f32x2*)(d + 3) = (f32x2){e[1], e[2]};
-            else if (v1) d[3] = e[1];
-            if (v3) {
-              *(f32x2*)(d + 5) = (f32x2){e[2], e[3]};
-              d[7] = e[3];
-            } else if (v2) {
-              d[5] = e[2];
-            }
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ci = 0; ci < C::XPT; ++ci) {
-        x_dst[ci * C::PSX] = xv[ci][0];
-        x_dst[ci * C::PSX + 1] = xv[ci][1];
-      }
+    for (int ci = 0; ci < C::XPT; ++ci) {
+      x_dst[ci * C::PSX] = xv[ci][0];
+      x_dst[ci * C::PSX + 1] = xv[ci][1];
     }
 #pragma unroll
     for (int k = 0; k < C::NZ4; ++k) {
@@ -388,12 +304,8 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
     for (int q = 0; q < C::NQW; ++q) {
       if (more && DLWP_WG_KNOCK != 1) {   // all loads are out after quad LQ - 1: the last ones have the remaining quads to land
         constexpr int LQ = C::NQW - 2;
-        if constexpr (C::WUPS) {
-          if (q < XPQ) load_xq(q);
-        } else {
 #pragma unroll
-          for (int ci = (q * C::XPT + LQ - 1) / LQ; ci < ((q + 1) * C::XPT + LQ - 1) / LQ && ci < C::XPT; ++ci) load_x(ci);
-        }
+        for (int ci = (q * C::XPT + LQ - 1) / LQ; ci < ((q + 1) * C::XPT + LQ - 1) / LQ && ci < C::XPT; ++ci) load_x(ci);
 #pragma unroll
         for (int k = (q * C::NZ4 + LQ - 1) / LQ; k < ((q + 1) * C::NZ4 + LQ - 1) / LQ && k < C::NZ4; ++k) load_z(k);
       }
@@ -456,13 +368,12 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
         for (int i = 0; i < 4; ++i) {
           const float m4[4] = {rw[nt][i][0], sd[nt][i][0], sd[nt][i][1], rw[nt][i][1]};
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (!(C::WUPS && (i == 2 || j == 2))) {
-              if (DLWP_WG_KNOCK == 2) acc[(i * 4 + j) * C::NT + nt][0] += v2[i][j >> 1][j & 1] * m4[j];
-              else
-                acc[(i * 4 + j) * C::NT + nt] =
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(v2[i][j >> 1][j & 1], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
-            }
+          for (int j = 0; j < 4; ++j) {
+            if (DLWP_WG_KNOCK == 2) acc[(i * 4 + j) * C::NT + nt][0] += v2[i][j >> 1][j & 1] * m4[j];
+            else
+              acc[(i * 4 + j) * C::NT + nt] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(v2[i][j >> 1][j & 1], m4[j], acc[(i * 4 + j) * C::NT + nt], 0, 0, 0);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -511,7 +422,8 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
 // 256 registers per wave: two waves per SIMD (8-wave workgroups: one per CU; 4-wave workgroups: two)
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, 512 / C::NTHREADS) void conv2d_wgrad_wino_cb_f32(const WgradArgs a) {
-  conv2d_wgrad_cb_body<C>(a, blockIdx.x, gridDim.x);
+  if constexpr (C::WUPS) conv2d_wgrad_cbu_body<typename C::U>(a, blockIdx.x, gridDim.x);
+  else conv2d_wgrad_cb_body<C>(a, blockIdx.x, gridDim.x);
 }
 
 template <class C>
@@ -529,16 +441,14 @@ static void wgrad_cb_launch_thunk(const WgradArgs& a, int grid, hipStream_t s) {
 
 template <class C>
 static int wgrad_cb_prepare() {
-  if (C::LDS_BYTES > 64 * 1024) {
-    typedef WgCbCfg<C::TH, C::TW, C::CIG, C::COG, C::NT, true> CU;
-    int e = (int)hipFuncSetAttribute((const void*)conv2d_wgrad_wino_cb_f32<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     C::LDS_BYTES);
-    if (e == 0)
-      e = (int)hipFuncSetAttribute((const void*)conv2d_wgrad_wino_cb_f32<CU>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   CU::LDS_BYTES);
-    return e;
-  }
-  return 0;
+  typedef WgCbCfg<C::TH, C::TW, C::CIG, C::COG, C::NT, true> CU;
+  int e = 0;
+  if (C::LDS_BYTES > 64 * 1024)
+    e = (int)hipFuncSetAttribute((const void*)conv2d_wgrad_wino_cb_f32<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  if (e == 0 && CU::LDS_BYTES > 64 * 1024)
+    e = (int)hipFuncSetAttribute((const void*)conv2d_wgrad_wino_cb_f32<CU>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 CU::LDS_BYTES);
+  return e;
 }
 
 // table entry: nt = cout fragments per BLOCK, cib = input channels per block (what the host derives its grid from), wino = 3
