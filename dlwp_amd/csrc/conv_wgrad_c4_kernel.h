@@ -150,21 +150,52 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
     if constexpr (C::FUSE) return ((wave * (C::GPW / 2) + k / 2) % C::GPR) * 16;
     else return ((wave * C::GPW + k) % C::GPR) * 16;
   };
-  if (t_begin < t_end) load_x_tile(n_i, th_i, tw_i);
+  // FUSE (r6): the raw values of the NEXT tile -- both rows of y under this lane's two pooling windows per cout fragment and the two
+  // pooled gradients -- are requested one tile ahead, beside the next x tile.  Loaded where they are used, every tile began with
+  // 8 loads and ~150 vector instructions of pooling backward that depend on them: a full memory latency per tile and wave in front of
+  // 48 MFMAs (0.26 of the matrix peak at 64 samples, 2.6 TB/s on a 200 MB launch).  20 registers; still 5 workgroups per CU.
+  f32x4 rtop[C::FUSE ? C::GPW / 2 : 1][C::NT], rbot[C::FUSE ? C::GPW / 2 : 1][C::NT];
+  float rg[C::FUSE ? C::GPW / 2 : 1][C::NT][2];
+  auto fuse_load = [&](int ni, int thi, int twi) {
+    const int i0 = thi * C::TH, j0 = twi * C::TW;
+    const int H2 = a.Ho >> 1, W2 = a.Wo >> 1;
+    const float* zp = a.y + ((long long)ni * a.dz_c_total + a.dz_c_off + co0) * oplane;
+    const __amdgpu_buffer_rsrc_t z_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)zp, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
+    const float* pp = a.dpool + ((long long)ni * a.Cout + co0) * (H2 * W2);
+    const __amdgpu_buffer_rsrc_t p_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)pp, 0, (unsigned)z_chans * (unsigned)(H2 * W2) * 4u, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < C::GPW; k += 2) {
+      const int prow = group_row(k), pcol = group_col(k) + 4 * (lane >> 4);
+      const int row = i0 + prow, col = j0 + pcol;             // row even (tiles start on even rows, pairs on even rows)
+      const bool okw = (row >> 1) < H2 && col < 2 * W2;
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) {
+        const unsigned voff = okw ? (unsigned)(((nt * 16 + (lane & 15)) * (int)oplane + row * a.Wo + col)) * 4u : DROP;
+        rtop[k / 2][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, voff, 0, 0));
+        rbot[k / 2][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, okw ? voff + (unsigned)a.Wo * 4u : DROP, 0, 0));
+        const unsigned doff = okw ? (unsigned)(((nt * 16 + (lane & 15)) * (H2 * W2) + (row >> 1) * W2 + (col >> 1))) * 4u : DROP;
+        rg[k / 2][nt][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p_rsrc, doff, 0, 0));
+        rg[k / 2][nt][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p_rsrc, okw ? doff + 4u : DROP, 0, 0));
+      }
+    }
+  };
+  if (t_begin < t_end) {
+    load_x_tile(n_i, th_i, tw_i);
+    if constexpr (C::FUSE) fuse_load(n_i, th_i, tw_i);
+  }
   int buf = 0;
   for (int tile = t_begin; tile < t_end; ++tile, buf ^= 1) {
     const int i0 = th_i * C::TH, j0 = tw_i * C::TW, n_cur = n_i;
     // ---- dz of this wave's groups, straight into registers: 16 bytes per lane, cout fragment and group.  (Requesting the
     //      NEXT tile's dz before this tile's MFMAs -- twice the registers -- was measured: 0.060 vs 0.056 ms at 64 samples; the
     //      four resident workgroups of a CU already cover the latency.)
-    const float* zp = (C::FUSE ? a.y : a.dz) + ((long long)n_cur * a.dz_c_total + a.dz_c_off + co0) * oplane;
-    const __amdgpu_buffer_rsrc_t z_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)zp, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
-    const float* pp = C::FUSE ? a.dpool + ((long long)n_cur * a.Cout + co0) * ((a.Ho >> 1) * (a.Wo >> 1)) : a.dz;
-    const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)pp, 0, C::FUSE ? (unsigned)z_chans * (unsigned)((a.Ho >> 1) * (a.Wo >> 1)) * 4u : 0u, 0x00020000);
     f32x4 zv[C::GPW][C::NT];
     if constexpr (!C::FUSE) {
+      const float* zp = a.dz + ((long long)n_cur * a.dz_c_total + a.dz_c_off + co0) * oplane;
+      const __amdgpu_buffer_rsrc_t z_rsrc =
+          __builtin_amdgcn_make_buffer_rsrc((void*)zp, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
 #pragma unroll
       for (int k = 0; k < C::GPW; ++k) {
         const int prow = group_row(k), pcol = group_col(k) + 4 * (lane >> 4);
@@ -182,7 +213,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
     } else {
       // groups come in vertical pairs (rows 2p, 2p + 1 of the same 16 columns): a lane holds both rows of its two pooling windows
       // -- every element of y is loaded once -- and forms the gradient of all 8 pixels: the window's FIRST maximum in row-major
-      // order takes dpool x act'(y) (maxpool2_bwd_kernel), everything else, an odd last row / column included, is zero
+      // order takes dpool x act'(y) (maxpool2_bwd_kernel), everything else, an odd last row / column included, is zero.  The raw
+      // values were requested a tile ago (fuse_load)
       const int H2 = a.Ho >> 1, W2 = a.Wo >> 1;
 #pragma unroll
       for (int k = 0; k < C::GPW; k += 2) {
@@ -191,12 +223,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
         const bool okw = (row >> 1) < H2 && col < 2 * W2;
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt) {
-          const unsigned voff = okw ? (unsigned)(((nt * 16 + (lane & 15)) * (int)oplane + row * a.Wo + col)) * 4u : DROP;
-          const f32x4 top = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, voff, 0, 0));
-          const f32x4 bot = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rsrc, okw ? voff + (unsigned)a.Wo * 4u : DROP, 0, 0));
-          const unsigned doff = okw ? (unsigned)(((nt * 16 + (lane & 15)) * (H2 * W2) + (row >> 1) * W2 + (col >> 1))) * 4u : DROP;
-          const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p_rsrc, doff, 0, 0));
-          const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p_rsrc, okw ? doff + 4u : DROP, 0, 0));
+          const f32x4 top = rtop[k / 2][nt], bot = rbot[k / 2][nt];
+          const float g0 = rg[k / 2][nt][0], g1 = rg[k / 2][nt][1];
 #pragma unroll
           for (int wdw = 0; wdw < 2; ++wdw) {
             const float v[4] = {top[2 * wdw], top[2 * wdw + 1], bot[2 * wdw], bot[2 * wdw + 1]};
@@ -234,7 +262,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
         ++n_i;
       }
     }
-    if (tile + 1 < t_end) load_x_tile(n_i, th_i, tw_i);
+    if (tile + 1 < t_end) {
+      load_x_tile(n_i, th_i, tw_i);
+      if constexpr (C::FUSE) fuse_load(n_i, th_i, tw_i);
+    }
     // ---- 16-pixel groups: 6 LDS reads (4 consecutive floats each) + 24 MFMAs
 #pragma unroll
     for (int k = 0; k < C::GPW; ++k) {

@@ -26,7 +26,28 @@ def disassemble(obj):
     subprocess.check_call(['objcopy', '-O', 'binary', '--only-section=.hip_fatbin', obj, fat])
     subprocess.check_call([LLVM + '/clang-offload-bundler', '--type=o', '--unbundle', '--input=' + fat,
                            '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
+    global NOTES
+    NOTES = subprocess.check_output([LLVM + '/llvm-readelf', '--notes', co], text=True)
     return subprocess.check_output([LLVM + '/llvm-objdump', '-d', '--demangle', co], text=True)
+
+
+NOTES = ''
+
+
+def registers():
+    """{demangled kernel name: 'vgpr N (spilled M) sgpr K'} from the code object's metadata"""
+    out = {}
+    for k in re.split(r'\n\s+- \.agpr_count', NOTES)[1:]:
+        n = re.search(r'\.name:\s+(\S+)', k)
+        if not n:
+            continue
+        name = subprocess.run(['c++filt', n.group(1)], capture_output=True, text=True).stdout.strip()
+
+        def g(f):
+            m = re.search(r'\.%s:\s+(\d+)' % f, k)
+            return m.group(1) if m else '?'
+        out[name.replace(' ', '')] = 'vgpr %s (spilled %s) sgpr %s (spilled %s)' % (g('vgpr_count'), g('vgpr_spill_count'), g('sgpr_count'), g('sgpr_spill_count'))
+    return out
 
 
 def kernels(txt):
@@ -38,6 +59,22 @@ def kernels(txt):
 
 def is_vload(l):
     return re.match(r'(buffer_load|global_load|flat_load|scratch_load)', l) is not None
+
+
+def scan_lds(lines, near):
+    """the same for LDS reads: s_waitcnt lgkmcnt(n) at most `near` instructions behind a ds_read, n below the reads issued since the
+    previous wait (scalar loads share the counter; they are rare inside the loops this is for)"""
+    found = []
+    last, since = None, 0
+    for i, l in enumerate(lines):
+        if l.startswith('ds_read'):
+            last, since = i, since + 1
+        elif l.startswith('s_waitcnt') and 'lgkmcnt' in l:
+            n = int(re.search(r'lgkmcnt\((\d+)\)', l).group(1))
+            if last is not None and i - last <= near and n < since:
+                found.append((i, l, i - last, since, lines[i + 1] if i + 1 < len(lines) else ''))
+            since = min(since, n)
+    return found
 
 
 def scan(lines, near):
@@ -62,9 +99,11 @@ def main():
     ap.add_argument('obj')
     ap.add_argument('--kernel', default='')
     ap.add_argument('--near', type=int, default=6)
+    ap.add_argument('--lds', action='store_true', help='also list lgkmcnt waits right behind the ds_read they wait for')
     ap.add_argument('--all', action='store_true', help='list every hit instead of the per-kernel count and first few')
     a = ap.parse_args()
     txt = disassemble(a.obj)
+    regs = registers()
     for name, lines in kernels(txt):
         if a.kernel not in name:
             continue
@@ -75,10 +114,16 @@ def main():
         # a memory instruction whose scalar operand the compiler could not prove wave-uniform: readfirstlane, compare, the
         # instruction under the matching lanes, repeat for the rest
         falls = sum(1 for i, l in enumerate(lines[:-1]) if l.startswith('s_xor_b64 exec') and lines[i + 1].startswith('s_cbranch_execnz'))
-        print('%s\n   %d instructions, %d MFMAs, %d scratch accesses, %d waterfall loops; waits right behind their load: %d (%d between '
-              'the first and the last MFMA)' % (name[:150], len(lines), len(mf), scratch, falls, len(hits), len(inside)))
+        print('%s\n   %s; %d instructions, %d MFMAs, %d scratch accesses, %d waterfall loops; waits right behind their load: %d (%d '
+              'between the first and the last MFMA)' % (name[:150], regs.get(name.replace(' ', ''), '?'), len(lines), len(mf), scratch, falls, len(hits),
+                                                       len(inside)))
         for h in (hits if a.all else inside[:6]):
             print('      +%d %-22s %d behind the load, %d loads out | then %s' % (h[0], h[1], h[2], h[3], h[4][:70]))
+        if a.lds:
+            lh = [h for h in scan_lds(lines, a.near) if mf and mf[0] < h[0] < mf[-1]]
+            print('   LDS waits right behind their read, between the first and the last MFMA: %d' % len(lh))
+            for h in (lh if a.all else lh[:6]):
+                print('      +%d %-22s %d behind the read, %d reads out | then %s' % (h[0], h[1], h[2], h[3], h[4][:70]))
 
 
 if __name__ == '__main__':
