@@ -126,6 +126,14 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
     if (mode == DLWP_PAD_EDGE) return min(max(p, 0), n - 1);
     return p < 0 ? p + n : (p >= n ? p - n : p);
   };
+  // zero / edge / periodic on an axis at least a window long, all three computed and selected on the (wave-uniform) mode: no branch
+  auto map_simple = [&](int p, int n, int mode) -> int {
+    const int z = (unsigned)p < (unsigned)n ? p : -1;
+    const int e = min(max(p, 0), n - 1);
+    const int w = p < 0 ? p + n : (p >= n ? p - n : p);
+    return mode == DLWP_PAD_ZERO ? z : (mode == DLWP_PAD_EDGE ? e : w);
+  };
+  const bool simple = fast_h && fast_w && a.mode_h < DLWP_PAD_REFLECT && a.mode_w < DLWP_PAD_REFLECT && a.src_mode == DLWP_SRC_DIRECT;
   const bool pair_x = (a.W & 1) == 0 && (a.mode_w == DLWP_PAD_ZERO || a.mode_w == DLWP_PAD_WRAP);
   const bool quad_z = (a.Wo & 3) == 0;
   constexpr unsigned DROP = 0x7ffffff0u;
@@ -167,10 +175,23 @@ __device__ __forceinline__ void conv2d_wgrad_cb_body(const WgradArgs& a, const i
     const int n_src = DLWP_WG_KNOCK == 5 ? 0 : n_i;
     const float* xn = a.x + ((long long)n_src * a.in_c_total + a.in_c_off + ci0) * plane;
     x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xn, 0, (unsigned)x_chans * plane_bytes, 0x00020000);
-    const int rs = map_axis(i0 + x_lr - a.pad_top, a.H, a.mode_h, fast_h);
     const int c0 = j0 + x_lc - a.pad_left - e_al;
-    gx0 = src_off(rs, map_axis(c0, a.W, a.mode_w, fast_w));
-    if (x_mode == 3) gx1 = src_off(rs, map_axis(c0 + 1, a.W, a.mode_w, fast_w));
+    if (simple) {
+      // (r6) the common case -- a plain source, zero / periodic / edge halos on axes longer than a tile window -- without a branch:
+      // the general maps below are ~100 scalar branches over modes that do not change between tiles, 1.1-1.6 k cycles of every tile
+      // (tools/microbench/wgrad_cb_phase_timing.hip) with nothing on the matrix pipe
+      const int rs = map_simple(i0 + x_lr - a.pad_top, a.H, a.mode_h);
+      const int cs = map_simple(c0, a.W, a.mode_w);
+      gx0 = (rs | cs) < 0 ? DROP : (unsigned)(rs * a.Ws + cs) * 4u;
+      if (x_mode == 3) {
+        const int cs1 = map_simple(c0 + 1, a.W, a.mode_w);
+        gx1 = (rs | cs1) < 0 ? DROP : (unsigned)(rs * a.Ws + cs1) * 4u;
+      }
+    } else {
+      const int rs = map_axis(i0 + x_lr - a.pad_top, a.H, a.mode_h, fast_h);
+      gx0 = src_off(rs, map_axis(c0, a.W, a.mode_w, fast_w));
+      if (x_mode == 3) gx1 = src_off(rs, map_axis(c0 + 1, a.W, a.mode_w, fast_w));
+    }
     const float* zn = a.dz + ((long long)n_src * a.dz_c_total + a.dz_c_off + co0) * oplane;
     z_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)zn, 0, (unsigned)z_chans * oplane_bytes, 0x00020000);
     z_tile_off = (unsigned)(i0 * a.Wo + j0) * 4u;

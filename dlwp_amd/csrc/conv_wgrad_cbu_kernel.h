@@ -124,10 +124,12 @@ __device__ __forceinline__ void conv2d_wgrad_cbu_body(const WgradArgs& a, const 
     // source row / columns of this lane's quad; halo modes at source resolution (zero / periodic / edge commute with the 2 x 2
     // replication on an even axis; the mirror modes do not: the host keeps them on the 16-position instance)
     const int Hs = a.Hs, Ws = a.Ws;
+    // (all three maps computed, selected on the wave-uniform mode: no branches in the tile walk)
     int rs = ((i0 - a.pad_top) >> 1) + u_sr;
-    if (a.mode_h == DLWP_PAD_ZERO) rs = (unsigned)rs < (unsigned)Hs ? rs : -1;
-    else if (a.mode_h == DLWP_PAD_EDGE) rs = min(max(rs, 0), Hs - 1);
-    else rs = rs < 0 ? rs + Hs : (rs >= Hs ? rs - Hs : rs);
+    {
+      const int z = (unsigned)rs < (unsigned)Hs ? rs : -1, e = min(max(rs, 0), Hs - 1), w = rs < 0 ? rs + Hs : (rs >= Hs ? rs - Hs : rs);
+      rs = a.mode_h == DLWP_PAD_ZERO ? z : (a.mode_h == DLWP_PAD_EDGE ? e : w);
+    }
     if ((unsigned)rs >= (unsigned)Hs) rs = -1;
     const int c0 = ((j0 - a.pad_left - e_al) >> 1) + 4 * u_sq;
     uq_quad = c0 >= 0 && c0 + 3 < Ws;
@@ -139,8 +141,10 @@ __device__ __forceinline__ void conv2d_wgrad_cbu_body(const WgradArgs& a, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int c = c0 + k;
-      if (a.mode_w == DLWP_PAD_ZERO) c = (unsigned)c < (unsigned)Ws ? c : -1;
-      else c = c < 0 ? c + Ws : (c >= Ws ? c - Ws : c);
+      {
+        const int z = (unsigned)c < (unsigned)Ws ? c : -1, w = c < 0 ? c + Ws : (c >= Ws ? c - Ws : c);
+        c = a.mode_w == DLWP_PAD_ZERO ? z : w;
+      }
       ue_off[k] = (rs >= 0 && u_it < U::UIT && !uq_quad && (unsigned)c < (unsigned)Ws) ? (unsigned)(rs * Ws + c) * 4u + ch_off : DROP;
     }
     const float* zn = a.dz + ((long long)n_i * a.dz_c_total + a.dz_c_off + co0) * oplane;

@@ -50,6 +50,12 @@ meta $O/r6_estimator_kernel_stats.csv "tools/experiments/r6_estimator_api_breakd
 cd $R
 for b in 64 8; do python tools/bench_train.py --batch $b --steps 40 --warmup 20 > $O/r6_train_b${b}_noprof.json 2>/dev/null; tail -1 $O/r6_train_b${b}_noprof.json | cut -c1-300; done
 python tools/bench_layer6.py > $O/r6_layer6.json 2>/dev/null; cat $O/r6_layer6.json
+# the weight-gradient launches alone: per-phase cycle counts of the channel-block instances on the config-3 layers (built here:
+# hipcc is on the box), the first layer's fused launch, the instance sweep at 64 and 8 samples
+(cd tools/microbench && hipcc -O3 -std=c++17 --offload-arch=gfx950 -DDLWP_PHASE_TIMING -o /tmp/wgrad_cb_phase_timing.bin wgrad_cb_phase_timing.hip -I../../include 2> $O/wgcb_build.err \
+  && /tmp/wgrad_cb_phase_timing.bin > $O/r6_wgrad_cb_phase_timing.txt 2>&1)
+for b in 64 8; do python tools/bench_wgrad_pooled.py --batch $b; done > $O/r6_wgrad_pooled.json 2>/dev/null
+for b in 64 8; do python tools/tune_wgrad.py --batch $b --layers L4,L2p,L3p,L5r,L6r --iters 20 2>/dev/null | grep -E "wgrad|cfg" | grep -v failed | awk '/wgrad/ {n=0; print; next} {if (n++ < 6) print}'; done > $O/r6_wgrad_sweep.txt
 # the bench line quotes the rocprofv3 / PMC summaries of THIS kernel source from profiles/: put the fresh ones there first
 for f in r6_kernel_stats.csv r6_kernel_stats.meta.json r6_hbm_traffic_b256.json r6_mfma_busy.json r6_train_mfma_b64.json r6_train_mfma_b8.json; do cp $O/$f $R/profiles/$f; done
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/cfg4_stats $O/cfg4_fetch $O/cfg4_write
