@@ -90,6 +90,13 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
     if (mode == DLWP_PAD_EDGE) return min(max(p, 0), n - 1);
     return p < 0 ? p + n : (p >= n ? p - n : p);
   };
+  auto map_simple = [&](int p, int n, int mode) -> int {   // zero / edge / periodic on an axis at least a window long, selected on the mode
+    const int z = (unsigned)p < (unsigned)n ? p : -1;
+    const int e = min(max(p, 0), n - 1);
+    const int w = p < 0 ? p + n : (p >= n ? p - n : p);
+    return mode == DLWP_PAD_ZERO ? z : (mode == DLWP_PAD_EDGE ? e : w);
+  };
+  const bool simple = fast_h && fast_w && a.mode_h < DLWP_PAD_REFLECT && a.mode_w < DLWP_PAD_REFLECT && a.src_mode == DLWP_SRC_DIRECT;
   const bool pair_x = (a.W & 1) == 0 && (a.mode_w == DLWP_PAD_ZERO || a.mode_w == DLWP_PAD_WRAP) && a.src_mode == DLWP_SRC_DIRECT;
   const bool quad_z = (a.Wo & 3) == 0;
 
@@ -122,9 +129,17 @@ __global__ __launch_bounds__(C::NTHREADS) void conv2d_wgrad_c4_f32(const WgradAr
       const unsigned g2 = g + a.Ws * 4u;
       return fmaxf(fmaxf(ld1(g, so), ld1(g + 4u, so)), fmaxf(ld1(g2, so), ld1(g2 + 4u, so)));
     };
-    const int rs = map_axis(i0 + x_lr - a.pad_top, a.H, a.mode_h, fast_h);
     const int c0 = j0 + x_lc - a.pad_left - e_al;
-    const unsigned g0 = src_off(rs, map_axis(c0, a.W, a.mode_w, fast_w));
+    int rs;
+    unsigned g0;
+    if (simple) {     // (r6, as conv_wgrad_cb_kernel.h: the common case of the tile walk without a branch)
+      rs = map_simple(i0 + x_lr - a.pad_top, a.H, a.mode_h);
+      const int cs = map_simple(c0, a.W, a.mode_w);
+      g0 = (rs | cs) < 0 ? DROP : (unsigned)(rs * a.Ws + cs) * 4u;
+    } else {
+      rs = map_axis(i0 + x_lr - a.pad_top, a.H, a.mode_h, fast_h);
+      g0 = src_off(rs, map_axis(c0, a.W, a.mode_w, fast_w));
+    }
     if (pair_x) {
 #pragma unroll
       for (int ci = 0; ci < C::CI; ++ci) {

@@ -1001,6 +1001,43 @@ def test_conv_weight_gradient_every_compiled_tile_configuration():
         ops.force_wgrad_config(-1)
 
 
+@pytest.mark.parametrize('mode_h,mode_w', [(0, 1), (2, 1), (0, 0), (1, 1)])
+def test_weight_gradient_on_an_up_sampled_source_every_channel_block_instance_long_tile_walks(mode_h, mode_w):
+    """The 9-position body for an up-sampled source (r6: conv_wgrad_cbu_kernel.h -- source-resolution LDS window, two buffers, one
+    barrier per tile) against the float64 oracle on every channel-block instance: zero / periodic / edge (pole rows) halos at source
+    resolution, quads that straddle the periodic seam, a ragged last dz quad (output width 4 k + 2), ragged channel groups -- and with
+    DLWP_OPT_WGRAD_FILL = 1, so that a workgroup walks MANY tiles and both buffers change roles several times (at the default fill
+    these small launches give every workgroup one or two tiles)."""
+    from dlwp_amd import _lib, ops
+    rng = np.random.default_rng(23 + 5 * mode_h + mode_w)
+    cfgs, forms = ops.wgrad_configs(), ops.wgrad_config_forms()
+    n, cin, cout, hs, ws = 5, 40, 72, 11, 23                  # up-sampled: 22 x 46 (46 = 4 k + 2); 40 = 32 + 8, 72 = 64 + 8 channels
+    x = rng.standard_normal((n, cin, hs, ws)).astype(np.float32)
+    xu = np_ref.upsample2(np.asarray(x, np.float64))
+    xp = np_ref.pad2d_modes(xu, (1, 1, 1, 1), mode_h, mode_w)
+    dz = rng.standard_normal((n, cout, 2 * hs, 2 * ws)).astype(np.float32)
+    _, dw_ref, _ = np_ref.conv2d_grads(xp, np.zeros((3, 3, cin, cout)), dz, 1)
+    xd, dzd = torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda()
+    cd = ops.make_conv(cout, 3, 3, 1, ops.make_pad(1, 1, 1, 1, mode_h, mode_w), ops.ACT_LINEAR, src_mode=1)
+    seen = 0
+    try:
+        for fill in (1, 4):
+            _lib.set_option(_lib.OPT_WGRAD_FILL, fill)
+            for i, (ks, dil, th, tw, nt, waves, lds) in enumerate(cfgs):
+                if forms[i][1] != 3 or (ks, dil) != (3, 1):
+                    continue
+                ops.force_wgrad_config(i)
+                dwd = torch.full((3, 3, cin, cout), float('nan'), dtype=torch.float32, device='cuda')
+                ops.conv2d_bwd_weight(xd, dzd, dwd, cd, _lib.Shape4(n, cin, hs, ws))
+                err = np.abs(dwd.cpu().numpy() - dw_ref).max()
+                assert err <= 2e-5 * max(1., np.abs(dw_ref).max()), (fill, i, cfgs[i], err)
+                seen += 1
+    finally:
+        ops.force_wgrad_config(-1)
+        _lib.set_option(_lib.OPT_WGRAD_FILL, 4)
+    assert seen >= 2 * 9                                       # the nine channel-block instances, at both fills
+
+
 def test_reference_style_example_script_runs_end_to_end(tmp_path):
     """examples/train_and_forecast.py is written with the reference's imports (DLWP.*, keras.*) through the compat shim:
     data generator -> build_model -> fit_generator with callbacks -> save / load -> predict_timeseries."""
