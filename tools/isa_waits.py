@@ -5,8 +5,9 @@ The lesson of profiles/r6_wgrad_cb_knockout.txt: a select (or any ALU use) writt
 put `s_waitcnt vmcnt(0)` a few instructions after the load -- a full memory latency exposed on every load of a software-pipelined
 loop, and a wait for every load issued before it.  Knock-out builds see it only as "the loads cost N cycles to issue".  It also counts WATERFALL loops: a buffer instruction whose scalar offset lives in a VGPR (a value that differs inside the wave, or
 one the compiler cannot prove uniform) is wrapped in readfirstlane / compare / execute-under-mask / repeat.  This
-scanner lists, for every kernel, the `s_waitcnt vmcnt(n)` that sit at most --near instructions behind a vector memory load with
-n below the number of loads issued since the previous wait (i.e. the wait is for THAT load, not for older ones).
+scanner lists, for every kernel, the `s_waitcnt vmcnt(n)` that force the completion of a vector memory load issued at most --near
+instructions earlier (the counter decrements in issue order: `vmcnt(n)` completes everything but the newest n; a wait for the OLDEST of
+many loads in flight right after issuing new ones is a working pipeline and is not listed).
 
     python tools/isa_waits.py dlwp_amd/csrc/build/conv_bwd.o [--kernel wino_cb] [--near 6] [--all]
 """
@@ -61,37 +62,31 @@ def is_vload(l):
     return re.match(r'(buffer_load|global_load|flat_load|scratch_load)', l) is not None
 
 
-def scan_lds(lines, near):
-    """the same for LDS reads: s_waitcnt lgkmcnt(n) at most `near` instructions behind a ds_read, n below the reads issued since the
-    previous wait (scalar loads share the counter; they are rare inside the loops this is for)"""
-    found = []
-    last, since = None, 0
+def _scan(lines, near, is_issue, counter):
+    """-> [(index, wait, distance to the newest load the wait forces to complete, loads in flight, next instruction)] for the waits
+    that force a load issued at most `near` instructions earlier.  The counter decrements in issue order: `cnt(n)` completes
+    everything but the newest n."""
+    found, flying = [], []
     for i, l in enumerate(lines):
-        if l.startswith('ds_read'):
-            last, since = i, since + 1
-        elif l.startswith('s_waitcnt') and 'lgkmcnt' in l:
-            n = int(re.search(r'lgkmcnt\((\d+)\)', l).group(1))
-            if last is not None and i - last <= near and n < since:
-                found.append((i, l, i - last, since, lines[i + 1] if i + 1 < len(lines) else ''))
-            since = min(since, n)
+        if is_issue(l):
+            flying.append(i)
+        elif l.startswith('s_waitcnt') and counter in l:
+            n = int(re.search(counter + r'\((\d+)\)', l).group(1))
+            if len(flying) > n:
+                forced = flying[:len(flying) - n]
+                if i - forced[-1] <= near:
+                    found.append((i, l, i - forced[-1], len(flying), lines[i + 1] if i + 1 < len(lines) else ''))
+                flying = flying[len(flying) - n:]
     return found
+
+
+def scan_lds(lines, near):
+    """LDS reads (scalar loads share lgkmcnt; they are rare inside the loops this is for)"""
+    return _scan(lines, near, lambda l: l.startswith('ds_read'), 'lgkmcnt')
 
 
 def scan(lines, near):
-    """-> [(index, wait, distance to the last load, loads since the previous wait, next instruction)]"""
-    found = []
-    last_load, since = None, 0
-    for i, l in enumerate(lines):
-        if is_vload(l):
-            last_load, since = i, since + 1
-        elif l.startswith('s_waitcnt') and 'vmcnt' in l:
-            n = int(re.search(r'vmcnt\((\d+)\)', l).group(1))
-            if last_load is not None and i - last_load <= near and n < since:
-                found.append((i, l, i - last_load, since, lines[i + 1] if i + 1 < len(lines) else ''))
-            since = min(since, n)
-        elif l.startswith('s_cbranch') or l.startswith('s_branch') or l.startswith('s_endpgm'):
-            pass
-    return found
+    return _scan(lines, near, is_vload, 'vmcnt')
 
 
 def main():
