@@ -72,3 +72,19 @@ def test_matrix_kernels_have_no_waterfall_loops(obj):
     # (the two-fragment plain channel-block instances spill by design and are priced out by pick_wgrad: scratch is not asserted here)
     bad = {n[:120]: v['waterfall'] for n, v in _kernels(obj).items() if v['mfma'] > 0 and v['waterfall']}
     assert not bad, bad
+
+
+def test_the_scanner_flags_a_wait_for_a_fresh_load_and_not_a_wait_for_the_oldest_of_many():
+    """tools/isa_waits.py on synthetic listings: vmcnt decrements in issue order, `vmcnt(n)` completes all but the newest n loads.
+    A wait that forces a load issued a few instructions earlier is the defect; a wait for the oldest of many loads in flight, placed
+    right behind fresh loads, is a working software pipeline."""
+    import isa_waits as w
+    fresh = ['buffer_load_dwordx4 v[0:3], v9, s[0:3], 0 offen', 's_waitcnt vmcnt(0)', 'v_cndmask_b32_e32 v0, 0, v0, vcc']
+    assert [h[:4] for h in w.scan(fresh, 6)] == [(1, 's_waitcnt vmcnt(0)', 1, 1)]
+    pipe = ['buffer_load_dword v%d, v9, s[0:3], 0 offen' % k for k in range(4)] + ['v_add_f32_e32 v20, v21, v22'] * 30 + \
+           ['buffer_load_dword v%d, v9, s[0:3], 0 offen' % k for k in range(4, 8)] + ['s_waitcnt vmcnt(4)', 'ds_write_b32 v30, v0']
+    assert w.scan(pipe, 6) == []                                   # forces loads 0-3, issued 30+ instructions ago
+    assert len(w.scan(pipe[:-2] + ['s_waitcnt vmcnt(3)', 'ds_write_b32 v30, v4'], 6)) == 1      # ... one of the fresh four as well
+    lds = ['ds_read_b64 v[0:1], v9', 'ds_read_b64 v[2:3], v9 offset:8', 's_waitcnt lgkmcnt(1)', 'v_mfma_f32_16x16x4_f32 v[4:7], v0, v1, v[4:7]']
+    assert [h[0] for h in w.scan_lds(lds, 3)] == [2]
+    assert w.is_vload('global_load_dwordx2 v[0:1], v[2:3], off') and not w.is_vload('buffer_store_dword v0, v1, s[0:3], 0 offen')
